@@ -1,0 +1,329 @@
+"""Explicit forward / backward / gradient-penalty sequencing of the RNA-GAN DCGAN pair.
+
+This module replaces what the reference gets from PyTorch autograd on its hot path
+(reference: src/wgan_loss.py:107-129 G step, :213-263 D step, :369-389 GP step, with the
+functional losses :24-44).  It contains NO arithmetic of its own: every tensor operation goes
+through an ``ops`` backend object whose methods map 1:1 onto the C-ABI entry points declared in
+include/rnagan_hip.h (product backend: rna_gan_amd.ops_hip.HipOps).  The same sequencing can be
+driven by the torch twin in oracle/ops_ref.py, which is how the algorithm (in particular the
+second-order gradient-penalty pass) is validated on CPU against the autograd oracle.
+
+Layout conventions: see include/rnagan_hip.h / DESIGN.md ("Data layout in HBM").
+
+Gradient penalty without autograd (DESIGN.md "GP second-order pass"):
+  L = lambd * (||g|| - 1)^2,  g = d(sum_n D(xhat)_n)/d xhat.
+  dL/dtheta = d/dtheta <v, g(theta)> with v = dL/dg held constant
+            = d/dtheta [ directional derivative of sum_n D(xhat)_n along v ]      (linearity)
+  so: (1) primal forward, (2) first backward (data gradients only) -> g, v,
+      (3) tangent forward along v (forward mode through conv / train-mode BN / LeakyReLU),
+      (4) one joint reverse sweep over (primal, tangent).  The cotangent of every tangent
+          quantity equals the matching first-backward gradient (already in memory), so the joint
+          sweep only propagates the PRIMAL cotangent: 6 conv passes in total, the algorithmic
+          minimum for this loss.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+
+class ConvW:
+    """Handle of one 4x4 conv weight: fp32 master ``w[O][I][4][4]`` (+ optional bias[.]).
+
+    O = channels on the LOW-resolution side, I = channels on the HIGH-resolution side: this is
+    nn.Conv2d's (out,in,kh,kw) and nn.ConvTranspose2d's (in,out,kh,kw), so one handle type serves
+    both networks.  ``packs`` caches backend-private re-layouts (bf16 GEMM operand images); they
+    are rebuilt when ``version`` changes (after an optimizer step / state_dict load).
+    """
+
+    __slots__ = ("w", "bias", "dw", "dbias", "packs", "packs_version", "version")
+
+    def __init__(self, w, bias=None, dw=None, dbias=None):
+        self.w = w
+        self.bias = bias
+        self.dw = dw
+        self.dbias = dbias
+        self.packs = None
+        self.packs_version = -1
+        self.version = 0
+
+
+class BNP:
+    """BatchNorm2d parameters/buffers of one layer (train-mode statistics are per call)."""
+
+    __slots__ = ("gamma", "beta", "running_mean", "running_var", "nbt", "dgamma", "dbeta", "eps", "momentum")
+
+    def __init__(self, gamma, beta, running_mean, running_var, nbt, dgamma=None, dbeta=None,
+                 eps=1e-5, momentum=0.1):
+        self.gamma, self.beta = gamma, beta
+        self.running_mean, self.running_var, self.nbt = running_mean, running_var, nbt
+        self.dgamma, self.dbeta = dgamma, dbeta
+        self.eps, self.momentum = eps, momentum
+
+
+class DiscNet:
+    """Discriminator as the engine sees it (torchgan DCGANDiscriminator recipe)."""
+
+    def __init__(self, conv0: ConvW, blocks: List, head: ConvW, slope: float, last_slope: float):
+        self.conv0, self.blocks, self.head = conv0, blocks, head   # blocks: [(ConvW, BNP)]
+        self.slope, self.last_slope = slope, last_slope
+
+    def bump(self):
+        for cw in [self.conv0, self.head] + [b[0] for b in self.blocks]:
+            cw.version += 1
+
+
+class GenNet:
+    """Generator as the engine sees it (torchgan DCGANGenerator recipe)."""
+
+    def __init__(self, g0: ConvW, bn0: BNP, blocks: List, last: ConvW, slope: float):
+        self.g0, self.bn0, self.blocks, self.last = g0, bn0, blocks, last   # blocks: [(ConvW, BNP)]
+        self.slope = slope
+
+    def bump(self):
+        for cw in [self.g0, self.last] + [b[0] for b in self.blocks]:
+            cw.version += 1
+
+
+class _Ctx:
+    pass
+
+
+def _bn_forward(ops, z, bn: BNP, slope, update_running=True):
+    C = z.shape[-1]
+    count = z.numel() // C
+    s, ss = ops.bn_stats(z)
+    if update_running:
+        mean, invstd = ops.bn_finalize(s, ss, count, bn.eps, bn.momentum,
+                                       bn.running_mean, bn.running_var, bn.nbt)
+    else:
+        mean, invstd = ops.bn_finalize(s, ss, count, bn.eps, bn.momentum)
+    a = ops.bn_act(z, mean, invstd, bn.gamma, bn.beta, slope)
+    return a, mean, invstd
+
+
+# --------------------------------------------------------------------------------------------
+# Discriminator
+# --------------------------------------------------------------------------------------------
+def disc_forward(ops, D: DiscNet, x_nchw, update_running=True):
+    """D(x): Conv+LReLU, R x [Conv+BN(train)+LReLU], Conv(4x4 valid)+LReLU -> (N,).
+    Returns (out, ctx); ctx keeps what the backward passes need."""
+    ctx = _Ctx()
+    ctx.x = x_nchw
+    a = ops.first_down(x_nchw, D.conv0, D.conv0.bias, D.slope)
+    ctx.a = [a]
+    ctx.z, ctx.mean, ctx.invstd = [None], [None], [None]
+    for cw, bn in D.blocks:
+        z = ops.conv_down(a, cw)
+        a, mean, invstd = _bn_forward(ops, z, bn, D.slope, update_running)
+        ctx.z.append(z); ctx.mean.append(mean); ctx.invstd.append(invstd); ctx.a.append(a)
+    ctx.h, out = ops.head_fwd(a, D.head, D.last_slope)
+    return out, ctx
+
+
+def disc_backward(ops, D: DiscNet, ctx, coef: float, wgrad: bool, accumulate: bool,
+                  need_input_grad: bool, keep_for_gp: bool = False):
+    """Backward of sum_n coef * D(x)_n.  wgrad: also produce parameter gradients (written with
+    ``accumulate`` semantics into the .dw/.dbias/.dgamma/.dbeta buffers).  Returns d/dx (NCHW
+    fp32) if requested.  keep_for_gp stores the per-layer first-backward gradients on ctx."""
+    R = len(D.blocks)
+    gh = ops.head_grad(ctx.h, coef, D.last_slope)
+    if wgrad:
+        ops.head_wgrad(gh, ctx.a[R], D.head.dw, accumulate)
+    ga = ops.head_bwd_data(gh, D.head)
+    if keep_for_gp:
+        ctx.gh = gh
+        ctx.ga1 = [None] * (R + 1)
+        ctx.gz1 = [None] * (R + 1)
+        ctx.s_gy = [None] * (R + 1)
+        ctx.s_gyxh = [None] * (R + 1)
+    for l in range(R, 0, -1):
+        cw, bn = D.blocks[l - 1]
+        gz, s_gy, s_gyxh = ops.bn_act_bwd(ctx.z[l], ga, ctx.mean[l], ctx.invstd[l], bn.gamma, bn.beta,
+                                          D.slope, bn.dgamma if wgrad else None,
+                                          bn.dbeta if wgrad else None, accumulate)
+        if keep_for_gp:
+            ctx.ga1[l], ctx.gz1[l], ctx.s_gy[l], ctx.s_gyxh[l] = ga, gz, s_gy, s_gyxh
+        if wgrad:
+            ops.conv_wgrad(gz, ctx.a[l - 1], cw.dw, accumulate)
+        ga = ops.conv_up(gz, cw)
+    gz0 = ops.lrelu_bwd(ga, ctx.a[0], D.slope)
+    if keep_for_gp:
+        ctx.gz1[0] = gz0
+    if wgrad:
+        ops.skinny_wgrad(gz0, ctx.x, D.conv0.dw, accumulate)
+        ops.col_sum(gz0, D.conv0.dbias, accumulate)
+    if need_input_grad:
+        return ops.last_up(gz0, D.conv0, None, False)
+    return None
+
+
+def disc_gradient_penalty(ops, D: DiscNet, xhat, lambd: float, update_running=True):
+    """lambd*(||d sum D(xhat)/d xhat||_2 - 1)^2 and its parameter gradients (written, not
+    accumulated).  Reference: src/wgan_loss.py:32-44 + :379-387.  Returns the UNWEIGHTED penalty
+    as a 1-element device tensor (the reference returns loss.item() of the unweighted value)."""
+    R = len(D.blocks)
+    out, ctx = disc_forward(ops, D, xhat, update_running)
+    # (2) first backward: data gradients only
+    g = disc_backward(ops, D, ctx, 1.0, wgrad=False, accumulate=False, need_input_grad=True,
+                      keep_for_gp=True)
+    sq = ops.sqnorm(g)
+    loss, coef = ops.gp_coef(sq, lambd)
+    v = ops.scale_by(g, coef)
+    # (3) tangent forward along v
+    zt0 = ops.first_down(v, D.conv0, None, 1.0)
+    at = ops.lrelu_bwd(zt0, ctx.a[0], D.slope)
+    ats, zts, s_zt, s_xhzt = [at], [None], [None], [None]
+    for l in range(1, R + 1):
+        cw, bn = D.blocks[l - 1]
+        zt = ops.conv_down(at, cw)
+        at, szt, sxz = ops.bn_tangent(ctx.z[l], zt, ctx.mean[l], ctx.invstd[l], bn.gamma, bn.beta, D.slope)
+        zts.append(zt); ats.append(at); s_zt.append(szt); s_xhzt.append(sxz)
+    # (4) joint reverse.  Head: t = sum_n lrelu'(h_n) * hdot_n  ->  dW_head = sum_n gh_n * at_R[n]
+    ops.head_wgrad(ctx.gh, ats[R], D.head.dw, False)
+    qa = None
+    for l in range(R, 0, -1):
+        cw, bn = D.blocks[l - 1]
+        pz = ops.bn_double_bwd(ctx.z[l], qa, zts[l], ctx.ga1[l], ctx.mean[l], ctx.invstd[l],
+                               bn.gamma, bn.beta, D.slope, ctx.s_gy[l], ctx.s_gyxh[l],
+                               s_zt[l], s_xhzt[l], bn.dgamma, bn.dbeta, False)
+        ops.conv_wgrad(pz, ctx.a[l - 1], cw.dw, False)
+        ops.conv_wgrad(ctx.gz1[l], ats[l - 1], cw.dw, True)
+        qa = ops.conv_up(pz, cw)
+    p0 = ops.lrelu_bwd(qa, ctx.a[0], D.slope)
+    ops.skinny_wgrad(p0, xhat, D.conv0.dw, False)
+    ops.skinny_wgrad(ctx.gz1[0], v, D.conv0.dw, True)
+    ops.col_sum(p0, D.conv0.dbias, False)
+    return loss
+
+
+# --------------------------------------------------------------------------------------------
+# Generator
+# --------------------------------------------------------------------------------------------
+def gen_forward(ops, G: GenNet, noise, update_running=True, keep=True):
+    """G(z): ConvT(E->C0,k4,s1,p0)+BN+LReLU, R x [ConvT(k4,s2,p1)+BN+LReLU], ConvT+bias+Tanh."""
+    ctx = _Ctx()
+    ctx.noise = noise
+    z = ops.g0_fwd(noise, G.g0)
+    a, mean, invstd = _bn_forward(ops, z, G.bn0, G.slope, update_running)
+    ctx.z, ctx.mean, ctx.invstd, ctx.a = [z], [mean], [invstd], [a]
+    for cw, bn in G.blocks:
+        z = ops.conv_up(a, cw)
+        a, mean, invstd = _bn_forward(ops, z, bn, G.slope, update_running)
+        if keep:
+            ctx.z.append(z); ctx.mean.append(mean); ctx.invstd.append(invstd); ctx.a.append(a)
+    img = ops.last_up(a, G.last, G.last.bias, True)
+    ctx.img = img
+    return img, ctx
+
+
+def gen_backward(ops, G: GenNet, ctx, gimg, accumulate: bool):
+    """Parameter gradients of G for d(loss)/d(img) = gimg (NCHW fp32)."""
+    R = len(G.blocks)
+    gzl = ops.tanh_bwd(gimg, ctx.img)
+    ops.skinny_wgrad(ctx.a[R], gzl, G.last.dw, accumulate)
+    ops.nchw_chan_sum(gzl, G.last.dbias, accumulate)
+    ga = ops.first_down(gzl, G.last, None, 1.0)
+    for l in range(R, 0, -1):
+        cw, bn = G.blocks[l - 1]
+        gz, _, _ = ops.bn_act_bwd(ctx.z[l], ga, ctx.mean[l], ctx.invstd[l], bn.gamma, bn.beta,
+                                  G.slope, bn.dgamma, bn.dbeta, accumulate)
+        ops.conv_wgrad(ctx.a[l - 1], gz, cw.dw, accumulate)
+        ga = ops.conv_down(gz, cw)
+    gz0, _, _ = ops.bn_act_bwd(ctx.z[0], ga, ctx.mean[0], ctx.invstd[0], G.bn0.gamma, G.bn0.beta,
+                               G.slope, G.bn0.dgamma, G.bn0.dbeta, accumulate)
+    ops.g0_wgrad(ctx.noise, gz0, G.g0.dw, accumulate)
+
+
+# --------------------------------------------------------------------------------------------
+# The three train_ops bodies (gradient part; the optimizer step is applied by the caller so that
+# a data-parallel all-reduce can sit between the two)
+# --------------------------------------------------------------------------------------------
+def gen_loss_grads(ops, G: GenNet, D: DiscNet, noise):
+    """src/wgan_loss.py:113-126: loss = mean(-D(G(z))); fills G's gradients.  D's weight
+    gradients, which the reference computes and discards, are not computed."""
+    n = noise.shape[0]
+    img, gctx = gen_forward(ops, G, noise)
+    out, dctx = disc_forward(ops, D, img)
+    loss = ops.mean_diff(out, None, -1.0)
+    gimg = disc_backward(ops, D, dctx, -1.0 / n, wgrad=False, accumulate=False, need_input_grad=True)
+    gen_backward(ops, G, gctx, gimg, accumulate=False)
+    return loss
+
+
+def disc_loss_grads(ops, G: GenNet, D: DiscNet, real, noise):
+    """src/wgan_loss.py:241-260: loss = mean(D(G(z).detach()) - D(real)); fills D's gradients.
+    Forward order D(real), G(z), D(fake) as in the reference (BN running statistics)."""
+    n = real.shape[0]
+    out_r, ctx_r = disc_forward(ops, D, real)
+    img, _ = gen_forward(ops, G, noise, keep=False)
+    out_f, ctx_f = disc_forward(ops, D, img)
+    loss = ops.mean_diff(out_f, out_r, 1.0)
+    disc_backward(ops, D, ctx_r, -1.0 / n, wgrad=True, accumulate=False, need_input_grad=False)
+    disc_backward(ops, D, ctx_f, 1.0 / n, wgrad=True, accumulate=True, need_input_grad=False)
+    return loss
+
+
+def gp_loss_grads(ops, G: GenNet, D: DiscNet, real, noise, eps: float, lambd: float):
+    """src/wgan_loss.py:371-387: fake = G(z); xhat = eps*real + (1-eps)*fake; D gradients of
+    lambd*GP.  The generator gradients the reference produces here are never used and are skipped."""
+    img, _ = gen_forward(ops, G, noise, keep=False)
+    xhat = ops.interp(real, img, eps)
+    return disc_gradient_penalty(ops, D, xhat, lambd)
+
+
+# --------------------------------------------------------------------------------------------
+# Building the engine view from nn.Modules that follow the torchgan key structure
+# (model.{i}.0 = conv, model.{i}.1 = BatchNorm2d; disc.0 = head conv)
+# --------------------------------------------------------------------------------------------
+def _grad_of(p):
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+def _slope_of(act, default):
+    ns = getattr(act, "negative_slope", None)
+    return float(ns) if ns is not None else default
+
+
+def _bnp(bn):
+    return BNP(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+               _grad_of(bn.weight), _grad_of(bn.bias), eps=bn.eps, momentum=bn.momentum)
+
+
+def build_disc_net(mod) -> DiscNet:
+    blocks = list(mod.model.children())
+    c0 = blocks[0][0]
+    conv0 = ConvW(c0.weight.data, c0.bias.data, _grad_of(c0.weight), _grad_of(c0.bias))
+    slope = _slope_of(blocks[0][-1], 0.2)
+    bl = []
+    for blk in blocks[1:]:
+        conv, bn = blk[0], blk[1]
+        if conv.bias is not None or not isinstance(bn, torch.nn.BatchNorm2d):
+            raise NotImplementedError("HIP path supports the batchnorm=True recipe only")
+        bl.append((ConvW(conv.weight.data, None, _grad_of(conv.weight)), _bnp(bn)))
+    hc = mod.disc[0]
+    if hc.bias is not None:
+        raise NotImplementedError("HIP path supports the batchnorm=True recipe only")
+    head = ConvW(hc.weight.data, None, _grad_of(hc.weight))
+    return DiscNet(conv0, bl, head, slope, _slope_of(mod.disc[-1], 0.2))
+
+
+def build_gen_net(mod) -> GenNet:
+    blocks = list(mod.model.children())
+    c0, b0 = blocks[0][0], blocks[0][1]
+    if c0.bias is not None or not isinstance(b0, torch.nn.BatchNorm2d):
+        raise NotImplementedError("HIP path supports the batchnorm=True recipe only")
+    g0 = ConvW(c0.weight.data, None, _grad_of(c0.weight))
+    slope = _slope_of(blocks[0][-1], 0.2)
+    bl = []
+    for blk in blocks[1:-1]:
+        conv, bn = blk[0], blk[1]
+        bl.append((ConvW(conv.weight.data, None, _grad_of(conv.weight)), _bnp(bn)))
+    lc = blocks[-1][0]
+    if not isinstance(blocks[-1][-1], torch.nn.Tanh):
+        raise NotImplementedError("HIP path supports last_nonlinearity=Tanh only")
+    last = ConvW(lc.weight.data, lc.bias.data, _grad_of(lc.weight), _grad_of(lc.bias))
+    return GenNet(g0, _bnp(b0), bl, last, slope)

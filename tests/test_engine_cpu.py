@@ -1,0 +1,83 @@
+"""The explicit (autograd-free) forward/backward/GP sequencing of rna_gan_amd.engine, driven by
+the torch twin ops (oracle/ops_ref.py), must reproduce the autograd oracle.  CPU only: this
+validates the ALGORITHM (incl. the second-order gradient-penalty pass); the HIP kernels are
+checked against the same twins in the gpu tests."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import ref_cpu as R
+from oracle.ops_ref import RefOps
+from rna_gan_amd import engine as E
+
+
+def mk(in_size, step, enc, seed=5):
+    G = R.seeded_fill_(R.OracleDCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                              last_nonlinearity=nn.Tanh()), seed)
+    D = R.seeded_fill_(R.OracleDCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                                  last_nonlinearity=nn.LeakyReLU(0.2)), seed + 1)
+    return G.double(), D.double()
+
+
+def grads_of(mod):
+    return {k: p.grad.clone() for k, p in mod.named_parameters()}
+
+
+def bufs_of(mod):
+    return {k: b.clone() for k, b in mod.named_buffers()}
+
+
+def assert_close_dict(a, b, rtol, atol):
+    assert a.keys() == b.keys()
+    for k in a:
+        np.testing.assert_allclose(a[k].double().numpy(), b[k].double().numpy(), rtol=rtol, atol=atol, err_msg=k)
+
+
+@pytest.mark.parametrize("in_size,step,enc,n", [(16, 4, 24, 5), (32, 4, 16, 3)])
+def test_three_steps_match_autograd(in_size, step, enc, n):
+    torch.manual_seed(0)
+    G, D = mk(in_size, step, enc)
+    G2, D2 = copy.deepcopy(G), copy.deepcopy(D)
+    for m in (G, D, G2, D2):
+        m.train()
+    real = R.synthetic_images(n, in_size, seed=3).double()
+    noise = R.synthetic_normal(n, enc, seed=4).double()
+    ops = RefOps(torch.float64)
+    Gn, Dn = E.build_gen_net(G2), E.build_disc_net(D2)
+
+    # ---- G step gradients
+    for p in list(G.parameters()) + list(D.parameters()):
+        p.grad = None
+    loss_o = R.generator_loss(D(G(noise)))
+    loss_o.backward()
+    loss_e = E.gen_loss_grads(ops, Gn, Dn, noise)
+    np.testing.assert_allclose(float(loss_e), float(loss_o), rtol=1e-9)
+    assert_close_dict(grads_of(G2), grads_of(G), 1e-7, 1e-10)
+    assert_close_dict(bufs_of(G2), bufs_of(G), 1e-9, 1e-12)
+    assert_close_dict(bufs_of(D2), bufs_of(D), 1e-9, 1e-12)
+
+    # ---- D step gradients
+    for p in D.parameters():
+        p.grad = None
+    loss_o = R.discriminator_loss(D(real), D(G(noise).detach()))
+    loss_o.backward()
+    loss_e = E.disc_loss_grads(ops, Gn, Dn, real, noise)
+    np.testing.assert_allclose(float(loss_e), float(loss_o), rtol=1e-9)
+    assert_close_dict(grads_of(D2), grads_of(D), 1e-7, 1e-10)
+    assert_close_dict(bufs_of(D2), bufs_of(D), 1e-9, 1e-12)
+
+    # ---- GP step gradients (second order)
+    for p in D.parameters():
+        p.grad = None
+    eps = 0.3
+    xhat = eps * real + (1 - eps) * G(noise)
+    gp = R.gradient_penalty(xhat, D(xhat))
+    (10.0 * gp).backward()
+    loss_e = E.gp_loss_grads(ops, Gn, Dn, real, noise, eps, 10.0)
+    np.testing.assert_allclose(float(loss_e), float(gp), rtol=1e-8)
+    assert_close_dict(grads_of(D2), grads_of(D), 1e-6, 1e-9)
+    assert_close_dict(bufs_of(D2), bufs_of(D), 1e-9, 1e-12)
+    assert_close_dict(bufs_of(G2), bufs_of(G), 1e-9, 1e-12)
