@@ -1,0 +1,222 @@
+/* rnagan_hip.h -- C ABI of librnagan_hip.so: the MI355X (gfx950) kernels behind the RNA-GAN
+ * WGAN-GP training path.
+ *
+ * The reference (gevaertlab/RNA-GAN) has no native code; its hot path reaches native kernels only
+ * through PyTorch ATen/cuDNN/cuBLAS calls made from Python.  Each entry point below replaces one
+ * such implicit native op (SURVEY.md 2.2 "native-op inventory", K1..K15) and cites the reference
+ * call site (paths relative to /root/reference) whose arithmetic it provides.  The Python side
+ * (rna_gan_amd/_abi.py, ctypes) binds exactly these symbols; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch); the library never
+ *     allocates, frees or retains memory.  Workspace is passed in (rg_*_workspace_bytes).
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises.
+ *     Safe under HIP graph capture.  Re-entrant; no global mutable state except the thread-local
+ *     error string.
+ *   - return value: 0 = RG_OK, <0 = error (rg_last_error() gives the text).  Launch errors are
+ *     detected with hipGetLastError() only.
+ *   - activations: NHWC ([N][H][W][C], C fastest) in `dtype` = RG_F32 or RG_BF16; arithmetic and
+ *     all per-channel statistics are fp32.  Image-side boundary tensors (discriminator input,
+ *     generator output) are NCHW fp32 exactly as in PyTorch.
+ *   - a 4x4 / stride-2 / pad-1 conv weight is w[O][I][4][4] fp32 (PyTorch memory layout), where
+ *     O = channels on the LOW-resolution side and I = channels on the HIGH-resolution side: this is
+ *     nn.Conv2d.weight (out,in,kh,kw) in the discriminator and nn.ConvTranspose2d.weight
+ *     (in,out,kh,kw) in the generator, so "down"/"up" serve both networks and each other's backward.
+ *   - `algo`: RG_ALGO_AUTO picks the MFMA implicit-GEMM kernels when dtype is bf16 and the shape
+ *     is tile-aligned, else the generic tiled fp32 kernels; RG_ALGO_GENERIC / RG_ALGO_MFMA force one
+ *     (MFMA returns RG_EUNSUPPORTED for shapes it cannot take).
+ */
+#ifndef RNAGAN_HIP_H
+#define RNAGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RG_OK 0
+#define RG_EINVAL (-1)
+#define RG_EUNSUPPORTED (-2)
+#define RG_EWORKSPACE (-3)
+#define RG_EHIP (-4)
+
+#define RG_F32 0
+#define RG_BF16 1
+
+#define RG_ALGO_AUTO 0
+#define RG_ALGO_GENERIC 1
+#define RG_ALGO_MFMA 2
+
+int rg_version(void);
+const char* rg_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stride-2 4x4 convolution family (K1/K2/K3 of SURVEY 2.2)
+ * ------------------------------------------------------------------------------------------- */
+
+/* Re-layout of a master weight for the MFMA kernels (either output may be NULL):
+ *   wdn[O][16][I]  (B operand of rg_conv_down: k = (tap, i) contiguous in i)
+ *   wup[I][16][O]  (B operand of rg_conv_up:   k = (tap, o) contiguous in o)
+ * both in `dtype`.  Runs after every optimizer step (src/wgan_loss.py:127,261,388). */
+int rg_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I, int dtype, void* stream);
+
+/* y[N][Hi/2][Wi/2][O] = conv2d(x[N][Hi][Wi][I], w, stride 2, pad 1).
+ * nn.Conv2d forward in the discriminator (D(.) at src/wgan_loss.py:119,241,253,379) and the
+ * data-gradient of nn.ConvTranspose2d in the generator (loss.backward(), :126).
+ * `wdn` may be NULL when the generic kernel runs (it reads `w`). */
+int rg_conv_down(const void* x, const float* w, const void* wdn, void* y, int N, int Hi, int Wi, int I,
+                 int O, int dtype, int algo, void* stream);
+
+/* y[N][2Ho][2Wo][I] = conv_transpose2d(x[N][Ho][Wo][O], w, stride 2, pad 1).
+ * nn.ConvTranspose2d forward in the generator (G(.) at src/wgan_loss.py:113,247,371) and the
+ * data-gradient of nn.Conv2d in the discriminator (.backward() :126,260,387; autograd.grad :34-41). */
+int rg_conv_up(const void* x, const float* w, const void* wup, void* y, int N, int Ho, int Wo, int O, int I,
+               int dtype, int algo, void* stream);
+
+/* dw[O][I][4][4] (+)= sum_{n,ho,wo} low[n][ho][wo][o] * high[n][2ho-1+kh][2wo-1+kw][i].
+ * Weight gradient of both layer kinds (every .backward()).  Deterministic: split-K partial slabs
+ * in `ws` are summed in a fixed order. */
+size_t rg_conv_wgrad_workspace_bytes(int N, int Ho, int Wo, int O, int I, int dtype, int algo);
+int rg_conv_wgrad(const void* low, const void* high, float* dw, int N, int Ho, int Wo, int O, int I, int dtype,
+                  int accumulate, int algo, void* ws, size_t ws_bytes, void* stream);
+
+/* Image-side layers (I = 3 channels, NCHW fp32 on the high-resolution side; HBM-bound).
+ * rg_first_down: y[N][H/2][W/2][O] = lrelu_slope(conv2d(x_nchw, w) + bias); bias may be NULL,
+ *   slope = 1 disables the activation.  Discriminator layer 0 forward
+ *   (Conv2d(3,64,4,2,1)+LeakyReLU, histopathology_gan.py:186-192) and data-gradient of the
+ *   generator's last ConvTranspose2d.
+ * rg_last_up: y_nchw[N][I][2Ho][2Wo] = act(conv_transpose2d(x, w) + bias), act = tanh or none.
+ *   Generator last layer forward (ConvTranspose2d(64,3,4,2,1)+Tanh, dcgan.py:82) and
+ *   data-gradient of discriminator layer 0 (gives d/d xhat for the penalty, wgan_loss.py:34-41).
+ * rg_skinny_wgrad: weight gradient of those two layers. */
+int rg_first_down(const float* x_nchw, const float* w, const float* bias, void* y, int N, int H, int W, int I,
+                  int O, float slope, int dtype, void* stream);
+int rg_last_up(const void* x, const float* w, const float* bias, float* y_nchw, int N, int Ho, int Wo, int O,
+               int I, int apply_tanh, int dtype, void* stream);
+size_t rg_skinny_wgrad_workspace_bytes(int N, int Ho, int Wo, int O, int I);
+int rg_skinny_wgrad(const void* low, const float* high_nchw, float* dw, int N, int Ho, int Wo, int O, int I,
+                    int dtype, int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense layers: generator layer 0 (K4), discriminator head (K5), betaVAE encoder (K8)
+ * ------------------------------------------------------------------------------------------- */
+
+/* Generator layer 0, ConvTranspose2d(E,C,4,1,0) on a 1x1 input (dcgan.py:38-40):
+ *   y[N][4][4][C] = sum_e z[n][e] * w[e][c][kh][kw].   w is [E][C][4][4] fp32;
+ *   wp = packed [16*C][E] in dtype (rg_pack_g0_weight), NULL for the generic kernel. */
+int rg_pack_g0_weight(const float* w, void* wp, int E, int C, int dtype, void* stream);
+int rg_g0_fwd(const float* z, const float* w, const void* wp, void* y, int N, int E, int C, int dtype, int algo,
+              void* ws, size_t ws_bytes, void* stream);
+size_t rg_g0_workspace_bytes(int N, int E, int C, int dtype, int algo);
+int rg_g0_wgrad(const float* z, const void* gy, float* dw, int N, int E, int C, int dtype, int accumulate,
+                int algo, void* ws, size_t ws_bytes, void* stream);
+
+/* Discriminator head, Conv2d(C,1,4,1,0)+LeakyReLU on a 4x4 map -> (N,):
+ *   h[n] = sum a[n][kh][kw][c] * w[0][c][kh][kw];  out[n] = lrelu(h[n]). */
+int rg_head_fwd(const void* a, const float* w, float* h, float* out, int N, int C, float slope, int dtype,
+                void* stream);
+/* gh[n] = coef * lrelu'(h[n])  (coef = d loss / d out[n]: -1/N, +1/N or 1; wgan_loss.py:24-29,33) */
+int rg_head_grad(const float* h, float* gh, int N, float coef, float slope, void* stream);
+int rg_head_bwd_data(const float* gh, const float* w, void* ga, int N, int C, int dtype, void* stream);
+int rg_head_wgrad(const float* gh, const void* a, float* dw, int N, int C, int dtype, int accumulate,
+                  void* stream);
+
+/* y[M][ldy] = act((x[M][K] . w[Nout][K]^T) * scale[j] + shift[j]) : Linear + BatchNorm1d(eval)
+ * folded + LeakyReLU(0.01) of the betaVAE encoder, and z_mu (betaVAE.py:26-42,102-107).
+ * x is fp32 [M][ldx]; w fp32 [Nout][K] (PyTorch Linear layout); y fp32. slope=1: no activation.
+ * wp: optional bf16 copy of w padded to [Nout_pad][K_pad] (rg_pack_linear_weight) for the MFMA
+ * kernel (weight streaming is the bound: 2 B/weight instead of 4). */
+int rg_pack_linear_weight(const float* w, void* wp, int Nout, int K, int Nout_pad, int K_pad, void* stream);
+size_t rg_linear_workspace_bytes(int M, int K, int Nout, int algo);
+int rg_linear_affine_act(const float* x, int ldx, const float* w, const void* wp, const float* scale,
+                         const float* shift, float* y, int ldy, int M, int K, int Nout, float slope, int algo,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * BatchNorm2d in TRAIN mode + LeakyReLU: forward, backward, forward-mode tangent and the joint
+ * (double) backward needed by the gradient penalty (K6/K7).  z, a, g* are [M][C] views of NHWC
+ * tensors (M = N*H*W).  All column reductions are two-stage and deterministic; `ws` must hold
+ * rg_colreduce_workspace_bytes(M, C, nq) bytes (nq = number of sums, <= 3).
+ * ------------------------------------------------------------------------------------------- */
+size_t rg_colreduce_workspace_bytes(int M, int C, int nq);
+
+/* sum[c] = sum_m z, sumsq[c] = sum_m z^2 */
+int rg_bn_stats(const void* z, float* sum, float* sumsq, int M, int C, int dtype, void* ws, size_t ws_bytes,
+                void* stream);
+/* mean, invstd = 1/sqrt(biased var + eps); if running_mean != NULL also the PyTorch running-stat
+ * update (momentum, unbiased variance) and ++(*num_batches_tracked) (int64). */
+int rg_bn_finalize(const float* sum, const float* sumsq, int M, int C, float eps, float momentum, float* mean,
+                   float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                   void* stream);
+/* a = lrelu((z-mean)*invstd*gamma + beta) */
+int rg_bn_act(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
+              void* a, int M, int C, float slope, int dtype, void* stream);
+/* gy = ga*lrelu'(y); s_gy = sum gy; s_gyxh = sum gy*xhat; gz = gamma*invstd*(gy - s_gy/M - xhat*s_gyxh/M);
+ * dgamma (+)= s_gyxh, dbeta (+)= s_gy when dgamma != NULL. */
+int rg_bn_act_bwd(const void* z, const void* ga, const float* mean, const float* invstd, const float* gamma,
+                  const float* beta, void* gz, float* s_gy, float* s_gyxh, float* dgamma, float* dbeta,
+                  int accumulate, int M, int C, float slope, int dtype, void* ws, size_t ws_bytes, void* stream);
+/* tangent of a = lrelu(bn(z)) along zt with batch statistics varying:
+ * at = lrelu'(y)*gamma*invstd*(zt - s_zt/M - xhat*s_xhzt/M) */
+int rg_bn_tangent(const void* z, const void* zt, const float* mean, const float* invstd, const float* gamma,
+                  const float* beta, void* at, float* s_zt, float* s_xhzt, int M, int C, float slope, int dtype,
+                  void* ws, size_t ws_bytes, void* stream);
+/* joint reverse through (a, at): see DESIGN.md "GP second-order pass" for the formula.
+ * qa may be NULL (zero primal cotangent). */
+int rg_bn_double_bwd(const void* z, const void* qa, const void* zt, const void* ga1, const float* mean,
+                     const float* invstd, const float* gamma, const float* beta, const float* s_gy,
+                     const float* s_gyxh, const float* s_zt, const float* s_xhzt, void* pz, float* dgamma,
+                     float* dbeta, int accumulate, int M, int C, float slope, int dtype, void* ws,
+                     size_t ws_bytes, void* stream);
+
+/* out = g * lrelu'(a) with the mask taken from the sign of the activation OUTPUT a */
+int rg_lrelu_bwd(const void* g, const void* a, void* out, size_t n, float slope, int dtype, void* stream);
+/* out[c] (+)= sum_m g[m][c]   (bias gradient) */
+int rg_col_sum(const void* g, float* out, int M, int C, int dtype, int accumulate, void* ws, size_t ws_bytes,
+               void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Image-side pointwise ops and reductions (NCHW fp32) (K7, K10, K11)
+ * ------------------------------------------------------------------------------------------- */
+int rg_tanh_bwd(const float* gy, const float* y, float* gz, size_t n, void* stream);
+/* out[c] (+)= sum_{n,h,w} g[n][c][h][w] */
+int rg_nchw_chan_sum(const float* g, float* out, int N, int C, int HW, int accumulate, void* ws, size_t ws_bytes,
+                     void* stream);
+/* xhat = eps*real + (1-eps)*fake (wgan_loss.py:377) */
+int rg_interp(const float* real, const float* fake, float* out, size_t n, float eps, void* stream);
+/* out[0] = sum x^2 (fp32 result, pairwise/blocked accumulation; deterministic) */
+size_t rg_reduce_workspace_bytes(size_t n);
+int rg_sqnorm(const float* x, float* out, size_t n, void* ws, size_t ws_bytes, void* stream);
+/* from sq = ||g||^2: loss = (sqrt(sq)-1)^2 ; coef = lambd*2*(sqrt(sq)-1)/sqrt(sq) (wgan_loss.py:43) */
+int rg_gp_coef(const float* sq, float* loss, float* coef, float lambd, void* stream);
+/* out = x * coef[0] (coef on device: no host sync inside the step) */
+int rg_scale_by(const float* x, const float* coef, float* out, size_t n, void* stream);
+/* out[0] = sign * mean(a - b) (b may be NULL) (wgan_loss.py:24-29) */
+int rg_mean_diff(const float* a, const float* b, float* out, int n, float sign, void* stream);
+/* noise = (u+z - mean_col)/std_col, unbiased std over the batch (wgan_loss.py:105-106) */
+int rg_latent_prep(const float* u, const float* z, float* out, int N, int E, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimizer (K12/K13): torch.optim.Adam semantics on flat fp32 buffers
+ * (histopathology_gan.py:252,257; stepped at wgan_loss.py:127,261,388), optional weight clamp
+ * (wgan_loss.py:213-215).  step is 1-based.
+ * ------------------------------------------------------------------------------------------- */
+int rg_adam_step(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float beta1,
+                 float beta2, float eps, void* stream);
+int rg_clamp(float* p, size_t n, float lo, float hi, void* stream);
+
+/* fp32 -> dtype cast with optional row padding: dst[M][ldd] = src[M][K] (pad columns zeroed) */
+int rg_cast_pad(const float* src, void* dst, int M, int K, int ldd, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Hardware self-tests (used by tests/ on the GPU box): check the MFMA / transposed-LDS-read lane
+ * maps this library relies on with exact integer data.  Return 0 when the layouts match.
+ * ------------------------------------------------------------------------------------------- */
+int rg_selftest_layouts(int* detail, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNAGAN_HIP_H */

@@ -271,7 +271,7 @@ class RefOps:
         p.clamp_(lo, hi)
 
     # ------------------------------------------------------------------ dense (betaVAE encoder)
-    def linear_affine_act(self, x, w, scale, shift, slope: float):
+    def linear_affine_act(self, x, w, scale, shift, slope: float, wp=None):
         """act((x @ w.T) * scale + shift); Linear+BatchNorm1d(eval) folded, slope=1 -> no act."""
         y = (x.to(self.f) @ self._wq(w).t()) * scale + shift
         if slope != 1.0:

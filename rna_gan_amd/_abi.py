@@ -1,0 +1,99 @@
+"""ctypes binding of librnagan_hip.so (include/rnagan_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librnagan_hip.so")
+
+RG_F32, RG_BF16 = 0, 1
+ALGO_AUTO, ALGO_GENERIC, ALGO_MFMA = 0, 1, 2
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_z = C.c_size_t
+
+# name -> (restype, [argtypes])   -- must list every symbol declared in include/rnagan_hip.h
+PROTOTYPES = {
+    "rg_version": (_i, []),
+    "rg_last_error": (C.c_char_p, []),
+    "rg_pack_conv_weight": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "rg_conv_down": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "rg_conv_up": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "rg_conv_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),
+    "rg_conv_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "rg_first_down": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "rg_last_up": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "rg_skinny_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "rg_skinny_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "rg_pack_g0_weight": (_i, [_p, _p, _i, _i, _i, _p]),
+    "rg_g0_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "rg_g0_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "rg_g0_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "rg_head_fwd": (_i, [_p, _p, _p, _p, _i, _i, _f, _i, _p]),
+    "rg_head_grad": (_i, [_p, _p, _i, _f, _f, _p]),
+    "rg_head_bwd_data": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "rg_head_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "rg_pack_linear_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "rg_linear_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "rg_linear_affine_act": (_i, [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _z, _p]),
+    "rg_colreduce_workspace_bytes": (_z, [_i, _i, _i]),
+    "rg_bn_stats": (_i, [_p, _p, _p, _i, _i, _i, _p, _z, _p]),
+    "rg_bn_finalize": (_i, [_p, _p, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p]),
+    "rg_bn_act": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p]),
+    "rg_bn_act_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _z, _p]),
+    "rg_bn_tangent": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p, _z, _p]),
+    "rg_bn_double_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i,
+                              _p, _z, _p]),
+    "rg_lrelu_bwd": (_i, [_p, _p, _p, _z, _f, _i, _p]),
+    "rg_col_sum": (_i, [_p, _p, _i, _i, _i, _i, _p, _z, _p]),
+    "rg_tanh_bwd": (_i, [_p, _p, _p, _z, _p]),
+    "rg_nchw_chan_sum": (_i, [_p, _p, _i, _i, _i, _i, _p, _z, _p]),
+    "rg_interp": (_i, [_p, _p, _p, _z, _f, _p]),
+    "rg_reduce_workspace_bytes": (_z, [_z]),
+    "rg_sqnorm": (_i, [_p, _p, _z, _p, _z, _p]),
+    "rg_gp_coef": (_i, [_p, _p, _p, _f, _p]),
+    "rg_scale_by": (_i, [_p, _p, _p, _z, _p]),
+    "rg_mean_diff": (_i, [_p, _p, _p, _i, _f, _p]),
+    "rg_latent_prep": (_i, [_p, _p, _p, _i, _i, _p]),
+    "rg_adam_step": (_i, [_p, _p, _p, _p, _z, _i, _f, _f, _f, _f, _p]),
+    "rg_clamp": (_i, [_p, _z, _f, _f, _p]),
+    "rg_cast_pad": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "rg_selftest_layouts": (_i, [_p, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once).  Raises RuntimeError if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "rna_gan_amd: %s not found. Build it with `python -m rna_gan_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU / eager fallback." % LIB_PATH)
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise RuntimeError("rna_gan_amd: cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise RuntimeError("rna_gan_amd: symbol %s missing from %s" % (name, LIB_PATH))
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().rg_last_error()
+        raise RuntimeError("rna_gan_amd: %s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))

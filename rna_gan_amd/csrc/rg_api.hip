@@ -1,0 +1,163 @@
+// rg_api.hip -- C-ABI dispatchers: argument validation, algorithm choice (MFMA vs generic),
+// error string.  See include/rnagan_hip.h for the contract.
+#include "rg_common.h"
+#include "rg_internal.h"
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+void rg_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int rg_version(void) { return 100; }
+extern "C" const char* rg_last_error(void) { return g_err; }
+
+static bool want_mfma(int algo, int dtype) { return algo != RG_ALGO_GENERIC && dtype == RG_BF16; }
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int rg_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I, int dtype, void* stream) {
+  RG_REQUIRE(w && O > 0 && I > 0, RG_EINVAL, "pack_conv_weight: bad args");
+  RG_REQUIRE(dtype == RG_BF16, RG_EUNSUPPORTED, "pack_conv_weight: only bf16 packs exist (fp32 kernels read w)");
+  return rg_mfma_pack_conv_weight(w, wdn, wup, O, I, rg_stream(stream));
+}
+
+extern "C" int rg_conv_down(const void* x, const float* w, const void* wdn, void* y, int N, int Hi, int Wi, int I,
+                            int O, int dtype, int algo, void* stream) {
+  RG_REQUIRE(x && y && N > 0 && Hi > 0 && Wi > 0 && I > 0 && O > 0 && Hi % 2 == 0 && Wi % 2 == 0, RG_EINVAL,
+             "conv_down: bad args");
+  if (want_mfma(algo, dtype) && wdn && rg_mfma_conv_supported(N, Hi / 2, Wi / 2, /*Kc=*/I, /*Ncols=*/O))
+    return rg_mfma_conv_down(x, wdn, y, N, Hi, Wi, I, O, rg_stream(stream));
+  RG_REQUIRE(algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "conv_down: shape/dtype not supported by the MFMA kernel");
+  RG_REQUIRE(w, RG_EINVAL, "conv_down: generic kernel needs the fp32 master weight");
+  return rg_generic_conv_down(x, w, y, N, Hi, Wi, I, O, dtype, rg_stream(stream));
+}
+
+extern "C" int rg_conv_up(const void* x, const float* w, const void* wup, void* y, int N, int Ho, int Wo, int O, int I,
+                          int dtype, int algo, void* stream) {
+  RG_REQUIRE(x && y && N > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0, RG_EINVAL, "conv_up: bad args");
+  if (want_mfma(algo, dtype) && wup && rg_mfma_conv_supported(N, Ho, Wo, /*Kc=*/O, /*Ncols=*/I))
+    return rg_mfma_conv_up(x, wup, y, N, Ho, Wo, O, I, rg_stream(stream));
+  RG_REQUIRE(algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "conv_up: shape/dtype not supported by the MFMA kernel");
+  RG_REQUIRE(w, RG_EINVAL, "conv_up: generic kernel needs the fp32 master weight");
+  return rg_generic_conv_up(x, w, y, N, Ho, Wo, O, I, dtype, rg_stream(stream));
+}
+
+extern "C" size_t rg_conv_wgrad_workspace_bytes(int N, int Ho, int Wo, int O, int I, int dtype, int algo) {
+  size_t a = rg_generic_wgrad_ws_bytes(N, Ho, Wo, O, I);
+  size_t b = 0;
+  if (want_mfma(algo, dtype) && rg_mfma_wgrad_supported(N, Ho, Wo, O, I)) b = rg_mfma_wgrad_ws_bytes(N, Ho, Wo, O, I);
+  return a > b ? a : b;
+}
+
+extern "C" int rg_conv_wgrad(const void* low, const void* high, float* dw, int N, int Ho, int Wo, int O, int I,
+                             int dtype, int accumulate, int algo, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(low && high && dw && N > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0, RG_EINVAL, "conv_wgrad: bad args");
+  if (want_mfma(algo, dtype) && rg_mfma_wgrad_supported(N, Ho, Wo, O, I))
+    return rg_mfma_conv_wgrad(low, high, dw, N, Ho, Wo, O, I, accumulate, ws, ws_bytes, rg_stream(stream));
+  RG_REQUIRE(algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "conv_wgrad: shape/dtype not supported by the MFMA kernel");
+  return rg_generic_conv_wgrad(low, high, dw, N, Ho, Wo, O, I, dtype, accumulate, ws, ws_bytes, rg_stream(stream));
+}
+
+extern "C" int rg_first_down(const float* x_nchw, const float* w, const float* bias, void* y, int N, int H, int W,
+                             int I, int O, float slope, int dtype, void* stream) {
+  RG_REQUIRE(x_nchw && w && y && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && I > 0 && O > 0, RG_EINVAL,
+             "first_down: bad args");
+  if (rg_skinny_supported(I, O))
+    return rg_skinny_first_down(x_nchw, w, bias, y, N, H, W, I, O, slope, dtype, rg_stream(stream));
+  return rg_generic_first_down(x_nchw, w, bias, y, N, H, W, I, O, slope, dtype, rg_stream(stream));
+}
+
+extern "C" int rg_last_up(const void* x, const float* w, const float* bias, float* y_nchw, int N, int Ho, int Wo,
+                          int O, int I, int apply_tanh, int dtype, void* stream) {
+  RG_REQUIRE(x && w && y_nchw && N > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0, RG_EINVAL, "last_up: bad args");
+  if (rg_skinny_supported(I, O))
+    return rg_skinny_last_up(x, w, bias, y_nchw, N, Ho, Wo, O, I, apply_tanh, dtype, rg_stream(stream));
+  return rg_generic_last_up(x, w, bias, y_nchw, N, Ho, Wo, O, I, apply_tanh, dtype, rg_stream(stream));
+}
+
+extern "C" size_t rg_skinny_wgrad_workspace_bytes(int N, int Ho, int Wo, int O, int I) {
+  size_t a = rg_generic_wgrad_ws_bytes(N, Ho, Wo, O, I);
+  size_t b = rg_skinny_supported(I, O) ? rg_skinny_wgrad_ws_bytes(N, Ho, Wo, O, I) : 0;
+  return a > b ? a : b;
+}
+
+extern "C" int rg_skinny_wgrad(const void* low, const float* high_nchw, float* dw, int N, int Ho, int Wo, int O, int I,
+                               int dtype, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(low && high_nchw && dw && N > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0, RG_EINVAL,
+             "skinny_wgrad: bad args");
+  if (rg_skinny_supported(I, O))
+    return rg_skinny_wgrad_impl(low, high_nchw, dw, N, Ho, Wo, O, I, dtype, accumulate, ws, ws_bytes,
+                                rg_stream(stream));
+  return rg_generic_skinny_wgrad(low, high_nchw, dw, N, Ho, Wo, O, I, dtype, accumulate, ws, ws_bytes,
+                                 rg_stream(stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int rg_pack_g0_weight(const float* w, void* wp, int E, int C, int dtype, void* stream) {
+  RG_REQUIRE(w && wp && E > 0 && C > 0, RG_EINVAL, "pack_g0_weight: bad args");
+  RG_REQUIRE(dtype == RG_BF16, RG_EUNSUPPORTED, "pack_g0_weight: only bf16 packs exist");
+  return rg_mfma_pack_g0_weight(w, wp, E, C, rg_stream(stream));
+}
+
+extern "C" size_t rg_g0_workspace_bytes(int N, int E, int C, int dtype, int algo) {
+  if (!want_mfma(algo, dtype)) return 0;
+  size_t a = (size_t)N * E * 2;                       // bf16 copy of z
+  size_t b = (size_t)E * 16 * C * sizeof(float);      // wgrad slab
+  return rg_align_up(a, 256) + b;
+}
+
+extern "C" int rg_g0_fwd(const float* z, const float* w, const void* wp, void* y, int N, int E, int C, int dtype,
+                         int algo, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(z && y && N > 0 && E > 0 && C > 0, RG_EINVAL, "g0_fwd: bad args");
+  if (want_mfma(algo, dtype) && wp && rg_mfma_plain_supported(N, E, 16 * C)) {
+    RG_REQUIRE(ws && ws_bytes >= (size_t)N * E * 2, RG_EWORKSPACE, "g0_fwd: workspace too small");
+    int rc = rg_cast_pad(z, ws, N, E, E, RG_BF16, stream);
+    if (rc) return rc;
+    return rg_mfma_gemm_plain(ws, wp, y, N, E, 16 * C, 16 * C, rg_stream(stream));
+  }
+  RG_REQUIRE(algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "g0_fwd: shape/dtype not supported by the MFMA kernel");
+  RG_REQUIRE(w, RG_EINVAL, "g0_fwd: generic kernel needs the fp32 master weight");
+  return rg_generic_g0_fwd(z, w, y, N, E, C, dtype, rg_stream(stream));
+}
+
+extern "C" int rg_g0_wgrad(const float* z, const void* gy, float* dw, int N, int E, int C, int dtype, int accumulate,
+                           int algo, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(z && gy && dw && N > 0 && E > 0 && C > 0, RG_EINVAL, "g0_wgrad: bad args");
+  (void)ws; (void)ws_bytes; (void)algo;
+  // weight-streaming bound (|dw| = 16*E*C fp32 written once); the generic kernel is used for now
+  return rg_generic_g0_wgrad(z, gy, dw, N, E, C, dtype, accumulate, rg_stream(stream));
+}
+
+extern "C" int rg_pack_linear_weight(const float* w, void* wp, int Nout, int K, int Nout_pad, int K_pad, void* stream) {
+  RG_REQUIRE(w && wp && Nout > 0 && K > 0 && Nout_pad >= Nout && K_pad >= K, RG_EINVAL, "pack_linear_weight: bad args");
+  return rg_mfma_pack_linear_weight(w, wp, Nout, K, Nout_pad, K_pad, rg_stream(stream));
+}
+
+extern "C" size_t rg_linear_workspace_bytes(int M, int K, int Nout, int algo) {
+  (void)Nout;
+  if (algo == RG_ALGO_GENERIC) return 0;
+  size_t kp = rg_align_up((size_t)K, 64);
+  return (size_t)M * kp * 2;
+}
+
+extern "C" int rg_linear_affine_act(const float* x, int ldx, const float* w, const void* wp, const float* scale,
+                                    const float* shift, float* y, int ldy, int M, int K, int Nout, float slope,
+                                    int algo, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(x && y && M > 0 && K > 0 && Nout > 0 && ldx >= K && ldy >= Nout, RG_EINVAL, "linear: bad args");
+  if (algo != RG_ALGO_GENERIC && wp) {
+    int kp = (int)rg_align_up((size_t)K, 64);
+    RG_REQUIRE(ws && ws_bytes >= (size_t)M * kp * 2, RG_EWORKSPACE, "linear: workspace too small");
+    RG_REQUIRE(ldx == K, RG_EINVAL, "linear(MFMA): x must be dense");
+    int rc = rg_cast_pad(x, ws, M, K, kp, RG_BF16, stream);
+    if (rc) return rc;
+    return rg_mfma_linear(ws, wp, scale, shift, y, ldy, M, kp, Nout, slope, rg_stream(stream));
+  }
+  RG_REQUIRE(algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "linear: MFMA path needs the packed weight");
+  RG_REQUIRE(w, RG_EINVAL, "linear: generic kernel needs the fp32 weight");
+  return rg_generic_linear(x, ldx, w, scale, shift, y, ldy, M, K, Nout, slope, rg_stream(stream));
+}

@@ -1,0 +1,121 @@
+// rg_common.h -- shared device/host helpers of librnagan_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include "../../include/rnagan_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// error handling (no exceptions cross the C ABI)
+// ---------------------------------------------------------------------------------------------
+void rg_set_error(const char* fmt, ...);
+
+#define RG_REQUIRE(cond, code, ...)     \
+  do {                                  \
+    if (!(cond)) {                      \
+      rg_set_error(__VA_ARGS__);        \
+      return (code);                    \
+    }                                   \
+  } while (0)
+
+#define RG_LAUNCH_CHECK(name)                                              \
+  do {                                                                     \
+    hipError_t e__ = hipGetLastError();                                    \
+    if (e__ != hipSuccess) {                                               \
+      rg_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return RG_EHIP;                                                      \
+    }                                                                      \
+  } while (0)
+
+static inline hipStream_t rg_stream(void* s) { return (hipStream_t)s; }
+static inline size_t rg_dtype_size(int dtype) { return dtype == RG_BF16 ? 2 : 4; }
+static inline bool rg_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+static inline int rg_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static inline size_t rg_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------
+// bf16 storage type (raw 16 bits) and conversions.  Round-to-nearest-even via the compiler's
+// native conversion (v_cvt_pk_bf16_f32 on gfx950, NaN-preserving).
+// ---------------------------------------------------------------------------------------------
+struct bf16_t { uint16_t bits; };
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) {
+  return __uint_as_float(((uint32_t)b) << 16);
+}
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  __bf16 h = (__bf16)f;
+  return __builtin_bit_cast(uint16_t, h);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int dtype = RG_F32;
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+  __device__ static __forceinline__ float round(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int dtype = RG_BF16;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(p->bits); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { p->bits = f32_to_bf16(v); }
+  __device__ static __forceinline__ float round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+};
+
+// vector load/store of VEC (1 or 4) consecutive elements as floats
+template <typename T, int VEC> struct Vec;
+template <> struct Vec<float, 1> {
+  __device__ static __forceinline__ void ld(const float* p, float* o) { o[0] = p[0]; }
+  __device__ static __forceinline__ void st(float* p, const float* v) { p[0] = v[0]; }
+};
+template <> struct Vec<float, 4> {
+  __device__ static __forceinline__ void ld(const float* p, float* o) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+  }
+  __device__ static __forceinline__ void st(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <> struct Vec<bf16_t, 1> {
+  __device__ static __forceinline__ void ld(const bf16_t* p, float* o) { o[0] = bf16_to_f32(p->bits); }
+  __device__ static __forceinline__ void st(bf16_t* p, const float* v) { p->bits = f32_to_bf16(v[0]); }
+};
+template <> struct Vec<bf16_t, 4> {
+  __device__ static __forceinline__ void ld(const bf16_t* p, float* o) {
+    uint2 t = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(t.x << 16); o[1] = __uint_as_float(t.x & 0xffff0000u);
+    o[2] = __uint_as_float(t.y << 16); o[3] = __uint_as_float(t.y & 0xffff0000u);
+  }
+  __device__ static __forceinline__ void st(bf16_t* p, const float* v) {
+    uint2 t;
+    t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = t;
+  }
+};
+
+__device__ __forceinline__ float lrelu_f(float v, float slope) { return v > 0.f ? v : v * slope; }
+__device__ __forceinline__ float lrelu_mask(float v, float slope) { return v > 0.f ? 1.f : slope; }
+
+// 64-lane wave reduction (sum)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+// block-wide sum for blockDim.x == 256; result valid in thread 0
+__device__ __forceinline__ float block_sum_256(float v, float* smem4) {
+  v = wave_sum(v);
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) smem4[w] = v;
+  __syncthreads();
+  return smem4[0] + smem4[1] + smem4[2] + smem4[3];
+}
+
+// dtype dispatch helper for host code
+#define RG_DISPATCH_DTYPE(dtype, T, ...)                                  \
+  if ((dtype) == RG_F32) { using T = float; __VA_ARGS__ }                 \
+  else if ((dtype) == RG_BF16) { using T = bf16_t; __VA_ARGS__ }          \
+  else { rg_set_error("bad dtype %d", (int)(dtype)); return RG_EINVAL; }

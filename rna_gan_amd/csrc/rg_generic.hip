@@ -1,0 +1,415 @@
+// rg_generic.hip -- generic (any shape, fp32 math on the vector ALUs) tiled kernels.
+//
+// One LDS-tiled GEMM skeleton, C[M][N] = sum_k A(m,k) * B(k,n), whose operands are fetched through
+// functors (implicit im2col with zero padding, NHWC / NCHW, fp32 / bf16 storage).  It implements
+// every conv / dense entry point of include/rnagan_hip.h for shapes the MFMA kernels do not take
+// and IS the fp32 parity path (RG_F32 activations): same operation order on every launch,
+// deterministic split-K (slabs summed in fixed order).
+#include "rg_common.h"
+
+namespace {
+
+constexpr int GB_M = 64, GB_N = 64, GB_K = 16;
+
+// A_KFAST: consecutive threads fetch consecutive k (else consecutive m); same idea for B.
+template <bool A_KFAST, bool B_KFAST, class FA, class FB, class SC>
+__global__ __launch_bounds__(256) void gemm_generic_kernel(FA fa, FB fb, SC sc, int M, int N, int K, int nsplit,
+                                                           int klen) {
+  __shared__ float As[GB_K][GB_M + 4];
+  __shared__ float Bs[GB_K][GB_N + 4];
+  const int bm = blockIdx.x * GB_M, bn = blockIdx.y * GB_N;
+  const int zs = blockIdx.z % nsplit, zb = blockIdx.z / nsplit;
+  const int k_begin = zs * klen;
+  const int k_end = min(K, k_begin + klen);
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+  for (int k0 = k_begin; k0 < k_end; k0 += GB_K) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int idx = threadIdx.x + i * 256;
+      int kk, mm;
+      if (A_KFAST) { kk = idx & 15; mm = idx >> 4; } else { mm = idx & 63; kk = idx >> 6; }
+      float v = 0.f;
+      if (bm + mm < M && k0 + kk < k_end) v = fa(zb, bm + mm, k0 + kk);
+      As[kk][mm] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int idx = threadIdx.x + i * 256;
+      int kk, nn;
+      if (B_KFAST) { kk = idx & 15; nn = idx >> 4; } else { nn = idx & 63; kk = idx >> 6; }
+      float v = 0.f;
+      if (bn + nn < N && k0 + kk < k_end) v = fb(zb, k0 + kk, bn + nn);
+      Bs[kk][nn] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GB_K; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int m = bm + ty * 4 + i, n = bn + tx * 4 + j;
+      if (m < M && n < N) sc(zb, zs, m, n, acc[i][j]);
+    }
+}
+
+template <bool AK, bool BK, class FA, class FB, class SC>
+int launch_generic(const char* name, FA fa, FB fb, SC sc, int M, int N, int K, int nbatch, int nsplit,
+                   hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0) return RG_OK;
+  int klen = (K + nsplit - 1) / nsplit;
+  klen = (klen + GB_K - 1) / GB_K * GB_K;
+  dim3 grid((M + GB_M - 1) / GB_M, (N + GB_N - 1) / GB_N, nbatch * nsplit);
+  RG_REQUIRE(grid.y <= 65535 && grid.z <= 65535, RG_EINVAL, "%s: grid too large", name);
+  hipLaunchKernelGGL((gemm_generic_kernel<AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, nsplit,
+                     klen);
+  RG_LAUNCH_CHECK(name);
+  return RG_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// split-K slab reduction: dst[idx] = (accumulate ? dst[idx] : 0) + sum_s slab[s][perm(idx)]
+// perm_mode 0: identity.  perm_mode 1: slab layout [o][tap][i] -> dst layout [o][i][tap] (MFMA wgrad)
+// perm_mode 2: slab layout [e][tap*C + c]  -> dst layout [e][c][tap]                    (MFMA g0 wgrad)
+// ----------------------------------------------------------------------------------------------
+__global__ void reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ dst, size_t n, int nsplit,
+                                    int accumulate, int perm_mode, int P, int Q) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  size_t src = idx;
+  if (perm_mode == 1) {          // dst idx = (o*Q + i)*16 + tap, P unused, Q = I
+    size_t tap = idx & 15, oi = idx >> 4;
+    size_t i = oi % Q, o = oi / Q;
+    src = (o * 16 + tap) * Q + i;
+  } else if (perm_mode == 2) {   // dst idx = (e*Q + c)*16 + tap, Q = C
+    size_t tap = idx & 15, ec = idx >> 4;
+    size_t c = ec % Q, e = ec / Q;
+    src = e * (16 * (size_t)Q) + tap * Q + c;
+  }
+  float s = accumulate ? dst[idx] : 0.f;
+  for (int z = 0; z < nsplit; ++z) s += slab[(size_t)z * n + src];
+  dst[idx] = s;
+}
+
+}  // namespace
+
+int rg_reduce_slabs(const float* slab, float* dst, size_t n, int nsplit, int accumulate, int perm_mode, int Q,
+                    hipStream_t st) {
+  if (n == 0) return RG_OK;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, dst, n, nsplit,
+                     accumulate, perm_mode, 0, Q);
+  RG_LAUNCH_CHECK("reduce_slabs");
+  return RG_OK;
+}
+
+namespace {
+// ----------------------------------------------------------------------------------------------
+// functors
+// ----------------------------------------------------------------------------------------------
+struct Geo {
+  int N, Hl, Wl, Hh, Wh, O, I;  // low-res dims (Hl,Wl), high-res dims (Hh=2Hl, Wh=2Wl)
+};
+
+// ---- conv_down: M = N*Hl*Wl, K = I*16 (k = ci*16 + tap), Ncols = O
+template <typename T> struct DownA {
+  const T* x; Geo g;
+  __device__ float operator()(int, int m, int k) const {
+    int wo = m % g.Wl, t = m / g.Wl, ho = t % g.Hl, n = t / g.Hl;
+    int ci = k >> 4, tap = k & 15;
+    int hi = 2 * ho - 1 + (tap >> 2), wi = 2 * wo - 1 + (tap & 3);
+    if (hi < 0 || hi >= g.Hh || wi < 0 || wi >= g.Wh) return 0.f;
+    return Elem<T>::ld(x + (((size_t)n * g.Hh + hi) * g.Wh + wi) * g.I + ci);
+  }
+};
+template <typename T> struct DownB {
+  const float* w; Geo g;
+  __device__ float operator()(int, int k, int o) const { return Elem<T>::round(w[(size_t)o * g.I * 16 + k]); }
+};
+template <typename T> struct RowMajorC {
+  T* y; int ld;
+  __device__ void operator()(int, int, int m, int n, float v) const { Elem<T>::st(y + (size_t)m * ld + n, v); }
+};
+
+// ---- conv_up: batch z = parity class (ph,pw); M = N*Hl*Wl, K = O*4 (k = o*4 + t4), Ncols = I
+__device__ __forceinline__ void up_tap(int par, int a, int q, int& kidx, int& src) {
+  // output index 2q+par along one axis, tap a in {0,1}: kernel index and low-res source index
+  if (par == 0) { kidx = a == 0 ? 1 : 3; src = a == 0 ? q : q - 1; }
+  else          { kidx = a == 0 ? 0 : 2; src = a == 0 ? q + 1 : q; }
+}
+template <typename T> struct UpA {
+  const T* x; Geo g;
+  __device__ float operator()(int zb, int m, int k) const {
+    int wq = m % g.Wl, t = m / g.Wl, hq = t % g.Hl, n = t / g.Hl;
+    int o = k >> 2, t4 = k & 3, kh, kw, ho, wo;
+    up_tap(zb >> 1, t4 >> 1, hq, kh, ho);
+    up_tap(zb & 1, t4 & 1, wq, kw, wo);
+    if (ho < 0 || ho >= g.Hl || wo < 0 || wo >= g.Wl) return 0.f;
+    return Elem<T>::ld(x + (((size_t)n * g.Hl + ho) * g.Wl + wo) * g.O + o);
+  }
+};
+template <typename T> struct UpB {
+  const float* w; Geo g;
+  __device__ float operator()(int zb, int k, int i) const {
+    int o = k >> 2, t4 = k & 3, kh, kw, d;
+    up_tap(zb >> 1, t4 >> 1, 0, kh, d);
+    up_tap(zb & 1, t4 & 1, 0, kw, d);
+    return Elem<T>::round(w[((size_t)o * g.I + i) * 16 + kh * 4 + kw]);
+  }
+};
+template <typename T> struct UpC {
+  T* y; Geo g;
+  __device__ void operator()(int zb, int, int m, int i, float v) const {
+    int wq = m % g.Wl, t = m / g.Wl, hq = t % g.Hl, n = t / g.Hl;
+    int hi = 2 * hq + (zb >> 1), wi = 2 * wq + (zb & 1);
+    Elem<T>::st(y + (((size_t)n * g.Hh + hi) * g.Wh + wi) * g.I + i, v);
+  }
+};
+// image-side variant: NCHW fp32 output with bias + optional tanh
+struct UpCNchw {
+  float* y; const float* bias; int tanh_; Geo g;
+  __device__ void operator()(int zb, int, int m, int i, float v) const {
+    int wq = m % g.Wl, t = m / g.Wl, hq = t % g.Hl, n = t / g.Hl;
+    int hi = 2 * hq + (zb >> 1), wi = 2 * wq + (zb & 1);
+    if (bias) v += bias[i];
+    if (tanh_) v = tanhf(v);
+    y[(((size_t)n * g.I + i) * g.Hh + hi) * g.Wh + wi] = v;
+  }
+};
+
+// ---- image-side first_down: A from NCHW fp32; epilogue bias + lrelu
+struct FirstDownA {
+  const float* x; Geo g;
+  __device__ float operator()(int, int m, int k) const {
+    int wo = m % g.Wl, t = m / g.Wl, ho = t % g.Hl, n = t / g.Hl;
+    int ci = k >> 4, tap = k & 15;
+    int hi = 2 * ho - 1 + (tap >> 2), wi = 2 * wo - 1 + (tap & 3);
+    if (hi < 0 || hi >= g.Hh || wi < 0 || wi >= g.Wh) return 0.f;
+    return x[(((size_t)n * g.I + ci) * g.Hh + hi) * g.Wh + wi];
+  }
+};
+template <typename T> struct BiasActC {
+  T* y; const float* bias; float slope; int ld;
+  __device__ void operator()(int, int, int m, int n, float v) const {
+    if (bias) v += bias[n];
+    Elem<T>::st(y + (size_t)m * ld + n, lrelu_f(v, slope));
+  }
+};
+
+// ---- wgrad: M = O, Ncols = I*16 (col = i*16 + tap), K = N*Hl*Wl pixels
+template <typename T> struct WgradA {
+  const T* low; Geo g;
+  __device__ float operator()(int, int o, int pix) const { return Elem<T>::ld(low + (size_t)pix * g.O + o); }
+};
+template <typename T> struct WgradB {
+  const T* high; Geo g;
+  __device__ float operator()(int, int pix, int col) const {
+    int wo = pix % g.Wl, t = pix / g.Wl, ho = t % g.Hl, n = t / g.Hl;
+    int i = col >> 4, tap = col & 15;
+    int hi = 2 * ho - 1 + (tap >> 2), wi = 2 * wo - 1 + (tap & 3);
+    if (hi < 0 || hi >= g.Hh || wi < 0 || wi >= g.Wh) return 0.f;
+    return Elem<T>::ld(high + (((size_t)n * g.Hh + hi) * g.Wh + wi) * g.I + i);
+  }
+};
+struct WgradBNchw {
+  const float* high; Geo g;
+  __device__ float operator()(int, int pix, int col) const {
+    int wo = pix % g.Wl, t = pix / g.Wl, ho = t % g.Hl, n = t / g.Hl;
+    int i = col >> 4, tap = col & 15;
+    int hi = 2 * ho - 1 + (tap >> 2), wi = 2 * wo - 1 + (tap & 3);
+    if (hi < 0 || hi >= g.Hh || wi < 0 || wi >= g.Wh) return 0.f;
+    return high[(((size_t)n * g.I + i) * g.Hh + hi) * g.Wh + wi];
+  }
+};
+struct SlabC {  // slab[zs][m*ld + n]
+  float* slab; size_t slab_elems; int ld;
+  __device__ void operator()(int, int zs, int m, int n, float v) const {
+    slab[(size_t)zs * slab_elems + (size_t)m * ld + n] = v;
+  }
+};
+
+// ---- g0: fwd  A(n,e) = z, B(e, col=tap*C+c) = w[e][c][tap];  wgrad A(e,n)=z, B(n, col'=c*16+tap)=gy[n][tap*C+c]
+template <typename T> struct G0A {
+  const float* z; int E;
+  __device__ float operator()(int, int n, int e) const { return Elem<T>::round(z[(size_t)n * E + e]); }
+};
+template <typename T> struct G0B {
+  const float* w; int C;
+  __device__ float operator()(int, int e, int col) const {
+    int tap = col / C, c = col % C;
+    return Elem<T>::round(w[((size_t)e * C + c) * 16 + tap]);
+  }
+};
+template <typename T> struct G0WA {
+  const float* z; int E;
+  __device__ float operator()(int, int e, int n) const { return Elem<T>::round(z[(size_t)n * E + e]); }
+};
+template <typename T> struct G0WB {
+  const T* gy; int C;
+  __device__ float operator()(int, int n, int col) const {
+    int c = col >> 4, tap = col & 15;
+    return Elem<T>::ld(gy + (size_t)n * 16 * C + (size_t)tap * C + c);
+  }
+};
+struct AccumC {
+  float* dst; int ld; int accumulate;
+  __device__ void operator()(int, int, int m, int n, float v) const {
+    size_t idx = (size_t)m * ld + n;
+    dst[idx] = accumulate ? dst[idx] + v : v;
+  }
+};
+
+// ---- linear
+struct LinA {
+  const float* x; int ldx;
+  __device__ float operator()(int, int m, int k) const { return x[(size_t)m * ldx + k]; }
+};
+struct LinB {
+  const float* w; int K;
+  __device__ float operator()(int, int k, int j) const { return w[(size_t)j * K + k]; }
+};
+struct LinC {
+  float* y; int ldy; const float* scale; const float* shift; float slope;
+  __device__ void operator()(int, int, int m, int j, float v) const {
+    if (scale) v *= scale[j];
+    if (shift) v += shift[j];
+    y[(size_t)m * ldy + j] = lrelu_f(v, slope);
+  }
+};
+
+int pick_split(int tiles, int K) {
+  // enough blocks to fill 256 CUs a few times, at least 64 k-steps per split
+  int want = (1024 + tiles - 1) / tiles;
+  int maxs = K / (GB_K * 16);
+  if (maxs < 1) maxs = 1;
+  int s = want < maxs ? want : maxs;
+  if (s > 256) s = 256;
+  return s < 1 ? 1 : s;
+}
+
+}  // namespace
+
+// ==============================================================================================
+// host entry points for the generic path (called by the dispatchers in rg_api.hip)
+// ==============================================================================================
+int rg_generic_conv_down(const void* x, const float* w, void* y, int N, int Hi, int Wi, int I, int O, int dtype,
+                         hipStream_t st) {
+  Geo g{N, Hi / 2, Wi / 2, Hi, Wi, O, I};
+  RG_DISPATCH_DTYPE(dtype, T, {
+    return launch_generic<true, true>("conv_down(generic)", DownA<T>{(const T*)x, g}, DownB<T>{w, g},
+                                      RowMajorC<T>{(T*)y, O}, N * g.Hl * g.Wl, O, I * 16, 1, 1, st);
+  })
+}
+
+int rg_generic_conv_up(const void* x, const float* w, void* y, int N, int Ho, int Wo, int O, int I, int dtype,
+                       hipStream_t st) {
+  Geo g{N, Ho, Wo, 2 * Ho, 2 * Wo, O, I};
+  RG_DISPATCH_DTYPE(dtype, T, {
+    return launch_generic<true, false>("conv_up(generic)", UpA<T>{(const T*)x, g}, UpB<T>{w, g}, UpC<T>{(T*)y, g},
+                                       N * Ho * Wo, I, O * 4, 4, 1, st);
+  })
+}
+
+int rg_generic_first_down(const float* x, const float* w, const float* bias, void* y, int N, int H, int W, int I,
+                          int O, float slope, int dtype, hipStream_t st) {
+  Geo g{N, H / 2, W / 2, H, W, O, I};
+  RG_DISPATCH_DTYPE(dtype, T, {
+    return launch_generic<true, true>("first_down(generic)", FirstDownA{x, g}, DownB<T>{w, g},
+                                      BiasActC<T>{(T*)y, bias, slope, O}, N * g.Hl * g.Wl, O, I * 16, 1, 1, st);
+  })
+}
+
+int rg_generic_last_up(const void* x, const float* w, const float* bias, float* y, int N, int Ho, int Wo, int O,
+                       int I, int apply_tanh, int dtype, hipStream_t st) {
+  Geo g{N, Ho, Wo, 2 * Ho, 2 * Wo, O, I};
+  RG_DISPATCH_DTYPE(dtype, T, {
+    return launch_generic<true, false>("last_up(generic)", UpA<T>{(const T*)x, g}, UpB<T>{w, g},
+                                       UpCNchw{y, bias, apply_tanh, g}, N * Ho * Wo, I, O * 4, 4, 1, st);
+  })
+}
+
+static int generic_wgrad_split(int N, int Ho, int Wo, int O, int I) {
+  int tiles = ((O + GB_M - 1) / GB_M) * ((I * 16 + GB_N - 1) / GB_N);
+  return pick_split(tiles, N * Ho * Wo);
+}
+
+size_t rg_generic_wgrad_ws_bytes(int N, int Ho, int Wo, int O, int I) {
+  int s = generic_wgrad_split(N, Ho, Wo, O, I);
+  return s > 1 ? (size_t)s * O * I * 16 * sizeof(float) : 0;
+}
+
+template <class FB>
+static int generic_wgrad_impl(const char* name, const void* low, FB fb, float* dw, Geo g, int dtype, int accumulate,
+                              void* ws, size_t ws_bytes, hipStream_t st) {
+  int K = g.N * g.Hl * g.Wl;
+  int s = generic_wgrad_split(g.N, g.Hl, g.Wl, g.O, g.I);
+  size_t elems = (size_t)g.O * g.I * 16;
+  if (s > 1) {
+    RG_REQUIRE(ws && ws_bytes >= (size_t)s * elems * sizeof(float), RG_EWORKSPACE, "%s: workspace too small", name);
+    RG_DISPATCH_DTYPE(dtype, T, {
+      int rc = launch_generic<false, false>(name, WgradA<T>{(const T*)low, g}, fb, SlabC{(float*)ws, elems, g.I * 16},
+                                            g.O, g.I * 16, K, 1, s, st);
+      if (rc) return rc;
+    })
+    return rg_reduce_slabs((const float*)ws, dw, elems, s, accumulate, 0, 0, st);
+  }
+  RG_DISPATCH_DTYPE(dtype, T, {
+    return launch_generic<false, false>(name, WgradA<T>{(const T*)low, g}, fb, AccumC{dw, g.I * 16, accumulate}, g.O,
+                                        g.I * 16, K, 1, 1, st);
+  })
+}
+
+int rg_generic_conv_wgrad(const void* low, const void* high, float* dw, int N, int Ho, int Wo, int O, int I,
+                          int dtype, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+  Geo g{N, Ho, Wo, 2 * Ho, 2 * Wo, O, I};
+  if (dtype == RG_F32)
+    return generic_wgrad_impl("conv_wgrad(generic)", low, WgradB<float>{(const float*)high, g}, dw, g, dtype,
+                              accumulate, ws, ws_bytes, st);
+  return generic_wgrad_impl("conv_wgrad(generic)", low, WgradB<bf16_t>{(const bf16_t*)high, g}, dw, g, dtype,
+                            accumulate, ws, ws_bytes, st);
+}
+
+int rg_generic_skinny_wgrad(const void* low, const float* high_nchw, float* dw, int N, int Ho, int Wo, int O, int I,
+                            int dtype, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+  Geo g{N, Ho, Wo, 2 * Ho, 2 * Wo, O, I};
+  return generic_wgrad_impl("skinny_wgrad(generic)", low, WgradBNchw{high_nchw, g}, dw, g, dtype, accumulate, ws,
+                            ws_bytes, st);
+}
+
+int rg_generic_g0_fwd(const float* z, const float* w, void* y, int N, int E, int C, int dtype, hipStream_t st) {
+  RG_DISPATCH_DTYPE(dtype, T, {
+    return launch_generic<true, false>("g0_fwd(generic)", G0A<T>{z, E}, G0B<T>{w, C}, RowMajorC<T>{(T*)y, 16 * C}, N,
+                                       16 * C, E, 1, 1, st);
+  })
+}
+
+int rg_generic_g0_wgrad(const float* z, const void* gy, float* dw, int N, int E, int C, int dtype, int accumulate,
+                        hipStream_t st) {
+  RG_DISPATCH_DTYPE(dtype, T, {
+    return launch_generic<false, false>("g0_wgrad(generic)", G0WA<T>{z, E}, G0WB<T>{(const T*)gy, C},
+                                        AccumC{dw, 16 * C, accumulate}, E, 16 * C, N, 1, 1, st);
+  })
+}
+
+int rg_generic_linear(const float* x, int ldx, const float* w, const float* scale, const float* shift, float* y,
+                      int ldy, int M, int K, int Nout, float slope, hipStream_t st) {
+  return launch_generic<true, true>("linear(generic)", LinA{x, ldx}, LinB{w, K}, LinC{y, ldy, scale, shift, slope}, M,
+                                    Nout, K, 1, 1, st);
+}

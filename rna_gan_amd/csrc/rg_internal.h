@@ -1,0 +1,51 @@
+// rg_internal.h -- host-side functions shared between the translation units of librnagan_hip.so.
+#pragma once
+#include "rg_common.h"
+
+// rg_generic.hip
+int rg_reduce_slabs(const float* slab, float* dst, size_t n, int nsplit, int accumulate, int perm_mode, int Q,
+                    hipStream_t st);
+int rg_generic_conv_down(const void* x, const float* w, void* y, int N, int Hi, int Wi, int I, int O, int dtype,
+                         hipStream_t st);
+int rg_generic_conv_up(const void* x, const float* w, void* y, int N, int Ho, int Wo, int O, int I, int dtype,
+                       hipStream_t st);
+int rg_generic_first_down(const float* x, const float* w, const float* bias, void* y, int N, int H, int W, int I,
+                          int O, float slope, int dtype, hipStream_t st);
+int rg_generic_last_up(const void* x, const float* w, const float* bias, float* y, int N, int Ho, int Wo, int O,
+                       int I, int apply_tanh, int dtype, hipStream_t st);
+size_t rg_generic_wgrad_ws_bytes(int N, int Ho, int Wo, int O, int I);
+int rg_generic_conv_wgrad(const void* low, const void* high, float* dw, int N, int Ho, int Wo, int O, int I,
+                          int dtype, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+int rg_generic_skinny_wgrad(const void* low, const float* high_nchw, float* dw, int N, int Ho, int Wo, int O, int I,
+                            int dtype, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+int rg_generic_g0_fwd(const float* z, const float* w, void* y, int N, int E, int C, int dtype, hipStream_t st);
+int rg_generic_g0_wgrad(const float* z, const void* gy, float* dw, int N, int E, int C, int dtype, int accumulate,
+                        hipStream_t st);
+int rg_generic_linear(const float* x, int ldx, const float* w, const float* scale, const float* shift, float* y,
+                      int ldy, int M, int K, int Nout, float slope, hipStream_t st);
+
+// rg_mfma.hip (bf16 MFMA implicit-GEMM kernels)
+bool rg_mfma_conv_supported(int N, int Hq, int Wq, int Kc, int Ncols);
+bool rg_mfma_plain_supported(int M, int K, int Ncols);
+bool rg_mfma_wgrad_supported(int N, int Ho, int Wo, int O, int I);
+size_t rg_mfma_wgrad_ws_bytes(int N, int Ho, int Wo, int O, int I);
+int rg_mfma_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I, hipStream_t st);
+int rg_mfma_pack_g0_weight(const float* w, void* wp, int E, int C, hipStream_t st);
+int rg_mfma_pack_linear_weight(const float* w, void* wp, int Nout, int K, int Nout_pad, int K_pad, hipStream_t st);
+int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, int Wi, int I, int O, hipStream_t st);
+int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, hipStream_t st);
+int rg_mfma_gemm_plain(const void* a, const void* bt, void* c, int M, int K, int Ncols, int ldc, hipStream_t st);
+int rg_mfma_linear(const void* a, const void* bt, const float* scale, const float* shift, float* y, int ldy, int M,
+                   int Kpad, int Nout, float slope, hipStream_t st);
+int rg_mfma_conv_wgrad(const void* low, const void* high, float* dw, int N, int Ho, int Wo, int O, int I,
+                       int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+
+// rg_skinny.hip (image-side 3-channel layers)
+bool rg_skinny_supported(int I, int O);
+int rg_skinny_first_down(const float* x, const float* w, const float* bias, void* y, int N, int H, int W, int I,
+                         int O, float slope, int dtype, hipStream_t st);
+int rg_skinny_last_up(const void* x, const float* w, const float* bias, float* y, int N, int Ho, int Wo, int O, int I,
+                      int apply_tanh, int dtype, hipStream_t st);
+size_t rg_skinny_wgrad_ws_bytes(int N, int Ho, int Wo, int O, int I);
+int rg_skinny_wgrad_impl(const void* low, const float* high_nchw, float* dw, int N, int Ho, int Wo, int O, int I,
+                         int dtype, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);

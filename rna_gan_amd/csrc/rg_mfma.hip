@@ -1,0 +1,621 @@
+// rg_mfma.hip -- bf16 MFMA implicit-GEMM kernels for gfx950 (v_mfma_f32_32x32x16_bf16, fp32 acc).
+//
+//  * gather_gemm_kernel<MODE,EPI>: C[M][Ncols] = sum_k A(m,k) * Bt[col][k]
+//      MODE_DOWN : stride-2 4x4 conv      (A rows gathered from the high-res NHWC tensor, 16 taps)
+//      MODE_UP   : its transpose          (4 output-parity classes, 2x2 taps each, grid.y = class)
+//      MODE_PLAIN: ordinary row-major A   (generator layer 0, betaVAE Linear layers)
+//    128x128 block tile, BK = 64 bf16 (one 128-byte line per row per k-tile), 4 waves as 2x2 with a
+//    64x64 wave tile (2x2 MFMA 32x32x16).  Operands are staged global -> registers -> LDS
+//    (issue-early / write-late, double-buffered, ONE barrier per k-tile); the LDS image is
+//    [row][8 chunks of 16 B] with chunk ^= (row>>1)&7, which makes both the ds_write_b128 staging
+//    stores and the ds_read_b128 fragment reads bank-conflict free (MI355X_MICROARCH LDS table).
+//    The epilogue transposes the accumulators through LDS so every global store is 16 bytes wide
+//    and row-contiguous.
+//  * wgrad_kernel: dW[o][tap][i] = sum_pix low[pix][o] * high[src(pix,tap)][i].  The contraction
+//    index (pixels) is the slow axis of both NHWC operands, so the [pixel][channel] LDS images are
+//    read with ds_read_b64_tr_b16 (hardware transpose) to build k-contiguous MFMA fragments.
+//    Split-K over pixels into fp32 slabs, reduced in fixed order (deterministic).
+#include "rg_internal.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+constexpr int MODE_DOWN = 0, MODE_UP = 1, MODE_PLAIN = 2;
+constexpr int EPI_BF16 = 0, EPI_LINEAR = 1;
+
+struct GArgs {
+  const uint16_t* A;
+  const uint16_t* B;
+  void* C;
+  int M, Ncols, Cin, taps;
+  int lgW, lgH;     // row m -> (n, hq, wq): wq = m & (2^lgW-1), hq = (m>>lgW) & (2^lgH-1)
+  int Hs, Ws;       // spatial dims of the tensor A rows are gathered from
+  int ldc;          // output row stride in elements
+  int Btaps;        // taps per B row (16 for conv packs, 1 for plain)
+  int tiles_n;      // number of 128-wide column tiles
+  const float* scale;
+  const float* shift;
+  float slope;
+};
+
+__device__ __forceinline__ uint4 ld16_if(const uint16_t* p, bool pred) {
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (pred) v = *reinterpret_cast<const uint4*>(p);
+  return v;
+}
+
+__device__ __forceinline__ int lds_chunk_index(int row, int chunk) { return row * 8 + (chunk ^ ((row >> 1) & 7)); }
+
+__device__ __forceinline__ void up_tap_dev(int par, int a, int& kidx, int& d) {
+  if (par == 0) { kidx = a == 0 ? 1 : 3; d = a == 0 ? 0 : -1; }
+  else          { kidx = a == 0 ? 0 : 2; d = a == 0 ? 1 : 0; }
+}
+
+template <int MODE, int EPI>
+__global__ __launch_bounds__(256, 2) void gather_gemm_kernel(GArgs g) {
+  // 2 stages x (A,B) x 128 rows x 8 chunks x 16 B = 64 KB; reused as the fp32 C tile (128x128x4 B)
+  __shared__ __attribute__((aligned(16))) uint4 lds[2 * 2 * 1024];
+
+  const int t = threadIdx.x;
+  const int tile_m = blockIdx.x / g.tiles_n, tile_n = blockIdx.x - tile_m * g.tiles_n;
+  const int bm = tile_m * 128, bn = tile_n * 128;
+  const int par = (MODE == MODE_UP) ? (int)blockIdx.y : 0;
+  const int ph = par >> 1, pw = par & 1;
+
+  // ---- per-thread staging assignment: chunk (16 B) of rows r0 + 32*j
+  const int chunk = t & 7, r0 = t >> 3;
+  const int Wq = 1 << g.lgW, Hq = 1 << g.lgH;
+  const uint16_t *a_ptr0, *a_ptr1, *a_ptr2, *a_ptr3, *b_ptr0, *b_ptr1, *b_ptr2, *b_ptr3;
+  unsigned a_mask0, a_mask1, a_mask2, a_mask3;
+  bool b_ok0, b_ok1, b_ok2, b_ok3;
+#define RG_ROW_SETUP(J, APTR, AMASK, BPTR, BOK)                                                   \
+  do {                                                                                            \
+    int m = bm + r0 + 32 * (J);                                                                   \
+    bool ok = m < g.M;                                                                            \
+    int mm = ok ? m : 0;                                                                          \
+    int wq = mm & (Wq - 1), hq = (mm >> g.lgW) & (Hq - 1), n = mm >> (g.lgW + g.lgH);             \
+    unsigned mask = 0;                                                                            \
+    long long base;                                                                               \
+    if (MODE == MODE_DOWN) {                                                                      \
+      int hs0 = 2 * hq - 1, ws0 = 2 * wq - 1;                                                     \
+      base = (((long long)n * g.Hs + hs0) * g.Ws + ws0) * g.Cin;                                  \
+      _Pragma("unroll") for (int kh = 0; kh < 4; ++kh)                                            \
+      _Pragma("unroll") for (int kw = 0; kw < 4; ++kw) {                                          \
+        bool v = (unsigned)(hs0 + kh) < (unsigned)g.Hs && (unsigned)(ws0 + kw) < (unsigned)g.Ws;  \
+        mask |= (v ? 1u : 0u) << (kh * 4 + kw);                                                   \
+      }                                                                                           \
+    } else if (MODE == MODE_UP) {                                                                 \
+      base = (((long long)n * g.Hs + hq) * g.Ws + wq) * g.Cin;                                    \
+      _Pragma("unroll") for (int a = 0; a < 2; ++a)                                               \
+      _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                             \
+        int kh, kw, dh, dw;                                                                       \
+        up_tap_dev(ph, a, kh, dh);                                                                \
+        up_tap_dev(pw, b, kw, dw);                                                                \
+        bool v = (unsigned)(hq + dh) < (unsigned)g.Hs && (unsigned)(wq + dw) < (unsigned)g.Ws;    \
+        mask |= (v ? 1u : 0u) << (a * 2 + b);                                                     \
+      }                                                                                           \
+    } else {                                                                                      \
+      base = (long long)mm * g.Cin;                                                               \
+      mask = 1u;                                                                                  \
+    }                                                                                             \
+    APTR = g.A + base + chunk * 8;                                                                \
+    AMASK = ok ? mask : 0u;                                                                       \
+    int col = bn + r0 + 32 * (J);                                                                 \
+    BOK = col < g.Ncols;                                                                          \
+    BPTR = g.B + (long long)(BOK ? col : 0) * g.Btaps * g.Cin + chunk * 8;                        \
+  } while (0)
+  RG_ROW_SETUP(0, a_ptr0, a_mask0, b_ptr0, b_ok0);
+  RG_ROW_SETUP(1, a_ptr1, a_mask1, b_ptr1, b_ok1);
+  RG_ROW_SETUP(2, a_ptr2, a_mask2, b_ptr2, b_ok2);
+  RG_ROW_SETUP(3, a_ptr3, a_mask3, b_ptr3, b_ok3);
+
+  const int cpt = g.Cin >> 6;          // k-tiles per tap
+  const int nkt = g.taps * cpt;
+
+  // staging registers are named scalars (not arrays captured by a lambda): keeps them out of scratch
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define RG_LOAD_TILE(TAP, C0)                                                                     \
+  do {                                                                                            \
+    const int tap_ = (TAP), c0_ = (C0);                                                           \
+    int a_delta, b_tap;                                                                           \
+    if (MODE == MODE_DOWN) {                                                                      \
+      a_delta = ((tap_ >> 2) * g.Ws + (tap_ & 3)) * g.Cin;                                        \
+      b_tap = tap_;                                                                               \
+    } else if (MODE == MODE_UP) {                                                                 \
+      int kh, kw, dh, dw;                                                                         \
+      up_tap_dev(ph, tap_ >> 1, kh, dh);                                                          \
+      up_tap_dev(pw, tap_ & 1, kw, dw);                                                           \
+      a_delta = (dh * g.Ws + dw) * g.Cin;                                                         \
+      b_tap = kh * 4 + kw;                                                                        \
+    } else {                                                                                      \
+      a_delta = 0;                                                                                \
+      b_tap = 0;                                                                                  \
+    }                                                                                             \
+    const int ao = a_delta + c0_, bo = b_tap * g.Cin + c0_;                                       \
+    ra0 = ld16_if(a_ptr0 + ao, (a_mask0 >> tap_) & 1u);                                           \
+    ra1 = ld16_if(a_ptr1 + ao, (a_mask1 >> tap_) & 1u);                                           \
+    ra2 = ld16_if(a_ptr2 + ao, (a_mask2 >> tap_) & 1u);                                           \
+    ra3 = ld16_if(a_ptr3 + ao, (a_mask3 >> tap_) & 1u);                                           \
+    rb0 = ld16_if(b_ptr0 + bo, b_ok0);                                                            \
+    rb1 = ld16_if(b_ptr1 + bo, b_ok1);                                                            \
+    rb2 = ld16_if(b_ptr2 + bo, b_ok2);                                                            \
+    rb3 = ld16_if(b_ptr3 + bo, b_ok3);                                                            \
+  } while (0)
+#define RG_STORE_TILE(STAGE)                                                                      \
+  do {                                                                                            \
+    uint4* sa_ = lds + (STAGE) * 2048;                                                            \
+    uint4* sb_ = sa_ + 1024;                                                                      \
+    sa_[lds_chunk_index(r0, chunk)] = ra0;       sb_[lds_chunk_index(r0, chunk)] = rb0;           \
+    sa_[lds_chunk_index(r0 + 32, chunk)] = ra1;  sb_[lds_chunk_index(r0 + 32, chunk)] = rb1;      \
+    sa_[lds_chunk_index(r0 + 64, chunk)] = ra2;  sb_[lds_chunk_index(r0 + 64, chunk)] = rb2;      \
+    sa_[lds_chunk_index(r0 + 96, chunk)] = ra3;  sb_[lds_chunk_index(r0 + 96, chunk)] = rb3;      \
+  } while (0)
+
+  // ---- MFMA assignment
+  const int wave = t >> 6, lane = t & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 31, fh = lane >> 5;
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int tap_n = 0, cc_n = 0;   // coordinates of the NEXT tile to load
+  RG_LOAD_TILE(0, 0);
+  RG_STORE_TILE(0);
+  if (++cc_n == cpt) { cc_n = 0; ++tap_n; }
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const bool more = kt + 1 < nkt;
+    if (more) {
+      RG_LOAD_TILE(tap_n, cc_n << 6);
+      if (++cc_n == cpt) { cc_n = 0; ++tap_n; }
+    }
+    const uint4* sa = lds + cur * 2048;
+    const uint4* sb = sa + 1024;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int ch = 2 * kk + fh;
+      bf16x8_t fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int row = wm * 64 + i * 32 + fr;
+        uint4 v = sa[lds_chunk_index(row, ch)];
+        fa[i] = __builtin_bit_cast(bf16x8_t, v);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int row = wn * 64 + j * 32 + fr;
+        uint4 v = sb[lds_chunk_index(row, ch)];
+        fb[j] = __builtin_bit_cast(bf16x8_t, v);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) RG_STORE_TILE(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+#undef RG_LOAD_TILE
+#undef RG_STORE_TILE
+#undef RG_ROW_SETUP
+
+  // ---- epilogue: accumulators -> LDS (fp32 [128][128]) -> 16-byte row-contiguous global stores
+  float* cs = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        int col = wn * 64 + j * 32 + fr;
+        cs[row * 128 + col] = acc[i][j][r];
+      }
+  __syncthreads();
+  const int cg = t & 15, rr = t >> 4;
+  const int col = bn + cg * 8;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    int row = rr + 16 * p;
+    int m = bm + row;
+    if (m >= g.M || col >= g.Ncols) continue;
+    float4 v0 = *reinterpret_cast<const float4*>(cs + row * 128 + cg * 8);
+    float4 v1 = *reinterpret_cast<const float4*>(cs + row * 128 + cg * 8 + 4);
+    long long orow;
+    if (MODE == MODE_UP) {
+      int wq = m & (Wq - 1), hq = (m >> g.lgW) & (Hq - 1), n = m >> (g.lgW + g.lgH);
+      orow = ((long long)n * (2 * Hq) + 2 * hq + ph) * (2 * Wq) + 2 * wq + pw;
+    } else {
+      orow = m;
+    }
+    if (EPI == EPI_BF16) {
+      uint4 o;
+      o.x = (uint32_t)f32_to_bf16(v0.x) | ((uint32_t)f32_to_bf16(v0.y) << 16);
+      o.y = (uint32_t)f32_to_bf16(v0.z) | ((uint32_t)f32_to_bf16(v0.w) << 16);
+      o.z = (uint32_t)f32_to_bf16(v1.x) | ((uint32_t)f32_to_bf16(v1.y) << 16);
+      o.w = (uint32_t)f32_to_bf16(v1.z) | ((uint32_t)f32_to_bf16(v1.w) << 16);
+      *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(g.C) + orow * g.ldc + col) = o;
+    } else {
+      float vals[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      float* yo = reinterpret_cast<float*>(g.C) + orow * g.ldc + col;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = vals[e];
+        if (g.scale) v *= g.scale[col + e];
+        if (g.shift) v += g.shift[col + e];
+        yo[e] = lrelu_f(v, g.slope);
+      }
+    }
+  }
+}
+
+// ================================================================================================
+// weight gradient
+// ================================================================================================
+struct WArgs {
+  const uint16_t* low;   // [pix][O]
+  const uint16_t* high;  // [N][Hh][Wh][I]
+  float* slab;           // [nsplit][O][16][I]
+  int O, I, K;           // K = N*Ho*Wo pixels
+  int lgWo, lgHo, Hh, Wh;
+  int tiles_c;           // column tiles (over 16*I)
+  int klen;              // pixels per split (multiple of 64)
+};
+
+constexpr int WROW = 160;  // LDS row stride in bf16 elements (128 + 32 pad = 320 B): conflict-free tr reads
+
+__device__ __forceinline__ s16x4_t lds_tr_read(const uint16_t* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WArgs g) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[2 * 2 * 64 * WROW];   // 80 KB
+  const int t = threadIdx.x;
+  const int tile_o = blockIdx.x / g.tiles_c, tile_c = blockIdx.x - tile_o * g.tiles_c;
+  const int o0 = tile_o * 128, c0 = tile_c * 128;
+  const int zs = blockIdx.y;
+  const int k_begin = zs * g.klen;
+  const int k_end = min(g.K, k_begin + g.klen);
+  const int nkt = (k_end - k_begin + 63) >> 6;
+
+  // staging: chunk (8 channels) of pixel rows pr0 + 16*j
+  const int chunk = t & 15, pr0 = t >> 4;
+  const int gc = c0 + chunk * 8;           // global column = tap*I + i
+  const int tap = gc / g.I, ci = gc - tap * g.I;
+  const int kh = tap >> 2, kw = tap & 3;
+  const int Wo = 1 << g.lgWo, Ho = 1 << g.lgHo;
+  uint4 rl0, rl1, rl2, rl3, rh0, rh1, rh2, rh3;
+#define RG_WLOAD_ROW(J, RL, RH, KT)                                                               \
+  do {                                                                                            \
+    int p = k_begin + (KT) * 64 + pr0 + 16 * (J);                                                 \
+    bool ok = p < k_end;                                                                          \
+    int pp = ok ? p : 0;                                                                          \
+    RL = ld16_if(g.low + (long long)pp * g.O + o0 + chunk * 8, ok);                               \
+    int wo = pp & (Wo - 1), ho = (pp >> g.lgWo) & (Ho - 1), n = pp >> (g.lgWo + g.lgHo);          \
+    int hi = 2 * ho - 1 + kh, wi = 2 * wo - 1 + kw;                                               \
+    bool v = ok && (unsigned)hi < (unsigned)g.Hh && (unsigned)wi < (unsigned)g.Wh;                \
+    long long off = (((long long)n * g.Hh + (v ? hi : 0)) * g.Wh + (v ? wi : 0)) * g.I + ci;      \
+    RH = ld16_if(g.high + off, v);                                                                \
+  } while (0)
+#define RG_WLOAD_TILE(KT)                                                                         \
+  do {                                                                                            \
+    RG_WLOAD_ROW(0, rl0, rh0, KT); RG_WLOAD_ROW(1, rl1, rh1, KT);                                 \
+    RG_WLOAD_ROW(2, rl2, rh2, KT); RG_WLOAD_ROW(3, rl3, rh3, KT);                                 \
+  } while (0)
+#define RG_WSTORE_TILE(STAGE)                                                                     \
+  do {                                                                                            \
+    uint16_t* sl_ = lds + (STAGE) * (2 * 64 * WROW);                                              \
+    uint16_t* sh_ = sl_ + 64 * WROW;                                                              \
+    *reinterpret_cast<uint4*>(sl_ + (pr0)*WROW + chunk * 8) = rl0;                                \
+    *reinterpret_cast<uint4*>(sh_ + (pr0)*WROW + chunk * 8) = rh0;                                \
+    *reinterpret_cast<uint4*>(sl_ + (pr0 + 16) * WROW + chunk * 8) = rl1;                         \
+    *reinterpret_cast<uint4*>(sh_ + (pr0 + 16) * WROW + chunk * 8) = rh1;                         \
+    *reinterpret_cast<uint4*>(sl_ + (pr0 + 32) * WROW + chunk * 8) = rl2;                         \
+    *reinterpret_cast<uint4*>(sh_ + (pr0 + 32) * WROW + chunk * 8) = rh2;                         \
+    *reinterpret_cast<uint4*>(sl_ + (pr0 + 48) * WROW + chunk * 8) = rl3;                         \
+    *reinterpret_cast<uint4*>(sh_ + (pr0 + 48) * WROW + chunk * 8) = rh3;                         \
+  } while (0)
+
+  const int wave = t >> 6, lane = t & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int grp = lane >> 4, idx = lane & 15;
+  const int q = idx >> 2, p4 = idx & 3, fh = grp >> 1, cb = grp & 1;
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nkt > 0) {
+    RG_WLOAD_TILE(0);
+    RG_WSTORE_TILE(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const bool more = kt + 1 < nkt;
+    if (more) RG_WLOAD_TILE(kt + 1);
+    const uint16_t* sl = lds + cur * (2 * 64 * WROW);
+    const uint16_t* sh = sl + 64 * WROW;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int prow = ks * 16 + 8 * fh + q;
+      bf16x8_t fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint16_t* p = sl + prow * WROW + wm * 64 + i * 32 + 16 * cb + 4 * p4;
+        s16x4_t lo = lds_tr_read(p);
+        s16x4_t hi = lds_tr_read(p + 4 * WROW);
+        s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        fa[i] = __builtin_bit_cast(bf16x8_t, v);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint16_t* p = sh + prow * WROW + wn * 64 + j * 32 + 16 * cb + 4 * p4;
+        s16x4_t lo = lds_tr_read(p);
+        s16x4_t hi = lds_tr_read(p + 4 * WROW);
+        s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        fb[j] = __builtin_bit_cast(bf16x8_t, v);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) RG_WSTORE_TILE(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+#undef RG_WLOAD_ROW
+#undef RG_WLOAD_TILE
+#undef RG_WSTORE_TILE
+
+  // epilogue: slab[zs][o][col]  (col = tap*I + i), 128-byte row segments per store instruction
+  const int fr = lane & 31, fh2 = lane >> 5;
+  const long long ldw = (long long)16 * g.I;
+  float* slab = g.slab + (long long)zs * g.O * ldw;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int o = o0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh2;
+        int c = c0 + wn * 64 + j * 32 + fr;
+        slab[(long long)o * ldw + c] = acc[i][j][r];
+      }
+}
+
+// ================================================================================================
+// packs
+// ================================================================================================
+// wdn[o][tap][i] = bf16(w[o][i][tap])
+__global__ void pack_wdn_kernel(const float* w, uint16_t* wdn, int O, int I) {
+  size_t n = (size_t)O * I * 16;
+  for (size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += (size_t)gridDim.x * blockDim.x) {
+    size_t i = d % I, ot = d / I;
+    size_t tap = ot & 15, o = ot >> 4;
+    wdn[d] = f32_to_bf16(w[(o * I + i) * 16 + tap]);
+  }
+}
+// generic tiled transpose-pack: src[R][Cc] fp32 -> dst[perm(col)][R] bf16, perm(col) = tap*(Cc/16) + c
+// when permute != 0 (col = c*16 + tap), identity otherwise.
+__global__ __launch_bounds__(256) void transpose_pack_kernel(const float* src, uint16_t* dst, int R, int Cc,
+                                                             int permute) {
+  __shared__ float tile[64][65];
+  int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int rr = ty; rr < 64; rr += 4) {
+    int r = r0 + rr, c = c0 + tx;
+    tile[rr][tx] = (r < R && c < Cc) ? src[(size_t)r * Cc + c] : 0.f;
+  }
+  __syncthreads();
+  for (int cc = ty; cc < 64; cc += 4) {
+    int c = c0 + cc, r = r0 + tx;
+    if (c < Cc && r < R) {
+      int pc = c;
+      if (permute) { int tap = c & 15, ch = c >> 4; pc = tap * (Cc >> 4) + ch; }
+      dst[(size_t)pc * R + r] = f32_to_bf16(tile[tx][cc]);
+    }
+  }
+}
+__global__ void pack_linear_kernel(const float* w, uint16_t* wp, int Nout, int K, int Np, int Kp) {
+  size_t n = (size_t)Np * Kp;
+  for (size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += (size_t)gridDim.x * blockDim.x) {
+    size_t k = d % Kp, j = d / Kp;
+    wp[d] = (j < (size_t)Nout && k < (size_t)K) ? f32_to_bf16(w[j * K + k]) : (uint16_t)0;
+  }
+}
+
+// ================================================================================================
+// hardware layout self-test (exact small-integer data)
+// ================================================================================================
+__global__ void selftest_kernel(int* out) {
+  __shared__ __attribute__((aligned(16))) uint16_t sm[32 * 16 * 2 + 16 * WROW];
+  uint16_t* A = sm;              // A[32][16] row-major (k contiguous)
+  uint16_t* Bt = sm + 32 * 16;   // Bt[32 cols][16] (k contiguous)
+  uint16_t* P = sm + 2 * 32 * 16;  // [16 pixels][WROW] channel-contiguous image for the tr read
+  int lane = threadIdx.x;
+  for (int i = lane; i < 32 * 16; i += 64) {
+    int r = i / 16, k = i % 16;
+    A[i] = f32_to_bf16((float)((r * 3 + k * 5) % 7 - 3));
+    Bt[i] = f32_to_bf16((float)((r * 2 + k * 7 + 1) % 5 - 2));   // asymmetric in (col r, k)
+  }
+  for (int i = lane; i < 16 * 32; i += 64) {
+    int p = i / 32, c = i % 32;
+    P[p * WROW + c] = (uint16_t)(p * 64 + c);
+  }
+  __syncthreads();
+  int fr = lane & 31, fh = lane >> 5;
+  int bad_mfma = 0, bad_tr = 0;
+  // (1) MFMA operand / accumulator maps
+  bf16x8_t fa = *reinterpret_cast<const bf16x8_t*>(A + fr * 16 + fh * 8);
+  bf16x8_t fb = *reinterpret_cast<const bf16x8_t*>(Bt + fr * 16 + fh * 8);
+  f32x16_t acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+  for (int r = 0; r < 16; ++r) {
+    int row = (r & 3) + 8 * (r >> 2) + 4 * fh, col = fr;
+    float ref = 0.f;
+    for (int k = 0; k < 16; ++k) ref += bf16_to_f32(A[row * 16 + k]) * bf16_to_f32(Bt[col * 16 + k]);
+    if (ref != acc[r]) ++bad_mfma;
+  }
+  // (2) transposed LDS read: lane must receive P[8*fh + e][16*cb + idx], e = 0..7
+  int grp = lane >> 4, idx = lane & 15, q = idx >> 2, p4 = idx & 3, h = grp >> 1, cb = grp & 1;
+  const uint16_t* p = P + (8 * h + q) * WROW + 16 * cb + 4 * p4;
+  s16x4_t lo = lds_tr_read(p);
+  s16x4_t hi = lds_tr_read(p + 4 * WROW);
+  for (int e = 0; e < 4; ++e) {
+    int want_lo = (8 * h + e) * 64 + 16 * cb + idx;
+    int want_hi = (8 * h + 4 + e) * 64 + 16 * cb + idx;
+    if ((uint16_t)lo[e] != (uint16_t)want_lo) ++bad_tr;
+    if ((uint16_t)hi[e] != (uint16_t)want_hi) ++bad_tr;
+  }
+  atomicAdd(&out[0], bad_mfma);
+  atomicAdd(&out[1], bad_tr);
+}
+
+inline unsigned grid_cap(size_t n) {
+  size_t b = (n + 255) / 256;
+  if (b > 16384) b = 16384;
+  return (unsigned)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+// ================================================================================================
+// host side
+// ================================================================================================
+bool rg_mfma_conv_supported(int N, int Hq, int Wq, int Kc, int Ncols) {
+  return N > 0 && rg_is_pow2(Hq) && rg_is_pow2(Wq) && Kc % 64 == 0 && Ncols % 8 == 0 && Ncols >= 64;
+}
+bool rg_mfma_plain_supported(int M, int K, int Ncols) { return M > 0 && K % 64 == 0 && Ncols % 8 == 0; }
+
+template <int MODE, int EPI>
+static int launch_gather(const char* name, GArgs& g, int nclass, hipStream_t st) {
+  int tiles_m = (g.M + 127) / 128;
+  g.tiles_n = (g.Ncols + 127) / 128;
+  hipLaunchKernelGGL((gather_gemm_kernel<MODE, EPI>), dim3(tiles_m * g.tiles_n, nclass), dim3(256), 0, st, g);
+  RG_LAUNCH_CHECK(name);
+  return RG_OK;
+}
+
+int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, int Wi, int I, int O, hipStream_t st) {
+  GArgs g{};
+  g.A = (const uint16_t*)x; g.B = (const uint16_t*)wdn; g.C = y;
+  int Ho = Hi / 2, Wo = Wi / 2;
+  g.M = N * Ho * Wo; g.Ncols = O; g.Cin = I; g.taps = 16;
+  g.lgW = rg_ilog2(Wo); g.lgH = rg_ilog2(Ho); g.Hs = Hi; g.Ws = Wi; g.ldc = O; g.Btaps = 16;
+  return launch_gather<MODE_DOWN, EPI_BF16>("conv_down(mfma)", g, 1, st);
+}
+
+int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, hipStream_t st) {
+  GArgs g{};
+  g.A = (const uint16_t*)x; g.B = (const uint16_t*)wup; g.C = y;
+  g.M = N * Ho * Wo; g.Ncols = I; g.Cin = O; g.taps = 4;
+  g.lgW = rg_ilog2(Wo); g.lgH = rg_ilog2(Ho); g.Hs = Ho; g.Ws = Wo; g.ldc = I; g.Btaps = 16;
+  return launch_gather<MODE_UP, EPI_BF16>("conv_up(mfma)", g, 4, st);
+}
+
+int rg_mfma_gemm_plain(const void* a, const void* bt, void* c, int M, int K, int Ncols, int ldc, hipStream_t st) {
+  GArgs g{};
+  g.A = (const uint16_t*)a; g.B = (const uint16_t*)bt; g.C = c;
+  g.M = M; g.Ncols = Ncols; g.Cin = K; g.taps = 1; g.lgW = 0; g.lgH = 0; g.Hs = 1; g.Ws = 1; g.ldc = ldc; g.Btaps = 1;
+  return launch_gather<MODE_PLAIN, EPI_BF16>("gemm_plain(mfma)", g, 1, st);
+}
+
+int rg_mfma_linear(const void* a, const void* bt, const float* scale, const float* shift, float* y, int ldy, int M,
+                   int Kpad, int Nout, float slope, hipStream_t st) {
+  RG_REQUIRE(Kpad % 64 == 0 && Nout % 8 == 0, RG_EUNSUPPORTED, "linear(mfma): K_pad %% 64 and Nout %% 8 required");
+  GArgs g{};
+  g.A = (const uint16_t*)a; g.B = (const uint16_t*)bt; g.C = y;
+  g.M = M; g.Ncols = Nout; g.Cin = Kpad; g.taps = 1; g.lgW = 0; g.lgH = 0; g.Hs = 1; g.Ws = 1; g.ldc = ldy; g.Btaps = 1;
+  g.scale = scale; g.shift = shift; g.slope = slope;
+  return launch_gather<MODE_PLAIN, EPI_LINEAR>("linear(mfma)", g, 1, st);
+}
+
+bool rg_mfma_wgrad_supported(int N, int Ho, int Wo, int O, int I) {
+  return N > 0 && rg_is_pow2(Ho) && rg_is_pow2(Wo) && O % 128 == 0 && I % 64 == 0;
+}
+static int mfma_wgrad_split(int N, int Ho, int Wo, int O, int I) {
+  int tiles = (O / 128) * (16 * I / 128);
+  int K = N * Ho * Wo;
+  int want = (768 + tiles - 1) / tiles;
+  int maxs = K / 256;
+  if (maxs < 1) maxs = 1;
+  int s = want < maxs ? want : maxs;
+  return s < 1 ? 1 : s;
+}
+size_t rg_mfma_wgrad_ws_bytes(int N, int Ho, int Wo, int O, int I) {
+  return (size_t)mfma_wgrad_split(N, Ho, Wo, O, I) * O * I * 16 * sizeof(float);
+}
+int rg_mfma_conv_wgrad(const void* low, const void* high, float* dw, int N, int Ho, int Wo, int O, int I,
+                       int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+  int nsplit = mfma_wgrad_split(N, Ho, Wo, O, I);
+  size_t elems = (size_t)O * I * 16;
+  RG_REQUIRE(ws && ws_bytes >= (size_t)nsplit * elems * sizeof(float), RG_EWORKSPACE,
+             "conv_wgrad(mfma): workspace too small");
+  WArgs g{};
+  g.low = (const uint16_t*)low; g.high = (const uint16_t*)high; g.slab = (float*)ws;
+  g.O = O; g.I = I; g.K = N * Ho * Wo;
+  g.lgWo = rg_ilog2(Wo); g.lgHo = rg_ilog2(Ho); g.Hh = 2 * Ho; g.Wh = 2 * Wo;
+  g.tiles_c = 16 * I / 128;
+  int klen = (g.K + nsplit - 1) / nsplit;
+  g.klen = (klen + 63) / 64 * 64;
+  hipLaunchKernelGGL(wgrad_kernel, dim3((O / 128) * g.tiles_c, nsplit), dim3(256), 0, st, g);
+  RG_LAUNCH_CHECK("conv_wgrad(mfma)");
+  return rg_reduce_slabs((const float*)ws, dw, elems, nsplit, accumulate, 1, I, st);
+}
+
+int rg_mfma_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I, hipStream_t st) {
+  if (wdn) {
+    hipLaunchKernelGGL(pack_wdn_kernel, dim3(grid_cap((size_t)O * I * 16)), dim3(256), 0, st, w, (uint16_t*)wdn, O, I);
+    RG_LAUNCH_CHECK("pack_wdn");
+  }
+  if (wup) {
+    // w viewed as [O][I*16] -> wup[(i*16+tap)][O]
+    hipLaunchKernelGGL(transpose_pack_kernel, dim3((I * 16 + 63) / 64, (O + 63) / 64), dim3(256), 0, st, w,
+                       (uint16_t*)wup, O, I * 16, 0);
+    RG_LAUNCH_CHECK("pack_wup");
+  }
+  return RG_OK;
+}
+int rg_mfma_pack_g0_weight(const float* w, void* wp, int E, int C, hipStream_t st) {
+  // w viewed as [E][C*16] (col = c*16+tap) -> wp[(tap*C + c)][E]
+  hipLaunchKernelGGL(transpose_pack_kernel, dim3((C * 16 + 63) / 64, (E + 63) / 64), dim3(256), 0, st, w,
+                     (uint16_t*)wp, E, C * 16, 1);
+  RG_LAUNCH_CHECK("pack_g0");
+  return RG_OK;
+}
+int rg_mfma_pack_linear_weight(const float* w, void* wp, int Nout, int K, int Np, int Kp, hipStream_t st) {
+  hipLaunchKernelGGL(pack_linear_kernel, dim3(grid_cap((size_t)Np * Kp)), dim3(256), 0, st, w, (uint16_t*)wp, Nout, K,
+                     Np, Kp);
+  RG_LAUNCH_CHECK("pack_linear");
+  return RG_OK;
+}
+
+extern "C" int rg_selftest_layouts(int* detail, void* stream) {
+  RG_REQUIRE(detail, RG_EINVAL, "selftest: detail must point at 2 device ints");
+  hipStream_t st = rg_stream(stream);
+  hipError_t e = hipMemsetAsync(detail, 0, 2 * sizeof(int), st);
+  RG_REQUIRE(e == hipSuccess, RG_EHIP, "selftest: memset failed");
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, st, detail);
+  RG_LAUNCH_CHECK("selftest");
+  return RG_OK;
+}

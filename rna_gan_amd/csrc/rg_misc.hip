@@ -1,0 +1,351 @@
+// rg_misc.hip -- image-side pointwise ops, scalar reductions, discriminator head, latent prep,
+// Adam.  All HBM-bound streaming kernels: 16-byte accesses, grid-stride, deterministic two-stage sums.
+#include "rg_common.h"
+
+namespace {
+
+constexpr int RED_BLOCKS = 1024;
+
+inline unsigned grid_for(size_t n, int per_thread = 1) {
+  size_t b = (n + (size_t)256 * per_thread - 1) / ((size_t)256 * per_thread);
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+// ---------------------------------------------------------------------------------- pointwise fp32
+template <class F>
+__global__ __launch_bounds__(256) void ew4_kernel(F f, size_t n) {
+  size_t n4 = n / 4;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) f.vec(i * 4);
+  // tail
+  size_t t = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) f.one(t);
+}
+
+struct TanhBwd {
+  const float* gy; const float* y; float* gz;
+  __device__ void vec(size_t i) const {
+    float4 g = *(const float4*)(gy + i), v = *(const float4*)(y + i);
+    *(float4*)(gz + i) = make_float4(g.x * (1.f - v.x * v.x), g.y * (1.f - v.y * v.y), g.z * (1.f - v.z * v.z),
+                                     g.w * (1.f - v.w * v.w));
+  }
+  __device__ void one(size_t i) const { gz[i] = gy[i] * (1.f - y[i] * y[i]); }
+};
+struct Interp {
+  const float* r; const float* f; float* o; float eps;
+  __device__ void vec(size_t i) const {
+    float4 a = *(const float4*)(r + i), b = *(const float4*)(f + i);
+    float e = eps, e1 = 1.f - eps;
+    *(float4*)(o + i) = make_float4(e * a.x + e1 * b.x, e * a.y + e1 * b.y, e * a.z + e1 * b.z, e * a.w + e1 * b.w);
+  }
+  __device__ void one(size_t i) const { o[i] = eps * r[i] + (1.f - eps) * f[i]; }
+};
+struct ScaleBy {
+  const float* x; const float* coef; float* o;
+  __device__ void vec(size_t i) const {
+    float c = coef[0];
+    float4 a = *(const float4*)(x + i);
+    *(float4*)(o + i) = make_float4(a.x * c, a.y * c, a.z * c, a.w * c);
+  }
+  __device__ void one(size_t i) const { o[i] = x[i] * coef[0]; }
+};
+struct Clamp {
+  float* p; float lo, hi;
+  __device__ void vec(size_t i) const {
+    float4 a = *(float4*)(p + i);
+    *(float4*)(p + i) = make_float4(fminf(fmaxf(a.x, lo), hi), fminf(fmaxf(a.y, lo), hi), fminf(fmaxf(a.z, lo), hi),
+                                    fminf(fmaxf(a.w, lo), hi));
+  }
+  __device__ void one(size_t i) const { p[i] = fminf(fmaxf(p[i], lo), hi); }
+};
+struct Adam {
+  float* p; const float* g; float* m; float* v; float b1, b2, eps, step_size, inv_sqrt_bc2;
+  __device__ __forceinline__ void upd(float& pp, float gg, float& mm, float& vv) const {
+    // torch.optim.Adam (single-tensor path): m = b1*m + (1-b1)g ; v = b2*v + (1-b2)g^2 ;
+    // denom = sqrt(v)/sqrt(bc2) + eps ; p -= (lr/bc1) * m/denom
+    mm = b1 * mm + (1.f - b1) * gg;
+    vv = b2 * vv + (1.f - b2) * gg * gg;
+    float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+    pp -= step_size * (mm / denom);
+  }
+  __device__ void vec(size_t i) const {
+    float4 P = *(float4*)(p + i), G = *(const float4*)(g + i), M = *(float4*)(m + i), V = *(float4*)(v + i);
+    upd(P.x, G.x, M.x, V.x); upd(P.y, G.y, M.y, V.y); upd(P.z, G.z, M.z, V.z); upd(P.w, G.w, M.w, V.w);
+    *(float4*)(p + i) = P; *(float4*)(m + i) = M; *(float4*)(v + i) = V;
+  }
+  __device__ void one(size_t i) const { upd(p[i], g[i], m[i], v[i]); }
+};
+
+// ---------------------------------------------------------------------------------- reductions
+// stage 1: each block writes one partial (double accumulation across a thread's strided elements is
+// avoided: fp32 per-thread sums over <= n/(blocks*256) items, then tree) ; stage 2: one block.
+template <class F>
+__global__ __launch_bounds__(256) void reduce1_kernel(F f, size_t n, float* partial) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += f(i);
+  float t = block_sum_256(s, sm);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+template <class Fin>
+__global__ __launch_bounds__(256) void reduce2_kernel(Fin fin, const float* partial, int nb) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
+  float t = block_sum_256(s, sm);
+  if (threadIdx.x == 0) fin(t);
+}
+struct SqF {
+  const float* x;
+  __device__ float operator()(size_t i) const { float v = x[i]; return v * v; }
+};
+struct StoreFin {
+  float* out;
+  __device__ void operator()(float t) const { out[0] = t; }
+};
+
+// out[c] (+)= sum over n,hw of g[n][c][hw]: one block-row per (c, chunk)
+__global__ __launch_bounds__(256) void nchw_chan_partial_kernel(const float* g, float* partial, int N, int C, int HW,
+                                                                int chunks) {
+  __shared__ float sm[4];
+  int c = blockIdx.x, ch = blockIdx.y;
+  size_t per = ((size_t)N * HW + chunks - 1) / chunks;
+  size_t b = (size_t)ch * per, e = b + per;
+  size_t tot = (size_t)N * HW;
+  if (e > tot) e = tot;
+  float s = 0.f;
+  for (size_t i = b + threadIdx.x; i < e; i += 256) {
+    size_t n = i / HW, hw = i - n * HW;
+    s += g[(n * C + c) * (size_t)HW + hw];
+  }
+  float t = block_sum_256(s, sm);
+  if (threadIdx.x == 0) partial[(size_t)c * chunks + ch] = t;
+}
+__global__ void nchw_chan_final_kernel(const float* partial, float* out, int C, int chunks, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int i = 0; i < chunks; ++i) s += partial[(size_t)c * chunks + i];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+__global__ void gp_coef_kernel(const float* sq, float* loss, float* coef, float lambd) {
+  float nrm = sqrtf(sq[0]);
+  loss[0] = (nrm - 1.f) * (nrm - 1.f);
+  coef[0] = lambd * 2.f * (nrm - 1.f) / nrm;
+}
+
+__global__ __launch_bounds__(256) void mean_diff_kernel(const float* a, const float* b, float* out, int n, float sign) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += b ? (a[i] - b[i]) : a[i];
+  float t = block_sum_256(s, sm);
+  if (threadIdx.x == 0) out[0] = sign * t / (float)n;
+}
+
+// latent prep: per column e: v = u+z ; mean, unbiased std over the N rows ; out = (v-mean)/std
+__global__ void latent_prep_kernel(const float* u, const float* z, float* out, int N, int E) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += u[(size_t)n * E + e] + z[(size_t)n * E + e];
+  float mu = s / (float)N;
+  float ss = 0.f;
+  for (int n = 0; n < N; ++n) {
+    float d = u[(size_t)n * E + e] + z[(size_t)n * E + e] - mu;
+    ss += d * d;
+  }
+  float sd = sqrtf(ss / (float)(N - 1));   // N == 1 -> NaN, as torch.std does
+  for (int n = 0; n < N; ++n) out[(size_t)n * E + e] = (u[(size_t)n * E + e] + z[(size_t)n * E + e] - mu) / sd;
+}
+
+// ---------------------------------------------------------------------------------- head
+// h[n] = sum_j a[n][j] * wq[j], j = tap*C + c, wq[j] = round_T(w[c*16 + tap])
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* a, const float* w, float* h, float* out, int C,
+                                                       float slope) {
+  __shared__ float sm[4];
+  int n = blockIdx.x;
+  int J = 16 * C;
+  float s = 0.f;
+  for (int j = threadIdx.x; j < J; j += 256) {
+    int tap = j / C, c = j - tap * C;
+    s += Elem<T>::ld(a + (size_t)n * J + j) * Elem<T>::round(w[c * 16 + tap]);
+  }
+  float t = block_sum_256(s, sm);
+  if (threadIdx.x == 0) { h[n] = t; out[n] = lrelu_f(t, slope); }
+}
+__global__ void head_grad_kernel(const float* h, float* gh, int N, float coef, float slope) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < N) gh[n] = coef * lrelu_mask(h[n], slope);
+}
+template <typename T>
+__global__ void head_bwd_data_kernel(const float* gh, const float* w, T* ga, int N, int C) {
+  size_t J = (size_t)16 * C, tot = (size_t)N * J;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+    size_t n = i / J;
+    int j = (int)(i - n * J);
+    int tap = j / C, c = j - tap * C;
+    Elem<T>::st(ga + i, gh[n] * Elem<T>::round(w[c * 16 + tap]));
+  }
+}
+template <typename T>
+__global__ void head_wgrad_kernel(const float* gh, const T* a, float* dw, int N, int C, int accumulate) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int J = 16 * C;
+  if (j >= J) return;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += gh[n] * Elem<T>::ld(a + (size_t)n * J + j);
+  int tap = j / C, c = j - tap * C;
+  float* d = dw + c * 16 + tap;
+  *d = accumulate ? *d + s : s;
+}
+
+template <typename T>
+__global__ void cast_pad_kernel(const float* src, T* dst, int M, int K, int ldd) {
+  size_t tot = (size_t)M * ldd;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+    size_t m = i / ldd;
+    int k = (int)(i - m * ldd);
+    Elem<T>::st(dst + i, k < K ? src[m * K + k] : 0.f);
+  }
+}
+
+}  // namespace
+
+#define EW_LAUNCH(name, functor, n, st)                                                        \
+  do {                                                                                         \
+    if ((n) == 0) return RG_OK;                                                                \
+    hipLaunchKernelGGL((ew4_kernel<decltype(functor)>), dim3(grid_for((n), 4)), dim3(256), 0, st, functor, n); \
+    RG_LAUNCH_CHECK(name);                                                                     \
+    return RG_OK;                                                                              \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" int rg_tanh_bwd(const float* gy, const float* y, float* gz, size_t n, void* stream) {
+  RG_REQUIRE(gy && y && gz && aligned16(gy) && aligned16(y) && aligned16(gz), RG_EINVAL, "tanh_bwd: bad args");
+  TanhBwd f{gy, y, gz};
+  EW_LAUNCH("tanh_bwd", f, n, rg_stream(stream));
+}
+extern "C" int rg_interp(const float* real, const float* fake, float* out, size_t n, float eps, void* stream) {
+  RG_REQUIRE(real && fake && out && aligned16(real) && aligned16(fake) && aligned16(out), RG_EINVAL, "interp: bad args");
+  Interp f{real, fake, out, eps};
+  EW_LAUNCH("interp", f, n, rg_stream(stream));
+}
+extern "C" int rg_scale_by(const float* x, const float* coef, float* out, size_t n, void* stream) {
+  RG_REQUIRE(x && coef && out && aligned16(x) && aligned16(out), RG_EINVAL, "scale_by: bad args");
+  ScaleBy f{x, coef, out};
+  EW_LAUNCH("scale_by", f, n, rg_stream(stream));
+}
+extern "C" int rg_clamp(float* p, size_t n, float lo, float hi, void* stream) {
+  RG_REQUIRE(p && aligned16(p), RG_EINVAL, "clamp: bad args");
+  Clamp f{p, lo, hi};
+  EW_LAUNCH("clamp", f, n, rg_stream(stream));
+}
+extern "C" int rg_adam_step(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float beta1,
+                            float beta2, float eps, void* stream) {
+  RG_REQUIRE(p && g && m && v && step >= 1, RG_EINVAL, "adam_step: bad args");
+  RG_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), RG_EINVAL, "adam_step: 16-byte alignment");
+  double bc1 = 1.0 - pow((double)beta1, (double)step);
+  double bc2 = 1.0 - pow((double)beta2, (double)step);
+  Adam f{p, g, m, v, beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2))};
+  EW_LAUNCH("adam_step", f, n, rg_stream(stream));
+}
+
+extern "C" size_t rg_reduce_workspace_bytes(size_t n) { (void)n; return RED_BLOCKS * sizeof(float); }
+
+extern "C" int rg_sqnorm(const float* x, float* out, size_t n, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(x && out, RG_EINVAL, "sqnorm: bad args");
+  RG_REQUIRE(ws && ws_bytes >= RED_BLOCKS * sizeof(float), RG_EWORKSPACE, "sqnorm: workspace too small");
+  hipStream_t st = rg_stream(stream);
+  int nb = (int)((n + 255) / 256);
+  if (nb > RED_BLOCKS) nb = RED_BLOCKS;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL((reduce1_kernel<SqF>), dim3(nb), dim3(256), 0, st, SqF{x}, n, (float*)ws);
+  RG_LAUNCH_CHECK("sqnorm");
+  hipLaunchKernelGGL((reduce2_kernel<StoreFin>), dim3(1), dim3(256), 0, st, StoreFin{out}, (const float*)ws, nb);
+  RG_LAUNCH_CHECK("sqnorm");
+  return RG_OK;
+}
+
+extern "C" int rg_nchw_chan_sum(const float* g, float* out, int N, int C, int HW, int accumulate, void* ws,
+                                size_t ws_bytes, void* stream) {
+  RG_REQUIRE(g && out && N > 0 && C > 0 && HW > 0, RG_EINVAL, "nchw_chan_sum: bad args");
+  int chunks = 256;
+  RG_REQUIRE(ws && ws_bytes >= (size_t)C * chunks * sizeof(float), RG_EWORKSPACE, "nchw_chan_sum: workspace too small");
+  hipStream_t st = rg_stream(stream);
+  hipLaunchKernelGGL(nchw_chan_partial_kernel, dim3(C, chunks), dim3(256), 0, st, g, (float*)ws, N, C, HW, chunks);
+  RG_LAUNCH_CHECK("nchw_chan_sum");
+  hipLaunchKernelGGL(nchw_chan_final_kernel, dim3((C + 63) / 64), dim3(64), 0, st, (const float*)ws, out, C, chunks,
+                     accumulate);
+  RG_LAUNCH_CHECK("nchw_chan_sum");
+  return RG_OK;
+}
+
+extern "C" int rg_gp_coef(const float* sq, float* loss, float* coef, float lambd, void* stream) {
+  RG_REQUIRE(sq && loss && coef, RG_EINVAL, "gp_coef: bad args");
+  hipLaunchKernelGGL(gp_coef_kernel, dim3(1), dim3(1), 0, rg_stream(stream), sq, loss, coef, lambd);
+  RG_LAUNCH_CHECK("gp_coef");
+  return RG_OK;
+}
+extern "C" int rg_mean_diff(const float* a, const float* b, float* out, int n, float sign, void* stream) {
+  RG_REQUIRE(a && out && n > 0, RG_EINVAL, "mean_diff: bad args");
+  hipLaunchKernelGGL(mean_diff_kernel, dim3(1), dim3(256), 0, rg_stream(stream), a, b, out, n, sign);
+  RG_LAUNCH_CHECK("mean_diff");
+  return RG_OK;
+}
+extern "C" int rg_latent_prep(const float* u, const float* z, float* out, int N, int E, void* stream) {
+  RG_REQUIRE(u && z && out && N > 0 && E > 0, RG_EINVAL, "latent_prep: bad args");
+  hipLaunchKernelGGL(latent_prep_kernel, dim3((E + 63) / 64), dim3(64), 0, rg_stream(stream), u, z, out, N, E);
+  RG_LAUNCH_CHECK("latent_prep");
+  return RG_OK;
+}
+
+extern "C" int rg_head_fwd(const void* a, const float* w, float* h, float* out, int N, int C, float slope, int dtype,
+                           void* stream) {
+  RG_REQUIRE(a && w && h && out && N > 0 && C > 0, RG_EINVAL, "head_fwd: bad args");
+  RG_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((head_fwd_kernel<T>), dim3(N), dim3(256), 0, rg_stream(stream), (const T*)a, w, h, out, C, slope);
+    RG_LAUNCH_CHECK("head_fwd");
+    return RG_OK;
+  })
+}
+extern "C" int rg_head_grad(const float* h, float* gh, int N, float coef, float slope, void* stream) {
+  RG_REQUIRE(h && gh && N > 0, RG_EINVAL, "head_grad: bad args");
+  hipLaunchKernelGGL(head_grad_kernel, dim3((N + 255) / 256), dim3(256), 0, rg_stream(stream), h, gh, N, coef, slope);
+  RG_LAUNCH_CHECK("head_grad");
+  return RG_OK;
+}
+extern "C" int rg_head_bwd_data(const float* gh, const float* w, void* ga, int N, int C, int dtype, void* stream) {
+  RG_REQUIRE(gh && w && ga && N > 0 && C > 0, RG_EINVAL, "head_bwd_data: bad args");
+  RG_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((head_bwd_data_kernel<T>), dim3(grid_for((size_t)N * 16 * C)), dim3(256), 0, rg_stream(stream),
+                       gh, w, (T*)ga, N, C);
+    RG_LAUNCH_CHECK("head_bwd_data");
+    return RG_OK;
+  })
+}
+extern "C" int rg_head_wgrad(const float* gh, const void* a, float* dw, int N, int C, int dtype, int accumulate,
+                             void* stream) {
+  RG_REQUIRE(gh && a && dw && N > 0 && C > 0, RG_EINVAL, "head_wgrad: bad args");
+  RG_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((head_wgrad_kernel<T>), dim3((16 * C + 255) / 256), dim3(256), 0, rg_stream(stream), gh,
+                       (const T*)a, dw, N, C, accumulate);
+    RG_LAUNCH_CHECK("head_wgrad");
+    return RG_OK;
+  })
+}
+
+extern "C" int rg_cast_pad(const float* src, void* dst, int M, int K, int ldd, int dtype, void* stream) {
+  RG_REQUIRE(src && dst && M > 0 && K > 0 && ldd >= K, RG_EINVAL, "cast_pad: bad args");
+  RG_DISPATCH_DTYPE(dtype, T, {
+    hipLaunchKernelGGL((cast_pad_kernel<T>), dim3(grid_for((size_t)M * ldd)), dim3(256), 0, rg_stream(stream), src,
+                       (T*)dst, M, K, ldd);
+    RG_LAUNCH_CHECK("cast_pad");
+    return RG_OK;
+  })
+}

@@ -1,0 +1,325 @@
+"""HipOps: the product op backend -- thin tensor->pointer marshalling onto the C ABI
+(include/rnagan_hip.h).  PyTorch is used for device memory (caching allocator) and the stream
+only; every arithmetic op below is one or two hand-written HIP kernels.  No fallback paths.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _abi
+from ._abi import RG_BF16, RG_F32, check
+from .engine import ConvW
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class HipOps:
+    name = "hip"
+
+    def __init__(self, act_dtype=torch.bfloat16, device="cuda:0", algo=_abi.ALGO_AUTO):
+        if not torch.cuda.is_available():
+            raise RuntimeError("rna_gan_amd.HipOps needs a ROCm GPU (no CPU fallback exists)")
+        self.lib = _abi.load()
+        self.device = torch.device(device)
+        if act_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("act_dtype must be torch.float32 or torch.bfloat16")
+        self.act_dtype = act_dtype
+        self.dt = RG_F32 if act_dtype == torch.float32 else RG_BF16
+        self.algo = algo
+        self._wsbuf = None
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _ws(self, nbytes: int):
+        nbytes = max(int(nbytes), 256)
+        if self._wsbuf is None or self._wsbuf.numel() < nbytes:
+            self._wsbuf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
+        return self._wsbuf
+
+    def _act(self, *shape):
+        return torch.empty(shape, dtype=self.act_dtype, device=self.device)
+
+    def _f32(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    def _packs(self, cw: ConvW):
+        if self.dt != RG_BF16:
+            return None, None
+        if cw.packs is None or cw.packs_version != cw.version:
+            O, I = cw.w.shape[0], cw.w.shape[1]
+            if cw.packs is None:
+                cw.packs = (torch.empty((O, 16, I), dtype=torch.bfloat16, device=self.device),
+                            torch.empty((I, 16, O), dtype=torch.bfloat16, device=self.device))
+            check(self.lib.rg_pack_conv_weight(_ptr(cw.w), _ptr(cw.packs[0]), _ptr(cw.packs[1]), O, I, RG_BF16,
+                                               self.stream), "rg_pack_conv_weight")
+            cw.packs_version = cw.version
+        return cw.packs
+
+    # ------------------------------------------------------------------ conv family
+    def conv_down(self, x, cw: ConvW):
+        N, Hi, Wi, I = x.shape
+        O = cw.w.shape[0]
+        assert cw.w.shape[1] == I and x.is_contiguous()
+        wdn, _ = self._packs(cw)
+        y = self._act(N, Hi // 2, Wi // 2, O)
+        check(self.lib.rg_conv_down(_ptr(x), _ptr(cw.w), _ptr(wdn), _ptr(y), N, Hi, Wi, I, O, self.dt, self.algo,
+                                    self.stream), "rg_conv_down")
+        return y
+
+    def conv_up(self, x, cw: ConvW):
+        N, Ho, Wo, O = x.shape
+        I = cw.w.shape[1]
+        assert cw.w.shape[0] == O and x.is_contiguous()
+        _, wup = self._packs(cw)
+        y = self._act(N, 2 * Ho, 2 * Wo, I)
+        check(self.lib.rg_conv_up(_ptr(x), _ptr(cw.w), _ptr(wup), _ptr(y), N, Ho, Wo, O, I, self.dt, self.algo,
+                                  self.stream), "rg_conv_up")
+        return y
+
+    def conv_wgrad(self, low, high, dw, accumulate: bool):
+        N, Ho, Wo, O = low.shape
+        I = high.shape[3]
+        assert high.shape[1] == 2 * Ho and tuple(dw.shape) == (O, I, 4, 4) and dw.is_contiguous()
+        nb = self.lib.rg_conv_wgrad_workspace_bytes(N, Ho, Wo, O, I, self.dt, self.algo)
+        ws = self._ws(nb)
+        check(self.lib.rg_conv_wgrad(_ptr(low), _ptr(high), _ptr(dw), N, Ho, Wo, O, I, self.dt, int(accumulate),
+                                     self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_wgrad")
+
+    def first_down(self, x_nchw, cw: ConvW, bias, slope: float):
+        N, I, H, W = x_nchw.shape
+        O = cw.w.shape[0]
+        assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and cw.w.shape[1] == I
+        y = self._act(N, H // 2, W // 2, O)
+        check(self.lib.rg_first_down(_ptr(x_nchw), _ptr(cw.w), _ptr(bias), _ptr(y), N, H, W, I, O, float(slope),
+                                     self.dt, self.stream), "rg_first_down")
+        return y
+
+    def last_up(self, x, cw: ConvW, bias, tanh: bool):
+        N, Ho, Wo, O = x.shape
+        I = cw.w.shape[1]
+        assert cw.w.shape[0] == O and x.is_contiguous()
+        y = self._f32(N, I, 2 * Ho, 2 * Wo)
+        check(self.lib.rg_last_up(_ptr(x), _ptr(cw.w), _ptr(bias), _ptr(y), N, Ho, Wo, O, I, int(tanh), self.dt,
+                                  self.stream), "rg_last_up")
+        return y
+
+    def skinny_wgrad(self, low, high_nchw, dw, accumulate: bool):
+        N, Ho, Wo, O = low.shape
+        I = high_nchw.shape[1]
+        assert high_nchw.dtype == torch.float32 and high_nchw.is_contiguous() and low.is_contiguous()
+        nb = self.lib.rg_skinny_wgrad_workspace_bytes(N, Ho, Wo, O, I)
+        ws = self._ws(nb)
+        check(self.lib.rg_skinny_wgrad(_ptr(low), _ptr(high_nchw), _ptr(dw), N, Ho, Wo, O, I, self.dt,
+                                       int(accumulate), _ptr(ws), ws.numel(), self.stream), "rg_skinny_wgrad")
+
+    # ------------------------------------------------------------------ G.0 / head
+    def g0_fwd(self, z, cw: ConvW):
+        N, E = z.shape
+        C = cw.w.shape[1]
+        assert z.dtype == torch.float32 and z.is_contiguous() and cw.w.shape[0] == E
+        wp = None
+        if self.dt == RG_BF16:
+            if cw.packs is None or cw.packs_version != cw.version:
+                if cw.packs is None:
+                    cw.packs = (torch.empty((16 * C, E), dtype=torch.bfloat16, device=self.device),)
+                check(self.lib.rg_pack_g0_weight(_ptr(cw.w), _ptr(cw.packs[0]), E, C, RG_BF16, self.stream),
+                      "rg_pack_g0_weight")
+                cw.packs_version = cw.version
+            wp = cw.packs[0]
+        y = self._act(N, 4, 4, C)
+        ws = self._ws(self.lib.rg_g0_workspace_bytes(N, E, C, self.dt, self.algo))
+        check(self.lib.rg_g0_fwd(_ptr(z), _ptr(cw.w), _ptr(wp), _ptr(y), N, E, C, self.dt, self.algo, _ptr(ws),
+                                 ws.numel(), self.stream), "rg_g0_fwd")
+        return y
+
+    def g0_wgrad(self, z, gy, dw, accumulate: bool):
+        N, E = z.shape
+        C = gy.shape[3]
+        ws = self._ws(self.lib.rg_g0_workspace_bytes(N, E, C, self.dt, self.algo))
+        check(self.lib.rg_g0_wgrad(_ptr(z), _ptr(gy), _ptr(dw), N, E, C, self.dt, int(accumulate), self.algo,
+                                   _ptr(ws), ws.numel(), self.stream), "rg_g0_wgrad")
+
+    def head_fwd(self, a, cw: ConvW, slope: float):
+        N, C = a.shape[0], a.shape[3]
+        assert a.shape[1] == 4 and a.shape[2] == 4 and a.is_contiguous()
+        h, out = self._f32(N), self._f32(N)
+        check(self.lib.rg_head_fwd(_ptr(a), _ptr(cw.w), _ptr(h), _ptr(out), N, C, float(slope), self.dt,
+                                   self.stream), "rg_head_fwd")
+        return h, out
+
+    def head_grad(self, h, coef: float, slope: float):
+        gh = torch.empty_like(h)
+        check(self.lib.rg_head_grad(_ptr(h), _ptr(gh), h.numel(), float(coef), float(slope), self.stream),
+              "rg_head_grad")
+        return gh
+
+    def head_bwd_data(self, gh, cw: ConvW):
+        N, C = gh.numel(), cw.w.shape[1]
+        ga = self._act(N, 4, 4, C)
+        check(self.lib.rg_head_bwd_data(_ptr(gh), _ptr(cw.w), _ptr(ga), N, C, self.dt, self.stream),
+              "rg_head_bwd_data")
+        return ga
+
+    def head_wgrad(self, gh, a, dw, accumulate: bool):
+        N, C = a.shape[0], a.shape[3]
+        check(self.lib.rg_head_wgrad(_ptr(gh), _ptr(a), _ptr(dw), N, C, self.dt, int(accumulate), self.stream),
+              "rg_head_wgrad")
+
+    # ------------------------------------------------------------------ batch norm
+    def _mc(self, z):
+        C = z.shape[-1]
+        return z.numel() // C, C
+
+    def bn_stats(self, z):
+        M, C = self._mc(z)
+        s, ss = self._f32(C), self._f32(C)
+        ws = self._ws(self.lib.rg_colreduce_workspace_bytes(M, C, 2))
+        check(self.lib.rg_bn_stats(_ptr(z), _ptr(s), _ptr(ss), M, C, self.dt, _ptr(ws), ws.numel(), self.stream),
+              "rg_bn_stats")
+        return s, ss
+
+    def bn_finalize(self, s, ss, count: int, eps: float, momentum: float,
+                    running_mean=None, running_var=None, nbt=None):
+        C = s.numel()
+        mean, invstd = self._f32(C), self._f32(C)
+        check(self.lib.rg_bn_finalize(_ptr(s), _ptr(ss), int(count), C, float(eps), float(momentum), _ptr(mean),
+                                      _ptr(invstd), _ptr(running_mean), _ptr(running_var), _ptr(nbt), self.stream),
+              "rg_bn_finalize")
+        return mean, invstd
+
+    def bn_act(self, z, mean, invstd, gamma, beta, slope: float):
+        M, C = self._mc(z)
+        a = torch.empty_like(z)
+        check(self.lib.rg_bn_act(_ptr(z), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(a), M, C,
+                                 float(slope), self.dt, self.stream), "rg_bn_act")
+        return a
+
+    def bn_act_bwd(self, z, ga, mean, invstd, gamma, beta, slope: float, dgamma=None, dbeta=None,
+                   accumulate: bool = False):
+        M, C = self._mc(z)
+        gz = torch.empty_like(z)
+        s_gy, s_gyxh = self._f32(C), self._f32(C)
+        ws = self._ws(self.lib.rg_colreduce_workspace_bytes(M, C, 2))
+        check(self.lib.rg_bn_act_bwd(_ptr(z), _ptr(ga), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(gz),
+                                     _ptr(s_gy), _ptr(s_gyxh), _ptr(dgamma), _ptr(dbeta), int(accumulate), M, C,
+                                     float(slope), self.dt, _ptr(ws), ws.numel(), self.stream), "rg_bn_act_bwd")
+        return gz, s_gy, s_gyxh
+
+    def bn_tangent(self, z, zt, mean, invstd, gamma, beta, slope: float):
+        M, C = self._mc(z)
+        at = torch.empty_like(z)
+        s_zt, s_xhzt = self._f32(C), self._f32(C)
+        ws = self._ws(self.lib.rg_colreduce_workspace_bytes(M, C, 2))
+        check(self.lib.rg_bn_tangent(_ptr(z), _ptr(zt), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(at),
+                                     _ptr(s_zt), _ptr(s_xhzt), M, C, float(slope), self.dt, _ptr(ws), ws.numel(),
+                                     self.stream), "rg_bn_tangent")
+        return at, s_zt, s_xhzt
+
+    def bn_double_bwd(self, z, qa, zt, ga1, mean, invstd, gamma, beta, slope: float, s_gy, s_gyxh, s_zt, s_xhzt,
+                      dgamma, dbeta, accumulate: bool):
+        M, C = self._mc(z)
+        pz = torch.empty_like(z)
+        ws = self._ws(self.lib.rg_colreduce_workspace_bytes(M, C, 3))
+        check(self.lib.rg_bn_double_bwd(_ptr(z), _ptr(qa), _ptr(zt), _ptr(ga1), _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                        _ptr(beta), _ptr(s_gy), _ptr(s_gyxh), _ptr(s_zt), _ptr(s_xhzt), _ptr(pz),
+                                        _ptr(dgamma), _ptr(dbeta), int(accumulate), M, C, float(slope), self.dt,
+                                        _ptr(ws), ws.numel(), self.stream), "rg_bn_double_bwd")
+        return pz
+
+    # ------------------------------------------------------------------ pointwise / reductions
+    def lrelu_bwd(self, g, a, slope: float):
+        out = torch.empty_like(a)
+        check(self.lib.rg_lrelu_bwd(_ptr(g), _ptr(a), _ptr(out), a.numel(), float(slope), self.dt, self.stream),
+              "rg_lrelu_bwd")
+        return out
+
+    def col_sum(self, g, out, accumulate: bool):
+        M, C = self._mc(g)
+        ws = self._ws(self.lib.rg_colreduce_workspace_bytes(M, C, 1))
+        check(self.lib.rg_col_sum(_ptr(g), _ptr(out), M, C, self.dt, int(accumulate), _ptr(ws), ws.numel(),
+                                  self.stream), "rg_col_sum")
+
+    def tanh_bwd(self, gy_nchw, y_nchw):
+        gz = torch.empty_like(y_nchw)
+        check(self.lib.rg_tanh_bwd(_ptr(gy_nchw), _ptr(y_nchw), _ptr(gz), y_nchw.numel(), self.stream), "rg_tanh_bwd")
+        return gz
+
+    def nchw_chan_sum(self, g_nchw, out, accumulate: bool):
+        N, C, H, W = g_nchw.shape
+        ws = self._ws(C * 256 * 4)
+        check(self.lib.rg_nchw_chan_sum(_ptr(g_nchw), _ptr(out), N, C, H * W, int(accumulate), _ptr(ws), ws.numel(),
+                                        self.stream), "rg_nchw_chan_sum")
+
+    def interp(self, real, fake, eps: float):
+        assert real.dtype == torch.float32 and real.is_contiguous() and fake.is_contiguous()
+        out = torch.empty_like(real)
+        check(self.lib.rg_interp(_ptr(real), _ptr(fake), _ptr(out), real.numel(), float(eps), self.stream),
+              "rg_interp")
+        return out
+
+    def sqnorm(self, x):
+        out = self._f32(1)
+        ws = self._ws(self.lib.rg_reduce_workspace_bytes(x.numel()))
+        check(self.lib.rg_sqnorm(_ptr(x), _ptr(out), x.numel(), _ptr(ws), ws.numel(), self.stream), "rg_sqnorm")
+        return out
+
+    def gp_coef(self, sq, lambd: float):
+        loss, coef = self._f32(1), self._f32(1)
+        check(self.lib.rg_gp_coef(_ptr(sq), _ptr(loss), _ptr(coef), float(lambd), self.stream), "rg_gp_coef")
+        return loss, coef
+
+    def scale_by(self, x, coef_dev):
+        out = torch.empty_like(x)
+        check(self.lib.rg_scale_by(_ptr(x), _ptr(coef_dev), _ptr(out), x.numel(), self.stream), "rg_scale_by")
+        return out
+
+    def mean_diff(self, a, b=None, sign: float = 1.0):
+        out = self._f32(1)
+        check(self.lib.rg_mean_diff(_ptr(a), _ptr(b), _ptr(out), a.numel(), float(sign), self.stream), "rg_mean_diff")
+        return out
+
+    def latent_prep(self, u, z):
+        N, E = u.shape
+        out = torch.empty_like(u)
+        check(self.lib.rg_latent_prep(_ptr(u), _ptr(z), _ptr(out), N, E, self.stream), "rg_latent_prep")
+        return out
+
+    # ------------------------------------------------------------------ optimizer
+    def adam_step(self, p, g, m, v, step: int, lr: float, b1: float, b2: float, eps: float):
+        check(self.lib.rg_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(step), float(lr), float(b1),
+                                    float(b2), float(eps), self.stream), "rg_adam_step")
+
+    def clamp_(self, p, lo: float, hi: float):
+        check(self.lib.rg_clamp(_ptr(p), p.numel(), float(lo), float(hi), self.stream), "rg_clamp")
+
+    # ------------------------------------------------------------------ dense (betaVAE encoder)
+    def linear_affine_act(self, x, w, scale, shift, slope: float, wp=None):
+        M, K = x.shape
+        Nout = w.shape[0]
+        assert x.dtype == torch.float32 and x.is_contiguous()
+        y = self._f32(M, Nout)
+        algo = self.algo if wp is not None else _abi.ALGO_GENERIC
+        ws = self._ws(self.lib.rg_linear_workspace_bytes(M, K, Nout, algo))
+        check(self.lib.rg_linear_affine_act(_ptr(x), K, _ptr(w), _ptr(wp), _ptr(scale), _ptr(shift), _ptr(y), Nout, M,
+                                            K, Nout, float(slope), algo, _ptr(ws), ws.numel(), self.stream),
+              "rg_linear_affine_act")
+        return y
+
+    def pack_linear(self, w):
+        Nout, K = w.shape
+        Kp = (K + 63) // 64 * 64
+        Np = (Nout + 127) // 128 * 128
+        wp = torch.empty((Np, Kp), dtype=torch.bfloat16, device=self.device)
+        check(self.lib.rg_pack_linear_weight(_ptr(w), _ptr(wp), Nout, K, Np, Kp, self.stream),
+              "rg_pack_linear_weight")
+        return wp
+
+    def selftest(self):
+        d = torch.zeros(2, dtype=torch.int32, device=self.device)
+        check(self.lib.rg_selftest_layouts(_ptr(d), self.stream), "rg_selftest_layouts")
+        return [int(v) for v in d.cpu()]

@@ -1,0 +1,237 @@
+"""GPU parity: every C-ABI op (through rna_gan_amd.ops_hip.HipOps) against its torch twin
+(oracle/ops_ref.py) on the same seeded inputs, generic (fp32 / bf16 storage) and MFMA (bf16) paths.
+Tolerances: fp32 path 2e-5 of the tensor's max magnitude (different summation order only);
+bf16 path 1.5e-2 (one bf16 rounding of inputs/outputs, fp32 accumulation)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.ops_ref import RefOps
+from rna_gan_amd.engine import ConvW
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.5e-2}
+
+
+def _hip(dtype):
+    from rna_gan_amd.ops_hip import HipOps
+    return HipOps(dtype, "cuda:0")
+
+
+def rnd(shape, seed, scale=1.0):
+    g = np.random.default_rng(seed)
+    return torch.from_numpy((g.standard_normal(size=shape) * scale).astype(np.float32))
+
+
+def relerr(a, b):
+    a = a.detach().float().cpu().double()
+    b = b.detach().float().cpu().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.isfinite(a).all(), "non-finite output"
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def check(a, b, tol, what=""):
+    e = relerr(a, b)
+    assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
+
+
+def dev(t, dtype=None):
+    t = t.cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def cwpair(w, bias=None):
+    return ConvW(w.clone(), bias), ConvW(w.cuda(), None if bias is None else bias.cuda())
+
+
+def test_selftest_layouts():
+    assert _hip(torch.bfloat16).selftest() == [0, 0]
+
+
+CONV_CASES = [
+    # N, Hi, Wi, I, O, dtype
+    (2, 8, 8, 4, 8, torch.float32),
+    (2, 8, 8, 4, 8, torch.bfloat16),
+    (3, 4, 8, 5, 6, torch.float32),
+    (2, 16, 16, 64, 128, torch.float32),
+    (2, 16, 16, 64, 128, torch.bfloat16),      # MFMA, I=64
+    (3, 8, 8, 128, 256, torch.bfloat16),       # MFMA, M tail (48 rows), 2 column tiles
+    (1, 8, 8, 256, 128, torch.bfloat16),       # MFMA, 16 rows only
+    (4, 32, 32, 64, 128, torch.bfloat16),      # MFMA, several row tiles
+]
+
+
+@pytest.mark.parametrize("N,Hi,Wi,I,O,dtype", CONV_CASES)
+def test_conv_down_up_wgrad(N, Hi, Wi, I, O, dtype):
+    ref, hip = RefOps(dtype), _hip(dtype)
+    w = rnd((O, I, 4, 4), 1, (2.0 / (I * 16)) ** 0.5)
+    cr, ch = cwpair(w)
+    x = rnd((N, Hi, Wi, I), 2).to(dtype)
+    y_ref = ref.conv_down(x, cr)
+    y = hip.conv_down(dev(x), ch)
+    check(y, y_ref, TOL[dtype], "conv_down")
+    g = rnd((N, Hi // 2, Wi // 2, O), 3).to(dtype)
+    u_ref = ref.conv_up(g, cr)
+    u = hip.conv_up(dev(g), ch)
+    check(u, u_ref, TOL[dtype], "conv_up")
+    dw_ref = torch.zeros(O, I, 4, 4)
+    ref.conv_wgrad(g, x, dw_ref, False)
+    dw = torch.full((O, I, 4, 4), 7.0).cuda()
+    hip.conv_wgrad(dev(g), dev(x), dw, False)
+    check(dw, dw_ref, TOL[dtype] * 2, "conv_wgrad")
+    hip.conv_wgrad(dev(g), dev(x), dw, True)
+    check(dw, 2 * dw_ref, TOL[dtype] * 2, "conv_wgrad(accumulate)")
+
+
+@pytest.mark.parametrize("O,dtype", [(4, torch.float32), (4, torch.bfloat16), (64, torch.float32),
+                                     (64, torch.bfloat16), (128, torch.bfloat16)])
+def test_image_side_layers(O, dtype):
+    ref, hip = RefOps(dtype), _hip(dtype)
+    N, H, W, I = 3, 16, 32, 3
+    w = rnd((O, I, 4, 4), 4, 0.2)
+    b = rnd((O,), 5, 0.1)
+    cr, ch = cwpair(w)
+    x = rnd((N, I, H, W), 6)
+    check(hip.first_down(dev(x), ch, dev(b), 0.2), ref.first_down(x, cr, b, 0.2), TOL[dtype], "first_down")
+    check(hip.first_down(dev(x), ch, None, 1.0), ref.first_down(x, cr, None, 1.0), TOL[dtype], "first_down(raw)")
+    a = rnd((N, H // 2, W // 2, O), 7).to(dtype)
+    b3 = rnd((I,), 8, 0.1)
+    check(hip.last_up(dev(a), ch, dev(b3), True), ref.last_up(a, cr, b3, True), TOL[dtype], "last_up(tanh)")
+    check(hip.last_up(dev(a), ch, None, False), ref.last_up(a, cr, None, False), TOL[dtype], "last_up(raw)")
+    dw_ref = torch.zeros(O, I, 4, 4)
+    ref.skinny_wgrad(a, x, dw_ref, False)
+    dw = torch.full((O, I, 4, 4), 3.0).cuda()
+    hip.skinny_wgrad(dev(a), dev(x), dw, False)
+    check(dw, dw_ref, TOL[dtype] * 2, "skinny_wgrad")
+    hip.skinny_wgrad(dev(a), dev(x), dw, True)
+    check(dw, 2 * dw_ref, TOL[dtype] * 2, "skinny_wgrad(acc)")
+
+
+@pytest.mark.parametrize("N,E,C,dtype", [(5, 24, 8, torch.float32), (5, 24, 8, torch.bfloat16),
+                                         (6, 128, 64, torch.bfloat16), (64, 256, 128, torch.bfloat16)])
+def test_g0_and_head(N, E, C, dtype):
+    ref, hip = RefOps(dtype), _hip(dtype)
+    w = rnd((E, C, 4, 4), 9, (2.0 / (C * 16)) ** 0.5)
+    cr, ch = cwpair(w)
+    z = rnd((N, E), 10)
+    check(hip.g0_fwd(dev(z), ch), ref.g0_fwd(z, cr), TOL[dtype], "g0_fwd")
+    gy = rnd((N, 4, 4, C), 11).to(dtype)
+    dw_ref = torch.zeros(E, C, 4, 4)
+    ref.g0_wgrad(z, gy, dw_ref, False)
+    dw = torch.zeros(E, C, 4, 4).cuda()
+    hip.g0_wgrad(dev(z), dev(gy), dw, False)
+    check(dw, dw_ref, TOL[dtype] * 2, "g0_wgrad")
+    # head
+    wh = rnd((1, C, 4, 4), 12, 0.1)
+    hr, hh = cwpair(wh)
+    a = rnd((N, 4, 4, C), 13).to(dtype)
+    h_ref, o_ref = ref.head_fwd(a, hr, 0.2)
+    h, o = hip.head_fwd(dev(a), hh, 0.2)
+    check(h, h_ref, TOL[dtype], "head_fwd.h"); check(o, o_ref, TOL[dtype], "head_fwd.out")
+    gh_ref = ref.head_grad(h_ref, -0.25, 0.2)
+    gh = hip.head_grad(dev(h_ref), -0.25, 0.2)
+    check(gh, gh_ref, 1e-6, "head_grad")
+    check(hip.head_bwd_data(gh, hh), ref.head_bwd_data(gh_ref, hr), TOL[dtype], "head_bwd_data")
+    dwh_ref = torch.zeros(1, C, 4, 4)
+    ref.head_wgrad(gh_ref, a, dwh_ref, False)
+    dwh = torch.zeros(1, C, 4, 4).cuda()
+    hip.head_wgrad(gh, dev(a), dwh, False)
+    check(dwh, dwh_ref, TOL[dtype], "head_wgrad")
+
+
+@pytest.mark.parametrize("M,C,dtype", [(40, 8, torch.float32), (37, 6, torch.float32), (40, 8, torch.bfloat16),
+                                       (4096, 128, torch.float32), (4096, 128, torch.bfloat16),
+                                       (70000, 64, torch.bfloat16)])
+def test_bn_family(M, C, dtype):
+    ref, hip = RefOps(dtype), _hip(dtype)
+    tol = TOL[dtype] if dtype == torch.bfloat16 else 1e-4
+    z = (rnd((1, M, 1, C), 20) * 1.5 + 0.3).to(dtype)
+    gamma, beta = 1 + 0.1 * rnd((C,), 21), 0.1 * rnd((C,), 22)
+    rm, rv = 0.1 * rnd((C,), 23), 1 + 0.1 * rnd((C,), 24).abs()
+    nbt = torch.zeros((), dtype=torch.int64)
+    s_ref, ss_ref = ref.bn_stats(z)
+    s, ss = hip.bn_stats(dev(z))
+    check(s, s_ref, 1e-4, "bn_stats.sum"); check(ss, ss_ref, 1e-4, "bn_stats.sumsq")
+    rm_d, rv_d, nbt_d = dev(rm.clone()), dev(rv.clone()), dev(nbt.clone())
+    mean_ref, inv_ref = ref.bn_finalize(s_ref, ss_ref, M, 1e-5, 0.1, rm, rv, nbt)
+    mean, inv = hip.bn_finalize(dev(s_ref), dev(ss_ref), M, 1e-5, 0.1, rm_d, rv_d, nbt_d)
+    check(mean, mean_ref, 1e-6, "mean"); check(inv, inv_ref, 1e-5, "invstd")
+    check(rm_d, rm, 1e-6, "running_mean"); check(rv_d, rv, 1e-5, "running_var")
+    assert int(nbt_d.cpu()) == int(nbt) == 1
+    D = lambda t: None if t is None else dev(t)
+    a_ref = ref.bn_act(z, mean_ref, inv_ref, gamma, beta, 0.2)
+    check(hip.bn_act(D(z), D(mean_ref), D(inv_ref), D(gamma), D(beta), 0.2), a_ref, tol, "bn_act")
+    ga = rnd((1, M, 1, C), 25).to(dtype)
+    dg_ref, db_ref = torch.zeros(C), torch.zeros(C)
+    gz_ref, sgy_ref, sgx_ref = ref.bn_act_bwd(z, ga, mean_ref, inv_ref, gamma, beta, 0.2, dg_ref, db_ref, False)
+    dg, db = torch.ones(C).cuda(), torch.ones(C).cuda()
+    gz, sgy, sgx = hip.bn_act_bwd(D(z), D(ga), D(mean_ref), D(inv_ref), D(gamma), D(beta), 0.2, dg, db, False)
+    check(gz, gz_ref, tol, "bn_act_bwd.gz"); check(sgy, sgy_ref, 2e-4, "s_gy"); check(sgx, sgx_ref, 2e-4, "s_gyxh")
+    check(dg, dg_ref, 2e-4, "dgamma"); check(db, db_ref, 2e-4, "dbeta")
+    zt = rnd((1, M, 1, C), 26).to(dtype)
+    at_ref, szt_ref, sxz_ref = ref.bn_tangent(z, zt, mean_ref, inv_ref, gamma, beta, 0.2)
+    at, szt, sxz = hip.bn_tangent(D(z), D(zt), D(mean_ref), D(inv_ref), D(gamma), D(beta), 0.2)
+    check(at, at_ref, tol, "bn_tangent.at"); check(szt, szt_ref, 2e-4, "s_zt"); check(sxz, sxz_ref, 2e-4, "s_xhzt")
+    for qa in (None, rnd((1, M, 1, C), 27).to(dtype)):
+        dg_ref, db_ref = torch.zeros(C), torch.zeros(C)
+        pz_ref = ref.bn_double_bwd(z, qa, zt, ga, mean_ref, inv_ref, gamma, beta, 0.2, sgy_ref, sgx_ref, szt_ref,
+                                   sxz_ref, dg_ref, db_ref, False)
+        dg, db = torch.ones(C).cuda(), torch.ones(C).cuda()
+        pz = hip.bn_double_bwd(D(z), D(qa), D(zt), D(ga), D(mean_ref), D(inv_ref), D(gamma), D(beta), 0.2,
+                               D(sgy_ref), D(sgx_ref), D(szt_ref), D(sxz_ref), dg, db, False)
+        check(pz, pz_ref, 5 * tol, "bn_double_bwd.pz")
+        check(dg, dg_ref, 1e-3, "dbl.dgamma"); check(db, db_ref, 1e-3 if qa is not None else 1e-30, "dbl.dbeta")
+    check(hip.lrelu_bwd(D(ga), D(a_ref), 0.2), ref.lrelu_bwd(ga, a_ref, 0.2), tol, "lrelu_bwd")
+    out_ref, out = torch.ones(C), torch.ones(C).cuda()
+    ref.col_sum(ga, out_ref, True); hip.col_sum(D(ga), out, True)
+    check(out, out_ref, 2e-4, "col_sum")
+
+
+def test_pointwise_reductions_adam():
+    ref, hip = RefOps(torch.float32), _hip(torch.float32)
+    n = (3, 3, 20, 24)
+    a, b = rnd(n, 30), torch.tanh(rnd(n, 31))
+    check(hip.tanh_bwd(dev(a), dev(b)), ref.tanh_bwd(a, b), 1e-6, "tanh_bwd")
+    check(hip.interp(dev(a), dev(b), 0.37), ref.interp(a, b, 0.37), 1e-6, "interp")
+    o_ref, o = torch.ones(3), torch.ones(3).cuda()
+    ref.nchw_chan_sum(a, o_ref, True); hip.nchw_chan_sum(dev(a), o, True)
+    check(o, o_ref, 1e-5, "nchw_chan_sum")
+    big = rnd((1, 3, 300, 301), 32)
+    sq_ref, sq = ref.sqnorm(big), hip.sqnorm(dev(big))
+    check(sq, sq_ref, 1e-5, "sqnorm")
+    l_ref, c_ref = ref.gp_coef(sq_ref, 10.0)
+    l, c = hip.gp_coef(dev(sq_ref), 10.0)
+    check(l, l_ref, 1e-5, "gp loss"); check(c, c_ref, 1e-5, "gp coef")
+    check(hip.scale_by(dev(a), dev(c_ref)), ref.scale_by(a, c_ref), 1e-6, "scale_by")
+    v1, v2 = rnd((37,), 33), rnd((37,), 34)
+    check(hip.mean_diff(dev(v1), dev(v2), 1.0), ref.mean_diff(v1, v2, 1.0), 1e-5, "mean_diff")
+    check(hip.mean_diff(dev(v1), None, -1.0), ref.mean_diff(v1, None, -1.0), 1e-5, "mean_diff(neg)")
+    u, z = rnd((7, 50), 35, 0.17), rnd((7, 50), 36)
+    check(hip.latent_prep(dev(u), dev(z)), ref.latent_prep(u, z), 1e-5, "latent_prep")
+    # adam: 3 steps against torch.optim.Adam itself
+    p0, g0 = rnd((1003,), 37), rnd((1003,), 38)
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pt], lr=4e-4, betas=(0.5, 0.999))
+    p, m, v = dev(p0.clone()), torch.zeros(1003).cuda(), torch.zeros(1003).cuda()
+    for step in range(1, 4):
+        g = g0 * step
+        pt.grad = g.clone(); opt.step()
+        hip.adam_step(p, dev(g), m, v, step, 4e-4, 0.5, 0.999, 1e-8)
+    check(p, pt.detach(), 1e-6, "adam p")
+    check(m, opt.state[pt]["exp_avg"], 1e-6, "adam m"); check(v, opt.state[pt]["exp_avg_sq"], 1e-6, "adam v")
+    q = dev(p0.clone()); hip.clamp_(q, -0.01, 0.01)
+    check(q, p0.clamp(-0.01, 0.01), 1e-7, "clamp")
+
+
+@pytest.mark.parametrize("M,K,Nout,packed", [(6, 50, 24, False), (16, 200, 136, True), (64, 19198, 256, True)])
+def test_linear(M, K, Nout, packed):
+    ref, hip = RefOps(torch.float32), _hip(torch.bfloat16)
+    x, w = rnd((M, K), 40), rnd((Nout, K), 41, (1.0 / K) ** 0.5)
+    sc, sh = 1 + 0.1 * rnd((Nout,), 42), 0.1 * rnd((Nout,), 43)
+    y_ref = ref.linear_affine_act(x, w, sc, sh, 0.01)
+    wd = dev(w)
+    wp = hip.pack_linear(wd) if packed else None
+    y = hip.linear_affine_act(dev(x), wd, dev(sc), dev(sh), 0.01, wp=wp)
+    check(y, y_ref, 1.5e-2 if packed else 2e-5, "linear")
