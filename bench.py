@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- training imgs/sec of the RNA-GAN WGAN-GP iteration on MI355X.
+
+One "step" = one full hot-loop iteration of the reference (src/histopathology_gan.py:298-314 ->
+torchgan Trainer -> the three train_ops of src/wgan_loss.py): generator-loss step, discriminator-loss
+step, gradient-penalty step (3 optimizer steps, 3 G forwards, 4 D forwards, all backwards incl. the
+second-order GP pass), on synthetic 256x256 RGB tiles with betaVAE-conditioned noise (wganvae path),
+reference model size (encoding 2048, step_channels 64, rna_features 19198).
+
+Workload = BASELINE.json configs[1] ("RNA-GAN lung 256x256 bf16 batch 64 on 1xMI355X"); with
+--gpus N it is configs[2] (64 per rank, weak scaling, RCCL gradient all-reduce).
+
+Contract: W untimed warm-up steps, K timed steps bracketed by barrier + synchronize, MAX over
+ranks, rank 0 prints ONE JSON line.  Extra objects:
+  roofline     : dominant kernel (bf16 MFMA implicit-GEMM conv, gather_gemm_kernel), achieved =
+                 algorithmic conv FLOPs of its launches / their summed duration, measured with
+                 HIP events inside this process on a dedicated pass (see DESIGN.md "Measurement").
+  cpu_baseline : the oracle (plain PyTorch fp32 restatement of the reference path, oracle/ref_cpu.py)
+                 timed on this box's host cores on a bounded sample (batch 8, the reference's own
+                 hard-coded batch size).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # MI355X dense bf16 (MI355X_MICROARCH.md)
+
+
+def conv_flops_per_image(in_size=256, step=64, enc=2048):
+    """Algorithmic conv FLOPs of ONE pass (2*MACs), SURVEY 8d: D 5.469 GFLOP, G 5.604 GFLOP."""
+    reps = in_size.bit_length() - 4
+    d_layers, g_layers = [], []
+    c, s = step, in_size // 2
+    d_layers.append(2 * s * s * c * 3 * 16)
+    for _ in range(reps):
+        s //= 2
+        d_layers.append(2 * s * s * (2 * c) * c * 16)
+        c *= 2
+    head = 2 * c * 16
+    g0 = 2 * enc * c * 16
+    cc, ss = c, 4
+    for _ in range(reps):
+        g_layers.append(2 * ss * ss * cc * (cc // 2) * 16)
+        cc //= 2
+        ss *= 2
+    g_last = 2 * ss * ss * cc * 3 * 16
+    return dict(D=sum(d_layers) + head, G=g0 + sum(g_layers) + g_last, D_mfma=sum(d_layers[1:]),
+                G_mfma=sum(g_layers), D_layers=d_layers, G_layers=g_layers)
+
+
+def build(device, precision, batch, rna_features, seed):
+    import torch.nn as nn
+    import rna_gan_amd as P
+    from oracle import ref_cpu as R          # seeded weight / input generators only
+    G = P.DCGANGenerator(2048, 256, 3, 64, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+    D = P.DCGANDiscriminator(256, 3, 64, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.LeakyReLU(0.2))
+    R.seeded_fill_(G, seed); R.seeded_fill_(D, seed + 1)
+    G.set_precision(precision); D.set_precision(precision)
+    G, D = G.to(device).train(), D.to(device).train()
+    og = P.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.999)).bind(G)
+    od = P.Adam(D.parameters(), lr=4e-4, betas=(0.5, 0.999)).bind(D)
+    bv = P.betaVAE(rna_features, 2048, [6000, 4000, 2048], [4000, 6000], beta=0.005)
+    R.seeded_fill_(bv, seed + 2)
+    bv.set_precision(precision)
+    bv = bv.to(device).eval()
+    return G, D, og, od, bv
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE configs[1])")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--seed", type=int, default=99)
+    args = ap.parse_args()
+
+    from rna_gan_amd import dist as D_
+    from rna_gan_amd import losses as PL
+    from oracle import ref_cpu as R
+    D_.init_from_env()
+    rank, world = D_.rank(), D_.world_size()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    N = args.batch
+    rna_features = 19198
+    G, Dm, og, od, bv = build(device, args.precision, N, rna_features, args.seed)
+    for mod in (G, Dm):
+        for t in list(mod.parameters()) + list(mod.buffers()):
+            D_.broadcast_(t.data, 0)
+
+    # synthetic inputs, resident in HBM before the timed region
+    real = R.synthetic_images(N, 256, seed=1234 + rank).to(device)
+    rna = R.synthetic_rna(N, rna_features, seed=4321 + rank, distinct=16).to(device)
+    gen = torch.Generator(device="cpu").manual_seed(args.seed + rank)
+    ops, _ = G.runtime()
+
+    def one_step():
+        # the three train_ops bodies (src/wgan_loss.py:82-129,181-263,314-389); fresh uniform noise and
+        # a betaVAE encode per train_op, eps ~ U(0,1) per GP step, as the reference does
+        losses = []
+        for tag in ("g", "d", "gp"):
+            z = bv.encode(rna)[0]
+            u = (torch.rand(N, 2048, generator=gen) * 0.6 - 0.3).to(device, non_blocking=True)
+            noise = ops.latent_prep(u, z)
+            if tag == "g":
+                losses.append(PL._g_step(G, Dm, og, noise))
+            elif tag == "d":
+                losses.append(PL._d_step(G, Dm, od, real, noise, None))
+            else:
+                eps = float(torch.rand(1, generator=gen))
+                losses.append(PL._gp_step(G, Dm, od, real, noise, eps, 10.0))
+        return losses
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ls = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    last_losses = [float(l.item()) for l in ls]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = N * world * args.steps / dt
+
+    out = {
+        "metric": "training imgs/sec (G+D WGAN-GP step, 256x256)",
+        "value": round(value, 2), "unit": "imgs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": "RNA-GAN lung (betaVAE-conditioned wganvae path) 256x256, DCGAN enc2048/step64, "
+                               "per-GPU batch %d, one iteration = G-loss + D-loss + GP steps" % N,
+                   "global_batch": N * world, "parallelism": "dp%d" % world, "rna_features": rna_features,
+                   "losses_last_step": last_losses},
+    }
+
+    # the instrumented extra iteration contains collectives in a data-parallel run: every rank runs it
+    roof = None if args.no_roofline else measure_roofline(ops, device, one_step, ms_per_step)
+    if rank == 0:
+        fl = conv_flops_per_image()
+        total_flops_img = 5 * fl["G"] + 14 * fl["D"]        # 104.6 GFLOP / image / iteration
+        out["config"]["algorithmic_conv_tflops_whole_step"] = round(total_flops_img * value / world / 1e12, 2)
+        if roof is not None:
+            out["roofline"] = roof
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.seed)
+        print(json.dumps(out), flush=True)
+    barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def measure_roofline(ops, device, one_step, step_ms):
+    """Per-launch HIP events (recorded on the stream the kernels are enqueued on) around every conv
+    launch of ONE extra, instrumented iteration of the same workload, run right after the timed
+    region.  Kernel families:
+      conv_fwd_dgrad = gather_gemm_kernel (bf16 MFMA implicit GEMM; every stride-2 conv / transposed
+                       conv, forward, data-gradient and GP tangent pass of both networks)
+      conv_wgrad     = wgrad_kernel + its slab reduction
+    `achieved` = algorithmic FLOPs of the family's launches / their summed duration (SURVEY 8d:
+    2*N*Ho*Wo*Cout*Cin*16 per launch).  The dominant family (largest share of the iteration) is the
+    one reported; the other is listed under `others`."""
+    ops.timing = []
+    one_step()
+    torch.cuda.synchronize(device)
+    fam = {}
+    for key, flops, e0, e1 in ops.timing:
+        f = fam.setdefault(key, {"launches": 0, "flops": 0.0, "ms": 0.0})
+        f["launches"] += 1
+        f["flops"] += flops
+        f["ms"] += e0.elapsed_time(e1)
+    ops.timing = None
+    rows = {}
+    for k, f in fam.items():
+        rows[k] = {"launches": f["launches"], "ms_total": round(f["ms"], 3),
+                   "avg_us_per_launch": round(f["ms"] * 1e3 / max(f["launches"], 1), 1),
+                   "tflops": round(f["flops"] / (f["ms"] * 1e-3) / 1e12, 1) if f["ms"] > 0 else None,
+                   "share_of_step": round(f["ms"] / step_ms, 3)}
+    dom = max(rows, key=lambda k: rows[k]["ms_total"])
+    names = {"conv_fwd_dgrad": "gather_gemm_kernel (bf16 MFMA implicit-GEMM conv: fwd / dgrad / tangent)",
+             "conv_wgrad": "wgrad_kernel (bf16 MFMA weight gradient) + reduce_slabs_kernel"}
+    return {"bound": "mfma", "kernel": names.get(dom, dom), "achieved": rows[dom]["tflops"],
+            "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(rows[dom]["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+            "launches": rows[dom]["launches"], "avg_us_per_launch": rows[dom]["avg_us_per_launch"],
+            "share_of_step": rows[dom]["share_of_step"],
+            "others": {k: v for k, v in rows.items() if k != dom}}
+
+
+def cpu_baseline(seed):
+    """The oracle on the host cores: batch 8 (the reference's hard-coded batch size,
+    src/histopathology_gan.py:94), fp32, all cores, 1 warm-up + 2 timed iterations."""
+    import torch.nn as nn
+    from oracle import ref_cpu as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n = 8
+    G = R.seeded_fill_(R.OracleDCGANGenerator(2048, 256, 3, 64, nonlinearity=nn.LeakyReLU(0.2),
+                                              last_nonlinearity=nn.Tanh()), seed).train()
+    D = R.seeded_fill_(R.OracleDCGANDiscriminator(256, 3, 64, nonlinearity=nn.LeakyReLU(0.2),
+                                                  last_nonlinearity=nn.LeakyReLU(0.2)), seed + 1).train()
+    og, od = R.make_adam(G.parameters(), 1e-4), R.make_adam(D.parameters(), 4e-4)
+    real = R.synthetic_images(n, 256, seed=1234)
+    times = []
+    for it in range(3):
+        noises = [R.conditioned_noise(R.synthetic_uniform(n, 2048, seed=10 * it + j),
+                                      R.synthetic_normal(n, 2048, seed=100 * it + j)) for j in range(3)]
+        t0 = time.perf_counter()
+        R.train_iteration(G, D, og, od, real, noises, 0.5)
+        times.append(time.perf_counter() - t0)
+    t = sum(times[1:]) / len(times[1:])
+    return {"value": round(n / t, 3), "unit": "imgs/sec", "cores": cores, "kind": "port",
+            "sample": "oracle/ref_cpu.py (PyTorch fp32 restatement of the reference path, betaVAE encode "
+                      "excluded: ~3% of the reference's CPU time), batch 8, 1 warm-up + 2 timed iterations, "
+                      "%.2f s/iteration, torch %s, %d threads" % (t, torch.__version__, torch.get_num_threads())}
+
+
+if __name__ == "__main__":
+    main()

@@ -201,10 +201,12 @@ int rg_latent_prep(const float* u, const float* z, float* out, int N, int E, voi
 /* ---------------------------------------------------------------------------------------------
  * Optimizer (K12/K13): torch.optim.Adam semantics on flat fp32 buffers
  * (histopathology_gan.py:252,257; stepped at wgan_loss.py:127,261,388), optional weight clamp
- * (wgan_loss.py:213-215).  step is 1-based.
+ * (wgan_loss.py:213-215).  step is 1-based.  Hyper-parameters are doubles, as torch holds them: the
+ * kernel's constants (1-beta, lr/bias_correction1, 1/sqrt(bias_correction2)) are formed in double and
+ * rounded once, which reproduces torch's fp32 results to the last bits.
  * ------------------------------------------------------------------------------------------- */
-int rg_adam_step(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float beta1,
-                 float beta2, float eps, void* stream);
+int rg_adam_step(float* p, const float* g, float* m, float* v, size_t n, int step, double lr, double beta1,
+                 double beta2, double eps, void* stream);
 int rg_clamp(float* p, size_t n, float lo, float hi, void* stream);
 
 /* fp32 -> dtype cast with optional row padding: dst[M][ldd] = src[M][K] (pad columns zeroed) */

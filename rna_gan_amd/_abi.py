@@ -16,6 +16,7 @@ ALGO_AUTO, ALGO_GENERIC, ALGO_MFMA = 0, 1, 2
 _p = C.c_void_p
 _i = C.c_int
 _f = C.c_float
+_d = C.c_double
 _z = C.c_size_t
 
 # name -> (restype, [argtypes])   -- must list every symbol declared in include/rnagan_hip.h
@@ -61,7 +62,7 @@ PROTOTYPES = {
     "rg_scale_by": (_i, [_p, _p, _p, _z, _p]),
     "rg_mean_diff": (_i, [_p, _p, _p, _i, _f, _p]),
     "rg_latent_prep": (_i, [_p, _p, _p, _i, _i, _p]),
-    "rg_adam_step": (_i, [_p, _p, _p, _p, _z, _i, _f, _f, _f, _f, _p]),
+    "rg_adam_step": (_i, [_p, _p, _p, _p, _z, _i, _d, _d, _d, _d, _p]),
     "rg_clamp": (_i, [_p, _z, _f, _f, _p]),
     "rg_cast_pad": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "rg_selftest_layouts": (_i, [_p, _p]),

@@ -1,0 +1,105 @@
+"""betaVAE with the reference's module layout / state_dict keys (src/betaVAE.py:18-42,63-107).
+
+Only the hot-path part is implemented natively: ``encode`` in EVAL mode (Dropout = identity,
+BatchNorm1d with running statistics), i.e. 3 x [Linear + BN1d + LeakyReLU(0.01)] then ``z_mu`` /
+``z_logvar`` (src/wgan_loss.py:67-69,96-97).  Each layer is ONE HIP GEMM whose epilogue applies the
+folded BatchNorm scale/shift and the activation (rg_linear_affine_act); with precision "bf16" the
+weights are streamed as a packed bf16 copy (this path is weight-streaming/HBM bound).
+Training the VAE and the decoder are out of scope: ``forward`` raises.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.nn as nn
+
+
+class RNAEncoder(nn.Module):
+    def __init__(self, in_channels: int, hidden_dims: List[int]):
+        super().__init__()
+        self.in_channels = in_channels
+        modules: List[nn.Module] = [nn.Sequential(nn.Dropout())]
+        for h in hidden_dims:
+            modules.append(nn.Sequential(nn.Linear(in_channels, h), nn.BatchNorm1d(h), nn.LeakyReLU()))
+            in_channels = h
+        self.encoder = nn.Sequential(*modules)
+
+
+class betaVAE(nn.Module):
+    def __init__(self, in_channels: int, z_dim: int, encoder_dims: List[int], hidden_dims_decoder: List[int],
+                 beta: float = 2, encoder_checkpoint=None):
+        super().__init__()
+        self.encoder = RNAEncoder(in_channels, encoder_dims)
+        if encoder_checkpoint:
+            self.encoder.load_state_dict(torch.load(encoder_checkpoint))
+        self.z_mu = nn.Linear(z_dim, z_dim)
+        self.z_logvar = nn.Linear(z_dim, z_dim)
+        self.beta = beta
+        mods: List[nn.Module] = []
+        cin = z_dim
+        for h in hidden_dims_decoder:
+            mods.append(nn.Sequential(nn.Linear(cin, h), nn.BatchNorm1d(h), nn.LeakyReLU()))
+            cin = h
+        mods.append(nn.Sequential(nn.Linear(cin, in_channels), nn.Tanh()))
+        self.decoder = nn.Sequential(*mods)
+        self.z_dim = z_dim
+        self.precision = "bf16"
+        self._plan = None
+        self._ops = None
+
+    # ---------------------------------------------------------------- runtime
+    def set_precision(self, precision: str):
+        self.precision = precision
+        self._plan = None
+        return self
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._plan = None
+        self._ops = None
+        return r
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._plan = None
+        return r
+
+    def _build_plan(self):
+        from .ops_hip import HipOps
+        dev = self.z_mu.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("betaVAE.encode runs on the HIP kernels only (move the module to a ROCm GPU)")
+        self._ops = HipOps(torch.bfloat16, dev)
+        packed = self.precision == "bf16"
+        plan = []
+        with torch.no_grad():
+            for blk in list(self.encoder.encoder.children())[1:]:
+                lin, bn, act = blk[0], blk[1], blk[2]
+                scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)      # one-time fold, C-length vectors
+                shift = (lin.bias - bn.running_mean) * scale + bn.bias
+                plan.append((lin.weight.detach(), self._ops.pack_linear(lin.weight.detach()) if packed else None,
+                             scale.contiguous(), shift.contiguous(), float(act.negative_slope)))
+            for lin in (self.z_mu, self.z_logvar):
+                plan.append((lin.weight.detach(), self._ops.pack_linear(lin.weight.detach()) if packed else None,
+                             None, lin.bias.detach(), 1.0))
+        self._plan = plan
+
+    def encode(self, x):
+        """(z_mean, z_log_var, x_encoded) as src/betaVAE.py:102-107, eval mode."""
+        if self.training:
+            raise NotImplementedError("rna_gan_amd.betaVAE implements the frozen (eval) encoder used by RNA-GAN")
+        if self._plan is None:
+            self._build_plan()
+        ops = self._ops
+        h = x.contiguous().float()
+        for (w, wp, scale, shift, slope) in self._plan[:-2]:
+            h = ops.linear_affine_act(h, w, scale, shift, slope, wp=wp)
+        w, wp, scale, shift, slope = self._plan[-2]
+        z_mean = ops.linear_affine_act(h, w, scale, shift, slope, wp=wp)
+        w, wp, scale, shift, slope = self._plan[-1]
+        z_log_var = ops.linear_affine_act(h, w, scale, shift, slope, wp=wp)
+        return z_mean, z_log_var, h
+
+    def forward(self, x):
+        raise NotImplementedError("betaVAE training/decoding is outside the RNA-GAN hot path (SURVEY 8f f4)")

@@ -61,12 +61,13 @@ struct Clamp {
   __device__ void one(size_t i) const { p[i] = fminf(fmaxf(p[i], lo), hi); }
 };
 struct Adam {
-  float* p; const float* g; float* m; float* v; float b1, b2, eps, step_size, inv_sqrt_bc2;
+  float* p; const float* g; float* m; float* v; float b1, b2, omb1, omb2, eps, step_size, inv_sqrt_bc2;
   __device__ __forceinline__ void upd(float& pp, float gg, float& mm, float& vv) const {
     // torch.optim.Adam (single-tensor path): m = b1*m + (1-b1)g ; v = b2*v + (1-b2)g^2 ;
     // denom = sqrt(v)/sqrt(bc2) + eps ; p -= (lr/bc1) * m/denom
-    mm = b1 * mm + (1.f - b1) * gg;
-    vv = b2 * vv + (1.f - b2) * gg * gg;
+    // (1-beta) is rounded from double like torch's python-side `1 - beta2`; lerp form for m as torch
+    mm = mm + omb1 * (gg - mm);
+    vv = b2 * vv + omb2 * gg * gg;
     float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
     pp -= step_size * (mm / denom);
   }
@@ -246,13 +247,14 @@ extern "C" int rg_clamp(float* p, size_t n, float lo, float hi, void* stream) {
   Clamp f{p, lo, hi};
   EW_LAUNCH("clamp", f, n, rg_stream(stream));
 }
-extern "C" int rg_adam_step(float* p, const float* g, float* m, float* v, size_t n, int step, float lr, float beta1,
-                            float beta2, float eps, void* stream) {
+extern "C" int rg_adam_step(float* p, const float* g, float* m, float* v, size_t n, int step, double lr, double beta1,
+                            double beta2, double eps, void* stream) {
   RG_REQUIRE(p && g && m && v && step >= 1, RG_EINVAL, "adam_step: bad args");
   RG_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), RG_EINVAL, "adam_step: 16-byte alignment");
-  double bc1 = 1.0 - pow((double)beta1, (double)step);
-  double bc2 = 1.0 - pow((double)beta2, (double)step);
-  Adam f{p, g, m, v, beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2))};
+  double bc1 = 1.0 - pow(beta1, (double)step);
+  double bc2 = 1.0 - pow(beta2, (double)step);
+  Adam f{p, g, m, v, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
+         (float)(lr / bc1), (float)(1.0 / sqrt(bc2))};
   EW_LAUNCH("adam_step", f, n, rg_stream(stream));
 }
 

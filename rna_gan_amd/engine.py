@@ -161,7 +161,7 @@ def disc_backward(ops, D: DiscNet, ctx, coef: float, wgrad: bool, accumulate: bo
 
 def disc_gradient_penalty(ops, D: DiscNet, xhat, lambd: float, update_running=True):
     """lambd*(||d sum D(xhat)/d xhat||_2 - 1)^2 and its parameter gradients (written, not
-    accumulated).  Reference: src/wgan_loss.py:32-44 + :379-387.  Returns the UNWEIGHTED penalty
+    accumulated; lambd may carry the data-parallel 1/world factor -- it only scales the gradients).  Reference: src/wgan_loss.py:32-44 + :379-387.  Returns the UNWEIGHTED penalty
     as a 1-element device tensor (the reference returns loss.item() of the unweighted value)."""
     R = len(D.blocks)
     out, ctx = disc_forward(ops, D, xhat, update_running)
@@ -240,19 +240,19 @@ def gen_backward(ops, G: GenNet, ctx, gimg, accumulate: bool):
 # The three train_ops bodies (gradient part; the optimizer step is applied by the caller so that
 # a data-parallel all-reduce can sit between the two)
 # --------------------------------------------------------------------------------------------
-def gen_loss_grads(ops, G: GenNet, D: DiscNet, noise):
+def gen_loss_grads(ops, G: GenNet, D: DiscNet, noise, grad_scale: float = 1.0):
     """src/wgan_loss.py:113-126: loss = mean(-D(G(z))); fills G's gradients.  D's weight
     gradients, which the reference computes and discards, are not computed."""
     n = noise.shape[0]
     img, gctx = gen_forward(ops, G, noise)
     out, dctx = disc_forward(ops, D, img)
     loss = ops.mean_diff(out, None, -1.0)
-    gimg = disc_backward(ops, D, dctx, -1.0 / n, wgrad=False, accumulate=False, need_input_grad=True)
+    gimg = disc_backward(ops, D, dctx, -grad_scale / n, wgrad=False, accumulate=False, need_input_grad=True)
     gen_backward(ops, G, gctx, gimg, accumulate=False)
     return loss
 
 
-def disc_loss_grads(ops, G: GenNet, D: DiscNet, real, noise):
+def disc_loss_grads(ops, G: GenNet, D: DiscNet, real, noise, grad_scale: float = 1.0):
     """src/wgan_loss.py:241-260: loss = mean(D(G(z).detach()) - D(real)); fills D's gradients.
     Forward order D(real), G(z), D(fake) as in the reference (BN running statistics)."""
     n = real.shape[0]
@@ -260,17 +260,17 @@ def disc_loss_grads(ops, G: GenNet, D: DiscNet, real, noise):
     img, _ = gen_forward(ops, G, noise, keep=False)
     out_f, ctx_f = disc_forward(ops, D, img)
     loss = ops.mean_diff(out_f, out_r, 1.0)
-    disc_backward(ops, D, ctx_r, -1.0 / n, wgrad=True, accumulate=False, need_input_grad=False)
-    disc_backward(ops, D, ctx_f, 1.0 / n, wgrad=True, accumulate=True, need_input_grad=False)
+    disc_backward(ops, D, ctx_r, -grad_scale / n, wgrad=True, accumulate=False, need_input_grad=False)
+    disc_backward(ops, D, ctx_f, grad_scale / n, wgrad=True, accumulate=True, need_input_grad=False)
     return loss
 
 
-def gp_loss_grads(ops, G: GenNet, D: DiscNet, real, noise, eps: float, lambd: float):
+def gp_loss_grads(ops, G: GenNet, D: DiscNet, real, noise, eps: float, lambd: float, grad_scale: float = 1.0):
     """src/wgan_loss.py:371-387: fake = G(z); xhat = eps*real + (1-eps)*fake; D gradients of
     lambd*GP.  The generator gradients the reference produces here are never used and are skipped."""
     img, _ = gen_forward(ops, G, noise, keep=False)
     xhat = ops.interp(real, img, eps)
-    return disc_gradient_penalty(ops, D, xhat, lambd)
+    return disc_gradient_penalty(ops, D, xhat, lambd * grad_scale)
 
 
 # --------------------------------------------------------------------------------------------
@@ -327,3 +327,15 @@ def build_gen_net(mod) -> GenNet:
         raise NotImplementedError("HIP path supports last_nonlinearity=Tanh only")
     last = ConvW(lc.weight.data, lc.bias.data, _grad_of(lc.weight), _grad_of(lc.bias))
     return GenNet(g0, _bnp(b0), bl, last, slope)
+
+
+def gen_forward_eval(ops, G: GenNet, noise):
+    """Generator forward with BatchNorm in EVAL mode (running statistics), used for the per-epoch
+    sample grid (torchgan Logger: generator.eval(); generator(test_noise))."""
+    def bn_eval(z, bn):
+        invstd = torch.rsqrt(bn.running_var + bn.eps)     # C-length vector: host-side plumbing
+        return ops.bn_act(z, bn.running_mean, invstd, bn.gamma, bn.beta, G.slope)
+    a = bn_eval(ops.g0_fwd(noise, G.g0), G.bn0)
+    for cw, bn in G.blocks:
+        a = bn_eval(ops.conv_up(a, cw), bn)
+    return ops.last_up(a, G.last, G.last.bias, True)

@@ -1,0 +1,232 @@
+"""DCGAN generator / discriminator with the torchgan constructor signatures and state_dict keys
+(reference: src/histopathology_gan.py:175-192 instantiates torchgan.models.DCGANGenerator /
+DCGANDiscriminator; the generator recipe is mirrored by src/dcgan.py:27-44,52,57-75,82; the
+discriminator recipe is the third-party one recalled in SURVEY.md Appendix A).
+
+The nn.Conv2d / nn.ConvTranspose2d / nn.BatchNorm2d children are PARAMETER CONTAINERS only: they
+give the modules the exact key names, shapes and dtypes of the reference checkpoints.  ``forward``
+never calls them; it runs the hand-written HIP kernels through rna_gan_amd.engine.  There is no
+eager fallback: on a machine without the HIP library / a GPU, forward raises.
+"""
+from __future__ import annotations
+
+from math import ceil, log2
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from . import engine as E
+
+
+def _num_repeats(size: int, what: str) -> int:
+    if size < 16 or ceil(log2(size)) != log2(size):
+        raise Exception("%s must be at least 16*16 and an exact power of 2" % what)
+    return size.bit_length() - 4
+
+
+class FlatParams:
+    """All parameters of a module re-homed into ONE flat fp32 buffer (and their gradients into
+    another), so that the optimizer step is a single fused kernel and the data-parallel gradient
+    all-reduce runs on a few large contiguous buckets.  Parameters stay ordinary nn.Parameters
+    (views), so state_dict / load_state_dict / .parameters() behave as usual."""
+
+    def __init__(self, module: nn.Module):
+        params = [p for p in module.parameters()]
+        dev = params[0].device
+        self.numel = sum(p.numel() for p in params)
+        pad = (-self.numel) % 4
+        self.data = torch.zeros(self.numel + pad, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.numel + pad, dtype=torch.float32, device=dev)
+        self.offsets = []
+        off = 0
+        for p in params:
+            n = p.numel()
+            self.data[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.data[off:off + n].view(p.shape)
+            p.grad = self.grad[off:off + n].view(p.shape)
+            self.offsets.append((off, n))
+            off += n
+        self.params = params
+
+    def owns(self, module: nn.Module) -> bool:
+        """True if the module's parameters still live in this flat buffer.  Gradient views that were
+        dropped (zero_grad(set_to_none=True)) or replaced are re-attached."""
+        ps = list(module.parameters())
+        if len(ps) != len(self.params):
+            return False
+        base = self.data.data_ptr()
+        for p, (off, n) in zip(ps, self.offsets):
+            if p.data_ptr() != base + 4 * off:
+                return False
+        gbase = self.grad.data_ptr()
+        for p, (off, n) in zip(ps, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != gbase + 4 * off:
+                p.grad = self.grad[off:off + n].view(p.shape)
+        return True
+
+
+class _HipModule(nn.Module):
+    """Shared runtime plumbing: lazily binds the module to a HipOps backend + engine view."""
+
+    def __init__(self):
+        super().__init__()
+        self._rt_ops = None
+        self._rt_net = None
+        self._rt_flat = None
+        self.precision = "bf16"     # "bf16" (MFMA kernels) or "fp32" (generic fp32 kernels, parity mode)
+
+    def set_precision(self, precision: str):
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        if precision != self.precision:
+            self.precision = precision
+            self._rt_ops = None
+            self._rt_net = None
+        return self
+
+    def _build_net(self):
+        raise NotImplementedError
+
+    def runtime(self):
+        """(ops, net) for the module's current device; (re)built when parameters were re-homed."""
+        p0 = next(self.parameters())
+        if p0.device.type != "cuda":
+            raise RuntimeError("%s runs on the HIP kernels only: move it to a ROCm GPU (.to('cuda')); "
+                               "there is no CPU fallback" % type(self).__name__)
+        if self._rt_flat is None or not self._rt_flat.owns(self):
+            self._rt_flat = FlatParams(self)
+            self._rt_net = None
+        if self._rt_ops is None or self._rt_net is None:
+            from .ops_hip import HipOps
+            dt = torch.bfloat16 if self.precision == "bf16" else torch.float32
+            self._rt_ops = HipOps(dt, p0.device)
+            self._rt_net = self._build_net()
+        return self._rt_ops, self._rt_net
+
+    @property
+    def flat(self) -> "FlatParams":
+        self.runtime()
+        return self._rt_flat
+
+    def weights_changed(self):
+        """Call after the parameters were modified in place (optimizer step, clamp, load)."""
+        if self._rt_net is not None:
+            self._rt_net.bump()
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.weights_changed()
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._rt_ops = None
+        self._rt_net = None
+        self._rt_flat = None
+        return r
+
+
+class Generator(_HipModule):
+    """torchgan.models.Generator base (attributes used at src/wgan_loss.py:91,100; src/gan_utils.py:226)."""
+
+    def __init__(self, encoding_dims, label_type="none"):
+        super().__init__()
+        self.encoding_dims = encoding_dims
+        self.label_type = label_type
+
+    def _weight_initializer(self):
+        for m in self.modules():
+            if isinstance(m, (nn.ConvTranspose2d, nn.Conv2d, nn.Linear)):
+                nn.init.kaiming_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0.0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1.0)
+                nn.init.constant_(m.bias, 0.0)
+
+    def sampler(self, sample_size, device):
+        return [torch.randn(sample_size, self.encoding_dims, device=device)]
+
+
+class Discriminator(_HipModule):
+    """torchgan.models.Discriminator base."""
+
+    def __init__(self, input_dims, label_type="none"):
+        super().__init__()
+        self.input_dims = input_dims
+        self.label_type = label_type
+
+    _weight_initializer = Generator._weight_initializer
+
+
+class DCGANGenerator(Generator):
+    """ConvT(E,d,4,1,0)+BN+nl ; R x [ConvT(d,d/2,4,2,1)+BN+nl] ; ConvT(d,ch,4,2,1,bias)+last_nl."""
+
+    def __init__(self, encoding_dims=100, out_size=32, out_channels=3, step_channels=64, batchnorm=True,
+                 nonlinearity=None, last_nonlinearity=None, label_type="none"):
+        super().__init__(encoding_dims, label_type)
+        if not batchnorm:
+            raise NotImplementedError("rna_gan_amd implements the batchnorm=True recipe used by RNA-GAN")
+        reps = _num_repeats(out_size, "Target Image Size")
+        self.ch = out_channels
+        self.n = step_channels
+        nl = nn.LeakyReLU(0.2) if nonlinearity is None else nonlinearity
+        last_nl = nn.Tanh() if last_nonlinearity is None else last_nonlinearity
+        d = int(self.n * (2 ** reps))
+        model: List[nn.Module] = [nn.Sequential(nn.ConvTranspose2d(self.encoding_dims, d, 4, 1, 0, bias=False),
+                                                nn.BatchNorm2d(d), nl)]
+        for _ in range(reps):
+            model.append(nn.Sequential(nn.ConvTranspose2d(d, d // 2, 4, 2, 1, bias=False), nn.BatchNorm2d(d // 2), nl))
+            d = d // 2
+        model.append(nn.Sequential(nn.ConvTranspose2d(d, self.ch, 4, 2, 1, bias=True), last_nl))
+        self.model = nn.Sequential(*model)
+        self._weight_initializer()
+
+    def _build_net(self):
+        return E.build_gen_net(self)
+
+    def forward(self, x, feature_matching=False):
+        """Generated images (N, ch, S, S) fp32.  Train mode: batch statistics + running-stat update
+        (what the reference's generator(noise) calls do).  Inference only: no autograd graph."""
+        ops, net = self.runtime()
+        x = x.view(-1, x.size(1)).contiguous().float()
+        if self.training:
+            img, _ = E.gen_forward(ops, net, x, update_running=True, keep=False)
+        else:
+            img = E.gen_forward_eval(ops, net, x)
+        return img
+
+
+class DCGANDiscriminator(Discriminator):
+    """Conv(c,d,4,2,1,bias)+nl ; R x [Conv(d,2d,4,2,1)+BN+nl] ; disc = Conv(d,1,4,1,0)+last_nl -> (N,)."""
+
+    def __init__(self, in_size=32, in_channels=3, step_channels=64, batchnorm=True, nonlinearity=None,
+                 last_nonlinearity=None, label_type="none"):
+        super().__init__(in_channels, label_type)
+        if not batchnorm:
+            raise NotImplementedError("rna_gan_amd implements the batchnorm=True recipe used by RNA-GAN")
+        reps = _num_repeats(in_size, "Input Image Size")
+        self.n = step_channels
+        nl = nn.LeakyReLU(0.2) if nonlinearity is None else nonlinearity
+        last_nl = nn.LeakyReLU(0.2) if last_nonlinearity is None else last_nonlinearity
+        d = self.n
+        model: List[nn.Module] = [nn.Sequential(nn.Conv2d(self.input_dims, d, 4, 2, 1, bias=True), nl)]
+        for _ in range(reps):
+            model.append(nn.Sequential(nn.Conv2d(d, d * 2, 4, 2, 1, bias=False), nn.BatchNorm2d(d * 2), nl))
+            d *= 2
+        self.model = nn.Sequential(*model)
+        self.disc = nn.Sequential(nn.Conv2d(d, 1, 4, 1, 0, bias=False), last_nl)
+        self._weight_initializer()
+
+    def _build_net(self):
+        return E.build_disc_net(self)
+
+    def forward(self, x, feature_matching=False):
+        if feature_matching:
+            raise NotImplementedError("feature_matching is not on the RNA-GAN path")
+        ops, net = self.runtime()
+        if not self.training:
+            raise NotImplementedError("the reference only ever runs the discriminator in train mode")
+        out, _ = E.disc_forward(ops, net, x.contiguous().float(), update_running=True)
+        return out

@@ -29,6 +29,9 @@ class HipOps:
         self.dt = RG_F32 if act_dtype == torch.float32 else RG_BF16
         self.algo = algo
         self._wsbuf = None
+        # optional per-launch timing (bench.py roofline): list of (kernel family, algorithmic FLOPs,
+        # start event, end event); events are recorded on the stream the kernels are enqueued on
+        self.timing = None
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -40,6 +43,16 @@ class HipOps:
         if self._wsbuf is None or self._wsbuf.numel() < nbytes:
             self._wsbuf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
         return self._wsbuf
+
+    def _timed(self, key, flops, thunk):
+        if self.timing is None:
+            return thunk()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(self.device))
+        r = thunk()
+        e1.record(torch.cuda.current_stream(self.device))
+        self.timing.append((key, float(flops), e0, e1))
+        return r
 
     def _act(self, *shape):
         return torch.empty(shape, dtype=self.act_dtype, device=self.device)
@@ -67,8 +80,9 @@ class HipOps:
         assert cw.w.shape[1] == I and x.is_contiguous()
         wdn, _ = self._packs(cw)
         y = self._act(N, Hi // 2, Wi // 2, O)
-        check(self.lib.rg_conv_down(_ptr(x), _ptr(cw.w), _ptr(wdn), _ptr(y), N, Hi, Wi, I, O, self.dt, self.algo,
-                                    self.stream), "rg_conv_down")
+        self._timed("conv_fwd_dgrad", 2.0 * N * (Hi // 2) * (Wi // 2) * O * I * 16, lambda: check(
+            self.lib.rg_conv_down(_ptr(x), _ptr(cw.w), _ptr(wdn), _ptr(y), N, Hi, Wi, I, O, self.dt, self.algo,
+                                  self.stream), "rg_conv_down"))
         return y
 
     def conv_up(self, x, cw: ConvW):
@@ -77,8 +91,9 @@ class HipOps:
         assert cw.w.shape[0] == O and x.is_contiguous()
         _, wup = self._packs(cw)
         y = self._act(N, 2 * Ho, 2 * Wo, I)
-        check(self.lib.rg_conv_up(_ptr(x), _ptr(cw.w), _ptr(wup), _ptr(y), N, Ho, Wo, O, I, self.dt, self.algo,
-                                  self.stream), "rg_conv_up")
+        self._timed("conv_fwd_dgrad", 2.0 * N * Ho * Wo * O * I * 16, lambda: check(
+            self.lib.rg_conv_up(_ptr(x), _ptr(cw.w), _ptr(wup), _ptr(y), N, Ho, Wo, O, I, self.dt, self.algo,
+                                self.stream), "rg_conv_up"))
         return y
 
     def conv_wgrad(self, low, high, dw, accumulate: bool):
@@ -87,8 +102,9 @@ class HipOps:
         assert high.shape[1] == 2 * Ho and tuple(dw.shape) == (O, I, 4, 4) and dw.is_contiguous()
         nb = self.lib.rg_conv_wgrad_workspace_bytes(N, Ho, Wo, O, I, self.dt, self.algo)
         ws = self._ws(nb)
-        check(self.lib.rg_conv_wgrad(_ptr(low), _ptr(high), _ptr(dw), N, Ho, Wo, O, I, self.dt, int(accumulate),
-                                     self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_wgrad")
+        self._timed("conv_wgrad", 2.0 * N * Ho * Wo * O * I * 16, lambda: check(
+            self.lib.rg_conv_wgrad(_ptr(low), _ptr(high), _ptr(dw), N, Ho, Wo, O, I, self.dt, int(accumulate),
+                                   self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_wgrad"))
 
     def first_down(self, x_nchw, cw: ConvW, bias, slope: float):
         N, I, H, W = x_nchw.shape

@@ -1,0 +1,76 @@
+"""Fused Adam on the flat parameter buffers (one HIP kernel per optimizer step).
+
+Drop-in for ``torch.optim.Adam(params, lr, betas)`` as configured at
+src/histopathology_gan.py:252,257 (stepped at src/wgan_loss.py:127,261,388): same update rule
+(rg_adam_step), same ``state_dict()`` layout (per-parameter ``step`` / ``exp_avg`` /
+``exp_avg_sq``), so optimizer state in reference checkpoints loads and vice versa.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _abi
+from ._abi import check
+
+
+class Adam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **kw):
+        if weight_decay != 0 or amsgrad:
+            raise NotImplementedError("rna_gan_amd.optim.Adam: weight_decay/amsgrad are not on the RNA-GAN path")
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False,
+                         foreach=False, fused=False)
+        self._module = None
+        self._m = None
+        self._v = None
+        self._flat_id = None
+
+    def bind(self, module):
+        """Tell the optimizer which HIP module owns its parameters (done by the Trainer)."""
+        self._module = module
+        return self
+
+    def _ensure(self):
+        if self._module is None:
+            raise RuntimeError("rna_gan_amd.optim.Adam must be bound to its module (Adam(...).bind(module))")
+        flat = self._module.flat
+        if self._flat_id is not flat:
+            old = {p: self.state.get(p) for p in flat.params}
+            self._m = torch.zeros_like(flat.data)
+            self._v = torch.zeros_like(flat.data)
+            for p, (off, n) in zip(flat.params, flat.offsets):
+                st = old.get(p) or {}
+                m = self._m[off:off + n].view(p.shape)
+                v = self._v[off:off + n].view(p.shape)
+                if "exp_avg" in st:
+                    m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
+                step = st.get("step", torch.tensor(0.0))
+                self.state[p] = {"step": step if torch.is_tensor(step) else torch.tensor(float(step)),
+                                 "exp_avg": m, "exp_avg_sq": v}
+            self._flat_id = flat
+        return flat
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._flat_id = None      # re-home the loaded moments into the flat buffers at next use
+
+    def zero_grad(self, set_to_none: bool = False):
+        # gradients are written (not accumulated) by the first backward of every step; keep the views
+        if self._module is not None:
+            self._module.flat.grad.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        flat = self._ensure()
+        g = self.param_groups[0]
+        p0 = flat.params[0]
+        st0 = self.state[p0]
+        step = int(float(st0["step"])) + 1
+        lib = _abi.load()
+        stream = torch.cuda.current_stream(flat.data.device).cuda_stream
+        check(lib.rg_adam_step(flat.data.data_ptr(), flat.grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
+                               flat.data.numel(), step, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                               float(g["eps"]), stream), "rg_adam_step")
+        for p in flat.params:
+            self.state[p]["step"] = torch.tensor(float(step))
+        self._module.weights_changed()
+        return None

@@ -1,0 +1,234 @@
+"""Training loop with the torchgan ``Trainer`` interface the reference drives
+(src/histopathology_gan.py:298-314, src/gan_utils.py:286-297).  torchgan itself is third-party
+and absent from the reference tree; behaviour follows SURVEY.md Appendix A:
+
+  * ``Trainer(models, losses_list, ..., device, ncritic, epochs, sample_size, checkpoints,
+    retain_checkpoints, recon, test_noise, nrow, **kwargs)``; unknown kwargs become attributes
+    (the reference passes ``devices=[0]``);
+  * models / optimizers are built from ``{"name": cls, "args": {...}, "optimizer": {"name": cls,
+    "args": {...}}}`` and exposed as attributes ``generator``, ``optimizer_generator``, ...;
+  * per batch every loss's ``train_ops`` is called with arguments resolved BY NAME from the
+    trainer's attributes (``loss.arg_map`` may rename); losses run in list order, generator losses
+    only every ``ncritic`` discriminator iterations;
+  * per epoch: checkpoint ``<checkpoints><k>.model`` (k cycling), console summary, sample grid
+    ``<recon>/epoch<e+1>_generator.png`` from the generator in eval mode;
+  * checkpoint dict keys: epoch, loss_information, loss_objects, metric_objects, loss_logs,
+    metric_logs, <model>, optimizer_<model>.
+
+Data parallel: one process per GPU; rank 0's parameters are broadcast at start, gradients are
+all-reduced inside the losses, only rank 0 writes checkpoints / images.
+"""
+from __future__ import annotations
+
+import os
+from inspect import signature
+
+import torch
+
+from . import dist as D_
+from . import losses as L
+from . import optim
+
+
+class Trainer:
+    def __init__(self, models, losses_list, metrics_list=None, device=torch.device("cuda:0"), ncritic=1, epochs=5,
+                 sample_size=8, checkpoints="./model/gan", retain_checkpoints=5, recon="./images", log_dir=None,
+                 test_noise=None, nrow=8, precision="bf16", **kwargs):
+        self.device = torch.device(device)
+        self.model_names = []
+        self.optimizer_names = []
+        self.schedulers = []
+        for key, cfg in models.items():
+            self.model_names.append(key)
+            model = cfg["name"](**cfg.get("args", {}))
+            if hasattr(model, "set_precision"):
+                model.set_precision(precision)
+            model = model.to(self.device)
+            setattr(self, key, model)
+            opt_cfg = cfg["optimizer"]
+            opt_cls = opt_cfg["name"]
+            if opt_cls is torch.optim.Adam:
+                opt_cls = optim.Adam                       # same update rule, fused HIP kernel
+            opt = opt_cls(model.parameters(), **opt_cfg.get("args", {}))
+            if isinstance(opt, optim.Adam):
+                opt.bind(model)
+            opt_name = "optimizer_{}".format(key)
+            setattr(self, opt_name, opt)
+            self.optimizer_names.append(opt_name)
+            if "scheduler" in cfg:
+                sch = cfg["scheduler"]
+                self.schedulers.append(sch["name"](opt, **sch.get("args", {})))
+        for m in self.model_names:                         # identical replicas in a data-parallel run
+            mod = getattr(self, m)
+            for t in list(mod.parameters()) + list(mod.buffers()):
+                D_.broadcast_(t.data, 0)
+        self.losses = {}
+        for loss in losses_list:
+            self.losses[type(loss).__name__] = loss
+        self.metrics = {} if metrics_list is None else {type(m).__name__: m for m in metrics_list}
+        self.sample_size = sample_size
+        self.nrow = nrow
+        self.checkpoints = checkpoints
+        self.retain_checkpoints = retain_checkpoints
+        self.recon = recon
+        self.log_dir = log_dir
+        self.test_noise = test_noise
+        self.loss_information = {"generator_losses": 0.0, "discriminator_losses": 0.0,
+                                 "generator_iters": 0, "discriminator_iters": 0}
+        self.loss_logs = {name: [] for name in self.losses}
+        self.metric_logs = {}
+        self.ncritic = ncritic
+        self.start_epoch = 0
+        self.last_retained_checkpoint = 0
+        self.epochs = epochs
+        self.batch_size = None
+        self.real_inputs = None
+        self.labels = None
+        self.noise = None
+        for k, v in kwargs.items():
+            if k not in self.__dict__:
+                setattr(self, k, v)
+        os.makedirs(os.path.dirname(self.checkpoints) or ".", exist_ok=True) if D_.rank() == 0 else None
+        if D_.rank() == 0 and self.recon:
+            os.makedirs(self.recon, exist_ok=True)
+
+    # ------------------------------------------------------------------ checkpoints
+    def save_model(self, epoch, save_items=None):
+        if D_.rank() != 0:
+            return
+        if self.last_retained_checkpoint == self.retain_checkpoints:
+            self.last_retained_checkpoint = 0
+        save_path = self.checkpoints + str(self.last_retained_checkpoint) + ".model"
+        self.last_retained_checkpoint += 1
+        print("Saving Model at '{}'".format(save_path))
+        model = {"epoch": epoch + 1, "loss_information": self.loss_information, "loss_objects": self.losses,
+                 "metric_objects": self.metrics, "loss_logs": self.loss_logs, "metric_logs": self.metric_logs}
+        for save_item in self.model_names + self.optimizer_names:
+            model.update({save_item: getattr(self, save_item).state_dict()})
+        if save_items is not None:
+            for it in ([save_items] if isinstance(save_items, str) else save_items):
+                model.update({it: getattr(self, it)})
+        torch.save(model, save_path)
+
+    def load_model(self, load_path="", load_items=None):
+        if load_path == "":
+            load_path = self.checkpoints + str(self.last_retained_checkpoint) + ".model"
+        print("Loading Model From '{}'".format(load_path))
+        try:
+            checkpoint = torch.load(load_path, map_location="cpu", weights_only=False)
+            self.start_epoch = checkpoint["epoch"]
+            self.loss_information = checkpoint.get("loss_information", self.loss_information)
+            # loss_objects / metric_objects of a reference checkpoint are pickled torchgan objects; they are
+            # tolerated-if-unloadable: the live loss objects are kept.
+            self.loss_logs = checkpoint.get("loss_logs", self.loss_logs)
+            self.metric_logs = checkpoint.get("metric_logs", self.metric_logs)
+            for load_item in self.model_names + self.optimizer_names:
+                getattr(self, load_item).load_state_dict(checkpoint[load_item])
+            if load_items is not None:
+                for it in ([load_items] if isinstance(load_items, str) else load_items):
+                    setattr(self, it, checkpoint[it])
+        except Exception as e:  # torchgan prints and continues; a silent restart would hide corruption
+            raise RuntimeError("Model could not be loaded from {}: {}".format(load_path, e))
+
+    # ------------------------------------------------------------------ loop
+    def _get_argument_maps(self, default_map, func):
+        sig = signature(func)
+        arg_map = dict(default_map)
+        for sig_param in sig.parameters:
+            if sig_param not in arg_map:
+                arg_map[sig_param] = sig_param
+        return arg_map
+
+    def _get_arguments(self, arg_map):
+        return dict(zip(arg_map.keys(), map(lambda x: getattr(self, x), arg_map.values())))
+
+    def _store_loss_maps(self):
+        self._arg_maps = {name: self._get_argument_maps(loss.arg_map, loss.train_ops)
+                          for name, loss in self.losses.items()}
+
+    def train_iter(self):
+        lgen, ldis, gen_iter, dis_iter = 0.0, 0.0, 0, 0
+        for name, loss in self.losses.items():
+            if isinstance(loss, L.GeneratorLoss) and isinstance(loss, L.DiscriminatorLoss):
+                raise NotImplementedError("joint generator/discriminator losses are not on the RNA-GAN path")
+            if isinstance(loss, L.GeneratorLoss):
+                if self.loss_information["discriminator_iters"] % self.ncritic == 0:
+                    cur = loss.train_ops(**self._get_arguments(self._arg_maps[name]))
+                    self.loss_logs[name].append(cur)
+                    lgen += cur
+                    gen_iter += 1
+            elif isinstance(loss, L.DiscriminatorLoss):
+                cur = loss.train_ops(**self._get_arguments(self._arg_maps[name]))
+                self.loss_logs[name].append(cur)
+                ldis += cur
+                dis_iter += 1
+        return lgen, ldis, gen_iter, dis_iter
+
+    def sample_images(self, epoch):
+        if D_.rank() != 0 or not self.recon:
+            return
+        gen = self.generator
+        was_training = gen.training
+        gen.eval()
+        with torch.no_grad():
+            img = gen(self.test_noise[0] if isinstance(self.test_noise, (list, tuple)) else self.test_noise)
+        gen.train(was_training)
+        save_image_grid(img, "{}/epoch{}_generator.png".format(self.recon, epoch + 1), nrow=self.nrow)
+
+    def train(self, data_loader, **kwargs):
+        for name in self.model_names:
+            getattr(self, name).train()
+        self._store_loss_maps()
+        if self.test_noise is None:
+            self.test_noise = self.generator.sampler(self.sample_size, self.device)
+        for epoch in range(self.start_epoch, self.epochs):
+            for name in self.model_names:
+                getattr(self, name).train()
+            for data in data_loader:
+                if isinstance(data, (tuple, list)):
+                    self.real_inputs = data[0].to(self.device)
+                    self.labels = data[1].to(self.device)
+                elif isinstance(data, torch.Tensor):
+                    self.real_inputs = data.to(self.device)
+                else:
+                    self.real_inputs = data
+                lgen, ldis, gen_iter, dis_iter = self.train_iter()
+                self.loss_information["generator_losses"] += lgen
+                self.loss_information["discriminator_losses"] += ldis
+                self.loss_information["generator_iters"] += gen_iter
+                self.loss_information["discriminator_iters"] += dis_iter
+            self.save_model(epoch)
+            if D_.rank() == 0:
+                gi = max(self.loss_information["generator_iters"], 1)
+                di = max(self.loss_information["discriminator_iters"], 1)
+                print("Epoch {} Summary\ngenerator Mean Loss : {}\ndiscriminator Mean Loss : {}".format(
+                    epoch + 1, self.loss_information["generator_losses"] / gi,
+                    self.loss_information["discriminator_losses"] / di))
+            self.sample_images(epoch)
+            for sch in self.schedulers:
+                sch.step()
+        print("Training of the Model is Complete") if D_.rank() == 0 else None
+
+    def __call__(self, data_loader, **kwargs):
+        self.batch_size = data_loader.batch_size
+        self.train(data_loader, **kwargs)
+
+
+def save_image_grid(img, path, nrow=8, pad=2):
+    """torchvision.utils.save_image(img, path, nrow, normalize=True) without torchvision: min-max
+    normalisation over the whole batch, zero-padded grid, 8-bit PNG."""
+    from PIL import Image
+    x = img.detach().float().cpu()
+    lo, hi = float(x.min()), float(x.max())
+    x = (x - lo) / max(hi - lo, 1e-5)
+    n, c, h, w = x.shape
+    ncol = min(nrow, n)
+    nrows = (n + ncol - 1) // ncol
+    grid = torch.zeros(c, nrows * (h + pad) + pad, ncol * (w + pad) + pad)
+    for i in range(n):
+        r, q = divmod(i, ncol)
+        grid[:, pad + r * (h + pad): pad + r * (h + pad) + h, pad + q * (w + pad): pad + q * (w + pad) + w] = x[i]
+    arr = (grid.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8)).numpy()
+    if c == 1:
+        arr = arr[:, :, 0]
+    Image.fromarray(arr).save(path)

@@ -219,8 +219,8 @@ def test_pointwise_reductions_adam():
         g = g0 * step
         pt.grad = g.clone(); opt.step()
         hip.adam_step(p, dev(g), m, v, step, 4e-4, 0.5, 0.999, 1e-8)
-    check(p, pt.detach(), 1e-6, "adam p")
-    check(m, opt.state[pt]["exp_avg"], 1e-6, "adam m"); check(v, opt.state[pt]["exp_avg_sq"], 1e-6, "adam v")
+    check(p, pt.detach(), 2e-6, "adam p")
+    check(m, opt.state[pt]["exp_avg"], 2e-6, "adam m"); check(v, opt.state[pt]["exp_avg_sq"], 2e-6, "adam v")
     q = dev(p0.clone()); hip.clamp_(q, -0.01, 0.01)
     check(q, p0.clamp(-0.01, 0.01), 1e-7, "clamp")
 

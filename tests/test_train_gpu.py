@@ -1,0 +1,161 @@
+"""GPU parity of the PRODUCT path (rna_gan_amd modules / losses / optimizer through the C ABI):
+  * against the golden fixture produced by the reference's own *LossVAE.train_ops
+    (tests/golden/f5_trainops_vae.npz, made by importing /root/reference/src/wgan_loss.py);
+  * against the CPU oracle for two full iterations at a mid-size config (fp32 and bf16 paths);
+  * full-size (256x256, reference model) one iteration in bf16: finite, losses near the oracle.
+"""
+import copy
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as R
+import rna_gan_amd as P
+from rna_gan_amd import losses as PL
+
+DIGEST_OVER = 20000
+
+
+def digest(t):
+    a = t.detach().float().cpu().numpy()
+    if a.size <= DIGEST_OVER:
+        return a
+    f = a.reshape(-1).astype(np.float64)
+    return np.concatenate([[f.sum(), (f * f).sum()], f[:64], f[-64:]])
+
+
+def l2rel(a, b):
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def product_pair(in_size, step, enc, precision, G_src, D_src):
+    G = P.DCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+    D = P.DCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.LeakyReLU(0.2))
+    G.load_state_dict(G_src.state_dict()); D.load_state_dict(D_src.state_dict())
+    G.set_precision(precision); D.set_precision(precision)
+    G, D = G.cuda().train(), D.cuda().train()
+    og = P.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.999)).bind(G)
+    od = P.Adam(D.parameters(), lr=4e-4, betas=(0.5, 0.999)).bind(D)
+    return G, D, og, od
+
+
+def test_reference_trainops_fixture(golden_dir):
+    """Our *LossVAE.train_ops (HIP, fp32 path) vs what the REFERENCE's train_ops produced."""
+    fx = np.load(os.path.join(golden_dir, "f5_trainops_vae.npz"))
+    RNA_F, bs = 64, 6
+    G0 = R.seeded_fill_(R.OracleDCGANGenerator(2048, 16, 3, 4, nonlinearity=nn.LeakyReLU(0.2),
+                                               last_nonlinearity=nn.Tanh()), 31)
+    D0 = R.seeded_fill_(R.OracleDCGANDiscriminator(16, 3, 4, nonlinearity=nn.LeakyReLU(0.2),
+                                                   last_nonlinearity=nn.LeakyReLU(0.2)), 21)
+    G, D, og, od = product_pair(16, 4, 2048, "fp32", G0, D0)
+    bv = R.seeded_fill_(R.OracleBetaVAE(RNA_F, 2048, [6000, 4000, 2048], [4000, 6000]), 51)
+    with tempfile.TemporaryDirectory() as td:
+        ck = os.path.join(td, "bv.pt")
+        torch.save(bv.state_dict(), ck)
+        lg = PL.WassersteinGeneratorLossVAE(checkpoint=ck, rna_features=RNA_F)
+        ld = PL.WassersteinDiscriminatorLossVAE(checkpoint=ck, rna_features=RNA_F)
+        lp = PL.WassersteinGradientPenaltyVAE(checkpoint=ck, rna_features=RNA_F)
+    for l in (lg, ld, lp):
+        l.betavae.set_precision("fp32")
+    assert isinstance(lg.reduction, str) and lg.override_train_ops == RNA_F and lp.lambd == 10.0 and ld.clip is None
+    dev = torch.device("cuda:0")
+    call = 0
+    for it in range(2):
+        batch = {"image": R.synthetic_images(bs, 16, seed=60 + it),
+                 "rna_data": R.synthetic_rna(bs, RNA_F, seed=70 + it, distinct=3)}
+        for tag, fn in (("g", lambda: lg.train_ops(G, D, og, dev, bs, batch)),
+                        ("d", lambda: ld.train_ops(G, D, od, batch, dev)),
+                        ("gp", lambda: lp.train_ops(G, D, od, batch, dev))):
+            torch.manual_seed(1000 + call)      # the reference run was seeded the same way per call
+            loss = fn()
+            ref = float(fx[f"loss.{it}.{tag}"])
+            assert abs(loss - ref) <= 2e-3 * (abs(ref) + 1e-2), (it, tag, loss, ref)
+            call += 1
+    for k, v in G.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(fx["G." + k]); continue
+        assert l2rel(digest(v), fx["G." + k]) <= 2e-3, "G." + k
+    for k, v in D.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(fx["D." + k]); continue
+        assert l2rel(digest(v), fx["D." + k]) <= 2e-3, "D." + k
+    for nm, opt, mod in (("optG", og, G), ("optD", od, D)):
+        sd = opt.state_dict()["state"]
+        for i, (k, _) in enumerate(mod.named_parameters()):
+            assert float(sd[i]["step"]) == float(fx[f"{nm}.{k}.step"])
+            assert l2rel(digest(sd[i]["exp_avg"]), fx[f"{nm}.{k}.exp_avg"]) <= 5e-3, f"{nm}.{k}.exp_avg"
+            assert l2rel(digest(sd[i]["exp_avg_sq"]), fx[f"{nm}.{k}.exp_avg_sq"]) <= 1e-2, f"{nm}.{k}.exp_avg_sq"
+
+
+@pytest.mark.parametrize("precision,tol_loss,tol_p", [("fp32", 2e-3, 2e-3), ("bf16", 5e-2, 2.5e-1)])
+def test_two_iterations_vs_oracle(precision, tol_loss, tol_p):
+    """Two full iterations (3 optimizer steps each) at in_size 32 / step 64 / enc 128, batch 16.
+    Compared quantity for parameters: the UPDATE (p_after - p_before), L2-relative."""
+    in_size, step, enc, n = 32, 64, 128, 16
+    G0 = R.seeded_fill_(R.OracleDCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                               last_nonlinearity=nn.Tanh()), 7)
+    D0 = R.seeded_fill_(R.OracleDCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                                   last_nonlinearity=nn.LeakyReLU(0.2)), 8)
+    Go, Do = copy.deepcopy(G0).train(), copy.deepcopy(D0).train()
+    ogo, odo = R.make_adam(Go.parameters(), 1e-4), R.make_adam(Do.parameters(), 4e-4)
+    G, D, og, od = product_pair(in_size, step, enc, precision, G0, D0)
+    for it in range(2):
+        real = R.synthetic_images(n, in_size, seed=100 + it)
+        noises = [R.synthetic_normal(n, enc, seed=200 + 3 * it + j) for j in range(3)]
+        eps = 0.25 + 0.5 * it
+        ref = R.train_iteration(Go, Do, ogo, odo, real, noises, eps, clip=(-0.01, 0.01) if it == 1 else None)
+        rd = real.cuda()
+        lg = PL._g_step(G, D, og, noises[0].cuda()).item()
+        ld = PL._d_step(G, D, od, rd, noises[1].cuda(), (-0.01, 0.01) if it == 1 else None).item()
+        lp = PL._gp_step(G, D, od, rd, noises[2].cuda(), eps, 10.0).item()
+        for got, want, nm in ((lg, ref["g"], "g"), (ld, ref["d"], "d"), (lp, ref["gp"], "gp")):
+            assert np.isfinite(got) and abs(got - want) <= tol_loss * (abs(want) + 0.05), (it, nm, got, want)
+        if it == 0:
+            for mod, ref_mod, src in ((G, Go, G0), (D, Do, D0)):
+                for (k, p), (_, q), (_, s) in zip(mod.named_parameters(), ref_mod.named_parameters(),
+                                                  src.named_parameters()):
+                    du, dr = p.detach().cpu() - s.detach(), q.detach() - s.detach()
+                    # Adam's first steps move every weight by ~lr*sign(g): compare update directions
+                    cos = float((du * dr).sum() / (du.norm() * dr.norm() + 1e-30))
+                    assert cos >= 1 - tol_p, (k, cos)
+    for mod, ref_mod in ((G, Go), (D, Do)):
+        for (k, b), (_, q) in zip(mod.named_buffers(), ref_mod.named_buffers()):
+            if k.endswith("num_batches_tracked"):
+                assert int(b) == int(q), k
+            else:
+                assert l2rel(b.cpu().numpy(), q.numpy()) <= (5e-4 if precision == "fp32" else 3e-2), k
+
+
+def test_full_size_one_iteration_bf16():
+    """Reference model size (enc 2048, step 64, 256x256), batch 8, bf16 MFMA path: runs, finite,
+    losses close to the fp32 CPU oracle."""
+    in_size, step, enc, n = 256, 64, 2048, 8
+    G0 = R.seeded_fill_(R.OracleDCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                               last_nonlinearity=nn.Tanh()), 17)
+    D0 = R.seeded_fill_(R.OracleDCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                                   last_nonlinearity=nn.LeakyReLU(0.2)), 18)
+    Go, Do = copy.deepcopy(G0).train(), copy.deepcopy(D0).train()
+    ogo, odo = R.make_adam(Go.parameters(), 1e-4), R.make_adam(Do.parameters(), 4e-4)
+    G, D, og, od = product_pair(in_size, step, enc, "bf16", G0, D0)
+    real = R.synthetic_images(n, in_size, seed=300)
+    noises = [R.synthetic_normal(n, enc, seed=400 + j) for j in range(3)]
+    ref = R.train_iteration(Go, Do, ogo, odo, real, noises, 0.4)
+    rd = real.cuda()
+    lg = PL._g_step(G, D, og, noises[0].cuda()).item()
+    ld = PL._d_step(G, D, od, rd, noises[1].cuda(), None).item()
+    lp = PL._gp_step(G, D, od, rd, noises[2].cuda(), 0.4, 10.0).item()
+    print("full-size losses hip/ref:", lg, ref["g"], ld, ref["d"], lp, ref["gp"])
+    for got, want in ((lg, ref["g"]), (ld, ref["d"]), (lp, ref["gp"])):
+        assert np.isfinite(got) and abs(got - want) <= 6e-2 * (abs(want) + 0.1)
+    for p in list(G.parameters()) + list(D.parameters()):
+        assert torch.isfinite(p).all()
+    img = G(noises[0].cuda())
+    assert img.shape == (n, 3, 256, 256) and torch.isfinite(img).all() and float(img.abs().max()) <= 1.0
