@@ -66,11 +66,26 @@ def build(device, precision, batch, rna_features, seed):
     G, D = G.to(device).train(), D.to(device).train()
     og = P.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.999)).bind(G)
     od = P.Adam(D.parameters(), lr=4e-4, betas=(0.5, 0.999)).bind(D)
-    bv = P.betaVAE(rna_features, 2048, [6000, 4000, 2048], [4000, 6000], beta=0.005)
-    R.seeded_fill_(bv, seed + 2)
-    bv.set_precision(precision)
-    bv = bv.to(device).eval()
-    return G, D, og, od, bv
+    # the three loss plugins of --loss_type wganvae, each with its own frozen betaVAE copy as in the
+    # reference (src/histopathology_gan.py:273-278); seeded weights instead of a checkpoint file
+    lg = P.WassersteinGeneratorLossVAE(checkpoint=None, rna_features=rna_features)
+    ld = P.WassersteinDiscriminatorLossVAE(checkpoint=None, rna_features=rna_features)
+    lp = P.WassersteinGradientPenaltyVAE(checkpoint=None, rna_features=rna_features)
+    R.seeded_fill_(lg.betavae, seed + 2)
+    sd = lg.betavae.state_dict()
+    for l in (lg, ld, lp):
+        if l is not lg:
+            l.betavae.load_state_dict(sd)
+        l.betavae.set_precision(precision)
+        l.betavae = l.betavae.to(device).eval()
+    return G, D, og, od, (lg, ld, lp)
+
+
+def log(*a):
+    print("[bench %.1fs]" % (time.perf_counter() - _T0), *a, file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
 
 
 def main():
@@ -88,6 +103,7 @@ def main():
     from rna_gan_amd import dist as D_
     from rna_gan_amd import losses as PL
     from oracle import ref_cpu as R
+    torch.set_num_threads(min(8, torch.get_num_threads()))   # host side only draws noise; avoid 100+ idle threads
     D_.init_from_env()
     rank, world = D_.rank(), D_.world_size()
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -96,7 +112,7 @@ def main():
 
     N = args.batch
     rna_features = 19198
-    G, Dm, og, od, bv = build(device, args.precision, N, rna_features, args.seed)
+    G, Dm, og, od, (lg, ld, lp) = build(device, args.precision, N, rna_features, args.seed)
     for mod in (G, Dm):
         for t in list(mod.parameters()) + list(mod.buffers()):
             D_.broadcast_(t.data, 0)
@@ -107,43 +123,47 @@ def main():
     gen = torch.Generator(device="cpu").manual_seed(args.seed + rank)
     ops, _ = G.runtime()
 
+    def draw_u():
+        # U(-0.3, 0.3) on the CPU generator (src/wgan_loss.py:100), written in place into a pinned
+        # buffer so that the H2D copy is asynchronous and the host can run ahead of the GPU
+        return torch.empty(N, 2048, pin_memory=True).uniform_(-0.3, 0.3, generator=gen).to(device, non_blocking=True)
+
+    def draw_eps():
+        return torch.empty(1, pin_memory=True).uniform_(0.0, 1.0, generator=gen).to(device, non_blocking=True)
+
     def one_step():
-        # the three train_ops bodies (src/wgan_loss.py:82-129,181-263,314-389); fresh uniform noise and
-        # a betaVAE encode per train_op, eps ~ U(0,1) per GP step, as the reference does
-        losses = []
-        for tag in ("g", "d", "gp"):
-            z = bv.encode(rna)[0]
-            u = (torch.rand(N, 2048, generator=gen) * 0.6 - 0.3).to(device, non_blocking=True)
-            noise = ops.latent_prep(u, z)
-            if tag == "g":
-                losses.append(PL._g_step(G, Dm, og, noise))
-            elif tag == "d":
-                losses.append(PL._d_step(G, Dm, od, real, noise, None))
-            else:
-                eps = float(torch.rand(1, generator=gen))
-                losses.append(PL._gp_step(G, Dm, od, real, noise, eps, 10.0))
-        return losses
+        # the three train_ops of src/wgan_loss.py:82-129,181-263,314-389 in Trainer order, through the
+        # loss plugins' step() (= train_ops without the final .item() host sync): per train_op a fresh
+        # uniform draw on the CPU generator, a betaVAE encode, and eps ~ U(0,1) for the penalty
+        return [lg.step(G, Dm, og, rna, draw_u()),
+                ld.step(G, Dm, od, real, rna, draw_u()),
+                lp.step(G, Dm, od, real, rna, draw_u(), draw_eps())]
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
 
+    log("models built; warm-up")
     for _ in range(args.warmup):
         one_step()
     barrier()
+    log("warm-up done; timing %d steps" % args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ls = one_step()
     barrier()
     dt = time.perf_counter() - t0
     last_losses = [float(l.item()) for l in ls]
+    from rna_gan_amd import graphed as _gr
+    out_graphs = bool(_gr.ENABLED)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = N * world * args.steps / dt
+    log("timed region: %.3f ms/step, %.1f imgs/s" % (ms_per_step, value))
 
     out = {
         "metric": "training imgs/sec (G+D WGAN-GP step, 256x256)",
@@ -153,7 +173,7 @@ def main():
         "config": {"workload": "RNA-GAN lung (betaVAE-conditioned wganvae path) 256x256, DCGAN enc2048/step64, "
                                "per-GPU batch %d, one iteration = G-loss + D-loss + GP steps" % N,
                    "global_batch": N * world, "parallelism": "dp%d" % world, "rna_features": rna_features,
-                   "losses_last_step": last_losses},
+                   "losses_last_step": last_losses, "hip_graphs": out_graphs},
     }
 
     # the instrumented extra iteration contains collectives in a data-parallel run: every rank runs it
@@ -182,9 +202,13 @@ def measure_roofline(ops, device, one_step, step_ms):
     `achieved` = algorithmic FLOPs of the family's launches / their summed duration (SURVEY 8d:
     2*N*Ho*Wo*Cout*Cin*16 per launch).  The dominant family (largest share of the iteration) is the
     one reported; the other is listed under `others`."""
+    from rna_gan_amd import graphed
+    was = graphed.ENABLED
+    graphed.ENABLED = False            # per-launch events need eager launches (not a graph replay)
     ops.timing = []
     one_step()
     torch.cuda.synchronize(device)
+    graphed.ENABLED = was
     fam = {}
     for key, flops, e0, e1 in ops.timing:
         f = fam.setdefault(key, {"launches": 0, "flops": 0.0, "ms": 0.0})
@@ -214,8 +238,13 @@ def cpu_baseline(seed):
     src/histopathology_gan.py:94), fp32, all cores, 1 warm-up + 2 timed iterations."""
     import torch.nn as nn
     from oracle import ref_cpu as R
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, torch.get_num_threads() if torch.get_num_threads() > 0 else cores))
     torch.set_num_threads(cores)
+    log("cpu baseline on %d threads" % cores)
     n = 8
     G = R.seeded_fill_(R.OracleDCGANGenerator(2048, 256, 3, 64, nonlinearity=nn.LeakyReLU(0.2),
                                               last_nonlinearity=nn.Tanh()), seed).train()
@@ -230,6 +259,9 @@ def cpu_baseline(seed):
         t0 = time.perf_counter()
         R.train_iteration(G, D, og, od, real, noises, 0.5)
         times.append(time.perf_counter() - t0)
+        log("cpu baseline iteration %d: %.2f s" % (it, times[-1]))
+        if it >= 1 and sum(times) > 60:
+            break
     t = sum(times[1:]) / len(times[1:])
     return {"value": round(n / t, 3), "unit": "imgs/sec", "cores": cores, "kind": "port",
             "sample": "oracle/ref_cpu.py (PyTorch fp32 restatement of the reference path, betaVAE encode "

@@ -186,6 +186,8 @@ int rg_nchw_chan_sum(const float* g, float* out, int N, int C, int HW, int accum
                      void* stream);
 /* xhat = eps*real + (1-eps)*fake (wgan_loss.py:377) */
 int rg_interp(const float* real, const float* fake, float* out, size_t n, float eps, void* stream);
+/* graph-replayable variant: eps read from device memory */
+int rg_interp_dev(const float* real, const float* fake, float* out, size_t n, const float* eps, void* stream);
 /* out[0] = sum x^2 (fp32 result, pairwise/blocked accumulation; deterministic) */
 size_t rg_reduce_workspace_bytes(size_t n);
 int rg_sqnorm(const float* x, float* out, size_t n, void* ws, size_t ws_bytes, void* stream);
@@ -208,6 +210,13 @@ int rg_latent_prep(const float* u, const float* z, float* out, int N, int E, voi
 int rg_adam_step(float* p, const float* g, float* m, float* v, size_t n, int step, double lr, double beta1,
                  double beta2, double eps, void* stream);
 int rg_clamp(float* p, size_t n, float lo, float hi, void* stream);
+/* Same update with the step-dependent constants read from DEVICE memory, so the launch can live in
+ * a captured HIP graph and be replayed every step: hyper[0..6] = {beta1, beta2, 1-beta1, 1-beta2, eps,
+ * lr/bias_correction1, 1/sqrt(bias_correction2)}, produced by rg_adam_hyper_dev. */
+int rg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, void* stream);
+/* ++(*step_dev) and recompute hyper[0..6] from it on the device (double arithmetic, one thread): with
+ * this launch in front of rg_adam_step_dev the whole optimizer step replays from a graph untouched. */
+int rg_adam_hyper_dev(int* step_dev, double lr, double beta1, double beta2, double eps, float* hyper, void* stream);
 
 /* fp32 -> dtype cast with optional row padding: dst[M][ldd] = src[M][K] (pad columns zeroed) */
 int rg_cast_pad(const float* src, void* dst, int M, int K, int ldd, int dtype, void* stream);

@@ -72,13 +72,14 @@ class RefOps:
             dw.copy_(g)
 
     def first_down(self, x_nchw, cw: ConvW, bias, slope: float):
-        y = F.conv2d(x_nchw.to(self.f), self._wq(cw.w), bias, stride=2, padding=1)
+        # image-side layers use the fp32 master weights (no bf16 rounding), like the HIP kernels
+        y = F.conv2d(x_nchw.to(self.f), cw.w.to(self.f), bias, stride=2, padding=1)
         if slope != 1.0:
             y = F.leaky_relu(y, slope)
         return _nhwc(y, self.act_dtype)
 
     def last_up(self, x, cw: ConvW, bias, tanh: bool):
-        y = F.conv_transpose2d(self._nchw(x), self._wq(cw.w), bias, stride=2, padding=1)
+        y = F.conv_transpose2d(self._nchw(x), cw.w.to(self.f), bias, stride=2, padding=1)
         return torch.tanh(y) if tanh else y.contiguous()
 
     def skinny_wgrad(self, low, high_nchw, dw, accumulate: bool):
@@ -231,7 +232,7 @@ class RefOps:
         else:
             out.copy_(s)
 
-    def interp(self, real, fake, eps: float):
+    def interp(self, real, fake, eps):
         return eps * real + (1 - eps) * fake
 
     def sqnorm(self, x):

@@ -65,6 +65,12 @@ class betaVAE(nn.Module):
         self._plan = None
         return r
 
+    def __getstate__(self):          # pickled inside loss objects in checkpoints: drop runtime handles
+        d = dict(self.__dict__)
+        d["_plan"] = None
+        d["_ops"] = None
+        return d
+
     def _build_plan(self):
         from .ops_hip import HipOps
         dev = self.z_mu.weight.device

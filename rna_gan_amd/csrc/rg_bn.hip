@@ -15,11 +15,12 @@ static CRPlan cr_plan(int M, int C, int vec) {
   CRPlan p;
   int cvec = (C + vec - 1) / vec;
   p.gx = (cvec + CR_TX - 1) / CR_TX;
-  int want = (2048 + p.gx - 1) / p.gx;
+  // enough row-chunks to fill 256 CUs x 4-8 blocks, but few enough that the finishing pass stays tiny
+  int want = (1536 + p.gx - 1) / p.gx;
   int maxg = (M + 4 * CR_TY - 1) / (4 * CR_TY);
   p.gy = want < maxg ? want : maxg;
   if (p.gy < 1) p.gy = 1;
-  if (p.gy > 4096) p.gy = 4096;
+  if (p.gy > 512) p.gy = 512;
   p.rows_per_block = (M + p.gy - 1) / p.gy;
   p.gy = (M + p.rows_per_block - 1) / p.rows_per_block;
   return p;
@@ -58,17 +59,35 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, int M, int C, int r
   }
 }
 
+// finishing pass: block = 32 channels x 8 partial-row lanes; each lane strides over the G partial rows
+// (independent loads, pipelined), LDS tree over the 8 lanes, lane 0 applies the finisher.
 template <int NQ, class Fin>
-__global__ void colfinish_kernel(Fin fin, const float* partial, int C, int G) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void colfinish_kernel(Fin fin, const float* partial, int C, int G) {
+  __shared__ float sm[8][NQ][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tx;
   float s[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) s[q] = 0.f;
-  for (int g = 0; g < G; ++g)
+  if (c < C) {
+#pragma unroll 4
+    for (int g = ty; g < G; g += 8)
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) s[q] += partial[((size_t)g * NQ + q) * C + c];
-  fin(c, s);
+      for (int q = 0; q < NQ; ++q) s[q] += partial[((size_t)g * NQ + q) * C + c];
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) sm[ty][q][tx] = s[q];
+  __syncthreads();
+  if (ty == 0 && c < C) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += sm[k][q][tx];
+      s[q] = t;
+    }
+    fin(c, s);
+  }
 }
 
 template <int NQ, template <int> class F, class Fin, class... Args>
@@ -88,7 +107,7 @@ int col_reduce(const char* name, int M, int C, void* ws, size_t ws_bytes, hipStr
                        partial);
   }
   RG_LAUNCH_CHECK(name);
-  hipLaunchKernelGGL((colfinish_kernel<NQ, Fin>), dim3((C + 255) / 256), dim3(256), 0, st, fin, partial, C, p.gy);
+  hipLaunchKernelGGL((colfinish_kernel<NQ, Fin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, partial, C, p.gy);
   RG_LAUNCH_CHECK(name);
   return RG_OK;
 }

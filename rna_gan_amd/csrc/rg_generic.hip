@@ -331,7 +331,7 @@ int rg_generic_first_down(const float* x, const float* w, const float* bias, voi
                           int O, float slope, int dtype, hipStream_t st) {
   Geo g{N, H / 2, W / 2, H, W, O, I};
   RG_DISPATCH_DTYPE(dtype, T, {
-    return launch_generic<true, true>("first_down(generic)", FirstDownA{x, g}, DownB<T>{w, g},
+    return launch_generic<true, true>("first_down(generic)", FirstDownA{x, g}, DownB<float>{w, g},
                                       BiasActC<T>{(T*)y, bias, slope, O}, N * g.Hl * g.Wl, O, I * 16, 1, 1, st);
   })
 }
@@ -340,7 +340,7 @@ int rg_generic_last_up(const void* x, const float* w, const float* bias, float* 
                        int I, int apply_tanh, int dtype, hipStream_t st) {
   Geo g{N, Ho, Wo, 2 * Ho, 2 * Wo, O, I};
   RG_DISPATCH_DTYPE(dtype, T, {
-    return launch_generic<true, false>("last_up(generic)", UpA<T>{(const T*)x, g}, UpB<T>{w, g},
+    return launch_generic<true, false>("last_up(generic)", UpA<T>{(const T*)x, g}, UpB<float>{w, g},
                                        UpCNchw{y, bias, apply_tanh, g}, N * Ho * Wo, I, O * 4, 4, 1, st);
   })
 }

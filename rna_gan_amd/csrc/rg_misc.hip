@@ -42,6 +42,15 @@ struct Interp {
   }
   __device__ void one(size_t i) const { o[i] = eps * r[i] + (1.f - eps) * f[i]; }
 };
+struct InterpDev {
+  const float* r; const float* f; float* o; const float* eps;
+  __device__ void vec(size_t i) const {
+    float4 a = *(const float4*)(r + i), b = *(const float4*)(f + i);
+    float e = eps[0], e1 = 1.f - e;
+    *(float4*)(o + i) = make_float4(e * a.x + e1 * b.x, e * a.y + e1 * b.y, e * a.z + e1 * b.z, e * a.w + e1 * b.w);
+  }
+  __device__ void one(size_t i) const { float e = eps[0]; o[i] = e * r[i] + (1.f - e) * f[i]; }
+};
 struct ScaleBy {
   const float* x; const float* coef; float* o;
   __device__ void vec(size_t i) const {
@@ -78,6 +87,24 @@ struct Adam {
   }
   __device__ void one(size_t i) const { upd(p[i], g[i], m[i], v[i]); }
 };
+
+struct AdamDev {
+  float* p; const float* g; float* m; float* v; const float* hyper;
+  __device__ __forceinline__ Adam load() const {
+    return Adam{p, g, m, v, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6]};
+  }
+  __device__ void vec(size_t i) const { load().vec(i); }
+  __device__ void one(size_t i) const { load().one(i); }
+};
+
+__global__ void adam_hyper_kernel(int* step_dev, double lr, double b1, double b2, double eps, float* hyper) {
+  int step = *step_dev + 1;
+  *step_dev = step;
+  double bc1 = 1.0 - pow(b1, (double)step);
+  double bc2 = 1.0 - pow(b2, (double)step);
+  hyper[0] = (float)b1; hyper[1] = (float)b2; hyper[2] = (float)(1.0 - b1); hyper[3] = (float)(1.0 - b2);
+  hyper[4] = (float)eps; hyper[5] = (float)(lr / bc1); hyper[6] = (float)(1.0 / sqrt(bc2));
+}
 
 // ---------------------------------------------------------------------------------- reductions
 // stage 1: each block writes one partial (double accumulation across a thread's strided elements is
@@ -256,6 +283,28 @@ extern "C" int rg_adam_step(float* p, const float* g, float* m, float* v, size_t
   Adam f{p, g, m, v, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
          (float)(lr / bc1), (float)(1.0 / sqrt(bc2))};
   EW_LAUNCH("adam_step", f, n, rg_stream(stream));
+}
+
+extern "C" int rg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* hyper,
+                                void* stream) {
+  RG_REQUIRE(p && g && m && v && hyper, RG_EINVAL, "adam_step_dev: bad args");
+  RG_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), RG_EINVAL, "adam_step_dev: alignment");
+  AdamDev f{p, g, m, v, hyper};
+  EW_LAUNCH("adam_step_dev", f, n, rg_stream(stream));
+}
+extern "C" int rg_adam_hyper_dev(int* step_dev, double lr, double beta1, double beta2, double eps, float* hyper,
+                                 void* stream) {
+  RG_REQUIRE(step_dev && hyper, RG_EINVAL, "adam_hyper_dev: bad args");
+  hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(1), 0, rg_stream(stream), step_dev, lr, beta1, beta2, eps, hyper);
+  RG_LAUNCH_CHECK("adam_hyper_dev");
+  return RG_OK;
+}
+extern "C" int rg_interp_dev(const float* real, const float* fake, float* out, size_t n, const float* eps,
+                             void* stream) {
+  RG_REQUIRE(real && fake && out && eps && aligned16(real) && aligned16(fake) && aligned16(out), RG_EINVAL,
+             "interp_dev: bad args");
+  InterpDev f{real, fake, out, eps};
+  EW_LAUNCH("interp_dev", f, n, rg_stream(stream));
 }
 
 extern "C" size_t rg_reduce_workspace_bytes(size_t n) { (void)n; return RED_BLOCKS * sizeof(float); }

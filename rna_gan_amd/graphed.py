@@ -1,0 +1,76 @@
+"""HIP-graph execution of a train_op.
+
+One train_op is ~180 kernel launches of 5-150 us each; issued from Python they cost more host time
+than device time.  A train_op's launch sequence is static for fixed shapes, so after two eager
+executions it is captured once (torch.cuda.CUDAGraph = hipGraph on ROCm; our kernels are enqueued on
+the capturing stream like any other) and replayed afterwards.  Everything that varies per step is
+read from device memory inside the graph: inputs are copied into static buffers before the replay,
+the Adam step counter / bias corrections and the penalty's eps are device scalars.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+ENABLED = os.environ.get("RNAGAN_GRAPHS", "1") != "0"
+WARMUP_CALLS = 2
+_POOL = None
+
+
+def _pool():
+    """One memory pool for all step graphs: they never run concurrently, so they share activations."""
+    global _POOL
+    if _POOL is None:
+        _POOL = torch.cuda.graph_pool_handle()
+    return _POOL
+
+
+class StepGraph:
+    """fn(*static_inputs) -> 1-element loss tensor, replayed from a captured graph.
+
+    ``modules``: HIP modules whose packed weights must be rebuilt at the start of the step (their
+    Python-side version counters are frozen inside a graph, so the step always repacks);
+    ``optimizers``: rna_gan_amd.optim.Adam instances stepped inside fn (host step mirror)."""
+
+    def __init__(self, fn, example_inputs, modules, optimizers):
+        self.fn = fn
+        self.static_in = [t.detach().clone() for t in example_inputs]
+        self.modules = modules
+        self.optimizers = optimizers
+        self.graph = None
+        self.static_out = None
+        self.calls = 0
+        self.failed = False
+
+    def _run(self):
+        for m in self.modules:
+            m.weights_changed()
+        return self.fn(*self.static_in)
+
+    def __call__(self, *inputs):
+        for s, t in zip(self.static_in, inputs):
+            if s.shape != t.shape:
+                raise RuntimeError("StepGraph: input shape changed")
+            s.copy_(t, non_blocking=True)
+        self.calls += 1
+        if self.failed or self.calls <= WARMUP_CALLS:
+            return self._run()
+        if self.graph is None:
+            try:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=_pool()):
+                    self.static_out = self._run()
+                self.graph = g
+            except Exception as e:  # capture unsupported (e.g. a collective that cannot be captured)
+                self.failed = True
+                print("rna_gan_amd: HIP graph capture failed (%s); continuing without graphs" % str(e)[:200])
+                torch.cuda.synchronize()
+                return self._run()
+        self.graph.replay()
+        for o in self.optimizers:
+            o.note_replayed()
+        for m in self.modules:
+            m.weights_changed()
+        return self.static_out

@@ -74,6 +74,10 @@ class DiscriminatorLoss(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # shared step bodies
 # ------------------------------------------------------------------------------------------------
+def _pinned(*shape):
+    return torch.empty(*shape, dtype=torch.float32, pin_memory=torch.cuda.is_available())
+
+
 def _check_labels(generator, discriminator, labels):
     if generator.label_type != "none" or discriminator.label_type != "none":
         raise NotImplementedError("label-conditioned GANs are not on the RNA-GAN DCGAN path")
@@ -113,54 +117,106 @@ def _d_step(generator, discriminator, optimizer_discriminator, real, noise, clip
 
 
 def _gp_step(generator, discriminator, optimizer_discriminator, real, noise, eps, lambd):
+    """eps: python float or 1-element device tensor."""
     ops, gn, dn = _nets(generator, discriminator)
-    loss = E.gp_loss_grads(ops, gn, dn, real.contiguous().float(), noise.contiguous().float(), float(eps),
-                           float(lambd), grad_scale=D_.grad_scale())
+    loss = E.gp_loss_grads(ops, gn, dn, real.contiguous().float(), noise.contiguous().float(),
+                           eps if torch.is_tensor(eps) else float(eps), float(lambd), grad_scale=D_.grad_scale())
     _finish(discriminator, optimizer_discriminator)
     return loss
+
+
+class _Runner:
+    """Executes a step body eagerly for the first calls, then from a captured HIP graph
+    (rna_gan_amd.graphed.StepGraph).  One graph per (body, modules, optimizer, input shapes)."""
+
+    def __init__(self):
+        self._graphs = {}
+
+    def __getstate__(self):          # loss objects are pickled into checkpoints; graphs are not state
+        return {}
+
+    def __setstate__(self, state):
+        self._graphs = {}
+
+    def run(self, key, fn, inputs, modules, optimizers):
+        from . import graphed
+        if not graphed.ENABLED:
+            return fn(*inputs)
+        key = key + tuple(tuple(t.shape) for t in inputs) + tuple(id(m) for m in modules) + \
+            tuple(id(o) for o in optimizers)
+        sg = self._graphs.get(key)
+        if sg is None:
+            hip_opts = [o for o in optimizers if hasattr(o, "note_replayed")]
+            if len(hip_opts) != len(optimizers):
+                return fn(*inputs)          # a foreign optimizer keeps host-side state: no capture
+            sg = self._graphs[key] = graphed.StepGraph(fn, inputs, modules, hip_opts)
+        return sg(*inputs)
 
 
 # ------------------------------------------------------------------------------------------------
 # stock losses (--loss_type wgan)
 # ------------------------------------------------------------------------------------------------
 class WassersteinGeneratorLoss(GeneratorLoss):
+    def __init__(self, reduction="mean", override_train_ops=None):
+        super().__init__(reduction, override_train_ops)
+        self._runner = _Runner()
+
     def forward(self, fgz):
         return wasserstein_generator_loss(fgz, self.reduction)
+
+    def step(self, generator, discriminator, optimizer_generator, noise):
+        """The train_op body on explicit inputs; returns the loss as a 1-element device tensor."""
+        return self._runner.run(("g",), lambda nz: _g_step(generator, discriminator, optimizer_generator, nz),
+                                [noise], [generator, discriminator], [optimizer_generator])
 
     def train_ops(self, generator, discriminator, optimizer_generator, device, batch_size, labels=None):
         _check_labels(generator, discriminator, labels)
         noise = torch.randn(batch_size, generator.encoding_dims, device=device)
-        return _g_step(generator, discriminator, optimizer_generator, noise).item()
+        return self.step(generator, discriminator, optimizer_generator, noise).item()
 
 
 class WassersteinDiscriminatorLoss(DiscriminatorLoss):
     def __init__(self, reduction="mean", clip=None, override_train_ops=None):
         super().__init__(reduction, override_train_ops)
         self.clip = clip if isinstance(clip, (tuple, list)) and len(clip) > 1 else None
+        self._runner = _Runner()
 
     def forward(self, fx, fgz):
         return wasserstein_discriminator_loss(fx, fgz, self.reduction)
+
+    def step(self, generator, discriminator, optimizer_discriminator, real, noise):
+        clip = self.clip
+        return self._runner.run(("d", clip), lambda r, nz: _d_step(generator, discriminator,
+                                                                   optimizer_discriminator, r, nz, clip),
+                                [real, noise], [generator, discriminator], [optimizer_discriminator])
 
     def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
         _check_labels(generator, discriminator, labels)
         batch_size = real_inputs.size(0)
         noise = torch.randn(batch_size, generator.encoding_dims, device=device)
-        return _d_step(generator, discriminator, optimizer_discriminator, real_inputs.to(device), noise,
-                       self.clip).item()
+        return self.step(generator, discriminator, optimizer_discriminator, real_inputs.to(device), noise).item()
 
 
 class WassersteinGradientPenalty(DiscriminatorLoss):
     def __init__(self, reduction="mean", lambd=10.0, override_train_ops=None):
         super().__init__(reduction, override_train_ops)
         self.lambd = lambd
+        self._runner = _Runner()
+
+    def step(self, generator, discriminator, optimizer_discriminator, real, noise, eps):
+        """eps: 1-element float32 device tensor (read inside the graph)."""
+        lambd = self.lambd
+        return self._runner.run(("gp", lambd), lambda r, nz, e: _gp_step(generator, discriminator,
+                                                                         optimizer_discriminator, r, nz, e, lambd),
+                                [real, noise, eps], [generator, discriminator], [optimizer_discriminator])
 
     def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
         _check_labels(generator, discriminator, labels)
         batch_size = real_inputs.size(0)
         noise = torch.randn(batch_size, generator.encoding_dims, device=device)
-        eps = torch.rand(1).item()
-        return _gp_step(generator, discriminator, optimizer_discriminator, real_inputs.to(device), noise, eps,
-                        self.lambd).item()
+        eps = _pinned(1).uniform_(0.0, 1.0).to(device, non_blocking=True)   # CPU generator, as the reference
+        return self.step(generator, discriminator, optimizer_discriminator, real_inputs.to(device), noise,
+                         eps).item()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -172,16 +228,22 @@ class _VAEMixin:
         if checkpoint is not None:
             self.betavae.load_state_dict(torch.load(checkpoint, map_location="cpu"))
         self.betavae.eval()
+        self._runner = _Runner()
 
-    def _conditioned_noise(self, generator, real_inputs, device):
-        """src/wgan_loss.py:94-106: z_mean = betavae.encode(rna)[0]; u ~ U(-0.3, 0.3) drawn on the CPU
-        generator; noise = standardise_columns(u + z_mean)."""
+    def _inputs(self, generator, real_inputs, device):
+        """src/wgan_loss.py:94-101: rna to the device; u ~ U(-0.3, 0.3) drawn on the CPU generator."""
         batch_size = real_inputs["image"].size(0)
-        gene_coding = real_inputs["rna_data"]
         if next(self.betavae.parameters()).device != torch.device(device):
             self.betavae = self.betavae.to(device)
-        z, _, _ = self.betavae.encode(gene_coding.to(device))
-        u = torch.FloatTensor(batch_size, generator.encoding_dims).uniform_(-0.3, 0.3).to(device)
+        rna = real_inputs["rna_data"].to(device, non_blocking=True).float()
+        # same generator consumption as torch.FloatTensor(bs, E).uniform_(-0.3, 0.3); drawn into pinned
+        # memory so that the copy to the device is asynchronous
+        u = _pinned(batch_size, generator.encoding_dims).uniform_(-0.3, 0.3).to(device, non_blocking=True)
+        return rna, u
+
+    def _noise(self, generator, rna, u):
+        """src/wgan_loss.py:96-106: z_mean = betavae.encode(rna)[0]; noise = standardise_columns(u + z_mean)."""
+        z, _, _ = self.betavae.encode(rna)
         ops, _ = generator.runtime()
         return ops.latent_prep(u, z)
 
@@ -196,11 +258,16 @@ class WassersteinGeneratorLossVAE(GeneratorLoss, _VAEMixin):
     def forward(self, fgz):
         return wasserstein_generator_loss_vae(fgz, self.reduction)
 
+    def step(self, generator, discriminator, optimizer_generator, rna, u):
+        return self._runner.run(("g",), lambda r, uu: _g_step(generator, discriminator, optimizer_generator,
+                                                              self._noise(generator, r, uu)),
+                                [rna, u], [generator, discriminator], [optimizer_generator])
+
     def train_ops(self, generator, discriminator, optimizer_generator, device, batch_size, real_inputs,
                   labels=None):
         _check_labels(generator, discriminator, labels)
-        noise = self._conditioned_noise(generator, real_inputs, device)
-        return _g_step(generator, discriminator, optimizer_generator, noise).item()
+        rna, u = self._inputs(generator, real_inputs, device)
+        return self.step(generator, discriminator, optimizer_generator, rna, u).item()
 
 
 class WassersteinDiscriminatorLossVAE(DiscriminatorLoss, _VAEMixin):
@@ -212,11 +279,18 @@ class WassersteinDiscriminatorLossVAE(DiscriminatorLoss, _VAEMixin):
     def forward(self, fx, fgz):
         return wasserstein_discriminator_loss_vae(fx, fgz, self.reduction)
 
+    def step(self, generator, discriminator, optimizer_discriminator, real, rna, u):
+        clip = self.clip
+        return self._runner.run(("d", clip), lambda x, r, uu: _d_step(generator, discriminator,
+                                                                      optimizer_discriminator, x,
+                                                                      self._noise(generator, r, uu), clip),
+                                [real, rna, u], [generator, discriminator], [optimizer_discriminator])
+
     def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
         _check_labels(generator, discriminator, labels)
-        noise = self._conditioned_noise(generator, real_inputs, device)
+        rna, u = self._inputs(generator, real_inputs, device)
         real = real_inputs["image"].to(device)
-        return _d_step(generator, discriminator, optimizer_discriminator, real, noise, self.clip).item()
+        return self.step(generator, discriminator, optimizer_discriminator, real, rna, u).item()
 
 
 class WassersteinGradientPenaltyVAE(DiscriminatorLoss, _VAEMixin):
@@ -226,9 +300,16 @@ class WassersteinGradientPenaltyVAE(DiscriminatorLoss, _VAEMixin):
         self.override_train_ops = override_train_ops
         self._init_vae(checkpoint, rna_features, beta)
 
+    def step(self, generator, discriminator, optimizer_discriminator, real, rna, u, eps):
+        lambd = self.lambd
+        return self._runner.run(("gp", lambd), lambda x, r, uu, e: _gp_step(generator, discriminator,
+                                                                            optimizer_discriminator, x,
+                                                                            self._noise(generator, r, uu), e, lambd),
+                                [real, rna, u, eps], [generator, discriminator], [optimizer_discriminator])
+
     def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
         _check_labels(generator, discriminator, labels)
-        noise = self._conditioned_noise(generator, real_inputs, device)
+        rna, u = self._inputs(generator, real_inputs, device)
         real = real_inputs["image"].to(device)
-        eps = torch.rand(1).item()
-        return _gp_step(generator, discriminator, optimizer_discriminator, real, noise, eps, self.lambd).item()
+        eps = _pinned(1).uniform_(0.0, 1.0).to(device, non_blocking=True)   # torch.rand(1) in the reference (:376)
+        return self.step(generator, discriminator, optimizer_discriminator, real, rna, u, eps).item()

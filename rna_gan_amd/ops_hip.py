@@ -271,11 +271,16 @@ class HipOps:
         check(self.lib.rg_nchw_chan_sum(_ptr(g_nchw), _ptr(out), N, C, H * W, int(accumulate), _ptr(ws), ws.numel(),
                                         self.stream), "rg_nchw_chan_sum")
 
-    def interp(self, real, fake, eps: float):
+    def interp(self, real, fake, eps):
+        """eps: python float, or a 1-element device tensor (graph-replayable form)."""
         assert real.dtype == torch.float32 and real.is_contiguous() and fake.is_contiguous()
         out = torch.empty_like(real)
-        check(self.lib.rg_interp(_ptr(real), _ptr(fake), _ptr(out), real.numel(), float(eps), self.stream),
-              "rg_interp")
+        if torch.is_tensor(eps):
+            check(self.lib.rg_interp_dev(_ptr(real), _ptr(fake), _ptr(out), real.numel(), _ptr(eps), self.stream),
+                  "rg_interp_dev")
+        else:
+            check(self.lib.rg_interp(_ptr(real), _ptr(fake), _ptr(out), real.numel(), float(eps), self.stream),
+                  "rg_interp")
         return out
 
     def sqnorm(self, x):

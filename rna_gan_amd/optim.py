@@ -1,9 +1,13 @@
 """Fused Adam on the flat parameter buffers (one HIP kernel per optimizer step).
 
 Drop-in for ``torch.optim.Adam(params, lr, betas)`` as configured at
-src/histopathology_gan.py:252,257 (stepped at src/wgan_loss.py:127,261,388): same update rule
-(rg_adam_step), same ``state_dict()`` layout (per-parameter ``step`` / ``exp_avg`` /
-``exp_avg_sq``), so optimizer state in reference checkpoints loads and vice versa.
+src/histopathology_gan.py:252,257 (stepped at src/wgan_loss.py:127,261,388): same update rule,
+same ``state_dict()`` layout (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``), so optimizer
+state in reference checkpoints loads and vice versa.
+
+The step counter and the bias-correction constants live in DEVICE memory (rg_adam_hyper_dev +
+rg_adam_step_dev), so an optimizer step contains no host-computed kernel argument and can be
+replayed from a captured HIP graph (rna_gan_amd.graphed).
 """
 from __future__ import annotations
 
@@ -23,6 +27,9 @@ class Adam(torch.optim.Adam):
         self._m = None
         self._v = None
         self._flat_id = None
+        self._step_dev = None      # int32[1] on the device
+        self._hyper = None         # float32[8] on the device
+        self._host_steps = 0       # number of steps enqueued/replayed so far (mirror of *_step_dev)
 
     def bind(self, module):
         """Tell the optimizer which HIP module owns its parameters (done by the Trainer)."""
@@ -37,17 +44,28 @@ class Adam(torch.optim.Adam):
             old = {p: self.state.get(p) for p in flat.params}
             self._m = torch.zeros_like(flat.data)
             self._v = torch.zeros_like(flat.data)
+            step0 = 0
             for p, (off, n) in zip(flat.params, flat.offsets):
                 st = old.get(p) or {}
                 m = self._m[off:off + n].view(p.shape)
                 v = self._v[off:off + n].view(p.shape)
                 if "exp_avg" in st:
                     m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
-                step = st.get("step", torch.tensor(0.0))
-                self.state[p] = {"step": step if torch.is_tensor(step) else torch.tensor(float(step)),
-                                 "exp_avg": m, "exp_avg_sq": v}
+                step0 = max(step0, int(float(st.get("step", 0))))
+                self.state[p] = {"step": torch.tensor(float(step0)), "exp_avg": m, "exp_avg_sq": v}
+            self._host_steps = step0
+            self._step_dev = torch.tensor([step0], dtype=torch.int32, device=flat.data.device)
+            self._hyper = torch.zeros(8, dtype=torch.float32, device=flat.data.device)
             self._flat_id = flat
         return flat
+
+    def _sync_step_state(self):
+        for p in (self._flat_id.params if self._flat_id is not None else []):
+            self.state[p]["step"] = torch.tensor(float(self._host_steps))
+
+    def state_dict(self):
+        self._sync_step_state()
+        return super().state_dict()
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -58,19 +76,22 @@ class Adam(torch.optim.Adam):
         if self._module is not None:
             self._module.flat.grad.zero_()
 
+    def note_replayed(self):
+        """A captured graph containing one step of this optimizer was replayed."""
+        self._host_steps += 1
+
     @torch.no_grad()
     def step(self, closure=None):
         flat = self._ensure()
         g = self.param_groups[0]
-        p0 = flat.params[0]
-        st0 = self.state[p0]
-        step = int(float(st0["step"])) + 1
         lib = _abi.load()
         stream = torch.cuda.current_stream(flat.data.device).cuda_stream
-        check(lib.rg_adam_step(flat.data.data_ptr(), flat.grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
-                               flat.data.numel(), step, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
-                               float(g["eps"]), stream), "rg_adam_step")
-        for p in flat.params:
-            self.state[p]["step"] = torch.tensor(float(step))
+        check(lib.rg_adam_hyper_dev(self._step_dev.data_ptr(), float(g["lr"]), float(g["betas"][0]),
+                                    float(g["betas"][1]), float(g["eps"]), self._hyper.data_ptr(), stream),
+              "rg_adam_hyper_dev")
+        check(lib.rg_adam_step_dev(flat.data.data_ptr(), flat.grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
+                                   flat.data.numel(), self._hyper.data_ptr(), stream), "rg_adam_step_dev")
+        if not torch.cuda.is_current_stream_capturing():
+            self._host_steps += 1
         self._module.weights_changed()
         return None
