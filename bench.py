@@ -86,6 +86,7 @@ def log(*a):
 
 
 _T0 = time.perf_counter()
+_DEFAULT_THREADS = 1
 
 
 def main():
@@ -103,7 +104,9 @@ def main():
     from rna_gan_amd import dist as D_
     from rna_gan_amd import losses as PL
     from oracle import ref_cpu as R
-    torch.set_num_threads(min(8, torch.get_num_threads()))   # host side only draws noise; avoid 100+ idle threads
+    global _DEFAULT_THREADS
+    _DEFAULT_THREADS = torch.get_num_threads()
+    torch.set_num_threads(min(8, _DEFAULT_THREADS))   # GPU leg: the host only draws noise
     D_.init_from_env()
     rank, world = D_.rank(), D_.world_size()
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -242,7 +245,7 @@ def cpu_baseline(seed):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, torch.get_num_threads() if torch.get_num_threads() > 0 else cores))
+    cores = max(1, min(cores, _DEFAULT_THREADS))        # torch's own default for this box (all cores / SMT)
     torch.set_num_threads(cores)
     log("cpu baseline on %d threads" % cores)
     n = 8
@@ -265,7 +268,7 @@ def cpu_baseline(seed):
     t = sum(times[1:]) / len(times[1:])
     return {"value": round(n / t, 3), "unit": "imgs/sec", "cores": cores, "kind": "port",
             "sample": "oracle/ref_cpu.py (PyTorch fp32 restatement of the reference path, betaVAE encode "
-                      "excluded: ~3% of the reference's CPU time), batch 8, 1 warm-up + 2 timed iterations, "
+                      "excluded: ~3%% of the reference's CPU time), batch 8, 1 warm-up + 2 timed iterations, "
                       "%.2f s/iteration, torch %s, %d threads" % (t, torch.__version__, torch.get_num_threads())}
 
 

@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Working counterpart of the reference CLI (src/histopathology_gan.py) on the MI355X path.
+
+Same flags (--config --checkpoint --seed --image_dir --model_dir --num_epochs --num_patches
+--gan_type --loss_type) and the same JSON keys (path_csv, patch_data_path, save_dir, img_size,
+[flag, encoder_checkpoint, bag_size]); the model/optimizer dictionary, loss selection, Trainer call
+and checkpoint naming follow src/histopathology_gan.py:175-192,248-278,298-314.
+
+The reference script itself cannot start (absent modules wsi_model/biggan/sagan); the
+tile store (LMDB + lz4 + pickle, src/read_data.py) is outside this build's scope, so real data needs
+the reference's dataset classes on PYTHONPATH; ``--synthetic`` trains on synthetic tiles / RNA rows of
+the right shapes (what bench.py measures).  Extra flags: --batch_size (reference hard-codes 8),
+--precision, --betavae_checkpoint, --steps_per_epoch.
+"""
+import argparse
+import datetime
+import json
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.optim import Adam
+from torch.utils.data import DataLoader, Dataset
+
+import rna_gan_amd as P
+from rna_gan_amd import dist as D_
+
+
+class SyntheticTiles(Dataset):
+    """uint8 uniform tiles -> float -> (x-0.5)/0.5 (src/histopathology_gan.py:106-109) and N(0,1) RNA rows
+    (StandardScaler output, :148-151) with 16 distinct rows (tiles of a slide share RNA)."""
+
+    def __init__(self, n, img_size, rna_features, with_rna, seed):
+        self.n, self.s, self.f, self.with_rna = n, img_size, rna_features, with_rna
+        rng = np.random.default_rng(seed)
+        self.rows = torch.from_numpy(rng.normal(size=(16, rna_features)).astype(np.float32))
+        self.seed = seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        rng = np.random.default_rng([self.seed, i])
+        img = torch.from_numpy(rng.integers(0, 256, size=(3, self.s, self.s), dtype=np.uint8)).float() / 255.0
+        img = (img - 0.5) / 0.5
+        if self.with_rna:
+            return {"image": img, "rna_data": self.rows[i % 16], "labels": torch.tensor(0.0)}
+        return img, torch.tensor(0.0)
+
+
+def main():
+    parser = argparse.ArgumentParser(description="GANs training on histology data (MI355X path)")
+    parser.add_argument("--config", type=str, help="JSON config file")
+    parser.add_argument("--checkpoint", type=str, default=None, help="File with the checkpoint to start with")
+    parser.add_argument("--seed", type=int, default=99, help="Seed for random generation")
+    parser.add_argument("--image_dir", type=str, default="images", help="Image dir to save image")
+    parser.add_argument("--model_dir", type=str, default="./model/gan", help="Image dir to save model checkpoints")
+    parser.add_argument("--num_epochs", type=int, default=None, help="Number of epochs to train the model")
+    parser.add_argument("--num_patches", type=int, default=250, help="Number of tiles to use per slide")
+    parser.add_argument("--gan_type", type=str, default="dcgan", help="Architecture to use")
+    parser.add_argument("--loss_type", type=str, default="wgangp", help="Loss type to use")
+    parser.add_argument("--synthetic", action="store_true", help="train on synthetic tiles / RNA rows")
+    parser.add_argument("--batch_size", type=int, default=8, help="reference hard-codes 8 (:94)")
+    parser.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    parser.add_argument("--betavae_checkpoint", default="checkpoints/betavae_training_tissues/model_dict_best.pt")
+    parser.add_argument("--steps_per_epoch", type=int, default=100, help="synthetic dataset length / batch")
+    args = parser.parse_args()
+
+    D_.init_from_env()
+    torch.manual_seed(args.seed + D_.rank())
+    np.random.seed(args.seed + D_.rank())
+    with open(args.config) as f:
+        config = json.load(f)
+    if D_.rank() == 0:
+        print(10 * "-"); print("Config for this experiment \n"); print(config); print(10 * "-")
+    args.flag = config.get("flag", "train_{date:%Y-%m-%d %H:%M:%S}".format(date=datetime.datetime.now()))
+    img_size = config["img_size"]
+    rna_features = config.get("rna_features", 19198)
+    with_rna = args.loss_type == "wganvae"
+    if not args.synthetic:
+        raise SystemExit("real tiles need the reference's LMDB dataset classes (out of scope here); use --synthetic")
+    ds = SyntheticTiles(args.steps_per_epoch * args.batch_size, img_size, rna_features, with_rna,
+                        args.seed + 1000 * D_.rank())
+    loader = DataLoader(ds, batch_size=args.batch_size, num_workers=0, pin_memory=True, drop_last=True)
+
+    if args.gan_type != "dcgan":
+        raise SystemExit("only --gan_type dcgan is on the RNA-GAN path (condgan/biggan/sagan sources are absent upstream)")
+    gan_network = {
+        "generator": {"name": P.DCGANGenerator,
+                      "args": {"encoding_dims": 2048, "out_channels": 3, "step_channels": 64, "out_size": img_size,
+                               "nonlinearity": nn.LeakyReLU(0.2), "last_nonlinearity": nn.Tanh()},
+                      "optimizer": {"name": Adam, "args": {"lr": 0.0001, "betas": (0.5, 0.999)}}},
+        "discriminator": {"name": P.DCGANDiscriminator,
+                          "args": {"in_size": img_size, "in_channels": 3, "step_channels": 64,
+                                   "nonlinearity": nn.LeakyReLU(0.2), "last_nonlinearity": nn.LeakyReLU(0.2)},
+                          "optimizer": {"name": Adam, "args": {"lr": 0.0004, "betas": (0.5, 0.999)}}},
+    }
+    if args.loss_type == "wgan":
+        losses = [P.WassersteinGeneratorLoss(), P.WassersteinDiscriminatorLoss(clip=(-0.01, 0.01)),
+                  P.WassersteinGradientPenalty()]
+    elif args.loss_type == "wganvae":
+        ck = args.betavae_checkpoint if os.path.exists(args.betavae_checkpoint) else None
+        if ck is None and D_.rank() == 0:
+            print("betaVAE checkpoint not found: using randomly initialised encoder weights")
+        losses = [P.WassersteinGeneratorLossVAE(checkpoint=ck, rna_features=rna_features),
+                  P.WassersteinDiscriminatorLossVAE(checkpoint=ck, rna_features=rna_features),
+                  P.WassersteinGradientPenaltyVAE(checkpoint=ck, rna_features=rna_features)]
+    else:
+        raise SystemExit(f"Loss type {args.loss_type} not implemented on this path. Choose wgan or wganvae.")
+
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    epochs = args.num_epochs if args.num_epochs is not None else 5
+    print("Device: {}".format(device)); print("Epochs: {}".format(epochs))
+    trainer = P.Trainer(gan_network, losses, checkpoints=args.model_dir, sample_size=64, epochs=epochs, devices=[0],
+                        recon=args.image_dir, device=device, precision=args.precision)
+    if args.checkpoint is not None:
+        trainer.load_model(load_path=args.checkpoint)
+    trainer(loader)
+
+
+if __name__ == "__main__":
+    main()

@@ -36,8 +36,10 @@ class FlatParams:
         dev = params[0].device
         self.numel = sum(p.numel() for p in params)
         pad = (-self.numel) % 4
-        self.data = torch.zeros(self.numel + pad, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(self.numel + pad, dtype=torch.float32, device=dev)
+        dt = params[0].dtype          # fp32 in the product; tests of the DP glue run the engine in fp64
+        self.data = torch.zeros(self.numel + pad, dtype=dt, device=dev)
+        self.grad = torch.zeros(self.numel + pad, dtype=dt, device=dev)
+        self.esize = self.data.element_size()
         self.offsets = []
         off = 0
         for p in params:
@@ -57,11 +59,11 @@ class FlatParams:
             return False
         base = self.data.data_ptr()
         for p, (off, n) in zip(ps, self.offsets):
-            if p.data_ptr() != base + 4 * off:
+            if p.data_ptr() != base + self.esize * off:
                 return False
         gbase = self.grad.data_ptr()
         for p, (off, n) in zip(ps, self.offsets):
-            if p.grad is None or p.grad.data_ptr() != gbase + 4 * off:
+            if p.grad is None or p.grad.data_ptr() != gbase + self.esize * off:
                 p.grad = self.grad[off:off + n].view(p.shape)
         return True
 
