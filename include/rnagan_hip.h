@@ -67,13 +67,16 @@ int rg_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I, int 
  * data-gradient of nn.ConvTranspose2d in the generator (loss.backward(), :126).
  * `wdn` may be NULL when the generic kernel runs (it reads `w`). */
 int rg_conv_down(const void* x, const float* w, const void* wdn, void* y, int N, int Hi, int Wi, int I,
-                 int O, int dtype, int algo, void* stream);
+                 int O, int dtype, int algo, void* ws, size_t ws_bytes, void* stream);
+/* workspace of rg_conv_down (up = 0) / rg_conv_up (up = 1): split-K partial slabs for layers whose tile
+ * grid cannot fill the chip (few rows, long K); Hlow/Wlow = low-resolution side.  May be 0. */
+size_t rg_conv_workspace_bytes(int up, int N, int Hlow, int Wlow, int O, int I, int dtype, int algo);
 
 /* y[N][2Ho][2Wo][I] = conv_transpose2d(x[N][Ho][Wo][O], w, stride 2, pad 1).
  * nn.ConvTranspose2d forward in the generator (G(.) at src/wgan_loss.py:113,247,371) and the
  * data-gradient of nn.Conv2d in the discriminator (.backward() :126,260,387; autograd.grad :34-41). */
 int rg_conv_up(const void* x, const float* w, const void* wup, void* y, int N, int Ho, int Wo, int O, int I,
-               int dtype, int algo, void* stream);
+               int dtype, int algo, void* ws, size_t ws_bytes, void* stream);
 
 /* dw[O][I][4][4] (+)= sum_{n,ho,wo} low[n][ho][wo][o] * high[n][2ho-1+kh][2wo-1+kw][i].
  * Weight gradient of both layer kinds (every .backward()).  Deterministic: split-K partial slabs
@@ -81,6 +84,13 @@ int rg_conv_up(const void* x, const float* w, const void* wup, void* y, int N, i
 size_t rg_conv_wgrad_workspace_bytes(int N, int Ho, int Wo, int O, int I, int dtype, int algo);
 int rg_conv_wgrad(const void* low, const void* high, float* dw, int N, int Ho, int Wo, int O, int I, int dtype,
                   int accumulate, int algo, void* ws, size_t ws_bytes, void* stream);
+/* Two contributions of the same layer in one launch: dw (+)= wgrad(low0, high0) + wgrad(low1, high1).
+ * Used where the reference's autograd accumulates two backward passes into one .grad: D(real) + D(fake)
+ * in the discriminator step (wgan_loss.py:241-260) and primal + tangent in the penalty step (:379-387).
+ * Same workspace as rg_conv_wgrad. */
+int rg_conv_wgrad2(const void* low0, const void* high0, const void* low1, const void* high1, float* dw, int N,
+                   int Ho, int Wo, int O, int I, int dtype, int accumulate, int algo, void* ws, size_t ws_bytes,
+                   void* stream);
 
 /* Image-side layers (I = 3 channels, NCHW fp32 on the high-resolution side; HBM-bound).
  * rg_first_down: y[N][H/2][W/2][O] = lrelu_slope(conv2d(x_nchw, w) + bias); bias may be NULL,
@@ -218,6 +228,8 @@ int rg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, con
  * this launch in front of rg_adam_step_dev the whole optimizer step replays from a graph untouched. */
 int rg_adam_hyper_dev(int* step_dev, double lr, double beta1, double beta2, double eps, float* hyper, void* stream);
 
+/* bf16 -> fp32 widening of a flat buffer (gradient all-reduce decompression) */
+int rg_widen_bf16(const void* src, float* dst, size_t n, void* stream);
 /* fp32 -> dtype cast with optional row padding: dst[M][ldd] = src[M][K] (pad columns zeroed) */
 int rg_cast_pad(const float* src, void* dst, int M, int K, int ldd, int dtype, void* stream);
 

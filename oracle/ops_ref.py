@@ -71,6 +71,10 @@ class RefOps:
         else:
             dw.copy_(g)
 
+    def conv_wgrad2(self, low0, high0, low1, high1, dw, accumulate: bool):
+        self.conv_wgrad(low0, high0, dw, accumulate)
+        self.conv_wgrad(low1, high1, dw, True)
+
     def first_down(self, x_nchw, cw: ConvW, bias, slope: float):
         # image-side layers use the fp32 master weights (no bf16 rounding), like the HIP kernels
         y = F.conv2d(x_nchw.to(self.f), cw.w.to(self.f), bias, stride=2, padding=1)

@@ -24,10 +24,12 @@ PROTOTYPES = {
     "rg_version": (_i, []),
     "rg_last_error": (C.c_char_p, []),
     "rg_pack_conv_weight": (_i, [_p, _p, _p, _i, _i, _i, _p]),
-    "rg_conv_down": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "rg_conv_up": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "rg_conv_down": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "rg_conv_up": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "rg_conv_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "rg_conv_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),
     "rg_conv_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "rg_conv_wgrad2": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_first_down": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "rg_last_up": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "rg_skinny_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
@@ -67,6 +69,7 @@ PROTOTYPES = {
     "rg_adam_step_dev": (_i, [_p, _p, _p, _p, _z, _p, _p]),
     "rg_interp_dev": (_i, [_p, _p, _p, _z, _p, _p]),
     "rg_adam_hyper_dev": (_i, [_p, _d, _d, _d, _d, _p, _p]),
+    "rg_widen_bf16": (_i, [_p, _p, _z, _p]),
     "rg_cast_pad": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "rg_selftest_layouts": (_i, [_p, _p]),
 }

@@ -26,22 +26,28 @@ extern "C" int rg_pack_conv_weight(const float* w, void* wdn, void* wup, int O, 
   return rg_mfma_pack_conv_weight(w, wdn, wup, O, I, rg_stream(stream));
 }
 
+extern "C" size_t rg_conv_workspace_bytes(int up, int N, int Hlow, int Wlow, int O, int I, int dtype, int algo) {
+  if (!want_mfma(algo, dtype)) return 0;
+  if (!rg_mfma_conv_supported(N, Hlow, Wlow, up ? O : I, up ? I : O)) return 0;
+  return rg_mfma_conv_ws_bytes(up, N, Hlow, Wlow, O, I);
+}
+
 extern "C" int rg_conv_down(const void* x, const float* w, const void* wdn, void* y, int N, int Hi, int Wi, int I,
-                            int O, int dtype, int algo, void* stream) {
+                            int O, int dtype, int algo, void* ws, size_t ws_bytes, void* stream) {
   RG_REQUIRE(x && y && N > 0 && Hi > 0 && Wi > 0 && I > 0 && O > 0 && Hi % 2 == 0 && Wi % 2 == 0, RG_EINVAL,
              "conv_down: bad args");
   if (want_mfma(algo, dtype) && wdn && rg_mfma_conv_supported(N, Hi / 2, Wi / 2, /*Kc=*/I, /*Ncols=*/O))
-    return rg_mfma_conv_down(x, wdn, y, N, Hi, Wi, I, O, rg_stream(stream));
+    return rg_mfma_conv_down(x, wdn, y, N, Hi, Wi, I, O, ws, ws_bytes, rg_stream(stream));
   RG_REQUIRE(algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "conv_down: shape/dtype not supported by the MFMA kernel");
   RG_REQUIRE(w, RG_EINVAL, "conv_down: generic kernel needs the fp32 master weight");
   return rg_generic_conv_down(x, w, y, N, Hi, Wi, I, O, dtype, rg_stream(stream));
 }
 
 extern "C" int rg_conv_up(const void* x, const float* w, const void* wup, void* y, int N, int Ho, int Wo, int O, int I,
-                          int dtype, int algo, void* stream) {
+                          int dtype, int algo, void* ws, size_t ws_bytes, void* stream) {
   RG_REQUIRE(x && y && N > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0, RG_EINVAL, "conv_up: bad args");
   if (want_mfma(algo, dtype) && wup && rg_mfma_conv_supported(N, Ho, Wo, /*Kc=*/O, /*Ncols=*/I))
-    return rg_mfma_conv_up(x, wup, y, N, Ho, Wo, O, I, rg_stream(stream));
+    return rg_mfma_conv_up(x, wup, y, N, Ho, Wo, O, I, ws, ws_bytes, rg_stream(stream));
   RG_REQUIRE(algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "conv_up: shape/dtype not supported by the MFMA kernel");
   RG_REQUIRE(w, RG_EINVAL, "conv_up: generic kernel needs the fp32 master weight");
   return rg_generic_conv_up(x, w, y, N, Ho, Wo, O, I, dtype, rg_stream(stream));
@@ -50,15 +56,34 @@ extern "C" int rg_conv_up(const void* x, const float* w, const void* wup, void* 
 extern "C" size_t rg_conv_wgrad_workspace_bytes(int N, int Ho, int Wo, int O, int I, int dtype, int algo) {
   size_t a = rg_generic_wgrad_ws_bytes(N, Ho, Wo, O, I);
   size_t b = 0;
-  if (want_mfma(algo, dtype) && rg_mfma_wgrad_supported(N, Ho, Wo, O, I)) b = rg_mfma_wgrad_ws_bytes(N, Ho, Wo, O, I);
+  if (want_mfma(algo, dtype) && rg_mfma_wgrad_supported(N, Ho, Wo, O, I)) {
+    b = rg_mfma_wgrad_ws_bytes(N, Ho, Wo, O, I);
+    size_t c = rg_mfma_wgrad2_ws_bytes(N, Ho, Wo, O, I);
+    if (c > b) b = c;
+  }
   return a > b ? a : b;
+}
+
+extern "C" int rg_conv_wgrad2(const void* low0, const void* high0, const void* low1, const void* high1, float* dw,
+                              int N, int Ho, int Wo, int O, int I, int dtype, int accumulate, int algo, void* ws,
+                              size_t ws_bytes, void* stream) {
+  RG_REQUIRE(low0 && high0 && low1 && high1 && dw && N > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0, RG_EINVAL,
+             "conv_wgrad2: bad args");
+  if (want_mfma(algo, dtype) && rg_mfma_wgrad_supported(N, Ho, Wo, O, I))
+    return rg_mfma_conv_wgrad2(low0, high0, low1, high1, dw, N, Ho, Wo, O, I, accumulate, ws, ws_bytes,
+                               rg_stream(stream));
+  RG_REQUIRE(algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "conv_wgrad2: shape/dtype not supported by the MFMA kernel");
+  int rc = rg_generic_conv_wgrad(low0, high0, dw, N, Ho, Wo, O, I, dtype, accumulate, ws, ws_bytes, rg_stream(stream));
+  if (rc) return rc;
+  return rg_generic_conv_wgrad(low1, high1, dw, N, Ho, Wo, O, I, dtype, 1, ws, ws_bytes, rg_stream(stream));
 }
 
 extern "C" int rg_conv_wgrad(const void* low, const void* high, float* dw, int N, int Ho, int Wo, int O, int I,
                              int dtype, int accumulate, int algo, void* ws, size_t ws_bytes, void* stream) {
   RG_REQUIRE(low && high && dw && N > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0, RG_EINVAL, "conv_wgrad: bad args");
   if (want_mfma(algo, dtype) && rg_mfma_wgrad_supported(N, Ho, Wo, O, I))
-    return rg_mfma_conv_wgrad(low, high, dw, N, Ho, Wo, O, I, accumulate, ws, ws_bytes, rg_stream(stream));
+    return rg_mfma_conv_wgrad2(low, high, nullptr, nullptr, dw, N, Ho, Wo, O, I, accumulate, ws, ws_bytes,
+                               rg_stream(stream));
   RG_REQUIRE(algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "conv_wgrad: shape/dtype not supported by the MFMA kernel");
   return rg_generic_conv_wgrad(low, high, dw, N, Ho, Wo, O, I, dtype, accumulate, ws, ws_bytes, rg_stream(stream));
 }

@@ -32,13 +32,20 @@ size_t rg_mfma_wgrad_ws_bytes(int N, int Ho, int Wo, int O, int I);
 int rg_mfma_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I, hipStream_t st);
 int rg_mfma_pack_g0_weight(const float* w, void* wp, int E, int C, hipStream_t st);
 int rg_mfma_pack_linear_weight(const float* w, void* wp, int Nout, int K, int Nout_pad, int K_pad, hipStream_t st);
-int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, int Wi, int I, int O, hipStream_t st);
-int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, hipStream_t st);
+int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, int Wi, int I, int O, void* ws,
+                      size_t ws_bytes, hipStream_t st);
+int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, void* ws,
+                    size_t ws_bytes, hipStream_t st);
+size_t rg_mfma_conv_ws_bytes(int up, int N, int Hlow, int Wlow, int O, int I);
 int rg_mfma_gemm_plain(const void* a, const void* bt, void* c, int M, int K, int Ncols, int ldc, hipStream_t st);
 int rg_mfma_linear(const void* a, const void* bt, const float* scale, const float* shift, float* y, int ldy, int M,
                    int Kpad, int Nout, float slope, hipStream_t st);
 int rg_mfma_conv_wgrad(const void* low, const void* high, float* dw, int N, int Ho, int Wo, int O, int I,
                        int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+
+int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, const void* high1, float* dw, int N,
+                        int Ho, int Wo, int O, int I, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+size_t rg_mfma_wgrad2_ws_bytes(int N, int Ho, int Wo, int O, int I);
 
 // rg_skinny.hip (image-side 3-channel layers)
 bool rg_skinny_supported(int I, int O);

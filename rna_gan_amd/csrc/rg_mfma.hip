@@ -16,6 +16,7 @@
 //    read with ds_read_b64_tr_b16 (hardware transpose) to build k-contiguous MFMA fragments.
 //    Split-K over pixels into fp32 slabs, reduced in fixed order (deterministic).
 #include "rg_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -263,6 +264,259 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(GArgs g) {
 }
 
 // ================================================================================================
+// gather-GEMM v2: LDS-DMA staging (buffer_load_dwordx4 ... lds)
+// ================================================================================================
+// Same tile math as gather_gemm_kernel, but operands go global -> LDS directly: no staging VGPRs, no
+// ds_write_b128 (the slowest LDS instruction: ~79 B/clk/CU, MI355X_MICROARCH LDS table), and the buffer
+// descriptor's range check returns zeros for out-of-image taps / rows beyond M (voffset >= num_records).
+// One wave-instruction writes 64 consecutive 16-byte LDS slots (8 rows x 8 chunks); the XOR swizzle is
+// applied to the SOURCE chunk each lane fetches (rule 21 of the CDNA guide: linear destination,
+// swizzled source, swizzled read).  2 stages, tile k+1 in flight during the MFMAs of tile k, one
+// barrier per k-tile.  Tile = BM x BN with 64x64 wave tiles: 128x128 (2x2 waves) or 256x64 (4x1 waves,
+// for 64-channel outputs).  SPLITK: blockIdx.z owns a k-tile range and writes fp32 partials.
+struct G2Args {
+  GArgs g;
+  unsigned a_bytes, b_bytes;   // sizes for the buffer descriptors
+  int nsplit;
+  float* slab;                 // [nsplit][rows_out][Ncols] fp32 when nsplit > 1
+  long long slab_stride;       // elements per split
+};
+
+typedef __attribute__((address_space(3))) void* lds_vptr_t;
+
+template <int MODE, int EPI, int BN>
+__global__ __launch_bounds__(256, 2) void gather_gemm_dma_kernel(G2Args a2) {
+  constexpr int BM = BN == 128 ? 128 : 256;
+  constexpr int A_SLOTS = BM * 8, B_SLOTS = BN * 8;          // 16-byte slots per stage
+  constexpr int STAGE_SLOTS = A_SLOTS + B_SLOTS;
+  constexpr int A_LD = BM / 32, B_LD = BN / 32;              // wave-instructions per thread per k-tile
+  constexpr int LDS_SLOTS = (2 * STAGE_SLOTS * 16 > BM * BN * 4) ? 2 * STAGE_SLOTS : BM * BN / 4;
+  __shared__ __attribute__((aligned(16))) uint4 lds[LDS_SLOTS];
+  const GArgs& g = a2.g;
+
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int tile_m = blockIdx.x / g.tiles_n, tile_n = blockIdx.x - tile_m * g.tiles_n;
+  const int bm = tile_m * BM, bn = tile_n * BN;
+  const int par = (MODE == MODE_UP) ? (int)blockIdx.y : 0;
+  const int ph = par >> 1, pw = par & 1;
+  const int zs = blockIdx.z;
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, a2.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, a2.b_bytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+
+  // lane -> (row within an 8-row group, physical chunk); logical chunk = pc ^ ((row>>1)&7) = pc ^ ((t>>4)&7)
+  const int pc = t & 7, r0 = t >> 3;
+  const int lc = pc ^ ((t >> 4) & 7);
+  const int Wq = 1 << g.lgW, Hq = 1 << g.lgH;
+  int a_off[A_LD];          // byte offset of the row's base pixel + this lane's chunk
+  unsigned a_mask[A_LD];
+  int b_off[B_LD];
+#pragma unroll
+  for (int j = 0; j < A_LD; ++j) {
+    int m = bm + r0 + 32 * j;
+    bool ok = m < g.M;
+    int mm = ok ? m : 0;
+    int wq = mm & (Wq - 1), hq = (mm >> g.lgW) & (Hq - 1), n = mm >> (g.lgW + g.lgH);
+    unsigned mask = 0;
+    long long base;
+    if (MODE == MODE_DOWN) {
+      int hs0 = 2 * hq - 1, ws0 = 2 * wq - 1;
+      base = (((long long)n * g.Hs + hs0) * g.Ws + ws0) * g.Cin;
+#pragma unroll
+      for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+          bool v = (unsigned)(hs0 + kh) < (unsigned)g.Hs && (unsigned)(ws0 + kw) < (unsigned)g.Ws;
+          mask |= (v ? 1u : 0u) << (kh * 4 + kw);
+        }
+    } else if (MODE == MODE_UP) {
+      base = (((long long)n * g.Hs + hq) * g.Ws + wq) * g.Cin;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          int kh, kw, dh, dw;
+          up_tap_dev(ph, a, kh, dh);
+          up_tap_dev(pw, b, kw, dw);
+          bool v = (unsigned)(hq + dh) < (unsigned)g.Hs && (unsigned)(wq + dw) < (unsigned)g.Ws;
+          mask |= (v ? 1u : 0u) << (a * 2 + b);
+        }
+    } else {
+      base = (long long)mm * g.Cin;
+      mask = 1u;
+    }
+    a_off[j] = (int)((base + lc * 8) * 2);
+    a_mask[j] = ok ? mask : 0u;
+  }
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    int col = bn + r0 + 32 * j;
+    b_off[j] = col < g.Ncols ? (int)((((long long)col * g.Btaps) * g.Cin + lc * 8) * 2) : -1;
+  }
+
+  const int cpt = g.Cin >> 6;
+  const int nkt_all = g.taps * cpt;
+  const int per = (nkt_all + a2.nsplit - 1) / a2.nsplit;
+  const int kt_begin = zs * per;
+  const int kt_end = min(nkt_all, kt_begin + per);
+  const int nkt = kt_end - kt_begin;
+
+  auto issue = [&](int stage, int tap, int c0) {
+    int a_delta, b_tap;
+    if (MODE == MODE_DOWN) {
+      a_delta = ((tap >> 2) * g.Ws + (tap & 3)) * g.Cin;
+      b_tap = tap;
+    } else if (MODE == MODE_UP) {
+      int kh, kw, dh, dw;
+      up_tap_dev(ph, tap >> 1, kh, dh);
+      up_tap_dev(pw, tap & 1, kw, dw);
+      a_delta = (dh * g.Ws + dw) * g.Cin;
+      b_tap = kh * 4 + kw;
+    } else {
+      a_delta = 0;
+      b_tap = 0;
+    }
+    const int ao = (a_delta + c0) * 2, bo = (b_tap * g.Cin + c0) * 2;
+    uint4* sbase = lds + stage * STAGE_SLOTS;
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      unsigned vo = ((a_mask[j] >> tap) & 1u) ? (unsigned)(a_off[j] + ao) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vptr_t)(sbase + j * 256 + wave * 64), 16, vo, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      unsigned vo = b_off[j] >= 0 ? (unsigned)(b_off[j] + bo) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_vptr_t)(sbase + A_SLOTS + j * 256 + wave * 64), 16, vo, 0, 0,
+                                               0);
+    }
+  };
+
+  const int lane = t & 63;
+  const int wm = BN == 128 ? (wave >> 1) : wave, wn = BN == 128 ? (wave & 1) : 0;
+  const int fr = lane & 31, fh = lane >> 5;
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int tap_n = kt_begin / cpt, cc_n = kt_begin - tap_n * cpt;
+  if (nkt > 0) {
+    issue(0, tap_n, cc_n << 6);
+    if (++cc_n == cpt) { cc_n = 0; ++tap_n; }
+  }
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();   // = s_waitcnt vmcnt(0) (own DMAs of tile kt landed) + barrier (everyone's landed, and
+                       //   everyone finished reading the other stage in iteration kt-1)
+    if (kt + 1 < nkt) {
+      issue((kt + 1) & 1, tap_n, cc_n << 6);
+      if (++cc_n == cpt) { cc_n = 0; ++tap_n; }
+    }
+    const uint4* sa = lds + (kt & 1) * STAGE_SLOTS;
+    const uint4* sb = sa + A_SLOTS;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int ch = 2 * kk + fh;
+      bf16x8_t fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int row = wm * 64 + i * 32 + fr;
+        fa[i] = __builtin_bit_cast(bf16x8_t, sa[lds_chunk_index(row, ch)]);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int row = wn * 64 + j * 32 + fr;
+        fb[j] = __builtin_bit_cast(bf16x8_t, sb[lds_chunk_index(row, ch)]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue through LDS (fp32 [BM][BN])
+  float* cs = reinterpret_cast<float*>(lds);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        int col = wn * 64 + j * 32 + fr;
+        cs[row * BN + col] = acc[i][j][r];
+      }
+  __syncthreads();
+  constexpr int CG = BN / 8, RPP = 256 / CG;     // column groups per row, rows per pass
+  const int cg = t % CG, rr = t / CG;
+  const int col = bn + cg * 8;
+#pragma unroll
+  for (int p = 0; p < BM / RPP; ++p) {
+    int row = rr + RPP * p;
+    int m = bm + row;
+    if (m >= g.M || col >= g.Ncols) continue;
+    float4 v0 = *reinterpret_cast<const float4*>(cs + row * BN + cg * 8);
+    float4 v1 = *reinterpret_cast<const float4*>(cs + row * BN + cg * 8 + 4);
+    long long orow;
+    if (MODE == MODE_UP) {
+      int wq = m & (Wq - 1), hq = (m >> g.lgW) & (Hq - 1), n = m >> (g.lgW + g.lgH);
+      orow = ((long long)n * (2 * Hq) + 2 * hq + ph) * (2 * Wq) + 2 * wq + pw;
+    } else {
+      orow = m;
+    }
+    if (a2.nsplit > 1) {
+      float* so = a2.slab + (long long)zs * a2.slab_stride + orow * g.ldc + col;
+      *reinterpret_cast<float4*>(so) = v0;
+      *reinterpret_cast<float4*>(so + 4) = v1;
+    } else if (EPI == EPI_BF16) {
+      uint4 o;
+      o.x = (uint32_t)f32_to_bf16(v0.x) | ((uint32_t)f32_to_bf16(v0.y) << 16);
+      o.y = (uint32_t)f32_to_bf16(v0.z) | ((uint32_t)f32_to_bf16(v0.w) << 16);
+      o.z = (uint32_t)f32_to_bf16(v1.x) | ((uint32_t)f32_to_bf16(v1.y) << 16);
+      o.w = (uint32_t)f32_to_bf16(v1.z) | ((uint32_t)f32_to_bf16(v1.w) << 16);
+      *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(g.C) + orow * g.ldc + col) = o;
+    } else {
+      float vals[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      float* yo = reinterpret_cast<float*>(g.C) + orow * g.ldc + col;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = vals[e];
+        if (g.scale) v *= g.scale[col + e];
+        if (g.shift) v += g.shift[col + e];
+        yo[e] = lrelu_f(v, g.slope);
+      }
+    }
+  }
+}
+
+// out_bf16[i] = sum_z slab[z][i]   (split-K partials of gather_gemm_dma_kernel; 8 elements per thread)
+__global__ void reduce_slabs_bf16_kernel(const float* __restrict__ slab, uint16_t* __restrict__ out, size_t n8,
+                                         size_t stride, int nsplit) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  float4 a = make_float4(0, 0, 0, 0), b = a;
+  for (int z = 0; z < nsplit; ++z) {
+    const float4* p = reinterpret_cast<const float4*>(slab + (size_t)z * stride + i * 8);
+    float4 x = p[0], y = p[1];
+    a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+    b.x += y.x; b.y += y.y; b.z += y.z; b.w += y.w;
+  }
+  uint4 o;
+  o.x = (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16);
+  o.y = (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16);
+  o.z = (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16);
+  o.w = (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16);
+  reinterpret_cast<uint4*>(out)[i] = o;
+}
+
+// ================================================================================================
 // weight gradient
 // ================================================================================================
 struct WArgs {
@@ -403,6 +657,143 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WArgs g) {
 }
 
 // ================================================================================================
+// weight gradient v2: LDS-DMA staging, swizzled [pixel][128 ch] images (256-byte rows, no padding),
+// optional second (low, high) segment so that two gradient contributions of the same layer
+// (D step: real + fake batch; GP step: primal + tangent) are summed inside ONE launch.
+// LDS image: off(row, chunk) = 256*row + 16*(chunk ^ f(row)), f(row) = ((row&3)<<2) | ((row>>2)&3)
+// (CDNA guide T10 layout (b)): conflict-free for ds_read_b64_tr_b16 with 4 rows x 64 B per half-wave.
+// ================================================================================================
+struct W2Args {
+  const uint16_t* low[2];
+  const uint16_t* high[2];
+  unsigned low_bytes[2], high_bytes[2];
+  int Kseg[2];           // pixels per segment (Kseg[1] = 0: single segment); Kseg[0] % 64 == 0 when two segments
+  float* slab;
+  int O, I;
+  int lgWo, lgHo, Hh, Wh;
+  int tiles_c, klen;
+};
+
+__device__ __forceinline__ int wswz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(W2Args g) {
+  constexpr int STAGE = 2 * 64 * 16;                           // 16-byte slots per stage (low + high)
+  __shared__ __attribute__((aligned(16))) uint4 lds[2 * STAGE];   // 64 KB
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lane = t & 63;
+  const int tile_o = blockIdx.x / g.tiles_c, tile_c = blockIdx.x - tile_o * g.tiles_c;
+  const int o0 = tile_o * 128, c0 = tile_c * 128;
+  const int zs = blockIdx.y;
+  const int Ktot = g.Kseg[0] + g.Kseg[1];
+  const int k_begin = zs * g.klen;
+  const int k_end = min(Ktot, k_begin + g.klen);
+  const int nkt = (k_end - k_begin + 63) >> 6;
+  constexpr unsigned OOB = 0x80000000u;
+
+  const __amdgpu_buffer_rsrc_t rsL0 = __builtin_amdgcn_make_buffer_rsrc((void*)g.low[0], 0, g.low_bytes[0], 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsH0 = __builtin_amdgcn_make_buffer_rsrc((void*)g.high[0], 0, g.high_bytes[0], 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsL1 = __builtin_amdgcn_make_buffer_rsrc((void*)g.low[1], 0, g.low_bytes[1], 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsH1 = __builtin_amdgcn_make_buffer_rsrc((void*)g.high[1], 0, g.high_bytes[1], 0x00020000);
+
+  // loader lane -> (row within a 4-row group, physical chunk); instruction j of wave w covers rows j*16 + w*4 + (lane>>4)
+  const int lrow = wave * 4 + (lane >> 4);
+  const int lc = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (wave & 3));      // logical 16-byte chunk (8 channels)
+  const int gc = c0 + lc * 8;                                              // global column = tap*I + i
+  const int tap = gc / g.I, ci = gc - tap * g.I;
+  const int kh = tap >> 2, kw = tap & 3;
+  const int Wo = 1 << g.lgWo, Ho = 1 << g.lgHo;
+
+  auto issue = [&](int stage, int kt) {
+    const int p0 = k_begin + kt * 64;                    // block-uniform
+    const bool seg1 = p0 >= g.Kseg[0];
+    const int pbase = seg1 ? p0 - g.Kseg[0] : p0;
+    const int kend = (seg1 ? k_end - g.Kseg[0] : min(k_end, g.Kseg[0]));
+    uint4* sl = lds + stage * STAGE;
+    uint4* sh = sl + 64 * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int p = pbase + j * 16 + lrow;
+      bool ok = p < kend;
+      unsigned lo = ok ? (unsigned)(((long long)p * g.O + o0 + lc * 8) * 2) : OOB;
+      int wo = p & (Wo - 1), ho = (p >> g.lgWo) & (Ho - 1), n = p >> (g.lgWo + g.lgHo);
+      int hi = 2 * ho - 1 + kh, wi = 2 * wo - 1 + kw;
+      bool v = ok && (unsigned)hi < (unsigned)g.Hh && (unsigned)wi < (unsigned)g.Wh;
+      unsigned ho_ = v ? (unsigned)(((((long long)n * g.Hh + hi) * g.Wh + wi) * g.I + ci) * 2) : OOB;
+      if (!seg1) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL0, (lds_vptr_t)(sl + j * 256 + wave * 64), 16, lo, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsH0, (lds_vptr_t)(sh + j * 256 + wave * 64), 16, ho_, 0, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL1, (lds_vptr_t)(sl + j * 256 + wave * 64), 16, lo, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsH1, (lds_vptr_t)(sh + j * 256 + wave * 64), 16, ho_, 0, 0, 0);
+      }
+    }
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  const int grp = lane >> 4, idx = lane & 15;
+  const int q = idx >> 2, p4 = idx & 3, fh = grp >> 1, cb = grp & 1;
+  const int f1 = (q << 2) | (2 * fh), f2 = (q << 2) | (2 * fh + 1);        // wswz(row), wswz(row + 4)
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nkt > 0) issue(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();
+    if (kt + 1 < nkt) issue((kt + 1) & 1, kt + 1);
+    const unsigned char* sl = reinterpret_cast<const unsigned char*>(lds + (kt & 1) * STAGE);
+    const unsigned char* sh = sl + 64 * 256;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int prow = ks * 16 + 8 * fh + q;
+      bf16x8_t fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int chunk = wm * 8 + i * 4 + 2 * cb + (p4 >> 1);
+        const unsigned char* pa = sl + prow * 256 + ((chunk ^ f1) << 4) + (p4 & 1) * 8;
+        const unsigned char* pb = sl + (prow + 4) * 256 + ((chunk ^ f2) << 4) + (p4 & 1) * 8;
+        s16x4_t lo = lds_tr_read(reinterpret_cast<const uint16_t*>(pa));
+        s16x4_t hi = lds_tr_read(reinterpret_cast<const uint16_t*>(pb));
+        fa[i] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int chunk = wn * 8 + j * 4 + 2 * cb + (p4 >> 1);
+        const unsigned char* pa = sh + prow * 256 + ((chunk ^ f1) << 4) + (p4 & 1) * 8;
+        const unsigned char* pb = sh + (prow + 4) * 256 + ((chunk ^ f2) << 4) + (p4 & 1) * 8;
+        s16x4_t lo = lds_tr_read(reinterpret_cast<const uint16_t*>(pa));
+        s16x4_t hi = lds_tr_read(reinterpret_cast<const uint16_t*>(pb));
+        fb[j] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  const int fr = lane & 31, fh2 = lane >> 5;
+  const long long ldw = (long long)16 * g.I;
+  float* slab = g.slab + (long long)zs * g.O * ldw;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int o = o0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh2;
+        int c = c0 + wn * 64 + j * 32 + fr;
+        slab[(long long)o * ldw + c] = acc[i][j][r];
+      }
+}
+
+// ================================================================================================
 // packs
 // ================================================================================================
 // wdn[o][tap][i] = bf16(w[o][i][tap])
@@ -516,28 +907,93 @@ static int launch_gather(const char* name, GArgs& g, int nclass, hipStream_t st)
   return RG_OK;
 }
 
-int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, int Wi, int I, int O, hipStream_t st) {
+static bool use_v1() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("RNAGAN_CONV_V1"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v == 1;
+}
+
+// split-K policy of the DMA kernel: only when the grid cannot fill the chip (< 1 block per CU) and K is long
+static int gather_split(int M, int Ncols, int nclass, int nkt, bool allow) {
+  if (!allow) return 1;
+  int bn = Ncols <= 64 ? 64 : 128, bmm = bn == 128 ? 128 : 256;
+  long long tiles = (long long)((M + bmm - 1) / bmm) * ((Ncols + bn - 1) / bn) * nclass;
+  if (tiles >= 256 || nkt < 32) return 1;
+  int s = (int)((512 + tiles - 1) / tiles);
+  if (s > 4) s = 4;
+  if (s > nkt / 16) s = nkt / 16;
+  return s < 1 ? 1 : s;
+}
+
+size_t rg_mfma_gather_ws_bytes(int M_out_rows, int M, int Ncols, int nclass, int nkt) {
+  int s = gather_split(M, Ncols, nclass, nkt, true);
+  return s > 1 ? (size_t)s * M_out_rows * Ncols * sizeof(float) : 0;
+}
+
+template <int MODE, int EPI>
+static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows_out, size_t a_bytes, size_t b_bytes,
+                          void* ws, size_t ws_bytes, hipStream_t st) {
+  if (use_v1() || a_bytes >= 0x7fffff00ull || b_bytes >= 0x7fffff00ull) return launch_gather<MODE, EPI>(name, g, nclass, st);
+  G2Args a2{};
+  const int nkt = g.taps * (g.Cin >> 6);
+  int nsplit = gather_split(g.M, g.Ncols, nclass, nkt, EPI == EPI_BF16);
+  size_t need = (size_t)nsplit * rows_out * g.Ncols * sizeof(float);
+  if (nsplit > 1 && (!ws || ws_bytes < need)) nsplit = 1;
+  a2.a_bytes = (unsigned)a_bytes; a2.b_bytes = (unsigned)b_bytes;
+  a2.nsplit = nsplit; a2.slab = (float*)ws; a2.slab_stride = rows_out * g.Ncols;
+  const bool narrow = g.Ncols <= 64;
+  const int bn = narrow ? 64 : 128, bmm = narrow ? 256 : 128;
+  g.tiles_n = (g.Ncols + bn - 1) / bn;
+  a2.g = g;
+  dim3 grid(((g.M + bmm - 1) / bmm) * g.tiles_n, nclass, nsplit);
+  if (narrow)
+    hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 64>), grid, dim3(256), 0, st, a2);
+  else
+    hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 128>), grid, dim3(256), 0, st, a2);
+  RG_LAUNCH_CHECK(name);
+  if (nsplit > 1) {
+    size_t n8 = (size_t)rows_out * g.Ncols / 8;
+    hipLaunchKernelGGL(reduce_slabs_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, (const float*)ws,
+                       (uint16_t*)g.C, n8, (size_t)rows_out * g.Ncols, nsplit);
+    RG_LAUNCH_CHECK(name);
+  }
+  return RG_OK;
+}
+
+int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, int Wi, int I, int O, void* ws,
+                      size_t ws_bytes, hipStream_t st) {
   GArgs g{};
   g.A = (const uint16_t*)x; g.B = (const uint16_t*)wdn; g.C = y;
   int Ho = Hi / 2, Wo = Wi / 2;
   g.M = N * Ho * Wo; g.Ncols = O; g.Cin = I; g.taps = 16;
   g.lgW = rg_ilog2(Wo); g.lgH = rg_ilog2(Ho); g.Hs = Hi; g.Ws = Wi; g.ldc = O; g.Btaps = 16;
-  return launch_gather<MODE_DOWN, EPI_BF16>("conv_down(mfma)", g, 1, st);
+  return launch_gather2<MODE_DOWN, EPI_BF16>("conv_down(mfma)", g, 1, g.M, (size_t)N * Hi * Wi * I * 2,
+                                             (size_t)O * 16 * I * 2, ws, ws_bytes, st);
 }
 
-int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, hipStream_t st) {
+int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, void* ws,
+                    size_t ws_bytes, hipStream_t st) {
   GArgs g{};
   g.A = (const uint16_t*)x; g.B = (const uint16_t*)wup; g.C = y;
   g.M = N * Ho * Wo; g.Ncols = I; g.Cin = O; g.taps = 4;
   g.lgW = rg_ilog2(Wo); g.lgH = rg_ilog2(Ho); g.Hs = Ho; g.Ws = Wo; g.ldc = I; g.Btaps = 16;
-  return launch_gather<MODE_UP, EPI_BF16>("conv_up(mfma)", g, 4, st);
+  return launch_gather2<MODE_UP, EPI_BF16>("conv_up(mfma)", g, 4, (long long)g.M * 4, (size_t)N * Ho * Wo * O * 2,
+                                           (size_t)I * 16 * O * 2, ws, ws_bytes, st);
+}
+
+size_t rg_mfma_conv_ws_bytes(int up, int N, int Hlow, int Wlow, int O, int I) {
+  int M = N * Hlow * Wlow;
+  if (up) return rg_mfma_gather_ws_bytes(M * 4, M, I, 4, 4 * (O >> 6));
+  return rg_mfma_gather_ws_bytes(M, M, O, 1, 16 * (I >> 6));
 }
 
 int rg_mfma_gemm_plain(const void* a, const void* bt, void* c, int M, int K, int Ncols, int ldc, hipStream_t st) {
   GArgs g{};
   g.A = (const uint16_t*)a; g.B = (const uint16_t*)bt; g.C = c;
   g.M = M; g.Ncols = Ncols; g.Cin = K; g.taps = 1; g.lgW = 0; g.lgH = 0; g.Hs = 1; g.Ws = 1; g.ldc = ldc; g.Btaps = 1;
-  return launch_gather<MODE_PLAIN, EPI_BF16>("gemm_plain(mfma)", g, 1, st);
+  RG_REQUIRE(ldc == Ncols, RG_EINVAL, "gemm_plain: dense output expected");
+  return launch_gather2<MODE_PLAIN, EPI_BF16>("gemm_plain(mfma)", g, 1, M, (size_t)M * K * 2, (size_t)Ncols * K * 2,
+                                              nullptr, 0, st);
 }
 
 int rg_mfma_linear(const void* a, const void* bt, const float* scale, const float* shift, float* y, int ldy, int M,
@@ -547,7 +1003,8 @@ int rg_mfma_linear(const void* a, const void* bt, const float* scale, const floa
   g.A = (const uint16_t*)a; g.B = (const uint16_t*)bt; g.C = y;
   g.M = M; g.Ncols = Nout; g.Cin = Kpad; g.taps = 1; g.lgW = 0; g.lgH = 0; g.Hs = 1; g.Ws = 1; g.ldc = ldy; g.Btaps = 1;
   g.scale = scale; g.shift = shift; g.slope = slope;
-  return launch_gather<MODE_PLAIN, EPI_LINEAR>("linear(mfma)", g, 1, st);
+  return launch_gather2<MODE_PLAIN, EPI_LINEAR>("linear(mfma)", g, 1, M, (size_t)M * Kpad * 2, (size_t)Nout * Kpad * 2,
+                                                nullptr, 0, st);
 }
 
 bool rg_mfma_wgrad_supported(int N, int Ho, int Wo, int O, int I) {
@@ -581,6 +1038,52 @@ int rg_mfma_conv_wgrad(const void* low, const void* high, float* dw, int N, int 
   hipLaunchKernelGGL(wgrad_kernel, dim3((O / 128) * g.tiles_c, nsplit), dim3(256), 0, st, g);
   RG_LAUNCH_CHECK("conv_wgrad(mfma)");
   return rg_reduce_slabs((const float*)ws, dw, elems, nsplit, accumulate, 1, I, st);
+}
+
+static int mfma_wgrad_split_k(int K, int O, int I) {
+  int tiles = (O / 128) * (16 * I / 128);
+  int want = (768 + tiles - 1) / tiles;
+  int maxs = K / 256;
+  if (maxs < 1) maxs = 1;
+  int s = want < maxs ? want : maxs;
+  return s < 1 ? 1 : s;
+}
+
+int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, const void* high1, float* dw, int N,
+                        int Ho, int Wo, int O, int I, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int Kseg = N * Ho * Wo;
+  const bool two = low1 != nullptr;
+  size_t lowb = (size_t)Kseg * O * 2, highb = (size_t)Kseg * 4 * I * 2;
+  if (use_v1() || lowb >= 0x7fffff00ull || highb >= 0x7fffff00ull || (two && Kseg % 64 != 0)) {
+    int rc = rg_mfma_conv_wgrad(low0, high0, dw, N, Ho, Wo, O, I, accumulate, ws, ws_bytes, st);
+    if (rc || !two) return rc;
+    return rg_mfma_conv_wgrad(low1, high1, dw, N, Ho, Wo, O, I, 1, ws, ws_bytes, st);
+  }
+  const int K = two ? 2 * Kseg : Kseg;
+  int nsplit = mfma_wgrad_split_k(K, O, I);
+  size_t elems = (size_t)O * I * 16;
+  RG_REQUIRE(ws && ws_bytes >= (size_t)nsplit * elems * sizeof(float), RG_EWORKSPACE,
+             "conv_wgrad(mfma): workspace too small");
+  W2Args g{};
+  g.low[0] = (const uint16_t*)low0; g.high[0] = (const uint16_t*)high0;
+  g.low[1] = (const uint16_t*)(two ? low1 : low0); g.high[1] = (const uint16_t*)(two ? high1 : high0);
+  g.low_bytes[0] = g.low_bytes[1] = (unsigned)lowb; g.high_bytes[0] = g.high_bytes[1] = (unsigned)highb;
+  g.Kseg[0] = Kseg; g.Kseg[1] = two ? Kseg : 0;
+  g.slab = (float*)ws; g.O = O; g.I = I;
+  g.lgWo = rg_ilog2(Wo); g.lgHo = rg_ilog2(Ho); g.Hh = 2 * Ho; g.Wh = 2 * Wo;
+  g.tiles_c = 16 * I / 128;
+  int klen = (K + nsplit - 1) / nsplit;
+  g.klen = (klen + 63) / 64 * 64;
+  nsplit = (K + g.klen - 1) / g.klen;
+  hipLaunchKernelGGL(wgrad_dma_kernel, dim3((O / 128) * g.tiles_c, nsplit), dim3(256), 0, st, g);
+  RG_LAUNCH_CHECK("conv_wgrad(mfma)");
+  return rg_reduce_slabs((const float*)ws, dw, elems, nsplit, accumulate, 1, I, st);
+}
+
+size_t rg_mfma_wgrad2_ws_bytes(int N, int Ho, int Wo, int O, int I) {
+  size_t a = (size_t)mfma_wgrad_split_k(N * Ho * Wo, O, I) * O * I * 16 * sizeof(float);
+  size_t b = (size_t)mfma_wgrad_split_k(2 * N * Ho * Wo, O, I) * O * I * 16 * sizeof(float);
+  return a > b ? a : b;
 }
 
 int rg_mfma_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I, hipStream_t st) {

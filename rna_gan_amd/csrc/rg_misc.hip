@@ -232,6 +232,17 @@ __global__ void head_wgrad_kernel(const float* gh, const T* a, float* dw, int N,
   *d = accumulate ? *d + s : s;
 }
 
+__global__ void widen_bf16_kernel(const uint16_t* src, float* dst, size_t n) {
+  size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    uint2 v = reinterpret_cast<const uint2*>(src)[i];
+    reinterpret_cast<float4*>(dst)[i] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                                                    __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+  }
+  size_t t = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) dst[t] = bf16_to_f32(src[t]);
+}
+
 template <typename T>
 __global__ void cast_pad_kernel(const float* src, T* dst, int M, int K, int ldd) {
   size_t tot = (size_t)M * ldd;
@@ -389,6 +400,15 @@ extern "C" int rg_head_wgrad(const float* gh, const void* a, float* dw, int N, i
     RG_LAUNCH_CHECK("head_wgrad");
     return RG_OK;
   })
+}
+
+extern "C" int rg_widen_bf16(const void* src, float* dst, size_t n, void* stream) {
+  RG_REQUIRE(src && dst, RG_EINVAL, "widen_bf16: bad args");
+  if (n == 0) return RG_OK;
+  hipLaunchKernelGGL(widen_bf16_kernel, dim3(grid_for(n, 4)), dim3(256), 0, rg_stream(stream), (const uint16_t*)src,
+                     dst, n);
+  RG_LAUNCH_CHECK("widen_bf16");
+  return RG_OK;
 }
 
 extern "C" int rg_cast_pad(const float* src, void* dst, int M, int K, int ldd, int dtype, void* stream) {

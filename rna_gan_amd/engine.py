@@ -159,6 +159,34 @@ def disc_backward(ops, D: DiscNet, ctx, coef: float, wgrad: bool, accumulate: bo
     return None
 
 
+def disc_backward_pair(ops, D: DiscNet, ctx_a, coef_a: float, ctx_b, coef_b: float):
+    """Parameter gradients of sum_n coef_a*D(x_a)_n + coef_b*D(x_b)_n (written, not accumulated): the
+    two backward chains run in lock step so that each layer's weight gradient is ONE two-segment
+    launch (rg_conv_wgrad2) instead of two launches + two reductions.  Used by the D-loss step."""
+    R = len(D.blocks)
+    gha = ops.head_grad(ctx_a.h, coef_a, D.last_slope)
+    ghb = ops.head_grad(ctx_b.h, coef_b, D.last_slope)
+    ops.head_wgrad(gha, ctx_a.a[R], D.head.dw, False)
+    ops.head_wgrad(ghb, ctx_b.a[R], D.head.dw, True)
+    ga_a = ops.head_bwd_data(gha, D.head)
+    ga_b = ops.head_bwd_data(ghb, D.head)
+    for l in range(R, 0, -1):
+        cw, bn = D.blocks[l - 1]
+        gz_a, _, _ = ops.bn_act_bwd(ctx_a.z[l], ga_a, ctx_a.mean[l], ctx_a.invstd[l], bn.gamma, bn.beta, D.slope,
+                                    bn.dgamma, bn.dbeta, False)
+        gz_b, _, _ = ops.bn_act_bwd(ctx_b.z[l], ga_b, ctx_b.mean[l], ctx_b.invstd[l], bn.gamma, bn.beta, D.slope,
+                                    bn.dgamma, bn.dbeta, True)
+        ops.conv_wgrad2(gz_a, ctx_a.a[l - 1], gz_b, ctx_b.a[l - 1], cw.dw, False)
+        ga_a = ops.conv_up(gz_a, cw)
+        ga_b = ops.conv_up(gz_b, cw)
+    gz0_a = ops.lrelu_bwd(ga_a, ctx_a.a[0], D.slope)
+    gz0_b = ops.lrelu_bwd(ga_b, ctx_b.a[0], D.slope)
+    ops.skinny_wgrad(gz0_a, ctx_a.x, D.conv0.dw, False)
+    ops.skinny_wgrad(gz0_b, ctx_b.x, D.conv0.dw, True)
+    ops.col_sum(gz0_a, D.conv0.dbias, False)
+    ops.col_sum(gz0_b, D.conv0.dbias, True)
+
+
 def disc_gradient_penalty(ops, D: DiscNet, xhat, lambd: float, update_running=True):
     """lambd*(||d sum D(xhat)/d xhat||_2 - 1)^2 and its parameter gradients (written, not
     accumulated; lambd may carry the data-parallel 1/world factor -- it only scales the gradients).  Reference: src/wgan_loss.py:32-44 + :379-387.  Returns the UNWEIGHTED penalty
@@ -188,8 +216,8 @@ def disc_gradient_penalty(ops, D: DiscNet, xhat, lambd: float, update_running=Tr
         pz = ops.bn_double_bwd(ctx.z[l], qa, zts[l], ctx.ga1[l], ctx.mean[l], ctx.invstd[l],
                                bn.gamma, bn.beta, D.slope, ctx.s_gy[l], ctx.s_gyxh[l],
                                s_zt[l], s_xhzt[l], bn.dgamma, bn.dbeta, False)
-        ops.conv_wgrad(pz, ctx.a[l - 1], cw.dw, False)
-        ops.conv_wgrad(ctx.gz1[l], ats[l - 1], cw.dw, True)
+        # dW = wgrad(pz, a_prev) + wgrad(gz1, at_prev): one launch, one split-K reduction
+        ops.conv_wgrad2(pz, ctx.a[l - 1], ctx.gz1[l], ats[l - 1], cw.dw, False)
         qa = ops.conv_up(pz, cw)
     p0 = ops.lrelu_bwd(qa, ctx.a[0], D.slope)
     ops.skinny_wgrad(p0, xhat, D.conv0.dw, False)
@@ -260,8 +288,7 @@ def disc_loss_grads(ops, G: GenNet, D: DiscNet, real, noise, grad_scale: float =
     img, _ = gen_forward(ops, G, noise, keep=False)
     out_f, ctx_f = disc_forward(ops, D, img)
     loss = ops.mean_diff(out_f, out_r, 1.0)
-    disc_backward(ops, D, ctx_r, -grad_scale / n, wgrad=True, accumulate=False, need_input_grad=False)
-    disc_backward(ops, D, ctx_f, grad_scale / n, wgrad=True, accumulate=True, need_input_grad=False)
+    disc_backward_pair(ops, D, ctx_r, -grad_scale / n, ctx_f, grad_scale / n)
     return loss
 
 

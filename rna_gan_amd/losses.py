@@ -93,36 +93,67 @@ def _nets(generator, discriminator):
 
 def _finish(module, optimizer):
     """all-reduce (data parallel) -> optimizer step -> invalidate packed weights."""
-    D_.allreduce_sum_(module.flat.grad)
+    _reduce(module)
+    _apply(module, optimizer)
+
+
+def _reduce(module):
+    ops, _ = module.runtime()
+    D_.allreduce_sum_(module.flat.grad, compress=(ops.act_dtype == torch.bfloat16))
+
+
+def _apply(module, optimizer):
     optimizer.step()
     module.weights_changed()
+    return module.flat.data[:1]          # a tensor result, so that this half can be a graph of its own
+
+
+# gradient halves (no collective, no optimizer): capturable on their own in a data-parallel run
+def _g_grads(generator, discriminator, noise):
+    ops, gn, dn = _nets(generator, discriminator)
+    return E.gen_loss_grads(ops, gn, dn, noise.contiguous().float(), grad_scale=D_.grad_scale())
+
+
+def _d_grads(generator, discriminator, real, noise, clip):
+    ops, gn, dn = _nets(generator, discriminator)
+    if clip is not None:
+        ops.clamp_(discriminator.flat.data, clip[0], clip[1])      # every D parameter (wgan_loss.py:213-215)
+        discriminator.weights_changed()
+    return E.disc_loss_grads(ops, gn, dn, real.contiguous().float(), noise.contiguous().float(),
+                             grad_scale=D_.grad_scale())
+
+
+def _gp_grads(generator, discriminator, real, noise, eps, lambd):
+    ops, gn, dn = _nets(generator, discriminator)
+    return E.gp_loss_grads(ops, gn, dn, real.contiguous().float(), noise.contiguous().float(),
+                           eps if torch.is_tensor(eps) else float(eps), float(lambd), grad_scale=D_.grad_scale())
 
 
 def _g_step(generator, discriminator, optimizer_generator, noise):
-    ops, gn, dn = _nets(generator, discriminator)
-    loss = E.gen_loss_grads(ops, gn, dn, noise.contiguous().float(), grad_scale=D_.grad_scale())
+    loss = _g_grads(generator, discriminator, noise)
     _finish(generator, optimizer_generator)
     return loss
 
 
 def _d_step(generator, discriminator, optimizer_discriminator, real, noise, clip):
-    ops, gn, dn = _nets(generator, discriminator)
-    if clip is not None:
-        ops.clamp_(discriminator.flat.data, clip[0], clip[1])      # every D parameter (wgan_loss.py:213-215)
-        discriminator.weights_changed()
-    loss = E.disc_loss_grads(ops, gn, dn, real.contiguous().float(), noise.contiguous().float(),
-                             grad_scale=D_.grad_scale())
+    loss = _d_grads(generator, discriminator, real, noise, clip)
     _finish(discriminator, optimizer_discriminator)
     return loss
 
 
 def _gp_step(generator, discriminator, optimizer_discriminator, real, noise, eps, lambd):
     """eps: python float or 1-element device tensor."""
-    ops, gn, dn = _nets(generator, discriminator)
-    loss = E.gp_loss_grads(ops, gn, dn, real.contiguous().float(), noise.contiguous().float(),
-                           eps if torch.is_tensor(eps) else float(eps), float(lambd), grad_scale=D_.grad_scale())
+    loss = _gp_grads(generator, discriminator, real, noise, eps, lambd)
     _finish(discriminator, optimizer_discriminator)
     return loss
+
+
+def _dispatch(runner, key, grads_fn, full_fn, inputs, generator, discriminator, stepped, optimizer):
+    """single process: one graph per train_op; data parallel: gradients graph, eager all-reduce, step graph"""
+    mods = [generator, discriminator]
+    if D_.active():
+        return runner.run_dp(key, grads_fn, inputs, mods, stepped, optimizer)
+    return runner.run(key, full_fn, inputs, mods, [optimizer])
 
 
 class _Runner:
@@ -137,6 +168,13 @@ class _Runner:
 
     def __setstate__(self, state):
         self._graphs = {}
+
+    def run_dp(self, key, grads_fn, inputs, modules, stepped, optimizer):
+        """Data-parallel form: graph(gradients) -> eager RCCL all-reduce -> graph(optimizer step)."""
+        loss = self.run(key + ("grads",), grads_fn, inputs, modules, [])
+        _reduce(stepped)
+        self.run(key + ("apply",), lambda: _apply(stepped, optimizer), [], [stepped], [optimizer])
+        return loss
 
     def run(self, key, fn, inputs, modules, optimizers):
         from . import graphed
@@ -166,8 +204,9 @@ class WassersteinGeneratorLoss(GeneratorLoss):
 
     def step(self, generator, discriminator, optimizer_generator, noise):
         """The train_op body on explicit inputs; returns the loss as a 1-element device tensor."""
-        return self._runner.run(("g",), lambda nz: _g_step(generator, discriminator, optimizer_generator, nz),
-                                [noise], [generator, discriminator], [optimizer_generator])
+        return _dispatch(self._runner, ("g",), lambda nz: _g_grads(generator, discriminator, nz),
+                         lambda nz: _g_step(generator, discriminator, optimizer_generator, nz), [noise],
+                         generator, discriminator, generator, optimizer_generator)
 
     def train_ops(self, generator, discriminator, optimizer_generator, device, batch_size, labels=None):
         _check_labels(generator, discriminator, labels)
@@ -186,9 +225,9 @@ class WassersteinDiscriminatorLoss(DiscriminatorLoss):
 
     def step(self, generator, discriminator, optimizer_discriminator, real, noise):
         clip = self.clip
-        return self._runner.run(("d", clip), lambda r, nz: _d_step(generator, discriminator,
-                                                                   optimizer_discriminator, r, nz, clip),
-                                [real, noise], [generator, discriminator], [optimizer_discriminator])
+        return _dispatch(self._runner, ("d", clip), lambda r, nz: _d_grads(generator, discriminator, r, nz, clip),
+                         lambda r, nz: _d_step(generator, discriminator, optimizer_discriminator, r, nz, clip),
+                         [real, noise], generator, discriminator, discriminator, optimizer_discriminator)
 
     def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
         _check_labels(generator, discriminator, labels)
@@ -206,9 +245,10 @@ class WassersteinGradientPenalty(DiscriminatorLoss):
     def step(self, generator, discriminator, optimizer_discriminator, real, noise, eps):
         """eps: 1-element float32 device tensor (read inside the graph)."""
         lambd = self.lambd
-        return self._runner.run(("gp", lambd), lambda r, nz, e: _gp_step(generator, discriminator,
-                                                                         optimizer_discriminator, r, nz, e, lambd),
-                                [real, noise, eps], [generator, discriminator], [optimizer_discriminator])
+        return _dispatch(self._runner, ("gp", lambd),
+                         lambda r, nz, e: _gp_grads(generator, discriminator, r, nz, e, lambd),
+                         lambda r, nz, e: _gp_step(generator, discriminator, optimizer_discriminator, r, nz, e, lambd),
+                         [real, noise, eps], generator, discriminator, discriminator, optimizer_discriminator)
 
     def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
         _check_labels(generator, discriminator, labels)
@@ -259,9 +299,11 @@ class WassersteinGeneratorLossVAE(GeneratorLoss, _VAEMixin):
         return wasserstein_generator_loss_vae(fgz, self.reduction)
 
     def step(self, generator, discriminator, optimizer_generator, rna, u):
-        return self._runner.run(("g",), lambda r, uu: _g_step(generator, discriminator, optimizer_generator,
-                                                              self._noise(generator, r, uu)),
-                                [rna, u], [generator, discriminator], [optimizer_generator])
+        return _dispatch(self._runner, ("g",),
+                         lambda r, uu: _g_grads(generator, discriminator, self._noise(generator, r, uu)),
+                         lambda r, uu: _g_step(generator, discriminator, optimizer_generator,
+                                               self._noise(generator, r, uu)),
+                         [rna, u], generator, discriminator, generator, optimizer_generator)
 
     def train_ops(self, generator, discriminator, optimizer_generator, device, batch_size, real_inputs,
                   labels=None):
@@ -281,10 +323,11 @@ class WassersteinDiscriminatorLossVAE(DiscriminatorLoss, _VAEMixin):
 
     def step(self, generator, discriminator, optimizer_discriminator, real, rna, u):
         clip = self.clip
-        return self._runner.run(("d", clip), lambda x, r, uu: _d_step(generator, discriminator,
-                                                                      optimizer_discriminator, x,
-                                                                      self._noise(generator, r, uu), clip),
-                                [real, rna, u], [generator, discriminator], [optimizer_discriminator])
+        return _dispatch(self._runner, ("d", clip),
+                         lambda x, r, uu: _d_grads(generator, discriminator, x, self._noise(generator, r, uu), clip),
+                         lambda x, r, uu: _d_step(generator, discriminator, optimizer_discriminator, x,
+                                                  self._noise(generator, r, uu), clip),
+                         [real, rna, u], generator, discriminator, discriminator, optimizer_discriminator)
 
     def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
         _check_labels(generator, discriminator, labels)
@@ -302,10 +345,12 @@ class WassersteinGradientPenaltyVAE(DiscriminatorLoss, _VAEMixin):
 
     def step(self, generator, discriminator, optimizer_discriminator, real, rna, u, eps):
         lambd = self.lambd
-        return self._runner.run(("gp", lambd), lambda x, r, uu, e: _gp_step(generator, discriminator,
-                                                                            optimizer_discriminator, x,
-                                                                            self._noise(generator, r, uu), e, lambd),
-                                [real, rna, u, eps], [generator, discriminator], [optimizer_discriminator])
+        return _dispatch(self._runner, ("gp", lambd),
+                         lambda x, r, uu, e: _gp_grads(generator, discriminator, x, self._noise(generator, r, uu), e,
+                                                       lambd),
+                         lambda x, r, uu, e: _gp_step(generator, discriminator, optimizer_discriminator, x,
+                                                      self._noise(generator, r, uu), e, lambd),
+                         [real, rna, u, eps], generator, discriminator, discriminator, optimizer_discriminator)
 
     def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
         _check_labels(generator, discriminator, labels)

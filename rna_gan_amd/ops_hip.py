@@ -80,9 +80,10 @@ class HipOps:
         assert cw.w.shape[1] == I and x.is_contiguous()
         wdn, _ = self._packs(cw)
         y = self._act(N, Hi // 2, Wi // 2, O)
+        ws = self._ws(self.lib.rg_conv_workspace_bytes(0, N, Hi // 2, Wi // 2, O, I, self.dt, self.algo))
         self._timed("conv_fwd_dgrad", 2.0 * N * (Hi // 2) * (Wi // 2) * O * I * 16, lambda: check(
             self.lib.rg_conv_down(_ptr(x), _ptr(cw.w), _ptr(wdn), _ptr(y), N, Hi, Wi, I, O, self.dt, self.algo,
-                                  self.stream), "rg_conv_down"))
+                                  _ptr(ws), ws.numel(), self.stream), "rg_conv_down"))
         return y
 
     def conv_up(self, x, cw: ConvW):
@@ -91,9 +92,10 @@ class HipOps:
         assert cw.w.shape[0] == O and x.is_contiguous()
         _, wup = self._packs(cw)
         y = self._act(N, 2 * Ho, 2 * Wo, I)
+        ws = self._ws(self.lib.rg_conv_workspace_bytes(1, N, Ho, Wo, O, I, self.dt, self.algo))
         self._timed("conv_fwd_dgrad", 2.0 * N * Ho * Wo * O * I * 16, lambda: check(
             self.lib.rg_conv_up(_ptr(x), _ptr(cw.w), _ptr(wup), _ptr(y), N, Ho, Wo, O, I, self.dt, self.algo,
-                                self.stream), "rg_conv_up"))
+                                _ptr(ws), ws.numel(), self.stream), "rg_conv_up"))
         return y
 
     def conv_wgrad(self, low, high, dw, accumulate: bool):
@@ -105,6 +107,18 @@ class HipOps:
         self._timed("conv_wgrad", 2.0 * N * Ho * Wo * O * I * 16, lambda: check(
             self.lib.rg_conv_wgrad(_ptr(low), _ptr(high), _ptr(dw), N, Ho, Wo, O, I, self.dt, int(accumulate),
                                    self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_wgrad"))
+
+    def conv_wgrad2(self, low0, high0, low1, high1, dw, accumulate: bool):
+        """dw (+)= wgrad(low0, high0) + wgrad(low1, high1) in one launch (one split-K reduction)."""
+        N, Ho, Wo, O = low0.shape
+        I = high0.shape[3]
+        assert low1.shape == low0.shape and high1.shape == high0.shape
+        nb = self.lib.rg_conv_wgrad_workspace_bytes(N, Ho, Wo, O, I, self.dt, self.algo)
+        ws = self._ws(nb)
+        self._timed("conv_wgrad", 4.0 * N * Ho * Wo * O * I * 16, lambda: check(
+            self.lib.rg_conv_wgrad2(_ptr(low0), _ptr(high0), _ptr(low1), _ptr(high1), _ptr(dw), N, Ho, Wo, O, I,
+                                    self.dt, int(accumulate), self.algo, _ptr(ws), ws.numel(), self.stream),
+            "rg_conv_wgrad2"))
 
     def first_down(self, x_nchw, cw: ConvW, bias, slope: float):
         N, I, H, W = x_nchw.shape

@@ -1,0 +1,62 @@
+"""The data-parallel code path on ONE GPU: a 1-rank RCCL process group + RNAGAN_FORCE_DP=1 makes the
+losses take the DP route (gradients graph -> eager bf16-compressed RCCL all-reduce -> step graph).
+With one rank the all-reduce is the identity up to the bf16 wire rounding, so the result must stay
+close to the single-process path."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SCRIPT = r'''
+import os, sys, torch, torch.nn as nn
+sys.path.insert(0, os.environ["REPO"])
+from rna_gan_amd import dist as D_, losses as PL
+import rna_gan_amd as P
+from oracle import ref_cpu as R
+D_.init_from_env()
+assert D_.active() == (os.environ.get("RNAGAN_FORCE_DP") == "1")
+in_size, step, enc, n = 32, 64, 128, 8
+G0 = R.seeded_fill_(R.OracleDCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh()), 7)
+D0 = R.seeded_fill_(R.OracleDCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.LeakyReLU(0.2)), 8)
+G = P.DCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+D = P.DCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.LeakyReLU(0.2))
+G.load_state_dict(G0.state_dict()); D.load_state_dict(D0.state_dict())
+G, D = G.cuda().train(), D.cuda().train()
+og = P.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.999)).bind(G)
+od = P.Adam(D.parameters(), lr=4e-4, betas=(0.5, 0.999)).bind(D)
+lg, ld, lp = PL.WassersteinGeneratorLoss(), PL.WassersteinDiscriminatorLoss(), PL.WassersteinGradientPenalty()
+out = []
+for it in range(5):
+    real = R.synthetic_images(n, in_size, seed=100 + it).cuda()
+    nz = [R.synthetic_normal(n, enc, seed=200 + 3 * it + j).cuda() for j in range(3)]
+    eps = torch.tensor([0.1 + 0.2 * it], device="cuda")
+    out += [lg.step(G, D, og, nz[0]).item(), ld.step(G, D, od, real, nz[1]).item(), lp.step(G, D, od, real, nz[2], eps).item()]
+torch.save({"losses": out, "g": G.flat.data.cpu(), "d": D.flat.data.cpu()}, os.environ["OUT"])
+if torch.distributed.is_initialized():
+    torch.distributed.destroy_process_group()
+'''
+
+
+def _run(tmp_path, force):
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / ("dp%d.pt" % force))
+    env = dict(os.environ, REPO=repo, OUT=out, RNAGAN_FORCE_DP=str(force), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29533", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import torch
+    return torch.load(out)
+
+
+def test_dp_path_single_rank(tmp_path):
+    import torch
+    a = _run(tmp_path, 0)
+    b = _run(tmp_path, 1)
+    for x, y in zip(a["losses"], b["losses"]):
+        assert abs(x - y) <= 5e-2 * (abs(x) + 1.0), (a["losses"], b["losses"])
+    for k in ("g", "d"):
+        du = (a[k] - b[k]).norm() / (a[k].norm() + 1e-30)
+        assert float(du) <= 1e-3, (k, float(du))

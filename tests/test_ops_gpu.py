@@ -83,6 +83,13 @@ def test_conv_down_up_wgrad(N, Hi, Wi, I, O, dtype):
     check(dw, dw_ref, TOL[dtype] * 2, "conv_wgrad")
     hip.conv_wgrad(dev(g), dev(x), dw, True)
     check(dw, 2 * dw_ref, TOL[dtype] * 2, "conv_wgrad(accumulate)")
+    # two-segment form: dw = wgrad(g, x) + wgrad(g2, x2)
+    g2, x2 = rnd((N, Hi // 2, Wi // 2, O), 13).to(dtype), rnd((N, Hi, Wi, I), 12).to(dtype)
+    dw2_ref = torch.zeros(O, I, 4, 4)
+    ref.conv_wgrad(g, x, dw2_ref, False); ref.conv_wgrad(g2, x2, dw2_ref, True)
+    dw2 = torch.full((O, I, 4, 4), -5.0).cuda()
+    hip.conv_wgrad2(dev(g), dev(x), dev(g2), dev(x2), dw2, False)
+    check(dw2, dw2_ref, TOL[dtype] * 2, "conv_wgrad2")
 
 
 @pytest.mark.parametrize("O,dtype", [(4, torch.float32), (4, torch.bfloat16), (64, torch.float32),
