@@ -164,10 +164,9 @@ extern "C" int rg_pack_linear_weight(const float* w, void* wp, int Nout, int K, 
 }
 
 extern "C" size_t rg_linear_workspace_bytes(int M, int K, int Nout, int algo) {
-  (void)Nout;
   if (algo == RG_ALGO_GENERIC) return 0;
   size_t kp = rg_align_up((size_t)K, 64);
-  return (size_t)M * kp * 2;
+  return rg_align_up((size_t)M * kp * 2, 256) + rg_mfma_linear_ws_bytes(M, (int)kp, Nout);
 }
 
 extern "C" int rg_linear_affine_act(const float* x, int ldx, const float* w, const void* wp, const float* scale,
@@ -176,11 +175,14 @@ extern "C" int rg_linear_affine_act(const float* x, int ldx, const float* w, con
   RG_REQUIRE(x && y && M > 0 && K > 0 && Nout > 0 && ldx >= K && ldy >= Nout, RG_EINVAL, "linear: bad args");
   if (algo != RG_ALGO_GENERIC && wp) {
     int kp = (int)rg_align_up((size_t)K, 64);
+    size_t xb = rg_align_up((size_t)M * kp * 2, 256);
     RG_REQUIRE(ws && ws_bytes >= (size_t)M * kp * 2, RG_EWORKSPACE, "linear: workspace too small");
     RG_REQUIRE(ldx == K, RG_EINVAL, "linear(MFMA): x must be dense");
     int rc = rg_cast_pad(x, ws, M, K, kp, RG_BF16, stream);
     if (rc) return rc;
-    return rg_mfma_linear(ws, wp, scale, shift, y, ldy, M, kp, Nout, slope, rg_stream(stream));
+    void* slab = ws_bytes > xb ? (char*)ws + xb : nullptr;
+    return rg_mfma_linear(ws, wp, scale, shift, y, ldy, M, kp, Nout, slope, slab, ws_bytes > xb ? ws_bytes - xb : 0,
+                          rg_stream(stream));
   }
   RG_REQUIRE(algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "linear: MFMA path needs the packed weight");
   RG_REQUIRE(w, RG_EINVAL, "linear: generic kernel needs the fp32 weight");

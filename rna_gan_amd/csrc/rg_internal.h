@@ -39,7 +39,8 @@ int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int 
 size_t rg_mfma_conv_ws_bytes(int up, int N, int Hlow, int Wlow, int O, int I);
 int rg_mfma_gemm_plain(const void* a, const void* bt, void* c, int M, int K, int Ncols, int ldc, hipStream_t st);
 int rg_mfma_linear(const void* a, const void* bt, const float* scale, const float* shift, float* y, int ldy, int M,
-                   int Kpad, int Nout, float slope, hipStream_t st);
+                   int Kpad, int Nout, float slope, void* ws, size_t ws_bytes, hipStream_t st);
+size_t rg_mfma_linear_ws_bytes(int M, int Kpad, int Nout);
 int rg_mfma_conv_wgrad(const void* low, const void* high, float* dw, int N, int Ho, int Wo, int O, int I,
                        int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 

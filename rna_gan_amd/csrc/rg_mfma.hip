@@ -496,6 +496,19 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_dma_kernel(G2Args a2) {
   }
 }
 
+// y[m][j] = act((sum_z slab[z][m][j]) * scale[j] + shift[j])   (split-K partials of the linear layers)
+__global__ void reduce_linear_kernel(const float* __restrict__ slab, float* __restrict__ y, int M, int Nout, int ldy,
+                                     size_t stride, int nsplit, const float* scale, const float* shift, float slope) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * Nout) return;
+  int m = (int)(i / Nout), j = (int)(i - (size_t)m * Nout);
+  float v = 0.f;
+  for (int z = 0; z < nsplit; ++z) v += slab[(size_t)z * stride + (size_t)m * ldy + j];
+  if (scale) v *= scale[j];
+  if (shift) v += shift[j];
+  y[(size_t)m * ldy + j] = lrelu_f(v, slope);
+}
+
 // out_bf16[i] = sum_z slab[z][i]   (split-K partials of gather_gemm_dma_kernel; 8 elements per thread)
 __global__ void reduce_slabs_bf16_kernel(const float* __restrict__ slab, uint16_t* __restrict__ out, size_t n8,
                                          size_t stride, int nsplit) {
@@ -914,14 +927,14 @@ static bool use_v1() {
 }
 
 // split-K policy of the DMA kernel: only when the grid cannot fill the chip (< 1 block per CU) and K is long
-static int gather_split(int M, int Ncols, int nclass, int nkt, bool allow) {
+static int gather_split(int M, int Ncols, int nclass, int nkt, bool allow, int cap = 4, int min_kt = 16) {
   if (!allow) return 1;
   int bn = Ncols <= 64 ? 64 : 128, bmm = bn == 128 ? 128 : 256;
   long long tiles = (long long)((M + bmm - 1) / bmm) * ((Ncols + bn - 1) / bn) * nclass;
-  if (tiles >= 256 || nkt < 32) return 1;
+  if (tiles >= 256 || nkt < 2 * min_kt) return 1;
   int s = (int)((512 + tiles - 1) / tiles);
-  if (s > 4) s = 4;
-  if (s > nkt / 16) s = nkt / 16;
+  if (s > cap) s = cap;
+  if (s > nkt / min_kt) s = nkt / min_kt;
   return s < 1 ? 1 : s;
 }
 
@@ -936,11 +949,14 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   if (use_v1() || a_bytes >= 0x7fffff00ull || b_bytes >= 0x7fffff00ull) return launch_gather<MODE, EPI>(name, g, nclass, st);
   G2Args a2{};
   const int nkt = g.taps * (g.Cin >> 6);
-  int nsplit = gather_split(g.M, g.Ncols, nclass, nkt, EPI == EPI_BF16);
-  size_t need = (size_t)nsplit * rows_out * g.Ncols * sizeof(float);
+  // conv outputs: up to 4 splits; dense weight-streaming layers (M = batch): up to 16 (HBM-bound, the grid
+  // must cover all CUs to pull full bandwidth)
+  int nsplit = EPI == EPI_BF16 ? gather_split(g.M, g.Ncols, nclass, nkt, true)
+                               : gather_split(g.M, g.Ncols, nclass, nkt, true, 16, 8);
+  size_t need = (size_t)nsplit * rows_out * (EPI == EPI_BF16 ? g.Ncols : g.ldc) * sizeof(float);
   if (nsplit > 1 && (!ws || ws_bytes < need)) nsplit = 1;
   a2.a_bytes = (unsigned)a_bytes; a2.b_bytes = (unsigned)b_bytes;
-  a2.nsplit = nsplit; a2.slab = (float*)ws; a2.slab_stride = rows_out * g.Ncols;
+  a2.nsplit = nsplit; a2.slab = (float*)ws; a2.slab_stride = rows_out * (EPI == EPI_BF16 ? g.Ncols : g.ldc);
   const bool narrow = g.Ncols <= 64;
   const int bn = narrow ? 64 : 128, bmm = narrow ? 256 : 128;
   g.tiles_n = (g.Ncols + bn - 1) / bn;
@@ -951,7 +967,12 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   else
     hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 128>), grid, dim3(256), 0, st, a2);
   RG_LAUNCH_CHECK(name);
-  if (nsplit > 1) {
+  if (nsplit > 1 && EPI == EPI_LINEAR) {
+    size_t n = (size_t)g.M * g.Ncols;
+    hipLaunchKernelGGL(reduce_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws,
+                       (float*)g.C, g.M, g.Ncols, g.ldc, (size_t)a2.slab_stride, nsplit, g.scale, g.shift, g.slope);
+    RG_LAUNCH_CHECK(name);
+  } else if (nsplit > 1) {
     size_t n8 = (size_t)rows_out * g.Ncols / 8;
     hipLaunchKernelGGL(reduce_slabs_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, (const float*)ws,
                        (uint16_t*)g.C, n8, (size_t)rows_out * g.Ncols, nsplit);
@@ -996,15 +1017,20 @@ int rg_mfma_gemm_plain(const void* a, const void* bt, void* c, int M, int K, int
                                               nullptr, 0, st);
 }
 
+size_t rg_mfma_linear_ws_bytes(int M, int Kpad, int Nout) {
+  int s = gather_split(M, Nout, 1, Kpad >> 6, true, 16, 8);
+  return s > 1 ? (size_t)s * M * Nout * sizeof(float) : 0;
+}
+
 int rg_mfma_linear(const void* a, const void* bt, const float* scale, const float* shift, float* y, int ldy, int M,
-                   int Kpad, int Nout, float slope, hipStream_t st) {
+                   int Kpad, int Nout, float slope, void* ws, size_t ws_bytes, hipStream_t st) {
   RG_REQUIRE(Kpad % 64 == 0 && Nout % 8 == 0, RG_EUNSUPPORTED, "linear(mfma): K_pad %% 64 and Nout %% 8 required");
   GArgs g{};
   g.A = (const uint16_t*)a; g.B = (const uint16_t*)bt; g.C = y;
   g.M = M; g.Ncols = Nout; g.Cin = Kpad; g.taps = 1; g.lgW = 0; g.lgH = 0; g.Hs = 1; g.Ws = 1; g.ldc = ldy; g.Btaps = 1;
   g.scale = scale; g.shift = shift; g.slope = slope;
   return launch_gather2<MODE_PLAIN, EPI_LINEAR>("linear(mfma)", g, 1, M, (size_t)M * Kpad * 2, (size_t)Nout * Kpad * 2,
-                                                nullptr, 0, st);
+                                                ws, ws_bytes, st);
 }
 
 bool rg_mfma_wgrad_supported(int N, int Ho, int Wo, int O, int I) {

@@ -69,8 +69,11 @@ class DiscNet:
         self.conv0, self.blocks, self.head = conv0, blocks, head   # blocks: [(ConvW, BNP)]
         self.slope, self.last_slope = slope, last_slope
 
+    def convs(self):
+        return [self.conv0, self.head] + [b[0] for b in self.blocks]
+
     def bump(self):
-        for cw in [self.conv0, self.head] + [b[0] for b in self.blocks]:
+        for cw in self.convs():
             cw.version += 1
 
 
@@ -81,8 +84,11 @@ class GenNet:
         self.g0, self.bn0, self.blocks, self.last = g0, bn0, blocks, last   # blocks: [(ConvW, BNP)]
         self.slope = slope
 
+    def convs(self):
+        return [self.g0, self.last] + [b[0] for b in self.blocks]
+
     def bump(self):
-        for cw in [self.g0, self.last] + [b[0] for b in self.blocks]:
+        for cw in self.convs():
             cw.version += 1
 
 

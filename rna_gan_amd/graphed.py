@@ -29,23 +29,24 @@ def _pool():
 class StepGraph:
     """fn(*static_inputs) -> 1-element loss tensor, replayed from a captured graph.
 
-    ``modules``: HIP modules whose packed weights must be rebuilt at the start of the step (their
-    Python-side version counters are frozen inside a graph, so the step always repacks);
+    ``modules``: HIP modules used by fn.  Weight re-packing is decided by Python-side version counters
+    that are frozen inside a graph, so the caller keys graphs by the staleness pattern of the modules
+    (losses._Runner) and this class replays the counters' evolution after each replay: every module
+    used ends up freshly packed, then the ``stepped`` modules (whose optimizer ran) become stale;
     ``optimizers``: rna_gan_amd.optim.Adam instances stepped inside fn (host step mirror)."""
 
-    def __init__(self, fn, example_inputs, modules, optimizers):
+    def __init__(self, fn, example_inputs, modules, optimizers, stepped=()):
         self.fn = fn
         self.static_in = [t.detach().clone() for t in example_inputs]
         self.modules = modules
         self.optimizers = optimizers
+        self.stepped = list(stepped)
         self.graph = None
         self.static_out = None
         self.calls = 0
         self.failed = False
 
     def _run(self):
-        for m in self.modules:
-            m.weights_changed()
         return self.fn(*self.static_in)
 
     def __call__(self, *inputs):
@@ -72,5 +73,7 @@ class StepGraph:
         for o in self.optimizers:
             o.note_replayed()
         for m in self.modules:
+            m.mark_packs_fresh()
+        for m in self.stepped:
             m.weights_changed()
         return self.static_out

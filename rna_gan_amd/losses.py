@@ -171,23 +171,26 @@ class _Runner:
 
     def run_dp(self, key, grads_fn, inputs, modules, stepped, optimizer):
         """Data-parallel form: graph(gradients) -> eager RCCL all-reduce -> graph(optimizer step)."""
-        loss = self.run(key + ("grads",), grads_fn, inputs, modules, [])
+        loss = self.run(key + ("grads",), grads_fn, inputs, modules, [], [])
         _reduce(stepped)
-        self.run(key + ("apply",), lambda: _apply(stepped, optimizer), [], [stepped], [optimizer])
+        self.run(key + ("apply",), lambda: _apply(stepped, optimizer), [], [], [optimizer], [stepped])
         return loss
 
-    def run(self, key, fn, inputs, modules, optimizers):
+    def run(self, key, fn, inputs, modules, optimizers, stepped=None):
         from . import graphed
         if not graphed.ENABLED:
             return fn(*inputs)
+        if stepped is None:
+            stepped = [o._module for o in optimizers if getattr(o, "_module", None) is not None]
+        # the launch sequence depends on which packed weights are stale: one graph per pattern
         key = key + tuple(tuple(t.shape) for t in inputs) + tuple(id(m) for m in modules) + \
-            tuple(id(o) for o in optimizers)
+            tuple(id(o) for o in optimizers) + tuple(bool(m.packs_stale()) for m in modules)
         sg = self._graphs.get(key)
         if sg is None:
             hip_opts = [o for o in optimizers if hasattr(o, "note_replayed")]
             if len(hip_opts) != len(optimizers):
                 return fn(*inputs)          # a foreign optimizer keeps host-side state: no capture
-            sg = self._graphs[key] = graphed.StepGraph(fn, inputs, modules, hip_opts)
+            sg = self._graphs[key] = graphed.StepGraph(fn, inputs, modules, hip_opts, stepped)
         return sg(*inputs)
 
 

@@ -116,6 +116,18 @@ class _HipModule(nn.Module):
         if self._rt_net is not None:
             self._rt_net.bump()
 
+    def packs_stale(self) -> bool:
+        """True if any packed (bf16 GEMM-operand) weight image is older than its master."""
+        if self._rt_net is None:
+            return True
+        return any(cw.packs_version != cw.version for cw in self._rt_net.convs())
+
+    def mark_packs_fresh(self):
+        """A captured graph that rebuilt the packs was replayed: bring the Python-side counters in line."""
+        if self._rt_net is not None:
+            for cw in self._rt_net.convs():
+                cw.packs_version = cw.version
+
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
         self.weights_changed()

@@ -59,4 +59,4 @@ def test_dp_path_single_rank(tmp_path):
         assert abs(x - y) <= 5e-2 * (abs(x) + 1.0), (a["losses"], b["losses"])
     for k in ("g", "d"):
         du = (a[k] - b[k]).norm() / (a[k].norm() + 1e-30)
-        assert float(du) <= 1e-3, (k, float(du))
+        assert float(du) <= 1e-2, (k, float(du))
