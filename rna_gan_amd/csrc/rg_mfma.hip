@@ -284,13 +284,15 @@ struct G2Args {
 
 typedef __attribute__((address_space(3))) void* lds_vptr_t;
 
-template <int MODE, int EPI, int BN>
-__global__ __launch_bounds__(256, 2) void gather_gemm_dma_kernel(G2Args a2) {
-  constexpr int BM = BN == 128 ? 128 : 256;
+template <int MODE, int EPI, int BM, int BN, int NSTAGE, int NT>
+__global__ __launch_bounds__(NT, (NT == 512 || NSTAGE == 2) ? 2 : 1) void gather_gemm_dma_kernel(G2Args a2) {
+  constexpr int WN = BN / 64;                                // waves along N (64x64 wave tiles)
+  constexpr int RPI = NT / 8;                                // rows covered by one block-wide load instruction
   constexpr int A_SLOTS = BM * 8, B_SLOTS = BN * 8;          // 16-byte slots per stage
   constexpr int STAGE_SLOTS = A_SLOTS + B_SLOTS;
-  constexpr int A_LD = BM / 32, B_LD = BN / 32;              // wave-instructions per thread per k-tile
-  constexpr int LDS_SLOTS = (2 * STAGE_SLOTS * 16 > BM * BN * 4) ? 2 * STAGE_SLOTS : BM * BN / 4;
+  constexpr int A_LD = BM / RPI, B_LD = BN / RPI;            // wave-instructions per thread per k-tile
+  static_assert((BM / 64) * WN * 64 == NT, "one 64x64 wave tile per wave");
+  constexpr int LDS_SLOTS = (NSTAGE * STAGE_SLOTS * 16 > BM * BN * 4) ? NSTAGE * STAGE_SLOTS : BM * BN / 4;
   __shared__ __attribute__((aligned(16))) uint4 lds[LDS_SLOTS];
   const GArgs& g = a2.g;
 
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_dma_kernel(G2Args a2) {
   int b_off[B_LD];
 #pragma unroll
   for (int j = 0; j < A_LD; ++j) {
-    int m = bm + r0 + 32 * j;
+    int m = bm + r0 + RPI * j;
     bool ok = m < g.M;
     int mm = ok ? m : 0;
     int wq = mm & (Wq - 1), hq = (mm >> g.lgW) & (Hq - 1), n = mm >> (g.lgW + g.lgH);
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_dma_kernel(G2Args a2) {
   }
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) {
-    int col = bn + r0 + 32 * j;
+    int col = bn + r0 + RPI * j;
     b_off[j] = col < g.Ncols ? (int)((((long long)col * g.Btaps) * g.Cin + lc * 8) * 2) : -1;
   }
 
@@ -383,18 +385,18 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_dma_kernel(G2Args a2) {
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
       unsigned vo = ((a_mask[j] >> tap) & 1u) ? (unsigned)(a_off[j] + ao) : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vptr_t)(sbase + j * 256 + wave * 64), 16, vo, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_vptr_t)(sbase + j * NT + wave * 64), 16, vo, 0, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
       unsigned vo = b_off[j] >= 0 ? (unsigned)(b_off[j] + bo) : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_vptr_t)(sbase + A_SLOTS + j * 256 + wave * 64), 16, vo, 0, 0,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_vptr_t)(sbase + A_SLOTS + j * NT + wave * 64), 16, vo, 0, 0,
                                                0);
     }
   };
 
   const int lane = t & 63;
-  const int wm = BN == 128 ? (wave >> 1) : wave, wn = BN == 128 ? (wave & 1) : 0;
+  const int wm = wave / WN, wn = wave - wm * WN;
   const int fr = lane & 31, fh = lane >> 5;
   f32x16_t acc[2][2];
 #pragma unroll
@@ -405,39 +407,56 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_dma_kernel(G2Args a2) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   int tap_n = kt_begin / cpt, cc_n = kt_begin - tap_n * cpt;
-  if (nkt > 0) {
-    issue(0, tap_n, cc_n << 6);
-    if (++cc_n == cpt) { cc_n = 0; ++tap_n; }
-  }
-  for (int kt = 0; kt < nkt; ++kt) {
-    __syncthreads();   // = s_waitcnt vmcnt(0) (own DMAs of tile kt landed) + barrier (everyone's landed, and
-                       //   everyone finished reading the other stage in iteration kt-1)
-    if (kt + 1 < nkt) {
-      issue((kt + 1) & 1, tap_n, cc_n << 6);
+  // prologue: NSTAGE-1 tiles in flight
+#pragma unroll
+  for (int p = 0; p < NSTAGE - 1; ++p)
+    if (p < nkt) {
+      issue(p, tap_n, cc_n << 6);
       if (++cc_n == cpt) { cc_n = 0; ++tap_n; }
     }
-    const uint4* sa = lds + (kt & 1) * STAGE_SLOTS;
+  int st_c = 0, st_i = NSTAGE - 1;     // stage being computed / stage to issue into
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (NSTAGE == 2) {
+      __syncthreads();   // vmcnt(0): own DMAs of tile kt landed; barrier: everyone's landed and everyone finished
+                         // reading the stage about to be overwritten
+    } else {
+      // counted wait: only tile kt has to be here, the NSTAGE-2 younger tiles stay in flight across the barrier
+      if (kt + NSTAGE - 2 < nkt) __builtin_amdgcn_s_waitcnt(0x0F70 | ((A_LD + B_LD) * (NSTAGE - 2)));   // vmcnt(N)
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    const uint4* sa = lds + st_c * STAGE_SLOTS;
     const uint4* sb = sa + A_SLOTS;
+    // ALL fragment reads of this tile first, THEN the DMA of the next tile, THEN the MFMAs: hipcc puts a
+    // vmcnt(0) in front of any ds_read that follows an outstanding LDS-DMA (it assumes they may alias), which
+    // would serialise the prefetch with the compute if reads came after the issue.
+    uint4 qa[4][2], qb[4][2];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int ch = 2 * kk + fh;
-      bf16x8_t fa[2], fb[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        int row = wm * 64 + i * 32 + fr;
-        fa[i] = __builtin_bit_cast(bf16x8_t, sa[lds_chunk_index(row, ch)]);
+        qa[kk][i] = sa[lds_chunk_index(wm * 64 + i * 32 + fr, ch)];
+        qb[kk][i] = sb[lds_chunk_index(wn * 64 + i * 32 + fr, ch)];
       }
+    }
+    if (kt + NSTAGE - 1 < nkt) {
+      issue(st_i, tap_n, cc_n << 6);
+      if (++cc_n == cpt) { cc_n = 0; ++tap_n; }
+    }
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        int row = wn * 64 + j * 32 + fr;
-        fb[j] = __builtin_bit_cast(bf16x8_t, sb[lds_chunk_index(row, ch)]);
-      }
+    for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, qa[kk][i]),
+                                                              __builtin_bit_cast(bf16x8_t, qb[kk][j]), acc[i][j], 0, 0,
+                                                              0);
+    __builtin_amdgcn_s_setprio(0);
+    st_c = st_c + 1 == NSTAGE ? 0 : st_c + 1;
+    st_i = st_i + 1 == NSTAGE ? 0 : st_i + 1;
   }
   __syncthreads();
 
@@ -454,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_dma_kernel(G2Args a2) {
         cs[row * BN + col] = acc[i][j][r];
       }
   __syncthreads();
-  constexpr int CG = BN / 8, RPP = 256 / CG;     // column groups per row, rows per pass
+  constexpr int CG = BN / 8, RPP = NT / CG;      // column groups per row, rows per pass
   const int cg = t % CG, rr = t / CG;
   const int col = bn + cg * 8;
 #pragma unroll
@@ -931,7 +950,8 @@ static int gather_split(int M, int Ncols, int nclass, int nkt, bool allow, int c
   if (!allow) return 1;
   int bn = Ncols <= 64 ? 64 : 128, bmm = bn == 128 ? 128 : 256;
   long long tiles = (long long)((M + bmm - 1) / bmm) * ((Ncols + bn - 1) / bn) * nclass;
-  if (tiles >= 256 || nkt < 2 * min_kt) return 1;
+  // fewer than 2 blocks per CU leaves half of the wave slots empty (1 wave/SIMD cannot hide the LDS/DMA waits)
+  if (tiles >= 512 || nkt < 2 * min_kt) return 1;
   int s = (int)((512 + tiles - 1) / tiles);
   if (s > cap) s = cap;
   if (s > nkt / min_kt) s = nkt / min_kt;
@@ -958,14 +978,22 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   a2.a_bytes = (unsigned)a_bytes; a2.b_bytes = (unsigned)b_bytes;
   a2.nsplit = nsplit; a2.slab = (float*)ws; a2.slab_stride = rows_out * (EPI == EPI_BF16 ? g.Ncols : g.ldc);
   const bool narrow = g.Ncols <= 64;
-  const int bn = narrow ? 64 : 128, bmm = narrow ? 256 : 128;
+  static int variant = -1;     // RNAGAN_CONV_TILE: 0 = 128x128x2st (4 waves), 1 = 256x128x3st (8 waves) where it fits
+  if (variant < 0) { const char* e = getenv("RNAGAN_CONV_TILE"); variant = e ? atoi(e) : 0; }
+  // the big tile needs enough row tiles to fill the chip
+  const bool big = !narrow && variant == 1 && EPI == EPI_BF16 &&
+                   (long long)((g.M + 255) / 256) * ((g.Ncols + 127) / 128) * nclass * nsplit >= 256;
+  const int bn = narrow ? 64 : 128, bmm = (narrow || big) ? 256 : 128;
   g.tiles_n = (g.Ncols + bn - 1) / bn;
   a2.g = g;
   dim3 grid(((g.M + bmm - 1) / bmm) * g.tiles_n, nclass, nsplit);
-  if (narrow)
-    hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 64>), grid, dim3(256), 0, st, a2);
-  else
-    hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 128>), grid, dim3(256), 0, st, a2);
+  if (narrow) {
+    hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 256, 64, 2, 256>), grid, dim3(256), 0, st, a2);
+  } else if (big) {
+    hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 256, 128, 3, 512>), grid, dim3(512), 0, st, a2);
+  } else {
+    hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 128, 128, 2, 256>), grid, dim3(256), 0, st, a2);
+  }
   RG_LAUNCH_CHECK(name);
   if (nsplit > 1 && EPI == EPI_LINEAR) {
     size_t n = (size_t)g.M * g.Ncols;
