@@ -704,6 +704,7 @@ struct W2Args {
   int O, I;
   int lgWo, lgHo, Hh, Wh;
   int tiles_c, klen;
+  int tiles_o, nsplit;
 };
 
 __device__ __forceinline__ int wswz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -714,9 +715,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(W2Args g) {
   const int t = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int lane = t & 63;
-  const int tile_o = blockIdx.x / g.tiles_c, tile_c = blockIdx.x - tile_o * g.tiles_c;
+  // XCD-aware work mapping (blocks b and b+8 share an XCD / L2): each XCD walks a contiguous range of work
+  // items ordered split-major, so the column tiles that read the SAME pixels run back to back on one L2.
+  const int ntiles = g.tiles_o * g.tiles_c;
+  const int total = ntiles * g.nsplit;
+  int wid = blockIdx.x;
+  {
+    const int q = total >> 3, r = total & 7, xcd = wid & 7, j = wid >> 3;
+    wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int zs = wid / ntiles;
+  const int tid = wid - zs * ntiles;
+  const int tile_o = tid / g.tiles_c, tile_c = tid - tile_o * g.tiles_c;
   const int o0 = tile_o * 128, c0 = tile_c * 128;
-  const int zs = blockIdx.y;
   const int Ktot = g.Kseg[0] + g.Kseg[1];
   const int k_begin = zs * g.klen;
   const int k_end = min(Ktot, k_begin + g.klen);
@@ -777,52 +788,59 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(W2Args g) {
   if (nkt > 0) issue(0, 0);
   for (int kt = 0; kt < nkt; ++kt) {
     __syncthreads();
-    if (kt + 1 < nkt) issue((kt + 1) & 1, kt + 1);
     const unsigned char* sl = reinterpret_cast<const unsigned char*>(lds + (kt & 1) * STAGE);
     const unsigned char* sh = sl + 64 * 256;
+    // all transposed fragment reads of this tile, then the next tile's DMA, then the MFMAs (see gather kernel)
+    s16x8_t qa[4][2], qb[4][2];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int prow = ks * 16 + 8 * fh + q;
-      bf16x8_t fa[2], fb[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int chunk = wm * 8 + i * 4 + 2 * cb + (p4 >> 1);
-        const unsigned char* pa = sl + prow * 256 + ((chunk ^ f1) << 4) + (p4 & 1) * 8;
-        const unsigned char* pb = sl + (prow + 4) * 256 + ((chunk ^ f2) << 4) + (p4 & 1) * 8;
-        s16x4_t lo = lds_tr_read(reinterpret_cast<const uint16_t*>(pa));
-        s16x4_t hi = lds_tr_read(reinterpret_cast<const uint16_t*>(pb));
-        fa[i] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        const int ca = wm * 8 + i * 4 + 2 * cb + (p4 >> 1), cbk = wn * 8 + i * 4 + 2 * cb + (p4 >> 1);
+        s16x4_t lo = lds_tr_read(reinterpret_cast<const uint16_t*>(sl + prow * 256 + ((ca ^ f1) << 4) + (p4 & 1) * 8));
+        s16x4_t hi = lds_tr_read(reinterpret_cast<const uint16_t*>(sl + (prow + 4) * 256 + ((ca ^ f2) << 4) + (p4 & 1) * 8));
+        qa[ks][i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        lo = lds_tr_read(reinterpret_cast<const uint16_t*>(sh + prow * 256 + ((cbk ^ f1) << 4) + (p4 & 1) * 8));
+        hi = lds_tr_read(reinterpret_cast<const uint16_t*>(sh + (prow + 4) * 256 + ((cbk ^ f2) << 4) + (p4 & 1) * 8));
+        qb[ks][i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       }
+    }
+    if (kt + 1 < nkt) issue((kt + 1) & 1, kt + 1);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int chunk = wn * 8 + j * 4 + 2 * cb + (p4 >> 1);
-        const unsigned char* pa = sh + prow * 256 + ((chunk ^ f1) << 4) + (p4 & 1) * 8;
-        const unsigned char* pb = sh + (prow + 4) * 256 + ((chunk ^ f2) << 4) + (p4 & 1) * 8;
-        s16x4_t lo = lds_tr_read(reinterpret_cast<const uint16_t*>(pa));
-        s16x4_t hi = lds_tr_read(reinterpret_cast<const uint16_t*>(pb));
-        fb[j] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-      }
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, qa[ks][i]),
+                                                              __builtin_bit_cast(bf16x8_t, qb[ks][j]), acc[i][j], 0, 0,
+                                                              0);
+    __builtin_amdgcn_s_setprio(0);
   }
+  __syncthreads();
 
+  // epilogue: accumulators -> LDS fp32 [128][128] -> 16-byte stores, 512 contiguous bytes per slab row
+  float* cs = reinterpret_cast<float*>(lds);
   const int fr = lane & 31, fh2 = lane >> 5;
-  const long long ldw = (long long)16 * g.I;
-  float* slab = g.slab + (long long)zs * g.O * ldw;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int o = o0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh2;
-        int c = c0 + wn * 64 + j * 32 + fr;
-        slab[(long long)o * ldw + c] = acc[i][j][r];
-      }
+      for (int r = 0; r < 16; ++r)
+        cs[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh2) * 128 + wn * 64 + j * 32 + fr] = acc[i][j][r];
+  __syncthreads();
+  const long long ldw = (long long)16 * g.I;
+  float* slab = g.slab + (long long)zs * g.O * ldw;
+  const int c4 = (t & 31) * 4, rr = t >> 5;
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    const int row = rr + 8 * p;
+    *reinterpret_cast<float4*>(slab + (long long)(o0 + row) * ldw + c0 + c4) =
+        *reinterpret_cast<const float4*>(cs + row * 128 + c4);
+  }
 }
 
 // ================================================================================================
@@ -1129,7 +1147,8 @@ int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, c
   int klen = (K + nsplit - 1) / nsplit;
   g.klen = (klen + 63) / 64 * 64;
   nsplit = (K + g.klen - 1) / g.klen;
-  hipLaunchKernelGGL(wgrad_dma_kernel, dim3((O / 128) * g.tiles_c, nsplit), dim3(256), 0, st, g);
+  g.tiles_o = O / 128; g.nsplit = nsplit;
+  hipLaunchKernelGGL(wgrad_dma_kernel, dim3((unsigned)(g.tiles_o * g.tiles_c * nsplit)), dim3(256), 0, st, g);
   RG_LAUNCH_CHECK("conv_wgrad(mfma)");
   return rg_reduce_slabs((const float*)ws, dw, elems, nsplit, accumulate, 1, I, st);
 }
