@@ -109,11 +109,45 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slab, float* __res
   dst[idx] = s;
 }
 
+// perm_mode 1, LDS-tiled: block = one o-row x 64 consecutive i.  Reads 16 tap-rows of 64 floats (256
+// contiguous bytes each, summed over the splits), transposes through LDS, writes 64 x 16 contiguous floats.
+__global__ __launch_bounds__(256) void reduce_slabs_tap_kernel(const float* __restrict__ slab, float* __restrict__ dst,
+                                                               size_t n, int nsplit, int accumulate, int I) {
+  __shared__ float tile[64][17];
+  const int t = threadIdx.x;
+  const int itiles = I >> 6;
+  const int o = blockIdx.x / itiles, i0 = (blockIdx.x - o * itiles) << 6;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = t + 256 * r, tap = e >> 6, ii = e & 63;
+    const size_t src = ((size_t)o * 16 + tap) * I + i0 + ii;
+    float v = 0.f;
+    for (int z = 0; z < nsplit; ++z) v += slab[(size_t)z * n + src];
+    tile[ii][tap] = v;
+  }
+  __syncthreads();
+  const int ii = t >> 2, t4 = (t & 3) * 4;
+  float* d = dst + ((size_t)o * I + i0 + ii) * 16 + t4;
+  float4 v = make_float4(tile[ii][t4], tile[ii][t4 + 1], tile[ii][t4 + 2], tile[ii][t4 + 3]);
+  if (accumulate) {
+    float4 a = *reinterpret_cast<const float4*>(d);
+    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+  }
+  *reinterpret_cast<float4*>(d) = v;
+}
+
 }  // namespace
 
 int rg_reduce_slabs(const float* slab, float* dst, size_t n, int nsplit, int accumulate, int perm_mode, int Q,
                     hipStream_t st) {
   if (n == 0) return RG_OK;
+  if (perm_mode == 1 && Q % 64 == 0 && nsplit <= 4) {   // many splits: the element-wise form has more parallelism
+    size_t O = n / ((size_t)Q * 16);
+    hipLaunchKernelGGL(reduce_slabs_tap_kernel, dim3((unsigned)(O * (Q / 64))), dim3(256), 0, st, slab, dst, n, nsplit,
+                       accumulate, Q);
+    RG_LAUNCH_CHECK("reduce_slabs");
+    return RG_OK;
+  }
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, dst, n, nsplit,
                      accumulate, perm_mode, 0, Q);
   RG_LAUNCH_CHECK("reduce_slabs");
