@@ -136,11 +136,37 @@ __global__ __launch_bounds__(256) void reduce_slabs_tap_kernel(const float* __re
   *reinterpret_cast<float4*>(d) = v;
 }
 
+// identity layout, MANY slabs of a small tensor (image-side weight gradients: 1024 x 12 KB): 16 elements x
+// 16 slab lanes per block, fixed summation order (lane-strided partials, then lane 0..15).
+__global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __restrict__ slab, float* __restrict__ dst,
+                                                                size_t n, int nsplit, int accumulate) {
+  __shared__ float sm[16][17];
+  const int e = threadIdx.x & 15, l = threadIdx.x >> 4;
+  const size_t idx = (size_t)blockIdx.x * 16 + e;
+  float s = 0.f;
+  if (idx < n)
+    for (int z = l; z < nsplit; z += 16) s += slab[(size_t)z * n + idx];
+  sm[l][e] = s;
+  __syncthreads();
+  if (l == 0 && idx < n) {
+    float t = accumulate ? dst[idx] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sm[k][e];
+    dst[idx] = t;
+  }
+}
+
 }  // namespace
 
 int rg_reduce_slabs(const float* slab, float* dst, size_t n, int nsplit, int accumulate, int perm_mode, int Q,
                     hipStream_t st) {
   if (n == 0) return RG_OK;
+  if (perm_mode == 0 && nsplit >= 64 && n <= (1u << 20)) {
+    hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, slab, dst, n, nsplit,
+                       accumulate);
+    RG_LAUNCH_CHECK("reduce_slabs");
+    return RG_OK;
+  }
   if (perm_mode == 1 && Q % 64 == 0 && nsplit <= 4) {   // many splits: the element-wise form has more parallelism
     size_t O = n / ((size_t)Q * 16);
     hipLaunchKernelGGL(reduce_slabs_tap_kernel, dim3((unsigned)(O * (Q / 64))), dim3(256), 0, st, slab, dst, n, nsplit,

@@ -61,7 +61,9 @@ class StepGraph:
             try:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=_pool()):
+                # thread_local: other threads (RCCL's watchdog polls events) may touch the HIP runtime while
+                # this thread captures; the default global mode turns that into a capture error / hang
+                with torch.cuda.graph(g, pool=_pool(), capture_error_mode="thread_local"):
                     self.static_out = self._run()
                 self.graph = g
             except Exception as e:  # capture unsupported (e.g. a collective that cannot be captured)

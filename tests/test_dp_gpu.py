@@ -44,8 +44,8 @@ def _run(tmp_path, force):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / ("dp%d.pt" % force))
     env = dict(os.environ, REPO=repo, OUT=out, RNAGAN_FORCE_DP=str(force), MASTER_ADDR="127.0.0.1",
-               MASTER_PORT="29533", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+               MASTER_PORT=str(29533 + force), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=150)
     assert r.returncode == 0, r.stderr[-3000:]
     import torch
     return torch.load(out)

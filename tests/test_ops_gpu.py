@@ -92,11 +92,12 @@ def test_conv_down_up_wgrad(N, Hi, Wi, I, O, dtype):
     check(dw2, dw2_ref, TOL[dtype] * 2, "conv_wgrad2")
 
 
-@pytest.mark.parametrize("O,dtype", [(4, torch.float32), (4, torch.bfloat16), (64, torch.float32),
-                                     (64, torch.bfloat16), (128, torch.bfloat16)])
-def test_image_side_layers(O, dtype):
+@pytest.mark.parametrize("O,dtype,W", [(4, torch.float32, 32), (4, torch.bfloat16, 32), (64, torch.float32, 32),
+                                       (64, torch.bfloat16, 32), (128, torch.bfloat16, 32),
+                                       (64, torch.bfloat16, 128), (64, torch.bfloat16, 64)])   # last two: MFMA path
+def test_image_side_layers(O, dtype, W):
     ref, hip = RefOps(dtype), _hip(dtype)
-    N, H, W, I = 3, 16, 32, 3
+    N, H, I = 3, 16, 3
     w = rnd((O, I, 4, 4), 4, 0.2)
     b = rnd((O,), 5, 0.1)
     cr, ch = cwpair(w)
