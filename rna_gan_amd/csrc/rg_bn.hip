@@ -1,23 +1,27 @@
 // rg_bn.hip -- train-mode BatchNorm2d + LeakyReLU on NHWC [M][C] tensors: forward, backward,
 // forward-mode tangent and the joint (double) backward of the gradient penalty; pointwise helpers.
-// All HBM-bound: one coalesced pass per tensor, 8/16-byte vector accesses, per-channel sums through
-// a deterministic two-stage column reduction (partials in the caller's workspace).
+// All HBM-bound streaming kernels built on ONE skeleton ("row loop"): a thread owns a fixed vector of
+// VEC consecutive channels (16-byte accesses for bf16, VEC = 8), loads the per-channel parameters into
+// registers ONCE, then walks rows with a stride of TY; a wave covers whole 128..512-byte row segments.
+// Per-channel sums use a deterministic two-stage reduction (block partials in the caller's workspace,
+// then a small finishing kernel).
 #include "rg_common.h"
 
 namespace {
 
-constexpr int CR_TX = 32;  // channel-vector lanes per block
-constexpr int CR_TY = 8;   // row lanes per block
+struct Plan { int vec, tx, gx, gy, rows_per_block; };
 
-struct CRPlan { int gx, gy, rows_per_block; };
-
-static CRPlan cr_plan(int M, int C, int vec) {
-  CRPlan p;
-  int cvec = (C + vec - 1) / vec;
-  p.gx = (cvec + CR_TX - 1) / CR_TX;
-  // enough row-chunks to fill 256 CUs x 4-8 blocks, but few enough that the finishing pass stays tiny
-  int want = (1536 + p.gx - 1) / p.gx;
-  int maxg = (M + 4 * CR_TY - 1) / (4 * CR_TY);
+template <typename T>
+static Plan make_plan(int M, int C, int target_blocks) {
+  Plan p;
+  const int vmax = sizeof(T) == 2 ? 8 : 4;
+  p.vec = (C % vmax == 0) ? vmax : (C % 4 == 0 ? 4 : 1);
+  int cvec = (C + p.vec - 1) / p.vec;
+  p.tx = cvec >= 32 ? 32 : (cvec >= 16 ? 16 : 8);
+  p.gx = (cvec + p.tx - 1) / p.tx;
+  int ty = 256 / p.tx;
+  int want = (target_blocks + p.gx - 1) / p.gx;
+  int maxg = (M + 4 * ty - 1) / (4 * ty);
   p.gy = want < maxg ? want : maxg;
   if (p.gy < 1) p.gy = 1;
   if (p.gy > 512) p.gy = 512;
@@ -25,13 +29,20 @@ static CRPlan cr_plan(int M, int C, int vec) {
   p.gy = (M + p.rows_per_block - 1) / p.rows_per_block;
   return p;
 }
-static inline int vec_of(int C) { return (C % 4 == 0) ? 4 : 1; }
 
-template <int NQ, int VEC, class F>
-__global__ __launch_bounds__(256) void colreduce_kernel(F f, int M, int C, int rows_per_block, float* partial) {
-  __shared__ float sm[CR_TY][NQ][CR_TX * VEC];
-  const int tx = threadIdx.x % CR_TX, ty = threadIdx.x / CR_TX;
-  const int c = (blockIdx.x * CR_TX + tx) * VEC;
+// upper bound of gy over both element types (workspace sizing)
+static int max_gy(int M, int C) {
+  Plan a = make_plan<float>(M, C, 1536), b = make_plan<bf16_t>(M, C, 1536);
+  return a.gy > b.gy ? a.gy : b.gy;
+}
+
+// ---- reduction skeleton: F has  init(c)  and  row(r, c, acc[NQ][VEC])
+template <int NQ, int VEC, int TX, class F>
+__global__ __launch_bounds__(256) void rowreduce_kernel(F f, int M, int C, int rows_per_block, float* partial) {
+  constexpr int TY = 256 / TX;
+  __shared__ float sm[TY][NQ][TX * VEC];
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int c = (blockIdx.x * TX + tx) * VEC;
   float acc[NQ][VEC];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
@@ -39,8 +50,10 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, int M, int C, int r
     for (int v = 0; v < VEC; ++v) acc[q][v] = 0.f;
   const int r0 = blockIdx.y * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
-  if (c < C)
-    for (int r = r0 + ty; r < r1; r += CR_TY) f(r, c, acc);
+  if (c < C) {
+    f.init(c);
+    for (int r = r0 + ty; r < r1; r += TY) f.row(r, c, acc);
+  }
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -53,14 +66,13 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, int M, int C, int r
       for (int v = 0; v < VEC; ++v) {
         float s = 0.f;
 #pragma unroll
-        for (int t = 0; t < CR_TY; ++t) s += sm[t][q][tx * VEC + v];
+        for (int t = 0; t < TY; ++t) s += sm[t][q][tx * VEC + v];
         partial[((size_t)blockIdx.y * NQ + q) * C + c + v] = s;
       }
   }
 }
 
-// finishing pass: block = 32 channels x 8 partial-row lanes; each lane strides over the G partial rows
-// (independent loads, pipelined), LDS tree over the 8 lanes, lane 0 applies the finisher.
+// finishing pass: block = 32 channels x 8 partial-row lanes
 template <int NQ, class Fin>
 __global__ __launch_bounds__(256) void colfinish_kernel(Fin fin, const float* partial, int C, int G) {
   __shared__ float sm[8][NQ][32];
@@ -90,72 +102,82 @@ __global__ __launch_bounds__(256) void colfinish_kernel(Fin fin, const float* pa
   }
 }
 
-template <int NQ, template <int> class F, class Fin, class... Args>
-int col_reduce(const char* name, int M, int C, void* ws, size_t ws_bytes, hipStream_t st, Fin fin, Args... args) {
-  int vec = vec_of(C);
-  CRPlan p = cr_plan(M, C, vec);
+// ---- pointwise skeleton: F has  init(c)  and  row(r, c)
+template <int VEC, int TX, class F>
+__global__ __launch_bounds__(256) void rowapply_kernel(F f, int M, int C, int rows_per_block) {
+  constexpr int TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int c = (blockIdx.x * TX + tx) * VEC;
+  if (c >= C) return;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  f.init(c);
+  for (int r = r0 + ty; r < r1; r += TY) f.row(r, c);
+}
+
+template <int NQ, typename T, template <typename, int> class F, class Fin, class... Args>
+int row_reduce(const char* name, int M, int C, void* ws, size_t ws_bytes, hipStream_t st, Fin fin, Args... args) {
+  Plan p = make_plan<T>(M, C, 1536);
   size_t need = (size_t)p.gy * NQ * C * sizeof(float);
   RG_REQUIRE(ws && ws_bytes >= need, RG_EWORKSPACE, "%s: workspace %zu < %zu", name, ws_bytes, need);
   float* partial = (float*)ws;
-  if (vec == 4) {
-    F<4> f{args...};
-    hipLaunchKernelGGL((colreduce_kernel<NQ, 4, F<4>>), dim3(p.gx, p.gy), dim3(256), 0, st, f, M, C, p.rows_per_block,
-                       partial);
-  } else {
-    F<1> f{args...};
-    hipLaunchKernelGGL((colreduce_kernel<NQ, 1, F<1>>), dim3(p.gx, p.gy), dim3(256), 0, st, f, M, C, p.rows_per_block,
-                       partial);
-  }
+  dim3 grid(p.gx, p.gy);
+#define RG_RR(V, X)                                                                                          \
+  do {                                                                                                       \
+    F<T, V> f{args...};                                                                                      \
+    hipLaunchKernelGGL((rowreduce_kernel<NQ, V, X, F<T, V>>), grid, dim3(256), 0, st, f, M, C, p.rows_per_block, partial); \
+  } while (0)
+  if (p.vec == 8) { if (p.tx == 32) RG_RR(8, 32); else if (p.tx == 16) RG_RR(8, 16); else RG_RR(8, 8); }
+  else if (p.vec == 4) { if (p.tx == 32) RG_RR(4, 32); else if (p.tx == 16) RG_RR(4, 16); else RG_RR(4, 8); }
+  else { if (p.tx == 32) RG_RR(1, 32); else if (p.tx == 16) RG_RR(1, 16); else RG_RR(1, 8); }
+#undef RG_RR
   RG_LAUNCH_CHECK(name);
   hipLaunchKernelGGL((colfinish_kernel<NQ, Fin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, partial, C, p.gy);
   RG_LAUNCH_CHECK(name);
   return RG_OK;
 }
 
-template <int VEC, class F>
-__global__ __launch_bounds__(256) void pointwise_kernel(F f, size_t nvec, int cvec) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
-    size_t row = i / cvec;
-    int c = (int)(i - row * cvec) * VEC;
-    f(row, c);
-  }
-}
-
-template <template <int> class F, class... Args>
-int pointwise(const char* name, int M, int C, hipStream_t st, Args... args) {
-  int vec = vec_of(C);
-  int cvec = C / vec;
-  size_t nvec = (size_t)M * cvec;
-  if (nvec == 0) return RG_OK;
-  size_t blocks = (nvec + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  if (vec == 4) {
-    F<4> f{args...};
-    hipLaunchKernelGGL((pointwise_kernel<4, F<4>>), dim3((unsigned)blocks), dim3(256), 0, st, f, nvec, cvec);
-  } else {
-    F<1> f{args...};
-    hipLaunchKernelGGL((pointwise_kernel<1, F<1>>), dim3((unsigned)blocks), dim3(256), 0, st, f, nvec, cvec);
-  }
+template <typename T, template <typename, int> class F, class... Args>
+int row_apply(const char* name, int M, int C, hipStream_t st, Args... args) {
+  Plan p = make_plan<T>(M, C, 4096);
+  dim3 grid(p.gx, p.gy);
+#define RG_RA(V, X)                                                                                   \
+  do {                                                                                                \
+    F<T, V> f{args...};                                                                               \
+    hipLaunchKernelGGL((rowapply_kernel<V, X, F<T, V>>), grid, dim3(256), 0, st, f, M, C, p.rows_per_block); \
+  } while (0)
+  if (p.vec == 8) { if (p.tx == 32) RG_RA(8, 32); else if (p.tx == 16) RG_RA(8, 16); else RG_RA(8, 8); }
+  else if (p.vec == 4) { if (p.tx == 32) RG_RA(4, 32); else if (p.tx == 16) RG_RA(4, 16); else RG_RA(4, 8); }
+  else { if (p.tx == 32) RG_RA(1, 32); else if (p.tx == 16) RG_RA(1, 16); else RG_RA(1, 8); }
+#undef RG_RA
   RG_LAUNCH_CHECK(name);
   return RG_OK;
 }
 
-// per-channel parameter bundle
+// per-channel parameter bundle (device pointers) and its register image for VEC channels
 struct BNC {
   const float* mean; const float* invstd; const float* gamma; const float* beta; float slope;
 };
+template <int VEC> struct BNR {
+  float mean[VEC], rstd[VEC], gam[VEC], bet[VEC];
+  __device__ __forceinline__ void load(const BNC& p, int c) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      mean[i] = p.mean[c + i]; rstd[i] = p.invstd[c + i]; gam[i] = p.gamma[c + i]; bet[i] = p.beta[c + i];
+    }
+  }
+};
 
 // ------------------------------------------------------------------------------------------ stats
-template <typename T> struct StatsF {
-  template <int VEC> struct K {
-    const T* z; int C;
-    __device__ void operator()(int r, int c, float (*acc)[VEC]) const {
-      float v[VEC];
-      Vec<T, VEC>::ld(z + (size_t)r * C + c, v);
+template <typename T, int VEC> struct StatsF {
+  const T* z; int C;
+  __device__ void init(int) {}
+  __device__ void row(int r, int c, float (*acc)[VEC]) const {
+    float v[VEC];
+    Vec<T, VEC>::ld(z + (size_t)r * C + c, v);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) { acc[0][i] += v[i]; acc[1][i] += v[i] * v[i]; }
-    }
-  };
+    for (int i = 0; i < VEC; ++i) { acc[0][i] += v[i]; acc[1][i] += v[i] * v[i]; }
+  }
 };
 struct Store2Fin {
   float* a; float* b;
@@ -163,39 +185,35 @@ struct Store2Fin {
 };
 
 // ------------------------------------------------------------------------------------------ bn_act
-template <typename T> struct BnActF {
-  template <int VEC> struct K {
-    const T* z; T* a; BNC p; int C;
-    __device__ void operator()(size_t r, int c) const {
-      float v[VEC], o[VEC];
-      Vec<T, VEC>::ld(z + r * C + c, v);
+template <typename T, int VEC> struct BnActF {
+  const T* z; T* a; BNC p; int C;
+  BNR<VEC> q;
+  __device__ void init(int c) { q.load(p, c); }
+  __device__ void row(int r, int c) const {
+    float v[VEC], o[VEC];
+    Vec<T, VEC>::ld(z + (size_t)r * C + c, v);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        float y = (v[i] - p.mean[c + i]) * (p.invstd[c + i] * p.gamma[c + i]) + p.beta[c + i];
-        o[i] = lrelu_f(y, p.slope);
-      }
-      Vec<T, VEC>::st(a + r * C + c, o);
-    }
-  };
+    for (int i = 0; i < VEC; ++i) o[i] = lrelu_f((v[i] - q.mean[i]) * (q.rstd[i] * q.gam[i]) + q.bet[i], p.slope);
+    Vec<T, VEC>::st(a + (size_t)r * C + c, o);
+  }
 };
 
 // ------------------------------------------------------------------------------------------ bwd
-template <typename T> struct BwdRedF {
-  template <int VEC> struct K {
-    const T* z; const T* ga; BNC p; int C;
-    __device__ void operator()(int r, int c, float (*acc)[VEC]) const {
-      float v[VEC], g[VEC];
-      Vec<T, VEC>::ld(z + (size_t)r * C + c, v);
-      Vec<T, VEC>::ld(ga + (size_t)r * C + c, g);
+template <typename T, int VEC> struct BwdRedF {
+  const T* z; const T* ga; BNC p; int C;
+  BNR<VEC> q;
+  __device__ void init(int c) { q.load(p, c); }
+  __device__ void row(int r, int c, float (*acc)[VEC]) const {
+    float v[VEC], g[VEC];
+    Vec<T, VEC>::ld(z + (size_t)r * C + c, v);
+    Vec<T, VEC>::ld(ga + (size_t)r * C + c, g);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        float xh = (v[i] - p.mean[c + i]) * p.invstd[c + i];
-        float y = xh * p.gamma[c + i] + p.beta[c + i];
-        float gy = g[i] * lrelu_mask(y, p.slope);
-        acc[0][i] += gy; acc[1][i] += gy * xh;
-      }
+    for (int i = 0; i < VEC; ++i) {
+      float xh = (v[i] - q.mean[i]) * q.rstd[i];
+      float gy = g[i] * lrelu_mask(xh * q.gam[i] + q.bet[i], p.slope);
+      acc[0][i] += gy; acc[1][i] += gy * xh;
     }
-  };
+  }
 };
 struct BwdFin {
   float* s_gy; float* s_gyxh; float* dgamma; float* dbeta; int accumulate;
@@ -207,82 +225,85 @@ struct BwdFin {
     }
   }
 };
-template <typename T> struct BwdApplyF {
-  template <int VEC> struct K {
-    const T* z; const T* ga; T* gz; BNC p; const float* s_gy; const float* s_gyxh; float inv_m; int C;
-    __device__ void operator()(size_t r, int c) const {
-      float v[VEC], g[VEC], o[VEC];
-      Vec<T, VEC>::ld(z + r * C + c, v);
-      Vec<T, VEC>::ld(ga + r * C + c, g);
+template <typename T, int VEC> struct BwdApplyF {
+  const T* z; const T* ga; T* gz; BNC p; const float* s_gy; const float* s_gyxh; float inv_m; int C;
+  BNR<VEC> q; float m1[VEC], m2[VEC];
+  __device__ void init(int c) {
+    q.load(p, c);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        float is = p.invstd[c + i], gm = p.gamma[c + i];
-        float xh = (v[i] - p.mean[c + i]) * is;
-        float y = xh * gm + p.beta[c + i];
-        float gy = g[i] * lrelu_mask(y, p.slope);
-        o[i] = (gm * is) * (gy - s_gy[c + i] * inv_m - xh * (s_gyxh[c + i] * inv_m));
-      }
-      Vec<T, VEC>::st(gz + r * C + c, o);
+    for (int i = 0; i < VEC; ++i) { m1[i] = s_gy[c + i] * inv_m; m2[i] = s_gyxh[c + i] * inv_m; }
+  }
+  __device__ void row(int r, int c) const {
+    float v[VEC], g[VEC], o[VEC];
+    Vec<T, VEC>::ld(z + (size_t)r * C + c, v);
+    Vec<T, VEC>::ld(ga + (size_t)r * C + c, g);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float xh = (v[i] - q.mean[i]) * q.rstd[i];
+      float gy = g[i] * lrelu_mask(xh * q.gam[i] + q.bet[i], p.slope);
+      o[i] = (q.gam[i] * q.rstd[i]) * (gy - m1[i] - xh * m2[i]);
     }
-  };
+    Vec<T, VEC>::st(gz + (size_t)r * C + c, o);
+  }
 };
 
 // ------------------------------------------------------------------------------------------ tangent
-template <typename T> struct TanRedF {
-  template <int VEC> struct K {
-    const T* z; const T* zt; BNC p; int C;
-    __device__ void operator()(int r, int c, float (*acc)[VEC]) const {
-      float v[VEC], t[VEC];
-      Vec<T, VEC>::ld(z + (size_t)r * C + c, v);
-      Vec<T, VEC>::ld(zt + (size_t)r * C + c, t);
+template <typename T, int VEC> struct TanRedF {
+  const T* z; const T* zt; BNC p; int C;
+  BNR<VEC> q;
+  __device__ void init(int c) { q.load(p, c); }
+  __device__ void row(int r, int c, float (*acc)[VEC]) const {
+    float v[VEC], t[VEC];
+    Vec<T, VEC>::ld(z + (size_t)r * C + c, v);
+    Vec<T, VEC>::ld(zt + (size_t)r * C + c, t);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        float xh = (v[i] - p.mean[c + i]) * p.invstd[c + i];
-        acc[0][i] += t[i]; acc[1][i] += xh * t[i];
-      }
+    for (int i = 0; i < VEC; ++i) {
+      float xh = (v[i] - q.mean[i]) * q.rstd[i];
+      acc[0][i] += t[i]; acc[1][i] += xh * t[i];
     }
-  };
+  }
 };
-template <typename T> struct TanApplyF {
-  template <int VEC> struct K {
-    const T* z; const T* zt; T* at; BNC p; const float* s_zt; const float* s_xhzt; float inv_m; int C;
-    __device__ void operator()(size_t r, int c) const {
-      float v[VEC], t[VEC], o[VEC];
-      Vec<T, VEC>::ld(z + r * C + c, v);
-      Vec<T, VEC>::ld(zt + r * C + c, t);
+template <typename T, int VEC> struct TanApplyF {
+  const T* z; const T* zt; T* at; BNC p; const float* s_zt; const float* s_xhzt; float inv_m; int C;
+  BNR<VEC> q; float m1[VEC], m2[VEC];
+  __device__ void init(int c) {
+    q.load(p, c);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        float is = p.invstd[c + i], gm = p.gamma[c + i];
-        float xh = (v[i] - p.mean[c + i]) * is;
-        float y = xh * gm + p.beta[c + i];
-        float yt = (gm * is) * (t[i] - s_zt[c + i] * inv_m - xh * (s_xhzt[c + i] * inv_m));
-        o[i] = yt * lrelu_mask(y, p.slope);
-      }
-      Vec<T, VEC>::st(at + r * C + c, o);
+    for (int i = 0; i < VEC; ++i) { m1[i] = s_zt[c + i] * inv_m; m2[i] = s_xhzt[c + i] * inv_m; }
+  }
+  __device__ void row(int r, int c) const {
+    float v[VEC], t[VEC], o[VEC];
+    Vec<T, VEC>::ld(z + (size_t)r * C + c, v);
+    Vec<T, VEC>::ld(zt + (size_t)r * C + c, t);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float xh = (v[i] - q.mean[i]) * q.rstd[i];
+      float yt = (q.gam[i] * q.rstd[i]) * (t[i] - m1[i] - xh * m2[i]);
+      o[i] = yt * lrelu_mask(xh * q.gam[i] + q.bet[i], p.slope);
     }
-  };
+    Vec<T, VEC>::st(at + (size_t)r * C + c, o);
+  }
 };
 
 // ------------------------------------------------------------------------------------------ double bwd
-template <typename T> struct DblRedF {
-  template <int VEC> struct K {
-    const T* z; const T* qa; const T* zt; const T* ga1; BNC p; int C;
-    __device__ void operator()(int r, int c, float (*acc)[VEC]) const {
-      float v[VEC], t[VEC], g[VEC], q[VEC];
-      Vec<T, VEC>::ld(z + (size_t)r * C + c, v);
-      Vec<T, VEC>::ld(zt + (size_t)r * C + c, t);
-      Vec<T, VEC>::ld(ga1 + (size_t)r * C + c, g);
-      if (qa) Vec<T, VEC>::ld(qa + (size_t)r * C + c, q);
+template <typename T, int VEC> struct DblRedF {
+  const T* z; const T* qa; const T* zt; const T* ga1; BNC p; int C;
+  BNR<VEC> q;
+  __device__ void init(int c) { q.load(p, c); }
+  __device__ void row(int r, int c, float (*acc)[VEC]) const {
+    float v[VEC], t[VEC], g[VEC], qq[VEC];
+    Vec<T, VEC>::ld(z + (size_t)r * C + c, v);
+    Vec<T, VEC>::ld(zt + (size_t)r * C + c, t);
+    Vec<T, VEC>::ld(ga1 + (size_t)r * C + c, g);
+    if (qa) Vec<T, VEC>::ld(qa + (size_t)r * C + c, qq);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        float xh = (v[i] - p.mean[c + i]) * p.invstd[c + i];
-        float y = xh * p.gamma[c + i] + p.beta[c + i];
-        float mk = lrelu_mask(y, p.slope);
-        acc[0][i] += g[i] * mk * t[i];
-        if (qa) { float qy = q[i] * mk; acc[1][i] += qy; acc[2][i] += qy * xh; }
-      }
+    for (int i = 0; i < VEC; ++i) {
+      float xh = (v[i] - q.mean[i]) * q.rstd[i];
+      float mk = lrelu_mask(xh * q.gam[i] + q.bet[i], p.slope);
+      acc[0][i] += g[i] * mk * t[i];
+      if (qa) { float qy = qq[i] * mk; acc[1][i] += qy; acc[2][i] += qy * xh; }
     }
-  };
+  }
 };
 // per-channel coefficients for the apply pass: coef[0]=A-3bc, [1]=c, [2]=b, [3]=s_qy/m, [4]=s_qyxh/m
 struct DblFin {
@@ -303,62 +324,54 @@ struct DblFin {
     else { dgamma[c] = dg; dbeta[c] = db; }
   }
 };
-template <typename T> struct DblApplyF {
-  template <int VEC> struct K {
-    const T* z; const T* qa; const T* zt; const T* ga1; T* pz; BNC p; const float* s_gy; const float* s_zt;
-    const float* coef; float inv_m; int C;
-    __device__ void operator()(size_t r, int c) const {
-      float v[VEC], t[VEC], g[VEC], q[VEC], o[VEC];
-      Vec<T, VEC>::ld(z + r * C + c, v);
-      Vec<T, VEC>::ld(zt + r * C + c, t);
-      Vec<T, VEC>::ld(ga1 + r * C + c, g);
-      if (qa) Vec<T, VEC>::ld(qa + r * C + c, q);
+template <typename T, int VEC> struct DblApplyF {
+  const T* z; const T* qa; const T* zt; const T* ga1; T* pz; BNC p; const float* s_gy; const float* s_zt;
+  const float* coef; float inv_m; int C;
+  BNR<VEC> q; float k0[VEC], k1[VEC], k2[VEC], k3[VEC], k4[VEC], mgy[VEC], mzt[VEC];
+  __device__ void init(int c) {
+    q.load(p, c);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        int ch = c + i;
-        float is = p.invstd[ch], gm = p.gamma[ch];
-        float xh = (v[i] - p.mean[ch]) * is;
-        float y = xh * gm + p.beta[ch];
-        float mk = lrelu_mask(y, p.slope);
-        float gy = g[i] * mk;
-        float r0 = xh * coef[0 * C + ch] + coef[1 * C + ch] * (gy - s_gy[ch] * inv_m) +
-                   coef[2 * C + ch] * (t[i] - s_zt[ch] * inv_m);
-        float out = -(gm * is * is) * r0;
-        if (qa) {
-          float qy = q[i] * mk;
-          out += (gm * is) * (qy - coef[3 * C + ch] - xh * coef[4 * C + ch]);
-        }
-        o[i] = out;
-      }
-      Vec<T, VEC>::st(pz + r * C + c, o);
+    for (int i = 0; i < VEC; ++i) {
+      k0[i] = coef[0 * C + c + i]; k1[i] = coef[1 * C + c + i]; k2[i] = coef[2 * C + c + i];
+      k3[i] = coef[3 * C + c + i]; k4[i] = coef[4 * C + c + i];
+      mgy[i] = s_gy[c + i] * inv_m; mzt[i] = s_zt[c + i] * inv_m;
     }
-  };
+  }
+  __device__ void row(int r, int c) const {
+    float v[VEC], t[VEC], g[VEC], qq[VEC], o[VEC];
+    Vec<T, VEC>::ld(z + (size_t)r * C + c, v);
+    Vec<T, VEC>::ld(zt + (size_t)r * C + c, t);
+    Vec<T, VEC>::ld(ga1 + (size_t)r * C + c, g);
+    if (qa) Vec<T, VEC>::ld(qa + (size_t)r * C + c, qq);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float is = q.rstd[i], gm = q.gam[i];
+      float xh = (v[i] - q.mean[i]) * is;
+      float mk = lrelu_mask(xh * gm + q.bet[i], p.slope);
+      float gy = g[i] * mk;
+      float r0 = xh * k0[i] + k1[i] * (gy - mgy[i]) + k2[i] * (t[i] - mzt[i]);
+      float out = -(gm * is * is) * r0;
+      if (qa) out += (gm * is) * (qq[i] * mk - k3[i] - xh * k4[i]);
+      o[i] = out;
+    }
+    Vec<T, VEC>::st(pz + (size_t)r * C + c, o);
+  }
 };
 
 // ------------------------------------------------------------------------------------------ misc
-template <typename T> struct ColSumF {
-  template <int VEC> struct K {
-    const T* g; int C;
-    __device__ void operator()(int r, int c, float (*acc)[VEC]) const {
-      float v[VEC];
-      Vec<T, VEC>::ld(g + (size_t)r * C + c, v);
+template <typename T, int VEC> struct ColSumF {
+  const T* g; int C;
+  __device__ void init(int) {}
+  __device__ void row(int r, int c, float (*acc)[VEC]) const {
+    float v[VEC];
+    Vec<T, VEC>::ld(g + (size_t)r * C + c, v);
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[0][i] += v[i];
-    }
-  };
+    for (int i = 0; i < VEC; ++i) acc[0][i] += v[i];
+  }
 };
 struct AccFin {
   float* out; int accumulate;
   __device__ void operator()(int c, const float* s) const { out[c] = accumulate ? out[c] + s[0] : s[0]; }
-};
-
-template <typename T> struct LreluBwdF {
-  template <int VEC> struct K {
-    const T* g; const T* a; T* out; float slope;
-    __device__ void operator()(size_t r, int c) const {   // called with C = VEC*cvec = row length
-      (void)c;
-    }
-  };
 };
 
 template <typename T, int VEC>
@@ -392,37 +405,18 @@ __global__ void bn_finalize_kernel(const float* sum, const float* sumsq, int M, 
 
 }  // namespace
 
-// helper aliases: template-template adaptors (F<VEC>) for col_reduce / pointwise
-#define RG_TT(NAME, OUTER) \
-  template <int V> using NAME = typename OUTER::template K<V>;
-
 extern "C" size_t rg_colreduce_workspace_bytes(int M, int C, int nq) {
   if (M <= 0 || C <= 0) return 0;
-  CRPlan p = cr_plan(M, C, vec_of(C));
   // partials + 5 per-channel coefficient rows used by rg_bn_double_bwd
-  return rg_align_up((size_t)p.gy * (nq < 1 ? 1 : nq) * C * sizeof(float), 256) + (size_t)5 * C * sizeof(float);
+  return rg_align_up((size_t)max_gy(M, C) * (nq < 1 ? 1 : nq) * C * sizeof(float), 256) + (size_t)5 * C * sizeof(float);
 }
-
-namespace {
-template <typename T> struct Impl {
-  RG_TT(StatsK, StatsF<T>)
-  RG_TT(BnActK, BnActF<T>)
-  RG_TT(BwdRedK, BwdRedF<T>)
-  RG_TT(BwdApplyK, BwdApplyF<T>)
-  RG_TT(TanRedK, TanRedF<T>)
-  RG_TT(TanApplyK, TanApplyF<T>)
-  RG_TT(DblRedK, DblRedF<T>)
-  RG_TT(DblApplyK, DblApplyF<T>)
-  RG_TT(ColSumK, ColSumF<T>)
-};
-}  // namespace
 
 extern "C" int rg_bn_stats(const void* z, float* sum, float* sumsq, int M, int C, int dtype, void* ws, size_t ws_bytes,
                            void* stream) {
   RG_REQUIRE(z && sum && sumsq && M > 0 && C > 0, RG_EINVAL, "bn_stats: bad args");
   RG_DISPATCH_DTYPE(dtype, T, {
-    return (col_reduce<2, Impl<T>::template StatsK>("bn_stats", M, C, ws, ws_bytes, rg_stream(stream),
-                                                     Store2Fin{sum, sumsq}, (const T*)z, C));
+    return (row_reduce<2, T, StatsF>("bn_stats", M, C, ws, ws_bytes, rg_stream(stream), Store2Fin{sum, sumsq},
+                                     (const T*)z, C));
   })
 }
 
@@ -441,7 +435,7 @@ extern "C" int rg_bn_act(const void* z, const float* mean, const float* invstd, 
   RG_REQUIRE(z && a && mean && invstd && gamma && beta && M > 0 && C > 0, RG_EINVAL, "bn_act: bad args");
   BNC p{mean, invstd, gamma, beta, slope};
   RG_DISPATCH_DTYPE(dtype, T, {
-    return (pointwise<Impl<T>::template BnActK>("bn_act", M, C, rg_stream(stream), (const T*)z, (T*)a, p, C));
+    return (row_apply<T, BnActF>("bn_act", M, C, rg_stream(stream), (const T*)z, (T*)a, p, C));
   })
 }
 
@@ -454,12 +448,11 @@ extern "C" int rg_bn_act_bwd(const void* z, const void* ga, const float* mean, c
   BNC p{mean, invstd, gamma, beta, slope};
   hipStream_t st = rg_stream(stream);
   RG_DISPATCH_DTYPE(dtype, T, {
-    int rc = col_reduce<2, Impl<T>::template BwdRedK>("bn_act_bwd", M, C, ws, ws_bytes, st,
-                                                       BwdFin{s_gy, s_gyxh, dgamma, dbeta, accumulate}, (const T*)z,
-                                                       (const T*)ga, p, C);
+    int rc = row_reduce<2, T, BwdRedF>("bn_act_bwd", M, C, ws, ws_bytes, st,
+                                       BwdFin{s_gy, s_gyxh, dgamma, dbeta, accumulate}, (const T*)z, (const T*)ga, p, C);
     if (rc) return rc;
-    return (pointwise<Impl<T>::template BwdApplyK>("bn_act_bwd", M, C, st, (const T*)z, (const T*)ga, (T*)gz, p,
-                                                    (const float*)s_gy, (const float*)s_gyxh, 1.f / (float)M, C));
+    return (row_apply<T, BwdApplyF>("bn_act_bwd", M, C, st, (const T*)z, (const T*)ga, (T*)gz, p, (const float*)s_gy,
+                                    (const float*)s_gyxh, 1.f / (float)M, C));
   })
 }
 
@@ -470,11 +463,11 @@ extern "C" int rg_bn_tangent(const void* z, const void* zt, const float* mean, c
   BNC p{mean, invstd, gamma, beta, slope};
   hipStream_t st = rg_stream(stream);
   RG_DISPATCH_DTYPE(dtype, T, {
-    int rc = col_reduce<2, Impl<T>::template TanRedK>("bn_tangent", M, C, ws, ws_bytes, st, Store2Fin{s_zt, s_xhzt},
-                                                       (const T*)z, (const T*)zt, p, C);
+    int rc = row_reduce<2, T, TanRedF>("bn_tangent", M, C, ws, ws_bytes, st, Store2Fin{s_zt, s_xhzt}, (const T*)z,
+                                       (const T*)zt, p, C);
     if (rc) return rc;
-    return (pointwise<Impl<T>::template TanApplyK>("bn_tangent", M, C, st, (const T*)z, (const T*)zt, (T*)at, p,
-                                                    (const float*)s_zt, (const float*)s_xhzt, 1.f / (float)M, C));
+    return (row_apply<T, TanApplyF>("bn_tangent", M, C, st, (const T*)z, (const T*)zt, (T*)at, p, (const float*)s_zt,
+                                    (const float*)s_xhzt, 1.f / (float)M, C));
   })
 }
 
@@ -491,14 +484,13 @@ extern "C" int rg_bn_double_bwd(const void* z, const void* qa, const void* zt, c
   BNC p{mean, invstd, gamma, beta, slope};
   hipStream_t st = rg_stream(stream);
   RG_DISPATCH_DTYPE(dtype, T, {
-    int rc = col_reduce<3, Impl<T>::template DblRedK>(
-        "bn_double_bwd", M, C, ws, ws_bytes - (size_t)5 * C * sizeof(float), st,
-        DblFin{s_gy, s_gyxh, s_zt, s_xhzt, invstd, coef, dgamma, dbeta, accumulate, (float)M, C}, (const T*)z,
-        (const T*)qa, (const T*)zt, (const T*)ga1, p, C);
+    int rc = row_reduce<3, T, DblRedF>("bn_double_bwd", M, C, ws, ws_bytes - (size_t)5 * C * sizeof(float), st,
+                                       DblFin{s_gy, s_gyxh, s_zt, s_xhzt, invstd, coef, dgamma, dbeta, accumulate,
+                                              (float)M, C},
+                                       (const T*)z, (const T*)qa, (const T*)zt, (const T*)ga1, p, C);
     if (rc) return rc;
-    return (pointwise<Impl<T>::template DblApplyK>("bn_double_bwd", M, C, st, (const T*)z, (const T*)qa, (const T*)zt,
-                                                    (const T*)ga1, (T*)pz, p, s_gy, s_zt, (const float*)coef,
-                                                    1.f / (float)M, C));
+    return (row_apply<T, DblApplyF>("bn_double_bwd", M, C, st, (const T*)z, (const T*)qa, (const T*)zt, (const T*)ga1,
+                                    (T*)pz, p, s_gy, s_zt, (const float*)coef, 1.f / (float)M, C));
   })
 }
 
@@ -506,8 +498,8 @@ extern "C" int rg_col_sum(const void* g, float* out, int M, int C, int dtype, in
                           void* stream) {
   RG_REQUIRE(g && out && M > 0 && C > 0, RG_EINVAL, "col_sum: bad args");
   RG_DISPATCH_DTYPE(dtype, T, {
-    return (col_reduce<1, Impl<T>::template ColSumK>("col_sum", M, C, ws, ws_bytes, rg_stream(stream),
-                                                      AccFin{out, accumulate}, (const T*)g, C));
+    return (row_reduce<1, T, ColSumF>("col_sum", M, C, ws, ws_bytes, rg_stream(stream), AccFin{out, accumulate},
+                                      (const T*)g, C));
   })
 }
 
@@ -516,10 +508,11 @@ extern "C" int rg_lrelu_bwd(const void* g, const void* a, void* out, size_t n, f
   if (n == 0) return RG_OK;
   hipStream_t st = rg_stream(stream);
   RG_DISPATCH_DTYPE(dtype, T, {
-    if (n % 4 == 0) {
-      size_t nvec = n / 4, blocks = (nvec + 255) / 256;
+    constexpr int VM = sizeof(T) == 2 ? 8 : 4;
+    if (n % VM == 0) {
+      size_t nvec = n / VM, blocks = (nvec + 255) / 256;
       if (blocks > 8192) blocks = 8192;
-      hipLaunchKernelGGL((lrelu_bwd_kernel<T, 4>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)g, (const T*)a,
+      hipLaunchKernelGGL((lrelu_bwd_kernel<T, VM>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)g, (const T*)a,
                          (T*)out, nvec, slope);
     } else {
       size_t blocks = (n + 255) / 256;

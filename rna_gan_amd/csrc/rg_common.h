@@ -95,6 +95,28 @@ template <> struct Vec<bf16_t, 4> {
   }
 };
 
+template <> struct Vec<float, 8> {
+  __device__ static __forceinline__ void ld(const float* p, float* o) { Vec<float, 4>::ld(p, o); Vec<float, 4>::ld(p + 4, o + 4); }
+  __device__ static __forceinline__ void st(float* p, const float* v) { Vec<float, 4>::st(p, v); Vec<float, 4>::st(p + 4, v + 4); }
+};
+template <> struct Vec<bf16_t, 8> {
+  __device__ static __forceinline__ void ld(const bf16_t* p, float* o) {
+    uint4 t = *reinterpret_cast<const uint4*>(p);
+    o[0] = __uint_as_float(t.x << 16); o[1] = __uint_as_float(t.x & 0xffff0000u);
+    o[2] = __uint_as_float(t.y << 16); o[3] = __uint_as_float(t.y & 0xffff0000u);
+    o[4] = __uint_as_float(t.z << 16); o[5] = __uint_as_float(t.z & 0xffff0000u);
+    o[6] = __uint_as_float(t.w << 16); o[7] = __uint_as_float(t.w & 0xffff0000u);
+  }
+  __device__ static __forceinline__ void st(bf16_t* p, const float* v) {
+    uint4 t;
+    t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    t.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+    t.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = t;
+  }
+};
+
 __device__ __forceinline__ float lrelu_f(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float lrelu_mask(float v, float slope) { return v > 0.f ? 1.f : slope; }
 
