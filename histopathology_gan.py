@@ -49,23 +49,38 @@ class SyntheticTiles(Dataset):
         return img, torch.tensor(0.0)
 
 
+# (flag, type, default, help) -- the reference's flag set (src/histopathology_gan.py:54-72) + this build's extras
+REFERENCE_FLAGS = [
+    ("--config", str, None, "JSON config file"),
+    ("--checkpoint", str, None, "File with the checkpoint to start with"),
+    ("--seed", int, 99, "Seed for random generation"),
+    ("--image_dir", str, "images", "Image dir to save image"),
+    ("--model_dir", str, "./model/gan", "Image dir to save model checkpoints"),
+    ("--num_epochs", int, None, "Number of epochs to train the model"),
+    ("--num_patches", int, 250, "Number of tiles to use per slide"),
+    ("--gan_type", str, "dcgan", "Architecture to use"),
+    ("--loss_type", str, "wgangp", "Loss type to use"),
+]
+EXTRA_FLAGS = [
+    ("--batch_size", int, 8, "per-process batch (the reference hard-codes 8, :94)"),
+    ("--precision", str, "bf16", "bf16 (MFMA kernels) or fp32 (parity mode)"),
+    ("--betavae_checkpoint", str, "checkpoints/betavae_training_tissues/model_dict_best.pt", "frozen betaVAE weights"),
+    ("--steps_per_epoch", int, 100, "synthetic dataset length / batch"),
+]
+
+
+def parse_args():
+    ap = argparse.ArgumentParser(description="GANs training on histology data (MI355X path)")
+    for flag, typ, default, text in REFERENCE_FLAGS + EXTRA_FLAGS:
+        ap.add_argument(flag, type=typ, default=default, help=text)
+    ap.add_argument("--synthetic", action="store_true", help="train on synthetic tiles / RNA rows")
+    return ap.parse_args()
+
+
 def main():
-    parser = argparse.ArgumentParser(description="GANs training on histology data (MI355X path)")
-    parser.add_argument("--config", type=str, help="JSON config file")
-    parser.add_argument("--checkpoint", type=str, default=None, help="File with the checkpoint to start with")
-    parser.add_argument("--seed", type=int, default=99, help="Seed for random generation")
-    parser.add_argument("--image_dir", type=str, default="images", help="Image dir to save image")
-    parser.add_argument("--model_dir", type=str, default="./model/gan", help="Image dir to save model checkpoints")
-    parser.add_argument("--num_epochs", type=int, default=None, help="Number of epochs to train the model")
-    parser.add_argument("--num_patches", type=int, default=250, help="Number of tiles to use per slide")
-    parser.add_argument("--gan_type", type=str, default="dcgan", help="Architecture to use")
-    parser.add_argument("--loss_type", type=str, default="wgangp", help="Loss type to use")
-    parser.add_argument("--synthetic", action="store_true", help="train on synthetic tiles / RNA rows")
-    parser.add_argument("--batch_size", type=int, default=8, help="reference hard-codes 8 (:94)")
-    parser.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    parser.add_argument("--betavae_checkpoint", default="checkpoints/betavae_training_tissues/model_dict_best.pt")
-    parser.add_argument("--steps_per_epoch", type=int, default=100, help="synthetic dataset length / batch")
-    args = parser.parse_args()
+    args = parse_args()
+    if args.precision not in ("bf16", "fp32"):
+        raise SystemExit("--precision must be bf16 or fp32")
 
     D_.init_from_env()
     torch.manual_seed(args.seed + D_.rank())
