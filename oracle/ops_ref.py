@@ -51,6 +51,15 @@ class RefOps:
     def _nchw(self, x):
         return x.to(self.f).permute(0, 3, 1, 2)
 
+    from contextlib import contextmanager as _cm
+
+    @_cm
+    def side(self, *tensors):
+        yield
+
+    def join(self):
+        pass
+
     def _wq(self, w):
         # the bf16 path computes with weights rounded to bf16
         return w.to(self.f) if self.act_dtype != torch.bfloat16 else w.to(self.act_dtype).to(self.f)

@@ -278,27 +278,39 @@ struct G2Args {
   GArgs g;
   unsigned a_bytes, b_bytes;   // sizes for the buffer descriptors
   int nsplit;
+  int xcd_swizzle;             // 1: remap blockIdx.x so each XCD (block b runs on XCD b % 8) owns a contiguous tile range
   float* slab;                 // [nsplit][rows_out][Ncols] fp32 when nsplit > 1
   long long slab_stride;       // elements per split
 };
 
 typedef __attribute__((address_space(3))) void* lds_vptr_t;
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// s_waitcnt immediate for vmcnt(n) only (expcnt/lgkmcnt left at their maxima); vmcnt is split over bits 3:0 and 15:14
+static constexpr int vmcnt_imm(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
 
-template <int MODE, int EPI, int BM, int BN, int NSTAGE, int NT>
-__global__ __launch_bounds__(NT, (NT == 512 || NSTAGE == 2) ? 2 : 1) void gather_gemm_dma_kernel(G2Args a2) {
-  constexpr int WN = BN / 64;                                // waves along N (64x64 wave tiles)
+template <int MODE, int EPI, int BM, int BN, int NSTAGE, int NT, int WTM = 64>
+__global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT == 256) ? 2 : 1) void gather_gemm_dma_kernel(G2Args a2) {
+  constexpr int WN = BN / 64;                                // waves along N (WTM x 64 wave tiles)
+  constexpr int TI = WTM / 32;                               // 32-row MFMA sub-tiles per wave (2 or 4)
   constexpr int RPI = NT / 8;                                // rows covered by one block-wide load instruction
   constexpr int A_SLOTS = BM * 8, B_SLOTS = BN * 8;          // 16-byte slots per stage
   constexpr int STAGE_SLOTS = A_SLOTS + B_SLOTS;
   constexpr int A_LD = BM / RPI, B_LD = BN / RPI;            // wave-instructions per thread per k-tile
-  static_assert((BM / 64) * WN * 64 == NT, "one 64x64 wave tile per wave");
-  constexpr int LDS_SLOTS = (NSTAGE * STAGE_SLOTS * 16 > BM * BN * 4) ? NSTAGE * STAGE_SLOTS : BM * BN / 4;
+  static_assert((BM / WTM) * WN * 64 == NT, "one WTM x 64 wave tile per wave");
+  static_assert(TI == 2 || TI == 4, "wave tile is 64x64 or 128x64");
+  // the epilogue goes through LDS in column slices of EP_COLS when the whole fp32 tile does not fit
+  constexpr int EP_COLS = (BM * BN * 4 <= 128 * 1024) ? BN : BN / 2;
+  constexpr int LDS_SLOTS = (NSTAGE * STAGE_SLOTS * 16 > BM * EP_COLS * 4) ? NSTAGE * STAGE_SLOTS : BM * EP_COLS / 4;
   __shared__ __attribute__((aligned(16))) uint4 lds[LDS_SLOTS];
   const GArgs& g = a2.g;
 
   const int t = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int tile_m = blockIdx.x / g.tiles_n, tile_n = blockIdx.x - tile_m * g.tiles_n;
+  // consecutive workgroups go to consecutive XCDs; giving XCD x the x-th contiguous eighth of the tile list keeps
+  // the A rows that neighbouring column tiles (and neighbouring output rows) share inside one XCD's L2
+  int bid = blockIdx.x;
+  if (a2.xcd_swizzle) bid = (bid & 7) * ((int)gridDim.x >> 3) + (bid >> 3);
+  const int tile_m = bid / g.tiles_n, tile_n = bid - tile_m * g.tiles_n;
   const int bm = tile_m * BM, bn = tile_n * BN;
   const int par = (MODE == MODE_UP) ? (int)blockIdx.y : 0;
   const int ph = par >> 1, pw = par & 1;
@@ -398,9 +410,9 @@ __global__ __launch_bounds__(NT, (NT == 512 || NSTAGE == 2) ? 2 : 1) void gather
   const int lane = t & 63;
   const int wm = wave / WN, wn = wave - wm * WN;
   const int fr = lane & 31, fh = lane >> 5;
-  f32x16_t acc[2][2];
+  f32x16_t acc[TI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -415,101 +427,144 @@ __global__ __launch_bounds__(NT, (NT == 512 || NSTAGE == 2) ? 2 : 1) void gather
       if (++cc_n == cpt) { cc_n = 0; ++tap_n; }
     }
   int st_c = 0, st_i = NSTAGE - 1;     // stage being computed / stage to issue into
+  // Fragment reads are asm ds_read_b128 with hand-counted lgkmcnt waits.  (1) hipcc puts s_waitcnt vmcnt(0) in
+  // front of every compiler-visible ds_read that follows an outstanding LDS-DMA (it assumes they alias), which
+  // drains the prefetch queue each k-tile; (2) fragments are double-buffered per 16-wide k-step: the reads of
+  // step kk+1 are in flight during the MFMAs of step kk (LDS returns in order, so lgkmcnt(TI+2) means "step kk
+  // landed" even with scalar loads outstanding).
+  // LDS bandwidth is what bounds this kernel: a WTM x 64 wave tile reads (WTM+64)*32 B per k-step for
+  // WTM*64*32 flops, i.e. 32 flop/B at 64x64 (= the full 128 B/clk/CU LDS rate at MFMA peak) and 42.7 at 128x64.
+  const unsigned lds_base = (unsigned)(size_t)(lds_vptr_t)lds;
+  const int rowA = wm * WTM + fr, rowB = wn * 64 + fr;
+  const int c0a = fh ^ ((rowA >> 1) & 7), c0b = fh ^ ((rowB >> 1) & 7);   // chunk(kk) = c0 ^ 2kk; +32 rows keeps the swizzle
+  unsigned fa[4], fb[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    fa[kk] = lds_base + 16u * (unsigned)(rowA * 8 + (c0a ^ (2 * kk)));
+    fb[kk] = lds_base + 16u * (unsigned)(A_SLOTS + rowB * 8 + (c0b ^ (2 * kk)));
+  }
+#define RG_DSR(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:" #imm : "=v"(dst) : "v"(addr) : "memory")
+#define RG_READ(buf, kk)                                  \
+  do {                                                    \
+    RG_DSR(qa[buf][0], fas[kk], 0);                       \
+    RG_DSR(qb[buf][0], fbs[kk], 0);                       \
+    RG_DSR(qa[buf][1], fas[kk], 4096);                    \
+    RG_DSR(qb[buf][1], fbs[kk], 4096);                    \
+    if constexpr (TI == 4) {                              \
+      RG_DSR(qa[buf][2], fas[kk], 8192);                  \
+      RG_DSR(qa[buf][3], fas[kk], 12288);                 \
+    }                                                     \
+  } while (0)
+#define RG_WAIT(buf, cnt4, cnt6)                                                                                    \
+  do {                                                                                                              \
+    if constexpr (TI == 4)                                                                                          \
+      asm volatile("s_waitcnt lgkmcnt(" #cnt6 ")"                                                                   \
+                   : "+v"(qa[buf][0]), "+v"(qa[buf][1]), "+v"(qa[buf][2]), "+v"(qa[buf][3]), "+v"(qb[buf][0]),      \
+                     "+v"(qb[buf][1])::"memory");                                                                   \
+    else                                                                                                            \
+      asm volatile("s_waitcnt lgkmcnt(" #cnt4 ")"                                                                   \
+                   : "+v"(qa[buf][0]), "+v"(qa[buf][1]), "+v"(qb[buf][0]), "+v"(qb[buf][1])::"memory");             \
+  } while (0)
+#define RG_MFMAS(buf)                                                                                              \
+  _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] =         \
+      __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, qa[buf][i]),                            \
+                                              __builtin_bit_cast(bf16x8_t, qb[buf][j]), acc[i][j], 0, 0, 0)
+  constexpr int WAIT_A = vmcnt_imm((A_LD + B_LD) * (NSTAGE > 2 ? NSTAGE - 2 : 0));
+  constexpr int WAIT_B = vmcnt_imm((A_LD + B_LD) * (NSTAGE > 3 ? NSTAGE - 3 : 0));
   for (int kt = 0; kt < nkt; ++kt) {
-    if (NSTAGE == 2) {
-      __syncthreads();   // vmcnt(0): own DMAs of tile kt landed; barrier: everyone's landed and everyone finished
-                         // reading the stage about to be overwritten
-    } else {
-      // counted wait: only tile kt has to be here, the NSTAGE-2 younger tiles stay in flight across the barrier
-      if (kt + NSTAGE - 2 < nkt) __builtin_amdgcn_s_waitcnt(0x0F70 | ((A_LD + B_LD) * (NSTAGE - 2)));   // vmcnt(N)
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
-    const uint4* sa = lds + st_c * STAGE_SLOTS;
-    const uint4* sb = sa + A_SLOTS;
-    // ALL fragment reads of this tile first, THEN the DMA of the next tile, THEN the MFMAs: hipcc puts a
-    // vmcnt(0) in front of any ds_read that follows an outstanding LDS-DMA (it assumes they may alias), which
-    // would serialise the prefetch with the compute if reads came after the issue.
-    uint4 qa[4][2], qb[4][2];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int ch = 2 * kk + fh;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        qa[kk][i] = sa[lds_chunk_index(wm * 64 + i * 32 + fr, ch)];
-        qb[kk][i] = sb[lds_chunk_index(wn * 64 + i * 32 + fr, ch)];
-      }
-    }
-    if (kt + NSTAGE - 1 < nkt) {
+    // counted wait: only tile kt has to be here, the NSTAGE-2 younger tiles stay in flight across the barrier
+    if (NSTAGE > 2 && kt + NSTAGE - 2 < nkt) __builtin_amdgcn_s_waitcnt(WAIT_A);
+    else if (NSTAGE > 3 && kt + NSTAGE - 3 < nkt) __builtin_amdgcn_s_waitcnt(WAIT_B);
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // everyone's part of tile kt landed; everyone finished reading tile kt-1
+    if (kt + NSTAGE - 1 < nkt) {       // refill the stage tile kt-1 lived in
       issue(st_i, tap_n, cc_n << 6);
       if (++cc_n == cpt) { cc_n = 0; ++tap_n; }
     }
+    const unsigned so = (unsigned)(st_c * STAGE_SLOTS * 16);
+    unsigned fas[4], fbs[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { fas[kk] = fa[kk] + so; fbs[kk] = fb[kk] + so; }
+    u32x4_t qa[2][TI], qb[2][2];
+    RG_READ(0, 0);
+    RG_READ(1, 1);
     __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, qa[kk][i]),
-                                                              __builtin_bit_cast(bf16x8_t, qb[kk][j]), acc[i][j], 0, 0,
-                                                              0);
+    RG_WAIT(0, 4, 6);
+    RG_MFMAS(0);
+    RG_READ(0, 2);
+    RG_WAIT(1, 4, 6);
+    RG_MFMAS(1);
+    RG_READ(1, 3);
+    RG_WAIT(0, 4, 6);
+    RG_MFMAS(0);
+    RG_WAIT(1, 0, 0);
+    RG_MFMAS(1);
     __builtin_amdgcn_s_setprio(0);
     st_c = st_c + 1 == NSTAGE ? 0 : st_c + 1;
     st_i = st_i + 1 == NSTAGE ? 0 : st_i + 1;
   }
+#undef RG_DSR
+#undef RG_READ
+#undef RG_WAIT
+#undef RG_MFMAS
   __syncthreads();
 
-  // ---- epilogue through LDS (fp32 [BM][BN])
+  // ---- epilogue through LDS (fp32 [BM][EP_COLS] per pass)
   float* cs = reinterpret_cast<float*>(lds);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        int col = wn * 64 + j * 32 + fr;
-        cs[row * BN + col] = acc[i][j][r];
-      }
-  __syncthreads();
-  constexpr int CG = BN / 8, RPP = NT / CG;      // column groups per row, rows per pass
+  constexpr int CG = EP_COLS / 8, RPP = NT / CG;      // column groups per row, rows per pass
   const int cg = t % CG, rr = t / CG;
-  const int col = bn + cg * 8;
+#pragma unroll 1
+  for (int ep = 0; ep < BN / EP_COLS; ++ep) {
+    if (ep) __syncthreads();
+    if ((wn * 64) / EP_COLS == ep) {
 #pragma unroll
-  for (int p = 0; p < BM / RPP; ++p) {
-    int row = rr + RPP * p;
-    int m = bm + row;
-    if (m >= g.M || col >= g.Ncols) continue;
-    float4 v0 = *reinterpret_cast<const float4*>(cs + row * BN + cg * 8);
-    float4 v1 = *reinterpret_cast<const float4*>(cs + row * BN + cg * 8 + 4);
-    long long orow;
-    if (MODE == MODE_UP) {
-      int wq = m & (Wq - 1), hq = (m >> g.lgW) & (Hq - 1), n = m >> (g.lgW + g.lgH);
-      orow = ((long long)n * (2 * Hq) + 2 * hq + ph) * (2 * Wq) + 2 * wq + pw;
-    } else {
-      orow = m;
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            int col = wn * 64 - ep * EP_COLS + j * 32 + fr;
+            cs[row * EP_COLS + col] = acc[i][j][r];
+          }
     }
-    if (a2.nsplit > 1) {
-      float* so = a2.slab + (long long)zs * a2.slab_stride + orow * g.ldc + col;
-      *reinterpret_cast<float4*>(so) = v0;
-      *reinterpret_cast<float4*>(so + 4) = v1;
-    } else if (EPI == EPI_BF16) {
-      uint4 o;
-      o.x = (uint32_t)f32_to_bf16(v0.x) | ((uint32_t)f32_to_bf16(v0.y) << 16);
-      o.y = (uint32_t)f32_to_bf16(v0.z) | ((uint32_t)f32_to_bf16(v0.w) << 16);
-      o.z = (uint32_t)f32_to_bf16(v1.x) | ((uint32_t)f32_to_bf16(v1.y) << 16);
-      o.w = (uint32_t)f32_to_bf16(v1.z) | ((uint32_t)f32_to_bf16(v1.w) << 16);
-      *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(g.C) + orow * g.ldc + col) = o;
-    } else {
-      float vals[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      float* yo = reinterpret_cast<float*>(g.C) + orow * g.ldc + col;
+    __syncthreads();
+    const int col = bn + ep * EP_COLS + cg * 8;
+#pragma unroll 4
+    for (int p = 0; p < BM / RPP; ++p) {
+      int row = rr + RPP * p;
+      int m = bm + row;
+      if (m >= g.M || col >= g.Ncols) continue;
+      float4 v0 = *reinterpret_cast<const float4*>(cs + row * EP_COLS + cg * 8);
+      float4 v1 = *reinterpret_cast<const float4*>(cs + row * EP_COLS + cg * 8 + 4);
+      long long orow;
+      if (MODE == MODE_UP) {
+        int wq = m & (Wq - 1), hq = (m >> g.lgW) & (Hq - 1), n = m >> (g.lgW + g.lgH);
+        orow = ((long long)n * (2 * Hq) + 2 * hq + ph) * (2 * Wq) + 2 * wq + pw;
+      } else {
+        orow = m;
+      }
+      if (a2.nsplit > 1) {
+        float* so = a2.slab + (long long)zs * a2.slab_stride + orow * g.ldc + col;
+        *reinterpret_cast<float4*>(so) = v0;
+        *reinterpret_cast<float4*>(so + 4) = v1;
+      } else if (EPI == EPI_BF16) {
+        uint4 o;
+        o.x = (uint32_t)f32_to_bf16(v0.x) | ((uint32_t)f32_to_bf16(v0.y) << 16);
+        o.y = (uint32_t)f32_to_bf16(v0.z) | ((uint32_t)f32_to_bf16(v0.w) << 16);
+        o.z = (uint32_t)f32_to_bf16(v1.x) | ((uint32_t)f32_to_bf16(v1.y) << 16);
+        o.w = (uint32_t)f32_to_bf16(v1.z) | ((uint32_t)f32_to_bf16(v1.w) << 16);
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(g.C) + orow * g.ldc + col) = o;
+      } else {
+        float vals[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        float* yo = reinterpret_cast<float*>(g.C) + orow * g.ldc + col;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float v = vals[e];
-        if (g.scale) v *= g.scale[col + e];
-        if (g.shift) v += g.shift[col + e];
-        yo[e] = lrelu_f(v, g.slope);
+        for (int e = 0; e < 8; ++e) {
+          float v = vals[e];
+          if (g.scale) v *= g.scale[col + e];
+          if (g.shift) v += g.shift[col + e];
+          yo[e] = lrelu_f(v, g.slope);
+        }
       }
     }
   }
@@ -989,26 +1044,39 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   const int nkt = g.taps * (g.Cin >> 6);
   // conv outputs: up to 4 splits; dense weight-streaming layers (M = batch): up to 16 (HBM-bound, the grid
   // must cover all CUs to pull full bandwidth)
-  int nsplit = EPI == EPI_BF16 ? gather_split(g.M, g.Ncols, nclass, nkt, true)
-                               : gather_split(g.M, g.Ncols, nclass, nkt, true, 16, 8);
+  const bool narrow = g.Ncols <= 64;
+  // 128x128 block with 64x64 wave tiles (4 waves, 2 blocks/CU) by default.  The 256x256 block with 128x64 wave
+  // tiles (8 waves, 1 block/CU; 42.7 instead of 32 flop per LDS byte) is faster (+9..13 %) exactly when its tile
+  // count fills the chip without split-K (whose fp32 partials cost more HBM time than the tile saves):
+  // RNAGAN_CONV_TILE=0 disables it, =5 forces it wherever it fits (with split-K).
+  static int variant = -1;
+  if (variant < 0) { const char* e = getenv("RNAGAN_CONV_TILE"); variant = e ? atoi(e) : 1; }
+  const long long tiles256 = (long long)((g.M + 255) / 256) * ((g.Ncols + 255) / 256) * nclass;
+  const bool wide = !narrow && EPI == EPI_BF16 && g.M >= 256 && g.Ncols >= 256 && g.Ncols % 256 == 0 &&
+                    (variant == 5 || (variant == 1 && tiles256 >= 256 && tiles256 % 256 == 0));
+  int nsplit;
+  if (wide) {
+    nsplit = 1;
+    while (tiles256 * nsplit < 256 && nsplit < 8 && nkt / (nsplit * 2) >= 8) nsplit *= 2;   // one block per CU
+  } else {
+    nsplit = EPI == EPI_BF16 ? gather_split(g.M, g.Ncols, nclass, nkt, true)
+                             : gather_split(g.M, g.Ncols, nclass, nkt, true, 16, 8);
+  }
   size_t need = (size_t)nsplit * rows_out * (EPI == EPI_BF16 ? g.Ncols : g.ldc) * sizeof(float);
   if (nsplit > 1 && (!ws || ws_bytes < need)) nsplit = 1;
   a2.a_bytes = (unsigned)a_bytes; a2.b_bytes = (unsigned)b_bytes;
   a2.nsplit = nsplit; a2.slab = (float*)ws; a2.slab_stride = rows_out * (EPI == EPI_BF16 ? g.Ncols : g.ldc);
-  const bool narrow = g.Ncols <= 64;
-  static int variant = -1;     // RNAGAN_CONV_TILE: 0 = 128x128x2st (4 waves), 1 = 256x128x3st (8 waves) where it fits
-  if (variant < 0) { const char* e = getenv("RNAGAN_CONV_TILE"); variant = e ? atoi(e) : 0; }
-  // the big tile needs enough row tiles to fill the chip
-  const bool big = !narrow && variant == 1 && EPI == EPI_BF16 &&
-                   (long long)((g.M + 255) / 256) * ((g.Ncols + 127) / 128) * nclass * nsplit >= 256;
-  const int bn = narrow ? 64 : 128, bmm = (narrow || big) ? 256 : 128;
+  const int bn = narrow ? 64 : wide ? 256 : 128, bmm = (narrow || wide) ? 256 : 128;
   g.tiles_n = (g.Ncols + bn - 1) / bn;
   a2.g = g;
   dim3 grid(((g.M + bmm - 1) / bmm) * g.tiles_n, nclass, nsplit);
+  static int xcd = -1;
+  if (xcd < 0) { const char* e = getenv("RNAGAN_XCD"); xcd = e ? atoi(e) : 1; }
+  a2.xcd_swizzle = (xcd && grid.x % 8 == 0 && grid.x >= 16 && (xcd == 2 || a_bytes > b_bytes)) ? 1 : 0;
   if (narrow) {
     hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 256, 64, 2, 256>), grid, dim3(256), 0, st, a2);
-  } else if (big) {
-    hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 256, 128, 3, 512>), grid, dim3(512), 0, st, a2);
+  } else if (wide) {
+    hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 256, 256, 2, 512, 128>), grid, dim3(512), 0, st, a2);
   } else {
     hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 128, 128, 2, 256>), grid, dim3(256), 0, st, a2);
   }

@@ -136,7 +136,8 @@ def disc_backward(ops, D: DiscNet, ctx, coef: float, wgrad: bool, accumulate: bo
     R = len(D.blocks)
     gh = ops.head_grad(ctx.h, coef, D.last_slope)
     if wgrad:
-        ops.head_wgrad(gh, ctx.a[R], D.head.dw, accumulate)
+        with ops.side(gh):
+            ops.head_wgrad(gh, ctx.a[R], D.head.dw, accumulate)
     ga = ops.head_bwd_data(gh, D.head)
     if keep_for_gp:
         ctx.gh = gh
@@ -152,17 +153,20 @@ def disc_backward(ops, D: DiscNet, ctx, coef: float, wgrad: bool, accumulate: bo
         if keep_for_gp:
             ctx.ga1[l], ctx.gz1[l], ctx.s_gy[l], ctx.s_gyxh[l] = ga, gz, s_gy, s_gyxh
         if wgrad:
-            ops.conv_wgrad(gz, ctx.a[l - 1], cw.dw, accumulate)
+            with ops.side(gz):
+                ops.conv_wgrad(gz, ctx.a[l - 1], cw.dw, accumulate)
         ga = ops.conv_up(gz, cw)
     gz0 = ops.lrelu_bwd(ga, ctx.a[0], D.slope)
     if keep_for_gp:
         ctx.gz1[0] = gz0
     if wgrad:
-        ops.skinny_wgrad(gz0, ctx.x, D.conv0.dw, accumulate)
+        with ops.side(gz0):
+            ops.skinny_wgrad(gz0, ctx.x, D.conv0.dw, accumulate)
         ops.col_sum(gz0, D.conv0.dbias, accumulate)
-    if need_input_grad:
-        return ops.last_up(gz0, D.conv0, None, False)
-    return None
+    gx = ops.last_up(gz0, D.conv0, None, False) if need_input_grad else None
+    if wgrad:
+        ops.join()
+    return gx
 
 
 def disc_backward_pair(ops, D: DiscNet, ctx_a, coef_a: float, ctx_b, coef_b: float):
@@ -172,8 +176,9 @@ def disc_backward_pair(ops, D: DiscNet, ctx_a, coef_a: float, ctx_b, coef_b: flo
     R = len(D.blocks)
     gha = ops.head_grad(ctx_a.h, coef_a, D.last_slope)
     ghb = ops.head_grad(ctx_b.h, coef_b, D.last_slope)
-    ops.head_wgrad(gha, ctx_a.a[R], D.head.dw, False)
-    ops.head_wgrad(ghb, ctx_b.a[R], D.head.dw, True)
+    with ops.side(gha, ghb):
+        ops.head_wgrad(gha, ctx_a.a[R], D.head.dw, False)
+        ops.head_wgrad(ghb, ctx_b.a[R], D.head.dw, True)
     ga_a = ops.head_bwd_data(gha, D.head)
     ga_b = ops.head_bwd_data(ghb, D.head)
     for l in range(R, 0, -1):
@@ -182,15 +187,18 @@ def disc_backward_pair(ops, D: DiscNet, ctx_a, coef_a: float, ctx_b, coef_b: flo
                                     bn.dgamma, bn.dbeta, False)
         gz_b, _, _ = ops.bn_act_bwd(ctx_b.z[l], ga_b, ctx_b.mean[l], ctx_b.invstd[l], bn.gamma, bn.beta, D.slope,
                                     bn.dgamma, bn.dbeta, True)
-        ops.conv_wgrad2(gz_a, ctx_a.a[l - 1], gz_b, ctx_b.a[l - 1], cw.dw, False)
+        with ops.side(gz_a, gz_b):
+            ops.conv_wgrad2(gz_a, ctx_a.a[l - 1], gz_b, ctx_b.a[l - 1], cw.dw, False)
         ga_a = ops.conv_up(gz_a, cw)
         ga_b = ops.conv_up(gz_b, cw)
     gz0_a = ops.lrelu_bwd(ga_a, ctx_a.a[0], D.slope)
     gz0_b = ops.lrelu_bwd(ga_b, ctx_b.a[0], D.slope)
-    ops.skinny_wgrad(gz0_a, ctx_a.x, D.conv0.dw, False)
-    ops.skinny_wgrad(gz0_b, ctx_b.x, D.conv0.dw, True)
+    with ops.side(gz0_a, gz0_b):
+        ops.skinny_wgrad(gz0_a, ctx_a.x, D.conv0.dw, False)
+        ops.skinny_wgrad(gz0_b, ctx_b.x, D.conv0.dw, True)
     ops.col_sum(gz0_a, D.conv0.dbias, False)
     ops.col_sum(gz0_b, D.conv0.dbias, True)
+    ops.join()
 
 
 def disc_gradient_penalty(ops, D: DiscNet, xhat, lambd: float, update_running=True):
@@ -215,7 +223,8 @@ def disc_gradient_penalty(ops, D: DiscNet, xhat, lambd: float, update_running=Tr
         at, szt, sxz = ops.bn_tangent(ctx.z[l], zt, ctx.mean[l], ctx.invstd[l], bn.gamma, bn.beta, D.slope)
         zts.append(zt); ats.append(at); s_zt.append(szt); s_xhzt.append(sxz)
     # (4) joint reverse.  Head: t = sum_n lrelu'(h_n) * hdot_n  ->  dW_head = sum_n gh_n * at_R[n]
-    ops.head_wgrad(ctx.gh, ats[R], D.head.dw, False)
+    with ops.side():
+        ops.head_wgrad(ctx.gh, ats[R], D.head.dw, False)
     qa = None
     for l in range(R, 0, -1):
         cw, bn = D.blocks[l - 1]
@@ -223,12 +232,15 @@ def disc_gradient_penalty(ops, D: DiscNet, xhat, lambd: float, update_running=Tr
                                bn.gamma, bn.beta, D.slope, ctx.s_gy[l], ctx.s_gyxh[l],
                                s_zt[l], s_xhzt[l], bn.dgamma, bn.dbeta, False)
         # dW = wgrad(pz, a_prev) + wgrad(gz1, at_prev): one launch, one split-K reduction
-        ops.conv_wgrad2(pz, ctx.a[l - 1], ctx.gz1[l], ats[l - 1], cw.dw, False)
+        with ops.side(pz):
+            ops.conv_wgrad2(pz, ctx.a[l - 1], ctx.gz1[l], ats[l - 1], cw.dw, False)
         qa = ops.conv_up(pz, cw)
     p0 = ops.lrelu_bwd(qa, ctx.a[0], D.slope)
-    ops.skinny_wgrad(p0, xhat, D.conv0.dw, False)
-    ops.skinny_wgrad(ctx.gz1[0], v, D.conv0.dw, True)
+    with ops.side(p0, v):
+        ops.skinny_wgrad(p0, xhat, D.conv0.dw, False)
+        ops.skinny_wgrad(ctx.gz1[0], v, D.conv0.dw, True)
     ops.col_sum(p0, D.conv0.dbias, False)
+    ops.join()
     return loss
 
 
@@ -256,18 +268,21 @@ def gen_backward(ops, G: GenNet, ctx, gimg, accumulate: bool):
     """Parameter gradients of G for d(loss)/d(img) = gimg (NCHW fp32)."""
     R = len(G.blocks)
     gzl = ops.tanh_bwd(gimg, ctx.img)
-    ops.skinny_wgrad(ctx.a[R], gzl, G.last.dw, accumulate)
+    with ops.side(gzl):
+        ops.skinny_wgrad(ctx.a[R], gzl, G.last.dw, accumulate)
     ops.nchw_chan_sum(gzl, G.last.dbias, accumulate)
     ga = ops.first_down(gzl, G.last, None, 1.0)
     for l in range(R, 0, -1):
         cw, bn = G.blocks[l - 1]
         gz, _, _ = ops.bn_act_bwd(ctx.z[l], ga, ctx.mean[l], ctx.invstd[l], bn.gamma, bn.beta,
                                   G.slope, bn.dgamma, bn.dbeta, accumulate)
-        ops.conv_wgrad(ctx.a[l - 1], gz, cw.dw, accumulate)
+        with ops.side(gz):
+            ops.conv_wgrad(ctx.a[l - 1], gz, cw.dw, accumulate)
         ga = ops.conv_down(gz, cw)
     gz0, _, _ = ops.bn_act_bwd(ctx.z[0], ga, ctx.mean[0], ctx.invstd[0], G.bn0.gamma, G.bn0.beta,
                                G.slope, G.bn0.dgamma, G.bn0.dbeta, accumulate)
     ops.g0_wgrad(ctx.noise, gz0, G.g0.dw, accumulate)
+    ops.join()
 
 
 # --------------------------------------------------------------------------------------------

@@ -4,6 +4,9 @@ only; every arithmetic op below is one or two hand-written HIP kernels.  No fall
 """
 from __future__ import annotations
 
+import os
+from contextlib import contextmanager
+
 import torch
 
 from . import _abi
@@ -32,6 +35,14 @@ class HipOps:
         # optional per-launch timing (bench.py roofline): list of (kernel family, algorithmic FLOPs,
         # start event, end event); events are recorded on the stream the kernels are enqueued on
         self.timing = None
+        # weight-gradient launches are forked onto a side stream (they are off the backward chain's critical
+        # path and MFMA-bound, so they co-run with the HBM-bound BatchNorm passes); own workspace; inputs are
+        # kept alive until join() so the caching allocator cannot hand their memory to the main stream early
+        self.side_stream = None
+        self._wsbuf_side = None
+        self._in_side = False
+        self._keep = []
+        self.use_side = os.environ.get("RNAGAN_SIDE_STREAM", "0") != "0"
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -40,9 +51,38 @@ class HipOps:
 
     def _ws(self, nbytes: int):
         nbytes = max(int(nbytes), 256)
+        if self._in_side:
+            if self._wsbuf_side is None or self._wsbuf_side.numel() < nbytes:
+                self._wsbuf_side = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
+            return self._wsbuf_side
         if self._wsbuf is None or self._wsbuf.numel() < nbytes:
             self._wsbuf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
         return self._wsbuf
+
+    @contextmanager
+    def side(self, *tensors):
+        """Run the enclosed ops on the side stream, ordered after everything enqueued so far on the
+        current stream.  ``tensors``: operands to keep alive until join()."""
+        if not self.use_side or self.timing is not None:
+            yield
+            return
+        if self.side_stream is None:
+            self.side_stream = torch.cuda.Stream(self.device)
+        main = torch.cuda.current_stream(self.device)
+        self.side_stream.wait_stream(main)
+        self._keep.extend(tensors)
+        self._in_side = True
+        try:
+            with torch.cuda.stream(self.side_stream):
+                yield
+        finally:
+            self._in_side = False
+
+    def join(self):
+        """Make the current stream wait for the side stream's work (before gradients are consumed)."""
+        if self.side_stream is not None and self.use_side:
+            torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
+        self._keep.clear()
 
     def _timed(self, key, flops, thunk):
         if self.timing is None:
