@@ -85,14 +85,16 @@ class RefOps:
         self.conv_wgrad(low1, high1, dw, True)
 
     def first_down(self, x_nchw, cw: ConvW, bias, slope: float):
-        # image-side layers use the fp32 master weights (no bf16 rounding), like the HIP kernels
-        y = F.conv2d(x_nchw.to(self.f), cw.w.to(self.f), bias, stride=2, padding=1)
+        # bf16 path: the image-side layers run on the matrix cores too, so image and weights are rounded to
+        # bf16 operands (fp32 accumulation); the fp32 path uses the masters as they are
+        xin = x_nchw.to(self.f) if self.act_dtype != torch.bfloat16 else x_nchw.to(torch.bfloat16).to(self.f)
+        y = F.conv2d(xin, self._wq(cw.w), bias, stride=2, padding=1)
         if slope != 1.0:
             y = F.leaky_relu(y, slope)
         return _nhwc(y, self.act_dtype)
 
     def last_up(self, x, cw: ConvW, bias, tanh: bool):
-        y = F.conv_transpose2d(self._nchw(x), cw.w.to(self.f), bias, stride=2, padding=1)
+        y = F.conv_transpose2d(self._nchw(x), self._wq(cw.w), bias, stride=2, padding=1)
         return torch.tanh(y) if tanh else y.contiguous()
 
     def skinny_wgrad(self, low, high_nchw, dw, accumulate: bool):

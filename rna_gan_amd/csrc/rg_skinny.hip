@@ -1,6 +1,7 @@
 // rg_skinny.hip -- the two image-side layers (3 <-> 64 channels at 256x256).  K = 48 (or 3 output
-// channels) cannot fill an MFMA tile; these layers are HBM-bound (SURVEY 7 hard part 3), so they
-// run on the vector ALUs with scalar-loaded weights and coalesced image-side accesses.
+// channels) is far from an MFMA-bound shape; these layers are HBM-bound (SURVEY 7 hard part 3).  The bf16
+// path stages image rows through LDS and uses the matrix cores only to get the arithmetic out of the way
+// (the VALU versions were compute-bound at 1/3 of the HBM rate); the fp32 parity path stays on the VALUs.
 //   first_down : NCHW fp32 image  -> NHWC T, 4x4 s2 p1 conv (+bias, LeakyReLU)
 //   last_up    : NHWC T           -> NCHW fp32 image, transposed conv (+bias, tanh)
 //   wgrad      : dW[o][3][16] = sum_pix low[pix][o] * patch(pix)
@@ -13,9 +14,11 @@ constexpr int SK_I = 3;
 constexpr int SK_K = SK_I * 16;   // 48
 
 // ---------------------------------------------------------------------------------------------
-// The image-side layers use the fp32 master weights directly (no bf16 rounding): they are read with
-// UNIFORM indices, so hipcc emits scalar loads (s_load_dwordx*) and the FMAs take the weight as an
-// SGPR operand -- no LDS or vector-memory traffic for weights.
+// VALU kernels (the fp32 parity path, and bf16 shapes the matrix-core kernels below do not take): the fp32
+// master weights are read with UNIFORM indices, so hipcc emits scalar loads (s_load_dwordx*) and the FMAs take
+// the weight as an SGPR operand -- no LDS or vector-memory traffic for weights.  With T = bf16 the operands are
+// rounded to bf16 first (Elem<T>::round) so that both bf16 paths compute the same thing: bf16 x bf16 products,
+// fp32 accumulation.
 
 // first_down: one thread = one output pixel, all O channels in OC-wide register chunks.
 // x NCHW fp32; lanes run along wo so every patch load instruction covers a 512-byte span.
@@ -39,7 +42,7 @@ __global__ __launch_bounds__(256) void first_down_kernel(const float* __restrict
       for (int kw = 0; kw < 4; ++kw) {
         int hi = 2 * ho - 1 + kh, wi = 2 * wo - 1 + kw;
         bool v = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
-        patch[ci * 16 + kh * 4 + kw] = v ? x[(((long long)n * SK_I + ci) * H + hi) * W + wi] : 0.f;
+        patch[ci * 16 + kh * 4 + kw] = v ? Elem<T>::round(x[(((long long)n * SK_I + ci) * H + hi) * W + wi]) : 0.f;
       }
   for (int oc = 0; oc < O; oc += OC) {
     float acc[OC];
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(256) void first_down_kernel(const float* __restrict
       const float* wr = wq + (size_t)(oc + j) * SK_K;     // uniform -> scalar loads
       float a = bias ? bias[oc + j] : 0.f;
 #pragma unroll
-      for (int k = 0; k < SK_K; ++k) a = fmaf(patch[k], wr[k], a);
+      for (int k = 0; k < SK_K; ++k) a = fmaf(patch[k], Elem<T>::round(wr[k]), a);
       acc[j] = lrelu_f(a, slope);
     }
     T* yo = y + p * O + oc;
@@ -58,27 +61,106 @@ __global__ __launch_bounds__(256) void first_down_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-// first_down on the matrix cores (bf16 output).  Roles are swapped so that the PIXEL is the MFMA
-// column (lane) index:  D[ch][pix] = sum_k W[ch][k] * P[k][pix],  k = ci*16 + tap (48, one 16-wide k-step
-// per input channel).  Per 32-pixel group a lane (pixel r = lane&31, half h = lane>>5) builds the B-operand
-// fragment of channel ci = the 8 taps kh in {2h, 2h+1} x kw 0..3 of its pixel directly from two NCHW
-// image rows (lanes run along wo: every load instruction covers a 256-byte span); A = weights, 6 fragments
-// kept in registers.  The 32x32 result has the pixel on the lane and 16 channels in registers;
-// v_permlane32_swap pairs the two half-waves so that every store is 16 bytes of consecutive NHWC channels.
+// bf16 path of first_down / skinny_wgrad: row-staged patches on the matrix cores.
+//
+// Work unit = `chunk` (32..128) consecutive output pixels of one output row (n, ho).  Its 12 input rows
+// (3 channels x 4 kh) are read with coalesced float4 loads and scattered ONCE into the transposed patch
+// matrix  PT[k = ci*16 + kh*4 + kw][pixel]  (bf16) in LDS -- per-lane strided 4-byte gathers of the NCHW image
+// were 60 % of the old kernels' time.  Column wi = 2*wo - 1 + kw, so an aligned float4 (4m .. 4m+3, relative
+// to 2*wo0) lands as: kw=1 <- (x0, x2) at pixels 2m, 2m+1 (one packed 32-bit store), kw=2 <- (x1, x3), kw=3 <-
+// x0 at 2m-1 and x2 at 2m, kw=0 <- x1 at 2m+1 and x3 at 2m+2; the two columns outside the aligned span
+// (2*wo0 - 1 and 2*wo0 + 2*chunk) are loaded by 24 edge lanes.  The NEXT unit's loads are issued into registers
+// before the current unit is computed (4 blocks/CU keep > 100 KB in flight per CU).
 typedef __attribute__((ext_vector_type(8))) __bf16 sk_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float sk_f32x16;
+typedef __attribute__((ext_vector_type(4))) short sk_s16x4;
+typedef __attribute__((ext_vector_type(8))) short sk_s16x8;
 
 __device__ __forceinline__ uint32_t sk_pack2(float a, float b) {
   return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
 }
+__device__ __forceinline__ sk_s16x4 sk_tr_read(const uint16_t* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sk_s16x4*)(p));
+}
 
-__global__ __launch_bounds__(256) void first_down_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                              const float* __restrict__ bias, uint16_t* __restrict__ y,
-                                                              int N, int H, int W, float slope, int ngroups) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+struct SkUnit { int n, ho, wo0; };
+__device__ __forceinline__ SkUnit sk_unit(int u, int Ho, int cpr, int chunk) {
+  SkUnit q;
+  const int cx = u % cpr, row = u / cpr;
+  q.wo0 = cx * chunk; q.ho = row % Ho; q.n = row / Ho;
+  return q;
+}
+
+// registers of one unit's image rows: 3 float4 per thread (12 rows x chunk/2 float4) + one edge value
+struct SkRows { float4 v0, v1, v2; float edge; };
+
+__device__ __forceinline__ float4 sk_load4(const float* __restrict__ x, const SkUnit& q, int H, int W, int lgc, int f,
+                                           int nf) {
+  float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (f >= nf) return z;
+  const int row = f >> lgc, m = f & ((1 << lgc) - 1);        // row = ci*4 + kh
+  const int hi = 2 * q.ho - 1 + (row & 3);
+  if ((unsigned)hi >= (unsigned)H) return z;
+  return *reinterpret_cast<const float4*>(x + (((size_t)q.n * SK_I + (row >> 2)) * H + hi) * W + 2 * q.wo0 + 4 * m);
+}
+__device__ __forceinline__ void sk_load_rows(SkRows& r, const float* __restrict__ x, const SkUnit& q, int H, int W,
+                                             int chunk, int lgc, int t) {
+  const int nf = 12 << lgc;
+  r.v0 = sk_load4(x, q, H, W, lgc, t, nf);
+  r.v1 = sk_load4(x, q, H, W, lgc, t + 256, nf);
+  r.v2 = sk_load4(x, q, H, W, lgc, t + 512, nf);
+  r.edge = 0.f;
+  if (t < 24) {
+    const int row = t >> 1, hi = 2 * q.ho - 1 + (row & 3);
+    const int wi = (t & 1) ? 2 * q.wo0 + 2 * chunk : 2 * q.wo0 - 1;
+    if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+      r.edge = x[(((size_t)q.n * SK_I + (row >> 2)) * H + hi) * W + wi];
+  }
+}
+template <int PTS>
+__device__ __forceinline__ void sk_scatter4(uint16_t* pt, float4 v, int lgc, int chunk, int f, int nf) {
+  if (f >= nf) return;
+  const int row = f >> lgc, m = f & ((1 << lgc) - 1);
+  uint16_t* k0 = pt + (4 * row) * PTS + 2 * m;               // k = 4*row + kw
+  *reinterpret_cast<uint32_t*>(k0 + 1 * PTS) = sk_pack2(v.x, v.z);
+  *reinterpret_cast<uint32_t*>(k0 + 2 * PTS) = sk_pack2(v.y, v.w);
+  k0[3 * PTS] = f32_to_bf16(v.z);
+  if (m > 0) k0[3 * PTS - 1] = f32_to_bf16(v.x);
+  k0[1] = f32_to_bf16(v.y);
+  if (2 * m + 2 < chunk) k0[2] = f32_to_bf16(v.w);
+}
+template <int PTS>
+__device__ __forceinline__ void sk_scatter_rows(uint16_t* pt, const SkRows& r, int chunk, int lgc, int t) {
+  const int nf = 12 << lgc;
+  sk_scatter4<PTS>(pt, r.v0, lgc, chunk, t, nf);
+  sk_scatter4<PTS>(pt, r.v1, lgc, chunk, t + 256, nf);
+  sk_scatter4<PTS>(pt, r.v2, lgc, chunk, t + 512, nf);
+  if (t < 24) {
+    const int row = t >> 1;
+    if (t & 1) pt[(4 * row + 3) * PTS + chunk - 1] = f32_to_bf16(r.edge);
+    else       pt[(4 * row) * PTS] = f32_to_bf16(r.edge);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// first_down (bf16):  D[ch][pix] = sum_k W[ch][k] * PT[k][pix].  A = weights (6 fragments in registers),
+// B = transposed LDS reads of PT (rows 320 bytes apart: the 4 rows x 64 bytes one half-wave touches fall into
+// disjoint bank quarters).  The 32x32 result (pixel on the lane, 16 channels in registers) gets bias +
+// LeakyReLU and is transposed through a wave-private LDS tile so that every global store instruction writes
+// 1 KB of consecutive NHWC bytes.
+constexpr int FD_PTS = 160;
+constexpr int FD_OTS = 72;      // out-tile row stride (bf16): 144 bytes
+
+__global__ __launch_bounds__(256, 3) void first_down_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, uint16_t* __restrict__ y,
+                                                                 int N, int H, int W, float slope, int chunk, int nunits) {
+  __shared__ __attribute__((aligned(16))) uint16_t pt[SK_K * FD_PTS];        // 15 KB
+  __shared__ __attribute__((aligned(16))) uint16_t ot[4 * 32 * FD_OTS];      // 18 KB
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int Ho = H >> 1, Wo = W >> 1;
-  const int gpr = Wo >> 5;                       // 32-pixel groups per output row
+  const int cpr = Wo / chunk, lgc = 31 - __builtin_clz(chunk >> 1);
+  const int nact = chunk >> 5;
   // A fragments: W[ch = 32*i + r][k = ci*16 + 8h .. +7]  (torch layout w[o][ci][16 taps] is k-contiguous)
   sk_bf16x8 wa[2][SK_I];
 #pragma unroll
@@ -99,96 +181,72 @@ __global__ __launch_bounds__(256) void first_down_mfma_kernel(const float* __res
 #pragma unroll
       for (int e = 0; e < 4; ++e) bs[i][g4][e] = bias ? bias[32 * i + 8 * g4 + 4 * h + e] : 0.f;
 
-  for (int grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
-    const int wo = (grp % gpr) * 32 + r;
-    const int row = grp / gpr;
-    const int ho = row % Ho, n = row / Ho;
-    sk_f32x16 acc[2];
+  const int grp16 = lane >> 4, idx = lane & 15, q4 = idx >> 2, p4 = idx & 3, fh = grp16 >> 1, cb = grp16 & 1;
+  uint16_t* otw = ot + wave * 32 * FD_OTS;
+  const int per = (nunits + gridDim.x - 1) / gridDim.x;
+  const int u0 = blockIdx.x * per, u1 = min(nunits, u0 + per);
+  SkRows rows;
+  if (u0 < u1) sk_load_rows(rows, x, sk_unit(u0, Ho, cpr, chunk), H, W, chunk, lgc, t);
+  for (int u = u0; u < u1; ++u) {
+    const SkUnit q = sk_unit(u, Ho, cpr, chunk);
+    sk_scatter_rows<FD_PTS>(pt, rows, chunk, lgc, t);
+    __syncthreads();
+    if (u + 1 < u1) sk_load_rows(rows, x, sk_unit(u + 1, Ho, cpr, chunk), H, W, chunk, lgc, t);
+    if (wave < nact) {
+      sk_f32x16 acc[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-    const int wi0 = 2 * wo - 1;
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 #pragma unroll
-    for (int ci = 0; ci < SK_I; ++ci) {
-      float pv[8];
+      for (int ci = 0; ci < SK_I; ++ci) {
+        const uint16_t* bp = pt + (16 * ci + 8 * fh + q4) * FD_PTS + wave * 32 + 16 * cb + 4 * p4;
+        sk_s16x4 lo = sk_tr_read(bp), hi = sk_tr_read(bp + 4 * FD_PTS);
+        sk_bf16x8 pb = __builtin_bit_cast(sk_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int hi = 2 * ho - 1 + 2 * h + a;
-        const bool vh = (unsigned)hi < (unsigned)H;
-        const float* xr = x + (((size_t)n * SK_I + ci) * H + (vh ? hi : 0)) * W;
+        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i][ci], pb, acc[i], 0, 0, 0);
+      }
+      // acc[i][4*g + e] = D[ch = 32*i + 8*g + 4*h + e][pixel r]
 #pragma unroll
-        for (int kw = 0; kw < 4; ++kw) {
-          const int wi = wi0 + kw;
-          const bool v = vh && (unsigned)wi < (unsigned)W;
-          pv[a * 4 + kw] = v ? xr[wi] : 0.f;
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          float v0 = lrelu_f(acc[i][4 * g4 + 0] + bs[i][g4][0], slope), v1 = lrelu_f(acc[i][4 * g4 + 1] + bs[i][g4][1], slope);
+          float v2 = lrelu_f(acc[i][4 * g4 + 2] + bs[i][g4][2], slope), v3 = lrelu_f(acc[i][4 * g4 + 3] + bs[i][g4][3], slope);
+          *reinterpret_cast<uint2*>(otw + r * FD_OTS + 32 * i + 8 * g4 + 4 * h) = make_uint2(sk_pack2(v0, v1), sk_pack2(v2, v3));
         }
-      }
-      uint4 pk = make_uint4(sk_pack2(pv[0], pv[1]), sk_pack2(pv[2], pv[3]), sk_pack2(pv[4], pv[5]),
-                            sk_pack2(pv[6], pv[7]));
-      sk_bf16x8 pb = __builtin_bit_cast(sk_bf16x8, pk);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // wave-private tile: in-order DS pipe, no barrier needed
+      uint16_t* yo = y + (((size_t)q.n * Ho + q.ho) * Wo + q.wo0 + wave * 32) * 64;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i][ci], pb, acc[i], 0, 0, 0);
-    }
-    // acc[i][4*g + e] = D[ch = 32*i + 8*g + 4*h + e][pixel r]
-    uint16_t* yo = y + (((size_t)n * Ho + ho) * Wo + wo) * 64;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      uint32_t q[4][2];
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        float v0 = lrelu_f(acc[i][4 * g4 + 0] + bs[i][g4][0], slope), v1 = lrelu_f(acc[i][4 * g4 + 1] + bs[i][g4][1], slope);
-        float v2 = lrelu_f(acc[i][4 * g4 + 2] + bs[i][g4][2], slope), v3 = lrelu_f(acc[i][4 * g4 + 3] + bs[i][g4][3], slope);
-        q[g4][0] = sk_pack2(v0, v1);
-        q[g4][1] = sk_pack2(v2, v3);
-      }
-      // pair groups (0,1) and (2,3): afterwards the lower half-wave holds [own g | upper's g] = 8 consecutive
-      // channels 8g..8g+7 and the upper half-wave [lower's g+1 | own g+1] = channels 8(g+1)..8(g+1)+7
-#pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        const int ga = 2 * pr, gb = 2 * pr + 1;
-        auto s0 = __builtin_amdgcn_permlane32_swap(q[ga][0], q[gb][0], false, false);
-        auto s1 = __builtin_amdgcn_permlane32_swap(q[ga][1], q[gb][1], false, false);
-        uint4 o = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-        const int ch = 32 * i + 8 * (ga + h);
-        *reinterpret_cast<uint4*>(yo + ch) = o;
+      for (int j = 0; j < 4; ++j) {
+        const int sidx = j * 64 + lane, px = sidx >> 3, c = sidx & 7;
+        *reinterpret_cast<uint4*>(yo + px * 64 + c * 8) = *reinterpret_cast<const uint4*>(otw + px * FD_OTS + c * 8);
       }
     }
+    __syncthreads();
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// skinny weight gradient on the matrix cores (bf16 `low`):  dW[o][k] = sum_pix low[pix][o] * P[pix][k].
-// The contraction index is the pixel, which is the slow axis of both operands, so per 32-pixel group a
-// wave (a) builds the patch values exactly like first_down_mfma (pixel on the lane, 8 taps per lane and
-// input channel, coalesced NCHW row reads) and writes them as [pixel][k] rows into its PRIVATE LDS
-// region, (b) copies its [32 pixel][64 ch] tile of `low` (4 KB, 16-byte coalesced loads) next to it, and
-// (c) reads both back pixel-contiguous with ds_read_b64_tr_b16 as MFMA A/B fragments (2 k-steps x 4
-// MFMAs).  Rows are 192 bytes apart: the 4 rows x 64 bytes a half-wave touches per transposed read fall
-// into 4 disjoint bank ranges.  No block barrier inside the loop; the 4 waves' accumulators are summed
-// through LDS at the end and written as one fp32 slab per block (reduced deterministically afterwards).
-typedef __attribute__((ext_vector_type(4))) short sk_s16x4;
-typedef __attribute__((ext_vector_type(8))) short sk_s16x8;
-constexpr int SKW_ROW = 96;     // uint16 elements per LDS row (192 bytes)
+// skinny weight gradient (bf16 `low`):  dW[o][k] = sum_pix low[pix][o] * P[pix][k]; the contraction index is
+// the pixel.  Per unit the block stages PT (above; rows 272 bytes apart so the 16 rows of a ds_read_b128
+// lane group hit disjoint banks) and the [pixel][64 ch] tile of `low` (coalesced 16-byte loads; 16-byte chunk
+// c of pixel p sits at slot c ^ 4*((p>>1)&1), which makes the transposed reads conflict-free).  A = low^T via
+// ds_read_b64_tr_b16, B = PT via ds_read_b128 (8 consecutive pixels of one k row); 2 k-steps x 4 MFMAs per
+// wave and unit.  The 4 waves' accumulators are summed through LDS at the end; one fp32 slab per block,
+// reduced deterministically afterwards.
+constexpr int SW_PTS = 136;
 
-__device__ __forceinline__ sk_s16x4 sk_tr_read(const uint16_t* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sk_s16x4*)(p));
-}
-
-__global__ __launch_bounds__(256) void skinny_wgrad_mfma_kernel(const uint16_t* __restrict__ low,
-                                                                const float* __restrict__ x, float* __restrict__ slab,
-                                                                int N, int H, int W, int ngroups) {
-  __shared__ __attribute__((aligned(16))) uint16_t lds[4 * 2 * 32 * SKW_ROW];     // 48 KB: per wave [patch | low]
-  __shared__ float red[64 * SK_K];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(256, 3) void skinny_wgrad_rows_kernel(const uint16_t* __restrict__ low,
+                                                                   const float* __restrict__ x, float* __restrict__ slab,
+                                                                   int N, int H, int W, int chunk, int nunits) {
+  __shared__ __attribute__((aligned(16))) uint16_t pt[SK_K * SW_PTS];        // 12.75 KB
+  __shared__ __attribute__((aligned(16))) uint16_t lt[128 * 64];             // 16 KB (reused for the final reduction)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int Ho = H >> 1, Wo = W >> 1;
-  const int gpr = Wo >> 5;
-  uint16_t* pt = lds + wave * (2 * 32 * SKW_ROW);      // patch tile  [32 pix][96] (k 0..47 valid, 48..63 zero)
-  uint16_t* lt = pt + 32 * SKW_ROW;                    // low tile    [32 pix][96] (ch 0..63)
-  // zero the k-padding once (columns 48..63 feed output columns that are never written out)
-  *reinterpret_cast<uint4*>(pt + r * SKW_ROW + 48 + 8 * h) = make_uint4(0, 0, 0, 0);
-  for (int i = threadIdx.x; i < 64 * SK_K; i += 256) red[i] = 0.f;
+  const int cpr = Wo / chunk, lgc = 31 - __builtin_clz(chunk >> 1);
+  const int nact = chunk >> 5;
 
   sk_f32x16 acc[2][2];
 #pragma unroll
@@ -198,66 +256,73 @@ __global__ __launch_bounds__(256) void skinny_wgrad_mfma_kernel(const uint16_t* 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int grp16 = lane >> 4, idx = lane & 15, q = idx >> 2, p4 = idx & 3, fh = grp16 >> 1, cb = grp16 & 1;
-  // contiguous range of 32-pixel groups per wave (sequential pixels: L2-friendly)
-  const int nw = gridDim.x * 4, wid = blockIdx.x * 4 + wave;
-  const int per = (ngroups + nw - 1) / nw;
-  const int g0 = wid * per, g1 = min(ngroups, g0 + per);
-  for (int grp = g0; grp < g1; ++grp) {
-    const int wo = (grp % gpr) * 32 + r;
-    const int row = grp / gpr;
-    const int ho = row % Ho, n = row / Ho;
-    const int wi0 = 2 * wo - 1;
-    // (a) patch rows: lane (pixel r, half h) writes taps 8h..8h+7 of each input channel
+  const int grp16 = lane >> 4, idx = lane & 15, q4 = idx >> 2, p4 = idx & 3, fh = grp16 >> 1, cb = grp16 & 1;
+  const int per = (nunits + gridDim.x - 1) / gridDim.x;
+  const int u0 = blockIdx.x * per, u1 = min(nunits, u0 + per);
+  SkRows rows;
+  uint4 lv0, lv1, lv2, lv3;
+  // (pixel, 16-byte chunk) = (sidx >> 3, sidx & 7), sidx = j*256 + t
+#define SK_LOAD_LOW(q)                                                                                       \
+  do {                                                                                                       \
+    const uint16_t* src_ = low + (((size_t)(q).n * Ho + (q).ho) * Wo + (q).wo0) * 64 + (size_t)t * 8;         \
+    lv0 = lv1 = lv2 = lv3 = make_uint4(0, 0, 0, 0);    /* if-assign, not ?: (a ?: of lvalues selects POINTERS) */ \
+    if ((t >> 3) < chunk) lv0 = *reinterpret_cast<const uint4*>(src_);                                       \
+    if ((t >> 3) + 32 < chunk) lv1 = *reinterpret_cast<const uint4*>(src_ + 2048);                           \
+    if ((t >> 3) + 64 < chunk) lv2 = *reinterpret_cast<const uint4*>(src_ + 4096);                           \
+    if ((t >> 3) + 96 < chunk) lv3 = *reinterpret_cast<const uint4*>(src_ + 6144);                           \
+  } while (0)
+  if (u0 < u1) {
+    const SkUnit q = sk_unit(u0, Ho, cpr, chunk);
+    sk_load_rows(rows, x, q, H, W, chunk, lgc, t);
+    SK_LOAD_LOW(q);
+  }
+  for (int u = u0; u < u1; ++u) {
+    sk_scatter_rows<SW_PTS>(pt, rows, chunk, lgc, t);
+    {
+      // pixel px = (t >> 3) + 32 j: (px >> 1) & 1 does not depend on j
+      const int px = t >> 3, c = t & 7;
+      uint16_t* d = lt + px * 64 + ((c ^ (((px >> 1) & 1) << 2)) << 3);
+      *reinterpret_cast<uint4*>(d) = lv0;
+      *reinterpret_cast<uint4*>(d + 32 * 64) = lv1;
+      *reinterpret_cast<uint4*>(d + 64 * 64) = lv2;
+      *reinterpret_cast<uint4*>(d + 96 * 64) = lv3;
+    }
+    __syncthreads();
+    if (u + 1 < u1) {
+      const SkUnit q = sk_unit(u + 1, Ho, cpr, chunk);
+      sk_load_rows(rows, x, q, H, W, chunk, lgc, t);
+      SK_LOAD_LOW(q);
+    }
+    if (wave < nact) {
 #pragma unroll
-    for (int ci = 0; ci < SK_I; ++ci) {
-      float pv[8];
+      for (int ks = 0; ks < 2; ++ks) {
+        const int prow = wave * 32 + ks * 16 + 8 * fh + q4;
+        const int sw = ((prow >> 1) & 1) << 2;                 // same for prow + 4
+        sk_bf16x8 fa[2], fb[2];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int hi = 2 * ho - 1 + 2 * h + a;
-        const bool vh = (unsigned)hi < (unsigned)H;
-        const float* xr = x + (((size_t)n * SK_I + ci) * H + (vh ? hi : 0)) * W;
-#pragma unroll
-        for (int kw = 0; kw < 4; ++kw) {
-          const int wi = wi0 + kw;
-          pv[a * 4 + kw] = (vh && (unsigned)wi < (unsigned)W) ? xr[wi] : 0.f;
+        for (int i = 0; i < 2; ++i) {
+          const int c = 4 * i + 2 * cb + (p4 >> 1);
+          const uint16_t* ap = lt + prow * 64 + ((c ^ sw) << 3) + (p4 & 1) * 4;
+          sk_s16x4 lo = sk_tr_read(ap), hi = sk_tr_read(ap + 4 * 64);
+          fa[i] = __builtin_bit_cast(sk_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          const int k = 32 * i + r;
+          fb[i] = __builtin_bit_cast(sk_bf16x8, *reinterpret_cast<const uint4*>(pt + (k < SK_K ? k : 0) * SW_PTS +
+                                                                                wave * 32 + ks * 16 + 8 * h));
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
-      *reinterpret_cast<uint4*>(pt + r * SKW_ROW + ci * 16 + 8 * h) =
-          make_uint4(sk_pack2(pv[0], pv[1]), sk_pack2(pv[2], pv[3]), sk_pack2(pv[4], pv[5]), sk_pack2(pv[6], pv[7]));
     }
-    // (b) low tile: 32 pixels x 128 bytes, 4 x 16 bytes per lane, fully coalesced
-    const uint16_t* lsrc = low + (size_t)grp * 32 * 64;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int c = p * 64 + lane, px = c >> 3, ch = c & 7;
-      *reinterpret_cast<uint4*>(lt + px * SKW_ROW + ch * 8) = *reinterpret_cast<const uint4*>(lsrc + px * 64 + ch * 8);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // wave-private LDS: in-order DS pipe, no barrier needed
-    // (c) 2 k-steps of 16 pixels: A = low^T (rows = o), B = patch (cols = k)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int prow = ks * 16 + 8 * fh + q;
-      sk_bf16x8 fa[2], fb[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int col = 32 * i + 16 * cb + 4 * p4;
-        sk_s16x4 lo = sk_tr_read(lt + prow * SKW_ROW + col), hi = sk_tr_read(lt + (prow + 4) * SKW_ROW + col);
-        fa[i] = __builtin_bit_cast(sk_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-        lo = sk_tr_read(pt + prow * SKW_ROW + col); hi = sk_tr_read(pt + (prow + 4) * SKW_ROW + col);
-        fb[i] = __builtin_bit_cast(sk_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-    asm volatile("" ::: "memory");
+    __syncthreads();
   }
   // block reduction of the 4 waves: acc[i][j][reg] = D[o = 32i + (reg&3)+8(reg>>2)+4h][k = 32j + r]
+  float* red = reinterpret_cast<float*>(lt);
+  for (int i = t; i < 64 * SK_K; i += 256) red[i] = 0.f;
   __syncthreads();
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -272,7 +337,139 @@ __global__ __launch_bounds__(256) void skinny_wgrad_mfma_kernel(const uint16_t* 
     __syncthreads();
   }
   float* sl = slab + (size_t)blockIdx.x * 64 * SK_K;
-  for (int i = threadIdx.x; i < 64 * SK_K; i += 256) sl[i] = red[i];
+  for (int i = t; i < 64 * SK_K; i += 256) sl[i] = red[i];
+#undef SK_LOAD_LOW
+}
+
+// ---------------------------------------------------------------------------------------------
+// last_up (bf16 input) on the matrix cores.  out[n][i][2hq+ph][2wq+pw] = sum over the 3x3 neighbourhood
+// (dh, dw) of x[n][hq-1+dh][wq-1+dw][o] * w[o][i][kh][kw] with kh = ph + 3 - 2dh, kw = pw + 3 - 2dw (taps outside
+// 0..3 do not exist).  As a GEMM: rows = 16 consecutive low-res pixels of one row, columns = (i, ph, pw) (12 of 16
+// used), K = 9 shifts x 64 channels; v_mfma_f32_16x16x32_bf16, 18 per 16-pixel tile.  The B operand (weights,
+// zero where the tap does not exist) is built once per block and lives in 72 VGPRs.  A block walks a strip of
+// consecutive rows of one image keeping a 3-row ring of the NHWC input in LDS (pixels 144 bytes apart, so the
+// 16-byte fragment reads of 16 neighbouring pixels spread over the banks): every input row is read from HBM once
+// per strip, with the next row's loads in flight during the current row's MFMAs.  The 16x16 results get bias +
+// tanh and go through an LDS tile so that the NCHW rows are written with 16-byte coalesced stores.
+typedef __attribute__((ext_vector_type(4))) float sk_f32x4;
+constexpr int LU_PXS = 72;                 // bf16 elements per staged pixel (144 bytes)
+constexpr int LU_MAXC = 128;               // pixels per unit row
+constexpr int LU_OS = 2 * LU_MAXC + 4;     // floats per staged output row
+
+__global__ __launch_bounds__(256, 2) void last_up_rows_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y, int N,
+                                                              int Ho, int Wo, int apply_tanh, int chunk, int strip,
+                                                              int nstrips) {
+  __shared__ __attribute__((aligned(16))) uint16_t ring[3 * (LU_MAXC + 2) * LU_PXS];    // 54.8 KB
+  __shared__ __attribute__((aligned(16))) float outt[6 * LU_OS];                          // 6.1 KB
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lp = lane & 15, lq = lane >> 4;
+  const int cpr = Wo / chunk, spi = Ho / strip;            // column chunks per row, strips per image
+  const int H = 2 * Ho, W = 2 * Wo;
+  // column n = i*4 + ph*2 + pw of the B operand
+  const int ni = lp >> 2, nph = (lp >> 1) & 1, npw = lp & 1;
+  sk_bf16x8 wf[3][3][2];
+#pragma unroll
+  for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+    for (int dw = 0; dw < 3; ++dw) {
+      const int kh = nph + 3 - 2 * dh, kw = npw + 3 - 2 * dw;
+      const bool ok = ni < SK_I && (unsigned)kh < 4u && (unsigned)kw < 4u;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        if (ok) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = w[(size_t)(32 * c + 8 * lq + j) * SK_K + ni * 16 + kh * 4 + kw];
+        }
+        uint4 pk = make_uint4(sk_pack2(v[0], v[1]), sk_pack2(v[2], v[3]), sk_pack2(v[4], v[5]), sk_pack2(v[6], v[7]));
+        wf[dh][dw][c] = __builtin_bit_cast(sk_bf16x8, pk);
+      }
+    }
+  const float bv = (bias && ni < SK_I) ? bias[ni] : 0.f;
+
+  for (int sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+    const int cx = sidx % cpr, rest = sidx / cpr;
+    const int hq0 = (rest % spi) * strip, n = rest / spi;
+    const int wo0 = cx * chunk;
+    const uint16_t* xn = x + (size_t)n * Ho * Wo * 64;
+    uint4 lv0, lv1, lv2, lv3, le;
+    // one input row -> registers: (pixel, 16-byte chunk) = (t >> 3 (+32 j), t & 7); 16 edge lanes take the two halo pixels
+#define LU_LOAD_ROW(row)                                                                                      \
+  do {                                                                                                        \
+    lv0 = lv1 = lv2 = lv3 = le = make_uint4(0, 0, 0, 0);                                                      \
+    if ((unsigned)(row) < (unsigned)Ho) {                                                                     \
+      const uint16_t* src_ = xn + ((size_t)(row) * Wo + wo0) * 64 + (size_t)t * 8;                            \
+      if ((t >> 3) < chunk) lv0 = *reinterpret_cast<const uint4*>(src_);                                      \
+      if ((t >> 3) + 32 < chunk) lv1 = *reinterpret_cast<const uint4*>(src_ + 2048);                          \
+      if ((t >> 3) + 64 < chunk) lv2 = *reinterpret_cast<const uint4*>(src_ + 4096);                          \
+      if ((t >> 3) + 96 < chunk) lv3 = *reinterpret_cast<const uint4*>(src_ + 6144);                          \
+      if (t < 16) {                                                                                           \
+        const int col_ = (t >> 3) ? wo0 + chunk : wo0 - 1;                                                    \
+        if ((unsigned)col_ < (unsigned)Wo)                                                                    \
+          le = *reinterpret_cast<const uint4*>(xn + ((size_t)(row) * Wo + col_) * 64 + (t & 7) * 8);          \
+      }                                                                                                       \
+    }                                                                                                         \
+  } while (0)
+    LU_LOAD_ROW(hq0 - 1);
+    for (int k = 0; k < strip + 2; ++k) {
+      uint16_t* slot = ring + (k % 3) * ((LU_MAXC + 2) * LU_PXS);
+      {
+        uint16_t* d = slot + (1 + (t >> 3)) * LU_PXS + (t & 7) * 8;
+        if ((t >> 3) < chunk) *reinterpret_cast<uint4*>(d) = lv0;
+        if ((t >> 3) + 32 < chunk) *reinterpret_cast<uint4*>(d + 32 * LU_PXS) = lv1;
+        if ((t >> 3) + 64 < chunk) *reinterpret_cast<uint4*>(d + 64 * LU_PXS) = lv2;
+        if ((t >> 3) + 96 < chunk) *reinterpret_cast<uint4*>(d + 96 * LU_PXS) = lv3;
+        if (t < 16) *reinterpret_cast<uint4*>(slot + ((t >> 3) ? chunk + 1 : 0) * LU_PXS + (t & 7) * 8) = le;
+      }
+      __syncthreads();
+      if (k + 1 < strip + 2) LU_LOAD_ROW(hq0 + k);
+      if (k >= 2) {
+        const int hq = hq0 + k - 2;
+        const uint16_t* s0 = ring + ((k - 2) % 3) * ((LU_MAXC + 2) * LU_PXS);
+        const uint16_t* s1 = ring + ((k - 1) % 3) * ((LU_MAXC + 2) * LU_PXS);
+        const uint16_t* s2 = slot;
+        for (int st = wave; st < (chunk >> 4); st += 4) {
+          sk_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          const int aoff = (16 * st + lp) * LU_PXS + 8 * lq;
+#pragma unroll
+          for (int dw = 0; dw < 3; ++dw)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              const int o = aoff + dw * LU_PXS + 32 * c;
+              sk_bf16x8 a0 = __builtin_bit_cast(sk_bf16x8, *reinterpret_cast<const uint4*>(s0 + o));
+              sk_bf16x8 a1 = __builtin_bit_cast(sk_bf16x8, *reinterpret_cast<const uint4*>(s1 + o));
+              sk_bf16x8 a2 = __builtin_bit_cast(sk_bf16x8, *reinterpret_cast<const uint4*>(s2 + o));
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wf[0][dw][c], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wf[1][dw][c], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, wf[2][dw][c], acc, 0, 0, 0);
+            }
+          // acc[r] = D[pixel 16 st + 4 lq + r][column lp]
+          if (ni < SK_I) {
+            float* orow = outt + (ni * 2 + nph) * LU_OS + 2 * (16 * st + 4 * lq) + npw;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float v = acc[r] + bv;
+              if (apply_tanh) v = tanhf(v);
+              orow[2 * r] = v;
+            }
+          }
+        }
+        __syncthreads();
+        const int lgh = 31 - __builtin_clz(chunk >> 1);          // float4 per output row = chunk / 2
+        for (int f = t; f < (6 << lgh); f += 256) {
+          const int rid = f >> lgh, m = f & ((1 << lgh) - 1);
+          const int i = rid >> 1, ph = rid & 1;
+          *reinterpret_cast<float4*>(y + (((size_t)n * SK_I + i) * H + 2 * hq + ph) * W + 2 * wo0 + 4 * m) =
+              *reinterpret_cast<const float4*>(outt + rid * LU_OS + 4 * m);
+        }
+      }
+      __syncthreads();
+    }
+#undef LU_LOAD_ROW
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -346,7 +543,7 @@ __global__ __launch_bounds__(LU_TH * 32) void last_up_kernel(const T* __restrict
               const float xval = xv[dh][dw][oo];
 #pragma unroll
               for (int i = 0; i < SK_I; ++i)
-                acc[ph][pw][i] = fmaf(xval, wr[i * 16 + kh * 4 + kw], acc[ph][pw][i]);
+                acc[ph][pw][i] = fmaf(xval, Elem<T>::round(wr[i * 16 + kh * 4 + kw]), acc[ph][pw][i]);
             }
     }
   }
@@ -441,6 +638,14 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const T* __restrict__
   }
 }
 
+// row-staged bf16 kernels: unit width (output pixels) for an output row of Wo pixels; 3 resident blocks per CU (VGPR-limited)
+constexpr int SK_ROWS_BLOCKS = 768;
+bool sk_rows_chunk(int Wo, int* chunk) {
+  if (Wo >= 128 && Wo % 128 == 0) { *chunk = 128; return true; }
+  if (Wo == 32 || Wo == 64) { *chunk = Wo; return true; }
+  return false;
+}
+
 int skinny_wgrad_blocks(long long npix, int* ppb) {
   long long want = 512;
   long long per = (npix + want - 1) / want;
@@ -460,12 +665,12 @@ int rg_skinny_first_down(const float* x, const float* w, const float* bias, void
   long long npix = (long long)N * (H / 2) * (W / 2);
   static int no_mfma = -1;
   if (no_mfma < 0) { const char* e = getenv("RNAGAN_SKINNY_VALU"); no_mfma = (e && e[0] == '1') ? 1 : 0; }
-  if (dtype == RG_BF16 && O == 64 && (W / 2) % 32 == 0 && npix / 32 < 0x7fffffff && !no_mfma) {
-    int ngroups = (int)(npix / 32);
-    int blocks = (ngroups + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(first_down_mfma_kernel, dim3(blocks), dim3(256), 0, st, x, w, bias, (uint16_t*)y, N, H, W, slope,
-                       ngroups);
+  int chunk;
+  if (dtype == RG_BF16 && O == 64 && sk_rows_chunk(W / 2, &chunk) && npix / chunk < 0x7fffffff && !no_mfma) {
+    int nunits = (int)(npix / chunk);
+    int blocks = nunits < SK_ROWS_BLOCKS ? nunits : SK_ROWS_BLOCKS;
+    hipLaunchKernelGGL(first_down_rows_kernel, dim3(blocks), dim3(256), 0, st, x, w, bias, (uint16_t*)y, N, H, W, slope,
+                       chunk, nunits);
     RG_LAUNCH_CHECK("first_down(mfma)");
     return RG_OK;
   }
@@ -480,6 +685,19 @@ int rg_skinny_first_down(const float* x, const float* w, const float* bias, void
 int rg_skinny_last_up(const void* x, const float* w, const float* bias, float* y, int N, int Ho, int Wo, int O, int I,
                       int apply_tanh, int dtype, hipStream_t st) {
   (void)I;
+  static int lu_valu = -1;
+  if (lu_valu < 0) { const char* e = getenv("RNAGAN_SKINNY_VALU"); lu_valu = (e && e[0] == '1') ? 1 : 0; }
+  int chunk;
+  if (dtype == RG_BF16 && O == 64 && sk_rows_chunk(Wo, &chunk) && !lu_valu) {
+    int strip = Ho < 16 ? Ho : 16;
+    while (Ho % strip) --strip;
+    long long nstrips = (long long)N * (Ho / strip) * (Wo / chunk);
+    int blocks = nstrips < 512 ? (int)nstrips : 512;
+    hipLaunchKernelGGL(last_up_rows_kernel, dim3(blocks), dim3(256), 0, st, (const uint16_t*)x, w, bias, y, N, Ho, Wo,
+                       apply_tanh, chunk, strip, (int)nstrips);
+    RG_LAUNCH_CHECK("last_up(mfma)");
+    return RG_OK;
+  }
   if (dtype == RG_BF16) {
     constexpr int TH = 8;
     int tiles = ((Wo + LU_TW - 1) / LU_TW) * ((Ho + TH - 1) / TH);
@@ -500,7 +718,7 @@ int rg_skinny_last_up(const void* x, const float* w, const float* bias, float* y
   return RG_OK;
 }
 
-constexpr int SKW_BLOCKS = 1024;
+constexpr int SKW_BLOCKS = SK_ROWS_BLOCKS;
 
 size_t rg_skinny_wgrad_ws_bytes(int N, int Ho, int Wo, int O, int I) {
   (void)I;
@@ -517,13 +735,13 @@ int rg_skinny_wgrad_impl(const void* low, const float* high_nchw, float* dw, int
   long long npix = (long long)N * Ho * Wo;
   static int no_mfma = -1;
   if (no_mfma < 0) { const char* e = getenv("RNAGAN_SKINNY_VALU"); no_mfma = (e && e[0] == '1') ? 1 : 0; }
-  if (dtype == RG_BF16 && O == 64 && Wo % 32 == 0 && npix / 32 < 0x7fffffff && !no_mfma) {
-    int ngroups = (int)(npix / 32);
-    int nbm = (ngroups + 3) / 4;
-    if (nbm > SKW_BLOCKS) nbm = SKW_BLOCKS;
+  int chunk;
+  if (dtype == RG_BF16 && O == 64 && sk_rows_chunk(Wo, &chunk) && npix / chunk < 0x7fffffff && !no_mfma) {
+    int nunits = (int)(npix / chunk);
+    int nbm = nunits < SK_ROWS_BLOCKS ? nunits : SK_ROWS_BLOCKS;
     RG_REQUIRE(ws && ws_bytes >= (size_t)nbm * elems * sizeof(float), RG_EWORKSPACE, "skinny_wgrad: workspace too small");
-    hipLaunchKernelGGL(skinny_wgrad_mfma_kernel, dim3(nbm), dim3(256), 0, st, (const uint16_t*)low, high_nchw, (float*)ws,
-                       N, 2 * Ho, 2 * Wo, ngroups);
+    hipLaunchKernelGGL(skinny_wgrad_rows_kernel, dim3(nbm), dim3(256), 0, st, (const uint16_t*)low, high_nchw, (float*)ws,
+                       N, 2 * Ho, 2 * Wo, chunk, nunits);
     RG_LAUNCH_CHECK("skinny_wgrad(mfma)");
     return rg_reduce_slabs((const float*)ws, dw, elems, nbm, accumulate, 0, 0, st);
   }
