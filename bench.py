@@ -228,12 +228,27 @@ def measure_roofline(ops, device, one_step, step_ms):
     dom = max(rows, key=lambda k: rows[k]["ms_total"])
     names = {"conv_fwd_dgrad": "gather_gemm_kernel (bf16 MFMA implicit-GEMM conv: fwd / dgrad / tangent)",
              "conv_wgrad": "wgrad_kernel (bf16 MFMA weight gradient) + reduce_slabs_kernel"}
+    traffic, traffic_src = pmc_traffic({"conv_fwd_dgrad": "gather_gemm", "conv_wgrad": "wgrad_dma"}.get(dom))
     return {"bound": "mfma", "kernel": names.get(dom, dom), "achieved": rows[dom]["tflops"],
             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(rows[dom]["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(rows[dom]["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+            "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
             "launches": rows[dom]["launches"], "avg_us_per_launch": rows[dom]["avg_us_per_launch"],
             "share_of_step": rows[dom]["share_of_step"],
             "others": {k: v for k, v in rows.items() if k != dom}}
+
+
+def pmc_traffic(family):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC summary (two separate --pmc passes,
+    FETCH_SIZE doubled per the gfx950 correction; tools/pmc_traffic.py).  Counters cannot be read from inside
+    this process, so the figure is the one measured on this workload (batch 64) when the profile was taken."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            row = json.load(f)[family]
+        return row["hbm_bytes_per_launch"], "profiles/round1_pmc_hbm_traffic.json (%d launches)" % row["launches"]
+    except (OSError, KeyError, ValueError, TypeError):
+        return None, None
 
 
 def cpu_baseline(seed):
