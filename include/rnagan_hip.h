@@ -56,13 +56,20 @@ const char* rg_last_error(void);
  * Stride-2 4x4 convolution family (K1/K2/K3 of SURVEY 2.2)
  * ------------------------------------------------------------------------------------------- */
 
-/* Re-layout of a master weight for the MFMA kernels (either output may be NULL):
- *   wdn[O][16][I]  (B operand of rg_conv_down: k = (tap, i) contiguous in i)
- *   wup[I][16][O]  (B operand of rg_conv_up:   k = (tap, o) contiguous in o)
+/* Weight layout of this family: fp32 masters and gradients are TAP-MAJOR, w[O][4][4][I] (O = channels on the
+ * low-resolution side, I = on the high-resolution side), i.e. nn.Conv2d's weight[O][I][kh][kw] /
+ * nn.ConvTranspose2d's weight[O][I][kh][kw] with the dimensions permuted (0,2,3,1).  The host side keeps the
+ * nn.Parameter as a strided view of this storage, so state_dicts and checkpoints still show the PyTorch shape.
+ * With this order the bf16 GEMM operand of rg_conv_down is an element-wise cast of the master and rg_conv_wgrad
+ * writes dw without a permuting pass.
+ *
+ * bf16 operand images for the MFMA kernels (either output may be NULL):
+ *   wdn[O][16][I]  (B operand of rg_conv_down: k = (tap, i) contiguous in i) = cast of w
+ *   wup[16][I][O]  (B operand of rg_conv_up:   k = (tap, o) contiguous in o) = transpose of w as [O][16*I]
  * both in `dtype`.  Runs after every optimizer step (src/wgan_loss.py:127,261,388). */
 int rg_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I, int dtype, void* stream);
 
-/* y[N][Hi/2][Wi/2][O] = conv2d(x[N][Hi][Wi][I], w, stride 2, pad 1).
+/* y[N][Hi/2][Wi/2][O] = conv2d(x[N][Hi][Wi][I], w[O][4][4][I], stride 2, pad 1).
  * nn.Conv2d forward in the discriminator (D(.) at src/wgan_loss.py:119,241,253,379) and the
  * data-gradient of nn.ConvTranspose2d in the generator (loss.backward(), :126).
  * `wdn` may be NULL when the generic kernel runs (it reads `w`). */
@@ -72,13 +79,13 @@ int rg_conv_down(const void* x, const float* w, const void* wdn, void* y, int N,
  * grid cannot fill the chip (few rows, long K); Hlow/Wlow = low-resolution side.  May be 0. */
 size_t rg_conv_workspace_bytes(int up, int N, int Hlow, int Wlow, int O, int I, int dtype, int algo);
 
-/* y[N][2Ho][2Wo][I] = conv_transpose2d(x[N][Ho][Wo][O], w, stride 2, pad 1).
+/* y[N][2Ho][2Wo][I] = conv_transpose2d(x[N][Ho][Wo][O], w[O][4][4][I], stride 2, pad 1).
  * nn.ConvTranspose2d forward in the generator (G(.) at src/wgan_loss.py:113,247,371) and the
  * data-gradient of nn.Conv2d in the discriminator (.backward() :126,260,387; autograd.grad :34-41). */
 int rg_conv_up(const void* x, const float* w, const void* wup, void* y, int N, int Ho, int Wo, int O, int I,
                int dtype, int algo, void* ws, size_t ws_bytes, void* stream);
 
-/* dw[O][I][4][4] (+)= sum_{n,ho,wo} low[n][ho][wo][o] * high[n][2ho-1+kh][2wo-1+kw][i].
+/* dw[O][kh][kw][I] (+)= sum_{n,ho,wo} low[n][ho][wo][o] * high[n][2ho-1+kh][2wo-1+kw][i].
  * Weight gradient of both layer kinds (every .backward()).  Deterministic: split-K partial slabs
  * in `ws` are summed in a fixed order. */
 size_t rg_conv_wgrad_workspace_bytes(int N, int Ho, int Wo, int O, int I, int dtype, int algo);
@@ -92,7 +99,8 @@ int rg_conv_wgrad2(const void* low0, const void* high0, const void* low1, const 
                    int Ho, int Wo, int O, int I, int dtype, int accumulate, int algo, void* ws, size_t ws_bytes,
                    void* stream);
 
-/* Image-side layers (I = 3 channels, NCHW fp32 on the high-resolution side; HBM-bound).
+/* Image-side layers (I = 3 channels, NCHW fp32 on the high-resolution side; HBM-bound).  Their weights keep
+ * the PyTorch layout w[O][I][4][4] (48 values per O).
  * rg_first_down: y[N][H/2][W/2][O] = lrelu_slope(conv2d(x_nchw, w) + bias); bias may be NULL,
  *   slope = 1 disables the activation.  Discriminator layer 0 forward
  *   (Conv2d(3,64,4,2,1)+LeakyReLU, histopathology_gan.py:186-192) and data-gradient of the

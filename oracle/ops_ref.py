@@ -65,24 +65,22 @@ class RefOps:
         return w.to(self.f) if self.act_dtype != torch.bfloat16 else w.to(self.act_dtype).to(self.f)
 
     # ------------------------------------------------------------------ conv family
+    # (the handle's master may be stored tap-major; cw.oihw() / cw.store_grad_oihw() give the PyTorch view)
     def conv_down(self, x, cw: ConvW):
-        y = F.conv2d(self._nchw(x), self._wq(cw.w), None, stride=2, padding=1)
+        y = F.conv2d(self._nchw(x), self._wq(cw.oihw()), None, stride=2, padding=1)
         return _nhwc(y, self.act_dtype)
 
     def conv_up(self, x, cw: ConvW):
-        y = F.conv_transpose2d(self._nchw(x), self._wq(cw.w), None, stride=2, padding=1)
+        y = F.conv_transpose2d(self._nchw(x), self._wq(cw.oihw()), None, stride=2, padding=1)
         return _nhwc(y, self.act_dtype)
 
-    def conv_wgrad(self, low, high, dw, accumulate: bool):
-        g = torch.nn.grad.conv2d_weight(self._nchw(high), dw.shape, self._nchw(low), stride=2, padding=1)
-        if accumulate:
-            dw.add_(g)
-        else:
-            dw.copy_(g)
+    def conv_wgrad(self, low, high, cw: ConvW, accumulate: bool):
+        g = torch.nn.grad.conv2d_weight(self._nchw(high), (cw.O, cw.I, 4, 4), self._nchw(low), stride=2, padding=1)
+        cw.store_grad_oihw(g, accumulate)
 
-    def conv_wgrad2(self, low0, high0, low1, high1, dw, accumulate: bool):
-        self.conv_wgrad(low0, high0, dw, accumulate)
-        self.conv_wgrad(low1, high1, dw, True)
+    def conv_wgrad2(self, low0, high0, low1, high1, cw: ConvW, accumulate: bool):
+        self.conv_wgrad(low0, high0, cw, accumulate)
+        self.conv_wgrad(low1, high1, cw, True)
 
     def first_down(self, x_nchw, cw: ConvW, bias, slope: float):
         # bf16 path: the image-side layers run on the matrix cores too, so image and weights are rounded to

@@ -109,6 +109,19 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slab, float* __res
   dst[idx] = s;
 }
 
+// identity layout, 16 bytes per thread (the tap-major conv weight gradients: slab layout == dW layout)
+__global__ void reduce_slabs_vec4_kernel(const float* __restrict__ slab, float* __restrict__ dst, size_t n4, size_t n,
+                                         int nsplit, int accumulate) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n4) return;
+  float4 s = accumulate ? reinterpret_cast<const float4*>(dst)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < nsplit; ++z) {
+    const float4 v = reinterpret_cast<const float4*>(slab + (size_t)z * n)[idx];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  reinterpret_cast<float4*>(dst)[idx] = s;
+}
+
 // perm_mode 1, LDS-tiled: block = one o-row x 64 consecutive i.  Reads 16 tap-rows of 64 floats (256
 // contiguous bytes each, summed over the splits), transposes through LDS, writes 64 x 16 contiguous floats.
 __global__ __launch_bounds__(256) void reduce_slabs_tap_kernel(const float* __restrict__ slab, float* __restrict__ dst,
@@ -167,6 +180,12 @@ int rg_reduce_slabs(const float* slab, float* dst, size_t n, int nsplit, int acc
     RG_LAUNCH_CHECK("reduce_slabs");
     return RG_OK;
   }
+  if (perm_mode == 0 && n % 4 == 0 && n >= 4096) {
+    hipLaunchKernelGGL(reduce_slabs_vec4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, slab, dst, n / 4,
+                       n, nsplit, accumulate);
+    RG_LAUNCH_CHECK("reduce_slabs");
+    return RG_OK;
+  }
   if (perm_mode == 1 && Q % 64 == 0 && nsplit <= 4) {   // many splits: the element-wise form has more parallelism
     size_t O = n / ((size_t)Q * 16);
     hipLaunchKernelGGL(reduce_slabs_tap_kernel, dim3((unsigned)(O * (Q / 64))), dim3(256), 0, st, slab, dst, n, nsplit,
@@ -188,12 +207,12 @@ struct Geo {
   int N, Hl, Wl, Hh, Wh, O, I;  // low-res dims (Hl,Wl), high-res dims (Hh=2Hl, Wh=2Wl)
 };
 
-// ---- conv_down: M = N*Hl*Wl, K = I*16 (k = ci*16 + tap), Ncols = O
+// ---- conv_down: M = N*Hl*Wl, K = 16*I (k = tap*I + ci: tap-major masters w[O][16][I]), Ncols = O
 template <typename T> struct DownA {
   const T* x; Geo g;
   __device__ float operator()(int, int m, int k) const {
     int wo = m % g.Wl, t = m / g.Wl, ho = t % g.Hl, n = t / g.Hl;
-    int ci = k >> 4, tap = k & 15;
+    int tap = k / g.I, ci = k - tap * g.I;
     int hi = 2 * ho - 1 + (tap >> 2), wi = 2 * wo - 1 + (tap & 3);
     if (hi < 0 || hi >= g.Hh || wi < 0 || wi >= g.Wh) return 0.f;
     return Elem<T>::ld(x + (((size_t)n * g.Hh + hi) * g.Wh + wi) * g.I + ci);
@@ -231,7 +250,17 @@ template <typename T> struct UpB {
     int o = k >> 2, t4 = k & 3, kh, kw, d;
     up_tap(zb >> 1, t4 >> 1, 0, kh, d);
     up_tap(zb & 1, t4 & 1, 0, kw, d);
-    return Elem<T>::round(w[((size_t)o * g.I + i) * 16 + kh * 4 + kw]);
+    return Elem<T>::round(w[((size_t)o * 16 + kh * 4 + kw) * g.I + i]);      // tap-major master
+  }
+};
+// image-side last_up keeps the PyTorch layout w[O][I][4][4]
+struct UpBOihw {
+  const float* w; Geo g;
+  __device__ float operator()(int zb, int k, int i) const {
+    int o = k >> 2, t4 = k & 3, kh, kw, d;
+    up_tap(zb >> 1, t4 >> 1, 0, kh, d);
+    up_tap(zb & 1, t4 & 1, 0, kw, d);
+    return w[((size_t)o * g.I + i) * 16 + kh * 4 + kw];
   }
 };
 template <typename T> struct UpC {
@@ -273,7 +302,8 @@ template <typename T> struct BiasActC {
   }
 };
 
-// ---- wgrad: M = O, Ncols = I*16 (col = i*16 + tap), K = N*Hl*Wl pixels
+// ---- wgrad: M = O, Ncols = 16*I, K = N*Hl*Wl pixels.  col = tap*I + i (tap-major dW[O][16][I]) for the 4x4 conv
+// layers, col = i*16 + tap (PyTorch layout) for the image-side layer
 template <typename T> struct WgradA {
   const T* low; Geo g;
   __device__ float operator()(int, int o, int pix) const { return Elem<T>::ld(low + (size_t)pix * g.O + o); }
@@ -282,7 +312,7 @@ template <typename T> struct WgradB {
   const T* high; Geo g;
   __device__ float operator()(int, int pix, int col) const {
     int wo = pix % g.Wl, t = pix / g.Wl, ho = t % g.Hl, n = t / g.Hl;
-    int i = col >> 4, tap = col & 15;
+    int tap = col / g.I, i = col - tap * g.I;
     int hi = 2 * ho - 1 + (tap >> 2), wi = 2 * wo - 1 + (tap & 3);
     if (hi < 0 || hi >= g.Hh || wi < 0 || wi >= g.Wh) return 0.f;
     return Elem<T>::ld(high + (((size_t)n * g.Hh + hi) * g.Wh + wi) * g.I + i);
@@ -400,7 +430,7 @@ int rg_generic_last_up(const void* x, const float* w, const float* bias, float* 
                        int I, int apply_tanh, int dtype, hipStream_t st) {
   Geo g{N, Ho, Wo, 2 * Ho, 2 * Wo, O, I};
   RG_DISPATCH_DTYPE(dtype, T, {
-    return launch_generic<true, false>("last_up(generic)", UpA<T>{(const T*)x, g}, UpB<float>{w, g},
+    return launch_generic<true, false>("last_up(generic)", UpA<T>{(const T*)x, g}, UpBOihw{w, g},
                                        UpCNchw{y, bias, apply_tanh, g}, N * Ho * Wo, I, O * 4, 4, 1, st);
   })
 }

@@ -36,7 +36,7 @@ struct GArgs {
   int lgW, lgH;     // row m -> (n, hq, wq): wq = m & (2^lgW-1), hq = (m>>lgW) & (2^lgH-1)
   int Hs, Ws;       // spatial dims of the tensor A rows are gathered from
   int ldc;          // output row stride in elements
-  int Btaps;        // taps per B row (16 for conv packs, 1 for plain)
+  int b_col, b_tap; // B operand: elements between consecutive output columns / between consecutive taps
   int tiles_n;      // number of 128-wide column tiles
   const float* scale;
   const float* shift;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(GArgs g) {
     AMASK = ok ? mask : 0u;                                                                       \
     int col = bn + r0 + 32 * (J);                                                                 \
     BOK = col < g.Ncols;                                                                          \
-    BPTR = g.B + (long long)(BOK ? col : 0) * g.Btaps * g.Cin + chunk * 8;                        \
+    BPTR = g.B + (long long)(BOK ? col : 0) * g.b_col + chunk * 8;                             \
   } while (0)
   RG_ROW_SETUP(0, a_ptr0, a_mask0, b_ptr0, b_ok0);
   RG_ROW_SETUP(1, a_ptr1, a_mask1, b_ptr1, b_ok1);
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(GArgs g) {
       a_delta = 0;                                                                                \
       b_tap = 0;                                                                                  \
     }                                                                                             \
-    const int ao = a_delta + c0_, bo = b_tap * g.Cin + c0_;                                       \
+    const int ao = a_delta + c0_, bo = b_tap * g.b_tap + c0_;                                       \
     ra0 = ld16_if(a_ptr0 + ao, (a_mask0 >> tap_) & 1u);                                           \
     ra1 = ld16_if(a_ptr1 + ao, (a_mask1 >> tap_) & 1u);                                           \
     ra2 = ld16_if(a_ptr2 + ao, (a_mask2 >> tap_) & 1u);                                           \
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) {
     int col = bn + r0 + RPI * j;
-    b_off[j] = col < g.Ncols ? (int)((((long long)col * g.Btaps) * g.Cin + lc * 8) * 2) : -1;
+    b_off[j] = col < g.Ncols ? (int)(((long long)col * g.b_col + lc * 8) * 2) : -1;
   }
 
   const int cpt = g.Cin >> 6;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
       a_delta = 0;
       b_tap = 0;
     }
-    const int ao = (a_delta + c0) * 2, bo = (b_tap * g.Cin + c0) * 2;
+    const int ao = (a_delta + c0) * 2, bo = (b_tap * g.b_tap + c0) * 2;
     uint4* sbase = lds + stage * STAGE_SLOTS;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
@@ -760,6 +760,7 @@ struct W2Args {
   int lgWo, lgHo, Hh, Wh;
   int tiles_c, klen;
   int tiles_o, nsplit;
+  int accumulate;        // nsplit == 1 only: `slab` IS dW[O][16][I] and the tile is added to it
 };
 
 __device__ __forceinline__ int wswz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -893,21 +894,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(W2Args g) {
 #pragma unroll
   for (int p = 0; p < 16; ++p) {
     const int row = rr + 8 * p;
-    *reinterpret_cast<float4*>(slab + (long long)(o0 + row) * ldw + c0 + c4) =
-        *reinterpret_cast<const float4*>(cs + row * 128 + c4);
+    float4* d = reinterpret_cast<float4*>(slab + (long long)(o0 + row) * ldw + c0 + c4);
+    float4 v = *reinterpret_cast<const float4*>(cs + row * 128 + c4);
+    if (g.accumulate) {
+      const float4 a = *d;
+      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    *d = v;
   }
 }
 
 // ================================================================================================
 // packs
 // ================================================================================================
-// wdn[o][tap][i] = bf16(w[o][i][tap])
-__global__ void pack_wdn_kernel(const float* w, uint16_t* wdn, int O, int I) {
-  size_t n = (size_t)O * I * 16;
-  for (size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += (size_t)gridDim.x * blockDim.x) {
-    size_t i = d % I, ot = d / I;
-    size_t tap = ot & 15, o = ot >> 4;
-    wdn[d] = f32_to_bf16(w[(o * I + i) * 16 + tap]);
+// wdn = bf16(w): the fp32 masters of the 4x4 conv layers are tap-major [O][16][I] already (8 elements per thread)
+__global__ void cast_bf16_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, size_t n8) {
+  for (size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x; d < n8; d += (size_t)gridDim.x * blockDim.x) {
+    float v[8];
+    Vec<float, 8>::ld(w + d * 8, v);
+    Vec<bf16_t, 8>::st(reinterpret_cast<bf16_t*>(out) + d * 8, v);
   }
 }
 // generic tiled transpose-pack: src[R][Cc] fp32 -> dst[perm(col)][R] bf16, perm(col) = tap*(Cc/16) + c
@@ -1101,7 +1106,7 @@ int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, in
   g.A = (const uint16_t*)x; g.B = (const uint16_t*)wdn; g.C = y;
   int Ho = Hi / 2, Wo = Wi / 2;
   g.M = N * Ho * Wo; g.Ncols = O; g.Cin = I; g.taps = 16;
-  g.lgW = rg_ilog2(Wo); g.lgH = rg_ilog2(Ho); g.Hs = Hi; g.Ws = Wi; g.ldc = O; g.Btaps = 16;
+  g.lgW = rg_ilog2(Wo); g.lgH = rg_ilog2(Ho); g.Hs = Hi; g.Ws = Wi; g.ldc = O; g.b_col = 16 * I; g.b_tap = I;       // wdn[O][16][I]
   return launch_gather2<MODE_DOWN, EPI_BF16>("conv_down(mfma)", g, 1, g.M, (size_t)N * Hi * Wi * I * 2,
                                              (size_t)O * 16 * I * 2, ws, ws_bytes, st);
 }
@@ -1111,7 +1116,7 @@ int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int 
   GArgs g{};
   g.A = (const uint16_t*)x; g.B = (const uint16_t*)wup; g.C = y;
   g.M = N * Ho * Wo; g.Ncols = I; g.Cin = O; g.taps = 4;
-  g.lgW = rg_ilog2(Wo); g.lgH = rg_ilog2(Ho); g.Hs = Ho; g.Ws = Wo; g.ldc = I; g.Btaps = 16;
+  g.lgW = rg_ilog2(Wo); g.lgH = rg_ilog2(Ho); g.Hs = Ho; g.Ws = Wo; g.ldc = I; g.b_col = O; g.b_tap = I * O;        // wup[16][I][O]
   return launch_gather2<MODE_UP, EPI_BF16>("conv_up(mfma)", g, 4, (long long)g.M * 4, (size_t)N * Ho * Wo * O * 2,
                                            (size_t)I * 16 * O * 2, ws, ws_bytes, st);
 }
@@ -1125,7 +1130,7 @@ size_t rg_mfma_conv_ws_bytes(int up, int N, int Hlow, int Wlow, int O, int I) {
 int rg_mfma_gemm_plain(const void* a, const void* bt, void* c, int M, int K, int Ncols, int ldc, hipStream_t st) {
   GArgs g{};
   g.A = (const uint16_t*)a; g.B = (const uint16_t*)bt; g.C = c;
-  g.M = M; g.Ncols = Ncols; g.Cin = K; g.taps = 1; g.lgW = 0; g.lgH = 0; g.Hs = 1; g.Ws = 1; g.ldc = ldc; g.Btaps = 1;
+  g.M = M; g.Ncols = Ncols; g.Cin = K; g.taps = 1; g.lgW = 0; g.lgH = 0; g.Hs = 1; g.Ws = 1; g.ldc = ldc; g.b_col = K; g.b_tap = 0;
   RG_REQUIRE(ldc == Ncols, RG_EINVAL, "gemm_plain: dense output expected");
   return launch_gather2<MODE_PLAIN, EPI_BF16>("gemm_plain(mfma)", g, 1, M, (size_t)M * K * 2, (size_t)Ncols * K * 2,
                                               nullptr, 0, st);
@@ -1141,7 +1146,7 @@ int rg_mfma_linear(const void* a, const void* bt, const float* scale, const floa
   RG_REQUIRE(Kpad % 64 == 0 && Nout % 8 == 0, RG_EUNSUPPORTED, "linear(mfma): K_pad %% 64 and Nout %% 8 required");
   GArgs g{};
   g.A = (const uint16_t*)a; g.B = (const uint16_t*)bt; g.C = y;
-  g.M = M; g.Ncols = Nout; g.Cin = Kpad; g.taps = 1; g.lgW = 0; g.lgH = 0; g.Hs = 1; g.Ws = 1; g.ldc = ldy; g.Btaps = 1;
+  g.M = M; g.Ncols = Nout; g.Cin = Kpad; g.taps = 1; g.lgW = 0; g.lgH = 0; g.Hs = 1; g.Ws = 1; g.ldc = ldy; g.b_col = Kpad; g.b_tap = 0;
   g.scale = scale; g.shift = shift; g.slope = slope;
   return launch_gather2<MODE_PLAIN, EPI_LINEAR>("linear(mfma)", g, 1, M, (size_t)M * Kpad * 2, (size_t)Nout * Kpad * 2,
                                                 ws, ws_bytes, st);
@@ -1177,7 +1182,7 @@ int rg_mfma_conv_wgrad(const void* low, const void* high, float* dw, int N, int 
   g.klen = (klen + 63) / 64 * 64;
   hipLaunchKernelGGL(wgrad_kernel, dim3((O / 128) * g.tiles_c, nsplit), dim3(256), 0, st, g);
   RG_LAUNCH_CHECK("conv_wgrad(mfma)");
-  return rg_reduce_slabs((const float*)ws, dw, elems, nsplit, accumulate, 1, I, st);
+  return rg_reduce_slabs((const float*)ws, dw, elems, nsplit, accumulate, 0, 0, st);
 }
 
 static int mfma_wgrad_split_k(int K, int O, int I) {
@@ -1216,9 +1221,12 @@ int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, c
   g.klen = (klen + 63) / 64 * 64;
   nsplit = (K + g.klen - 1) / g.klen;
   g.tiles_o = O / 128; g.nsplit = nsplit;
+  // dW is tap-major [O][16][I] = the slab layout: a single split writes (or adds to) dW straight from its epilogue
+  if (nsplit == 1) { g.slab = dw; g.accumulate = accumulate; }
   hipLaunchKernelGGL(wgrad_dma_kernel, dim3((unsigned)(g.tiles_o * g.tiles_c * nsplit)), dim3(256), 0, st, g);
   RG_LAUNCH_CHECK("conv_wgrad(mfma)");
-  return rg_reduce_slabs((const float*)ws, dw, elems, nsplit, accumulate, 1, I, st);
+  if (nsplit == 1) return RG_OK;
+  return rg_reduce_slabs((const float*)ws, dw, elems, nsplit, accumulate, 0, 0, st);
 }
 
 size_t rg_mfma_wgrad2_ws_bytes(int N, int Ho, int Wo, int O, int I) {
@@ -1229,11 +1237,12 @@ size_t rg_mfma_wgrad2_ws_bytes(int N, int Ho, int Wo, int O, int I) {
 
 int rg_mfma_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I, hipStream_t st) {
   if (wdn) {
-    hipLaunchKernelGGL(pack_wdn_kernel, dim3(grid_cap((size_t)O * I * 16)), dim3(256), 0, st, w, (uint16_t*)wdn, O, I);
+    const size_t n8 = (size_t)O * I * 2;     // I % 8 == 0 on the MFMA path
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_cap(n8)), dim3(256), 0, st, w, (uint16_t*)wdn, n8);
     RG_LAUNCH_CHECK("pack_wdn");
   }
   if (wup) {
-    // w viewed as [O][I*16] -> wup[(i*16+tap)][O]
+    // w viewed as [O][16*I] (col = tap*I + i) -> wup[tap][i][O]: a plain transpose
     hipLaunchKernelGGL(transpose_pack_kernel, dim3((I * 16 + 63) / 64, (O + 63) / 64), dim3(256), 0, st, w,
                        (uint16_t*)wup, O, I * 16, 0);
     RG_LAUNCH_CHECK("pack_wup");

@@ -29,17 +29,23 @@ import torch
 
 
 class ConvW:
-    """Handle of one 4x4 conv weight: fp32 master ``w[O][I][4][4]`` (+ optional bias[.]).
+    """Handle of one 4x4 conv weight: fp32 master (+ optional bias[.]) and its gradient.
 
     O = channels on the LOW-resolution side, I = channels on the HIGH-resolution side: this is
     nn.Conv2d's (out,in,kh,kw) and nn.ConvTranspose2d's (in,out,kh,kw), so one handle type serves
-    both networks.  ``packs`` caches backend-private re-layouts (bf16 GEMM operand images); they
-    are rebuilt when ``version`` changes (after an optimizer step / state_dict load).
+    both networks.  ``layout`` says how ``w`` and ``dw`` are stored:
+      "OIHW": ``w[O][I][4][4]``, the PyTorch layout (image-side layers, G.0, the head, and any layer of a plain
+              nn.Module handed to the CPU twin);
+      "OHWI": ``w[O][4][4][I]``, tap-major -- what the HIP conv_down / conv_up / conv_wgrad kernels take
+              (models.tap_major_ re-homes a module's parameters this way; the nn.Parameter stays a strided
+              view with the PyTorch shape).
+    ``packs`` caches backend-private re-layouts (bf16 GEMM operand images); they are rebuilt when
+    ``version`` changes (after an optimizer step / state_dict load).
     """
 
-    __slots__ = ("w", "bias", "dw", "dbias", "packs", "packs_version", "version")
+    __slots__ = ("w", "bias", "dw", "dbias", "packs", "packs_version", "version", "layout")
 
-    def __init__(self, w, bias=None, dw=None, dbias=None):
+    def __init__(self, w, bias=None, dw=None, dbias=None, layout="OIHW"):
         self.w = w
         self.bias = bias
         self.dw = dw
@@ -47,6 +53,35 @@ class ConvW:
         self.packs = None
         self.packs_version = -1
         self.version = 0
+        self.layout = layout
+
+    @classmethod
+    def from_param(cls, weight, grad=None):
+        """Handle of a 4x4 conv nn.Parameter (logical shape [O][I][4][4]): tap-major if its storage is."""
+        w = weight.data if hasattr(weight, "data") else weight
+        t = w.permute(0, 2, 3, 1)
+        if t.is_contiguous() and (not w.is_contiguous() or w.shape[1] == 1):
+            return cls(t, None, None if grad is None else grad.permute(0, 2, 3, 1), None, "OHWI")
+        return cls(w, None, grad, None, "OIHW")
+
+    @property
+    def O(self):
+        return self.w.shape[0]
+
+    @property
+    def I(self):
+        return self.w.shape[3] if self.layout == "OHWI" else self.w.shape[1]
+
+    def oihw(self):
+        """The master in PyTorch order (a view)."""
+        return self.w.permute(0, 3, 1, 2) if self.layout == "OHWI" else self.w
+
+    def store_grad_oihw(self, g, accumulate):
+        d = self.dw.permute(0, 3, 1, 2) if self.layout == "OHWI" else self.dw
+        if accumulate:
+            d.add_(g)
+        else:
+            d.copy_(g)
 
 
 class BNP:
@@ -154,7 +189,7 @@ def disc_backward(ops, D: DiscNet, ctx, coef: float, wgrad: bool, accumulate: bo
             ctx.ga1[l], ctx.gz1[l], ctx.s_gy[l], ctx.s_gyxh[l] = ga, gz, s_gy, s_gyxh
         if wgrad:
             with ops.side(gz):
-                ops.conv_wgrad(gz, ctx.a[l - 1], cw.dw, accumulate)
+                ops.conv_wgrad(gz, ctx.a[l - 1], cw, accumulate)
         ga = ops.conv_up(gz, cw)
     gz0 = ops.lrelu_bwd(ga, ctx.a[0], D.slope)
     if keep_for_gp:
@@ -188,7 +223,7 @@ def disc_backward_pair(ops, D: DiscNet, ctx_a, coef_a: float, ctx_b, coef_b: flo
         gz_b, _, _ = ops.bn_act_bwd(ctx_b.z[l], ga_b, ctx_b.mean[l], ctx_b.invstd[l], bn.gamma, bn.beta, D.slope,
                                     bn.dgamma, bn.dbeta, True)
         with ops.side(gz_a, gz_b):
-            ops.conv_wgrad2(gz_a, ctx_a.a[l - 1], gz_b, ctx_b.a[l - 1], cw.dw, False)
+            ops.conv_wgrad2(gz_a, ctx_a.a[l - 1], gz_b, ctx_b.a[l - 1], cw, False)
         ga_a = ops.conv_up(gz_a, cw)
         ga_b = ops.conv_up(gz_b, cw)
     gz0_a = ops.lrelu_bwd(ga_a, ctx_a.a[0], D.slope)
@@ -233,7 +268,7 @@ def disc_gradient_penalty(ops, D: DiscNet, xhat, lambd: float, update_running=Tr
                                s_zt[l], s_xhzt[l], bn.dgamma, bn.dbeta, False)
         # dW = wgrad(pz, a_prev) + wgrad(gz1, at_prev): one launch, one split-K reduction
         with ops.side(pz):
-            ops.conv_wgrad2(pz, ctx.a[l - 1], ctx.gz1[l], ats[l - 1], cw.dw, False)
+            ops.conv_wgrad2(pz, ctx.a[l - 1], ctx.gz1[l], ats[l - 1], cw, False)
         qa = ops.conv_up(pz, cw)
     p0 = ops.lrelu_bwd(qa, ctx.a[0], D.slope)
     with ops.side(p0, v):
@@ -277,7 +312,7 @@ def gen_backward(ops, G: GenNet, ctx, gimg, accumulate: bool):
         gz, _, _ = ops.bn_act_bwd(ctx.z[l], ga, ctx.mean[l], ctx.invstd[l], bn.gamma, bn.beta,
                                   G.slope, bn.dgamma, bn.dbeta, accumulate)
         with ops.side(gz):
-            ops.conv_wgrad(ctx.a[l - 1], gz, cw.dw, accumulate)
+            ops.conv_wgrad(ctx.a[l - 1], gz, cw, accumulate)
         ga = ops.conv_down(gz, cw)
     gz0, _, _ = ops.bn_act_bwd(ctx.z[0], ga, ctx.mean[0], ctx.invstd[0], G.bn0.gamma, G.bn0.beta,
                                G.slope, G.bn0.dgamma, G.bn0.dbeta, accumulate)
@@ -341,6 +376,34 @@ def _bnp(bn):
                _grad_of(bn.weight), _grad_of(bn.bias), eps=bn.eps, momentum=bn.momentum)
 
 
+def is_tap_major(t) -> bool:
+    """4-D tensor of logical shape [O][I][4][4] whose storage order is [O][4][4][I]."""
+    return t.dim() == 4 and not t.is_contiguous() and t.permute(0, 2, 3, 1).is_contiguous()
+
+
+def _middle_convs(mod):
+    """The stride-2 4x4 conv layers between the image-side layer and G.0 / the head (torchgan DCGAN recipe)."""
+    blocks = list(mod.model.children())
+    sel = blocks[1:] if hasattr(mod, "disc") else blocks[1:-1]
+    return [blk[0] for blk in sel]
+
+
+def tap_major_(mod):
+    """Re-home the weights of the middle conv layers into tap-major storage w[O][4][4][I] (what the HIP conv
+    kernels take, include/rnagan_hip.h).  The nn.Parameters keep their PyTorch shape [O][I][4][4] as strided
+    views, so state_dict(), load_state_dict() and checkpoints are unchanged; only the memory order differs.
+    Idempotent."""
+    for conv in _middle_convs(mod):
+        w = conv.weight
+        if is_tap_major(w.data):
+            continue
+        g = w.grad
+        w.data = w.data.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        if g is not None:
+            w.grad = g.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    return mod
+
+
 def build_disc_net(mod) -> DiscNet:
     blocks = list(mod.model.children())
     c0 = blocks[0][0]
@@ -351,7 +414,7 @@ def build_disc_net(mod) -> DiscNet:
         conv, bn = blk[0], blk[1]
         if conv.bias is not None or not isinstance(bn, torch.nn.BatchNorm2d):
             raise NotImplementedError("HIP path supports the batchnorm=True recipe only")
-        bl.append((ConvW(conv.weight.data, None, _grad_of(conv.weight)), _bnp(bn)))
+        bl.append((ConvW.from_param(conv.weight, _grad_of(conv.weight)), _bnp(bn)))
     hc = mod.disc[0]
     if hc.bias is not None:
         raise NotImplementedError("HIP path supports the batchnorm=True recipe only")
@@ -369,7 +432,7 @@ def build_gen_net(mod) -> GenNet:
     bl = []
     for blk in blocks[1:-1]:
         conv, bn = blk[0], blk[1]
-        bl.append((ConvW(conv.weight.data, None, _grad_of(conv.weight)), _bnp(bn)))
+        bl.append((ConvW.from_param(conv.weight, _grad_of(conv.weight)), _bnp(bn)))
     lc = blocks[-1][0]
     if not isinstance(blocks[-1][-1], torch.nn.Tanh):
         raise NotImplementedError("HIP path supports last_nonlinearity=Tanh only")

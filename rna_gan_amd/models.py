@@ -25,6 +25,13 @@ def _num_repeats(size: int, what: str) -> int:
     return size.bit_length() - 4
 
 
+def _flat_view(buf, off, n, p):
+    if E.is_tap_major(p.data):
+        O, I = p.shape[0], p.shape[1]
+        return buf[off:off + n].view(O, 4, 4, I).permute(0, 3, 1, 2)
+    return buf[off:off + n].view(p.shape)
+
+
 class FlatParams:
     """All parameters of a module re-homed into ONE flat fp32 buffer (and their gradients into
     another), so that the optimizer step is a single fused kernel and the data-parallel gradient
@@ -44,9 +51,12 @@ class FlatParams:
         off = 0
         for p in params:
             n = p.numel()
-            self.data[off:off + n].copy_(p.data.reshape(-1))
-            p.data = self.data[off:off + n].view(p.shape)
-            p.grad = self.grad[off:off + n].view(p.shape)
+            # storage order is kept: a tap-major conv weight stays tap-major inside the flat buffer
+            dst = _flat_view(self.data, off, n, p)
+            gview = _flat_view(self.grad, off, n, p)
+            dst.copy_(p.data)
+            p.data = dst
+            p.grad = gview
             self.offsets.append((off, n))
             off += n
         self.params = params
@@ -64,7 +74,7 @@ class FlatParams:
         gbase = self.grad.data_ptr()
         for p, (off, n) in zip(ps, self.offsets):
             if p.grad is None or p.grad.data_ptr() != gbase + self.esize * off:
-                p.grad = self.grad[off:off + n].view(p.shape)
+                p.grad = _flat_view(self.grad, off, n, p)
         return True
 
 
@@ -97,6 +107,7 @@ class _HipModule(nn.Module):
             raise RuntimeError("%s runs on the HIP kernels only: move it to a ROCm GPU (.to('cuda')); "
                                "there is no CPU fallback" % type(self).__name__)
         if self._rt_flat is None or not self._rt_flat.owns(self):
+            E.tap_major_(self)
             self._rt_flat = FlatParams(self)
             self._rt_net = None
         if self._rt_ops is None or self._rt_net is None:

@@ -104,20 +104,28 @@ class HipOps:
         if self.dt != RG_BF16:
             return None, None
         if cw.packs is None or cw.packs_version != cw.version:
-            O, I = cw.w.shape[0], cw.w.shape[1]
+            O, I = cw.O, cw.I
             if cw.packs is None:
                 cw.packs = (torch.empty((O, 16, I), dtype=torch.bfloat16, device=self.device),
-                            torch.empty((I, 16, O), dtype=torch.bfloat16, device=self.device))
+                            torch.empty((16, I, O), dtype=torch.bfloat16, device=self.device))
             check(self.lib.rg_pack_conv_weight(_ptr(cw.w), _ptr(cw.packs[0]), _ptr(cw.packs[1]), O, I, RG_BF16,
                                                self.stream), "rg_pack_conv_weight")
             cw.packs_version = cw.version
         return cw.packs
 
     # ------------------------------------------------------------------ conv family
+    @staticmethod
+    def _tap_major(cw: ConvW):
+        if cw.layout != "OHWI" or not cw.w.is_contiguous():
+            raise ValueError("the HIP conv kernels take tap-major masters w[O][4][4][I]: re-home the module's 4x4 "
+                             "conv weights with rna_gan_amd.models.tap_major_(module) (or build the handle with "
+                             "ConvW.from_param on such a parameter)")
+
     def conv_down(self, x, cw: ConvW):
         N, Hi, Wi, I = x.shape
-        O = cw.w.shape[0]
-        assert cw.w.shape[1] == I and x.is_contiguous()
+        O = cw.O
+        self._tap_major(cw)
+        assert cw.I == I and x.is_contiguous()
         wdn, _ = self._packs(cw)
         y = self._act(N, Hi // 2, Wi // 2, O)
         ws = self._ws(self.lib.rg_conv_workspace_bytes(0, N, Hi // 2, Wi // 2, O, I, self.dt, self.algo))
@@ -128,8 +136,9 @@ class HipOps:
 
     def conv_up(self, x, cw: ConvW):
         N, Ho, Wo, O = x.shape
-        I = cw.w.shape[1]
-        assert cw.w.shape[0] == O and x.is_contiguous()
+        I = cw.I
+        self._tap_major(cw)
+        assert cw.O == O and x.is_contiguous()
         _, wup = self._packs(cw)
         y = self._act(N, 2 * Ho, 2 * Wo, I)
         ws = self._ws(self.lib.rg_conv_workspace_bytes(1, N, Ho, Wo, O, I, self.dt, self.algo))
@@ -138,21 +147,26 @@ class HipOps:
                                 _ptr(ws), ws.numel(), self.stream), "rg_conv_up"))
         return y
 
-    def conv_wgrad(self, low, high, dw, accumulate: bool):
+    def conv_wgrad(self, low, high, cw: ConvW, accumulate: bool):
         N, Ho, Wo, O = low.shape
         I = high.shape[3]
-        assert high.shape[1] == 2 * Ho and tuple(dw.shape) == (O, I, 4, 4) and dw.is_contiguous()
+        self._tap_major(cw)
+        dw = cw.dw
+        assert high.shape[1] == 2 * Ho and tuple(dw.shape) == (O, 4, 4, I) and dw.is_contiguous()
         nb = self.lib.rg_conv_wgrad_workspace_bytes(N, Ho, Wo, O, I, self.dt, self.algo)
         ws = self._ws(nb)
         self._timed("conv_wgrad", 2.0 * N * Ho * Wo * O * I * 16, lambda: check(
             self.lib.rg_conv_wgrad(_ptr(low), _ptr(high), _ptr(dw), N, Ho, Wo, O, I, self.dt, int(accumulate),
                                    self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_wgrad"))
 
-    def conv_wgrad2(self, low0, high0, low1, high1, dw, accumulate: bool):
+    def conv_wgrad2(self, low0, high0, low1, high1, cw: ConvW, accumulate: bool):
         """dw (+)= wgrad(low0, high0) + wgrad(low1, high1) in one launch (one split-K reduction)."""
         N, Ho, Wo, O = low0.shape
         I = high0.shape[3]
+        self._tap_major(cw)
+        dw = cw.dw
         assert low1.shape == low0.shape and high1.shape == high0.shape
+        assert tuple(dw.shape) == (O, 4, 4, I) and dw.is_contiguous()
         nb = self.lib.rg_conv_wgrad_workspace_bytes(N, Ho, Wo, O, I, self.dt, self.algo)
         ws = self._ws(nb)
         self._timed("conv_wgrad", 4.0 * N * Ho * Wo * O * I * 16, lambda: check(

@@ -13,6 +13,8 @@ from __future__ import annotations
 
 import torch
 
+from .models import _flat_view
+
 from . import _abi
 from ._abi import check
 
@@ -47,8 +49,9 @@ class Adam(torch.optim.Adam):
             step0 = 0
             for p, (off, n) in zip(flat.params, flat.offsets):
                 st = old.get(p) or {}
-                m = self._m[off:off + n].view(p.shape)
-                v = self._v[off:off + n].view(p.shape)
+                # same storage order as the parameter (tap-major conv weights stay strided views)
+                m = _flat_view(self._m, off, n, p)
+                v = _flat_view(self._v, off, n, p)
                 if "exp_avg" in st:
                     m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
                 step0 = max(step0, int(float(st.get("step", 0))))

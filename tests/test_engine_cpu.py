@@ -36,13 +36,17 @@ def assert_close_dict(a, b, rtol, atol):
         np.testing.assert_allclose(a[k].double().numpy(), b[k].double().numpy(), rtol=rtol, atol=atol, err_msg=k)
 
 
-@pytest.mark.parametrize("in_size,step,enc,n", [(16, 4, 24, 5), (32, 4, 16, 3)])
-def test_three_steps_match_autograd(in_size, step, enc, n):
+@pytest.mark.parametrize("in_size,step,enc,n,tap_major", [(16, 4, 24, 5, False), (32, 4, 16, 3, False),
+                                                          (32, 4, 16, 3, True)])
+def test_three_steps_match_autograd(in_size, step, enc, n, tap_major):
     torch.manual_seed(0)
     G, D = mk(in_size, step, enc)
     G2, D2 = copy.deepcopy(G), copy.deepcopy(D)
     for m in (G, D, G2, D2):
         m.train()
+    if tap_major:      # the product's storage order for the middle conv weights; parameters keep their shape
+        E.tap_major_(G2), E.tap_major_(D2)
+        assert any(E.is_tap_major(p.data) for p in D2.parameters())
     real = R.synthetic_images(n, in_size, seed=3).double()
     noise = R.synthetic_normal(n, enc, seed=4).double()
     ops = RefOps(torch.float64)

@@ -120,6 +120,7 @@ def test_three_steps_vs_autograd(in_size, step, enc, n, dtype, mode):
     else:
         pytest.skip("no seed with the required LeakyReLU margin")
     Gg, Dg = copy.deepcopy(G).cuda().train(), copy.deepcopy(D).cuda().train()
+    E.tap_major_(Gg), E.tap_major_(Dg)        # the HIP conv kernels take tap-major masters
     Gn, Dn = E.build_gen_net(Gg), E.build_disc_net(Dg)
     real_d, noise_d = real.cuda(), noise.cuda()
     ltol = 2e-4 if dtype == torch.float32 else 5e-2

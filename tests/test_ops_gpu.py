@@ -46,6 +46,13 @@ def cwpair(w, bias=None):
     return ConvW(w.clone(), bias), ConvW(w.cuda(), None if bias is None else bias.cuda())
 
 
+def cwpair_tm(w):
+    """Tap-major handles w[O][4][4][I] (what the HIP conv kernels take) for the twin and the product, each with dw."""
+    wt = w.permute(0, 2, 3, 1).contiguous()
+    return (ConvW(wt.clone(), None, torch.zeros_like(wt), None, "OHWI"),
+            ConvW(wt.cuda(), None, torch.full_like(wt, 7.0).cuda(), None, "OHWI"))
+
+
 def test_selftest_layouts():
     assert _hip(torch.bfloat16).selftest() == [0, 0]
 
@@ -67,7 +74,7 @@ CONV_CASES = [
 def test_conv_down_up_wgrad(N, Hi, Wi, I, O, dtype):
     ref, hip = RefOps(dtype), _hip(dtype)
     w = rnd((O, I, 4, 4), 1, (2.0 / (I * 16)) ** 0.5)
-    cr, ch = cwpair(w)
+    cr, ch = cwpair_tm(w)
     x = rnd((N, Hi, Wi, I), 2).to(dtype)
     y_ref = ref.conv_down(x, cr)
     y = hip.conv_down(dev(x), ch)
@@ -76,20 +83,20 @@ def test_conv_down_up_wgrad(N, Hi, Wi, I, O, dtype):
     u_ref = ref.conv_up(g, cr)
     u = hip.conv_up(dev(g), ch)
     check(u, u_ref, TOL[dtype], "conv_up")
-    dw_ref = torch.zeros(O, I, 4, 4)
-    ref.conv_wgrad(g, x, dw_ref, False)
-    dw = torch.full((O, I, 4, 4), 7.0).cuda()
-    hip.conv_wgrad(dev(g), dev(x), dw, False)
-    check(dw, dw_ref, TOL[dtype] * 2, "conv_wgrad")
-    hip.conv_wgrad(dev(g), dev(x), dw, True)
-    check(dw, 2 * dw_ref, TOL[dtype] * 2, "conv_wgrad(accumulate)")
+    ref.conv_wgrad(g, x, cr, False)
+    dw_ref = cr.dw.clone()
+    hip.conv_wgrad(dev(g), dev(x), ch, False)          # overwrites the 7.0 fill
+    check(ch.dw, dw_ref, TOL[dtype] * 2, "conv_wgrad")
+    hip.conv_wgrad(dev(g), dev(x), ch, True)
+    check(ch.dw, 2 * dw_ref, TOL[dtype] * 2, "conv_wgrad(accumulate)")
     # two-segment form: dw = wgrad(g, x) + wgrad(g2, x2)
     g2, x2 = rnd((N, Hi // 2, Wi // 2, O), 13).to(dtype), rnd((N, Hi, Wi, I), 12).to(dtype)
-    dw2_ref = torch.zeros(O, I, 4, 4)
-    ref.conv_wgrad(g, x, dw2_ref, False); ref.conv_wgrad(g2, x2, dw2_ref, True)
-    dw2 = torch.full((O, I, 4, 4), -5.0).cuda()
-    hip.conv_wgrad2(dev(g), dev(x), dev(g2), dev(x2), dw2, False)
-    check(dw2, dw2_ref, TOL[dtype] * 2, "conv_wgrad2")
+    ref.conv_wgrad(g, x, cr, False); ref.conv_wgrad(g2, x2, cr, True)
+    ch.dw.fill_(-5.0)
+    hip.conv_wgrad2(dev(g), dev(x), dev(g2), dev(x2), ch, False)
+    check(ch.dw, cr.dw, TOL[dtype] * 2, "conv_wgrad2")
+    hip.conv_wgrad2(dev(g), dev(x), dev(g2), dev(x2), ch, True)
+    check(ch.dw, 2 * cr.dw, TOL[dtype] * 2, "conv_wgrad2(accumulate)")
 
 
 @pytest.mark.parametrize("O,dtype,W", [(4, torch.float32, 32), (4, torch.bfloat16, 32), (64, torch.float32, 32),

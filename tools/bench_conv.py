@@ -25,13 +25,13 @@ tot = {"down": [0, 0], "up": [0, 0], "wgrad": [0, 0]}
 for l in range(5):
     I, O, hs = c, 2 * c, s            # D layer l+1: x[N,hs,hs,I] -> [N,hs/2,hs/2,O]
     w = torch.randn(O, I, 4, 4, device=dev) * (2.0 / (I * 16)) ** 0.5
-    cw = ConvW(w)
+    wt = w.permute(0, 2, 3, 1).contiguous()
+    cw = ConvW(wt, None, torch.zeros_like(wt), None, "OHWI")
     x = torch.randn(N, hs, hs, I, device=dev).to(torch.bfloat16)
     g = torch.randn(N, hs // 2, hs // 2, O, device=dev).to(torch.bfloat16)
-    dw = torch.zeros_like(w)
     flops = 2.0 * N * (hs // 2) ** 2 * O * I * 16
     for kind, fn in (("down", lambda: ops.conv_down(x, cw)), ("up", lambda: ops.conv_up(g, cw)),
-                     ("wgrad", lambda: ops.conv_wgrad(g, x, dw, False))):
+                     ("wgrad", lambda: ops.conv_wgrad(g, x, cw, False))):
         t = timeit(fn)
         tot[kind][0] += flops; tot[kind][1] += t
         print(f"I={I:5d} O={O:5d} hi={hs:4d}  {kind:6s} {t*1e6:8.1f} us  {flops/t/1e12:7.1f} TF/s")
