@@ -66,7 +66,7 @@ PROTOTYPES = {
     "rg_latent_prep": (_i, [_p, _p, _p, _i, _i, _p]),
     "rg_adam_step": (_i, [_p, _p, _p, _p, _z, _i, _d, _d, _d, _d, _p]),
     "rg_clamp": (_i, [_p, _z, _f, _f, _p]),
-    "rg_adam_step_dev": (_i, [_p, _p, _p, _p, _z, _p, _p]),
+    "rg_adam_step_dev": (_i, [_p, _p, _p, _p, _z, _p, _p, _p]),
     "rg_interp_dev": (_i, [_p, _p, _p, _z, _p, _p]),
     "rg_adam_hyper_dev": (_i, [_p, _d, _d, _d, _d, _p, _p]),
     "rg_widen_bf16": (_i, [_p, _p, _z, _p]),

@@ -90,11 +90,22 @@ struct Adam {
 
 struct AdamDev {
   float* p; const float* g; float* m; float* v; const float* hyper;
+  uint16_t* shadow;      // optional bf16 image of the updated parameters (the GEMM operand of the tap-major convs)
   __device__ __forceinline__ Adam load() const {
     return Adam{p, g, m, v, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6]};
   }
-  __device__ void vec(size_t i) const { load().vec(i); }
-  __device__ void one(size_t i) const { load().one(i); }
+  __device__ void vec(size_t i) const {
+    load().vec(i);
+    if (shadow) {
+      const float4 P = *(const float4*)(p + i);      // just written by this thread
+      *(uint2*)(shadow + i) = make_uint2((uint32_t)f32_to_bf16(P.x) | ((uint32_t)f32_to_bf16(P.y) << 16),
+                                         (uint32_t)f32_to_bf16(P.z) | ((uint32_t)f32_to_bf16(P.w) << 16));
+    }
+  }
+  __device__ void one(size_t i) const {
+    load().one(i);
+    if (shadow) shadow[i] = f32_to_bf16(p[i]);
+  }
 };
 
 __global__ void adam_hyper_kernel(int* step_dev, double lr, double b1, double b2, double eps, float* hyper) {
@@ -297,10 +308,11 @@ extern "C" int rg_adam_step(float* p, const float* g, float* m, float* v, size_t
 }
 
 extern "C" int rg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* hyper,
-                                void* stream) {
+                                void* shadow_bf16, void* stream) {
   RG_REQUIRE(p && g && m && v && hyper, RG_EINVAL, "adam_step_dev: bad args");
-  RG_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), RG_EINVAL, "adam_step_dev: alignment");
-  AdamDev f{p, g, m, v, hyper};
+  RG_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && ((uintptr_t)shadow_bf16 & 7) == 0,
+             RG_EINVAL, "adam_step_dev: alignment");
+  AdamDev f{p, g, m, v, hyper, (uint16_t*)shadow_bf16};
   EW_LAUNCH("adam_step_dev", f, n, rg_stream(stream));
 }
 extern "C" int rg_adam_hyper_dev(int* step_dev, double lr, double beta1, double beta2, double eps, float* hyper,

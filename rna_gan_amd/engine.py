@@ -43,7 +43,8 @@ class ConvW:
     ``version`` changes (after an optimizer step / state_dict load).
     """
 
-    __slots__ = ("w", "bias", "dw", "dbias", "packs", "packs_version", "version", "layout")
+    __slots__ = ("w", "bias", "dw", "dbias", "packs", "packs_version", "version", "layout", "shadow",
+                 "shadow_version")
 
     def __init__(self, w, bias=None, dw=None, dbias=None, layout="OIHW"):
         self.w = w
@@ -54,6 +55,8 @@ class ConvW:
         self.packs_version = -1
         self.version = 0
         self.layout = layout
+        self.shadow = None            # bf16 [O][16][I] image of a tap-major master maintained by the fused Adam
+        self.shadow_version = -1      # master version the shadow reflects
 
     @classmethod
     def from_param(cls, weight, grad=None):

@@ -15,6 +15,7 @@ import torch
 
 ENABLED = os.environ.get("RNAGAN_GRAPHS", "1") != "0"
 WARMUP_CALLS = 2
+_captured = []
 _POOL = None
 
 
@@ -66,6 +67,10 @@ class StepGraph:
                 with torch.cuda.graph(g, pool=_pool(), capture_error_mode="thread_local"):
                     self.static_out = self._run()
                 self.graph = g
+                if os.environ.get("RNAGAN_GRAPH_DEBUG"):
+                    print("rna_gan_amd: captured graph #%d for %s" % (len(_captured), getattr(self.fn, "__name__", "?")),
+                          flush=True)
+                _captured.append(self)
             except Exception as e:  # capture unsupported (e.g. a collective that cannot be captured)
                 self.failed = True
                 print("rna_gan_amd: HIP graph capture failed (%s); continuing without graphs" % str(e)[:200])
@@ -77,5 +82,5 @@ class StepGraph:
         for m in self.modules:
             m.mark_packs_fresh()
         for m in self.stepped:
-            m.weights_changed()
+            m.weights_changed(by_optimizer=True)      # the replayed fused Adam refreshed the bf16 shadows too
         return self.static_out

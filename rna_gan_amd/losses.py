@@ -104,7 +104,8 @@ def _reduce(module):
 
 def _apply(module, optimizer):
     optimizer.step()
-    module.weights_changed()
+    if not hasattr(optimizer, "note_replayed"):      # rna_gan_amd.optim.Adam reports the change itself
+        module.weights_changed()
     return module.flat.data[:1]          # a tensor result, so that this half can be a graph of its own
 
 
@@ -184,7 +185,7 @@ class _Runner:
             stepped = [o._module for o in optimizers if getattr(o, "_module", None) is not None]
         # the launch sequence depends on which packed weights are stale: one graph per pattern
         key = key + tuple(tuple(t.shape) for t in inputs) + tuple(id(m) for m in modules) + \
-            tuple(id(o) for o in optimizers) + tuple(bool(m.packs_stale()) for m in modules)
+            tuple(id(o) for o in optimizers) + tuple(int(m.packs_stale()) for m in modules)
         sg = self._graphs.get(key)
         if sg is None:
             hip_opts = [o for o in optimizers if hasattr(o, "note_replayed")]

@@ -47,6 +47,7 @@ class FlatParams:
         self.data = torch.zeros(self.numel + pad, dtype=dt, device=dev)
         self.grad = torch.zeros(self.numel + pad, dtype=dt, device=dev)
         self.esize = self.data.element_size()
+        self.shadow = None            # optional bf16 image of `data` kept current by the fused Adam (ensure_shadow)
         self.offsets = []
         off = 0
         for p in params:
@@ -60,6 +61,11 @@ class FlatParams:
             self.offsets.append((off, n))
             off += n
         self.params = params
+
+    def ensure_shadow(self):
+        if self.shadow is None:
+            self.shadow = torch.zeros(self.data.numel(), dtype=torch.bfloat16, device=self.data.device)
+        return self.shadow
 
     def owns(self, module: nn.Module) -> bool:
         """True if the module's parameters still live in this flat buffer.  Gradient views that were
@@ -115,29 +121,58 @@ class _HipModule(nn.Module):
             dt = torch.bfloat16 if self.precision == "bf16" else torch.float32
             self._rt_ops = HipOps(dt, p0.device)
             self._rt_net = self._build_net()
+            if self.precision == "bf16" and p0.dtype == torch.float32:
+                self._attach_shadows()
         return self._rt_ops, self._rt_net
+
+    def _attach_shadows(self):
+        """bf16 precision: the tap-major conv weights' GEMM operand (wdn) is a slice of the flat bf16 shadow that
+        the fused Adam writes together with the fp32 masters."""
+        flat = self._rt_flat
+        shadow = flat.ensure_shadow()
+        base = flat.data.data_ptr()
+        for cw in self._rt_net.convs():
+            if cw.layout != "OHWI":
+                continue
+            off = (cw.w.data_ptr() - base) // flat.esize
+            n = cw.w.numel()
+            cw.shadow = shadow[off:off + n].view(cw.O, 16, cw.I)
+            cw.shadow_version = -1
 
     @property
     def flat(self) -> "FlatParams":
         self.runtime()
         return self._rt_flat
 
-    def weights_changed(self):
-        """Call after the parameters were modified in place (optimizer step, clamp, load)."""
+    def weights_changed(self, by_optimizer=False):
+        """Call after the parameters were modified in place (optimizer step, clamp, load).  by_optimizer: the
+        fused Adam did it, which also refreshed the bf16 shadow in the same launch."""
         if self._rt_net is not None:
             self._rt_net.bump()
+            if by_optimizer and self._rt_flat is not None and self._rt_flat.shadow is not None:
+                for cw in self._rt_net.convs():
+                    if cw.shadow is not None:
+                        cw.shadow_version = cw.version
 
-    def packs_stale(self) -> bool:
-        """True if any packed (bf16 GEMM-operand) weight image is older than its master."""
+    def packs_stale(self) -> int:
+        """0: every packed (bf16 GEMM-operand) weight image is current; 1: some are older than their master but
+        the bf16 shadows are current (only the transposed images need rebuilding); 2: shadows are stale too.
+        The launch sequence of a step depends on this, so it is part of the graph cache key."""
         if self._rt_net is None:
-            return True
-        return any(cw.packs_version != cw.version for cw in self._rt_net.convs())
+            return 2
+        st = 0
+        for cw in self._rt_net.convs():
+            if cw.packs_version != cw.version:
+                st = max(st, 2 if (cw.shadow is not None and cw.shadow_version != cw.version) else 1)
+        return st
 
     def mark_packs_fresh(self):
         """A captured graph that rebuilt the packs was replayed: bring the Python-side counters in line."""
         if self._rt_net is not None:
             for cw in self._rt_net.convs():
                 cw.packs_version = cw.version
+                if cw.shadow is not None:
+                    cw.shadow_version = cw.version
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)

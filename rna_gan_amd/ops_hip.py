@@ -106,11 +106,16 @@ class HipOps:
         if cw.packs is None or cw.packs_version != cw.version:
             O, I = cw.O, cw.I
             if cw.packs is None:
-                cw.packs = (torch.empty((O, 16, I), dtype=torch.bfloat16, device=self.device),
-                            torch.empty((16, I, O), dtype=torch.bfloat16, device=self.device))
-            check(self.lib.rg_pack_conv_weight(_ptr(cw.w), _ptr(cw.packs[0]), _ptr(cw.packs[1]), O, I, RG_BF16,
-                                               self.stream), "rg_pack_conv_weight")
+                wdn = cw.shadow if cw.shadow is not None else torch.empty((O, 16, I), dtype=torch.bfloat16,
+                                                                         device=self.device)
+                cw.packs = (wdn, torch.empty((16, I, O), dtype=torch.bfloat16, device=self.device))
+            # wdn is a cast of the tap-major master: skipped when the fused Adam already wrote it (shadow)
+            need_wdn = cw.shadow is None or cw.shadow_version != cw.version
+            check(self.lib.rg_pack_conv_weight(_ptr(cw.w), _ptr(cw.packs[0]) if need_wdn else 0, _ptr(cw.packs[1]),
+                                               O, I, RG_BF16, self.stream), "rg_pack_conv_weight")
             cw.packs_version = cw.version
+            if cw.shadow is not None:
+                cw.shadow_version = cw.version
         return cw.packs
 
     # ------------------------------------------------------------------ conv family

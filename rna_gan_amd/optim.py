@@ -92,9 +92,11 @@ class Adam(torch.optim.Adam):
         check(lib.rg_adam_hyper_dev(self._step_dev.data_ptr(), float(g["lr"]), float(g["betas"][0]),
                                     float(g["betas"][1]), float(g["eps"]), self._hyper.data_ptr(), stream),
               "rg_adam_hyper_dev")
+        shadow = flat.shadow           # bf16 image of the parameters (bf16 precision only), written by the same launch
         check(lib.rg_adam_step_dev(flat.data.data_ptr(), flat.grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
-                                   flat.data.numel(), self._hyper.data_ptr(), stream), "rg_adam_step_dev")
+                                   flat.data.numel(), self._hyper.data_ptr(),
+                                   0 if shadow is None else shadow.data_ptr(), stream), "rg_adam_step_dev")
         if not torch.cuda.is_current_stream_capturing():
             self._host_steps += 1
-        self._module.weights_changed()
+        self._module.weights_changed(by_optimizer=True)
         return None
