@@ -175,11 +175,12 @@ def main():
     # HIP-graph capture phase (part of building the step, like a compiler's first run): the loss plugins run a
     # train_op eagerly twice per launch-sequence variant and capture it on the third call; the very first
     # iteration uses a different variant (all bf16 weight images stale), so the replayed graphs are in place
-    # after ~6 iterations (5 graphs: the G step is captured for two staleness variants).  The first ~8 replays run
-    # 10-20 % slower than the steady state (measured with --trace-steps), so 16 priming iterations (~0.3 s) are
-    # run before the W warm-up steps.
+    # after ~6 iterations (5 graphs: the G step is captured for two staleness variants).  Once back-to-back
+    # replay starts, the chip needs another ~10-20 iterations to settle (steps run 15-25 % slower during that
+    # transient, see --trace-steps; it moves with the start of continuous load, not with the iteration count), so
+    # 40 priming iterations (~0.7 s) are run before the W warm-up steps.
     from rna_gan_amd import graphed as _gr
-    prime = (_gr.WARMUP_CALLS + 14) if _gr.ENABLED else 1
+    prime = 40 if _gr.ENABLED else 1
     log("models built; %d priming iterations (graph capture)" % prime)
     for it in range(prime):
         one_step()

@@ -81,9 +81,12 @@ size_t rg_conv_workspace_bytes(int up, int N, int Hlow, int Wlow, int O, int I, 
 
 /* y[N][2Ho][2Wo][I] = conv_transpose2d(x[N][Ho][Wo][O], w[O][4][4][I], stride 2, pad 1).
  * nn.ConvTranspose2d forward in the generator (G(.) at src/wgan_loss.py:113,247,371) and the
- * data-gradient of nn.Conv2d in the discriminator (.backward() :126,260,387; autograd.grad :34-41). */
+ * data-gradient of nn.Conv2d in the discriminator (.backward() :126,260,387; autograd.grad :34-41).
+ * mask_act (may be NULL): an activation tensor with y's shape and dtype; then y *= (mask_act > 0 ? 1 : mask_slope),
+ * i.e. the LeakyReLU backward of the layer below is applied in the epilogue (the data-gradient of discriminator
+ * layer 1 feeding layer 0's LeakyReLU) instead of in a separate pass over y. */
 int rg_conv_up(const void* x, const float* w, const void* wup, void* y, int N, int Ho, int Wo, int O, int I,
-               int dtype, int algo, void* ws, size_t ws_bytes, void* stream);
+               const void* mask_act, float mask_slope, int dtype, int algo, void* ws, size_t ws_bytes, void* stream);
 
 /* dw[O][kh][kw][I] (+)= sum_{n,ho,wo} low[n][ho][wo][o] * high[n][2ho-1+kh][2wo-1+kw][i].
  * Weight gradient of both layer kinds (every .backward()).  Deterministic: split-K partial slabs

@@ -70,8 +70,10 @@ class RefOps:
         y = F.conv2d(self._nchw(x), self._wq(cw.oihw()), None, stride=2, padding=1)
         return _nhwc(y, self.act_dtype)
 
-    def conv_up(self, x, cw: ConvW):
+    def conv_up(self, x, cw: ConvW, mask_act=None, slope=1.0):
         y = F.conv_transpose2d(self._nchw(x), self._wq(cw.oihw()), None, stride=2, padding=1)
+        if mask_act is not None:       # fused LeakyReLU backward: applied to the fp32 result, rounded once
+            y = y * _lrelu_mask(self._nchw(mask_act), slope)
         return _nhwc(y, self.act_dtype)
 
     def conv_wgrad(self, low, high, cw: ConvW, accumulate: bool):

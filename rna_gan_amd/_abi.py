@@ -25,7 +25,7 @@ PROTOTYPES = {
     "rg_last_error": (C.c_char_p, []),
     "rg_pack_conv_weight": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "rg_conv_down": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
-    "rg_conv_up": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "rg_conv_up": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _f, _i, _i, _p, _z, _p]),
     "rg_conv_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "rg_conv_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),
     "rg_conv_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),

@@ -44,13 +44,14 @@ extern "C" int rg_conv_down(const void* x, const float* w, const void* wdn, void
 }
 
 extern "C" int rg_conv_up(const void* x, const float* w, const void* wup, void* y, int N, int Ho, int Wo, int O, int I,
-                          int dtype, int algo, void* ws, size_t ws_bytes, void* stream) {
+                          const void* mask_act, float mask_slope, int dtype, int algo, void* ws, size_t ws_bytes,
+                          void* stream) {
   RG_REQUIRE(x && y && N > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0, RG_EINVAL, "conv_up: bad args");
   if (want_mfma(algo, dtype) && wup && rg_mfma_conv_supported(N, Ho, Wo, /*Kc=*/O, /*Ncols=*/I))
-    return rg_mfma_conv_up(x, wup, y, N, Ho, Wo, O, I, ws, ws_bytes, rg_stream(stream));
+    return rg_mfma_conv_up(x, wup, y, N, Ho, Wo, O, I, mask_act, mask_slope, ws, ws_bytes, rg_stream(stream));
   RG_REQUIRE(algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "conv_up: shape/dtype not supported by the MFMA kernel");
   RG_REQUIRE(w, RG_EINVAL, "conv_up: generic kernel needs the fp32 master weight");
-  return rg_generic_conv_up(x, w, y, N, Ho, Wo, O, I, dtype, rg_stream(stream));
+  return rg_generic_conv_up(x, w, y, N, Ho, Wo, O, I, mask_act, mask_slope, dtype, rg_stream(stream));
 }
 
 extern "C" size_t rg_conv_wgrad_workspace_bytes(int N, int Ho, int Wo, int O, int I, int dtype, int algo) {
@@ -131,9 +132,9 @@ extern "C" int rg_pack_g0_weight(const float* w, void* wp, int E, int C, int dty
 
 extern "C" size_t rg_g0_workspace_bytes(int N, int E, int C, int dtype, int algo) {
   if (!want_mfma(algo, dtype)) return 0;
-  size_t a = (size_t)N * E * 2;                       // bf16 copy of z
-  size_t b = (size_t)E * 16 * C * sizeof(float);      // wgrad slab
-  return rg_align_up(a, 256) + b;
+  size_t a = (size_t)N * E * 2;                       // forward: bf16 copy of z
+  size_t b = rg_mfma_g0_wgrad_ws_bytes(N, E, C);      // wgrad: k-contiguous bf16 images of z and gy
+  return a > b ? a : b;
 }
 
 extern "C" int rg_g0_fwd(const float* z, const float* w, const void* wp, void* y, int N, int E, int C, int dtype,
@@ -153,8 +154,10 @@ extern "C" int rg_g0_fwd(const float* z, const float* w, const void* wp, void* y
 extern "C" int rg_g0_wgrad(const float* z, const void* gy, float* dw, int N, int E, int C, int dtype, int accumulate,
                            int algo, void* ws, size_t ws_bytes, void* stream) {
   RG_REQUIRE(z && gy && dw && N > 0 && E > 0 && C > 0, RG_EINVAL, "g0_wgrad: bad args");
-  (void)ws; (void)ws_bytes; (void)algo;
-  // weight-streaming bound (|dw| = 16*E*C fp32 written once); the generic kernel is used for now
+  // output-streaming bound (|dw| = 16*E*C fp32 written once)
+  if (want_mfma(algo, dtype) && !accumulate && rg_mfma_g0_wgrad_supported(N, E, C) && ws &&
+      ws_bytes >= rg_mfma_g0_wgrad_ws_bytes(N, E, C))
+    return rg_mfma_g0_wgrad(z, gy, dw, N, E, C, ws, ws_bytes, rg_stream(stream));
   return rg_generic_g0_wgrad(z, gy, dw, N, E, C, dtype, accumulate, rg_stream(stream));
 }
 

@@ -264,11 +264,13 @@ struct UpBOihw {
   }
 };
 template <typename T> struct UpC {
-  T* y; Geo g;
+  T* y; Geo g; const T* mask; float mslope;       // optional fused LeakyReLU backward: v *= lrelu'(mask)
   __device__ void operator()(int zb, int, int m, int i, float v) const {
     int wq = m % g.Wl, t = m / g.Wl, hq = t % g.Hl, n = t / g.Hl;
     int hi = 2 * hq + (zb >> 1), wi = 2 * wq + (zb & 1);
-    Elem<T>::st(y + (((size_t)n * g.Hh + hi) * g.Wh + wi) * g.I + i, v);
+    size_t idx = (((size_t)n * g.Hh + hi) * g.Wh + wi) * g.I + i;
+    if (mask) v *= lrelu_mask(Elem<T>::ld(mask + idx), mslope);
+    Elem<T>::st(y + idx, v);
   }
 };
 // image-side variant: NCHW fp32 output with bias + optional tanh
@@ -408,11 +410,12 @@ int rg_generic_conv_down(const void* x, const float* w, void* y, int N, int Hi, 
   })
 }
 
-int rg_generic_conv_up(const void* x, const float* w, void* y, int N, int Ho, int Wo, int O, int I, int dtype,
-                       hipStream_t st) {
+int rg_generic_conv_up(const void* x, const float* w, void* y, int N, int Ho, int Wo, int O, int I, const void* mask,
+                       float mslope, int dtype, hipStream_t st) {
   Geo g{N, Ho, Wo, 2 * Ho, 2 * Wo, O, I};
   RG_DISPATCH_DTYPE(dtype, T, {
-    return launch_generic<true, false>("conv_up(generic)", UpA<T>{(const T*)x, g}, UpB<T>{w, g}, UpC<T>{(T*)y, g},
+    return launch_generic<true, false>("conv_up(generic)", UpA<T>{(const T*)x, g}, UpB<T>{w, g},
+                                       UpC<T>{(T*)y, g, (const T*)mask, mslope},
                                        N * Ho * Wo, I, O * 4, 4, 1, st);
   })
 }

@@ -7,8 +7,8 @@ int rg_reduce_slabs(const float* slab, float* dst, size_t n, int nsplit, int acc
                     hipStream_t st);
 int rg_generic_conv_down(const void* x, const float* w, void* y, int N, int Hi, int Wi, int I, int O, int dtype,
                          hipStream_t st);
-int rg_generic_conv_up(const void* x, const float* w, void* y, int N, int Ho, int Wo, int O, int I, int dtype,
-                       hipStream_t st);
+int rg_generic_conv_up(const void* x, const float* w, void* y, int N, int Ho, int Wo, int O, int I, const void* mask,
+                       float mslope, int dtype, hipStream_t st);
 int rg_generic_first_down(const float* x, const float* w, const float* bias, void* y, int N, int H, int W, int I,
                           int O, float slope, int dtype, hipStream_t st);
 int rg_generic_last_up(const void* x, const float* w, const float* bias, float* y, int N, int Ho, int Wo, int O,
@@ -34,9 +34,13 @@ int rg_mfma_pack_g0_weight(const float* w, void* wp, int E, int C, hipStream_t s
 int rg_mfma_pack_linear_weight(const float* w, void* wp, int Nout, int K, int Nout_pad, int K_pad, hipStream_t st);
 int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, int Wi, int I, int O, void* ws,
                       size_t ws_bytes, hipStream_t st);
-int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, void* ws,
-                    size_t ws_bytes, hipStream_t st);
+int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, const void* mask,
+                    float mslope, void* ws, size_t ws_bytes, hipStream_t st);
 size_t rg_mfma_conv_ws_bytes(int up, int N, int Hlow, int Wlow, int O, int I);
+size_t rg_mfma_g0_wgrad_ws_bytes(int N, int E, int C);
+bool rg_mfma_g0_wgrad_supported(int N, int E, int C);
+int rg_mfma_g0_wgrad(const float* z, const void* gy, float* dw, int N, int E, int C, void* ws, size_t ws_bytes,
+                     hipStream_t st);
 int rg_mfma_gemm_plain(const void* a, const void* bt, void* c, int M, int K, int Ncols, int ldc, hipStream_t st);
 int rg_mfma_linear(const void* a, const void* bt, const float* scale, const float* shift, float* y, int ldy, int M,
                    int Kpad, int Nout, float slope, void* ws, size_t ws_bytes, hipStream_t st);

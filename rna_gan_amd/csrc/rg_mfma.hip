@@ -41,7 +41,14 @@ struct GArgs {
   const float* scale;
   const float* shift;
   float slope;
+  const uint16_t* mask;   // EPI_BF16, optional: activation with the output's shape; out *= (mask > 0 ? 1 : mslope)
+  float mslope;           // (LeakyReLU backward of the consumer fused into the data-gradient conv)
 };
+
+// 8 bf16 outputs (packed in o) times the LeakyReLU derivative at 8 bf16 activations (packed in a)
+__device__ __forceinline__ float rg_lmask(uint32_t abits, float slope) {
+  return (abits & 0x8000u) || !(abits & 0x7fffu) ? slope : 1.f;      // a <= 0 (incl. -0): slope
+}
 
 __device__ __forceinline__ uint4 ld16_if(const uint16_t* p, bool pred) {
   uint4 v = make_uint4(0, 0, 0, 0);
@@ -243,6 +250,13 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(GArgs g) {
       orow = m;
     }
     if (EPI == EPI_BF16) {
+      if (g.mask) {
+        const uint4 a = *reinterpret_cast<const uint4*>(g.mask + orow * g.ldc + col);
+        v0.x *= rg_lmask(a.x, g.mslope); v0.y *= rg_lmask(a.x >> 16, g.mslope);
+        v0.z *= rg_lmask(a.y, g.mslope); v0.w *= rg_lmask(a.y >> 16, g.mslope);
+        v1.x *= rg_lmask(a.z, g.mslope); v1.y *= rg_lmask(a.z >> 16, g.mslope);
+        v1.z *= rg_lmask(a.w, g.mslope); v1.w *= rg_lmask(a.w >> 16, g.mslope);
+      }
       uint4 o;
       o.x = (uint32_t)f32_to_bf16(v0.x) | ((uint32_t)f32_to_bf16(v0.y) << 16);
       o.y = (uint32_t)f32_to_bf16(v0.z) | ((uint32_t)f32_to_bf16(v0.w) << 16);
@@ -549,6 +563,13 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
         *reinterpret_cast<float4*>(so) = v0;
         *reinterpret_cast<float4*>(so + 4) = v1;
       } else if (EPI == EPI_BF16) {
+        if (g.mask) {
+          const uint4 a = *reinterpret_cast<const uint4*>(g.mask + orow * g.ldc + col);
+          v0.x *= rg_lmask(a.x, g.mslope); v0.y *= rg_lmask(a.x >> 16, g.mslope);
+          v0.z *= rg_lmask(a.y, g.mslope); v0.w *= rg_lmask(a.y >> 16, g.mslope);
+          v1.x *= rg_lmask(a.z, g.mslope); v1.y *= rg_lmask(a.z >> 16, g.mslope);
+          v1.z *= rg_lmask(a.w, g.mslope); v1.w *= rg_lmask(a.w >> 16, g.mslope);
+        }
         uint4 o;
         o.x = (uint32_t)f32_to_bf16(v0.x) | ((uint32_t)f32_to_bf16(v0.y) << 16);
         o.y = (uint32_t)f32_to_bf16(v0.z) | ((uint32_t)f32_to_bf16(v0.w) << 16);
@@ -563,7 +584,14 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
           float v = vals[e];
           if (g.scale) v *= g.scale[col + e];
           if (g.shift) v += g.shift[col + e];
-          yo[e] = lrelu_f(v, g.slope);
+          vals[e] = lrelu_f(v, g.slope);
+        }
+        if ((g.ldc & 3) == 0) {          // rows 16-byte aligned: two 16-byte stores
+          *reinterpret_cast<float4*>(yo) = make_float4(vals[0], vals[1], vals[2], vals[3]);
+          *reinterpret_cast<float4*>(yo + 4) = make_float4(vals[4], vals[5], vals[6], vals[7]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) yo[e] = vals[e];
         }
       }
     }
@@ -915,23 +943,26 @@ __global__ void cast_bf16_kernel(const float* __restrict__ w, uint16_t* __restri
     Vec<bf16_t, 8>::st(reinterpret_cast<bf16_t*>(out) + d * 8, v);
   }
 }
-// generic tiled transpose-pack: src[R][Cc] fp32 -> dst[perm(col)][R] bf16, perm(col) = tap*(Cc/16) + c
-// when permute != 0 (col = c*16 + tap), identity otherwise.
-__global__ __launch_bounds__(256) void transpose_pack_kernel(const float* src, uint16_t* dst, int R, int Cc,
-                                                             int permute) {
+// generic tiled transpose-pack: src[R][Cc] (fp32 or bf16) -> dst[perm(col)][R] bf16.  permute 0: identity;
+// 1: col = c*16 + tap -> tap*(Cc/16) + c;  2: the inverse, col = tap*(Cc/16) + c -> c*16 + tap.
+__device__ __forceinline__ float tp_load(const float* p) { return *p; }
+__device__ __forceinline__ float tp_load(const uint16_t* p) { return bf16_to_f32(*p); }
+template <typename S>
+__global__ __launch_bounds__(256) void transpose_pack_kernel(const S* src, uint16_t* dst, int R, int Cc, int permute) {
   __shared__ float tile[64][65];
   int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int rr = ty; rr < 64; rr += 4) {
     int r = r0 + rr, c = c0 + tx;
-    tile[rr][tx] = (r < R && c < Cc) ? src[(size_t)r * Cc + c] : 0.f;
+    tile[rr][tx] = (r < R && c < Cc) ? tp_load(src + (size_t)r * Cc + c) : 0.f;
   }
   __syncthreads();
   for (int cc = ty; cc < 64; cc += 4) {
     int c = c0 + cc, r = r0 + tx;
     if (c < Cc && r < R) {
       int pc = c;
-      if (permute) { int tap = c & 15, ch = c >> 4; pc = tap * (Cc >> 4) + ch; }
+      if (permute == 1) { int tap = c & 15, ch = c >> 4; pc = tap * (Cc >> 4) + ch; }
+      else if (permute == 2) { int q = Cc >> 4, tap = c / q, ch = c - tap * q; pc = ch * 16 + tap; }
       dst[(size_t)pc * R + r] = f32_to_bf16(tile[tx][cc]);
     }
   }
@@ -1060,7 +1091,9 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   const bool wide = !narrow && EPI == EPI_BF16 && g.M >= 256 && g.Ncols >= 256 && g.Ncols % 256 == 0 &&
                     (variant == 5 || (variant == 1 && tiles256 >= 256 && tiles256 % 256 == 0));
   int nsplit;
-  if (wide) {
+  if (g.mask) {
+    nsplit = 1;       // the fused mask lives in the bf16 epilogue, not in the slab reduction
+  } else if (wide) {
     nsplit = 1;
     while (tiles256 * nsplit < 256 && nsplit < 8 && nkt / (nsplit * 2) >= 8) nsplit *= 2;   // one block per CU
   } else {
@@ -1111,9 +1144,10 @@ int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, in
                                              (size_t)O * 16 * I * 2, ws, ws_bytes, st);
 }
 
-int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, void* ws,
-                    size_t ws_bytes, hipStream_t st) {
+int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, const void* mask,
+                    float mslope, void* ws, size_t ws_bytes, hipStream_t st) {
   GArgs g{};
+  g.mask = (const uint16_t*)mask; g.mslope = mslope;
   g.A = (const uint16_t*)x; g.B = (const uint16_t*)wup; g.C = y;
   g.M = N * Ho * Wo; g.Ncols = I; g.Cin = O; g.taps = 4;
   g.lgW = rg_ilog2(Wo); g.lgH = rg_ilog2(Ho); g.Hs = Ho; g.Ws = Wo; g.ldc = I; g.b_col = O; g.b_tap = I * O;        // wup[16][I][O]
@@ -1243,7 +1277,7 @@ int rg_mfma_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I,
   }
   if (wup) {
     // w viewed as [O][16*I] (col = tap*I + i) -> wup[tap][i][O]: a plain transpose
-    hipLaunchKernelGGL(transpose_pack_kernel, dim3((I * 16 + 63) / 64, (O + 63) / 64), dim3(256), 0, st, w,
+    hipLaunchKernelGGL(transpose_pack_kernel<float>, dim3((I * 16 + 63) / 64, (O + 63) / 64), dim3(256), 0, st, w,
                        (uint16_t*)wup, O, I * 16, 0);
     RG_LAUNCH_CHECK("pack_wup");
   }
@@ -1251,11 +1285,30 @@ int rg_mfma_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I,
 }
 int rg_mfma_pack_g0_weight(const float* w, void* wp, int E, int C, hipStream_t st) {
   // w viewed as [E][C*16] (col = c*16+tap) -> wp[(tap*C + c)][E]
-  hipLaunchKernelGGL(transpose_pack_kernel, dim3((C * 16 + 63) / 64, (E + 63) / 64), dim3(256), 0, st, w,
+  hipLaunchKernelGGL(transpose_pack_kernel<float>, dim3((C * 16 + 63) / 64, (E + 63) / 64), dim3(256), 0, st, w,
                      (uint16_t*)wp, E, C * 16, 1);
   RG_LAUNCH_CHECK("pack_g0");
   return RG_OK;
 }
+// G.0 weight gradient dw[e][c][tap] = sum_n z[n][e] * gy[n][tap][c]: a [E x N] x [N x 16C] GEMM whose 16*E*C fp32
+// output (268 MB at E = C = 2048) is all that matters -- K is the batch.  Both operands are tiny: they are
+// transposed into k-contiguous bf16 images (gy's columns permuted to the master's (c, tap) order on the way),
+// then the plain gather-GEMM streams the result out with 16-byte stores.
+size_t rg_mfma_g0_wgrad_ws_bytes(int N, int E, int C) { return ((size_t)E + (size_t)16 * C) * N * 2 + 512; }
+bool rg_mfma_g0_wgrad_supported(int N, int E, int C) { return N % 64 == 0 && E % 8 == 0 && C % 8 == 0; }
+int rg_mfma_g0_wgrad(const float* z, const void* gy, float* dw, int N, int E, int C, void* ws, size_t ws_bytes,
+                     hipStream_t st) {
+  RG_REQUIRE(ws && ws_bytes >= rg_mfma_g0_wgrad_ws_bytes(N, E, C), RG_EWORKSPACE, "g0_wgrad(mfma): workspace too small");
+  uint16_t* zT = (uint16_t*)ws;
+  uint16_t* gyP = zT + rg_align_up((size_t)E * N, 128);
+  hipLaunchKernelGGL(transpose_pack_kernel<float>, dim3((E + 63) / 64, (N + 63) / 64), dim3(256), 0, st, z, zT, N, E, 0);
+  RG_LAUNCH_CHECK("g0_wgrad(pack z)");
+  hipLaunchKernelGGL(transpose_pack_kernel<uint16_t>, dim3((16 * C + 63) / 64, (N + 63) / 64), dim3(256), 0, st,
+                     (const uint16_t*)gy, gyP, N, 16 * C, 2);
+  RG_LAUNCH_CHECK("g0_wgrad(pack gy)");
+  return rg_mfma_linear(zT, gyP, nullptr, nullptr, dw, 16 * C, E, N, 16 * C, 1.0f, nullptr, 0, st);
+}
+
 int rg_mfma_pack_linear_weight(const float* w, void* wp, int Nout, int K, int Np, int Kp, hipStream_t st) {
   hipLaunchKernelGGL(pack_linear_kernel, dim3(grid_cap((size_t)Np * Kp)), dim3(256), 0, st, w, (uint16_t*)wp, Nout, K,
                      Np, Kp);

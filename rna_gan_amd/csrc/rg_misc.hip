@@ -186,7 +186,43 @@ __global__ __launch_bounds__(256) void mean_diff_kernel(const float* a, const fl
 }
 
 // latent prep: per column e: v = u+z ; mean, unbiased std over the N rows ; out = (v-mean)/std
-__global__ void latent_prep_kernel(const float* u, const float* z, float* out, int N, int E) {
+// block = 64 columns x 4 row groups; a thread keeps its <= 16 rows in registers (one pass over memory), the
+// row groups are combined through LDS.  N > 64 takes the plain three-pass kernel.
+__global__ __launch_bounds__(256) void latent_prep_kernel(const float* __restrict__ u, const float* __restrict__ z,
+                                                          float* __restrict__ out, int N, int E) {
+  __shared__ float sm[4][64];
+  const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + col;
+  const bool ok = e < E;
+  float v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int n = rg + 4 * k;
+    v[k] = 0.f;
+    if (ok && n < N) v[k] = u[(size_t)n * E + e] + z[(size_t)n * E + e];
+    s += v[k];
+  }
+  sm[rg][col] = s;
+  __syncthreads();
+  const float mu = (sm[0][col] + sm[1][col] + sm[2][col] + sm[3][col]) / (float)N;
+  __syncthreads();
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const float d = v[k] - mu;
+    if (rg + 4 * k < N) ss += d * d;
+  }
+  sm[rg][col] = ss;
+  __syncthreads();
+  const float sd = sqrtf((sm[0][col] + sm[1][col] + sm[2][col] + sm[3][col]) / (float)(N - 1));   // N == 1 -> NaN, as torch.std
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int n = rg + 4 * k;
+    if (ok && n < N) out[(size_t)n * E + e] = (v[k] - mu) / sd;
+  }
+}
+__global__ void latent_prep_big_kernel(const float* u, const float* z, float* out, int N, int E) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   float s = 0.f;
@@ -197,7 +233,7 @@ __global__ void latent_prep_kernel(const float* u, const float* z, float* out, i
     float d = u[(size_t)n * E + e] + z[(size_t)n * E + e] - mu;
     ss += d * d;
   }
-  float sd = sqrtf(ss / (float)(N - 1));   // N == 1 -> NaN, as torch.std does
+  float sd = sqrtf(ss / (float)(N - 1));
   for (int n = 0; n < N; ++n) out[(size_t)n * E + e] = (u[(size_t)n * E + e] + z[(size_t)n * E + e] - mu) / sd;
 }
 
@@ -206,13 +242,18 @@ __global__ void latent_prep_kernel(const float* u, const float* z, float* out, i
 template <typename T>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* a, const float* w, float* h, float* out, int C,
                                                        float slope) {
+  // thread = channel: its 16 taps are one contiguous 64-byte weight row, and for a fixed tap the block reads
+  // consecutive channels of the activation
   __shared__ float sm[4];
-  int n = blockIdx.x;
-  int J = 16 * C;
+  const int n = blockIdx.x;
+  const T* an = a + (size_t)n * 16 * C;
   float s = 0.f;
-  for (int j = threadIdx.x; j < J; j += 256) {
-    int tap = j / C, c = j - tap * C;
-    s += Elem<T>::ld(a + (size_t)n * J + j) * Elem<T>::round(w[c * 16 + tap]);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float wv[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Vec<float, 4>::ld(w + (size_t)c * 16 + 4 * q, wv + 4 * q);
+#pragma unroll
+    for (int tap = 0; tap < 16; ++tap) s += Elem<T>::ld(an + (size_t)tap * C + c) * Elem<T>::round(wv[tap]);
   }
   float t = block_sum_256(s, sm);
   if (threadIdx.x == 0) { h[n] = t; out[n] = lrelu_f(t, slope); }
@@ -374,7 +415,10 @@ extern "C" int rg_mean_diff(const float* a, const float* b, float* out, int n, f
 }
 extern "C" int rg_latent_prep(const float* u, const float* z, float* out, int N, int E, void* stream) {
   RG_REQUIRE(u && z && out && N > 0 && E > 0, RG_EINVAL, "latent_prep: bad args");
-  hipLaunchKernelGGL(latent_prep_kernel, dim3((E + 63) / 64), dim3(64), 0, rg_stream(stream), u, z, out, N, E);
+  if (N <= 64)
+    hipLaunchKernelGGL(latent_prep_kernel, dim3((E + 63) / 64), dim3(256), 0, rg_stream(stream), u, z, out, N, E);
+  else
+    hipLaunchKernelGGL(latent_prep_big_kernel, dim3((E + 63) / 64), dim3(64), 0, rg_stream(stream), u, z, out, N, E);
   RG_LAUNCH_CHECK("latent_prep");
   return RG_OK;
 }

@@ -193,8 +193,9 @@ def disc_backward(ops, D: DiscNet, ctx, coef: float, wgrad: bool, accumulate: bo
         if wgrad:
             with ops.side(gz):
                 ops.conv_wgrad(gz, ctx.a[l - 1], cw, accumulate)
-        ga = ops.conv_up(gz, cw)
-    gz0 = ops.lrelu_bwd(ga, ctx.a[0], D.slope)
+        # the data gradient of layer 1 feeds layer 0's LeakyReLU: its backward is fused into the epilogue
+        ga = ops.conv_up(gz, cw) if l > 1 else ops.conv_up(gz, cw, ctx.a[0], D.slope)
+    gz0 = ga if R > 0 else ops.lrelu_bwd(ga, ctx.a[0], D.slope)
     if keep_for_gp:
         ctx.gz1[0] = gz0
     if wgrad:
@@ -227,10 +228,14 @@ def disc_backward_pair(ops, D: DiscNet, ctx_a, coef_a: float, ctx_b, coef_b: flo
                                     bn.dgamma, bn.dbeta, True)
         with ops.side(gz_a, gz_b):
             ops.conv_wgrad2(gz_a, ctx_a.a[l - 1], gz_b, ctx_b.a[l - 1], cw, False)
-        ga_a = ops.conv_up(gz_a, cw)
-        ga_b = ops.conv_up(gz_b, cw)
-    gz0_a = ops.lrelu_bwd(ga_a, ctx_a.a[0], D.slope)
-    gz0_b = ops.lrelu_bwd(ga_b, ctx_b.a[0], D.slope)
+        if l > 1:
+            ga_a, ga_b = ops.conv_up(gz_a, cw), ops.conv_up(gz_b, cw)
+        else:
+            ga_a = ops.conv_up(gz_a, cw, ctx_a.a[0], D.slope)
+            ga_b = ops.conv_up(gz_b, cw, ctx_b.a[0], D.slope)
+    if R == 0:
+        ga_a, ga_b = ops.lrelu_bwd(ga_a, ctx_a.a[0], D.slope), ops.lrelu_bwd(ga_b, ctx_b.a[0], D.slope)
+    gz0_a, gz0_b = ga_a, ga_b
     with ops.side(gz0_a, gz0_b):
         ops.skinny_wgrad(gz0_a, ctx_a.x, D.conv0.dw, False)
         ops.skinny_wgrad(gz0_b, ctx_b.x, D.conv0.dw, True)
@@ -272,8 +277,8 @@ def disc_gradient_penalty(ops, D: DiscNet, xhat, lambd: float, update_running=Tr
         # dW = wgrad(pz, a_prev) + wgrad(gz1, at_prev): one launch, one split-K reduction
         with ops.side(pz):
             ops.conv_wgrad2(pz, ctx.a[l - 1], ctx.gz1[l], ats[l - 1], cw, False)
-        qa = ops.conv_up(pz, cw)
-    p0 = ops.lrelu_bwd(qa, ctx.a[0], D.slope)
+        qa = ops.conv_up(pz, cw) if l > 1 else ops.conv_up(pz, cw, ctx.a[0], D.slope)
+    p0 = qa if R > 0 else ops.lrelu_bwd(qa, ctx.a[0], D.slope)
     with ops.side(p0, v):
         ops.skinny_wgrad(p0, xhat, D.conv0.dw, False)
         ops.skinny_wgrad(ctx.gz1[0], v, D.conv0.dw, True)

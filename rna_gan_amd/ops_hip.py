@@ -139,17 +139,20 @@ class HipOps:
                                   _ptr(ws), ws.numel(), self.stream), "rg_conv_down"))
         return y
 
-    def conv_up(self, x, cw: ConvW):
+    def conv_up(self, x, cw: ConvW, mask_act=None, slope=1.0):
+        """Transposed conv; with mask_act (same shape as the result) the LeakyReLU backward
+        ``y *= (mask_act > 0 ? 1 : slope)`` is applied in the kernel's epilogue."""
         N, Ho, Wo, O = x.shape
         I = cw.I
         self._tap_major(cw)
         assert cw.O == O and x.is_contiguous()
         _, wup = self._packs(cw)
         y = self._act(N, 2 * Ho, 2 * Wo, I)
+        assert mask_act is None or (mask_act.shape == y.shape and mask_act.dtype == y.dtype and mask_act.is_contiguous())
         ws = self._ws(self.lib.rg_conv_workspace_bytes(1, N, Ho, Wo, O, I, self.dt, self.algo))
         self._timed("conv_fwd_dgrad", 2.0 * N * Ho * Wo * O * I * 16, lambda: check(
-            self.lib.rg_conv_up(_ptr(x), _ptr(cw.w), _ptr(wup), _ptr(y), N, Ho, Wo, O, I, self.dt, self.algo,
-                                _ptr(ws), ws.numel(), self.stream), "rg_conv_up"))
+            self.lib.rg_conv_up(_ptr(x), _ptr(cw.w), _ptr(wup), _ptr(y), N, Ho, Wo, O, I, _ptr(mask_act), float(slope),
+                                self.dt, self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_up"))
         return y
 
     def conv_wgrad(self, low, high, cw: ConvW, accumulate: bool):

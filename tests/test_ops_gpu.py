@@ -83,6 +83,8 @@ def test_conv_down_up_wgrad(N, Hi, Wi, I, O, dtype):
     u_ref = ref.conv_up(g, cr)
     u = hip.conv_up(dev(g), ch)
     check(u, u_ref, TOL[dtype], "conv_up")
+    m = rnd((N, Hi, Wi, I), 21).to(dtype)       # fused LeakyReLU backward of the consumer layer
+    check(hip.conv_up(dev(g), ch, dev(m), 0.2), ref.conv_up(g, cr, m, 0.2), TOL[dtype], "conv_up(masked)")
     ref.conv_wgrad(g, x, cr, False)
     dw_ref = cr.dw.clone()
     hip.conv_wgrad(dev(g), dev(x), ch, False)          # overwrites the 7.0 fill
