@@ -171,6 +171,11 @@ int rg_bn_stats(const void* z, float* sum, float* sumsq, int M, int C, int dtype
 int rg_bn_finalize(const float* sum, const float* sumsq, int M, int C, float eps, float momentum, float* mean,
                    float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                    void* stream);
+/* rg_bn_stats + rg_bn_finalize in one pass: the finishing step of the column reduction writes mean / invstd and
+ * updates the running statistics directly (one launch less per BatchNorm forward; same arithmetic). */
+int rg_bn_stats_finalize(const void* z, int M, int C, float eps, float momentum, float* mean, float* invstd,
+                         float* running_mean, float* running_var, int64_t* num_batches_tracked, int dtype, void* ws,
+                         size_t ws_bytes, void* stream);
 /* a = lrelu((z-mean)*invstd*gamma + beta) */
 int rg_bn_act(const void* z, const float* mean, const float* invstd, const float* gamma, const float* beta,
               void* a, int M, int C, float slope, int dtype, void* stream);

@@ -141,6 +141,10 @@ class RefOps:
         zf = z.to(self.f).reshape(-1, z.shape[-1])
         return zf.sum(0), (zf * zf).sum(0)
 
+    def bn_stats_finalize(self, z, eps: float, momentum: float, running_mean=None, running_var=None, nbt=None):
+        s, ss = self.bn_stats(z)
+        return self.bn_finalize(s, ss, z.numel() // z.shape[-1], eps, momentum, running_mean, running_var, nbt)
+
     def bn_finalize(self, s, ss, count: int, eps: float, momentum: float,
                     running_mean=None, running_var=None, nbt=None):
         mean = s / count

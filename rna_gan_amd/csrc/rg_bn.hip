@@ -184,6 +184,25 @@ struct Store2Fin {
   __device__ void operator()(int c, const float* s) const { a[c] = s[0]; b[c] = s[1]; }
 };
 
+// finisher of the fused statistics pass: batch mean / inverse std and the running-statistics update of
+// nn.BatchNorm2d in train mode, straight from the column sums (same arithmetic as bn_finalize_kernel)
+struct StatsFinalizeFin {
+  float m, eps, momentum;
+  float* mean; float* invstd; float* rmean; float* rvar; int64_t* nbt;
+  __device__ void operator()(int c, const float* s) const {
+    if (c == 0 && nbt) *nbt += 1;
+    float mu = s[0] / m;
+    float var = fmaxf(s[1] / m - mu * mu, 0.f);
+    mean[c] = mu;
+    invstd[c] = rsqrtf(var + eps);
+    if (rmean) {
+      float unb = var * (m / fmaxf(m - 1.f, 1.f));
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+    }
+  }
+};
+
 // ------------------------------------------------------------------------------------------ bn_act
 template <typename T, int VEC> struct BnActF {
   const T* z; T* a; BNC p; int C;
@@ -417,6 +436,17 @@ extern "C" int rg_bn_stats(const void* z, float* sum, float* sumsq, int M, int C
   RG_DISPATCH_DTYPE(dtype, T, {
     return (row_reduce<2, T, StatsF>("bn_stats", M, C, ws, ws_bytes, rg_stream(stream), Store2Fin{sum, sumsq},
                                      (const T*)z, C));
+  })
+}
+
+extern "C" int rg_bn_stats_finalize(const void* z, int M, int C, float eps, float momentum, float* mean, float* invstd,
+                                    float* running_mean, float* running_var, int64_t* num_batches_tracked, int dtype,
+                                    void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(z && mean && invstd && M > 0 && C > 0, RG_EINVAL, "bn_stats_finalize: bad args");
+  StatsFinalizeFin fin{(float)M, eps, momentum, mean, invstd, running_mean, running_var,
+                       running_mean ? num_batches_tracked : nullptr};
+  RG_DISPATCH_DTYPE(dtype, T, {
+    return (row_reduce<2, T, StatsF>("bn_stats_finalize", M, C, ws, ws_bytes, rg_stream(stream), fin, (const T*)z, C));
   })
 }
 

@@ -135,14 +135,10 @@ class _Ctx:
 
 
 def _bn_forward(ops, z, bn: BNP, slope, update_running=True):
-    C = z.shape[-1]
-    count = z.numel() // C
-    s, ss = ops.bn_stats(z)
     if update_running:
-        mean, invstd = ops.bn_finalize(s, ss, count, bn.eps, bn.momentum,
-                                       bn.running_mean, bn.running_var, bn.nbt)
+        mean, invstd = ops.bn_stats_finalize(z, bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.nbt)
     else:
-        mean, invstd = ops.bn_finalize(s, ss, count, bn.eps, bn.momentum)
+        mean, invstd = ops.bn_stats_finalize(z, bn.eps, bn.momentum)
     a = ops.bn_act(z, mean, invstd, bn.gamma, bn.beta, slope)
     return a, mean, invstd
 

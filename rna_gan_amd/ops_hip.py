@@ -284,6 +284,16 @@ class HipOps:
               "rg_bn_finalize")
         return mean, invstd
 
+    def bn_stats_finalize(self, z, eps: float, momentum: float, running_mean=None, running_var=None, nbt=None):
+        """Batch statistics of z -> (mean, invstd) (+ running-statistics update) in one reduction pass."""
+        M, C = self._mc(z)
+        mean, invstd = self._f32(C), self._f32(C)
+        ws = self._ws(self.lib.rg_colreduce_workspace_bytes(M, C, 2))
+        check(self.lib.rg_bn_stats_finalize(_ptr(z), M, C, float(eps), float(momentum), _ptr(mean), _ptr(invstd),
+                                            _ptr(running_mean), _ptr(running_var), _ptr(nbt), self.dt, _ptr(ws),
+                                            ws.numel(), self.stream), "rg_bn_stats_finalize")
+        return mean, invstd
+
     def bn_act(self, z, mean, invstd, gamma, beta, slope: float):
         M, C = self._mc(z)
         a = torch.empty_like(z)

@@ -177,6 +177,12 @@ def test_bn_family(M, C, dtype):
     check(mean, mean_ref, 1e-6, "mean"); check(inv, inv_ref, 1e-5, "invstd")
     check(rm_d, rm, 1e-6, "running_mean"); check(rv_d, rv, 1e-5, "running_var")
     assert int(nbt_d.cpu()) == int(nbt) == 1
+    # fused statistics + finalize (what the engine's BatchNorm forward uses): second update of the running stats
+    mean_ref2, inv_ref2 = ref.bn_stats_finalize(z, 1e-5, 0.1, rm, rv, nbt)
+    mean2, inv2 = hip.bn_stats_finalize(dev(z), 1e-5, 0.1, rm_d, rv_d, nbt_d)
+    check(mean2, mean_ref2, 1e-5, "fused mean"); check(inv2, inv_ref2, 1e-4, "fused invstd")
+    check(rm_d, rm, 1e-5, "fused running_mean"); check(rv_d, rv, 1e-4, "fused running_var")
+    assert int(nbt_d.cpu()) == int(nbt) == 2
     D = lambda t: None if t is None else dev(t)
     a_ref = ref.bn_act(z, mean_ref, inv_ref, gamma, beta, 0.2)
     check(hip.bn_act(D(z), D(mean_ref), D(inv_ref), D(gamma), D(beta), 0.2), a_ref, tol, "bn_act")
