@@ -99,10 +99,11 @@ def main():
                         args.seed + 1000 * D_.rank())
     loader = DataLoader(ds, batch_size=args.batch_size, num_workers=0, pin_memory=True, drop_last=True)
 
-    if args.gan_type != "dcgan":
-        raise SystemExit("only --gan_type dcgan is on the RNA-GAN path (condgan/biggan/sagan sources are absent upstream)")
+    if args.gan_type not in ("dcgan", "dcgan_up"):
+        raise SystemExit("--gan_type dcgan (the reference CLI's path) or dcgan_up (src/dcgan.py's DCGANUpGenerator, "
+                         "which the reference defines but never selects); condgan/biggan/sagan sources are absent upstream")
     gan_network = {
-        "generator": {"name": P.DCGANGenerator,
+        "generator": {"name": P.DCGANUpGenerator if args.gan_type == "dcgan_up" else P.DCGANGenerator,
                       "args": {"encoding_dims": 2048, "out_channels": 3, "step_channels": 64, "out_size": img_size,
                                "nonlinearity": nn.LeakyReLU(0.2), "last_nonlinearity": nn.Tanh()},
                       "optimizer": {"name": Adam, "args": {"lr": 0.0001, "betas": (0.5, 0.999)}}},

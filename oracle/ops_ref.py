@@ -84,6 +84,36 @@ class RefOps:
         self.conv_wgrad(low0, high0, cw, accumulate)
         self.conv_wgrad(low1, high1, cw, True)
 
+    # ------------------------------------------------------------------ resize-conv block (DCGANUpGenerator)
+    def _uppad(self, x_nhwc):
+        up = F.interpolate(self._nchw(x_nhwc), scale_factor=2, mode="bilinear", align_corners=False)
+        pad = F.pad(up, (1, 1, 1, 1), mode="reflect")
+        # the interpolated image is a GEMM operand: rounded to the activation dtype on the bf16 path
+        return pad if self.act_dtype != torch.bfloat16 else pad.to(torch.bfloat16).to(self.f)
+
+    def upconv3(self, x, cw: ConvW, bias, out_nchw=False):
+        y = F.conv2d(self._uppad(x), self._wq(cw.w), None if bias is None else bias.to(self.f))
+        return y.contiguous() if out_nchw else _nhwc(y, self.act_dtype)
+
+    def upconv3_bwd_data(self, gy, cw: ConvW, gy_nchw=False):
+        g = gy.to(self.f) if gy_nchw else self._nchw(gy)
+        gpad = F.conv_transpose2d(g, self._wq(cw.w))                      # gradient wrt the padded upsampled image
+        N, Cin, Hp, Wp = gpad.shape
+        x0 = torch.zeros(N, Cin, (Hp - 2) // 2, (Wp - 2) // 2, dtype=self.f, requires_grad=True)
+        with torch.enable_grad():
+            pad = F.pad(F.interpolate(x0, scale_factor=2, mode="bilinear", align_corners=False), (1, 1, 1, 1),
+                        mode="reflect")
+            gx, = torch.autograd.grad(pad, x0, gpad)                      # adjoint of a fixed linear map
+        return _nhwc(gx, self.act_dtype)
+
+    def upconv3_wgrad(self, gy, x, cw: ConvW, accumulate: bool, gy_nchw=False):
+        g = gy.to(self.f) if gy_nchw else self._nchw(gy)
+        d = torch.nn.grad.conv2d_weight(self._uppad(x), cw.w.shape, g)
+        if accumulate:
+            cw.dw.add_(d)
+        else:
+            cw.dw.copy_(d)
+
     def first_down(self, x_nchw, cw: ConvW, bias, slope: float):
         # bf16 path: the image-side layers run on the matrix cores too, so image and weights are rounded to
         # bf16 operands (fp32 accumulation); the fp32 path uses the masters as they are

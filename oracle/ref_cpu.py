@@ -87,6 +87,47 @@ class OracleDCGANGenerator(nn.Module):
         return [torch.randn(sample_size, self.encoding_dims, device=device)]
 
 
+class OracleDCGANUpGenerator(nn.Module):
+    """DCGANUpGenerator (resize-convolution generator), restated from src/dcgan.py:8-99.
+
+    First block as the DCGAN generator (src/dcgan.py:36-44: ConvTranspose2d(E, d, 4, 1, 0, bias=not batchnorm) +
+    BN + nl); ``num_repeats`` blocks [Upsample(x2, bilinear) + ReflectionPad2d(1) + Conv2d(d, d/2, 3, 1, 0) + BN +
+    nl] (src/dcgan.py:45-56; the Conv2d keeps its default bias=True); last block [Upsample + ReflectionPad2d(1) +
+    Conv2d(d, out_channels, 3)] WITHOUT an activation (src/dcgan.py:76-84: ``last_nl`` is built at :32 but never
+    used).  Only the batchnorm=True recipe uses the resize convolution (:57-75 falls back to ConvTranspose2d).
+    state_dict keys model.0.{0,1}.*, model.{1..R}.{2,3}.*, model.{R+1}.2.* -- pinned by tests/golden F4/F6."""
+
+    def __init__(self, encoding_dims=100, out_size=32, out_channels=3, step_channels=64,
+                 batchnorm=True, nonlinearity=None, last_nonlinearity=None, label_type="none"):
+        super().__init__()
+        if not batchnorm:
+            raise NotImplementedError("oracle covers the batchnorm=True recipe (the resize-convolution one)")
+        self.encoding_dims = encoding_dims
+        self.label_type = label_type
+        reps = _num_repeats(out_size)
+        self.ch = out_channels
+        self.n = step_channels
+        nl = nn.LeakyReLU(0.2) if nonlinearity is None else nonlinearity
+        d = int(self.n * (2 ** reps))
+        blocks: List[nn.Module] = [nn.Sequential(nn.ConvTranspose2d(encoding_dims, d, 4, 1, 0, bias=False),
+                                                 nn.BatchNorm2d(d), nl)]
+        for _ in range(reps):
+            blocks.append(nn.Sequential(nn.Upsample(scale_factor=2, mode="bilinear"), nn.ReflectionPad2d(1),
+                                        nn.Conv2d(d, d // 2, kernel_size=3, stride=1, padding=0),
+                                        nn.BatchNorm2d(d // 2), nl))
+            d //= 2
+        blocks.append(nn.Sequential(nn.Upsample(scale_factor=2, mode="bilinear"), nn.ReflectionPad2d(1),
+                                    nn.Conv2d(d, self.ch, kernel_size=3, stride=1, padding=0)))
+        self.model = nn.Sequential(*blocks)
+
+    def forward(self, x, feature_matching=False):
+        x = x.view(-1, x.size(1), 1, 1)
+        return self.model(x)
+
+    def sampler(self, sample_size, device):
+        return [torch.randn(sample_size, self.encoding_dims, device=device)]
+
+
 class OracleDCGANDiscriminator(nn.Module):
     """torchgan DCGANDiscriminator, ctor kwargs per src/histopathology_gan.py:186-192.
 

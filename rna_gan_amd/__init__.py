@@ -1,6 +1,6 @@
 """rna_gan_amd -- MI355X-native WGAN-GP training path of RNA-GAN (hand-written HIP kernels behind a
 C ABI; Python host side mirroring the reference's torchgan plugin interface).  See DESIGN.md."""
-from .models import DCGANDiscriminator, DCGANGenerator, Discriminator, Generator  # noqa: F401
+from .models import DCGANDiscriminator, DCGANGenerator, DCGANUpGenerator, Discriminator, Generator  # noqa: F401
 from .betavae import betaVAE  # noqa: F401
 from .losses import (WassersteinDiscriminatorLoss, WassersteinDiscriminatorLossVAE,  # noqa: F401
                      WassersteinGeneratorLoss, WassersteinGeneratorLossVAE, WassersteinGradientPenalty,
@@ -8,6 +8,6 @@ from .losses import (WassersteinDiscriminatorLoss, WassersteinDiscriminatorLossV
 from .trainer import Trainer  # noqa: F401
 from .optim import Adam  # noqa: F401
 
-__all__ = ["DCGANGenerator", "DCGANDiscriminator", "Generator", "Discriminator", "betaVAE", "Trainer", "Adam",
+__all__ = ["DCGANGenerator", "DCGANUpGenerator", "DCGANDiscriminator", "Generator", "Discriminator", "betaVAE", "Trainer", "Adam",
            "WassersteinGeneratorLoss", "WassersteinDiscriminatorLoss", "WassersteinGradientPenalty",
            "WassersteinGeneratorLossVAE", "WassersteinDiscriminatorLossVAE", "WassersteinGradientPenaltyVAE"]

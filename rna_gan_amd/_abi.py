@@ -67,6 +67,10 @@ PROTOTYPES = {
     "rg_latent_prep": (_i, [_p, _p, _p, _i, _i, _p]),
     "rg_adam_step": (_i, [_p, _p, _p, _p, _z, _i, _d, _d, _d, _d, _p]),
     "rg_clamp": (_i, [_p, _z, _f, _f, _p]),
+    "rg_upconv3_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "rg_upconv3_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "rg_upconv3_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "rg_upconv3_wgrad": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_adam_step_dev": (_i, [_p, _p, _p, _p, _z, _p, _p, _p]),
     "rg_interp_dev": (_i, [_p, _p, _p, _z, _p, _p]),
     "rg_adam_hyper_dev": (_i, [_p, _d, _d, _d, _d, _p, _p]),

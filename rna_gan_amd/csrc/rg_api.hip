@@ -191,3 +191,25 @@ extern "C" int rg_linear_affine_act(const float* x, int ldx, const float* w, con
   RG_REQUIRE(w, RG_EINVAL, "linear: generic kernel needs the fp32 weight");
   return rg_generic_linear(x, ldx, w, scale, shift, y, ldy, M, K, Nout, slope, rg_stream(stream));
 }
+
+/* ---- resize-convolution block of DCGANUpGenerator (src/dcgan.py:45-56,76-84) ---- */
+extern "C" size_t rg_upconv3_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+  if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  return rg_generic_upconv3_ws_bytes(N, H, W, Cin, Cout);
+}
+extern "C" int rg_upconv3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int Cin,
+                              int Cout, int out_nchw_f32, int dtype, void* stream) {
+  RG_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, RG_EINVAL, "upconv3_fwd: bad args");
+  return rg_generic_upconv3_fwd(x, w, bias, y, N, H, W, Cin, Cout, out_nchw_f32, dtype, rg_stream(stream));
+}
+extern "C" int rg_upconv3_bwd_data(const void* gy, int gy_nchw_f32, const float* w, void* gx, int N, int H, int W,
+                                   int Cin, int Cout, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(gy && w && gx && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, RG_EINVAL, "upconv3_bwd_data: bad args");
+  return rg_generic_upconv3_bwd_data(gy, gy_nchw_f32, w, gx, N, H, W, Cin, Cout, dtype, ws, ws_bytes, rg_stream(stream));
+}
+extern "C" int rg_upconv3_wgrad(const void* gy, int gy_nchw_f32, const void* x, float* dw, int N, int H, int W, int Cin,
+                                int Cout, int dtype, int accumulate, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(gy && x && dw && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, RG_EINVAL, "upconv3_wgrad: bad args");
+  return rg_generic_upconv3_wgrad(gy, gy_nchw_f32, x, dw, N, H, W, Cin, Cout, dtype, accumulate, ws, ws_bytes,
+                                  rg_stream(stream));
+}

@@ -506,3 +506,214 @@ int rg_generic_linear(const float* x, int ldx, const float* w, const float* scal
   return launch_generic<true, true>("linear(generic)", LinA{x, ldx}, LinB{w, K}, LinC{y, ldy, scale, shift, slope}, M,
                                     Nout, K, 1, 1, st);
 }
+
+// ================================================================================================
+// Resize-convolution block of DCGANUpGenerator (src/dcgan.py:45-56, 76-84):
+//   y = Conv2d(Cin, Cout, 3, 1, 0)(ReflectionPad2d(1)(Upsample(x2, bilinear, align_corners=False)(x))) + bias
+// The upsampled + padded image is never materialised in the forward and weight-gradient passes: the GEMM's
+// operand functor interpolates it on the fly (and rounds it to the activation dtype, the GEMM operand precision).
+// ================================================================================================
+namespace {
+struct UGeo { int N, H, W, Cin, Cout; };     // input H x W, output 2H x 2W
+
+// padded coordinate i in [0, 2H+2) -> upsampled coordinate (reflection without repeating the edge)
+__device__ __forceinline__ int up_reflect(int i, int L2) {
+  int u = i - 1;
+  return u < 0 ? -u : (u >= L2 ? 2 * L2 - 2 - u : u);
+}
+// bilinear x2, align_corners=False: u = 2q   -> 0.25 x[q-1] + 0.75 x[q]   (x[-1] := x[0])
+//                                   u = 2q+1 -> 0.75 x[q]   + 0.25 x[q+1] (x[L]  := x[L-1])
+__device__ __forceinline__ void up_taps(int u, int L, int& i0, int& i1, float& l1) {
+  int q = u >> 1;
+  if (u & 1) { i0 = q; i1 = min(q + 1, L - 1); l1 = 0.25f; }
+  else       { i0 = max(q - 1, 0); i1 = q; l1 = 0.75f; }
+}
+template <typename T>
+__device__ __forceinline__ float uppad_at(const T* x, const UGeo& g, int n, int i, int j, int c) {
+  int h0, h1, w0, w1;
+  float lh, lw;
+  up_taps(up_reflect(i, 2 * g.H), g.H, h0, h1, lh);
+  up_taps(up_reflect(j, 2 * g.W), g.W, w0, w1, lw);
+  const T* xn = x + (size_t)n * g.H * g.W * g.Cin + c;
+  float v00 = Elem<T>::ld(xn + ((size_t)h0 * g.W + w0) * g.Cin), v01 = Elem<T>::ld(xn + ((size_t)h0 * g.W + w1) * g.Cin);
+  float v10 = Elem<T>::ld(xn + ((size_t)h1 * g.W + w0) * g.Cin), v11 = Elem<T>::ld(xn + ((size_t)h1 * g.W + w1) * g.Cin);
+  return (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
+}
+
+// forward: M = N*2H*2W, K = Cin*9 (k = ci*9 + kh*3 + kw), Ncols = Cout
+template <typename T> struct UpFwdA {
+  const T* x; UGeo g;
+  __device__ float operator()(int, int m, int k) const {
+    int W2 = 2 * g.W, H2 = 2 * g.H;
+    int wo = m % W2, t = m / W2, ho = t % H2, n = t / H2;
+    int ci = k / 9, r = k - ci * 9, kh = r / 3, kw = r - kh * 3;
+    return Elem<T>::round(uppad_at(x, g, n, ho + kh, wo + kw, ci));
+  }
+};
+template <typename T> struct UpFwdB {
+  const float* w; UGeo g;
+  __device__ float operator()(int, int k, int o) const { return Elem<T>::round(w[(size_t)o * g.Cin * 9 + k]); }
+};
+struct UpNchwC {   // image-side output: NCHW fp32 + bias
+  float* y; const float* bias; UGeo g;
+  __device__ void operator()(int, int, int m, int o, float v) const {
+    int W2 = 2 * g.W, H2 = 2 * g.H;
+    int wo = m % W2, t = m / W2, ho = t % H2, n = t / H2;
+    y[(((size_t)n * g.Cout + o) * H2 + ho) * W2 + wo] = v + (bias ? bias[o] : 0.f);
+  }
+};
+
+// gradient wrt the padded upsampled image: M = N*(2H+2)*(2W+2), K = Cout*9 (k = o*9 + kh*3 + kw), Ncols = Cin
+template <typename T, bool NCHW> struct UpBwdA {
+  const void* gy; UGeo g;
+  __device__ float operator()(int, int m, int k) const {
+    int Wp = 2 * g.W + 2, Hp = 2 * g.H + 2;
+    int j = m % Wp, t = m / Wp, i = t % Hp, n = t / Hp;
+    int o = k / 9, r = k - o * 9, kh = r / 3, kw = r - kh * 3;
+    int ho = i - kh, wo = j - kw;
+    if (ho < 0 || ho >= 2 * g.H || wo < 0 || wo >= 2 * g.W) return 0.f;
+    if (NCHW) return ((const float*)gy)[(((size_t)n * g.Cout + o) * (2 * g.H) + ho) * (2 * g.W) + wo];
+    return Elem<T>::ld((const T*)gy + (((size_t)n * (2 * g.H) + ho) * (2 * g.W) + wo) * g.Cout + o);
+  }
+};
+template <typename T> struct UpBwdB {
+  const float* w; UGeo g;
+  __device__ float operator()(int, int k, int c) const {
+    int o = k / 9, r = k - o * 9;
+    return Elem<T>::round(w[((size_t)o * g.Cin + c) * 9 + r]);
+  }
+};
+// adjoint of (reflection pad o bilinear x2): gx[n][h][w][c] from gpad[n][2H+2][2W+2][c] (fp32)
+template <typename T>
+__global__ void uppad_adjoint_kernel(const float* __restrict__ gpad, T* __restrict__ gx, UGeo g) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t tot = (size_t)g.N * g.H * g.W * g.Cin;
+  if (idx >= tot) return;
+  int c = (int)(idx % g.Cin);
+  size_t t = idx / g.Cin;
+  int w = (int)(t % g.W); t /= g.W;
+  int h = (int)(t % g.H);
+  int n = (int)(t / g.H);
+  const int H2 = 2 * g.H, W2 = 2 * g.W, Wp = W2 + 2;
+  const float* gp = gpad + (size_t)n * (H2 + 2) * Wp * g.Cin + c;
+  float acc = 0.f;
+  for (int du = -1; du <= 2; ++du) {
+    int u = 2 * h + du;
+    if (u < 0 || u >= H2) continue;
+    int a0, a1; float la;
+    up_taps(u, g.H, a0, a1, la);
+    float ch = (a0 == h ? 1.f - la : 0.f) + (a1 == h ? la : 0.f);
+    if (ch == 0.f) continue;
+    for (int dv = -1; dv <= 2; ++dv) {
+      int v = 2 * w + dv;
+      if (v < 0 || v >= W2) continue;
+      int b0, b1; float lb;
+      up_taps(v, g.W, b0, b1, lb);
+      float cw = (b0 == w ? 1.f - lb : 0.f) + (b1 == w ? lb : 0.f);
+      if (cw == 0.f) continue;
+      // padded rows / columns that read upsampled row u / column v
+      float s = 0.f;
+      for (int ri = 0; ri < 3; ++ri) {
+        int i = ri == 0 ? u + 1 : (ri == 1 ? (u == 1 ? 0 : -1) : (u == H2 - 2 ? H2 + 1 : -1));
+        if (i < 0) continue;
+        for (int rj = 0; rj < 3; ++rj) {
+          int j = rj == 0 ? v + 1 : (rj == 1 ? (v == 1 ? 0 : -1) : (v == W2 - 2 ? W2 + 1 : -1));
+          if (j < 0) continue;
+          s += gp[((size_t)i * Wp + j) * g.Cin];
+        }
+      }
+      acc += ch * cw * s;
+    }
+  }
+  Elem<T>::st(gx + idx, acc);
+}
+
+// weight gradient: M = Cout, Ncols = Cin*9 (col = c*9 + kh*3 + kw), K = N*2H*2W pixels
+template <typename T, bool NCHW> struct UpWgA {
+  const void* gy; UGeo g;
+  __device__ float operator()(int, int o, int pix) const {
+    if (NCHW) {
+      int HW = 4 * g.H * g.W, n = pix / HW, r = pix - n * HW;
+      return ((const float*)gy)[((size_t)n * g.Cout + o) * HW + r];
+    }
+    return Elem<T>::ld((const T*)gy + (size_t)pix * g.Cout + o);
+  }
+};
+template <typename T> struct UpWgB {
+  const T* x; UGeo g;
+  __device__ float operator()(int, int pix, int col) const {
+    int W2 = 2 * g.W, H2 = 2 * g.H;
+    int wo = pix % W2, t = pix / W2, ho = t % H2, n = t / H2;
+    int c = col / 9, r = col - c * 9, kh = r / 3, kw = r - kh * 3;
+    return Elem<T>::round(uppad_at(x, g, n, ho + kh, wo + kw, c));
+  }
+};
+int upconv3_split(const UGeo& g) {
+  long long K = (long long)g.N * 4 * g.H * g.W;
+  long long tiles = (long long)((g.Cout + GB_M - 1) / GB_M) * ((g.Cin * 9 + GB_N - 1) / GB_N);
+  long long want = (1024 + tiles - 1) / tiles, maxs = K / 256;
+  long long s = want < maxs ? want : maxs;
+  return (int)(s < 1 ? 1 : (s > 256 ? 256 : s));
+}
+}  // namespace
+
+size_t rg_generic_upconv3_ws_bytes(int N, int H, int W, int Cin, int Cout) {
+  UGeo g{N, H, W, Cin, Cout};
+  size_t a = (size_t)N * (2 * H + 2) * (2 * W + 2) * Cin * sizeof(float);              // gpad
+  size_t b = (size_t)upconv3_split(g) * Cout * Cin * 9 * sizeof(float);                 // wgrad slabs
+  return a > b ? a : b;
+}
+
+int rg_generic_upconv3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int Cin,
+                           int Cout, int out_nchw, int dtype, hipStream_t st) {
+  UGeo g{N, H, W, Cin, Cout};
+  const int M = N * 4 * H * W;
+  RG_DISPATCH_DTYPE(dtype, T, {
+    if (out_nchw)
+      return launch_generic<true, true>("upconv3_fwd", UpFwdA<T>{(const T*)x, g}, UpFwdB<T>{w, g},
+                                        UpNchwC{(float*)y, bias, g}, M, Cout, Cin * 9, 1, 1, st);
+    return launch_generic<true, true>("upconv3_fwd", UpFwdA<T>{(const T*)x, g}, UpFwdB<T>{w, g},
+                                      BiasActC<T>{(T*)y, bias, 1.0f, Cout}, M, Cout, Cin * 9, 1, 1, st);
+  })
+}
+
+int rg_generic_upconv3_bwd_data(const void* gy, int gy_nchw, const float* w, void* gx, int N, int H, int W, int Cin,
+                                int Cout, int dtype, void* ws, size_t ws_bytes, hipStream_t st) {
+  UGeo g{N, H, W, Cin, Cout};
+  const int Mp = N * (2 * H + 2) * (2 * W + 2);
+  RG_REQUIRE(ws && ws_bytes >= (size_t)Mp * Cin * sizeof(float), RG_EWORKSPACE, "upconv3_bwd_data: workspace too small");
+  float* gpad = (float*)ws;
+  RG_DISPATCH_DTYPE(dtype, T, {
+    int rc;
+    if (gy_nchw)
+      rc = launch_generic<true, false>("upconv3_bwd_data", UpBwdA<T, true>{gy, g}, UpBwdB<T>{w, g},
+                                       RowMajorC<float>{gpad, Cin}, Mp, Cin, Cout * 9, 1, 1, st);
+    else
+      rc = launch_generic<true, false>("upconv3_bwd_data", UpBwdA<T, false>{gy, g}, UpBwdB<T>{w, g},
+                                       RowMajorC<float>{gpad, Cin}, Mp, Cin, Cout * 9, 1, 1, st);
+    if (rc) return rc;
+    size_t tot = (size_t)N * H * W * Cin;
+    hipLaunchKernelGGL((uppad_adjoint_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, gpad, (T*)gx, g);
+    RG_LAUNCH_CHECK("upconv3_bwd_data");
+    return RG_OK;
+  })
+}
+
+int rg_generic_upconv3_wgrad(const void* gy, int gy_nchw, const void* x, float* dw, int N, int H, int W, int Cin,
+                             int Cout, int dtype, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+  UGeo g{N, H, W, Cin, Cout};
+  const int K = N * 4 * H * W, s = upconv3_split(g);
+  const size_t elems = (size_t)Cout * Cin * 9;
+  RG_REQUIRE(ws && ws_bytes >= (size_t)s * elems * sizeof(float), RG_EWORKSPACE, "upconv3_wgrad: workspace too small");
+  RG_DISPATCH_DTYPE(dtype, T, {
+    int rc;
+    if (gy_nchw)
+      rc = launch_generic<false, false>("upconv3_wgrad", UpWgA<T, true>{gy, g}, UpWgB<T>{(const T*)x, g},
+                                        SlabC{(float*)ws, elems, Cin * 9}, Cout, Cin * 9, K, 1, s, st);
+    else
+      rc = launch_generic<false, false>("upconv3_wgrad", UpWgA<T, false>{gy, g}, UpWgB<T>{(const T*)x, g},
+                                        SlabC{(float*)ws, elems, Cin * 9}, Cout, Cin * 9, K, 1, s, st);
+    if (rc) return rc;
+  })
+  return rg_reduce_slabs((const float*)ws, dw, elems, s, accumulate, 0, 0, st);
+}

@@ -37,6 +37,13 @@ int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, in
 int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, const void* mask,
                     float mslope, void* ws, size_t ws_bytes, hipStream_t st);
 size_t rg_mfma_conv_ws_bytes(int up, int N, int Hlow, int Wlow, int O, int I);
+size_t rg_generic_upconv3_ws_bytes(int N, int H, int W, int Cin, int Cout);
+int rg_generic_upconv3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int Cin,
+                           int Cout, int out_nchw, int dtype, hipStream_t st);
+int rg_generic_upconv3_bwd_data(const void* gy, int gy_nchw, const float* w, void* gx, int N, int H, int W, int Cin,
+                                int Cout, int dtype, void* ws, size_t ws_bytes, hipStream_t st);
+int rg_generic_upconv3_wgrad(const void* gy, int gy_nchw, const void* x, float* dw, int N, int H, int W, int Cin,
+                             int Cout, int dtype, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 size_t rg_mfma_g0_wgrad_ws_bytes(int N, int E, int C);
 bool rg_mfma_g0_wgrad_supported(int N, int E, int C);
 int rg_mfma_g0_wgrad(const float* z, const void* gy, float* dw, int N, int E, int C, void* ws, size_t ws_bytes,

@@ -130,6 +130,23 @@ class GenNet:
             cw.version += 1
 
 
+class UpGenNet:
+    """DCGANUpGenerator as the engine sees it (src/dcgan.py:8-99): G.0 block as GenNet, then R resize-convolution
+    blocks [bilinear x2 + ReflectionPad(1) + Conv3x3(+bias) + BN + LReLU] and a last resize-convolution WITHOUT an
+    activation.  The 3x3 weights keep the PyTorch layout w[Cout][Cin][3][3]."""
+
+    def __init__(self, g0: ConvW, bn0: BNP, blocks: List, last: ConvW, slope: float):
+        self.g0, self.bn0, self.blocks, self.last = g0, bn0, blocks, last   # blocks: [(ConvW, BNP)]
+        self.slope = slope
+
+    def convs(self):
+        return [self.g0, self.last] + [b[0] for b in self.blocks]
+
+    def bump(self):
+        for cw in self.convs():
+            cw.version += 1
+
+
 class _Ctx:
     pass
 
@@ -303,6 +320,52 @@ def gen_forward(ops, G: GenNet, noise, update_running=True, keep=True):
     return img, ctx
 
 
+def upgen_forward(ops, G: UpGenNet, noise, update_running=True, keep=True):
+    """DCGANUpGenerator forward (src/dcgan.py:85-99 through the blocks of :36-56,:76-84)."""
+    ctx = _Ctx()
+    ctx.noise = noise
+    z = ops.g0_fwd(noise, G.g0)
+    a, mean, invstd = _bn_forward(ops, z, G.bn0, G.slope, update_running)
+    ctx.z, ctx.mean, ctx.invstd, ctx.a = [z], [mean], [invstd], [a]
+    for cw, bn in G.blocks:
+        z = ops.upconv3(a, cw, cw.bias)
+        a, mean, invstd = _bn_forward(ops, z, bn, G.slope, update_running)
+        if keep:
+            ctx.z.append(z); ctx.mean.append(mean); ctx.invstd.append(invstd); ctx.a.append(a)
+    ctx.a_last = a
+    img = ops.upconv3(a, G.last, G.last.bias, out_nchw=True)       # no activation (src/dcgan.py:76-84)
+    ctx.img = img
+    return img, ctx
+
+
+def upgen_backward(ops, G: UpGenNet, ctx, gimg, accumulate: bool):
+    """Parameter gradients of the up-generator for d(loss)/d(img) = gimg (NCHW fp32)."""
+    R = len(G.blocks)
+    ops.upconv3_wgrad(gimg, ctx.a[R], G.last, accumulate, gy_nchw=True)
+    ops.nchw_chan_sum(gimg, G.last.dbias, accumulate)
+    ga = ops.upconv3_bwd_data(gimg, G.last, gy_nchw=True)
+    for l in range(R, 0, -1):
+        cw, bn = G.blocks[l - 1]
+        gz, _, _ = ops.bn_act_bwd(ctx.z[l], ga, ctx.mean[l], ctx.invstd[l], bn.gamma, bn.beta,
+                                  G.slope, bn.dgamma, bn.dbeta, accumulate)
+        ops.upconv3_wgrad(gz, ctx.a[l - 1], cw, accumulate)
+        ops.col_sum(gz, cw.dbias, accumulate)      # the Conv2d keeps its bias in front of the BatchNorm (:50-51)
+        ga = ops.upconv3_bwd_data(gz, cw)
+    gz0, _, _ = ops.bn_act_bwd(ctx.z[0], ga, ctx.mean[0], ctx.invstd[0], G.bn0.gamma, G.bn0.beta,
+                               G.slope, G.bn0.dgamma, G.bn0.dbeta, accumulate)
+    ops.g0_wgrad(ctx.noise, gz0, G.g0.dw, accumulate)
+
+
+def _gen_fwd(ops, G, noise, **kw):
+    return upgen_forward(ops, G, noise, **kw) if isinstance(G, UpGenNet) else gen_forward(ops, G, noise, **kw)
+
+
+def _gen_bwd(ops, G, ctx, gimg, accumulate):
+    if isinstance(G, UpGenNet):
+        return upgen_backward(ops, G, ctx, gimg, accumulate)
+    return gen_backward(ops, G, ctx, gimg, accumulate)
+
+
 def gen_backward(ops, G: GenNet, ctx, gimg, accumulate: bool):
     """Parameter gradients of G for d(loss)/d(img) = gimg (NCHW fp32)."""
     R = len(G.blocks)
@@ -332,11 +395,11 @@ def gen_loss_grads(ops, G: GenNet, D: DiscNet, noise, grad_scale: float = 1.0):
     """src/wgan_loss.py:113-126: loss = mean(-D(G(z))); fills G's gradients.  D's weight
     gradients, which the reference computes and discards, are not computed."""
     n = noise.shape[0]
-    img, gctx = gen_forward(ops, G, noise)
+    img, gctx = _gen_fwd(ops, G, noise)
     out, dctx = disc_forward(ops, D, img)
     loss = ops.mean_diff(out, None, -1.0)
     gimg = disc_backward(ops, D, dctx, -grad_scale / n, wgrad=False, accumulate=False, need_input_grad=True)
-    gen_backward(ops, G, gctx, gimg, accumulate=False)
+    _gen_bwd(ops, G, gctx, gimg, accumulate=False)
     return loss
 
 
@@ -345,7 +408,7 @@ def disc_loss_grads(ops, G: GenNet, D: DiscNet, real, noise, grad_scale: float =
     Forward order D(real), G(z), D(fake) as in the reference (BN running statistics)."""
     n = real.shape[0]
     out_r, ctx_r = disc_forward(ops, D, real)
-    img, _ = gen_forward(ops, G, noise, keep=False)
+    img, _ = _gen_fwd(ops, G, noise, keep=False)
     out_f, ctx_f = disc_forward(ops, D, img)
     loss = ops.mean_diff(out_f, out_r, 1.0)
     disc_backward_pair(ops, D, ctx_r, -grad_scale / n, ctx_f, grad_scale / n)
@@ -355,7 +418,7 @@ def disc_loss_grads(ops, G: GenNet, D: DiscNet, real, noise, grad_scale: float =
 def gp_loss_grads(ops, G: GenNet, D: DiscNet, real, noise, eps: float, lambd: float, grad_scale: float = 1.0):
     """src/wgan_loss.py:371-387: fake = G(z); xhat = eps*real + (1-eps)*fake; D gradients of
     lambd*GP.  The generator gradients the reference produces here are never used and are skipped."""
-    img, _ = gen_forward(ops, G, noise, keep=False)
+    img, _ = _gen_fwd(ops, G, noise, keep=False)
     xhat = ops.interp(real, img, eps)
     return disc_gradient_penalty(ops, D, xhat, lambd * grad_scale)
 
@@ -386,10 +449,12 @@ def is_tap_major(t) -> bool:
 
 
 def _middle_convs(mod):
-    """The stride-2 4x4 conv layers between the image-side layer and G.0 / the head (torchgan DCGAN recipe)."""
+    """The stride-2 4x4 conv layers between the image-side layer and G.0 / the head (torchgan DCGAN recipe);
+    none in the resize-convolution generator."""
     blocks = list(mod.model.children())
     sel = blocks[1:] if hasattr(mod, "disc") else blocks[1:-1]
-    return [blk[0] for blk in sel]
+    return [blk[0] for blk in sel if isinstance(blk[0], (torch.nn.Conv2d, torch.nn.ConvTranspose2d))
+            and tuple(blk[0].kernel_size) == (4, 4)]
 
 
 def tap_major_(mod):
@@ -442,6 +507,34 @@ def build_gen_net(mod) -> GenNet:
         raise NotImplementedError("HIP path supports last_nonlinearity=Tanh only")
     last = ConvW(lc.weight.data, lc.bias.data, _grad_of(lc.weight), _grad_of(lc.bias))
     return GenNet(g0, _bnp(b0), bl, last, slope)
+
+
+def build_upgen_net(mod) -> UpGenNet:
+    """Engine view of a DCGANUpGenerator-structured module: model.0 = [ConvT, BN, nl], model.{1..R} = [Upsample,
+    ReflectionPad2d, Conv2d(3x3, bias), BN, nl], model.{R+1} = [Upsample, ReflectionPad2d, Conv2d(3x3, bias)]."""
+    blocks = list(mod.model.children())
+    c0, b0 = blocks[0][0], blocks[0][1]
+    if c0.bias is not None or not isinstance(b0, torch.nn.BatchNorm2d):
+        raise NotImplementedError("HIP path supports the batchnorm=True recipe only")
+    g0 = ConvW(c0.weight.data, None, _grad_of(c0.weight))
+    slope = _slope_of(blocks[0][-1], 0.2)
+
+    def conv3(conv):
+        if tuple(conv.kernel_size) != (3, 3) or conv.bias is None:
+            raise NotImplementedError("resize-convolution blocks are Conv2d(3x3, bias=True)")
+        return ConvW(conv.weight.data, conv.bias.data, _grad_of(conv.weight), _grad_of(conv.bias))
+    bl = [(conv3(blk[2]), _bnp(blk[3])) for blk in blocks[1:-1]]
+    return UpGenNet(g0, _bnp(b0), bl, conv3(blocks[-1][2]), slope)
+
+
+def upgen_forward_eval(ops, G: UpGenNet, noise):
+    def bn_eval(z, bn):
+        invstd = torch.rsqrt(bn.running_var + bn.eps)
+        return ops.bn_act(z, bn.running_mean, invstd, bn.gamma, bn.beta, G.slope)
+    a = bn_eval(ops.g0_fwd(noise, G.g0), G.bn0)
+    for cw, bn in G.blocks:
+        a = bn_eval(ops.upconv3(a, cw, cw.bias), bn)
+    return ops.upconv3(a, G.last, G.last.bias, out_nchw=True)
 
 
 def gen_forward_eval(ops, G: GenNet, noise):

@@ -258,6 +258,47 @@ class DCGANGenerator(Generator):
         return img
 
 
+class DCGANUpGenerator(Generator):
+    """Resize-convolution generator of src/dcgan.py:8-99 (same constructor): ConvT(E,d,4,1,0)+BN+nl ;
+    R x [Upsample(x2, bilinear)+ReflectionPad2d(1)+Conv2d(d,d/2,3)+BN+nl] ; Upsample+ReflectionPad2d(1)+Conv2d(d,ch,3)
+    with NO final activation (``last_nonlinearity`` is accepted and unused, as in the reference, :32,:76-84).
+    state_dict keys as the reference's: model.0.{0,1}.*, model.{i}.{2,3}.*, model.{R+1}.2.*."""
+
+    def __init__(self, encoding_dims=100, out_size=32, out_channels=3, step_channels=64, batchnorm=True,
+                 nonlinearity=None, last_nonlinearity=None, label_type="none"):
+        super().__init__(encoding_dims, label_type)
+        if not batchnorm:
+            raise NotImplementedError("rna_gan_amd implements the batchnorm=True (resize-convolution) recipe")
+        reps = _num_repeats(out_size, "Target Image Size")
+        self.ch = out_channels
+        self.n = step_channels
+        nl = nn.LeakyReLU(0.2) if nonlinearity is None else nonlinearity
+        d = int(self.n * (2 ** reps))
+        model: List[nn.Module] = [nn.Sequential(nn.ConvTranspose2d(self.encoding_dims, d, 4, 1, 0, bias=False),
+                                                nn.BatchNorm2d(d), nl)]
+        for _ in range(reps):
+            model.append(nn.Sequential(nn.Upsample(scale_factor=2, mode="bilinear"), nn.ReflectionPad2d(1),
+                                       nn.Conv2d(d, d // 2, kernel_size=3, stride=1, padding=0),
+                                       nn.BatchNorm2d(d // 2), nl))
+            d = d // 2
+        model.append(nn.Sequential(nn.Upsample(scale_factor=2, mode="bilinear"), nn.ReflectionPad2d(1),
+                                   nn.Conv2d(d, self.ch, kernel_size=3, stride=1, padding=0)))
+        self.model = nn.Sequential(*model)
+        self._weight_initializer()
+
+    def _build_net(self):
+        return E.build_upgen_net(self)
+
+    def forward(self, x, feature_matching=False):
+        ops, net = self.runtime()
+        x = x.view(-1, x.size(1)).contiguous().float()
+        if self.training:
+            img, _ = E.upgen_forward(ops, net, x, update_running=True, keep=False)
+        else:
+            img = E.upgen_forward_eval(ops, net, x)
+        return img
+
+
 class DCGANDiscriminator(Discriminator):
     """Conv(c,d,4,2,1,bias)+nl ; R x [Conv(d,2d,4,2,1)+BN+nl] ; disc = Conv(d,1,4,1,0)+last_nl -> (N,)."""
 

@@ -182,6 +182,42 @@ class HipOps:
                                     self.dt, int(accumulate), self.algo, _ptr(ws), ws.numel(), self.stream),
             "rg_conv_wgrad2"))
 
+    # ------------------------------------------------------------------ resize-conv block (DCGANUpGenerator)
+    def upconv3(self, x, cw: ConvW, bias, out_nchw=False):
+        """Conv3x3(ReflectionPad(1)(bilinear x2 (x))) + bias; NHWC activation out, or the NCHW fp32 image."""
+        N, H, W, Cin = x.shape
+        Cout = cw.w.shape[0]
+        assert tuple(cw.w.shape) == (Cout, Cin, 3, 3) and cw.w.is_contiguous() and x.is_contiguous()
+        y = self._f32(N, Cout, 2 * H, 2 * W) if out_nchw else self._act(N, 2 * H, 2 * W, Cout)
+        check(self.lib.rg_upconv3_fwd(_ptr(x), _ptr(cw.w), _ptr(bias), _ptr(y), N, H, W, Cin, Cout, int(out_nchw),
+                                      self.dt, self.stream), "rg_upconv3_fwd")
+        return y
+
+    def _up_dims(self, gy, cw, gy_nchw):
+        Cout, Cin = cw.w.shape[0], cw.w.shape[1]
+        if gy_nchw:
+            N, C, H2, W2 = gy.shape
+            assert gy.dtype == torch.float32
+        else:
+            N, H2, W2, C = gy.shape
+        assert C == Cout and gy.is_contiguous()
+        return N, H2 // 2, W2 // 2, Cin, Cout
+
+    def upconv3_bwd_data(self, gy, cw: ConvW, gy_nchw=False):
+        N, H, W, Cin, Cout = self._up_dims(gy, cw, gy_nchw)
+        gx = self._act(N, H, W, Cin)
+        ws = self._ws(self.lib.rg_upconv3_workspace_bytes(N, H, W, Cin, Cout))
+        check(self.lib.rg_upconv3_bwd_data(_ptr(gy), int(gy_nchw), _ptr(cw.w), _ptr(gx), N, H, W, Cin, Cout, self.dt,
+                                           _ptr(ws), ws.numel(), self.stream), "rg_upconv3_bwd_data")
+        return gx
+
+    def upconv3_wgrad(self, gy, x, cw: ConvW, accumulate: bool, gy_nchw=False):
+        N, H, W, Cin, Cout = self._up_dims(gy, cw, gy_nchw)
+        assert tuple(x.shape) == (N, H, W, Cin) and x.is_contiguous() and cw.dw.is_contiguous()
+        ws = self._ws(self.lib.rg_upconv3_workspace_bytes(N, H, W, Cin, Cout))
+        check(self.lib.rg_upconv3_wgrad(_ptr(gy), int(gy_nchw), _ptr(x), _ptr(cw.dw), N, H, W, Cin, Cout, self.dt,
+                                        int(accumulate), _ptr(ws), ws.numel(), self.stream), "rg_upconv3_wgrad")
+
     def first_down(self, x_nchw, cw: ConvW, bias, slope: float):
         N, I, H, W = x_nchw.shape
         O = cw.w.shape[0]

@@ -85,3 +85,34 @@ def test_three_steps_match_autograd(in_size, step, enc, n, tap_major):
     assert_close_dict(grads_of(D2), grads_of(D), 1e-6, 1e-9)
     assert_close_dict(bufs_of(D2), bufs_of(D), 1e-9, 1e-12)
     assert_close_dict(bufs_of(G2), bufs_of(G), 1e-9, 1e-12)
+
+
+def test_up_generator_step_matches_autograd():
+    """Resize-convolution generator (src/dcgan.py DCGANUpGenerator): the engine's autograd-free G step on the fp64
+    twin against torch autograd on the oracle modules (which tests/test_oracle_golden.py pins to the reference)."""
+    torch.manual_seed(0)
+    G = R.OracleDCGANUpGenerator(16, 32, 3, 4).double()
+    D = R.OracleDCGANDiscriminator(32, 3, 4).double()
+    R.seeded_fill_(G, 7), R.seeded_fill_(D, 8)
+    G2, D2 = copy.deepcopy(G), copy.deepcopy(D)
+    for m in (G, D, G2, D2):
+        m.train()
+    noise = R.synthetic_normal(5, 16, seed=4).double()
+    ops = RefOps(torch.float64)
+    Gn, Dn = E.build_upgen_net(G2), E.build_disc_net(D2)
+    assert isinstance(Gn, E.UpGenNet)
+    loss_o = R.generator_loss(D(G(noise)))
+    loss_o.backward()
+    loss_e = E.gen_loss_grads(ops, Gn, Dn, noise)
+    np.testing.assert_allclose(float(loss_e), float(loss_o), rtol=1e-9)
+    assert_close_dict(grads_of(G2), grads_of(G), 1e-6, 1e-10)
+    assert_close_dict(bufs_of(G2), bufs_of(G), 1e-9, 1e-12)
+    # D step / GP step only use the generator's forward
+    real = R.synthetic_images(5, 32, seed=3).double()
+    for p in D.parameters():
+        p.grad = None
+    loss_o = R.discriminator_loss(D(real), D(G(noise).detach()))
+    loss_o.backward()
+    loss_e = E.disc_loss_grads(ops, Gn, Dn, real, noise)
+    np.testing.assert_allclose(float(loss_e), float(loss_o), rtol=1e-9)
+    assert_close_dict(grads_of(D2), grads_of(D), 1e-6, 1e-10)

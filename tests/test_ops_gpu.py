@@ -258,3 +258,32 @@ def test_linear(M, K, Nout, packed):
     wp = hip.pack_linear(wd) if packed else None
     y = hip.linear_affine_act(dev(x), wd, dev(sc), dev(sh), 0.01, wp=wp)
     check(y, y_ref, 1.5e-2 if packed else 2e-5, "linear")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W,Cin,Cout,dtype", [(2, 4, 4, 8, 4, torch.float32), (3, 5, 3, 6, 7, torch.float32),
+                                                  (2, 8, 8, 16, 8, torch.bfloat16), (2, 1, 2, 4, 3, torch.float32)])
+def test_upconv3_block(N, H, W, Cin, Cout, dtype):
+    """Resize-convolution block of DCGANUpGenerator (src/dcgan.py:45-56,76-84): bilinear x2 + reflection pad + 3x3
+    conv, forward / data gradient / weight gradient, NHWC activation and NCHW fp32 image variants."""
+    ref, hip = RefOps(dtype), _hip(dtype)
+    w = rnd((Cout, Cin, 3, 3), 31, (2.0 / (Cin * 9)) ** 0.5)
+    b = rnd((Cout,), 32, 0.1)
+    cr = ConvW(w.clone(), b.clone(), torch.zeros_like(w))
+    ch = ConvW(w.cuda(), b.cuda(), torch.full_like(w, 3.0).cuda())
+    x = rnd((N, H, W, Cin), 33).to(dtype)
+    tol = TOL[dtype]
+    check(hip.upconv3(dev(x), ch, ch.bias), ref.upconv3(x, cr, cr.bias), tol, "upconv3")
+    check(hip.upconv3(dev(x), ch, ch.bias, out_nchw=True), ref.upconv3(x, cr, cr.bias, out_nchw=True), tol,
+          "upconv3(nchw)")
+    gy = rnd((N, 2 * H, 2 * W, Cout), 34).to(dtype)
+    gy_img = rnd((N, Cout, 2 * H, 2 * W), 35)
+    check(hip.upconv3_bwd_data(dev(gy), ch), ref.upconv3_bwd_data(gy, cr), tol, "upconv3_bwd_data")
+    check(hip.upconv3_bwd_data(dev(gy_img), ch, gy_nchw=True), ref.upconv3_bwd_data(gy_img, cr, gy_nchw=True), tol,
+          "upconv3_bwd_data(nchw)")
+    ref.upconv3_wgrad(gy, x, cr, False)
+    hip.upconv3_wgrad(dev(gy), dev(x), ch, False)
+    check(ch.dw, cr.dw, tol * 2, "upconv3_wgrad")
+    ref.upconv3_wgrad(gy_img, x, cr, True, gy_nchw=True)
+    hip.upconv3_wgrad(dev(gy_img), dev(x), ch, True, gy_nchw=True)
+    check(ch.dw, cr.dw, tol * 2, "upconv3_wgrad(nchw, accumulate)")

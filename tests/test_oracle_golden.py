@@ -84,6 +84,26 @@ def test_f3_losses(golden_dir):
     close(D.state_dict()["model.1.1.running_var"], fx["running_var"])
 
 
+@pytest.mark.parametrize("size", [16, 32])
+def test_f4_up_generator(golden_dir, size):
+    """The reference's DCGANUpGenerator (src/dcgan.py, imported when the fixture was made): output, every parameter
+    gradient and the BN buffers of one forward/backward, against the oracle's restatement."""
+    fx = np.load(os.path.join(golden_dir, "f4_upgen_tiny.npz"))
+    G = R.OracleDCGANUpGenerator(16, size, 3, 4, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+    R.seeded_fill_(G, 41)
+    G.train()
+    z = R.synthetic_normal(3, 16, seed=42)
+    y = G(z)
+    cot = R.synthetic_normal(3, 3 * size * size, seed=43).view(3, 3, size, size)
+    (y * cot).sum().backward()
+    np.testing.assert_allclose(y.detach().numpy(), fx[f"y{size}"], rtol=1e-5, atol=1e-6)
+    for k, p in G.named_parameters():
+        ref = fx[f"grad{size}.{k}"]
+        np.testing.assert_allclose(p.grad.numpy(), ref, rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(ref).max())), err_msg=k)
+    for k, b in G.named_buffers():
+        np.testing.assert_allclose(b.numpy(), fx[f"buf{size}.{k}"], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
 def test_f5_trainops(golden_dir):
     """The oracle's three steps (injected noise/eps) reproduce the reference's *LossVAE.train_ops."""
     fx = np.load(os.path.join(golden_dir, "f5_trainops_vae.npz"))

@@ -193,3 +193,35 @@ def test_graph_replay_equals_eager():
     assert float(oda["state"][0]["step"]) == float(odb["state"][0]["step"]) == 10.0
     for k in sda:
         assert torch.equal(sda[k], sdb[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [16, 32])
+def test_up_generator_reference_fixture(size):
+    """The reference's DCGANUpGenerator (fixture F4, generated by importing src/dcgan.py): output, every parameter
+    gradient and the BatchNorm buffers of one forward/backward through the product module on the HIP kernels."""
+    import numpy as np
+    import torch.nn as nn
+    from rna_gan_amd import DCGANUpGenerator
+    from rna_gan_amd import engine as E
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "f4_upgen_tiny.npz"))
+    G = DCGANUpGenerator(16, size, 3, 4, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+    R.seeded_fill_(G, 41)
+    G = G.cuda().train().set_precision("fp32")
+    z = R.synthetic_normal(3, 16, seed=42).cuda()
+    cot = R.synthetic_normal(3, 3 * size * size, seed=43).view(3, 3, size, size).cuda().contiguous()
+    ops, net = G.runtime()
+    y, ctx = E.upgen_forward(ops, net, z)
+    E.upgen_backward(ops, net, ctx, cot, accumulate=False)
+    np.testing.assert_allclose(y.cpu().numpy(), fx[f"y{size}"], rtol=2e-4, atol=2e-5)
+    for k, p in G.named_parameters():
+        ref = fx[f"grad{size}.{k}"]
+        scale = max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * scale, err_msg=k)
+    for k, b in G.named_buffers():
+        np.testing.assert_allclose(b.cpu().numpy(), fx[f"buf{size}.{k}"], rtol=1e-4, atol=1e-5, err_msg=k)
+    # the module's own forward (train mode) gives the same image
+    G2 = DCGANUpGenerator(16, size, 3, 4)
+    R.seeded_fill_(G2, 41)
+    G2 = G2.cuda().train().set_precision("fp32")
+    np.testing.assert_allclose(G2(z).cpu().numpy(), fx[f"y{size}"], rtol=2e-4, atol=2e-5)
