@@ -275,6 +275,10 @@ int rg_upconv3_bwd_data(const void* gy, int gy_nchw_f32, const float* w, void* g
 int rg_upconv3_wgrad(const void* gy, int gy_nchw_f32, const void* x, float* dw, int N, int H, int W, int Cin, int Cout,
                      int dtype, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
+/* Generated images for export (src/gan_utils.py:236-241): y_nhwc[N][H][W][C] = x_nchw * 0.5 + 0.5 (the inverse of
+ * the input normalisation, transforms.Normalize(-mean/std, 1/std) with mean = std = 0.5) in NHWC order. */
+int rg_export_images_nhwc(const float* x_nchw, float* y_nhwc, int N, int C, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

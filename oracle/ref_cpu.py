@@ -375,3 +375,20 @@ def train_iteration(G, D, opt_g, opt_d, real, noises: Sequence[torch.Tensor], ep
     out["d"] = disc_step(G, D, opt_d, real, noises[1], clip=clip)
     out["gp"] = gp_step(G, D, opt_d, real, noises[2], eps, lambd=lambd)
     return out
+
+
+def generate_images(generator, gene_exp=None, sample_size=64, betavae=None):
+    """Restatement of generate_images (src/gan_utils.py:197-244) on explicit modules: conditioned noise (:211-216),
+    generator on chunks of 10 rows in its current mode (:217-221 / :226-231), un-normalise + NHWC (:236-243)."""
+    if gene_exp is not None:
+        noise = torch.FloatTensor(sample_size, generator.encoding_dims).uniform_(-0.3, 0.3)
+        z, _, _ = betavae.encode(gene_exp)
+        noise = noise + z.detach()
+        noise = (noise - torch.mean(noise, dim=0)) / torch.std(noise, dim=0)
+    else:
+        noise = generator.sampler(sample_size, torch.device("cpu"))[0]
+    with torch.no_grad():
+        images = torch.cat([generator(chunk) for chunk in torch.split(noise, 10)], dim=0)
+    images = images.view((-1, 3, images.shape[-2], images.shape[-1]))
+    images = (images - (-1.0)) / 2.0                      # Normalize((-mean/std), (1/std)), mean = std = 0.5
+    return images.permute(0, 2, 3, 1).contiguous().numpy()

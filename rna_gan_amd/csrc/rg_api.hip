@@ -176,7 +176,8 @@ extern "C" int rg_linear_affine_act(const float* x, int ldx, const float* w, con
                                     const float* shift, float* y, int ldy, int M, int K, int Nout, float slope,
                                     int algo, void* ws, size_t ws_bytes, void* stream) {
   RG_REQUIRE(x && y && M > 0 && K > 0 && Nout > 0 && ldx >= K && ldy >= Nout, RG_EINVAL, "linear: bad args");
-  if (algo != RG_ALGO_GENERIC && wp) {
+  // AUTO falls back to the generic kernel for output widths the MFMA epilogue does not take (Nout % 8)
+  if (algo != RG_ALGO_GENERIC && wp && (Nout % 8 == 0 || algo == RG_ALGO_MFMA)) {
     int kp = (int)rg_align_up((size_t)K, 64);
     size_t xb = rg_align_up((size_t)M * kp * 2, 256);
     RG_REQUIRE(ws && ws_bytes >= (size_t)M * kp * 2, RG_EWORKSPACE, "linear: workspace too small");

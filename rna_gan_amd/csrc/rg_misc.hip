@@ -458,6 +458,25 @@ extern "C" int rg_head_wgrad(const float* gh, const void* a, float* dw, int N, i
   })
 }
 
+// images NCHW fp32 in [-1,1] -> NHWC fp32 in [0,1]: x*0.5 + 0.5 (transforms.Normalize(-mean/std, 1/std) with
+// mean = std = 0.5 followed by permute(0,2,3,1), src/gan_utils.py:236-241)
+__global__ void export_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int HW) {
+  size_t tot = (size_t)N * C * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    size_t t = i / C;
+    size_t p = t % HW, n = t / HW;
+    y[i] = (x[(n * C + c) * HW + p] - (-1.f)) / 2.f;       // (x - (-mean/std)) / (1/std)
+  }
+}
+extern "C" int rg_export_images_nhwc(const float* x_nchw, float* y_nhwc, int N, int C, int H, int W, void* stream) {
+  RG_REQUIRE(x_nchw && y_nhwc && N > 0 && C > 0 && H > 0 && W > 0, RG_EINVAL, "export_images_nhwc: bad args");
+  size_t tot = (size_t)N * C * H * W;
+  hipLaunchKernelGGL(export_nhwc_kernel, dim3(grid_for(tot)), dim3(256), 0, rg_stream(stream), x_nchw, y_nhwc, N, C, H * W);
+  RG_LAUNCH_CHECK("export_images_nhwc");
+  return RG_OK;
+}
+
 extern "C" int rg_widen_bf16(const void* src, float* dst, size_t n, void* stream) {
   RG_REQUIRE(src && dst, RG_EINVAL, "widen_bf16: bad args");
   if (n == 0) return RG_OK;

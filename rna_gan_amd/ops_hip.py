@@ -182,6 +182,14 @@ class HipOps:
                                     self.dt, int(accumulate), self.algo, _ptr(ws), ws.numel(), self.stream),
             "rg_conv_wgrad2"))
 
+    def export_images_nhwc(self, img_nchw):
+        """NCHW fp32 in [-1,1] -> NHWC fp32 in [0,1] (un-normalise + permute, src/gan_utils.py:236-241)."""
+        N, C, H, W = img_nchw.shape
+        assert img_nchw.dtype == torch.float32 and img_nchw.is_contiguous()
+        y = self._f32(N, H, W, C)
+        check(self.lib.rg_export_images_nhwc(_ptr(img_nchw), _ptr(y), N, C, H, W, self.stream), "rg_export_images_nhwc")
+        return y
+
     # ------------------------------------------------------------------ resize-conv block (DCGANUpGenerator)
     def upconv3(self, x, cw: ConvW, bias, out_nchw=False):
         """Conv3x3(ReflectionPad(1)(bilinear x2 (x))) + bias; NHWC activation out, or the NCHW fp32 image."""

@@ -73,3 +73,46 @@ def test_trainer_checkpoint_roundtrip(tmp_path):
         a = tr.generator(z.cuda()).cpu(); b = Go(z)
     tr.generator.train()
     assert float((a - b).abs().max()) <= 5e-2
+
+
+@pytest.mark.gpu
+def test_generate_images_matches_oracle():
+    """Conditioned generator-only inference (src/gan_utils.py:197-244): chunks of 10 in train mode, betaVAE-conditioned
+    noise, un-normalised NHWC export -- product (fp32 kernels) against the oracle restatement with the same CPU draws."""
+    import numpy as np
+    import torch
+    from types import SimpleNamespace
+    from oracle import ref_cpu as R
+    import rna_gan_amd as P
+    from rna_gan_amd.gan_utils import generate_images
+    E_, S = 32, 32
+    Go = R.OracleDCGANGenerator(E_, S, 3, 4)
+    R.seeded_fill_(Go, 61)
+    Go.train()
+    bvo = R.OracleBetaVAE(48, E_, [40, 36, E_], [36, 40], beta=0.005) if hasattr(R, "OracleBetaVAE") else None
+    Gp = P.DCGANGenerator(E_, S, 3, 4)
+    Gp.load_state_dict(Go.state_dict())
+    Gp = Gp.cuda().train().set_precision("fp32")
+    tr = SimpleNamespace(generator=Gp, device=torch.device("cuda:0"))
+    if bvo is not None:
+        R.seeded_fill_(bvo, 62)
+        bvo.eval()
+        bvp = P.betaVAE(48, E_, [40, 36, E_], [36, 40], beta=0.005)
+        bvp.load_state_dict(bvo.state_dict())
+        bvp.eval()
+        rna = R.synthetic_rna(1, 48, seed=63, distinct=1)
+        torch.manual_seed(5)
+        ref = R.generate_images(Go, gene_exp=rna, sample_size=23, betavae=bvo)
+        torch.manual_seed(5)
+        out = generate_images(tr, gene_exp=rna, sample_size=23, betavae=bvp)
+        assert out.shape == ref.shape == (23, S, S, 3) and out.dtype == np.float32
+        np.testing.assert_allclose(out, ref, rtol=0, atol=2e-3)
+        assert 0.0 <= out.min() and out.max() <= 1.0
+    # unconditioned branch: randn on the device in the product, so compare the plumbing with identical noise
+    z = torch.randn(20, E_)
+    with torch.no_grad():
+        ref = torch.cat([Go(c) for c in torch.split(z, 10)], 0)
+    ref = ((ref + 1) / 2).permute(0, 2, 3, 1).numpy()
+    ops, _ = Gp.runtime()
+    imgs = torch.cat([Gp(c.cuda()) for c in torch.split(z, 10)], 0)
+    np.testing.assert_allclose(ops.export_images_nhwc(imgs.contiguous()).cpu().numpy(), ref, rtol=0, atol=2e-3)
