@@ -198,6 +198,7 @@ def main():
         ls = one_step()
         if args.trace_steps:
             e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
+    D_.flush()            # data parallel: the last train_op's all-reduce + optimizer step belong to the timed work
     barrier()
     dt = time.perf_counter() - t0
     if args.trace_steps and rank == 0:

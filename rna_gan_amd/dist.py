@@ -9,8 +9,9 @@ the gradient of the MEAN over ranks of the rank-local losses.
   the volume is what matters.  In bf16 precision mode the flat fp32 gradient is compressed to bf16 for
   the wire (805 MB -> 403 MB per iteration and rank) and widened again (two streaming HIP kernels);
   the MFMA operands that produced it were bf16 already (DESIGN "Numerics").  fp32 mode sends fp32.
-* Collectives are never captured into HIP graphs: for world > 1 each train_op is two graphs (gradient
-  computation / optimizer step) with the eager all-reduce between them (losses._Runner).
+* Collectives are never captured into HIP graphs: for world > 1 each train_op is graph(prefix) / graph(rest) /
+  eager all-reduce start, and the wait + optimizer-step graph are issued by the NEXT train_op after its prefix
+  (which reads the other network), so the transfer overlaps with compute (losses._Runner.run_dp).
 """
 from __future__ import annotations
 
@@ -59,10 +60,12 @@ def grad_scale() -> float:
 _wire = {}
 
 
-def allreduce_sum_(flat: torch.Tensor, compress: bool = False):
-    """In-place SUM all-reduce of a flat fp32 gradient buffer, in fixed-size buckets."""
+def allreduce_start(flat: torch.Tensor, compress: bool = False):
+    """Start the in-place SUM all-reduce of a flat fp32 gradient buffer (fixed-size buckets, asynchronous: RCCL runs
+    on its own stream behind everything enqueued so far on the current one).  Returns a handle for
+    allreduce_finish(); None when there is nothing to reduce.  `flat` must not be written before the finish."""
     if not active():
-        return
+        return None
     if compress and COMPRESS and flat.is_cuda and flat.dtype == torch.float32:
         from . import _abi
         lib = _abi.load()
@@ -73,19 +76,47 @@ def allreduce_sum_(flat: torch.Tensor, compress: bool = False):
             wire = _wire[key] = torch.empty(n, dtype=torch.bfloat16, device=flat.device)
         stream = torch.cuda.current_stream(flat.device).cuda_stream
         _abi.check(lib.rg_cast_pad(flat.data_ptr(), wire.data_ptr(), 1, n, n, _abi.RG_BF16, stream), "rg_cast_pad")
-        _buckets(wire, BUCKET_BYTES // 2)
-        _abi.check(lib.rg_widen_bf16(wire.data_ptr(), flat.data_ptr(), n, stream), "rg_widen_bf16")
+        return (wire, flat, _launch_buckets(wire, BUCKET_BYTES // 2))
+    return (None, flat, _launch_buckets(flat, BUCKET_BYTES // flat.element_size()))
+
+
+def allreduce_finish(handle):
+    """Make the current stream wait for the all-reduce (and widen the bf16 wire buffer back into the gradients)."""
+    if handle is None:
         return
-    _buckets(flat, BUCKET_BYTES // flat.element_size())
+    wire, flat, works = handle
+    for w in works:
+        w.wait()
+    if wire is not None:
+        from . import _abi
+        stream = torch.cuda.current_stream(flat.device).cuda_stream
+        _abi.check(_abi.load().rg_widen_bf16(wire.data_ptr(), flat.data_ptr(), flat.numel(), stream), "rg_widen_bf16")
 
 
-def _buckets(t: torch.Tensor, elems: int):
+def allreduce_sum_(flat: torch.Tensor, compress: bool = False):
+    """In-place SUM all-reduce of a flat fp32 gradient buffer, in fixed-size buckets."""
+    allreduce_finish(allreduce_start(flat, compress))
+
+
+def _launch_buckets(t: torch.Tensor, elems: int):
     works = []
     n = t.numel()
     for off in range(0, n, elems):
         works.append(dist.all_reduce(t[off:min(n, off + elems)], op=dist.ReduceOp.SUM, async_op=True))
-    for w in works:
-        w.wait()
+    return works
+
+
+_flush_hook = [None]
+
+
+def set_flush_hook(fn):
+    _flush_hook[0] = fn
+
+
+def flush():
+    """Apply an optimizer step that a data-parallel train_op left in flight (losses.flush); no-op otherwise."""
+    if _flush_hook[0] is not None:
+        _flush_hook[0]()
 
 
 def broadcast_(t: torch.Tensor, src: int = 0):

@@ -391,11 +391,17 @@ def gen_backward(ops, G: GenNet, ctx, gimg, accumulate: bool):
 # The three train_ops bodies (gradient part; the optimizer step is applied by the caller so that
 # a data-parallel all-reduce can sit between the two)
 # --------------------------------------------------------------------------------------------
-def gen_loss_grads(ops, G: GenNet, D: DiscNet, noise, grad_scale: float = 1.0):
-    """src/wgan_loss.py:113-126: loss = mean(-D(G(z))); fills G's gradients.  D's weight
-    gradients, which the reference computes and discards, are not computed."""
-    n = noise.shape[0]
-    img, gctx = _gen_fwd(ops, G, noise)
+# Each body is split into a PREFIX that reads only one of the two networks and the REST.  A data-parallel run
+# keeps the previous train_op's gradient all-reduce and optimizer step of the OTHER network in flight while the
+# prefix executes (losses._Runner.run_dp); a single process simply runs rest(prefix()).
+def gen_loss_prefix(ops, G, noise):
+    """G(z): reads the generator only."""
+    return _gen_fwd(ops, G, noise)
+
+
+def gen_loss_rest(ops, G, D: DiscNet, pre, grad_scale: float = 1.0):
+    img, gctx = pre
+    n = img.shape[0]
     out, dctx = disc_forward(ops, D, img)
     loss = ops.mean_diff(out, None, -1.0)
     gimg = disc_backward(ops, D, dctx, -grad_scale / n, wgrad=False, accumulate=False, need_input_grad=True)
@@ -403,11 +409,20 @@ def gen_loss_grads(ops, G: GenNet, D: DiscNet, noise, grad_scale: float = 1.0):
     return loss
 
 
-def disc_loss_grads(ops, G: GenNet, D: DiscNet, real, noise, grad_scale: float = 1.0):
-    """src/wgan_loss.py:241-260: loss = mean(D(G(z).detach()) - D(real)); fills D's gradients.
-    Forward order D(real), G(z), D(fake) as in the reference (BN running statistics)."""
-    n = real.shape[0]
-    out_r, ctx_r = disc_forward(ops, D, real)
+def gen_loss_grads(ops, G: GenNet, D: DiscNet, noise, grad_scale: float = 1.0):
+    """src/wgan_loss.py:113-126: loss = mean(-D(G(z))); fills G's gradients.  D's weight
+    gradients, which the reference computes and discards, are not computed."""
+    return gen_loss_rest(ops, G, D, gen_loss_prefix(ops, G, noise), grad_scale)
+
+
+def disc_loss_prefix(ops, D: DiscNet, real):
+    """D(real): reads the discriminator only."""
+    return disc_forward(ops, D, real)
+
+
+def disc_loss_rest(ops, G, D: DiscNet, pre, noise, grad_scale: float = 1.0):
+    out_r, ctx_r = pre
+    n = out_r.shape[0]
     img, _ = _gen_fwd(ops, G, noise, keep=False)
     out_f, ctx_f = disc_forward(ops, D, img)
     loss = ops.mean_diff(out_f, out_r, 1.0)
@@ -415,12 +430,26 @@ def disc_loss_grads(ops, G: GenNet, D: DiscNet, real, noise, grad_scale: float =
     return loss
 
 
+def disc_loss_grads(ops, G: GenNet, D: DiscNet, real, noise, grad_scale: float = 1.0):
+    """src/wgan_loss.py:241-260: loss = mean(D(G(z).detach()) - D(real)); fills D's gradients.
+    Forward order D(real), G(z), D(fake) as in the reference (BN running statistics)."""
+    return disc_loss_rest(ops, G, D, disc_loss_prefix(ops, D, real), noise, grad_scale)
+
+
+def gp_loss_prefix(ops, G, real, noise, eps):
+    """fake = G(z); xhat = eps*real + (1-eps)*fake: reads the generator only."""
+    img, _ = _gen_fwd(ops, G, noise, keep=False)
+    return ops.interp(real, img, eps)
+
+
+def gp_loss_rest(ops, D: DiscNet, xhat, lambd: float, grad_scale: float = 1.0):
+    return disc_gradient_penalty(ops, D, xhat, lambd * grad_scale)
+
+
 def gp_loss_grads(ops, G: GenNet, D: DiscNet, real, noise, eps: float, lambd: float, grad_scale: float = 1.0):
     """src/wgan_loss.py:371-387: fake = G(z); xhat = eps*real + (1-eps)*fake; D gradients of
     lambd*GP.  The generator gradients the reference produces here are never used and are skipped."""
-    img, _ = _gen_fwd(ops, G, noise, keep=False)
-    xhat = ops.interp(real, img, eps)
-    return disc_gradient_penalty(ops, D, xhat, lambd * grad_scale)
+    return gp_loss_rest(ops, D, gp_loss_prefix(ops, G, real, noise, eps), lambd, grad_scale)
 
 
 # --------------------------------------------------------------------------------------------

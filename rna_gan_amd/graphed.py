@@ -50,13 +50,15 @@ class StepGraph:
     def _run(self):
         return self.fn(*self.static_in)
 
-    def __call__(self, *inputs):
+    def __call__(self, *inputs, allow_capture=True):
+        """allow_capture=False: run eagerly this time and do not capture yet (the function reads tensors whose
+        addresses are not stable yet, e.g. the outputs of another StepGraph that is still in its eager phase)."""
         for s, t in zip(self.static_in, inputs):
             if s.shape != t.shape:
                 raise RuntimeError("StepGraph: input shape changed")
             s.copy_(t, non_blocking=True)
         self.calls += 1
-        if self.failed or self.calls <= WARMUP_CALLS:
+        if self.failed or self.calls <= WARMUP_CALLS or (self.graph is None and not allow_capture):
             return self._run()
         if self.graph is None:
             try:

@@ -16,6 +16,8 @@ computed; in a data-parallel run the flat gradient buffer is all-reduced before 
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -109,52 +111,127 @@ def _apply(module, optimizer):
     return module.flat.data[:1]          # a tensor result, so that this half can be a graph of its own
 
 
-# gradient halves (no collective, no optimizer): capturable on their own in a data-parallel run
-def _g_grads(generator, discriminator, noise):
-    ops, gn, dn = _nets(generator, discriminator)
-    return E.gen_loss_grads(ops, gn, dn, noise.contiguous().float(), grad_scale=D_.grad_scale())
+# Every train_op body is  rest(prefix(...))  where the PREFIX reads only ONE of the two networks (engine.*_prefix):
+#   G step : prefix = conditioned noise + G(z)            (reads G)   rest = D(G(z)), backward through D and G
+#   D step : prefix = (clip) + D(real) [+ noise]          (reads D)   rest = G(z), D(fake), backward through D
+#   GP step: prefix = noise + G(z) + interpolation        (reads G)   rest = penalty forward / double backward in D
+# In a data-parallel run the previous train_op's all-reduce and optimizer step of the OTHER network stay in flight
+# while the prefix runs (run_dp below).
+def _g_prefix(generator, discriminator, noise):
+    ops, gn, _ = _nets(generator, discriminator)
+    return E.gen_loss_prefix(ops, gn, noise.contiguous().float())
 
 
-def _d_grads(generator, discriminator, real, noise, clip):
+def _g_rest(generator, discriminator, pre):
     ops, gn, dn = _nets(generator, discriminator)
+    return E.gen_loss_rest(ops, gn, dn, pre, grad_scale=D_.grad_scale())
+
+
+def _d_prefix(generator, discriminator, real, noise, clip):
+    ops, _, dn = _nets(generator, discriminator)
     if clip is not None:
         ops.clamp_(discriminator.flat.data, clip[0], clip[1])      # every D parameter (wgan_loss.py:213-215)
         discriminator.weights_changed()
-    return E.disc_loss_grads(ops, gn, dn, real.contiguous().float(), noise.contiguous().float(),
-                             grad_scale=D_.grad_scale())
+    return E.disc_loss_prefix(ops, dn, real.contiguous().float()), noise.contiguous().float()
 
 
-def _gp_grads(generator, discriminator, real, noise, eps, lambd):
+def _d_rest(generator, discriminator, pre):
     ops, gn, dn = _nets(generator, discriminator)
-    return E.gp_loss_grads(ops, gn, dn, real.contiguous().float(), noise.contiguous().float(),
-                           eps if torch.is_tensor(eps) else float(eps), float(lambd), grad_scale=D_.grad_scale())
+    fwd_real, noise = pre
+    return E.disc_loss_rest(ops, gn, dn, fwd_real, noise, grad_scale=D_.grad_scale())
+
+
+def _gp_prefix(generator, discriminator, real, noise, eps):
+    ops, gn, _ = _nets(generator, discriminator)
+    return E.gp_loss_prefix(ops, gn, real.contiguous().float(), noise.contiguous().float(),
+                            eps if torch.is_tensor(eps) else float(eps))
+
+
+def _gp_rest(generator, discriminator, xhat, lambd):
+    ops, _, dn = _nets(generator, discriminator)
+    return E.gp_loss_rest(ops, dn, xhat, float(lambd), grad_scale=D_.grad_scale())
 
 
 def _g_step(generator, discriminator, optimizer_generator, noise):
-    loss = _g_grads(generator, discriminator, noise)
+    """Eager G train_op body (gradients + all-reduce + optimizer step)."""
+    loss = _g_body(generator, discriminator).grads(noise)
     _finish(generator, optimizer_generator)
     return loss
 
 
 def _d_step(generator, discriminator, optimizer_discriminator, real, noise, clip):
-    loss = _d_grads(generator, discriminator, real, noise, clip)
+    loss = _d_body(generator, discriminator, clip).grads(real, noise)
     _finish(discriminator, optimizer_discriminator)
     return loss
 
 
 def _gp_step(generator, discriminator, optimizer_discriminator, real, noise, eps, lambd):
     """eps: python float or 1-element device tensor."""
-    loss = _gp_grads(generator, discriminator, real, noise, eps, lambd)
+    loss = _gp_body(generator, discriminator, lambd).grads(real, noise, eps)
     _finish(discriminator, optimizer_discriminator)
     return loss
 
 
-def _dispatch(runner, key, grads_fn, full_fn, inputs, generator, discriminator, stepped, optimizer):
-    """single process: one graph per train_op; data parallel: gradients graph, eager all-reduce, step graph"""
+class _Body:
+    """One train_op: prefix(*inputs) -> pre ; rest(pre) -> loss ; which network the prefix reads."""
+
+    def __init__(self, prefix, rest, prefix_reads):
+        self.prefix, self.rest, self.prefix_reads = prefix, rest, prefix_reads
+
+    def grads(self, *inputs):
+        return self.rest(self.prefix(*inputs))
+
+
+def _g_body(generator, discriminator, noise_fn=None):
+    nf = noise_fn or (lambda nz: nz)
+    return _Body(lambda *a: _g_prefix(generator, discriminator, nf(*a)),
+                 lambda pre: _g_rest(generator, discriminator, pre), generator)
+
+
+def _d_body(generator, discriminator, clip, noise_fn=None):
+    nf = noise_fn or (lambda nz: nz)
+    return _Body(lambda real, *a: _d_prefix(generator, discriminator, real, nf(*a), clip),
+                 lambda pre: _d_rest(generator, discriminator, pre), discriminator)
+
+
+def _gp_body(generator, discriminator, lambd, noise_fn=None):
+    nf = noise_fn or (lambda nz: nz)
+    return _Body(lambda real, *a: _gp_prefix(generator, discriminator, real, nf(*a[:-1]), a[-1]),
+                 lambda xhat: _gp_rest(generator, discriminator, xhat, lambd), generator)
+
+
+def _dispatch(runner, key, body, inputs, generator, discriminator, stepped, optimizer):
+    """single process: one graph per train_op (gradients + optimizer step); data parallel: see _Runner.run_dp"""
     mods = [generator, discriminator]
     if D_.active():
-        return runner.run_dp(key, grads_fn, inputs, mods, stepped, optimizer)
-    return runner.run(key, full_fn, inputs, mods, [optimizer])
+        return runner.run_dp(key, body, inputs, mods, stepped, optimizer)
+
+    def full(*a):
+        loss = body.grads(*a)
+        _finish(stepped, optimizer)
+        return loss
+    return runner.run(key, full, inputs, mods, [optimizer])
+
+
+# data-parallel runs: the gradient all-reduce + optimizer step of the last train_op, not yet applied
+_PENDING = [None]
+OVERLAP = os.environ.get("RNAGAN_DP_OVERLAP", "1") != "0"
+
+
+class _Pending:
+    def __init__(self, module, optimizer, handle):
+        self.module, self.optimizer, self.handle = module, optimizer, handle
+
+
+def flush():
+    """Apply the optimizer step a data-parallel train_op may have left in flight (all-reduce started, update not
+    applied yet).  Called before anything reads parameters outside the train_ops: state_dict(), forward(), save."""
+    pend, _PENDING[0] = _PENDING[0], None
+    if pend is None:
+        return
+    D_.allreduce_finish(pend.handle)
+    _APPLY_RUNNER.run(("apply", id(pend.module)), lambda: _apply(pend.module, pend.optimizer), [], [],
+                      [pend.optimizer], [pend.module])
 
 
 class _Runner:
@@ -163,24 +240,51 @@ class _Runner:
 
     def __init__(self):
         self._graphs = {}
+        self._pre = {}
 
     def __getstate__(self):          # loss objects are pickled into checkpoints; graphs are not state
         return {}
 
     def __setstate__(self, state):
         self._graphs = {}
+        self._pre = {}
 
-    def run_dp(self, key, grads_fn, inputs, modules, stepped, optimizer):
-        """Data-parallel form: graph(gradients) -> eager RCCL all-reduce -> graph(optimizer step)."""
-        loss = self.run(key + ("grads",), grads_fn, inputs, modules, [], [])
-        _reduce(stepped)
-        self.run(key + ("apply",), lambda: _apply(stepped, optimizer), [], [], [optimizer], [stepped])
+    def run_dp(self, key, body, inputs, modules, stepped, optimizer):
+        """Data-parallel form.  Collectives are never captured, so a train_op is graph(prefix) -> graph(rest) ->
+        eager all-reduce START; the all-reduce is only waited for -- and the optimizer step applied (a graph of its
+        own) -- by the NEXT train_op after it has enqueued its prefix, which reads the other network: the RCCL
+        transfer over xGMI overlaps with that compute.  flush() applies a trailing update."""
+        pend = _PENDING[0]
+        if pend is not None and (not OVERLAP or pend.module is body.prefix_reads):
+            flush()                                   # the prefix needs the updated weights: no overlap possible
+        sg_pre = self._step_graph(key + ("pre",), body.prefix, inputs, [body.prefix_reads], [], [])
+        pre = sg_pre(*inputs) if sg_pre is not None else body.prefix(*inputs)
+        flush()
+        # the rest reads the prefix's outputs through a holder: they are the prefix graph's static outputs once it is
+        # captured, so the rest graph is tied to that prefix graph and may only be captured after it
+        holder = self._pre.setdefault((key, id(sg_pre)), {})
+        holder["pre"] = pre
+        sg_rest = self._step_graph(key + ("rest", id(sg_pre)), lambda: body.rest(holder["pre"]), [], modules, [], [])
+        if sg_rest is not None:
+            loss = sg_rest(allow_capture=sg_pre is not None and sg_pre.graph is not None)
+        else:
+            loss = body.rest(pre)
+        ops, _ = stepped.runtime()
+        handle = D_.allreduce_start(stepped.flat.grad, compress=(ops.act_dtype == torch.bfloat16))
+        _PENDING[0] = _Pending(stepped, optimizer, handle)
+        if not OVERLAP:
+            flush()
         return loss
 
     def run(self, key, fn, inputs, modules, optimizers, stepped=None):
+        sg = self._step_graph(key, fn, inputs, modules, optimizers, stepped)
+        return sg(*inputs) if sg is not None else fn(*inputs)
+
+    def _step_graph(self, key, fn, inputs, modules, optimizers, stepped=None):
+        """The StepGraph for this body / launch-sequence variant, or None when it has to run eagerly."""
         from . import graphed
         if not graphed.ENABLED:
-            return fn(*inputs)
+            return None
         if stepped is None:
             stepped = [o._module for o in optimizers if getattr(o, "_module", None) is not None]
         # the launch sequence depends on which packed weights are stale: one graph per pattern
@@ -190,9 +294,13 @@ class _Runner:
         if sg is None:
             hip_opts = [o for o in optimizers if hasattr(o, "note_replayed")]
             if len(hip_opts) != len(optimizers):
-                return fn(*inputs)          # a foreign optimizer keeps host-side state: no capture
+                return None                 # a foreign optimizer keeps host-side state: no capture
             sg = self._graphs[key] = graphed.StepGraph(fn, inputs, modules, hip_opts, stepped)
-        return sg(*inputs)
+        return sg
+
+
+_APPLY_RUNNER = _Runner()
+D_.set_flush_hook(flush)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -208,8 +316,7 @@ class WassersteinGeneratorLoss(GeneratorLoss):
 
     def step(self, generator, discriminator, optimizer_generator, noise):
         """The train_op body on explicit inputs; returns the loss as a 1-element device tensor."""
-        return _dispatch(self._runner, ("g",), lambda nz: _g_grads(generator, discriminator, nz),
-                         lambda nz: _g_step(generator, discriminator, optimizer_generator, nz), [noise],
+        return _dispatch(self._runner, ("g",), _g_body(generator, discriminator), [noise],
                          generator, discriminator, generator, optimizer_generator)
 
     def train_ops(self, generator, discriminator, optimizer_generator, device, batch_size, labels=None):
@@ -229,8 +336,7 @@ class WassersteinDiscriminatorLoss(DiscriminatorLoss):
 
     def step(self, generator, discriminator, optimizer_discriminator, real, noise):
         clip = self.clip
-        return _dispatch(self._runner, ("d", clip), lambda r, nz: _d_grads(generator, discriminator, r, nz, clip),
-                         lambda r, nz: _d_step(generator, discriminator, optimizer_discriminator, r, nz, clip),
+        return _dispatch(self._runner, ("d", clip), _d_body(generator, discriminator, clip),
                          [real, noise], generator, discriminator, discriminator, optimizer_discriminator)
 
     def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
@@ -249,9 +355,7 @@ class WassersteinGradientPenalty(DiscriminatorLoss):
     def step(self, generator, discriminator, optimizer_discriminator, real, noise, eps):
         """eps: 1-element float32 device tensor (read inside the graph)."""
         lambd = self.lambd
-        return _dispatch(self._runner, ("gp", lambd),
-                         lambda r, nz, e: _gp_grads(generator, discriminator, r, nz, e, lambd),
-                         lambda r, nz, e: _gp_step(generator, discriminator, optimizer_discriminator, r, nz, e, lambd),
+        return _dispatch(self._runner, ("gp", lambd), _gp_body(generator, discriminator, lambd),
                          [real, noise, eps], generator, discriminator, discriminator, optimizer_discriminator)
 
     def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
@@ -304,9 +408,7 @@ class WassersteinGeneratorLossVAE(GeneratorLoss, _VAEMixin):
 
     def step(self, generator, discriminator, optimizer_generator, rna, u):
         return _dispatch(self._runner, ("g",),
-                         lambda r, uu: _g_grads(generator, discriminator, self._noise(generator, r, uu)),
-                         lambda r, uu: _g_step(generator, discriminator, optimizer_generator,
-                                               self._noise(generator, r, uu)),
+                         _g_body(generator, discriminator, lambda r, uu: self._noise(generator, r, uu)),
                          [rna, u], generator, discriminator, generator, optimizer_generator)
 
     def train_ops(self, generator, discriminator, optimizer_generator, device, batch_size, real_inputs,
@@ -328,9 +430,7 @@ class WassersteinDiscriminatorLossVAE(DiscriminatorLoss, _VAEMixin):
     def step(self, generator, discriminator, optimizer_discriminator, real, rna, u):
         clip = self.clip
         return _dispatch(self._runner, ("d", clip),
-                         lambda x, r, uu: _d_grads(generator, discriminator, x, self._noise(generator, r, uu), clip),
-                         lambda x, r, uu: _d_step(generator, discriminator, optimizer_discriminator, x,
-                                                  self._noise(generator, r, uu), clip),
+                         _d_body(generator, discriminator, clip, lambda r, uu: self._noise(generator, r, uu)),
                          [real, rna, u], generator, discriminator, discriminator, optimizer_discriminator)
 
     def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
@@ -350,10 +450,7 @@ class WassersteinGradientPenaltyVAE(DiscriminatorLoss, _VAEMixin):
     def step(self, generator, discriminator, optimizer_discriminator, real, rna, u, eps):
         lambd = self.lambd
         return _dispatch(self._runner, ("gp", lambd),
-                         lambda x, r, uu, e: _gp_grads(generator, discriminator, x, self._noise(generator, r, uu), e,
-                                                       lambd),
-                         lambda x, r, uu, e: _gp_step(generator, discriminator, optimizer_discriminator, x,
-                                                      self._noise(generator, r, uu), e, lambd),
+                         _gp_body(generator, discriminator, lambd, lambda r, uu: self._noise(generator, r, uu)),
                          [real, rna, u, eps], generator, discriminator, discriminator, optimizer_discriminator)
 
     def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):

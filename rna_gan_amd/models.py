@@ -16,6 +16,7 @@ from typing import List
 import torch
 import torch.nn as nn
 
+from . import dist as D_
 from . import engine as E
 
 
@@ -175,9 +176,14 @@ class _HipModule(nn.Module):
                     cw.shadow_version = cw.version
 
     def load_state_dict(self, *a, **k):
+        D_.flush()
         r = super().load_state_dict(*a, **k)
         self.weights_changed()
         return r
+
+    def state_dict(self, *a, **k):
+        D_.flush()          # a data-parallel train_op may have left this module's optimizer step in flight
+        return super().state_dict(*a, **k)
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
@@ -249,6 +255,7 @@ class DCGANGenerator(Generator):
     def forward(self, x, feature_matching=False):
         """Generated images (N, ch, S, S) fp32.  Train mode: batch statistics + running-stat update
         (what the reference's generator(noise) calls do).  Inference only: no autograd graph."""
+        D_.flush()
         ops, net = self.runtime()
         x = x.view(-1, x.size(1)).contiguous().float()
         if self.training:
@@ -290,6 +297,7 @@ class DCGANUpGenerator(Generator):
         return E.build_upgen_net(self)
 
     def forward(self, x, feature_matching=False):
+        D_.flush()
         ops, net = self.runtime()
         x = x.view(-1, x.size(1)).contiguous().float()
         if self.training:
@@ -326,6 +334,7 @@ class DCGANDiscriminator(Discriminator):
     def forward(self, x, feature_matching=False):
         if feature_matching:
             raise NotImplementedError("feature_matching is not on the RNA-GAN path")
+        D_.flush()
         ops, net = self.runtime()
         if not self.training:
             raise NotImplementedError("the reference only ever runs the discriminator in train mode")

@@ -67,10 +67,14 @@ class Adam(torch.optim.Adam):
             self.state[p]["step"] = torch.tensor(float(self._host_steps))
 
     def state_dict(self):
+        from . import dist as D_
+        D_.flush()                 # a data-parallel train_op may have left this optimizer's step in flight
         self._sync_step_state()
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
+        from . import dist as D_
+        D_.flush()
         super().load_state_dict(state_dict)
         self._flat_id = None      # re-home the loaded moments into the flat buffers at next use
 

@@ -34,17 +34,19 @@ for it in range(5):
     nz = [R.synthetic_normal(n, enc, seed=200 + 3 * it + j).cuda() for j in range(3)]
     eps = torch.tensor([0.1 + 0.2 * it], device="cuda")
     out += [lg.step(G, D, og, nz[0]).item(), ld.step(G, D, od, real, nz[1]).item(), lp.step(G, D, od, real, nz[2], eps).item()]
+PL.flush()     # data parallel: the last train_op's optimizer step may still be in flight
 torch.save({"losses": out, "g": G.flat.data.cpu(), "d": D.flat.data.cpu()}, os.environ["OUT"])
 if torch.distributed.is_initialized():
     torch.distributed.destroy_process_group()
 '''
 
 
-def _run(tmp_path, force):
+def _run(tmp_path, force, overlap=1):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = str(tmp_path / ("dp%d.pt" % force))
-    env = dict(os.environ, REPO=repo, OUT=out, RNAGAN_FORCE_DP=str(force), MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(29533 + force), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = str(tmp_path / ("dp%d_%d.pt" % (force, overlap)))
+    env = dict(os.environ, REPO=repo, OUT=out, RNAGAN_FORCE_DP=str(force), RNAGAN_DP_OVERLAP=str(overlap),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29533 + force + 2 * overlap), RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=150)
     assert r.returncode == 0, r.stderr[-3000:]
     import torch
@@ -60,3 +62,8 @@ def test_dp_path_single_rank(tmp_path):
     for k in ("g", "d"):
         du = (a[k] - b[k]).norm() / (a[k].norm() + 1e-30)
         assert float(du) <= 1e-2, (k, float(du))
+    # deferring the optimizer step behind the next train_op's prefix (overlap) must not change a single bit
+    c = _run(tmp_path, 1, overlap=0)
+    assert b["losses"] == c["losses"], (b["losses"], c["losses"])
+    for k in ("g", "d"):
+        assert torch.equal(b[k], c[k]), k
