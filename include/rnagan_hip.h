@@ -240,9 +240,11 @@ int rg_clamp(float* p, size_t n, float lo, float hi, void* stream);
  * a captured HIP graph and be replayed every step: hyper[0..6] = {beta1, beta2, 1-beta1, 1-beta2, eps,
  * lr/bias_correction1, 1/sqrt(bias_correction2)}, produced by rg_adam_hyper_dev.
  * shadow_bf16 (may be NULL): bf16[n], receives the rounded updated parameters in the same launch -- for the
- * tap-major conv weights that IS the wdn operand of rg_conv_down, so no separate pack pass reads the masters. */
+ * tap-major conv weights that IS the wdn operand of rg_conv_down, so no separate pack pass reads the masters.
+ * grad_bf16 (may be NULL): bf16[n] gradient read INSTEAD of g -- the all-reduced bf16 wire buffer of a data-parallel
+ * run, which then needs no widening pass back to fp32. */
 int rg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, void* shadow_bf16,
-                     void* stream);
+                     const void* grad_bf16, void* stream);
 /* ++(*step_dev) and recompute hyper[0..6] from it on the device (double arithmetic, one thread): with
  * this launch in front of rg_adam_step_dev the whole optimizer step replays from a graph untouched. */
 int rg_adam_hyper_dev(int* step_dev, double lr, double beta1, double beta2, double eps, float* hyper, void* stream);

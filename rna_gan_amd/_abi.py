@@ -72,7 +72,7 @@ PROTOTYPES = {
     "rg_upconv3_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_upconv3_wgrad": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_export_images_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
-    "rg_adam_step_dev": (_i, [_p, _p, _p, _p, _z, _p, _p, _p]),
+    "rg_adam_step_dev": (_i, [_p, _p, _p, _p, _z, _p, _p, _p, _p]),
     "rg_interp_dev": (_i, [_p, _p, _p, _z, _p, _p]),
     "rg_adam_hyper_dev": (_i, [_p, _d, _d, _d, _d, _p, _p]),
     "rg_widen_bf16": (_i, [_p, _p, _z, _p]),

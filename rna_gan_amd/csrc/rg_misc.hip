@@ -91,10 +91,20 @@ struct Adam {
 struct AdamDev {
   float* p; const float* g; float* m; float* v; const float* hyper;
   uint16_t* shadow;      // optional bf16 image of the updated parameters (the GEMM operand of the tap-major convs)
+  const uint16_t* gw;    // optional: the gradient as bf16 (the all-reduced wire buffer of a data-parallel run), read
+                         // instead of g -- saves the pass that widens it back to fp32
   __device__ __forceinline__ Adam load() const {
     return Adam{p, g, m, v, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6]};
   }
   __device__ void vec(size_t i) const {
+    if (gw) {
+      const Adam a = load();
+      const uint2 w = *(const uint2*)(gw + i);
+      float4 P = *(float4*)(p + i), M = *(float4*)(m + i), V = *(float4*)(v + i);
+      a.upd(P.x, __uint_as_float(w.x << 16), M.x, V.x); a.upd(P.y, __uint_as_float(w.x & 0xffff0000u), M.y, V.y);
+      a.upd(P.z, __uint_as_float(w.y << 16), M.z, V.z); a.upd(P.w, __uint_as_float(w.y & 0xffff0000u), M.w, V.w);
+      *(float4*)(p + i) = P; *(float4*)(m + i) = M; *(float4*)(v + i) = V;
+    } else
     load().vec(i);
     if (shadow) {
       const float4 P = *(const float4*)(p + i);      // just written by this thread
@@ -103,7 +113,8 @@ struct AdamDev {
     }
   }
   __device__ void one(size_t i) const {
-    load().one(i);
+    if (gw) load().upd(p[i], bf16_to_f32(gw[i]), m[i], v[i]);
+    else load().one(i);
     if (shadow) shadow[i] = f32_to_bf16(p[i]);
   }
 };
@@ -349,11 +360,12 @@ extern "C" int rg_adam_step(float* p, const float* g, float* m, float* v, size_t
 }
 
 extern "C" int rg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* hyper,
-                                void* shadow_bf16, void* stream) {
-  RG_REQUIRE(p && g && m && v && hyper, RG_EINVAL, "adam_step_dev: bad args");
-  RG_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && ((uintptr_t)shadow_bf16 & 7) == 0,
+                                void* shadow_bf16, const void* grad_bf16, void* stream) {
+  RG_REQUIRE(p && (g || grad_bf16) && m && v && hyper, RG_EINVAL, "adam_step_dev: bad args");
+  RG_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && ((uintptr_t)shadow_bf16 & 7) == 0 &&
+                 ((uintptr_t)grad_bf16 & 7) == 0,
              RG_EINVAL, "adam_step_dev: alignment");
-  AdamDev f{p, g, m, v, hyper, (uint16_t*)shadow_bf16};
+  AdamDev f{p, g, m, v, hyper, (uint16_t*)shadow_bf16, (const uint16_t*)grad_bf16};
   EW_LAUNCH("adam_step_dev", f, n, rg_stream(stream));
 }
 extern "C" int rg_adam_hyper_dev(int* step_dev, double lr, double beta1, double beta2, double eps, float* hyper,

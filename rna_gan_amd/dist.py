@@ -80,17 +80,23 @@ def allreduce_start(flat: torch.Tensor, compress: bool = False):
     return (None, flat, _launch_buckets(flat, BUCKET_BYTES // flat.element_size()))
 
 
-def allreduce_finish(handle):
-    """Make the current stream wait for the all-reduce (and widen the bf16 wire buffer back into the gradients)."""
+def allreduce_finish(handle, widen=True):
+    """Make the current stream wait for the all-reduce and widen the bf16 wire buffer back into the fp32 gradients
+    (widen=False: the caller's optimizer reads the wire buffer itself, see wire_of)."""
     if handle is None:
         return
     wire, flat, works = handle
     for w in works:
         w.wait()
-    if wire is not None:
+    if wire is not None and widen:
         from . import _abi
         stream = torch.cuda.current_stream(flat.device).cuda_stream
         _abi.check(_abi.load().rg_widen_bf16(wire.data_ptr(), flat.data_ptr(), flat.numel(), stream), "rg_widen_bf16")
+
+
+def wire_of(handle):
+    """The bf16 wire buffer of a compressed all-reduce (None for an fp32 one)."""
+    return None if handle is None else handle[0]
 
 
 def allreduce_sum_(flat: torch.Tensor, compress: bool = False):

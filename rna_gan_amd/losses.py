@@ -216,6 +216,7 @@ def _dispatch(runner, key, body, inputs, generator, discriminator, stepped, opti
 # data-parallel runs: the gradient all-reduce + optimizer step of the last train_op, not yet applied
 _PENDING = [None]
 OVERLAP = os.environ.get("RNAGAN_DP_OVERLAP", "1") != "0"
+FUSED_WIDEN = os.environ.get("RNAGAN_DP_FUSED_WIDEN", "1") != "0"
 
 
 class _Pending:
@@ -229,9 +230,16 @@ def flush():
     pend, _PENDING[0] = _PENDING[0], None
     if pend is None:
         return
-    D_.allreduce_finish(pend.handle)
-    _APPLY_RUNNER.run(("apply", id(pend.module)), lambda: _apply(pend.module, pend.optimizer), [], [],
+    # rna_gan_amd.optim.Adam steps straight from the all-reduced bf16 wire buffer (no widening pass; .grad then keeps
+    # the rank-local gradient); other optimizers get the averaged gradient back in .grad first
+    wire = D_.wire_of(pend.handle) if FUSED_WIDEN and hasattr(pend.optimizer, "grad_wire") else None
+    D_.allreduce_finish(pend.handle, widen=wire is None)
+    if hasattr(pend.optimizer, "grad_wire"):
+        pend.optimizer.grad_wire = wire
+    _APPLY_RUNNER.run(("apply", id(pend.module), wire is not None), lambda: _apply(pend.module, pend.optimizer), [], [],
                       [pend.optimizer], [pend.module])
+    if hasattr(pend.optimizer, "grad_wire"):
+        pend.optimizer.grad_wire = None
 
 
 class _Runner:

@@ -32,6 +32,7 @@ class Adam(torch.optim.Adam):
         self._step_dev = None      # int32[1] on the device
         self._hyper = None         # float32[8] on the device
         self._host_steps = 0       # number of steps enqueued/replayed so far (mirror of *_step_dev)
+        self.grad_wire = None      # data parallel, bf16 wire: the all-reduced bf16 gradient buffer to step from
 
     def bind(self, module):
         """Tell the optimizer which HIP module owns its parameters (done by the Trainer)."""
@@ -99,7 +100,9 @@ class Adam(torch.optim.Adam):
         shadow = flat.shadow           # bf16 image of the parameters (bf16 precision only), written by the same launch
         check(lib.rg_adam_step_dev(flat.data.data_ptr(), flat.grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
                                    flat.data.numel(), self._hyper.data_ptr(),
-                                   0 if shadow is None else shadow.data_ptr(), stream), "rg_adam_step_dev")
+                                   0 if shadow is None else shadow.data_ptr(),
+                                   0 if self.grad_wire is None else self.grad_wire.data_ptr(), stream),
+              "rg_adam_step_dev")
         if not torch.cuda.is_current_stream_capturing():
             self._host_steps += 1
         self._module.weights_changed(by_optimizer=True)
