@@ -68,6 +68,10 @@ const char* rg_last_error(void);
  *   wup[16][I][O]  (B operand of rg_conv_up:   k = (tap, o) contiguous in o) = transpose of w as [O][16*I]
  * both in `dtype`.  Runs after every optimizer step (src/wgan_loss.py:127,261,388). */
 int rg_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I, int dtype, void* stream);
+/* The same wup / G.0 operand images built from the bf16 copy of the masters that rg_adam_step_dev(shadow_bf16) keeps
+ * (2-byte instead of 4-byte reads; w_bf16 is [O][16][I] resp. [E][C][16], the master's order). */
+int rg_pack_conv_wup_from_bf16(const void* w_bf16, void* wup, int O, int I, void* stream);
+int rg_pack_g0_weight_from_bf16(const void* w_bf16, void* wp, int E, int C, void* stream);
 
 /* y[N][Hi/2][Wi/2][O] = conv2d(x[N][Hi][Wi][I], w[O][4][4][I], stride 2, pad 1).
  * nn.Conv2d forward in the discriminator (D(.) at src/wgan_loss.py:119,241,253,379) and the

@@ -35,6 +35,8 @@ PROTOTYPES = {
     "rg_skinny_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "rg_skinny_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_pack_g0_weight": (_i, [_p, _p, _i, _i, _i, _p]),
+    "rg_pack_conv_wup_from_bf16": (_i, [_p, _p, _i, _i, _p]),
+    "rg_pack_g0_weight_from_bf16": (_i, [_p, _p, _i, _i, _p]),
     "rg_g0_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_g0_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "rg_g0_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),

@@ -124,6 +124,14 @@ extern "C" int rg_skinny_wgrad(const void* low, const float* high_nchw, float* d
 }
 
 // ------------------------------------------------------------------------------------------------
+extern "C" int rg_pack_conv_wup_from_bf16(const void* w_bf16, void* wup, int O, int I, void* stream) {
+  RG_REQUIRE(w_bf16 && wup && O > 0 && I > 0, RG_EINVAL, "pack_conv_wup_from_bf16: bad args");
+  return rg_mfma_transpose_bf16(w_bf16, wup, O, 16 * I, 0, rg_stream(stream));
+}
+extern "C" int rg_pack_g0_weight_from_bf16(const void* w_bf16, void* wp, int E, int C, void* stream) {
+  RG_REQUIRE(w_bf16 && wp && E > 0 && C > 0, RG_EINVAL, "pack_g0_weight_from_bf16: bad args");
+  return rg_mfma_transpose_bf16(w_bf16, wp, E, 16 * C, 1, rg_stream(stream));
+}
 extern "C" int rg_pack_g0_weight(const float* w, void* wp, int E, int C, int dtype, void* stream) {
   RG_REQUIRE(w && wp && E > 0 && C > 0, RG_EINVAL, "pack_g0_weight: bad args");
   RG_REQUIRE(dtype == RG_BF16, RG_EUNSUPPORTED, "pack_g0_weight: only bf16 packs exist");

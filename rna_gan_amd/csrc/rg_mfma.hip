@@ -970,6 +970,32 @@ __global__ __launch_bounds__(256) void transpose_pack_kernel(const S* src, uint1
     }
   }
 }
+// bf16 -> bf16 transpose (source = the bf16 shadow the fused Adam keeps next to the fp32 masters): dst[perm(c)][r] =
+// src[r][c], 64x64 tiles, 4-byte accesses on both sides.  R and Cc even.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
+                                                             int R, int Cc, int permute) {
+  __shared__ uint16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int e = t + 256 * k, rr = e >> 5, cp = (e & 31) * 2;
+    uint32_t v = 0;
+    if (r0 + rr < R && c0 + cp < Cc) v = *reinterpret_cast<const uint32_t*>(src + (size_t)(r0 + rr) * Cc + c0 + cp);
+    tile[rr][cp] = (uint16_t)v; tile[rr][cp + 1] = (uint16_t)(v >> 16);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int e = t + 256 * k, cc = e >> 5, rp = (e & 31) * 2;
+    const int c = c0 + cc, r = r0 + rp;
+    if (c < Cc && r < R) {
+      int pc = c;
+      if (permute == 1) { int tap = c & 15, ch = c >> 4; pc = tap * (Cc >> 4) + ch; }
+      *reinterpret_cast<uint32_t*>(dst + (size_t)pc * R + r) = (uint32_t)tile[rp][cc] | ((uint32_t)tile[rp + 1][cc] << 16);
+    }
+  }
+}
 __global__ void pack_linear_kernel(const float* w, uint16_t* wp, int Nout, int K, int Np, int Kp) {
   size_t n = (size_t)Np * Kp;
   for (size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += (size_t)gridDim.x * blockDim.x) {
@@ -1290,6 +1316,13 @@ int rg_mfma_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I,
                        (uint16_t*)wup, O, I * 16, 0);
     RG_LAUNCH_CHECK("pack_wup");
   }
+  return RG_OK;
+}
+int rg_mfma_transpose_bf16(const void* src, void* dst, int R, int Cc, int permute, hipStream_t st) {
+  RG_REQUIRE(R % 2 == 0 && Cc % 2 == 0, RG_EUNSUPPORTED, "transpose_bf16: even dimensions required");
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((Cc + 63) / 64, (R + 63) / 64), dim3(256), 0, st, (const uint16_t*)src,
+                     (uint16_t*)dst, R, Cc, permute);
+  RG_LAUNCH_CHECK("transpose_bf16");
   return RG_OK;
 }
 int rg_mfma_pack_g0_weight(const float* w, void* wp, int E, int C, hipStream_t st) {

@@ -132,12 +132,13 @@ class _HipModule(nn.Module):
         flat = self._rt_flat
         shadow = flat.ensure_shadow()
         base = flat.data.data_ptr()
+        g0 = getattr(self._rt_net, "g0", None)
         for cw in self._rt_net.convs():
-            if cw.layout != "OHWI":
-                continue
+            if cw.layout != "OHWI" and cw is not g0:
+                continue                      # only layers with a bf16 GEMM-operand image built from the master
             off = (cw.w.data_ptr() - base) // flat.esize
             n = cw.w.numel()
-            cw.shadow = shadow[off:off + n].view(cw.O, 16, cw.I)
+            cw.shadow = shadow[off:off + n].view(cw.O, 16, cw.I) if cw.layout == "OHWI" else shadow[off:off + n]
             cw.shadow_version = -1
 
     @property

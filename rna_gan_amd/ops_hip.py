@@ -43,6 +43,7 @@ class HipOps:
         self._in_side = False
         self._keep = []
         self.use_side = os.environ.get("RNAGAN_SIDE_STREAM", "0") != "0"
+        self.pack_from_shadow = os.environ.get("RNAGAN_PACK_FROM_SHADOW", "1") != "0"
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -109,10 +110,15 @@ class HipOps:
                 wdn = cw.shadow if cw.shadow is not None else torch.empty((O, 16, I), dtype=torch.bfloat16,
                                                                          device=self.device)
                 cw.packs = (wdn, torch.empty((16, I, O), dtype=torch.bfloat16, device=self.device))
-            # wdn is a cast of the tap-major master: skipped when the fused Adam already wrote it (shadow)
-            need_wdn = cw.shadow is None or cw.shadow_version != cw.version
-            check(self.lib.rg_pack_conv_weight(_ptr(cw.w), _ptr(cw.packs[0]) if need_wdn else 0, _ptr(cw.packs[1]),
-                                               O, I, RG_BF16, self.stream), "rg_pack_conv_weight")
+            # wdn is a cast of the tap-major master: skipped when the fused Adam already wrote it (shadow), and then
+            # wup is transposed from that bf16 copy (half the read traffic of the fp32 master)
+            need_wdn = cw.shadow is None or cw.shadow_version != cw.version or not self.pack_from_shadow
+            if need_wdn:
+                check(self.lib.rg_pack_conv_weight(_ptr(cw.w), _ptr(cw.packs[0]), _ptr(cw.packs[1]), O, I, RG_BF16,
+                                                   self.stream), "rg_pack_conv_weight")
+            else:
+                check(self.lib.rg_pack_conv_wup_from_bf16(_ptr(cw.shadow), _ptr(cw.packs[1]), O, I, self.stream),
+                      "rg_pack_conv_wup_from_bf16")
             cw.packs_version = cw.version
             if cw.shadow is not None:
                 cw.shadow_version = cw.version
@@ -263,9 +269,15 @@ class HipOps:
             if cw.packs is None or cw.packs_version != cw.version:
                 if cw.packs is None:
                     cw.packs = (torch.empty((16 * C, E), dtype=torch.bfloat16, device=self.device),)
-                check(self.lib.rg_pack_g0_weight(_ptr(cw.w), _ptr(cw.packs[0]), E, C, RG_BF16, self.stream),
-                      "rg_pack_g0_weight")
+                if cw.shadow is not None and cw.shadow_version == cw.version and self.pack_from_shadow:
+                    check(self.lib.rg_pack_g0_weight_from_bf16(_ptr(cw.shadow), _ptr(cw.packs[0]), E, C, self.stream),
+                          "rg_pack_g0_weight_from_bf16")
+                else:
+                    check(self.lib.rg_pack_g0_weight(_ptr(cw.w), _ptr(cw.packs[0]), E, C, RG_BF16, self.stream),
+                          "rg_pack_g0_weight")
                 cw.packs_version = cw.version
+                if cw.shadow is not None:
+                    cw.shadow_version = cw.version
             wp = cw.packs[0]
         y = self._act(N, 4, 4, C)
         ws = self._ws(self.lib.rg_g0_workspace_bytes(N, E, C, self.dt, self.algo))
