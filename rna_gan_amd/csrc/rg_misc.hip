@@ -88,36 +88,38 @@ struct Adam {
   __device__ void one(size_t i) const { upd(p[i], g[i], m[i], v[i]); }
 };
 
-struct AdamDev {
-  float* p; const float* g; float* m; float* v; const float* hyper;
-  uint16_t* shadow;      // optional bf16 image of the updated parameters (the GEMM operand of the tap-major convs)
-  const uint16_t* gw;    // optional: the gradient as bf16 (the all-reduced wire buffer of a data-parallel run), read
-                         // instead of g -- saves the pass that widens it back to fp32
-  __device__ __forceinline__ Adam load() const {
-    return Adam{p, g, m, v, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6]};
-  }
-  __device__ void vec(size_t i) const {
-    if (gw) {
-      const Adam a = load();
+// Adam with the step-dependent constants in device memory.  WIRE: the gradient is read as bf16 from the all-reduced
+// wire buffer of a data-parallel run instead of g; SHADOW: the rounded updated parameters are also written to a bf16
+// buffer (the GEMM operand image of the tap-major conv weights).  The 7 constants are loaded once per thread.
+template <bool WIRE, bool SHADOW>
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v,
+                                                       const float* __restrict__ hyper, uint16_t* __restrict__ shadow,
+                                                       const uint16_t* __restrict__ gw, size_t n) {
+  const Adam a{p, g, m, v, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6]};
+  const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
+    const size_t i = q * 4;
+    float4 P = *(float4*)(p + i), M = *(float4*)(m + i), V = *(float4*)(v + i), G;
+    if (WIRE) {
       const uint2 w = *(const uint2*)(gw + i);
-      float4 P = *(float4*)(p + i), M = *(float4*)(m + i), V = *(float4*)(v + i);
-      a.upd(P.x, __uint_as_float(w.x << 16), M.x, V.x); a.upd(P.y, __uint_as_float(w.x & 0xffff0000u), M.y, V.y);
-      a.upd(P.z, __uint_as_float(w.y << 16), M.z, V.z); a.upd(P.w, __uint_as_float(w.y & 0xffff0000u), M.w, V.w);
-      *(float4*)(p + i) = P; *(float4*)(m + i) = M; *(float4*)(v + i) = V;
-    } else
-    load().vec(i);
-    if (shadow) {
-      const float4 P = *(const float4*)(p + i);      // just written by this thread
+      G = make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                      __uint_as_float(w.y & 0xffff0000u));
+    } else {
+      G = *(const float4*)(g + i);
+    }
+    a.upd(P.x, G.x, M.x, V.x); a.upd(P.y, G.y, M.y, V.y); a.upd(P.z, G.z, M.z, V.z); a.upd(P.w, G.w, M.w, V.w);
+    *(float4*)(p + i) = P; *(float4*)(m + i) = M; *(float4*)(v + i) = V;
+    if (SHADOW)
       *(uint2*)(shadow + i) = make_uint2((uint32_t)f32_to_bf16(P.x) | ((uint32_t)f32_to_bf16(P.y) << 16),
                                          (uint32_t)f32_to_bf16(P.z) | ((uint32_t)f32_to_bf16(P.w) << 16));
-    }
   }
-  __device__ void one(size_t i) const {
-    if (gw) load().upd(p[i], bf16_to_f32(gw[i]), m[i], v[i]);
-    else load().one(i);
-    if (shadow) shadow[i] = f32_to_bf16(p[i]);
+  const size_t t = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // tail
+  if (t < n) {
+    a.upd(p[t], WIRE ? bf16_to_f32(gw[t]) : g[t], m[t], v[t]);
+    if (SHADOW) shadow[t] = f32_to_bf16(p[t]);
   }
-};
+}
 
 __global__ void adam_hyper_kernel(int* step_dev, double lr, double b1, double b2, double eps, float* hyper) {
   int step = *step_dev + 1;
@@ -365,8 +367,17 @@ extern "C" int rg_adam_step_dev(float* p, const float* g, float* m, float* v, si
   RG_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && ((uintptr_t)shadow_bf16 & 7) == 0 &&
                  ((uintptr_t)grad_bf16 & 7) == 0,
              RG_EINVAL, "adam_step_dev: alignment");
-  AdamDev f{p, g, m, v, hyper, (uint16_t*)shadow_bf16, (const uint16_t*)grad_bf16};
-  EW_LAUNCH("adam_step_dev", f, n, rg_stream(stream));
+  if (n == 0) return RG_OK;
+  uint16_t* sh = (uint16_t*)shadow_bf16;
+  const uint16_t* gw = (const uint16_t*)grad_bf16;
+  const dim3 grid(grid_for(n, 4)), block(256);
+  hipStream_t st = rg_stream(stream);
+  if (gw && sh) hipLaunchKernelGGL((adam_dev_kernel<true, true>), grid, block, 0, st, p, g, m, v, hyper, sh, gw, n);
+  else if (gw) hipLaunchKernelGGL((adam_dev_kernel<true, false>), grid, block, 0, st, p, g, m, v, hyper, sh, gw, n);
+  else if (sh) hipLaunchKernelGGL((adam_dev_kernel<false, true>), grid, block, 0, st, p, g, m, v, hyper, sh, gw, n);
+  else hipLaunchKernelGGL((adam_dev_kernel<false, false>), grid, block, 0, st, p, g, m, v, hyper, sh, gw, n);
+  RG_LAUNCH_CHECK("adam_step_dev");
+  return RG_OK;
 }
 extern "C" int rg_adam_hyper_dev(int* step_dev, double lr, double beta1, double beta2, double eps, float* hyper,
                                  void* stream) {
