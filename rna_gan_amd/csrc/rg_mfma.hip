@@ -1255,8 +1255,11 @@ int rg_mfma_conv_wgrad(const void* low, const void* high, float* dw, int N, int 
 }
 
 static int mfma_wgrad_split_k(int K, int O, int I) {
+  // 2 blocks are resident per CU: a grid of 512 (or a multiple) fills the 256 CUs without a half-empty last round
+  static int target = -1;
+  if (target < 0) { const char* e = getenv("RNAGAN_WGRAD_BLOCKS"); target = e ? atoi(e) : 512; }
   int tiles = (O / 128) * (16 * I / 128);
-  int want = (768 + tiles - 1) / tiles;
+  int want = (target + tiles - 1) / tiles;
   int maxs = K / 256;
   if (maxs < 1) maxs = 1;
   int s = want < maxs ? want : maxs;
