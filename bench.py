@@ -271,8 +271,8 @@ def measure_roofline(ops, device, one_step, step_ms):
                    "tflops": round(f["flops"] / (f["ms"] * 1e-3) / 1e12, 1) if f["ms"] > 0 else None,
                    "share_of_step": round(f["ms"] / step_ms, 3)}
     dom = max(rows, key=lambda k: rows[k]["ms_total"])
-    names = {"conv_fwd_dgrad": "gather_gemm_kernel (bf16 MFMA implicit-GEMM conv: fwd / dgrad / tangent)",
-             "conv_wgrad": "wgrad_kernel (bf16 MFMA weight gradient) + reduce_slabs_kernel"}
+    names = {"conv_fwd_dgrad": "gather_gemm_dma_kernel (bf16 MFMA implicit-GEMM conv: fwd / dgrad / tangent)",
+             "conv_wgrad": "wgrad_dma_kernel (bf16 MFMA weight gradient) + reduce_slabs_kernel"}
     traffic, traffic_src = pmc_traffic({"conv_fwd_dgrad": "gather_gemm", "conv_wgrad": "wgrad_dma"}.get(dom))
     return {"bound": "mfma", "kernel": names.get(dom, dom), "achieved": rows[dom]["tflops"],
             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
