@@ -177,6 +177,13 @@ int rg_bn_finalize(const float* sum, const float* sumsq, int M, int C, float eps
                    void* stream);
 /* rg_bn_stats + rg_bn_finalize in one pass: the finishing step of the column reduction writes mean / invstd and
  * updates the running statistics directly (one launch less per BatchNorm forward; same arithmetic). */
+/* The whole train-mode BatchNorm2d + LeakyReLU forward: a = lrelu(gamma * (z - mean) * invstd + beta) with the batch
+ * statistics of z (written to mean / invstd, running statistics updated when given): statistics pass (whose finishing
+ * step does the finalize) + pointwise pass.  RNAGAN_BN_FUSED=1 selects a single-launch form for small tensors in this
+ * and in rg_bn_act_bwd / rg_bn_tangent / rg_bn_double_bwd (measured slower on MI355X, kept for experiments). */
+int rg_bn_forward(const void* z, int M, int C, float eps, float momentum, const float* gamma, const float* beta,
+                  float slope, float* mean, float* invstd, float* running_mean, float* running_var,
+                  int64_t* num_batches_tracked, void* a, int dtype, void* ws, size_t ws_bytes, void* stream);
 int rg_bn_stats_finalize(const void* z, int M, int C, float eps, float momentum, float* mean, float* invstd,
                          float* running_mean, float* running_var, int64_t* num_batches_tracked, int dtype, void* ws,
                          size_t ws_bytes, void* stream);

@@ -171,6 +171,11 @@ class RefOps:
         zf = z.to(self.f).reshape(-1, z.shape[-1])
         return zf.sum(0), (zf * zf).sum(0)
 
+    def bn_forward(self, z, gamma, beta, slope: float, eps: float, momentum: float, running_mean=None,
+                   running_var=None, nbt=None):
+        mean, invstd = self.bn_stats_finalize(z, eps, momentum, running_mean, running_var, nbt)
+        return self.bn_act(z, mean, invstd, gamma, beta, slope), mean, invstd
+
     def bn_stats_finalize(self, z, eps: float, momentum: float, running_mean=None, running_var=None, nbt=None):
         s, ss = self.bn_stats(z)
         return self.bn_finalize(s, ss, z.numel() // z.shape[-1], eps, momentum, running_mean, running_var, nbt)

@@ -50,6 +50,7 @@ PROTOTYPES = {
     "rg_colreduce_workspace_bytes": (_z, [_i, _i, _i]),
     "rg_bn_stats": (_i, [_p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "rg_bn_finalize": (_i, [_p, _p, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p]),
+    "rg_bn_forward": (_i, [_p, _i, _i, _f, _f, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _p, _z, _p]),
     "rg_bn_stats_finalize": (_i, [_p, _i, _i, _f, _f, _p, _p, _p, _p, _p, _i, _p, _z, _p]),
     "rg_bn_act": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p]),
     "rg_bn_act_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _z, _p]),

@@ -6,6 +6,7 @@
 // Per-channel sums use a deterministic two-stage reduction (block partials in the caller's workspace,
 // then a small finishing kernel).
 #include "rg_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -153,6 +154,60 @@ int row_apply(const char* name, int M, int C, hipStream_t st, Args... args) {
   RG_LAUNCH_CHECK(name);
   return RG_OK;
 }
+
+// ---- single-launch form for SMALL tensors (the deep 4x4 / 8x8 layers): a block owns VEC channels for ALL rows, so
+// the per-channel reduction, its finisher and the pointwise pass need no other block:
+//   reduce over the rows -> wave shuffles + LDS -> fin(c, sums) -> block barrier -> pointwise pass.
+// One launch instead of three (row reduce, column finish, row apply); opt-in (RNAGAN_BN_FUSED=1), see fused_small_ok.
+template <int NQ, int VEC, class RF, class Fin, class AF>
+__global__ __launch_bounds__(256) void fused_rows_kernel(RF rf, Fin fin, AF af, int M, int C) {
+  __shared__ float sm[4][NQ][VEC];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int c = blockIdx.x * VEC;
+  float acc[NQ][VEC];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[q][v] = 0.f;
+  rf.init(c);
+#pragma unroll 8
+  for (int r = t; r < M; r += 256) rf.row(r, c, acc);      // independent loads: keep several rows in flight
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      float w = wave_sum(acc[q][v]);
+      if (lane == 0) sm[wave][q][v] = w;
+    }
+  __syncthreads();
+  if (t < VEC) {
+    float sv[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) sv[q] = sm[0][q][t] + sm[1][q][t] + sm[2][q][t] + sm[3][q][t];
+    fin(c + t, sv);
+  }
+  __threadfence_block();
+  __syncthreads();
+  af.init(c);
+#pragma unroll 8
+  for (int r = t; r < M; r += 256) af.row(r, c);
+}
+
+static bool fused_small_ok(int M, int C, int vec) {
+  static int on = -1;
+  // measured: slower than the three coalesced launches (15.8 vs 17.6 us forward at [1024][2048] but 27 vs 19 us backward,
+  // and 2x slower at [4096][1024]: a block's 16-byte column slices are strided by the row pitch) -> off by default
+  if (on < 0) { const char* e = getenv("RNAGAN_BN_FUSED"); on = e ? atoi(e) : 0; }
+  // up to the [64, 8, 8, 1024] layer; wider tensors have too few channel groups per row to fill the chip this way
+  return on && C % vec == 0 && C / vec >= 32 && (size_t)M * C <= ((size_t)9 << 19) && M >= 64;
+}
+template <int NQ, int VEC, class RF, class Fin, class AF>
+static int fused_rows(const char* name, int M, int C, hipStream_t st, RF rf, Fin fin, AF af) {
+  hipLaunchKernelGGL((fused_rows_kernel<NQ, VEC, RF, Fin, AF>), dim3(C / VEC), dim3(256), 0, st, rf, fin, af, M, C);
+  RG_LAUNCH_CHECK(name);
+  return RG_OK;
+}
+template <typename T> struct VecOf { static constexpr int value = sizeof(T) == 2 ? 8 : 4; };
 
 // per-channel parameter bundle (device pointers) and its register image for VEC channels
 struct BNC {
@@ -450,6 +505,25 @@ extern "C" int rg_bn_stats_finalize(const void* z, int M, int C, float eps, floa
   })
 }
 
+extern "C" int rg_bn_forward(const void* z, int M, int C, float eps, float momentum, const float* gamma, const float* beta,
+                             float slope, float* mean, float* invstd, float* running_mean, float* running_var,
+                             int64_t* num_batches_tracked, void* a, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(z && a && mean && invstd && gamma && beta && M > 0 && C > 0, RG_EINVAL, "bn_forward: bad args");
+  StatsFinalizeFin fin{(float)M, eps, momentum, mean, invstd, running_mean, running_var,
+                       running_mean ? num_batches_tracked : nullptr};
+  BNC p{mean, invstd, gamma, beta, slope};
+  hipStream_t st = rg_stream(stream);
+  RG_DISPATCH_DTYPE(dtype, T, {
+    constexpr int V = VecOf<T>::value;
+    if (fused_small_ok(M, C, V))
+      return fused_rows<2, V>("bn_forward(fused)", M, C, st, StatsF<T, V>{(const T*)z, C}, fin,
+                              BnActF<T, V>{(const T*)z, (T*)a, p, C});
+    int rc = row_reduce<2, T, StatsF>("bn_forward", M, C, ws, ws_bytes, st, fin, (const T*)z, C);
+    if (rc) return rc;
+    return (row_apply<T, BnActF>("bn_forward", M, C, st, (const T*)z, (T*)a, p, C));
+  })
+}
+
 extern "C" int rg_bn_finalize(const float* sum, const float* sumsq, int M, int C, float eps, float momentum,
                               float* mean, float* invstd, float* running_mean, float* running_var,
                               int64_t* num_batches_tracked, void* stream) {
@@ -478,6 +552,12 @@ extern "C" int rg_bn_act_bwd(const void* z, const void* ga, const float* mean, c
   BNC p{mean, invstd, gamma, beta, slope};
   hipStream_t st = rg_stream(stream);
   RG_DISPATCH_DTYPE(dtype, T, {
+    constexpr int V = VecOf<T>::value;
+    if (fused_small_ok(M, C, V))
+      return fused_rows<2, V>("bn_act_bwd(fused)", M, C, st, BwdRedF<T, V>{(const T*)z, (const T*)ga, p, C},
+                              BwdFin{s_gy, s_gyxh, dgamma, dbeta, accumulate},
+                              BwdApplyF<T, V>{(const T*)z, (const T*)ga, (T*)gz, p, (const float*)s_gy,
+                                              (const float*)s_gyxh, 1.f / (float)M, C});
     int rc = row_reduce<2, T, BwdRedF>("bn_act_bwd", M, C, ws, ws_bytes, st,
                                        BwdFin{s_gy, s_gyxh, dgamma, dbeta, accumulate}, (const T*)z, (const T*)ga, p, C);
     if (rc) return rc;
@@ -493,6 +573,12 @@ extern "C" int rg_bn_tangent(const void* z, const void* zt, const float* mean, c
   BNC p{mean, invstd, gamma, beta, slope};
   hipStream_t st = rg_stream(stream);
   RG_DISPATCH_DTYPE(dtype, T, {
+    constexpr int V = VecOf<T>::value;
+    if (fused_small_ok(M, C, V))
+      return fused_rows<2, V>("bn_tangent(fused)", M, C, st, TanRedF<T, V>{(const T*)z, (const T*)zt, p, C},
+                              Store2Fin{s_zt, s_xhzt},
+                              TanApplyF<T, V>{(const T*)z, (const T*)zt, (T*)at, p, (const float*)s_zt,
+                                              (const float*)s_xhzt, 1.f / (float)M, C});
     int rc = row_reduce<2, T, TanRedF>("bn_tangent", M, C, ws, ws_bytes, st, Store2Fin{s_zt, s_xhzt}, (const T*)z,
                                        (const T*)zt, p, C);
     if (rc) return rc;
@@ -514,6 +600,13 @@ extern "C" int rg_bn_double_bwd(const void* z, const void* qa, const void* zt, c
   BNC p{mean, invstd, gamma, beta, slope};
   hipStream_t st = rg_stream(stream);
   RG_DISPATCH_DTYPE(dtype, T, {
+    constexpr int V = VecOf<T>::value;
+    if (fused_small_ok(M, C, V))
+      return fused_rows<3, V>("bn_double_bwd(fused)", M, C, st,
+                              DblRedF<T, V>{(const T*)z, (const T*)qa, (const T*)zt, (const T*)ga1, p, C},
+                              DblFin{s_gy, s_gyxh, s_zt, s_xhzt, invstd, coef, dgamma, dbeta, accumulate, (float)M, C},
+                              DblApplyF<T, V>{(const T*)z, (const T*)qa, (const T*)zt, (const T*)ga1, (T*)pz, p, s_gy,
+                                              s_zt, (const float*)coef, 1.f / (float)M, C});
     int rc = row_reduce<3, T, DblRedF>("bn_double_bwd", M, C, ws, ws_bytes - (size_t)5 * C * sizeof(float), st,
                                        DblFin{s_gy, s_gyxh, s_zt, s_xhzt, invstd, coef, dgamma, dbeta, accumulate,
                                               (float)M, C},

@@ -153,11 +153,8 @@ class _Ctx:
 
 def _bn_forward(ops, z, bn: BNP, slope, update_running=True):
     if update_running:
-        mean, invstd = ops.bn_stats_finalize(z, bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.nbt)
-    else:
-        mean, invstd = ops.bn_stats_finalize(z, bn.eps, bn.momentum)
-    a = ops.bn_act(z, mean, invstd, bn.gamma, bn.beta, slope)
-    return a, mean, invstd
+        return ops.bn_forward(z, bn.gamma, bn.beta, slope, bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.nbt)
+    return ops.bn_forward(z, bn.gamma, bn.beta, slope, bn.eps, bn.momentum)
 
 
 # --------------------------------------------------------------------------------------------

@@ -350,6 +350,18 @@ class HipOps:
                                             ws.numel(), self.stream), "rg_bn_stats_finalize")
         return mean, invstd
 
+    def bn_forward(self, z, gamma, beta, slope: float, eps: float, momentum: float, running_mean=None,
+                   running_var=None, nbt=None):
+        """Train-mode BatchNorm + LeakyReLU: (a, mean, invstd); one launch for small tensors."""
+        M, C = self._mc(z)
+        mean, invstd = self._f32(C), self._f32(C)
+        a = torch.empty_like(z)
+        ws = self._ws(self.lib.rg_colreduce_workspace_bytes(M, C, 2))
+        check(self.lib.rg_bn_forward(_ptr(z), M, C, float(eps), float(momentum), _ptr(gamma), _ptr(beta), float(slope),
+                                     _ptr(mean), _ptr(invstd), _ptr(running_mean), _ptr(running_var), _ptr(nbt),
+                                     _ptr(a), self.dt, _ptr(ws), ws.numel(), self.stream), "rg_bn_forward")
+        return a, mean, invstd
+
     def bn_act(self, z, mean, invstd, gamma, beta, slope: float):
         M, C = self._mc(z)
         a = torch.empty_like(z)

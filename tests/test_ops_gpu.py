@@ -160,7 +160,10 @@ def test_g0_and_head(N, E, C, dtype):
 
 @pytest.mark.parametrize("M,C,dtype", [(40, 8, torch.float32), (37, 6, torch.float32), (40, 8, torch.bfloat16),
                                        (4096, 128, torch.float32), (4096, 128, torch.bfloat16),
-                                       (70000, 64, torch.bfloat16)])
+                                       (70000, 64, torch.bfloat16),
+                                       # single-launch (fused) path of the small deep layers
+                                       (1024, 2048, torch.bfloat16), (4096, 1024, torch.bfloat16),
+                                       (256, 512, torch.float32)])
 def test_bn_family(M, C, dtype):
     ref, hip = RefOps(dtype), _hip(dtype)
     tol = TOL[dtype] if dtype == torch.bfloat16 else 1e-4
@@ -184,6 +187,12 @@ def test_bn_family(M, C, dtype):
     check(rm_d, rm, 1e-5, "fused running_mean"); check(rv_d, rv, 1e-4, "fused running_var")
     assert int(nbt_d.cpu()) == int(nbt) == 2
     D = lambda t: None if t is None else dev(t)
+    # whole forward in one call (one launch for small tensors): third update of the running statistics
+    a_ref3, mean_ref3, inv_ref3 = ref.bn_forward(z, gamma, beta, 0.2, 1e-5, 0.1, rm, rv, nbt)
+    a3, mean3, inv3 = hip.bn_forward(dev(z), dev(gamma), dev(beta), 0.2, 1e-5, 0.1, rm_d, rv_d, nbt_d)
+    check(mean3, mean_ref3, 1e-5, "bn_forward mean"); check(inv3, inv_ref3, 1e-4, "bn_forward invstd")
+    check(a3, a_ref3, tol, "bn_forward a"); check(rv_d, rv, 1e-4, "bn_forward running_var")
+    assert int(nbt_d.cpu()) == int(nbt) == 3
     a_ref = ref.bn_act(z, mean_ref, inv_ref, gamma, beta, 0.2)
     check(hip.bn_act(D(z), D(mean_ref), D(inv_ref), D(gamma), D(beta), 0.2), a_ref, tol, "bn_act")
     ga = rnd((1, M, 1, C), 25).to(dtype)
