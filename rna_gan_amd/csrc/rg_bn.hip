@@ -194,10 +194,11 @@ __global__ __launch_bounds__(256) void fused_rows_kernel(RF rf, Fin fin, AF af, 
 }
 
 static bool fused_small_ok(int M, int C, int vec) {
-  static int on = -1;
+  // (read on every call so that a test can switch it; getenv is cheap next to a launch)
+  int on;
   // measured: slower than the three coalesced launches (15.8 vs 17.6 us forward at [1024][2048] but 27 vs 19 us backward,
   // and 2x slower at [4096][1024]: a block's 16-byte column slices are strided by the row pitch) -> off by default
-  if (on < 0) { const char* e = getenv("RNAGAN_BN_FUSED"); on = e ? atoi(e) : 0; }
+  { const char* e = getenv("RNAGAN_BN_FUSED"); on = e ? atoi(e) : 0; }
   // up to the [64, 8, 8, 1024] layer; wider tensors have too few channel groups per row to fill the chip this way
   return on && C % vec == 0 && C / vec >= 32 && (size_t)M * C <= ((size_t)9 << 19) && M >= 64;
 }

@@ -164,7 +164,9 @@ def test_g0_and_head(N, E, C, dtype):
                                        # single-launch (fused) path of the small deep layers
                                        (1024, 2048, torch.bfloat16), (4096, 1024, torch.bfloat16),
                                        (256, 512, torch.float32)])
-def test_bn_family(M, C, dtype):
+def test_bn_family(M, C, dtype, monkeypatch):
+    if M * C >= 256 * 512 and C >= 512:
+        monkeypatch.setenv("RNAGAN_BN_FUSED", "1")      # opt-in single-launch kernels: keep them covered
     ref, hip = RefOps(dtype), _hip(dtype)
     tol = TOL[dtype] if dtype == torch.bfloat16 else 1e-4
     z = (rnd((1, M, 1, C), 20) * 1.5 + 0.3).to(dtype)
