@@ -86,26 +86,15 @@ int launch_generic(const char* name, FA fa, FB fb, SC sc, int M, int N, int K, i
 }
 
 // ----------------------------------------------------------------------------------------------
-// split-K slab reduction: dst[idx] = (accumulate ? dst[idx] : 0) + sum_s slab[s][perm(idx)]
-// perm_mode 0: identity.  perm_mode 1: slab layout [o][tap][i] -> dst layout [o][i][tap] (MFMA wgrad)
-// perm_mode 2: slab layout [e][tap*C + c]  -> dst layout [e][c][tap]                    (MFMA g0 wgrad)
+// split-K slab reduction: dst[idx] = (accumulate ? dst[idx] : 0) + sum_s slab[s][idx], fixed summation order.
+// (Slabs have the destination's layout: the conv weight gradients are tap-major like their masters.)
 // ----------------------------------------------------------------------------------------------
 __global__ void reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ dst, size_t n, int nsplit,
-                                    int accumulate, int perm_mode, int P, int Q) {
+                                    int accumulate) {
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n) return;
-  size_t src = idx;
-  if (perm_mode == 1) {          // dst idx = (o*Q + i)*16 + tap, P unused, Q = I
-    size_t tap = idx & 15, oi = idx >> 4;
-    size_t i = oi % Q, o = oi / Q;
-    src = (o * 16 + tap) * Q + i;
-  } else if (perm_mode == 2) {   // dst idx = (e*Q + c)*16 + tap, Q = C
-    size_t tap = idx & 15, ec = idx >> 4;
-    size_t c = ec % Q, e = ec / Q;
-    src = e * (16 * (size_t)Q) + tap * Q + c;
-  }
   float s = accumulate ? dst[idx] : 0.f;
-  for (int z = 0; z < nsplit; ++z) s += slab[(size_t)z * n + src];
+  for (int z = 0; z < nsplit; ++z) s += slab[(size_t)z * n + idx];
   dst[idx] = s;
 }
 
@@ -120,33 +109,6 @@ __global__ void reduce_slabs_vec4_kernel(const float* __restrict__ slab, float* 
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
   reinterpret_cast<float4*>(dst)[idx] = s;
-}
-
-// perm_mode 1, LDS-tiled: block = one o-row x 64 consecutive i.  Reads 16 tap-rows of 64 floats (256
-// contiguous bytes each, summed over the splits), transposes through LDS, writes 64 x 16 contiguous floats.
-__global__ __launch_bounds__(256) void reduce_slabs_tap_kernel(const float* __restrict__ slab, float* __restrict__ dst,
-                                                               size_t n, int nsplit, int accumulate, int I) {
-  __shared__ float tile[64][17];
-  const int t = threadIdx.x;
-  const int itiles = I >> 6;
-  const int o = blockIdx.x / itiles, i0 = (blockIdx.x - o * itiles) << 6;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int e = t + 256 * r, tap = e >> 6, ii = e & 63;
-    const size_t src = ((size_t)o * 16 + tap) * I + i0 + ii;
-    float v = 0.f;
-    for (int z = 0; z < nsplit; ++z) v += slab[(size_t)z * n + src];
-    tile[ii][tap] = v;
-  }
-  __syncthreads();
-  const int ii = t >> 2, t4 = (t & 3) * 4;
-  float* d = dst + ((size_t)o * I + i0 + ii) * 16 + t4;
-  float4 v = make_float4(tile[ii][t4], tile[ii][t4 + 1], tile[ii][t4 + 2], tile[ii][t4 + 3]);
-  if (accumulate) {
-    float4 a = *reinterpret_cast<const float4*>(d);
-    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-  }
-  *reinterpret_cast<float4*>(d) = v;
 }
 
 // identity layout, MANY slabs of a small tensor (image-side weight gradients: 1024 x 12 KB): 16 elements x
@@ -173,28 +135,19 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __r
 
 int rg_reduce_slabs(const float* slab, float* dst, size_t n, int nsplit, int accumulate, int perm_mode, int Q,
                     hipStream_t st) {
+  (void)Q;
   if (n == 0) return RG_OK;
-  if (perm_mode == 0 && nsplit >= 64 && n <= (1u << 20)) {
+  RG_REQUIRE(perm_mode == 0, RG_EINVAL, "reduce_slabs: slabs must have the destination's layout");
+  if (nsplit >= 64 && n <= (1u << 20)) {
     hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, slab, dst, n, nsplit,
                        accumulate);
-    RG_LAUNCH_CHECK("reduce_slabs");
-    return RG_OK;
-  }
-  if (perm_mode == 0 && n % 4 == 0 && n >= 4096) {
+  } else if (n % 4 == 0 && n >= 4096) {
     hipLaunchKernelGGL(reduce_slabs_vec4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, slab, dst, n / 4,
                        n, nsplit, accumulate);
-    RG_LAUNCH_CHECK("reduce_slabs");
-    return RG_OK;
+  } else {
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, dst, n, nsplit,
+                       accumulate);
   }
-  if (perm_mode == 1 && Q % 64 == 0 && nsplit <= 4) {   // many splits: the element-wise form has more parallelism
-    size_t O = n / ((size_t)Q * 16);
-    hipLaunchKernelGGL(reduce_slabs_tap_kernel, dim3((unsigned)(O * (Q / 64))), dim3(256), 0, st, slab, dst, n, nsplit,
-                       accumulate, Q);
-    RG_LAUNCH_CHECK("reduce_slabs");
-    return RG_OK;
-  }
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, dst, n, nsplit,
-                     accumulate, perm_mode, 0, Q);
   RG_LAUNCH_CHECK("reduce_slabs");
   return RG_OK;
 }
