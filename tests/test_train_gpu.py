@@ -162,6 +162,39 @@ def test_full_size_one_iteration_bf16():
     assert img.shape == (n, 3, 256, 256) and torch.isfinite(img).all() and float(img.abs().max()) <= 1.0
 
 
+def test_full_size_batch64_bf16():
+    """BASELINE configs[1] shape exactly (batch 64 at the reference model size): this is where the MFMA launchers pick
+    their large-batch variants (256x256 tiles, class-fastest block order, 512-block wgrad grids, row-staged image-side
+    kernels).  One iteration against the fp32 CPU oracle: the three losses and the direction of the first Adam update
+    of the two largest layers."""
+    in_size, step, enc, n = 256, 64, 2048, 64
+    G0 = R.seeded_fill_(R.OracleDCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                               last_nonlinearity=nn.Tanh()), 27)
+    D0 = R.seeded_fill_(R.OracleDCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                                   last_nonlinearity=nn.LeakyReLU(0.2)), 28)
+    Go, Do = copy.deepcopy(G0).train(), copy.deepcopy(D0).train()
+    ogo, odo = R.make_adam(Go.parameters(), 1e-4), R.make_adam(Do.parameters(), 4e-4)
+    G, D, og, od = product_pair(in_size, step, enc, "bf16", G0, D0)
+    real = R.synthetic_images(n, in_size, seed=310)
+    noises = [R.synthetic_normal(n, enc, seed=410 + j) for j in range(3)]
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ref = R.train_iteration(Go, Do, ogo, odo, real, noises, 0.35)
+    rd = real.cuda()
+    lg = PL._g_step(G, D, og, noises[0].cuda()).item()
+    ld = PL._d_step(G, D, od, rd, noises[1].cuda(), None).item()
+    lp = PL._gp_step(G, D, od, rd, noises[2].cuda(), 0.35, 10.0).item()
+    print("batch-64 losses hip/ref:", lg, ref["g"], ld, ref["d"], lp, ref["gp"])
+    for got, want in ((lg, ref["g"]), (ld, ref["d"]), (lp, ref["gp"])):
+        assert np.isfinite(got) and abs(got - want) <= 6e-2 * (abs(want) + 0.1)
+    for name, mod, mod0, modo in (("model.1.0.weight", G, G0, Go), ("model.5.0.weight", D, D0, Do)):
+        w0 = mod0.state_dict()[name].double()
+        du_hip = mod.state_dict()[name].cpu().double() - w0
+        du_ref = modo.state_dict()[name].double() - w0
+        cos = float((du_hip * du_ref).sum() / (du_hip.norm() * du_ref.norm() + 1e-30))
+        print(name, "update cosine", cos)
+        assert cos >= 0.75, (name, cos)
+
+
 def test_graph_replay_equals_eager():
     """A train_op replayed from a captured HIP graph produces bit-identical parameters to eager launches."""
     from rna_gan_amd import graphed
