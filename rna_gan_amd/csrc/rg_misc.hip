@@ -91,6 +91,15 @@ struct Adam {
 // Adam with the step-dependent constants in device memory.  WIRE: the gradient is read as bf16 from the all-reduced
 // wire buffer of a data-parallel run instead of g; SHADOW: the rounded updated parameters are also written to a bf16
 // buffer (the GEMM operand image of the tap-major conv weights).  The 7 constants are loaded once per thread.
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_ld4(const float* p) {
+  nt_f4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void nt_st4(float* p, float4 v) {
+  nt_f4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(p));
+}
 template <bool WIRE, bool SHADOW>
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ m, float* __restrict__ v,
@@ -100,16 +109,18 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
   const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x;
   for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
     const size_t i = q * 4;
-    float4 P = *(float4*)(p + i), M = *(float4*)(m + i), V = *(float4*)(v + i), G;
+    // m, v and g are streamed (touched once per step): non-temporal so that they do not evict the activations and
+    // weight images the next kernels re-read from L2 / Infinity Cache
+    float4 P = *(float4*)(p + i), M = nt_ld4(m + i), V = nt_ld4(v + i), G;
     if (WIRE) {
       const uint2 w = *(const uint2*)(gw + i);
       G = make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
                       __uint_as_float(w.y & 0xffff0000u));
     } else {
-      G = *(const float4*)(g + i);
+      G = nt_ld4(g + i);
     }
     a.upd(P.x, G.x, M.x, V.x); a.upd(P.y, G.y, M.y, V.y); a.upd(P.z, G.z, M.z, V.z); a.upd(P.w, G.w, M.w, V.w);
-    *(float4*)(p + i) = P; *(float4*)(m + i) = M; *(float4*)(v + i) = V;
+    *(float4*)(p + i) = P; nt_st4(m + i, M); nt_st4(v + i, V);
     if (SHADOW)
       *(uint2*)(shadow + i) = make_uint2((uint32_t)f32_to_bf16(P.x) | ((uint32_t)f32_to_bf16(P.y) << 16),
                                          (uint32_t)f32_to_bf16(P.z) | ((uint32_t)f32_to_bf16(P.w) << 16));
