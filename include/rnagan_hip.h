@@ -76,9 +76,14 @@ int rg_pack_g0_weight_from_bf16(const void* w_bf16, void* wp, int E, int C, void
 /* y[N][Hi/2][Wi/2][O] = conv2d(x[N][Hi][Wi][I], w[O][4][4][I], stride 2, pad 1).
  * nn.Conv2d forward in the discriminator (D(.) at src/wgan_loss.py:119,241,253,379) and the
  * data-gradient of nn.ConvTranspose2d in the generator (loss.backward(), :126).
- * `wdn` may be NULL when the generic kernel runs (it reads `w`). */
+ * `wdn` may be NULL when the generic kernel runs (it reads `w`).
+ * stats_partial (may be NULL): when the layer is followed by a train-mode BatchNorm, the MFMA epilogue also writes
+ * per-tile column sums of y and y^2 (of the bf16 values as stored), fp32 [rows][2][O] with
+ * rows = rg_conv_stats_rows(...) (0: this shape takes split-K or the generic kernel -- pass NULL and use
+ * rg_bn_forward).  rg_bn_forward_partials finishes them: the separate statistics pass over y disappears. */
+int rg_conv_stats_rows(int up, int N, int Hlow, int Wlow, int O, int I, int dtype, int algo);
 int rg_conv_down(const void* x, const float* w, const void* wdn, void* y, int N, int Hi, int Wi, int I,
-                 int O, int dtype, int algo, void* ws, size_t ws_bytes, void* stream);
+                 int O, float* stats_partial, int dtype, int algo, void* ws, size_t ws_bytes, void* stream);
 /* workspace of rg_conv_down (up = 0) / rg_conv_up (up = 1): split-K partial slabs for layers whose tile
  * grid cannot fill the chip (few rows, long K); Hlow/Wlow = low-resolution side.  May be 0. */
 size_t rg_conv_workspace_bytes(int up, int N, int Hlow, int Wlow, int O, int I, int dtype, int algo);
@@ -90,7 +95,8 @@ size_t rg_conv_workspace_bytes(int up, int N, int Hlow, int Wlow, int O, int I, 
  * i.e. the LeakyReLU backward of the layer below is applied in the epilogue (the data-gradient of discriminator
  * layer 1 feeding layer 0's LeakyReLU) instead of in a separate pass over y. */
 int rg_conv_up(const void* x, const float* w, const void* wup, void* y, int N, int Ho, int Wo, int O, int I,
-               const void* mask_act, float mask_slope, int dtype, int algo, void* ws, size_t ws_bytes, void* stream);
+               const void* mask_act, float mask_slope, float* stats_partial, int dtype, int algo, void* ws,
+               size_t ws_bytes, void* stream);
 
 /* dw[O][kh][kw][I] (+)= sum_{n,ho,wo} low[n][ho][wo][o] * high[n][2ho-1+kh][2wo-1+kw][i].
  * Weight gradient of both layer kinds (every .backward()).  Deterministic: split-K partial slabs
@@ -184,6 +190,12 @@ int rg_bn_finalize(const float* sum, const float* sumsq, int M, int C, float eps
 int rg_bn_forward(const void* z, int M, int C, float eps, float momentum, const float* gamma, const float* beta,
                   float slope, float* mean, float* invstd, float* running_mean, float* running_var,
                   int64_t* num_batches_tracked, void* a, int dtype, void* ws, size_t ws_bytes, void* stream);
+/* rg_bn_forward with the statistics taken from the partial sums a conv epilogue wrote (rg_conv_down / rg_conv_up
+ * stats_partial, G rows): finishing kernel + pointwise pass. */
+int rg_bn_forward_partials(const float* partial, int G, const void* z, int M, int C, float eps, float momentum,
+                           const float* gamma, const float* beta, float slope, float* mean, float* invstd,
+                           float* running_mean, float* running_var, int64_t* num_batches_tracked, void* a, int dtype,
+                           void* ws, size_t ws_bytes, void* stream);     /* ws: 32 * 2 * C floats (two-level finish) */
 int rg_bn_stats_finalize(const void* z, int M, int C, float eps, float momentum, float* mean, float* invstd,
                          float* running_mean, float* running_var, int64_t* num_batches_tracked, int dtype, void* ws,
                          size_t ws_bytes, void* stream);

@@ -66,15 +66,16 @@ class RefOps:
 
     # ------------------------------------------------------------------ conv family
     # (the handle's master may be stored tap-major; cw.oihw() / cw.store_grad_oihw() give the PyTorch view)
-    def conv_down(self, x, cw: ConvW):
-        y = F.conv2d(self._nchw(x), self._wq(cw.oihw()), None, stride=2, padding=1)
-        return _nhwc(y, self.act_dtype)
+    def conv_down(self, x, cw: ConvW, want_stats=False):
+        y = _nhwc(F.conv2d(self._nchw(x), self._wq(cw.oihw()), None, stride=2, padding=1), self.act_dtype)
+        return (y, None) if want_stats else y          # the twin has no fused statistics: bn_forward computes them
 
-    def conv_up(self, x, cw: ConvW, mask_act=None, slope=1.0):
+    def conv_up(self, x, cw: ConvW, mask_act=None, slope=1.0, want_stats=False):
         y = F.conv_transpose2d(self._nchw(x), self._wq(cw.oihw()), None, stride=2, padding=1)
         if mask_act is not None:       # fused LeakyReLU backward: applied to the fp32 result, rounded once
             y = y * _lrelu_mask(self._nchw(mask_act), slope)
-        return _nhwc(y, self.act_dtype)
+        y = _nhwc(y, self.act_dtype)
+        return (y, None) if want_stats else y
 
     def conv_wgrad(self, low, high, cw: ConvW, accumulate: bool):
         g = torch.nn.grad.conv2d_weight(self._nchw(high), (cw.O, cw.I, 4, 4), self._nchw(low), stride=2, padding=1)
@@ -172,7 +173,7 @@ class RefOps:
         return zf.sum(0), (zf * zf).sum(0)
 
     def bn_forward(self, z, gamma, beta, slope: float, eps: float, momentum: float, running_mean=None,
-                   running_var=None, nbt=None):
+                   running_var=None, nbt=None, partials=None):
         mean, invstd = self.bn_stats_finalize(z, eps, momentum, running_mean, running_var, nbt)
         return self.bn_act(z, mean, invstd, gamma, beta, slope), mean, invstd
 

@@ -24,8 +24,9 @@ PROTOTYPES = {
     "rg_version": (_i, []),
     "rg_last_error": (C.c_char_p, []),
     "rg_pack_conv_weight": (_i, [_p, _p, _p, _i, _i, _i, _p]),
-    "rg_conv_down": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
-    "rg_conv_up": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _f, _i, _i, _p, _z, _p]),
+    "rg_conv_stats_rows": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "rg_conv_down": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _z, _p]),
+    "rg_conv_up": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _f, _p, _i, _i, _p, _z, _p]),
     "rg_conv_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "rg_conv_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),
     "rg_conv_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
@@ -51,6 +52,7 @@ PROTOTYPES = {
     "rg_bn_stats": (_i, [_p, _p, _p, _i, _i, _i, _p, _z, _p]),
     "rg_bn_finalize": (_i, [_p, _p, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p]),
     "rg_bn_forward": (_i, [_p, _i, _i, _f, _f, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _p, _z, _p]),
+    "rg_bn_forward_partials": (_i, [_p, _i, _p, _i, _i, _f, _f, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _p, _z, _p]),
     "rg_bn_stats_finalize": (_i, [_p, _i, _i, _f, _f, _p, _p, _p, _p, _p, _i, _p, _z, _p]),
     "rg_bn_act": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p]),
     "rg_bn_act_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _z, _p]),

@@ -32,23 +32,33 @@ extern "C" size_t rg_conv_workspace_bytes(int up, int N, int Hlow, int Wlow, int
   return rg_mfma_conv_ws_bytes(up, N, Hlow, Wlow, O, I);
 }
 
+extern "C" int rg_conv_stats_rows(int up, int N, int Hlow, int Wlow, int O, int I, int dtype, int algo) {
+  if (N <= 0 || Hlow <= 0 || Wlow <= 0 || O <= 0 || I <= 0 || !want_mfma(algo, dtype)) return 0;
+  if (!rg_mfma_conv_supported(N, Hlow, Wlow, up ? O : I, up ? I : O)) return 0;
+  return rg_mfma_conv_stats_rows(up, N, Hlow, Wlow, O, I);
+}
+
 extern "C" int rg_conv_down(const void* x, const float* w, const void* wdn, void* y, int N, int Hi, int Wi, int I,
-                            int O, int dtype, int algo, void* ws, size_t ws_bytes, void* stream) {
+                            int O, float* stats_partial, int dtype, int algo, void* ws, size_t ws_bytes, void* stream) {
   RG_REQUIRE(x && y && N > 0 && Hi > 0 && Wi > 0 && I > 0 && O > 0 && Hi % 2 == 0 && Wi % 2 == 0, RG_EINVAL,
              "conv_down: bad args");
   if (want_mfma(algo, dtype) && wdn && rg_mfma_conv_supported(N, Hi / 2, Wi / 2, /*Kc=*/I, /*Ncols=*/O))
-    return rg_mfma_conv_down(x, wdn, y, N, Hi, Wi, I, O, ws, ws_bytes, rg_stream(stream));
+    return rg_mfma_conv_down(x, wdn, y, N, Hi, Wi, I, O, stats_partial, ws, ws_bytes, rg_stream(stream));
+  RG_REQUIRE(!stats_partial, RG_EUNSUPPORTED, "conv_down: statistics come from the MFMA epilogue only");
   RG_REQUIRE(algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "conv_down: shape/dtype not supported by the MFMA kernel");
   RG_REQUIRE(w, RG_EINVAL, "conv_down: generic kernel needs the fp32 master weight");
   return rg_generic_conv_down(x, w, y, N, Hi, Wi, I, O, dtype, rg_stream(stream));
 }
 
 extern "C" int rg_conv_up(const void* x, const float* w, const void* wup, void* y, int N, int Ho, int Wo, int O, int I,
-                          const void* mask_act, float mask_slope, int dtype, int algo, void* ws, size_t ws_bytes,
-                          void* stream) {
+                          const void* mask_act, float mask_slope, float* stats_partial, int dtype, int algo, void* ws,
+                          size_t ws_bytes, void* stream) {
   RG_REQUIRE(x && y && N > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0, RG_EINVAL, "conv_up: bad args");
+  RG_REQUIRE(!(mask_act && stats_partial), RG_EINVAL, "conv_up: mask and statistics are exclusive");
   if (want_mfma(algo, dtype) && wup && rg_mfma_conv_supported(N, Ho, Wo, /*Kc=*/O, /*Ncols=*/I))
-    return rg_mfma_conv_up(x, wup, y, N, Ho, Wo, O, I, mask_act, mask_slope, ws, ws_bytes, rg_stream(stream));
+    return rg_mfma_conv_up(x, wup, y, N, Ho, Wo, O, I, mask_act, mask_slope, stats_partial, ws, ws_bytes,
+                           rg_stream(stream));
+  RG_REQUIRE(!stats_partial, RG_EUNSUPPORTED, "conv_up: statistics come from the MFMA epilogue only");
   RG_REQUIRE(algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "conv_up: shape/dtype not supported by the MFMA kernel");
   RG_REQUIRE(w, RG_EINVAL, "conv_up: generic kernel needs the fp32 master weight");
   return rg_generic_conv_up(x, w, y, N, Ho, Wo, O, I, mask_act, mask_slope, dtype, rg_stream(stream));

@@ -103,6 +103,55 @@ __global__ __launch_bounds__(256) void colfinish_kernel(Fin fin, const float* pa
   }
 }
 
+// finishing pass for MANY partial rows (conv-epilogue statistics: one row per (row tile, wave row)): block = 8 channels,
+// 256 threads stride over the partial rows with 32-byte loads, then wave shuffles + LDS.  Fixed order -> deterministic.
+// gridDim.y slices the partial rows (each slice finished by its own block: fin gets c + slice*C as the channel index,
+// i.e. a Store2Fin pointed at a [slices][C] staging area produces the input of a second, small colfinish pass).
+template <int NQ, class Fin>
+__global__ __launch_bounds__(256) void colfinish_wide_kernel(Fin fin, const float* __restrict__ partial, int C, int G) {
+  __shared__ float sm[4][NQ][8];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int c0 = blockIdx.x * 8;
+  const int per = (G + gridDim.y - 1) / gridDim.y;
+  const int g0 = blockIdx.y * per, g1 = min(G, g0 + per);
+  float acc[NQ][8];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int v = 0; v < 8; ++v) acc[q][v] = 0.f;
+  for (int g = g0 + t; g < g1; g += 256)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      float v[8];
+      Vec<float, 8>::ld(partial + ((size_t)g * NQ + q) * C + c0, v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[q][k] += v[k];
+    }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      float w = wave_sum(acc[q][v]);
+      if (lane == 0) sm[wave][q][v] = w;
+    }
+  __syncthreads();
+  if (t < 8) {
+    float sv[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) sv[q] = sm[0][q][t] + sm[1][q][t] + sm[2][q][t] + sm[3][q][t];
+    fin(c0 + t + (int)blockIdx.y * C, sv);
+  }
+}
+// level-1 finisher of the sliced form: row `slice` of a [slices][2][C] staging area (colfinish_kernel's input layout)
+struct SliceFin {
+  float* out; int C;
+  __device__ void operator()(int cs, const float* s) const {
+    const int slice = cs / C, c = cs - slice * C;
+    out[((size_t)slice * 2 + 0) * C + c] = s[0];
+    out[((size_t)slice * 2 + 1) * C + c] = s[1];
+  }
+};
+
 // ---- pointwise skeleton: F has  init(c)  and  row(r, c)
 template <int VEC, int TX, class F>
 __global__ __launch_bounds__(256) void rowapply_kernel(F f, int M, int C, int rows_per_block) {
@@ -523,6 +572,32 @@ extern "C" int rg_bn_forward(const void* z, int M, int C, float eps, float momen
     if (rc) return rc;
     return (row_apply<T, BnActF>("bn_forward", M, C, st, (const T*)z, (T*)a, p, C));
   })
+}
+
+extern "C" int rg_bn_forward_partials(const float* partial, int G, const void* z, int M, int C, float eps, float momentum,
+                                      const float* gamma, const float* beta, float slope, float* mean, float* invstd,
+                                      float* running_mean, float* running_var, int64_t* num_batches_tracked, void* a,
+                                      int dtype, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(partial && G > 0 && z && a && mean && invstd && gamma && beta && M > 0 && C > 0, RG_EINVAL,
+             "bn_forward_partials: bad args");
+  StatsFinalizeFin fin{(float)M, eps, momentum, mean, invstd, running_mean, running_var,
+                       running_mean ? num_batches_tracked : nullptr};
+  BNC p{mean, invstd, gamma, beta, slope};
+  hipStream_t st = rg_stream(stream);
+  // many partial rows (big layers: one per row tile and wave row): two levels, 32 slices first
+  constexpr int SLICES = 32;
+  if (G > 512 && C % 8 == 0 && ws && ws_bytes >= (size_t)SLICES * 2 * C * sizeof(float)) {
+    float* stage = (float*)ws;
+    hipLaunchKernelGGL((colfinish_wide_kernel<2, SliceFin>), dim3(C / 8, SLICES), dim3(256), 0, st, SliceFin{stage, C},
+                       partial, C, G);
+    RG_LAUNCH_CHECK("bn_forward_partials");
+    hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, stage, C,
+                       SLICES);
+  } else {
+    hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, partial, C, G);
+  }
+  RG_LAUNCH_CHECK("bn_forward_partials");
+  RG_DISPATCH_DTYPE(dtype, T, { return (row_apply<T, BnActF>("bn_forward_partials", M, C, st, (const T*)z, (T*)a, p, C)); })
 }
 
 extern "C" int rg_bn_finalize(const float* sum, const float* sumsq, int M, int C, float eps, float momentum,

@@ -32,10 +32,11 @@ size_t rg_mfma_wgrad_ws_bytes(int N, int Ho, int Wo, int O, int I);
 int rg_mfma_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I, hipStream_t st);
 int rg_mfma_pack_g0_weight(const float* w, void* wp, int E, int C, hipStream_t st);
 int rg_mfma_pack_linear_weight(const float* w, void* wp, int Nout, int K, int Nout_pad, int K_pad, hipStream_t st);
-int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, int Wi, int I, int O, void* ws,
-                      size_t ws_bytes, hipStream_t st);
+int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, int Wi, int I, int O, float* stats,
+                      void* ws, size_t ws_bytes, hipStream_t st);
+int rg_mfma_conv_stats_rows(int up, int N, int Hlow, int Wlow, int O, int I);
 int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, const void* mask,
-                    float mslope, void* ws, size_t ws_bytes, hipStream_t st);
+                    float mslope, float* stats, void* ws, size_t ws_bytes, hipStream_t st);
 size_t rg_mfma_conv_ws_bytes(int up, int N, int Hlow, int Wlow, int O, int I);
 size_t rg_generic_upconv3_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int rg_generic_upconv3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int Cin,

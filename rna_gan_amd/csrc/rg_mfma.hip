@@ -41,6 +41,8 @@ struct GArgs {
   const float* scale;
   const float* shift;
   float slope;
+  float* stats;           // EPI_BF16, optional: per-tile column sums of the (bf16-rounded) output and of its square,
+                          // [partial rows][2][Ncols] (BatchNorm statistics straight from the conv epilogue)
   const uint16_t* mask;   // EPI_BF16, optional: activation with the output's shape; out *= (mask > 0 ? 1 : mslope)
   float mslope;           // (LeakyReLU backward of the consumer fused into the data-gradient conv)
 };
@@ -293,6 +295,7 @@ struct G2Args {
   unsigned a_bytes, b_bytes;   // sizes for the buffer descriptors
   int nsplit;
   int xcd_swizzle;             // 1: remap blockIdx.x so each XCD (block b runs on XCD b % 8) owns a contiguous tile range
+  int tiles_m;                 // number of row tiles (per parity class)
   int class_fast;              // MODE_UP: the 4 output-parity classes are the fastest-varying part of blockIdx.x (they
                                // read the same input rows: back to back on one XCD the rows are fetched from HBM once)
   float* slab;                 // [nsplit][rows_out][Ncols] fp32 when nsplit > 1
@@ -525,6 +528,33 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
 #undef RG_WAIT
 #undef RG_MFMAS
   __syncthreads();
+
+  // ---- BatchNorm statistics straight from the accumulators: a lane's 16*TI registers of column tile j all belong to
+  // ONE output column (col = j*32 + lane%32, rows spread over the registers and the two half-waves), so the column
+  // sums of this wave's WTM rows are register adds plus one cross-half shuffle.  Values are rounded to bf16 first (the
+  // statistics of what is stored); rows beyond M were zero-filled operands and contribute exactly 0.
+  if (EPI == EPI_BF16 && g.stats && a2.nsplit == 1) {
+    constexpr int PARTS = BM / WTM;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = bf16_to_f32(f32_to_bf16(acc[i][j][r]));
+          s1 += v; s2 += v * v;
+        }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      const int gcol = bn + wn * 64 + j * 32 + fr;
+      if (fh == 0 && gcol < g.Ncols) {
+        const size_t grow = ((size_t)par * a2.tiles_m + tile_m) * PARTS + wm;
+        g.stats[(grow * 2 + 0) * g.Ncols + gcol] = s1;
+        g.stats[(grow * 2 + 1) * g.Ncols + gcol] = s2;
+      }
+    }
+  }
 
   // ---- epilogue through LDS (fp32 [BM][EP_COLS] per pass)
   float* cs = reinterpret_cast<float*>(lds);
@@ -1084,6 +1114,9 @@ static bool use_v1() {
 }
 
 // split-K policy of the DMA kernel: only when the grid cannot fill the chip (< 1 block per CU) and K is long
+// tile variant / split-K decision of the DMA kernel, shared by the launcher and by rg_mfma_conv_stats_rows
+struct GPlan { bool narrow, wide; int nsplit; };
+
 static int gather_split(int M, int Ncols, int nclass, int nkt, bool allow, int cap = 4, int min_kt = 16) {
   if (!allow) return 1;
   int bn = Ncols <= 64 ? 64 : 128, bmm = bn == 128 ? 128 : 256;
@@ -1096,9 +1129,46 @@ static int gather_split(int M, int Ncols, int nclass, int nkt, bool allow, int c
   return s < 1 ? 1 : s;
 }
 
+// 128x128 block with 64x64 wave tiles (4 waves, 2 blocks/CU) by default; 256x64 for <= 64 output columns.  The
+// 256x256 block with 128x64 wave tiles (8 waves, 1 block/CU; 42.7 instead of 32 flop per LDS byte) is faster
+// (+9..13 %) exactly when its tile count fills the chip without split-K (whose fp32 partials cost more HBM time than
+// the tile saves): RNAGAN_CONV_TILE=0 disables it, =5 forces it wherever it fits (with split-K).
+// Split-K: conv outputs up to 4 splits; dense weight-streaming layers (M = batch) up to 16 (HBM-bound, the grid
+// must cover all CUs to pull full bandwidth); none when a mask is fused into the bf16 epilogue.
+static GPlan gather_plan(bool bf16_out, int M, int Ncols, int nkt, int nclass, bool masked) {
+  static int variant = -1;
+  if (variant < 0) { const char* e = getenv("RNAGAN_CONV_TILE"); variant = e ? atoi(e) : 1; }
+  GPlan pl;
+  pl.narrow = Ncols <= 64;
+  const long long tiles256 = (long long)((M + 255) / 256) * ((Ncols + 255) / 256) * nclass;
+  pl.wide = !pl.narrow && bf16_out && M >= 256 && Ncols >= 256 && Ncols % 256 == 0 &&
+            (variant == 5 || (variant == 1 && tiles256 >= 256 && tiles256 % 256 == 0));
+  if (masked) {
+    pl.nsplit = 1;
+  } else if (pl.wide) {
+    pl.nsplit = 1;
+    while (tiles256 * pl.nsplit < 256 && pl.nsplit < 8 && nkt / (pl.nsplit * 2) >= 8) pl.nsplit *= 2;   // one block per CU
+  } else {
+    pl.nsplit = bf16_out ? gather_split(M, Ncols, nclass, nkt, true) : gather_split(M, Ncols, nclass, nkt, true, 16, 8);
+  }
+  return pl;
+}
+
 size_t rg_mfma_gather_ws_bytes(int M_out_rows, int M, int Ncols, int nclass, int nkt) {
   int s = gather_split(M, Ncols, nclass, nkt, true);
   return s > 1 ? (size_t)s * M_out_rows * Ncols * sizeof(float) : 0;
+}
+
+
+// partial rows the conv epilogue writes when asked for BatchNorm statistics (0: this launch cannot produce them)
+int rg_mfma_conv_stats_rows(int up, int N, int Hlow, int Wlow, int O, int I) {
+  const int M = N * Hlow * Wlow, Ncols = up ? I : O, Cin = up ? O : I, taps = up ? 4 : 16, nclass = up ? 4 : 1;
+  const size_t a_bytes = up ? (size_t)M * O * 2 : (size_t)M * 4 * I * 2, b_bytes = (size_t)O * 16 * I * 2;
+  if (use_v1() || a_bytes >= 0x7fffff00ull || b_bytes >= 0x7fffff00ull) return 0;
+  GPlan pl = gather_plan(true, M, Ncols, taps * (Cin >> 6), nclass, false);
+  if (pl.nsplit > 1) return 0;
+  const int bmm = (pl.narrow || pl.wide) ? 256 : 128, parts = pl.narrow ? 4 : 2;      // BM / wave-tile rows
+  return nclass * ((M + bmm - 1) / bmm) * parts;
 }
 
 template <int MODE, int EPI>
@@ -1107,28 +1177,9 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   if (use_v1() || a_bytes >= 0x7fffff00ull || b_bytes >= 0x7fffff00ull) return launch_gather<MODE, EPI>(name, g, nclass, st);
   G2Args a2{};
   const int nkt = g.taps * (g.Cin >> 6);
-  // conv outputs: up to 4 splits; dense weight-streaming layers (M = batch): up to 16 (HBM-bound, the grid
-  // must cover all CUs to pull full bandwidth)
-  const bool narrow = g.Ncols <= 64;
-  // 128x128 block with 64x64 wave tiles (4 waves, 2 blocks/CU) by default.  The 256x256 block with 128x64 wave
-  // tiles (8 waves, 1 block/CU; 42.7 instead of 32 flop per LDS byte) is faster (+9..13 %) exactly when its tile
-  // count fills the chip without split-K (whose fp32 partials cost more HBM time than the tile saves):
-  // RNAGAN_CONV_TILE=0 disables it, =5 forces it wherever it fits (with split-K).
-  static int variant = -1;
-  if (variant < 0) { const char* e = getenv("RNAGAN_CONV_TILE"); variant = e ? atoi(e) : 1; }
-  const long long tiles256 = (long long)((g.M + 255) / 256) * ((g.Ncols + 255) / 256) * nclass;
-  const bool wide = !narrow && EPI == EPI_BF16 && g.M >= 256 && g.Ncols >= 256 && g.Ncols % 256 == 0 &&
-                    (variant == 5 || (variant == 1 && tiles256 >= 256 && tiles256 % 256 == 0));
-  int nsplit;
-  if (g.mask) {
-    nsplit = 1;       // the fused mask lives in the bf16 epilogue, not in the slab reduction
-  } else if (wide) {
-    nsplit = 1;
-    while (tiles256 * nsplit < 256 && nsplit < 8 && nkt / (nsplit * 2) >= 8) nsplit *= 2;   // one block per CU
-  } else {
-    nsplit = EPI == EPI_BF16 ? gather_split(g.M, g.Ncols, nclass, nkt, true)
-                             : gather_split(g.M, g.Ncols, nclass, nkt, true, 16, 8);
-  }
+  const GPlan pl = gather_plan(EPI == EPI_BF16, g.M, g.Ncols, nkt, nclass, g.mask != nullptr);
+  const bool narrow = pl.narrow, wide = pl.wide;
+  int nsplit = pl.nsplit;
   size_t need = (size_t)nsplit * rows_out * (EPI == EPI_BF16 ? g.Ncols : g.ldc) * sizeof(float);
   if (nsplit > 1 && (!ws || ws_bytes < need)) nsplit = 1;
   a2.a_bytes = (unsigned)a_bytes; a2.b_bytes = (unsigned)b_bytes;
@@ -1136,6 +1187,7 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   const int bn = narrow ? 64 : wide ? 256 : 128, bmm = (narrow || wide) ? 256 : 128;
   g.tiles_n = (g.Ncols + bn - 1) / bn;
   a2.g = g;
+  a2.tiles_m = (g.M + bmm - 1) / bmm;
   dim3 grid(((g.M + bmm - 1) / bmm) * g.tiles_n, nclass, nsplit);
   static int xcd = -1;
   if (xcd < 0) { const char* e = getenv("RNAGAN_XCD"); xcd = e ? atoi(e) : 1; }
@@ -1168,9 +1220,10 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   return RG_OK;
 }
 
-int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, int Wi, int I, int O, void* ws,
-                      size_t ws_bytes, hipStream_t st) {
+int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, int Wi, int I, int O, float* stats,
+                      void* ws, size_t ws_bytes, hipStream_t st) {
   GArgs g{};
+  g.stats = stats;
   g.A = (const uint16_t*)x; g.B = (const uint16_t*)wdn; g.C = y;
   int Ho = Hi / 2, Wo = Wi / 2;
   g.M = N * Ho * Wo; g.Ncols = O; g.Cin = I; g.taps = 16;
@@ -1180,8 +1233,9 @@ int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, in
 }
 
 int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, const void* mask,
-                    float mslope, void* ws, size_t ws_bytes, hipStream_t st) {
+                    float mslope, float* stats, void* ws, size_t ws_bytes, hipStream_t st) {
   GArgs g{};
+  g.stats = mask ? nullptr : stats;
   g.mask = (const uint16_t*)mask; g.mslope = mslope;
   g.A = (const uint16_t*)x; g.B = (const uint16_t*)wup; g.C = y;
   g.M = N * Ho * Wo; g.Ncols = I; g.Cin = O; g.taps = 4;

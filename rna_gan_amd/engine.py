@@ -151,10 +151,12 @@ class _Ctx:
     pass
 
 
-def _bn_forward(ops, z, bn: BNP, slope, update_running=True):
+def _bn_forward(ops, z, bn: BNP, slope, update_running=True, partials=None):
+    """partials: BatchNorm column sums written by the epilogue of the conv that produced z (or None)."""
     if update_running:
-        return ops.bn_forward(z, bn.gamma, bn.beta, slope, bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.nbt)
-    return ops.bn_forward(z, bn.gamma, bn.beta, slope, bn.eps, bn.momentum)
+        return ops.bn_forward(z, bn.gamma, bn.beta, slope, bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.nbt,
+                              partials=partials)
+    return ops.bn_forward(z, bn.gamma, bn.beta, slope, bn.eps, bn.momentum, partials=partials)
 
 
 # --------------------------------------------------------------------------------------------
@@ -169,8 +171,8 @@ def disc_forward(ops, D: DiscNet, x_nchw, update_running=True):
     ctx.a = [a]
     ctx.z, ctx.mean, ctx.invstd = [None], [None], [None]
     for cw, bn in D.blocks:
-        z = ops.conv_down(a, cw)
-        a, mean, invstd = _bn_forward(ops, z, bn, D.slope, update_running)
+        z, st = ops.conv_down(a, cw, want_stats=True)
+        a, mean, invstd = _bn_forward(ops, z, bn, D.slope, update_running, st)
         ctx.z.append(z); ctx.mean.append(mean); ctx.invstd.append(invstd); ctx.a.append(a)
     ctx.h, out = ops.head_fwd(a, D.head, D.last_slope)
     return out, ctx
@@ -308,8 +310,8 @@ def gen_forward(ops, G: GenNet, noise, update_running=True, keep=True):
     a, mean, invstd = _bn_forward(ops, z, G.bn0, G.slope, update_running)
     ctx.z, ctx.mean, ctx.invstd, ctx.a = [z], [mean], [invstd], [a]
     for cw, bn in G.blocks:
-        z = ops.conv_up(a, cw)
-        a, mean, invstd = _bn_forward(ops, z, bn, G.slope, update_running)
+        z, st = ops.conv_up(a, cw, want_stats=True)
+        a, mean, invstd = _bn_forward(ops, z, bn, G.slope, update_running, st)
         if keep:
             ctx.z.append(z); ctx.mean.append(mean); ctx.invstd.append(invstd); ctx.a.append(a)
     img = ops.last_up(a, G.last, G.last.bias, True)

@@ -44,6 +44,7 @@ class HipOps:
         self._keep = []
         self.use_side = os.environ.get("RNAGAN_SIDE_STREAM", "0") != "0"
         self.pack_from_shadow = os.environ.get("RNAGAN_PACK_FROM_SHADOW", "1") != "0"
+        self.epilogue_stats = os.environ.get("RNAGAN_EPILOGUE_STATS", "1") != "0"
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -132,22 +133,32 @@ class HipOps:
                              "conv weights with rna_gan_amd.models.tap_major_(module) (or build the handle with "
                              "ConvW.from_param on such a parameter)")
 
-    def conv_down(self, x, cw: ConvW):
+    def _stats_buf(self, up, N, Hl, Wl, O, I, C):
+        """Buffer for the BatchNorm partial sums a conv epilogue can write, or None (split-K / generic kernel)."""
+        if not self.epilogue_stats:
+            return None
+        rows = self.lib.rg_conv_stats_rows(up, N, Hl, Wl, O, I, self.dt, self.algo)
+        return self._f32(rows, 2, C) if rows > 0 else None
+
+    def conv_down(self, x, cw: ConvW, want_stats=False):
+        """Stride-2 conv.  want_stats: also return the per-tile column sums of y and y^2 written by the MFMA epilogue
+        (None when this shape cannot produce them) for bn_forward(..., partials=...)."""
         N, Hi, Wi, I = x.shape
         O = cw.O
         self._tap_major(cw)
         assert cw.I == I and x.is_contiguous()
         wdn, _ = self._packs(cw)
         y = self._act(N, Hi // 2, Wi // 2, O)
+        st = self._stats_buf(0, N, Hi // 2, Wi // 2, O, I, O) if want_stats else None
         ws = self._ws(self.lib.rg_conv_workspace_bytes(0, N, Hi // 2, Wi // 2, O, I, self.dt, self.algo))
         self._timed("conv_fwd_dgrad", 2.0 * N * (Hi // 2) * (Wi // 2) * O * I * 16, lambda: check(
-            self.lib.rg_conv_down(_ptr(x), _ptr(cw.w), _ptr(wdn), _ptr(y), N, Hi, Wi, I, O, self.dt, self.algo,
-                                  _ptr(ws), ws.numel(), self.stream), "rg_conv_down"))
-        return y
+            self.lib.rg_conv_down(_ptr(x), _ptr(cw.w), _ptr(wdn), _ptr(y), N, Hi, Wi, I, O, _ptr(st), self.dt,
+                                  self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_down"))
+        return (y, st) if want_stats else y
 
-    def conv_up(self, x, cw: ConvW, mask_act=None, slope=1.0):
+    def conv_up(self, x, cw: ConvW, mask_act=None, slope=1.0, want_stats=False):
         """Transposed conv; with mask_act (same shape as the result) the LeakyReLU backward
-        ``y *= (mask_act > 0 ? 1 : slope)`` is applied in the kernel's epilogue."""
+        ``y *= (mask_act > 0 ? 1 : slope)`` is applied in the kernel's epilogue.  want_stats: as conv_down."""
         N, Ho, Wo, O = x.shape
         I = cw.I
         self._tap_major(cw)
@@ -155,11 +166,12 @@ class HipOps:
         _, wup = self._packs(cw)
         y = self._act(N, 2 * Ho, 2 * Wo, I)
         assert mask_act is None or (mask_act.shape == y.shape and mask_act.dtype == y.dtype and mask_act.is_contiguous())
+        st = self._stats_buf(1, N, Ho, Wo, O, I, I) if (want_stats and mask_act is None) else None
         ws = self._ws(self.lib.rg_conv_workspace_bytes(1, N, Ho, Wo, O, I, self.dt, self.algo))
         self._timed("conv_fwd_dgrad", 2.0 * N * Ho * Wo * O * I * 16, lambda: check(
             self.lib.rg_conv_up(_ptr(x), _ptr(cw.w), _ptr(wup), _ptr(y), N, Ho, Wo, O, I, _ptr(mask_act), float(slope),
-                                self.dt, self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_up"))
-        return y
+                                _ptr(st), self.dt, self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_up"))
+        return (y, st) if want_stats else y
 
     def conv_wgrad(self, low, high, cw: ConvW, accumulate: bool):
         N, Ho, Wo, O = low.shape
@@ -351,11 +363,20 @@ class HipOps:
         return mean, invstd
 
     def bn_forward(self, z, gamma, beta, slope: float, eps: float, momentum: float, running_mean=None,
-                   running_var=None, nbt=None):
-        """Train-mode BatchNorm + LeakyReLU: (a, mean, invstd); one launch for small tensors."""
+                   running_var=None, nbt=None, partials=None):
+        """Train-mode BatchNorm + LeakyReLU: (a, mean, invstd).  partials: the column sums the producing conv's
+        epilogue wrote (conv_down/conv_up want_stats) -- then no statistics pass over z is needed."""
         M, C = self._mc(z)
         mean, invstd = self._f32(C), self._f32(C)
         a = torch.empty_like(z)
+        if partials is not None:
+            ws = self._ws(32 * 2 * C * 4)
+            check(self.lib.rg_bn_forward_partials(_ptr(partials), partials.shape[0], _ptr(z), M, C, float(eps),
+                                                  float(momentum), _ptr(gamma), _ptr(beta), float(slope), _ptr(mean),
+                                                  _ptr(invstd), _ptr(running_mean), _ptr(running_var), _ptr(nbt),
+                                                  _ptr(a), self.dt, _ptr(ws), ws.numel(), self.stream),
+                  "rg_bn_forward_partials")
+            return a, mean, invstd
         ws = self._ws(self.lib.rg_colreduce_workspace_bytes(M, C, 2))
         check(self.lib.rg_bn_forward(_ptr(z), M, C, float(eps), float(momentum), _ptr(gamma), _ptr(beta), float(slope),
                                      _ptr(mean), _ptr(invstd), _ptr(running_mean), _ptr(running_var), _ptr(nbt),

@@ -83,6 +83,21 @@ def test_conv_down_up_wgrad(N, Hi, Wi, I, O, dtype):
     u_ref = ref.conv_up(g, cr)
     u = hip.conv_up(dev(g), ch)
     check(u, u_ref, TOL[dtype], "conv_up")
+    # BatchNorm partial sums from the MFMA epilogue (None where the launch cannot produce them): exact column sums of
+    # the stored values, and bn_forward(partials=...) == bn_forward()
+    for name, (yy, st) in (("conv_down", hip.conv_down(dev(x), ch, want_stats=True)),
+                           ("conv_up", hip.conv_up(dev(g), ch, want_stats=True))):
+        if st is None:
+            continue
+        C = yy.shape[-1]
+        yf = yy.float().reshape(-1, C)
+        check(st[:, 0, :].sum(0), yf.sum(0), 1e-4, name + " epilogue sum")
+        check(st[:, 1, :].sum(0), (yf * yf).sum(0), 1e-4, name + " epilogue sumsq")
+        gam, bet = dev(1 + 0.1 * rnd((C,), 40)), dev(0.1 * rnd((C,), 41))
+        a1, m1, i1 = hip.bn_forward(yy, gam, bet, 0.2, 1e-5, 0.1, partials=st)
+        a2, m2, i2 = hip.bn_forward(yy, gam, bet, 0.2, 1e-5, 0.1)
+        check(m1, m2, 1e-5, name + " mean from partials"); check(i1, i2, 1e-4, name + " invstd from partials")
+        check(a1, a2, 2e-2, name + " bn output from partials")
     m = rnd((N, Hi, Wi, I), 21).to(dtype)       # fused LeakyReLU backward of the consumer layer
     check(hip.conv_up(dev(g), ch, dev(m), 0.2), ref.conv_up(g, cr, m, 0.2), TOL[dtype], "conv_up(masked)")
     ref.conv_wgrad(g, x, cr, False)
