@@ -133,6 +133,9 @@ def main():
     if args.checkpoint is not None:
         trainer.load_model(load_path=args.checkpoint)
     trainer(loader)
+    D_.flush()                     # data parallel: apply a trailing optimizer step before the process group goes away
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
