@@ -226,6 +226,7 @@ def main():
 
     # the instrumented extra iteration contains collectives in a data-parallel run: every rank runs it
     roof = None if args.no_roofline else measure_roofline(ops, device, one_step, ms_per_step)
+    D_.flush()
     if rank == 0:
         fl = conv_flops_per_image()
         total_flops_img = 5 * fl["G"] + 14 * fl["D"]        # 104.6 GFLOP / image / iteration
