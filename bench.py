@@ -237,7 +237,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.seed)
         print(json.dumps(out), flush=True)
     barrier()
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 
