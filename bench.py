@@ -249,21 +249,31 @@ def measure_roofline(ops, device, one_step, step_ms):
                        conv, forward, data-gradient and GP tangent pass of both networks)
       conv_wgrad     = wgrad_kernel + its slab reduction
     `achieved` = algorithmic FLOPs of the family's launches / their summed duration (SURVEY 8d:
-    2*N*Ho*Wo*Cout*Cin*16 per launch).  The dominant family (largest share of the iteration) is the
+    2*N*Ho*Wo*Cout*Cin*16 per launch); a launch's duration is its event interval minus the interval an empty event
+    pair reads (calibrated just before; reported as event_pair_overhead_us) and includes the split-K slab reduction
+    where one follows.  The dominant family (largest share of the iteration) is the
     one reported; the other is listed under `others`."""
     from rna_gan_amd import graphed
     was = graphed.ENABLED
     graphed.ENABLED = False            # per-launch events need eager launches (not a graph replay)
+    # what an empty (record, record) pair reads on this stream: subtracted from every launch's interval
+    stream = torch.cuda.current_stream(device)
+    cal = []
+    for _ in range(32):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream); b.record(stream)
+        cal.append((a, b))
     ops.timing = []
     one_step()
     torch.cuda.synchronize(device)
     graphed.ENABLED = was
+    overhead_ms = sorted(a.elapsed_time(b) for a, b in cal)[len(cal) // 2]
     fam = {}
     for key, flops, e0, e1 in ops.timing:
         f = fam.setdefault(key, {"launches": 0, "flops": 0.0, "ms": 0.0})
         f["launches"] += 1
         f["flops"] += flops
-        f["ms"] += e0.elapsed_time(e1)
+        f["ms"] += max(e0.elapsed_time(e1) - overhead_ms, 0.0)
     ops.timing = None
     rows = {}
     for k, f in fam.items():
@@ -279,6 +289,7 @@ def measure_roofline(ops, device, one_step, step_ms):
             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(rows[dom]["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
+            "event_pair_overhead_us": round(overhead_ms * 1e3, 2),
             "launches": rows[dom]["launches"], "avg_us_per_launch": rows[dom]["avg_us_per_launch"],
             "share_of_step": rows[dom]["share_of_step"],
             "others": {k: v for k, v in rows.items() if k != dom}}
