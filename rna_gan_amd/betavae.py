@@ -91,8 +91,10 @@ class betaVAE(nn.Module):
                              None, lin.bias.detach(), 1.0))
         self._plan = plan
 
-    def encode(self, x):
-        """(z_mean, z_log_var, x_encoded) as src/betaVAE.py:102-107, eval mode."""
+    def encode(self, x, mean_only=False):
+        """(z_mean, z_log_var, x_encoded) as src/betaVAE.py:102-107, eval mode.  mean_only: skip z_log_var (returned as
+        None) -- the loss plugins only use z_mean (``z, _, _ = betavae.encode(rna)``, src/wgan_loss.py:96-97), the
+        reference computes and discards the other head."""
         if self.training:
             raise NotImplementedError("rna_gan_amd.betaVAE implements the frozen (eval) encoder used by RNA-GAN")
         if self._plan is None:
@@ -103,6 +105,8 @@ class betaVAE(nn.Module):
             h = ops.linear_affine_act(h, w, scale, shift, slope, wp=wp)
         w, wp, scale, shift, slope = self._plan[-2]
         z_mean = ops.linear_affine_act(h, w, scale, shift, slope, wp=wp)
+        if mean_only:
+            return z_mean, None, h
         w, wp, scale, shift, slope = self._plan[-1]
         z_log_var = ops.linear_affine_act(h, w, scale, shift, slope, wp=wp)
         return z_mean, z_log_var, h

@@ -399,7 +399,7 @@ class _VAEMixin:
 
     def _noise(self, generator, rna, u):
         """src/wgan_loss.py:96-106: z_mean = betavae.encode(rna)[0]; noise = standardise_columns(u + z_mean)."""
-        z, _, _ = self.betavae.encode(rna)
+        z, _, _ = self.betavae.encode(rna, mean_only=True)
         ops, _ = generator.runtime()
         return ops.latent_prep(u, z)
 
