@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--trace-steps", action="store_true", help="log every timed step's duration (diagnostic)")
+    ap.add_argument("--sync-stats", action="store_true",
+                    help="N > 1: global-batch BatchNorm / latent / penalty statistics (exact single-process semantics, no "
+                         "HIP graphs); default: rank-local statistics (plain DDP), which every reported number uses")
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE configs[1])")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -108,6 +111,7 @@ def main():
     global _DEFAULT_THREADS
     _DEFAULT_THREADS = torch.get_num_threads()
     torch.set_num_threads(min(8, _DEFAULT_THREADS))   # GPU leg: the host only draws noise
+    D_.set_sync_stats(args.sync_stats)
     D_.init_from_env()
     rank, world = D_.rank(), D_.world_size()
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -221,7 +225,8 @@ def main():
         "config": {"workload": "RNA-GAN lung (betaVAE-conditioned wganvae path) 256x256, DCGAN enc2048/step64, "
                                "per-GPU batch %d, one iteration = G-loss + D-loss + GP steps" % N,
                    "global_batch": N * world, "parallelism": "dp%d" % world, "rna_features": rna_features,
-                   "losses_last_step": last_losses, "hip_graphs": out_graphs},
+                   "losses_last_step": last_losses, "hip_graphs": out_graphs and not D_.sync_stats(),
+                   "dp_statistics": "global (sync-stats)" if D_.sync_stats() else "rank-local (DDP)"},
     }
 
     # the instrumented extra iteration contains collectives in a data-parallel run: every rank runs it

@@ -62,6 +62,8 @@ REFERENCE_FLAGS = [
     ("--loss_type", str, "wgangp", "Loss type to use"),
 ]
 EXTRA_FLAGS = [
+    ("--sync_stats", int, 0, "data parallel: 1 = BatchNorm / latent / penalty statistics over the GLOBAL batch (exact "
+                              "single-process semantics, no HIP graphs), 0 = rank-local statistics (plain DDP)"),
     ("--batch_size", int, 8, "per-process batch (the reference hard-codes 8, :94)"),
     ("--precision", str, "bf16", "bf16 (MFMA kernels) or fp32 (parity mode)"),
     ("--betavae_checkpoint", str, "checkpoints/betavae_training_tissues/model_dict_best.pt", "frozen betaVAE weights"),
@@ -82,6 +84,7 @@ def main():
     if args.precision not in ("bf16", "fp32"):
         raise SystemExit("--precision must be bf16 or fp32")
 
+    D_.set_sync_stats(bool(args.sync_stats))
     D_.init_from_env()
     torch.manual_seed(args.seed + D_.rank())
     np.random.seed(args.seed + D_.rank())

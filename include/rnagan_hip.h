@@ -300,6 +300,38 @@ int rg_upconv3_bwd_data(const void* gy, int gy_nchw_f32, const float* w, void* g
 int rg_upconv3_wgrad(const void* gy, int gy_nchw_f32, const void* x, float* dw, int N, int H, int W, int Cin, int Cout,
                      int dtype, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Split forms for synchronised (global-batch) statistics in a data-parallel run (--sync-stats): *_sums
+ * writes the RANK-LOCAL column sums, the caller all-reduces them (tiny RCCL all-reduces), *_apply finishes with the
+ * global sums and the global row count.  Forward statistics use rg_bn_stats + rg_bn_finalize(count = global) +
+ * rg_bn_act; the penalty norm is one scalar all-reduce of rg_sqnorm's result.
+ * ------------------------------------------------------------------------------------------- */
+int rg_bn_bwd_sums(const void* z, const void* ga, const float* mean, const float* invstd, const float* gamma,
+                   const float* beta, float* s_gy, float* s_gyxh, int M, int C, float slope, int dtype, void* ws,
+                   size_t ws_bytes, void* stream);
+int rg_bn_bwd_apply(const void* z, const void* ga, const float* mean, const float* invstd, const float* gamma,
+                    const float* beta, const float* s_gy, const float* s_gyxh, void* gz, int M, int C, int M_total,
+                    float slope, int dtype, void* stream);
+int rg_bn_tangent_sums(const void* z, const void* zt, const float* mean, const float* invstd, const float* gamma,
+                       const float* beta, float* s_zt, float* s_xhzt, int M, int C, float slope, int dtype, void* ws,
+                       size_t ws_bytes, void* stream);
+int rg_bn_tangent_apply(const void* z, const void* zt, const float* mean, const float* invstd, const float* gamma,
+                        const float* beta, const float* s_zt, const float* s_xhzt, void* at, int M, int C, int M_total,
+                        float slope, int dtype, void* stream);
+/* raw3[3][C] = column sums of (gy*zt', qy, qy*xhat) of rg_bn_double_bwd's reduction */
+int rg_bn_dbl_sums(const void* z, const void* qa, const void* zt, const void* ga1, const float* mean, const float* invstd,
+                   const float* gamma, const float* beta, float* raw3, int M, int C, float slope, int dtype, void* ws,
+                   size_t ws_bytes, void* stream);
+/* dgamma / dbeta receive this rank's contribution (summed later by the gradient all-reduce); ws >= 5*C floats */
+int rg_bn_dbl_apply(const void* z, const void* qa, const void* zt, const void* ga1, const float* mean, const float* invstd,
+                    const float* gamma, const float* beta, const float* s_gy, const float* s_gyxh, const float* s_zt,
+                    const float* s_xhzt, const float* raw3_global, const float* raw3_local, void* pz, float* dgamma,
+                    float* dbeta, int accumulate, int M, int C, int M_total, float slope, int dtype, void* ws,
+                    size_t ws_bytes, void* stream);
+int rg_latent_stats(const float* u, const float* z, float* s, float* ss, int N, int E, void* stream);
+int rg_latent_apply(const float* u, const float* z, const float* s, const float* ss, float* out, int N, int E, int N_total,
+                    void* stream);
+
 /* Generated images for export (src/gan_utils.py:236-241): y_nhwc[N][H][W][C] = x_nchw * 0.5 + 0.5 (the inverse of
  * the input normalisation, transforms.Normalize(-mean/std, 1/std) with mean = std = 0.5) in NHWC order. */
 int rg_export_images_nhwc(const float* x_nchw, float* y_nhwc, int N, int C, int H, int W, void* stream);

@@ -47,6 +47,10 @@ class RefOps:
         # math dtype: fp32 like the kernels; tests of the ALGORITHM use float64 to separate
         # algebra errors from rounding
         self.f = torch.float64 if act_dtype == torch.float64 else torch.float32
+        # synchronised (global-batch) statistics in a data-parallel run: an in-place SUM all-reduce for small fp tensors
+        # and the number of ranks (rna_gan_amd.dist.sync_stats); None = rank-local statistics
+        self.stat_reduce = None
+        self.stat_world = 1
 
     def _nchw(self, x):
         return x.to(self.f).permute(0, 3, 1, 2)
@@ -172,8 +176,24 @@ class RefOps:
         zf = z.to(self.f).reshape(-1, z.shape[-1])
         return zf.sum(0), (zf * zf).sum(0)
 
+    def _red(self, *ts):
+        if self.stat_reduce is not None:
+            for t in ts:
+                self.stat_reduce(t)
+
+    def stat_allreduce(self, t):
+        """SUM over the ranks when statistics are synchronised (the penalty's squared norm), identity otherwise."""
+        self._red(t)
+        return t
+
     def bn_forward(self, z, gamma, beta, slope: float, eps: float, momentum: float, running_mean=None,
                    running_var=None, nbt=None, partials=None):
+        if self.stat_reduce is not None:
+            s, ss = self.bn_stats(z)
+            self._red(s, ss)
+            count = (z.numel() // z.shape[-1]) * self.stat_world
+            mean, invstd = self.bn_finalize(s, ss, count, eps, momentum, running_mean, running_var, nbt)
+            return self.bn_act(z, mean, invstd, gamma, beta, slope), mean, invstd
         mean, invstd = self.bn_stats_finalize(z, eps, momentum, running_mean, running_var, nbt)
         return self.bn_act(z, mean, invstd, gamma, beta, slope), mean, invstd
 
@@ -204,15 +224,16 @@ class RefOps:
         y = xh * gamma + beta
         gy = ga.to(self.f) * _lrelu_mask(y, slope)
         C = z.shape[-1]
-        m = z.numel() // C
+        m = (z.numel() // C) * self.stat_world
         s_gy = gy.reshape(-1, C).sum(0)
         s_gyxh = (gy * xh).reshape(-1, C).sum(0)
-        gz = (gamma * invstd) * (gy - s_gy / m - xh * (s_gyxh / m))
-        if dgamma is not None:
+        if dgamma is not None:          # parameter gradients: this rank's contribution (summed by the grad all-reduce)
             if accumulate:
                 dgamma.add_(s_gyxh); dbeta.add_(s_gy)
             else:
                 dgamma.copy_(s_gyxh); dbeta.copy_(s_gy)
+        self._red(s_gy, s_gyxh)         # the data gradient needs the batch means: global sums when synchronised
+        gz = (gamma * invstd) * (gy - s_gy / m - xh * (s_gyxh / m))
         return gz.to(self.act_dtype), s_gy, s_gyxh
 
     def bn_tangent(self, z, zt, mean, invstd, gamma, beta, slope: float):
@@ -221,10 +242,11 @@ class RefOps:
         xh = (z.to(self.f) - mean) * invstd
         y = xh * gamma + beta
         C = z.shape[-1]
-        m = z.numel() // C
+        m = (z.numel() // C) * self.stat_world
         ztf = zt.to(self.f)
         s_zt = ztf.reshape(-1, C).sum(0)
         s_xhzt = (xh * ztf).reshape(-1, C).sum(0)
+        self._red(s_zt, s_xhzt)
         yt = (gamma * invstd) * (ztf - s_zt / m - xh * (s_xhzt / m))
         return (yt * _lrelu_mask(y, slope)).to(self.act_dtype), s_zt, s_xhzt
 
@@ -238,27 +260,30 @@ class RefOps:
         first backward's gz and is not recomputed).  Accumulates dgamma, dbeta.  DESIGN.md sec. GP.
         """
         C = z.shape[-1]
-        m = z.numel() // C
+        m_local = z.numel() // C
+        m = m_local * self.stat_world           # s_gy, s_gyxh, s_zt, s_xhzt are global sums when synchronised
         xh = (z.to(self.f) - mean) * invstd
         y = xh * gamma + beta
         mask = _lrelu_mask(y, slope)
         gy = ga1.to(self.f) * mask
         ztf = zt.to(self.f)
         s_gyzt = (gy * ztf).reshape(-1, C).sum(0)
+        self._red(s_gyzt)
         b = s_gyxh / m
         c = s_xhzt / m
         A = s_gyzt / m - (s_gy / m) * (s_zt / m)
         k2 = gamma * invstd * invstd
         pz = -k2 * (xh * (A - 3 * b * c) + c * (gy - s_gy / m) + b * (ztf - s_zt / m))
-        dg = (m * invstd) * (A - b * c)
+        dg = (m_local * invstd) * (A - b * c)       # this rank's share of m/sigma (A - bc)
         db = torch.zeros_like(dg)
         if qa is not None:
             qy = qa.to(self.f) * mask
             s_qy = qy.reshape(-1, C).sum(0)
             s_qyxh = (qy * xh).reshape(-1, C).sum(0)
+            dg = dg + s_qyxh                        # local sums for the parameter gradients
+            db = s_qy.clone()
+            self._red(s_qy, s_qyxh)
             pz = pz + (gamma * invstd) * (qy - s_qy / m - xh * (s_qyxh / m))
-            dg = dg + s_qyxh
-            db = s_qy
         if accumulate:
             dgamma.add_(dg); dbeta.add_(db)
         else:
@@ -311,6 +336,12 @@ class RefOps:
 
     def latent_prep(self, u, z):
         n = u + z
+        if self.stat_reduce is not None:
+            s, ss = n.sum(0), (n * n).sum(0)
+            self._red(s, ss)
+            nt = n.shape[0] * self.stat_world
+            mu = s / nt
+            return (n - mu) / torch.sqrt((ss - nt * mu * mu) / (nt - 1))
         return (n - n.mean(0)) / n.std(0)
 
     # ------------------------------------------------------------------ optimizer

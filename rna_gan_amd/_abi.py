@@ -77,6 +77,14 @@ PROTOTYPES = {
     "rg_upconv3_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_upconv3_wgrad": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_export_images_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "rg_bn_bwd_sums": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p, _z, _p]),
+    "rg_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),
+    "rg_bn_tangent_sums": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p, _z, _p]),
+    "rg_bn_tangent_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),
+    "rg_bn_dbl_sums": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p, _z, _p]),
+    "rg_bn_dbl_apply": (_i, [_p] * 17 + [_i, _i, _i, _i, _f, _i, _p, _z, _p]),
+    "rg_latent_stats": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "rg_latent_apply": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "rg_adam_step_dev": (_i, [_p, _p, _p, _p, _z, _p, _p, _p, _p]),
     "rg_interp_dev": (_i, [_p, _p, _p, _z, _p, _p]),
     "rg_adam_hyper_dev": (_i, [_p, _d, _d, _d, _d, _p, _p]),

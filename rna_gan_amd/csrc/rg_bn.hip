@@ -482,6 +482,33 @@ template <typename T, int VEC> struct DblApplyF {
   }
 };
 
+// ---- split forms (synchronised statistics): raw sums out / finish from all-reduced sums
+struct Store3Fin {
+  float* raw; int C;
+  __device__ void operator()(int c, const float* s) const { raw[c] = s[0]; raw[C + c] = s[1]; raw[2 * C + c] = s[2]; }
+};
+// DblFin with the coefficient means taken over the GLOBAL batch (sums in `s`, m_total rows) while the parameter
+// gradients stay rank-local contributions (they are summed by the gradient all-reduce):
+//   dgamma_local = sum_local(qy xh) + m_local/sigma (A - b c),  dbeta_local = sum_local(qy)
+struct DblFinSync {
+  const float* s_gy; const float* s_gyxh; const float* s_zt; const float* s_xhzt; const float* invstd;
+  const float* raw_local; float* coef; float* dgamma; float* dbeta; int accumulate; float m_total, m_local; int C;
+  __device__ void operator()(int c, const float* s) const {
+    float inv_m = 1.f / m_total;
+    float b = s_gyxh[c] * inv_m, cc = s_xhzt[c] * inv_m;
+    float A = s[0] * inv_m - (s_gy[c] * inv_m) * (s_zt[c] * inv_m);
+    coef[0 * C + c] = A - 3.f * b * cc;
+    coef[1 * C + c] = cc;
+    coef[2 * C + c] = b;
+    coef[3 * C + c] = s[1] * inv_m;
+    coef[4 * C + c] = s[2] * inv_m;
+    float dg = m_local * invstd[c] * (A - b * cc) + raw_local[2 * C + c];
+    float db = raw_local[C + c];
+    if (accumulate) { dgamma[c] += dg; dbeta[c] += db; }
+    else { dgamma[c] = dg; dbeta[c] = db; }
+  }
+};
+
 // ------------------------------------------------------------------------------------------ misc
 template <typename T, int VEC> struct ColSumF {
   const T* g; int C;
@@ -690,6 +717,81 @@ extern "C" int rg_bn_double_bwd(const void* z, const void* qa, const void* zt, c
     if (rc) return rc;
     return (row_apply<T, DblApplyF>("bn_double_bwd", M, C, st, (const T*)z, (const T*)qa, (const T*)zt, (const T*)ga1,
                                     (T*)pz, p, s_gy, s_zt, (const float*)coef, 1.f / (float)M, C));
+  })
+}
+
+/* ---- split forms for synchronised (global-batch) BatchNorm statistics: *_sums writes the RANK-LOCAL column sums,
+ * the caller all-reduces them, *_apply finishes with the global sums and the global row count M_total. ---- */
+extern "C" int rg_bn_bwd_sums(const void* z, const void* ga, const float* mean, const float* invstd, const float* gamma,
+                              const float* beta, float* s_gy, float* s_gyxh, int M, int C, float slope, int dtype, void* ws,
+                              size_t ws_bytes, void* stream) {
+  RG_REQUIRE(z && ga && s_gy && s_gyxh && M > 0 && C > 0, RG_EINVAL, "bn_bwd_sums: bad args");
+  BNC p{mean, invstd, gamma, beta, slope};
+  RG_DISPATCH_DTYPE(dtype, T, {
+    return (row_reduce<2, T, BwdRedF>("bn_bwd_sums", M, C, ws, ws_bytes, rg_stream(stream), Store2Fin{s_gy, s_gyxh},
+                                      (const T*)z, (const T*)ga, p, C));
+  })
+}
+extern "C" int rg_bn_bwd_apply(const void* z, const void* ga, const float* mean, const float* invstd, const float* gamma,
+                               const float* beta, const float* s_gy, const float* s_gyxh, void* gz, int M, int C,
+                               int M_total, float slope, int dtype, void* stream) {
+  RG_REQUIRE(z && ga && gz && s_gy && s_gyxh && M > 0 && C > 0 && M_total >= M, RG_EINVAL, "bn_bwd_apply: bad args");
+  BNC p{mean, invstd, gamma, beta, slope};
+  RG_DISPATCH_DTYPE(dtype, T, {
+    return (row_apply<T, BwdApplyF>("bn_bwd_apply", M, C, rg_stream(stream), (const T*)z, (const T*)ga, (T*)gz, p, s_gy,
+                                    s_gyxh, 1.f / (float)M_total, C));
+  })
+}
+extern "C" int rg_bn_tangent_sums(const void* z, const void* zt, const float* mean, const float* invstd,
+                                  const float* gamma, const float* beta, float* s_zt, float* s_xhzt, int M, int C,
+                                  float slope, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(z && zt && s_zt && s_xhzt && M > 0 && C > 0, RG_EINVAL, "bn_tangent_sums: bad args");
+  BNC p{mean, invstd, gamma, beta, slope};
+  RG_DISPATCH_DTYPE(dtype, T, {
+    return (row_reduce<2, T, TanRedF>("bn_tangent_sums", M, C, ws, ws_bytes, rg_stream(stream), Store2Fin{s_zt, s_xhzt},
+                                      (const T*)z, (const T*)zt, p, C));
+  })
+}
+extern "C" int rg_bn_tangent_apply(const void* z, const void* zt, const float* mean, const float* invstd,
+                                   const float* gamma, const float* beta, const float* s_zt, const float* s_xhzt, void* at,
+                                   int M, int C, int M_total, float slope, int dtype, void* stream) {
+  RG_REQUIRE(z && zt && at && s_zt && s_xhzt && M > 0 && C > 0 && M_total >= M, RG_EINVAL, "bn_tangent_apply: bad args");
+  BNC p{mean, invstd, gamma, beta, slope};
+  RG_DISPATCH_DTYPE(dtype, T, {
+    return (row_apply<T, TanApplyF>("bn_tangent_apply", M, C, rg_stream(stream), (const T*)z, (const T*)zt, (T*)at, p,
+                                    s_zt, s_xhzt, 1.f / (float)M_total, C));
+  })
+}
+extern "C" int rg_bn_dbl_sums(const void* z, const void* qa, const void* zt, const void* ga1, const float* mean,
+                              const float* invstd, const float* gamma, const float* beta, float* raw3, int M, int C,
+                              float slope, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(z && zt && ga1 && raw3 && M > 0 && C > 0, RG_EINVAL, "bn_dbl_sums: bad args");
+  BNC p{mean, invstd, gamma, beta, slope};
+  RG_DISPATCH_DTYPE(dtype, T, {
+    return (row_reduce<3, T, DblRedF>("bn_dbl_sums", M, C, ws, ws_bytes, rg_stream(stream), Store3Fin{raw3, C},
+                                      (const T*)z, (const T*)qa, (const T*)zt, (const T*)ga1, p, C));
+  })
+}
+extern "C" int rg_bn_dbl_apply(const void* z, const void* qa, const void* zt, const void* ga1, const float* mean,
+                               const float* invstd, const float* gamma, const float* beta, const float* s_gy,
+                               const float* s_gyxh, const float* s_zt, const float* s_xhzt, const float* raw3_global,
+                               const float* raw3_local, void* pz, float* dgamma, float* dbeta, int accumulate, int M,
+                               int C, int M_total, float slope, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(z && zt && ga1 && pz && dgamma && dbeta && s_gy && s_gyxh && s_zt && s_xhzt && raw3_global && raw3_local &&
+                 M > 0 && C > 0 && M_total >= M, RG_EINVAL, "bn_dbl_apply: bad args");
+  RG_REQUIRE(ws && ws_bytes >= (size_t)5 * C * sizeof(float), RG_EWORKSPACE, "bn_dbl_apply: workspace too small");
+  float* coef = (float*)ws;
+  BNC p{mean, invstd, gamma, beta, slope};
+  hipStream_t st = rg_stream(stream);
+  // the all-reduced sums are one "partial row" [3][C]: colfinish with G = 1 runs the finisher per channel
+  hipLaunchKernelGGL((colfinish_kernel<3, DblFinSync>), dim3((C + 31) / 32), dim3(256), 0, st,
+                     DblFinSync{s_gy, s_gyxh, s_zt, s_xhzt, invstd, raw3_local, coef, dgamma, dbeta, accumulate,
+                                (float)M_total, (float)M, C},
+                     raw3_global, C, 1);
+  RG_LAUNCH_CHECK("bn_dbl_apply");
+  RG_DISPATCH_DTYPE(dtype, T, {
+    return (row_apply<T, DblApplyF>("bn_dbl_apply", M, C, st, (const T*)z, (const T*)qa, (const T*)zt, (const T*)ga1,
+                                    (T*)pz, p, s_gy, s_zt, (const float*)coef, 1.f / (float)M_total, C));
   })
 }
 

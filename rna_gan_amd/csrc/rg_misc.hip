@@ -447,6 +447,40 @@ extern "C" int rg_mean_diff(const float* a, const float* b, float* out, int n, f
   RG_LAUNCH_CHECK("mean_diff");
   return RG_OK;
 }
+// split form of latent_prep for synchronised statistics: column sums of v = u + z, then (v - mean) / std with the
+// all-reduced sums and the global row count (unbiased std, as torch.std)
+__global__ void latent_stats_kernel(const float* u, const float* z, float* s, float* ss, int N, int E) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  float a = 0.f, b = 0.f;
+  for (int n = 0; n < N; ++n) { float v = u[(size_t)n * E + e] + z[(size_t)n * E + e]; a += v; b += v * v; }
+  s[e] = a; ss[e] = b;
+}
+__global__ void latent_apply_kernel(const float* u, const float* z, const float* s, const float* ss, float* out, int N,
+                                    int E, float nt) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * E) return;
+  int e = (int)(i % E);
+  float mu = s[e] / nt;
+  float var = fmaxf(ss[e] - nt * mu * mu, 0.f) / (nt - 1.f);
+  out[i] = (u[i] + z[i] - mu) / sqrtf(var);
+}
+extern "C" int rg_latent_stats(const float* u, const float* z, float* s, float* ss, int N, int E, void* stream) {
+  RG_REQUIRE(u && z && s && ss && N > 0 && E > 0, RG_EINVAL, "latent_stats: bad args");
+  hipLaunchKernelGGL(latent_stats_kernel, dim3((E + 63) / 64), dim3(64), 0, rg_stream(stream), u, z, s, ss, N, E);
+  RG_LAUNCH_CHECK("latent_stats");
+  return RG_OK;
+}
+extern "C" int rg_latent_apply(const float* u, const float* z, const float* s, const float* ss, float* out, int N, int E,
+                               int N_total, void* stream) {
+  RG_REQUIRE(u && z && s && ss && out && N > 0 && E > 0 && N_total >= N, RG_EINVAL, "latent_apply: bad args");
+  size_t tot = (size_t)N * E;
+  hipLaunchKernelGGL(latent_apply_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, rg_stream(stream), u, z, s, ss,
+                     out, N, E, (float)N_total);
+  RG_LAUNCH_CHECK("latent_apply");
+  return RG_OK;
+}
+
 extern "C" int rg_latent_prep(const float* u, const float* z, float* out, int N, int E, void* stream) {
   RG_REQUIRE(u && z && out && N > 0 && E > 0, RG_EINVAL, "latent_prep: bad args");
   if (N <= 64)

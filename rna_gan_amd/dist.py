@@ -24,6 +24,11 @@ import torch.distributed as dist
 BUCKET_BYTES = 64 * 1024 * 1024
 FORCE = os.environ.get("RNAGAN_FORCE_DP", "0") == "1"     # take the DP code path even with one rank (testing)
 COMPRESS = os.environ.get("RNAGAN_DP_BF16", "1") != "0"
+# --sync-stats: BatchNorm statistics (forward, backward, tangent, double backward), the latent
+# standardisation and the penalty norm are taken over the GLOBAL batch (tiny all-reduces of per-channel sums), so an
+# N-rank run reproduces the single-process reference step at batch N x n exactly.  Collectives then sit inside the
+# step: HIP graphs are not used in this mode.
+SYNC_STATS = os.environ.get("RNAGAN_SYNC_STATS", "0") == "1"
 
 
 def world_size() -> int:
@@ -53,8 +58,38 @@ def init_from_env(backend=None):
     dist.init_process_group(backend=backend, init_method="env://")
 
 
+def set_sync_stats(on: bool):
+    """Switch --sync-stats on/off programmatically (before the modules' runtimes are built)."""
+    global SYNC_STATS
+    SYNC_STATS = bool(on)
+
+
+def sync_stats() -> bool:
+    return SYNC_STATS and active()
+
+
+def allreduce_small_(t: torch.Tensor):
+    """Blocking in-place SUM all-reduce of a small statistics tensor."""
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def attach_sync(ops):
+    """Give an ops object (HipOps / the CPU twin) the global-statistics hooks when --sync-stats is active."""
+    if sync_stats():
+        ops.stat_reduce = allreduce_small_
+        ops.stat_world = world_size()
+    return ops
+
+
 def grad_scale() -> float:
     return 1.0 / world_size()
+
+
+def gp_grad_scale() -> float:
+    """Backward seed of the gradient penalty: the mean of per-rank penalties (plain DDP semantics) or, with
+    synchronised statistics, ONE whole-batch penalty whose per-rank gradient contributions simply add up."""
+    return 1.0 if sync_stats() else 1.0 / world_size()
 
 
 _wire = {}

@@ -265,7 +265,7 @@ def disc_gradient_penalty(ops, D: DiscNet, xhat, lambd: float, update_running=Tr
     # (2) first backward: data gradients only
     g = disc_backward(ops, D, ctx, 1.0, wgrad=False, accumulate=False, need_input_grad=True,
                       keep_for_gp=True)
-    sq = ops.sqnorm(g)
+    sq = ops.stat_allreduce(ops.sqnorm(g))      # whole-batch norm: summed over the ranks when statistics are synchronised
     loss, coef = ops.gp_coef(sq, lambd)
     v = ops.scale_by(g, coef)
     # (3) tangent forward along v

@@ -149,7 +149,7 @@ def _gp_prefix(generator, discriminator, real, noise, eps):
 
 def _gp_rest(generator, discriminator, xhat, lambd):
     ops, _, dn = _nets(generator, discriminator)
-    return E.gp_loss_rest(ops, dn, xhat, float(lambd), grad_scale=D_.grad_scale())
+    return E.gp_loss_rest(ops, dn, xhat, float(lambd), grad_scale=D_.gp_grad_scale())
 
 
 def _g_step(generator, discriminator, optimizer_generator, noise):
@@ -291,7 +291,7 @@ class _Runner:
     def _step_graph(self, key, fn, inputs, modules, optimizers, stepped=None):
         """The StepGraph for this body / launch-sequence variant, or None when it has to run eagerly."""
         from . import graphed
-        if not graphed.ENABLED:
+        if not graphed.ENABLED or D_.sync_stats():       # synchronised statistics put collectives inside the step
             return None
         if stepped is None:
             stepped = [o._module for o in optimizers if getattr(o, "_module", None) is not None]

@@ -120,7 +120,7 @@ class _HipModule(nn.Module):
         if self._rt_ops is None or self._rt_net is None:
             from .ops_hip import HipOps
             dt = torch.bfloat16 if self.precision == "bf16" else torch.float32
-            self._rt_ops = HipOps(dt, p0.device)
+            self._rt_ops = D_.attach_sync(HipOps(dt, p0.device))
             self._rt_net = self._build_net()
             if self.precision == "bf16" and p0.dtype == torch.float32:
                 self._attach_shadows()

@@ -45,6 +45,10 @@ class HipOps:
         self.use_side = os.environ.get("RNAGAN_SIDE_STREAM", "0") != "0"
         self.pack_from_shadow = os.environ.get("RNAGAN_PACK_FROM_SHADOW", "1") != "0"
         self.epilogue_stats = os.environ.get("RNAGAN_EPILOGUE_STATS", "1") != "0"
+        # synchronised (global-batch) statistics in a data-parallel run (dist.attach_sync): an in-place SUM all-reduce
+        # for small fp32 tensors and the number of ranks; None = rank-local statistics (plain DDP semantics)
+        self.stat_reduce = None
+        self.stat_world = 1
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -135,7 +139,7 @@ class HipOps:
 
     def _stats_buf(self, up, N, Hl, Wl, O, I, C):
         """Buffer for the BatchNorm partial sums a conv epilogue can write, or None (split-K / generic kernel)."""
-        if not self.epilogue_stats:
+        if not self.epilogue_stats or self.stat_reduce is not None:
             return None
         rows = self.lib.rg_conv_stats_rows(up, N, Hl, Wl, O, I, self.dt, self.algo)
         return self._f32(rows, 2, C) if rows > 0 else None
@@ -367,6 +371,11 @@ class HipOps:
         """Train-mode BatchNorm + LeakyReLU: (a, mean, invstd).  partials: the column sums the producing conv's
         epilogue wrote (conv_down/conv_up want_stats) -- then no statistics pass over z is needed."""
         M, C = self._mc(z)
+        if self.stat_reduce is not None:          # global statistics: local sums -> all-reduce -> finalize -> apply
+            s, ss = self.bn_stats(z)
+            self.stat_reduce(s); self.stat_reduce(ss)
+            mean, invstd = self.bn_finalize(s, ss, M * self.stat_world, eps, momentum, running_mean, running_var, nbt)
+            return self.bn_act(z, mean, invstd, gamma, beta, slope), mean, invstd
         mean, invstd = self._f32(C), self._f32(C)
         a = torch.empty_like(z)
         if partials is not None:
@@ -396,6 +405,20 @@ class HipOps:
         gz = torch.empty_like(z)
         s_gy, s_gyxh = self._f32(C), self._f32(C)
         ws = self._ws(self.lib.rg_colreduce_workspace_bytes(M, C, 2))
+        if self.stat_reduce is not None:
+            check(self.lib.rg_bn_bwd_sums(_ptr(z), _ptr(ga), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(s_gy),
+                                          _ptr(s_gyxh), M, C, float(slope), self.dt, _ptr(ws), ws.numel(), self.stream),
+                  "rg_bn_bwd_sums")
+            if dgamma is not None:      # parameter gradients: this rank's contribution (C-length vectors)
+                if accumulate:
+                    dgamma.add_(s_gyxh); dbeta.add_(s_gy)
+                else:
+                    dgamma.copy_(s_gyxh); dbeta.copy_(s_gy)
+            self.stat_reduce(s_gy); self.stat_reduce(s_gyxh)
+            check(self.lib.rg_bn_bwd_apply(_ptr(z), _ptr(ga), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(s_gy),
+                                           _ptr(s_gyxh), _ptr(gz), M, C, M * self.stat_world, float(slope), self.dt,
+                                           self.stream), "rg_bn_bwd_apply")
+            return gz, s_gy, s_gyxh
         check(self.lib.rg_bn_act_bwd(_ptr(z), _ptr(ga), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(gz),
                                      _ptr(s_gy), _ptr(s_gyxh), _ptr(dgamma), _ptr(dbeta), int(accumulate), M, C,
                                      float(slope), self.dt, _ptr(ws), ws.numel(), self.stream), "rg_bn_act_bwd")
@@ -406,6 +429,15 @@ class HipOps:
         at = torch.empty_like(z)
         s_zt, s_xhzt = self._f32(C), self._f32(C)
         ws = self._ws(self.lib.rg_colreduce_workspace_bytes(M, C, 2))
+        if self.stat_reduce is not None:
+            check(self.lib.rg_bn_tangent_sums(_ptr(z), _ptr(zt), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
+                                              _ptr(s_zt), _ptr(s_xhzt), M, C, float(slope), self.dt, _ptr(ws), ws.numel(),
+                                              self.stream), "rg_bn_tangent_sums")
+            self.stat_reduce(s_zt); self.stat_reduce(s_xhzt)
+            check(self.lib.rg_bn_tangent_apply(_ptr(z), _ptr(zt), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
+                                               _ptr(s_zt), _ptr(s_xhzt), _ptr(at), M, C, M * self.stat_world,
+                                               float(slope), self.dt, self.stream), "rg_bn_tangent_apply")
+            return at, s_zt, s_xhzt
         check(self.lib.rg_bn_tangent(_ptr(z), _ptr(zt), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(at),
                                      _ptr(s_zt), _ptr(s_xhzt), M, C, float(slope), self.dt, _ptr(ws), ws.numel(),
                                      self.stream), "rg_bn_tangent")
@@ -416,6 +448,21 @@ class HipOps:
         M, C = self._mc(z)
         pz = torch.empty_like(z)
         ws = self._ws(self.lib.rg_colreduce_workspace_bytes(M, C, 3))
+        if self.stat_reduce is not None:       # s_gy .. s_xhzt are global sums already (bn_act_bwd / bn_tangent)
+            raw_local = self._f32(3, C)
+            if qa is None:
+                raw_local.zero_()
+            check(self.lib.rg_bn_dbl_sums(_ptr(z), _ptr(qa), _ptr(zt), _ptr(ga1), _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                          _ptr(beta), _ptr(raw_local), M, C, float(slope), self.dt, _ptr(ws), ws.numel(),
+                                          self.stream), "rg_bn_dbl_sums")
+            raw_global = raw_local.clone()
+            self.stat_reduce(raw_global)
+            check(self.lib.rg_bn_dbl_apply(_ptr(z), _ptr(qa), _ptr(zt), _ptr(ga1), _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                           _ptr(beta), _ptr(s_gy), _ptr(s_gyxh), _ptr(s_zt), _ptr(s_xhzt), _ptr(raw_global),
+                                           _ptr(raw_local), _ptr(pz), _ptr(dgamma), _ptr(dbeta), int(accumulate), M, C,
+                                           M * self.stat_world, float(slope), self.dt, _ptr(ws), ws.numel(),
+                                           self.stream), "rg_bn_dbl_apply")
+            return pz
         check(self.lib.rg_bn_double_bwd(_ptr(z), _ptr(qa), _ptr(zt), _ptr(ga1), _ptr(mean), _ptr(invstd), _ptr(gamma),
                                         _ptr(beta), _ptr(s_gy), _ptr(s_gyxh), _ptr(s_zt), _ptr(s_xhzt), _ptr(pz),
                                         _ptr(dgamma), _ptr(dbeta), int(accumulate), M, C, float(slope), self.dt,
@@ -479,9 +526,22 @@ class HipOps:
         check(self.lib.rg_mean_diff(_ptr(a), _ptr(b), _ptr(out), a.numel(), float(sign), self.stream), "rg_mean_diff")
         return out
 
+    def stat_allreduce(self, t):
+        """SUM over the ranks when statistics are synchronised (the penalty's squared norm), identity otherwise."""
+        if self.stat_reduce is not None:
+            self.stat_reduce(t)
+        return t
+
     def latent_prep(self, u, z):
         N, E = u.shape
         out = torch.empty_like(u)
+        if self.stat_reduce is not None:
+            s, ss = self._f32(E), self._f32(E)
+            check(self.lib.rg_latent_stats(_ptr(u), _ptr(z), _ptr(s), _ptr(ss), N, E, self.stream), "rg_latent_stats")
+            self.stat_reduce(s); self.stat_reduce(ss)
+            check(self.lib.rg_latent_apply(_ptr(u), _ptr(z), _ptr(s), _ptr(ss), _ptr(out), N, E, N * self.stat_world,
+                                           self.stream), "rg_latent_apply")
+            return out
         check(self.lib.rg_latent_prep(_ptr(u), _ptr(z), _ptr(out), N, E, self.stream), "rg_latent_prep")
         return out
 

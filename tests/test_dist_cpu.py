@@ -33,8 +33,9 @@ def _shard_inputs(rank, n=4):
     return real, noise, 0.2 + 0.5 * rank
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _worker(rank, world, port, q, sync=False):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      RNAGAN_SYNC_STATS="1" if sync else "0")
     import torch.distributed as dist
     from oracle.ops_ref import RefOps
     from rna_gan_amd import dist as D_, engine as E
@@ -45,15 +46,19 @@ def _worker(rank, world, port, q):
     G, D = _mk()
     flat_g, flat_d = FlatParams(G), FlatParams(D)
     Gn, Dn = E.build_gen_net(G), E.build_disc_net(D)
-    ops = RefOps(torch.float64)
+    ops = D_.attach_sync(RefOps(torch.float64))
+    assert (ops.stat_reduce is not None) == sync
     real, noise, eps = _shard_inputs(rank)
+    if sync:
+        eps = 0.3                       # one interpolation weight for the whole (global) batch, as in the reference
     out = {}
     E.gen_loss_grads(ops, Gn, Dn, noise, grad_scale=D_.grad_scale())
     D_.allreduce_sum_(flat_g.grad); out["G"] = flat_g.grad.clone()
     E.disc_loss_grads(ops, Gn, Dn, real, noise, grad_scale=D_.grad_scale())
     D_.allreduce_sum_(flat_d.grad); out["D"] = flat_d.grad.clone()
-    E.gp_loss_grads(ops, Gn, Dn, real, noise, eps, 10.0, grad_scale=D_.grad_scale())
+    E.gp_loss_grads(ops, Gn, Dn, real, noise, eps, 10.0, grad_scale=D_.gp_grad_scale())
     D_.allreduce_sum_(flat_d.grad); out["P"] = flat_d.grad.clone()
+    out["rm"] = torch.cat([b.reshape(-1).double() for b in D.buffers()])
     q.put((rank, {k: v.numpy() for k, v in out.items()}))
     dist.barrier()
     dist.destroy_process_group()
@@ -94,3 +99,39 @@ def test_dp2_gloo_matches_shard_average():
             np.testing.assert_allclose(res[r][k][:n], acc[k].numpy(), rtol=1e-6, atol=1e-9, err_msg=f"rank{r} {k}")
     for k in ("G", "D", "P"):
         np.testing.assert_array_equal(res[0][k], res[1][k])
+
+
+def test_dp2_sync_stats_matches_single_process_global_batch():
+    """--sync-stats: two ranks with 4 samples each and synchronised statistics reproduce the gradients of
+    the SINGLE-process reference step on the concatenated batch of 8 -- whole-batch BatchNorm (forward, backward and
+    the penalty's second-order pass) and the whole-batch penalty norm -- to fp64 round-off."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    G, D = _mk()
+    real = torch.cat([_shard_inputs(r)[0] for r in range(world)])
+    noise = torch.cat([_shard_inputs(r)[1] for r in range(world)])
+    eps = 0.3
+    want = {}
+    R.generator_loss(D(G(noise))).backward(); want["G"] = _flat_grads(G)
+    for p in D.parameters():
+        p.grad = None
+    R.discriminator_loss(D(real), D(G(noise).detach())).backward(); want["D"] = _flat_grads(D)
+    for p in D.parameters():
+        p.grad = None
+    xhat = eps * real + (1 - eps) * G(noise)
+    (10.0 * R.gradient_penalty(xhat, D(xhat))).backward(); want["P"] = _flat_grads(D)
+    want_rm = torch.cat([b.reshape(-1).double() for b in D.buffers()])
+    for r in range(world):
+        for k in ("G", "D", "P"):
+            n = want[k].numel()
+            np.testing.assert_allclose(res[r][k][:n], want[k].numpy(), rtol=1e-6, atol=1e-9, err_msg=f"rank{r} {k}")
+        np.testing.assert_allclose(res[r]["rm"], want_rm.numpy(), rtol=1e-9, atol=1e-12, err_msg="BN buffers")

@@ -105,10 +105,16 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("in_size,step,enc,n,dtype,mode", CASES)
-def test_three_steps_vs_autograd(in_size, step, enc, n, dtype, mode):
+@pytest.mark.parametrize("in_size,step,enc,n,dtype,mode,sync", [c + (False,) for c in CASES] +
+                         [(32, 4, 16, 3, torch.float32, "tight", True), (32, 64, 128, 16, torch.bfloat16, "bf16", True)])
+def test_three_steps_vs_autograd(in_size, step, enc, n, dtype, mode, sync):
     from rna_gan_amd.ops_hip import HipOps
     ops = HipOps(dtype, "cuda:0")
+    if sync:
+        # the split (local sums -> all-reduce -> apply) kernels of --sync-stats with a one-rank "all-reduce": must give
+        # the single-process result like the fused kernels do
+        ops.stat_reduce = lambda t: t
+        ops.stat_world = 1
     eps = 0.3
     for seed in range(5, 45):
         G, D = mk(in_size, step, enc, seed)
