@@ -392,3 +392,19 @@ def generate_images(generator, gene_exp=None, sample_size=64, betavae=None):
     images = images.view((-1, 3, images.shape[-2], images.shape[-1]))
     images = (images - (-1.0)) / 2.0                      # Normalize((-mean/std), (1/std)), mean = std = 0.5
     return images.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+def frechet_distance(mu1, sigma1, mu2, sigma2, eps=1e-6):
+    """Restatement of calculate_frechet_distance (src/fid.py:112-163; statistics as calculate_activation_statistics
+    :106-109: mean and np.cov(rowvar=False)):  |mu1-mu2|^2 + Tr(C1) + Tr(C2) - 2 Tr((C1 C2)^(1/2))."""
+    from scipy import linalg
+    mu1, mu2 = np.atleast_1d(mu1), np.atleast_1d(mu2)
+    sigma1, sigma2 = np.atleast_2d(sigma1), np.atleast_2d(sigma2)
+    diff = mu1 - mu2
+    covmean, _ = linalg.sqrtm(sigma1.dot(sigma2), disp=False)
+    if not np.isfinite(covmean).all():
+        offset = np.eye(sigma1.shape[0]) * eps
+        covmean = linalg.sqrtm((sigma1 + offset).dot(sigma2 + offset))
+    if np.iscomplexobj(covmean):
+        covmean = covmean.real
+    return float(diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean))

@@ -565,6 +565,17 @@ def upgen_forward_eval(ops, G: UpGenNet, noise):
     return ops.upconv3(a, G.last, G.last.bias, out_nchw=True)
 
 
+def disc_features_eval(ops, D: DiscNet, x_nchw):
+    """Discriminator trunk with BatchNorm in EVAL mode (running statistics): the activation in front of the head,
+    NHWC (N, 4, 4, C).  Feature extractor of the Frechet-distance proxy (rna_gan_amd.fid)."""
+    a = ops.first_down(x_nchw, D.conv0, D.conv0.bias, D.slope)
+    for cw, bn in D.blocks:
+        z = ops.conv_down(a, cw)
+        invstd = torch.rsqrt(bn.running_var + bn.eps)     # C-length vector: host-side plumbing
+        a = ops.bn_act(z, bn.running_mean, invstd, bn.gamma, bn.beta, D.slope)
+    return a
+
+
 def gen_forward_eval(ops, G: GenNet, noise):
     """Generator forward with BatchNorm in EVAL mode (running statistics), used for the per-epoch
     sample grid (torchgan Logger: generator.eval(); generator(test_noise))."""

@@ -333,10 +333,17 @@ class DCGANDiscriminator(Discriminator):
         return E.build_disc_net(self)
 
     def forward(self, x, feature_matching=False):
-        if feature_matching:
-            raise NotImplementedError("feature_matching is not on the RNA-GAN path")
         D_.flush()
         ops, net = self.runtime()
+        if feature_matching:
+            # torchgan: the activation in front of the ``disc`` head, (N, C, 4, 4).  Train mode = batch statistics (and
+            # running-statistics update) like every other forward; eval mode = running statistics.
+            if self.training:
+                _, ctx = E.disc_forward(ops, net, x.contiguous().float(), update_running=True)
+                a = ctx.a[-1]
+            else:
+                a = E.disc_features_eval(ops, net, x.contiguous().float())
+            return a.float().permute(0, 3, 1, 2).contiguous()
         if not self.training:
             raise NotImplementedError("the reference only ever runs the discriminator in train mode")
         out, _ = E.disc_forward(ops, net, x.contiguous().float(), update_running=True)

@@ -116,3 +116,32 @@ def test_generate_images_matches_oracle():
     ops, _ = Gp.runtime()
     imgs = torch.cat([Gp(c.cuda()) for c in torch.split(z, 10)], 0)
     np.testing.assert_allclose(ops.export_images_nhwc(imgs.contiguous()).cpu().numpy(), ref, rtol=0, atol=2e-3)
+
+
+@pytest.mark.gpu
+def test_fid_proxy_and_feature_matching():
+    """feature_matching=True returns the trunk activation in front of the head (torchgan contract); the Frechet-distance
+    proxy built on it is ~0 between a set and itself and clearly positive between images and noise."""
+    import numpy as np
+    import torch
+    from oracle import ref_cpu as R
+    import rna_gan_amd as P
+    from rna_gan_amd import fid
+    Do = R.OracleDCGANDiscriminator(32, 3, 16)
+    R.seeded_fill_(Do, 71)
+    D = P.DCGANDiscriminator(32, 3, 16)
+    D.load_state_dict(Do.state_dict())
+    D = D.cuda().set_precision("fp32")
+    x = R.synthetic_images(24, 32, seed=72)
+    # eval-mode trunk features against the oracle module's trunk (running statistics)
+    Do.eval()
+    with torch.no_grad():
+        want = Do.model(x)
+    D.eval()
+    got = D(x.cuda(), feature_matching=True).cpu()
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-3, atol=2e-4)
+    same = fid.fid_proxy(D, x, x.clone(), batch_size=8)
+    other = fid.fid_proxy(D, x, torch.randn(24, 3, 32, 32).clamp(-1, 1), batch_size=8)
+    assert abs(same) < 1e-6 and other > 1e-3, (same, other)
+    assert not D.training      # mode restored
