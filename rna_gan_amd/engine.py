@@ -180,11 +180,16 @@ def disc_forward(ops, D: DiscNet, x_nchw, update_running=True):
 
 def disc_backward(ops, D: DiscNet, ctx, coef: float, wgrad: bool, accumulate: bool,
                   need_input_grad: bool, keep_for_gp: bool = False):
-    """Backward of sum_n coef * D(x)_n.  wgrad: also produce parameter gradients (written with
-    ``accumulate`` semantics into the .dw/.dbias/.dgamma/.dbeta buffers).  Returns d/dx (NCHW
-    fp32) if requested.  keep_for_gp stores the per-layer first-backward gradients on ctx."""
+    """Backward of sum_n coef * D(x)_n (coef: a float, or an (N,) tensor of per-sample cotangents as torch autograd
+    hands them over).  wgrad: also produce parameter gradients (written with ``accumulate`` semantics into the
+    .dw/.dbias/.dgamma/.dbeta buffers).  Returns d/dx (NCHW fp32) if requested.  keep_for_gp stores the per-layer
+    first-backward gradients on ctx."""
     R = len(D.blocks)
-    gh = ops.head_grad(ctx.h, coef, D.last_slope)
+    if torch.is_tensor(coef):       # N-length vector: host-side plumbing
+        gh = (coef.reshape(-1).float() * torch.where(ctx.h > 0, torch.ones_like(ctx.h),
+                                                     torch.full_like(ctx.h, D.last_slope))).contiguous()
+    else:
+        gh = ops.head_grad(ctx.h, coef, D.last_slope)
     if wgrad:
         with ops.side(gh):
             ops.head_wgrad(gh, ctx.a[R], D.head.dw, accumulate)

@@ -227,6 +227,50 @@ class Discriminator(_HipModule):
     _weight_initializer = Generator._weight_initializer
 
 
+class _GenForwardFn(torch.autograd.Function):
+    """``generator(noise)`` under torch autograd (custom losses that call loss.backward() themselves): forward = the HIP
+    engine's train-mode forward, backward = the engine's backward, which ADDS the parameter gradients straight into the
+    flat gradient buffer the parameters' .grad views live in (first order only; the gradient penalty's second-order
+    pass has its own path in the loss plugins)."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        ops, net = module.runtime()
+        img, gctx = E._gen_fwd(ops, net, x, update_running=True)
+        ctx.module, ctx.gctx = module, gctx
+        return img
+
+    @staticmethod
+    def backward(ctx, gimg):
+        ops, net = ctx.module.runtime()
+        E._gen_bwd(ops, net, ctx.gctx, gimg.contiguous().float(), accumulate=True)
+        return (None, None) + (None,) * len(ctx.module._rt_flat.params)
+
+
+class _DiscForwardFn(torch.autograd.Function):
+    """``discriminator(x)`` under torch autograd: per-sample cotangents in, parameter gradients added into the flat
+    gradient buffer, d/dx returned (so discriminator(generator(z)) chains)."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        ops, net = module.runtime()
+        out, dctx = E.disc_forward(ops, net, x, update_running=True)
+        ctx.module, ctx.dctx, ctx.need_x = module, dctx, x.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        ops, net = ctx.module.runtime()
+        wgrad = any(p.requires_grad for p in ctx.module._rt_flat.params)
+        gx = E.disc_backward(ops, net, ctx.dctx, gout.contiguous(), wgrad=wgrad, accumulate=True,
+                             need_input_grad=ctx.need_x)
+        return (None, gx) + (None,) * len(ctx.module._rt_flat.params)
+
+
+def _wants_autograd(module, x):
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in module.parameters()))
+
+
 class DCGANGenerator(Generator):
     """ConvT(E,d,4,1,0)+BN+nl ; R x [ConvT(d,d/2,4,2,1)+BN+nl] ; ConvT(d,ch,4,2,1,bias)+last_nl."""
 
@@ -254,11 +298,16 @@ class DCGANGenerator(Generator):
         return E.build_gen_net(self)
 
     def forward(self, x, feature_matching=False):
-        """Generated images (N, ch, S, S) fp32.  Train mode: batch statistics + running-stat update
-        (what the reference's generator(noise) calls do).  Inference only: no autograd graph."""
+        """Generated images (N, ch, S, S) fp32.  Train mode: batch statistics + running-stat update (what the reference's
+        generator(noise) calls do); with gradients enabled the call is recorded for torch autograd (first order:
+        _GenForwardFn), under torch.no_grad() it is a plain forward."""
         D_.flush()
         ops, net = self.runtime()
         x = x.view(-1, x.size(1)).contiguous().float()
+        if self.training and _wants_autograd(self, x):
+            if x.requires_grad:
+                raise NotImplementedError("the gradient with respect to the generator's input is not on the RNA-GAN path")
+            return _GenForwardFn.apply(self, x, *self._rt_flat.params)
         if self.training:
             img, _ = E.gen_forward(ops, net, x, update_running=True, keep=False)
         else:
@@ -301,6 +350,10 @@ class DCGANUpGenerator(Generator):
         D_.flush()
         ops, net = self.runtime()
         x = x.view(-1, x.size(1)).contiguous().float()
+        if self.training and _wants_autograd(self, x):
+            if x.requires_grad:
+                raise NotImplementedError("the gradient with respect to the generator's input is not on the RNA-GAN path")
+            return _GenForwardFn.apply(self, x, *self._rt_flat.params)
         if self.training:
             img, _ = E.upgen_forward(ops, net, x, update_running=True, keep=False)
         else:
@@ -346,5 +399,8 @@ class DCGANDiscriminator(Discriminator):
             return a.float().permute(0, 3, 1, 2).contiguous()
         if not self.training:
             raise NotImplementedError("the reference only ever runs the discriminator in train mode")
-        out, _ = E.disc_forward(ops, net, x.contiguous().float(), update_running=True)
+        x = x.contiguous().float()
+        if _wants_autograd(self, x):
+            return _DiscForwardFn.apply(self, x, *self._rt_flat.params)
+        out, _ = E.disc_forward(ops, net, x, update_running=True)
         return out

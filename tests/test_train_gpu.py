@@ -257,4 +257,45 @@ def test_up_generator_reference_fixture(size):
     G2 = DCGANUpGenerator(16, size, 3, 4)
     R.seeded_fill_(G2, 41)
     G2 = G2.cuda().train().set_precision("fp32")
-    np.testing.assert_allclose(G2(z).cpu().numpy(), fx[f"y{size}"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(G2(z).detach().cpu().numpy(), fx[f"y{size}"], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_autograd_wrappers_custom_loss():
+    """A loss written against plain torch autograd (not one of the train_ops plugins): out = D(G(z)), D(real);
+    least-squares objectives; loss.backward() -- the autograd.Function wrappers must leave the same .grad in every
+    parameter as PyTorch autograd does on the oracle modules (fp32 kernels, tight tolerance)."""
+    in_size, step, enc, n = 32, 4, 16, 6
+    G0 = R.seeded_fill_(R.OracleDCGANGenerator(enc, in_size, 3, step), 81)
+    D0 = R.seeded_fill_(R.OracleDCGANDiscriminator(in_size, 3, step), 82)
+    Go, Do = copy.deepcopy(G0).train(), copy.deepcopy(D0).train()
+    G, D, og, od = product_pair(in_size, step, enc, "fp32", G0, D0)
+    z = R.synthetic_normal(n, enc, seed=83)
+    real = R.synthetic_images(n, in_size, seed=84)
+    # generator objective through both networks
+    loss_o = ((Do(Go(z)) - 1.0) ** 2).mean()
+    loss_o.backward()
+    og.zero_grad(); od.zero_grad()
+    loss_p = ((D(G(z.cuda())) - 1.0) ** 2).mean()
+    loss_p.backward()
+    assert abs(float(loss_p) - float(loss_o)) <= 1e-4 * (abs(float(loss_o)) + 1)
+    for (k, po), pp in zip(Go.named_parameters(), G.parameters()):
+        ref = po.grad.numpy()
+        np.testing.assert_allclose(pp.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * max(1.0, float(np.abs(ref).max())),
+                                   err_msg="G." + k)
+    for (k, po), pp in zip(Do.named_parameters(), D.parameters()):
+        ref = po.grad.numpy()
+        np.testing.assert_allclose(pp.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * max(1.0, float(np.abs(ref).max())),
+                                   err_msg="D." + k)
+    # discriminator objective on real + detached fake, gradients accumulate over two backward calls like autograd's
+    for m in (Go, Do):
+        m.zero_grad()
+    og.zero_grad(); od.zero_grad()
+    (Do(real) ** 2).mean().backward()
+    ((Do(Go(z).detach()) + 1.0) ** 2).mean().backward()
+    (D(real.cuda()) ** 2).mean().backward()
+    ((D(G(z.cuda()).detach()) + 1.0) ** 2).mean().backward()
+    for (k, po), pp in zip(Do.named_parameters(), D.parameters()):
+        ref = po.grad.numpy()
+        np.testing.assert_allclose(pp.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * max(1.0, float(np.abs(ref).max())),
+                                   err_msg="D(acc)." + k)
