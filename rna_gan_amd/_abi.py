@@ -73,7 +73,7 @@ PROTOTYPES = {
     "rg_adam_step": (_i, [_p, _p, _p, _p, _z, _i, _d, _d, _d, _d, _p]),
     "rg_clamp": (_i, [_p, _z, _f, _f, _p]),
     "rg_upconv3_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
-    "rg_upconv3_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "rg_upconv3_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_upconv3_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_upconv3_wgrad": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_export_images_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),

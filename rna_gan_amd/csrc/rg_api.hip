@@ -214,11 +214,18 @@ extern "C" int rg_linear_affine_act(const float* x, int ldx, const float* w, con
 /* ---- resize-convolution block of DCGANUpGenerator (src/dcgan.py:45-56,76-84) ---- */
 extern "C" size_t rg_upconv3_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
   if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
-  return rg_generic_upconv3_ws_bytes(N, H, W, Cin, Cout);
+  size_t b = rg_generic_upconv3_ws_bytes(N, H, W, Cin, Cout);
+  if (rg_mfma_upconv3_supported(N, H, W, Cin, Cout)) b = std::max(b, rg_mfma_upconv3_fwd_ws_bytes(N, H, W, Cin, Cout));
+  return b;
 }
 extern "C" int rg_upconv3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int Cin,
-                              int Cout, int out_nchw_f32, int dtype, void* stream) {
+                              int Cout, int out_nchw_f32, int dtype, int algo, void* ws, size_t ws_bytes, void* stream) {
   RG_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, RG_EINVAL, "upconv3_fwd: bad args");
+  // bf16 NHWC output with Cin % 64 == 0: matrix cores (pad image + 9-tap implicit GEMM); otherwise the functor kernel
+  const bool mfma_ok = dtype == RG_BF16 && !out_nchw_f32 && rg_mfma_upconv3_supported(N, H, W, Cin, Cout);
+  RG_REQUIRE(mfma_ok || algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "upconv3_fwd: shape/dtype not supported by the MFMA kernel");
+  if (mfma_ok && algo != RG_ALGO_GENERIC)
+    return rg_mfma_upconv3_fwd(x, w, bias, y, N, H, W, Cin, Cout, ws, ws_bytes, rg_stream(stream));
   return rg_generic_upconv3_fwd(x, w, bias, y, N, H, W, Cin, Cout, out_nchw_f32, dtype, rg_stream(stream));
 }
 extern "C" int rg_upconv3_bwd_data(const void* gy, int gy_nchw_f32, const float* w, void* gx, int N, int H, int W,

@@ -136,6 +136,20 @@ __device__ __forceinline__ float block_sum_256(float v, float* smem4) {
   return smem4[0] + smem4[1] + smem4[2] + smem4[3];
 }
 
+// ---- resize-convolution geometry (DCGANUpGenerator): bilinear x2 (align_corners=False) + ReflectionPad2d(1)
+// padded coordinate i in [0, 2L+2) -> upsampled coordinate (reflection without repeating the edge)
+__device__ __forceinline__ int up_reflect(int i, int L2) {
+  int u = i - 1;
+  return u < 0 ? -u : (u >= L2 ? 2 * L2 - 2 - u : u);
+}
+// bilinear x2: u = 2q   -> 0.25 x[q-1] + 0.75 x[q]   (x[-1] := x[0])
+//              u = 2q+1 -> 0.75 x[q]   + 0.25 x[q+1] (x[L]  := x[L-1]);  out = (1 - l1) x[i0] + l1 x[i1]
+__device__ __forceinline__ void up_taps(int u, int L, int& i0, int& i1, float& l1) {
+  int q = u >> 1;
+  if (u & 1) { i0 = q; i1 = min(q + 1, L - 1); l1 = 0.25f; }
+  else       { i0 = max(q - 1, 0); i1 = q; l1 = 0.75f; }
+}
+
 // dtype dispatch helper for host code
 #define RG_DISPATCH_DTYPE(dtype, T, ...)                                  \
   if ((dtype) == RG_F32) { using T = float; __VA_ARGS__ }                 \

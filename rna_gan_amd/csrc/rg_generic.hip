@@ -469,18 +469,6 @@ int rg_generic_linear(const float* x, int ldx, const float* w, const float* scal
 namespace {
 struct UGeo { int N, H, W, Cin, Cout; };     // input H x W, output 2H x 2W
 
-// padded coordinate i in [0, 2H+2) -> upsampled coordinate (reflection without repeating the edge)
-__device__ __forceinline__ int up_reflect(int i, int L2) {
-  int u = i - 1;
-  return u < 0 ? -u : (u >= L2 ? 2 * L2 - 2 - u : u);
-}
-// bilinear x2, align_corners=False: u = 2q   -> 0.25 x[q-1] + 0.75 x[q]   (x[-1] := x[0])
-//                                   u = 2q+1 -> 0.75 x[q]   + 0.25 x[q+1] (x[L]  := x[L-1])
-__device__ __forceinline__ void up_taps(int u, int L, int& i0, int& i1, float& l1) {
-  int q = u >> 1;
-  if (u & 1) { i0 = q; i1 = min(q + 1, L - 1); l1 = 0.25f; }
-  else       { i0 = max(q - 1, 0); i1 = q; l1 = 0.75f; }
-}
 template <typename T>
 __device__ __forceinline__ float uppad_at(const T* x, const UGeo& g, int n, int i, int j, int c) {
   int h0, h1, w0, w1;

@@ -38,6 +38,10 @@ int rg_mfma_conv_stats_rows(int up, int N, int Hlow, int Wlow, int O, int I);
 int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, const void* mask,
                     float mslope, float* stats, void* ws, size_t ws_bytes, hipStream_t st);
 size_t rg_mfma_conv_ws_bytes(int up, int N, int Hlow, int Wlow, int O, int I);
+bool rg_mfma_upconv3_supported(int N, int H, int W, int Cin, int Cout);
+size_t rg_mfma_upconv3_fwd_ws_bytes(int N, int H, int W, int Cin, int Cout);
+int rg_mfma_upconv3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int Cin,
+                        int Cout, void* ws, size_t ws_bytes, hipStream_t st);
 size_t rg_generic_upconv3_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int rg_generic_upconv3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int Cin,
                            int Cout, int out_nchw, int dtype, hipStream_t st);

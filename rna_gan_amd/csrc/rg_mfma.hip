@@ -26,6 +26,9 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 constexpr int MODE_DOWN = 0, MODE_UP = 1, MODE_PLAIN = 2;
+// MODE_C3: 3x3 stride-1 VALID conv over a pre-padded image (the resize-convolution block of DCGANUpGenerator:
+// A = materialised bilinear-x2 + reflection-pad image [N][Hs][Ws][Cin], output grid (Hs-2) x (Ws-2), 9 taps)
+constexpr int MODE_C3 = 3;
 constexpr int EPI_BF16 = 0, EPI_LINEAR = 1;
 
 struct GArgs {
@@ -377,6 +380,9 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
           bool v = (unsigned)(hq + dh) < (unsigned)g.Hs && (unsigned)(wq + dw) < (unsigned)g.Ws;
           mask |= (v ? 1u : 0u) << (a * 2 + b);
         }
+    } else if (MODE == MODE_C3) {
+      base = (((long long)n * g.Hs + hq) * g.Ws + wq) * g.Cin;     // top-left tap of the 3x3 window; all 9 exist
+      mask = 0x1FFu;
     } else {
       base = (long long)mm * g.Cin;
       mask = 1u;
@@ -408,6 +414,10 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
       up_tap_dev(pw, tap & 1, kw, dw);
       a_delta = (dh * g.Ws + dw) * g.Cin;
       b_tap = kh * 4 + kw;
+    } else if (MODE == MODE_C3) {
+      const int kh = tap / 3;
+      a_delta = (kh * g.Ws + (tap - 3 * kh)) * g.Cin;
+      b_tap = tap;
     } else {
       a_delta = 0;
       b_tap = 0;
@@ -590,6 +600,11 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
         orow = ((long long)n * (2 * Hq) + 2 * hq + ph) * (2 * Wq) + 2 * wq + pw;
       } else {
         orow = m;
+      }
+      if (MODE == MODE_C3 && g.shift && zs == 0) {      // Conv2d bias of the resize-convolution block (first split only)
+        const float* b = g.shift + col;
+        v0.x += b[0]; v0.y += b[1]; v0.z += b[2]; v0.w += b[3];
+        v1.x += b[4]; v1.y += b[5]; v1.z += b[6]; v1.w += b[7];
       }
       if (a2.nsplit > 1) {
         float* so = a2.slab + (long long)zs * a2.slab_stride + orow * g.ldc + col;
@@ -1406,6 +1421,74 @@ int rg_mfma_g0_wgrad(const float* z, const void* gy, float* dw, int N, int E, in
                      (const uint16_t*)gy, gyP, N, 16 * C, 2);
   RG_LAUNCH_CHECK("g0_wgrad(pack gy)");
   return rg_mfma_linear(zT, gyP, nullptr, nullptr, dw, 16 * C, E, N, 16 * C, 1.0f, nullptr, 0, st);
+}
+
+// ---- resize-convolution block on the matrix cores (forward): materialise pad = ReflectionPad(1)(bilinear_x2(x)) as
+// bf16 NHWC once (HBM-bound pass, 16 bytes per thread), then a 9-tap stride-1 implicit GEMM over it (MODE_C3) with
+// the Conv2d bias in the epilogue.
+__global__ void uppad_bf16_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ pad, int N, int H, int W, int C) {
+  const int C8 = C >> 3, Hp = 2 * H + 2, Wp = 2 * W + 2;
+  const size_t tot = (size_t)N * Hp * Wp * C8;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c8 = (int)(idx % C8);
+    size_t t = idx / C8;
+    const int j = (int)(t % Wp); t /= Wp;
+    const int i = (int)(t % Hp);
+    const int n = (int)(t / Hp);
+    int h0, h1, w0, w1;
+    float lh, lw;
+    up_taps(up_reflect(i, 2 * H), H, h0, h1, lh);
+    up_taps(up_reflect(j, 2 * W), W, w0, w1, lw);
+    const bf16_t* xn = reinterpret_cast<const bf16_t*>(x) + (size_t)n * H * W * C + c8 * 8;
+    float v00[8], v01[8], v10[8], v11[8], o[8];
+    Vec<bf16_t, 8>::ld(xn + ((size_t)h0 * W + w0) * C, v00);
+    Vec<bf16_t, 8>::ld(xn + ((size_t)h0 * W + w1) * C, v01);
+    Vec<bf16_t, 8>::ld(xn + ((size_t)h1 * W + w0) * C, v10);
+    Vec<bf16_t, 8>::ld(xn + ((size_t)h1 * W + w1) * C, v11);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      o[k] = (1.f - lh) * ((1.f - lw) * v00[k] + lw * v01[k]) + lh * ((1.f - lw) * v10[k] + lw * v11[k]);
+    Vec<bf16_t, 8>::st(reinterpret_cast<bf16_t*>(pad) + idx * 8, o);
+  }
+}
+// w3[o][c][3][3] fp32 -> wp[o][tap][c] bf16
+__global__ void pack_w3_kernel(const float* __restrict__ w, uint16_t* __restrict__ wp, int Cout, int Cin) {
+  const size_t n = (size_t)Cout * 9 * Cin;
+  for (size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += (size_t)gridDim.x * blockDim.x) {
+    const size_t c = d % Cin, ot = d / Cin;
+    const size_t tap = ot % 9, o = ot / 9;
+    wp[d] = f32_to_bf16(w[(o * Cin + c) * 9 + tap]);
+  }
+}
+bool rg_mfma_upconv3_supported(int N, int H, int W, int Cin, int Cout) {
+  const long long M = (long long)N * 4 * H * W;
+  return Cin % 64 == 0 && Cout % 8 == 0 && rg_is_pow2(H) && rg_is_pow2(W) && M < 0x7fffffffLL && !use_v1() &&
+         (size_t)N * (2 * H + 2) * (2 * W + 2) * Cin * 2 < 0x7fffff00ull;
+}
+size_t rg_mfma_upconv3_fwd_ws_bytes(int N, int H, int W, int Cin, int Cout) {
+  return rg_align_up((size_t)N * (2 * H + 2) * (2 * W + 2) * Cin * 2, 256) + rg_align_up((size_t)Cout * 9 * Cin * 2, 256) +
+         rg_mfma_gather_ws_bytes(N * 4 * H * W, N * 4 * H * W, Cout, 1, 9 * (Cin >> 6));
+}
+int rg_mfma_upconv3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int Cin,
+                        int Cout, void* ws, size_t ws_bytes, hipStream_t st) {
+  RG_REQUIRE(ws && ws_bytes >= rg_mfma_upconv3_fwd_ws_bytes(N, H, W, Cin, Cout), RG_EWORKSPACE,
+             "upconv3_fwd(mfma): workspace too small");
+  const int Hp = 2 * H + 2, Wp = 2 * W + 2;
+  const size_t padb = rg_align_up((size_t)N * Hp * Wp * Cin * 2, 256), wpb = rg_align_up((size_t)Cout * 9 * Cin * 2, 256);
+  uint16_t* pad = (uint16_t*)ws;
+  uint16_t* wp = (uint16_t*)((char*)ws + padb);
+  hipLaunchKernelGGL(uppad_bf16_kernel, dim3(grid_cap((size_t)N * Hp * Wp * (Cin >> 3))), dim3(256), 0, st,
+                     (const uint16_t*)x, pad, N, H, W, Cin);
+  RG_LAUNCH_CHECK("upconv3_fwd(pad)");
+  hipLaunchKernelGGL(pack_w3_kernel, dim3(grid_cap((size_t)Cout * 9 * Cin)), dim3(256), 0, st, w, wp, Cout, Cin);
+  RG_LAUNCH_CHECK("upconv3_fwd(pack)");
+  GArgs g{};
+  g.A = pad; g.B = wp; g.C = y;
+  g.M = N * 4 * H * W; g.Ncols = Cout; g.Cin = Cin; g.taps = 9;
+  g.lgW = rg_ilog2(2 * W); g.lgH = rg_ilog2(2 * H); g.Hs = Hp; g.Ws = Wp; g.ldc = Cout; g.b_col = 9 * Cin; g.b_tap = Cin;
+  g.shift = bias;
+  return launch_gather2<MODE_C3, EPI_BF16>("upconv3_fwd(mfma)", g, 1, g.M, (size_t)N * Hp * Wp * Cin * 2,
+                                           (size_t)Cout * 9 * Cin * 2, (char*)ws + padb + wpb, ws_bytes - padb - wpb, st);
 }
 
 int rg_mfma_pack_linear_weight(const float* w, void* wp, int Nout, int K, int Np, int Kp, hipStream_t st) {

@@ -219,8 +219,9 @@ class HipOps:
         Cout = cw.w.shape[0]
         assert tuple(cw.w.shape) == (Cout, Cin, 3, 3) and cw.w.is_contiguous() and x.is_contiguous()
         y = self._f32(N, Cout, 2 * H, 2 * W) if out_nchw else self._act(N, 2 * H, 2 * W, Cout)
+        ws = self._ws(self.lib.rg_upconv3_workspace_bytes(N, H, W, Cin, Cout))
         check(self.lib.rg_upconv3_fwd(_ptr(x), _ptr(cw.w), _ptr(bias), _ptr(y), N, H, W, Cin, Cout, int(out_nchw),
-                                      self.dt, self.stream), "rg_upconv3_fwd")
+                                      self.dt, self.algo, _ptr(ws), ws.numel(), self.stream), "rg_upconv3_fwd")
         return y
 
     def _up_dims(self, gy, cw, gy_nchw):
