@@ -287,19 +287,21 @@ int rg_selftest_layouts(int* detail, void* stream);
  * Resize-convolution block of DCGANUpGenerator (src/dcgan.py:45-56 and the last block :76-84):
  *   y[N][2H][2W][Cout] = Conv2d(Cin, Cout, 3, 1, 0)(ReflectionPad2d(1)(Upsample(x2, bilinear)(x[N][H][W][Cin]))) + bias
  * w[Cout][Cin][3][3] and bias[Cout] in PyTorch layout.  out_nchw_f32 / gy_nchw_f32 = 1: the image-side tensor is
- * NCHW fp32 (the generator's output block).  Forward, bf16 NHWC with Cin % 64 == 0: matrix cores (the padded upsampled
- * image is materialised in the workspace, then a 9-tap stride-1 implicit GEMM with the bias in its epilogue); everything
- * else: functor-GEMM kernels on the vector ALUs (the variant is not on the reference CLI's path).
+ * NCHW fp32 (the generator's output block).  bf16 NHWC blocks run on the matrix cores: forward (Cin % 64 == 0) =
+ * padded upsampled image materialised in the workspace + 9-tap stride-1 implicit GEMM with the bias in its epilogue;
+ * data gradient (Cout % 64 == 0) = 9-tap full correlation onto the padded grid + adjoint of pad/upsample; weight
+ * gradient = the pixel-contracting kernel of the 4x4 layers with 9 stride-1 taps.  Everything else (fp32, the NCHW
+ * image block with Cout = 3): functor-GEMM kernels on the vector ALUs.
  * ------------------------------------------------------------------------------------------- */
 size_t rg_upconv3_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 int rg_upconv3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int Cin, int Cout,
                    int out_nchw_f32, int dtype, int algo, void* ws, size_t ws_bytes, void* stream);
 /* gx[N][H][W][Cin] = d/dx of the block for the output gradient gy */
 int rg_upconv3_bwd_data(const void* gy, int gy_nchw_f32, const float* w, void* gx, int N, int H, int W, int Cin,
-                        int Cout, int dtype, void* ws, size_t ws_bytes, void* stream);
+                        int Cout, int dtype, int algo, void* ws, size_t ws_bytes, void* stream);
 /* dw[Cout][Cin][3][3] (+)= weight gradient (the bias gradient is a column sum of gy: rg_col_sum / rg_nchw_chan_sum) */
 int rg_upconv3_wgrad(const void* gy, int gy_nchw_f32, const void* x, float* dw, int N, int H, int W, int Cin, int Cout,
-                     int dtype, int accumulate, void* ws, size_t ws_bytes, void* stream);
+                     int dtype, int algo, int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Split forms for synchronised (global-batch) statistics in a data-parallel run (--sync-stats): *_sums

@@ -74,8 +74,8 @@ PROTOTYPES = {
     "rg_clamp": (_i, [_p, _z, _f, _f, _p]),
     "rg_upconv3_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "rg_upconv3_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
-    "rg_upconv3_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
-    "rg_upconv3_wgrad": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "rg_upconv3_bwd_data": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "rg_upconv3_wgrad": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_export_images_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "rg_bn_bwd_sums": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p, _z, _p]),
     "rg_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p]),

@@ -29,6 +29,9 @@ constexpr int MODE_DOWN = 0, MODE_UP = 1, MODE_PLAIN = 2;
 // MODE_C3: 3x3 stride-1 VALID conv over a pre-padded image (the resize-convolution block of DCGANUpGenerator:
 // A = materialised bilinear-x2 + reflection-pad image [N][Hs][Ws][Cin], output grid (Hs-2) x (Ws-2), 9 taps)
 constexpr int MODE_C3 = 3;
+// MODE_C3T: its data gradient -- full 3x3 correlation of gy[N][Hs][Ws][Cin=Cout] onto the padded grid (Hs+2) x (Ws+2)
+// (row decode by division: the padded grid is not a power of two), B = w transposed to [c][tap][o]
+constexpr int MODE_C3T = 4;
 constexpr int EPI_BF16 = 0, EPI_LINEAR = 1;
 
 struct GArgs {
@@ -383,6 +386,17 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
     } else if (MODE == MODE_C3) {
       base = (((long long)n * g.Hs + hq) * g.Ws + wq) * g.Cin;     // top-left tap of the 3x3 window; all 9 exist
       mask = 0x1FFu;
+    } else if (MODE == MODE_C3T) {
+      const int Wp = g.Ws + 2, Hp = g.Hs + 2;
+      const int jj = mm % Wp, tt = mm / Wp, ii = tt % Hp, nn = tt / Hp;
+      base = (((long long)nn * g.Hs + ii) * g.Ws + jj) * g.Cin;    // tap (kh, kw) reads gy[ii - kh][jj - kw]
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          bool v = (unsigned)(ii - kh) < (unsigned)g.Hs && (unsigned)(jj - kw) < (unsigned)g.Ws;
+          mask |= (v ? 1u : 0u) << (kh * 3 + kw);
+        }
     } else {
       base = (long long)mm * g.Cin;
       mask = 1u;
@@ -417,6 +431,10 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
     } else if (MODE == MODE_C3) {
       const int kh = tap / 3;
       a_delta = (kh * g.Ws + (tap - 3 * kh)) * g.Cin;
+      b_tap = tap;
+    } else if (MODE == MODE_C3T) {
+      const int kh = tap / 3;
+      a_delta = -(kh * g.Ws + (tap - 3 * kh)) * g.Cin;
       b_tap = tap;
     } else {
       a_delta = 0;
@@ -841,7 +859,12 @@ struct W2Args {
 
 __device__ __forceinline__ int wswz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
+// C3 = true: the 3x3 stride-1 weight gradient of the resize-convolution block -- `high` is the padded upsampled image
+// [N][Hh = Ho + 2][Wh = Wo + 2][I], 9 taps, slab columns tap*I + i (9*I need not fill the last 128-column tile) and
+// O need not be a multiple of 128 (rows beyond O are never loaded nor stored).
+template <bool C3>
 __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(W2Args g) {
+  constexpr int NTAP = C3 ? 9 : 16;
   constexpr int STAGE = 2 * 64 * 16;                           // 16-byte slots per stage (low + high)
   __shared__ __attribute__((aligned(16))) uint4 lds[2 * STAGE];   // 64 KB
   const int t = threadIdx.x;
@@ -876,7 +899,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(W2Args g) {
   const int lc = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (wave & 3));      // logical 16-byte chunk (8 channels)
   const int gc = c0 + lc * 8;                                              // global column = tap*I + i
   const int tap = gc / g.I, ci = gc - tap * g.I;
-  const int kh = tap >> 2, kw = tap & 3;
+  const int kh = C3 ? tap / 3 : tap >> 2, kw = C3 ? tap - 3 * (tap / 3) : tap & 3;
+  const bool col_ok = !C3 || gc < NTAP * g.I;
+  const bool o_ok = !C3 || o0 + lc * 8 < g.O;
   const int Wo = 1 << g.lgWo, Ho = 1 << g.lgHo;
 
   auto issue = [&](int stage, int kt) {
@@ -890,10 +915,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(W2Args g) {
     for (int j = 0; j < 4; ++j) {
       int p = pbase + j * 16 + lrow;
       bool ok = p < kend;
-      unsigned lo = ok ? (unsigned)(((long long)p * g.O + o0 + lc * 8) * 2) : OOB;
+      unsigned lo = (ok && o_ok) ? (unsigned)(((long long)p * g.O + o0 + lc * 8) * 2) : OOB;
       int wo = p & (Wo - 1), ho = (p >> g.lgWo) & (Ho - 1), n = p >> (g.lgWo + g.lgHo);
-      int hi = 2 * ho - 1 + kh, wi = 2 * wo - 1 + kw;
-      bool v = ok && (unsigned)hi < (unsigned)g.Hh && (unsigned)wi < (unsigned)g.Wh;
+      int hi = C3 ? ho + kh : 2 * ho - 1 + kh, wi = C3 ? wo + kw : 2 * wo - 1 + kw;
+      bool v = ok && col_ok && (unsigned)hi < (unsigned)g.Hh && (unsigned)wi < (unsigned)g.Wh;
       unsigned ho_ = v ? (unsigned)(((((long long)n * g.Hh + hi) * g.Wh + wi) * g.I + ci) * 2) : OOB;
       if (!seg1) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL0, (lds_vptr_t)(sl + j * 256 + wave * 64), 16, lo, 0, 0, 0);
@@ -964,12 +989,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(W2Args g) {
       for (int r = 0; r < 16; ++r)
         cs[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh2) * 128 + wn * 64 + j * 32 + fr] = acc[i][j][r];
   __syncthreads();
-  const long long ldw = (long long)16 * g.I;
+  const long long ldw = (long long)NTAP * g.I;
   float* slab = g.slab + (long long)zs * g.O * ldw;
   const int c4 = (t & 31) * 4, rr = t >> 5;
 #pragma unroll
   for (int p = 0; p < 16; ++p) {
     const int row = rr + 8 * p;
+    if (C3 && (o0 + row >= g.O || c0 + c4 >= ldw)) continue;
     float4* d = reinterpret_cast<float4*>(slab + (long long)(o0 + row) * ldw + c0 + c4);
     float4 v = *reinterpret_cast<const float4*>(cs + row * 128 + c4);
     if (g.accumulate) {
@@ -1364,7 +1390,7 @@ int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, c
   g.tiles_o = O / 128; g.nsplit = nsplit;
   // dW is tap-major [O][16][I] = the slab layout: a single split writes (or adds to) dW straight from its epilogue
   if (nsplit == 1) { g.slab = dw; g.accumulate = accumulate; }
-  hipLaunchKernelGGL(wgrad_dma_kernel, dim3((unsigned)(g.tiles_o * g.tiles_c * nsplit)), dim3(256), 0, st, g);
+  hipLaunchKernelGGL(wgrad_dma_kernel<false>, dim3((unsigned)(g.tiles_o * g.tiles_c * nsplit)), dim3(256), 0, st, g);
   RG_LAUNCH_CHECK("conv_wgrad(mfma)");
   if (nsplit == 1) return RG_OK;
   return rg_reduce_slabs((const float*)ws, dw, elems, nsplit, accumulate, 0, 0, st);
@@ -1489,6 +1515,160 @@ int rg_mfma_upconv3_fwd(const void* x, const float* w, const float* bias, void* 
   g.shift = bias;
   return launch_gather2<MODE_C3, EPI_BF16>("upconv3_fwd(mfma)", g, 1, g.M, (size_t)N * Hp * Wp * Cin * 2,
                                            (size_t)Cout * 9 * Cin * 2, (char*)ws + padb + wpb, ws_bytes - padb - wpb, st);
+}
+
+// w3[o][c][3][3] fp32 -> wt[c][tap][o] bf16 (B operand of the data gradient)
+__global__ void pack_w3t_kernel(const float* __restrict__ w, uint16_t* __restrict__ wt, int Cout, int Cin) {
+  const size_t n = (size_t)Cout * 9 * Cin;
+  for (size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += (size_t)gridDim.x * blockDim.x) {
+    const size_t o = d % Cout, ct = d / Cout;
+    const size_t tap = ct % 9, c = ct / 9;
+    wt[d] = f32_to_bf16(w[(o * Cin + c) * 9 + tap]);
+  }
+}
+// adjoint of (reflection pad o bilinear x2) on a bf16 padded-grid gradient, 8 channels per thread:
+// gx[n][h][w][c] = sum over the upsampled pixels (u, v) that read x[h][w], each collecting the padded positions that
+// mirror it (same arithmetic as the functor path's adjoint kernel, fp32 accumulation)
+__global__ void uppad_adjoint_bf16_kernel(const uint16_t* __restrict__ gpad, uint16_t* __restrict__ gx, int N, int H, int W,
+                                          int C) {
+  const int C8 = C >> 3, H2 = 2 * H, W2 = 2 * W, Wp = W2 + 2;
+  const size_t tot = (size_t)N * H * W * C8;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c8 = (int)(idx % C8);
+    size_t t = idx / C8;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    const bf16_t* gp = reinterpret_cast<const bf16_t*>(gpad) + (size_t)n * (H2 + 2) * Wp * C + c8 * 8;
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int du = -1; du <= 2; ++du) {
+      const int u = 2 * h + du;
+      if (u < 0 || u >= H2) continue;
+      int a0, a1; float la;
+      up_taps(u, H, a0, a1, la);
+      const float ch = (a0 == h ? 1.f - la : 0.f) + (a1 == h ? la : 0.f);
+      if (ch == 0.f) continue;
+      for (int dv = -1; dv <= 2; ++dv) {
+        const int v = 2 * w + dv;
+        if (v < 0 || v >= W2) continue;
+        int b0, b1; float lb;
+        up_taps(v, W, b0, b1, lb);
+        const float cw = (b0 == w ? 1.f - lb : 0.f) + (b1 == w ? lb : 0.f);
+        if (cw == 0.f) continue;
+        const float f = ch * cw;
+        for (int ri = 0; ri < 3; ++ri) {       // padded rows that read upsampled row u: u+1, and the mirrored border rows
+          const int i = ri == 0 ? u + 1 : (ri == 1 ? (u == 1 ? 0 : -1) : (u == H2 - 2 ? H2 + 1 : -1));
+          if (i < 0) continue;
+          for (int rj = 0; rj < 3; ++rj) {
+            const int j = rj == 0 ? v + 1 : (rj == 1 ? (v == 1 ? 0 : -1) : (v == W2 - 2 ? W2 + 1 : -1));
+            if (j < 0) continue;
+            float gv[8];
+            Vec<bf16_t, 8>::ld(gp + ((size_t)i * Wp + j) * C, gv);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += f * gv[k];
+          }
+        }
+      }
+    }
+    Vec<bf16_t, 8>::st(reinterpret_cast<bf16_t*>(gx) + idx * 8, acc);
+  }
+}
+// data gradient: Cout % 64 == 0 (K = 9 * Cout), Cin % 8 == 0
+bool rg_mfma_upconv3_bwd_supported(int N, int H, int W, int Cin, int Cout) {
+  const long long Mp = (long long)N * (2 * H + 2) * (2 * W + 2);
+  return Cout % 64 == 0 && Cin % 8 == 0 && Mp < 0x7fffffffLL && !use_v1() &&
+         (size_t)N * 4 * H * W * Cout * 2 < 0x7f000000ull;
+}
+size_t rg_mfma_upconv3_bwd_ws_bytes(int N, int H, int W, int Cin, int Cout) {
+  const int Mp = N * (2 * H + 2) * (2 * W + 2);
+  return rg_align_up((size_t)Mp * Cin * 2, 256) + rg_align_up((size_t)Cout * 9 * Cin * 2, 256) +
+         rg_mfma_gather_ws_bytes(Mp, Mp, Cin, 1, 9 * (Cout >> 6));
+}
+int rg_mfma_upconv3_bwd_data(const void* gy, const float* w, void* gx, int N, int H, int W, int Cin, int Cout, void* ws,
+                             size_t ws_bytes, hipStream_t st) {
+  RG_REQUIRE(ws && ws_bytes >= rg_mfma_upconv3_bwd_ws_bytes(N, H, W, Cin, Cout), RG_EWORKSPACE,
+             "upconv3_bwd_data(mfma): workspace too small");
+  const int Hp = 2 * H + 2, Wp = 2 * W + 2, Mp = N * Hp * Wp;
+  const size_t gpb = rg_align_up((size_t)Mp * Cin * 2, 256), wtb = rg_align_up((size_t)Cout * 9 * Cin * 2, 256);
+  uint16_t* gpad = (uint16_t*)ws;
+  uint16_t* wt = (uint16_t*)((char*)ws + gpb);
+  hipLaunchKernelGGL(pack_w3t_kernel, dim3(grid_cap((size_t)Cout * 9 * Cin)), dim3(256), 0, st, w, wt, Cout, Cin);
+  RG_LAUNCH_CHECK("upconv3_bwd_data(pack)");
+  GArgs g{};
+  g.A = (const uint16_t*)gy; g.B = wt; g.C = gpad;
+  g.M = Mp; g.Ncols = Cin; g.Cin = Cout; g.taps = 9;
+  g.Hs = 2 * H; g.Ws = 2 * W; g.ldc = Cin; g.b_col = 9 * Cout; g.b_tap = Cout;
+  int rc = launch_gather2<MODE_C3T, EPI_BF16>("upconv3_bwd_data(mfma)", g, 1, g.M, (size_t)N * 4 * H * W * Cout * 2,
+                                              (size_t)Cout * 9 * Cin * 2, (char*)ws + gpb + wtb, ws_bytes - gpb - wtb, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(uppad_adjoint_bf16_kernel, dim3(grid_cap((size_t)N * H * W * (Cin >> 3))), dim3(256), 0, st, gpad,
+                     (uint16_t*)gx, N, H, W, Cin);
+  RG_LAUNCH_CHECK("upconv3_bwd_data(adjoint)");
+  return RG_OK;
+}
+
+// weight gradient: dw[o][c][kh][kw] (+)= sum_pixels gy[p][o] * pad[p + (kh, kw)][c] -- the pixel-contracting kernel of
+// the 4x4 layers with 9 stride-1 taps over the re-materialised padded image; slabs are [o][tap][c], the reduction
+// permutes them into the PyTorch layout of the 3x3 master.
+__global__ void reduce_w3_slabs_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin, int nsplit,
+                                       int accumulate) {
+  const size_t n = (size_t)Cout * 9 * Cin;
+  for (size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += (size_t)gridDim.x * blockDim.x) {
+    const size_t c = d % Cin, ot = d / Cin;
+    const size_t tap = ot % 9, o = ot / 9;
+    float v = 0.f;
+    for (int z = 0; z < nsplit; ++z) v += slab[(size_t)z * n + d];
+    float* out = dw + (o * Cin + c) * 9 + tap;
+    *out = accumulate ? *out + v : v;
+  }
+}
+static int upconv3_wgrad_split(int K, int Cout, int Cin) {
+  const int tiles = ((Cout + 127) / 128) * ((9 * Cin + 127) / 128);
+  int want = (512 + tiles - 1) / tiles, maxs = K / 256;
+  if (maxs < 1) maxs = 1;
+  const int s = want < maxs ? want : maxs;
+  return s < 1 ? 1 : s;
+}
+bool rg_mfma_upconv3_wgrad_supported(int N, int H, int W, int Cin, int Cout) {
+  return Cout % 8 == 0 && Cin % 8 == 0 && rg_is_pow2(H) && rg_is_pow2(W) && !use_v1() &&
+         (size_t)N * 4 * H * W * Cout * 2 < 0x7fffff00ull && (size_t)N * (2 * H + 2) * (2 * W + 2) * Cin * 2 < 0x7fffff00ull;
+}
+size_t rg_mfma_upconv3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout) {
+  return rg_align_up((size_t)N * (2 * H + 2) * (2 * W + 2) * Cin * 2, 256) +
+         (size_t)upconv3_wgrad_split(N * 4 * H * W, Cout, Cin) * Cout * 9 * Cin * sizeof(float);
+}
+int rg_mfma_upconv3_wgrad(const void* gy, const void* x, float* dw, int N, int H, int W, int Cin, int Cout, int accumulate,
+                          void* ws, size_t ws_bytes, hipStream_t st) {
+  RG_REQUIRE(ws && ws_bytes >= rg_mfma_upconv3_wgrad_ws_bytes(N, H, W, Cin, Cout), RG_EWORKSPACE,
+             "upconv3_wgrad(mfma): workspace too small");
+  const int Hp = 2 * H + 2, Wp = 2 * W + 2, K = N * 4 * H * W;
+  const size_t padb = rg_align_up((size_t)N * Hp * Wp * Cin * 2, 256);
+  uint16_t* pad = (uint16_t*)ws;
+  float* slab = (float*)((char*)ws + padb);
+  hipLaunchKernelGGL(uppad_bf16_kernel, dim3(grid_cap((size_t)N * Hp * Wp * (Cin >> 3))), dim3(256), 0, st,
+                     (const uint16_t*)x, pad, N, H, W, Cin);
+  RG_LAUNCH_CHECK("upconv3_wgrad(pad)");
+  int nsplit = upconv3_wgrad_split(K, Cout, Cin);
+  W2Args g{};
+  g.low[0] = g.low[1] = (const uint16_t*)gy; g.high[0] = g.high[1] = pad;
+  g.low_bytes[0] = g.low_bytes[1] = (unsigned)((size_t)K * Cout * 2);
+  g.high_bytes[0] = g.high_bytes[1] = (unsigned)((size_t)N * Hp * Wp * Cin * 2);
+  g.Kseg[0] = K; g.Kseg[1] = 0;
+  g.slab = slab; g.O = Cout; g.I = Cin;
+  g.lgWo = rg_ilog2(2 * W); g.lgHo = rg_ilog2(2 * H); g.Hh = Hp; g.Wh = Wp;
+  g.tiles_c = (9 * Cin + 127) / 128;
+  const int klen = (K + nsplit - 1) / nsplit;
+  g.klen = (klen + 63) / 64 * 64;
+  nsplit = (K + g.klen - 1) / g.klen;
+  g.tiles_o = (Cout + 127) / 128; g.nsplit = nsplit;
+  hipLaunchKernelGGL(wgrad_dma_kernel<true>, dim3((unsigned)(g.tiles_o * g.tiles_c * nsplit)), dim3(256), 0, st, g);
+  RG_LAUNCH_CHECK("upconv3_wgrad(mfma)");
+  hipLaunchKernelGGL(reduce_w3_slabs_kernel, dim3(grid_cap((size_t)Cout * 9 * Cin)), dim3(256), 0, st, slab, dw, Cout, Cin,
+                     nsplit, accumulate);
+  RG_LAUNCH_CHECK("upconv3_wgrad(reduce)");
+  return RG_OK;
 }
 
 int rg_mfma_pack_linear_weight(const float* w, void* wp, int Nout, int K, int Np, int Kp, hipStream_t st) {

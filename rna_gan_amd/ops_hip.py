@@ -239,7 +239,7 @@ class HipOps:
         gx = self._act(N, H, W, Cin)
         ws = self._ws(self.lib.rg_upconv3_workspace_bytes(N, H, W, Cin, Cout))
         check(self.lib.rg_upconv3_bwd_data(_ptr(gy), int(gy_nchw), _ptr(cw.w), _ptr(gx), N, H, W, Cin, Cout, self.dt,
-                                           _ptr(ws), ws.numel(), self.stream), "rg_upconv3_bwd_data")
+                                           self.algo, _ptr(ws), ws.numel(), self.stream), "rg_upconv3_bwd_data")
         return gx
 
     def upconv3_wgrad(self, gy, x, cw: ConvW, accumulate: bool, gy_nchw=False):
@@ -247,7 +247,7 @@ class HipOps:
         assert tuple(x.shape) == (N, H, W, Cin) and x.is_contiguous() and cw.dw.is_contiguous()
         ws = self._ws(self.lib.rg_upconv3_workspace_bytes(N, H, W, Cin, Cout))
         check(self.lib.rg_upconv3_wgrad(_ptr(gy), int(gy_nchw), _ptr(x), _ptr(cw.dw), N, H, W, Cin, Cout, self.dt,
-                                        int(accumulate), _ptr(ws), ws.numel(), self.stream), "rg_upconv3_wgrad")
+                                        self.algo, int(accumulate), _ptr(ws), ws.numel(), self.stream), "rg_upconv3_wgrad")
 
     def first_down(self, x_nchw, cw: ConvW, bias, slope: float):
         N, I, H, W = x_nchw.shape
