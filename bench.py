@@ -55,11 +55,12 @@ def conv_flops_per_image(in_size=256, step=64, enc=2048):
                 G_mfma=sum(g_layers), D_layers=d_layers, G_layers=g_layers)
 
 
-def build(device, precision, batch, rna_features, seed):
+def build(device, precision, batch, rna_features, seed, gan_type="dcgan"):
     import torch.nn as nn
     import rna_gan_amd as P
     from oracle import ref_cpu as R          # seeded weight / input generators only
-    G = P.DCGANGenerator(2048, 256, 3, 64, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+    gen_cls = P.DCGANUpGenerator if gan_type == "dcgan_up" else P.DCGANGenerator
+    G = gen_cls(2048, 256, 3, 64, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
     D = P.DCGANDiscriminator(256, 3, 64, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.LeakyReLU(0.2))
     R.seeded_fill_(G, seed); R.seeded_fill_(D, seed + 1)
     G.set_precision(precision); D.set_precision(precision)
@@ -103,7 +104,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--seed", type=int, default=99)
+    ap.add_argument("--gan-type", default="dcgan", choices=["dcgan", "dcgan_up"],
+                    help="dcgan = the reference CLI's generator (the benchmark); dcgan_up = src/dcgan.py's resize-convolution "
+                         "generator (diagnostic: implies --no-roofline --no-cpu-baseline)")
     args = ap.parse_args()
+    if args.gan_type != "dcgan":
+        args.no_roofline = args.no_cpu_baseline = True
 
     from rna_gan_amd import dist as D_
     from rna_gan_amd import losses as PL
@@ -120,7 +126,7 @@ def main():
 
     N = args.batch
     rna_features = 19198
-    G, Dm, og, od, (lg, ld, lp) = build(device, args.precision, N, rna_features, args.seed)
+    G, Dm, og, od, (lg, ld, lp) = build(device, args.precision, N, rna_features, args.seed, args.gan_type)
     for mod in (G, Dm):
         for t in list(mod.parameters()) + list(mod.buffers()):
             D_.broadcast_(t.data, 0)
@@ -222,7 +228,8 @@ def main():
         "value": round(value, 2), "unit": "imgs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": "RNA-GAN lung (betaVAE-conditioned wganvae path) 256x256, DCGAN enc2048/step64, "
+        "config": {"workload": "RNA-GAN lung (betaVAE-conditioned wganvae path) 256x256, %s enc2048/step64, "
+                               % ("DCGAN" if args.gan_type == "dcgan" else "DCGANUpGenerator + DCGAN discriminator") +
                                "per-GPU batch %d, one iteration = G-loss + D-loss + GP steps" % N,
                    "global_batch": N * world, "parallelism": "dp%d" % world, "rna_features": rna_features,
                    "losses_last_step": last_losses, "hip_graphs": out_graphs and not D_.sync_stats(),

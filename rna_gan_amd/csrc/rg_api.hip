@@ -218,14 +218,20 @@ extern "C" size_t rg_upconv3_workspace_bytes(int N, int H, int W, int Cin, int C
   if (rg_mfma_upconv3_supported(N, H, W, Cin, Cout)) b = std::max(b, rg_mfma_upconv3_fwd_ws_bytes(N, H, W, Cin, Cout));
   if (rg_mfma_upconv3_bwd_supported(N, H, W, Cin, Cout)) b = std::max(b, rg_mfma_upconv3_bwd_ws_bytes(N, H, W, Cin, Cout));
   if (rg_mfma_upconv3_wgrad_supported(N, H, W, Cin, Cout)) b = std::max(b, rg_mfma_upconv3_wgrad_ws_bytes(N, H, W, Cin, Cout));
+  if (rg_mfma_upconv3_image_supported(N, H, W, Cin, Cout))
+    b = std::max(b, std::max(rg_mfma_upconv3_image_fwd_ws_bytes(N, H, W, Cin, Cout),
+                             rg_mfma_upconv3_image_wgrad_ws_bytes(N, H, W, Cin, Cout)));
   return b;
 }
 extern "C" int rg_upconv3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int Cin,
                               int Cout, int out_nchw_f32, int dtype, int algo, void* ws, size_t ws_bytes, void* stream) {
   RG_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, RG_EINVAL, "upconv3_fwd: bad args");
   // bf16 NHWC output with Cin % 64 == 0: matrix cores (pad image + 9-tap implicit GEMM); otherwise the functor kernel
-  const bool mfma_ok = dtype == RG_BF16 && !out_nchw_f32 && rg_mfma_upconv3_supported(N, H, W, Cin, Cout);
+  const bool mfma_ok = dtype == RG_BF16 && (out_nchw_f32 ? rg_mfma_upconv3_image_supported(N, H, W, Cin, Cout)
+                                                         : rg_mfma_upconv3_supported(N, H, W, Cin, Cout));
   RG_REQUIRE(mfma_ok || algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "upconv3_fwd: shape/dtype not supported by the MFMA kernel");
+  if (mfma_ok && algo != RG_ALGO_GENERIC && out_nchw_f32)
+    return rg_mfma_upconv3_image_fwd(x, w, bias, (float*)y, N, H, W, Cin, Cout, ws, ws_bytes, rg_stream(stream));
   if (mfma_ok && algo != RG_ALGO_GENERIC)
     return rg_mfma_upconv3_fwd(x, w, bias, y, N, H, W, Cin, Cout, ws, ws_bytes, rg_stream(stream));
   return rg_generic_upconv3_fwd(x, w, bias, y, N, H, W, Cin, Cout, out_nchw_f32, dtype, rg_stream(stream));
@@ -242,8 +248,11 @@ extern "C" int rg_upconv3_bwd_data(const void* gy, int gy_nchw_f32, const float*
 extern "C" int rg_upconv3_wgrad(const void* gy, int gy_nchw_f32, const void* x, float* dw, int N, int H, int W, int Cin,
                                 int Cout, int dtype, int algo, int accumulate, void* ws, size_t ws_bytes, void* stream) {
   RG_REQUIRE(gy && x && dw && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, RG_EINVAL, "upconv3_wgrad: bad args");
-  const bool mfma_ok = dtype == RG_BF16 && !gy_nchw_f32 && rg_mfma_upconv3_wgrad_supported(N, H, W, Cin, Cout);
+  const bool mfma_ok = dtype == RG_BF16 && (gy_nchw_f32 ? rg_mfma_upconv3_image_supported(N, H, W, Cin, Cout)
+                                                        : rg_mfma_upconv3_wgrad_supported(N, H, W, Cin, Cout));
   RG_REQUIRE(mfma_ok || algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "upconv3_wgrad: shape/dtype not supported by the MFMA kernel");
+  if (mfma_ok && algo != RG_ALGO_GENERIC && gy_nchw_f32)
+    return rg_mfma_upconv3_image_wgrad((const float*)gy, x, dw, N, H, W, Cin, Cout, accumulate, ws, ws_bytes, rg_stream(stream));
   if (mfma_ok && algo != RG_ALGO_GENERIC)
     return rg_mfma_upconv3_wgrad(gy, x, dw, N, H, W, Cin, Cout, accumulate, ws, ws_bytes, rg_stream(stream));
   return rg_generic_upconv3_wgrad(gy, gy_nchw_f32, x, dw, N, H, W, Cin, Cout, dtype, accumulate, ws, ws_bytes,

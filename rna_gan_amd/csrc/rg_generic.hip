@@ -524,20 +524,23 @@ template <typename T> struct UpBwdB {
     return Elem<T>::round(w[((size_t)o * g.Cin + c) * 9 + r]);
   }
 };
-// adjoint of (reflection pad o bilinear x2): gx[n][h][w][c] from gpad[n][2H+2][2W+2][c] (fp32)
-template <typename T>
+// adjoint of (reflection pad o bilinear x2): gx[n][h][w][c] from gpad[n][2H+2][2W+2][c] (fp32), V channels per thread
+template <typename T, int V>
 __global__ void uppad_adjoint_kernel(const float* __restrict__ gpad, T* __restrict__ gx, UGeo g) {
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t tot = (size_t)g.N * g.H * g.W * g.Cin;
+  const int CV = g.Cin / V;
+  size_t tot = (size_t)g.N * g.H * g.W * CV;
   if (idx >= tot) return;
-  int c = (int)(idx % g.Cin);
-  size_t t = idx / g.Cin;
+  int c = (int)(idx % CV) * V;
+  size_t t = idx / CV;
   int w = (int)(t % g.W); t /= g.W;
   int h = (int)(t % g.H);
   int n = (int)(t / g.H);
   const int H2 = 2 * g.H, W2 = 2 * g.W, Wp = W2 + 2;
   const float* gp = gpad + (size_t)n * (H2 + 2) * Wp * g.Cin + c;
-  float acc = 0.f;
+  float acc[V];
+#pragma unroll
+  for (int k = 0; k < V; ++k) acc[k] = 0.f;
   for (int du = -1; du <= 2; ++du) {
     int u = 2 * h + du;
     if (u < 0 || u >= H2) continue;
@@ -553,20 +556,26 @@ __global__ void uppad_adjoint_kernel(const float* __restrict__ gpad, T* __restri
       float cw = (b0 == w ? 1.f - lb : 0.f) + (b1 == w ? lb : 0.f);
       if (cw == 0.f) continue;
       // padded rows / columns that read upsampled row u / column v
-      float s = 0.f;
+      float s[V];
+#pragma unroll
+      for (int k = 0; k < V; ++k) s[k] = 0.f;
       for (int ri = 0; ri < 3; ++ri) {
         int i = ri == 0 ? u + 1 : (ri == 1 ? (u == 1 ? 0 : -1) : (u == H2 - 2 ? H2 + 1 : -1));
         if (i < 0) continue;
         for (int rj = 0; rj < 3; ++rj) {
           int j = rj == 0 ? v + 1 : (rj == 1 ? (v == 1 ? 0 : -1) : (v == W2 - 2 ? W2 + 1 : -1));
           if (j < 0) continue;
-          s += gp[((size_t)i * Wp + j) * g.Cin];
+          float gv[V];
+          Vec<float, V>::ld(gp + ((size_t)i * Wp + j) * g.Cin, gv);
+#pragma unroll
+          for (int k = 0; k < V; ++k) s[k] += gv[k];
         }
       }
-      acc += ch * cw * s;
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] += ch * cw * s[k];
     }
   }
-  Elem<T>::st(gx + idx, acc);
+  Vec<T, V>::st(gx + (size_t)idx * V, acc);
 }
 
 // weight gradient: M = Cout, Ncols = Cin*9 (col = c*9 + kh*3 + kw), K = N*2H*2W pixels
@@ -633,8 +642,13 @@ int rg_generic_upconv3_bwd_data(const void* gy, int gy_nchw, const float* w, voi
       rc = launch_generic<true, false>("upconv3_bwd_data", UpBwdA<T, false>{gy, g}, UpBwdB<T>{w, g},
                                        RowMajorC<float>{gpad, Cin}, Mp, Cin, Cout * 9, 1, 1, st);
     if (rc) return rc;
-    size_t tot = (size_t)N * H * W * Cin;
-    hipLaunchKernelGGL((uppad_adjoint_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, gpad, (T*)gx, g);
+    if (Cin % 4 == 0) {
+      size_t tot = (size_t)N * H * W * (Cin / 4);
+      hipLaunchKernelGGL((uppad_adjoint_kernel<T, 4>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, gpad, (T*)gx, g);
+    } else {
+      size_t tot = (size_t)N * H * W * Cin;
+      hipLaunchKernelGGL((uppad_adjoint_kernel<T, 1>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, gpad, (T*)gx, g);
+    }
     RG_LAUNCH_CHECK("upconv3_bwd_data");
     return RG_OK;
   })

@@ -50,6 +50,13 @@ bool rg_mfma_upconv3_wgrad_supported(int N, int H, int W, int Cin, int Cout);
 size_t rg_mfma_upconv3_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int rg_mfma_upconv3_wgrad(const void* gy, const void* x, float* dw, int N, int H, int W, int Cin, int Cout, int accumulate,
                           void* ws, size_t ws_bytes, hipStream_t st);
+bool rg_mfma_upconv3_image_supported(int N, int H, int W, int Cin, int Cout);
+size_t rg_mfma_upconv3_image_fwd_ws_bytes(int N, int H, int W, int Cin, int Cout);
+int rg_mfma_upconv3_image_fwd(const void* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin,
+                              int Cout, void* ws, size_t ws_bytes, hipStream_t st);
+size_t rg_mfma_upconv3_image_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout);
+int rg_mfma_upconv3_image_wgrad(const float* gy, const void* x, float* dw, int N, int H, int W, int Cin, int Cout,
+                                int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 size_t rg_generic_upconv3_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int rg_generic_upconv3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int Cin,
                            int Cout, int out_nchw, int dtype, hipStream_t st);

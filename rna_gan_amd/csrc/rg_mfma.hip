@@ -619,7 +619,7 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
       } else {
         orow = m;
       }
-      if (MODE == MODE_C3 && g.shift && zs == 0) {      // Conv2d bias of the resize-convolution block (first split only)
+      if (MODE == MODE_C3 && EPI == EPI_BF16 && g.shift && zs == 0) {      // Conv2d bias of the resize-convolution block (first split only)
         const float* b = g.shift + col;
         v0.x += b[0]; v0.y += b[1]; v0.z += b[2]; v0.w += b[3];
         v1.x += b[4]; v1.y += b[5]; v1.z += b[6]; v1.w += b[7];
@@ -1517,6 +1517,54 @@ int rg_mfma_upconv3_fwd(const void* x, const float* w, const float* bias, void* 
                                            (size_t)Cout * 9 * Cin * 2, (char*)ws + padb + wpb, ws_bytes - padb - wpb, st);
 }
 
+// ---- the generator's image block (Cout <= 8, NCHW fp32 out): same pad + 9-tap GEMM with the output columns padded
+// to one 8-wide group (fp32 rows [M][8] in the workspace), then a transposing pass adds the bias and writes NCHW.
+__global__ void rows8_to_nchw_kernel(const float* __restrict__ tmp, const float* __restrict__ bias, float* __restrict__ y,
+                                     int Cout, unsigned HW, size_t M) {
+  for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (size_t)gridDim.x * blockDim.x) {
+    const float4 a = *reinterpret_cast<const float4*>(tmp + m * 8), b = *reinterpret_cast<const float4*>(tmp + m * 8 + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const size_t n = m / HW, p = m - n * HW;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < Cout) y[(n * Cout + c) * HW + p] = v[c] + (bias ? bias[c] : 0.f);
+  }
+}
+bool rg_mfma_upconv3_image_supported(int N, int H, int W, int Cin, int Cout) {
+  return Cout <= 8 && rg_mfma_upconv3_supported(N, H, W, Cin, 8);
+}
+size_t rg_mfma_upconv3_image_fwd_ws_bytes(int N, int H, int W, int Cin, int Cout) {
+  return rg_align_up((size_t)N * (2 * H + 2) * (2 * W + 2) * Cin * 2, 256) + rg_align_up((size_t)Cout * 9 * Cin * 2, 256) +
+         (size_t)N * 4 * H * W * 8 * sizeof(float);
+}
+int rg_mfma_upconv3_image_fwd(const void* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin,
+                              int Cout, void* ws, size_t ws_bytes, hipStream_t st) {
+  RG_REQUIRE(ws && ws_bytes >= rg_mfma_upconv3_image_fwd_ws_bytes(N, H, W, Cin, Cout), RG_EWORKSPACE,
+             "upconv3_fwd(mfma, image): workspace too small");
+  const int Hp = 2 * H + 2, Wp = 2 * W + 2;
+  const size_t padb = rg_align_up((size_t)N * Hp * Wp * Cin * 2, 256), wpb = rg_align_up((size_t)Cout * 9 * Cin * 2, 256);
+  uint16_t* pad = (uint16_t*)ws;
+  uint16_t* wp = (uint16_t*)((char*)ws + padb);
+  float* tmp = (float*)((char*)ws + padb + wpb);
+  hipLaunchKernelGGL(uppad_bf16_kernel, dim3(grid_cap((size_t)N * Hp * Wp * (Cin >> 3))), dim3(256), 0, st,
+                     (const uint16_t*)x, pad, N, H, W, Cin);
+  RG_LAUNCH_CHECK("upconv3_fwd(pad)");
+  hipLaunchKernelGGL(pack_w3_kernel, dim3(grid_cap((size_t)Cout * 9 * Cin)), dim3(256), 0, st, w, wp, Cout, Cin);
+  RG_LAUNCH_CHECK("upconv3_fwd(pack)");
+  GArgs g{};
+  g.A = pad; g.B = wp; g.C = tmp;
+  g.M = N * 4 * H * W; g.Ncols = Cout; g.Cin = Cin; g.taps = 9;
+  g.lgW = rg_ilog2(2 * W); g.lgH = rg_ilog2(2 * H); g.Hs = Hp; g.Ws = Wp; g.ldc = 8; g.b_col = 9 * Cin; g.b_tap = Cin;
+  g.slope = 1.0f;
+  int rc = launch_gather2<MODE_C3, EPI_LINEAR>("upconv3_fwd(mfma, image)", g, 1, g.M, (size_t)N * Hp * Wp * Cin * 2,
+                                               (size_t)Cout * 9 * Cin * 2, nullptr, 0, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(rows8_to_nchw_kernel, dim3(grid_cap((size_t)g.M)), dim3(256), 0, st, tmp, bias, y, Cout,
+                     (unsigned)(4 * H * W), (size_t)g.M);
+  RG_LAUNCH_CHECK("upconv3_fwd(nchw)");
+  return RG_OK;
+}
+
 // w3[o][c][3][3] fp32 -> wt[c][tap][o] bf16 (B operand of the data gradient)
 __global__ void pack_w3t_kernel(const float* __restrict__ w, uint16_t* __restrict__ wt, int Cout, int Cin) {
   const size_t n = (size_t)Cout * 9 * Cin;
@@ -1613,13 +1661,13 @@ int rg_mfma_upconv3_bwd_data(const void* gy, const float* w, void* gx, int N, in
 // the 4x4 layers with 9 stride-1 taps over the re-materialised padded image; slabs are [o][tap][c], the reduction
 // permutes them into the PyTorch layout of the 3x3 master.
 __global__ void reduce_w3_slabs_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin, int nsplit,
-                                       int accumulate) {
-  const size_t n = (size_t)Cout * 9 * Cin;
+                                       int accumulate, int slab_rows) {
+  const size_t n = (size_t)Cout * 9 * Cin, zstride = (size_t)slab_rows * 9 * Cin;
   for (size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += (size_t)gridDim.x * blockDim.x) {
     const size_t c = d % Cin, ot = d / Cin;
     const size_t tap = ot % 9, o = ot / 9;
     float v = 0.f;
-    for (int z = 0; z < nsplit; ++z) v += slab[(size_t)z * n + d];
+    for (int z = 0; z < nsplit; ++z) v += slab[z * zstride + d];
     float* out = dw + (o * Cin + c) * 9 + tap;
     *out = accumulate ? *out + v : v;
   }
@@ -1666,7 +1714,59 @@ int rg_mfma_upconv3_wgrad(const void* gy, const void* x, float* dw, int N, int H
   hipLaunchKernelGGL(wgrad_dma_kernel<true>, dim3((unsigned)(g.tiles_o * g.tiles_c * nsplit)), dim3(256), 0, st, g);
   RG_LAUNCH_CHECK("upconv3_wgrad(mfma)");
   hipLaunchKernelGGL(reduce_w3_slabs_kernel, dim3(grid_cap((size_t)Cout * 9 * Cin)), dim3(256), 0, st, slab, dw, Cout, Cin,
-                     nsplit, accumulate);
+                     nsplit, accumulate, Cout);
+  RG_LAUNCH_CHECK("upconv3_wgrad(reduce)");
+  return RG_OK;
+}
+// image block (gy NCHW fp32, Cout <= 8): gy is re-laid as bf16 rows [pixel][8] (zero padded) and takes the same kernel
+// with an 8-row output tile
+__global__ void nchw_to_rows8_kernel(const float* __restrict__ gy, uint16_t* __restrict__ rows, int Cout, unsigned HW, size_t M) {
+  for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = m / HW, p = m - n * HW;
+    uint32_t h[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) h[c] = c < Cout ? (uint32_t)f32_to_bf16(gy[(n * Cout + c) * HW + p]) : 0u;
+    uint4 o;
+    o.x = h[0] | (h[1] << 16); o.y = h[2] | (h[3] << 16); o.z = h[4] | (h[5] << 16); o.w = h[6] | (h[7] << 16);
+    *reinterpret_cast<uint4*>(rows + m * 8) = o;
+  }
+}
+size_t rg_mfma_upconv3_image_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout) {
+  return rg_align_up((size_t)N * (2 * H + 2) * (2 * W + 2) * Cin * 2, 256) + rg_align_up((size_t)N * 4 * H * W * 8 * 2, 256) +
+         (size_t)upconv3_wgrad_split(N * 4 * H * W, 8, Cin) * 8 * 9 * Cin * sizeof(float);
+}
+int rg_mfma_upconv3_image_wgrad(const float* gy, const void* x, float* dw, int N, int H, int W, int Cin, int Cout,
+                                int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+  RG_REQUIRE(ws && ws_bytes >= rg_mfma_upconv3_image_wgrad_ws_bytes(N, H, W, Cin, Cout), RG_EWORKSPACE,
+             "upconv3_wgrad(mfma, image): workspace too small");
+  const int Hp = 2 * H + 2, Wp = 2 * W + 2, K = N * 4 * H * W;
+  const size_t padb = rg_align_up((size_t)N * Hp * Wp * Cin * 2, 256), rowb = rg_align_up((size_t)K * 8 * 2, 256);
+  uint16_t* pad = (uint16_t*)ws;
+  uint16_t* rows = (uint16_t*)((char*)ws + padb);
+  float* slab = (float*)((char*)ws + padb + rowb);
+  hipLaunchKernelGGL(uppad_bf16_kernel, dim3(grid_cap((size_t)N * Hp * Wp * (Cin >> 3))), dim3(256), 0, st,
+                     (const uint16_t*)x, pad, N, H, W, Cin);
+  RG_LAUNCH_CHECK("upconv3_wgrad(pad)");
+  hipLaunchKernelGGL(nchw_to_rows8_kernel, dim3(grid_cap((size_t)K)), dim3(256), 0, st, gy, rows, Cout, (unsigned)(4 * H * W),
+                     (size_t)K);
+  RG_LAUNCH_CHECK("upconv3_wgrad(rows)");
+  int nsplit = upconv3_wgrad_split(K, 8, Cin);
+  W2Args g{};
+  g.low[0] = g.low[1] = rows; g.high[0] = g.high[1] = pad;
+  g.low_bytes[0] = g.low_bytes[1] = (unsigned)((size_t)K * 8 * 2);
+  g.high_bytes[0] = g.high_bytes[1] = (unsigned)((size_t)N * Hp * Wp * Cin * 2);
+  g.Kseg[0] = K; g.Kseg[1] = 0;
+  g.slab = slab; g.O = 8; g.I = Cin;
+  g.lgWo = rg_ilog2(2 * W); g.lgHo = rg_ilog2(2 * H); g.Hh = Hp; g.Wh = Wp;
+  g.tiles_c = (9 * Cin + 127) / 128;
+  const int klen = (K + nsplit - 1) / nsplit;
+  g.klen = (klen + 63) / 64 * 64;
+  nsplit = (K + g.klen - 1) / g.klen;
+  g.tiles_o = 1; g.nsplit = nsplit;
+  hipLaunchKernelGGL(wgrad_dma_kernel<true>, dim3((unsigned)(g.tiles_c * nsplit)), dim3(256), 0, st, g);
+  RG_LAUNCH_CHECK("upconv3_wgrad(mfma, image)");
+  hipLaunchKernelGGL(reduce_w3_slabs_kernel, dim3(grid_cap((size_t)Cout * 9 * Cin)), dim3(256), 0, st, slab, dw, Cout, Cin,
+                     nsplit, accumulate, 8);
   RG_LAUNCH_CHECK("upconv3_wgrad(reduce)");
   return RG_OK;
 }

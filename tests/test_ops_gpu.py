@@ -291,7 +291,9 @@ def test_linear(M, K, Nout, packed):
                                                   (2, 8, 8, 16, 8, torch.bfloat16), (2, 1, 2, 4, 3, torch.float32),
                                                   # matrix-core forward (Cin % 64 == 0): narrow / 128x128 / split-K tiles
                                                   (2, 8, 8, 64, 64, torch.bfloat16), (2, 4, 8, 128, 128, torch.bfloat16),
-                                                  (4, 4, 4, 512, 256, torch.bfloat16)])
+                                                  (4, 4, 4, 512, 256, torch.bfloat16),
+                                                  # the image block's shape class (Cout = 3 from 64 channels)
+                                                  (2, 8, 16, 64, 3, torch.bfloat16)])
 def test_upconv3_block(N, H, W, Cin, Cout, dtype):
     """Resize-convolution block of DCGANUpGenerator (src/dcgan.py:45-56,76-84): bilinear x2 + reflection pad + 3x3
     conv, forward / data gradient / weight gradient, NHWC activation and NCHW fp32 image variants."""
