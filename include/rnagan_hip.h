@@ -260,8 +260,8 @@ int rg_adam_step(float* p, const float* g, float* m, float* v, size_t n, int ste
                  double beta2, double eps, void* stream);
 int rg_clamp(float* p, size_t n, float lo, float hi, void* stream);
 /* Same update with the step-dependent constants read from DEVICE memory, so the launch can live in
- * a captured HIP graph and be replayed every step: hyper[0..6] = {beta1, beta2, 1-beta1, 1-beta2, eps,
- * lr/bias_correction1, 1/sqrt(bias_correction2)}, produced by rg_adam_hyper_dev.
+ * a captured HIP graph and be replayed every step: hyper[0..7] = {beta1, beta2, 1-beta1, 1-beta2, eps,
+ * lr/bias_correction1, 1/sqrt(bias_correction2), weight_decay}, produced by rg_adam_hyper_dev.
  * shadow_bf16 (may be NULL): bf16[n], receives the rounded updated parameters in the same launch -- for the
  * tap-major conv weights that IS the wdn operand of rg_conv_down, so no separate pack pass reads the masters.
  * grad_bf16 (may be NULL): bf16[n] gradient read INSTEAD of g -- the all-reduced bf16 wire buffer of a data-parallel
@@ -269,8 +269,46 @@ int rg_clamp(float* p, size_t n, float lo, float hi, void* stream);
 int rg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, void* shadow_bf16,
                      const void* grad_bf16, void* stream);
 /* ++(*step_dev) and recompute hyper[0..6] from it on the device (double arithmetic, one thread): with
- * this launch in front of rg_adam_step_dev the whole optimizer step replays from a graph untouched. */
-int rg_adam_hyper_dev(int* step_dev, double lr, double beta1, double beta2, double eps, float* hyper, void* stream);
+ * this launch in front of rg_adam_step_dev the whole optimizer step replays from a graph untouched.
+ * hyper[7] = weight_decay (torch.optim.Adam's L2 term g += wd * p; 0 on the GAN path, betaVAE training sets it,
+ * src/betaVAE_training.py:163). */
+int rg_adam_hyper_dev(int* step_dev, double lr, double beta1, double beta2, double eps, double weight_decay, float* hyper,
+                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * betaVAE TRAINING (src/betaVAE.py:63-107 model, :145-163 loss, :166-284 train loop).
+ * A Linear layer's three GEMMs all take the "NT" form C[M][Nout] = A[M][K] . B[Nout][K]^T:
+ *   forward  y  = x  . W^T      A = x [N][in]        B = W   [out][in]
+ *   data     dx = dy . W        A = dy [N][out]      B = W^T [in][out]     (rg_transpose_pack_bf16 of W)
+ *   weight   dW = dy^T . x      A = dy^T [out][N]    B = x^T [in][N]       (both transposed packs; K = batch)
+ * rg_gemm_nt_bf16: bf16 operands with K padded to K_pad (multiple of 64, zero filled), fp32 accumulate/output,
+ *   epilogue y = lrelu(acc * scale[j] + shift[j], slope) (scale/shift may be NULL, slope 1 = none).  Nout need not
+ *   be a multiple of 8; the columns up to the next multiple of 8 (when inside ldy) are zero-filled.
+ * rg_transpose_pack_bf16: dst bf16 [C_pad][R_pad] = src^T (fp32 [R][C]), zero padded; R_pad % 64 == 0.
+ * rg_transpose_f32: fp32 parity mode (the functor GEMM rg_linear_affine_act takes fp32 operands).
+ * ------------------------------------------------------------------------------------------- */
+int rg_transpose_f32(const float* src, float* dst, int R, int C, void* stream);
+int rg_transpose_pack_bf16(const float* src, void* dst, int R, int C, int R_pad, int C_pad, void* stream);
+size_t rg_gemm_nt_bf16_workspace_bytes(int M, int K_pad, int Nout);
+int rg_gemm_nt_bf16(const void* a, const void* b, const float* scale, const float* shift, float* y, int ldy, int M,
+                    int K_pad, int Nout, float slope, void* ws, size_t ws_bytes, void* stream);
+/* y[N][ld] = Dropout(x[N][F]) with the caller's keep-mask (uint8, NULL = keep all) and scale 1/(1-p); columns
+ * F..ld-1 are zero (src/betaVAE.py:27: nn.Dropout() in front of the encoder) */
+int rg_vae_dropout(const float* x, const unsigned char* mask, float* y, int N, int F, int ld, float scale, void* stream);
+/* z = mu + eps * exp(0.5 logvar) (betaVAE.py:96-100) and its backward joined with the loss gradients:
+ * gmu = gmu_loss + gz ; glv = glv_loss + gz * eps * 0.5 exp(0.5 logvar) */
+int rg_vae_reparam(const float* mu, const float* logvar, const float* eps, float* z, size_t n, void* stream);
+int rg_vae_reparam_bwd(const float* gz, const float* logvar, const float* eps, const float* gmu_loss,
+                       const float* glv_loss, float* gmu, float* glv, size_t n, void* stream);
+int rg_tanh_inplace(float* x, size_t n, void* stream);
+int rg_add_inplace(float* y, const float* x, size_t n, void* stream);     /* y += x (the two heads' gradients meet) */
+/* betaVAEloss (betaVAE.py:145-163): losses[3] = {total, reconstruction (MSE over N*F), kl}; total = recons + beta*kl
+ * when training else recons.  Also writes d total / d x_recons ([N][ld]), d total / d z_mean, d total / d z_logvar
+ * ([N][Z]).  x and x_recons are [N][ld] with zero pad columns F..ld-1.  Deterministic two-stage reduction. */
+size_t rg_vae_loss_workspace_bytes(void);
+int rg_vae_loss(const float* x, const float* x_recons, int N, int F, int ld, const float* z_mean, const float* z_logvar,
+                int Z, float beta, int training, float* losses, float* g_recons, float* g_mean, float* g_logvar, void* ws,
+                size_t ws_bytes, void* stream);
 
 /* bf16 -> fp32 widening of a flat buffer (gradient all-reduce decompression) */
 int rg_widen_bf16(const void* src, float* dst, size_t n, void* stream);

@@ -170,8 +170,8 @@ class OracleDCGANDiscriminator(nn.Module):
 class OracleBetaVAE(nn.Module):
     """betaVAE module layout of src/betaVAE.py:18-42,63-107 (same state_dict keys).
 
-    Only ``encode`` is on the hot path (src/wgan_loss.py:96-97,223-224,353-354);
-    the decoder exists so that reference checkpoints load with strict=True.
+    ``encode`` is on the GAN hot path (src/wgan_loss.py:96-97,223-224,353-354); ``forward_with`` restates the full
+    forward for the betaVAE training row, pinned by tests/golden/f7_vae_train.npz.
     """
 
     def __init__(self, in_channels, z_dim, encoder_dims, hidden_dims_decoder, beta=2):
@@ -206,6 +206,65 @@ class OracleBetaVAE(nn.Module):
         # src/betaVAE.py:102-107
         h = self.encoder(x)
         return self.z_mu(h), self.z_logvar(h), h
+
+    def forward_with(self, x, mask=None, eps=None, bf16_gemm=False):
+        """src/betaVAE.py:108-114 with the two random draws made explicit: ``mask`` = the keep-mask nn.Dropout()
+        (p = 0.5, :27) drew in train mode (None in eval mode: identity), ``eps`` = reparametrize's randn_like (:96-100).
+        bf16_gemm: the twin of the bf16 product path -- every GEMM (forward, data and weight gradient) takes its two
+        operands rounded to bf16 and accumulates in fp32; everything between the GEMMs stays fp32."""
+        lin = (lambda h, l: _Bf16GemmLinear.apply(h, l.weight, l.bias)) if bf16_gemm else (lambda h, l: l(h))
+        blocks = list(self.encoder.encoder.children())
+        h = x
+        if self.training:
+            p = blocks[0][0].p
+            h = x * mask.to(x.dtype) / (1.0 - p)
+        for blk in blocks[1:]:
+            h = blk[2](blk[1](lin(h, blk[0])))
+        z_mean, z_log_var = lin(h, self.z_mu), lin(h, self.z_logvar)
+        h = z_mean + eps * torch.exp(0.5 * z_log_var)
+        dec = list(self.decoder.children())
+        for blk in dec[:-1]:
+            h = blk[2](blk[1](lin(h, blk[0])))
+        return dec[-1][1](lin(h, dec[-1][0])), z_mean, z_log_var
+
+
+def _r16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _Bf16GemmLinear(torch.autograd.Function):
+    """y = bf16(x) . bf16(W)^T + b ;  dx = bf16(gy) . bf16(W) ;  dW = bf16(gy)^T . bf16(x) ;  db = sum gy  (fp32 sums)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xr, wr = _r16(x), _r16(w)
+        ctx.save_for_backward(xr, wr)
+        return xr @ wr.t() + b
+
+    @staticmethod
+    def backward(ctx, gy):
+        xr, wr = ctx.saved_tensors
+        gr = _r16(gy)
+        return gr @ wr, gr.t() @ xr, gy.sum(0)
+
+
+def oracle_vae_loss(x, x_recons, z_mean, z_logvar, beta, training=True):
+    """betaVAEloss, src/betaVAE.py:145-163 (kld_weight is unused there)."""
+    recons = torch.mean((x_recons - x) ** 2)
+    kld = torch.mean(-0.5 * torch.sum(1 + z_logvar - z_mean ** 2 - z_logvar.exp(), dim=1), dim=0)
+    total = recons + beta * kld if training else recons
+    return {"total_loss": total, "reconstruction_loss": recons, "kl_loss": kld}
+
+
+def oracle_vae_train_step(model, optimizer, x, mask, eps, bf16_gemm=False):
+    """One 'train'-phase iteration of train_betaVAE (src/betaVAE.py:218-234): zero_grad, forward, loss, backward, step."""
+    model.train()
+    optimizer.zero_grad(set_to_none=True)
+    out, z_mean, z_log_var = model.forward_with(x, mask, eps, bf16_gemm)
+    losses = oracle_vae_loss(x, out, z_mean, z_log_var, model.beta, training=True)
+    losses["total_loss"].backward()
+    optimizer.step()
+    return out.detach(), z_mean.detach(), z_log_var.detach(), {k: v.detach() for k, v in losses.items()}
 
 
 # --------------------------------------------------------------------------------------

@@ -87,7 +87,18 @@ PROTOTYPES = {
     "rg_latent_apply": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "rg_adam_step_dev": (_i, [_p, _p, _p, _p, _z, _p, _p, _p, _p]),
     "rg_interp_dev": (_i, [_p, _p, _p, _z, _p, _p]),
-    "rg_adam_hyper_dev": (_i, [_p, _d, _d, _d, _d, _p, _p]),
+    "rg_adam_hyper_dev": (_i, [_p, _d, _d, _d, _d, _d, _p, _p]),
+    "rg_transpose_f32": (_i, [_p, _p, _i, _i, _p]),
+    "rg_transpose_pack_bf16": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "rg_gemm_nt_bf16_workspace_bytes": (_z, [_i, _i, _i]),
+    "rg_gemm_nt_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _z, _p]),
+    "rg_vae_dropout": (_i, [_p, _p, _p, _i, _i, _i, _f, _p]),
+    "rg_vae_reparam": (_i, [_p, _p, _p, _p, _z, _p]),
+    "rg_vae_reparam_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "rg_tanh_inplace": (_i, [_p, _z, _p]),
+    "rg_add_inplace": (_i, [_p, _p, _z, _p]),
+    "rg_vae_loss_workspace_bytes": (_z, []),
+    "rg_vae_loss": (_i, [_p, _p, _i, _i, _i, _p, _p, _i, _f, _i, _p, _p, _p, _p, _p, _z, _p]),
     "rg_widen_bf16": (_i, [_p, _p, _z, _p]),
     "rg_cast_pad": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "rg_selftest_layouts": (_i, [_p, _p]),

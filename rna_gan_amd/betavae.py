@@ -1,11 +1,12 @@
 """betaVAE with the reference's module layout / state_dict keys (src/betaVAE.py:18-42,63-107).
 
-Only the hot-path part is implemented natively: ``encode`` in EVAL mode (Dropout = identity,
-BatchNorm1d with running statistics), i.e. 3 x [Linear + BN1d + LeakyReLU(0.01)] then ``z_mu`` /
-``z_logvar`` (src/wgan_loss.py:67-69,96-97).  Each layer is ONE HIP GEMM whose epilogue applies the
-folded BatchNorm scale/shift and the activation (rg_linear_affine_act); with precision "bf16" the
-weights are streamed as a packed bf16 copy (this path is weight-streaming/HBM bound).
-Training the VAE and the decoder are out of scope: ``forward`` raises.
+The GAN hot path uses ``encode`` in EVAL mode (Dropout = identity, BatchNorm1d with running
+statistics), i.e. 3 x [Linear + BN1d + LeakyReLU(0.01)] then ``z_mu`` / ``z_logvar``
+(src/wgan_loss.py:67-69,96-97).  Each layer is ONE HIP GEMM whose epilogue applies the folded
+BatchNorm scale/shift and the activation (rg_linear_affine_act); with precision "bf16" the weights
+are streamed as a packed bf16 copy (this path is weight-streaming/HBM bound).
+``forward`` (train and eval mode, decoder included) is the betaVAE training path of SURVEY 8f row f4:
+rna_gan_amd/vae_train.py.
 """
 from __future__ import annotations
 
@@ -47,18 +48,48 @@ class betaVAE(nn.Module):
         self.precision = "bf16"
         self._plan = None
         self._ops = None
+        self._flat = None
+        self._trt = None
+        # parity hooks: a fixed Dropout keep-mask ([N][in_channels] uint8) / reparametrisation noise ([N][z_dim])
+        # instead of device-side sampling
+        self.fixed_mask = None
+        self.fixed_eps = None
 
     # ---------------------------------------------------------------- runtime
     def set_precision(self, precision: str):
         self.precision = precision
         self._plan = None
+        self._trt = None
         return self
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
         self._plan = None
         self._ops = None
+        self._flat = None
+        self._trt = None
         return r
+
+    # training runtime: parameters / gradients re-homed into flat buffers (fused Adam), kernel-level fwd/bwd
+    def flat_params(self):
+        from .models import FlatParams
+        if self._flat is None or not self._flat.owns(self):
+            self._flat = FlatParams(self)
+            self._plan = None
+        return self._flat
+
+    @property
+    def flat(self):
+        return self.flat_params()
+
+    def weights_changed(self, by_optimizer: bool = False):
+        self._plan = None
+
+    def train_runtime(self):
+        if self._trt is None:
+            from .vae_train import VaeRuntime
+            self._trt = VaeRuntime(self)
+        return self._trt
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
@@ -69,6 +100,8 @@ class betaVAE(nn.Module):
         d = dict(self.__dict__)
         d["_plan"] = None
         d["_ops"] = None
+        d["_flat"] = None
+        d["_trt"] = None
         return d
 
     def _build_plan(self):
@@ -112,4 +145,19 @@ class betaVAE(nn.Module):
         return z_mean, z_log_var, h
 
     def forward(self, x):
-        raise NotImplementedError("betaVAE training/decoding is outside the RNA-GAN hot path (SURVEY 8f f4)")
+        """(out, z_mean, z_log_var) as src/betaVAE.py:108-114: train mode = Dropout + batch-statistics BatchNorm,
+        differentiable through one autograd.Function (parameter gradients land in the flat gradient buffer)."""
+        from .vae_train import vae_forward
+        return vae_forward(self, x)
+
+    def decode(self, z):
+        if self.training:
+            raise NotImplementedError("betaVAE.decode: eval mode only (the train-mode decoder runs inside forward)")
+        return self.train_runtime().decode_eval(z)[:, :self.encoder.in_channels]
+
+    def sample(self, num_samples: int, current_device, interpolation=None, alpha: float = 1.0):
+        """src/betaVAE.py:116-140: decode N(0, I) latents (optionally shifted by alpha * interpolation)."""
+        z = torch.randn(num_samples, self.z_dim).to(current_device)
+        if interpolation is not None:
+            z = z + torch.from_numpy(alpha * interpolation).float().to(current_device)
+        return self.decode(z)

@@ -648,16 +648,17 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float v = vals[e];
-          if (g.scale) v *= g.scale[col + e];
-          if (g.shift) v += g.shift[col + e];
+          if (g.scale && col + e < g.Ncols) v *= g.scale[col + e];
+          if (g.shift && col + e < g.Ncols) v += g.shift[col + e];
           vals[e] = lrelu_f(v, g.slope);
         }
-        if ((g.ldc & 3) == 0) {          // rows 16-byte aligned: two 16-byte stores
+        if ((g.ldc & 3) == 0 && col + 8 <= g.ldc) {          // rows 16-byte aligned: two 16-byte stores
           *reinterpret_cast<float4*>(yo) = make_float4(vals[0], vals[1], vals[2], vals[3]);
           *reinterpret_cast<float4*>(yo + 4) = make_float4(vals[4], vals[5], vals[6], vals[7]);
-        } else {
+        } else {                                             // ragged row end (Ncols % 8 != 0) / unaligned rows
 #pragma unroll
-          for (int e = 0; e < 8; ++e) yo[e] = vals[e];
+          for (int e = 0; e < 8; ++e)
+            if (col + e < g.Ncols) yo[e] = vals[e];
         }
       }
     }
@@ -1223,6 +1224,7 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   int nsplit = pl.nsplit;
   size_t need = (size_t)nsplit * rows_out * (EPI == EPI_BF16 ? g.Ncols : g.ldc) * sizeof(float);
   if (nsplit > 1 && (!ws || ws_bytes < need)) nsplit = 1;
+  if (EPI == EPI_LINEAR && (g.Ncols % 8 != 0 || g.ldc % 4 != 0)) nsplit = 1;      // slab rows are written 8 wide
   a2.a_bytes = (unsigned)a_bytes; a2.b_bytes = (unsigned)b_bytes;
   a2.nsplit = nsplit; a2.slab = (float*)ws; a2.slab_stride = rows_out * (EPI == EPI_BF16 ? g.Ncols : g.ldc);
   const int bn = narrow ? 64 : wide ? 256 : 128, bmm = (narrow || wide) ? 256 : 128;
@@ -1307,7 +1309,10 @@ size_t rg_mfma_linear_ws_bytes(int M, int Kpad, int Nout) {
 
 int rg_mfma_linear(const void* a, const void* bt, const float* scale, const float* shift, float* y, int ldy, int M,
                    int Kpad, int Nout, float slope, void* ws, size_t ws_bytes, hipStream_t st) {
-  RG_REQUIRE(Kpad % 64 == 0 && Nout % 8 == 0, RG_EUNSUPPORTED, "linear(mfma): K_pad %% 64 and Nout %% 8 required");
+  RG_REQUIRE(Kpad % 64 == 0, RG_EUNSUPPORTED, "linear(mfma): K_pad %% 64 required");
+  // ragged widths (Nout % 8 != 0) are an epilogue feature of the LDS-DMA kernel only (operands below 2 GB)
+  RG_REQUIRE(Nout % 8 == 0 || (!use_v1() && (size_t)M * Kpad * 2 < 0x7fffff00ull && (size_t)Nout * Kpad * 2 < 0x7fffff00ull),
+             RG_EUNSUPPORTED, "linear(mfma): Nout %% 8 required for operands of 2 GB and more");
   GArgs g{};
   g.A = (const uint16_t*)a; g.B = (const uint16_t*)bt; g.C = y;
   g.M = M; g.Ncols = Nout; g.Cin = Kpad; g.taps = 1; g.lgW = 0; g.lgH = 0; g.Hs = 1; g.Ws = 1; g.ldc = ldy; g.b_col = Kpad; g.b_tap = 0;

@@ -70,8 +70,9 @@ struct Clamp {
   __device__ void one(size_t i) const { p[i] = fminf(fmaxf(p[i], lo), hi); }
 };
 struct Adam {
-  float* p; const float* g; float* m; float* v; float b1, b2, omb1, omb2, eps, step_size, inv_sqrt_bc2;
+  float* p; const float* g; float* m; float* v; float b1, b2, omb1, omb2, eps, step_size, inv_sqrt_bc2, wd;
   __device__ __forceinline__ void upd(float& pp, float gg, float& mm, float& vv) const {
+    if (wd != 0.f) gg += wd * pp;               // torch.optim.Adam weight_decay (L2 on the gradient); betaVAE training
     // torch.optim.Adam (single-tensor path): m = b1*m + (1-b1)g ; v = b2*v + (1-b2)g^2 ;
     // denom = sqrt(v)/sqrt(bc2) + eps ; p -= (lr/bc1) * m/denom
     // (1-beta) is rounded from double like torch's python-side `1 - beta2`; lerp form for m as torch
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
                                                        float* __restrict__ m, float* __restrict__ v,
                                                        const float* __restrict__ hyper, uint16_t* __restrict__ shadow,
                                                        const uint16_t* __restrict__ gw, size_t n) {
-  const Adam a{p, g, m, v, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6]};
+  const Adam a{p, g, m, v, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6], hyper[7]};
   const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x;
   for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
     const size_t i = q * 4;
@@ -132,7 +133,8 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
   }
 }
 
-__global__ void adam_hyper_kernel(int* step_dev, double lr, double b1, double b2, double eps, float* hyper) {
+__global__ void adam_hyper_kernel(int* step_dev, double lr, double b1, double b2, double eps, double wd, float* hyper) {
+  hyper[7] = (float)wd;
   int step = *step_dev + 1;
   *step_dev = step;
   double bc1 = 1.0 - pow(b1, (double)step);
@@ -390,10 +392,11 @@ extern "C" int rg_adam_step_dev(float* p, const float* g, float* m, float* v, si
   RG_LAUNCH_CHECK("adam_step_dev");
   return RG_OK;
 }
-extern "C" int rg_adam_hyper_dev(int* step_dev, double lr, double beta1, double beta2, double eps, float* hyper,
-                                 void* stream) {
+extern "C" int rg_adam_hyper_dev(int* step_dev, double lr, double beta1, double beta2, double eps, double weight_decay,
+                                 float* hyper, void* stream) {
   RG_REQUIRE(step_dev && hyper, RG_EINVAL, "adam_hyper_dev: bad args");
-  hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(1), 0, rg_stream(stream), step_dev, lr, beta1, beta2, eps, hyper);
+  hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(1), 0, rg_stream(stream), step_dev, lr, beta1, beta2, eps, weight_decay,
+                     hyper);
   RG_LAUNCH_CHECK("adam_hyper_dev");
   return RG_OK;
 }

@@ -21,9 +21,9 @@ from ._abi import check
 
 class Adam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **kw):
-        if weight_decay != 0 or amsgrad:
-            raise NotImplementedError("rna_gan_amd.optim.Adam: weight_decay/amsgrad are not on the RNA-GAN path")
-        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False,
+        if amsgrad:
+            raise NotImplementedError("rna_gan_amd.optim.Adam: amsgrad is not on the RNA-GAN path")
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False,
                          foreach=False, fused=False)
         self._module = None
         self._m = None
@@ -95,7 +95,8 @@ class Adam(torch.optim.Adam):
         lib = _abi.load()
         stream = torch.cuda.current_stream(flat.data.device).cuda_stream
         check(lib.rg_adam_hyper_dev(self._step_dev.data_ptr(), float(g["lr"]), float(g["betas"][0]),
-                                    float(g["betas"][1]), float(g["eps"]), self._hyper.data_ptr(), stream),
+                                    float(g["betas"][1]), float(g["eps"]), float(g.get("weight_decay", 0.0)),
+                                    self._hyper.data_ptr(), stream),
               "rg_adam_hyper_dev")
         shadow = flat.shadow           # bf16 image of the parameters (bf16 precision only), written by the same launch
         check(lib.rg_adam_step_dev(flat.data.data_ptr(), flat.grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),

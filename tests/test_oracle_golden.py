@@ -146,3 +146,56 @@ def test_f6_manifests(golden_dir):
     assert sum(int(np.prod(s)) for k, s in ref_bv.items() if "num_batches" not in k and "running" not in k) == 303238046
     q = mf["loss_ctor_quirks"]
     assert q["reduction_is_path"] and q["override_train_ops"] == 64 and q["lambd"] == 10.0 and q["clip_none"]
+
+
+VAE_CFG = dict(features=70, z=16, enc=[48, 32, 16], dec=[32, 48], beta=2.0, batch=12, lr=3e-3, weight_decay=1e-4)
+
+
+def vae_fixture_model():
+    c = VAE_CFG
+    m = R.seeded_fill_(R.OracleBetaVAE(c["features"], c["z"], c["enc"], c["dec"], beta=c["beta"]), 21)
+    x = R.synthetic_rna(c["batch"], c["features"], seed=22, distinct=c["batch"])
+    return m, x
+
+
+# Linear biases in front of a BatchNorm have a mathematically ZERO gradient (the batch mean is subtracted again); what
+# autograd returns is rounding noise (~1e-9) and Adam normalises it to a full-size step of +-lr in a direction that
+# depends on summation order.  They are compared through Adam's step bound instead of value by value.
+VAE_DEAD_BIASES = ("encoder.encoder.1.0.bias", "encoder.encoder.2.0.bias", "encoder.encoder.3.0.bias",
+                   "decoder.0.0.bias", "decoder.1.0.bias")
+
+
+def check_vae_state_after_step(sd, g, rtol, atol):
+    for k in g.files:
+        if not k.startswith("after."):
+            continue
+        name = k[6:]
+        got = sd[name].detach().cpu().numpy()
+        if name in VAE_DEAD_BIASES:
+            assert np.abs(got - g[k]).max() <= 2.02 * VAE_CFG["lr"], name
+        else:
+            np.testing.assert_allclose(got, g[k], rtol=rtol, atol=atol, err_msg=k)
+
+
+def test_f7_vae_training_step(golden_dir):
+    """betaVAE training row: the oracle's forward / betaVAEloss / backward / Adam(weight_decay) step and
+    the eval-mode forward against the reference's own run (tests/golden/make_vae_train_fixture.py)."""
+    g = np.load(os.path.join(golden_dir, "f7_vae_train.npz"))
+    c = VAE_CFG
+    m, x = vae_fixture_model()
+    opt = torch.optim.Adam(m.parameters(), weight_decay=c["weight_decay"], lr=c["lr"])
+    out, mu, lv, losses = R.oracle_vae_train_step(m, opt, x, torch.from_numpy(g["train.mask"]), torch.from_numpy(g["train.eps"]))
+    for name, t in (("out", out), ("z_mean", mu), ("z_log_var", lv)):
+        np.testing.assert_allclose(t.numpy(), g["train." + name], rtol=1e-5, atol=1e-6, err_msg=name)
+    for k, v in losses.items():
+        np.testing.assert_allclose(float(v), float(g["train." + k]), rtol=1e-5, err_msg=k)
+    check_vae_state_after_step(m.state_dict(), g, rtol=1e-5, atol=1e-6)
+    # eval forward from the reference's own post-step state (in eval mode the dead biases are no longer cancelled)
+    m.load_state_dict({k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("after.")})
+    m.eval()
+    with torch.no_grad():
+        out, mu, lv = m.forward_with(x, None, torch.from_numpy(g["eval.eps"]))
+        losses = R.oracle_vae_loss(x, out, mu, lv, m.beta, training=False)
+    np.testing.assert_allclose(out.numpy(), g["eval.out"], rtol=1e-5, atol=1e-6)
+    for k, v in losses.items():
+        np.testing.assert_allclose(float(v), float(g["eval." + k]), rtol=1e-5, err_msg=k)
