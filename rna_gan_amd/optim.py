@@ -80,8 +80,10 @@ class Adam(torch.optim.Adam):
         self._flat_id = None      # re-home the loaded moments into the flat buffers at next use
 
     def zero_grad(self, set_to_none: bool = False):
-        # gradients are written (not accumulated) by the first backward of every step; keep the views
-        if self._module is not None:
+        # gradients are written (not accumulated) by the first backward of every step; the views are kept.
+        # set_to_none=True (train_betaVAE's call, src/betaVAE.py:221) asks for "no stale gradient", which the
+        # overwrite semantics already give: no 4 B/parameter memset
+        if self._module is not None and not set_to_none:
             self._module.flat.grad.zero_()
 
     def note_replayed(self):
