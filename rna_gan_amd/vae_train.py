@@ -310,15 +310,20 @@ def vae_forward(model, x):
         mask = mask.to(device=x.device, dtype=torch.uint8).contiguous()
         model.flat_params()                                   # parameters / gradients live in the flat buffers
         if torch.is_grad_enabled():
-            return _VaeForwardFn.apply(x, model.z_mu.bias, model, mask, eps.to(x.device))
-        sv = rt.forward_train(x, mask, eps.to(x.device))
-        return sv.out[:, :x.shape[1]], sv.mu, sv.lv
+            out, mu, lv = _VaeForwardFn.apply(x, model.z_mu.bias, model, mask, eps.to(x.device))
+        else:
+            sv = rt.forward_train(x, mask, eps.to(x.device))
+            out, mu, lv = sv.out[:, :x.shape[1]], sv.mu, sv.lv
+        out._vae_rt = rt                                      # betaVAEloss picks the model's runtime up from here
+        return out, mu, lv
     z_mean, z_log_var, _ = model.encode(x)
     z = torch.empty_like(z_mean)
     e = eps.to(x.device).contiguous().float()
     check(rt.lib.rg_vae_reparam(_ptr(z_mean), _ptr(z_log_var), _ptr(e), _ptr(z), z.numel(), rt.ops.stream),
           "rg_vae_reparam")
-    return rt.decode_eval(z)[:, :x.shape[1]], z_mean, z_log_var
+    out = rt.decode_eval(z)[:, :x.shape[1]]
+    out._vae_rt = rt
+    return out, z_mean, z_log_var
 
 
 # --------------------------------------------------------------------------------------------------------------
