@@ -13,7 +13,7 @@ namespace {
 struct Plan { int vec, tx, gx, gy, rows_per_block; };
 
 template <typename T>
-static Plan make_plan(int M, int C, int target_blocks) {
+static Plan make_plan(int M, int C, int target_blocks, int gy_cap = 512) {
   Plan p;
   const int vmax = sizeof(T) == 2 ? 8 : 4;
   p.vec = (C % vmax == 0) ? vmax : (C % 4 == 0 ? 4 : 1);
@@ -25,7 +25,7 @@ static Plan make_plan(int M, int C, int target_blocks) {
   int maxg = (M + 4 * ty - 1) / (4 * ty);
   p.gy = want < maxg ? want : maxg;
   if (p.gy < 1) p.gy = 1;
-  if (p.gy > 512) p.gy = 512;
+  if (p.gy > gy_cap) p.gy = gy_cap;
   p.rows_per_block = (M + p.gy - 1) / p.gy;
   p.gy = (M + p.rows_per_block - 1) / p.rows_per_block;
   return p;
@@ -53,7 +53,16 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(F f, int M, int C, int r
   const int r1 = min(M, r0 + rows_per_block);
   if (c < C) {
     f.init(c);
-    for (int r = r0 + ty; r < r1; r += TY) f.row(r, c, acc);
+    constexpr int U = F::U;                                       // rows in flight per thread (see rowapply_kernel)
+    int r = r0 + ty;
+    for (; r + (U - 1) * TY < r1; r += U * TY) {
+      typename F::In in[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) f.load(r + k * TY, c, in[k]);
+#pragma unroll
+      for (int k = 0; k < U; ++k) f.accum(in[k], acc);
+    }
+    for (; r < r1; r += TY) f.row(r, c, acc);
   }
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
@@ -152,17 +161,28 @@ struct SliceFin {
   }
 };
 
-// ---- pointwise skeleton: F has  init(c)  and  row(r, c)
+// ---- pointwise skeleton: F has  init(c),  load(r, c, In&)  and  finish(r, c, const In&)  (row = load + finish).
+// F::U rows are in flight per thread: all their loads are issued before the first store, so that a thread keeps
+// U x (inputs) x 16 bytes outstanding -- with one row at a time the kernels sat at ~3.7 TB/s, latency-bound (the
+// compiler cannot hoist the next row's loads over the previous row's store: the pointers may alias).
 template <int VEC, int TX, class F>
 __global__ __launch_bounds__(256) void rowapply_kernel(F f, int M, int C, int rows_per_block) {
-  constexpr int TY = 256 / TX;
+  constexpr int TY = 256 / TX, U = F::U;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int c = (blockIdx.x * TX + tx) * VEC;
   if (c >= C) return;
   const int r0 = blockIdx.y * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
   f.init(c);
-  for (int r = r0 + ty; r < r1; r += TY) f.row(r, c);
+  int r = r0 + ty;
+  for (; r + (U - 1) * TY < r1; r += U * TY) {
+    typename F::In in[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) f.load(r + k * TY, c, in[k]);
+#pragma unroll
+    for (int k = 0; k < U; ++k) f.finish(r + k * TY, c, in[k]);
+  }
+  for (; r < r1; r += TY) f.row(r, c);
 }
 
 template <int NQ, typename T, template <typename, int> class F, class Fin, class... Args>
@@ -189,7 +209,7 @@ int row_reduce(const char* name, int M, int C, void* ws, size_t ws_bytes, hipStr
 
 template <typename T, template <typename, int> class F, class... Args>
 int row_apply(const char* name, int M, int C, hipStream_t st, Args... args) {
-  Plan p = make_plan<T>(M, C, 4096);
+  Plan p = make_plan<T>(M, C, 4096, 8192);      // no partial rows behind an apply pass: as many blocks as the target asks
   dim3 grid(p.gx, p.gy);
 #define RG_RA(V, X)                                                                                   \
   do {                                                                                                \
@@ -277,12 +297,14 @@ template <int VEC> struct BNR {
 template <typename T, int VEC> struct StatsF {
   const T* z; int C;
   __device__ void init(int) {}
-  __device__ void row(int r, int c, float (*acc)[VEC]) const {
-    float v[VEC];
-    Vec<T, VEC>::ld(z + (size_t)r * C + c, v);
+  static constexpr int U = 4;
+  struct In { float v[VEC]; };
+  __device__ __forceinline__ void load(int r, int c, In& in) const { Vec<T, VEC>::ld(z + (size_t)r * C + c, in.v); }
+  __device__ __forceinline__ void accum(const In& in, float (*acc)[VEC]) const {
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) { acc[0][i] += v[i]; acc[1][i] += v[i] * v[i]; }
+    for (int i = 0; i < VEC; ++i) { acc[0][i] += in.v[i]; acc[1][i] += in.v[i] * in.v[i]; }
   }
+  __device__ void row(int r, int c, float (*acc)[VEC]) const { In in; load(r, c, in); accum(in, acc); }
 };
 struct Store2Fin {
   float* a; float* b;
@@ -312,14 +334,17 @@ struct StatsFinalizeFin {
 template <typename T, int VEC> struct BnActF {
   const T* z; T* a; BNC p; int C;
   BNR<VEC> q;
+  static constexpr int U = 4;
+  struct In { float v[VEC]; };
   __device__ void init(int c) { q.load(p, c); }
-  __device__ void row(int r, int c) const {
-    float v[VEC], o[VEC];
-    Vec<T, VEC>::ld(z + (size_t)r * C + c, v);
+  __device__ __forceinline__ void load(int r, int c, In& in) const { Vec<T, VEC>::ld(z + (size_t)r * C + c, in.v); }
+  __device__ __forceinline__ void finish(int r, int c, const In& in) const {
+    float o[VEC];
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) o[i] = lrelu_f((v[i] - q.mean[i]) * (q.rstd[i] * q.gam[i]) + q.bet[i], p.slope);
+    for (int i = 0; i < VEC; ++i) o[i] = lrelu_f((in.v[i] - q.mean[i]) * (q.rstd[i] * q.gam[i]) + q.bet[i], p.slope);
     Vec<T, VEC>::st(a + (size_t)r * C + c, o);
   }
+  __device__ void row(int r, int c) const { In in; load(r, c, in); finish(r, c, in); }
 };
 
 // ------------------------------------------------------------------------------------------ bwd
@@ -327,17 +352,21 @@ template <typename T, int VEC> struct BwdRedF {
   const T* z; const T* ga; BNC p; int C;
   BNR<VEC> q;
   __device__ void init(int c) { q.load(p, c); }
-  __device__ void row(int r, int c, float (*acc)[VEC]) const {
-    float v[VEC], g[VEC];
-    Vec<T, VEC>::ld(z + (size_t)r * C + c, v);
-    Vec<T, VEC>::ld(ga + (size_t)r * C + c, g);
+  static constexpr int U = 4;
+  struct In { float v[VEC], g[VEC]; };
+  __device__ __forceinline__ void load(int r, int c, In& in) const {
+    Vec<T, VEC>::ld(z + (size_t)r * C + c, in.v);
+    Vec<T, VEC>::ld(ga + (size_t)r * C + c, in.g);
+  }
+  __device__ __forceinline__ void accum(const In& in, float (*acc)[VEC]) const {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      float xh = (v[i] - q.mean[i]) * q.rstd[i];
-      float gy = g[i] * lrelu_mask(xh * q.gam[i] + q.bet[i], p.slope);
+      float xh = (in.v[i] - q.mean[i]) * q.rstd[i];
+      float gy = in.g[i] * lrelu_mask(xh * q.gam[i] + q.bet[i], p.slope);
       acc[0][i] += gy; acc[1][i] += gy * xh;
     }
   }
+  __device__ void row(int r, int c, float (*acc)[VEC]) const { In in; load(r, c, in); accum(in, acc); }
 };
 struct BwdFin {
   float* s_gy; float* s_gyxh; float* dgamma; float* dbeta; int accumulate;
@@ -357,18 +386,23 @@ template <typename T, int VEC> struct BwdApplyF {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { m1[i] = s_gy[c + i] * inv_m; m2[i] = s_gyxh[c + i] * inv_m; }
   }
-  __device__ void row(int r, int c) const {
-    float v[VEC], g[VEC], o[VEC];
-    Vec<T, VEC>::ld(z + (size_t)r * C + c, v);
-    Vec<T, VEC>::ld(ga + (size_t)r * C + c, g);
+  static constexpr int U = 4;
+  struct In { float v[VEC], g[VEC]; };
+  __device__ __forceinline__ void load(int r, int c, In& in) const {
+    Vec<T, VEC>::ld(z + (size_t)r * C + c, in.v);
+    Vec<T, VEC>::ld(ga + (size_t)r * C + c, in.g);
+  }
+  __device__ __forceinline__ void finish(int r, int c, const In& in) const {
+    float o[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      float xh = (v[i] - q.mean[i]) * q.rstd[i];
-      float gy = g[i] * lrelu_mask(xh * q.gam[i] + q.bet[i], p.slope);
+      float xh = (in.v[i] - q.mean[i]) * q.rstd[i];
+      float gy = in.g[i] * lrelu_mask(xh * q.gam[i] + q.bet[i], p.slope);
       o[i] = (q.gam[i] * q.rstd[i]) * (gy - m1[i] - xh * m2[i]);
     }
     Vec<T, VEC>::st(gz + (size_t)r * C + c, o);
   }
+  __device__ void row(int r, int c) const { In in; load(r, c, in); finish(r, c, in); }
 };
 
 // ------------------------------------------------------------------------------------------ tangent
@@ -376,16 +410,20 @@ template <typename T, int VEC> struct TanRedF {
   const T* z; const T* zt; BNC p; int C;
   BNR<VEC> q;
   __device__ void init(int c) { q.load(p, c); }
-  __device__ void row(int r, int c, float (*acc)[VEC]) const {
-    float v[VEC], t[VEC];
-    Vec<T, VEC>::ld(z + (size_t)r * C + c, v);
-    Vec<T, VEC>::ld(zt + (size_t)r * C + c, t);
+  static constexpr int U = 4;
+  struct In { float v[VEC], t[VEC]; };
+  __device__ __forceinline__ void load(int r, int c, In& in) const {
+    Vec<T, VEC>::ld(z + (size_t)r * C + c, in.v);
+    Vec<T, VEC>::ld(zt + (size_t)r * C + c, in.t);
+  }
+  __device__ __forceinline__ void accum(const In& in, float (*acc)[VEC]) const {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      float xh = (v[i] - q.mean[i]) * q.rstd[i];
-      acc[0][i] += t[i]; acc[1][i] += xh * t[i];
+      float xh = (in.v[i] - q.mean[i]) * q.rstd[i];
+      acc[0][i] += in.t[i]; acc[1][i] += xh * in.t[i];
     }
   }
+  __device__ void row(int r, int c, float (*acc)[VEC]) const { In in; load(r, c, in); accum(in, acc); }
 };
 template <typename T, int VEC> struct TanApplyF {
   const T* z; const T* zt; T* at; BNC p; const float* s_zt; const float* s_xhzt; float inv_m; int C;
@@ -395,18 +433,23 @@ template <typename T, int VEC> struct TanApplyF {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { m1[i] = s_zt[c + i] * inv_m; m2[i] = s_xhzt[c + i] * inv_m; }
   }
-  __device__ void row(int r, int c) const {
-    float v[VEC], t[VEC], o[VEC];
-    Vec<T, VEC>::ld(z + (size_t)r * C + c, v);
-    Vec<T, VEC>::ld(zt + (size_t)r * C + c, t);
+  static constexpr int U = 4;
+  struct In { float v[VEC], t[VEC]; };
+  __device__ __forceinline__ void load(int r, int c, In& in) const {
+    Vec<T, VEC>::ld(z + (size_t)r * C + c, in.v);
+    Vec<T, VEC>::ld(zt + (size_t)r * C + c, in.t);
+  }
+  __device__ __forceinline__ void finish(int r, int c, const In& in) const {
+    float o[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      float xh = (v[i] - q.mean[i]) * q.rstd[i];
-      float yt = (q.gam[i] * q.rstd[i]) * (t[i] - m1[i] - xh * m2[i]);
+      float xh = (in.v[i] - q.mean[i]) * q.rstd[i];
+      float yt = (q.gam[i] * q.rstd[i]) * (in.t[i] - m1[i] - xh * m2[i]);
       o[i] = yt * lrelu_mask(xh * q.gam[i] + q.bet[i], p.slope);
     }
     Vec<T, VEC>::st(at + (size_t)r * C + c, o);
   }
+  __device__ void row(int r, int c) const { In in; load(r, c, in); finish(r, c, in); }
 };
 
 // ------------------------------------------------------------------------------------------ double bwd
@@ -414,20 +457,24 @@ template <typename T, int VEC> struct DblRedF {
   const T* z; const T* qa; const T* zt; const T* ga1; BNC p; int C;
   BNR<VEC> q;
   __device__ void init(int c) { q.load(p, c); }
-  __device__ void row(int r, int c, float (*acc)[VEC]) const {
-    float v[VEC], t[VEC], g[VEC], qq[VEC];
-    Vec<T, VEC>::ld(z + (size_t)r * C + c, v);
-    Vec<T, VEC>::ld(zt + (size_t)r * C + c, t);
-    Vec<T, VEC>::ld(ga1 + (size_t)r * C + c, g);
-    if (qa) Vec<T, VEC>::ld(qa + (size_t)r * C + c, qq);
+  static constexpr int U = 2;
+  struct In { float v[VEC], t[VEC], g[VEC], qq[VEC]; };
+  __device__ __forceinline__ void load(int r, int c, In& in) const {
+    Vec<T, VEC>::ld(z + (size_t)r * C + c, in.v);
+    Vec<T, VEC>::ld(zt + (size_t)r * C + c, in.t);
+    Vec<T, VEC>::ld(ga1 + (size_t)r * C + c, in.g);
+    if (qa) Vec<T, VEC>::ld(qa + (size_t)r * C + c, in.qq);
+  }
+  __device__ __forceinline__ void accum(const In& in, float (*acc)[VEC]) const {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
-      float xh = (v[i] - q.mean[i]) * q.rstd[i];
+      float xh = (in.v[i] - q.mean[i]) * q.rstd[i];
       float mk = lrelu_mask(xh * q.gam[i] + q.bet[i], p.slope);
-      acc[0][i] += g[i] * mk * t[i];
-      if (qa) { float qy = qq[i] * mk; acc[1][i] += qy; acc[2][i] += qy * xh; }
+      acc[0][i] += in.g[i] * mk * in.t[i];
+      if (qa) { float qy = in.qq[i] * mk; acc[1][i] += qy; acc[2][i] += qy * xh; }
     }
   }
+  __device__ void row(int r, int c, float (*acc)[VEC]) const { In in; load(r, c, in); accum(in, acc); }
 };
 // per-channel coefficients for the apply pass: coef[0]=A-3bc, [1]=c, [2]=b, [3]=s_qy/m, [4]=s_qyxh/m
 struct DblFin {
@@ -461,25 +508,30 @@ template <typename T, int VEC> struct DblApplyF {
       mgy[i] = s_gy[c + i] * inv_m; mzt[i] = s_zt[c + i] * inv_m;
     }
   }
-  __device__ void row(int r, int c) const {
-    float v[VEC], t[VEC], g[VEC], qq[VEC], o[VEC];
-    Vec<T, VEC>::ld(z + (size_t)r * C + c, v);
-    Vec<T, VEC>::ld(zt + (size_t)r * C + c, t);
-    Vec<T, VEC>::ld(ga1 + (size_t)r * C + c, g);
-    if (qa) Vec<T, VEC>::ld(qa + (size_t)r * C + c, qq);
+  static constexpr int U = 2;
+  struct In { float v[VEC], t[VEC], g[VEC], qq[VEC]; };
+  __device__ __forceinline__ void load(int r, int c, In& in) const {
+    Vec<T, VEC>::ld(z + (size_t)r * C + c, in.v);
+    Vec<T, VEC>::ld(zt + (size_t)r * C + c, in.t);
+    Vec<T, VEC>::ld(ga1 + (size_t)r * C + c, in.g);
+    if (qa) Vec<T, VEC>::ld(qa + (size_t)r * C + c, in.qq);
+  }
+  __device__ __forceinline__ void finish(int r, int c, const In& in) const {
+    float o[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       float is = q.rstd[i], gm = q.gam[i];
-      float xh = (v[i] - q.mean[i]) * is;
+      float xh = (in.v[i] - q.mean[i]) * is;
       float mk = lrelu_mask(xh * gm + q.bet[i], p.slope);
-      float gy = g[i] * mk;
-      float r0 = xh * k0[i] + k1[i] * (gy - mgy[i]) + k2[i] * (t[i] - mzt[i]);
+      float gy = in.g[i] * mk;
+      float r0 = xh * k0[i] + k1[i] * (gy - mgy[i]) + k2[i] * (in.t[i] - mzt[i]);
       float out = -(gm * is * is) * r0;
-      if (qa) out += (gm * is) * (qq[i] * mk - k3[i] - xh * k4[i]);
+      if (qa) out += (gm * is) * (in.qq[i] * mk - k3[i] - xh * k4[i]);
       o[i] = out;
     }
     Vec<T, VEC>::st(pz + (size_t)r * C + c, o);
   }
+  __device__ void row(int r, int c) const { In in; load(r, c, in); finish(r, c, in); }
 };
 
 // ---- split forms (synchronised statistics): raw sums out / finish from all-reduced sums
@@ -513,12 +565,14 @@ struct DblFinSync {
 template <typename T, int VEC> struct ColSumF {
   const T* g; int C;
   __device__ void init(int) {}
-  __device__ void row(int r, int c, float (*acc)[VEC]) const {
-    float v[VEC];
-    Vec<T, VEC>::ld(g + (size_t)r * C + c, v);
+  static constexpr int U = 4;
+  struct In { float v[VEC]; };
+  __device__ __forceinline__ void load(int r, int c, In& in) const { Vec<T, VEC>::ld(g + (size_t)r * C + c, in.v); }
+  __device__ __forceinline__ void accum(const In& in, float (*acc)[VEC]) const {
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) acc[0][i] += v[i];
+    for (int i = 0; i < VEC; ++i) acc[0][i] += in.v[i];
   }
+  __device__ void row(int r, int c, float (*acc)[VEC]) const { In in; load(r, c, in); accum(in, acc); }
 };
 struct AccFin {
   float* out; int accumulate;
