@@ -1241,6 +1241,7 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
     grid = dim3(grid.x * 4, 1, nsplit);
   }
   a2.xcd_swizzle = (xcd && grid.x % 8 == 0 && grid.x >= 16 && (xcd == 2 || a_bytes > b_bytes)) ? 1 : 0;
+  // (measured and rejected for the 64-column tile: 2 waves with 128 x 64 wave tiles, 147-154 us vs 109-112 us)
   if (narrow) {
     hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 256, 64, 2, 256>), grid, dim3(256), 0, st, a2);
   } else if (wide) {
