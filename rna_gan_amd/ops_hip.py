@@ -40,6 +40,7 @@ class HipOps:
         # kept alive until join() so the caching allocator cannot hand their memory to the main stream early
         self.side_stream = None
         self._wsbuf_side = None
+        self._ws_retired = []
         self._in_side = False
         self._keep = []
         self.use_side = os.environ.get("RNAGAN_SIDE_STREAM", "0") != "0"
@@ -56,12 +57,18 @@ class HipOps:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def _ws(self, nbytes: int):
+        """Caller-owned workspace of the C ABI calls.  A buffer that is outgrown is RETIRED, not freed: captured HIP
+        graphs replay launches that hold its address (growth is geometric, so the retired list stays short)."""
         nbytes = max(int(nbytes), 256)
         if self._in_side:
             if self._wsbuf_side is None or self._wsbuf_side.numel() < nbytes:
+                if self._wsbuf_side is not None:
+                    self._ws_retired.append(self._wsbuf_side)
                 self._wsbuf_side = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
             return self._wsbuf_side
         if self._wsbuf is None or self._wsbuf.numel() < nbytes:
+            if self._wsbuf is not None:
+                self._ws_retired.append(self._wsbuf)
             self._wsbuf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
         return self._wsbuf
 
