@@ -1,0 +1,155 @@
+"""Full-size checks (BASELINE configs[1]: batch 64, the five 4x4 stride-2 layer shapes of the 256x256 model): the kernel
+variants the benchmark actually runs -- 256x256 tiles, parity classes in the block order, XCD remapping, split-K
+plans, direct weight-gradient writes, two-level statistics finishing -- only exist at these sizes, so the small
+parity cases of test_ops_gpu.py never reach them.  Two independent checks per layer, all through the C ABI:
+  * element-wise against the functor (generic) kernels of the same library, which are size-generic and pinned to
+    the oracle at small sizes;
+  * the size-independent adjoint identities of a convolution, per sample and per output channel:
+        <conv_down(x; w), g>_n = <x, conv_up(g; w)>_n        <conv_down(x; w), g>_o = <wgrad(g, x), w>_o
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from rna_gan_amd import _abi
+from rna_gan_amd.engine import ConvW
+from rna_gan_amd.ops_hip import HipOps
+
+N = 64
+LAYERS = [(64, 128, 128), (128, 256, 64), (256, 512, 32), (512, 1024, 16), (1024, 2048, 8)]      # I, O, input size
+
+
+def relmax(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize("I,O,hs", LAYERS)
+def test_conv_layers_full_size(I, O, hs):
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(100 + I)
+    mf = HipOps(torch.bfloat16, dev, algo=_abi.ALGO_AUTO)
+    ge = HipOps(torch.bfloat16, dev, algo=_abi.ALGO_GENERIC)
+    w = (torch.randn(O, 4, 4, I, generator=gen) * (2.0 / (I * 16)) ** 0.5).bfloat16().float().to(dev)   # bf16-exact masters
+    cw_m = ConvW(w.clone(), None, torch.full_like(w, 3.0), None, "OHWI")
+    cw_g = ConvW(w.clone(), None, torch.zeros_like(w), None, "OHWI")
+    x = torch.randn(N, hs, hs, I, generator=gen).bfloat16().to(dev)
+    g = torch.randn(N, hs // 2, hs // 2, O, generator=gen).bfloat16().to(dev)
+
+    y, st = mf.conv_down(x, cw_m, want_stats=True)
+    assert relmax(y, ge.conv_down(x, cw_g)) < 8e-3
+    mask = torch.randn(N, hs, hs, I, generator=gen).bfloat16().to(dev)
+    u = mf.conv_up(g, cw_m)
+    assert relmax(u, ge.conv_up(g, cw_g)) < 8e-3
+    assert relmax(mf.conv_up(g, cw_m, mask, 0.2), ge.conv_up(g, cw_g, mask, 0.2)) < 8e-3
+    mf.conv_wgrad(g, x, cw_m, False)
+    ge.conv_wgrad(g, x, cw_g, False)
+    assert relmax(cw_m.dw, cw_g.dw) < 2e-3
+    dw1 = cw_m.dw.clone()
+    g2, x2 = g.flip(0).contiguous(), x.flip(0).contiguous()          # second segment: the same pairs in another order
+    mf.conv_wgrad2(g, x, g2, x2, cw_m, True)
+    assert relmax(cw_m.dw, 3 * dw1) < 2e-3
+
+    # epilogue statistics (when this launch produces them): exact column sums of what was stored
+    if st is not None:
+        yf = y.float().reshape(-1, O)
+        assert relmax(st[:, 0, :].sum(0), yf.sum(0)) < 2e-3 and relmax(st[:, 1, :].sum(0), (yf * yf).sum(0)) < 1e-4
+
+    # adjoint identities in fp64 from the stored tensors
+    yd, gd, xd, ud, wd = y.double(), g.double(), x.double(), u.double(), w.double()
+    lhs_n = (yd * gd).sum(dim=(1, 2, 3))
+    rhs_n = (xd * ud).sum(dim=(1, 2, 3))
+    scale_n = float((yd * gd).abs().sum(dim=(1, 2, 3)).mean())
+    assert float((lhs_n - rhs_n).abs().max()) < 1e-3 * scale_n, "per-sample <conv_down x, g> = <x, conv_up g>"
+    lhs_o = (yd * gd).sum(dim=(0, 1, 2))
+    rhs_o = (dw1.double() * wd).sum(dim=(1, 2, 3))
+    scale_o = float((yd * gd).abs().sum(dim=(0, 1, 2)).mean())
+    assert float((lhs_o - rhs_o).abs().max()) < 1e-3 * scale_o, "per-channel <conv_down x, g> = <wgrad(g, x), w>"
+
+
+@pytest.mark.parametrize("M,C", [(64 * 128 * 128, 64), (64 * 64 * 64, 128), (64 * 32 * 32, 256), (64 * 4 * 4, 2048)])
+def test_batchnorm_full_size(M, C):
+    """BatchNorm + LeakyReLU forward / backward on the benchmark's row counts against plain fp32 tensor arithmetic on the
+    same device (checker only)."""
+    dev = torch.device("cuda:0")
+    ops = HipOps(torch.bfloat16, dev)
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    z = (torch.randn(M, C, generator=gen) * 1.5 + 0.3).bfloat16().to(dev).view(1, M, 1, C)
+    ga = torch.randn(M, C, generator=gen).bfloat16().to(dev).view(1, M, 1, C)
+    gam, bet = (1 + 0.1 * torch.randn(C, generator=gen)).to(dev), (0.1 * torch.randn(C, generator=gen)).to(dev)
+    a, mean, invstd = ops.bn_forward(z, gam, bet, 0.2, 1e-5, 0.1)
+    zf = z.float().view(M, C)
+    mu, var = zf.mean(0), zf.var(0, unbiased=False)
+    assert relmax(mean, mu) < 1e-4 and relmax(invstd, torch.rsqrt(var + 1e-5)) < 1e-4
+    xh = (zf - mu) * torch.rsqrt(var + 1e-5)
+    pre = xh * gam + bet
+    assert relmax(a.view(M, C), torch.where(pre > 0, pre, 0.2 * pre)) < 8e-3
+    gz, s_gy, s_gyxh = ops.bn_act_bwd(z, ga, mean, invstd, gam, bet, 0.2)
+    gy = ga.float().view(M, C) * torch.where(pre > 0, 1.0, 0.2)
+    assert relmax(s_gy, gy.sum(0)) < 2e-3 and relmax(s_gyxh, (gy * xh).sum(0)) < 2e-3
+    ref = gam * torch.rsqrt(var + 1e-5) * (gy - gy.mean(0) - xh * (gy * xh).mean(0))
+    assert relmax(gz.view(M, C), ref) < 8e-3
+
+
+def test_image_side_layers_full_size():
+    """The three row-staged image-side kernels at 64 x 3 x 256 x 256 (first_down, last_up, skinny weight gradient share
+    ONE weight array: Conv2d(3, 64) and ConvTranspose2d(64, 3) are adjoint for the same [64][3][4][4] values):
+        <first_down(x), g>_n = <x, last_up(g)>_n        <first_down(x), g>_o = <skinny_wgrad(g, x), w>_o
+    plus a direct check of first_down on a crop (border rows/columns and an interior window) in fp64."""
+    dev = torch.device("cuda:0")
+    ops = HipOps(torch.bfloat16, dev)
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    O, I, S = 64, 3, 256
+    w = (torch.randn(O, I, 4, 4, generator=gen) * 0.2).bfloat16().float().to(dev)
+    cw = ConvW(w, None)
+    x = torch.randn(N, I, S, S, generator=gen).bfloat16().float().to(dev)            # bf16-exact image
+    g = torch.randn(N, S // 2, S // 2, O, generator=gen).bfloat16().to(dev)
+    y = ops.first_down(x, cw, None, 1.0)                                             # slope 1: the bare convolution
+    u = ops.last_up(g, cw, None, False)
+    dw = torch.zeros(O, I, 4, 4, device=dev)
+    ops.skinny_wgrad(g, x, dw, False)
+    yd, gd = y.double(), g.double()
+    lhs_n, rhs_n = (yd * gd).sum(dim=(1, 2, 3)), (x.double() * u.double()).sum(dim=(1, 2, 3))
+    scale_n = float((yd * gd).abs().sum(dim=(1, 2, 3)).mean())
+    assert float((lhs_n - rhs_n).abs().max()) < 1e-3 * scale_n
+    lhs_o, rhs_o = (yd * gd).sum(dim=(0, 1, 2)), (dw.double() * w.double()).sum(dim=(1, 2, 3))
+    scale_o = float((yd * gd).abs().sum(dim=(0, 1, 2)).mean())
+    assert float((lhs_o - rhs_o).abs().max()) < 1e-3 * scale_o
+    # direct fp64 evaluation of y[n, ho, wo, :] at the four corners and an interior point of three samples
+    xp = torch.nn.functional.pad(x.double(), (1, 1, 1, 1))
+    for n in (0, 31, 63):
+        for ho, wo in ((0, 0), (0, 127), (127, 0), (127, 127), (60, 77)):
+            patch = xp[n, :, 2 * ho:2 * ho + 4, 2 * wo:2 * wo + 4]                   # [3][4][4]
+            ref = (w.double() * patch).sum(dim=(1, 2, 3))
+            assert float((y[n, ho, wo].double() - ref).abs().max()) < 8e-3 * float(ref.abs().max() + 1.0)
+
+
+def test_g0_and_head_full_size():
+    """G.0 (ConvTranspose2d(2048, 2048, 4) on a 1x1 input = a [64 x 2048] . [2048 x 32768] GEMM), its rank-64 weight
+    gradient (268 MB fp32 output) and the discriminator head at the benchmark's sizes: element-wise against the generic
+    kernels, plus <g0_fwd(z), gy> = <g0_wgrad(z, gy), w> per latent dimension."""
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(13)
+    E = C = 2048
+    mf = HipOps(torch.bfloat16, dev, algo=_abi.ALGO_AUTO)
+    ge = HipOps(torch.bfloat16, dev, algo=_abi.ALGO_GENERIC)
+    w = (torch.randn(E, C, 4, 4, generator=gen) * (1.0 / E) ** 0.5).bfloat16().float().to(dev)
+    z = torch.randn(N, E, generator=gen).bfloat16().float().to(dev)
+    gy = torch.randn(N, 4, 4, C, generator=gen).bfloat16().to(dev)
+    y = mf.g0_fwd(z, ConvW(w, None))
+    assert relmax(y, ge.g0_fwd(z, ConvW(w, None))) < 8e-3
+    dw, dw_g = torch.full_like(w, 2.0), torch.zeros_like(w)
+    mf.g0_wgrad(z, gy, dw, False)
+    ge.g0_wgrad(z, gy, dw_g, False)
+    assert relmax(dw, dw_g) < 2e-3
+    lhs = (y.double() * gy.double()).sum()
+    rhs = (dw.double() * w.double()).sum()
+    assert abs(float(lhs - rhs)) < 1e-3 * float((y.double() * gy.double()).abs().sum()) ** 0.5 * 50
+    # head: 4x4 valid conv over [64][4][4][2048] -> (64,)
+    a = torch.randn(N, 4, 4, C, generator=gen).bfloat16().to(dev)
+    wh = (torch.randn(1, C, 4, 4, generator=gen) * 0.01).to(dev)
+    h, out = mf.head_fwd(a, ConvW(wh, None), 0.2)
+    ref = (a.double().permute(0, 3, 1, 2) * wh.double()).sum(dim=(1, 2, 3))
+    assert relmax(h, ref.float()) < 2e-3 and relmax(out, torch.where(ref > 0, ref, 0.2 * ref).float()) < 2e-3
