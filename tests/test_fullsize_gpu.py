@@ -153,3 +153,41 @@ def test_g0_and_head_full_size():
     h, out = mf.head_fwd(a, ConvW(wh, None), 0.2)
     ref = (a.double().permute(0, 3, 1, 2) * wh.double()).sum(dim=(1, 2, 3))
     assert relmax(h, ref.float()) < 2e-3 and relmax(out, torch.where(ref > 0, ref, 0.2 * ref).float()) < 2e-3
+
+
+@pytest.mark.parametrize("H,Cin,Cout", [(4, 1024, 512), (16, 256, 128), (64, 64, 64)])
+def test_resize_convolution_full_size(H, Cin, Cout):
+    """DCGANUpGenerator's blocks at batch 64: matrix-core forward / data gradient / weight gradient against the functor
+    kernels (which interpolate the padded upsampled image inside their operand functors: an independent formulation)."""
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(17 + H)
+    mf = HipOps(torch.bfloat16, dev, algo=_abi.ALGO_AUTO)
+    ge = HipOps(torch.bfloat16, dev, algo=_abi.ALGO_GENERIC)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=gen) * (2.0 / (9 * Cin)) ** 0.5).to(dev)
+    b = (torch.randn(Cout, generator=gen) * 0.1).to(dev)
+    x = torch.randn(N, H, H, Cin, generator=gen).bfloat16().to(dev)
+    gy = torch.randn(N, 2 * H, 2 * H, Cout, generator=gen).bfloat16().to(dev)
+    cm, cg = ConvW(w, b, torch.full_like(w, 5.0)), ConvW(w, b, torch.zeros_like(w))
+    assert relmax(mf.upconv3(x, cm, b), ge.upconv3(x, cg, b)) < 1e-2
+    assert relmax(mf.upconv3_bwd_data(gy, cm), ge.upconv3_bwd_data(gy, cg)) < 1.5e-2
+    mf.upconv3_wgrad(gy, x, cm, False)
+    ge.upconv3_wgrad(gy, x, cg, False)
+    assert relmax(cm.dw, cg.dw) < 4e-3
+
+
+def test_resize_convolution_image_block_full_size():
+    """the generator's output block (64 -> 3 channels at 128 -> 256, NCHW fp32) at batch 64"""
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(23)
+    mf = HipOps(torch.bfloat16, dev, algo=_abi.ALGO_AUTO)
+    ge = HipOps(torch.bfloat16, dev, algo=_abi.ALGO_GENERIC)
+    H, Cin, Cout = 128, 64, 3
+    w = (torch.randn(Cout, Cin, 3, 3, generator=gen) * (2.0 / (9 * Cin)) ** 0.5).to(dev)
+    b = (torch.randn(Cout, generator=gen) * 0.1).to(dev)
+    x = torch.randn(N, H, H, Cin, generator=gen).bfloat16().to(dev)
+    g_img = torch.randn(N, Cout, 2 * H, 2 * H, generator=gen).to(dev)
+    cm, cg = ConvW(w, b, torch.zeros_like(w)), ConvW(w, b, torch.zeros_like(w))
+    assert relmax(mf.upconv3(x, cm, b, out_nchw=True), ge.upconv3(x, cg, b, out_nchw=True)) < 1e-2
+    mf.upconv3_wgrad(g_img, x, cm, False, gy_nchw=True)
+    ge.upconv3_wgrad(g_img, x, cg, False, gy_nchw=True)
+    assert relmax(cm.dw, cg.dw) < 4e-3
