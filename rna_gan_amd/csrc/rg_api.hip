@@ -14,7 +14,7 @@ void rg_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int rg_version(void) { return 100; }
+extern "C" int rg_version(void) { return 104; }   // 1.04: upconv3 algo/workspace args, Adam weight_decay, betaVAE training entry points
 extern "C" const char* rg_last_error(void) { return g_err; }
 
 static bool want_mfma(int algo, int dtype) { return algo != RG_ALGO_GENERIC && dtype == RG_BF16; }
