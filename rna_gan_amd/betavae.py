@@ -85,6 +85,12 @@ class betaVAE(nn.Module):
     def weights_changed(self, by_optimizer: bool = False):
         self._plan = None
 
+    def train(self, mode: bool = True):
+        # the eval-mode plan folds BatchNorm into per-layer scale/shift vectors: rebuild it after any training phase
+        # (a plain torch optimizer updates the parameter views without telling this module)
+        self._plan = None
+        return super().train(mode)
+
     def train_runtime(self):
         if self._trt is None:
             from .vae_train import VaeRuntime
