@@ -15,7 +15,8 @@ def load(d, counter):
         n = r["Kernel_Name"]
         fam = ("gather_gemm_linear" if "gather_gemm_dma_kernel<2" in n else "gather_gemm" if "gather_gemm_dma" in n else "wgrad_dma" if "wgrad_dma" in n else
                "first_down" if "first_down" in n else "last_up" if "last_up" in n else
-               "skinny_wgrad" if "skinny_wgrad" in n else "adam" if ("AdamDev" in n or "adam_dev_kernel" in n) else None)
+               "skinny_wgrad" if "skinny_wgrad" in n else "adam" if ("AdamDev" in n or "adam_dev_kernel" in n) else
+               "bn_apply" if "rowapply_kernel" in n else "bn_reduce" if "rowreduce_kernel" in n else None)
         if fam is None:
             continue
         acc[fam][0] += float(r["Counter_Value"])
