@@ -1227,7 +1227,12 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   if (EPI == EPI_LINEAR && (g.Ncols % 8 != 0 || g.ldc % 4 != 0)) nsplit = 1;      // slab rows are written 8 wide
   a2.a_bytes = (unsigned)a_bytes; a2.b_bytes = (unsigned)b_bytes;
   a2.nsplit = nsplit; a2.slab = (float*)ws; a2.slab_stride = rows_out * (EPI == EPI_BF16 ? g.Ncols : g.ldc);
-  const int bn = narrow ? 64 : wide ? 256 : 128, bmm = (narrow || wide) ? 256 : 128;
+  // weight-streaming GEMMs (a batch of <= 64 rows against a large weight matrix: betaVAE layers, G.0): 64-row tile with a
+  // 3-deep DMA ring -- the bound is HBM latency x bytes in flight, not the matrix cores (RNAGAN_STREAM_TILE=0: off)
+  static int stream_tile = -1;
+  if (stream_tile < 0) { const char* e = getenv("RNAGAN_STREAM_TILE"); stream_tile = e ? atoi(e) : 1; }
+  const bool stream = stream_tile && EPI == EPI_LINEAR && MODE == MODE_PLAIN && g.M <= 64 && !narrow;
+  const int bn = narrow ? 64 : wide ? 256 : 128, bmm = stream ? 64 : (narrow || wide) ? 256 : 128;
   g.tiles_n = (g.Ncols + bn - 1) / bn;
   a2.g = g;
   a2.tiles_m = (g.M + bmm - 1) / bmm;
@@ -1242,7 +1247,10 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   }
   a2.xcd_swizzle = (xcd && grid.x % 8 == 0 && grid.x >= 16 && (xcd == 2 || a_bytes > b_bytes)) ? 1 : 0;
   // (measured and rejected for the 64-column tile: 2 waves with 128 x 64 wave tiles, 147-154 us vs 109-112 us)
-  if (narrow) {
+  if (stream) {
+    if constexpr (EPI == EPI_LINEAR && MODE == MODE_PLAIN)
+      hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 64, 128, 3, 128>), grid, dim3(128), 0, st, a2);
+  } else if (narrow) {
     hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 256, 64, 2, 256>), grid, dim3(256), 0, st, a2);
   } else if (wide) {
     hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 256, 256, 2, 512, 128>), grid, dim3(512), 0, st, a2);
