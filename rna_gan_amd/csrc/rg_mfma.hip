@@ -1468,27 +1468,39 @@ int rg_mfma_g0_wgrad(const float* z, const void* gy, float* dw, int N, int E, in
 // the Conv2d bias in the epilogue.
 __global__ void uppad_bf16_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ pad, int N, int H, int W, int C) {
   const int C8 = C >> 3, Hp = 2 * H + 2, Wp = 2 * W + 2;
-  const size_t tot = (size_t)N * Hp * Wp * C8;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < tot; idx += (size_t)gridDim.x * blockDim.x) {
-    const int c8 = (int)(idx % C8);
-    size_t t = idx / C8;
-    const int j = (int)(t % Wp); t /= Wp;
-    const int i = (int)(t % Hp);
-    const int n = (int)(t / Hp);
-    int h0, h1, w0, w1;
-    float lh, lw;
-    up_taps(up_reflect(i, 2 * H), H, h0, h1, lh);
-    up_taps(up_reflect(j, 2 * W), W, w0, w1, lw);
-    const bf16_t* xn = reinterpret_cast<const bf16_t*>(x) + (size_t)n * H * W * C + c8 * 8;
-    float v00[8], v01[8], v10[8], v11[8], o[8];
-    Vec<bf16_t, 8>::ld(xn + ((size_t)h0 * W + w0) * C, v00);
-    Vec<bf16_t, 8>::ld(xn + ((size_t)h0 * W + w1) * C, v01);
-    Vec<bf16_t, 8>::ld(xn + ((size_t)h1 * W + w0) * C, v10);
-    Vec<bf16_t, 8>::ld(xn + ((size_t)h1 * W + w1) * C, v11);
+  const size_t tot = (size_t)N * Hp * Wp * C8, stride = (size_t)gridDim.x * blockDim.x;
+  constexpr int U = 2;                      // outputs per thread per pass: 8 x 16-byte loads in flight before the stores
+  for (size_t base = (size_t)blockIdx.x * blockDim.x + threadIdx.x; base < tot; base += U * stride) {
+    float v[U][4][8], lh[U], lw[U];
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      o[k] = (1.f - lh) * ((1.f - lw) * v00[k] + lw * v01[k]) + lh * ((1.f - lw) * v10[k] + lw * v11[k]);
-    Vec<bf16_t, 8>::st(reinterpret_cast<bf16_t*>(pad) + idx * 8, o);
+    for (int u = 0; u < U; ++u) {
+      const size_t idx = base + u * stride;
+      if (idx >= tot) continue;
+      const int c8 = (int)(idx % C8);
+      size_t t = idx / C8;
+      const int j = (int)(t % Wp); t /= Wp;
+      const int i = (int)(t % Hp);
+      const int n = (int)(t / Hp);
+      int h0, h1, w0, w1;
+      up_taps(up_reflect(i, 2 * H), H, h0, h1, lh[u]);
+      up_taps(up_reflect(j, 2 * W), W, w0, w1, lw[u]);
+      const bf16_t* xn = reinterpret_cast<const bf16_t*>(x) + (size_t)n * H * W * C + c8 * 8;
+      Vec<bf16_t, 8>::ld(xn + ((size_t)h0 * W + w0) * C, v[u][0]);
+      Vec<bf16_t, 8>::ld(xn + ((size_t)h0 * W + w1) * C, v[u][1]);
+      Vec<bf16_t, 8>::ld(xn + ((size_t)h1 * W + w0) * C, v[u][2]);
+      Vec<bf16_t, 8>::ld(xn + ((size_t)h1 * W + w1) * C, v[u][3]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t idx = base + u * stride;
+      if (idx >= tot) continue;
+      float o[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        o[k] = (1.f - lh[u]) * ((1.f - lw[u]) * v[u][0][k] + lw[u] * v[u][1][k]) +
+               lh[u] * ((1.f - lw[u]) * v[u][2][k] + lw[u] * v[u][3][k]);
+      Vec<bf16_t, 8>::st(reinterpret_cast<bf16_t*>(pad) + idx * 8, o);
+    }
   }
 }
 // w3[o][c][3][3] fp32 -> wp[o][tap][c] bf16
