@@ -51,6 +51,11 @@ extern "C" {
 
 int rg_version(void);
 const char* rg_last_error(void);
+/* Kernel-selection knobs for A/B measurements inside one process (tools/, tests/): name = the part of the matching
+ * environment variable after "RNAGAN_", lower case ("conv8", "conv8_blocks", "conv_tile", "xcd", "class_fast",
+ * "wgrad_blocks", "wgrad8", ...).  An option set here overrides the environment; value < 0 clears the override.  Returns RG_EINVAL for an
+ * unknown name.  Not thread-safe against concurrent launches. */
+int rg_set_option(const char* name, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * Stride-2 4x4 convolution family (K1/K2/K3 of SURVEY 2.2)

@@ -23,6 +23,7 @@ _z = C.c_size_t
 PROTOTYPES = {
     "rg_version": (_i, []),
     "rg_last_error": (C.c_char_p, []),
+    "rg_set_option": (_i, [C.c_char_p, _i]),
     "rg_pack_conv_weight": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "rg_conv_stats_rows": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "rg_conv_down": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _z, _p]),

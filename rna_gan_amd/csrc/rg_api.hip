@@ -4,6 +4,9 @@
 #include "rg_internal.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ctype.h>
 
 static thread_local char g_err[512] = "";
 
@@ -16,6 +19,39 @@ void rg_set_error(const char* fmt, ...) {
 
 extern "C" int rg_version(void) { return 104; }   // 1.04: upconv3 algo/workspace args, Adam weight_decay, betaVAE training entry points
 extern "C" const char* rg_last_error(void) { return g_err; }
+
+// ---- kernel-selection knobs: override table in front of the RNAGAN_* environment variables
+static const char* const g_opt_names[] = {"conv8", "conv8_blocks", "conv_tile", "xcd", "class_fast", "wgrad_blocks",
+                                          "wgrad8", "conv_v1", "stream_tile", "narrow8", "conv8_mfma", "conv8_epi"};
+constexpr int G_NOPT = sizeof(g_opt_names) / sizeof(g_opt_names[0]);
+static int g_opt_override[G_NOPT];      // value + 1; 0 = not set
+static int g_opt_env[G_NOPT];           // cached environment value + 1; 0 = not read yet; -1 = variable absent
+
+int rg_option(const char* name, int dflt) {
+  for (int i = 0; i < G_NOPT; ++i) {
+    if (strcmp(name, g_opt_names[i]) != 0) continue;
+    if (g_opt_override[i] > 0) return g_opt_override[i] - 1;
+    if (g_opt_env[i] == 0) {
+      char var[64] = "RNAGAN_";
+      size_t n = strlen(var);
+      for (const char* c = name; *c && n + 1 < sizeof(var); ++c) var[n++] = (char)toupper((unsigned char)*c);
+      var[n] = 0;
+      const char* e = getenv(var);
+      g_opt_env[i] = e ? atoi(e) + 1 : -1;
+      if (g_opt_env[i] == 0) g_opt_env[i] = -1;      // negative values are not representable: treated as absent
+    }
+    return g_opt_env[i] > 0 ? g_opt_env[i] - 1 : dflt;
+  }
+  return dflt;
+}
+
+extern "C" int rg_set_option(const char* name, int value) {
+  RG_REQUIRE(name, RG_EINVAL, "set_option: null name");
+  for (int i = 0; i < G_NOPT; ++i)
+    if (strcmp(name, g_opt_names[i]) == 0) { g_opt_override[i] = value < 0 ? 0 : value + 1; return RG_OK; }
+  rg_set_error("set_option: unknown option '%s'", name);
+  return RG_EINVAL;
+}
 
 static bool want_mfma(int algo, int dtype) { return algo != RG_ALGO_GENERIC && dtype == RG_BF16; }
 

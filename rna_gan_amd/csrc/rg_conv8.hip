@@ -1,0 +1,432 @@
+// rg_conv8.hip -- 8-wave ping-pong implicit-GEMM conv kernel for gfx950 (bf16 MFMA 32x32x16, fp32 accumulate).
+//
+// Same GEMM view as gather_gemm_dma_kernel (rg_mfma.hip): C[M][Ncols] = sum_k A(m,k) * Bt[col][k], A rows gathered
+// from an NHWC tensor (stride-2 4x4 conv, its transpose in 4 output-parity classes, or plain rows), operands DMA'd
+// global -> LDS (buffer_load_dwordx4 ... lds), XOR-swizzled source chunk / linear destination / swizzled read.
+// What differs is the pipeline (CDNA guide "256^2 8-phase template", re-derived for a gathered A operand):
+//
+//  * block tile BM x BN = (WM*128) x (WN*64) with 8 waves, every wave owns 128 x 64 of it as 2 x 2 QUADRANTS of
+//    64 x 32; quadrant row i of every wave lives in A half-tile i, quadrant column j in B half-tile j, so a k-tile is
+//    four half-tiles (A0, A1, B0, B1) that are staged, waited for, read and freed independently.
+//  * a k-tile is 4 PHASES (one quadrant x BK = 64 each: 8 MFMAs per wave).  Phase = load section (fragment
+//    ds_reads of the one half-tile this phase needs first, the DMA issue of ONE half-tile, a counted vmcnt) ->
+//    s_barrier -> MFMA section -> s_barrier.  Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave
+//    is in its MFMA section while its partner reads LDS / issues DMA (ping-pong).
+//  * the DMA stream runs 5 half-tiles ahead of the half-tile being waited for (issue order B0 A0 B1 A1 per k-tile,
+//    each issued 6 phases before its first read, into the slot freed 2 phases earlier); vmcnt is never 0 in the loop.
+//      phase of k-tile u :  reads        issues        MFMA quadrant
+//        P1                 A0[u]        A1[u+1]       (0,0)  with B0[u] read in P4 of k-tile u-1
+//        P2                 B1[u]        B0[u+2]       (0,1)
+//        P3                 A1[u]        A0[u+2]       (1,1)
+//        P4                 B0[u+1]      B1[u+2]       (1,0)
+//    k-tiles beyond the last one are issued as all-out-of-range DMAs (zero fill into free slots, no memory traffic):
+//    the counted waits stay uniform, there is no tail variant of the loop.
+//  * B fragments rotate through three register sets (B0[u], B1[u], B0[u+1]), period two k-tiles = the unroll.
+#include "rg_gather.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+template <int V> using ic = std::integral_constant<int, V>;
+
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// MF: MFMA shape, 32 = v_mfma_f32_32x32x16_bf16 (8 per phase), 16 = v_mfma_f32_16x16x32_bf16 (16 per phase)
+template <int MODE, int WM, int WN, int MF>
+__global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
+  static_assert(WM * WN == 8, "8 waves");
+  constexpr int BM = WM * 128, BN = WN * 64;
+  constexpr int AH_ROWS = BM / 2, BH_ROWS = BN / 2;          // rows per half-tile
+  constexpr int AH = AH_ROWS * 128, BH = BH_ROWS * 128;      // bytes per half-tile (BK = 64 bf16 = 128 B per row)
+  constexpr int STAGE = 2 * AH + 2 * BH;                     // bytes per stage, laid out [B0][B1][A0][A1]
+  constexpr int OFF_B = 0, OFF_A = 2 * BH;
+  constexpr int NA = AH_ROWS / 64, NB = BH_ROWS / 64;        // block-wide DMA instructions per half-tile (64 rows each)
+  static_assert(NA >= 1 && NB >= 1, "half-tiles are whole 64-row DMA instructions");
+  static_assert(AH + 4096 < 65536 && BH < 65536, "fragment offsets must fit the 16-bit ds_read offset");
+  constexpr int LDS_BYTES = 2 * STAGE;
+  constexpr int EP_COLS = BN / 2;                            // epilogue: one quadrant column per pass
+  static_assert(BM * EP_COLS * 4 <= LDS_BYTES, "fp32 epilogue slice must fit the staging LDS");
+  __shared__ __attribute__((aligned(16))) uint4 lds[LDS_BYTES / 16];
+  const GArgs& g = a2.g;
+
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lane = t & 63;
+  int bid = blockIdx.x;
+  if (a2.xcd_swizzle) bid = (bid & 7) * ((int)gridDim.x >> 3) + (bid >> 3);
+  int par = (MODE == MODE_UP) ? (int)blockIdx.y : 0;
+  if (MODE == MODE_UP && a2.class_fast) { par = bid & 3; bid >>= 2; }
+  const int tile_m = bid / g.tiles_n, tile_n = bid - tile_m * g.tiles_n;
+  const int bm = tile_m * BM, bn = tile_n * BN;
+  const int ph = par >> 1, pw = par & 1;
+  const int zs = blockIdx.z;
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, a2.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, a2.b_bytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+
+  // ---- DMA lane assignment: physical chunk pc of row r0 + 64*j of a half-tile; logical (source) chunk lc
+  const int pc = t & 7, r0 = t >> 3;
+  const int lc = pc ^ ((r0 >> 1) & 7);
+  const int Wq = 1 << g.lgW, Hq = 1 << g.lgH;
+  int a_off[2 * NA];                 // byte offset of the row's base pixel + this lane's chunk
+  unsigned a_mask[NA];               // tap-validity masks, two rows per register (h = 0 low half, h = 1 high half)
+  int b_off[2 * NB];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) a_mask[j] = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int m = bm + h * AH_ROWS + j * 64 + r0;
+      const bool ok = m < g.M;
+      const int mm = ok ? m : 0;
+      const int wq = mm & (Wq - 1), hq = (mm >> g.lgW) & (Hq - 1), n = mm >> (g.lgW + g.lgH);
+      unsigned mask = 0;
+      long long base;
+      if (MODE == MODE_DOWN) {
+        const int hs0 = 2 * hq - 1, ws0 = 2 * wq - 1;
+        base = (((long long)n * g.Hs + hs0) * g.Ws + ws0) * g.Cin;
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 4; ++kw) {
+            const bool v = (unsigned)(hs0 + kh) < (unsigned)g.Hs && (unsigned)(ws0 + kw) < (unsigned)g.Ws;
+            mask |= (v ? 1u : 0u) << (kh * 4 + kw);
+          }
+      } else if (MODE == MODE_UP) {
+        base = (((long long)n * g.Hs + hq) * g.Ws + wq) * g.Cin;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            int kh, kw, dh, dw;
+            up_tap_dev(ph, a, kh, dh);
+            up_tap_dev(pw, b, kw, dw);
+            const bool v = (unsigned)(hq + dh) < (unsigned)g.Hs && (unsigned)(wq + dw) < (unsigned)g.Ws;
+            mask |= (v ? 1u : 0u) << (a * 2 + b);
+          }
+      } else {
+        base = (long long)mm * g.Cin;
+        mask = 1u;
+      }
+      a_off[h * NA + j] = (int)((base + lc * 8) * 2);
+      a_mask[j] |= (ok ? mask : 0u) << (16 * h);
+    }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int col = bn + h * BH_ROWS + j * 64 + r0;
+      b_off[h * NB + j] = col < g.Ncols ? (int)(((long long)col * g.b_col + lc * 8) * 2) : -1;
+    }
+
+  const int cpt = g.Cin >> 6;
+  const int nkt_all = g.taps * cpt;
+  const int per = (nkt_all + a2.nsplit - 1) / a2.nsplit;      // host guarantees an even count per split
+  const int kt_begin = zs * per;
+  const int kt_end = min(nkt_all, kt_begin + per);
+  const int nkt = kt_end - kt_begin;
+  const int lgcpt = a2.lgcpt, cmask = a2.cmask;
+  char* const ldsb = reinterpret_cast<char*>(lds);
+
+  // k-tile index (relative to kt_begin) -> byte offsets added to the A row bases / B column bases, and the tap
+  auto decode = [&](int ktr, int& ao, int& bo, int& tap) {
+    const int kt = kt_begin + ktr;
+    tap = kt >> lgcpt;
+    const int c0 = (kt & cmask) << 6;
+    int a_delta, b_tap;
+    if (MODE == MODE_DOWN) {
+      a_delta = ((tap >> 2) * g.Ws + (tap & 3)) * g.Cin;
+      b_tap = tap;
+    } else if (MODE == MODE_UP) {
+      int kh, kw, dh, dw;
+      up_tap_dev(ph, tap >> 1, kh, dh);
+      up_tap_dev(pw, tap & 1, kw, dw);
+      a_delta = (dh * g.Ws + dw) * g.Cin;
+      b_tap = kh * 4 + kw;
+    } else {
+      a_delta = 0;
+      b_tap = 0;
+    }
+    ao = (a_delta + c0) * 2;
+    bo = (b_tap * g.b_tap + c0) * 2;
+  };
+  // one half-tile of k-tile ktr into stage S: NA (A) or NB (B) block-wide DMA instructions
+  auto issue_a = [&](auto S, auto H, int ktr) {
+    constexpr int s = decltype(S)::value, h = decltype(H)::value;
+    int ao, bo, tap;
+    decode(ktr, ao, bo, tap);
+    const unsigned dead = ktr < nkt ? 0u : OOB;         // k-tiles beyond the end: every lane out of range (branch-free)
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const bool v = (a_mask[j] >> ((tap & 15) + 16 * h)) & 1u;
+      const unsigned vo = (v ? (unsigned)(a_off[h * NA + j] + ao) : OOB) | dead;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsA, (lds_vptr_t)(ldsb + s * STAGE + OFF_A + h * AH + j * 8192 + wave * 1024), 16, vo, 0, 0, 0);
+    }
+  };
+  auto issue_b = [&](auto S, auto H, int ktr) {
+    constexpr int s = decltype(S)::value, h = decltype(H)::value;
+    int ao, bo, tap;
+    decode(ktr, ao, bo, tap);
+    const unsigned dead = ktr < nkt ? 0u : OOB;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const unsigned vo = (b_off[h * NB + j] >= 0 ? (unsigned)(b_off[h * NB + j] + bo) : OOB) | dead;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsB, (lds_vptr_t)(ldsb + s * STAGE + OFF_B + h * BH + j * 8192 + wave * 1024), 16, vo, 0, 0, 0);
+    }
+  };
+
+  // ---- MFMA / fragment-read assignment
+  const int wm = wave / WN, wn = wave - wm * WN;
+  // 32x32x16: lane = (row fr of 32, k-half fh), chunk(kk) = 2kk + fh, kk < 4.   16x16x32: lane = (row fr of 16, k-quarter
+  // fh), chunk(kk) = 4kk + fh, kk < 2.  The XOR swizzle (row>>1)&7 is the same for every sub-tile of a wave (16 | 32 rows apart).
+  constexpr int FRW = MF == 32 ? 32 : 16;            // rows per MFMA tile
+  constexpr int NKK = MF == 32 ? 4 : 2;              // k-steps per k-tile
+  constexpr int NAT = 64 / FRW, NBT = 32 / FRW;      // A row sub-tiles / B column sub-tiles per quadrant
+  const int fr = lane & (FRW - 1), fh = lane / FRW;
+  const unsigned lds_base = (unsigned)(size_t)(lds_vptr_t)lds;
+  unsigned aB[2][NKK], bB[2][NKK];   // [stage][k-step] byte addresses of this lane's A / B fragment chunk
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) {
+    const unsigned ch = (unsigned)(((64 / FRW) * kk + fh) ^ ((fr >> 1) & 7));
+    aB[0][kk] = lds_base + OFF_A + 16u * (unsigned)((wm * 64 + fr) * 8 + ch);
+    bB[0][kk] = lds_base + OFF_B + 16u * (unsigned)((wn * 32 + fr) * 8 + ch);
+    aB[1][kk] = aB[0][kk] + STAGE;
+    bB[1][kk] = bB[0][kk] + STAGE;
+  }
+  using acc_t = std::conditional_t<MF == 32, f32x16_t, f32x4_t>;
+  constexpr int NACC = NAT * NBT, ACC_R = MF == 32 ? 16 : 4;
+  acc_t acc[2][2][NACC];             // [quadrant row i][quadrant column j][A sub-tile * NBT + B sub-tile]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s = 0; s < NACC; ++s)
+#pragma unroll
+        for (int r = 0; r < ACC_R; ++r) acc[i][j][s][r] = 0.f;
+  u32x4_t aR[8];                     // A fragments of the current quadrant row: [A sub-tile][k-step]
+  u32x4_t bS[3][4];                  // three rotating B fragment sets: [set][B sub-tile][k-step]
+
+#define C8_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define C8_READ_A(S, H)                                                                     \
+  do {                                                                                      \
+    _Pragma("unroll") for (int t_ = 0; t_ < NAT; ++t_) _Pragma("unroll") for (int kk_ = 0; kk_ < NKK; ++kk_) \
+        C8_DSR(aR[t_ * NKK + kk_], aB[S][kk_], (H) * AH + t_ * FRW * 128);                  \
+  } while (0)
+#define C8_READ_B(S, H, SET)                                                                \
+  do {                                                                                      \
+    _Pragma("unroll") for (int t_ = 0; t_ < NBT; ++t_) _Pragma("unroll") for (int kk_ = 0; kk_ < NKK; ++kk_) \
+        C8_DSR(bS[SET][t_ * NKK + kk_], bB[S][kk_], (H) * BH + t_ * FRW * 128);             \
+  } while (0)
+#define C8_WAIT_A()                                                                                            \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                          \
+               : "+v"(aR[0]), "+v"(aR[1]), "+v"(aR[2]), "+v"(aR[3]), "+v"(aR[4]), "+v"(aR[5]), "+v"(aR[6]),    \
+                 "+v"(aR[7])::"memory")
+#define C8_WAIT_B(SET)                                                                                         \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bS[SET][0]), "+v"(bS[SET][1]), "+v"(bS[SET][2]), "+v"(bS[SET][3])::"memory")
+#define C8_MFMAS(I, J, SET)                                                                                    \
+  do {                                                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                                             \
+    _Pragma("unroll") for (int kk_ = 0; kk_ < NKK; ++kk_) _Pragma("unroll") for (int t_ = 0; t_ < NAT; ++t_)   \
+    _Pragma("unroll") for (int c_ = 0; c_ < NBT; ++c_) {                                                       \
+      if constexpr (MF == 32)                                                                                  \
+        acc[I][J][t_ * NBT + c_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                    \
+            __builtin_bit_cast(bf16x8_t, aR[t_ * NKK + kk_]), __builtin_bit_cast(bf16x8_t, bS[SET][c_ * NKK + kk_]), \
+            acc[I][J][t_ * NBT + c_], 0, 0, 0);                                                                \
+      else                                                                                                     \
+        acc[I][J][t_ * NBT + c_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                    \
+            __builtin_bit_cast(bf16x8_t, aR[t_ * NKK + kk_]), __builtin_bit_cast(bf16x8_t, bS[SET][c_ * NKK + kk_]), \
+            acc[I][J][t_ * NBT + c_], 0, 0, 0);                                                                \
+    }                                                                                                          \
+    __builtin_amdgcn_s_setprio(0);                                                                             \
+  } while (0)
+#define C8_SYNC() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+  // counted waits (see the table in the header): half-tiles allowed to stay in flight behind the one needed next phase
+  constexpr int W_ODD = vmcnt_imm(3 * NA + 2 * NB);     // P1, P3
+  constexpr int W_EVEN = vmcnt_imm(2 * NA + 3 * NB);    // P2, P4
+  // one k-tile u living in stage S; B0[u] is in set SB0, B1[u] goes to set 1, B0[u+1] goes to set SNX
+#define C8_TILE(S, SB0, SNX, U)                                                             \
+  do {                                                                                      \
+    /* P1 */                                                                                \
+    C8_READ_A(S, 0);                                                                        \
+    issue_a(ic<1 - (S)>{}, ic<1>{}, (U) + 1);                                               \
+    __builtin_amdgcn_s_waitcnt(W_ODD);                                                      \
+    C8_SYNC();                                                                              \
+    C8_WAIT_A();                                                                            \
+    C8_MFMAS(0, 0, SB0);                                                                    \
+    C8_SYNC();                                                                              \
+    /* P2 */                                                                                \
+    C8_READ_B(S, 1, 1);                                                                     \
+    issue_b(ic<(S)>{}, ic<0>{}, (U) + 2);                                                   \
+    __builtin_amdgcn_s_waitcnt(W_EVEN);                                                     \
+    C8_SYNC();                                                                              \
+    C8_WAIT_B(1);                                                                           \
+    C8_MFMAS(0, 1, 1);                                                                      \
+    C8_SYNC();                                                                              \
+    /* P3 */                                                                                \
+    C8_READ_A(S, 1);                                                                        \
+    issue_a(ic<(S)>{}, ic<0>{}, (U) + 2);                                                   \
+    __builtin_amdgcn_s_waitcnt(W_ODD);                                                      \
+    C8_SYNC();                                                                              \
+    C8_WAIT_A();                                                                            \
+    C8_MFMAS(1, 1, 1);                                                                      \
+    C8_SYNC();                                                                              \
+    /* P4 */                                                                                \
+    C8_READ_B(1 - (S), 0, SNX);                                                             \
+    issue_b(ic<(S)>{}, ic<1>{}, (U) + 2);                                                   \
+    __builtin_amdgcn_s_waitcnt(W_EVEN);                                                     \
+    C8_SYNC();                                                                              \
+    C8_WAIT_B(SNX);                                                                         \
+    C8_MFMAS(1, 0, SB0);                                                                    \
+    C8_SYNC();                                                                              \
+  } while (0)
+
+  // ---- prologue: k-tile 0 and the first three half-tiles of k-tile 1 in flight
+  issue_b(ic<0>{}, ic<0>{}, 0);
+  issue_a(ic<0>{}, ic<0>{}, 0);
+  issue_b(ic<0>{}, ic<1>{}, 0);
+  issue_a(ic<0>{}, ic<1>{}, 0);
+  issue_b(ic<1>{}, ic<0>{}, 1);
+  issue_a(ic<1>{}, ic<0>{}, 1);
+  issue_b(ic<1>{}, ic<1>{}, 1);
+  __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * NA + 3 * NB));      // B0[0] and A0[0] landed (this wave's part)
+  C8_SYNC();
+  C8_READ_B(0, 0, 0);                                          // "P4 of k-tile -1"
+  C8_WAIT_B(0);
+  if (wave >= 4) __builtin_amdgcn_s_barrier();                 // waves 4-7 run one barrier behind waves 0-3
+  __builtin_amdgcn_sched_barrier(0);
+  for (int u = 0; u < nkt; u += 2) {
+    C8_TILE(0, 0, 2, u);
+    C8_TILE(1, 2, 0, u + 1);
+  }
+  if (wave < 4) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+#undef C8_TILE
+#undef C8_SYNC
+#undef C8_MFMAS
+#undef C8_WAIT_A
+#undef C8_WAIT_B
+#undef C8_READ_A
+#undef C8_READ_B
+#undef C8_DSR
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the zero-fill DMAs of the k-tiles beyond the end
+  __syncthreads();
+
+  // ---- BatchNorm statistics from the accumulators (see gather_gemm_dma_kernel): a lane's registers of quadrant
+  // column j all belong to ONE output column; the wave's 128 rows are register adds + one cross-half shuffle.
+  if (g.stats && a2.nsplit == 1) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int c = 0; c < NBT; ++c) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int s = 0; s < NAT; ++s)
+#pragma unroll
+            for (int r = 0; r < ACC_R; ++r) {
+              const float v = bf16_to_f32(f32_to_bf16(acc[i][j][s * NBT + c][r]));
+              s1 += v; s2 += v * v;
+            }
+#pragma unroll
+        for (int o = FRW; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        const int gcol = bn + j * BH_ROWS + wn * 32 + c * FRW + fr;
+        if (fh == 0 && gcol < g.Ncols) {
+          const size_t grow = ((size_t)par * a2.tiles_m + tile_m) * WM + wm;
+          g.stats[(grow * 2 + 0) * g.Ncols + gcol] = s1;
+          g.stats[(grow * 2 + 1) * g.Ncols + gcol] = s2;
+        }
+      }
+  }
+
+  // ---- epilogue through LDS: fp32 [BM][EP_COLS] per quadrant column, 16-byte row-contiguous global stores
+  float* cs = reinterpret_cast<float*>(lds);
+  constexpr int CG = EP_COLS / 8, RPP = 512 / CG;      // column groups per row, rows per pass
+  const int cg = t % CG, rr = t / CG;
+#pragma unroll
+  for (int ep = 0; ep < 2; ++ep) {
+    if (ep) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int s = 0; s < NAT; ++s)
+#pragma unroll
+        for (int c = 0; c < NBT; ++c)
+#pragma unroll
+          for (int r = 0; r < ACC_R; ++r) {
+            // accumulator row maps: 32x32 -> (r&3) + 8*(r>>2) + 4*fh ; 16x16 -> 4*fh + r
+            const int rloc = MF == 32 ? (r & 3) + 8 * (r >> 2) + 4 * fh : 4 * fh + r;
+            const int row = i * AH_ROWS + wm * 64 + s * FRW + rloc;
+            cs[row * EP_COLS + wn * 32 + c * FRW + fr] = acc[i][ep][s * NBT + c][r];
+          }
+    __syncthreads();
+    const int col = bn + ep * EP_COLS + cg * 8;
+#pragma unroll 4
+    for (int p = 0; p < BM / RPP; ++p) {
+      const int row = rr + RPP * p;
+      const int m = bm + row;
+      if (m >= g.M || col >= g.Ncols) continue;
+      float4 v0 = *reinterpret_cast<const float4*>(cs + row * EP_COLS + cg * 8);
+      float4 v1 = *reinterpret_cast<const float4*>(cs + row * EP_COLS + cg * 8 + 4);
+      long long orow;
+      if (MODE == MODE_UP) {
+        const int wq = m & (Wq - 1), hq = (m >> g.lgW) & (Hq - 1), n = m >> (g.lgW + g.lgH);
+        orow = ((long long)n * (2 * Hq) + 2 * hq + ph) * (2 * Wq) + 2 * wq + pw;
+      } else {
+        orow = m;
+      }
+      if (a2.nsplit > 1) {
+        float* so = a2.slab + (long long)zs * a2.slab_stride + orow * g.ldc + col;
+        *reinterpret_cast<float4*>(so) = v0;
+        *reinterpret_cast<float4*>(so + 4) = v1;
+      } else {
+        if (g.mask) {
+          const uint4 a = *reinterpret_cast<const uint4*>(g.mask + orow * g.ldc + col);
+          v0.x *= rg_lmask(a.x, g.mslope); v0.y *= rg_lmask(a.x >> 16, g.mslope);
+          v0.z *= rg_lmask(a.y, g.mslope); v0.w *= rg_lmask(a.y >> 16, g.mslope);
+          v1.x *= rg_lmask(a.z, g.mslope); v1.y *= rg_lmask(a.z >> 16, g.mslope);
+          v1.z *= rg_lmask(a.w, g.mslope); v1.w *= rg_lmask(a.w >> 16, g.mslope);
+        }
+        uint4 o;
+        o.x = (uint32_t)f32_to_bf16(v0.x) | ((uint32_t)f32_to_bf16(v0.y) << 16);
+        o.y = (uint32_t)f32_to_bf16(v0.z) | ((uint32_t)f32_to_bf16(v0.w) << 16);
+        o.z = (uint32_t)f32_to_bf16(v1.x) | ((uint32_t)f32_to_bf16(v1.y) << 16);
+        o.w = (uint32_t)f32_to_bf16(v1.z) | ((uint32_t)f32_to_bf16(v1.w) << 16);
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(g.C) + orow * g.ldc + col) = o;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+
+
+
+int rg_conv8_launch(int mode, const void* args, int bm, unsigned gx, unsigned gy, unsigned gz, hipStream_t st) {
+  const G2Args& a2 = *reinterpret_cast<const G2Args*>(args);
+  const dim3 grid(gx, gy, gz), block(512);
+  const int mf = rg_option("conv8_mfma", 16);
+#define C8_GO(MODE_, WM_, WN_)                                                                       \
+  do {                                                                                               \
+    if (mf == 16) hipLaunchKernelGGL((conv8_kernel<MODE_, WM_, WN_, 16>), grid, block, 0, st, a2);   \
+    else hipLaunchKernelGGL((conv8_kernel<MODE_, WM_, WN_, 32>), grid, block, 0, st, a2);            \
+  } while (0)
+  if (bm == 256) {
+    if (mode == MODE_DOWN) C8_GO(MODE_DOWN, 2, 4);
+    else if (mode == MODE_UP) C8_GO(MODE_UP, 2, 4);
+    else C8_GO(MODE_PLAIN, 2, 4);
+  } else {
+    if (mode == MODE_DOWN) C8_GO(MODE_DOWN, 4, 2);
+    else if (mode == MODE_UP) C8_GO(MODE_UP, 4, 2);
+    else C8_GO(MODE_PLAIN, 4, 2);
+  }
+#undef C8_GO
+  return RG_OK;
+}

@@ -1,0 +1,70 @@
+// rg_gather.h -- argument blocks and small device helpers shared by the bf16 MFMA implicit-GEMM kernels
+// (rg_mfma.hip: 2-stage LDS-DMA gather GEMM; rg_conv8.hip: 8-wave ping-pong gather GEMM).
+#pragma once
+#include "rg_internal.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+constexpr int MODE_DOWN = 0, MODE_UP = 1, MODE_PLAIN = 2;
+// MODE_C3: 3x3 stride-1 VALID conv over a pre-padded image (the resize-convolution block of DCGANUpGenerator:
+// A = materialised bilinear-x2 + reflection-pad image [N][Hs][Ws][Cin], output grid (Hs-2) x (Ws-2), 9 taps)
+constexpr int MODE_C3 = 3;
+// MODE_C3T: its data gradient -- full 3x3 correlation of gy[N][Hs][Ws][Cin=Cout] onto the padded grid (Hs+2) x (Ws+2)
+// (row decode by division: the padded grid is not a power of two), B = w transposed to [c][tap][o]
+constexpr int MODE_C3T = 4;
+constexpr int EPI_BF16 = 0, EPI_LINEAR = 1;
+
+struct GArgs {
+  const uint16_t* A;
+  const uint16_t* B;
+  void* C;
+  int M, Ncols, Cin, taps;
+  int lgW, lgH;     // row m -> (n, hq, wq): wq = m & (2^lgW-1), hq = (m>>lgW) & (2^lgH-1)
+  int Hs, Ws;       // spatial dims of the tensor A rows are gathered from
+  int ldc;          // output row stride in elements
+  int b_col, b_tap; // B operand: elements between consecutive output columns / between consecutive taps
+  int tiles_n;      // number of 128-wide column tiles
+  const float* scale;
+  const float* shift;
+  float slope;
+  float* stats;           // EPI_BF16, optional: per-tile column sums of the (bf16-rounded) output and of its square,
+                          // [partial rows][2][Ncols] (BatchNorm statistics straight from the conv epilogue)
+  const uint16_t* mask;   // EPI_BF16, optional: activation with the output's shape; out *= (mask > 0 ? 1 : mslope)
+  float mslope;           // (LeakyReLU backward of the consumer fused into the data-gradient conv)
+};
+
+// 8 bf16 outputs (packed in o) times the LeakyReLU derivative at 8 bf16 activations (packed in a)
+__device__ __forceinline__ float rg_lmask(uint32_t abits, float slope) {
+  return (abits & 0x8000u) || !(abits & 0x7fffu) ? slope : 1.f;      // a <= 0 (incl. -0): slope
+}
+
+__device__ __forceinline__ void up_tap_dev(int par, int a, int& kidx, int& d) {
+  if (par == 0) { kidx = a == 0 ? 1 : 3; d = a == 0 ? 0 : -1; }
+  else          { kidx = a == 0 ? 0 : 2; d = a == 0 ? 1 : 0; }
+}
+
+struct G2Args {
+  GArgs g;
+  unsigned a_bytes, b_bytes;   // sizes for the buffer descriptors
+  int nsplit;
+  int xcd_swizzle;             // 1: remap blockIdx.x so each XCD (block b runs on XCD b % 8) owns a contiguous tile range
+  int tiles_m;                 // number of row tiles (per parity class)
+  int class_fast;              // MODE_UP: the 4 output-parity classes are the fastest-varying part of blockIdx.x (they
+                               // read the same input rows: back to back on one XCD the rows are fetched from HBM once)
+  float* slab;                 // [nsplit][rows_out][Ncols] fp32 when nsplit > 1
+  long long slab_stride;       // elements per split
+  int lgcpt, cmask;            // conv8_kernel: k-tile kt -> tap = kt >> lgcpt, channel block = kt & cmask
+};
+
+typedef __attribute__((address_space(3))) void* lds_vptr_t;
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// s_waitcnt immediate for vmcnt(n) only (expcnt/lgkmcnt left at their maxima); vmcnt is split over bits 3:0 and 15:14
+static constexpr int vmcnt_imm(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
+
+
+}  // namespace

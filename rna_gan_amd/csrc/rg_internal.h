@@ -2,6 +2,9 @@
 #pragma once
 #include "rg_common.h"
 
+// rg_api.hip: kernel-selection knob `name` (override set through rg_set_option, else RNAGAN_<NAME>, else dflt)
+int rg_option(const char* name, int dflt);
+
 // rg_generic.hip
 int rg_reduce_slabs(const float* slab, float* dst, size_t n, int nsplit, int accumulate, int perm_mode, int Q,
                     hipStream_t st);
@@ -79,6 +82,9 @@ int rg_mfma_conv_wgrad(const void* low, const void* high, float* dw, int N, int 
 int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, const void* high1, float* dw, int N,
                         int Ho, int Wo, int O, int I, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 size_t rg_mfma_wgrad2_ws_bytes(int N, int Ho, int Wo, int O, int I);
+
+// rg_conv8.hip (8-wave ping-pong gather GEMM; args = G2Args of rg_gather.h)
+int rg_conv8_launch(int mode, const void* args, int bm, unsigned gx, unsigned gy, unsigned gz, hipStream_t st);
 
 // rg_skinny.hip (image-side 3-channel layers)
 bool rg_skinny_supported(int I, int O);

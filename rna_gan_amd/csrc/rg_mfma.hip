@@ -15,48 +15,10 @@
 //    index (pixels) is the slow axis of both NHWC operands, so the [pixel][channel] LDS images are
 //    read with ds_read_b64_tr_b16 (hardware transpose) to build k-contiguous MFMA fragments.
 //    Split-K over pixels into fp32 slabs, reduced in fixed order (deterministic).
-#include "rg_internal.h"
+#include "rg_gather.h"
 #include <stdlib.h>
 
 namespace {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-
-constexpr int MODE_DOWN = 0, MODE_UP = 1, MODE_PLAIN = 2;
-// MODE_C3: 3x3 stride-1 VALID conv over a pre-padded image (the resize-convolution block of DCGANUpGenerator:
-// A = materialised bilinear-x2 + reflection-pad image [N][Hs][Ws][Cin], output grid (Hs-2) x (Ws-2), 9 taps)
-constexpr int MODE_C3 = 3;
-// MODE_C3T: its data gradient -- full 3x3 correlation of gy[N][Hs][Ws][Cin=Cout] onto the padded grid (Hs+2) x (Ws+2)
-// (row decode by division: the padded grid is not a power of two), B = w transposed to [c][tap][o]
-constexpr int MODE_C3T = 4;
-constexpr int EPI_BF16 = 0, EPI_LINEAR = 1;
-
-struct GArgs {
-  const uint16_t* A;
-  const uint16_t* B;
-  void* C;
-  int M, Ncols, Cin, taps;
-  int lgW, lgH;     // row m -> (n, hq, wq): wq = m & (2^lgW-1), hq = (m>>lgW) & (2^lgH-1)
-  int Hs, Ws;       // spatial dims of the tensor A rows are gathered from
-  int ldc;          // output row stride in elements
-  int b_col, b_tap; // B operand: elements between consecutive output columns / between consecutive taps
-  int tiles_n;      // number of 128-wide column tiles
-  const float* scale;
-  const float* shift;
-  float slope;
-  float* stats;           // EPI_BF16, optional: per-tile column sums of the (bf16-rounded) output and of its square,
-                          // [partial rows][2][Ncols] (BatchNorm statistics straight from the conv epilogue)
-  const uint16_t* mask;   // EPI_BF16, optional: activation with the output's shape; out *= (mask > 0 ? 1 : mslope)
-  float mslope;           // (LeakyReLU backward of the consumer fused into the data-gradient conv)
-};
-
-// 8 bf16 outputs (packed in o) times the LeakyReLU derivative at 8 bf16 activations (packed in a)
-__device__ __forceinline__ float rg_lmask(uint32_t abits, float slope) {
-  return (abits & 0x8000u) || !(abits & 0x7fffu) ? slope : 1.f;      // a <= 0 (incl. -0): slope
-}
 
 __device__ __forceinline__ uint4 ld16_if(const uint16_t* p, bool pred) {
   uint4 v = make_uint4(0, 0, 0, 0);
@@ -65,11 +27,6 @@ __device__ __forceinline__ uint4 ld16_if(const uint16_t* p, bool pred) {
 }
 
 __device__ __forceinline__ int lds_chunk_index(int row, int chunk) { return row * 8 + (chunk ^ ((row >> 1) & 7)); }
-
-__device__ __forceinline__ void up_tap_dev(int par, int a, int& kidx, int& d) {
-  if (par == 0) { kidx = a == 0 ? 1 : 3; d = a == 0 ? 0 : -1; }
-  else          { kidx = a == 0 ? 0 : 2; d = a == 0 ? 1 : 0; }
-}
 
 template <int MODE, int EPI>
 __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(GArgs g) {
@@ -296,23 +253,6 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(GArgs g) {
 // swizzled source, swizzled read).  2 stages, tile k+1 in flight during the MFMAs of tile k, one
 // barrier per k-tile.  Tile = BM x BN with 64x64 wave tiles: 128x128 (2x2 waves) or 256x64 (4x1 waves,
 // for 64-channel outputs).  SPLITK: blockIdx.z owns a k-tile range and writes fp32 partials.
-struct G2Args {
-  GArgs g;
-  unsigned a_bytes, b_bytes;   // sizes for the buffer descriptors
-  int nsplit;
-  int xcd_swizzle;             // 1: remap blockIdx.x so each XCD (block b runs on XCD b % 8) owns a contiguous tile range
-  int tiles_m;                 // number of row tiles (per parity class)
-  int class_fast;              // MODE_UP: the 4 output-parity classes are the fastest-varying part of blockIdx.x (they
-                               // read the same input rows: back to back on one XCD the rows are fetched from HBM once)
-  float* slab;                 // [nsplit][rows_out][Ncols] fp32 when nsplit > 1
-  long long slab_stride;       // elements per split
-};
-
-typedef __attribute__((address_space(3))) void* lds_vptr_t;
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-// s_waitcnt immediate for vmcnt(n) only (expcnt/lgkmcnt left at their maxima); vmcnt is split over bits 3:0 and 15:14
-static constexpr int vmcnt_imm(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
-
 template <int MODE, int EPI, int BM, int BN, int NSTAGE, int NT, int WTM = 64>
 __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT == 256) ? 2 : 1) void gather_gemm_dma_kernel(G2Args a2) {
   constexpr int WN = BN / 64;                                // waves along N (WTM x 64 wave tiles)
@@ -1149,15 +1089,11 @@ static int launch_gather(const char* name, GArgs& g, int nclass, hipStream_t st)
   return RG_OK;
 }
 
-static bool use_v1() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("RNAGAN_CONV_V1"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v == 1;
-}
+static bool use_v1() { return rg_option("conv_v1", 0) == 1; }
 
 // split-K policy of the DMA kernel: only when the grid cannot fill the chip (< 1 block per CU) and K is long
 // tile variant / split-K decision of the DMA kernel, shared by the launcher and by rg_mfma_conv_stats_rows
-struct GPlan { bool narrow, wide; int nsplit; };
+struct GPlan { bool narrow, wide; int nsplit; bool c8; int bm, bn; };
 
 static int gather_split(int M, int Ncols, int nclass, int nkt, bool allow, int cap = 4, int min_kt = 16) {
   if (!allow) return 1;
@@ -1177,10 +1113,35 @@ static int gather_split(int M, int Ncols, int nclass, int nkt, bool allow, int c
 // the tile saves): RNAGAN_CONV_TILE=0 disables it, =5 forces it wherever it fits (with split-K).
 // Split-K: conv outputs up to 4 splits; dense weight-streaming layers (M = batch) up to 16 (HBM-bound, the grid
 // must cover all CUs to pull full bandwidth); none when a mask is fused into the bf16 epilogue.
-static GPlan gather_plan(bool bf16_out, int M, int Ncols, int nkt, int nclass, bool masked) {
-  static int variant = -1;
-  if (variant < 0) { const char* e = getenv("RNAGAN_CONV_TILE"); variant = e ? atoi(e) : 1; }
-  GPlan pl;
+// c8: the 8-wave ping-pong kernel of rg_conv8.hip (256x256 or 512x128 tiles) takes the bf16-output conv / plain
+// GEMMs whose shape it supports (RNAGAN_CONV8=0: off).
+static int conv8_mode() { return rg_option("conv8", 1); }
+static int conv8_blocks_target() { return rg_option("conv8_blocks", 256); }
+
+static GPlan gather_plan(int mode, bool bf16_out, int M, int Ncols, int Cin, int taps, int nclass, bool masked) {
+  const int variant = rg_option("conv_tile", 1);
+  const int nkt = taps * (Cin >> 6);
+  GPlan pl{};
+  const int cpt = Cin >> 6;
+  if (conv8_mode() && bf16_out && (mode == MODE_DOWN || mode == MODE_UP || mode == MODE_PLAIN) &&
+      (taps == 1 || rg_is_pow2(cpt))) {
+    int bm = 0, bn = 0;
+    if (Ncols % 256 == 0 && M >= 256) { bm = 256; bn = 256; }
+    else if (Ncols % 128 == 0 && M >= 512) { bm = 512; bn = 128; }
+    if (bm && nkt >= 4 && nkt % 2 == 0) {
+      const long long tiles = (long long)((M + bm - 1) / bm) * (Ncols / bn) * nclass;
+      int ns = 1;
+      if (!masked)
+        while (tiles * ns < conv8_blocks_target() && ns < 8 && nkt % (ns * 4) == 0 && nkt / (ns * 2) >= 8) ns *= 2;
+      // conv8 = 1: only where the tile count fills the chip without split-K (measured at batch 64: with split-K the
+      // fp32 slabs of a 256x256 tile cost more than the pipeline gains; the 128x128 2-stage kernel splits less);
+      // conv8 & 4: also with split-K
+      if (ns == 1 || (conv8_mode() & 4)) {
+        pl.c8 = true; pl.bm = bm; pl.bn = bn; pl.nsplit = ns;
+        return pl;
+      }
+    }
+  }
   pl.narrow = Ncols <= 64;
   const long long tiles256 = (long long)((M + 255) / 256) * ((Ncols + 255) / 256) * nclass;
   pl.wide = !pl.narrow && bf16_out && M >= 256 && Ncols >= 256 && Ncols % 256 == 0 &&
@@ -1196,9 +1157,9 @@ static GPlan gather_plan(bool bf16_out, int M, int Ncols, int nkt, int nclass, b
   return pl;
 }
 
-size_t rg_mfma_gather_ws_bytes(int M_out_rows, int M, int Ncols, int nclass, int nkt) {
-  int s = gather_split(M, Ncols, nclass, nkt, true);
-  return s > 1 ? (size_t)s * M_out_rows * Ncols * sizeof(float) : 0;
+size_t rg_mfma_gather_ws_bytes(int mode, int M_out_rows, int M, int Ncols, int Cin, int taps, int nclass) {
+  const GPlan pl = gather_plan(mode, true, M, Ncols, Cin, taps, nclass, false);
+  return pl.nsplit > 1 ? (size_t)pl.nsplit * M_out_rows * Ncols * sizeof(float) : 0;
 }
 
 
@@ -1207,8 +1168,9 @@ int rg_mfma_conv_stats_rows(int up, int N, int Hlow, int Wlow, int O, int I) {
   const int M = N * Hlow * Wlow, Ncols = up ? I : O, Cin = up ? O : I, taps = up ? 4 : 16, nclass = up ? 4 : 1;
   const size_t a_bytes = up ? (size_t)M * O * 2 : (size_t)M * 4 * I * 2, b_bytes = (size_t)O * 16 * I * 2;
   if (use_v1() || a_bytes >= 0x7fffff00ull || b_bytes >= 0x7fffff00ull) return 0;
-  GPlan pl = gather_plan(true, M, Ncols, taps * (Cin >> 6), nclass, false);
+  GPlan pl = gather_plan(up ? MODE_UP : MODE_DOWN, true, M, Ncols, Cin, taps, nclass, false);
   if (pl.nsplit > 1) return 0;
+  if (pl.c8) return nclass * ((M + pl.bm - 1) / pl.bm) * (pl.bm / 128);
   const int bmm = (pl.narrow || pl.wide) ? 256 : 128, parts = pl.narrow ? 4 : 2;      // BM / wave-tile rows
   return nclass * ((M + bmm - 1) / bmm) * parts;
 }
@@ -1218,8 +1180,7 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
                           void* ws, size_t ws_bytes, hipStream_t st) {
   if (use_v1() || a_bytes >= 0x7fffff00ull || b_bytes >= 0x7fffff00ull) return launch_gather<MODE, EPI>(name, g, nclass, st);
   G2Args a2{};
-  const int nkt = g.taps * (g.Cin >> 6);
-  const GPlan pl = gather_plan(EPI == EPI_BF16, g.M, g.Ncols, nkt, nclass, g.mask != nullptr);
+  const GPlan pl = gather_plan(MODE, EPI == EPI_BF16, g.M, g.Ncols, g.Cin, g.taps, nclass, g.mask != nullptr);
   const bool narrow = pl.narrow, wide = pl.wide;
   int nsplit = pl.nsplit;
   size_t need = (size_t)nsplit * rows_out * (EPI == EPI_BF16 ? g.Ncols : g.ldc) * sizeof(float);
@@ -1229,25 +1190,27 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   a2.nsplit = nsplit; a2.slab = (float*)ws; a2.slab_stride = rows_out * (EPI == EPI_BF16 ? g.Ncols : g.ldc);
   // weight-streaming GEMMs (a batch of <= 64 rows against a large weight matrix: betaVAE layers, G.0): 64-row tile with a
   // 3-deep DMA ring -- the bound is HBM latency x bytes in flight, not the matrix cores (RNAGAN_STREAM_TILE=0: off)
-  static int stream_tile = -1;
-  if (stream_tile < 0) { const char* e = getenv("RNAGAN_STREAM_TILE"); stream_tile = e ? atoi(e) : 1; }
+  const int stream_tile = rg_option("stream_tile", 1);
   const bool stream = stream_tile && EPI == EPI_LINEAR && MODE == MODE_PLAIN && g.M <= 64 && !narrow;
-  const int bn = narrow ? 64 : wide ? 256 : 128, bmm = stream ? 64 : (narrow || wide) ? 256 : 128;
+  const bool c8 = pl.c8 && nsplit == pl.nsplit;      // (a missing split-K workspace falls back to the 2-stage kernel)
+  const int bn = c8 ? pl.bn : narrow ? 64 : wide ? 256 : 128, bmm = c8 ? pl.bm : stream ? 64 : (narrow || wide) ? 256 : 128;
   g.tiles_n = (g.Ncols + bn - 1) / bn;
   a2.g = g;
   a2.tiles_m = (g.M + bmm - 1) / bmm;
   dim3 grid(((g.M + bmm - 1) / bmm) * g.tiles_n, nclass, nsplit);
-  static int xcd = -1;
-  if (xcd < 0) { const char* e = getenv("RNAGAN_XCD"); xcd = e ? atoi(e) : 1; }
-  static int cfast = -1;
-  if (cfast < 0) { const char* e = getenv("RNAGAN_CLASS_FAST"); cfast = e ? atoi(e) : 1; }
-  if (MODE == MODE_UP && nclass == 4 && cfast && a_bytes > b_bytes && !wide) {   // (measured: -4 % on the 256x256 tile)
+  const int xcd = rg_option("xcd", 1), cfast = rg_option("class_fast", 1);
+  if (MODE == MODE_UP && nclass == 4 && cfast && a_bytes > b_bytes && !wide && (!c8 || conv8_mode() & 2)) {   // (measured: -4 % on the 256x256 tile)
     a2.class_fast = 1;
     grid = dim3(grid.x * 4, 1, nsplit);
   }
   a2.xcd_swizzle = (xcd && grid.x % 8 == 0 && grid.x >= 16 && (xcd == 2 || a_bytes > b_bytes)) ? 1 : 0;
   // (measured and rejected for the 64-column tile: 2 waves with 128 x 64 wave tiles, 147-154 us vs 109-112 us)
-  if (stream) {
+  if (c8) {
+    a2.lgcpt = g.taps == 1 ? 30 : rg_ilog2(g.Cin >> 6);
+    a2.cmask = g.taps == 1 ? 0x3fffffff : (g.Cin >> 6) - 1;
+    if constexpr (EPI == EPI_BF16 && (MODE == MODE_DOWN || MODE == MODE_UP || MODE == MODE_PLAIN))
+      rg_conv8_launch(MODE, &a2, pl.bm, grid.x, grid.y, grid.z, st);
+  } else if (stream) {
     if constexpr (EPI == EPI_LINEAR && MODE == MODE_PLAIN)
       hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 64, 128, 3, 128>), grid, dim3(128), 0, st, a2);
   } else if (narrow) {
@@ -1298,8 +1261,8 @@ int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int 
 
 size_t rg_mfma_conv_ws_bytes(int up, int N, int Hlow, int Wlow, int O, int I) {
   int M = N * Hlow * Wlow;
-  if (up) return rg_mfma_gather_ws_bytes(M * 4, M, I, 4, 4 * (O >> 6));
-  return rg_mfma_gather_ws_bytes(M, M, O, 1, 16 * (I >> 6));
+  if (up) return rg_mfma_gather_ws_bytes(MODE_UP, M * 4, M, I, O, 4, 4);
+  return rg_mfma_gather_ws_bytes(MODE_DOWN, M, M, O, I, 16, 1);
 }
 
 int rg_mfma_gemm_plain(const void* a, const void* bt, void* c, int M, int K, int Ncols, int ldc, hipStream_t st) {
@@ -1365,8 +1328,7 @@ int rg_mfma_conv_wgrad(const void* low, const void* high, float* dw, int N, int 
 
 static int mfma_wgrad_split_k(int K, int O, int I) {
   // 2 blocks are resident per CU: a grid of 512 (or a multiple) fills the 256 CUs without a half-empty last round
-  static int target = -1;
-  if (target < 0) { const char* e = getenv("RNAGAN_WGRAD_BLOCKS"); target = e ? atoi(e) : 512; }
+  const int target = rg_option("wgrad_blocks", 512);
   int tiles = (O / 128) * (16 * I / 128);
   int want = (target + tiles - 1) / tiles;
   int maxs = K / 256;
@@ -1519,7 +1481,7 @@ bool rg_mfma_upconv3_supported(int N, int H, int W, int Cin, int Cout) {
 }
 size_t rg_mfma_upconv3_fwd_ws_bytes(int N, int H, int W, int Cin, int Cout) {
   return rg_align_up((size_t)N * (2 * H + 2) * (2 * W + 2) * Cin * 2, 256) + rg_align_up((size_t)Cout * 9 * Cin * 2, 256) +
-         rg_mfma_gather_ws_bytes(N * 4 * H * W, N * 4 * H * W, Cout, 1, 9 * (Cin >> 6));
+         rg_mfma_gather_ws_bytes(MODE_C3, N * 4 * H * W, N * 4 * H * W, Cout, Cin, 9, 1);
 }
 int rg_mfma_upconv3_fwd(const void* x, const float* w, const float* bias, void* y, int N, int H, int W, int Cin,
                         int Cout, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -1658,7 +1620,7 @@ bool rg_mfma_upconv3_bwd_supported(int N, int H, int W, int Cin, int Cout) {
 size_t rg_mfma_upconv3_bwd_ws_bytes(int N, int H, int W, int Cin, int Cout) {
   const int Mp = N * (2 * H + 2) * (2 * W + 2);
   return rg_align_up((size_t)Mp * Cin * 2, 256) + rg_align_up((size_t)Cout * 9 * Cin * 2, 256) +
-         rg_mfma_gather_ws_bytes(Mp, Mp, Cin, 1, 9 * (Cout >> 6));
+         rg_mfma_gather_ws_bytes(MODE_C3T, Mp, Mp, Cin, Cout, 9, 1);
 }
 int rg_mfma_upconv3_bwd_data(const void* gy, const float* w, void* gx, int N, int H, int W, int Cin, int Cout, void* ws,
                              size_t ws_bytes, hipStream_t st) {
