@@ -20,8 +20,11 @@ ranks, rank 0 prints ONE JSON line.  Extra objects:
                  hard-coded batch size).
 """
 import argparse
+import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -58,7 +61,7 @@ def conv_flops_per_image(in_size=256, step=64, enc=2048):
 def build(device, precision, batch, rna_features, seed, gan_type="dcgan"):
     import torch.nn as nn
     import rna_gan_amd as P
-    from oracle import ref_cpu as R          # seeded weight / input generators only
+    from rna_gan_amd import synth as R       # seeded weight / input generators
     gen_cls = P.DCGANUpGenerator if gan_type == "dcgan_up" else P.DCGANGenerator
     G = gen_cls(2048, 256, 3, 64, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
     D = P.DCGANDiscriminator(256, 3, 64, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.LeakyReLU(0.2))
@@ -90,7 +93,7 @@ _T0 = time.perf_counter()
 _DEFAULT_THREADS = 1
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -107,43 +110,90 @@ def main():
     ap.add_argument("--gan-type", default="dcgan", choices=["dcgan", "dcgan_up"],
                     help="dcgan = the reference CLI's generator (the benchmark); dcgan_up = src/dcgan.py's resize-convolution "
                          "generator (diagnostic: implies --no-roofline --no-cpu-baseline)")
-    args = ap.parse_args()
+    ap.add_argument("--api-path", action="store_true",
+                    help="time the drop-in API instead of the kernel pipeline: Trainer.train_iter() -> the three train_ops "
+                         "with their .item() host syncs, a fresh uint8 batch per iteration normalised on the device "
+                         "(reported under config.api_path; the headline number is the default mode)")
+    ap.add_argument("--step-plugin", default=None,
+                    help="TEST HOOK module:function -- replaces the HIP workload by function(args, rank, world, device) -> "
+                         "(one_step, flush, items_per_rank_step, info); lets tests/ run the launcher and the timing "
+                         "protocol on CPU ranks (gloo).  Never used for a reported number.")
+    args = ap.parse_args(argv)
     if args.gan_type != "dcgan":
         args.no_roofline = args.no_cpu_baseline = True
+    return args
 
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` outside torchrun: this process becomes the launcher.  It starts N fresh rank
+    processes of this script (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; it has not touched the GPU
+    itself), relays rank 0's JSON line and exits non-zero if any rank fails (the other ranks are then stopped by PID)."""
+    n = args.gpus
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    out0 = b""
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                p = procs[r]
+                if r == 0 and p.stdout is not None:
+                    try:
+                        o, _ = p.communicate(timeout=0.2)
+                        out0 += o or b""
+                    except subprocess.TimeoutExpired:
+                        continue
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    rc = rc or code
+                    log("rank %d exited with code %d: stopping the other ranks" % (r, code))
+                    for q in pending:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return rc
+
+
+def hip_workload(args, rank, world, device):
+    """The product path: G / D / three loss plugins on `device`, synthetic inputs resident in HBM."""
     from rna_gan_amd import dist as D_
-    from rna_gan_amd import losses as PL
-    from oracle import ref_cpu as R
-    global _DEFAULT_THREADS
-    _DEFAULT_THREADS = torch.get_num_threads()
-    torch.set_num_threads(min(8, _DEFAULT_THREADS))   # GPU leg: the host only draws noise
-    D_.set_sync_stats(args.sync_stats)
-    D_.init_from_env()
-    rank, world = D_.rank(), D_.world_size()
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
-
+    from rna_gan_amd import synth as R
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py measures the HIP path: an MI355X is required (there is no CPU fallback)")
     N = args.batch
     rna_features = 19198
     G, Dm, og, od, (lg, ld, lp) = build(device, args.precision, N, rna_features, args.seed, args.gan_type)
     for mod in (G, Dm):
         for t in list(mod.parameters()) + list(mod.buffers()):
             D_.broadcast_(t.data, 0)
-
-    # synthetic inputs, resident in HBM before the timed region
     real = R.synthetic_images(N, 256, seed=1234 + rank).to(device)
     rna = R.synthetic_rna(N, rna_features, seed=4321 + rank, distinct=16).to(device)
     gen = torch.Generator(device="cpu").manual_seed(args.seed + rank)
     ops, _ = G.runtime()
-
-    def draw_u():
-        # U(-0.3, 0.3) on the CPU generator (src/wgan_loss.py:100), written in place into a pinned
-        # buffer so that the H2D copy is asynchronous and the host can run ahead of the GPU
-        return u_ring.draw(lambda b: b.uniform_(-0.3, 0.3, generator=gen))
-
-    def draw_eps():
-        return e_ring.draw(lambda b: b.uniform_(0.0, 1.0, generator=gen))
 
     class PinnedRing:
         """Fixed set of pinned staging buffers for the per-train_op host draws.  The host runs many steps ahead
@@ -169,18 +219,108 @@ def main():
 
     u_ring, e_ring = PinnedRing((N, 2048)), PinnedRing((1,))
 
+    def draw_u():
+        # U(-0.3, 0.3) on the CPU generator (src/wgan_loss.py:100), written in place into a pinned
+        # buffer so that the H2D copy is asynchronous and the host can run ahead of the GPU
+        return u_ring.draw(lambda b: b.uniform_(-0.3, 0.3, generator=gen))
+
+    def draw_eps():
+        return e_ring.draw(lambda b: b.uniform_(0.0, 1.0, generator=gen))
+
+    if args.api_path:
+        one_step, api_info = api_path_step(args, G, Dm, og, od, (lg, ld, lp), device, rank)
+    else:
+        api_info = None
+
+        def one_step():
+            # the three train_ops of src/wgan_loss.py:82-129,181-263,314-389 in Trainer order, through the
+            # loss plugins' step() (= train_ops without the final .item() host sync): per train_op a fresh
+            # uniform draw on the CPU generator, a betaVAE encode, and eps ~ U(0,1) for the penalty
+            return [lg.step(G, Dm, og, rna, draw_u()),
+                    ld.step(G, Dm, od, real, rna, draw_u()),
+                    lp.step(G, Dm, od, real, rna, draw_u(), draw_eps())]
+
+    info = {"ops": ops, "rna_features": rna_features, "api_path": api_info,
+            "workload": "RNA-GAN lung (betaVAE-conditioned wganvae path) 256x256, %s enc2048/step64, "
+                        % ("DCGAN" if args.gan_type == "dcgan" else "DCGANUpGenerator + DCGAN discriminator") +
+                        "per-GPU batch %d, one iteration = G-loss + D-loss + GP steps" % N}
+    return one_step, D_.flush, N, info
+
+
+def api_path_step(args, G, Dm, og, od, losses, device, rank):
+    """--api-path: one iteration as a user of the reference CLI gets it (src/histopathology_gan.py:298-314): the
+    Trainer's per-batch body -- real_inputs = the loader's dict batch, then every loss's train_ops resolved by
+    argument name, each ending in .item() -- fed with a FRESH uint8 tile batch per iteration (pinned host memory ->
+    H2D as uint8 -> rg_u8_to_norm on the device, the a15 input contract of :106-109)."""
+    import rna_gan_amd as P
+    from rna_gan_amd import synth as R
+    N = args.batch
+    pool = [R.synthetic_tiles_u8(N, 256, seed=1234 + rank + 17 * k).pin_memory() for k in range(4)]
+    rna = R.synthetic_rna(N, 19198, seed=4321 + rank, distinct=16).pin_memory()
+    trainer = P.Trainer.__new__(P.Trainer)       # the loop body only: models / optimizers are the ones built above
+    trainer.device = device
+    trainer.generator, trainer.discriminator = G, Dm
+    trainer.optimizer_generator, trainer.optimizer_discriminator = og, od
+    trainer.losses = {type(l).__name__: l for l in losses}
+    trainer.loss_logs = {name: [] for name in trainer.losses}
+    trainer.loss_information = {"generator_losses": 0.0, "discriminator_losses": 0.0, "generator_iters": 0,
+                                "discriminator_iters": 0}
+    trainer.ncritic = 1
+    trainer.batch_size = N
+    trainer.labels = None
+    trainer._store_loss_maps()
+    ops, _ = G.runtime()
+    k = [0]
+
     def one_step():
-        # the three train_ops of src/wgan_loss.py:82-129,181-263,314-389 in Trainer order, through the
-        # loss plugins' step() (= train_ops without the final .item() host sync): per train_op a fresh
-        # uniform draw on the CPU generator, a betaVAE encode, and eps ~ U(0,1) for the penalty
-        return [lg.step(G, Dm, og, rna, draw_u()),
-                ld.step(G, Dm, od, real, rna, draw_u()),
-                lp.step(G, Dm, od, real, rna, draw_u(), draw_eps())]
+        u8 = pool[k[0] % len(pool)].to(device, non_blocking=True)
+        k[0] += 1
+        trainer.real_inputs = {"image": ops.u8_to_norm(u8), "rna_data": rna, "labels": None}
+        trainer.train_iter()
+        return [torch.tensor(trainer.loss_logs[name][-1]) for name in trainer.losses]
+
+    return one_step, {"host_syncs_per_iteration": 3, "input": "uint8 tiles, pinned host -> device, normalised by "
+                                                              "rg_u8_to_norm", "loop": "Trainer.train_iter"}
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+
+    from rna_gan_amd import dist as D_
+    global _DEFAULT_THREADS
+    _DEFAULT_THREADS = torch.get_num_threads()
+    torch.set_num_threads(min(8, _DEFAULT_THREADS))   # GPU leg: the host only draws noise
+    D_.set_sync_stats(args.sync_stats)
+    use_cuda = torch.cuda.is_available()
+    D_.init_from_env()
+    rank, world = D_.rank(), D_.world_size()
+    if world != max(args.gpus, 1):
+        raise SystemExit("bench.py: --gpus %d but the process group has %d rank(s): launch with torchrun "
+                         "--nproc-per-node %d, or run `python bench.py --gpus %d` (it starts the ranks itself)"
+                         % (args.gpus, world, args.gpus, args.gpus))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
+    if use_cuda:
+        torch.cuda.set_device(device)
+
+    if args.step_plugin:
+        mod, fn = args.step_plugin.split(":")
+        one_step, flush, N, info = getattr(importlib.import_module(mod), fn)(args, rank, world, device)
+        args.no_roofline = args.no_cpu_baseline = True
+    else:
+        one_step, flush, N, info = hip_workload(args, rank, world, device)
+
+    def sync():
+        if use_cuda:
+            torch.cuda.synchronize(device)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize(device)
+        sync()
 
     # HIP-graph capture phase (part of building the step, like a compiler's first run): the loss plugins run a
     # train_op eagerly twice per launch-sequence variant and capture it on the third call; the very first
@@ -190,12 +330,12 @@ def main():
     # transient, see --trace-steps; it moves with the start of continuous load, not with the iteration count), so
     # 40 priming iterations (~0.7 s) are run before the W warm-up steps.
     from rna_gan_amd import graphed as _gr
-    prime = 40 if _gr.ENABLED else 1
-    log("models built; %d priming iterations (graph capture)" % prime)
+    prime = 0 if args.step_plugin else (40 if _gr.ENABLED else 1)
+    log("workload built; %d priming iterations (graph capture)" % prime)
     for it in range(prime):
         one_step()
         if os.environ.get("RNAGAN_GRAPH_DEBUG"):
-            torch.cuda.synchronize(device); log("priming iteration %d done" % it)
+            sync(); log("priming iteration %d done" % it)
     barrier()
     log("warm-up (%d steps)" % args.warmup)
     for _ in range(args.warmup):
@@ -206,15 +346,15 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ls = one_step()
-        if args.trace_steps:
+        if args.trace_steps and use_cuda:
             e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e)
-    D_.flush()            # data parallel: the last train_op's all-reduce + optimizer step belong to the timed work
+    flush()               # data parallel: the last train_op's all-reduce + optimizer step belong to the timed work
     barrier()
     dt = time.perf_counter() - t0
-    if args.trace_steps and rank == 0:
+    if args.trace_steps and rank == 0 and evs:
         log("per-step ms (GPU events): " + " ".join("%.2f" % evs[i - 1].elapsed_time(evs[i]) for i in range(1, len(evs))))
-    last_losses = [float(l.item()) for l in ls]
-    out_graphs = bool(_gr.ENABLED)
+    last_losses = [float(l.item()) for l in ls] if ls is not None else None
+    out_graphs = bool(_gr.ENABLED) and not args.step_plugin
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -223,26 +363,33 @@ def main():
     value = N * world * args.steps / dt
     log("timed region: %.3f ms/step, %.1f imgs/s" % (ms_per_step, value))
 
+    backend = torch.distributed.get_backend() if world > 1 or (torch.distributed.is_available() and
+                                                                torch.distributed.is_initialized()) else None
     out = {
         "metric": "training imgs/sec (G+D WGAN-GP step, 256x256)",
         "value": round(value, 2), "unit": "imgs/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": "RNA-GAN lung (betaVAE-conditioned wganvae path) 256x256, %s enc2048/step64, "
-                               % ("DCGAN" if args.gan_type == "dcgan" else "DCGANUpGenerator + DCGAN discriminator") +
-                               "per-GPU batch %d, one iteration = G-loss + D-loss + GP steps" % N,
-                   "global_batch": N * world, "parallelism": "dp%d" % world, "rna_features": rna_features,
+        "config": {"workload": info.get("workload", "plug-in step (test hook)"),
+                   "global_batch": N * world, "parallelism": "dp%d" % world,
+                   "ranks": world, "collective_backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend),
+                   "rna_features": info.get("rna_features"),
                    "losses_last_step": last_losses, "hip_graphs": out_graphs and not D_.sync_stats(),
                    "dp_statistics": "global (sync-stats)" if D_.sync_stats() else "rank-local (DDP)"},
     }
+    if info.get("api_path"):
+        out["config"]["api_path"] = info["api_path"]
+    if args.step_plugin:
+        out["config"]["step_plugin"] = args.step_plugin
 
     # the instrumented extra iteration contains collectives in a data-parallel run: every rank runs it
-    roof = None if args.no_roofline else measure_roofline(ops, device, one_step, ms_per_step)
-    D_.flush()
+    roof = None if args.no_roofline or args.api_path else measure_roofline(info["ops"], device, one_step, ms_per_step)
+    flush()
     if rank == 0:
-        fl = conv_flops_per_image()
-        total_flops_img = 5 * fl["G"] + 14 * fl["D"]        # 104.6 GFLOP / image / iteration
-        out["config"]["algorithmic_conv_tflops_whole_step"] = round(total_flops_img * value / world / 1e12, 2)
+        if not args.step_plugin:
+            fl = conv_flops_per_image()
+            total_flops_img = 5 * fl["G"] + 14 * fl["D"]        # 104.6 GFLOP / image / iteration
+            out["config"]["algorithmic_conv_tflops_whole_step"] = round(total_flops_img * value / world / 1e12, 2)
         if roof is not None:
             out["roofline"] = roof
         if not args.no_cpu_baseline and world == 1:
@@ -311,38 +458,44 @@ def pmc_traffic(family):
     """HBM bytes per launch of a kernel family from the committed rocprofv3 PMC summary (two separate --pmc passes,
     FETCH_SIZE doubled per the gfx950 correction; tools/pmc_traffic.py).  Counters cannot be read from inside
     this process, so the figure is the one measured on this workload (batch 64) when the profile was taken."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_hbm_traffic.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round2_pmc_hbm_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_hbm_traffic.json")
     try:
         with open(path) as f:
             row = json.load(f)[family]
-        return row["hbm_bytes_per_launch"], "profiles/round1_pmc_hbm_traffic.json (%d launches)" % row["launches"]
+        return row["hbm_bytes_per_launch"], "profiles/%s (%d launches)" % (os.path.basename(path), row["launches"])
     except (OSError, KeyError, ValueError, TypeError):
         return None, None
 
 
 def cpu_baseline(seed):
     """The oracle on the host cores: batch 8 (the reference's hard-coded batch size,
-    src/histopathology_gan.py:94), fp32.  The box's best intra-op thread count is found first (one
-    iteration each over a few candidates: torch's default of all SMT threads is far from optimal
-    on this host), then 2 iterations are timed at that setting.  Bounded to ~40 s."""
+    src/histopathology_gan.py:94), fp32, the wganvae path INCLUDING the three frozen-betaVAE encodes of an iteration
+    (src/wgan_loss.py:96-106).  The box's best intra-op thread count is found first (one iteration each over a few
+    candidates: torch's default of all SMT threads is far from optimal on this host), then 3 iterations are timed at
+    that setting.  Bounded to ~40 s."""
     import torch.nn as nn
     from oracle import ref_cpu as R
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    n = 8
+    n, rna_features = 8, 19198
     G = R.seeded_fill_(R.OracleDCGANGenerator(2048, 256, 3, 64, nonlinearity=nn.LeakyReLU(0.2),
                                               last_nonlinearity=nn.Tanh()), seed).train()
     D = R.seeded_fill_(R.OracleDCGANDiscriminator(256, 3, 64, nonlinearity=nn.LeakyReLU(0.2),
                                                   last_nonlinearity=nn.LeakyReLU(0.2)), seed + 1).train()
+    vae = R.seeded_fill_(R.OracleBetaVAE(rna_features, 2048, [6000, 4000, 2048], [4000, 6000]), seed + 2).eval()
     og, od = R.make_adam(G.parameters(), 1e-4), R.make_adam(D.parameters(), 4e-4)
     real = R.synthetic_images(n, 256, seed=1234)
+    rna = R.synthetic_rna(n, rna_features, seed=4321, distinct=16)
 
     def one(it):
-        noises = [R.conditioned_noise(R.synthetic_uniform(n, 2048, seed=10 * it + j),
-                                      R.synthetic_normal(n, 2048, seed=100 * it + j)) for j in range(3)]
+        us = [R.synthetic_uniform(n, 2048, seed=10 * it + j) for j in range(3)]
         t0 = time.perf_counter()
+        with torch.no_grad():
+            noises = [R.conditioned_noise(u, R.encode_latent(vae, rna)) for u in us]      # one encode per train_op
         R.train_iteration(G, D, og, od, real, noises, 0.5)
         return time.perf_counter() - t0
 
@@ -358,14 +511,14 @@ def cpu_baseline(seed):
             break
     best = min(trial, key=trial.get)
     torch.set_num_threads(best)
-    times = [one(10 + k) for k in range(2)]
+    times = [one(10 + k) for k in range(3)]
     t = sum(times) / len(times)
     log("cpu baseline: %d threads, %.2f s/iteration" % (best, t))
     return {"value": round(n / t, 3), "unit": "imgs/sec", "cores": best, "kind": "port",
-            "sample": "oracle/ref_cpu.py (PyTorch fp32 restatement of the reference path, betaVAE encode "
-                      "excluded: ~3%% of the reference's CPU time), batch 8, best of %s intra-op threads (%d host "
-                      "threads available), 2 timed iterations, %.2f s/iteration, torch %s"
-                      % (sorted(trial), avail, t, torch.__version__)}
+            "threads": "best of %s intra-op thread counts tried, %d host threads available" % (sorted(trial), avail),
+            "sample": "PyTorch fp32 restatement of the reference path incl. the 3 frozen-betaVAE encodes per "
+                      "iteration, batch 8, 3 timed iterations after a warm-up, %.2f s/iteration, torch %s"
+                      % (t, torch.__version__)}
 
 
 if __name__ == "__main__":

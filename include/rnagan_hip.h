@@ -382,6 +382,12 @@ int rg_latent_apply(const float* u, const float* z, const float* s, const float*
  * the input normalisation, transforms.Normalize(-mean/std, 1/std) with mean = std = 0.5) in NHWC order. */
 int rg_export_images_nhwc(const float* x_nchw, float* y_nhwc, int N, int C, int H, int W, void* stream);
 
+/* Input contract of the discriminator (src/histopathology_gan.py:106-109: ToTensor + Normalize(0.5, 0.5); dataset
+ * output src/read_data.py:339-342,366-370): dst[i] = ((float)src_u8[i] / 255 - mean) / std, element order unchanged
+ * (uint8 CHW tiles stay CHW).  The same three fp32 operations as the host transform: bit-identical to it.  Lets the
+ * loader hand over uint8 tiles (a quarter of the PCIe bytes) and normalise on the device. */
+int rg_u8_to_norm(const void* src_u8, float* dst, size_t n, float mean, float stdv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -103,6 +103,7 @@ PROTOTYPES = {
     "rg_widen_bf16": (_i, [_p, _p, _z, _p]),
     "rg_cast_pad": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "rg_selftest_layouts": (_i, [_p, _p]),
+    "rg_u8_to_norm": (_i, [_p, _p, _z, _f, _f, _p]),
 }
 
 _lib = None

@@ -548,6 +548,41 @@ extern "C" int rg_export_images_nhwc(const float* x_nchw, float* y_nhwc, int N, 
   return RG_OK;
 }
 
+// uint8 tile -> float / 255 -> (x - mean) / std, element order unchanged; the same three fp32 operations in the same
+// order as ToTensor + Normalize on the host, so the result is bit-identical to the reference's input transform.
+// 16 elements per thread: one 16-byte load, four 16-byte stores.
+__global__ void u8_to_norm_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, size_t n, float mean,
+                                  float stdv) {
+  const size_t n16 = n >> 4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+    const uint4 v = reinterpret_cast<const uint4*>(src)[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    float4* d = reinterpret_cast<float4*>(dst) + i * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float4 o;
+      o.x = ((float)(w[k] & 0xffu) / 255.0f - mean) / stdv;
+      o.y = ((float)((w[k] >> 8) & 0xffu) / 255.0f - mean) / stdv;
+      o.z = ((float)((w[k] >> 16) & 0xffu) / 255.0f - mean) / stdv;
+      o.w = ((float)(w[k] >> 24) / 255.0f - mean) / stdv;
+      d[k] = o;
+    }
+  }
+  // tail (n % 16 elements), first threads of block 0
+  const size_t tail0 = n16 << 4;
+  if (blockIdx.x == 0 && tail0 + threadIdx.x < n) dst[tail0 + threadIdx.x] = ((float)src[tail0 + threadIdx.x] / 255.0f - mean) / stdv;
+}
+extern "C" int rg_u8_to_norm(const void* src_u8, float* dst, size_t n, float mean, float stdv, void* stream) {
+  RG_REQUIRE(src_u8 && dst && stdv != 0.f, RG_EINVAL, "u8_to_norm: bad args");
+  RG_REQUIRE(((uintptr_t)src_u8 & 15) == 0 && ((uintptr_t)dst & 15) == 0, RG_EINVAL, "u8_to_norm: 16-byte aligned buffers required");
+  if (n == 0) return RG_OK;
+  hipLaunchKernelGGL(u8_to_norm_kernel, dim3(grid_for(n, 16)), dim3(256), 0, rg_stream(stream), (const uint8_t*)src_u8,
+                     dst, n, mean, stdv);
+  RG_LAUNCH_CHECK("u8_to_norm");
+  return RG_OK;
+}
+
 extern "C" int rg_widen_bf16(const void* src, float* dst, size_t n, void* stream) {
   RG_REQUIRE(src && dst, RG_EINVAL, "widen_bf16: bad args");
   if (n == 0) return RG_OK;

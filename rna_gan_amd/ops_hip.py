@@ -211,6 +211,14 @@ class HipOps:
                                     self.dt, int(accumulate), self.algo, _ptr(ws), ws.numel(), self.stream),
             "rg_conv_wgrad2"))
 
+    def u8_to_norm(self, u8, mean=0.5, std=0.5):
+        """uint8 tiles (any shape, CHW order kept) -> fp32 (x / 255 - mean) / std on the device: the input transform of
+        src/histopathology_gan.py:106-109, bit-identical to the host version."""
+        assert u8.dtype == torch.uint8 and u8.is_contiguous() and u8.is_cuda
+        y = self._f32(*u8.shape)
+        check(self.lib.rg_u8_to_norm(_ptr(u8), _ptr(y), u8.numel(), float(mean), float(std), self.stream), "rg_u8_to_norm")
+        return y
+
     def export_images_nhwc(self, img_nchw):
         """NCHW fp32 in [-1,1] -> NHWC fp32 in [0,1] (un-normalise + permute, src/gan_utils.py:236-241)."""
         N, C, H, W = img_nchw.shape

@@ -116,6 +116,65 @@ def test_conv_down_up_wgrad(N, Hi, Wi, I, O, dtype):
     check(ch.dw, 2 * cr.dw, TOL[dtype] * 2, "conv_wgrad2(accumulate)")
 
 
+CONV8_CASES = [
+    # N, Hi, Wi, I, O     (conv_down: M = N*Hi*Wi/4 rows, O columns, K = 16*I; conv_up: same M per class, I columns, K = 4*O)
+    (2, 32, 32, 64, 256),      # down: 256x256 tile, 2 whole row tiles, 16 k-tiles
+    (5, 16, 16, 128, 256),     # down: 256x256 tile with a ragged last row tile (320 rows), 32 k-tiles -> split-K when forced
+    (3, 32, 32, 64, 128),      # down: 512x128 tile, ragged (768 rows); up: 64 columns (not a conv8 shape)
+    (3, 32, 32, 128, 256),     # up: 512x128 tile (I = 128 columns), ragged, 16 k-tiles; down: 256x256
+    (2, 32, 32, 256, 128),     # up: 256x256 tile (I = 256 columns), 8 k-tiles; down: 512x128
+]
+
+
+@pytest.mark.parametrize("mfma", [16, 32])
+@pytest.mark.parametrize("mode", [1, 5, 7])
+@pytest.mark.parametrize("N,Hi,Wi,I,O", CONV8_CASES)
+def test_conv8_pingpong_kernel(N, Hi, Wi, I, O, mode, mfma):
+    """The 8-wave ping-pong conv kernel (rg_conv8.hip) forced on (conv8 = 5 / 7: also with split-K; 7: parity classes
+    fastest) at shapes that cover both tiles, both MFMA shapes, ragged row tiles, all four output-parity classes, the
+    fused LeakyReLU mask and the BatchNorm partial sums -- against the torch twin."""
+    from rna_gan_amd import _abi
+    lib = _abi.load()
+    dtype = torch.bfloat16
+    ref, hip = RefOps(dtype), _hip(dtype)
+    try:
+        _abi.check(lib.rg_set_option(b"conv8", mode), "rg_set_option")
+        _abi.check(lib.rg_set_option(b"conv8_mfma", mfma), "rg_set_option")
+        _abi.check(lib.rg_set_option(b"conv8_blocks", 8), "rg_set_option")      # small grids: split-K already at 8 tiles
+        w = rnd((O, I, 4, 4), 1, (2.0 / (I * 16)) ** 0.5)
+        cr, ch = cwpair_tm(w)
+        x = rnd((N, Hi, Wi, I), 2).to(dtype)
+        g = rnd((N, Hi // 2, Wi // 2, O), 3).to(dtype)
+        m = rnd((N, Hi, Wi, I), 21).to(dtype)
+        y, st = hip.conv_down(dev(x), ch, want_stats=True)
+        check(y, ref.conv_down(x, cr), TOL[dtype], "conv_down")
+        u, su = hip.conv_up(dev(g), ch, want_stats=True)
+        check(u, ref.conv_up(g, cr), TOL[dtype], "conv_up")
+        check(hip.conv_up(dev(g), ch, dev(m), 0.2), ref.conv_up(g, cr, m, 0.2), TOL[dtype], "conv_up(masked)")
+        for name, yy, ss in (("conv_down", y, st), ("conv_up", u, su)):
+            if ss is None:
+                continue
+            yf = yy.float().reshape(-1, yy.shape[-1])
+            check(ss[:, 0, :].sum(0), yf.sum(0), 1e-4, name + " epilogue sum")
+            check(ss[:, 1, :].sum(0), (yf * yf).sum(0), 1e-4, name + " epilogue sumsq")
+    finally:
+        for k in (b"conv8", b"conv8_mfma", b"conv8_blocks"):
+            lib.rg_set_option(k, -1)
+
+
+def test_u8_to_norm_bit_exact():
+    """a15 input contract (src/histopathology_gan.py:106-109): device-side uint8 -> (x / 255 - 0.5) / 0.5 equals the
+    host transform bit for bit, including a length that is not a multiple of 16."""
+    from rna_gan_amd import synth
+    hip = _hip(torch.bfloat16)
+    u8 = synth.synthetic_tiles_u8(3, 64, 11)
+    want = synth.synthetic_images(3, 64, 11)
+    got = hip.u8_to_norm(u8.cuda())
+    assert got.dtype == torch.float32 and torch.equal(got.cpu(), want)
+    allv = torch.arange(256, dtype=torch.uint8).repeat(3)[:-5].contiguous()        # every byte value, ragged length
+    assert torch.equal(hip.u8_to_norm(allv.cuda()).cpu(), (allv.float() / 255.0 - 0.5) / 0.5)
+
+
 @pytest.mark.parametrize("O,dtype,W", [(4, torch.float32, 32), (4, torch.bfloat16, 32), (64, torch.float32, 32),
                                        (64, torch.bfloat16, 32), (128, torch.bfloat16, 32),
                                        (64, torch.bfloat16, 128), (64, torch.bfloat16, 64)])   # last two: MFMA path
