@@ -47,6 +47,7 @@ class betaVAE(nn.Module):
         self.z_dim = z_dim
         self.precision = "bf16"
         self._plan = None
+        self._sig = None
         self._ops = None
         self._flat = None
         self._trt = None
@@ -129,6 +130,22 @@ class betaVAE(nn.Module):
                 plan.append((lin.weight.detach(), self._ops.pack_linear(lin.weight.detach()) if packed else None,
                              None, lin.bias.detach(), 1.0))
         self._plan = plan
+        # identity of the frozen encoder as the loss plugins see it (losses._LatentCache: the reference builds three
+        # copies from one checkpoint; copies with equal signatures produce equal latents): fp64 sum and the 2-norm
+        # of every folded operand, read back ONCE per plan
+        with torch.no_grad():
+            parts = []
+            for (w, _, scale, shift, slope) in plan[:-1]:
+                for t in (w, scale, shift):
+                    if t is not None:
+                        parts += [t.sum(dtype=torch.float64), torch.linalg.vector_norm(t.float()).double()]
+            self._sig = (self.precision,) + tuple(float(v) for v in torch.stack(parts).cpu())
+
+    def signature(self):
+        """Hashable fingerprint of the eval-mode encoder (weights, folded BatchNorm, precision)."""
+        if self._plan is None:
+            self._build_plan()
+        return self._sig
 
     def encode(self, x, mean_only=False):
         """(z_mean, z_log_var, x_encoded) as src/betaVAE.py:102-107, eval mode.  mean_only: skip z_log_var (returned as

@@ -148,6 +148,7 @@ class Trainer:
 
     def train_iter(self):
         lgen, ldis, gen_iter, dis_iter = 0.0, 0.0, 0, 0
+        L.new_batch()          # the conditioning latent is encoded once per batch and shared by the loss plugins
         for name, loss in self.losses.items():
             if isinstance(loss, L.GeneratorLoss) and isinstance(loss, L.DiscriminatorLoss):
                 raise NotImplementedError("joint generator/discriminator losses are not on the RNA-GAN path")
