@@ -86,8 +86,10 @@ def main():
 
     D_.set_sync_stats(bool(args.sync_stats))
     D_.init_from_env()
-    torch.manual_seed(args.seed + D_.rank())
-    np.random.seed(args.seed + D_.rank())
+    # every rank builds its replicas (G, D, and -- without a checkpoint file -- the betaVAE copies inside the three
+    # loss plugins) from the SAME seed; the per-rank offset is applied after construction, for noise / eps / data only
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
     with open(args.config) as f:
         config = json.load(f)
     if D_.rank() == 0:
@@ -135,6 +137,15 @@ def main():
                         recon=args.image_dir, device=device, precision=args.precision)
     if args.checkpoint is not None:
         trainer.load_model(load_path=args.checkpoint)
+    for loss in losses:                                   # identical frozen encoders on every rank (rank 0's)
+        bv = getattr(loss, "betavae", None)
+        if bv is not None and D_.world_size() > 1:
+            bv.to(device)
+            for t in list(bv.parameters()) + list(bv.buffers()):
+                D_.broadcast_(t.data, 0)
+            bv.weights_changed()
+    torch.manual_seed(args.seed + D_.rank())
+    np.random.seed(args.seed + D_.rank())
     trainer(loader)
     D_.flush()                     # data parallel: apply a trailing optimizer step before the process group goes away
     if torch.distributed.is_available() and torch.distributed.is_initialized():

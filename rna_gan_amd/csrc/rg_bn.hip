@@ -318,8 +318,10 @@ struct StatsFinalizeFin {
   float* mean; float* invstd; float* rmean; float* rvar; int64_t* nbt;
   __device__ void operator()(int c, const float* s) const {
     if (c == 0 && nbt) *nbt += 1;
-    float mu = s[0] / m;
-    float var = fmaxf(s[1] / m - mu * mu, 0.f);
+    // E[x^2] - E[x]^2 formed in double: the subtraction itself must not add to the cancellation when |mean| >> std
+    const double mud = (double)s[0] / (double)m;
+    const float mu = (float)mud;
+    const float var = (float)fmax((double)s[1] / (double)m - mud * mud, 0.0);
     mean[c] = mu;
     invstd[c] = rsqrtf(var + eps);
     if (rmean) {
@@ -597,8 +599,9 @@ __global__ void bn_finalize_kernel(const float* sum, const float* sumsq, int M, 
   if (c == 0 && nbt) *nbt += 1;
   if (c >= C) return;
   float m = (float)M;
-  float mu = sum[c] / m;
-  float var = fmaxf(sumsq[c] / m - mu * mu, 0.f);
+  const double mud = (double)sum[c] / (double)m;
+  const float mu = (float)mud;
+  const float var = (float)fmax((double)sumsq[c] / (double)m - mud * mud, 0.0);
   mean[c] = mu;
   invstd[c] = rsqrtf(var + eps);
   if (rmean) {

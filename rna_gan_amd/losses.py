@@ -246,6 +246,8 @@ class _Runner:
     """Executes a step body eagerly for the first calls, then from a captured HIP graph
     (rna_gan_amd.graphed.StepGraph).  One graph per (body, modules, optimizer, input shapes)."""
 
+    MAX_GRAPHS = 24
+
     def __init__(self):
         self._graphs = {}
         self._pre = {}
@@ -295,14 +297,25 @@ class _Runner:
             return None
         if stepped is None:
             stepped = [o._module for o in optimizers if getattr(o, "_module", None) is not None]
-        # the launch sequence depends on which packed weights are stale: one graph per pattern
+        hip_opts = [o for o in optimizers if hasattr(o, "note_replayed")]
+        if len(hip_opts) != len(optimizers):
+            return None                     # a foreign optimizer keeps host-side state: no capture
+        for o in hip_opts:
+            o._ensure()                     # moment / step buffers exist (and their generation is final) before keying
+        # A captured graph freezes (a) the launch sequence, which depends on which packed weights are stale, (b) the raw
+        # addresses of the flat parameter / gradient / shadow buffers and of Adam's moment / step buffers, (c) the
+        # optimizer hyper-parameters passed as kernel arguments.  All three are part of the key: a re-homed module
+        # (.to(), load into new storage), re-allocated optimizer state or a scheduler's new lr gets a new graph
+        # instead of replaying one that updates freed buffers or steps with the old lr.
         key = key + tuple(tuple(t.shape) for t in inputs) + tuple(id(m) for m in modules) + \
-            tuple(id(o) for o in optimizers) + tuple(int(m.packs_stale()) for m in modules)
+            tuple(id(o) for o in optimizers) + tuple(int(m.packs_stale()) for m in modules) + \
+            tuple(m.flat.gen for m in modules) + \
+            tuple((o.buf_gen, float(o.param_groups[0]["lr"]), tuple(float(b) for b in o.param_groups[0]["betas"]),
+                   float(o.param_groups[0]["eps"]), float(o.param_groups[0].get("weight_decay", 0.0))) for o in hip_opts)
         sg = self._graphs.get(key)
         if sg is None:
-            hip_opts = [o for o in optimizers if hasattr(o, "note_replayed")]
-            if len(hip_opts) != len(optimizers):
-                return None                 # a foreign optimizer keeps host-side state: no capture
+            while len(self._graphs) >= self.MAX_GRAPHS:          # e.g. one lr value per epoch under a scheduler
+                self._graphs.pop(next(iter(self._graphs)))
             sg = self._graphs[key] = graphed.StepGraph(fn, inputs, modules, hip_opts, stepped)
         return sg
 

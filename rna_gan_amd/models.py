@@ -39,9 +39,15 @@ class FlatParams:
     all-reduce runs on a few large contiguous buckets.  Parameters stay ordinary nn.Parameters
     (views), so state_dict / load_state_dict / .parameters() behave as usual."""
 
+    _GEN = [0]
+
     def __init__(self, module: nn.Module):
         params = [p for p in module.parameters()]
         dev = params[0].device
+        # generation of this re-homing: captured HIP graphs hold the raw addresses of data / grad / shadow, so the
+        # graph cache keys carry it (losses._Runner) and a rebuilt FlatParams never replays an older graph
+        FlatParams._GEN[0] += 1
+        self.gen = FlatParams._GEN[0]
         self.numel = sum(p.numel() for p in params)
         pad = (-self.numel) % 4
         dt = params[0].dtype          # fp32 in the product; tests of the DP glue run the engine in fp64
@@ -188,6 +194,13 @@ class _HipModule(nn.Module):
 
     def _apply(self, fn, *a, **k):
         r = super()._apply(fn, *a, **k)
+        # .to(same device) / .cuda() on a module that already lives there (gan_utils.generate_images does it on every
+        # call) leaves every parameter in place: keep the flat buffers, the engine view and with them every captured
+        # graph.  Only a real move / cast re-homes.
+        flat = self._rt_flat
+        if flat is not None and next(self.parameters()).device == flat.data.device and \
+                next(self.parameters()).dtype == flat.data.dtype and flat.owns(self):
+            return r
         self._rt_ops = None
         self._rt_net = None
         self._rt_flat = None

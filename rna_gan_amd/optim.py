@@ -32,10 +32,20 @@ class Adam(torch.optim.Adam):
         self._step_dev = None      # int32[1] on the device
         self._hyper = None         # float32[8] on the device
         self._host_steps = 0       # number of steps enqueued/replayed so far (mirror of *_step_dev)
+        self.buf_gen = 0           # bumped whenever the moment / step buffers are re-allocated (part of the graph keys)
         self.grad_wire = None      # data parallel, bf16 wire: the all-reduced bf16 gradient buffer to step from
 
     def bind(self, module):
-        """Tell the optimizer which HIP module owns its parameters (done by the Trainer)."""
+        """Tell the optimizer which HIP module owns its parameters (done by the Trainer).  The fused step updates the
+        module's WHOLE flat buffer with param_groups[0]'s hyper-parameters, so the optimizer must hold exactly one
+        group with every (trainable) parameter of the module."""
+        mine = {id(p) for g in self.param_groups for p in g["params"]}
+        theirs = list(module.parameters())
+        if len(self.param_groups) != 1 or mine != {id(p) for p in theirs}:
+            raise ValueError("rna_gan_amd.optim.Adam: one param group holding exactly module.parameters() is required "
+                             "(the fused kernel steps the module's whole flat buffer)")
+        if not all(p.requires_grad for p in theirs):
+            raise ValueError("rna_gan_amd.optim.Adam: frozen parameters (requires_grad=False) are not supported")
         self._module = module
         return self
 
@@ -61,6 +71,7 @@ class Adam(torch.optim.Adam):
             self._step_dev = torch.tensor([step0], dtype=torch.int32, device=flat.data.device)
             self._hyper = torch.zeros(8, dtype=torch.float32, device=flat.data.device)
             self._flat_id = flat
+            self.buf_gen += 1
         return flat
 
     def _sync_step_state(self):
@@ -77,13 +88,33 @@ class Adam(torch.optim.Adam):
         from . import dist as D_
         D_.flush()
         super().load_state_dict(state_dict)
-        self._flat_id = None      # re-home the loaded moments into the flat buffers at next use
+        flat = self._flat_id
+        if flat is None or self._module is None or self._module._rt_flat is not flat:
+            self._flat_id = None  # not homed yet (or the module was re-homed): done at next use by _ensure()
+            return
+        # already homed (Trainer.load_model after training has started): copy the loaded moments INTO the existing flat
+        # buffers -- captured graphs hold their addresses -- and point the per-parameter state back at the views
+        step0 = 0
+        with torch.no_grad():
+            for p, (off, n) in zip(flat.params, flat.offsets):
+                st = self.state.get(p) or {}
+                m, v = _flat_view(self._m, off, n, p), _flat_view(self._v, off, n, p)
+                if "exp_avg" in st:
+                    m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
+                else:
+                    m.zero_(); v.zero_()
+                step0 = max(step0, int(float(st.get("step", 0))))
+                self.state[p] = {"step": torch.tensor(float(step0)), "exp_avg": m, "exp_avg_sq": v}
+            self._step_dev.fill_(step0)
+        self._host_steps = step0
 
     def zero_grad(self, set_to_none: bool = False):
         # gradients are written (not accumulated) by the first backward of every step; the views are kept.
         # set_to_none=True (train_betaVAE's call, src/betaVAE.py:221) asks for "no stale gradient", which the
         # overwrite semantics already give: no 4 B/parameter memset
         if self._module is not None and not set_to_none:
+            from . import dist as D_
+            D_.flush()             # a pending data-parallel all-reduce still reads (fp32 wire: writes) this buffer
             self._module.flat.grad.zero_()
 
     def note_replayed(self):

@@ -145,3 +145,116 @@ def test_fid_proxy_and_feature_matching():
     other = fid.fid_proxy(D, x, torch.randn(24, 3, 32, 32).clamp(-1, 1), batch_size=8)
     assert abs(same) < 1e-6 and other > 1e-3, (same, other)
     assert not D.training      # mode restored
+
+
+@pytest.mark.gpu
+def test_graphs_survive_noop_move_and_optimizer_reload():
+    """Captured step graphs hold raw buffer addresses.  (a) generator.to(device) on a module that already lives there
+    (generate_images does it on every call) keeps the flat buffers -- same generation, graphs still valid; (b)
+    Adam.load_state_dict after training has started copies the loaded moments INTO the existing buffers, so the
+    replayed graph steps from them: the run equals an eager (RNAGAN_GRAPHS=0 semantics) run doing the same."""
+    import copy
+    from rna_gan_amd import graphed, losses as PL
+    enc, size, n = 32, 32, 8
+
+    def make():
+        G = P.DCGANGenerator(enc, size, 3, 64, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+        D = P.DCGANDiscriminator(size, 3, 64, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.LeakyReLU(0.2))
+        R.seeded_fill_(G, 1); R.seeded_fill_(D, 2)
+        G.set_precision("fp32"); D.set_precision("fp32")
+        G, D = G.cuda().train(), D.cuda().train()
+        og = P.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.999)).bind(G)
+        od = P.Adam(D.parameters(), lr=4e-4, betas=(0.5, 0.999)).bind(D)
+        return G, D, og, od
+
+    real = R.synthetic_images(n, size, seed=3).cuda()
+    noises = [R.synthetic_normal(n, enc, seed=10 + k).cuda() for k in range(12)]
+    eps = torch.tensor([0.4], device="cuda")
+
+    def run(use_graphs):
+        was = graphed.ENABLED
+        graphed.ENABLED = use_graphs
+        try:
+            G, D, og, od = make()
+            lg, ld, lp = P.WassersteinGeneratorLoss(), P.WassersteinDiscriminatorLoss(), P.WassersteinGradientPenalty()
+            saved = None
+            for it in range(6):
+                lg.step(G, D, og, noises[2 * it])
+                ld.step(G, D, od, real, noises[2 * it + 1])
+                lp.step(G, D, od, real, noises[2 * it + 1], eps)
+                if it == 1:
+                    saved = (copy.deepcopy(og.state_dict()), copy.deepcopy(od.state_dict()))
+                if it == 3:                      # graphs are captured by now (third call)
+                    gen_before = (G.flat.gen, D.flat.gen)
+                    G.to(torch.device("cuda:0")); D.cuda()
+                    assert (G.flat.gen, D.flat.gen) == gen_before, "no-op move must not re-home the parameters"
+                    og.load_state_dict(saved[0]); od.load_state_dict(saved[1])
+                    assert og.state_dict()["state"][0]["step"] == saved[0]["state"][0]["step"]
+            torch.cuda.synchronize()
+            return [p.detach().cpu().clone() for p in list(G.parameters()) + list(D.parameters())], og, od
+        finally:
+            graphed.ENABLED = was
+
+    pe, _, _ = run(False)
+    pg, og, od = run(True)
+    for a, b in zip(pe, pg):
+        assert torch.allclose(a, b, rtol=0, atol=1e-6), float((a - b).abs().max())
+    # steps counted from the reloaded value: 2 iterations before the save, reload at it == 3, 2 more iterations
+    assert float(og.state_dict()["state"][0]["step"]) == 2 + 2
+    assert float(od.state_dict()["state"][0]["step"]) == 4 + 4
+
+
+@pytest.mark.gpu
+def test_latent_is_encoded_once_per_batch():
+    """The three betaVAE-conditioned loss plugins share one encode per batch (rna_gan_amd.losses._LatentCache): equal
+    results with the cache on and off, 1 miss + 2 hits per iteration, and a different RNA tensor or a plugin whose
+    encoder weights differ always re-encodes."""
+    from rna_gan_amd import losses as PL
+    enc, size, n, F = 2048, 32, 8, 96
+
+    def run(cache):
+        PL.LATENT_CACHE = cache
+        PL.new_batch()
+        G = P.DCGANGenerator(enc, size, 3, 64, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+        D = P.DCGANDiscriminator(size, 3, 64, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.LeakyReLU(0.2))
+        R.seeded_fill_(G, 1); R.seeded_fill_(D, 2)
+        G, D = G.cuda().train(), D.cuda().train()
+        og = P.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.999)).bind(G)
+        od = P.Adam(D.parameters(), lr=4e-4, betas=(0.5, 0.999)).bind(D)
+        ls = [P.WassersteinGeneratorLossVAE(None, F), P.WassersteinDiscriminatorLossVAE(None, F),
+              P.WassersteinGradientPenaltyVAE(None, F)]
+        for l in ls:
+            R.seeded_fill_(l.betavae, 5)
+            l.betavae = l.betavae.cuda().eval()
+        real = R.synthetic_images(n, size, seed=3).cuda()
+        out = []
+        for it in range(3):
+            PL.new_batch()
+            rna = R.synthetic_rna(n, F, seed=20 + it, distinct=4).cuda()
+            u = [R.synthetic_uniform(n, enc, seed=30 + 3 * it + j).cuda() for j in range(3)]
+            out += [ls[0].step(G, D, og, rna, u[0]).item(), ls[1].step(G, D, od, real, rna, u[1]).item(),
+                    ls[2].step(G, D, od, real, rna, u[2], torch.tensor([0.3], device="cuda")).item()]
+        return out, ls, (G, D, og, od, real)
+
+    try:
+        h0, m0 = PL._LATENT.hits, PL._LATENT.misses
+        a, ls, (G, D, og, od, real) = run(True)
+        assert PL._LATENT.misses - m0 == 3 and PL._LATENT.hits - h0 == 6
+        b, _, _ = run(False)
+        assert a == b
+        PL.LATENT_CACHE = True
+        PL.new_batch()
+        rna = R.synthetic_rna(n, F, seed=50, distinct=4).cuda()
+        u = R.synthetic_uniform(n, enc, seed=51).cuda()
+        m1 = PL._LATENT.misses
+        ls[0].step(G, D, og, rna, u)
+        ls[1].step(G, D, od, real, rna.clone(), u)             # another tensor with equal contents: re-encoded
+        assert PL._LATENT.misses - m1 == 2
+        with torch.no_grad():
+            ls[2].betavae.z_mu.bias.add_(1.0)
+        ls[2].betavae.weights_changed()
+        ls[2].step(G, D, od, real, rna.clone(), u, torch.tensor([0.3], device="cuda"))   # different encoder weights
+        assert PL._LATENT.misses - m1 == 3
+    finally:
+        PL.LATENT_CACHE = True
+        PL.new_batch()
