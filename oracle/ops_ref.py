@@ -152,6 +152,10 @@ class RefOps:
         else:
             dw.copy_(g)
 
+    def g0_bwd_data(self, gz0, cw: ConvW):
+        # d/dz of the first generator layer: gin[n,e] = sum gz0[n,kh,kw,c] w[e,c,kh,kw]  (fp32 functor GEMM in the product)
+        return torch.einsum("nijc,ecij->ne", gz0.to(self.f), cw.w.to(self.f)).contiguous()
+
     def head_fwd(self, a, cw: ConvW, slope: float):
         # Conv2d(C->1, k4, s1, p0) on a 4x4 map: h[n] = sum a[n,kh,kw,c] w[0,c,kh,kw]
         h = torch.einsum("nijc,cij->n", a.to(self.f), self._wq(cw.w)[0])

@@ -152,7 +152,16 @@ class betaVAE(nn.Module):
         None) -- the loss plugins only use z_mean (``z, _, _ = betavae.encode(rna)``, src/wgan_loss.py:96-97), the
         reference computes and discards the other head."""
         if self.training:
-            raise NotImplementedError("rna_gan_amd.betaVAE implements the frozen (eval) encoder used by RNA-GAN")
+            # train mode (src/betaVAE.py:102-107 with the module in train(): Dropout active, BatchNorm1d on batch
+            # statistics with running-statistics update): the encoder half of the training forward, without autograd
+            # (gradients flow through forward(), the path train_betaVAE uses)
+            rt = self.train_runtime()
+            N = x.shape[0]
+            if self.fixed_mask is not None:
+                mask = self.fixed_mask
+            else:
+                mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device).bernoulli_(1.0 - rt.p_drop)
+            return rt.encode_train(x, mask.to(device=x.device, dtype=torch.uint8).contiguous(), mean_only)
         if self._plan is None:
             self._build_plan()
         ops = self._ops

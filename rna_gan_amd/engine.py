@@ -265,14 +265,30 @@ def disc_gradient_penalty(ops, D: DiscNet, xhat, lambd: float, update_running=Tr
     """lambd*(||d sum D(xhat)/d xhat||_2 - 1)^2 and its parameter gradients (written, not
     accumulated; lambd may carry the data-parallel 1/world factor -- it only scales the gradients).  Reference: src/wgan_loss.py:32-44 + :379-387.  Returns the UNWEIGHTED penalty
     as a 1-element device tensor (the reference returns loss.item() of the unweighted value)."""
-    R = len(D.blocks)
     out, ctx = disc_forward(ops, D, xhat, update_running)
-    # (2) first backward: data gradients only
-    g = disc_backward(ops, D, ctx, 1.0, wgrad=False, accumulate=False, need_input_grad=True,
-                      keep_for_gp=True)
+    loss, st = disc_gp_first(ops, D, ctx, lambd)
+    disc_gp_second(ops, D, ctx, st, accumulate=False, need_input_grad=False)
+    return loss
+
+
+def disc_gp_first(ops, D: DiscNet, ctx, lambd):
+    """Steps (2) of the penalty on the context of a primal forward D(xhat): first backward (data gradients only) ->
+    g = d sum D(xhat) / d xhat, the UNWEIGHTED penalty (||g|| - 1)^2 (1-element device tensor) and the tangent
+    direction v = lambd * 2 (||g|| - 1) / ||g|| * g.  lambd: float, or a 1-element device tensor is NOT supported (the
+    coefficient kernel takes a host scalar)."""
+    g = disc_backward(ops, D, ctx, 1.0, wgrad=False, accumulate=False, need_input_grad=True, keep_for_gp=True)
     sq = ops.stat_allreduce(ops.sqnorm(g))      # whole-batch norm: summed over the ranks when statistics are synchronised
     loss, coef = ops.gp_coef(sq, lambd)
-    v = ops.scale_by(g, coef)
+    return loss, (g, ops.scale_by(g, coef))
+
+
+def disc_gp_second(ops, D: DiscNet, ctx, st, accumulate: bool, need_input_grad: bool):
+    """Steps (3)+(4): tangent forward along v and the joint reverse sweep.  Parameter gradients of lambd * penalty are
+    written (accumulate=False) or added (True) into the .dw / .dbias / .dgamma / .dbeta buffers; with need_input_grad
+    the gradient with respect to xhat (= the primal cotangent at the input, NCHW fp32) is returned."""
+    R = len(D.blocks)
+    g, v = st
+    xhat = ctx.x
     # (3) tangent forward along v
     zt0 = ops.first_down(v, D.conv0, None, 1.0)
     at = ops.lrelu_bwd(zt0, ctx.a[0], D.slope)
@@ -284,24 +300,37 @@ def disc_gradient_penalty(ops, D: DiscNet, xhat, lambd: float, update_running=Tr
         zts.append(zt); ats.append(at); s_zt.append(szt); s_xhzt.append(sxz)
     # (4) joint reverse.  Head: t = sum_n lrelu'(h_n) * hdot_n  ->  dW_head = sum_n gh_n * at_R[n]
     with ops.side():
-        ops.head_wgrad(ctx.gh, ats[R], D.head.dw, False)
+        ops.head_wgrad(ctx.gh, ats[R], D.head.dw, accumulate)
     qa = None
     for l in range(R, 0, -1):
         cw, bn = D.blocks[l - 1]
         pz = ops.bn_double_bwd(ctx.z[l], qa, zts[l], ctx.ga1[l], ctx.mean[l], ctx.invstd[l],
                                bn.gamma, bn.beta, D.slope, ctx.s_gy[l], ctx.s_gyxh[l],
-                               s_zt[l], s_xhzt[l], bn.dgamma, bn.dbeta, False)
+                               s_zt[l], s_xhzt[l], bn.dgamma, bn.dbeta, accumulate)
         # dW = wgrad(pz, a_prev) + wgrad(gz1, at_prev): one launch, one split-K reduction
         with ops.side(pz):
-            ops.conv_wgrad2(pz, ctx.a[l - 1], ctx.gz1[l], ats[l - 1], cw, False)
+            ops.conv_wgrad2(pz, ctx.a[l - 1], ctx.gz1[l], ats[l - 1], cw, accumulate)
         qa = ops.conv_up(pz, cw) if l > 1 else ops.conv_up(pz, cw, ctx.a[0], D.slope)
-    p0 = qa if R > 0 else ops.lrelu_bwd(qa, ctx.a[0], D.slope)
+    if R == 0:
+        # no BatchNorm block: the penalty is piecewise constant in the first layer's parameters except through the head
+        raise NotImplementedError("gradient penalty needs at least one Conv+BN block (in_size >= 32)")
+    p0 = qa
     with ops.side(p0, v):
-        ops.skinny_wgrad(p0, xhat, D.conv0.dw, False)
+        ops.skinny_wgrad(p0, xhat, D.conv0.dw, accumulate)
         ops.skinny_wgrad(ctx.gz1[0], v, D.conv0.dw, True)
-    ops.col_sum(p0, D.conv0.dbias, False)
+    ops.col_sum(p0, D.conv0.dbias, accumulate)
+    gx = ops.last_up(p0, D.conv0, None, False) if need_input_grad else None
     ops.join()
-    return loss
+    return gx
+
+
+def disc_forward_eval(ops, D: DiscNet, x_nchw):
+    """D(x) with BatchNorm in EVAL mode (running statistics) -> (N,).  The reference never evaluates its
+    discriminator (every call site is in train mode); provided so that ``discriminator.eval(); discriminator(x)``
+    behaves like the nn.Module it replaces."""
+    a = disc_features_eval(ops, D, x_nchw)
+    _, out = ops.head_fwd(a, D.head, D.last_slope)
+    return out
 
 
 # --------------------------------------------------------------------------------------------
@@ -342,8 +371,8 @@ def upgen_forward(ops, G: UpGenNet, noise, update_running=True, keep=True):
     return img, ctx
 
 
-def upgen_backward(ops, G: UpGenNet, ctx, gimg, accumulate: bool):
-    """Parameter gradients of the up-generator for d(loss)/d(img) = gimg (NCHW fp32)."""
+def upgen_backward(ops, G: UpGenNet, ctx, gimg, accumulate: bool, need_input_grad: bool = False):
+    """Parameter gradients of the up-generator for d(loss)/d(img) = gimg (NCHW fp32) (+ d/d noise on request)."""
     R = len(G.blocks)
     ops.upconv3_wgrad(gimg, ctx.a[R], G.last, accumulate, gy_nchw=True)
     ops.nchw_chan_sum(gimg, G.last.dbias, accumulate)
@@ -358,20 +387,22 @@ def upgen_backward(ops, G: UpGenNet, ctx, gimg, accumulate: bool):
     gz0, _, _ = ops.bn_act_bwd(ctx.z[0], ga, ctx.mean[0], ctx.invstd[0], G.bn0.gamma, G.bn0.beta,
                                G.slope, G.bn0.dgamma, G.bn0.dbeta, accumulate)
     ops.g0_wgrad(ctx.noise, gz0, G.g0.dw, accumulate)
+    return ops.g0_bwd_data(gz0, G.g0) if need_input_grad else None
 
 
 def _gen_fwd(ops, G, noise, **kw):
     return upgen_forward(ops, G, noise, **kw) if isinstance(G, UpGenNet) else gen_forward(ops, G, noise, **kw)
 
 
-def _gen_bwd(ops, G, ctx, gimg, accumulate):
+def _gen_bwd(ops, G, ctx, gimg, accumulate, need_input_grad=False):
     if isinstance(G, UpGenNet):
-        return upgen_backward(ops, G, ctx, gimg, accumulate)
-    return gen_backward(ops, G, ctx, gimg, accumulate)
+        return upgen_backward(ops, G, ctx, gimg, accumulate, need_input_grad)
+    return gen_backward(ops, G, ctx, gimg, accumulate, need_input_grad)
 
 
-def gen_backward(ops, G: GenNet, ctx, gimg, accumulate: bool):
-    """Parameter gradients of G for d(loss)/d(img) = gimg (NCHW fp32)."""
+def gen_backward(ops, G: GenNet, ctx, gimg, accumulate: bool, need_input_grad: bool = False):
+    """Parameter gradients of G for d(loss)/d(img) = gimg (NCHW fp32); with need_input_grad also d(loss)/d(noise)
+    (N, E) -- off the reference's path (its noise never requires grad), one extra GEMM."""
     R = len(G.blocks)
     gzl = ops.tanh_bwd(gimg, ctx.img)
     with ops.side(gzl):
@@ -388,7 +419,9 @@ def gen_backward(ops, G: GenNet, ctx, gimg, accumulate: bool):
     gz0, _, _ = ops.bn_act_bwd(ctx.z[0], ga, ctx.mean[0], ctx.invstd[0], G.bn0.gamma, G.bn0.beta,
                                G.slope, G.bn0.dgamma, G.bn0.dbeta, accumulate)
     ops.g0_wgrad(ctx.noise, gz0, G.g0.dw, accumulate)
+    gin = ops.g0_bwd_data(gz0, G.g0) if need_input_grad else None
     ops.join()
+    return gin
 
 
 # --------------------------------------------------------------------------------------------

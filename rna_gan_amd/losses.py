@@ -51,6 +51,56 @@ def wasserstein_discriminator_loss_vae(fx, fgz, reduction="mean"):
     return reduce(fgz - fx, "mean")
 
 
+class _GradientPenaltyFn(torch.autograd.Function):
+    """(||d sum(d_interpolate) / d interpolate||_2 - 1)^2 as a differentiable scalar, for discriminator outputs produced
+    by the HIP discriminator under autograd (models._DiscForwardFn).  torch cannot differentiate through that node a
+    second time, so this Function takes the node's saved forward context and runs the engine's explicit second-order
+    pass (engine.disc_gp_first / disc_gp_second: tangent forward + joint reverse) in its own backward: parameter
+    gradients are ADDED into the flat gradient buffer, the gradient with respect to ``interpolate`` is returned."""
+
+    @staticmethod
+    def forward(ctx, interpolate, d_interpolate, *params):
+        node = d_interpolate.grad_fn
+        module, dctx = getattr(node, "module", None), getattr(node, "dctx", None)
+        if module is None or dctx is None:
+            raise RuntimeError("wasserstein_gradient_penalty: d_interpolate must be the direct output of a rna_gan_amd "
+                               "discriminator called on `interpolate` with gradients enabled")
+        if dctx.x.data_ptr() != interpolate.data_ptr() and not torch.equal(dctx.x, interpolate.detach().float()):
+            raise RuntimeError("wasserstein_gradient_penalty: d_interpolate was not computed from this `interpolate`")
+        ops, net = module.runtime()
+        loss, st = E.disc_gp_first(ops, net, dctx, 1.0)
+        ctx.module, ctx.dctx, ctx.st = module, dctx, st
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gloss):
+        ops, net = ctx.module.runtime()
+        g, v = ctx.st
+        scale = float(gloss)                      # host sync: this is the public functional form, not the hot path
+        v = v if scale == 1.0 else v * scale      # v is linear in the upstream gradient (v = dL/dg)
+        gx = E.disc_gp_second(ops, net, ctx.dctx, (g, v), accumulate=True, need_input_grad=ctx.needs_input_grad[0])
+        return (gx, None) + (None,) * (len(ctx.module._rt_flat.params))
+
+
+def wasserstein_gradient_penalty(interpolate, d_interpolate, reduction="mean"):
+    """torchgan.losses.functional.wasserstein_gradient_penalty / src/wgan_loss.py:32-44: the squared distance from 1 of
+    the 2-norm (over the WHOLE batch) of d sum(d_interpolate) / d interpolate.  ``d_interpolate`` must come from a
+    rna_gan_amd discriminator applied to ``interpolate`` (requires_grad=True) with gradients enabled; the result is
+    a scalar that can be back-propagated (see _GradientPenaltyFn)."""
+    fn = d_interpolate.grad_fn
+    module = getattr(fn, "module", None)
+    if module is None:
+        raise RuntimeError("wasserstein_gradient_penalty: d_interpolate carries no rna_gan_amd discriminator graph "
+                           "(call the discriminator on an `interpolate` that requires grad, gradients enabled)")
+    gp = _GradientPenaltyFn.apply(interpolate, d_interpolate, *module._rt_flat.params)
+    return reduce(gp, reduction)
+
+
+def wasserstein_gradient_penalty_vae(interpolate, d_interpolate, reduction="mean"):
+    """src/wgan_loss.py:32-44 (the reduction argument is ignored there: always the mean of the scalar)."""
+    return wasserstein_gradient_penalty(interpolate, d_interpolate, "mean")
+
+
 class GeneratorLoss(nn.Module):
     def __init__(self, reduction="mean", override_train_ops=None):
         super().__init__()
@@ -373,6 +423,10 @@ class WassersteinGradientPenalty(DiscriminatorLoss):
         self.lambd = lambd
         self._runner = _Runner()
 
+    def forward(self, interpolate, d_interpolate):
+        """torchgan WassersteinGradientPenalty.forward: the unweighted penalty as a differentiable scalar."""
+        return wasserstein_gradient_penalty(interpolate, d_interpolate, self.reduction)
+
     def step(self, generator, discriminator, optimizer_discriminator, real, noise, eps):
         """eps: 1-element float32 device tensor (read inside the graph)."""
         lambd = self.lambd
@@ -513,6 +567,11 @@ class WassersteinGradientPenaltyVAE(DiscriminatorLoss, _VAEMixin):
         self.lambd = lambd
         self.override_train_ops = override_train_ops
         self._init_vae(checkpoint, rna_features, beta)
+
+    def forward(self, interpolate, d_interpolate):
+        """src/wgan_loss.py:293-312 (``self.reduction`` holds the checkpoint path there and is ignored by the
+        functional form, :44)."""
+        return wasserstein_gradient_penalty_vae(interpolate, d_interpolate, self.reduction)
 
     def step(self, generator, discriminator, optimizer_discriminator, real, rna, u, eps):
         lambd = self.lambd

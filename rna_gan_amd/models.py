@@ -256,8 +256,9 @@ class _GenForwardFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gimg):
         ops, net = ctx.module.runtime()
-        E._gen_bwd(ops, net, ctx.gctx, gimg.contiguous().float(), accumulate=True)
-        return (None, None) + (None,) * len(ctx.module._rt_flat.params)
+        gin = E._gen_bwd(ops, net, ctx.gctx, gimg.contiguous().float(), accumulate=True,
+                         need_input_grad=ctx.needs_input_grad[1])
+        return (None, gin) + (None,) * len(ctx.module._rt_flat.params)
 
 
 class _DiscForwardFn(torch.autograd.Function):
@@ -318,8 +319,6 @@ class DCGANGenerator(Generator):
         ops, net = self.runtime()
         x = x.view(-1, x.size(1)).contiguous().float()
         if self.training and _wants_autograd(self, x):
-            if x.requires_grad:
-                raise NotImplementedError("the gradient with respect to the generator's input is not on the RNA-GAN path")
             return _GenForwardFn.apply(self, x, *self._rt_flat.params)
         if self.training:
             img, _ = E.gen_forward(ops, net, x, update_running=True, keep=False)
@@ -364,8 +363,6 @@ class DCGANUpGenerator(Generator):
         ops, net = self.runtime()
         x = x.view(-1, x.size(1)).contiguous().float()
         if self.training and _wants_autograd(self, x):
-            if x.requires_grad:
-                raise NotImplementedError("the gradient with respect to the generator's input is not on the RNA-GAN path")
             return _GenForwardFn.apply(self, x, *self._rt_flat.params)
         if self.training:
             img, _ = E.upgen_forward(ops, net, x, update_running=True, keep=False)
@@ -410,9 +407,10 @@ class DCGANDiscriminator(Discriminator):
             else:
                 a = E.disc_features_eval(ops, net, x.contiguous().float())
             return a.float().permute(0, 3, 1, 2).contiguous()
-        if not self.training:
-            raise NotImplementedError("the reference only ever runs the discriminator in train mode")
         x = x.contiguous().float()
+        if not self.training:
+            # eval mode (running statistics): never used by the reference, provided for drop-in completeness; forward only
+            return E.disc_forward_eval(ops, net, x)
         if _wants_autograd(self, x):
             return _DiscForwardFn.apply(self, x, *self._rt_flat.params)
         out, _ = E.disc_forward(ops, net, x, update_running=True)

@@ -324,6 +324,16 @@ class HipOps:
         check(self.lib.rg_g0_wgrad(_ptr(z), _ptr(gy), _ptr(dw), N, E, C, self.dt, int(accumulate), self.algo,
                                    _ptr(ws), ws.numel(), self.stream), "rg_g0_wgrad")
 
+    def g0_bwd_data(self, gz0, cw: ConvW):
+        """d/dz of the generator's first layer, gin[n][e] = sum_{tap,c} gz0[n][tap][c] * w[e][c][tap].  Off the
+        reference's path (its noise never requires grad): one fp32 functor GEMM (rg_linear_affine_act) on the master
+        weight viewed as [E][C*16]; the (tap, c) -> (c, tap) re-order of the small gz0 is host-side plumbing."""
+        N, C = gz0.shape[0], gz0.shape[3]
+        E = cw.w.shape[0]
+        assert tuple(cw.w.shape) == (E, C, 4, 4) and cw.w.is_contiguous()
+        x = gz0.float().reshape(N, 16, C).permute(0, 2, 1).contiguous().reshape(N, C * 16)
+        return self.linear_affine_act(x, cw.w.reshape(E, C * 16), None, None, 1.0)
+
     def head_fwd(self, a, cw: ConvW, slope: float):
         N, C = a.shape[0], a.shape[3]
         assert a.shape[1] == 4 and a.shape[2] == 4 and a.is_contiguous()

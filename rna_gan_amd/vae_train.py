@@ -134,6 +134,19 @@ class VaeRuntime:
         return self.ops.bn_forward(z, bn.weight, bn.bias, slope, bn.eps, 0.1 if bn.momentum is None else bn.momentum,
                                    bn.running_mean, bn.running_var, bn.num_batches_tracked)
 
+    def encode_train(self, x, mask, mean_only=False):
+        """Train-mode betaVAE.encode (src/betaVAE.py:102-107): Dropout keep-mask, batch-statistics BatchNorm1d (running
+        statistics updated), forward only -> (z_mean, z_log_var, x_encoded)."""
+        m = self.model
+        x = x.contiguous().float()
+        h = self.pad_rows(x, self.ld(x.shape[1]), mask, 1.0 / (1.0 - self.p_drop))
+        with torch.no_grad():
+            for lin, bn, slope in self.enc:
+                h, _, _ = self._bn(self.linear(h, lin), bn, slope)
+            mu = self.linear(h, m.z_mu)
+            lv = None if mean_only else self.linear(h, m.z_logvar)
+        return mu, lv, h
+
     # ------------------------------------------------------------------ train-mode forward / backward
     def forward_train(self, x, mask, eps):
         m = self.model

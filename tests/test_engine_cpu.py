@@ -116,3 +116,41 @@ def test_up_generator_step_matches_autograd():
     loss_e = E.disc_loss_grads(ops, Gn, Dn, real, noise)
     np.testing.assert_allclose(float(loss_e), float(loss_o), rtol=1e-9)
     assert_close_dict(grads_of(D2), grads_of(D), 1e-6, 1e-10)
+
+
+def test_penalty_parts_input_gradients_and_eval_discriminator():
+    """Pieces behind the public functional forms: (a) engine.disc_gp_first / disc_gp_second with accumulate=True and
+    need_input_grad=True reproduce torch's double backward of lambd * (||d sum D(x)/dx|| - 1)^2 with respect to the
+    parameters (added to existing gradients) AND to x; (b) the generator's input gradient; (c) eval-mode D."""
+    torch.manual_seed(0)
+    G, D = mk(32, 4, 16)
+    G2, D2 = copy.deepcopy(G), copy.deepcopy(D)
+    for m in (G, D, G2, D2):
+        m.train()
+    ops = RefOps(torch.float64)
+    Gn, Dn = E.build_gen_net(G2), E.build_disc_net(D2)
+    x = R.synthetic_images(4, 32, seed=3).double().requires_grad_(True)
+    # (a) autograd reference: gradient of 7 * penalty wrt parameters and x
+    gp = R.gradient_penalty(x, D(x))
+    (7.0 * gp).backward()
+    want_x = x.grad.clone()
+    for p in D2.parameters():
+        p.grad.fill_(0.5)                                   # accumulate semantics: gradients are ADDED
+    _, ctx = E.disc_forward(ops, Dn, x.detach().clone())
+    loss, (g, v) = E.disc_gp_first(ops, Dn, ctx, 1.0)
+    gx = E.disc_gp_second(ops, Dn, ctx, (g, 7.0 * v), accumulate=True, need_input_grad=True)
+    np.testing.assert_allclose(float(loss), float(gp), rtol=1e-9)
+    np.testing.assert_allclose(gx.numpy(), want_x.numpy(), rtol=1e-6, atol=1e-9)
+    assert_close_dict({k: v_ - 0.5 for k, v_ in grads_of(D2).items()}, grads_of(D), 1e-6, 1e-9)
+    # (b) d/dz of the generator
+    z = R.synthetic_normal(4, 16, seed=4).double().requires_grad_(True)
+    G(z).square().sum().backward()
+    img, gctx = E.gen_forward(ops, Gn, z.detach().clone())
+    gin = E.gen_backward(ops, Gn, gctx, 2.0 * img, accumulate=False, need_input_grad=True)
+    np.testing.assert_allclose(gin.numpy(), z.grad.numpy(), rtol=1e-7, atol=1e-10)
+    # (c) eval-mode discriminator (running statistics)
+    D.eval()
+    with torch.no_grad():
+        want = D(x.detach())
+    got = E.disc_forward_eval(ops, Dn, x.detach().clone())
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-9, atol=1e-12)

@@ -299,3 +299,77 @@ def test_autograd_wrappers_custom_loss():
         ref = po.grad.numpy()
         np.testing.assert_allclose(pp.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * max(1.0, float(np.abs(ref).max())),
                                    err_msg="D(acc)." + k)
+
+
+def test_public_functional_forms_fp32():
+    """The callable forms the reference's loss classes expose besides train_ops (src/wgan_loss.py:24-44, :293-312) and
+    the module modes it never uses but an nn.Module has: penalty.forward(interpolate, d_interpolate) through torch
+    autograd on the product discriminator (second-order pass inside _GradientPenaltyFn) -- value, parameter gradients
+    and d/d interpolate against torch's double backward on the oracle; eval-mode discriminator; d/dz of the generator."""
+    in_size, step, enc, n = 32, 16, 32, 6
+    G0 = R.seeded_fill_(R.OracleDCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                               last_nonlinearity=nn.Tanh()), 7)
+    D0 = R.seeded_fill_(R.OracleDCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                                   last_nonlinearity=nn.LeakyReLU(0.2)), 8)
+    Go, Do = copy.deepcopy(G0).train(), copy.deepcopy(D0).train()
+    G, D, og, od = product_pair(in_size, step, enc, "fp32", G0, D0)
+    x = R.synthetic_images(n, in_size, seed=3)
+    # --- oracle: 10 * penalty + mean(D(x)) back-propagated to parameters and x
+    xo = x.clone().requires_grad_(True)
+    do = Do(xo)
+    gpo = R.gradient_penalty(xo, do)
+    (10.0 * gpo + do.mean()).backward()
+    # --- product, through the public forms
+    for pen in (PL.WassersteinGradientPenalty(),):
+        D.flat.grad.zero_()                     # (builds the runtime: parameters / .grad views live in flat buffers)
+        xp = x.cuda().requires_grad_(True)
+        dp = D(xp)
+        gp = pen(xp, dp)                       # nn.Module.__call__ -> forward(interpolate, d_interpolate)
+        assert gp.dim() == 0 and abs(float(gp.detach()) - float(gpo.detach())) <= 2e-4 * (abs(float(gpo.detach())) + 1e-3)
+        (10.0 * gp + dp.mean()).backward()
+        assert l2rel(xp.grad.cpu().numpy(), xo.grad.numpy()) <= 2e-3
+        for (k, po), pp in zip(Do.named_parameters(), D.parameters()):
+            assert l2rel(pp.grad.detach().cpu().numpy(), po.grad.numpy()) <= 5e-3, k
+    xp2, xq = x.cuda().requires_grad_(True), x.clone().requires_grad_(True)
+    got_v = float(PL.wasserstein_gradient_penalty_vae(xp2, D(xp2), "sum").detach())      # reduction is ignored (:44)
+    assert abs(got_v - float(R.gradient_penalty(xq, Do(xq)).detach())) <= 1e-3
+    # --- eval-mode discriminator
+    D.eval(); Do.eval()
+    with torch.no_grad():
+        want = Do(x)
+        got = D(x.cuda())
+    assert got.shape == want.shape and l2rel(got.cpu().numpy(), want.numpy()) <= 1e-4
+    D.train(); Do.train()
+    # --- generator input gradient
+    zo = R.synthetic_normal(n, enc, seed=4).requires_grad_(True)
+    Go(zo).square().sum().backward()
+    zp = zo.detach().clone().cuda().requires_grad_(True)
+    G(zp).square().sum().backward()
+    assert l2rel(zp.grad.cpu().numpy(), zo.grad.numpy()) <= 2e-3
+
+
+def test_betavae_encode_train_mode():
+    """betaVAE.encode with the module in train mode (Dropout keep-mask injected, batch-statistics BatchNorm1d with a
+    running-statistics update) against the oracle module's train-mode encoder."""
+    F, Z, n = 96, 32, 12
+    bo = R.seeded_fill_(R.OracleBetaVAE(F, Z, [64, 48, Z], [48, 64]), 5)
+    bp = P.betaVAE(F, Z, [64, 48, Z], [48, 64])
+    bp.load_state_dict(bo.state_dict())
+    bp.set_precision("fp32")
+    bp = bp.cuda().train()
+    bo.train()
+    x = R.synthetic_rna(n, F, seed=6, distinct=n)
+    mask = (torch.rand(n, F, generator=torch.Generator().manual_seed(1)) > 0.5)
+    bp.fixed_mask = mask.to(torch.uint8)
+    zm, zl, h = bp.encode(x.cuda())
+    # oracle: the encoder with the same keep-mask (Dropout p = 0.5 -> scale 2), BatchNorm in train mode
+    hh = x * mask.float() * 2.0
+    for blk in list(bo.encoder.encoder.children())[1:]:
+        hh = blk(hh)
+    np.testing.assert_allclose(h[:, :Z].cpu().numpy(), hh.detach().numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(zm.cpu().numpy(), bo.z_mu(hh).detach().numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(zl.cpu().numpy(), bo.z_logvar(hh).detach().numpy(), rtol=2e-4, atol=2e-5)
+    sp, so = bp.state_dict(), bo.state_dict()
+    for k in so:
+        if "running" in k:
+            np.testing.assert_allclose(sp[k].cpu().numpy(), so[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
