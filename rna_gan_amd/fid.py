@@ -65,3 +65,50 @@ def fid_proxy(discriminator, images1, images2, batch_size=64):
     m1, s1 = activation_statistics(discriminator_features(discriminator, images1, batch_size))
     m2, s2 = activation_statistics(discriminator_features(discriminator, images2, batch_size))
     return frechet_distance(m1, s1, m2, s2)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The rest of the reference's FID procedure around the feature extractor (src/fid.py:166-232, :312-330).  The extractor
+# itself (Inception-v3 Mixed_7c pool features, :33-94) needs pretrained weights that are not obtainable offline, so it
+# is a parameter here: any callable (N, 3, 299, 299) float tensor in [0, 1] -> (N, F) array.
+# ------------------------------------------------------------------------------------------------------------------
+def preprocess_image(im):
+    """src/fid.py:166-190: (H, W, 3) uint8 or float32 in [0, 1] -> (3, 299, 299) float32 in [0, 1].  The reference
+    resizes with cv2.resize(im, (299, 299)) (bilinear, half-pixel centres, no anti-aliasing); cv2 is absent here, the
+    same sampling rule is applied with torch (parity with cv2 unpinned: no cv2 to compare with)."""
+    im = np.asarray(im)
+    if im.ndim != 3 or im.shape[2] != 3:
+        raise ValueError("preprocess_image expects an (H, W, 3) image")
+    if im.dtype == np.uint8:
+        im = im.astype(np.float32) / 255
+    t = torch.from_numpy(np.ascontiguousarray(im, dtype=np.float32)).permute(2, 0, 1)[None]
+    t = torch.nn.functional.interpolate(t, size=(299, 299), mode="bilinear", align_corners=False, antialias=False)[0]
+    if float(t.max()) > 1.0 or float(t.min()) < 0.0:
+        raise ValueError("preprocess_image: values outside [0, 1]")
+    return t.contiguous()
+
+
+def preprocess_images(images, use_multiprocessing=False):
+    """src/fid.py:193-214: (N, H, W, 3) -> (N, 3, 299, 299) float32 in [0, 1] (use_multiprocessing is accepted for
+    signature compatibility; the resize is a single batched op here)."""
+    out = torch.stack([preprocess_image(im) for im in images], dim=0)
+    assert out.shape == (len(images), 3, 299, 299) and out.dtype == torch.float32
+    return out
+
+
+def calculate_fid(images1, images2, feature_extractor, batch_size=2, use_multiprocessing=False):
+    """src/fid.py:217-232 with the feature extractor as a parameter: images (N, H, W, 3) uint8 / float in [0, 1]."""
+    def feats(images):
+        x = preprocess_images(images, use_multiprocessing)
+        return np.concatenate([np.asarray(feature_extractor(x[i:i + batch_size]), dtype=np.float64)
+                               for i in range(0, x.shape[0], batch_size)], axis=0)
+    m1, s1 = activation_statistics(feats(images1))
+    m2, s2 = activation_statistics(feats(images2))
+    return frechet_distance(m1, s1, m2, s2)
+
+
+def fid_protocol(generate_fake, real_images, feature_extractor, iterations=5, batch_size=2):
+    """The reference's reporting protocol (src/fid.py:312-330): `iterations` (= 5) independent generations of the fake
+    set against the same real set, FID of each, reported as mean +- std.  generate_fake() -> (N, H, W, 3) images."""
+    values = [calculate_fid(real_images, generate_fake(), feature_extractor, batch_size) for _ in range(iterations)]
+    return {"fid_values": values, "mean": float(np.mean(values)), "std": float(np.std(values))}

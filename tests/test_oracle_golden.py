@@ -199,3 +199,29 @@ def test_f7_vae_training_step(golden_dir):
     np.testing.assert_allclose(out.numpy(), g["eval.out"], rtol=1e-5, atol=1e-6)
     for k, v in losses.items():
         np.testing.assert_allclose(float(v), float(g["eval." + k]), rtol=1e-5, err_msg=k)
+
+
+def test_f9_generate_images_pins_oracle(golden_dir):
+    """f9_generate_images.npz = what the REFERENCE's gan_utils.generate_images (src/gan_utils.py:197-244, imported by
+    tests/golden/make_fid_genimg_fixtures.py) returned around the oracle generator and the reference betaVAE class:
+    the oracle restatement (generator + OracleBetaVAE) must reproduce it with the same torch seed."""
+    fx = np.load(os.path.join(golden_dir, "f9_generate_images.npz"))
+    E_, F = 16, 40
+    G = R.seeded_fill_(R.OracleDCGANGenerator(E_, 256, 3, 1, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh()), 81)
+    G.train()
+    bv = R.seeded_fill_(R.OracleBetaVAE(F, E_, [32, 24, E_], [24, 32], beta=0.0005), 82)
+    bv.eval()
+    rna = R.synthetic_rna(1, F, seed=83, distinct=1)
+    torch.manual_seed(5)
+    cond = R.generate_images(G, gene_exp=rna, sample_size=13, betavae=bv)
+    assert cond.shape == (13, 256, 256, 3)
+    np.testing.assert_allclose(cond[:, ::16, ::16, :], fx["cond.sub"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(cond.astype(np.float64).sum(), float(fx["cond.sum"]), rtol=1e-7)
+    np.testing.assert_allclose((cond.astype(np.float64) ** 2).sum(), float(fx["cond.sumsq"]), rtol=1e-7)
+    for k, v in G.state_dict().items():
+        if "running" in k:
+            np.testing.assert_allclose(v.numpy(), fx["bn_after_cond." + k], rtol=1e-6, atol=1e-7, err_msg=k)
+    torch.manual_seed(6)
+    unc = R.generate_images(G, sample_size=20)
+    np.testing.assert_allclose(unc[:, ::16, ::16, :], fx["unc.sub"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(unc.astype(np.float64).sum(), float(fx["unc.sum"]), rtol=1e-7)

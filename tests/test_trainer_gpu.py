@@ -258,3 +258,59 @@ def test_latent_is_encoded_once_per_batch():
     finally:
         PL.LATENT_CACHE = True
         PL.new_batch()
+
+
+@pytest.mark.gpu
+def test_generate_images_reference_fixture(golden_dir):
+    """Product generate_images (HIP kernels, fp32 path) against f9_generate_images.npz = the output of the REFERENCE's
+    gan_utils.generate_images on the same seeded generator / betaVAE weights and the same torch seed."""
+    import numpy as np
+    from types import SimpleNamespace
+    from rna_gan_amd.gan_utils import generate_images
+    fx = np.load(os.path.join(golden_dir, "f9_generate_images.npz"))
+    E_, F = 16, 40
+    Go = R.seeded_fill_(R.OracleDCGANGenerator(E_, 256, 3, 1, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh()), 81)
+    Gp = P.DCGANGenerator(E_, 256, 3, 1, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+    Gp.load_state_dict(Go.state_dict())
+    Gp = Gp.cuda().train().set_precision("fp32")
+    bvo = R.seeded_fill_(R.OracleBetaVAE(F, E_, [32, 24, E_], [24, 32], beta=0.0005), 82)
+    bvp = P.betaVAE(F, E_, [32, 24, E_], [24, 32], beta=0.0005)
+    bvp.load_state_dict(bvo.state_dict())
+    bvp.set_precision("fp32").eval()
+    tr = SimpleNamespace(generator=Gp, device=torch.device("cuda:0"))
+    rna = R.synthetic_rna(1, F, seed=83, distinct=1)
+    torch.manual_seed(5)
+    cond = generate_images(tr, gene_exp=rna, sample_size=13, betavae=bvp)
+    assert cond.shape == (13, 256, 256, 3) and cond.dtype == np.float32
+    np.testing.assert_allclose(cond[:, ::16, ::16, :], fx["cond.sub"], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(cond.astype(np.float64).sum(), float(fx["cond.sum"]), rtol=2e-4)
+    for k, v in Gp.state_dict().items():
+        if "running" in k:
+            np.testing.assert_allclose(v.cpu().numpy(), fx["bn_after_cond." + k], rtol=2e-3, atol=2e-5, err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16", 3e-2)])
+def test_betavae_encode_reference_fixtures(golden_dir, precision, tol):
+    """betaVAE.encode (eval) on the GPU against what the REFERENCE's betaVAE.encode produced: the reduced model in full
+    (f1_betavae_small.npz) and the full-size 19198 -> 2048 encoder through first / last 64 columns and row sums
+    (f1_betavae_full.npz)."""
+    import numpy as np
+    fx = np.load(os.path.join(golden_dir, "f1_betavae_small.npz"))
+    m = P.betaVAE(64, 16, [48, 32, 16], [32, 48], beta=0.005)
+    R.seeded_fill_(m, 11)
+    m = m.set_precision(precision).cuda().eval()
+    zm, zl, h = m.encode(R.synthetic_rna(6, 64, seed=12, distinct=4).cuda())
+    for got, key in ((zm, "z_mean"), (zl, "z_logvar"), (h[:, :16], "x_encoded")):
+        want = fx[key]
+        assert float(np.abs(got.cpu().numpy() - want).max()) <= tol * float(np.abs(want).max()), key
+    fx = np.load(os.path.join(golden_dir, "f1_betavae_full.npz"))
+    m = P.betaVAE(19198, 2048, [6000, 4000, 2048], [4000, 6000], beta=0.005)
+    R.seeded_fill_(m, 13)
+    m = m.set_precision(precision).cuda().eval()
+    zm, _, _ = m.encode(R.synthetic_rna(4, 19198, seed=14, distinct=4).cuda(), mean_only=True)
+    zc = zm.cpu().double().numpy()
+    scale = float(np.abs(fx["z_mean_first"]).max())
+    assert float(np.abs(zc[:, :64] - fx["z_mean_first"]).max()) <= tol * scale
+    assert float(np.abs(zc[:, -64:] - fx["z_mean_last"]).max()) <= tol * scale
+    np.testing.assert_allclose((zc ** 2).sum(1), fx["z_mean_sumsq"], rtol=4 * tol)
