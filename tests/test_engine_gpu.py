@@ -102,6 +102,7 @@ CASES = [
     (32, 64, 128, 4, torch.float32, "l2"),
     (32, 64, 128, 16, torch.bfloat16, "bf16"),     # MFMA kernels on the conv stack
     (64, 64, 128, 8, torch.bfloat16, "bf16"),
+    (256, 64, 2048, 4, torch.float32, "l2"),       # the reference model's full size (fp32 parity mode), batch 4
 ]
 
 
@@ -145,3 +146,82 @@ def test_three_steps_vs_autograd(in_size, step, enc, n, dtype, mode, sync):
     check_grads(Dg, ref["P"], mode, "GP step")
     check_bufs(Gg, ref["bufG"], btol, "G buffers")
     check_bufs(Dg, ref["bufD"], btol, "D buffers")
+
+
+@pytest.mark.parametrize("in_size,step,enc,n", [(32, 64, 128, 16), (64, 64, 128, 8)])
+def test_bf16_kernels_vs_bf16_rounding_twin(in_size, step, enc, n):
+    """Is the bf16 (MFMA) path's distance from the fp64 oracle EXPLAINED by bf16 rounding?  Three evaluations of one
+    iteration's gradients on the same inputs: fp64 autograd (oracle), the bf16-rounding twin (the same engine sequencing
+    on the CPU over oracle/ops_ref.RefOps(bfloat16): bf16 operands / activations, fp32 accumulation) and the HIP
+    kernels.  WGAN gradients have a large common-mode part that every BatchNorm backward subtracts, which amplifies the
+    2^-9 roundings of the stored gradients to several per cent, differently for any two bf16 evaluations (the twin
+    itself is 5-20 % from fp64); so, per parameter tensor:
+        err(kernels, fp64) <= 1.5 x err(twin, fp64) + 1e-2   and   err(kernels, twin) <= 1.6 x err(twin, fp64) + 1e-2   (relative L2)
+    -- a systematic error in one benchmarked kernel (a wrong tap, a dropped k-tile, a 10 % scale) breaks both.
+    Losses within 3 % of the twin, BatchNorm buffers 5e-3."""
+    from oracle.ops_ref import RefOps
+    from rna_gan_amd.ops_hip import HipOps
+    eps = 0.3
+    # The critic ends in LeakyReLU(h_n): a sample whose head pre-activation h_n sits within bf16 noise of 0 flips its
+    # whole backward contribution by a factor 5 in one evaluation and not in the other (seen: 38 % of the gradient norm
+    # from ONE of 16 samples).  That is a property of the function, not of a kernel, so seeds are searched until every
+    # h_n of the fp64 oracle (the discriminator calls of the iteration) is at least 8 % of the mean |h|.
+    for seed in range(11, 160):
+        G, D = mk(in_size, step, enc, seed)
+        real = R.synthetic_images(n, in_size, seed=3 * seed)
+        noise = R.synthetic_normal(n, enc, seed=3 * seed + 1)
+        hs = []
+        d64, g64 = copy.deepcopy(D).double().train(), copy.deepcopy(G).double().train()
+        hk = d64.disc[0].register_forward_hook(lambda _m, _i, o: hs.append(o.detach().reshape(-1)))
+        with torch.no_grad():
+            fake = g64(noise.double())
+            d64(fake); d64(real.double()); d64(eps * real.double() + (1 - eps) * fake)
+        hk.remove()
+        hcat = torch.cat(hs)
+        if float(hcat.abs().min()) >= 0.08 * float(hcat.abs().mean()):
+            break
+    else:
+        pytest.skip("no seed with a clear head margin")
+    ref, _ = oracle64(G, D, real, noise, eps)
+    res = {}
+    for name, make_ops, dev in (("twin", lambda: RefOps(torch.bfloat16), "cpu"), ("hip", lambda: HipOps(torch.bfloat16, "cuda:0"), "cuda")):
+        Gx, Dx = copy.deepcopy(G).to(dev).train(), copy.deepcopy(D).to(dev).train()
+        E.tap_major_(Gx), E.tap_major_(Dx)
+        Gn, Dn = E.build_gen_net(Gx), E.build_disc_net(Dx)
+        ops = make_ops()
+        r, z = real.to(dev), noise.to(dev)
+        out = {}
+        out["gl"] = float(E.gen_loss_grads(ops, Gn, Dn, z).cpu())
+        out["G"] = {k: p.grad.detach().cpu().clone() for k, p in Gx.named_parameters()}
+        out["dl"] = float(E.disc_loss_grads(ops, Gn, Dn, r, z).cpu())
+        out["D"] = {k: p.grad.detach().cpu().clone() for k, p in Dx.named_parameters()}
+        out["gp"] = float(E.gp_loss_grads(ops, Gn, Dn, r, z, eps, 10.0).cpu())
+        out["P"] = {k: p.grad.detach().cpu().clone() for k, p in Dx.named_parameters()}
+        out["buf"] = {"G." + k: b.detach().cpu().clone() for k, b in Gx.named_buffers()}
+        out["buf"].update({"D." + k: b.detach().cpu().clone() for k, b in Dx.named_buffers()})
+        res[name] = out
+    t, h = res["twin"], res["hip"]
+    for k in ("gl", "dl", "gp"):
+        # (the D loss is a difference of two O(1) means: absolute floor 0.5)
+        assert abs(h[k] - t[k]) <= 3e-2 * (abs(t[k]) + 0.5), (k, h[k], t[k])
+    bad = []
+    for grp in ("G", "D", "P"):
+        for k in t[grp]:
+            if float(ref[grp][k].abs().max()) == 0.0:
+                continue
+            _, e_h, _ = err(h[grp][k], ref[grp][k])
+            _, e_t, _ = err(t[grp][k], ref[grp][k])
+            _, e_ht, cos = err(h[grp][k], t[grp][k])
+            line = f"  {grp} {k}: kernels-fp64 {e_h:.3f}  twin-fp64 {e_t:.3f}  kernels-twin {e_ht:.3f} cos {cos:.5f}"
+            print(line)
+            # two independent bf16 evaluations at distance e from fp64 sit ~sqrt(2) e apart; a 3-element image-bias gradient
+            # is a sum with ~98 % cancellation and gets twice the allowance
+            slack = 2.0 if t[grp][k].numel() <= 16 else 1.0
+            if not (e_h <= slack * (1.5 * e_t + 1e-2) and e_ht <= slack * (1.6 * e_t + 1e-2)):
+                bad.append(line)
+    assert not bad, "\n".join(bad)
+    for k in t["buf"]:
+        if k.endswith("num_batches_tracked"):
+            assert int(h["buf"][k]) == int(t["buf"][k])
+        else:
+            assert err(h["buf"][k], t["buf"][k])[0] <= 5e-3, k

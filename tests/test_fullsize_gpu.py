@@ -52,6 +52,28 @@ def test_conv_layers_full_size(I, O, hs):
     mf.conv_wgrad2(g, x, g2, x2, cw_m, True)
     assert relmax(cw_m.dw, 3 * dw1) < 2e-3
 
+    # INDEPENDENT reference (not this library): torch's fp32 convolutions on the host over the same bf16-rounded
+    # operands -- forward / transposed convolution on a slice of samples (first, last and one from the middle, so row
+    # tiles at both ends of M and every parity class are covered), weight gradient over the FULL batch for a slice of
+    # 8 low-resolution-side channels at both ends of O
+    import torch.nn.functional as F
+    w_oihw = w.permute(0, 3, 1, 2).contiguous().cpu()
+    sel = [0, N // 2 + 1, N - 1]
+    xs = x[sel].float().permute(0, 3, 1, 2).cpu()
+    gs = g[sel].float().permute(0, 3, 1, 2).cpu()
+    y_ref = F.conv2d(xs, w_oihw, stride=2, padding=1).permute(0, 2, 3, 1)
+    u_ref = F.conv_transpose2d(gs, w_oihw, stride=2, padding=1).permute(0, 2, 3, 1)
+    assert relmax(y[sel].cpu(), y_ref) < 8e-3, "conv_down vs torch fp32 conv2d"
+    assert relmax(u[sel].cpu(), u_ref) < 8e-3, "conv_up vs torch fp32 conv_transpose2d"
+    m_ref = u_ref * torch.where(mask[sel].float().cpu() > 0, 1.0, 0.2)
+    assert relmax(mf.conv_up(g, cw_m, mask, 0.2)[sel].cpu(), m_ref) < 8e-3, "conv_up (fused LeakyReLU mask) vs torch"
+    xa = x.float().permute(0, 3, 1, 2).cpu()
+    for o0 in (0, O - 8):
+        ga = g[..., o0:o0 + 8].float().permute(0, 3, 1, 2).contiguous().cpu()
+        dw_ref = torch.nn.grad.conv2d_weight(xa, (8, I, 4, 4), ga, stride=2, padding=1)       # [8][I][4][4]
+        got = cw_m.dw[o0:o0 + 8].permute(0, 3, 1, 2).cpu() / 3.0                              # dw holds 3 x wgrad(g, x) now
+        assert relmax(got, dw_ref) < 3e-3, "conv_wgrad vs torch fp32 conv2d_weight (channels %d..)" % o0
+
     # epilogue statistics (when this launch produces them): exact column sums of what was stored
     if st is not None:
         yf = y.float().reshape(-1, O)
