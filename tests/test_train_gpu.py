@@ -165,8 +165,8 @@ def test_full_size_one_iteration_bf16():
 def test_full_size_batch64_bf16():
     """BASELINE configs[1] shape exactly (batch 64 at the reference model size): this is where the MFMA launchers pick
     their large-batch variants (256x256 tiles, class-fastest block order, 512-block wgrad grids, row-staged image-side
-    kernels).  One iteration against the fp32 CPU oracle: the three losses and the direction of the first Adam update
-    of the two largest layers."""
+    kernels).  One iteration against the fp32 CPU oracle: the three losses and the direction of the Adam update of
+    every parameter tensor."""
     in_size, step, enc, n = 256, 64, 2048, 64
     G0 = R.seeded_fill_(R.OracleDCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
                                                last_nonlinearity=nn.Tanh()), 27)
@@ -186,13 +186,22 @@ def test_full_size_batch64_bf16():
     print("batch-64 losses hip/ref:", lg, ref["g"], ld, ref["d"], lp, ref["gp"])
     for got, want in ((lg, ref["g"]), (ld, ref["d"]), (lp, ref["gp"])):
         assert np.isfinite(got) and abs(got - want) <= 6e-2 * (abs(want) + 0.1)
-    for name, mod, mod0, modo in (("model.1.0.weight", G, G0, Go), ("model.5.0.weight", D, D0, Do)):
-        w0 = mod0.state_dict()[name].double()
-        du_hip = mod.state_dict()[name].cpu().double() - w0
-        du_ref = modo.state_dict()[name].double() - w0
-        cos = float((du_hip * du_ref).sum() / (du_hip.norm() * du_ref.norm() + 1e-30))
-        print(name, "update cosine", cos)
-        assert cos >= 0.75, (name, cos)
+    # EVERY parameter tensor: direction of the accumulated update (G: one Adam step, D: two).  The first Adam step is
+    # lr * sign(g) element-wise, so the cosine is (sign agreements - disagreements) / numel: with the 10-15 % relative
+    # gradient noise of bf16 storage (test_bf16_kernels_vs_bf16_rounding_twin) ~5-8 % of the signs flip (elements with
+    # |g| inside the noise) -> cosine ~0.85-0.9; a wrong kernel on any layer drives its tensor's cosine towards 0.
+    worst = (1.0, None)
+    for tag, mod, mod0, modo in (("G", G, G0, Go), ("D", D, D0, Do)):
+        sd, sdo, sd0 = mod.state_dict(), modo.state_dict(), mod0.state_dict()
+        for name, _ in mod0.named_parameters():
+            w0 = sd0[name].double()
+            du_hip = sd[name].cpu().double() - w0
+            du_ref = sdo[name].double() - w0
+            cos = float((du_hip * du_ref).sum() / (du_hip.norm() * du_ref.norm() + 1e-30))
+            print("%s.%-22s numel %9d  update cosine %.4f" % (tag, name, w0.numel(), cos))
+            worst = min(worst, (cos, tag + "." + name))
+            assert cos >= (0.8 if w0.numel() >= 4096 else 0.65), (tag, name, cos)
+    print("worst update cosine:", worst)
 
 
 def test_graph_replay_equals_eager():
