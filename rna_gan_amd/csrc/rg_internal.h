@@ -86,6 +86,12 @@ size_t rg_mfma_wgrad2_ws_bytes(int N, int Ho, int Wo, int O, int I);
 // rg_conv8.hip (8-wave ping-pong gather GEMM; args = G2Args of rg_gather.h)
 int rg_conv8_launch(int mode, const void* args, int bm, unsigned gx, unsigned gy, unsigned gz, hipStream_t st);
 
+// rg_wgrad8.hip (8-wave ping-pong weight gradient)
+bool rg_wgrad8_supported(int K, int O, int I);
+int rg_wgrad8_split(int K, int O, int I, int* kt_per_split);
+int rg_wgrad8_launch(const void* low0, const void* high0, const void* low1, const void* high1, float* out, int Kseg,
+                     int two, int O, int I, int Ho, int Wo, int nsplit, int kt_per_split, int accumulate, hipStream_t st);
+
 // rg_skinny.hip (image-side 3-channel layers)
 bool rg_skinny_supported(int I, int O);
 int rg_skinny_first_down(const float* x, const float* w, const float* bias, void* y, int N, int H, int W, int I,

@@ -1348,8 +1348,21 @@ int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, c
     return rg_mfma_conv_wgrad(low1, high1, dw, N, Ho, Wo, O, I, 1, ws, ws_bytes, st);
   }
   const int K = two ? 2 * Kseg : Kseg;
-  int nsplit = mfma_wgrad_split_k(K, O, I);
   size_t elems = (size_t)O * I * 16;
+  if (rg_option("wgrad8", 1) && rg_wgrad8_supported(K, O, I)) {        // 8-wave ping-pong kernel (rg_wgrad8.hip)
+    int per = 0;
+    const int ns = rg_wgrad8_split(K, O, I, &per);
+    // (measured, batch 64: where the 128 x 128 kernel needs no split-K but this one does -- 128 tiles of 256 x 256 --
+    // a single segment is faster there: 76 vs 83 us, no slab pass; with two segments the longer k-loop wins back)
+    const bool old_direct = mfma_wgrad_split_k(K, O, I) == 1 && ns > 1 && !two && rg_option("wgrad8", 1) == 1;
+    if (!old_direct && (ns == 1 || (ws && ws_bytes >= (size_t)ns * elems * sizeof(float)))) {
+      int rc = rg_wgrad8_launch(low0, high0, low1, high1, ns == 1 ? dw : (float*)ws, Kseg, two ? 1 : 0, O, I, Ho, Wo, ns,
+                                per, accumulate, st);
+      if (rc || ns == 1) return rc;
+      return rg_reduce_slabs((const float*)ws, dw, elems, ns, accumulate, 0, 0, st);
+    }
+  }
+  int nsplit = mfma_wgrad_split_k(K, O, I);
   RG_REQUIRE(ws && ws_bytes >= (size_t)nsplit * elems * sizeof(float), RG_EWORKSPACE,
              "conv_wgrad(mfma): workspace too small");
   W2Args g{};
@@ -1375,7 +1388,14 @@ int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, c
 size_t rg_mfma_wgrad2_ws_bytes(int N, int Ho, int Wo, int O, int I) {
   size_t a = (size_t)mfma_wgrad_split_k(N * Ho * Wo, O, I) * O * I * 16 * sizeof(float);
   size_t b = (size_t)mfma_wgrad_split_k(2 * N * Ho * Wo, O, I) * O * I * 16 * sizeof(float);
-  return a > b ? a : b;
+  size_t m = a > b ? a : b;
+  for (int k = 1; k <= 2; ++k)
+    if (rg_wgrad8_supported(k * N * Ho * Wo, O, I)) {
+      int per = 0;
+      const size_t c = (size_t)rg_wgrad8_split(k * N * Ho * Wo, O, I, &per) * O * I * 16 * sizeof(float);
+      if (c > m) m = c;
+    }
+  return m;
 }
 
 int rg_mfma_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I, hipStream_t st) {

@@ -162,6 +162,44 @@ def test_conv8_pingpong_kernel(N, Hi, Wi, I, O, mode, mfma):
             lib.rg_set_option(k, -1)
 
 
+@pytest.mark.parametrize("blocks", [1, 8, 256])
+@pytest.mark.parametrize("N,Hi,Wi,I,O", [(2, 32, 32, 64, 256),      # 8 k-tiles of 64 pixels, 1 x 4 output tiles
+                                         (3, 16, 16, 128, 256),     # 192 pixels per segment: ragged last k-tile
+                                         (5, 16, 16, 64, 512),      # 320 pixels: two row tiles of output channels
+                                         (1, 32, 32, 256, 256)])    # one tap per 256-column tile
+def test_wgrad8_pingpong_kernel(N, Hi, Wi, I, O, blocks):
+    """The 8-wave ping-pong weight-gradient kernel (rg_wgrad8.hip): one and two segments, overwrite and accumulate,
+    direct write (one split) and split-K slabs, ragged pixel counts -- against the torch twin."""
+    from rna_gan_amd import _abi
+    lib = _abi.load()
+    dtype = torch.bfloat16
+    ref, hip = RefOps(dtype), _hip(dtype)
+    try:
+        _abi.check(lib.rg_set_option(b"wgrad8", 1), "rg_set_option")
+        _abi.check(lib.rg_set_option(b"wgrad8_blocks", blocks), "rg_set_option")
+        w = rnd((O, I, 4, 4), 1, (2.0 / (I * 16)) ** 0.5)
+        cr, ch = cwpair_tm(w)
+        x = rnd((N, Hi, Wi, I), 2).to(dtype)
+        g = rnd((N, Hi // 2, Wi // 2, O), 3).to(dtype)
+        ref.conv_wgrad(g, x, cr, False)
+        dw_ref = cr.dw.clone()
+        hip.conv_wgrad(dev(g), dev(x), ch, False)          # overwrites the 7.0 fill
+        check(ch.dw, dw_ref, TOL[dtype] * 2, "conv_wgrad")
+        hip.conv_wgrad(dev(g), dev(x), ch, True)
+        check(ch.dw, 2 * dw_ref, TOL[dtype] * 2, "conv_wgrad(accumulate)")
+        if (N * Hi * Wi // 4) % 64 == 0:                   # two segments need whole 64-pixel k-tiles per segment
+            g2, x2 = rnd((N, Hi // 2, Wi // 2, O), 13).to(dtype), rnd((N, Hi, Wi, I), 12).to(dtype)
+            ref.conv_wgrad(g, x, cr, False); ref.conv_wgrad(g2, x2, cr, True)
+            ch.dw.fill_(-5.0)
+            hip.conv_wgrad2(dev(g), dev(x), dev(g2), dev(x2), ch, False)
+            check(ch.dw, cr.dw, TOL[dtype] * 2, "conv_wgrad2")
+            hip.conv_wgrad2(dev(g), dev(x), dev(g2), dev(x2), ch, True)
+            check(ch.dw, 2 * cr.dw, TOL[dtype] * 2, "conv_wgrad2(accumulate)")
+    finally:
+        for k in (b"wgrad8", b"wgrad8_blocks"):
+            lib.rg_set_option(k, -1)
+
+
 def test_u8_to_norm_bit_exact():
     """a15 input contract (src/histopathology_gan.py:106-109): device-side uint8 -> (x / 255 - 0.5) / 0.5 equals the
     host transform bit for bit, including a length that is not a multiple of 16."""

@@ -63,7 +63,7 @@ def ref_slice(kind, x, g, w, n_s=2):
 
 
 layers = [int(v) for v in args.layers.split(",")]
-kinds = args.kinds.split(",") + (["wgrad"] if args.wgrad else [])
+kinds = [k for k in args.kinds.split(",") if k] + (["wgrad", "wgrad2"] if args.wgrad else [])
 tot = {(k, i): [0.0, 0.0] for k in kinds for i in range(len(sets))}
 torch.manual_seed(0)
 for l in range(5):
@@ -77,8 +77,9 @@ for l in range(5):
     x = torch.randn(N, hs, hs, I, device=dev).to(torch.bfloat16)
     g = torch.randn(N, hs // 2, hs // 2, O, device=dev).to(torch.bfloat16)
     flops = 2.0 * N * (hs // 2) ** 2 * O * I * 16
+    x2, g2 = x.flip(0).contiguous(), g.flip(0).contiguous()
     fns = {"down": lambda: ops.conv_down(x, cw, want_stats=True), "up": lambda: ops.conv_up(g, cw, want_stats=True),
-           "wgrad": lambda: ops.conv_wgrad(g, x, cw, False)}
+           "wgrad": lambda: ops.conv_wgrad(g, x, cw, False), "wgrad2": lambda: ops.conv_wgrad2(g, x, g2, x2, cw, False)}
     for kind in kinds:
         fn = fns[kind]
         base = None
@@ -86,7 +87,7 @@ for l in range(5):
         if args.check:
             for i, st in enumerate(sets):
                 apply(st)
-                if kind == "wgrad":
+                if kind.startswith("wgrad"):
                     fn()
                     y, stt = cw.dw.clone().float(), None
                 else:
@@ -95,7 +96,7 @@ for l in range(5):
                 torch.cuda.synchronize()
                 if base is None:
                     base = y
-                    if kind != "wgrad":
+                    if not kind.startswith("wgrad"):
                         r = ref_slice(kind, x, g, w)
                         err = (y[:r.shape[0]] - r).abs().max().item() / (r.abs().max().item() + 1e-9)
                         notes.append("set0 vs torch fp32 (2 samples): rel-max %.2e" % err)
@@ -118,9 +119,10 @@ for l in range(5):
         line = "L%d I=%4d O=%4d hi=%3d %-5s" % (l + 1, I, O, hs, kind)
         for i in range(len(sets)):
             med = sorted(times[i])[len(times[i]) // 2]
-            tot[(kind, i)][0] += flops
+            fl = flops * (2 if kind == "wgrad2" else 1)
+            tot[(kind, i)][0] += fl
             tot[(kind, i)][1] += med
-            line += " | set%d %7.1f us %7.1f TF (min %6.1f)" % (i, med * 1e6, flops / med / 1e12, min(times[i]) * 1e6)
+            line += " | set%d %7.1f us %7.1f TF (min %6.1f)" % (i, med * 1e6, fl / med / 1e12, min(times[i]) * 1e6)
         print(line, " ; ".join(notes), flush=True)
 for i, st in enumerate(sets):
     print("set%d = %s" % (i, st))
