@@ -404,10 +404,357 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
   }
 }
 
+
+// ================================================================================================================
+// conv8n_kernel: the transposed conv with 64 output channels (the generator's last MFMA layer 128 -> 64 at 128 x 128 and
+// the discriminator's data gradient of layer 1).  K per parity class is only 4 taps x Cin (8 k-tiles at Cin = 128), so
+// a block that computes one class of one row tile spends more time filling and draining its pipeline than computing.
+// Here a block keeps its 512 low-resolution pixels and walks ALL FOUR parity classes as one stream of 16 "virtual
+// taps" (class-major): the DMA prefetch runs across the class boundaries, and at each boundary the waves flush their
+// accumulators through a wave-private 2 KB LDS scratch (no block barrier) while the next class's tiles are already in
+// flight.  Block tile 512 x 64, 8 waves of 64 x 64 (quadrants 32 x 32, v_mfma_f32_16x16x32_bf16), A half-tile = 256
+// rows (4 block-wide DMA instructions), B half-tile = 32 rows (issued by waves 0-3 only: their counted waits differ).
+// ================================================================================================================
+__global__ __launch_bounds__(512, 2) void conv8n_kernel(G2Args a2) {
+  constexpr int AH = 256 * 128, BH = 32 * 128;               // bytes per half-tile
+  constexpr int STAGE = 2 * AH + 2 * BH;                     // 72 KB, [B0][B1][A0][A1]
+  constexpr int OFF_B = 0, OFF_A = 2 * BH;
+  constexpr int SCRATCH = 2 * STAGE;                         // 8 x 2 KB wave-private epilogue scratch behind the stages
+  constexpr int LDS_BYTES = SCRATCH + 8 * 2048;              // 160 KB
+  __shared__ __attribute__((aligned(16))) uint4 lds[LDS_BYTES / 16];
+  const GArgs& g = a2.g;
+
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lane = t & 63;
+  int bid = blockIdx.x;
+  if (a2.xcd_swizzle) bid = (bid & 7) * ((int)gridDim.x >> 3) + (bid >> 3);
+  const int tile_m = bid;
+  const int bm = tile_m * 512;
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, a2.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)g.B, 0, a2.b_bytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+
+  const int pc = t & 7, r0 = t >> 3;
+  const int lc = pc ^ ((r0 >> 1) & 7);
+  const int Wq = 1 << g.lgW, Hq = 1 << g.lgH;
+  int a_off[8];                      // [half][j]: byte offset of the row's own pixel + this lane's chunk
+  unsigned a_mask[4];                // 16 virtual-tap bits per row, two rows (half 0 low / half 1 high) per register
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a_mask[j] = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = bm + h * 256 + j * 64 + r0;
+      const bool ok = m < g.M;
+      const int mm = ok ? m : 0;
+      const int wq = mm & (Wq - 1), hq = (mm >> g.lgW) & (Hq - 1), n = mm >> (g.lgW + g.lgH);
+      unsigned mask = 0;
+#pragma unroll
+      for (int vt = 0; vt < 16; ++vt) {
+        int kh, kw, dh, dw;
+        up_tap_dev(vt >> 3, (vt >> 1) & 1, kh, dh);          // class = vt >> 2 = (ph, pw); tap = vt & 3 = (a, b)
+        up_tap_dev((vt >> 2) & 1, vt & 1, kw, dw);
+        const bool v = (unsigned)(hq + dh) < (unsigned)g.Hs && (unsigned)(wq + dw) < (unsigned)g.Ws;
+        mask |= (v ? 1u : 0u) << vt;
+      }
+      a_off[h * 4 + j] = (int)(((((long long)n * g.Hs + hq) * g.Ws + wq) * g.Cin + lc * 8) * 2);
+      a_mask[j] |= (ok ? mask : 0u) << (16 * h);
+    }
+  int b_off[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) b_off[h] = (int)(((long long)(h * 32 + (r0 & 31)) * g.b_col + lc * 8) * 2);
+
+  const int cpt = g.Cin >> 6;
+  const int nkc = 4 * cpt;                                    // k-tiles per class
+  const int nkt = 16 * cpt;
+  const int lgcpt = a2.lgcpt, cmask = a2.cmask;
+  char* const ldsb = reinterpret_cast<char*>(lds);
+
+  auto decode = [&](int kt, int& ao, int& bo, int& vt) {
+    vt = (kt >> lgcpt) & 15;
+    const int c0 = (kt & cmask) << 6;
+    int kh, kw, dh, dw;
+    up_tap_dev(vt >> 3, (vt >> 1) & 1, kh, dh);
+    up_tap_dev((vt >> 2) & 1, vt & 1, kw, dw);
+    ao = ((dh * g.Ws + dw) * g.Cin + c0) * 2;
+    bo = ((kh * 4 + kw) * g.b_tap + c0) * 2;
+  };
+  auto issue_a = [&](auto S, auto H, int kt) {
+    constexpr int s = decltype(S)::value, h = decltype(H)::value;
+    int ao, bo, vt;
+    decode(kt, ao, bo, vt);
+    const unsigned dead = kt < nkt ? 0u : OOB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool v = (a_mask[j] >> (vt + 16 * h)) & 1u;
+      const unsigned vo = (v ? (unsigned)(a_off[h * 4 + j] + ao) : OOB) | dead;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsA, (lds_vptr_t)(ldsb + s * STAGE + OFF_A + h * AH + j * 8192 + wave * 1024), 16, vo, 0, 0, 0);
+    }
+  };
+  auto issue_b = [&](auto S, auto H, int kt) {                // waves 0-3 only (32 rows = half a block-wide instruction)
+    constexpr int s = decltype(S)::value, h = decltype(H)::value;
+    if (wave < 4) {
+      int ao, bo, vt;
+      decode(kt, ao, bo, vt);
+      const unsigned dead = kt < nkt ? 0u : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_vptr_t)(ldsb + s * STAGE + OFF_B + h * BH + wave * 1024), 16,
+                                               (unsigned)(b_off[h] + bo) | dead, 0, 0, 0);
+    }
+  };
+
+  // ---- fragments (16x16x32: lane = (row fr of 16, k-quarter fh))
+  const int fr = lane & 15, fh = lane >> 4;
+  const unsigned lds_base = (unsigned)(size_t)(lds_vptr_t)lds;
+  unsigned aB[2][2], bB[2][2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const unsigned ch = (unsigned)((4 * kk + fh) ^ ((fr >> 1) & 7));
+    aB[0][kk] = lds_base + OFF_A + 16u * (unsigned)((wave * 32 + fr) * 8 + ch);
+    bB[0][kk] = lds_base + OFF_B + 16u * (unsigned)(fr * 8 + ch);
+    aB[1][kk] = aB[0][kk] + STAGE;
+    bB[1][kk] = bB[0][kk] + STAGE;
+  }
+  f32x4_t acc[2][2][4];              // [quadrant row i][quadrant column j][row sub-tile * 2 + column sub-tile]
+  u32x4_t aR[4];                     // [row sub-tile][k-step]
+  u32x4_t bS[3][4];                  // [set][column sub-tile][k-step]
+
+#define N8_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define N8_READ_A(S, H)                                                                                        \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_)       \
+        N8_DSR(aR[t_ * 2 + kk_], aB[S][kk_], (H) * AH + t_ * 2048);                                            \
+  } while (0)
+#define N8_READ_B(S, H, SET)                                                                                   \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_)       \
+        N8_DSR(bS[SET][t_ * 2 + kk_], bB[S][kk_], (H) * BH + t_ * 2048);                                       \
+  } while (0)
+#define N8_WAIT_A() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(aR[0]), "+v"(aR[1]), "+v"(aR[2]), "+v"(aR[3])::"memory")
+#define N8_WAIT_B(SET) \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bS[SET][0]), "+v"(bS[SET][1]), "+v"(bS[SET][2]), "+v"(bS[SET][3])::"memory")
+#define N8_MFMAS(I, J, SET)                                                                                    \
+  do {                                                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                                             \
+    _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_) _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_)       \
+    _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_)                                                           \
+        acc[I][J][t_ * 2 + c_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                      \
+            __builtin_bit_cast(bf16x8_t, aR[t_ * 2 + kk_]), __builtin_bit_cast(bf16x8_t, bS[SET][c_ * 2 + kk_]), \
+            acc[I][J][t_ * 2 + c_], 0, 0, 0);                                                                  \
+    __builtin_amdgcn_s_setprio(0);                                                                             \
+  } while (0)
+#define N8_SYNC() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+  // counted waits: NA = 4 DMA instructions per A half-tile, NB = 1 (waves 0-3) or 0 (waves 4-7) per B half-tile
+#define N8_WAITV(ODD)                                                                        \
+  do {                                                                                       \
+    if (wave < 4) __builtin_amdgcn_s_waitcnt((ODD) ? vmcnt_imm(14) : vmcnt_imm(11));         \
+    else __builtin_amdgcn_s_waitcnt((ODD) ? vmcnt_imm(12) : vmcnt_imm(8));                   \
+  } while (0)
+#define N8_TILE(S, SB0, SNX, U)                                                              \
+  do {                                                                                       \
+    N8_READ_A(S, 0);                                                                         \
+    issue_a(ic<1 - (S)>{}, ic<1>{}, (U) + 1);                                                \
+    N8_WAITV(1);                                                                             \
+    N8_SYNC();                                                                               \
+    N8_WAIT_A();                                                                             \
+    N8_MFMAS(0, 0, SB0);                                                                     \
+    N8_SYNC();                                                                               \
+    N8_READ_B(S, 1, 1);                                                                      \
+    issue_b(ic<(S)>{}, ic<0>{}, (U) + 2);                                                    \
+    N8_WAITV(0);                                                                             \
+    N8_SYNC();                                                                               \
+    N8_WAIT_B(1);                                                                            \
+    N8_MFMAS(0, 1, 1);                                                                       \
+    N8_SYNC();                                                                               \
+    N8_READ_A(S, 1);                                                                         \
+    issue_a(ic<(S)>{}, ic<0>{}, (U) + 2);                                                    \
+    N8_WAITV(1);                                                                             \
+    N8_SYNC();                                                                               \
+    N8_WAIT_A();                                                                             \
+    N8_MFMAS(1, 1, 1);                                                                       \
+    N8_SYNC();                                                                               \
+    N8_READ_B(1 - (S), 0, SNX);                                                              \
+    issue_b(ic<(S)>{}, ic<1>{}, (U) + 2);                                                    \
+    N8_WAITV(0);                                                                             \
+    N8_SYNC();                                                                               \
+    N8_WAIT_B(SNX);                                                                          \
+    N8_MFMAS(1, 0, SB0);                                                                     \
+    N8_SYNC();                                                                               \
+  } while (0)
+
+  // ---- epilogue geometry: a flush walks the wave's 64 rows in pieces of 8 rows x 64 columns of fp32 (2 KB); in the
+  // read-back lane L owns row L >> 3 of the piece and 8 consecutive channels (L & 7) * 8
+  const int e_row = lane >> 3, e_c8 = (lane & 7) * 8;
+  const unsigned scr_base = lds_base + SCRATCH + wave * 2048;
+  const unsigned scr_w = scr_base + (unsigned)(((4 * (fh & 1)) * 64 + fr) * 4);       // + (r*64 + j*32 + c*16) * 4
+  const unsigned scr_r = scr_base + (unsigned)((e_row * 64 + e_c8) * 4);
+  long long e_orow[8];               // output row (class (0,0)) of this lane's read-back row in each of the 8 pieces
+  bool e_ok[8];
+#pragma unroll
+  for (int pz = 0; pz < 8; ++pz) {                            // piece = (i, row sub-tile rt, half p): rows i*256 + wave*32 + rt*16 + 8p + e_row
+    const int m = bm + (pz >> 2) * 256 + wave * 32 + ((pz >> 1) & 1) * 16 + (pz & 1) * 8 + e_row;
+    e_ok[pz] = m < g.M;
+    const int mm = e_ok[pz] ? m : 0;
+    const int wq = mm & (Wq - 1), hq = (mm >> g.lgW) & (Hq - 1), n = mm >> (g.lgW + g.lgH);
+    e_orow[pz] = ((long long)n * (2 * Hq) + 2 * hq) * (2 * Wq) + 2 * wq;
+  }
+  // Fused LeakyReLU backward (data gradient of the discriminator's layer 1): the 8 mask vectors a lane needs for a class
+  // are loaded (inline asm: an ordinary load waited for by the compiler would drain the LDS-DMA queue) two k-tiles
+  // BEFORE the class ends and waited for with a counted vmcnt in the flush: the DMA instructions of those two k-tiles
+  // (2 x (4 + 4 + NB + NB)) are younger and stay in flight.
+  u32x4_t mreg[8];
+  auto load_masks = [&](int cls) {
+    const long long cls_off = (long long)(cls >> 1) * (2 * Wq) + (cls & 1);
+#pragma unroll
+    for (int pz = 0; pz < 8; ++pz) {
+      const uint16_t* mp = g.mask + (e_orow[pz] + cls_off) * 64 + e_c8;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(mreg[pz]) : "v"(mp) : "memory");
+    }
+  };
+  auto flush = [&](int cls) {
+    const int ph = cls >> 1, pw = cls & 1;
+    const long long cls_off = (long long)ph * (2 * Wq) + pw;
+    if (g.mask) {
+      if (wave < 4)
+        asm volatile("s_waitcnt vmcnt(20)" : "+v"(mreg[0]), "+v"(mreg[1]), "+v"(mreg[2]), "+v"(mreg[3]), "+v"(mreg[4]),
+                     "+v"(mreg[5]), "+v"(mreg[6]), "+v"(mreg[7])::"memory");
+      else
+        asm volatile("s_waitcnt vmcnt(16)" : "+v"(mreg[0]), "+v"(mreg[1]), "+v"(mreg[2]), "+v"(mreg[3]), "+v"(mreg[4]),
+                     "+v"(mreg[5]), "+v"(mreg[6]), "+v"(mreg[7])::"memory");
+    }
+    // BatchNorm partial sums of this class (column sums of the bf16-rounded values over the wave's 64 rows)
+    if (g.stats) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float v = bf16_to_f32(f32_to_bf16(acc[i][j][rt * 2 + c][r]));
+                s1 += v; s2 += v * v;
+              }
+          s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+          s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+          if (fh == 0) {
+            const size_t grow = ((size_t)cls * a2.tiles_m + tile_m) * 8 + wave;
+            const int gcol = j * 32 + c * 16 + fr;
+            g.stats[(grow * 2 + 0) * 64 + gcol] = s1;
+            g.stats[(grow * 2 + 1) * 64 + gcol] = s2;
+          }
+        }
+    }
+#pragma unroll
+    for (int pz = 0; pz < 8; ++pz) {
+      const int i = pz >> 2, rt = (pz >> 1) & 1, p = pz & 1;
+      // accumulator rows of a 16x16 tile: 4*fh + r; piece p holds rows 8p .. 8p+7, i.e. lanes with fh >> 1 == p.
+      // Scratch accesses are inline asm: compiler-visible LDS accesses behind outstanding LDS-DMAs get an
+      // s_waitcnt vmcnt(0) in front (hipcc assumes they alias), which would drain the prefetch at every class boundary.
+      if ((fh >> 1) == p) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(scr_w), "v"(acc[i][j][rt * 2 + c][r]),
+                           "n"(r * 256 + j * 128 + c * 64) : "memory");
+      }
+      // (same wave, LDS executes a wave's instructions in order: the reads see the writes without a barrier)
+      u32x4_t q0, q1;
+      asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(q0) : "v"(scr_r) : "memory");
+      asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(q1) : "v"(scr_r) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q0), "+v"(q1)::"memory");
+      float4 v0 = __builtin_bit_cast(float4, q0), v1 = __builtin_bit_cast(float4, q1);
+      if (e_ok[pz]) {
+        const long long orow = e_orow[pz] + cls_off;
+        if (g.mask) {
+          const u32x4_t a = mreg[pz];
+          v0.x *= rg_lmask(a.x, g.mslope); v0.y *= rg_lmask(a.x >> 16, g.mslope);
+          v0.z *= rg_lmask(a.y, g.mslope); v0.w *= rg_lmask(a.y >> 16, g.mslope);
+          v1.x *= rg_lmask(a.z, g.mslope); v1.y *= rg_lmask(a.z >> 16, g.mslope);
+          v1.z *= rg_lmask(a.w, g.mslope); v1.w *= rg_lmask(a.w >> 16, g.mslope);
+        }
+        uint4 o;
+        o.x = (uint32_t)f32_to_bf16(v0.x) | ((uint32_t)f32_to_bf16(v0.y) << 16);
+        o.y = (uint32_t)f32_to_bf16(v0.z) | ((uint32_t)f32_to_bf16(v0.w) << 16);
+        o.z = (uint32_t)f32_to_bf16(v1.x) | ((uint32_t)f32_to_bf16(v1.y) << 16);
+        o.w = (uint32_t)f32_to_bf16(v1.z) | ((uint32_t)f32_to_bf16(v1.w) << 16);
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(g.C) + orow * 64 + e_c8) = o;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][s][r] = 0.f;
+  };
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][s][r] = 0.f;
+
+  issue_b(ic<0>{}, ic<0>{}, 0);
+  issue_a(ic<0>{}, ic<0>{}, 0);
+  issue_b(ic<0>{}, ic<1>{}, 0);
+  issue_a(ic<0>{}, ic<1>{}, 0);
+  issue_b(ic<1>{}, ic<0>{}, 1);
+  issue_a(ic<1>{}, ic<0>{}, 1);
+  issue_b(ic<1>{}, ic<1>{}, 1);
+  N8_WAITV(0);                                                 // 2 NA + 3 NB behind A0[0]
+  N8_SYNC();
+  N8_READ_B(0, 0, 0);
+  N8_WAIT_B(0);
+  if (wave >= 4) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+  for (int cls = 0; cls < 4; ++cls) {
+    const int u0 = cls * nkc;
+#pragma unroll 1
+    for (int u = u0; u < u0 + nkc; u += 2) {
+      if (g.mask && u == u0 + nkc - 2) load_masks(cls);
+      N8_TILE(0, 0, 2, u);
+      N8_TILE(1, 2, 0, u + 1);
+    }
+    flush(cls);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (wave < 4) __builtin_amdgcn_s_barrier();
+#undef N8_TILE
+#undef N8_WAITV
+#undef N8_SYNC
+#undef N8_MFMAS
+#undef N8_WAIT_A
+#undef N8_WAIT_B
+#undef N8_READ_A
+#undef N8_READ_B
+#undef N8_DSR
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace
 
-
-
+// transposed conv with 64 output channels, all four parity classes per block (conv8n_kernel): grid = row tiles of 512
+int rg_conv8n_launch(const void* args, unsigned tiles_m, hipStream_t st) {
+  const G2Args& a2 = *reinterpret_cast<const G2Args*>(args);
+  hipLaunchKernelGGL(conv8n_kernel, dim3(tiles_m), dim3(512), 0, st, a2);
+  return RG_OK;
+}
 
 int rg_conv8_launch(int mode, const void* args, int bm, unsigned gx, unsigned gy, unsigned gz, hipStream_t st) {
   const G2Args& a2 = *reinterpret_cast<const G2Args*>(args);

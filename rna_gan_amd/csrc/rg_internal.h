@@ -85,6 +85,7 @@ size_t rg_mfma_wgrad2_ws_bytes(int N, int Ho, int Wo, int O, int I);
 
 // rg_conv8.hip (8-wave ping-pong gather GEMM; args = G2Args of rg_gather.h)
 int rg_conv8_launch(int mode, const void* args, int bm, unsigned gx, unsigned gy, unsigned gz, hipStream_t st);
+int rg_conv8n_launch(const void* args, unsigned tiles_m, hipStream_t st);
 
 // rg_wgrad8.hip (8-wave ping-pong weight gradient)
 bool rg_wgrad8_supported(int K, int O, int I);

@@ -1093,7 +1093,7 @@ static bool use_v1() { return rg_option("conv_v1", 0) == 1; }
 
 // split-K policy of the DMA kernel: only when the grid cannot fill the chip (< 1 block per CU) and K is long
 // tile variant / split-K decision of the DMA kernel, shared by the launcher and by rg_mfma_conv_stats_rows
-struct GPlan { bool narrow, wide; int nsplit; bool c8; int bm, bn; };
+struct GPlan { bool narrow, wide; int nsplit; bool c8; int bm, bn; bool n8; };
 
 static int gather_split(int M, int Ncols, int nclass, int nkt, bool allow, int cap = 4, int min_kt = 16) {
   if (!allow) return 1;
@@ -1123,6 +1123,16 @@ static GPlan gather_plan(int mode, bool bf16_out, int M, int Ncols, int Cin, int
   const int nkt = taps * (Cin >> 6);
   GPlan pl{};
   const int cpt = Cin >> 6;
+  // n8: the 64-column transposed conv with all four parity classes per block (conv8n_kernel).  Measured at batch 64
+  // (128 -> 64 channels at 128 x 128): 161-168 us against 110-112 us for the one-class 256 x 64 kernel -- correct
+  // (bit-identical) but slower: the layer re-reads every input pixel 16 times (4 classes x 4 taps) through LDS-DMA,
+  // the 160 KB of LDS bound the bytes in flight per CU and one wave group issuing at a time halves them again.  Off
+  // by default (RNAGAN_NARROW8=1 / rg_set_option("narrow8", 1) selects it); kept as the starting point of a kernel
+  // that keeps the input patch resident in LDS instead of re-fetching it per tap.
+  if (rg_option("narrow8", 0) && bf16_out && mode == MODE_UP && nclass == 4 && Ncols == 64 && rg_is_pow2(cpt) && M >= 512) {
+    pl.n8 = true; pl.nsplit = 1; pl.bm = 512; pl.bn = 64;
+    return pl;
+  }
   if (conv8_mode() && bf16_out && (mode == MODE_DOWN || mode == MODE_UP || mode == MODE_PLAIN) &&
       (taps == 1 || rg_is_pow2(cpt))) {
     int bm = 0, bn = 0;
@@ -1170,6 +1180,7 @@ int rg_mfma_conv_stats_rows(int up, int N, int Hlow, int Wlow, int O, int I) {
   if (use_v1() || a_bytes >= 0x7fffff00ull || b_bytes >= 0x7fffff00ull) return 0;
   GPlan pl = gather_plan(up ? MODE_UP : MODE_DOWN, true, M, Ncols, Cin, taps, nclass, false);
   if (pl.nsplit > 1) return 0;
+  if (pl.n8) return 4 * ((M + 511) / 512) * 8;
   if (pl.c8) return nclass * ((M + pl.bm - 1) / pl.bm) * (pl.bm / 128);
   const int bmm = (pl.narrow || pl.wide) ? 256 : 128, parts = pl.narrow ? 4 : 2;      // BM / wave-tile rows
   return nclass * ((M + bmm - 1) / bmm) * parts;
@@ -1205,7 +1216,17 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   }
   a2.xcd_swizzle = (xcd && grid.x % 8 == 0 && grid.x >= 16 && (xcd == 2 || a_bytes > b_bytes)) ? 1 : 0;
   // (measured and rejected for the 64-column tile: 2 waves with 128 x 64 wave tiles, 147-154 us vs 109-112 us)
-  if (c8) {
+  if (pl.n8) {
+    if constexpr (EPI == EPI_BF16 && MODE == MODE_UP) {
+      a2.class_fast = 0;
+      a2.tiles_m = (g.M + 511) / 512;
+      a2.xcd_swizzle = (xcd && a2.tiles_m % 8 == 0 && a2.tiles_m >= 16) ? 1 : 0;
+      a2.lgcpt = rg_ilog2(g.Cin >> 6);
+      a2.cmask = (g.Cin >> 6) - 1;
+      a2.g.tiles_n = 1;
+      rg_conv8n_launch(&a2, (unsigned)a2.tiles_m, st);
+    }
+  } else if (c8) {
     a2.lgcpt = g.taps == 1 ? 30 : rg_ilog2(g.Cin >> 6);
     a2.cmask = g.taps == 1 ? 0x3fffffff : (g.Cin >> 6) - 1;
     if constexpr (EPI == EPI_BF16 && (MODE == MODE_DOWN || MODE == MODE_UP || MODE == MODE_PLAIN))

@@ -141,6 +141,7 @@ def test_conv8_pingpong_kernel(N, Hi, Wi, I, O, mode, mfma):
         _abi.check(lib.rg_set_option(b"conv8", mode), "rg_set_option")
         _abi.check(lib.rg_set_option(b"conv8_mfma", mfma), "rg_set_option")
         _abi.check(lib.rg_set_option(b"conv8_blocks", 8), "rg_set_option")      # small grids: split-K already at 8 tiles
+        _abi.check(lib.rg_set_option(b"narrow8", 1), "rg_set_option")           # 64-column conv_up: all classes per block
         w = rnd((O, I, 4, 4), 1, (2.0 / (I * 16)) ** 0.5)
         cr, ch = cwpair_tm(w)
         x = rnd((N, Hi, Wi, I), 2).to(dtype)
@@ -158,7 +159,7 @@ def test_conv8_pingpong_kernel(N, Hi, Wi, I, O, mode, mfma):
             check(ss[:, 0, :].sum(0), yf.sum(0), 1e-4, name + " epilogue sum")
             check(ss[:, 1, :].sum(0), (yf * yf).sum(0), 1e-4, name + " epilogue sumsq")
     finally:
-        for k in (b"conv8", b"conv8_mfma", b"conv8_blocks"):
+        for k in (b"conv8", b"conv8_mfma", b"conv8_blocks", b"narrow8"):
             lib.rg_set_option(k, -1)
 
 
