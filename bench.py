@@ -446,13 +446,16 @@ def measure_roofline(ops, device, one_step, step_ms):
                    "tflops": round(f["flops"] / (f["ms"] * 1e-3) / 1e12, 1) if f["ms"] > 0 else None,
                    "share_of_step": round(f["ms"] / step_ms, 3)}
     dom = max(rows, key=lambda k: rows[k]["ms_total"])
-    names = {"conv_fwd_dgrad": "gather_gemm_dma_kernel (bf16 MFMA implicit-GEMM conv: fwd / dgrad / tangent)",
-             "conv_wgrad": "wgrad_dma_kernel (bf16 MFMA weight gradient) + reduce_slabs_kernel"}
-    traffic, traffic_src = pmc_traffic({"conv_fwd_dgrad": "gather_gemm", "conv_wgrad": "wgrad_dma"}.get(dom))
+    names = {"conv_fwd_dgrad": "conv8_kernel + gather_gemm_dma_kernel (bf16 MFMA implicit-GEMM conv: fwd / dgrad / tangent)",
+             "conv_wgrad": "wgrad8_kernel / wgrad_dma_kernel (bf16 MFMA weight gradient) + reduce_slabs_kernel"}
+    pmc_fam = {"conv_fwd_dgrad": "gather_gemm", "conv_wgrad": "wgrad_dma"}.get(dom)
+    traffic, traffic_src = pmc_traffic(pmc_fam)
+    util, util_src = pmc_mfma_util(pmc_fam)
     return {"bound": "mfma", "kernel": names.get(dom, dom), "achieved": rows[dom]["tflops"],
             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(rows[dom]["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
             "traffic_unit": "HBM bytes per launch (PMC)", "traffic_source": traffic_src,
+            "mfma_util": util, "mfma_util_source": util_src,
             "event_pair_overhead_us": round(overhead_ms * 1e3, 2),
             "launches": rows[dom]["launches"], "avg_us_per_launch": rows[dom]["avg_us_per_launch"],
             "share_of_step": rows[dom]["share_of_step"],
@@ -470,6 +473,17 @@ def pmc_traffic(family):
         with open(path) as f:
             row = json.load(f)[family]
         return row["hbm_bytes_per_launch"], "profiles/%s (%d launches)" % (os.path.basename(path), row["launches"])
+    except (OSError, KeyError, ValueError, TypeError):
+        return None, None
+
+
+def pmc_mfma_util(family):
+    """Time-weighted MFMA utilisation (SQ_VALU_MFMA_BUSY_CYCLES / elapsed cycles over the 4 x 256 SIMDs) of a kernel family
+    from the committed rocprofv3 --pmc summary of this workload (tools/pmc_bench.sh + tools/pmc_family.py)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round2_mfma_util.json")
+    try:
+        with open(path) as f:
+            return json.load(f)[family]["mfma_util"], "profiles/round2_mfma_util.json"
     except (OSError, KeyError, ValueError, TypeError):
         return None, None
 

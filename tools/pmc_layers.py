@@ -81,11 +81,13 @@ for key in sorted(rows, key=lambda k: (k[0], k[1])):
 cols = ["kernel", "grid", "wg", "n", "us", "clk_GHz", "mfma_util", "wait_any", "wait_inst", "active", "wait_lds",
         "lds_conflict", "fetch_MB", "write_MB", "l2_hit"]
 cols = [c for c in cols if any(c in r for r in table)]
-print(",".join(cols))
+w = csv.writer(sys.stdout)
+w.writerow(cols)
 for r in table:
-    print(",".join(str(r.get(c, "")) for c in cols))
+    w.writerow([r.get(c, "") for c in cols])
 if out_csv:
-    with open(out_csv, "w") as f:
-        f.write(",".join(cols) + "\n")
+    with open(out_csv, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(cols)
         for r in table:
-            f.write(",".join(str(r.get(c, "")) for c in cols) + "\n")
+            w.writerow([r.get(c, "") for c in cols])
