@@ -6,10 +6,10 @@ Same flags (--config --checkpoint --seed --image_dir --model_dir --num_epochs --
 [flag, encoder_checkpoint, bag_size]); the model/optimizer dictionary, loss selection, Trainer call
 and checkpoint naming follow src/histopathology_gan.py:175-192,248-278,298-314.
 
-The reference script itself cannot start (absent modules wsi_model/biggan/sagan); the
-tile store (LMDB + lz4 + pickle, src/read_data.py) is outside this build's scope, so real data needs
-the reference's dataset classes on PYTHONPATH; ``--synthetic`` trains on synthetic tiles / RNA rows of
-the right shapes (what bench.py measures).  Extra flags: --batch_size (reference hard-codes 8),
+The reference script itself cannot start (absent modules wsi_model/biggan/sagan).  Real data goes
+through rna_gan_amd.data (the reference's tile-record format, per-slide sampling and RNA log / StandardScaler
+preparation; slide databases as LMDB files when the ``lmdb`` package is installed, or as directory stores);
+``--synthetic`` trains on synthetic tiles / RNA rows of the right shapes (what bench.py measures).  Extra flags: --batch_size (reference hard-codes 8),
 --precision, --betavae_checkpoint, --steps_per_epoch.
 """
 import argparse
@@ -98,11 +98,41 @@ def main():
     img_size = config["img_size"]
     rna_features = config.get("rna_features", 19198)
     with_rna = args.loss_type == "wganvae"
-    if not args.synthetic:
-        raise SystemExit("real tiles need the reference's LMDB dataset classes (out of scope here); use --synthetic")
-    ds = SyntheticTiles(args.steps_per_epoch * args.batch_size, img_size, rna_features, with_rna,
-                        args.seed + 1000 * D_.rank())
-    loader = DataLoader(ds, batch_size=args.batch_size, num_workers=0, pin_memory=True, drop_last=True)
+    if args.synthetic:
+        ds = SyntheticTiles(args.steps_per_epoch * args.batch_size, img_size, rna_features, with_rna,
+                            args.seed + 1000 * D_.rank())
+        loader = DataLoader(ds, batch_size=args.batch_size, num_workers=0, pin_memory=True, drop_last=True)
+    else:
+        # the reference's data path (src/histopathology_gan.py:111-168): slide tables -> [log + StandardScaler on the
+        # rna_ columns] -> per-slide tile sampling from the slide databases -> batches; rna_gan_amd.data restates the
+        # record format / sampling / preparation (LMDB files need the `lmdb` package, directory stores do not)
+        import pandas as pd
+        from rna_gan_amd import data as PD
+        path_csv, patch_data_path = config["path_csv"], config["patch_data_path"]
+        if isinstance(path_csv, str):
+            path_csv, patch_data_path = [path_csv], [patch_data_path]
+        tables = []
+        for i, (csv_file, path) in enumerate(zip(path_csv, patch_data_path)):
+            df = pd.read_csv(csv_file)
+            df["patch_data_path"] = [path] * df.shape[0]
+            df["labels"] = [i] * df.shape[0]
+            tables.append(df)
+        train_df = pd.concat(tables) if len(tables) > 1 else tables[0]
+        tf = PD.ToFloatNormalize(0.5, 0.5)
+        if with_rna:
+            train_df, _, _ = PD.log_standardize_rna(train_df)
+            ds = PD.PatchRNADataset(patch_data_path, train_df, img_size, max_patches_total=args.num_patches, transforms=tf)
+        else:
+            ds = PD.PatchDataset(patch_data_path, train_df, img_size, max_patches_total=args.num_patches, transforms=tf)
+
+        def collate_fn(batch):                       # src/histopathology_gan.py:24-34: drop unreadable records
+            img = (lambda b: b["image"]) if with_rna else (lambda b: b[0])
+            batch = [b for b in batch if img(b) is not None]
+            return torch.utils.data.dataloader.default_collate(batch)
+        if D_.world_size() > 1:                      # one shard of the tile list per rank
+            ds = torch.utils.data.Subset(ds, list(range(D_.rank(), len(ds), D_.world_size())))
+        loader = DataLoader(ds, batch_size=args.batch_size, num_workers=0, pin_memory=True, shuffle=True, drop_last=True,
+                            collate_fn=collate_fn)
 
     if args.gan_type not in ("dcgan", "dcgan_up"):
         raise SystemExit("--gan_type dcgan (the reference CLI's path) or dcgan_up (src/dcgan.py's DCGANUpGenerator, "
