@@ -131,8 +131,7 @@ def main():
             return torch.utils.data.dataloader.default_collate(batch)
         if D_.world_size() > 1:                      # one shard of the tile list per rank
             ds = torch.utils.data.Subset(ds, list(range(D_.rank(), len(ds), D_.world_size())))
-        loader = DataLoader(ds, batch_size=args.batch_size, num_workers=0, pin_memory=True, shuffle=True, drop_last=True,
-                            collate_fn=collate_fn)
+        loader = DataLoader(ds, batch_size=args.batch_size, num_workers=4, pin_memory=True, collate_fn=collate_fn)   # :163-168
 
     if args.gan_type not in ("dcgan", "dcgan_up"):
         raise SystemExit("--gan_type dcgan (the reference CLI's path) or dcgan_up (src/dcgan.py's DCGANUpGenerator, "
