@@ -382,6 +382,16 @@ int rg_latent_apply(const float* u, const float* z, const float* s, const float*
  * the input normalisation, transforms.Normalize(-mean/std, 1/std) with mean = std = 0.5) in NHWC order. */
 int rg_export_images_nhwc(const float* x_nchw, float* y_nhwc, int N, int C, int H, int W, void* stream);
 
+/* Generator-only inference with eval-mode BatchNorm (torchgan's sample grid: generator.eval(); SURVEY 8 f1 / BASELINE
+ * configs[4]): the folded BatchNorm affine and the LeakyReLU are applied to the fp32 accumulators in the conv epilogue,
+ *   y = lrelu(conv(x) * scale[c] + shift[c], slope),  scale = gamma / sqrt(running_var + eps),  shift = beta - running_mean * scale
+ * so an inference layer is ONE kernel (no statistics, no apply pass).  bf16 MFMA path only (RG_EUNSUPPORTED otherwise).
+ * rg_g0_fwd_affine: the generator's first layer, scale / shift of length 16*C in the layer's (tap, c) column order. */
+int rg_conv_up_affine(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, const float* scale,
+                      const float* shift, float slope, void* ws, size_t ws_bytes, void* stream);
+int rg_g0_fwd_affine(const float* z, const void* wp, void* y, int N, int E, int C, const float* scale, const float* shift,
+                     float slope, void* ws, size_t ws_bytes, void* stream);
+
 /* Input contract of the discriminator (src/histopathology_gan.py:106-109: ToTensor + Normalize(0.5, 0.5); dataset
  * output src/read_data.py:339-342,366-370): dst[i] = ((float)src_u8[i] / 255 - mean) / std, element order unchanged
  * (uint8 CHW tiles stay CHW).  The same three fp32 operations as the host transform: bit-identical to it.  Lets the

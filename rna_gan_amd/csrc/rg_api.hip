@@ -205,6 +205,27 @@ extern "C" int rg_g0_fwd(const float* z, const float* w, const void* wp, void* y
   return rg_generic_g0_fwd(z, w, y, N, E, C, dtype, rg_stream(stream));
 }
 
+extern "C" int rg_g0_fwd_affine(const float* z, const void* wp, void* y, int N, int E, int C, const float* scale,
+                                const float* shift, float slope, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(z && wp && y && scale && shift && N > 0 && E > 0 && C > 0, RG_EINVAL, "g0_fwd_affine: bad args");
+  RG_REQUIRE(rg_mfma_plain_supported(N, E, 16 * C), RG_EUNSUPPORTED, "g0_fwd_affine: shape not supported by the MFMA kernel");
+  RG_REQUIRE(ws && ws_bytes >= (size_t)N * E * 2, RG_EWORKSPACE, "g0_fwd_affine: workspace too small");
+  int rc = rg_cast_pad(z, ws, N, E, E, RG_BF16, stream);
+  if (rc) return rc;
+  return rg_mfma_gemm_plain(ws, wp, y, N, E, 16 * C, 16 * C, rg_stream(stream), scale, shift, slope);
+}
+
+extern "C" int rg_conv_up_affine(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I,
+                                 const float* scale, const float* shift, float slope, void* ws, size_t ws_bytes,
+                                 void* stream) {
+  RG_REQUIRE(x && wup && y && scale && shift && N > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0, RG_EINVAL,
+             "conv_up_affine: bad args");
+  RG_REQUIRE(rg_mfma_conv_supported(N, Ho, Wo, /*Kc=*/O, /*Ncols=*/I), RG_EUNSUPPORTED,
+             "conv_up_affine: shape not supported by the MFMA kernel");
+  return rg_mfma_conv_up(x, wup, y, N, Ho, Wo, O, I, nullptr, 1.f, nullptr, ws, ws_bytes, rg_stream(stream), scale, shift,
+                         slope);
+}
+
 extern "C" int rg_g0_wgrad(const float* z, const void* gy, float* dw, int N, int E, int C, int dtype, int accumulate,
                            int algo, void* ws, size_t ws_bytes, void* stream) {
   RG_REQUIRE(z && gy && dw && N > 0 && E > 0 && C > 0, RG_EINVAL, "g0_wgrad: bad args");

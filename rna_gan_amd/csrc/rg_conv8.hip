@@ -393,6 +393,7 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
           v1.x *= rg_lmask(a.z, g.mslope); v1.y *= rg_lmask(a.z >> 16, g.mslope);
           v1.z *= rg_lmask(a.w, g.mslope); v1.w *= rg_lmask(a.w >> 16, g.mslope);
         }
+        if (g.affine) rg_affine8(v0, v1, g.scale + col, g.shift + col, g.slope);
         uint4 o;
         o.x = (uint32_t)f32_to_bf16(v0.x) | ((uint32_t)f32_to_bf16(v0.y) << 16);
         o.y = (uint32_t)f32_to_bf16(v0.z) | ((uint32_t)f32_to_bf16(v0.w) << 16);

@@ -36,11 +36,23 @@ struct GArgs {
                           // [partial rows][2][Ncols] (BatchNorm statistics straight from the conv epilogue)
   const uint16_t* mask;   // EPI_BF16, optional: activation with the output's shape; out *= (mask > 0 ? 1 : mslope)
   float mslope;           // (LeakyReLU backward of the consumer fused into the data-gradient conv)
+  int affine;             // EPI_BF16, bf16 output without split-K: out = lrelu(acc * scale[col] + shift[col], slope) (eval-mode
+                          // BatchNorm folded into the conv epilogue: generator-only inference)
 };
 
 // 8 bf16 outputs (packed in o) times the LeakyReLU derivative at 8 bf16 activations (packed in a)
 __device__ __forceinline__ float rg_lmask(uint32_t abits, float slope) {
   return (abits & 0x8000u) || !(abits & 0x7fffu) ? slope : 1.f;      // a <= 0 (incl. -0): slope
+}
+
+// 8 consecutive output columns: v = lrelu(v * scale[c] + shift[c], slope)
+__device__ __forceinline__ void rg_affine8(float4& v0, float4& v1, const float* sc, const float* sh, float slope) {
+  const float4 s0 = *reinterpret_cast<const float4*>(sc), s1 = *reinterpret_cast<const float4*>(sc + 4);
+  const float4 h0 = *reinterpret_cast<const float4*>(sh), h1 = *reinterpret_cast<const float4*>(sh + 4);
+  v0.x = lrelu_f(v0.x * s0.x + h0.x, slope); v0.y = lrelu_f(v0.y * s0.y + h0.y, slope);
+  v0.z = lrelu_f(v0.z * s0.z + h0.z, slope); v0.w = lrelu_f(v0.w * s0.w + h0.w, slope);
+  v1.x = lrelu_f(v1.x * s1.x + h1.x, slope); v1.y = lrelu_f(v1.y * s1.y + h1.y, slope);
+  v1.z = lrelu_f(v1.z * s1.z + h1.z, slope); v1.w = lrelu_f(v1.w * s1.w + h1.w, slope);
 }
 
 __device__ __forceinline__ void up_tap_dev(int par, int a, int& kidx, int& d) {

@@ -39,7 +39,8 @@ int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, in
                       void* ws, size_t ws_bytes, hipStream_t st);
 int rg_mfma_conv_stats_rows(int up, int N, int Hlow, int Wlow, int O, int I);
 int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, const void* mask,
-                    float mslope, float* stats, void* ws, size_t ws_bytes, hipStream_t st);
+                    float mslope, float* stats, void* ws, size_t ws_bytes, hipStream_t st, const float* scale = nullptr,
+                    const float* shift = nullptr, float slope = 1.f);
 size_t rg_mfma_conv_ws_bytes(int up, int N, int Hlow, int Wlow, int O, int I);
 bool rg_mfma_upconv3_supported(int N, int H, int W, int Cin, int Cout);
 size_t rg_mfma_upconv3_fwd_ws_bytes(int N, int H, int W, int Cin, int Cout);
@@ -72,7 +73,8 @@ size_t rg_mfma_g0_wgrad_ws_bytes(int N, int E, int C);
 bool rg_mfma_g0_wgrad_supported(int N, int E, int C);
 int rg_mfma_g0_wgrad(const float* z, const void* gy, float* dw, int N, int E, int C, void* ws, size_t ws_bytes,
                      hipStream_t st);
-int rg_mfma_gemm_plain(const void* a, const void* bt, void* c, int M, int K, int Ncols, int ldc, hipStream_t st);
+int rg_mfma_gemm_plain(const void* a, const void* bt, void* c, int M, int K, int Ncols, int ldc, hipStream_t st,
+                       const float* scale = nullptr, const float* shift = nullptr, float slope = 1.f);
 int rg_mfma_linear(const void* a, const void* bt, const float* scale, const float* shift, float* y, int ldy, int M,
                    int Kpad, int Nout, float slope, void* ws, size_t ws_bytes, hipStream_t st);
 size_t rg_mfma_linear_ws_bytes(int M, int Kpad, int Nout);

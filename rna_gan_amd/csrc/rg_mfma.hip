@@ -576,6 +576,7 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
           v1.x *= rg_lmask(a.z, g.mslope); v1.y *= rg_lmask(a.z >> 16, g.mslope);
           v1.z *= rg_lmask(a.w, g.mslope); v1.w *= rg_lmask(a.w >> 16, g.mslope);
         }
+        if (g.affine) rg_affine8(v0, v1, g.scale + col, g.shift + col, g.slope);
         uint4 o;
         o.x = (uint32_t)f32_to_bf16(v0.x) | ((uint32_t)f32_to_bf16(v0.y) << 16);
         o.y = (uint32_t)f32_to_bf16(v0.z) | ((uint32_t)f32_to_bf16(v0.w) << 16);
@@ -1191,7 +1192,7 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
                           void* ws, size_t ws_bytes, hipStream_t st) {
   if (use_v1() || a_bytes >= 0x7fffff00ull || b_bytes >= 0x7fffff00ull) return launch_gather<MODE, EPI>(name, g, nclass, st);
   G2Args a2{};
-  const GPlan pl = gather_plan(MODE, EPI == EPI_BF16, g.M, g.Ncols, g.Cin, g.taps, nclass, g.mask != nullptr);
+  const GPlan pl = gather_plan(MODE, EPI == EPI_BF16, g.M, g.Ncols, g.Cin, g.taps, nclass, g.mask != nullptr || g.affine);
   const bool narrow = pl.narrow, wide = pl.wide;
   int nsplit = pl.nsplit;
   size_t need = (size_t)nsplit * rows_out * (EPI == EPI_BF16 ? g.Ncols : g.ldc) * sizeof(float);
@@ -1269,8 +1270,10 @@ int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, in
 }
 
 int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, const void* mask,
-                    float mslope, float* stats, void* ws, size_t ws_bytes, hipStream_t st) {
+                    float mslope, float* stats, void* ws, size_t ws_bytes, hipStream_t st, const float* scale,
+                    const float* shift, float slope) {
   GArgs g{};
+  g.affine = scale != nullptr; g.scale = scale; g.shift = shift; g.slope = slope;
   g.stats = mask ? nullptr : stats;
   g.mask = (const uint16_t*)mask; g.mslope = mslope;
   g.A = (const uint16_t*)x; g.B = (const uint16_t*)wup; g.C = y;
@@ -1286,8 +1289,10 @@ size_t rg_mfma_conv_ws_bytes(int up, int N, int Hlow, int Wlow, int O, int I) {
   return rg_mfma_gather_ws_bytes(MODE_DOWN, M, M, O, I, 16, 1);
 }
 
-int rg_mfma_gemm_plain(const void* a, const void* bt, void* c, int M, int K, int Ncols, int ldc, hipStream_t st) {
+int rg_mfma_gemm_plain(const void* a, const void* bt, void* c, int M, int K, int Ncols, int ldc, hipStream_t st,
+                       const float* scale, const float* shift, float slope) {
   GArgs g{};
+  g.affine = scale != nullptr; g.scale = scale; g.shift = shift; g.slope = slope;
   g.A = (const uint16_t*)a; g.B = (const uint16_t*)bt; g.C = c;
   g.M = M; g.Ncols = Ncols; g.Cin = K; g.taps = 1; g.lgW = 0; g.lgH = 0; g.Hs = 1; g.Ws = 1; g.ldc = ldc; g.b_col = K; g.b_tap = 0;
   RG_REQUIRE(ldc == Ncols, RG_EINVAL, "gemm_plain: dense output expected");

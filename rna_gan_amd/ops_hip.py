@@ -184,6 +184,40 @@ class HipOps:
                                 _ptr(st), self.dt, self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_up"))
         return (y, st) if want_stats else y
 
+    def conv_up_affine(self, x, cw: ConvW, scale, shift, slope: float):
+        """Transposed conv with the eval-mode BatchNorm affine and LeakyReLU fused into its epilogue (bf16 MFMA path):
+        lrelu(conv_up(x) * scale[c] + shift[c], slope), rounded once.  None when this shape / precision has no fused form."""
+        if self.dt != RG_BF16:
+            return None
+        N, Ho, Wo, O = x.shape
+        I = cw.I
+        if O % 64 != 0 or I % 8 != 0 or I < 64 or (Ho & (Ho - 1)) or (Wo & (Wo - 1)):
+            return None
+        self._tap_major(cw)
+        _, wup = self._packs(cw)
+        y = self._act(N, 2 * Ho, 2 * Wo, I)
+        ws = self._ws(self.lib.rg_conv_workspace_bytes(1, N, Ho, Wo, O, I, self.dt, self.algo))
+        sc, sh = scale.float().contiguous(), shift.float().contiguous()
+        self._timed("conv_fwd_dgrad", 2.0 * N * Ho * Wo * O * I * 16, lambda: check(
+            self.lib.rg_conv_up_affine(_ptr(x), _ptr(wup), _ptr(y), N, Ho, Wo, O, I, _ptr(sc), _ptr(sh), float(slope),
+                                       _ptr(ws), ws.numel(), self.stream), "rg_conv_up_affine"))
+        return y
+
+    def g0_fwd_affine(self, z, cw: ConvW, scale, shift, slope: float):
+        """Generator layer 0 with the folded BatchNorm affine + LeakyReLU in the GEMM epilogue (scale / shift per channel
+        c, expanded here to the layer's 16*C (tap, c) columns).  None when there is no fused form."""
+        N, E = z.shape
+        C = cw.w.shape[1]
+        if self.dt != RG_BF16 or E % 64 != 0 or C % 8 != 0:
+            return None
+        self.g0_pack(cw)
+        y = self._act(N, 4, 4, C)
+        ws = self._ws(self.lib.rg_g0_workspace_bytes(N, E, C, self.dt, self.algo))
+        sc, sh = scale.float().repeat(16).contiguous(), shift.float().repeat(16).contiguous()
+        check(self.lib.rg_g0_fwd_affine(_ptr(z), _ptr(cw.packs[0]), _ptr(y), N, E, C, _ptr(sc), _ptr(sh), float(slope),
+                                        _ptr(ws), ws.numel(), self.stream), "rg_g0_fwd_affine")
+        return y
+
     def conv_wgrad(self, low, high, cw: ConvW, accumulate: bool):
         N, Ho, Wo, O = low.shape
         I = high.shape[3]
@@ -292,12 +326,10 @@ class HipOps:
                                        int(accumulate), _ptr(ws), ws.numel(), self.stream), "rg_skinny_wgrad")
 
     # ------------------------------------------------------------------ G.0 / head
-    def g0_fwd(self, z, cw: ConvW):
-        N, E = z.shape
-        C = cw.w.shape[1]
-        assert z.dtype == torch.float32 and z.is_contiguous() and cw.w.shape[0] == E
-        wp = None
-        if self.dt == RG_BF16:
+    def g0_pack(self, cw: ConvW):
+        """bf16 GEMM operand image [(tap, c)][E] of the generator's first weight (rebuilt when the master changed)."""
+        E, C = cw.w.shape[0], cw.w.shape[1]
+        if True:
             if cw.packs is None or cw.packs_version != cw.version:
                 if cw.packs is None:
                     cw.packs = (torch.empty((16 * C, E), dtype=torch.bfloat16, device=self.device),)
@@ -310,6 +342,14 @@ class HipOps:
                 cw.packs_version = cw.version
                 if cw.shadow is not None:
                     cw.shadow_version = cw.version
+
+    def g0_fwd(self, z, cw: ConvW):
+        N, E = z.shape
+        C = cw.w.shape[1]
+        assert z.dtype == torch.float32 and z.is_contiguous() and cw.w.shape[0] == E
+        wp = None
+        if self.dt == RG_BF16:
+            self.g0_pack(cw)
             wp = cw.packs[0]
         y = self._act(N, 4, 4, C)
         ws = self._ws(self.lib.rg_g0_workspace_bytes(N, E, C, self.dt, self.algo))

@@ -382,3 +382,46 @@ def test_betavae_encode_train_mode():
     for k in so:
         if "running" in k:
             np.testing.assert_allclose(sp[k].cpu().numpy(), so[k].numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def test_generator_eval_fused_epilogue():
+    """Generator-only inference, eval-mode BatchNorm: the fused path (folded BatchNorm affine + LeakyReLU in
+    the conv / GEMM epilogue, one kernel per block) against the unfused conv -> bn_act pairs and against the oracle
+    generator in eval mode; then the BASELINE configs[4] batch (4096 samples in chunks of 256 at the reference size)
+    with device-resident output, spot-checked against the unfused path."""
+    from rna_gan_amd import engine as E
+    in_size, step, enc, n = 64, 64, 128, 128
+    G0 = R.seeded_fill_(R.OracleDCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                               last_nonlinearity=nn.Tanh()), 7).eval()
+    G = P.DCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+    G.load_state_dict(G0.state_dict())
+    G = G.set_precision("bf16").cuda().eval()
+    z = R.synthetic_normal(n, enc, seed=5)
+    with torch.no_grad():
+        want = G0(z)
+    ops, net = G.runtime()
+    fused = E.gen_forward_eval(ops, net, z.cuda())
+    plain = E.gen_forward_eval(ops, net, z.cuda(), fused_epilogue=False)
+    assert fused.shape == want.shape == (n, 3, in_size, in_size)
+    assert float((fused.cpu() - want).abs().max()) <= 6e-2 and float((plain.cpu() - want).abs().max()) <= 6e-2
+    assert float((fused - plain).abs().max()) <= 4e-2
+    assert float((fused.cpu() - want).abs().mean()) <= 1.2 * float((plain.cpu() - want).abs().mean()) + 1e-4
+    assert torch.equal(G(z.cuda()), fused)                     # nn.Module call in eval mode = the fused path
+    # configs[4] shape: 4096 samples, reference model size, chunks of 256, output stays on the device
+    Gf = P.DCGANGenerator(2048, 256, 3, 64, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+    R.seeded_fill_(Gf, 3)
+    Gf = Gf.set_precision("bf16").cuda().eval()
+    ops, net = Gf.runtime()
+    noise = torch.randn(4096, 2048, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    outs = []
+    with torch.no_grad():
+        for c in torch.split(noise, 256):
+            img = E.gen_forward_eval(ops, net, c.contiguous())
+            assert img.is_cuda and img.shape == (256, 3, 256, 256)
+            outs.append(img[:2].clone())
+    got = torch.cat(outs)
+    assert torch.isfinite(got).all() and float(got.abs().max()) <= 1.0
+    ref = torch.cat([E.gen_forward_eval(ops, net, c[:64].contiguous(), fused_epilogue=False)[:2]
+                     for c in torch.split(noise, 256)[:3]])
+    # (batch-independent in eval mode: the first samples of a chunk do not depend on the chunk size)
+    assert float((got[:6] - ref).abs().max()) <= 5e-2

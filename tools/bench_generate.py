@@ -7,7 +7,8 @@ import torch.nn as nn
 sys.path.insert(0, ".")
 import rna_gan_amd as P
 from rna_gan_amd import gan_utils as GU
-from oracle import ref_cpu as R
+from rna_gan_amd import synth as R
+from rna_gan_amd import engine as E
 
 
 class _T:
@@ -47,6 +48,25 @@ def main():
         m = (n // chunk) * chunk
         print(f"generator forward only, chunk {chunk:4d}: {m / dt:.0f} imgs/s ({dt / (n // chunk) * 1e3:.3f} ms per chunk)", flush=True)
     assert imgs.shape == (n, 256, 256, 3)
+    # eval-mode BatchNorm (BASELINE configs[4] as SURVEY 8d specifies it: running statistics, stated explicitly), output
+    # resident on the device: fused epilogue (one kernel per Conv+BN+LReLU block) against the unfused conv -> bn_act pairs
+    G.eval()
+    ops, net = G.runtime()
+    for fused in (False, True):
+        for chunk in (64, 256, 512):
+            with torch.no_grad():
+                for c in torch.split(noise[:2 * chunk], chunk):
+                    E.gen_forward_eval(ops, net, c.contiguous(), fused_epilogue=fused)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for c in torch.split(noise, chunk):
+                    if c.shape[0] == chunk:
+                        E.gen_forward_eval(ops, net, c.contiguous(), fused_epilogue=fused)
+                torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            m = (n // chunk) * chunk
+            print(f"eval-mode generator, fused epilogue {fused}, chunk {chunk:4d}: {m / dt:.0f} imgs/s "
+                  f"({dt / (n // chunk) * 1e3:.3f} ms per chunk, {5.604e9 * m / dt / 1e12:.0f} TFLOP/s)", flush=True)
 
 
 if __name__ == "__main__":
