@@ -392,6 +392,22 @@ int rg_conv_up_affine(const void* x, const void* wup, void* y, int N, int Ho, in
 int rg_g0_fwd_affine(const float* z, const void* wp, void* y, int N, int E, int C, const float* scale, const float* shift,
                      float slope, void* ws, size_t ws_bytes, void* stream);
 
+/* fp8 (OCP e4m3) operands for generator-only inference (BASELINE configs[4]: "Generator-only tile synthesis, batch 4096
+ * fp8"): activations x8[N][Ho][Wo][O] and weights wup8[16][I][O] (rg_conv_up) / b8[Ncols][K] (plain GEMM: the generator's
+ * first layer) are fp8 bytes, fp32 accumulation (v_mfma_f32_16x16x32_fp8_fp8, 128-deep k-tiles on the pipeline of
+ * rg_conv8.hip), epilogue y = lrelu(acc * scale[c] + shift[c], slope) -- scale carries the folded BatchNorm AND the
+ * per-column weight quantisation scale -- written as bf16 (out_fp8 = 0) or fp8 (1, the next fp8 layer's input).
+ * rg_fp8_supported: 1 when a (M rows, K = taps * channels, Ncols) problem has an fp8 kernel (channels multiples of 128,
+ * Ncols a multiple of 128, M >= 256 / 512); the caller keeps the layer in bf16 otherwise.
+ * rg_cast_fp8: dst[i] = fp8(src[i] * mul).  rg_selftest_fp8: lane map of the fp8 MFMA and converter known answers. */
+int rg_conv_up_fp8(const void* x8, const void* wup8, void* y, int N, int Ho, int Wo, int O, int I, const float* scale,
+                   const float* shift, float slope, int out_fp8, void* stream);
+int rg_gemm_fp8(const void* a8, const void* b8, void* y, int M, int K, int Ncols, const float* scale, const float* shift,
+                float slope, int out_fp8, void* stream);
+int rg_fp8_supported(int M, int K, int Ncols, int taps);
+int rg_cast_fp8(const float* src, void* dst, size_t n, float mul, void* stream);
+int rg_selftest_fp8(int* detail, void* stream);
+
 /* Input contract of the discriminator (src/histopathology_gan.py:106-109: ToTensor + Normalize(0.5, 0.5); dataset
  * output src/read_data.py:339-342,366-370): dst[i] = ((float)src_u8[i] / 255 - mean) / std, element order unchanged
  * (uint8 CHW tiles stay CHW).  The same three fp32 operations as the host transform: bit-identical to it.  Lets the

@@ -104,6 +104,11 @@ PROTOTYPES = {
     "rg_cast_pad": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "rg_selftest_layouts": (_i, [_p, _p]),
     "rg_u8_to_norm": (_i, [_p, _p, _z, _f, _f, _p]),
+    "rg_conv_up_fp8": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _f, _i, _p]),
+    "rg_gemm_fp8": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _f, _i, _p]),
+    "rg_fp8_supported": (_i, [_i, _i, _i, _i]),
+    "rg_cast_fp8": (_i, [_p, _p, _z, _f, _p]),
+    "rg_selftest_fp8": (_i, [_p, _p]),
     "rg_conv_up_affine": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _f, _p, _z, _p]),
     "rg_g0_fwd_affine": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _f, _p, _z, _p]),
 }

@@ -226,6 +226,21 @@ extern "C" int rg_conv_up_affine(const void* x, const void* wup, void* y, int N,
                          slope);
 }
 
+extern "C" int rg_conv_up_fp8(const void* x8, const void* wup8, void* y, int N, int Ho, int Wo, int O, int I,
+                              const float* scale, const float* shift, float slope, int out_fp8, void* stream) {
+  RG_REQUIRE(x8 && wup8 && y && scale && shift && N > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0, RG_EINVAL, "conv_up_fp8: bad args");
+  RG_REQUIRE(rg_is_pow2(Ho) && rg_is_pow2(Wo) && rg_mfma_fp8_supported(N * Ho * Wo, 4 * O, I, 4), RG_EUNSUPPORTED,
+             "conv_up_fp8: shape not supported (O, I multiples of 128, at least 256 / 512 low-resolution pixels)");
+  return rg_mfma_conv_up_fp8(x8, wup8, y, N, Ho, Wo, O, I, scale, shift, slope, out_fp8, rg_stream(stream));
+}
+extern "C" int rg_gemm_fp8(const void* a8, const void* b8, void* y, int M, int K, int Ncols, const float* scale,
+                           const float* shift, float slope, int out_fp8, void* stream) {
+  RG_REQUIRE(a8 && b8 && y && scale && shift && M > 0 && K > 0 && Ncols > 0, RG_EINVAL, "gemm_fp8: bad args");
+  RG_REQUIRE(rg_mfma_fp8_supported(M, K, Ncols, 1), RG_EUNSUPPORTED, "gemm_fp8: shape not supported");
+  return rg_mfma_gemm_fp8(a8, b8, y, M, K, Ncols, scale, shift, slope, out_fp8, rg_stream(stream));
+}
+extern "C" int rg_fp8_supported(int M, int K, int Ncols, int taps) { return rg_mfma_fp8_supported(M, K, Ncols, taps) ? 1 : 0; }
+
 extern "C" int rg_g0_wgrad(const float* z, const void* gy, float* dw, int N, int E, int C, int dtype, int accumulate,
                            int algo, void* ws, size_t ws_bytes, void* stream) {
   RG_REQUIRE(z && gy && dw && N > 0 && E > 0 && C > 0, RG_EINVAL, "g0_wgrad: bad args");

@@ -32,10 +32,19 @@ template <int V> using ic = std::integral_constant<int, V>;
 
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-// MF: MFMA shape, 32 = v_mfma_f32_32x32x16_bf16 (8 per phase), 16 = v_mfma_f32_16x16x32_bf16 (16 per phase)
-template <int MODE, int WM, int WN, int MF>
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+// MF: MFMA shape, 32 = v_mfma_f32_32x32x16_bf16 (8 per phase), 16 = v_mfma_f32_16x16x32_bf16 (16 per phase).
+// EB: operand element bytes.  2 = bf16 (k-tile 64 deep).  1 = fp8 e4m3 (OCP) operands for generator-only inference
+// (BASELINE configs[4]): the same 128-byte LDS rows hold a 128-deep k-tile, fragments are 64-bit
+// (v_mfma_f32_16x16x32_fp8_fp8, 32 per phase), fp32 accumulate; the epilogue applies the folded BatchNorm affine and
+// LeakyReLU (the affine also carries the per-column weight scale) and writes bf16 or fp8 (a2.g.out_fp8).
+template <int MODE, int WM, int WN, int MF, int EB = 2>
 __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
   static_assert(WM * WN == 8, "8 waves");
+  static_assert(EB == 2 || (EB == 1 && MF == 16), "fp8 operands use the 16x16x32 MFMA");
+  constexpr int KD = 128 / EB;                               // k-tile depth in elements
+  constexpr int LGKD = EB == 2 ? 6 : 7;
   constexpr int BM = WM * 128, BN = WN * 64;
   constexpr int AH_ROWS = BM / 2, BH_ROWS = BN / 2;          // rows per half-tile
   constexpr int AH = AH_ROWS * 128, BH = BH_ROWS * 128;      // bytes per half-tile (BK = 64 bf16 = 128 B per row)
@@ -111,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
         base = (long long)mm * g.Cin;
         mask = 1u;
       }
-      a_off[h * NA + j] = (int)((base + lc * 8) * 2);
+      a_off[h * NA + j] = (int)((base + lc * (16 / EB)) * EB);
       a_mask[j] |= (ok ? mask : 0u) << (16 * h);
     }
 #pragma unroll
@@ -119,10 +128,10 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int col = bn + h * BH_ROWS + j * 64 + r0;
-      b_off[h * NB + j] = col < g.Ncols ? (int)(((long long)col * g.b_col + lc * 8) * 2) : -1;
+      b_off[h * NB + j] = col < g.Ncols ? (int)(((long long)col * g.b_col + lc * (16 / EB)) * EB) : -1;
     }
 
-  const int cpt = g.Cin >> 6;
+  const int cpt = g.Cin >> LGKD;
   const int nkt_all = g.taps * cpt;
   const int per = (nkt_all + a2.nsplit - 1) / a2.nsplit;      // host guarantees an even count per split
   const int kt_begin = zs * per;
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
   auto decode = [&](int ktr, int& ao, int& bo, int& tap) {
     const int kt = kt_begin + ktr;
     tap = kt >> lgcpt;
-    const int c0 = (kt & cmask) << 6;
+    const int c0 = (kt & cmask) * KD;
     int a_delta, b_tap;
     if (MODE == MODE_DOWN) {
       a_delta = ((tap >> 2) * g.Ws + (tap & 3)) * g.Cin;
@@ -150,8 +159,8 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
       a_delta = 0;
       b_tap = 0;
     }
-    ao = (a_delta + c0) * 2;
-    bo = (b_tap * g.b_tap + c0) * 2;
+    ao = (a_delta + c0) * EB;
+    bo = (b_tap * g.b_tap + c0) * EB;
   };
   // one half-tile of k-tile ktr into stage S: NA (A) or NB (B) block-wide DMA instructions
   auto issue_a = [&](auto S, auto H, int ktr) {
@@ -185,16 +194,19 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
   // 32x32x16: lane = (row fr of 32, k-half fh), chunk(kk) = 2kk + fh, kk < 4.   16x16x32: lane = (row fr of 16, k-quarter
   // fh), chunk(kk) = 4kk + fh, kk < 2.  The XOR swizzle (row>>1)&7 is the same for every sub-tile of a wave (16 | 32 rows apart).
   constexpr int FRW = MF == 32 ? 32 : 16;            // rows per MFMA tile
-  constexpr int NKK = MF == 32 ? 4 : 2;              // k-steps per k-tile
+  constexpr int NKK = EB == 1 ? 4 : (MF == 32 ? 4 : 2);   // k-steps per k-tile (fp8: 4 steps of 32)
   constexpr int NAT = 64 / FRW, NBT = 32 / FRW;      // A row sub-tiles / B column sub-tiles per quadrant
   const int fr = lane & (FRW - 1), fh = lane / FRW;
   const unsigned lds_base = (unsigned)(size_t)(lds_vptr_t)lds;
   unsigned aB[2][NKK], bB[2][NKK];   // [stage][k-step] byte addresses of this lane's A / B fragment chunk
 #pragma unroll
   for (int kk = 0; kk < NKK; ++kk) {
-    const unsigned ch = (unsigned)(((64 / FRW) * kk + fh) ^ ((fr >> 1) & 7));
-    aB[0][kk] = lds_base + OFF_A + 16u * (unsigned)((wm * 64 + fr) * 8 + ch);
-    bB[0][kk] = lds_base + OFF_B + 16u * (unsigned)((wn * 32 + fr) * 8 + ch);
+    // bf16: lane's 16-byte chunk of the 128-byte row; fp8: 8 bytes (fh & 1) of chunk 2 kk + (fh >> 1)
+    const unsigned ch = EB == 1 ? (unsigned)((2 * kk + (fh >> 1)) ^ ((fr >> 1) & 7))
+                                : (unsigned)(((64 / FRW) * kk + fh) ^ ((fr >> 1) & 7));
+    const unsigned sub = EB == 1 ? 8u * (unsigned)(fh & 1) : 0u;
+    aB[0][kk] = lds_base + OFF_A + 16u * (unsigned)((wm * 64 + fr) * 8 + ch) + sub;
+    bB[0][kk] = lds_base + OFF_B + 16u * (unsigned)((wn * 32 + fr) * 8 + ch) + sub;
     aB[1][kk] = aB[0][kk] + STAGE;
     bB[1][kk] = bB[0][kk] + STAGE;
   }
@@ -211,36 +223,63 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
         for (int r = 0; r < ACC_R; ++r) acc[i][j][s][r] = 0.f;
   u32x4_t aR[8];                     // A fragments of the current quadrant row: [A sub-tile][k-step]
   u32x4_t bS[3][4];                  // three rotating B fragment sets: [set][B sub-tile][k-step]
+  u32x2_t aQ[16];                    // fp8: 64-bit fragments, [A sub-tile (4)][k-step (4)]
+  u32x2_t bQ[3][8];                  //      [set][B sub-tile (2)][k-step (4)]
 
 #define C8_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define C8_DSR8(dst, addr, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
 #define C8_READ_A(S, H)                                                                     \
   do {                                                                                      \
-    _Pragma("unroll") for (int t_ = 0; t_ < NAT; ++t_) _Pragma("unroll") for (int kk_ = 0; kk_ < NKK; ++kk_) \
-        C8_DSR(aR[t_ * NKK + kk_], aB[S][kk_], (H) * AH + t_ * FRW * 128);                  \
+    _Pragma("unroll") for (int t_ = 0; t_ < NAT; ++t_) _Pragma("unroll") for (int kk_ = 0; kk_ < NKK; ++kk_) { \
+      if constexpr (EB == 1) C8_DSR8(aQ[t_ * NKK + kk_], aB[S][kk_], (H) * AH + t_ * FRW * 128); \
+      else C8_DSR(aR[(t_ * NKK + kk_) & 7], aB[S][kk_], (H) * AH + t_ * FRW * 128);         \
+    }                                                                                       \
   } while (0)
 #define C8_READ_B(S, H, SET)                                                                \
   do {                                                                                      \
-    _Pragma("unroll") for (int t_ = 0; t_ < NBT; ++t_) _Pragma("unroll") for (int kk_ = 0; kk_ < NKK; ++kk_) \
-        C8_DSR(bS[SET][t_ * NKK + kk_], bB[S][kk_], (H) * BH + t_ * FRW * 128);             \
+    _Pragma("unroll") for (int t_ = 0; t_ < NBT; ++t_) _Pragma("unroll") for (int kk_ = 0; kk_ < NKK; ++kk_) { \
+      if constexpr (EB == 1) C8_DSR8(bQ[SET][t_ * NKK + kk_], bB[S][kk_], (H) * BH + t_ * FRW * 128); \
+      else C8_DSR(bS[SET][(t_ * NKK + kk_) & 3], bB[S][kk_], (H) * BH + t_ * FRW * 128);    \
+    }                                                                                       \
   } while (0)
 #define C8_WAIT_A()                                                                                            \
-  asm volatile("s_waitcnt lgkmcnt(0)"                                                                          \
-               : "+v"(aR[0]), "+v"(aR[1]), "+v"(aR[2]), "+v"(aR[3]), "+v"(aR[4]), "+v"(aR[5]), "+v"(aR[6]),    \
-                 "+v"(aR[7])::"memory")
+  do {                                                                                                         \
+    if constexpr (EB == 1)                                                                                     \
+      asm volatile("s_waitcnt lgkmcnt(0)"                                                                      \
+                   : "+v"(aQ[0]), "+v"(aQ[1]), "+v"(aQ[2]), "+v"(aQ[3]), "+v"(aQ[4]), "+v"(aQ[5]), "+v"(aQ[6]), \
+                     "+v"(aQ[7]), "+v"(aQ[8]), "+v"(aQ[9]), "+v"(aQ[10]), "+v"(aQ[11]), "+v"(aQ[12]),          \
+                     "+v"(aQ[13]), "+v"(aQ[14]), "+v"(aQ[15])::"memory");                                      \
+    else                                                                                                       \
+      asm volatile("s_waitcnt lgkmcnt(0)"                                                                      \
+                   : "+v"(aR[0]), "+v"(aR[1]), "+v"(aR[2]), "+v"(aR[3]), "+v"(aR[4]), "+v"(aR[5]), "+v"(aR[6]), \
+                     "+v"(aR[7])::"memory");                                                                   \
+  } while (0)
 #define C8_WAIT_B(SET)                                                                                         \
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bS[SET][0]), "+v"(bS[SET][1]), "+v"(bS[SET][2]), "+v"(bS[SET][3])::"memory")
+  do {                                                                                                         \
+    if constexpr (EB == 1)                                                                                     \
+      asm volatile("s_waitcnt lgkmcnt(0)"                                                                      \
+                   : "+v"(bQ[SET][0]), "+v"(bQ[SET][1]), "+v"(bQ[SET][2]), "+v"(bQ[SET][3]), "+v"(bQ[SET][4]), \
+                     "+v"(bQ[SET][5]), "+v"(bQ[SET][6]), "+v"(bQ[SET][7])::"memory");                          \
+    else                                                                                                       \
+      asm volatile("s_waitcnt lgkmcnt(0)"                                                                      \
+                   : "+v"(bS[SET][0]), "+v"(bS[SET][1]), "+v"(bS[SET][2]), "+v"(bS[SET][3])::"memory");        \
+  } while (0)
 #define C8_MFMAS(I, J, SET)                                                                                    \
   do {                                                                                                         \
     __builtin_amdgcn_s_setprio(1);                                                                             \
     _Pragma("unroll") for (int kk_ = 0; kk_ < NKK; ++kk_) _Pragma("unroll") for (int t_ = 0; t_ < NAT; ++t_)   \
     _Pragma("unroll") for (int c_ = 0; c_ < NBT; ++c_) {                                                       \
-      if constexpr (MF == 32)                                                                                  \
+      if constexpr (EB == 1)                                                                                   \
+        acc[I][J][t_ * NBT + c_] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(                                 \
+            __builtin_bit_cast(long, aQ[t_ * NKK + kk_]), __builtin_bit_cast(long, bQ[SET][c_ * NKK + kk_]),   \
+            acc[I][J][t_ * NBT + c_], 0, 0, 0);                                                                \
+      else if constexpr (MF == 32)                                                                             \
         acc[I][J][t_ * NBT + c_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                    \
-            __builtin_bit_cast(bf16x8_t, aR[t_ * NKK + kk_]), __builtin_bit_cast(bf16x8_t, bS[SET][c_ * NKK + kk_]), \
+            __builtin_bit_cast(bf16x8_t, aR[(t_ * NKK + kk_) & 7]), __builtin_bit_cast(bf16x8_t, bS[SET][(c_ * NKK + kk_) & 3]), \
             acc[I][J][t_ * NBT + c_], 0, 0, 0);                                                                \
       else                                                                                                     \
         acc[I][J][t_ * NBT + c_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                    \
-            __builtin_bit_cast(bf16x8_t, aR[t_ * NKK + kk_]), __builtin_bit_cast(bf16x8_t, bS[SET][c_ * NKK + kk_]), \
+            __builtin_bit_cast(bf16x8_t, aR[(t_ * NKK + kk_) & 7]), __builtin_bit_cast(bf16x8_t, bS[SET][(c_ * NKK + kk_) & 3]), \
             acc[I][J][t_ * NBT + c_], 0, 0, 0);                                                                \
     }                                                                                                          \
     __builtin_amdgcn_s_setprio(0);                                                                             \
@@ -394,6 +433,15 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
           v1.z *= rg_lmask(a.w, g.mslope); v1.w *= rg_lmask(a.w >> 16, g.mslope);
         }
         if (g.affine) rg_affine8(v0, v1, g.scale + col, g.shift + col, g.slope);
+        if (g.out_fp8) {                 // 8 OCP e4m3 values = 8 bytes (the next fp8 layer's A operand)
+          int lo = 0, hi = 0;
+          lo = __builtin_amdgcn_cvt_pk_fp8_f32(v0.x, v0.y, lo, false);
+          lo = __builtin_amdgcn_cvt_pk_fp8_f32(v0.z, v0.w, lo, true);
+          hi = __builtin_amdgcn_cvt_pk_fp8_f32(v1.x, v1.y, hi, false);
+          hi = __builtin_amdgcn_cvt_pk_fp8_f32(v1.z, v1.w, hi, true);
+          *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(g.C) + orow * g.ldc + col) = make_uint2((unsigned)lo, (unsigned)hi);
+          continue;
+        }
         uint4 o;
         o.x = (uint32_t)f32_to_bf16(v0.x) | ((uint32_t)f32_to_bf16(v0.y) << 16);
         o.y = (uint32_t)f32_to_bf16(v0.z) | ((uint32_t)f32_to_bf16(v0.w) << 16);
@@ -760,6 +808,16 @@ int rg_conv8n_launch(const void* args, unsigned tiles_m, hipStream_t st) {
 int rg_conv8_launch(int mode, const void* args, int bm, unsigned gx, unsigned gy, unsigned gz, hipStream_t st) {
   const G2Args& a2 = *reinterpret_cast<const G2Args*>(args);
   const dim3 grid(gx, gy, gz), block(512);
+  if (a2.g.in_fp8) {                    // fp8 operands (generator-only inference): transposed conv and plain GEMM
+    if (bm == 256) {
+      if (mode == MODE_UP) hipLaunchKernelGGL((conv8_kernel<MODE_UP, 2, 4, 16, 1>), grid, block, 0, st, a2);
+      else hipLaunchKernelGGL((conv8_kernel<MODE_PLAIN, 2, 4, 16, 1>), grid, block, 0, st, a2);
+    } else {
+      if (mode == MODE_UP) hipLaunchKernelGGL((conv8_kernel<MODE_UP, 4, 2, 16, 1>), grid, block, 0, st, a2);
+      else hipLaunchKernelGGL((conv8_kernel<MODE_PLAIN, 4, 2, 16, 1>), grid, block, 0, st, a2);
+    }
+    return RG_OK;
+  }
   const int mf = rg_option("conv8_mfma", 16);
 #define C8_GO(MODE_, WM_, WN_)                                                                       \
   do {                                                                                               \

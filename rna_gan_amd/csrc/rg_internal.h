@@ -85,6 +85,12 @@ int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, c
                         int Ho, int Wo, int O, int I, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 size_t rg_mfma_wgrad2_ws_bytes(int N, int Ho, int Wo, int O, int I);
 
+bool rg_mfma_fp8_supported(int M, int K, int Ncols, int taps);
+int rg_mfma_conv_up_fp8(const void* x8, const void* wup8, void* y, int N, int Ho, int Wo, int O, int I, const float* scale,
+                        const float* shift, float slope, int out_fp8, hipStream_t st);
+int rg_mfma_gemm_fp8(const void* a8, const void* b8, void* y, int M, int K, int Ncols, const float* scale, const float* shift,
+                     float slope, int out_fp8, hipStream_t st);
+
 // rg_conv8.hip (8-wave ping-pong gather GEMM; args = G2Args of rg_gather.h)
 int rg_conv8_launch(int mode, const void* args, int bm, unsigned gx, unsigned gy, unsigned gz, hipStream_t st);
 int rg_conv8n_launch(const void* args, unsigned tiles_m, hipStream_t st);

@@ -1283,6 +1283,51 @@ int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int 
                                            (size_t)I * 16 * O * 2, ws, ws_bytes, st);
 }
 
+// ---- fp8 e4m3 operands (generator-only inference, BASELINE configs[4]): conv8_kernel<.., EB = 1> only, no split-K
+bool rg_mfma_fp8_supported(int M, int K, int Ncols, int taps) {
+  const int cpt = K / taps / 128;
+  if (K % (taps * 128) != 0 || !(taps == 1 || rg_is_pow2(cpt))) return false;
+  const int nkt = K / 128;
+  if (nkt < 4 || (nkt & 1)) return false;
+  return (Ncols % 256 == 0 && M >= 256) || (Ncols % 128 == 0 && M >= 512);
+}
+static int launch_conv8_fp8(const char* name, int mode, GArgs& g, int nclass, size_t a_bytes, size_t b_bytes, hipStream_t st) {
+  RG_REQUIRE(a_bytes < 0x7fffff00ull && b_bytes < 0x7fffff00ull, RG_EUNSUPPORTED, "%s: operand of 2 GB or more", name);
+  G2Args a2{};
+  const int bm = g.Ncols % 256 == 0 && g.M >= 256 ? 256 : 512, bn = bm == 256 ? 256 : 128;
+  g.in_fp8 = 1;
+  g.tiles_n = g.Ncols / bn;
+  a2.g = g;
+  a2.a_bytes = (unsigned)a_bytes; a2.b_bytes = (unsigned)b_bytes;
+  a2.nsplit = 1;
+  a2.tiles_m = (g.M + bm - 1) / bm;
+  const int cpt = g.Cin / 128;
+  a2.lgcpt = g.taps == 1 ? 30 : rg_ilog2(cpt);
+  a2.cmask = g.taps == 1 ? 0x3fffffff : cpt - 1;
+  dim3 grid((unsigned)(a2.tiles_m * g.tiles_n), (unsigned)nclass, 1);
+  a2.xcd_swizzle = (rg_option("xcd", 1) && grid.x % 8 == 0 && grid.x >= 16 && a_bytes > b_bytes) ? 1 : 0;
+  rg_conv8_launch(mode, &a2, bm, grid.x, grid.y, grid.z, st);
+  RG_LAUNCH_CHECK(name);
+  return RG_OK;
+}
+int rg_mfma_conv_up_fp8(const void* x8, const void* wup8, void* y, int N, int Ho, int Wo, int O, int I, const float* scale,
+                        const float* shift, float slope, int out_fp8, hipStream_t st) {
+  GArgs g{};
+  g.affine = 1; g.scale = scale; g.shift = shift; g.slope = slope; g.out_fp8 = out_fp8;
+  g.A = (const uint16_t*)x8; g.B = (const uint16_t*)wup8; g.C = y;
+  g.M = N * Ho * Wo; g.Ncols = I; g.Cin = O; g.taps = 4;
+  g.lgW = rg_ilog2(Wo); g.lgH = rg_ilog2(Ho); g.Hs = Ho; g.Ws = Wo; g.ldc = I; g.b_col = O; g.b_tap = I * O;        // wup8[16][I][O]
+  return launch_conv8_fp8("conv_up_fp8", MODE_UP, g, 4, (size_t)N * Ho * Wo * O, (size_t)I * 16 * O, st);
+}
+int rg_mfma_gemm_fp8(const void* a8, const void* b8, void* y, int M, int K, int Ncols, const float* scale, const float* shift,
+                     float slope, int out_fp8, hipStream_t st) {
+  GArgs g{};
+  g.affine = 1; g.scale = scale; g.shift = shift; g.slope = slope; g.out_fp8 = out_fp8;
+  g.A = (const uint16_t*)a8; g.B = (const uint16_t*)b8; g.C = y;
+  g.M = M; g.Ncols = Ncols; g.Cin = K; g.taps = 1; g.lgW = 0; g.lgH = 0; g.Hs = 1; g.Ws = 1; g.ldc = Ncols; g.b_col = K; g.b_tap = 0;
+  return launch_conv8_fp8("gemm_fp8", MODE_PLAIN, g, 1, (size_t)M * K, (size_t)Ncols * K, st);
+}
+
 size_t rg_mfma_conv_ws_bytes(int up, int N, int Hlow, int Wlow, int O, int I) {
   int M = N * Hlow * Wlow;
   if (up) return rg_mfma_gather_ws_bytes(MODE_UP, M * 4, M, I, O, 4, 4);

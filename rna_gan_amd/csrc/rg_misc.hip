@@ -583,6 +583,71 @@ extern "C" int rg_u8_to_norm(const void* src_u8, float* dst, size_t n, float mea
   return RG_OK;
 }
 
+// fp32 -> OCP fp8 e4m3 (v_cvt_pk_fp8_f32), dst[i] = fp8(src[i] * mul): weights / latents of the fp8 inference path
+__global__ void cast_fp8_kernel(const float* __restrict__ src, uint8_t* __restrict__ dst, size_t n, float mul) {
+  const size_t n4 = n >> 2;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v.x * mul, v.y * mul, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(v.z * mul, v.w * mul, w, true);
+    reinterpret_cast<int*>(dst)[i] = w;
+  }
+  const size_t t0 = n4 << 2;
+  if (blockIdx.x == 0 && t0 + threadIdx.x < n) {
+    const int w = __builtin_amdgcn_cvt_pk_fp8_f32(src[t0 + threadIdx.x] * mul, 0.f, 0, false);
+    dst[t0 + threadIdx.x] = (uint8_t)(w & 0xff);
+  }
+}
+extern "C" int rg_cast_fp8(const float* src, void* dst, size_t n, float mul, void* stream) {
+  RG_REQUIRE(src && dst && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 3) == 0, RG_EINVAL, "cast_fp8: bad args");
+  if (n == 0) return RG_OK;
+  hipLaunchKernelGGL(cast_fp8_kernel, dim3(grid_for(n, 4)), dim3(256), 0, rg_stream(stream), src, (uint8_t*)dst, n, mul);
+  RG_LAUNCH_CHECK("cast_fp8");
+  return RG_OK;
+}
+// hardware check of the fp8 MFMA operand map this library assumes (exact small integers): lane l of
+// v_mfma_f32_16x16x32_fp8_fp8 holds A[row l & 15][k = 8 (l >> 4) + j] and B[k = 8 (l >> 4) + j][col l & 15] in byte j
+__global__ void selftest_fp8_kernel(int* out) {
+  const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+  auto enc = [](int v) -> unsigned {          // small integers -4..4 as e4m3 bytes
+    const int a = v < 0 ? -v : v;
+    const unsigned m = a == 0 ? 0x00u : a == 1 ? 0x38u : a == 2 ? 0x40u : a == 3 ? 0x44u : 0x48u;
+    return m | (v < 0 ? 0x80u : 0u);
+  };
+  unsigned long long fa = 0, fb = 0;
+  for (int j = 0; j < 8; ++j) {
+    const int k = 8 * q + j;
+    fa |= (unsigned long long)enc((r * 3 + k * 5) % 7 - 3) << (8 * j);            // A[r][k]
+    fb |= (unsigned long long)enc((r * 2 + k * 7 + 1) % 5 - 2) << (8 * j);        // B[k][col r]  (asymmetric in (col, k))
+  }
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)fa, (long)fb, acc, 0, 0, 0);
+  int bad = 0;
+  for (int i = 0; i < 4; ++i) {
+    const int row = 4 * q + i, col = r;
+    float ref = 0.f;
+    for (int k = 0; k < 32; ++k) ref += (float)((row * 3 + k * 5) % 7 - 3) * (float)((col * 2 + k * 7 + 1) % 5 - 2);
+    if (ref != acc[i]) ++bad;
+  }
+  // round trip of the converter: small integers and a few representable values come back exactly
+  const float probes[8] = {0.f, 1.f, -2.f, 3.f, 0.5f, -0.875f, 448.f, 0.015625f};
+  const unsigned want[8] = {0x00u, 0x38u, 0xC0u, 0x44u, 0x30u, 0xB6u, 0x7Eu, 0x08u};
+  if (lane < 8) {
+    const int w = __builtin_amdgcn_cvt_pk_fp8_f32(probes[lane], 0.f, 0, false);
+    if ((unsigned)(w & 0xff) != want[lane]) atomicAdd(&out[1], 1);
+  }
+  atomicAdd(&out[0], bad);
+}
+extern "C" int rg_selftest_fp8(int* detail, void* stream) {
+  RG_REQUIRE(detail, RG_EINVAL, "selftest_fp8: bad args");
+  hipLaunchKernelGGL(selftest_fp8_kernel, dim3(1), dim3(64), 0, rg_stream(stream), detail);
+  RG_LAUNCH_CHECK("selftest_fp8");
+  return RG_OK;
+}
+
 extern "C" int rg_widen_bf16(const void* src, float* dst, size_t n, void* stream) {
   RG_REQUIRE(src && dst, RG_EINVAL, "widen_bf16: bad args");
   if (n == 0) return RG_OK;

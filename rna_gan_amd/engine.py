@@ -44,7 +44,7 @@ class ConvW:
     """
 
     __slots__ = ("w", "bias", "dw", "dbias", "packs", "packs_version", "version", "layout", "shadow",
-                 "shadow_version")
+                 "shadow_version", "_fp8")
 
     def __init__(self, w, bias=None, dw=None, dbias=None, layout="OIHW"):
         self.w = w
@@ -57,6 +57,7 @@ class ConvW:
         self.layout = layout
         self.shadow = None            # bf16 [O][16][I] image of a tap-major master maintained by the fused Adam
         self.shadow_version = -1      # master version the shadow reflects
+        self._fp8 = None              # backend-private fp8 inference image (key, bytes, column scales)
 
     @classmethod
     def from_param(cls, weight, grad=None):
@@ -612,6 +613,37 @@ def disc_features_eval(ops, D: DiscNet, x_nchw):
         invstd = torch.rsqrt(bn.running_var + bn.eps)     # C-length vector: host-side plumbing
         a = ops.bn_act(z, bn.running_mean, invstd, bn.gamma, bn.beta, D.slope)
     return a
+
+
+def gen_forward_eval_fp8(ops, G: GenNet, noise):
+    """Generator-only inference with fp8 (e4m3) weights and activations (BASELINE configs[4]): eval-mode BatchNorm folded,
+    one kernel per block.  The chain starts in fp8 at the first layer and stays there while a layer's shape has an
+    fp8 kernel (channels multiples of 128, enough rows); the remaining layers (for the reference generator: the
+    128 -> 64 block and the image layer) run the fused bf16 kernels.  Returns (images NCHW fp32, number of fp8 layers)."""
+    def folded(bn):
+        scale = bn.gamma * torch.rsqrt(bn.running_var + bn.eps)
+        return scale, bn.beta - bn.running_mean * scale
+    N, E = noise.shape
+    C0 = G.g0.w.shape[1]
+    modes = [ops.fp8_supported(N, E, 16 * C0, 1)]
+    hw = 4
+    for cw, _ in G.blocks:
+        modes.append(modes[-1] and ops.fp8_supported(N * hw * hw, 4 * cw.O, cw.I, 4))
+        hw *= 2
+    if not modes[0]:
+        return gen_forward_eval(ops, G, noise), 0
+    a = ops.g0_fwd_fp8(ops.cast_fp8(noise), G.g0, *folded(G.bn0), G.slope, out_fp8=modes[1] if len(modes) > 1 else False)
+    for l, (cw, bn) in enumerate(G.blocks):
+        if modes[l + 1]:
+            nxt = modes[l + 2] if l + 2 < len(modes) else False
+            a = ops.conv_up_fp8(a, cw, *folded(bn), G.slope, out_fp8=nxt)
+        else:
+            y = ops.conv_up_affine(a, cw, *folded(bn), G.slope)
+            if y is None:
+                invstd = torch.rsqrt(bn.running_var + bn.eps)
+                y = ops.bn_act(ops.conv_up(a, cw), bn.running_mean, invstd, bn.gamma, bn.beta, G.slope)
+            a = y
+    return ops.last_up(a, G.last, G.last.bias, True), sum(modes)
 
 
 def gen_forward_eval(ops, G: GenNet, noise, fused_epilogue=True):

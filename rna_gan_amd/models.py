@@ -322,9 +322,17 @@ class DCGANGenerator(Generator):
             return _GenForwardFn.apply(self, x, *self._rt_flat.params)
         if self.training:
             img, _ = E.gen_forward(ops, net, x, update_running=True, keep=False)
+        elif getattr(self, "inference_fp8", False) and self.precision == "bf16":
+            img, _ = E.gen_forward_eval_fp8(ops, net, x)
         else:
             img = E.gen_forward_eval(ops, net, x)
         return img
+
+    def set_inference_fp8(self, on: bool = True):
+        """Eval-mode forward with fp8 (e4m3) weights / activations where the layer shapes allow (BASELINE configs[4]);
+        training and train-mode forwards are unaffected."""
+        self.inference_fp8 = bool(on)
+        return self
 
 
 class DCGANUpGenerator(Generator):

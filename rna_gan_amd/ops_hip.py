@@ -218,6 +218,70 @@ class HipOps:
                                         _ptr(ws), ws.numel(), self.stream), "rg_g0_fwd_affine")
         return y
 
+    # ------------------------------------------------------------------ fp8 (e4m3) inference operands
+    def cast_fp8(self, t, mul=1.0):
+        """fp32 tensor -> fp8 e4m3 bytes (uint8 tensor of the same shape), fp8(t * mul)."""
+        t = t.float().contiguous()
+        out = torch.empty(t.shape, dtype=torch.uint8, device=self.device)
+        check(self.lib.rg_cast_fp8(_ptr(t), _ptr(out), t.numel(), float(mul), self.stream), "rg_cast_fp8")
+        return out
+
+    def fp8_supported(self, M, K, Ncols, taps):
+        return bool(self.lib.rg_fp8_supported(int(M), int(K), int(Ncols), int(taps)))
+
+    def fp8_pack_up(self, cw: ConvW):
+        """(wup8[16][I][O] fp8 bytes, colscale[I]) of a transposed-conv weight: per output channel i the weights are
+        divided by s_i = max |w[., i, .]| / 448 before the cast, s_i is folded into the epilogue scale.  Cached per
+        master version (inference weights do not change).  The re-layout is host-side plumbing on the device."""
+        key = ("fp8up", cw.version)
+        if getattr(cw, "_fp8", None) is not None and cw._fp8[0] == key:
+            return cw._fp8[1], cw._fp8[2]
+        w = cw.w if cw.layout == "OHWI" else cw.w.permute(0, 2, 3, 1)          # [O][4][4][I]
+        wt = w.permute(1, 2, 3, 0).reshape(16, cw.I, cw.O).float()               # [tap][i][o]
+        s = wt.abs().amax(dim=(0, 2)).clamp_min(1e-30) / 448.0
+        q = self.cast_fp8((wt / s[None, :, None]).contiguous())
+        cw._fp8 = (key, q, s.contiguous())
+        return q, cw._fp8[2]
+
+    def fp8_pack_g0(self, cw: ConvW):
+        """(b8[(tap, c)][E] fp8 bytes, colscale[16*C]) of the generator's first weight w[E][C][4][4]."""
+        key = ("fp8g0", cw.version)
+        if getattr(cw, "_fp8", None) is not None and cw._fp8[0] == key:
+            return cw._fp8[1], cw._fp8[2]
+        E, C = cw.w.shape[0], cw.w.shape[1]
+        b = cw.w.permute(2, 3, 1, 0).reshape(16 * C, E).float()
+        s = b.abs().amax(dim=1).clamp_min(1e-30) / 448.0
+        q = self.cast_fp8((b / s[:, None]).contiguous())
+        cw._fp8 = (key, q, s.contiguous())
+        return q, cw._fp8[2]
+
+    def conv_up_fp8(self, x8, cw: ConvW, scale, shift, slope: float, out_fp8: bool):
+        N, Ho, Wo, O = x8.shape
+        I = cw.I
+        assert x8.dtype == torch.uint8 and x8.is_contiguous() and cw.O == O
+        q, s = self.fp8_pack_up(cw)
+        y = torch.empty((N, 2 * Ho, 2 * Wo, I), dtype=torch.uint8 if out_fp8 else torch.bfloat16, device=self.device)
+        sc, sh = (scale.float() * s).contiguous(), shift.float().contiguous()
+        self._timed("conv_fwd_dgrad", 2.0 * N * Ho * Wo * O * I * 16, lambda: check(
+            self.lib.rg_conv_up_fp8(_ptr(x8), _ptr(q), _ptr(y), N, Ho, Wo, O, I, _ptr(sc), _ptr(sh), float(slope),
+                                    int(out_fp8), self.stream), "rg_conv_up_fp8"))
+        return y
+
+    def g0_fwd_fp8(self, z8, cw: ConvW, scale, shift, slope: float, out_fp8: bool):
+        N, E = z8.shape
+        C = cw.w.shape[1]
+        q, s = self.fp8_pack_g0(cw)
+        y = torch.empty((N, 4, 4, C), dtype=torch.uint8 if out_fp8 else torch.bfloat16, device=self.device)
+        sc, sh = (scale.float().repeat(16) * s).contiguous(), shift.float().repeat(16).contiguous()
+        check(self.lib.rg_gemm_fp8(_ptr(z8), _ptr(q), _ptr(y), N, E, 16 * C, _ptr(sc), _ptr(sh), float(slope), int(out_fp8),
+                                   self.stream), "rg_gemm_fp8")
+        return y
+
+    def selftest_fp8(self):
+        d = torch.zeros(2, dtype=torch.int32, device=self.device)
+        check(self.lib.rg_selftest_fp8(_ptr(d), self.stream), "rg_selftest_fp8")
+        return d.cpu().tolist()
+
     def conv_wgrad(self, low, high, cw: ConvW, accumulate: bool):
         N, Ho, Wo, O = low.shape
         I = high.shape[3]

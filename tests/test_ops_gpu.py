@@ -416,3 +416,54 @@ def test_upconv3_block(N, H, W, Cin, Cout, dtype):
     ref.upconv3_wgrad(gy_img, x, cr, True, gy_nchw=True)
     hip.upconv3_wgrad(dev(gy_img), dev(x), ch, True, gy_nchw=True)
     check(ch.dw, cr.dw, tol * 2, "upconv3_wgrad(nchw, accumulate)")
+
+
+def _fp8_decode(u8):
+    return u8.cpu().view(torch.float8_e4m3fn).float()
+
+
+def test_fp8_selftest_and_cast():
+    hip = _hip(torch.bfloat16)
+    assert hip.selftest_fp8() == [0, 0]
+    x = rnd((1000,), 5, 3.0)
+    q = hip.cast_fp8(x.cuda())
+    want = x.to(torch.float8_e4m3fn).float()                 # torch's OCP e4m3 round-to-nearest-even
+    assert torch.equal(_fp8_decode(q), want)
+
+
+@pytest.mark.parametrize("N,Ho,O,I,out_fp8", [(2, 16, 128, 128, False), (3, 16, 256, 256, True), (1, 32, 128, 256, False),
+                                              (5, 8, 512, 128, True)])
+def test_fp8_conv_up_and_gemm(N, Ho, O, I, out_fp8):
+    """fp8 operand kernels (conv8_kernel<.., EB = 1>) against fp32 torch arithmetic on the DEQUANTISED fp8 operands:
+    transposed conv (all four parity classes, ragged row tiles) and the plain GEMM of the generator's first layer, with the
+    affine + LeakyReLU epilogue and bf16 / fp8 output."""
+    import torch.nn.functional as F
+    hip = _hip(torch.bfloat16)
+    w = rnd((O, I, 4, 4), 1, (2.0 / (I * 16)) ** 0.5)
+    _, ch = cwpair_tm(w)
+    x8 = hip.cast_fp8(rnd((N, Ho, Ho, O), 2).cuda())
+    scale, shift = 1 + 0.1 * rnd((I,), 3), 0.1 * rnd((I,), 4)
+    if not hip.fp8_supported(N * Ho * Ho, 4 * O, I, 4):
+        pytest.skip("no fp8 kernel for this shape")
+    y = hip.conv_up_fp8(x8, ch, scale.cuda(), shift.cuda(), 0.2, out_fp8)
+    q, s = hip.fp8_pack_up(ch)
+    wq = _fp8_decode(q).reshape(4, 4, I, O) * s.cpu()[None, None, :, None]           # dequantised [kh][kw][i][o]
+    ref = F.conv_transpose2d(_fp8_decode(x8).permute(0, 3, 1, 2), wq.permute(3, 2, 0, 1), stride=2, padding=1)
+    ref = ref.permute(0, 2, 3, 1) * scale + shift
+    ref = torch.where(ref > 0, ref, 0.2 * ref)
+    got = _fp8_decode(y) if out_fp8 else y.float().cpu()
+    tol = 0.07 if out_fp8 else 1.2e-2                       # one e4m3 (3 mantissa bits) / one bf16 rounding of the output
+    assert float((got - ref).abs().max()) <= tol * float(ref.abs().max())
+    assert float((wq - w.permute(2, 3, 1, 0)).abs().max()) <= 0.07 * float(w.abs().max())     # weight quantisation itself
+    # plain GEMM: M rows x K, B[(tap, c)][E]
+    M, E, C = 256, 512, 32
+    g0 = ConvW(rnd((E, C, 4, 4), 7, (2.0 / E) ** 0.5).cuda())
+    z8 = hip.cast_fp8(rnd((M, E), 8).cuda())
+    sc, sh = 1 + 0.1 * rnd((C,), 9), 0.1 * rnd((C,), 10)
+    y0 = hip.g0_fwd_fp8(z8, g0, sc.cuda(), sh.cuda(), 0.2, out_fp8)
+    q0, s0 = hip.fp8_pack_g0(g0)
+    ref0 = _fp8_decode(z8) @ (_fp8_decode(q0) * s0.cpu()[:, None]).t()
+    ref0 = ref0 * sc.repeat(16) + sh.repeat(16)
+    ref0 = torch.where(ref0 > 0, ref0, 0.2 * ref0).reshape(M, 4, 4, C)
+    got0 = _fp8_decode(y0) if out_fp8 else y0.float().cpu()
+    assert float((got0 - ref0).abs().max()) <= tol * float(ref0.abs().max())

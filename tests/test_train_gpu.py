@@ -425,3 +425,45 @@ def test_generator_eval_fused_epilogue():
                      for c in torch.split(noise, 256)[:3]])
     # (batch-independent in eval mode: the first samples of a chunk do not depend on the chunk size)
     assert float((got[:6] - ref).abs().max()) <= 5e-2
+
+
+def test_generator_inference_fp8():
+    """BASELINE configs[4] (generator-only synthesis, fp8): eval-mode generator with fp8 (e4m3) weights / activations on
+    the layers that have an fp8 kernel -- against the oracle generator (fp32, eval mode) at a covered size, and at the
+    reference size for 4096 samples (chunks of 512, device-resident output) against the bf16 path on sampled images."""
+    from rna_gan_amd import engine as E
+    in_size, step, enc, n = 64, 64, 512, 256
+    G0 = R.seeded_fill_(R.OracleDCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                               last_nonlinearity=nn.Tanh()), 7).eval()
+    G = P.DCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+    G.load_state_dict(G0.state_dict())
+    G = G.set_precision("bf16").cuda().eval()
+    z = R.synthetic_normal(n, enc, seed=5)
+    with torch.no_grad():
+        want = G0(z)
+    ops, net = G.runtime()
+    img8, nfp8 = E.gen_forward_eval_fp8(ops, net, z.cuda())
+    img16 = E.gen_forward_eval(ops, net, z.cuda())
+    assert nfp8 == 3, nfp8                                     # first layer + 512 -> 256 -> 128; the 128 -> 64 block and the image layer: bf16
+    e8, e16 = (img8.cpu() - want).abs(), (img16.cpu() - want).abs()
+    print("fp8 vs oracle: mean %.4f max %.4f ; bf16 vs oracle: mean %.4f max %.4f" % (e8.mean(), e8.max(), e16.mean(), e16.max()))
+    assert float(e8.mean()) <= 2e-2 and float(e8.max()) <= 0.35 and float(e16.mean()) <= 4e-3
+    G.set_inference_fp8(True)
+    assert torch.equal(G(z.cuda()), img8)
+    # reference size, 4096 samples
+    Gf = P.DCGANGenerator(2048, 256, 3, 64, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+    R.seeded_fill_(Gf, 3)
+    Gf = Gf.set_precision("bf16").cuda().eval()
+    ops, net = Gf.runtime()
+    noise = torch.randn(4096, 2048, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    d_mean, d_max = 0.0, 0.0
+    with torch.no_grad():
+        for k, c in enumerate(torch.split(noise, 512)):
+            img, nfp8 = E.gen_forward_eval_fp8(ops, net, c.contiguous())
+            assert nfp8 == 5 and img.is_cuda and img.shape == (512, 3, 256, 256) and torch.isfinite(img).all()
+            if k < 2:
+                ref = E.gen_forward_eval(ops, net, c[:128].contiguous())
+                d = (img[:128] - ref).abs()
+                d_mean, d_max = max(d_mean, float(d.mean())), max(d_max, float(d.max()))
+    print("fp8 vs bf16 at the reference size: mean |diff| %.4f, max %.4f" % (d_mean, d_max))
+    assert d_mean <= 3e-2

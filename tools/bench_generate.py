@@ -52,6 +52,20 @@ def main():
     # resident on the device: fused epilogue (one kernel per Conv+BN+LReLU block) against the unfused conv -> bn_act pairs
     G.eval()
     ops, net = G.runtime()
+    for chunk in (256, 512):
+        with torch.no_grad():
+            for c in torch.split(noise[:2 * chunk], chunk):
+                E.gen_forward_eval_fp8(ops, net, c.contiguous())
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for c in torch.split(noise, chunk):
+                if c.shape[0] == chunk:
+                    _, nfp8 = E.gen_forward_eval_fp8(ops, net, c.contiguous())
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        m = (n // chunk) * chunk
+        print(f"eval-mode generator, fp8 e4m3 on {nfp8} of 7 layers, chunk {chunk:4d}: {m / dt:.0f} imgs/s "
+              f"({dt / (n // chunk) * 1e3:.3f} ms per chunk, {5.604e9 * m / dt / 1e12:.0f} TFLOP/s)", flush=True)
     for fused in (False, True):
         for chunk in (64, 256, 512):
             with torch.no_grad():
