@@ -294,6 +294,11 @@ def main(argv=None):
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args, argv))
 
+    # stdout carries exactly ONE line (the JSON record): everything else this process or the libraries it loads write
+    # to file descriptor 1 (RCCL prints a version banner there when a communicator is created) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     from rna_gan_amd import dist as D_
     global _DEFAULT_THREADS
     _DEFAULT_THREADS = torch.get_num_threads()
@@ -399,7 +404,8 @@ def main(argv=None):
             out["roofline"] = roof
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.seed)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     barrier()
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

@@ -20,8 +20,11 @@ import os
 import torch
 import torch.distributed as dist
 
-# 64 MiB buckets: large enough to be bandwidth- rather than latency-bound on xGMI
-BUCKET_BYTES = 64 * 1024 * 1024
+# One collective per gradient buffer (G: 224 MB, D: 89 MB on the bf16 wire): the all-reduce of a train_op is started
+# once its whole backward is done (90 % of the generator's gradient bytes are written by the last two launches of the
+# backward, so buckets in backward order would have nothing to overlap with), and every extra RCCL launch costs
+# 20-50 us per rank.  RNAGAN_DP_BUCKET_MB splits the buffer into fixed-size buckets for experiments.
+BUCKET_BYTES = int(os.environ.get("RNAGAN_DP_BUCKET_MB", "1024")) * 1024 * 1024
 FORCE = os.environ.get("RNAGAN_FORCE_DP", "0") == "1"     # take the DP code path even with one rank (testing)
 COMPRESS = os.environ.get("RNAGAN_DP_BF16", "1") != "0"
 # --sync-stats: BatchNorm statistics (forward, backward, tangent, double backward), the latent
