@@ -143,8 +143,16 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
   // k-tile index (relative to kt_begin) -> byte offsets added to the A row bases / B column bases, and the tap
   auto decode = [&](int ktr, int& ao, int& bo, int& tap) {
     const int kt = kt_begin + ktr;
-    tap = kt >> lgcpt;
-    const int c0 = (kt & cmask) * KD;
+    int cb;
+    if (a2.korder && MODE != MODE_PLAIN) {
+      const int ti = kt & (g.taps - 1);
+      cb = kt >> (MODE == MODE_DOWN ? 4 : 2);
+      tap = MODE == MODE_DOWN ? rg_down_tap(ti) : ti;
+    } else {
+      tap = kt >> lgcpt;
+      cb = kt & cmask;
+    }
+    const int c0 = cb * KD;
     int a_delta, b_tap;
     if (MODE == MODE_DOWN) {
       a_delta = ((tap >> 2) * g.Ws + (tap & 3)) * g.Cin;

@@ -61,6 +61,13 @@ __device__ __forceinline__ void up_tap_dev(int par, int a, int& kidx, int& d) {
   else          { kidx = a == 0 ? 0 : 2; d = a == 0 ? 1 : 0; }
 }
 
+// korder tap sequence of the stride-2 4x4 conv: index bits (py, px, jy, jx) -> tap (kh, kw) = (2 jy + py, 2 jx + px).  The four
+// taps of one (py, px) class read the same input pixels shifted by whole output pixels, so they hit the lines the previous
+// k-tile brought into L2.
+__device__ __forceinline__ int rg_down_tap(int ti) {
+  return ((((ti >> 1) & 1) * 2 + (ti >> 3)) << 2) | ((ti & 1) * 2 + ((ti >> 2) & 1));
+}
+
 struct G2Args {
   GArgs g;
   unsigned a_bytes, b_bytes;   // sizes for the buffer descriptors
@@ -72,6 +79,8 @@ struct G2Args {
   float* slab;                 // [nsplit][rows_out][Ncols] fp32 when nsplit > 1
   long long slab_stride;       // elements per split
   int lgcpt, cmask;            // conv8_kernel: k-tile kt -> tap = kt >> lgcpt, channel block = kt & cmask
+  int korder;                  // 1: channel-block-major k order (tap = kt & (taps-1), block = kt / taps; MODE_DOWN taps in
+                               // parity-class order): the taps that revisit the same input lines are adjacent k-tiles
 };
 
 typedef __attribute__((address_space(3))) void* lds_vptr_t;

@@ -94,6 +94,10 @@ int rg_mfma_gemm_fp8(const void* a8, const void* b8, void* y, int M, int K, int 
 // rg_conv8.hip (8-wave ping-pong gather GEMM; args = G2Args of rg_gather.h)
 int rg_conv8_launch(int mode, const void* args, int bm, unsigned gx, unsigned gy, unsigned gz, hipStream_t st);
 int rg_conv8n_launch(const void* args, unsigned tiles_m, hipStream_t st);
+// rg_convp.hip: 128 -> 64 channel transposed conv with the input patch resident in LDS
+bool rg_convp_supported(int M, int Ncols, int Cin, int Hs, int Ws);
+int rg_convp_tiles(int M);
+int rg_convp_launch(const void* args, hipStream_t st);
 
 // rg_wgrad8.hip (8-wave ping-pong weight gradient)
 bool rg_wgrad8_supported(int K, int O, int I);

@@ -357,8 +357,10 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
   const int kt_end = min(nkt_all, kt_begin + per);
   const int nkt = kt_end - kt_begin;
 
+  const bool korder = a2.korder && (MODE == MODE_DOWN || MODE == MODE_UP);
   auto issue = [&](int stage, int tap, int c0) {
     int a_delta, b_tap;
+    if (MODE == MODE_DOWN && korder) tap = rg_down_tap(tap);
     if (MODE == MODE_DOWN) {
       a_delta = ((tap >> 2) * g.Ws + (tap & 3)) * g.Cin;
       b_tap = tap;
@@ -407,12 +409,17 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   int tap_n = kt_begin / cpt, cc_n = kt_begin - tap_n * cpt;
+  if (korder) { cc_n = kt_begin / g.taps; tap_n = kt_begin - cc_n * g.taps; }
+  auto advance = [&]() {
+    if (korder) { if (++tap_n == g.taps) { tap_n = 0; ++cc_n; } }
+    else if (++cc_n == cpt) { cc_n = 0; ++tap_n; }
+  };
   // prologue: NSTAGE-1 tiles in flight
 #pragma unroll
   for (int p = 0; p < NSTAGE - 1; ++p)
     if (p < nkt) {
       issue(p, tap_n, cc_n << 6);
-      if (++cc_n == cpt) { cc_n = 0; ++tap_n; }
+      advance();
     }
   int st_c = 0, st_i = NSTAGE - 1;     // stage being computed / stage to issue into
   // Fragment reads are asm ds_read_b128 with hand-counted lgkmcnt waits.  (1) hipcc puts s_waitcnt vmcnt(0) in
@@ -467,7 +474,7 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
     __builtin_amdgcn_s_barrier();      // everyone's part of tile kt landed; everyone finished reading tile kt-1
     if (kt + NSTAGE - 1 < nkt) {       // refill the stage tile kt-1 lived in
       issue(st_i, tap_n, cc_n << 6);
-      if (++cc_n == cpt) { cc_n = 0; ++tap_n; }
+      advance();
     }
     const unsigned so = (unsigned)(st_c * STAGE_SLOTS * 16);
     unsigned fas[4], fbs[4];
@@ -1094,7 +1101,7 @@ static bool use_v1() { return rg_option("conv_v1", 0) == 1; }
 
 // split-K policy of the DMA kernel: only when the grid cannot fill the chip (< 1 block per CU) and K is long
 // tile variant / split-K decision of the DMA kernel, shared by the launcher and by rg_mfma_conv_stats_rows
-struct GPlan { bool narrow, wide; int nsplit; bool c8; int bm, bn; bool n8; };
+struct GPlan { bool narrow, wide; int nsplit; bool c8; int bm, bn; bool n8, pp; };
 
 static int gather_split(int M, int Ncols, int nclass, int nkt, bool allow, int cap = 4, int min_kt = 16) {
   if (!allow) return 1;
@@ -1119,7 +1126,8 @@ static int gather_split(int M, int Ncols, int nclass, int nkt, bool allow, int c
 static int conv8_mode() { return rg_option("conv8", 1); }
 static int conv8_blocks_target() { return rg_option("conv8_blocks", 256); }
 
-static GPlan gather_plan(int mode, bool bf16_out, int M, int Ncols, int Cin, int taps, int nclass, bool masked) {
+static GPlan gather_plan(int mode, bool bf16_out, int M, int Ncols, int Cin, int taps, int nclass, bool masked, int Hs = 0,
+                         int Ws = 0, bool has_mask = false) {
   const int variant = rg_option("conv_tile", 1);
   const int nkt = taps * (Cin >> 6);
   GPlan pl{};
@@ -1130,6 +1138,12 @@ static GPlan gather_plan(int mode, bool bf16_out, int M, int Ncols, int Cin, int
   // the 160 KB of LDS bound the bytes in flight per CU and one wave group issuing at a time halves them again.  Off
   // by default (RNAGAN_NARROW8=1 / rg_set_option("narrow8", 1) selects it); kept as the starting point of a kernel
   // that keeps the input patch resident in LDS instead of re-fetching it per tap.
+  // pp: the same layer with the input patch resident in LDS (rg_convp.hip; RNAGAN_CONVP=0: off)
+  if (rg_option("convp", 1) && !has_mask && bf16_out && mode == MODE_UP && nclass == 4 && taps == 4 && Ws > 0 &&
+      rg_convp_supported(M, Ncols, Cin, Hs, Ws)) {
+    pl.pp = true; pl.nsplit = 1; pl.bm = 256; pl.bn = 64;
+    return pl;
+  }
   if (rg_option("narrow8", 0) && bf16_out && mode == MODE_UP && nclass == 4 && Ncols == 64 && rg_is_pow2(cpt) && M >= 512) {
     pl.n8 = true; pl.nsplit = 1; pl.bm = 512; pl.bn = 64;
     return pl;
@@ -1179,8 +1193,10 @@ int rg_mfma_conv_stats_rows(int up, int N, int Hlow, int Wlow, int O, int I) {
   const int M = N * Hlow * Wlow, Ncols = up ? I : O, Cin = up ? O : I, taps = up ? 4 : 16, nclass = up ? 4 : 1;
   const size_t a_bytes = up ? (size_t)M * O * 2 : (size_t)M * 4 * I * 2, b_bytes = (size_t)O * 16 * I * 2;
   if (use_v1() || a_bytes >= 0x7fffff00ull || b_bytes >= 0x7fffff00ull) return 0;
-  GPlan pl = gather_plan(up ? MODE_UP : MODE_DOWN, true, M, Ncols, Cin, taps, nclass, false);
+  GPlan pl = gather_plan(up ? MODE_UP : MODE_DOWN, true, M, Ncols, Cin, taps, nclass, false, up ? Hlow : 2 * Hlow,
+                         up ? Wlow : 2 * Wlow);
   if (pl.nsplit > 1) return 0;
+  if (pl.pp) return 4 * rg_convp_tiles(M) * 2;
   if (pl.n8) return 4 * ((M + 511) / 512) * 8;
   if (pl.c8) return nclass * ((M + pl.bm - 1) / pl.bm) * (pl.bm / 128);
   const int bmm = (pl.narrow || pl.wide) ? 256 : 128, parts = pl.narrow ? 4 : 2;      // BM / wave-tile rows
@@ -1192,13 +1208,15 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
                           void* ws, size_t ws_bytes, hipStream_t st) {
   if (use_v1() || a_bytes >= 0x7fffff00ull || b_bytes >= 0x7fffff00ull) return launch_gather<MODE, EPI>(name, g, nclass, st);
   G2Args a2{};
-  const GPlan pl = gather_plan(MODE, EPI == EPI_BF16, g.M, g.Ncols, g.Cin, g.taps, nclass, g.mask != nullptr || g.affine);
+  const GPlan pl = gather_plan(MODE, EPI == EPI_BF16, g.M, g.Ncols, g.Cin, g.taps, nclass, g.mask != nullptr || g.affine,
+                               g.Hs, g.Ws, g.mask != nullptr);
   const bool narrow = pl.narrow, wide = pl.wide;
   int nsplit = pl.nsplit;
   size_t need = (size_t)nsplit * rows_out * (EPI == EPI_BF16 ? g.Ncols : g.ldc) * sizeof(float);
   if (nsplit > 1 && (!ws || ws_bytes < need)) nsplit = 1;
   if (EPI == EPI_LINEAR && (g.Ncols % 8 != 0 || g.ldc % 4 != 0)) nsplit = 1;      // slab rows are written 8 wide
   a2.a_bytes = (unsigned)a_bytes; a2.b_bytes = (unsigned)b_bytes;
+  a2.korder = (MODE == MODE_DOWN || MODE == MODE_UP) ? rg_option("korder", 1) : 0;
   a2.nsplit = nsplit; a2.slab = (float*)ws; a2.slab_stride = rows_out * (EPI == EPI_BF16 ? g.Ncols : g.ldc);
   // weight-streaming GEMMs (a batch of <= 64 rows against a large weight matrix: betaVAE layers, G.0): 64-row tile with a
   // 3-deep DMA ring -- the bound is HBM latency x bytes in flight, not the matrix cores (RNAGAN_STREAM_TILE=0: off)
@@ -1217,7 +1235,14 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   }
   a2.xcd_swizzle = (xcd && grid.x % 8 == 0 && grid.x >= 16 && (xcd == 2 || a_bytes > b_bytes)) ? 1 : 0;
   // (measured and rejected for the 64-column tile: 2 waves with 128 x 64 wave tiles, 147-154 us vs 109-112 us)
-  if (pl.n8) {
+  if (pl.pp) {
+    if constexpr (EPI == EPI_BF16 && MODE == MODE_UP) {
+      RG_REQUIRE(g.ldc == 64 && g.b_col == g.Cin, RG_EUNSUPPORTED, "%s: convp layout", name);
+      a2.g.tiles_n = 1;
+      a2.tiles_m = rg_convp_tiles(g.M);
+      rg_convp_launch(&a2, st);
+    }
+  } else if (pl.n8) {
     if constexpr (EPI == EPI_BF16 && MODE == MODE_UP) {
       a2.class_fast = 0;
       a2.tiles_m = (g.M + 511) / 512;

@@ -14,4 +14,4 @@ run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run l2 TCC_HIT_sum TCC_MISS_sum
-python3 tools/pmc_layers.py gpurun_out/${OUT}_sq gpurun_out/${OUT}_lds gpurun_out/${OUT}_fetch gpurun_out/${OUT}_write gpurun_out/${OUT}_l2 --csv gpurun_out/${OUT}_summary.csv | grep -E "kernel|conv8|gather_gemm|wgrad"
+python3 tools/pmc_layers.py gpurun_out/${OUT}_sq gpurun_out/${OUT}_lds gpurun_out/${OUT}_fetch gpurun_out/${OUT}_write gpurun_out/${OUT}_l2 --csv gpurun_out/${OUT}_summary.csv | grep -E "kernel|conv8|convp|gather_gemm|wgrad"
