@@ -131,6 +131,20 @@ int rg_first_down(const float* x_nchw, const float* w, const float* bias, void* 
                   int O, float slope, int dtype, void* stream);
 int rg_last_up(const void* x, const float* w, const float* bias, float* y_nchw, int N, int Ho, int Wo, int O,
                int I, int apply_tanh, int dtype, void* stream);
+/* Packed LeakyReLU mask of the discriminator's layer 0 (histopathology_gan.py:186-192) for the data-gradient conv of
+ * layer 1 (.backward() at src/wgan_loss.py:126,260,387 and autograd.grad :34-41): bits[pixel] (uint64, pixel = NHWC row of
+ * y) has bit c set when y[pixel][c] > 0 (the bf16 value as stored).  rg_first_down_bits = rg_first_down + those bits
+ * (O = 64, bf16; written by the same kernel); rg_sign_pack computes them from an existing activation [npix][64].
+ * rg_conv_up_maskbits = rg_conv_up with mask_act given in this packed form (8 B instead of 128 B per output pixel, and the
+ * kernel that keeps the input patch resident in LDS); rg_conv_up_maskbits_supported tells whether the shape takes it
+ * (O = 128 -> I = 64 channels, Wo in {16, 32, 64}); otherwise use rg_conv_up with the activation itself. */
+int rg_first_down_bits(const float* x_nchw, const float* w, const float* bias, void* y, void* bits, int N, int H, int W,
+                       int I, int O, float slope, int dtype, void* stream);
+int rg_sign_pack(const void* a, void* bits, long long npix, int C, int dtype, void* stream);
+int rg_conv_up_maskbits_supported(int N, int Ho, int Wo, int O, int I, int dtype, int algo);
+int rg_conv_up_maskbits(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I,
+                        const void* mask_bits, float mask_slope, int dtype, int algo, void* ws, size_t ws_bytes,
+                        void* stream);
 size_t rg_skinny_wgrad_workspace_bytes(int N, int Ho, int Wo, int O, int I);
 int rg_skinny_wgrad(const void* low, const float* high_nchw, float* dw, int N, int Ho, int Wo, int O, int I,
                     int dtype, int accumulate, void* ws, size_t ws_bytes, void* stream);

@@ -33,6 +33,10 @@ PROTOTYPES = {
     "rg_conv_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_conv_wgrad2": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_first_down": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "rg_first_down_bits": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "rg_sign_pack": (_i, [_p, _p, C.c_longlong, _i, _i, _p]),
+    "rg_conv_up_maskbits_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "rg_conv_up_maskbits": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _f, _i, _i, _p, _z, _p]),
     "rg_last_up": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "rg_skinny_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "rg_skinny_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),

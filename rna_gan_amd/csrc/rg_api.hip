@@ -140,8 +140,39 @@ extern "C" int rg_first_down(const float* x_nchw, const float* w, const float* b
   RG_REQUIRE(x_nchw && w && y && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && I > 0 && O > 0, RG_EINVAL,
              "first_down: bad args");
   if (rg_skinny_supported(I, O))
-    return rg_skinny_first_down(x_nchw, w, bias, y, N, H, W, I, O, slope, dtype, rg_stream(stream));
+    return rg_skinny_first_down(x_nchw, w, bias, y, nullptr, N, H, W, I, O, slope, dtype, rg_stream(stream));
   return rg_generic_first_down(x_nchw, w, bias, y, N, H, W, I, O, slope, dtype, rg_stream(stream));
+}
+
+// first_down that also writes the packed sign bits of its (bf16, 64-channel) output: bits[pixel] bit c = y[pixel][c] > 0
+extern "C" int rg_first_down_bits(const float* x_nchw, const float* w, const float* bias, void* y, void* bits, int N, int H,
+                                  int W, int I, int O, float slope, int dtype, void* stream) {
+  RG_REQUIRE(x_nchw && w && y && bits && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && I > 0 && O == 64 &&
+                 dtype == RG_BF16, RG_EINVAL, "first_down_bits: bad args (64 bf16 output channels)");
+  if (rg_skinny_supported(I, O))
+    return rg_skinny_first_down(x_nchw, w, bias, y, bits, N, H, W, I, O, slope, dtype, rg_stream(stream));
+  int rc = rg_generic_first_down(x_nchw, w, bias, y, N, H, W, I, O, slope, dtype, rg_stream(stream));
+  return rc != RG_OK ? rc : rg_skinny_sign_pack(y, bits, (long long)N * (H / 2) * (W / 2), O, dtype, rg_stream(stream));
+}
+
+extern "C" int rg_sign_pack(const void* a, void* bits, long long npix, int C, int dtype, void* stream) {
+  RG_REQUIRE(a && bits && npix > 0, RG_EINVAL, "sign_pack: bad args");
+  return rg_skinny_sign_pack(a, bits, npix, C, dtype, rg_stream(stream));
+}
+
+extern "C" int rg_conv_up_maskbits_supported(int N, int Ho, int Wo, int O, int I, int dtype, int algo) {
+  return want_mfma(algo, dtype) && N > 0 && Ho > 0 && Wo > 0 && rg_mfma_conv_supported(N, Ho, Wo, O, I) &&
+         rg_mfma_conv_up_maskbits_supported(N, Ho, Wo, O, I);
+}
+
+// conv_up with the consumer's LeakyReLU backward fused from PACKED sign bits (rg_first_down_bits / rg_sign_pack)
+extern "C" int rg_conv_up_maskbits(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I,
+                                   const void* mask_bits, float mask_slope, int dtype, int algo, void* ws, size_t ws_bytes,
+                                   void* stream) {
+  RG_REQUIRE(x && wup && y && mask_bits, RG_EINVAL, "conv_up_maskbits: bad args");
+  RG_REQUIRE(rg_conv_up_maskbits_supported(N, Ho, Wo, O, I, dtype, algo), RG_EUNSUPPORTED, "conv_up_maskbits: shape");
+  return rg_mfma_conv_up(x, wup, y, N, Ho, Wo, O, I, mask_bits, mask_slope, nullptr, ws, ws_bytes, rg_stream(stream),
+                         nullptr, nullptr, 1.f, 1);
 }
 
 extern "C" int rg_last_up(const void* x, const float* w, const float* bias, float* y_nchw, int N, int Ho, int Wo,

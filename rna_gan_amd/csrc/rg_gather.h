@@ -37,6 +37,7 @@ struct GArgs {
   const uint16_t* mask;   // EPI_BF16, optional: activation with the output's shape; out *= (mask > 0 ? 1 : mslope)
   float mslope;           // (LeakyReLU backward of the consumer fused into the data-gradient conv)
   int in_fp8, out_fp8;    // conv8_kernel<.., EB = 1>: fp8 e4m3 operands (A, B) / fp8 output (row stride ldc in elements)
+  int mask_packed;        // mask holds packed sign bits (one 64-bit word per output pixel: convp_kernel only)
   int affine;             // EPI_BF16, bf16 output without split-K: out = lrelu(acc * scale[col] + shift[col], slope) (eval-mode
                           // BatchNorm folded into the conv epilogue: generator-only inference)
 };

@@ -40,7 +40,9 @@ int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, in
 int rg_mfma_conv_stats_rows(int up, int N, int Hlow, int Wlow, int O, int I);
 int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, const void* mask,
                     float mslope, float* stats, void* ws, size_t ws_bytes, hipStream_t st, const float* scale = nullptr,
-                    const float* shift = nullptr, float slope = 1.f);
+                    const float* shift = nullptr, float slope = 1.f, int mask_packed = 0);
+// packed-mask form of the transposed conv's fused LeakyReLU backward (rg_convp.hip): shapes that take it
+bool rg_mfma_conv_up_maskbits_supported(int N, int Ho, int Wo, int O, int I);
 size_t rg_mfma_conv_ws_bytes(int up, int N, int Hlow, int Wlow, int O, int I);
 bool rg_mfma_upconv3_supported(int N, int H, int W, int Cin, int Cout);
 size_t rg_mfma_upconv3_fwd_ws_bytes(int N, int H, int W, int Cin, int Cout);
@@ -107,8 +109,9 @@ int rg_wgrad8_launch(const void* low0, const void* high0, const void* low1, cons
 
 // rg_skinny.hip (image-side 3-channel layers)
 bool rg_skinny_supported(int I, int O);
-int rg_skinny_first_down(const float* x, const float* w, const float* bias, void* y, int N, int H, int W, int I,
+int rg_skinny_first_down(const float* x, const float* w, const float* bias, void* y, void* bits, int N, int H, int W, int I,
                          int O, float slope, int dtype, hipStream_t st);
+int rg_skinny_sign_pack(const void* a, void* bits, long long npix, int C, int dtype, hipStream_t st);
 int rg_skinny_last_up(const void* x, const float* w, const float* bias, float* y, int N, int Ho, int Wo, int O, int I,
                       int apply_tanh, int dtype, hipStream_t st);
 size_t rg_skinny_wgrad_ws_bytes(int N, int Ho, int Wo, int O, int I);

@@ -1209,7 +1209,7 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   if (use_v1() || a_bytes >= 0x7fffff00ull || b_bytes >= 0x7fffff00ull) return launch_gather<MODE, EPI>(name, g, nclass, st);
   G2Args a2{};
   const GPlan pl = gather_plan(MODE, EPI == EPI_BF16, g.M, g.Ncols, g.Cin, g.taps, nclass, g.mask != nullptr || g.affine,
-                               g.Hs, g.Ws, g.mask != nullptr);
+                               g.Hs, g.Ws, g.mask != nullptr && !g.mask_packed);
   const bool narrow = pl.narrow, wide = pl.wide;
   int nsplit = pl.nsplit;
   size_t need = (size_t)nsplit * rows_out * (EPI == EPI_BF16 ? g.Ncols : g.ldc) * sizeof(float);
@@ -1235,6 +1235,7 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   }
   a2.xcd_swizzle = (xcd && grid.x % 8 == 0 && grid.x >= 16 && (xcd == 2 || a_bytes > b_bytes)) ? 1 : 0;
   // (measured and rejected for the 64-column tile: 2 waves with 128 x 64 wave tiles, 147-154 us vs 109-112 us)
+  RG_REQUIRE(!g.mask_packed || pl.pp, RG_EUNSUPPORTED, "%s: packed mask bits without the patch-resident kernel", name);
   if (pl.pp) {
     if constexpr (EPI == EPI_BF16 && MODE == MODE_UP) {
       RG_REQUIRE(g.ldc == 64 && g.b_col == g.Cin, RG_EUNSUPPORTED, "%s: convp layout", name);
@@ -1296,8 +1297,11 @@ int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, in
 
 int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, const void* mask,
                     float mslope, float* stats, void* ws, size_t ws_bytes, hipStream_t st, const float* scale,
-                    const float* shift, float slope) {
+                    const float* shift, float slope, int mask_packed) {
   GArgs g{};
+  RG_REQUIRE(!mask_packed || (mask && rg_mfma_conv_up_maskbits_supported(N, Ho, Wo, O, I)), RG_EUNSUPPORTED,
+             "conv_up: packed mask bits need the patch-resident kernel's shape (128 -> 64 channels, width 16..64)");
+  g.mask_packed = mask_packed;
   g.affine = scale != nullptr; g.scale = scale; g.shift = shift; g.slope = slope;
   g.stats = mask ? nullptr : stats;
   g.mask = (const uint16_t*)mask; g.mslope = mslope;
@@ -1306,6 +1310,10 @@ int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int 
   g.lgW = rg_ilog2(Wo); g.lgH = rg_ilog2(Ho); g.Hs = Ho; g.Ws = Wo; g.ldc = I; g.b_col = O; g.b_tap = I * O;        // wup[16][I][O]
   return launch_gather2<MODE_UP, EPI_BF16>("conv_up(mfma)", g, 4, (long long)g.M * 4, (size_t)N * Ho * Wo * O * 2,
                                            (size_t)I * 16 * O * 2, ws, ws_bytes, st);
+}
+
+bool rg_mfma_conv_up_maskbits_supported(int N, int Ho, int Wo, int O, int I) {
+  return rg_option("convp", 1) && rg_convp_supported(N * Ho * Wo, I, O, Ho, Wo) && (size_t)N * Ho * Wo * O * 2 < 0x7fffff00ull;
 }
 
 // ---- fp8 e4m3 operands (generator-only inference, BASELINE configs[4]): conv8_kernel<.., EB = 1> only, no split-K

@@ -129,6 +129,7 @@ __device__ __forceinline__ void sk_scatter4(uint16_t* pt, float4 v, int lgc, int
   k0[1] = f32_to_bf16(v.y);
   if (2 * m + 2 < chunk) k0[2] = f32_to_bf16(v.w);
 }
+__device__ __forceinline__ bool sk_pos16(uint32_t h) { return !(h & 0x8000u) && (h & 0x7fffu); }
 template <int PTS>
 __device__ __forceinline__ void sk_scatter_rows(uint16_t* pt, const SkRows& r, int chunk, int lgc, int t) {
   const int nf = 12 << lgc;
@@ -151,8 +152,11 @@ __device__ __forceinline__ void sk_scatter_rows(uint16_t* pt, const SkRows& r, i
 constexpr int FD_PTS = 160;
 constexpr int FD_OTS = 72;      // out-tile row stride (bf16): 144 bytes
 
+// bits (optional): packed sign bits of the activation, one 64-bit word per output pixel, bit c = (y[pixel][c] > 0) -- the
+// LeakyReLU-backward mask of the data-gradient conv of layer 1 (rg_convp.hip reads 8 B per pixel instead of 128 B).
 __global__ __launch_bounds__(256, 3) void first_down_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                  const float* __restrict__ bias, uint16_t* __restrict__ y,
+                                                                 unsigned long long* __restrict__ bits,
                                                                  int N, int H, int W, float slope, int chunk, int nunits) {
   __shared__ __attribute__((aligned(16))) uint16_t pt[SK_K * FD_PTS];        // 15 KB
   __shared__ __attribute__((aligned(16))) uint16_t ot[4 * 32 * FD_OTS];      // 18 KB
@@ -207,14 +211,30 @@ __global__ __launch_bounds__(256, 3) void first_down_rows_kernel(const float* __
         for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i][ci], pb, acc[i], 0, 0, 0);
       }
       // acc[i][4*g + e] = D[ch = 32*i + 8*g + 4*h + e][pixel r]
+      unsigned nib = 0;                                    // nibble 4*i + g: sign bits of channels 32*i + 8*g + 4*h + 0..3
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           float v0 = lrelu_f(acc[i][4 * g4 + 0] + bs[i][g4][0], slope), v1 = lrelu_f(acc[i][4 * g4 + 1] + bs[i][g4][1], slope);
           float v2 = lrelu_f(acc[i][4 * g4 + 2] + bs[i][g4][2], slope), v3 = lrelu_f(acc[i][4 * g4 + 3] + bs[i][g4][3], slope);
-          *reinterpret_cast<uint2*>(otw + r * FD_OTS + 32 * i + 8 * g4 + 4 * h) = make_uint2(sk_pack2(v0, v1), sk_pack2(v2, v3));
+          const uint32_t p01 = sk_pack2(v0, v1), p23 = sk_pack2(v2, v3);
+          *reinterpret_cast<uint2*>(otw + r * FD_OTS + 32 * i + 8 * g4 + 4 * h) = make_uint2(p01, p23);
+          // bit = the STORED bf16 value is > 0 (sign clear, magnitude non-zero): what rg_lmask tests on the bf16 activation
+          const unsigned b = (sk_pos16(p01) ? 1u : 0u) | (sk_pos16(p01 >> 16) ? 2u : 0u) | (sk_pos16(p23) ? 4u : 0u) |
+                             (sk_pos16(p23 >> 16) ? 8u : 0u);
+          nib |= b << (4 * (4 * i + g4));
         }
+      if (bits) {
+        // lanes r and r + 32 hold the low (h = 0) / high (h = 1) nibble of every byte of pixel r's word
+        const unsigned other = (unsigned)__shfl_xor((int)nib, 32, 64);
+        const unsigned lo = h ? other : nib, hi = h ? nib : other;
+        unsigned long long word = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          word |= ((unsigned long long)(((lo >> (4 * k)) & 15u) | (((hi >> (4 * k)) & 15u) << 4))) << (8 * k);
+        if (h == 0) bits[((size_t)q.n * Ho + q.ho) * Wo + q.wo0 + wave * 32 + r] = word;
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // wave-private tile: in-order DS pipe, no barrier needed
       uint16_t* yo = y + (((size_t)q.n * Ho + q.ho) * Wo + q.wo0 + wave * 32) * 64;
 #pragma unroll
@@ -659,7 +679,38 @@ int skinny_wgrad_blocks(long long npix, int* ppb) {
 
 bool rg_skinny_supported(int I, int O) { return I == SK_I && O % 64 == 0 && O <= 128; }
 
-int rg_skinny_first_down(const float* x, const float* w, const float* bias, void* y, int N, int H, int W, int I,
+// sign bits of a bf16 activation [npix][64] (fallback where the producer does not write them itself)
+__global__ __launch_bounds__(256) void sign_pack64_kernel(const uint16_t* __restrict__ a, unsigned long long* __restrict__ bits,
+                                                          size_t npix) {
+  // 8 lanes per pixel, 16 B (8 channels) each; the 8 bytes of the word are gathered with 3 xor-shuffles
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t p = gid >> 3;
+  const int c8 = (int)(gid & 7);
+  unsigned long long part = 0;
+  if (p < npix) {
+    const uint4 v = *reinterpret_cast<const uint4*>(a + p * 64 + c8 * 8);
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+    unsigned b = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b |= ((sk_pos16(d[k]) ? 1u : 0u) | (sk_pos16(d[k] >> 16) ? 2u : 0u)) << (2 * k);
+    part = (unsigned long long)b << (8 * c8);
+  }
+  part |= __shfl_xor(part, 1, 64);
+  part |= __shfl_xor(part, 2, 64);
+  part |= __shfl_xor(part, 4, 64);
+  if (p < npix && c8 == 0) bits[p] = part;
+}
+
+int rg_skinny_sign_pack(const void* a, void* bits, long long npix, int C, int dtype, hipStream_t st) {
+  RG_REQUIRE(C == 64 && dtype == RG_BF16, RG_EUNSUPPORTED, "sign_pack: 64 bf16 channels only");
+  const unsigned blocks = (unsigned)((npix * 8 + 255) / 256);
+  hipLaunchKernelGGL(sign_pack64_kernel, dim3(blocks), dim3(256), 0, st, (const uint16_t*)a, (unsigned long long*)bits,
+                     (size_t)npix);
+  RG_LAUNCH_CHECK("sign_pack");
+  return RG_OK;
+}
+
+int rg_skinny_first_down(const float* x, const float* w, const float* bias, void* y, void* bits, int N, int H, int W, int I,
                          int O, float slope, int dtype, hipStream_t st) {
   (void)I;
   long long npix = (long long)N * (H / 2) * (W / 2);
@@ -669,10 +720,14 @@ int rg_skinny_first_down(const float* x, const float* w, const float* bias, void
   if (dtype == RG_BF16 && O == 64 && sk_rows_chunk(W / 2, &chunk) && npix / chunk < 0x7fffffff && !no_mfma) {
     int nunits = (int)(npix / chunk);
     int blocks = nunits < SK_ROWS_BLOCKS ? nunits : SK_ROWS_BLOCKS;
-    hipLaunchKernelGGL(first_down_rows_kernel, dim3(blocks), dim3(256), 0, st, x, w, bias, (uint16_t*)y, N, H, W, slope,
-                       chunk, nunits);
+    hipLaunchKernelGGL(first_down_rows_kernel, dim3(blocks), dim3(256), 0, st, x, w, bias, (uint16_t*)y,
+                       (unsigned long long*)bits, N, H, W, slope, chunk, nunits);
     RG_LAUNCH_CHECK("first_down(mfma)");
     return RG_OK;
+  }
+  if (bits) {
+    int rc = rg_skinny_first_down(x, w, bias, y, nullptr, N, H, W, I, O, slope, dtype, st);
+    return rc != RG_OK ? rc : rg_skinny_sign_pack(y, bits, npix, O, dtype, st);
   }
   unsigned blocks = (unsigned)((npix + 255) / 256);
   RG_DISPATCH_DTYPE(dtype, T, {

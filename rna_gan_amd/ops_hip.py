@@ -179,6 +179,12 @@ class HipOps:
         assert mask_act is None or (mask_act.shape == y.shape and mask_act.dtype == y.dtype and mask_act.is_contiguous())
         st = self._stats_buf(1, N, Ho, Wo, O, I, I) if (want_stats and mask_act is None) else None
         ws = self._ws(self.lib.rg_conv_workspace_bytes(1, N, Ho, Wo, O, I, self.dt, self.algo))
+        bits = getattr(mask_act, "_rg_sign_bits", None) if mask_act is not None else None
+        if bits is not None and self.lib.rg_conv_up_maskbits_supported(N, Ho, Wo, O, I, self.dt, self.algo):
+            self._timed("conv_fwd_dgrad", 2.0 * N * Ho * Wo * O * I * 16, lambda: check(
+                self.lib.rg_conv_up_maskbits(_ptr(x), _ptr(wup), _ptr(y), N, Ho, Wo, O, I, _ptr(bits), float(slope), self.dt,
+                                             self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_up_maskbits"))
+            return (y, None) if want_stats else y
         self._timed("conv_fwd_dgrad", 2.0 * N * Ho * Wo * O * I * 16, lambda: check(
             self.lib.rg_conv_up(_ptr(x), _ptr(cw.w), _ptr(wup), _ptr(y), N, Ho, Wo, O, I, _ptr(mask_act), float(slope),
                                 _ptr(st), self.dt, self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_up"))
@@ -367,9 +373,26 @@ class HipOps:
         O = cw.w.shape[0]
         assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and cw.w.shape[1] == I
         y = self._act(N, H // 2, W // 2, O)
+        # Discriminator layer 0 (slope != 1): the kernel also writes the packed sign bits of its output, one uint64 per
+        # pixel, when the data-gradient conv of layer 1 can take its fused LeakyReLU mask in that form (conv_up below
+        # picks them up from the tensor: 8 B instead of 128 B per pixel, and the patch-resident kernel).
+        if (self.dt == RG_BF16 and O == 64 and slope != 1.0 and H % 4 == 0 and W % 4 == 0 and
+                self.lib.rg_conv_up_maskbits_supported(N, H // 4, W // 4, 128, 64, self.dt, self.algo)):
+            bits = torch.empty((N, H // 2, W // 2), dtype=torch.int64, device=self.device)
+            check(self.lib.rg_first_down_bits(_ptr(x_nchw), _ptr(cw.w), _ptr(bias), _ptr(y), _ptr(bits), N, H, W, I, O,
+                                              float(slope), self.dt, self.stream), "rg_first_down_bits")
+            y._rg_sign_bits = bits
+            return y
         check(self.lib.rg_first_down(_ptr(x_nchw), _ptr(cw.w), _ptr(bias), _ptr(y), N, H, W, I, O, float(slope),
                                      self.dt, self.stream), "rg_first_down")
         return y
+
+    def sign_pack(self, a):
+        """Packed sign bits (uint64 per pixel, bit c = a[pixel][c] > 0) of a bf16 activation [..., 64]."""
+        assert a.dtype == torch.bfloat16 and a.shape[-1] == 64 and a.is_contiguous()
+        bits = torch.empty(a.shape[:-1], dtype=torch.int64, device=a.device)
+        check(self.lib.rg_sign_pack(_ptr(a), _ptr(bits), a.numel() // 64, 64, self.dt, self.stream), "rg_sign_pack")
+        return bits
 
     def last_up(self, x, cw: ConvW, bias, tanh: bool):
         N, Ho, Wo, O = x.shape

@@ -163,6 +163,85 @@ def test_conv8_pingpong_kernel(N, Hi, Wi, I, O, mode, mfma):
             lib.rg_set_option(k, -1)
 
 
+@pytest.mark.parametrize("blocks", [256, 3])
+@pytest.mark.parametrize("N,Ws", [(1, 16), (3, 16), (2, 32), (1, 64), (5, 64)])
+def test_convp_patch_resident_kernel(N, Ws, blocks):
+    """The 128 -> 64 channel transposed conv with the input patch resident in LDS (rg_convp.hip), all three image widths,
+    one and several tiles per workgroup (blocks = 3: persistent loop with the cross-tile prefetch): plain, BatchNorm partial
+    sums, fused LeakyReLU mask from PACKED sign bits (rg_sign_pack), folded affine -- against the torch twin, and
+    bit-identical to the implicit-GEMM kernel it replaces."""
+    from rna_gan_amd import _abi
+    lib = _abi.load()
+    dtype = torch.bfloat16
+    ref, hip = RefOps(dtype), _hip(dtype)
+    O, I = 128, 64
+    assert lib.rg_conv_up_maskbits_supported(N, Ws, Ws, O, I, _abi.RG_BF16, 0) == 1
+    w = rnd((O, I, 4, 4), 1, (2.0 / (O * 4)) ** 0.5)
+    cr, ch = cwpair_tm(w)
+    g = rnd((N, Ws, Ws, O), 3).to(dtype)
+    m = rnd((N, 2 * Ws, 2 * Ws, I), 21).to(dtype)
+    m[0, 0, :4, :8] = 0.0                                   # +0 / -0 count as "not positive"
+    m[0, 1, :4, :8] = -0.0
+    try:
+        _abi.check(lib.rg_set_option(b"convp_blocks", blocks), "rg_set_option")
+        outs = {}
+        for on in (1, 0):
+            _abi.check(lib.rg_set_option(b"convp", on), "rg_set_option")
+            u, su = hip.conv_up(dev(g), ch, want_stats=True)
+            md = dev(m)
+            if on:
+                md._rg_sign_bits = hip.sign_pack(md)
+            um = hip.conv_up(dev(g), ch, md, 0.2)
+            outs[on] = (u, su, um)
+        u, su, um = outs[1]
+        check(u, ref.conv_up(g, cr), TOL[dtype], "conv_up")
+        check(um, ref.conv_up(g, cr, m, 0.2), TOL[dtype], "conv_up(packed mask)")
+        assert torch.equal(u, outs[0][0]) and torch.equal(um, outs[0][2])
+        assert su is not None and su.shape[0] == 4 * (N * Ws * Ws // 256) * 2
+        uf = u.float().reshape(-1, I)
+        check(su[:, 0, :].sum(0), uf.sum(0), 1e-4, "epilogue sum")
+        check(su[:, 1, :].sum(0), (uf * uf).sum(0), 1e-4, "epilogue sumsq")
+        # sign bits: bit c of word p = activation[p][c] > 0
+        bits = hip.sign_pack(dev(m)).cpu().reshape(-1)
+        mm = (m.float().reshape(-1, 64) > 0)
+        expect = torch.zeros(mm.shape[0], dtype=torch.int64)
+        for c in range(64):
+            expect |= mm[:, c].to(torch.int64) << c
+        assert torch.equal(bits, expect)
+        # folded affine epilogue (generator-only inference)
+        sc, sh = rnd((I,), 31).abs() + 0.5, rnd((I,), 32)
+        ua = hip.conv_up_affine(dev(g), ch, dev(sc), dev(sh), 0.2)
+        _abi.check(lib.rg_set_option(b"convp", 0), "rg_set_option")
+        ub = hip.conv_up_affine(dev(g), ch, dev(sc), dev(sh), 0.2)
+        assert torch.equal(ua, ub)
+    finally:
+        for k in (b"convp", b"convp_blocks"):
+            lib.rg_set_option(k, -1)
+
+
+def test_first_down_sign_bits():
+    """first_down writes the packed sign bits of its output itself (discriminator layer 0); they equal rg_sign_pack of the
+    stored activation, and the data-gradient conv of layer 1 picks them up from the tensor."""
+    dtype = torch.bfloat16
+    ref, hip = RefOps(dtype), _hip(dtype)
+    for N, H in ((2, 64), (1, 128), (1, 256)):
+        x = rnd((N, 3, H, H), 5)
+        w = rnd((64, 3, 4, 4), 6, 0.2)
+        b = rnd((64,), 7, 0.1)
+        cr, ch = cwpair(w)
+        a = hip.first_down(dev(x), ch, dev(b), 0.2)
+        bits = getattr(a, "_rg_sign_bits", None)
+        assert bits is not None and bits.shape == (N, H // 2, H // 2)
+        assert torch.equal(bits, hip.sign_pack(a))
+        check(a, ref.first_down(x, cr, b, 0.2), TOL[dtype], "first_down")
+        a1 = hip.first_down(dev(x), ch, dev(b), 1.0)                    # slope 1: no consumer for the bits
+        assert getattr(a1, "_rg_sign_bits", None) is None
+        w1 = rnd((128, 64, 4, 4), 8, (2.0 / 512) ** 0.5)
+        c1r, c1h = cwpair_tm(w1)
+        gz = rnd((N, H // 4, H // 4, 128), 9).to(dtype)
+        check(hip.conv_up(dev(gz), c1h, a, 0.2), ref.conv_up(gz, c1r, a.cpu(), 0.2), TOL[dtype], "conv_up(mask from first_down)")
+
+
 @pytest.mark.parametrize("blocks", [1, 8, 256])
 @pytest.mark.parametrize("N,Hi,Wi,I,O", [(2, 32, 32, 64, 256),      # 8 k-tiles of 64 pixels, 1 x 4 output tiles
                                          (3, 16, 16, 128, 256),     # 192 pixels per segment: ragged last k-tile
