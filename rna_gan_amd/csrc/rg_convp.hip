@@ -47,8 +47,11 @@ constexpr int CP_OFF_BITS = CP_OFF_AFF + 512;          // 8 x 1 KB packed LeakyR
 constexpr int CP_OFF_DUMMY = CP_OFF_BITS + 8192;       // 1 KB target of the dead (all-out-of-range) DMAs
 constexpr int CP_LDS = CP_OFF_DUMMY + 1024;            // 159232 B
 
-template <int LGW>
+// EPI: 0 plain, 1 BatchNorm partial sums, 2 packed LeakyReLU mask, 3 folded BatchNorm affine + LeakyReLU (compile-time: the
+// epilogue walks 32 accumulator tiles, run-time flags would be tested in every one of them)
+template <int LGW, int EPI>
 __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
+  constexpr bool HAS_STATS = EPI == 1, HAS_MASK = EPI == 2, HAS_AFFINE = EPI == 3;
   constexpr int Ws = 1 << LGW, Wp = Ws + 1;
   constexpr int R = 256 >> LGW;                            // image rows per tile
   constexpr int PATCH_PX = (R + 2) * Wp + 1;
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
   // registers live there is no room for those, and a spilled one costs an s_waitcnt vmcnt(0) (scratch reload) that drains the
   // DMA queue.  Used for everything outside the 16 steps' own few persistent values.
   auto opq = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
-  if (g.affine && t < 128)                                // (before any DMA is in flight; published by the prologue's barrier)
+  if (HAS_AFFINE && t < 128)                                // (before any DMA is in flight; published by the prologue's barrier)
     reinterpret_cast<float*>(ldsb + CP_OFF_AFF)[t] = t < 64 ? g.scale[t] : g.shift[t - 64];
 
   // ---- tap tables of this wave's class (wave-uniform scalars): patch row shift and B tap offset (bytes) of tap (a, b)
@@ -190,6 +193,17 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
         asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[(RT0) + i_][j_]) : "v"(bS[SET][j_]), "v"(AS[i_])); \
     __builtin_amdgcn_s_setprio(0);                                                                \
   } while (0)
+// wait states tied to every accumulator: hazards between the asm MFMAs and the VALU instructions around them (the clearing
+// v_movs before a tile's first MFMAs, the epilogue's reads after its last ones) are invisible to the compiler
+#define CP_ACC_FENCE()                                                                                       \
+  do {                                                                                                       \
+    _Pragma("unroll") for (int rt_ = 0; rt_ < 8; rt_ += 4)                                                   \
+      asm volatile("s_nop 15\n\ts_nop 15"                                                                    \
+                   : "+v"(acc[rt_][0]), "+v"(acc[rt_][1]), "+v"(acc[rt_][2]), "+v"(acc[rt_][3]), "+v"(acc[rt_ + 1][0]),      \
+                     "+v"(acc[rt_ + 1][1]), "+v"(acc[rt_ + 1][2]), "+v"(acc[rt_ + 1][3]), "+v"(acc[rt_ + 2][0]),              \
+                     "+v"(acc[rt_ + 2][1]), "+v"(acc[rt_ + 2][2]), "+v"(acc[rt_ + 2][3]), "+v"(acc[rt_ + 3][0]),              \
+                     "+v"(acc[rt_ + 3][1]), "+v"(acc[rt_ + 3][2]), "+v"(acc[rt_ + 3][3]));                                    \
+  } while (0)
 #define CP_SYNC() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 
   // ---- epilogue.  The MFMAs compute the TRANSPOSED tile (weights as the A operand, pixels as the B operand): accumulator
@@ -228,14 +242,14 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
   };
 
   auto epilogue = [&](int T) {
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // MFMA write -> VALU read of the accumulators (see CP_MFMAS)
+    CP_ACC_FENCE();                                       // MFMA write -> VALU read
     const int m_w = (T << 8) + half * 128;                // first pixel of this wave
     const int ln = opq();
     const int px = ln & 15, fq = ln >> 4;                 // the lane's pixel of a row tile; its channels are 16 fq + 4 j + r
     const unsigned e_off = (unsigned)(px * 256 + fq * 32);
     const unsigned bits_r = lds_base + CP_OFF_BITS + wave * 1024 + (unsigned)(px * 8);
     u32x4_t asc[4], ash[4];                               // scale / shift of channels 16 fq + 4 j .. + 3 (LDS table, asm reads)
-    if (g.affine) {
+    if constexpr (HAS_AFFINE) {
       const unsigned aff_r = lds_base + CP_OFF_AFF + (unsigned)(fq * 64);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
 #pragma unroll
     for (int rt = 0; rt < 8; ++rt) {
       unsigned b16 = 0;
-      if (g.mask) {
+      if constexpr (HAS_MASK) {
         u32x2_t w;
         asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(w) : "v"(bits_r), "n"(rt * 128) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w)::"memory");
@@ -263,13 +277,13 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         f32x4_t v = acc[rt][j];
-        if (g.mask) {
+        if constexpr (HAS_MASK) {
           const float sl = g.mslope;
           const unsigned b4 = b16 >> (4 * j);
           v[0] *= (b4 & 1u) ? 1.f : sl; v[1] *= (b4 & 2u) ? 1.f : sl;
           v[2] *= (b4 & 4u) ? 1.f : sl; v[3] *= (b4 & 8u) ? 1.f : sl;
         }
-        if (g.affine) {
+        if constexpr (HAS_AFFINE) {
           const float4 sc = __builtin_bit_cast(float4, asc[j]), sh = __builtin_bit_cast(float4, ash[j]);
           v[0] = lrelu_f(v[0] * sc.x + sh.x, g.slope); v[1] = lrelu_f(v[1] * sc.y + sh.y, g.slope);
           v[2] = lrelu_f(v[2] * sc.z + sh.z, g.slope); v[3] = lrelu_f(v[3] * sc.w + sh.w, g.slope);
@@ -278,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
         const uint32_t d0 = h0 | (h1 << 16), d1 = h2 | (h3 << 16);
         o[j >> 1][(j & 1) * 2] = d0;
         o[j >> 1][(j & 1) * 2 + 1] = d1;
-        if (g.stats) {
+        if constexpr (HAS_STATS) {
           const f32x2_t r01 = {__builtin_bit_cast(float, d0 << 16), __builtin_bit_cast(float, d0 & 0xffff0000u)};
           const f32x2_t r23 = {__builtin_bit_cast(float, d1 << 16), __builtin_bit_cast(float, d1 & 0xffff0000u)};
           s1[j][0] += r01; s2[j][0] += r01 * r01;
@@ -289,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
       asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(e_off), "v"(o[0]), "s"(cb) : "memory");
       asm volatile("global_store_dwordx4 %0, %1, %2 offset:16" ::"v"(e_off), "v"(o[1]), "s"(cb) : "memory");
     }
-    if (g.stats) {
+    if constexpr (HAS_STATS) {
       const size_t grow = ((size_t)cls * tiles + T) * 2 + half;
       const char* sb = reinterpret_cast<const char*>(g.stats + grow * 128);       // wave-uniform row [2][64]
       const unsigned so = (unsigned)(fq * 64);
@@ -311,6 +325,7 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[rt][j][r] = 0.f;
+    CP_ACC_FENCE();                                       // VALU write -> MFMA read
   };
 
   // ---- prologue: X half of the first tile, B steps 0-2, then the fragments of step 0 and its sub-block 0
@@ -328,6 +343,7 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[rt][j][r] = 0.f;
+  CP_ACC_FENCE();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   CP_SYNC();
   {
@@ -366,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
         __builtin_amdgcn_sched_barrier(0);                 // (one address computation at a time: register pressure)
       }
       if constexpr (s == 8)
-        if (g.mask) load_maskbits(T);
+        if constexpr (HAS_MASK) load_maskbits(T);
     }
   };
   // Counted wait at the end of interval s.  Operations of interval s in issue order: B (2), patch (2 in steps 0-3 / 8-11),
@@ -377,9 +393,9 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
     constexpr int np_s = (s & 4) == 0 ? 2 : 0, np_p = (sp & 4) == 0 ? 2 : 0;
     constexpr int base = np_p + 2 + np_s;
     if constexpr (s == 8 || s == 9) {
-      if (g.mask) __builtin_amdgcn_s_waitcnt(vmcnt_imm(base + 4)); else __builtin_amdgcn_s_waitcnt(vmcnt_imm(base));
+      __builtin_amdgcn_s_waitcnt(vmcnt_imm(base + (HAS_MASK ? 4 : 0)));
     } else if constexpr (s == 15 || s == 0) {
-      if (g.stats) __builtin_amdgcn_s_waitcnt(vmcnt_imm(base + 24)); else __builtin_amdgcn_s_waitcnt(vmcnt_imm(base + 16));
+      __builtin_amdgcn_s_waitcnt(vmcnt_imm(base + (HAS_STATS ? 24 : 16)));
     } else {
       __builtin_amdgcn_s_waitcnt(vmcnt_imm(base));
     }
@@ -435,6 +451,7 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
 #undef CP_LAST
 #undef CP_INTERVAL
 #undef CP_SYNC
+#undef CP_ACC_FENCE
 #undef CP_MFMAS
 #undef CP_WAIT4
 #undef CP_READ_B
@@ -459,8 +476,17 @@ int rg_convp_launch(const void* args, hipStream_t st) {
   int grid = tiles < target ? tiles : target;
   const int per = (tiles + grid - 1) / grid;             // equal tile counts per workgroup where the tile count allows it
   grid = (tiles + per - 1) / per;
-  if (a2.g.Ws == 64) hipLaunchKernelGGL(convp_kernel<6>, dim3((unsigned)grid), dim3(512), 0, st, a2);
-  else if (a2.g.Ws == 32) hipLaunchKernelGGL(convp_kernel<5>, dim3((unsigned)grid), dim3(512), 0, st, a2);
-  else hipLaunchKernelGGL(convp_kernel<4>, dim3((unsigned)grid), dim3(512), 0, st, a2);
+  const int epi = a2.g.mask ? 2 : a2.g.affine ? 3 : a2.g.stats ? 1 : 0;
+#define CP_GO(LGW_)                                                                                            \
+  do {                                                                                                         \
+    if (epi == 0) hipLaunchKernelGGL((convp_kernel<LGW_, 0>), dim3((unsigned)grid), dim3(512), 0, st, a2);      \
+    else if (epi == 1) hipLaunchKernelGGL((convp_kernel<LGW_, 1>), dim3((unsigned)grid), dim3(512), 0, st, a2); \
+    else if (epi == 2) hipLaunchKernelGGL((convp_kernel<LGW_, 2>), dim3((unsigned)grid), dim3(512), 0, st, a2); \
+    else hipLaunchKernelGGL((convp_kernel<LGW_, 3>), dim3((unsigned)grid), dim3(512), 0, st, a2);               \
+  } while (0)
+  if (a2.g.Ws == 64) CP_GO(6);
+  else if (a2.g.Ws == 32) CP_GO(5);
+  else CP_GO(4);
+#undef CP_GO
   return RG_OK;
 }
