@@ -190,8 +190,10 @@ def hip_workload(args, rank, world, device):
     for mod in (G, Dm):
         for t in list(mod.parameters()) + list(mod.buffers()):
             D_.broadcast_(t.data, 0)
-    real = R.synthetic_images(N, 256, seed=1234 + rank).to(device)
-    rna = R.synthetic_rna(N, rna_features, seed=4321 + rank, distinct=16).to(device)
+    from rna_gan_amd import graphed
+    # the two resident input tensors are persistent buffers: the step graphs read them in place (no per-call copy)
+    real = graphed.mark_static(R.synthetic_images(N, 256, seed=1234 + rank).to(device))
+    rna = graphed.mark_static(R.synthetic_rna(N, rna_features, seed=4321 + rank, distinct=16).to(device))
     gen = torch.Generator(device="cpu").manual_seed(args.seed + rank)
     ops, _ = G.runtime()
 

@@ -27,6 +27,13 @@ def _pool():
     return _POOL
 
 
+def mark_static(t):
+    """Declare ``t`` a persistent input buffer: the caller passes this same tensor object to every call of a train_op and
+    updates its contents in place.  Step graphs then read it directly instead of copying it into a buffer of their own."""
+    t._rg_static = True
+    return t
+
+
 class StepGraph:
     """fn(*static_inputs) -> 1-element loss tensor, replayed from a captured graph.
 
@@ -38,7 +45,9 @@ class StepGraph:
 
     def __init__(self, fn, example_inputs, modules, optimizers, stepped=()):
         self.fn = fn
-        self.static_in = [t.detach().clone() for t in example_inputs]
+        # An input tensor marked ``t._rg_static = True`` is a buffer the caller reuses for every call (contents updated in
+        # place, e.g. the trainer's normalised image batch): it is captured as is and never copied (mark_static()).
+        self.static_in = [t if getattr(t, "_rg_static", False) else t.detach().clone() for t in example_inputs]
         self.modules = modules
         self.optimizers = optimizers
         self.stepped = list(stepped)
@@ -53,10 +62,14 @@ class StepGraph:
     def __call__(self, *inputs, allow_capture=True):
         """allow_capture=False: run eagerly this time and do not capture yet (the function reads tensors whose
         addresses are not stable yet, e.g. the outputs of another StepGraph that is still in its eager phase)."""
-        for s, t in zip(self.static_in, inputs):
+        for i, (s, t) in enumerate(zip(self.static_in, inputs)):
             if s.shape != t.shape:
                 raise RuntimeError("StepGraph: input shape changed")
-            s.copy_(t, non_blocking=True)
+            if s is not t:
+                if self.graph is None and getattr(t, "_rg_static", False) and t.dtype == s.dtype:
+                    self.static_in[i] = t          # became a persistent buffer meanwhile (another graph's output): adopt it
+                else:
+                    s.copy_(t, non_blocking=True)
         self.calls += 1
         if self.failed or self.calls <= WARMUP_CALLS or (self.graph is None and not allow_capture):
             return self._run()
@@ -79,6 +92,8 @@ class StepGraph:
                 torch.cuda.synchronize()
                 return self._run()
         self.graph.replay()
+        if torch.is_tensor(self.static_out):
+            self.static_out._rg_static = True      # a captured graph's output IS a persistent buffer (see mark_static)
         for o in self.optimizers:
             o.note_replayed()
         for m in self.modules:
