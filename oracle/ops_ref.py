@@ -119,7 +119,13 @@ class RefOps:
         else:
             cw.dw.copy_(d)
 
-    def first_down(self, x_nchw, cw: ConvW, bias, slope: float):
+    def sign_bits_for(self, N, H, W):
+        return None
+
+    def first_down(self, x_nchw, cw: ConvW, bias, slope: float, out=None):
+        if out is not None:
+            out[0].copy_(self.first_down(x_nchw, cw, bias, slope))
+            return out[0]
         # bf16 path: the image-side layers run on the matrix cores too, so image and weights are rounded to
         # bf16 operands (fp32 accumulation); the fp32 path uses the masters as they are
         xin = x_nchw.to(self.f) if self.act_dtype != torch.bfloat16 else x_nchw.to(torch.bfloat16).to(self.f)
@@ -191,7 +197,11 @@ class RefOps:
         return t
 
     def bn_forward(self, z, gamma, beta, slope: float, eps: float, momentum: float, running_mean=None,
-                   running_var=None, nbt=None, partials=None):
+                   running_var=None, nbt=None, partials=None, out=None):
+        if out is not None:
+            a, mean, invstd = self.bn_forward(z, gamma, beta, slope, eps, momentum, running_mean, running_var, nbt, partials)
+            out.copy_(a)
+            return out, mean, invstd
         if self.stat_reduce is not None:
             s, ss = self.bn_stats(z)
             self._red(s, ss)
@@ -222,8 +232,12 @@ class RefOps:
         return F.leaky_relu(y, slope).to(self.act_dtype)
 
     def bn_act_bwd(self, z, ga, mean, invstd, gamma, beta, slope: float,
-                   dgamma=None, dbeta=None, accumulate: bool = False):
+                   dgamma=None, dbeta=None, accumulate: bool = False, out=None):
         """Backward of a = lrelu(bn(z)).  Returns (gz, s_gy, s_gyxh) with gy = ga * lrelu'(y)."""
+        if out is not None:
+            gz, s_gy, s_gyxh = self.bn_act_bwd(z, ga, mean, invstd, gamma, beta, slope, dgamma, dbeta, accumulate)
+            out.copy_(gz)
+            return out, s_gy, s_gyxh
         xh = (z.to(self.f) - mean) * invstd
         y = xh * gamma + beta
         gy = ga.to(self.f) * _lrelu_mask(y, slope)

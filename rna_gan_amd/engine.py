@@ -468,6 +468,73 @@ def disc_loss_rest(ops, G, D: DiscNet, pre, noise, grad_scale: float = 1.0):
     return loss
 
 
+def _half_partials(st, m_half: int, m_total: int, h: int):
+    """Rows of the conv-epilogue statistics [rows][2][C] that belong to batch half h, or None when a partial row straddles
+    the halves (then the BatchNorm pass reduces its half itself)."""
+    if st is None:
+        return None
+    rows = st.shape[0]
+    if rows % 2 or m_total % rows or m_half % (m_total // rows):
+        return None
+    return st[h * (rows // 2):(h + 1) * (rows // 2)]
+
+
+def disc_loss_grads_batched(ops, G, D: DiscNet, real, noise, grad_scale: float = 1.0):
+    """The D-loss step with D(real) and D(fake) as ONE double batch through the conv layers (forward, data gradient and
+    weight gradient: one launch each per layer instead of two, at a size where the 256 x 256-tile kernels need no split-K),
+    BatchNorm per half exactly as two separate forward calls would do it (own batch statistics, running statistics updated
+    by the real half first -- the reference's call order D(real), G(z), D(fake) of src/wgan_loss.py:241-253 -- own
+    backward reductions, parameter gradients summed).  Same result as disc_loss_grads up to the kernels' tile shapes."""
+    n = real.shape[0]
+    R = len(D.blocks)
+    img, _ = _gen_fwd(ops, G, noise, keep=False)
+    xs = (real, img)
+    H, W = real.shape[2], real.shape[3]
+    C0 = D.conv0.w.shape[0]
+    a = torch.empty((2 * n, H // 2, W // 2, C0), dtype=ops.act_dtype, device=real.device)
+    bits = ops.sign_bits_for(2 * n, H // 2, W // 2) if R > 0 else None
+    for h in range(2):
+        ops.first_down(xs[h], D.conv0, D.conv0.bias, D.slope,
+                       out=(a[h * n:(h + 1) * n], None if bits is None else bits[h * n:(h + 1) * n]))
+    if bits is not None:
+        a._rg_sign_bits = bits
+    acts, zs, means, invstds = [a], [None], [None], [None]
+    for cw, bn in D.blocks:
+        z, st = ops.conv_down(a, cw, want_stats=True)
+        m_half = z.numel() // z.shape[-1] // 2
+        a = torch.empty_like(z)
+        mean, invstd = [], []
+        for h in range(2):
+            _, mu, iv = ops.bn_forward(z[h * n:(h + 1) * n], bn.gamma, bn.beta, D.slope, bn.eps, bn.momentum, bn.running_mean,
+                                       bn.running_var, bn.nbt, partials=_half_partials(st, m_half, 2 * m_half, h),
+                                       out=a[h * n:(h + 1) * n])
+            mean.append(mu); invstd.append(iv)
+        zs.append(z); means.append(mean); invstds.append(invstd); acts.append(a)
+    hh, out = ops.head_fwd(a, D.head, D.last_slope)
+    loss = ops.mean_diff(out[n:], out[:n], 1.0)
+    # backward: coefficient -1/n on the real half, +1/n on the fake half
+    gh = torch.cat([ops.head_grad(hh[:n], -grad_scale / n, D.last_slope), ops.head_grad(hh[n:], grad_scale / n, D.last_slope)])
+    with ops.side(gh):
+        ops.head_wgrad(gh, acts[R], D.head.dw, False)
+    ga = ops.head_bwd_data(gh, D.head)
+    for l in range(R, 0, -1):
+        cw, bn = D.blocks[l - 1]
+        gz = torch.empty_like(zs[l])
+        for h in range(2):
+            ops.bn_act_bwd(zs[l][h * n:(h + 1) * n], ga[h * n:(h + 1) * n], means[l][h], invstds[l][h], bn.gamma, bn.beta,
+                           D.slope, bn.dgamma, bn.dbeta, h == 1, out=gz[h * n:(h + 1) * n])
+        with ops.side(gz):
+            ops.conv_wgrad(gz, acts[l - 1], cw, False)
+        ga = ops.conv_up(gz, cw) if l > 1 else ops.conv_up(gz, cw, acts[0], D.slope)
+    gz0 = ga if R > 0 else ops.lrelu_bwd(ga, acts[0], D.slope)
+    with ops.side(gz0):
+        ops.skinny_wgrad(gz0[:n], xs[0], D.conv0.dw, False)
+        ops.skinny_wgrad(gz0[n:], xs[1], D.conv0.dw, True)
+    ops.col_sum(gz0, D.conv0.dbias, False)
+    ops.join()
+    return loss
+
+
 def disc_loss_grads(ops, G: GenNet, D: DiscNet, real, noise, grad_scale: float = 1.0):
     """src/wgan_loss.py:241-260: loss = mean(D(G(z).detach()) - D(real)); fills D's gradients.
     Forward order D(real), G(z), D(fake) as in the reference (BN running statistics)."""

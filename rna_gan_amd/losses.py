@@ -185,6 +185,16 @@ def _d_prefix(generator, discriminator, real, noise, clip):
     return E.disc_loss_prefix(ops, dn, real.contiguous().float()), noise.contiguous().float()
 
 
+def _d_batched(generator, discriminator, real, noise, clip):
+    """single process: D(real) and D(fake) as one double batch through the conv layers (engine.disc_loss_grads_batched)"""
+    ops, gn, dn = _nets(generator, discriminator)
+    if clip is not None:
+        ops.clamp_(discriminator.flat.data, clip[0], clip[1])
+        discriminator.weights_changed()
+    return E.disc_loss_grads_batched(ops, gn, dn, real.contiguous().float(), noise.contiguous().float(),
+                                     grad_scale=D_.grad_scale())
+
+
 def _d_rest(generator, discriminator, pre):
     ops, gn, dn = _nets(generator, discriminator)
     fwd_real, noise = pre
@@ -223,12 +233,15 @@ def _gp_step(generator, discriminator, optimizer_discriminator, real, noise, eps
 
 
 class _Body:
-    """One train_op: prefix(*inputs) -> pre ; rest(pre) -> loss ; which network the prefix reads."""
+    """One train_op: prefix(*inputs) -> pre ; rest(pre) -> loss ; which network the prefix reads.  whole (optional): the
+    single-process form of the same train_op when it is not simply rest(prefix(...))."""
 
-    def __init__(self, prefix, rest, prefix_reads):
-        self.prefix, self.rest, self.prefix_reads = prefix, rest, prefix_reads
+    def __init__(self, prefix, rest, prefix_reads, whole=None):
+        self.prefix, self.rest, self.prefix_reads, self.whole = prefix, rest, prefix_reads, whole
 
     def grads(self, *inputs):
+        if self.whole is not None and not D_.active():
+            return self.whole(*inputs)
         return self.rest(self.prefix(*inputs))
 
 
@@ -240,8 +253,9 @@ def _g_body(generator, discriminator, noise_fn=None):
 
 def _d_body(generator, discriminator, clip, noise_fn=None):
     nf = noise_fn or (lambda nz: nz)
+    whole = (lambda real, *a: _d_batched(generator, discriminator, real, nf(*a), clip)) if D_BATCHED else None
     return _Body(lambda real, *a: _d_prefix(generator, discriminator, real, nf(*a), clip),
-                 lambda pre: _d_rest(generator, discriminator, pre), discriminator)
+                 lambda pre: _d_rest(generator, discriminator, pre), discriminator, whole)
 
 
 def _gp_body(generator, discriminator, lambd, noise_fn=None):
@@ -262,6 +276,9 @@ def _dispatch(runner, key, body, inputs, generator, discriminator, stepped, opti
         return loss
     return runner.run(key, full, inputs, mods, [optimizer])
 
+
+# D-loss step of a single process: D(real) and D(fake) as one double batch (RNAGAN_D_BATCHED=0: two forward / backward chains)
+D_BATCHED = os.environ.get("RNAGAN_D_BATCHED", "1") != "0"
 
 # data-parallel runs: the gradient all-reduce + optimizer step of the last train_op, not yet applied
 _PENDING = [None]

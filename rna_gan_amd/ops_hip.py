@@ -368,10 +368,22 @@ class HipOps:
         check(self.lib.rg_upconv3_wgrad(_ptr(gy), int(gy_nchw), _ptr(x), _ptr(cw.dw), N, H, W, Cin, Cout, self.dt,
                                         self.algo, int(accumulate), _ptr(ws), ws.numel(), self.stream), "rg_upconv3_wgrad")
 
-    def first_down(self, x_nchw, cw: ConvW, bias, slope: float):
+    def first_down(self, x_nchw, cw: ConvW, bias, slope: float, out=None):
+        """out: (activation view, sign-bit view or None) to write into -- a batch slice of a larger tensor (the D step runs
+        D(real) and D(fake) as one double batch from layer 1 on); the sign bits then stay with the caller."""
         N, I, H, W = x_nchw.shape
         O = cw.w.shape[0]
         assert x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and cw.w.shape[1] == I
+        if out is not None:
+            y, bits = out
+            assert y.shape == (N, H // 2, W // 2, O) and y.is_contiguous() and y.dtype == self.act_dtype
+            if bits is not None:
+                check(self.lib.rg_first_down_bits(_ptr(x_nchw), _ptr(cw.w), _ptr(bias), _ptr(y), _ptr(bits), N, H, W, I, O,
+                                                  float(slope), self.dt, self.stream), "rg_first_down_bits")
+            else:
+                check(self.lib.rg_first_down(_ptr(x_nchw), _ptr(cw.w), _ptr(bias), _ptr(y), N, H, W, I, O, float(slope),
+                                             self.dt, self.stream), "rg_first_down")
+            return y
         y = self._act(N, H // 2, W // 2, O)
         # Discriminator layer 0 (slope != 1): the kernel also writes the packed sign bits of its output, one uint64 per
         # pixel, when the data-gradient conv of layer 1 can take its fused LeakyReLU mask in that form (conv_up below
@@ -519,8 +531,16 @@ class HipOps:
                                             ws.numel(), self.stream), "rg_bn_stats_finalize")
         return mean, invstd
 
+    def sign_bits_for(self, N, H, W):
+        """An (uninitialised) packed sign-bit tensor for a [N, H, W, 64] activation when the data-gradient conv above it
+        takes its LeakyReLU mask in that form (see first_down), else None."""
+        if (self.dt == RG_BF16 and H % 2 == 0 and W % 2 == 0 and
+                self.lib.rg_conv_up_maskbits_supported(N, H // 2, W // 2, 128, 64, self.dt, self.algo)):
+            return torch.empty((N, H, W), dtype=torch.int64, device=self.device)
+        return None
+
     def bn_forward(self, z, gamma, beta, slope: float, eps: float, momentum: float, running_mean=None,
-                   running_var=None, nbt=None, partials=None):
+                   running_var=None, nbt=None, partials=None, out=None):
         """Train-mode BatchNorm + LeakyReLU: (a, mean, invstd).  partials: the column sums the producing conv's
         epilogue wrote (conv_down/conv_up want_stats) -- then no statistics pass over z is needed."""
         M, C = self._mc(z)
@@ -528,9 +548,14 @@ class HipOps:
             s, ss = self.bn_stats(z)
             self.stat_reduce(s); self.stat_reduce(ss)
             mean, invstd = self.bn_finalize(s, ss, M * self.stat_world, eps, momentum, running_mean, running_var, nbt)
-            return self.bn_act(z, mean, invstd, gamma, beta, slope), mean, invstd
+            a = self.bn_act(z, mean, invstd, gamma, beta, slope)
+            if out is not None:
+                out.copy_(a)
+                a = out
+            return a, mean, invstd
         mean, invstd = self._f32(C), self._f32(C)
-        a = torch.empty_like(z)
+        a = out if out is not None else torch.empty_like(z)
+        assert a.shape == z.shape and a.is_contiguous()
         if partials is not None:
             ws = self._ws(32 * 2 * C * 4)
             check(self.lib.rg_bn_forward_partials(_ptr(partials), partials.shape[0], _ptr(z), M, C, float(eps),
@@ -553,9 +578,10 @@ class HipOps:
         return a
 
     def bn_act_bwd(self, z, ga, mean, invstd, gamma, beta, slope: float, dgamma=None, dbeta=None,
-                   accumulate: bool = False):
+                   accumulate: bool = False, out=None):
         M, C = self._mc(z)
-        gz = torch.empty_like(z)
+        gz = out if out is not None else torch.empty_like(z)
+        assert gz.shape == z.shape and gz.is_contiguous()
         s_gy, s_gyxh = self._f32(C), self._f32(C)
         ws = self._ws(self.lib.rg_colreduce_workspace_bytes(M, C, 2))
         if self.stat_reduce is not None:

@@ -154,3 +154,28 @@ def test_penalty_parts_input_gradients_and_eval_discriminator():
         want = D(x.detach())
     got = E.disc_forward_eval(ops, Dn, x.detach().clone())
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("in_size,step,enc,n", [(16, 4, 24, 5), (32, 4, 16, 4)])
+def test_batched_d_step_matches_autograd(in_size, step, enc, n):
+    """engine.disc_loss_grads_batched (D(real) and D(fake) as one double batch through the conv layers, BatchNorm per half)
+    against the autograd oracle: loss, every parameter gradient, and the running statistics (updated by the real half
+    first, as the reference's call order does)."""
+    torch.manual_seed(0)
+    G, D = mk(in_size, step, enc)
+    G2, D2 = copy.deepcopy(G), copy.deepcopy(D)
+    for m in (G, D, G2, D2):
+        m.train()
+    real = R.synthetic_images(n, in_size, seed=3).double()
+    noise = R.synthetic_normal(n, enc, seed=4).double()
+    ops = RefOps(torch.float64)
+    Gn, Dn = E.build_gen_net(G2), E.build_disc_net(D2)
+    for p in D.parameters():
+        p.grad = None
+    loss_o = R.discriminator_loss(D(real), D(G(noise).detach()))
+    loss_o.backward()
+    loss_e = E.disc_loss_grads_batched(ops, Gn, Dn, real, noise)
+    np.testing.assert_allclose(float(loss_e), float(loss_o), rtol=1e-9)
+    assert_close_dict(grads_of(D2), grads_of(D), 1e-7, 1e-10)
+    assert_close_dict(bufs_of(D2), bufs_of(D), 1e-9, 1e-12)
+    assert_close_dict(bufs_of(G2), bufs_of(G), 1e-9, 1e-12)

@@ -213,3 +213,42 @@ def test_resize_convolution_image_block_full_size():
     mf.upconv3_wgrad(g_img, x, cm, False, gy_nchw=True)
     ge.upconv3_wgrad(g_img, x, cg, False, gy_nchw=True)
     assert relmax(cm.dw, cg.dw) < 4e-3
+
+
+@pytest.mark.parametrize("in_size,n", [(64, 16), (256, 64)])
+def test_batched_d_step_matches_two_chains(in_size, n):
+    """engine.disc_loss_grads_batched (D(real) and D(fake) as one double batch through the conv layers, BatchNorm per half)
+    against engine.disc_loss_grads (two forward / backward chains) on the HIP path: same loss, same running statistics, every
+    parameter gradient within the bf16 noise of two different tile shapes (the exact equivalence is the CPU test
+    test_engine_cpu.py::test_batched_d_step_matches_autograd)."""
+    import torch.nn as nn
+    import rna_gan_amd as P
+    from rna_gan_amd import engine as E
+    from oracle import ref_cpu as R
+    step, enc = 64, 128
+    G0 = R.seeded_fill_(R.OracleDCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                               last_nonlinearity=nn.Tanh()), 7)
+    D0 = R.seeded_fill_(R.OracleDCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                                   last_nonlinearity=nn.LeakyReLU(0.2)), 8)
+    res = []
+    for fn in (E.disc_loss_grads, E.disc_loss_grads_batched):
+        G = P.DCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+        D = P.DCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.LeakyReLU(0.2))
+        G.load_state_dict(G0.state_dict()); D.load_state_dict(D0.state_dict())
+        G, D = G.cuda().train(), D.cuda().train()
+        ops, gn = G.runtime()
+        _, dn = D.runtime()
+        real = R.synthetic_images(n, in_size, seed=100).cuda()
+        nz = R.synthetic_normal(n, enc, seed=200).cuda()
+        loss = fn(ops, gn, dn, real, nz)
+        torch.cuda.synchronize()
+        res.append((float(loss), {k: p.grad.detach().float().cpu() for k, p in D.named_parameters()},
+                    {k: b.detach().double().cpu() for k, b in D.named_buffers()}))
+    (la, ga, ba), (lb, gb, bb) = res
+    assert abs(la - lb) <= 0.1 * abs(la) + 1e-3, (la, lb)
+    for k in ga:
+        cos = float((ga[k] * gb[k]).sum() / (ga[k].norm() * gb[k].norm() + 1e-30))
+        ratio = float(gb[k].norm() / (ga[k].norm() + 1e-30))
+        assert cos >= 0.97 and 0.85 <= ratio <= 1.15, (k, cos, ratio)
+    for k in ba:
+        np.testing.assert_allclose(bb[k].numpy(), ba[k].numpy(), rtol=2e-3, atol=1e-4, err_msg=k)
