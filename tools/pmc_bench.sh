@@ -18,5 +18,6 @@ run write WRITE_SIZE
 run l2 TCC_HIT_sum TCC_MISS_sum
 python3 tools/pmc_layers.py gpurun_out/${OUT}_sq gpurun_out/${OUT}_lds gpurun_out/${OUT}_fetch gpurun_out/${OUT}_write gpurun_out/${OUT}_l2 --csv gpurun_out/${OUT}_layers.csv > /dev/null
 python3 tools/pmc_traffic.py gpurun_out/${OUT}_fetch gpurun_out/${OUT}_write > gpurun_out/${OUT}_traffic.json
-grep -E "kernel,|conv8|gather_gemm|wgrad" gpurun_out/${OUT}_layers.csv
+grep -E "kernel,|conv8|convp|gather_gemm|wgrad" gpurun_out/${OUT}_layers.csv
+python3 tools/pmc_family.py gpurun_out/${OUT}_layers.csv > gpurun_out/${OUT}_mfma_util.json
 cat gpurun_out/${OUT}_traffic.json

@@ -3,7 +3,7 @@
 weighted by n x us).  Usage: pmc_family.py <layers.csv>  -> JSON"""
 import csv, json, sys
 
-fam_of = lambda n: ("gather_gemm" if ("gather_gemm_dma_kernel<0" in n or "gather_gemm_dma_kernel<1" in n or "conv8" in n)
+fam_of = lambda n: ("gather_gemm" if ("gather_gemm_dma_kernel<0" in n or "gather_gemm_dma_kernel<1" in n or "conv8" in n or "convp_kernel" in n)
                     else "wgrad_dma" if "wgrad" in n and "skinny" not in n else None)
 acc = {}
 for r in csv.DictReader(open(sys.argv[1])):
