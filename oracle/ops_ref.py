@@ -211,6 +211,19 @@ class RefOps:
         mean, invstd = self.bn_stats_finalize(z, eps, momentum, running_mean, running_var, nbt)
         return self.bn_act(z, mean, invstd, gamma, beta, slope), mean, invstd
 
+    def bn_forward2(self, z, gamma, beta, slope: float, eps: float, momentum: float, running_mean=None,
+                    running_var=None, nbt=None, partials=None):
+        n = z.shape[0] // 2
+        r = [self.bn_forward(z[h * n:(h + 1) * n], gamma, beta, slope, eps, momentum, running_mean, running_var, nbt)
+             for h in range(2)]
+        return torch.cat([r[0][0], r[1][0]]), torch.stack([r[0][1], r[1][1]]), torch.stack([r[0][2], r[1][2]])
+
+    def bn_act_bwd2(self, z, ga, mean, invstd, gamma, beta, slope: float, dgamma=None, dbeta=None, accumulate: bool = False):
+        n = z.shape[0] // 2
+        r = [self.bn_act_bwd(z[h * n:(h + 1) * n], ga[h * n:(h + 1) * n], mean[h], invstd[h], gamma, beta, slope, dgamma, dbeta,
+                             accumulate or h == 1)[0] for h in range(2)]
+        return torch.cat(r)
+
     def bn_stats_finalize(self, z, eps: float, momentum: float, running_mean=None, running_var=None, nbt=None):
         s, ss = self.bn_stats(z)
         return self.bn_finalize(s, ss, z.numel() // z.shape[-1], eps, momentum, running_mean, running_var, nbt)

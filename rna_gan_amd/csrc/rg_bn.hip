@@ -37,10 +37,18 @@ static int max_gy(int M, int C) {
   return a.gy > b.gy ? a.gy : b.gy;
 }
 
+// ---- batch GROUPS (gridDim.z): the same pass over several equally sized row blocks [g*M, (g+1)*M) of one tensor, each with
+// its own statistics -- the D step runs D(real) and D(fake) as one double batch and BatchNorm has to see the two halves as
+// two forward calls.  A functor / finisher that supports groups has shift(g); others ignore the group index (gridDim.z = 1).
+template <class F> __device__ __forceinline__ auto shift_group(F& f, int g, int) -> decltype(f.shift(g), void()) { f.shift(g); }
+template <class F> __device__ __forceinline__ void shift_group(F&, int, long) {}
+
 // ---- reduction skeleton: F has  init(c)  and  row(r, c, acc[NQ][VEC])
 template <int NQ, int VEC, int TX, class F>
 __global__ __launch_bounds__(256) void rowreduce_kernel(F f, int M, int C, int rows_per_block, float* partial) {
   constexpr int TY = 256 / TX;
+  shift_group(f, (int)blockIdx.z, 0);
+  partial += (size_t)blockIdx.z * gridDim.y * NQ * C;
   __shared__ float sm[TY][NQ][TX * VEC];
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int c = (blockIdx.x * TX + tx) * VEC;
@@ -84,31 +92,39 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(F f, int M, int C, int r
 
 // finishing pass: block = 32 channels x 8 partial-row lanes
 template <int NQ, class Fin>
-__global__ __launch_bounds__(256) void colfinish_kernel(Fin fin, const float* partial, int C, int G) {
+__global__ __launch_bounds__(256) void colfinish_kernel(Fin fin, const float* partial, int C, int G, int groups = 1) {
   __shared__ float sm[8][NQ][32];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + tx;
-  float s[NQ];
+  // groups are finished one after the other by the same thread: a finisher that updates shared state (running statistics,
+  // accumulated parameter gradients) sees them in order, exactly as consecutive calls would
+  for (int grp = 0; grp < groups; ++grp) {
+    const float* part = partial + (size_t)grp * G * NQ * C;
+    float s[NQ];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) s[q] = 0.f;
-  if (c < C) {
+    for (int q = 0; q < NQ; ++q) s[q] = 0.f;
+    if (c < C) {
 #pragma unroll 4
-    for (int g = ty; g < G; g += 8)
+      for (int g = ty; g < G; g += 8)
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) s[q] += partial[((size_t)g * NQ + q) * C + c];
-  }
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) sm[ty][q][tx] = s[q];
-  __syncthreads();
-  if (ty == 0 && c < C) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      float t = 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) t += sm[k][q][tx];
-      s[q] = t;
+        for (int q = 0; q < NQ; ++q) s[q] += part[((size_t)g * NQ + q) * C + c];
     }
-    fin(c, s);
+    if (grp) __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) sm[ty][q][tx] = s[q];
+    __syncthreads();
+    if (ty == 0 && c < C) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sm[k][q][tx];
+        s[q] = t;
+      }
+      Fin fg = fin;
+      shift_group(fg, grp, 0);
+      fg(c, s);
+    }
   }
 }
 
@@ -123,6 +139,8 @@ __global__ __launch_bounds__(256) void colfinish_wide_kernel(Fin fin, const floa
   const int c0 = blockIdx.x * 8;
   const int per = (G + gridDim.y - 1) / gridDim.y;
   const int g0 = blockIdx.y * per, g1 = min(G, g0 + per);
+  partial += (size_t)blockIdx.z * G * NQ * C;             // batch group (see shift_group)
+  shift_group(fin, (int)blockIdx.z, 0);
   float acc[NQ][8];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
@@ -153,7 +171,8 @@ __global__ __launch_bounds__(256) void colfinish_wide_kernel(Fin fin, const floa
 }
 // level-1 finisher of the sliced form: row `slice` of a [slices][2][C] staging area (colfinish_kernel's input layout)
 struct SliceFin {
-  float* out; int C;
+  float* out; int C; int slices = 0;
+  __device__ void shift(int g) { out += (size_t)g * slices * 2 * C; }
   __device__ void operator()(int cs, const float* s) const {
     const int slice = cs / C, c = cs - slice * C;
     out[((size_t)slice * 2 + 0) * C + c] = s[0];
@@ -173,6 +192,7 @@ __global__ __launch_bounds__(256) void rowapply_kernel(F f, int M, int C, int ro
   if (c >= C) return;
   const int r0 = blockIdx.y * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
+  shift_group(f, (int)blockIdx.z, 0);
   f.init(c);
   int r = r0 + ty;
   for (; r + (U - 1) * TY < r1; r += U * TY) {
@@ -186,12 +206,12 @@ __global__ __launch_bounds__(256) void rowapply_kernel(F f, int M, int C, int ro
 }
 
 template <int NQ, typename T, template <typename, int> class F, class Fin, class... Args>
-int row_reduce(const char* name, int M, int C, void* ws, size_t ws_bytes, hipStream_t st, Fin fin, Args... args) {
-  Plan p = make_plan<T>(M, C, 1536);
-  size_t need = (size_t)p.gy * NQ * C * sizeof(float);
+int row_reduce_g(const char* name, int groups, int M, int C, void* ws, size_t ws_bytes, hipStream_t st, Fin fin, Args... args) {
+  Plan p = make_plan<T>(M, C, 1536 / groups);
+  size_t need = (size_t)groups * p.gy * NQ * C * sizeof(float);
   RG_REQUIRE(ws && ws_bytes >= need, RG_EWORKSPACE, "%s: workspace %zu < %zu", name, ws_bytes, need);
   float* partial = (float*)ws;
-  dim3 grid(p.gx, p.gy);
+  dim3 grid(p.gx, p.gy, groups);
 #define RG_RR(V, X)                                                                                          \
   do {                                                                                                       \
     F<T, V> f{args...};                                                                                      \
@@ -202,15 +222,19 @@ int row_reduce(const char* name, int M, int C, void* ws, size_t ws_bytes, hipStr
   else { if (p.tx == 32) RG_RR(1, 32); else if (p.tx == 16) RG_RR(1, 16); else RG_RR(1, 8); }
 #undef RG_RR
   RG_LAUNCH_CHECK(name);
-  hipLaunchKernelGGL((colfinish_kernel<NQ, Fin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, partial, C, p.gy);
+  hipLaunchKernelGGL((colfinish_kernel<NQ, Fin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, partial, C, p.gy, groups);
   RG_LAUNCH_CHECK(name);
   return RG_OK;
 }
+template <int NQ, typename T, template <typename, int> class F, class Fin, class... Args>
+int row_reduce(const char* name, int M, int C, void* ws, size_t ws_bytes, hipStream_t st, Fin fin, Args... args) {
+  return row_reduce_g<NQ, T, F, Fin, Args...>(name, 1, M, C, ws, ws_bytes, st, fin, args...);
+}
 
 template <typename T, template <typename, int> class F, class... Args>
-int row_apply(const char* name, int M, int C, hipStream_t st, Args... args) {
-  Plan p = make_plan<T>(M, C, 4096, 8192);      // no partial rows behind an apply pass: as many blocks as the target asks
-  dim3 grid(p.gx, p.gy);
+int row_apply_g(const char* name, int groups, int M, int C, hipStream_t st, Args... args) {
+  Plan p = make_plan<T>(M, C, 4096 / groups, 8192);      // no partial rows behind an apply pass: as many blocks as the target asks
+  dim3 grid(p.gx, p.gy, groups);
 #define RG_RA(V, X)                                                                                   \
   do {                                                                                                \
     F<T, V> f{args...};                                                                               \
@@ -222,6 +246,10 @@ int row_apply(const char* name, int M, int C, hipStream_t st, Args... args) {
 #undef RG_RA
   RG_LAUNCH_CHECK(name);
   return RG_OK;
+}
+template <typename T, template <typename, int> class F, class... Args>
+int row_apply(const char* name, int M, int C, hipStream_t st, Args... args) {
+  return row_apply_g<T, F, Args...>(name, 1, M, C, st, args...);
 }
 
 // ---- single-launch form for SMALL tensors (the deep 4x4 / 8x8 layers): a block owns VEC channels for ALL rows, so
@@ -295,7 +323,8 @@ template <int VEC> struct BNR {
 
 // ------------------------------------------------------------------------------------------ stats
 template <typename T, int VEC> struct StatsF {
-  const T* z; int C;
+  const T* z; int C; size_t gs = 0;                        // gs: elements per batch group
+  __device__ void shift(int g) { z += g * gs; }
   __device__ void init(int) {}
   static constexpr int U = 4;
   struct In { float v[VEC]; };
@@ -315,7 +344,8 @@ struct Store2Fin {
 // nn.BatchNorm2d in train mode, straight from the column sums (same arithmetic as bn_finalize_kernel)
 struct StatsFinalizeFin {
   float m, eps, momentum;
-  float* mean; float* invstd; float* rmean; float* rvar; int64_t* nbt;
+  float* mean; float* invstd; float* rmean; float* rvar; int64_t* nbt; int gC = 0;       // gC: channels (group stride of mean / invstd)
+  __device__ void shift(int g) { mean += g * gC; invstd += g * gC; }
   __device__ void operator()(int c, const float* s) const {
     if (c == 0 && nbt) *nbt += 1;
     // E[x^2] - E[x]^2 formed in double: the subtraction itself must not add to the cancellation when |mean| >> std
@@ -334,8 +364,9 @@ struct StatsFinalizeFin {
 
 // ------------------------------------------------------------------------------------------ bn_act
 template <typename T, int VEC> struct BnActF {
-  const T* z; T* a; BNC p; int C;
+  const T* z; T* a; BNC p; int C; size_t gs = 0;
   BNR<VEC> q;
+  __device__ void shift(int g) { z += g * gs; a += g * gs; p.mean += g * C; p.invstd += g * C; }
   static constexpr int U = 4;
   struct In { float v[VEC]; };
   __device__ void init(int c) { q.load(p, c); }
@@ -351,8 +382,9 @@ template <typename T, int VEC> struct BnActF {
 
 // ------------------------------------------------------------------------------------------ bwd
 template <typename T, int VEC> struct BwdRedF {
-  const T* z; const T* ga; BNC p; int C;
+  const T* z; const T* ga; BNC p; int C; size_t gs = 0;
   BNR<VEC> q;
+  __device__ void shift(int g) { z += g * gs; ga += g * gs; p.mean += g * C; p.invstd += g * C; }
   __device__ void init(int c) { q.load(p, c); }
   static constexpr int U = 4;
   struct In { float v[VEC], g[VEC]; };
@@ -371,7 +403,8 @@ template <typename T, int VEC> struct BwdRedF {
   __device__ void row(int r, int c, float (*acc)[VEC]) const { In in; load(r, c, in); accum(in, acc); }
 };
 struct BwdFin {
-  float* s_gy; float* s_gyxh; float* dgamma; float* dbeta; int accumulate;
+  float* s_gy; float* s_gyxh; float* dgamma; float* dbeta; int accumulate; int gC = 0;
+  __device__ void shift(int g) { s_gy += g * gC; s_gyxh += g * gC; if (g) accumulate = 1; }     // later groups add to the first one's
   __device__ void operator()(int c, const float* s) const {
     s_gy[c] = s[0]; s_gyxh[c] = s[1];
     if (dgamma) {
@@ -381,8 +414,11 @@ struct BwdFin {
   }
 };
 template <typename T, int VEC> struct BwdApplyF {
-  const T* z; const T* ga; T* gz; BNC p; const float* s_gy; const float* s_gyxh; float inv_m; int C;
+  const T* z; const T* ga; T* gz; BNC p; const float* s_gy; const float* s_gyxh; float inv_m; int C; size_t gs = 0;
   BNR<VEC> q; float m1[VEC], m2[VEC];
+  __device__ void shift(int g) {
+    z += g * gs; ga += g * gs; gz += g * gs; p.mean += g * C; p.invstd += g * C; s_gy += g * C; s_gyxh += g * C;
+  }
   __device__ void init(int c) {
     q.load(p, c);
 #pragma unroll
@@ -682,6 +718,66 @@ extern "C" int rg_bn_forward_partials(const float* partial, int G, const void* z
   }
   RG_LAUNCH_CHECK("bn_forward_partials");
   RG_DISPATCH_DTYPE(dtype, T, { return (row_apply<T, BnActF>("bn_forward_partials", M, C, st, (const T*)z, (T*)a, p, C)); })
+}
+
+// Two batch groups in one call: z / a are [2*M][C] (group-major), mean / invstd [2][C]; statistics, normalisation and the
+// running-statistics update exactly as two consecutive rg_bn_forward(_partials) calls on the halves (first half first).
+// partial (may be NULL): conv-epilogue column sums [2*G][2][C], the first G rows belonging to the first half.
+extern "C" int rg_bn_forward_g2(const float* partial, int G, const void* z, int M, int C, float eps, float momentum,
+                                const float* gamma, const float* beta, float slope, float* mean, float* invstd,
+                                float* running_mean, float* running_var, int64_t* num_batches_tracked, void* a, int dtype,
+                                void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(z && a && mean && invstd && gamma && beta && M > 0 && C > 0 && (!partial || G > 0), RG_EINVAL,
+             "bn_forward_g2: bad args");
+  StatsFinalizeFin fin{(float)M, eps, momentum, mean, invstd, running_mean, running_var,
+                       running_mean ? num_batches_tracked : nullptr, C};
+  BNC p{mean, invstd, gamma, beta, slope};
+  hipStream_t st = rg_stream(stream);
+  const size_t gs = (size_t)M * C;
+  if (partial) {
+    constexpr int SLICES = 32;
+    if (G > 512 && C % 8 == 0 && ws && ws_bytes >= (size_t)2 * SLICES * 2 * C * sizeof(float)) {
+      float* stage = (float*)ws;
+      hipLaunchKernelGGL((colfinish_wide_kernel<2, SliceFin>), dim3(C / 8, SLICES, 2), dim3(256), 0, st,
+                         SliceFin{stage, C, SLICES}, partial, C, G);
+      RG_LAUNCH_CHECK("bn_forward_g2");
+      hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, stage, C,
+                         SLICES, 2);
+    } else {
+      hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, partial, C, G,
+                         2);
+    }
+    RG_LAUNCH_CHECK("bn_forward_g2");
+    RG_DISPATCH_DTYPE(dtype, T, {
+      return (row_apply_g<T, BnActF>("bn_forward_g2", 2, M, C, st, (const T*)z, (T*)a, p, C, gs));
+    })
+  }
+  RG_DISPATCH_DTYPE(dtype, T, {
+    int rc = row_reduce_g<2, T, StatsF>("bn_forward_g2", 2, M, C, ws, ws_bytes, st, fin, (const T*)z, C, gs);
+    if (rc) return rc;
+    return (row_apply_g<T, BnActF>("bn_forward_g2", 2, M, C, st, (const T*)z, (T*)a, p, C, gs));
+  })
+}
+
+// Backward of two batch groups (see rg_bn_forward_g2): gz as two rg_bn_act_bwd calls on the halves would give it, s_gy /
+// s_gyxh [2][C] per half, dgamma / dbeta = the sum over both halves (written, or added when `accumulate`).
+extern "C" int rg_bn_act_bwd_g2(const void* z, const void* ga, const float* mean, const float* invstd, const float* gamma,
+                                const float* beta, void* gz, float* s_gy, float* s_gyxh, float* dgamma, float* dbeta,
+                                int accumulate, int M, int C, float slope, int dtype, void* ws, size_t ws_bytes,
+                                void* stream) {
+  RG_REQUIRE(z && ga && gz && s_gy && s_gyxh && M > 0 && C > 0, RG_EINVAL, "bn_act_bwd_g2: bad args");
+  RG_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), RG_EINVAL, "bn_act_bwd_g2: dgamma/dbeta must come together");
+  BNC p{mean, invstd, gamma, beta, slope};
+  hipStream_t st = rg_stream(stream);
+  const size_t gs = (size_t)M * C;
+  RG_DISPATCH_DTYPE(dtype, T, {
+    int rc = row_reduce_g<2, T, BwdRedF>("bn_act_bwd_g2", 2, M, C, ws, ws_bytes, st,
+                                         BwdFin{s_gy, s_gyxh, dgamma, dbeta, accumulate, C}, (const T*)z, (const T*)ga, p, C,
+                                         gs);
+    if (rc) return rc;
+    return (row_apply_g<T, BwdApplyF>("bn_act_bwd_g2", 2, M, C, st, (const T*)z, (const T*)ga, (T*)gz, p,
+                                      (const float*)s_gy, (const float*)s_gyxh, 1.f / (float)M, C, gs));
+  })
 }
 
 extern "C" int rg_bn_finalize(const float* sum, const float* sumsq, int M, int C, float eps, float momentum,

@@ -482,8 +482,8 @@ def _half_partials(st, m_half: int, m_total: int, h: int):
 def disc_loss_grads_batched(ops, G, D: DiscNet, real, noise, grad_scale: float = 1.0):
     """The D-loss step with D(real) and D(fake) as ONE double batch through the conv layers (forward, data gradient and
     weight gradient: one launch each per layer instead of two, at a size where the 256 x 256-tile kernels need no split-K),
-    BatchNorm per half exactly as two separate forward calls would do it (own batch statistics, running statistics updated
-    by the real half first -- the reference's call order D(real), G(z), D(fake) of src/wgan_loss.py:241-253 -- own
+    BatchNorm per half exactly as two separate forward calls would do it (bn_forward2 / bn_act_bwd2: one set of launches over
+    two batch groups; own batch statistics, running statistics updated by the real half first -- the reference's call order D(real), G(z), D(fake) of src/wgan_loss.py:241-253 -- own
     backward reductions, parameter gradients summed).  Same result as disc_loss_grads up to the kernels' tile shapes."""
     n = real.shape[0]
     R = len(D.blocks)
@@ -502,13 +502,10 @@ def disc_loss_grads_batched(ops, G, D: DiscNet, real, noise, grad_scale: float =
     for cw, bn in D.blocks:
         z, st = ops.conv_down(a, cw, want_stats=True)
         m_half = z.numel() // z.shape[-1] // 2
-        a = torch.empty_like(z)
-        mean, invstd = [], []
-        for h in range(2):
-            _, mu, iv = ops.bn_forward(z[h * n:(h + 1) * n], bn.gamma, bn.beta, D.slope, bn.eps, bn.momentum, bn.running_mean,
-                                       bn.running_var, bn.nbt, partials=_half_partials(st, m_half, 2 * m_half, h),
-                                       out=a[h * n:(h + 1) * n])
-            mean.append(mu); invstd.append(iv)
+        if _half_partials(st, m_half, 2 * m_half, 0) is None:
+            st = None                                       # a partial row straddles the halves: BatchNorm reduces itself
+        a, mean, invstd = ops.bn_forward2(z, bn.gamma, bn.beta, D.slope, bn.eps, bn.momentum, bn.running_mean,
+                                          bn.running_var, bn.nbt, partials=st)
         zs.append(z); means.append(mean); invstds.append(invstd); acts.append(a)
     hh, out = ops.head_fwd(a, D.head, D.last_slope)
     loss = ops.mean_diff(out[n:], out[:n], 1.0)
@@ -519,10 +516,7 @@ def disc_loss_grads_batched(ops, G, D: DiscNet, real, noise, grad_scale: float =
     ga = ops.head_bwd_data(gh, D.head)
     for l in range(R, 0, -1):
         cw, bn = D.blocks[l - 1]
-        gz = torch.empty_like(zs[l])
-        for h in range(2):
-            ops.bn_act_bwd(zs[l][h * n:(h + 1) * n], ga[h * n:(h + 1) * n], means[l][h], invstds[l][h], bn.gamma, bn.beta,
-                           D.slope, bn.dgamma, bn.dbeta, h == 1, out=gz[h * n:(h + 1) * n])
+        gz = ops.bn_act_bwd2(zs[l], ga, means[l], invstds[l], bn.gamma, bn.beta, D.slope, bn.dgamma, bn.dbeta, False)
         with ops.side(gz):
             ops.conv_wgrad(gz, acts[l - 1], cw, False)
         ga = ops.conv_up(gz, cw) if l > 1 else ops.conv_up(gz, cw, acts[0], D.slope)

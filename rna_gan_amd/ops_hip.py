@@ -570,6 +570,38 @@ class HipOps:
                                      _ptr(a), self.dt, _ptr(ws), ws.numel(), self.stream), "rg_bn_forward")
         return a, mean, invstd
 
+    def bn_forward2(self, z, gamma, beta, slope: float, eps: float, momentum: float, running_mean=None,
+                    running_var=None, nbt=None, partials=None):
+        """bn_forward on the two batch halves of z ([2n, ...]) in one set of launches: (a, mean[2][C], invstd[2][C]), running
+        statistics updated by the first half, then the second -- exactly two bn_forward calls.  partials: the conv
+        epilogue's column sums with the first half of the rows belonging to the first batch half, or None."""
+        M2, C = self._mc(z)
+        M = M2 // 2
+        assert M2 % 2 == 0 and self.stat_reduce is None
+        mean, invstd = self._f32(2, C), self._f32(2, C)
+        a = torch.empty_like(z)
+        ws = self._ws(2 * self.lib.rg_colreduce_workspace_bytes(M, C, 2) + 2 * 32 * 2 * C * 4)
+        G = 0 if partials is None else partials.shape[0] // 2
+        check(self.lib.rg_bn_forward_g2(_ptr(partials), G, _ptr(z), M, C, float(eps), float(momentum), _ptr(gamma),
+                                        _ptr(beta), float(slope), _ptr(mean), _ptr(invstd), _ptr(running_mean),
+                                        _ptr(running_var), _ptr(nbt), _ptr(a), self.dt, _ptr(ws), ws.numel(), self.stream),
+              "rg_bn_forward_g2")
+        return a, mean, invstd
+
+    def bn_act_bwd2(self, z, ga, mean, invstd, gamma, beta, slope: float, dgamma=None, dbeta=None, accumulate: bool = False):
+        """bn_act_bwd on the two batch halves (mean / invstd [2][C] from bn_forward2): gz, with dgamma / dbeta summed over
+        both halves."""
+        M2, C = self._mc(z)
+        M = M2 // 2
+        assert M2 % 2 == 0 and self.stat_reduce is None and mean.shape == (2, C)
+        gz = torch.empty_like(z)
+        s_gy, s_gyxh = self._f32(2, C), self._f32(2, C)
+        ws = self._ws(2 * self.lib.rg_colreduce_workspace_bytes(M, C, 2))
+        check(self.lib.rg_bn_act_bwd_g2(_ptr(z), _ptr(ga), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(gz),
+                                        _ptr(s_gy), _ptr(s_gyxh), _ptr(dgamma), _ptr(dbeta), int(accumulate), M, C,
+                                        float(slope), self.dt, _ptr(ws), ws.numel(), self.stream), "rg_bn_act_bwd_g2")
+        return gz
+
     def bn_act(self, z, mean, invstd, gamma, beta, slope: float):
         M, C = self._mc(z)
         a = torch.empty_like(z)

@@ -546,3 +546,44 @@ def test_fp8_conv_up_and_gemm(N, Ho, O, I, out_fp8):
     ref0 = torch.where(ref0 > 0, ref0, 0.2 * ref0).reshape(M, 4, 4, C)
     got0 = _fp8_decode(y0) if out_fp8 else y0.float().cpu()
     assert float((got0 - ref0).abs().max()) <= tol * float(ref0.abs().max())
+
+
+@pytest.mark.parametrize("N,H,C", [(4, 8, 256), (8, 4, 2048), (16, 32, 128), (64, 64, 128)])
+def test_bn_two_batch_groups(N, H, C):
+    """bn_forward2 / bn_act_bwd2 (two batch groups in one set of launches) against two separate calls on the halves:
+    activations, per-half statistics, running statistics (first half first), data gradient, summed parameter gradients;
+    with the statistics taken from conv-epilogue style partial sums and computed by the pass itself."""
+    dtype = torch.bfloat16
+    hip = _hip(dtype)
+    z = dev(rnd((2 * N, H, H, C), 1).to(dtype))
+    ga = dev(rnd((2 * N, H, H, C), 2).to(dtype))
+    gamma, beta = dev(rnd((C,), 3).abs() + 0.5), dev(rnd((C,), 4))
+    M = N * H * H
+    for with_partials in (False, True):
+        rm1, rv1, nb1 = dev(torch.zeros(C)), dev(torch.ones(C)), torch.zeros((), dtype=torch.int64, device="cuda")
+        rm2, rv2, nb2 = rm1.clone(), rv1.clone(), nb1.clone()
+        parts = None
+        if with_partials:                      # [rows][2][C]: one partial row per 64 tensor rows, first half first
+            zf = z.float().reshape(2 * M // 64, 64, C)
+            parts = torch.stack([zf.sum(1), (zf * zf).sum(1)], dim=1).contiguous()
+        ref = []
+        for h in range(2):
+            ph = None if parts is None else parts[h * (parts.shape[0] // 2):(h + 1) * (parts.shape[0] // 2)]
+            ref.append(hip.bn_forward(z[h * N:(h + 1) * N], gamma, beta, 0.2, 1e-5, 0.1, rm1, rv1, nb1, partials=ph))
+        a2, mean2, invstd2 = hip.bn_forward2(z, gamma, beta, 0.2, 1e-5, 0.1, rm2, rv2, nb2, partials=parts)
+        for h in range(2):
+            check(a2[h * N:(h + 1) * N], ref[h][0], 1e-2, "a")
+            check(mean2[h], ref[h][1], 1e-5, "mean")
+            check(invstd2[h], ref[h][2], 1e-5, "invstd")
+        check(rm2, rm1, 1e-6, "running_mean")
+        check(rv2, rv1, 1e-6, "running_var")
+        assert int(nb2) == int(nb1) == 2
+        dg1, db1 = dev(torch.zeros(C)), dev(torch.zeros(C))
+        dg2, db2 = dev(torch.zeros(C)), dev(torch.zeros(C))
+        gz_ref = [hip.bn_act_bwd(z[h * N:(h + 1) * N], ga[h * N:(h + 1) * N], ref[h][1], ref[h][2], gamma, beta, 0.2, dg1, db1,
+                                 h == 1)[0] for h in range(2)]
+        gz2 = hip.bn_act_bwd2(z, ga, mean2, invstd2, gamma, beta, 0.2, dg2, db2, False)
+        for h in range(2):
+            check(gz2[h * N:(h + 1) * N], gz_ref[h], 1e-2, "gz")
+        check(dg2, dg1, 1e-4, "dgamma")
+        check(db2, db1, 1e-4, "dbeta")
