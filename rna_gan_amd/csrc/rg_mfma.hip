@@ -1016,6 +1016,32 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __r
     }
   }
 }
+// The same transpose for R % 64 == 0, Cc % 128 == 0 (every conv weight of the reference model) with 16-byte accesses on both
+// sides: 64 x 128 tile, rows stored as 16 chunks of 8 elements with chunk' = chunk ^ ((row >> 3) & 7), which keeps the
+// 16-byte stores aligned and makes the column gathers of the second phase conflict-free (8 row groups x 8 adjacent columns
+// per wave-instruction land in 32 different banks).  dst rows are written as 128-byte segments.
+__global__ __launch_bounds__(256) void transpose_bf16_wide_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
+                                                                  int R, int Cc) {
+  __shared__ __attribute__((aligned(16))) uint16_t tile[64][128];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 128;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = t + 256 * k, row = e >> 4, chunk = e & 15;
+    const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)(r0 + row) * Cc + c0 + chunk * 8);
+    *reinterpret_cast<uint4*>(&tile[row][(chunk ^ ((row >> 3) & 7)) * 8]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = t + 256 * k, c = e >> 3, rg = e & 7;
+    const int pc = (((c >> 3) ^ rg) << 3) | (c & 7);
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (uint32_t)tile[8 * rg + 2 * j][pc] | ((uint32_t)tile[8 * rg + 2 * j + 1][pc] << 16);
+    *reinterpret_cast<uint4*>(dst + (size_t)(c0 + c) * R + r0 + 8 * rg) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
 __global__ void pack_linear_kernel(const float* w, uint16_t* wp, int Nout, int K, int Np, int Kp) {
   size_t n = (size_t)Np * Kp;
   for (size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += (size_t)gridDim.x * blockDim.x) {
@@ -1518,6 +1544,12 @@ int rg_mfma_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I,
 }
 int rg_mfma_transpose_bf16(const void* src, void* dst, int R, int Cc, int permute, hipStream_t st) {
   RG_REQUIRE(R % 2 == 0 && Cc % 2 == 0, RG_EUNSUPPORTED, "transpose_bf16: even dimensions required");
+  if (permute == 0 && R % 64 == 0 && Cc % 128 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0) {
+    hipLaunchKernelGGL(transpose_bf16_wide_kernel, dim3(Cc / 128, R / 64), dim3(256), 0, st, (const uint16_t*)src,
+                       (uint16_t*)dst, R, Cc);
+    RG_LAUNCH_CHECK("transpose_bf16");
+    return RG_OK;
+  }
   hipLaunchKernelGGL(transpose_bf16_kernel, dim3((Cc + 63) / 64, (R + 63) / 64), dim3(256), 0, st, (const uint16_t*)src,
                      (uint16_t*)dst, R, Cc, permute);
   RG_LAUNCH_CHECK("transpose_bf16");
