@@ -141,6 +141,12 @@ int rg_last_up(const void* x, const float* w, const float* bias, float* y_nchw, 
 int rg_first_down_bits(const float* x_nchw, const float* w, const float* bias, void* y, void* bits, int N, int H, int W,
                        int I, int O, float slope, int dtype, void* stream);
 int rg_sign_pack(const void* a, void* bits, long long npix, int C, int dtype, void* stream);
+/* y = lrelu'(a) * conv2d(x_nchw, w) (no bias), lrelu'(a) taken from a's packed sign bits: the tangent of discriminator
+ * layer 0 in the penalty's forward-mode pass (second-order term of src/wgan_loss.py:32-44) in one kernel.
+ * rg_first_down_masked_supported == 0: use rg_first_down(slope 1) + rg_lrelu_bwd instead. */
+int rg_first_down_masked_supported(int H, int W, int I, int O, int dtype);
+int rg_first_down_masked(const float* x_nchw, const float* w, void* y, const void* mask_bits, float mask_slope, int N,
+                         int H, int W, int I, int O, int dtype, void* stream);
 int rg_conv_up_maskbits_supported(int N, int Ho, int Wo, int O, int I, int dtype, int algo);
 int rg_conv_up_maskbits(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I,
                         const void* mask_bits, float mask_slope, int dtype, int algo, void* ws, size_t ws_bytes,

@@ -119,6 +119,9 @@ class RefOps:
         else:
             cw.dw.copy_(d)
 
+    def first_down_tangent(self, v_nchw, cw: ConvW, a0, slope: float):
+        return self.lrelu_bwd(self.first_down(v_nchw, cw, None, 1.0), a0, slope)
+
     def sign_bits_for(self, N, H, W):
         return None
 

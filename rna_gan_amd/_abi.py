@@ -35,6 +35,8 @@ PROTOTYPES = {
     "rg_first_down": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "rg_first_down_bits": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "rg_sign_pack": (_i, [_p, _p, C.c_longlong, _i, _i, _p]),
+    "rg_first_down_masked_supported": (_i, [_i, _i, _i, _i, _i]),
+    "rg_first_down_masked": (_i, [_p, _p, _p, _p, _f, _i, _i, _i, _i, _i, _i, _p]),
     "rg_conv_up_maskbits_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "rg_conv_up_maskbits": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _f, _i, _i, _p, _z, _p]),
     "rg_last_up": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),

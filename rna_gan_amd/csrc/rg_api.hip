@@ -155,6 +155,20 @@ extern "C" int rg_first_down_bits(const float* x_nchw, const float* w, const flo
   return rc != RG_OK ? rc : rg_skinny_sign_pack(y, bits, (long long)N * (H / 2) * (W / 2), O, dtype, rg_stream(stream));
 }
 
+// y = lrelu'(a) * conv2d(x, w) with lrelu'(a) given as a's packed sign bits (rg_first_down_bits): the tangent of
+// discriminator layer 0 in the gradient penalty's forward-mode pass.  rg_first_down_masked_supported: 0 -> use
+// rg_first_down(slope = 1) + rg_lrelu_bwd.
+extern "C" int rg_first_down_masked_supported(int H, int W, int I, int O, int dtype) {
+  return rg_skinny_supported(I, O) && rg_skinny_first_down_masked_supported(H, W, I, O, dtype);
+}
+extern "C" int rg_first_down_masked(const float* x_nchw, const float* w, void* y, const void* mask_bits, float mask_slope,
+                                    int N, int H, int W, int I, int O, int dtype, void* stream) {
+  RG_REQUIRE(x_nchw && w && y && mask_bits && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, RG_EINVAL,
+             "first_down_masked: bad args");
+  RG_REQUIRE(rg_first_down_masked_supported(H, W, I, O, dtype), RG_EUNSUPPORTED, "first_down_masked: shape");
+  return rg_skinny_first_down_masked(x_nchw, w, y, mask_bits, mask_slope, N, H, W, I, O, dtype, rg_stream(stream));
+}
+
 extern "C" int rg_sign_pack(const void* a, void* bits, long long npix, int C, int dtype, void* stream) {
   RG_REQUIRE(a && bits && npix > 0, RG_EINVAL, "sign_pack: bad args");
   return rg_skinny_sign_pack(a, bits, npix, C, dtype, rg_stream(stream));

@@ -112,6 +112,9 @@ bool rg_skinny_supported(int I, int O);
 int rg_skinny_first_down(const float* x, const float* w, const float* bias, void* y, void* bits, int N, int H, int W, int I,
                          int O, float slope, int dtype, hipStream_t st);
 int rg_skinny_sign_pack(const void* a, void* bits, long long npix, int C, int dtype, hipStream_t st);
+bool rg_skinny_first_down_masked_supported(int H, int W, int I, int O, int dtype);
+int rg_skinny_first_down_masked(const float* x, const float* w, void* y, const void* mask_bits, float mslope, int N, int H,
+                                int W, int I, int O, int dtype, hipStream_t st);
 int rg_skinny_last_up(const void* x, const float* w, const float* bias, float* y, int N, int Ho, int Wo, int O, int I,
                       int apply_tanh, int dtype, hipStream_t st);
 size_t rg_skinny_wgrad_ws_bytes(int N, int Ho, int Wo, int O, int I);

@@ -291,8 +291,7 @@ def disc_gp_second(ops, D: DiscNet, ctx, st, accumulate: bool, need_input_grad: 
     g, v = st
     xhat = ctx.x
     # (3) tangent forward along v
-    zt0 = ops.first_down(v, D.conv0, None, 1.0)
-    at = ops.lrelu_bwd(zt0, ctx.a[0], D.slope)
+    at = ops.first_down_tangent(v, D.conv0, ctx.a[0], D.slope)
     ats, zts, s_zt, s_xhzt = [at], [None], [None], [None]
     for l in range(1, R + 1):
         cw, bn = D.blocks[l - 1]

@@ -399,6 +399,19 @@ class HipOps:
                                      self.dt, self.stream), "rg_first_down")
         return y
 
+    def first_down_tangent(self, v_nchw, cw: ConvW, a0, slope: float):
+        """lrelu'(a0) * conv(v) (no bias): the tangent of discriminator layer 0.  One kernel when a0 carries its packed sign
+        bits (first_down), else the conv followed by a masking pass."""
+        N, I, H, W = v_nchw.shape
+        O = cw.w.shape[0]
+        bits = getattr(a0, "_rg_sign_bits", None)
+        if bits is not None and self.lib.rg_first_down_masked_supported(H, W, I, O, self.dt):
+            y = self._act(N, H // 2, W // 2, O)
+            check(self.lib.rg_first_down_masked(_ptr(v_nchw), _ptr(cw.w), _ptr(y), _ptr(bits), float(slope), N, H, W, I, O,
+                                                self.dt, self.stream), "rg_first_down_masked")
+            return y
+        return self.lrelu_bwd(self.first_down(v_nchw, cw, None, 1.0), a0, slope)
+
     def sign_pack(self, a):
         """Packed sign bits (uint64 per pixel, bit c = a[pixel][c] > 0) of a bf16 activation [..., 64]."""
         assert a.dtype == torch.bfloat16 and a.shape[-1] == 64 and a.is_contiguous()

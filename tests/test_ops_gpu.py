@@ -240,6 +240,13 @@ def test_first_down_sign_bits():
         c1r, c1h = cwpair_tm(w1)
         gz = rnd((N, H // 4, H // 4, 128), 9).to(dtype)
         check(hip.conv_up(dev(gz), c1h, a, 0.2), ref.conv_up(gz, c1r, a.cpu(), 0.2), TOL[dtype], "conv_up(mask from first_down)")
+        # tangent of layer 0: lrelu'(a) * conv(v) in one kernel (mask from the packed bits) against conv + masking pass
+        v = rnd((N, 3, H, H), 10)
+        t1 = hip.first_down_tangent(dev(v), ch, a, 0.2)
+        a_nobits = a.clone()
+        t0 = hip.first_down_tangent(dev(v), ch, a_nobits, 0.2)
+        check(t1, t0, 1e-2, "first_down_tangent")
+        check(t1, ref.first_down_tangent(v, cr, a.cpu(), 0.2), TOL[dtype], "first_down_tangent vs twin")
 
 
 @pytest.mark.parametrize("blocks", [1, 8, 256])
