@@ -151,6 +151,14 @@ int rg_conv_up_maskbits_supported(int N, int Ho, int Wo, int O, int I, int dtype
 int rg_conv_up_maskbits(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I,
                         const void* mask_bits, float mask_slope, int dtype, int algo, void* ws, size_t ws_bytes,
                         void* stream);
+/* rg_last_up with the generator's last train-mode BatchNorm + LeakyReLU applied to its input on the fly (z = the pre-BatchNorm
+ * conv output; mean / invstd from rg_bn_finalize_partials or rg_bn_stats_finalize): the no-grad generator forwards of the
+ * D-loss and penalty steps (src/wgan_loss.py:247,371) skip the normalisation pass over their largest activation.  Same bf16
+ * rounding as rg_bn_act followed by rg_last_up.  rg_last_up_pre_supported == 0: use those two. */
+int rg_last_up_pre_supported(int Wo, int O, int I, int dtype);
+int rg_last_up_pre(const void* z, const float* w, const float* bias, float* y_nchw, const float* mean, const float* invstd,
+                   const float* gamma, const float* beta, float slope, int N, int Ho, int Wo, int O, int I, int apply_tanh,
+                   int dtype, void* stream);
 size_t rg_skinny_wgrad_workspace_bytes(int N, int Ho, int Wo, int O, int I);
 int rg_skinny_wgrad(const void* low, const float* high_nchw, float* dw, int N, int Ho, int Wo, int O, int I,
                     int dtype, int accumulate, void* ws, size_t ws_bytes, void* stream);
@@ -232,6 +240,10 @@ int rg_bn_act(const void* z, const float* mean, const float* invstd, const float
 int rg_bn_act_bwd(const void* z, const void* ga, const float* mean, const float* invstd, const float* gamma,
                   const float* beta, void* gz, float* s_gy, float* s_gyxh, float* dgamma, float* dbeta,
                   int accumulate, int M, int C, float slope, int dtype, void* ws, size_t ws_bytes, void* stream);
+/* mean / invstd (+ running statistics) from the conv epilogue's column sums, without the normalisation pass. */
+int rg_bn_finalize_partials(const float* partial, int G, int M, int C, float eps, float momentum, float* mean,
+                            float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, void* ws,
+                            size_t ws_bytes, void* stream);
 /* Two batch groups in one call (the D-loss step runs D(real) and D(fake) -- src/wgan_loss.py:241-253 -- as one double
  * batch through the conv layers; BatchNorm must treat the halves as the two separate forward calls they are in the
  * reference): z / a / ga / gz are [2*M][C] (first half first), mean / invstd / s_gy / s_gyxh [2][C].  rg_bn_forward_g2 =

@@ -137,6 +137,9 @@ class RefOps:
             y = F.leaky_relu(y, slope)
         return _nhwc(y, self.act_dtype)
 
+    def last_up_bn(self, z, partials, bn, slope, cw, bias, tanh, update_running=True):
+        return None
+
     def last_up(self, x, cw: ConvW, bias, tanh: bool):
         y = F.conv_transpose2d(self._nchw(x), self._wq(cw.w), bias, stride=2, padding=1)
         return torch.tanh(y) if tanh else y.contiguous()

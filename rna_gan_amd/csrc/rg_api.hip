@@ -189,6 +189,21 @@ extern "C" int rg_conv_up_maskbits(const void* x, const void* wup, void* y, int 
                          nullptr, nullptr, 1.f, 1);
 }
 
+// rg_last_up whose input is the PRE-BatchNorm tensor z: lrelu(bn_train(z)) is applied while the rows are staged (same bf16
+// rounding as rg_bn_act), for generator forwards that keep nothing for a backward pass.
+extern "C" int rg_last_up_pre_supported(int Wo, int O, int I, int dtype) {
+  return rg_skinny_supported(I, O) && rg_skinny_last_up_pre_supported(Wo, O, dtype);
+}
+extern "C" int rg_last_up_pre(const void* z, const float* w, const float* bias, float* y_nchw, const float* mean,
+                              const float* invstd, const float* gamma, const float* beta, float slope, int N, int Ho, int Wo,
+                              int O, int I, int apply_tanh, int dtype, void* stream) {
+  RG_REQUIRE(z && w && y_nchw && mean && invstd && gamma && beta && N > 0 && Ho > 0 && Wo > 0, RG_EINVAL,
+             "last_up_pre: bad args");
+  RG_REQUIRE(rg_last_up_pre_supported(Wo, O, I, dtype), RG_EUNSUPPORTED, "last_up_pre: shape");
+  return rg_skinny_last_up(z, w, bias, y_nchw, N, Ho, Wo, O, I, apply_tanh, dtype, rg_stream(stream), mean, invstd, gamma,
+                           beta, slope);
+}
+
 extern "C" int rg_last_up(const void* x, const float* w, const float* bias, float* y_nchw, int N, int Ho, int Wo,
                           int O, int I, int apply_tanh, int dtype, void* stream) {
   RG_REQUIRE(x && w && y_nchw && N > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0, RG_EINVAL, "last_up: bad args");

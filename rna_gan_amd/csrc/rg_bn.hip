@@ -720,6 +720,30 @@ extern "C" int rg_bn_forward_partials(const float* partial, int G, const void* z
   RG_DISPATCH_DTYPE(dtype, T, { return (row_apply<T, BnActF>("bn_forward_partials", M, C, st, (const T*)z, (T*)a, p, C)); })
 }
 
+// Statistics only, from conv-epilogue column sums: mean / invstd (+ running statistics) as rg_bn_forward_partials computes
+// them, without the normalisation pass (its consumer applies BatchNorm itself: rg_last_up_pre).
+extern "C" int rg_bn_finalize_partials(const float* partial, int G, int M, int C, float eps, float momentum, float* mean,
+                                       float* invstd, float* running_mean, float* running_var,
+                                       int64_t* num_batches_tracked, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(partial && G > 0 && mean && invstd && M > 0 && C > 0, RG_EINVAL, "bn_finalize_partials: bad args");
+  StatsFinalizeFin fin{(float)M, eps, momentum, mean, invstd, running_mean, running_var,
+                       running_mean ? num_batches_tracked : nullptr};
+  hipStream_t st = rg_stream(stream);
+  constexpr int SLICES = 32;
+  if (G > 512 && C % 8 == 0 && ws && ws_bytes >= (size_t)SLICES * 2 * C * sizeof(float)) {
+    float* stage = (float*)ws;
+    hipLaunchKernelGGL((colfinish_wide_kernel<2, SliceFin>), dim3(C / 8, SLICES), dim3(256), 0, st, SliceFin{stage, C},
+                       partial, C, G);
+    RG_LAUNCH_CHECK("bn_finalize_partials");
+    hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, stage, C, SLICES,
+                       1);
+  } else {
+    hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, partial, C, G, 1);
+  }
+  RG_LAUNCH_CHECK("bn_finalize_partials");
+  return RG_OK;
+}
+
 // Two batch groups in one call: z / a are [2*M][C] (group-major), mean / invstd [2][C]; statistics, normalisation and the
 // running-statistics update exactly as two consecutive rg_bn_forward(_partials) calls on the halves (first half first).
 // partial (may be NULL): conv-epilogue column sums [2*G][2][C], the first G rows belonging to the first half.

@@ -386,10 +386,15 @@ constexpr int LU_PXS = 72;                 // bf16 elements per staged pixel (14
 constexpr int LU_MAXC = 128;               // pixels per unit row
 constexpr int LU_OS = 2 * LU_MAXC + 4;     // floats per staged output row
 
+// pre (optional): the input is the PRE-BatchNorm tensor z and the layer's train-mode BatchNorm + LeakyReLU is applied while
+// a row is staged -- lrelu((z - mean) * (invstd * gamma) + beta), rounded to bf16 exactly as rg_bn_act would store it -- so a
+// generator forward that keeps nothing for a backward pass (the fakes of the D-loss and penalty steps) skips the BatchNorm
+// apply pass over its largest activation (134 MB read + 134 MB written).
+struct LuPre { const float* mean; const float* invstd; const float* gamma; const float* beta; float slope; };
 __global__ __launch_bounds__(256, 2) void last_up_rows_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ y, int N,
                                                               int Ho, int Wo, int apply_tanh, int chunk, int strip,
-                                                              int nstrips) {
+                                                              int nstrips, LuPre pre) {
   __shared__ __attribute__((aligned(16))) uint16_t ring[3 * (LU_MAXC + 2) * LU_PXS];    // 54.8 KB
   __shared__ __attribute__((aligned(16))) float outt[6 * LU_OS];                          // 6.1 KB
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -419,6 +424,26 @@ __global__ __launch_bounds__(256, 2) void last_up_rows_kernel(const uint16_t* __
       }
     }
   const float bv = (bias && ni < SK_I) ? bias[ni] : 0.f;
+  // BatchNorm parameters of this thread's 8 input channels (t & 7) * 8 .. + 7
+  float pm[8], pr[8], pb[8];
+  if (pre.mean) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = (t & 7) * 8 + j;
+      pm[j] = pre.mean[c]; pr[j] = pre.invstd[c] * pre.gamma[c]; pb[j] = pre.beta[c];
+    }
+  }
+  auto bn8 = [&](uint4& v) {
+    uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float lo = lrelu_f((bf16_to_f32((uint16_t)d[j]) - pm[2 * j]) * pr[2 * j] + pb[2 * j], pre.slope);
+      const float hi = lrelu_f((bf16_to_f32((uint16_t)(d[j] >> 16)) - pm[2 * j + 1]) * pr[2 * j + 1] + pb[2 * j + 1], pre.slope);
+      d[j] = sk_pack2(lo, hi);
+    }
+    v = make_uint4(d[0], d[1], d[2], d[3]);
+  };
+  bool row_ok = false, edge_ok = false;            // validity of the row / halo pixel held in lv*, le (padding stays zero)
 
   for (int sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
     const int cx = sidx % cpr, rest = sidx / cpr;
@@ -430,6 +455,8 @@ __global__ __launch_bounds__(256, 2) void last_up_rows_kernel(const uint16_t* __
 #define LU_LOAD_ROW(row)                                                                                      \
   do {                                                                                                        \
     lv0 = lv1 = lv2 = lv3 = le = make_uint4(0, 0, 0, 0);                                                      \
+    row_ok = (unsigned)(row) < (unsigned)Ho;                                                                  \
+    edge_ok = false;                                                                                          \
     if ((unsigned)(row) < (unsigned)Ho) {                                                                     \
       const uint16_t* src_ = xn + ((size_t)(row) * Wo + wo0) * 64 + (size_t)t * 8;                            \
       if ((t >> 3) < chunk) lv0 = *reinterpret_cast<const uint4*>(src_);                                      \
@@ -438,8 +465,10 @@ __global__ __launch_bounds__(256, 2) void last_up_rows_kernel(const uint16_t* __
       if ((t >> 3) + 96 < chunk) lv3 = *reinterpret_cast<const uint4*>(src_ + 6144);                          \
       if (t < 16) {                                                                                           \
         const int col_ = (t >> 3) ? wo0 + chunk : wo0 - 1;                                                    \
-        if ((unsigned)col_ < (unsigned)Wo)                                                                    \
+        if ((unsigned)col_ < (unsigned)Wo) {                                                                  \
           le = *reinterpret_cast<const uint4*>(xn + ((size_t)(row) * Wo + col_) * 64 + (t & 7) * 8);          \
+          edge_ok = true;                                                                                     \
+        }                                                                                                     \
       }                                                                                                       \
     }                                                                                                         \
   } while (0)
@@ -447,6 +476,13 @@ __global__ __launch_bounds__(256, 2) void last_up_rows_kernel(const uint16_t* __
     for (int k = 0; k < strip + 2; ++k) {
       uint16_t* slot = ring + (k % 3) * ((LU_MAXC + 2) * LU_PXS);
       {
+        if (pre.mean && row_ok) {
+          if ((t >> 3) < chunk) bn8(lv0);
+          if ((t >> 3) + 32 < chunk) bn8(lv1);
+          if ((t >> 3) + 64 < chunk) bn8(lv2);
+          if ((t >> 3) + 96 < chunk) bn8(lv3);
+          if (t < 16 && edge_ok) bn8(le);
+        }
         uint16_t* d = slot + (1 + (t >> 3)) * LU_PXS + (t & 7) * 8;
         if ((t >> 3) < chunk) *reinterpret_cast<uint4*>(d) = lv0;
         if ((t >> 3) + 32 < chunk) *reinterpret_cast<uint4*>(d + 32 * LU_PXS) = lv1;
@@ -768,8 +804,15 @@ int rg_skinny_first_down(const float* x, const float* w, const float* bias, void
   })
 }
 
+bool rg_skinny_last_up_pre_supported(int Wo, int O, int dtype) {
+  int chunk;
+  return dtype == RG_BF16 && O == 64 && sk_rows_chunk(Wo, &chunk);
+}
 int rg_skinny_last_up(const void* x, const float* w, const float* bias, float* y, int N, int Ho, int Wo, int O, int I,
-                      int apply_tanh, int dtype, hipStream_t st) {
+                      int apply_tanh, int dtype, hipStream_t st, const float* pre_mean, const float* pre_invstd,
+                      const float* pre_gamma, const float* pre_beta, float pre_slope) {
+  const LuPre pre{pre_mean, pre_invstd, pre_gamma, pre_beta, pre_slope};
+  RG_REQUIRE(!pre_mean || rg_skinny_last_up_pre_supported(Wo, O, dtype), RG_EUNSUPPORTED, "last_up: fused BatchNorm input");
   (void)I;
   static int lu_valu = -1;
   if (lu_valu < 0) { const char* e = getenv("RNAGAN_SKINNY_VALU"); lu_valu = (e && e[0] == '1') ? 1 : 0; }
@@ -780,7 +823,7 @@ int rg_skinny_last_up(const void* x, const float* w, const float* bias, float* y
     long long nstrips = (long long)N * (Ho / strip) * (Wo / chunk);
     int blocks = nstrips < 512 ? (int)nstrips : 512;
     hipLaunchKernelGGL(last_up_rows_kernel, dim3(blocks), dim3(256), 0, st, (const uint16_t*)x, w, bias, y, N, Ho, Wo,
-                       apply_tanh, chunk, strip, (int)nstrips);
+                       apply_tanh, chunk, strip, (int)nstrips, pre);
     RG_LAUNCH_CHECK("last_up(mfma)");
     return RG_OK;
   }

@@ -343,8 +343,14 @@ def gen_forward(ops, G: GenNet, noise, update_running=True, keep=True):
     z = ops.g0_fwd(noise, G.g0)
     a, mean, invstd = _bn_forward(ops, z, G.bn0, G.slope, update_running)
     ctx.z, ctx.mean, ctx.invstd, ctx.a = [z], [mean], [invstd], [a]
-    for cw, bn in G.blocks:
+    for l, (cw, bn) in enumerate(G.blocks):
         z, st = ops.conv_up(a, cw, want_stats=True)
+        if not keep and l == len(G.blocks) - 1:
+            # nothing is kept for a backward pass: the last BatchNorm + LeakyReLU is applied inside the image layer
+            img = ops.last_up_bn(z, st, bn, G.slope, G.last, G.last.bias, True, update_running)
+            if img is not None:
+                ctx.img = img
+                return img, ctx
         a, mean, invstd = _bn_forward(ops, z, bn, G.slope, update_running, st)
         if keep:
             ctx.z.append(z); ctx.mean.append(mean); ctx.invstd.append(invstd); ctx.a.append(a)

@@ -419,6 +419,30 @@ class HipOps:
         check(self.lib.rg_sign_pack(_ptr(a), _ptr(bits), a.numel() // 64, 64, self.dt, self.stream), "rg_sign_pack")
         return bits
 
+    def last_up_bn(self, z, partials, bn, slope: float, cw: ConvW, bias, tanh: bool, update_running=True):
+        """last_up(lrelu(bn_train(z))) without materialising the normalised activation (a forward that keeps nothing for a
+        backward pass): statistics from the conv epilogue's partial sums (or one reduction pass), BatchNorm + LeakyReLU applied
+        while last_up stages its input rows.  None when this shape has no fused form."""
+        N, Ho, Wo, O = z.shape
+        I = cw.w.shape[1]
+        if self.stat_reduce is not None or not self.lib.rg_last_up_pre_supported(Wo, O, I, self.dt):
+            return None
+        M, C = self._mc(z)
+        rm, rv, nbt = (bn.running_mean, bn.running_var, bn.nbt) if update_running else (None, None, None)
+        if partials is not None:
+            mean, invstd = self._f32(C), self._f32(C)
+            ws = self._ws(32 * 2 * C * 4)
+            check(self.lib.rg_bn_finalize_partials(_ptr(partials), partials.shape[0], M, C, float(bn.eps), float(bn.momentum),
+                                                   _ptr(mean), _ptr(invstd), _ptr(rm), _ptr(rv), _ptr(nbt), _ptr(ws),
+                                                   ws.numel(), self.stream), "rg_bn_finalize_partials")
+        else:
+            mean, invstd = self.bn_stats_finalize(z, bn.eps, bn.momentum, rm, rv, nbt)
+        y = self._f32(N, I, 2 * Ho, 2 * Wo)
+        check(self.lib.rg_last_up_pre(_ptr(z), _ptr(cw.w), _ptr(bias), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(bn.gamma),
+                                      _ptr(bn.beta), float(slope), N, Ho, Wo, O, I, int(tanh), self.dt, self.stream),
+              "rg_last_up_pre")
+        return y
+
     def last_up(self, x, cw: ConvW, bias, tanh: bool):
         N, Ho, Wo, O = x.shape
         I = cw.w.shape[1]

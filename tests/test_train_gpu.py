@@ -467,3 +467,28 @@ def test_generator_inference_fp8():
                 d_mean, d_max = max(d_mean, float(d.mean())), max(d_max, float(d.max()))
     print("fp8 vs bf16 at the reference size: mean |diff| %.4f, max %.4f" % (d_mean, d_max))
     assert d_mean <= 3e-2
+
+
+def test_generator_forward_without_kept_context_fuses_last_batchnorm():
+    """gen_forward(keep=False) applies the last BatchNorm + LeakyReLU inside the image layer (rg_last_up_pre): the images and
+    the running statistics are bit-identical to the forward that materialises the normalised activation (keep=True)."""
+    import torch.nn as nn
+    import rna_gan_amd as P
+    from rna_gan_amd import engine as E
+    from oracle import ref_cpu as R
+    for in_size, n in ((128, 4), (256, 8)):
+        G0 = R.seeded_fill_(R.OracleDCGANGenerator(128, in_size, 3, 64, nonlinearity=nn.LeakyReLU(0.2),
+                                                   last_nonlinearity=nn.Tanh()), 7)
+        out = []
+        for keep in (True, False):
+            G = P.DCGANGenerator(128, in_size, 3, 64, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+            G.load_state_dict(G0.state_dict())
+            G = G.cuda().train()
+            ops, gn = G.runtime()
+            nz = R.synthetic_normal(n, 128, seed=200).cuda()
+            img, _ = E.gen_forward(ops, gn, nz, keep=keep)
+            torch.cuda.synchronize()
+            out.append((img.clone(), {k: b.clone() for k, b in G.named_buffers()}))
+        assert torch.equal(out[0][0], out[1][0])
+        for k in out[0][1]:
+            assert torch.equal(out[0][1][k], out[1][1][k]), k
