@@ -243,9 +243,12 @@ def hip_workload(args, rank, world, device):
             # iteration's RNA rows ONCE (first train_op) and the other two reuse the latent (new_batch() drops it, so
             # every iteration encodes although this benchmark reuses one resident RNA tensor)
             PL.new_batch()
-            return [lg.step(G, Dm, og, rna, draw_u()),
-                    ld.step(G, Dm, od, real, rna, draw_u()),
-                    lp.step(G, Dm, od, real, rna, draw_u(), draw_eps())]
+            u_g, u_d, u_p = draw_u(), draw_u(), draw_u()       # same order of draws as three separate train_ops
+            # the D-loss step is told the penalty step's draw: both fake batches (same generator weights) come out of one
+            # generator pass over the double batch; the penalty step picks its fake up (losses._FAKE)
+            return [lg.step(G, Dm, og, rna, u_g),
+                    ld.step(G, Dm, od, real, rna, u_d, next_u=u_p),
+                    lp.step(G, Dm, od, real, rna, u_p, draw_eps())]
 
     info = {"ops": ops, "rna_features": rna_features, "api_path": api_info,
             "workload": "RNA-GAN lung (betaVAE-conditioned wganvae path) 256x256, %s enc2048/step64, "

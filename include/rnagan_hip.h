@@ -247,10 +247,14 @@ int rg_bn_finalize_partials(const float* partial, int G, int M, int C, float eps
 /* Two batch groups in one call (the D-loss step runs D(real) and D(fake) -- src/wgan_loss.py:241-253 -- as one double
  * batch through the conv layers; BatchNorm must treat the halves as the two separate forward calls they are in the
  * reference): z / a / ga / gz are [2*M][C] (first half first), mean / invstd / s_gy / s_gyxh [2][C].  rg_bn_forward_g2 =
- * rg_bn_forward_partials (partial != NULL: [2*G][2][C]) or rg_bn_forward (partial == NULL) on the first half, then on the
- * second (running statistics and num_batches_tracked updated in that order); rg_bn_act_bwd_g2 = rg_bn_act_bwd on both
+ * rg_bn_forward_partials (partial != NULL: 2*G rows [.][2][C] laid out [nblk][2 halves][G/nblk] -- nblk = 1 for
+ * rg_conv_down's row-tile order, 4 for rg_conv_up's class-major order) or rg_bn_forward (partial == NULL) on the first half,
+ * then on the second (running statistics and num_batches_tracked updated in that order); rg_bn_act_bwd_g2 = rg_bn_act_bwd on both
  * halves with dgamma / dbeta summed.  Workspace: twice rg_colreduce_workspace_bytes(M, C, 2). */
-int rg_bn_forward_g2(const float* partial, int G, const void* z, int M, int C, float eps, float momentum,
+int rg_bn_finalize_partials_g2(const float* partial, int G, int nblk, int M, int C, float eps, float momentum, float* mean,
+                               float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                               void* ws, size_t ws_bytes, void* stream);
+int rg_bn_forward_g2(const float* partial, int G, int nblk, const void* z, int M, int C, float eps, float momentum,
                      const float* gamma, const float* beta, float slope, float* mean, float* invstd, float* running_mean,
                      float* running_var, int64_t* num_batches_tracked, void* a, int dtype, void* ws, size_t ws_bytes,
                      void* stream);

@@ -140,6 +140,9 @@ class RefOps:
     def last_up_bn(self, z, partials, bn, slope, cw, bias, tanh, update_running=True):
         return None
 
+    def last_up_bn2(self, z, partials, bn, slope, cw, bias, tanh, update_running=True):
+        return None
+
     def last_up(self, x, cw: ConvW, bias, tanh: bool):
         y = F.conv_transpose2d(self._nchw(x), self._wq(cw.w), bias, stride=2, padding=1)
         return torch.tanh(y) if tanh else y.contiguous()
@@ -218,7 +221,7 @@ class RefOps:
         return self.bn_act(z, mean, invstd, gamma, beta, slope), mean, invstd
 
     def bn_forward2(self, z, gamma, beta, slope: float, eps: float, momentum: float, running_mean=None,
-                    running_var=None, nbt=None, partials=None):
+                    running_var=None, nbt=None, partials=None, nblk=1):
         n = z.shape[0] // 2
         r = [self.bn_forward(z[h * n:(h + 1) * n], gamma, beta, slope, eps, momentum, running_mean, running_var, nbt)
              for h in range(2)]

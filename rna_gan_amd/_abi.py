@@ -67,7 +67,8 @@ PROTOTYPES = {
     "rg_bn_finalize_partials": (_i, [_p, _i, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p, _z, _p]),
     "rg_last_up_pre_supported": (_i, [_i, _i, _i, _i]),
     "rg_last_up_pre": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "rg_bn_forward_g2": (_i, [_p, _i, _p, _i, _i, _f, _f, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _p, _z, _p]),
+    "rg_bn_forward_g2": (_i, [_p, _i, _i, _p, _i, _i, _f, _f, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _p, _z, _p]),
+    "rg_bn_finalize_partials_g2": (_i, [_p, _i, _i, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p, _z, _p]),
     "rg_bn_tangent": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p, _z, _p]),
     "rg_bn_double_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i,
                               _p, _z, _p]),

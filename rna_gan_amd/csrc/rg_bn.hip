@@ -91,15 +91,21 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(F f, int M, int C, int r
 }
 
 // finishing pass: block = 32 channels x 8 partial-row lanes
+// Partial-row layout with groups: [nblk][groups][G / nblk] rows (nblk = 1: group-major; nblk = 4: the transposed conv's
+// statistics, whose rows are ordered by output-parity class first and row tile second, so a batch half is the first / second
+// half of EVERY class block).
+__device__ __forceinline__ size_t group_row(int r, int grp, int groups, int Gb) { return (size_t)((r / Gb) * groups + grp) * Gb + r % Gb; }
+
 template <int NQ, class Fin>
-__global__ __launch_bounds__(256) void colfinish_kernel(Fin fin, const float* partial, int C, int G, int groups = 1) {
+__global__ __launch_bounds__(256) void colfinish_kernel(Fin fin, const float* partial, int C, int G, int groups = 1,
+                                                        int nblk = 1) {
   __shared__ float sm[8][NQ][32];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + tx;
   // groups are finished one after the other by the same thread: a finisher that updates shared state (running statistics,
   // accumulated parameter gradients) sees them in order, exactly as consecutive calls would
   for (int grp = 0; grp < groups; ++grp) {
-    const float* part = partial + (size_t)grp * G * NQ * C;
+    const int Gb = G / nblk;
     float s[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) s[q] = 0.f;
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(256) void colfinish_kernel(Fin fin, const float* pa
 #pragma unroll 4
       for (int g = ty; g < G; g += 8)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) s[q] += part[((size_t)g * NQ + q) * C + c];
+        for (int q = 0; q < NQ; ++q) s[q] += partial[(group_row(g, grp, groups, Gb) * NQ + q) * C + c];
     }
     if (grp) __syncthreads();
 #pragma unroll
@@ -133,14 +139,15 @@ __global__ __launch_bounds__(256) void colfinish_kernel(Fin fin, const float* pa
 // gridDim.y slices the partial rows (each slice finished by its own block: fin gets c + slice*C as the channel index,
 // i.e. a Store2Fin pointed at a [slices][C] staging area produces the input of a second, small colfinish pass).
 template <int NQ, class Fin>
-__global__ __launch_bounds__(256) void colfinish_wide_kernel(Fin fin, const float* __restrict__ partial, int C, int G) {
+__global__ __launch_bounds__(256) void colfinish_wide_kernel(Fin fin, const float* __restrict__ partial, int C, int G,
+                                                             int nblk = 1) {
   __shared__ float sm[4][NQ][8];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int c0 = blockIdx.x * 8;
   const int per = (G + gridDim.y - 1) / gridDim.y;
   const int g0 = blockIdx.y * per, g1 = min(G, g0 + per);
-  partial += (size_t)blockIdx.z * G * NQ * C;             // batch group (see shift_group)
-  shift_group(fin, (int)blockIdx.z, 0);
+  const int grp = (int)blockIdx.z, groups = (int)gridDim.z, Gb = G / nblk;       // batch group (see shift_group)
+  shift_group(fin, grp, 0);
   float acc[NQ][8];
 #pragma unroll
   for (int q = 0; q < NQ; ++q)
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(256) void colfinish_wide_kernel(Fin fin, const floa
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       float v[8];
-      Vec<float, 8>::ld(partial + ((size_t)g * NQ + q) * C + c0, v);
+      Vec<float, 8>::ld(partial + (group_row(g, grp, groups, Gb) * NQ + q) * C + c0, v);
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[q][k] += v[k];
     }
@@ -746,8 +753,38 @@ extern "C" int rg_bn_finalize_partials(const float* partial, int G, int M, int C
 
 // Two batch groups in one call: z / a are [2*M][C] (group-major), mean / invstd [2][C]; statistics, normalisation and the
 // running-statistics update exactly as two consecutive rg_bn_forward(_partials) calls on the halves (first half first).
-// partial (may be NULL): conv-epilogue column sums [2*G][2][C], the first G rows belonging to the first half.
-extern "C" int rg_bn_forward_g2(const float* partial, int G, const void* z, int M, int C, float eps, float momentum,
+// partial (may be NULL): conv-epilogue column sums, 2*G rows [.][2][C] laid out [nblk][2 halves][G / nblk]: nblk = 1 for
+// rg_conv_down (rows in row-tile order: the first G rows are the first half), nblk = 4 for rg_conv_up (class-major rows).
+static int finalize_partials_g2(const char* name, const float* partial, int G, int nblk, int C, StatsFinalizeFin fin, void* ws,
+                                size_t ws_bytes, hipStream_t st) {
+  constexpr int SLICES = 32;
+  RG_REQUIRE(nblk >= 1 && G % nblk == 0, RG_EINVAL, "%s: partial rows %d not a multiple of %d blocks", name, G, nblk);
+  if (G > 512 && C % 8 == 0 && ws && ws_bytes >= (size_t)2 * SLICES * 2 * C * sizeof(float)) {
+    float* stage = (float*)ws;
+    hipLaunchKernelGGL((colfinish_wide_kernel<2, SliceFin>), dim3(C / 8, SLICES, 2), dim3(256), 0, st,
+                       SliceFin{stage, C, SLICES}, partial, C, G, nblk);
+    RG_LAUNCH_CHECK(name);
+    hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, stage, C, SLICES,
+                       2, 1);
+  } else {
+    hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, partial, C, G, 2,
+                       nblk);
+  }
+  RG_LAUNCH_CHECK(name);
+  return RG_OK;
+}
+
+// rg_bn_finalize_partials for two batch groups (mean / invstd [2][C]); nblk as in rg_bn_forward_g2.
+extern "C" int rg_bn_finalize_partials_g2(const float* partial, int G, int nblk, int M, int C, float eps, float momentum,
+                                          float* mean, float* invstd, float* running_mean, float* running_var,
+                                          int64_t* num_batches_tracked, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(partial && G > 0 && mean && invstd && M > 0 && C > 0, RG_EINVAL, "bn_finalize_partials_g2: bad args");
+  StatsFinalizeFin fin{(float)M, eps, momentum, mean, invstd, running_mean, running_var,
+                       running_mean ? num_batches_tracked : nullptr, C};
+  return finalize_partials_g2("bn_finalize_partials_g2", partial, G, nblk, C, fin, ws, ws_bytes, rg_stream(stream));
+}
+
+extern "C" int rg_bn_forward_g2(const float* partial, int G, int nblk, const void* z, int M, int C, float eps, float momentum,
                                 const float* gamma, const float* beta, float slope, float* mean, float* invstd,
                                 float* running_mean, float* running_var, int64_t* num_batches_tracked, void* a, int dtype,
                                 void* ws, size_t ws_bytes, void* stream) {
@@ -759,19 +796,8 @@ extern "C" int rg_bn_forward_g2(const float* partial, int G, const void* z, int 
   hipStream_t st = rg_stream(stream);
   const size_t gs = (size_t)M * C;
   if (partial) {
-    constexpr int SLICES = 32;
-    if (G > 512 && C % 8 == 0 && ws && ws_bytes >= (size_t)2 * SLICES * 2 * C * sizeof(float)) {
-      float* stage = (float*)ws;
-      hipLaunchKernelGGL((colfinish_wide_kernel<2, SliceFin>), dim3(C / 8, SLICES, 2), dim3(256), 0, st,
-                         SliceFin{stage, C, SLICES}, partial, C, G);
-      RG_LAUNCH_CHECK("bn_forward_g2");
-      hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, stage, C,
-                         SLICES, 2);
-    } else {
-      hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, partial, C, G,
-                         2);
-    }
-    RG_LAUNCH_CHECK("bn_forward_g2");
+    int rc = finalize_partials_g2("bn_forward_g2", partial, G, nblk, C, fin, ws, ws_bytes, st);
+    if (rc) return rc;
     RG_DISPATCH_DTYPE(dtype, T, {
       return (row_apply_g<T, BnActF>("bn_forward_g2", 2, M, C, st, (const T*)z, (T*)a, p, C, gs));
     })

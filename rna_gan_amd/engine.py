@@ -359,6 +359,40 @@ def gen_forward(ops, G: GenNet, noise, update_running=True, keep=True):
     return img, ctx
 
 
+def _class_partials(st, m_half: int):
+    """conv_up's column sums [rows][2][C] (class-major: [4 classes][row tiles]) if every class block splits into the two
+    batch halves at a partial-row boundary, else None.  m_half: low-resolution pixels of one half."""
+    if st is None:
+        return None
+    rows = st.shape[0]
+    if rows % 8:
+        return None
+    per_class = rows // 4
+    if (2 * m_half) % per_class or m_half % ((2 * m_half) // per_class):
+        return None
+    return st
+
+
+def gen_forward_pair(ops, G: GenNet, noise2, update_running=True):
+    """G(z) for TWO noise batches (noise2 = [z_a; z_b], nothing kept for a backward pass) as one double batch through the
+    GEMM / conv layers, BatchNorm per half exactly as two consecutive forward calls would do it (own batch statistics, running
+    statistics updated by the first half first).  The D-loss and the penalty step both need a fake batch from the SAME
+    generator weights (src/wgan_loss.py:247 and :371): their two forwards become one.  Returns images [2n, 3, H, W]."""
+    def run(bn):
+        return (bn.running_mean, bn.running_var, bn.nbt) if update_running else (None, None, None)
+    z = ops.g0_fwd(noise2, G.g0)
+    a, _, _ = ops.bn_forward2(z, G.bn0.gamma, G.bn0.beta, G.slope, G.bn0.eps, G.bn0.momentum, *run(G.bn0))
+    for l, (cw, bn) in enumerate(G.blocks):
+        z, st = ops.conv_up(a, cw, want_stats=True)
+        st = _class_partials(st, a.numel() // a.shape[-1] // 2)
+        if l == len(G.blocks) - 1:
+            img = ops.last_up_bn2(z, st, bn, G.slope, G.last, G.last.bias, True, update_running)
+            if img is not None:
+                return img
+        a, _, _ = ops.bn_forward2(z, bn.gamma, bn.beta, G.slope, bn.eps, bn.momentum, *run(bn), partials=st, nblk=4)
+    return ops.last_up(a, G.last, G.last.bias, True)
+
+
 def upgen_forward(ops, G: UpGenNet, noise, update_running=True, keep=True):
     """DCGANUpGenerator forward (src/dcgan.py:85-99 through the blocks of :36-56,:76-84)."""
     ctx = _Ctx()
@@ -484,15 +518,25 @@ def _half_partials(st, m_half: int, m_total: int, h: int):
     return st[h * (rows // 2):(h + 1) * (rows // 2)]
 
 
-def disc_loss_grads_batched(ops, G, D: DiscNet, real, noise, grad_scale: float = 1.0):
+def disc_loss_grads_batched(ops, G, D: DiscNet, real, noise, grad_scale: float = 1.0, next_noise=None):
     """The D-loss step with D(real) and D(fake) as ONE double batch through the conv layers (forward, data gradient and
     weight gradient: one launch each per layer instead of two, at a size where the 256 x 256-tile kernels need no split-K),
     BatchNorm per half exactly as two separate forward calls would do it (bn_forward2 / bn_act_bwd2: one set of launches over
     two batch groups; own batch statistics, running statistics updated by the real half first -- the reference's call order D(real), G(z), D(fake) of src/wgan_loss.py:241-253 -- own
-    backward reductions, parameter gradients summed).  Same result as disc_loss_grads up to the kernels' tile shapes."""
+    backward reductions, parameter gradients summed).  Same result as disc_loss_grads up to the kernels' tile shapes.
+    next_noise: also produce G(next_noise) -- the fake batch of the penalty step that follows (same generator weights) -- in
+    the same generator pass (gen_forward_pair); returns (loss, fake_next) then."""
     n = real.shape[0]
     R = len(D.blocks)
-    img, _ = _gen_fwd(ops, G, noise, keep=False)
+    fake_next = None
+    if next_noise is not None and isinstance(G, GenNet):
+        # the penalty step that follows needs a fake batch from the same generator weights: both forwards as one double batch
+        img2 = gen_forward_pair(ops, G, torch.cat([noise, next_noise]))
+        img, fake_next = img2[:n], img2[n:]
+    else:
+        img, _ = _gen_fwd(ops, G, noise, keep=False)
+        if next_noise is not None:
+            fake_next, _ = _gen_fwd(ops, G, next_noise, keep=False)
     xs = (real, img)
     H, W = real.shape[2], real.shape[3]
     C0 = D.conv0.w.shape[0]
@@ -531,7 +575,7 @@ def disc_loss_grads_batched(ops, G, D: DiscNet, real, noise, grad_scale: float =
         ops.skinny_wgrad(gz0[n:], xs[1], D.conv0.dw, True)
     ops.col_sum(gz0, D.conv0.dbias, False)
     ops.join()
-    return loss
+    return loss if next_noise is None else (loss, fake_next)
 
 
 def disc_loss_grads(ops, G: GenNet, D: DiscNet, real, noise, grad_scale: float = 1.0):
@@ -544,6 +588,11 @@ def gp_loss_prefix(ops, G, real, noise, eps):
     """fake = G(z); xhat = eps*real + (1-eps)*fake: reads the generator only."""
     img, _ = _gen_fwd(ops, G, noise, keep=False)
     return ops.interp(real, img, eps)
+
+
+def gp_loss_prefix_fake(ops, real, fake, eps):
+    """xhat from a fake batch that is already there (produced with the D-loss step's, see disc_loss_grads_batched)."""
+    return ops.interp(real, fake, eps)
 
 
 def gp_loss_rest(ops, D: DiscNet, xhat, lambd: float, grad_scale: float = 1.0):

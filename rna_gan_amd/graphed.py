@@ -92,8 +92,9 @@ class StepGraph:
                 torch.cuda.synchronize()
                 return self._run()
         self.graph.replay()
-        if torch.is_tensor(self.static_out):
-            self.static_out._rg_static = True      # a captured graph's output IS a persistent buffer (see mark_static)
+        for t in (self.static_out if isinstance(self.static_out, (tuple, list)) else (self.static_out,)):
+            if torch.is_tensor(t):
+                t._rg_static = True                # a captured graph's output IS a persistent buffer (see mark_static)
         for o in self.optimizers:
             o.note_replayed()
         for m in self.modules:

@@ -185,14 +185,69 @@ def _d_prefix(generator, discriminator, real, noise, clip):
     return E.disc_loss_prefix(ops, dn, real.contiguous().float()), noise.contiguous().float()
 
 
-def _d_batched(generator, discriminator, real, noise, clip):
-    """single process: D(real) and D(fake) as one double batch through the conv layers (engine.disc_loss_grads_batched)"""
+def _d_batched(generator, discriminator, real, noise, clip, next_noise=None):
+    """single process: D(real) and D(fake) as one double batch through the conv layers (engine.disc_loss_grads_batched);
+    next_noise: the noise of the penalty step that follows -- its fake batch comes out of the same generator pass"""
     ops, gn, dn = _nets(generator, discriminator)
     if clip is not None:
         ops.clamp_(discriminator.flat.data, clip[0], clip[1])
         discriminator.weights_changed()
     return E.disc_loss_grads_batched(ops, gn, dn, real.contiguous().float(), noise.contiguous().float(),
-                                     grad_scale=D_.grad_scale())
+                                     grad_scale=D_.grad_scale(),
+                                     next_noise=None if next_noise is None else next_noise.contiguous().float())
+
+
+class _FakeCache:
+    """G(noise) of the penalty step, produced ahead by the D-loss step of the same iteration (both need a fake batch from the
+    same generator weights, src/wgan_loss.py:247 and :371; one generator pass over the double batch instead of two).  The
+    entry is used only by a penalty step that is handed the very noise tensor it was produced for, with the generator
+    unchanged in between."""
+
+    def __init__(self):
+        self.key, self.src, self.img = None, None, None
+
+    @staticmethod
+    def make_key(generator, noise_tensors):
+        _, gn = generator.runtime()
+        return (id(generator), gn.g0.version) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in noise_tensors)
+
+    def put(self, generator, noise_tensors, img):
+        self.key, self.src, self.img = self.make_key(generator, noise_tensors), list(noise_tensors), img
+
+    def take(self, generator, noise_tensors):
+        if self.key is None or self.key != self.make_key(generator, noise_tensors):
+            return None
+        img = self.img
+        self.key, self.src, self.img = None, None, None
+        return img
+
+
+_FAKE = _FakeCache()
+LOOKAHEAD = os.environ.get("RNAGAN_FAKE_LOOKAHEAD", "1") != "0"
+
+
+_NEXT_NOISE = [None]            # Trainer flow: the penalty step's noise, drawn by the D-loss plugin right after its own
+TRAINER_LOOKAHEAD = [False]     # set by Trainer when a gradient-penalty plugin directly follows the D-loss plugin
+
+
+def _lookahead_ok():
+    return LOOKAHEAD and D_BATCHED and not D_.active()
+
+
+def _d_step_lookahead(runner, key, generator, discriminator, optimizer, clip, inputs, noise_fn, next_tensors):
+    """D-loss step whose generator pass also produces the fake batch of the penalty step that follows (kept in _FAKE)."""
+    body = _d_body(generator, discriminator, clip, noise_fn, lookahead=True)
+    loss, fake_next = _dispatch(runner, key + ("lookahead",), body, inputs, generator, discriminator, discriminator, optimizer)
+    _FAKE.put(generator, next_tensors, fake_next)
+    return loss
+
+
+def _gp_fake_body(generator, discriminator, lambd):
+    """penalty step on a fake batch that is already there: inputs (real, fake, eps)"""
+    def prefix(real, fake, eps):
+        ops, _, _ = _nets(generator, discriminator)
+        return E.gp_loss_prefix_fake(ops, real.contiguous().float(), fake, eps if torch.is_tensor(eps) else float(eps))
+    return _Body(prefix, lambda xhat: _gp_rest(generator, discriminator, xhat, lambd), generator)
 
 
 def _d_rest(generator, discriminator, pre):
@@ -251,8 +306,12 @@ def _g_body(generator, discriminator, noise_fn=None):
                  lambda pre: _g_rest(generator, discriminator, pre), generator)
 
 
-def _d_body(generator, discriminator, clip, noise_fn=None):
+def _d_body(generator, discriminator, clip, noise_fn=None, lookahead=False):
     nf = noise_fn or (lambda nz: nz)
+    if lookahead:
+        # inputs (real, *conditioning, noise, next_noise): the penalty step's fake batch comes out of this step's generator pass
+        return _Body(None, None, discriminator,
+                     lambda real, *a: _d_batched(generator, discriminator, real, nf(*a[:-1]), clip, nf(*a[:-2], a[-1])))
     whole = (lambda real, *a: _d_batched(generator, discriminator, real, nf(*a), clip)) if D_BATCHED else None
     return _Body(lambda real, *a: _d_prefix(generator, discriminator, real, nf(*a), clip),
                  lambda pre: _d_rest(generator, discriminator, pre), discriminator, whole)
@@ -422,8 +481,13 @@ class WassersteinDiscriminatorLoss(DiscriminatorLoss):
     def forward(self, fx, fgz):
         return wasserstein_discriminator_loss(fx, fgz, self.reduction)
 
-    def step(self, generator, discriminator, optimizer_discriminator, real, noise):
+    def step(self, generator, discriminator, optimizer_discriminator, real, noise, next_noise=None):
+        """next_noise: the noise tensor the gradient-penalty step of this iteration will be called with; its fake batch is
+        then produced by this step's generator pass (same generator weights) and picked up by that step."""
         clip = self.clip
+        if next_noise is not None and _lookahead_ok():
+            return _d_step_lookahead(self._runner, ("d", clip), generator, discriminator, optimizer_discriminator, clip,
+                                     [real, noise, next_noise], None, (next_noise,))
         return _dispatch(self._runner, ("d", clip), _d_body(generator, discriminator, clip),
                          [real, noise], generator, discriminator, discriminator, optimizer_discriminator)
 
@@ -431,7 +495,10 @@ class WassersteinDiscriminatorLoss(DiscriminatorLoss):
         _check_labels(generator, discriminator, labels)
         batch_size = real_inputs.size(0)
         noise = torch.randn(batch_size, generator.encoding_dims, device=device)
-        return self.step(generator, discriminator, optimizer_discriminator, real_inputs.to(device), noise).item()
+        nxt = None
+        if TRAINER_LOOKAHEAD[0] and _lookahead_ok():       # the penalty plugin's randn, drawn now (same generator order)
+            nxt = _NEXT_NOISE[0] = torch.randn(batch_size, generator.encoding_dims, device=device)
+        return self.step(generator, discriminator, optimizer_discriminator, real_inputs.to(device), noise, nxt).item()
 
 
 class WassersteinGradientPenalty(DiscriminatorLoss):
@@ -447,13 +514,19 @@ class WassersteinGradientPenalty(DiscriminatorLoss):
     def step(self, generator, discriminator, optimizer_discriminator, real, noise, eps):
         """eps: 1-element float32 device tensor (read inside the graph)."""
         lambd = self.lambd
+        fake = _FAKE.take(generator, (noise,)) if not D_.active() else None
+        if fake is not None:                  # G(noise) came out of the D-loss step's generator pass
+            return _dispatch(self._runner, ("gpf", lambd), _gp_fake_body(generator, discriminator, lambd),
+                             [real, fake, eps], generator, discriminator, discriminator, optimizer_discriminator)
         return _dispatch(self._runner, ("gp", lambd), _gp_body(generator, discriminator, lambd),
                          [real, noise, eps], generator, discriminator, discriminator, optimizer_discriminator)
 
     def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
         _check_labels(generator, discriminator, labels)
         batch_size = real_inputs.size(0)
-        noise = torch.randn(batch_size, generator.encoding_dims, device=device)
+        noise, _NEXT_NOISE[0] = _NEXT_NOISE[0], None       # drawn ahead by the D-loss plugin (Trainer flow), else now
+        if noise is None or noise.shape != (batch_size, generator.encoding_dims):
+            noise = torch.randn(batch_size, generator.encoding_dims, device=device)
         eps = _pinned(1).uniform_(0.0, 1.0).to(device, non_blocking=True)   # CPU generator, as the reference
         return self.step(generator, discriminator, optimizer_discriminator, real_inputs.to(device), noise,
                          eps).item()
@@ -488,9 +561,15 @@ _LATENT = _LatentCache()
 LATENT_CACHE = os.environ.get("RNAGAN_LATENT_CACHE", "1") != "0"
 
 
+def _drop_lookahead():
+    _NEXT_NOISE[0] = None
+    _FAKE.key, _FAKE.src, _FAKE.img = None, None, None
+
+
 def new_batch():
-    """Start of a new batch: forget the cached conditioning latent."""
+    """Start of a new batch: forget the cached conditioning latent (and anything prepared ahead for a step that never ran)."""
     _LATENT.clear()
+    _drop_lookahead()
 
 
 class _VAEMixin:
@@ -565,17 +644,25 @@ class WassersteinDiscriminatorLossVAE(DiscriminatorLoss, _VAEMixin):
     def forward(self, fx, fgz):
         return wasserstein_discriminator_loss_vae(fx, fgz, self.reduction)
 
-    def step(self, generator, discriminator, optimizer_discriminator, real, rna, u):
+    def step(self, generator, discriminator, optimizer_discriminator, real, rna, u, next_u=None):
+        """next_u: the uniform draw the gradient-penalty step of this iteration will be called with (same RNA batch): its fake
+        batch is then produced by this step's generator pass and picked up by that step."""
         clip = self.clip
-        return _dispatch(self._runner, ("d", clip),
-                         _d_body(generator, discriminator, clip, lambda z, uu: self._noise(generator, z, uu)),
+        nf = lambda z, uu: self._noise(generator, z, uu)
+        if next_u is not None and _lookahead_ok():
+            return _d_step_lookahead(self._runner, ("d", clip), generator, discriminator, optimizer_discriminator, clip,
+                                     [real, self._latent(rna), u, next_u], nf, (next_u,))
+        return _dispatch(self._runner, ("d", clip), _d_body(generator, discriminator, clip, nf),
                          [real, self._latent(rna), u], generator, discriminator, discriminator, optimizer_discriminator)
 
     def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
         _check_labels(generator, discriminator, labels)
         rna, u = self._inputs(generator, real_inputs, device)
+        nxt = None
+        if TRAINER_LOOKAHEAD[0] and _lookahead_ok():       # the penalty plugin's draw, made now (same generator order)
+            nxt = _NEXT_NOISE[0] = self._inputs(generator, real_inputs, device)[1]
         real = real_inputs["image"].to(device)
-        return self.step(generator, discriminator, optimizer_discriminator, real, rna, u).item()
+        return self.step(generator, discriminator, optimizer_discriminator, real, rna, u, nxt).item()
 
 
 class WassersteinGradientPenaltyVAE(DiscriminatorLoss, _VAEMixin):
@@ -592,13 +679,21 @@ class WassersteinGradientPenaltyVAE(DiscriminatorLoss, _VAEMixin):
 
     def step(self, generator, discriminator, optimizer_discriminator, real, rna, u, eps):
         lambd = self.lambd
+        fake = _FAKE.take(generator, (u,)) if not D_.active() else None
+        if fake is not None:                  # G(noise(u)) came out of the D-loss step's generator pass
+            return _dispatch(self._runner, ("gpf", lambd), _gp_fake_body(generator, discriminator, lambd),
+                             [real, fake, eps], generator, discriminator, discriminator, optimizer_discriminator)
         return _dispatch(self._runner, ("gp", lambd),
                          _gp_body(generator, discriminator, lambd, lambda z, uu: self._noise(generator, z, uu)),
                          [real, self._latent(rna), u, eps], generator, discriminator, discriminator, optimizer_discriminator)
 
     def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
         _check_labels(generator, discriminator, labels)
-        rna, u = self._inputs(generator, real_inputs, device)
+        ahead, _NEXT_NOISE[0] = _NEXT_NOISE[0], None       # u drawn ahead by the D-loss plugin (Trainer flow), else now
+        if ahead is not None and ahead.shape == (real_inputs["image"].size(0), generator.encoding_dims):
+            rna, u = real_inputs["rna_data"], ahead
+        else:
+            rna, u = self._inputs(generator, real_inputs, device)
         real = real_inputs["image"].to(device)
         eps = _pinned(1).uniform_(0.0, 1.0).to(device, non_blocking=True)   # torch.rand(1) in the reference (:376)
         return self.step(generator, discriminator, optimizer_discriminator, real, rna, u, eps).item()

@@ -443,6 +443,34 @@ class HipOps:
               "rg_last_up_pre")
         return y
 
+    def last_up_bn2(self, z, partials, bn, slope: float, cw: ConvW, bias, tanh: bool, update_running=True):
+        """last_up_bn for a double batch whose halves are two separate forward calls (own statistics, running statistics
+        updated by the first half first): z [2n, ...], partials = conv_up's class-major column sums or None."""
+        N2, Ho, Wo, O = z.shape
+        I = cw.w.shape[1]
+        n = N2 // 2
+        if self.stat_reduce is not None or N2 % 2 or not self.lib.rg_last_up_pre_supported(Wo, O, I, self.dt):
+            return None
+        M2, C = self._mc(z)
+        M = M2 // 2
+        rm, rv, nbt = (bn.running_mean, bn.running_var, bn.nbt) if update_running else (None, None, None)
+        if partials is not None:
+            mean, invstd = self._f32(2, C), self._f32(2, C)
+            ws = self._ws(2 * 32 * 2 * C * 4)
+            check(self.lib.rg_bn_finalize_partials_g2(_ptr(partials), partials.shape[0] // 2, 4, M, C, float(bn.eps),
+                                                      float(bn.momentum), _ptr(mean), _ptr(invstd), _ptr(rm), _ptr(rv),
+                                                      _ptr(nbt), _ptr(ws), ws.numel(), self.stream),
+                  "rg_bn_finalize_partials_g2")
+        else:
+            st = [self.bn_stats_finalize(z[h * n:(h + 1) * n], bn.eps, bn.momentum, rm, rv, nbt) for h in range(2)]
+            mean, invstd = torch.stack([st[0][0], st[1][0]]), torch.stack([st[0][1], st[1][1]])
+        y = self._f32(N2, I, 2 * Ho, 2 * Wo)
+        for h in range(2):
+            check(self.lib.rg_last_up_pre(_ptr(z[h * n:(h + 1) * n]), _ptr(cw.w), _ptr(bias), _ptr(y[h * n:(h + 1) * n]),
+                                          _ptr(mean[h]), _ptr(invstd[h]), _ptr(bn.gamma), _ptr(bn.beta), float(slope), n, Ho, Wo,
+                                          O, I, int(tanh), self.dt, self.stream), "rg_last_up_pre")
+        return y
+
     def last_up(self, x, cw: ConvW, bias, tanh: bool):
         N, Ho, Wo, O = x.shape
         I = cw.w.shape[1]
@@ -608,10 +636,10 @@ class HipOps:
         return a, mean, invstd
 
     def bn_forward2(self, z, gamma, beta, slope: float, eps: float, momentum: float, running_mean=None,
-                    running_var=None, nbt=None, partials=None):
+                    running_var=None, nbt=None, partials=None, nblk=1):
         """bn_forward on the two batch halves of z ([2n, ...]) in one set of launches: (a, mean[2][C], invstd[2][C]), running
         statistics updated by the first half, then the second -- exactly two bn_forward calls.  partials: the conv
-        epilogue's column sums with the first half of the rows belonging to the first batch half, or None."""
+        epilogue's column sums laid out [nblk][2 halves][rows] (nblk = 1: conv_down, 4: conv_up's class-major rows), or None."""
         M2, C = self._mc(z)
         M = M2 // 2
         assert M2 % 2 == 0 and self.stat_reduce is None
@@ -619,7 +647,7 @@ class HipOps:
         a = torch.empty_like(z)
         ws = self._ws(2 * self.lib.rg_colreduce_workspace_bytes(M, C, 2) + 2 * 32 * 2 * C * 4)
         G = 0 if partials is None else partials.shape[0] // 2
-        check(self.lib.rg_bn_forward_g2(_ptr(partials), G, _ptr(z), M, C, float(eps), float(momentum), _ptr(gamma),
+        check(self.lib.rg_bn_forward_g2(_ptr(partials), G, int(nblk), _ptr(z), M, C, float(eps), float(momentum), _ptr(gamma),
                                         _ptr(beta), float(slope), _ptr(mean), _ptr(invstd), _ptr(running_mean),
                                         _ptr(running_var), _ptr(nbt), _ptr(a), self.dt, _ptr(ws), ws.numel(), self.stream),
               "rg_bn_forward_g2")

@@ -145,6 +145,14 @@ class Trainer:
     def _store_loss_maps(self):
         self._arg_maps = {name: self._get_argument_maps(loss.arg_map, loss.train_ops)
                           for name, loss in self.losses.items()}
+        # a gradient-penalty plugin directly behind the D-loss plugin (the reference's loss list): the D-loss plugin then
+        # draws the penalty's noise right after its own and produces both fake batches in one generator pass
+        names = list(self.losses.values())
+        L.TRAINER_LOOKAHEAD[0] = any(
+            isinstance(a, (L.WassersteinDiscriminatorLoss, L.WassersteinDiscriminatorLossVAE)) and
+            isinstance(b, (L.WassersteinGradientPenalty, L.WassersteinGradientPenaltyVAE)) and
+            isinstance(a, L._VAEMixin) == isinstance(b, L._VAEMixin)
+            for a, b in zip(names, names[1:]))
 
     def train_iter(self):
         lgen, ldis, gen_iter, dis_iter = 0.0, 0.0, 0, 0

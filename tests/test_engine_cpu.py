@@ -179,3 +179,21 @@ def test_batched_d_step_matches_autograd(in_size, step, enc, n):
     assert_close_dict(grads_of(D2), grads_of(D), 1e-7, 1e-10)
     assert_close_dict(bufs_of(D2), bufs_of(D), 1e-9, 1e-12)
     assert_close_dict(bufs_of(G2), bufs_of(G), 1e-9, 1e-12)
+
+
+def test_generator_forward_pair_equals_two_forwards():
+    """engine.gen_forward_pair (two noise batches as one double batch, BatchNorm per half) against two consecutive
+    gen_forward calls: images and running statistics (updated by the first half first)."""
+    torch.manual_seed(0)
+    G, _ = mk(32, 4, 16)
+    G2 = copy.deepcopy(G)
+    G.train(); G2.train()
+    ops = RefOps(torch.float64)
+    Gn, Gn2 = E.build_gen_net(G), E.build_gen_net(G2)
+    za, zb = R.synthetic_normal(3, 16, seed=4).double(), R.synthetic_normal(3, 16, seed=5).double()
+    ia, _ = E.gen_forward(ops, Gn, za, keep=False)
+    ib, _ = E.gen_forward(ops, Gn, zb, keep=False)
+    pair = E.gen_forward_pair(ops, Gn2, torch.cat([za, zb]))
+    np.testing.assert_allclose(pair[:3].numpy(), ia.numpy(), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(pair[3:].numpy(), ib.numpy(), rtol=1e-10, atol=1e-12)
+    assert_close_dict(bufs_of(G2), bufs_of(G), 1e-10, 1e-13)

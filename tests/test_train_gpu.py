@@ -492,3 +492,33 @@ def test_generator_forward_without_kept_context_fuses_last_batchnorm():
         assert torch.equal(out[0][0], out[1][0])
         for k in out[0][1]:
             assert torch.equal(out[0][1][k], out[1][1][k]), k
+
+
+@pytest.mark.parametrize("in_size,n", [(64, 8), (256, 64)])
+def test_generator_forward_pair_on_gpu(in_size, n):
+    """engine.gen_forward_pair on the HIP path against two gen_forward calls: images within bf16 noise of a different tile
+    shape, running statistics equal (first half first)."""
+    import torch.nn as nn
+    import rna_gan_amd as P
+    from rna_gan_amd import engine as E
+    from oracle import ref_cpu as R
+    G0 = R.seeded_fill_(R.OracleDCGANGenerator(128, in_size, 3, 64, nonlinearity=nn.LeakyReLU(0.2),
+                                               last_nonlinearity=nn.Tanh()), 7)
+    za, zb = R.synthetic_normal(n, 128, seed=200).cuda(), R.synthetic_normal(n, 128, seed=201).cuda()
+    res = []
+    for pair in (False, True):
+        G = P.DCGANGenerator(128, in_size, 3, 64, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+        G.load_state_dict(G0.state_dict())
+        G = G.cuda().train()
+        ops, gn = G.runtime()
+        if pair:
+            img = E.gen_forward_pair(ops, gn, torch.cat([za, zb]))
+        else:
+            img = torch.cat([E.gen_forward(ops, gn, za, keep=False)[0], E.gen_forward(ops, gn, zb, keep=False)[0]])
+        torch.cuda.synchronize()
+        res.append((img.clone(), {k: b.double().clone() for k, b in G.named_buffers()}))
+    a, b = res[0][0], res[1][0]
+    assert float((a - b).abs().mean()) <= 5e-3 and float((a - b).abs().max()) <= 0.25, (float((a - b).abs().mean()),
+                                                                                          float((a - b).abs().max()))
+    for k in res[0][1]:
+        assert torch.allclose(res[0][1][k], res[1][1][k], rtol=2e-3, atol=1e-4), k

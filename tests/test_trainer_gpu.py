@@ -314,3 +314,51 @@ def test_betavae_encode_reference_fixtures(golden_dir, precision, tol):
     assert float(np.abs(zc[:, :64] - fx["z_mean_first"]).max()) <= tol * scale
     assert float(np.abs(zc[:, -64:] - fx["z_mean_last"]).max()) <= tol * scale
     np.testing.assert_allclose((zc ** 2).sum(1), fx["z_mean_sumsq"], rtol=4 * tol)
+
+
+def test_penalty_fake_from_the_d_step_generator_pass():
+    """D-loss step with next_noise: the penalty step's fake batch comes out of the D-loss step's generator pass (one double
+    batch) and the penalty step picks it up; same training as three independent train_ops with the same noise (within the
+    bf16 noise of different tile shapes), and a penalty step called with other noise ignores the cached batch."""
+    import torch.nn as nn
+    import rna_gan_amd as P
+    from rna_gan_amd import losses as PL
+    from oracle import ref_cpu as R
+    in_size, step, enc, n = 64, 64, 128, 8
+    G0 = R.seeded_fill_(R.OracleDCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh()), 7)
+    D0 = R.seeded_fill_(R.OracleDCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.LeakyReLU(0.2)), 8)
+    res = []
+    for ahead in (False, True):
+        G = P.DCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+        D = P.DCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.LeakyReLU(0.2))
+        G.load_state_dict(G0.state_dict()); D.load_state_dict(D0.state_dict())
+        G, D = G.cuda().train(), D.cuda().train()
+        og = P.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.999)).bind(G)
+        od = P.Adam(D.parameters(), lr=4e-4, betas=(0.5, 0.999)).bind(D)
+        lg, ld, lp = PL.WassersteinGeneratorLoss(), PL.WassersteinDiscriminatorLoss(), PL.WassersteinGradientPenalty()
+        out = []
+        for it in range(5):                       # eager, eager, then captured graphs
+            PL.new_batch()
+            real = R.synthetic_images(n, in_size, seed=100 + it).cuda()
+            nz = [R.synthetic_normal(n, enc, seed=200 + 3 * it + j).cuda() for j in range(3)]
+            eps = torch.tensor([0.1 + 0.2 * it], device="cuda")
+            out.append(lg.step(G, D, og, nz[0]).item())
+            out.append(ld.step(G, D, od, real, nz[1], next_noise=nz[2] if ahead else None).item())
+            if ahead:
+                assert PL._FAKE.key is not None
+            out.append(lp.step(G, D, od, real, nz[2], eps).item())
+            assert PL._FAKE.key is None
+        if ahead:                                 # a cached batch for OTHER noise is not used
+            real = R.synthetic_images(n, in_size, seed=300).cuda()
+            a, b, c = (R.synthetic_normal(n, enc, seed=400 + j).cuda() for j in range(3))
+            ld.step(G, D, od, real, a, next_noise=b)
+            key = PL._FAKE.key
+            lp.step(G, D, od, real, c, torch.tensor([0.5], device="cuda"))
+            assert PL._FAKE.key == key
+            PL.new_batch()
+            assert PL._FAKE.key is None
+        res.append((out, G.flat.data.float().cpu().clone(), D.flat.data.float().cpu().clone()))
+    (la, ga, da), (lb, gb, db) = res
+    for i, (x, y) in enumerate(zip(la[:9], lb[:9])):          # first three iterations: before the trajectories drift apart
+        assert abs(x - y) <= (0.35 if i % 3 == 2 else 5e-2) * (abs(x) + 1.0), (i, la, lb)
+    assert float((ga - gb).norm() / ga.norm()) <= 2e-2 and float((da - db).norm() / da.norm()) <= 2e-2
