@@ -1149,7 +1149,11 @@ static int gather_split(int M, int Ncols, int nclass, int nkt, bool allow, int c
 // must cover all CUs to pull full bandwidth); none when a mask is fused into the bf16 epilogue.
 // c8: the 8-wave ping-pong kernel of rg_conv8.hip (256x256 or 512x128 tiles) takes the bf16-output conv / plain
 // GEMMs whose shape it supports (RNAGAN_CONV8=0: off).
-static int conv8_mode() { return rg_option("conv8", 1); }
+// conv8: 0 off; bit 0 on; bit 2 (default) also where the tile count needs split-K.  With the tap-major k order the split form
+// lost to the 128 x 128 kernel (81-88 vs 68-78 us per deep layer at batch 64); with the channel-block-major order (korder) a
+// split covers all 16 taps of a channel range, re-reads its input rows from L2 and wins: 72-83 vs 81-91 us, the benchmark
+// 12.3 -> 11.8 ms.  Bit 1: parity classes fastest in the block order (neutral).
+static int conv8_mode() { return rg_option("conv8", 5); }
 static int conv8_blocks_target() { return rg_option("conv8_blocks", 256); }
 
 static GPlan gather_plan(int mode, bool bf16_out, int M, int Ncols, int Cin, int taps, int nclass, bool masked, int Hs = 0,
