@@ -1488,7 +1488,8 @@ int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, c
     const int ns = rg_wgrad8_split(K, O, I, &per);
     // (measured, batch 64: where the 128 x 128 kernel needs no split-K but this one does -- 128 tiles of 256 x 256 --
     // a single segment is faster there: 76 vs 83 us, no slab pass; with two segments the longer k-loop wins back)
-    const bool old_direct = mfma_wgrad_split_k(K, O, I) == 1 && ns > 1 && !two && rg_option("wgrad8", 1) == 1;
+    // (at twice the pixels -- the batched D step -- the longer k-loop wins there too: 134 vs 141 us)
+    const bool old_direct = mfma_wgrad_split_k(K, O, I) == 1 && ns > 1 && !two && K < 8192 && rg_option("wgrad8", 1) == 1;
     if (!old_direct && (ns == 1 || (ws && ws_bytes >= (size_t)ns * elems * sizeof(float)))) {
       int rc = rg_wgrad8_launch(low0, high0, low1, high1, ns == 1 ? dw : (float*)ws, Kseg, two ? 1 : 0, O, I, Ho, Wo, ns,
                                 per, accumulate, st);
