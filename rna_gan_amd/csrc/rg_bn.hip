@@ -99,9 +99,12 @@ __device__ __forceinline__ size_t group_row(int r, int grp, int groups, int Gb) 
 template <int NQ, class Fin>
 __global__ __launch_bounds__(256) void colfinish_kernel(Fin fin, const float* partial, int C, int G, int groups = 1,
                                                         int nblk = 1) {
-  __shared__ float sm[8][NQ][32];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + tx;
+  // block = CF_CH channels x CF_RL partial-row lanes: C / 8 blocks (the pass is latency-bound -- a few hundred KB read by a
+  // grid that used to be C / 32 blocks with 24 dependent loads per thread; 8-10 us per launch, 48 launches per iteration)
+  constexpr int CF_CH = 8, CF_RL = 32;
+  __shared__ float sm[CF_RL][NQ][CF_CH];
+  const int tx = threadIdx.x % CF_CH, ty = threadIdx.x / CF_CH;
+  const int c = blockIdx.x * CF_CH + tx;
   // groups are finished one after the other by the same thread: a finisher that updates shared state (running statistics,
   // accumulated parameter gradients) sees them in order, exactly as consecutive calls would
   for (int grp = 0; grp < groups; ++grp) {
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) void colfinish_kernel(Fin fin, const float* pa
     for (int q = 0; q < NQ; ++q) s[q] = 0.f;
     if (c < C) {
 #pragma unroll 4
-      for (int g = ty; g < G; g += 8)
+      for (int g = ty; g < G; g += CF_RL)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) s[q] += partial[(group_row(g, grp, groups, Gb) * NQ + q) * C + c];
     }
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256) void colfinish_kernel(Fin fin, const float* pa
       for (int q = 0; q < NQ; ++q) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += sm[k][q][tx];
+        for (int k = 0; k < CF_RL; ++k) t += sm[k][q][tx];
         s[q] = t;
       }
       Fin fg = fin;
@@ -229,7 +232,7 @@ int row_reduce_g(const char* name, int groups, int M, int C, void* ws, size_t ws
   else { if (p.tx == 32) RG_RR(1, 32); else if (p.tx == 16) RG_RR(1, 16); else RG_RR(1, 8); }
 #undef RG_RR
   RG_LAUNCH_CHECK(name);
-  hipLaunchKernelGGL((colfinish_kernel<NQ, Fin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, partial, C, p.gy, groups);
+  hipLaunchKernelGGL((colfinish_kernel<NQ, Fin>), dim3((C + 7) / 8), dim3(256), 0, st, fin, partial, C, p.gy, groups);
   RG_LAUNCH_CHECK(name);
   return RG_OK;
 }
@@ -718,10 +721,10 @@ extern "C" int rg_bn_forward_partials(const float* partial, int G, const void* z
     hipLaunchKernelGGL((colfinish_wide_kernel<2, SliceFin>), dim3(C / 8, SLICES), dim3(256), 0, st, SliceFin{stage, C},
                        partial, C, G);
     RG_LAUNCH_CHECK("bn_forward_partials");
-    hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, stage, C,
+    hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 7) / 8), dim3(256), 0, st, fin, stage, C,
                        SLICES);
   } else {
-    hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, partial, C, G);
+    hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 7) / 8), dim3(256), 0, st, fin, partial, C, G);
   }
   RG_LAUNCH_CHECK("bn_forward_partials");
   RG_DISPATCH_DTYPE(dtype, T, { return (row_apply<T, BnActF>("bn_forward_partials", M, C, st, (const T*)z, (T*)a, p, C)); })
@@ -742,10 +745,10 @@ extern "C" int rg_bn_finalize_partials(const float* partial, int G, int M, int C
     hipLaunchKernelGGL((colfinish_wide_kernel<2, SliceFin>), dim3(C / 8, SLICES), dim3(256), 0, st, SliceFin{stage, C},
                        partial, C, G);
     RG_LAUNCH_CHECK("bn_finalize_partials");
-    hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, stage, C, SLICES,
+    hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 7) / 8), dim3(256), 0, st, fin, stage, C, SLICES,
                        1);
   } else {
-    hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, partial, C, G, 1);
+    hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 7) / 8), dim3(256), 0, st, fin, partial, C, G, 1);
   }
   RG_LAUNCH_CHECK("bn_finalize_partials");
   return RG_OK;
@@ -764,10 +767,10 @@ static int finalize_partials_g2(const char* name, const float* partial, int G, i
     hipLaunchKernelGGL((colfinish_wide_kernel<2, SliceFin>), dim3(C / 8, SLICES, 2), dim3(256), 0, st,
                        SliceFin{stage, C, SLICES}, partial, C, G, nblk);
     RG_LAUNCH_CHECK(name);
-    hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, stage, C, SLICES,
+    hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 7) / 8), dim3(256), 0, st, fin, stage, C, SLICES,
                        2, 1);
   } else {
-    hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 31) / 32), dim3(256), 0, st, fin, partial, C, G, 2,
+    hipLaunchKernelGGL((colfinish_kernel<2, StatsFinalizeFin>), dim3((C + 7) / 8), dim3(256), 0, st, fin, partial, C, G, 2,
                        nblk);
   }
   RG_LAUNCH_CHECK(name);
@@ -987,7 +990,7 @@ extern "C" int rg_bn_dbl_apply(const void* z, const void* qa, const void* zt, co
   BNC p{mean, invstd, gamma, beta, slope};
   hipStream_t st = rg_stream(stream);
   // the all-reduced sums are one "partial row" [3][C]: colfinish with G = 1 runs the finisher per channel
-  hipLaunchKernelGGL((colfinish_kernel<3, DblFinSync>), dim3((C + 31) / 32), dim3(256), 0, st,
+  hipLaunchKernelGGL((colfinish_kernel<3, DblFinSync>), dim3((C + 7) / 8), dim3(256), 0, st,
                      DblFinSync{s_gy, s_gyxh, s_zt, s_xhzt, invstd, raw3_local, coef, dgamma, dbeta, accumulate,
                                 (float)M_total, (float)M, C},
                      raw3_global, C, 1);
