@@ -1020,8 +1020,9 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const uint16_t* __r
 // sides: 64 x 128 tile, rows stored as 16 chunks of 8 elements with chunk' = chunk ^ ((row >> 3) & 7), which keeps the
 // 16-byte stores aligned and makes the column gathers of the second phase conflict-free (8 row groups x 8 adjacent columns
 // per wave-instruction land in 32 different banks).  dst rows are written as 128-byte segments.
+// permute 1 (G.0: column c = ch * 16 + tap -> dst row tap * (Cc / 16) + ch): only the destination row changes.
 __global__ __launch_bounds__(256) void transpose_bf16_wide_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
-                                                                  int R, int Cc) {
+                                                                  int R, int Cc, int permute) {
   __shared__ __attribute__((aligned(16))) uint16_t tile[64][128];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 128;
   const int t = threadIdx.x;
@@ -1039,7 +1040,9 @@ __global__ __launch_bounds__(256) void transpose_bf16_wide_kernel(const uint16_t
     uint32_t o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = (uint32_t)tile[8 * rg + 2 * j][pc] | ((uint32_t)tile[8 * rg + 2 * j + 1][pc] << 16);
-    *reinterpret_cast<uint4*>(dst + (size_t)(c0 + c) * R + r0 + 8 * rg) = make_uint4(o[0], o[1], o[2], o[3]);
+    int orow = c0 + c;
+    if (permute == 1) orow = (orow & 15) * (Cc >> 4) + (orow >> 4);
+    *reinterpret_cast<uint4*>(dst + (size_t)orow * R + r0 + 8 * rg) = make_uint4(o[0], o[1], o[2], o[3]);
   }
 }
 __global__ void pack_linear_kernel(const float* w, uint16_t* wp, int Nout, int K, int Np, int Kp) {
@@ -1549,9 +1552,10 @@ int rg_mfma_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I,
 }
 int rg_mfma_transpose_bf16(const void* src, void* dst, int R, int Cc, int permute, hipStream_t st) {
   RG_REQUIRE(R % 2 == 0 && Cc % 2 == 0, RG_EUNSUPPORTED, "transpose_bf16: even dimensions required");
-  if (permute == 0 && R % 64 == 0 && Cc % 128 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0) {
+  if ((permute == 0 || permute == 1) && R % 64 == 0 && Cc % 128 == 0 && ((uintptr_t)src & 15) == 0 &&
+      ((uintptr_t)dst & 15) == 0) {
     hipLaunchKernelGGL(transpose_bf16_wide_kernel, dim3(Cc / 128, R / 64), dim3(256), 0, st, (const uint16_t*)src,
-                       (uint16_t*)dst, R, Cc);
+                       (uint16_t*)dst, R, Cc, permute);
     RG_LAUNCH_CHECK("transpose_bf16");
     return RG_OK;
   }

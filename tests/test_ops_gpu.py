@@ -594,3 +594,23 @@ def test_bn_two_batch_groups(N, H, C):
             check(gz2[h * N:(h + 1) * N], gz_ref[h], 1e-2, "gz")
         check(dg2, dg1, 1e-4, "dgamma")
         check(db2, db1, 1e-4, "dbeta")
+
+
+@pytest.mark.parametrize("E,C", [(128, 8), (192, 24), (64, 6)])
+def test_g0_weight_pack_from_bf16_shadow(E, C):
+    """The transposed bf16 image of G.0's weight written from the bf16 shadow (16-byte tile kernel when E % 64 == 0 and
+    16 C % 128 == 0, the 4-byte kernel otherwise) is bit-identical to the one packed from the fp32 master, and to the
+    layout dst[tap * C + c][e] = w[e][c][tap]."""
+    from rna_gan_amd import _abi
+    lib = _abi.load()
+    w = rnd((E, C, 4, 4), 71).cuda()
+    shadow = w.to(torch.bfloat16).contiguous()
+    a = torch.empty(16 * C, E, dtype=torch.bfloat16, device="cuda")
+    b = torch.empty_like(a)
+    st = torch.cuda.current_stream().cuda_stream
+    _abi.check(lib.rg_pack_g0_weight(w.data_ptr(), a.data_ptr(), E, C, _abi.RG_BF16, st), "rg_pack_g0_weight")
+    _abi.check(lib.rg_pack_g0_weight_from_bf16(shadow.data_ptr(), b.data_ptr(), E, C, st), "rg_pack_g0_weight_from_bf16")
+    torch.cuda.synchronize()
+    want = shadow.view(E, C, 16).permute(2, 1, 0).reshape(16 * C, E)
+    assert torch.equal(b.view(torch.int16), want.contiguous().view(torch.int16))
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))
