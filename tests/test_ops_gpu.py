@@ -614,3 +614,20 @@ def test_g0_weight_pack_from_bf16_shadow(E, C):
     want = shadow.view(E, C, 16).permute(2, 1, 0).reshape(16 * C, E)
     assert torch.equal(b.view(torch.int16), want.contiguous().view(torch.int16))
     assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
+@pytest.mark.parametrize("M,K,ldd", [(1, 1 << 20, 1 << 20), (1, 4096 + 8, 4096 + 8), (3, 1000, 1024), (1, 4100, 4100), (64, 256, 256)])
+def test_cast_pad_matches_torch(M, K, ldd):
+    """fp32 -> bf16 cast with optional row padding (rg_cast_pad: the data-parallel gradient compression and the betaVAE
+    operand casts): bit-exact against torch's round-to-nearest-even on both the 8-wide and the scalar kernel."""
+    from rna_gan_amd import _abi
+    lib = _abi.load()
+    x = rnd((M, K), 5, 3.0).cuda()
+    x.view(-1)[:4] = torch.tensor([0.0, -0.0, 1e-40, 3.3895e38], device="cuda")
+    out = torch.full((M, ldd), 7.0, dtype=torch.bfloat16, device="cuda")
+    _abi.check(lib.rg_cast_pad(x.data_ptr(), out.data_ptr(), M, K, ldd, _abi.RG_BF16, torch.cuda.current_stream().cuda_stream),
+               "rg_cast_pad")
+    torch.cuda.synchronize()
+    want = torch.zeros(M, ldd, dtype=torch.bfloat16, device="cuda")
+    want[:, :K] = x.to(torch.bfloat16)
+    assert torch.equal(out.view(torch.int16), want.view(torch.int16))
