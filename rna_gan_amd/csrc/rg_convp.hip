@@ -195,6 +195,13 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
   } while (0)
 // wait states tied to every accumulator: hazards between the asm MFMAs and the VALU instructions around them (the clearing
 // v_movs before a tile's first MFMAs, the epilogue's reads after its last ones) are invisible to the compiler
+// An MFMA re-reads its A / B registers in every pass: a VALU write to one of them within the MFMA's 16 cycles corrupts the rows
+// of the later passes (seen while moving the DMA issue between the MFMAs: channels 4 j + 2, 4 j + 3 of a tile wrong).  hipcc
+// cannot know that about the asm MFMAs and may reuse a dead fragment register as a temporary of the address arithmetic that
+// follows a group: keep the group's operands allocated (and two more wait states) behind the waits that end it.
+#define CP_KEEP_ALL(AS, SET)                                                                                  \
+  asm volatile("s_nop 1" ::"v"(bS[SET][0]), "v"(bS[SET][1]), "v"(bS[SET][2]), "v"(bS[SET][3]), "v"(AS[0]), "v"(AS[1]), \
+               "v"(AS[2]), "v"(AS[3]))
 #define CP_ACC_FENCE()                                                                                       \
   do {                                                                                                       \
     _Pragma("unroll") for (int rt_ = 0; rt_ < 8; rt_ += 4)                                                   \
@@ -414,9 +421,11 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
     CP_MFMAS(4, aS1, kc_);                                                                                  \
     CP_WAIT4(bS[1 - kc_]);                                                                                  \
     CP_WAIT4(aS0);                                                                                          \
+    CP_KEEP_ALL(aS1, kc_);                                                                                  \
     read_a(aS1, icp<4>{}, dn_, bufn_, icp<1 - kc_>{});                                                      \
     CP_MFMAS(0, aS0, 1 - kc_);                                                                              \
     CP_WAIT4(aS1);                                                                                          \
+    CP_KEEP_ALL(aS0, 1 - kc_);                                                                              \
     wait_v(icp<(S)>{});                                                                                     \
   } while (0)
 #define CP_LAST()                                                                                           \
@@ -434,6 +443,7 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
     CP_WAIT4(aS0);                                                                                          \
     CP_MFMAS(0, aS0, 0);                                                                                    \
     CP_WAIT4(aS1);                                                                                          \
+    CP_KEEP_ALL(aS0, 0);                                                                                    \
     wait_v(icp<15>{});                                                                                      \
   } while (0)
 
@@ -453,6 +463,7 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
 #undef CP_SYNC
 #undef CP_ACC_FENCE
 #undef CP_MFMAS
+#undef CP_KEEP_ALL
 #undef CP_WAIT4
 #undef CP_READ_B
 #undef CP_DSR
