@@ -106,18 +106,9 @@ def main():
         # the reference's data path (src/histopathology_gan.py:111-168): slide tables -> [log + StandardScaler on the
         # rna_ columns] -> per-slide tile sampling from the slide databases -> batches; rna_gan_amd.data restates the
         # record format / sampling / preparation (LMDB files need the `lmdb` package, directory stores do not)
-        import pandas as pd
         from rna_gan_amd import data as PD
-        path_csv, patch_data_path = config["path_csv"], config["patch_data_path"]
-        if isinstance(path_csv, str):
-            path_csv, patch_data_path = [path_csv], [patch_data_path]
-        tables = []
-        for i, (csv_file, path) in enumerate(zip(path_csv, patch_data_path)):
-            df = pd.read_csv(csv_file)
-            df["patch_data_path"] = [path] * df.shape[0]
-            df["labels"] = [i] * df.shape[0]
-            tables.append(df)
-        train_df = pd.concat(tables) if len(tables) > 1 else tables[0]
+        patch_data_path = config["patch_data_path"]
+        train_df = PD.load_slide_tables(config["path_csv"], patch_data_path)
         tf = PD.ToFloatNormalize(0.5, 0.5)
         if with_rna:
             train_df, _, _ = PD.log_standardize_rna(train_df)

@@ -322,6 +322,24 @@ def write_tile_store(path: str, tiles_hwc_u8, slide_id: str = "slide"):
 # ------------------------------------------------------------------------------------------------------------------
 # RNA table (src/histopathology_gan.py:131-151)
 # ------------------------------------------------------------------------------------------------------------------
+def load_slide_tables(path_csv, patch_data_path):
+    """The slide table of a run (src/histopathology_gan.py:111-127): one CSV per tissue, each row tagged with its tile
+    directory (``patch_data_path``) and the index of its CSV as the tissue id (``labels``), the tables concatenated in the
+    order given (a single path may be passed as a string)."""
+    import pandas as pd
+    if isinstance(path_csv, str):
+        path_csv, patch_data_path = [path_csv], [patch_data_path]
+    if len(path_csv) != len(patch_data_path):
+        raise ValueError("path_csv and patch_data_path must have one entry per tissue")
+    tables = []
+    for i, (csv_file, path) in enumerate(zip(path_csv, patch_data_path)):
+        df = pd.read_csv(csv_file)
+        df["patch_data_path"] = [path] * df.shape[0]
+        df["labels"] = [i] * df.shape[0]
+        tables.append(df)
+    return pd.concat(tables) if len(tables) > 1 else tables[0]
+
+
 def log_standardize_rna(df):
     """Returns (DataFrame with columns [rna_*, others], mean, scale).  rna_ columns: ln(x) with zeros left at 0
     (:133-136), then StandardScaler().fit_transform (:148-151): (x - mean) / sqrt(population variance), a zero

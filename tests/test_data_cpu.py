@@ -116,3 +116,52 @@ def test_datasets_and_rna_table_reference_fixture(golden_dir, tmp_path):
     it = ds[0]
     assert it["image"].dtype == torch.uint8
     np.testing.assert_allclose(float(PD.ToFloatNormalize(0.0, 1.0)(it["image"]).double().sum()), fx["rna.image_sums"][0], rtol=1e-6)
+
+
+def test_mixed_tissue_tables(tmp_path):
+    """BASELINE configs[3]'s data side (src/histopathology_gan.py:111-151): two tissue tables -> one table with the CSV index
+    as tissue id and each row's own tile directory, RNA columns ln'd (zeros stay 0) and standardised over the UNION of the
+    tissues, per-slide tile sampling from each tissue's store; the items carry the tissue id."""
+    import pandas as pd
+    rng = np.random.default_rng(5)
+    genes = ["rna_G%d" % i for i in range(6)]
+    paths, roots, slides = [], [], {}
+    for t, (tissue, n) in enumerate((("lung", 3), ("brain", 2))):
+        names = ["%s_%d.svs" % (tissue, i) for i in range(n)]
+        x = rng.gamma(2.0, 3.0 + 4.0 * t, size=(n, len(genes)))
+        x[0, 1] = 0.0                                      # an unexpressed gene: ln(0) -> 0
+        df = pd.DataFrame(x, columns=genes)
+        df.insert(0, "wsi_file_name", names)
+        df["tissue"] = tissue
+        p = str(tmp_path / ("%s.csv" % tissue))
+        df.to_csv(p, index=False)
+        root = str(tmp_path / ("patches_" + tissue))
+        for wsi in names:
+            tiles = [rng.integers(0, 256, size=(16, 16, 3), dtype=np.uint8) for _ in range(4)]
+            PD.write_tile_store(os.path.join(root, wsi, wsi.replace(".svs", "")), tiles, slide_id=wsi)
+            slides[wsi] = t
+        paths.append(p); roots.append(root)
+    table = PD.load_slide_tables(paths, roots)
+    assert table.shape[0] == 5 and list(table["labels"]) == [0, 0, 0, 1, 1]
+    assert list(table["patch_data_path"]) == [roots[0]] * 3 + [roots[1]] * 2
+    raw = table[genes].to_numpy(dtype=np.float64)
+    prepared, mean, scale = PD.log_standardize_rna(table)
+    lx = np.where(raw == 0, 0.0, np.log(np.where(raw == 0, 1.0, raw)))
+    np.testing.assert_allclose(mean, lx.mean(0), rtol=1e-12)
+    np.testing.assert_allclose(prepared[genes].to_numpy(dtype=np.float64), (lx - lx.mean(0)) / lx.std(0), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(prepared[genes].to_numpy(dtype=np.float64).mean(0), 0.0, atol=1e-12)   # over the union
+    assert abs(float(prepared[genes].to_numpy(dtype=np.float64)[:3].mean())) > 1e-3                   # not per tissue
+    random.seed(7)
+    ds = PD.PatchRNADataset(roots, prepared, 16, transforms=PD.ToFloatNormalize(0.5, 0.5), max_patches_total=3)
+    assert len(ds) == 15
+    for i in range(len(ds)):
+        it = ds[i]
+        wsi = ds.filenames[i] if isinstance(ds.filenames[i], str) else ds.filenames[i].decode()
+        key = [k for k in slides if wsi.startswith(k.replace(".svs", ""))]
+        assert len(key) == 1 and float(it["labels"]) == float(slides[key[0]])
+        assert it["image"].shape == (3, 16, 16) and it["rna_data"].shape == (6,)
+        row = prepared[prepared["wsi_file_name"] == key[0]][genes].to_numpy(dtype=np.float32)[0]
+        np.testing.assert_array_equal(it["rna_data"].numpy(), row)
+    # a single table passed as a string (configs/gan_run_lung.json's form)
+    one = PD.load_slide_tables(paths[0], roots[0])
+    assert one.shape[0] == 3 and set(one["labels"]) == {0}
