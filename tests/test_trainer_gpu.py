@@ -362,3 +362,50 @@ def test_penalty_fake_from_the_d_step_generator_pass():
     for i, (x, y) in enumerate(zip(la[:9], lb[:9])):          # first three iterations: before the trajectories drift apart
         assert abs(x - y) <= (0.35 if i % 3 == 2 else 5e-2) * (abs(x) + 1.0), (i, la, lb)
     assert float((ga - gb).norm() / ga.norm()) <= 2e-2 and float((da - db).norm() / da.norm()) <= 2e-2
+
+
+def test_cli_trains_on_mixed_tissue_tables(tmp_path):
+    """The reference CLI's real-data path end to end (src/histopathology_gan.py:111-168, BASELINE configs[3]'s data side): two
+    tissue tables with their own tile stores -> concatenated table -> log / standardised RNA -> per-slide tile sampling ->
+    DataLoader -> Trainer with the three betaVAE-conditioned plugins, on the HIP kernels.  One short epoch at 32 x 32; checks
+    the run completes, the checkpoint has the reference's keys and the logged losses are finite."""
+    import json
+    import subprocess
+    import sys
+    import numpy as np
+    import pandas as pd
+    from rna_gan_amd import data as PD
+    rng = np.random.default_rng(11)
+    genes = ["rna_G%d" % i for i in range(48)]
+    csvs, roots = [], []
+    for t, (tissue, n) in enumerate((("lung", 3), ("brain", 3))):
+        names = ["%s_%d.svs" % (tissue, i) for i in range(n)]
+        df = pd.DataFrame(rng.gamma(2.0, 3.0 + 4.0 * t, size=(n, len(genes))), columns=genes)
+        df.insert(0, "wsi_file_name", names)
+        csv = str(tmp_path / (tissue + ".csv"))
+        df.to_csv(csv, index=False)
+        root = str(tmp_path / ("patches_" + tissue))
+        for wsi in names:
+            tiles = [rng.integers(0, 256, size=(32, 32, 3), dtype=np.uint8) for _ in range(8)]
+            PD.write_tile_store(os.path.join(root, wsi, wsi.replace(".svs", "")), tiles, slide_id=wsi)
+        csvs.append(csv); roots.append(root)
+    cfg = {"path_csv": csvs, "patch_data_path": roots, "img_size": 32, "rna_features": len(genes),
+           "save_dir": str(tmp_path / "ck"), "flag": "mixed"}
+    cfg_path = str(tmp_path / "cfg.json")
+    with open(cfg_path, "w") as f:
+        json.dump(cfg, f)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(repo, "histopathology_gan.py"), "--config", cfg_path, "--loss_type", "wganvae",
+           "--num_epochs", "1", "--num_patches", "8", "--batch_size", "8", "--model_dir", str(tmp_path / "model"),
+           "--image_dir", str(tmp_path / "img"), "--betavae_checkpoint", str(tmp_path / "none.pt")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Training of the Model is Complete" in r.stdout
+    vals = [float(l.split(":")[1]) for l in r.stdout.splitlines() if "Mean Loss" in l]
+    assert len(vals) >= 2 and all(np.isfinite(v) for v in vals)
+    cks = [f for f in os.listdir(str(tmp_path)) if f.startswith("model")] + \
+          ([os.path.join("model", f) for f in os.listdir(str(tmp_path / "model"))] if os.path.isdir(str(tmp_path / "model")) else [])
+    files = [os.path.join(str(tmp_path), c) for c in cks if os.path.isfile(os.path.join(str(tmp_path), c))]
+    assert files, "no checkpoint written"
+    ck = torch.load(files[0], map_location="cpu", weights_only=False)
+    assert {"epoch", "generator", "discriminator", "optimizer_generator", "optimizer_discriminator"} <= set(ck)
