@@ -18,6 +18,11 @@ ranks, rank 0 prints ONE JSON line.  Extra objects:
   cpu_baseline : the oracle (plain PyTorch fp32 restatement of the reference path, oracle/ref_cpu.py)
                  timed on this box's host cores on a bounded sample (batch 8, the reference's own
                  hard-coded batch size).
+  parity       : the FIRST iteration of that batch-8 CPU-oracle run (seeded weights / inputs / draws) repeated through the
+                 HIP product path in this process: the three losses side by side with the stated tolerance.
+  config.extras: figures measured AFTER the headline timed region in the same process (never part of `value`):
+                 generate (BASELINE configs[4]: generator-only synthesis of 4096 samples, fp8 and bf16), api_path (the
+                 drop-in Trainer.train_iter() loop with its host syncs and uint8 input), fp32_step (the fp32 parity mode).
 """
 import argparse
 import importlib
@@ -106,6 +111,8 @@ def parse_args(argv=None):
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary figures measured after the timed region (config.extras) and the parity object")
     ap.add_argument("--seed", type=int, default=99)
     ap.add_argument("--gan-type", default="dcgan", choices=["dcgan", "dcgan_up"],
                     help="dcgan = the reference CLI's generator (the benchmark); dcgan_up = src/dcgan.py's resize-convolution "
@@ -120,7 +127,9 @@ def parse_args(argv=None):
                          "protocol on CPU ranks (gloo).  Never used for a reported number.")
     args = ap.parse_args(argv)
     if args.gan_type != "dcgan":
-        args.no_roofline = args.no_cpu_baseline = True
+        args.no_roofline = args.no_cpu_baseline = args.no_extras = True
+    if args.api_path or args.precision != "bf16" or args.batch != 64:
+        args.no_extras = True              # the extras belong to the headline configuration only
     return args
 
 
@@ -251,6 +260,10 @@ def hip_workload(args, rank, world, device):
                     lp.step(G, Dm, od, real, rna, u_p, draw_eps())]
 
     info = {"ops": ops, "rna_features": rna_features, "api_path": api_info,
+            # the live objects of the workload (tests/test_bench_step_gpu.py compares this very step with the CPU oracle;
+            # the extras below reuse the models): never serialised
+            "handles": {"G": G, "D": Dm, "og": og, "od": od, "losses": (lg, ld, lp), "real": real, "rna": rna,
+                        "host_generator": gen},
             "workload": "RNA-GAN lung (betaVAE-conditioned wganvae path) 256x256, %s enc2048/step64, "
                         % ("DCGAN" if args.gan_type == "dcgan" else "DCGANUpGenerator + DCGAN discriminator") +
                         "per-GPU batch %d, one iteration = G-loss + D-loss + GP steps" % N}
@@ -324,7 +337,7 @@ def main(argv=None):
     if args.step_plugin:
         mod, fn = args.step_plugin.split(":")
         one_step, flush, N, info = getattr(importlib.import_module(mod), fn)(args, rank, world, device)
-        args.no_roofline = args.no_cpu_baseline = True
+        args.no_roofline = args.no_cpu_baseline = args.no_extras = True
     else:
         one_step, flush, N, info = hip_workload(args, rank, world, device)
 
@@ -400,6 +413,10 @@ def main(argv=None):
     # the instrumented extra iteration contains collectives in a data-parallel run: every rank runs it
     roof = None if args.no_roofline or args.api_path else measure_roofline(info["ops"], device, one_step, ms_per_step)
     flush()
+    extras = parity_gpu = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = measure_extras(args, device, info)
+        parity_gpu = parity_gpu_leg(args, device)
     if rank == 0:
         if not args.step_plugin:
             fl = conv_flops_per_image()
@@ -407,8 +424,12 @@ def main(argv=None):
             out["config"]["algorithmic_conv_tflops_whole_step"] = round(total_flops_img * value / world / 1e12, 2)
         if roof is not None:
             out["roofline"] = roof
+        if extras is not None:
+            out["config"]["extras"] = extras
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.seed)
+            out["cpu_baseline"], first = cpu_baseline(args.seed)
+            if parity_gpu is not None:
+                out["parity"] = parity_object(parity_gpu, first, args.precision)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     barrier()
@@ -521,17 +542,19 @@ def cpu_baseline(seed):
     real = R.synthetic_images(n, 256, seed=1234)
     rna = R.synthetic_rna(n, rna_features, seed=4321, distinct=16)
 
+    losses = {}
+
     def one(it):
         us = [R.synthetic_uniform(n, 2048, seed=10 * it + j) for j in range(3)]
         t0 = time.perf_counter()
         with torch.no_grad():
             noises = [R.conditioned_noise(u, R.encode_latent(vae, rna)) for u in us]      # one encode per train_op
-        R.train_iteration(G, D, og, od, real, noises, 0.5)
+        losses[it] = R.train_iteration(G, D, og, od, real, noises, PARITY_EPS)
         return time.perf_counter() - t0
 
     cands = [c for c in (8, 16, 32, 64) if c <= avail] or [max(1, avail)]
     torch.set_num_threads(cands[0])
-    one(0)                                            # warm-up (allocator, oneDNN primitive caches)
+    one(0)                                            # warm-up (allocator, oneDNN primitive caches); = the parity iteration
     trial = {}
     for i, c in enumerate(cands):
         torch.set_num_threads(c)
@@ -544,11 +567,127 @@ def cpu_baseline(seed):
     times = [one(10 + k) for k in range(3)]
     t = sum(times) / len(times)
     log("cpu baseline: %d threads, %.2f s/iteration" % (best, t))
+    first = [losses[0]["g"], losses[0]["d"], losses[0]["gp"]]
     return {"value": round(n / t, 3), "unit": "imgs/sec", "cores": best, "kind": "port",
             "threads": "best of %s intra-op thread counts tried, %d host threads available" % (sorted(trial), avail),
             "sample": "PyTorch fp32 restatement of the reference path incl. the 3 frozen-betaVAE encodes per "
                       "iteration, batch 8, 3 timed iterations after a warm-up, %.2f s/iteration, torch %s"
-                      % (t, torch.__version__)}
+                      % (t, torch.__version__)}, first
+
+
+PARITY_EPS = 0.5          # the interpolation coefficient of the parity iteration (both legs)
+PARITY_TOL = {"bf16": 6e-2, "fp32": 2e-3}       # |gpu - cpu| <= tol * (|cpu| + 0.1), as tests/test_train_gpu.py states it
+
+
+def parity_gpu_leg(args, device):
+    """The first iteration of cpu_baseline()'s run (batch 8; weights seeded seed / seed+1 / seed+2, tiles seed 1234, RNA
+    seed 4321, uniform draws seeds 0..2, eps 0.5) through the HIP product path: the three loss plugins' step() on a fresh
+    model set.  Returns the three losses (floats)."""
+    from rna_gan_amd import losses as PL
+    from rna_gan_amd import synth as R
+    n, rna_features = 8, 19198
+    G, Dm, og, od, (lg, ld, lp) = build(device, args.precision, n, rna_features, args.seed)
+    real = R.synthetic_images(n, 256, seed=1234).to(device)
+    rna = R.synthetic_rna(n, rna_features, seed=4321, distinct=16).to(device)
+    us = [R.synthetic_uniform(n, 2048, seed=j).to(device) for j in range(3)]
+    eps = torch.tensor([PARITY_EPS], dtype=torch.float32, device=device)
+    PL.new_batch()
+    ls = [lg.step(G, Dm, og, rna, us[0]), ld.step(G, Dm, od, real, rna, us[1], next_u=us[2]),
+          lp.step(G, Dm, od, real, rna, us[2], eps)]
+    out = [float(l.item()) for l in ls]
+    PL.new_batch()
+    log("parity (GPU leg, batch 8, first iteration): %s" % out)
+    return out
+
+
+def parity_object(gpu, cpu, precision):
+    tol = PARITY_TOL[precision]
+    err = [abs(g - c) / (abs(c) + 0.1) for g, c in zip(gpu, cpu)]
+    return {"what": "first iteration (G-loss, D-loss, gradient-penalty train_ops) of the batch-8 cpu_baseline run repeated on "
+                    "the HIP path: same seeded weights, tiles, RNA rows, uniform draws and eps",
+            "losses_gpu": [round(v, 6) for v in gpu], "losses_cpu_oracle": [round(v, 6) for v in cpu],
+            "rel_err": [round(e, 5) for e in err], "tolerance": tol, "tolerance_form": "|gpu - cpu| <= tol * (|cpu| + 0.1)",
+            "ok": bool(max(err) <= tol), "gpu_precision": precision, "cpu_precision": "fp32"}
+
+
+def measure_extras(args, device, info):
+    """Secondary figures, measured after the headline timed region on the same box in the same process."""
+    ex = {}
+    for name, fn in (("generate", extra_generate), ("api_path", extra_api_path), ("fp32_step", extra_fp32_step)):
+        try:
+            ex[name] = fn(args, device, info)
+            log("extra %s: %s" % (name, json.dumps(ex[name])))
+        except Exception as e:                      # an extra never takes the headline record down with it
+            ex[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+            log("extra %s FAILED: %s" % (name, ex[name]["error"]))
+    return ex
+
+
+def extra_generate(args, device, info, n=4096, chunk=512):
+    """BASELINE configs[4]: generator-only synthesis of 4096 samples from random 2048-d latents, eval-mode BatchNorm
+    (running statistics, folded into the conv epilogues -- SURVEY 8d states the mode), images written into one device-resident
+    (N, 3, 256, 256) fp32 buffer; fp8 e4m3 weights / activations on the layers that have an fp8 kernel, and bf16."""
+    from rna_gan_amd import gan_utils as GU
+    G = info["handles"]["G"]
+    fl = conv_flops_per_image()["G"]
+    gen = torch.Generator(device="cpu").manual_seed(args.seed + 7)
+    noise = torch.randn(n, 2048, generator=gen).to(device)
+    out = torch.empty((n, 3, 256, 256), dtype=torch.float32, device=device)
+    res = {"samples": n, "chunk": chunk, "batchnorm": "eval mode (running statistics folded into the conv epilogues)",
+           "output": "fp32 NCHW resident on the device"}
+    for tag, fp8 in (("fp8", True), ("bf16", False)):
+        GU.synthesize(G, noise[:2 * chunk], chunk=chunk, fp8=fp8, out=out[:2 * chunk])        # warm-up (operand images)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        GU.synthesize(G, noise, chunk=chunk, fp8=fp8, out=out)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        res[tag] = {"imgs_per_sec": round(n / dt, 1), "ms_total": round(dt * 1e3, 2),
+                    "tflops": round(fl * n / dt / 1e12, 1), "finite": bool(torch.isfinite(out[::257]).all())}
+    return res
+
+
+def extra_api_path(args, device, info, steps=20, warm=12):
+    """The drop-in API as a user of the reference CLI gets it (see api_path_step): ms per iteration and imgs/sec."""
+    h = info["handles"]
+    step, api_info = api_path_step(args, h["G"], h["D"], h["og"], h["od"], h["losses"], device, 0)
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    return dict(api_info, ms_per_step=round(dt * 1e3, 3), imgs_per_sec=round(args.batch / dt, 1), steps=steps)
+
+
+def extra_fp32_step(args, device, info, steps=2):
+    """The fp32 parity mode (--precision fp32: VALU functor kernels, the anchor of the tight-tolerance parity tests) on the
+    same workload: throughput of the mode the bf16 numbers are validated against."""
+    from rna_gan_amd import losses as PL
+    from rna_gan_amd import synth as R
+    N = args.batch
+    G, Dm, og, od, (lg, ld, lp) = build(device, "fp32", N, 19198, args.seed)
+    h = info["handles"]
+    gen = torch.Generator(device="cpu").manual_seed(args.seed + 11)
+
+    def it():
+        PL.new_batch()
+        us = [torch.empty(N, 2048).uniform_(-0.3, 0.3, generator=gen).to(device) for _ in range(3)]
+        eps = torch.empty(1).uniform_(0.0, 1.0, generator=gen).to(device)
+        return [lg.step(G, Dm, og, h["rna"], us[0]), ld.step(G, Dm, od, h["real"], h["rna"], us[1], next_u=us[2]),
+                lp.step(G, Dm, od, h["real"], h["rna"], us[2], eps)]
+    it()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ls = it()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    PL.new_batch()
+    return {"ms_per_step": round(dt * 1e3, 2), "imgs_per_sec": round(N / dt, 1), "steps": steps, "hip_graphs": False,
+            "losses": [round(float(l.item()), 5) for l in ls], "kernels": "fp32 functor kernels (no MFMA), fp32 activations"}
 
 
 if __name__ == "__main__":

@@ -71,6 +71,13 @@ EXTRA_FLAGS = [
 ]
 
 
+def shard_indices(n_items: int, rank: int, world: int, batch_size: int):
+    """Indices of rank ``rank``'s shard of a list of n_items: strided (rank, rank + world, ...), truncated so that EVERY rank
+    gets the same number of items and that number is a multiple of the batch size (equal batch counts on all ranks)."""
+    per_rank = (n_items // world) // batch_size * batch_size
+    return list(range(rank, n_items, world))[:per_rank]
+
+
 def parse_args():
     ap = argparse.ArgumentParser(description="GANs training on histology data (MI355X path)")
     for flag, typ, default, text in REFERENCE_FLAGS + EXTRA_FLAGS:
@@ -107,6 +114,10 @@ def main():
         # rna_ columns] -> per-slide tile sampling from the slide databases -> batches; rna_gan_amd.data restates the
         # record format / sampling / preparation (LMDB files need the `lmdb` package, directory stores do not)
         from rna_gan_amd import data as PD
+        import random
+        # every rank must build the SAME tile list (the datasets draw their per-slide tile sample from the global `random`
+        # generator, src/read_data.py:313-316), so that the strided shards below partition one list
+        random.seed(args.seed)
         patch_data_path = config["patch_data_path"]
         train_df = PD.load_slide_tables(config["path_csv"], patch_data_path)
         tf = PD.ToFloatNormalize(0.5, 0.5)
@@ -120,9 +131,13 @@ def main():
             img = (lambda b: b["image"]) if with_rna else (lambda b: b[0])
             batch = [b for b in batch if img(b) is not None]
             return torch.utils.data.dataloader.default_collate(batch)
-        if D_.world_size() > 1:                      # one shard of the tile list per rank
-            ds = torch.utils.data.Subset(ds, list(range(D_.rank(), len(ds), D_.world_size())))
-        loader = DataLoader(ds, batch_size=args.batch_size, num_workers=4, pin_memory=True, collate_fn=collate_fn)   # :163-168
+        world = D_.world_size()
+        if world > 1:
+            # one shard of the (identical) tile list per rank, the SAME number of full batches on every rank: each train_op
+            # issues a gradient all-reduce, so a rank with one batch more would pair its collectives with nobody
+            ds = torch.utils.data.Subset(ds, shard_indices(len(ds), D_.rank(), world, args.batch_size))
+        loader = DataLoader(ds, batch_size=args.batch_size, num_workers=4, pin_memory=True, collate_fn=collate_fn,
+                            drop_last=world > 1)   # :163-168
 
     if args.gan_type not in ("dcgan", "dcgan_up"):
         raise SystemExit("--gan_type dcgan (the reference CLI's path) or dcgan_up (src/dcgan.py's DCGANUpGenerator, "
@@ -161,9 +176,13 @@ def main():
         bv = getattr(loss, "betavae", None)
         if bv is not None and D_.world_size() > 1:
             bv.to(device)
+            before = bv.signature()                       # which of this rank's three encoders held the same weights
             for t in list(bv.parameters()) + list(bv.buffers()):
                 D_.broadcast_(t.data, 0)
             bv.weights_changed()
+            # every rank runs the same construction, so encoders that shared weights before the broadcast (one checkpoint
+            # file) share rank 0's afterwards: keep that identity for the per-batch latent cache (losses._LatentCache)
+            bv.adopt_weights_token(("broadcast",) + tuple(before))
     torch.manual_seed(args.seed + D_.rank())
     np.random.seed(args.seed + D_.rank())
     trainer(loader)

@@ -16,6 +16,14 @@ import torch
 import torch.nn as nn
 
 
+_TOKENS = [0]
+
+
+def _next_token():
+    _TOKENS[0] += 1
+    return _TOKENS[0]
+
+
 class RNAEncoder(nn.Module):
     def __init__(self, in_channels: int, hidden_dims: List[int]):
         super().__init__()
@@ -47,7 +55,11 @@ class betaVAE(nn.Module):
         self.z_dim = z_dim
         self.precision = "bf16"
         self._plan = None
-        self._sig = None
+        # provenance of the current weights (losses._LatentCache shares one encode between modules holding the SAME weights):
+        # a token handed over by load_state_dict / state_dict / a checkpoint file, valid while no parameter or buffer has
+        # been written since (tensor version counters) -- identity, not a fingerprint of the values
+        self._token = None
+        self._token_versions = None
         self._ops = None
         self._flat = None
         self._trt = None
@@ -85,11 +97,14 @@ class betaVAE(nn.Module):
 
     def weights_changed(self, by_optimizer: bool = False):
         self._plan = None
+        self._token = None          # kernels wrote the flat buffers (no tensor version counter sees that)
 
     def train(self, mode: bool = True):
         # the eval-mode plan folds BatchNorm into per-layer scale/shift vectors: rebuild it after any training phase
         # (a plain torch optimizer updates the parameter views without telling this module)
         self._plan = None
+        if mode:
+            self._token = None      # a training phase may rewrite the weights through the flat buffers
         return super().train(mode)
 
     def train_runtime(self):
@@ -98,9 +113,42 @@ class betaVAE(nn.Module):
             self._trt = VaeRuntime(self)
         return self._trt
 
-    def load_state_dict(self, *a, **k):
-        r = super().load_state_dict(*a, **k)
+    def _versions(self):
+        return tuple(t._version for t in list(self.parameters()) + list(self.buffers()))
+
+    def adopt_weights_token(self, token):
+        """Declare that the weights now held are the ones identified by ``token`` (a hashable value: the same token on two
+        modules means 'loaded from the same source, untouched since')."""
+        self._token = token
+        self._token_versions = self._versions()
+
+    def state_dict(self, *a, **k):
+        sd = super().state_dict(*a, **k)
+        if not a and not k.get("prefix"):
+            # a full state_dict carries the identity of the weights it was read from: a module that loads it holds the
+            # same weights as this one (bench.py / tests hand one module's state_dict to the other two loss plugins)
+            if self._token is None or self._token_versions != self._versions():
+                self.adopt_weights_token(("module", id(self), _next_token()))
+            sd._rg_weights_token = self._token
+        return sd
+
+    def load_state_dict(self, state_dict, *a, **k):
+        r = super().load_state_dict(state_dict, *a, **k)
         self._plan = None
+        token = getattr(state_dict, "_rg_weights_token", None)
+        if token is not None and not r.missing_keys and not r.unexpected_keys:
+            self.adopt_weights_token(token)
+        else:
+            self._token = None
+        return r
+
+    def load_checkpoint_file(self, path):
+        """load_state_dict(torch.load(path)) with the file's identity as the weights token: the three loss plugins of
+        --loss_type wganvae each load the same checkpoint (src/wgan_loss.py:67-69, :159-161, :289-291)."""
+        import os
+        st = os.stat(path)
+        r = self.load_state_dict(torch.load(path, map_location="cpu"))
+        self.adopt_weights_token(("file", os.path.realpath(path), st.st_mtime_ns, st.st_size))
         return r
 
     def __getstate__(self):          # pickled inside loss objects in checkpoints: drop runtime handles
@@ -130,22 +178,16 @@ class betaVAE(nn.Module):
                 plan.append((lin.weight.detach(), self._ops.pack_linear(lin.weight.detach()) if packed else None,
                              None, lin.bias.detach(), 1.0))
         self._plan = plan
-        # identity of the frozen encoder as the loss plugins see it (losses._LatentCache: the reference builds three
-        # copies from one checkpoint; copies with equal signatures produce equal latents): fp64 sum and the 2-norm
-        # of every folded operand, read back ONCE per plan
-        with torch.no_grad():
-            parts = []
-            for (w, _, scale, shift, slope) in plan[:-1]:
-                for t in (w, scale, shift):
-                    if t is not None:
-                        parts += [t.sum(dtype=torch.float64), torch.linalg.vector_norm(t.float()).double()]
-            self._sig = (self.precision,) + tuple(float(v) for v in torch.stack(parts).cpu())
 
     def signature(self):
-        """Hashable fingerprint of the eval-mode encoder (weights, folded BatchNorm, precision)."""
-        if self._plan is None:
-            self._build_plan()
-        return self._sig
+        """Identity of the eval-mode encoder's weights as the loss plugins see it (losses._LatentCache: the reference builds
+        three copies from one checkpoint; copies with equal signatures hold the same weights and produce equal latents).
+        (precision, weights token) while the weights are untouched since the token was adopted; otherwise private to this
+        module and its current tensor versions -- never equal to another module's."""
+        versions = self._versions()
+        if self._token is not None and self._token_versions == versions:
+            return (self.precision, self._token)
+        return (self.precision, ("private", id(self)), versions)
 
     def encode(self, x, mean_only=False):
         """(z_mean, z_log_var, x_encoded) as src/betaVAE.py:102-107, eval mode.  mean_only: skip z_log_var (returned as

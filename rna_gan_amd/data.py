@@ -4,9 +4,10 @@ RNA table preparation, restated without the packages that are absent here.
 * **Tile store** (writer src/preprocess/patch_gen_grid.py:92-142, readers src/read_data.py:146-372): one key-value
   database per slide; value of key ``b"<i>"`` = ``lz4framed.compress(pickle.dumps((name, bytes, shape)))`` with
   ``bytes`` the uint8 HWC tile, and ``b"__keys__"`` = the compressed pickle of the key list.  The reference keeps the
-  databases in LMDB files; LMDB's on-disk B+tree is not restated: ``open_tile_store`` uses the ``lmdb`` package when it is
-  installed and otherwise accepts any mapping (dict / shelve / a directory of files through ``DirStore``) -- the record
-  format, the sampling and the decoding are the same for every backend.
+  databases in LMDB files: ``open_tile_store`` reads them through the ``lmdb`` package when it is installed and through
+  the built-in read-only walker of LMDB's on-disk B+tree otherwise (rna_gan_amd/lmdb_ro.py: meta pages, branch / leaf /
+  overflow pages); any mapping (dict / shelve / a directory of files through ``DirStore``) is accepted as well -- the
+  record format, the sampling and the decoding are the same for every backend.
 * **LZ4 frame** (``lz4framed`` is absent): ``lz4f_decompress`` implements the LZ4 frame format v1.6 (magic 0x184D2204,
   FLG / BD / header checksum, independent or linked blocks, stored blocks, optional content size / block / content
   checksums -- checksums are skipped, not verified: xxHash32 is only needed to WRITE a header) and the LZ4 block format
@@ -275,7 +276,7 @@ class DirStore(Mapping):
 class _LmdbStore(Mapping):
     def __init__(self, path):
         import lmdb
-        self.env = lmdb.open(path, subdir=False, readonly=True, lock=False, readahead=False, meminit=False)
+        self.env = lmdb.open(path, subdir=os.path.isdir(path), readonly=True, lock=False, readahead=False, meminit=False)
 
     def __getitem__(self, key):
         with self.env.begin(write=False) as txn:
@@ -292,18 +293,23 @@ class _LmdbStore(Mapping):
         with self.env.begin(write=False) as txn:
             return txn.stat()["entries"]
 
+    def close(self):
+        self.env.close()
+
 
 def open_tile_store(path):
-    """``path``: a mapping (returned as is), a directory written by ``write_tile_store`` or an LMDB file (needs ``lmdb``)."""
+    """``path``: a mapping (returned as is), a directory written by ``write_tile_store``, or an LMDB file as the reference
+    writes them (src/preprocess/patch_gen_grid.py:92-133): read through the ``lmdb`` package when it is installed, else by
+    the built-in read-only walker of the LMDB file format (rna_gan_amd.lmdb_ro)."""
     if isinstance(path, Mapping):
         return path
-    if os.path.isdir(path):
+    if os.path.isdir(path) and not os.path.exists(os.path.join(path, "data.mdb")):
         return DirStore(path)
     try:
         return _LmdbStore(path)
     except ImportError:
-        raise RuntimeError("%s is an LMDB file and the `lmdb` package is not installed; convert the slide database to a "
-                           "directory store (rna_gan_amd.data.write_tile_store) or install lmdb" % path)
+        from .lmdb_ro import LmdbReadOnly
+        return LmdbReadOnly(path)
 
 
 def write_tile_store(path: str, tiles_hwc_u8, slide_id: str = "slide"):
@@ -398,10 +404,22 @@ class PatchRNADataset(Dataset):
             label = torch.tensor(label, dtype=torch.float32)
             path = os.path.join(row["patch_data_path"], wsi, wsi.replace(".svs", ".db"))
             try:
-                store = self._store(path)
-                n_patches = len(store) - 1                                   # every entry but __keys__
-                keys = pickle.loads(lz4f_decompress(store[b"__keys__"]))
+                # opened for the count and the key list only, then let go -- as the reference does (one lmdb.open per
+                # row, src/read_data.py:306-312): no descriptor / mapping per slide is held for the dataset's lifetime
+                store, owned = self._open(path)
+                try:
+                    n_patches = len(store) - 1                               # every entry but __keys__
+                    keys = pickle.loads(lz4f_decompress(store[b"__keys__"]))
+                finally:
+                    if owned and hasattr(store, "close"):
+                        store.close()
                 index = random.sample(list(range(n_patches)), min(n_patches, max_patches_total))
+            except OSError as e:
+                import errno
+                if e.errno in (errno.EMFILE, errno.ENFILE, errno.ENOMEM):     # resource exhaustion is not "a bad database"
+                    raise
+                print("Error with db {}".format(path))
+                continue
             except Exception:
                 print("Error with db {}".format(path))
                 continue
@@ -413,17 +431,49 @@ class PatchRNADataset(Dataset):
                 self.keys.append(keys[i])
                 self.rna_data_arrays.append(rna)
 
-    def _store(self, path):
+    MAX_OPEN_STORES = 64          # per process: an LMDB environment is a descriptor + a mapping
+
+    def _open(self, path):
+        """(store, owned): a caller-supplied mapping (not owned), or a freshly opened store the caller closes."""
         st = self._stores.get(path)
+        if st is not None:
+            return st, False
+        return open_tile_store(path if os.path.exists(path) else path[:-3]), True
+
+    def _store(self, path):
+        """Store for item access: caller-supplied mappings as they are; files opened lazily in the process that reads them
+        (a DataLoader worker never inherits an environment opened by its parent -- LMDB forbids using one across fork)
+        and kept in a small per-process LRU."""
+        st = self._stores.get(path)
+        if st is not None:
+            return st
+        pid = os.getpid()
+        if getattr(self, "_lru_pid", None) != pid:
+            self._lru, self._lru_pid = {}, pid
+        st = self._lru.pop(path, None)
         if st is None:
-            st = self._stores[path] = open_tile_store(path if os.path.exists(path) else path[:-3])
+            st, _ = self._open(path)
+            while len(self._lru) >= self.MAX_OPEN_STORES:
+                old = self._lru.pop(next(iter(self._lru)))
+                if hasattr(old, "close"):
+                    old.close()
+        self._lru[path] = st                                                  # most recently used last
         return st
+
+    def __getstate__(self):           # pickled into spawned DataLoader workers: open stores stay behind
+        d = dict(self.__dict__)
+        d.pop("_lru", None); d.pop("_lru_pid", None)
+        return d
 
     def __len__(self):
         return len(self.images)
 
     def __getitem__(self, idx):
-        image = decompress_and_deserialize(self._store(self.lmdbs_path[idx])[self.keys[idx]])
+        try:
+            value = self._store(self.lmdbs_path[idx])[self.keys[idx]]
+        except KeyError:
+            value = None          # txn.get() of a missing key is None in the reference: decoded to image None, dropped by collate_fn
+        image = decompress_and_deserialize(value)
         if image is not None and self.transforms is not None:
             image = self.transforms(image)
         if not self.with_rna:

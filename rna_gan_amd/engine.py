@@ -541,7 +541,8 @@ def disc_loss_grads_batched(ops, G, D: DiscNet, real, noise, grad_scale: float =
     H, W = real.shape[2], real.shape[3]
     C0 = D.conv0.w.shape[0]
     a = torch.empty((2 * n, H // 2, W // 2, C0), dtype=ops.act_dtype, device=real.device)
-    bits = ops.sign_bits_for(2 * n, H // 2, W // 2) if R > 0 else None
+    # packed LeakyReLU sign bits of layer 0's output: only the 64-channel layer 0 under a 64 -> 128 layer 1 has that form
+    bits = ops.sign_bits_for(2 * n, H // 2, W // 2, C0, D.blocks[0][0].O) if R > 0 else None
     for h in range(2):
         ops.first_down(xs[h], D.conv0, D.conv0.bias, D.slope,
                        out=(a[h * n:(h + 1) * n], None if bits is None else bits[h * n:(h + 1) * n]))

@@ -542,7 +542,9 @@ class _LatentCache:
     and encodes the same RNA rows three times per iteration (:96-97, :223-224, :353-354); the result is the same
     tensor each time.  Here the first train_op of a batch encodes (its own small HIP graph), the other two reuse the
     latent when (a) they are handed the same RNA tensor (the cache keeps a reference to it, so identity by address +
-    version counter is sound) and (b) their encoder has the same weight signature.  ``new_batch()`` (called by
+    version counter is sound) and (b) their encoder holds the same weights BY PROVENANCE (betaVAE.signature(): the token of
+    the checkpoint file / state_dict the weights were loaded from, valid while no tensor of the module has been written
+    since -- not a fingerprint of the values).  ``new_batch()`` (called by
     Trainer.train_iter and by bench.py at the start of every iteration) drops the entry, so a latent is never carried
     from one iteration to the next even when the caller reuses one input tensor."""
 
@@ -576,7 +578,7 @@ class _VAEMixin:
     def _init_vae(self, checkpoint, rna_features, beta):
         self.betavae = betaVAE(rna_features, 2048, [6000, 4000, 2048], [4000, 6000], beta=beta)
         if checkpoint is not None:
-            self.betavae.load_state_dict(torch.load(checkpoint, map_location="cpu"))
+            self.betavae.load_checkpoint_file(checkpoint)      # weights token = the file's identity (_LatentCache)
         self.betavae.eval()
         self._runner = _Runner()
         self._enc_runner = _Runner()

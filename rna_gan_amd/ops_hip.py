@@ -388,6 +388,8 @@ class HipOps:
         # Discriminator layer 0 (slope != 1): the kernel also writes the packed sign bits of its output, one uint64 per
         # pixel, when the data-gradient conv of layer 1 can take its fused LeakyReLU mask in that form (conv_up below
         # picks them up from the tensor: 8 B instead of 128 B per pixel, and the patch-resident kernel).
+        # (the caller of layer 1's data gradient decides by rg_conv_up_maskbits_supported with ITS channel counts whether
+        # the bits are used; a 64 -> 128 second layer is the only shape that has the kernel)
         if (self.dt == RG_BF16 and O == 64 and slope != 1.0 and H % 4 == 0 and W % 4 == 0 and
                 self.lib.rg_conv_up_maskbits_supported(N, H // 4, W // 4, 128, 64, self.dt, self.algo)):
             bits = torch.empty((N, H // 2, W // 2), dtype=torch.int64, device=self.device)
@@ -596,11 +598,12 @@ class HipOps:
                                             ws.numel(), self.stream), "rg_bn_stats_finalize")
         return mean, invstd
 
-    def sign_bits_for(self, N, H, W):
-        """An (uninitialised) packed sign-bit tensor for a [N, H, W, 64] activation when the data-gradient conv above it
-        takes its LeakyReLU mask in that form (see first_down), else None."""
-        if (self.dt == RG_BF16 and H % 2 == 0 and W % 2 == 0 and
-                self.lib.rg_conv_up_maskbits_supported(N, H // 2, W // 2, 128, 64, self.dt, self.algo)):
+    def sign_bits_for(self, N, H, W, C0=64, C1=128):
+        """An (uninitialised) packed sign-bit tensor for a [N, H, W, C0] activation when the data-gradient conv above it
+        (C1 -> C0 channels) takes its LeakyReLU mask in that form (see first_down), else None.  rg_first_down_bits packs one
+        uint64 per pixel: 64 channels exactly."""
+        if (self.dt == RG_BF16 and C0 == 64 and H % 2 == 0 and W % 2 == 0 and
+                self.lib.rg_conv_up_maskbits_supported(N, H // 2, W // 2, C1, C0, self.dt, self.algo)):
             return torch.empty((N, H, W), dtype=torch.int64, device=self.device)
         return None
 

@@ -67,3 +67,9 @@ def synthetic_rna(n: int, features: int, seed: int, distinct: int = 16) -> torch
     rows = rng.normal(0.0, 1.0, size=(min(distinct, n), features)).astype(np.float32)
     idx = np.arange(n) % rows.shape[0]
     return torch.from_numpy(rows[idx])
+
+
+def synthetic_uniform(n: int, dims: int, seed: int, lo=-0.3, hi=0.3) -> torch.Tensor:
+    """The uniform draw of a train_op (src/wgan_loss.py:100), seeded: same values as the oracle's generator."""
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy(rng.uniform(lo, hi, size=(n, dims)).astype(np.float32))

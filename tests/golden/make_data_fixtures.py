@@ -89,21 +89,19 @@ def main():
         st[b"__keys__"] = PD.encode_keys(len(tiles))
         STORES[path] = st
     table = make_table(list(slides))
-    # (b) RNA preparation, the reference's call sequence (src/histopathology_gan.py:131-151)
+    # (b) RNA preparation: the reference's OWN TEXT (src/histopathology_gan.py:133-151 is inline code of its main(), not an
+    # importable function), extracted at generation time and executed on the synthetic table -- nothing is re-typed here
+    import linecache
+    import textwrap
     from sklearn.preprocessing import StandardScaler
-    train_df = table.copy()
-
-    def _get_log(x):
-        x = np.log(x.replace(0, np.nan))
-        return x.replace(np.nan, 0)
-    rna_columns = [x for x in train_df.columns if 'rna_' in x]
-    non_rna_columns = [x for x in train_df.columns if 'rna_' not in x]
-    train_df[rna_columns] = train_df[rna_columns].apply(_get_log)
-    train_df = train_df[rna_columns + non_rna_columns]
-    rna_values = train_df[rna_columns].values
-    scaler = StandardScaler()
-    rna_values = scaler.fit_transform(rna_values)
-    train_df[rna_columns] = rna_values
+    ref_file = os.path.join(REF, "histopathology_gan.py")
+    text = "".join(linecache.getline(ref_file, n) for n in range(133, 152))
+    assert "def _get_log" in text and "scaler.fit_transform" in text and "train_df[rna_columns] = rna_values" in text, \
+        "src/histopathology_gan.py:133-151 is not the RNA preparation block any more"
+    ns = {"np": np, "StandardScaler": StandardScaler, "train_df": table.copy()}
+    exec(compile(textwrap.dedent(text), ref_file + ":133-151", "exec"), ns)
+    train_df = ns["train_df"]
+    rna_columns = ns["rna_columns"]
     out["rna.columns"] = np.array(list(train_df.columns))
     out["rna.values"] = train_df[rna_columns].values.astype(np.float64)
     # (a) the reference datasets on the prepared table

@@ -165,3 +165,21 @@ def test_mixed_tissue_tables(tmp_path):
     # a single table passed as a string (configs/gan_run_lung.json's form)
     one = PD.load_slide_tables(paths[0], roots[0])
     assert one.shape[0] == 3 and set(one["labels"]) == {0}
+
+
+def test_rank_shards_have_equal_batch_counts():
+    """Multi-rank CLI runs: every rank must see the same number of full batches -- each train_op issues a
+    gradient all-reduce, so one extra batch on one rank hangs the job -- and the shards must partition one tile list."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("cli_hgan", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "histopathology_gan.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    for n_items in (0, 7, 63, 64, 65, 1000, 1001, 1023):
+        for world in (2, 4, 8):
+            for bs in (1, 8, 64):
+                shards = [cli.shard_indices(n_items, r, world, bs) for r in range(world)]
+                assert len({len(s) for s in shards}) == 1 and len(shards[0]) % bs == 0
+                flat = [i for s in shards for i in s]
+                assert len(set(flat)) == len(flat) and all(0 <= i < n_items for i in flat)
+                assert len(flat) >= n_items - world * bs - world + 1 or n_items < world * bs

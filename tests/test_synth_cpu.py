@@ -13,6 +13,7 @@ def test_generators_agree():
         assert torch.equal(S.seeded_tensor(name, shape, 7), R.seeded_tensor(name, shape, 7)), name
     assert torch.equal(S.synthetic_images(3, 16, 5), R.synthetic_images(3, 16, 5))
     assert torch.equal(S.synthetic_rna(5, 33, 9, distinct=2), R.synthetic_rna(5, 33, 9, distinct=2))
+    assert torch.equal(S.synthetic_uniform(4, 9, 11), R.synthetic_uniform(4, 9, 11))
     u8 = S.synthetic_tiles_u8(3, 16, 5)
     assert u8.dtype == torch.uint8 and torch.equal((u8.float() / 255.0 - 0.5) / 0.5, S.synthetic_images(3, 16, 5))
     a, b = nn.Linear(5, 3), nn.Linear(5, 3)

@@ -208,11 +208,13 @@ def test_graphs_survive_noop_move_and_optimizer_reload():
 def test_latent_is_encoded_once_per_batch():
     """The three betaVAE-conditioned loss plugins share one encode per batch (rna_gan_amd.losses._LatentCache): equal
     results with the cache on and off, 1 miss + 2 hits per iteration, and a different RNA tensor or a plugin whose
-    encoder weights differ always re-encodes."""
+    encoder weights differ always re-encodes.  Encoders are identified by the PROVENANCE of their weights (one state_dict /
+    one checkpoint file loaded into all three, untouched since), never by a fingerprint of the values: three encoders filled
+    independently with equal values do not share."""
     from rna_gan_amd import losses as PL
     enc, size, n, F = 2048, 32, 8, 96
 
-    def run(cache):
+    def run(cache, shared=True):
         PL.LATENT_CACHE = cache
         PL.new_batch()
         G = P.DCGANGenerator(enc, size, 3, 64, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
@@ -223,8 +225,14 @@ def test_latent_is_encoded_once_per_batch():
         od = P.Adam(D.parameters(), lr=4e-4, betas=(0.5, 0.999)).bind(D)
         ls = [P.WassersteinGeneratorLossVAE(None, F), P.WassersteinDiscriminatorLossVAE(None, F),
               P.WassersteinGradientPenaltyVAE(None, F)]
+        R.seeded_fill_(ls[0].betavae, 5)
+        sd = ls[0].betavae.state_dict()
         for l in ls:
-            R.seeded_fill_(l.betavae, 5)
+            if l is not ls[0]:
+                if shared:
+                    l.betavae.load_state_dict(sd)          # same weights by provenance
+                else:
+                    R.seeded_fill_(l.betavae, 5)           # equal values, independent fills: never shared
             l.betavae = l.betavae.cuda().eval()
         real = R.synthetic_images(n, size, seed=3).cuda()
         out = []
@@ -242,6 +250,9 @@ def test_latent_is_encoded_once_per_batch():
         assert PL._LATENT.misses - m0 == 3 and PL._LATENT.hits - h0 == 6
         b, _, _ = run(False)
         assert a == b
+        h2, m2 = PL._LATENT.hits, PL._LATENT.misses
+        c, _, _ = run(True, shared=False)
+        assert a == c and PL._LATENT.misses - m2 == 9 and PL._LATENT.hits == h2
         PL.LATENT_CACHE = True
         PL.new_batch()
         rna = R.synthetic_rna(n, F, seed=50, distinct=4).cuda()
