@@ -244,6 +244,38 @@ int rg_bn_act_bwd(const void* z, const void* ga, const float* mean, const float*
 int rg_bn_finalize_partials(const float* partial, int G, int M, int C, float eps, float momentum, float* mean,
                             float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, void* ws,
                             size_t ws_bytes, void* stream);
+/* ---- split-K conv + train-mode BatchNorm without the intermediate passes (bf16 path) -------------------------------
+ * The deep Conv2d / ConvTranspose2d layers at small batch run split-K (rg_conv_split(...) > 1): every launch leaves
+ * nsplit fp32 slabs [nsplit][rows][C] in the workspace.  rg_conv_down_partial / rg_conv_up_partial run ONLY that launch
+ * (slabs in `ws`, slab s at ws + s * rows * C floats, rows in output NHWC order); the consumer sums them:
+ *   rg_bn_forward_slabs : z = bf16(sum_s slab_s) (written), batch statistics of z (per batch group, running statistics
+ *                         updated group after group), a = lrelu(BN(z)) -- nn.Conv2d -> nn.BatchNorm2d(train) ->
+ *                         nn.LeakyReLU of the torchgan DCGAN blocks, = rg_conv_* + rg_bn_forward[_g2];
+ *   rg_bn_act_bwd_slabs : ga = bf16(sum_s slab_s) = the data gradient arriving at the block (written when ga_out != NULL),
+ *                         then exactly rg_bn_act_bwd[_g2] (.backward() of the same block).
+ * One launch each: the workgroups of a 128-column slice exchange their partial column sums through `scratch` and meet at
+ * a counter in `sync` (agent-scope release/acquire hand-off, deterministic summation order).  `sync`: a caller-owned
+ * buffer of rg_slab_bn_sync_words() 32-bit words, ZEROED ONCE when allocated and private to one stream (every launch
+ * leaves it zero); `scratch`: rg_slab_bn_scratch_bytes(M, C, groups) bytes, contents irrelevant.  M = rows per batch group
+ * (groups = 1 or 2, z is [groups * M][C]).  rg_slab_bn_supported: C % 128 == 0, nsplit in {2, 4, 8}, row count divisible
+ * into 32..256-row blocks with at most 768 workgroups (all co-resident on the 256 CUs -- required by the hand-off). */
+int rg_conv_split(int up, int N, int Hlow, int Wlow, int O, int I, int dtype, int algo);
+int rg_conv_down_partial(const void* x, const void* wdn, int N, int Hi, int Wi, int I, int O, int dtype, int algo,
+                         void* ws, size_t ws_bytes, void* stream);
+int rg_conv_up_partial(const void* x, const void* wup, int N, int Ho, int Wo, int O, int I, int dtype, int algo,
+                       void* ws, size_t ws_bytes, void* stream);
+int rg_slab_bn_supported(long long M, int C, int groups, int nsplit);
+size_t rg_slab_bn_scratch_bytes(long long M, int C, int groups);
+size_t rg_slab_bn_sync_words(void);
+int rg_bn_forward_slabs(const void* slab, int nsplit, size_t slab_stride, void* z, void* a, long long M, int C, int groups,
+                        float eps, float momentum, const float* gamma, const float* beta, float slope, float* mean,
+                        float* invstd, float* running_mean, float* running_var, long long* num_batches_tracked,
+                        void* scratch, size_t scratch_bytes, void* sync, void* stream);
+int rg_bn_act_bwd_slabs(const void* slab, int nsplit, size_t slab_stride, const void* z, void* ga_out, void* gz, long long M,
+                        int C, int groups, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                        float slope, float* s_gy, float* s_gyxh, float* dgamma, float* dbeta, int accumulate, void* scratch,
+                        size_t scratch_bytes, void* sync, void* stream);
+
 /* Two batch groups in one call (the D-loss step runs D(real) and D(fake) -- src/wgan_loss.py:241-253 -- as one double
  * batch through the conv layers; BatchNorm must treat the halves as the two separate forward calls they are in the
  * reference): z / a / ga / gz are [2*M][C] (first half first), mean / invstd / s_gy / s_gyxh [2][C].  rg_bn_forward_g2 =

@@ -121,9 +121,21 @@ PROTOTYPES = {
     "rg_fp8_supported": (_i, [_i, _i, _i, _i]),
     "rg_cast_fp8": (_i, [_p, _p, _z, _f, _p]),
     "rg_selftest_fp8": (_i, [_p, _p]),
+    "rg_conv_split": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "rg_conv_down_partial": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "rg_conv_up_partial": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "rg_slab_bn_supported": (_i, [C.c_longlong, _i, _i, _i]),
+    "rg_slab_bn_scratch_bytes": (_z, [C.c_longlong, _i, _i]),
+    "rg_slab_bn_sync_words": (_z, []),
+    "rg_bn_forward_slabs": (_i, [_p, _i, _z, _p, _p, C.c_longlong, _i, _i, _f, _f, _p, _p, _f, _p, _p, _p, _p, _p, _p, _z, _p, _p]),
+    "rg_bn_act_bwd_slabs": (_i, [_p, _i, _z, _p, _p, _p, C.c_longlong, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _p, _z,
+                                 _p, _p]),
     "rg_conv_up_affine": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _f, _p, _z, _p]),
     "rg_g0_fwd_affine": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _f, _p, _z, _p]),
 }
+
+# must equal rg_version() of the library (rna_gan_amd/csrc/rg_api.hip): bumped together with PROTOTYPES
+ABI_VERSION = 301
 
 _lib = None
 
@@ -144,9 +156,14 @@ def load():
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name, None)
         if fn is None:
-            raise RuntimeError("rna_gan_amd: symbol %s missing from %s" % (name, LIB_PATH))
+            raise RuntimeError("rna_gan_amd: symbol %s missing from %s: the library is older than this package -- rebuild "
+                               "it with `python -m rna_gan_amd.build`" % (name, LIB_PATH))
         fn.restype = res
         fn.argtypes = args
+    got = lib.rg_version()
+    if got != ABI_VERSION:
+        raise RuntimeError("rna_gan_amd: %s reports ABI version %d, this package binds version %d (a stale or swapped "
+                           "build): rebuild it with `python -m rna_gan_amd.build`" % (LIB_PATH, got, ABI_VERSION))
     _lib = lib
     return lib
 

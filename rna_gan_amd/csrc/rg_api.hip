@@ -17,7 +17,8 @@ void rg_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int rg_version(void) { return 104; }   // 1.04: upconv3 algo/workspace args, Adam weight_decay, betaVAE training entry points
+// bumped whenever an entry point is added or a signature changes; rna_gan_amd/_abi.py (ABI_VERSION) refuses any other value
+extern "C" int rg_version(void) { return 301; }   // 3.01: round 3 (split-K slabs consumed by the fused BatchNorm pass)
 extern "C" const char* rg_last_error(void) { return g_err; }
 
 // ---- kernel-selection knobs: override table in front of the RNAGAN_* environment variables
@@ -72,6 +73,31 @@ extern "C" int rg_conv_stats_rows(int up, int N, int Hlow, int Wlow, int O, int 
   if (N <= 0 || Hlow <= 0 || Wlow <= 0 || O <= 0 || I <= 0 || !want_mfma(algo, dtype)) return 0;
   if (!rg_mfma_conv_supported(N, Hlow, Wlow, up ? O : I, up ? I : O)) return 0;
   return rg_mfma_conv_stats_rows(up, N, Hlow, Wlow, O, I);
+}
+
+// ---- split-K launches whose slab reduction is left to the consumer (rg_bn_forward_slabs / rg_bn_act_bwd_slabs)
+extern "C" int rg_conv_split(int up, int N, int Hlow, int Wlow, int O, int I, int dtype, int algo) {
+  if (N <= 0 || Hlow <= 0 || Wlow <= 0 || O <= 0 || I <= 0 || !want_mfma(algo, dtype)) return 1;
+  if (!rg_mfma_conv_supported(N, Hlow, Wlow, up ? O : I, up ? I : O)) return 1;
+  return rg_mfma_conv_nsplit(up, N, Hlow, Wlow, O, I);
+}
+
+extern "C" int rg_conv_down_partial(const void* x, const void* wdn, int N, int Hi, int Wi, int I, int O, int dtype, int algo,
+                                    void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(x && wdn && ws && N > 0 && Hi > 0 && Wi > 0 && I > 0 && O > 0 && Hi % 2 == 0 && Wi % 2 == 0, RG_EINVAL,
+             "conv_down_partial: bad args");
+  RG_REQUIRE(rg_conv_split(0, N, Hi / 2, Wi / 2, O, I, dtype, algo) > 1, RG_EUNSUPPORTED,
+             "conv_down_partial: this shape does not run split-K (rg_conv_split)");
+  return rg_mfma_conv_down(x, wdn, nullptr, N, Hi, Wi, I, O, nullptr, ws, ws_bytes, rg_stream(stream), 1);
+}
+
+extern "C" int rg_conv_up_partial(const void* x, const void* wup, int N, int Ho, int Wo, int O, int I, int dtype, int algo,
+                                  void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(x && wup && ws && N > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0, RG_EINVAL, "conv_up_partial: bad args");
+  RG_REQUIRE(rg_conv_split(1, N, Ho, Wo, O, I, dtype, algo) > 1, RG_EUNSUPPORTED,
+             "conv_up_partial: this shape does not run split-K (rg_conv_split)");
+  return rg_mfma_conv_up(x, wup, nullptr, N, Ho, Wo, O, I, nullptr, 1.f, nullptr, ws, ws_bytes, rg_stream(stream), nullptr,
+                         nullptr, 1.f, 0, 1);
 }
 
 extern "C" int rg_conv_down(const void* x, const float* w, const void* wdn, void* y, int N, int Hi, int Wi, int I,

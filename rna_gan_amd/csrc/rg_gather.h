@@ -38,6 +38,8 @@ struct GArgs {
   float mslope;           // (LeakyReLU backward of the consumer fused into the data-gradient conv)
   int in_fp8, out_fp8;    // conv8_kernel<.., EB = 1>: fp8 e4m3 operands (A, B) / fp8 output (row stride ldc in elements)
   int mask_packed;        // mask holds packed sign bits (one 64-bit word per output pixel: convp_kernel only)
+  int defer_reduce;       // split-K launches: leave the fp32 slabs in the workspace, do not launch the slab reduction (the consumer
+                          // reduces them itself: rg_splitbn.hip fuses the reduction into the BatchNorm pass that follows)
   int affine;             // EPI_BF16, bf16 output without split-K: out = lrelu(acc * scale[col] + shift[col], slope) (eval-mode
                           // BatchNorm folded into the conv epilogue: generator-only inference)
 };

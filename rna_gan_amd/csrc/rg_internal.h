@@ -36,11 +36,12 @@ int rg_mfma_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I,
 int rg_mfma_pack_g0_weight(const float* w, void* wp, int E, int C, hipStream_t st);
 int rg_mfma_pack_linear_weight(const float* w, void* wp, int Nout, int K, int Nout_pad, int K_pad, hipStream_t st);
 int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, int Wi, int I, int O, float* stats,
-                      void* ws, size_t ws_bytes, hipStream_t st);
+                      void* ws, size_t ws_bytes, hipStream_t st, int defer_reduce = 0);
+int rg_mfma_conv_nsplit(int up, int N, int Hlow, int Wlow, int O, int I);
 int rg_mfma_conv_stats_rows(int up, int N, int Hlow, int Wlow, int O, int I);
 int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, const void* mask,
                     float mslope, float* stats, void* ws, size_t ws_bytes, hipStream_t st, const float* scale = nullptr,
-                    const float* shift = nullptr, float slope = 1.f, int mask_packed = 0);
+                    const float* shift = nullptr, float slope = 1.f, int mask_packed = 0, int defer_reduce = 0);
 // packed-mask form of the transposed conv's fused LeakyReLU backward (rg_convp.hip): shapes that take it
 bool rg_mfma_conv_up_maskbits_supported(int N, int Ho, int Wo, int O, int I);
 size_t rg_mfma_conv_ws_bytes(int up, int N, int Hlow, int Wlow, int O, int I);

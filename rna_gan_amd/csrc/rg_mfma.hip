@@ -1247,6 +1247,8 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   int nsplit = pl.nsplit;
   size_t need = (size_t)nsplit * rows_out * (EPI == EPI_BF16 ? g.Ncols : g.ldc) * sizeof(float);
   if (nsplit > 1 && (!ws || ws_bytes < need)) nsplit = 1;
+  RG_REQUIRE(!g.defer_reduce || (nsplit > 1 && nsplit == pl.nsplit), RG_EUNSUPPORTED,
+             "%s: partial (split-K slab) output asked for a launch that does not split (rg_conv_split)", name);
   if (EPI == EPI_LINEAR && (g.Ncols % 8 != 0 || g.ldc % 4 != 0)) nsplit = 1;      // slab rows are written 8 wide
   a2.a_bytes = (unsigned)a_bytes; a2.b_bytes = (unsigned)b_bytes;
   a2.korder = (MODE == MODE_DOWN || MODE == MODE_UP) ? rg_option("korder", 1) : 0;
@@ -1307,7 +1309,7 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
     hipLaunchKernelGGL(reduce_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws,
                        (float*)g.C, g.M, g.Ncols, g.ldc, (size_t)a2.slab_stride, nsplit, g.scale, g.shift, g.slope);
     RG_LAUNCH_CHECK(name);
-  } else if (nsplit > 1) {
+  } else if (nsplit > 1 && !g.defer_reduce) {
     size_t n8 = (size_t)rows_out * g.Ncols / 8;
     hipLaunchKernelGGL(reduce_slabs_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, (const float*)ws,
                        (uint16_t*)g.C, n8, (size_t)rows_out * g.Ncols, nsplit);
@@ -1317,8 +1319,9 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
 }
 
 int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, int Wi, int I, int O, float* stats,
-                      void* ws, size_t ws_bytes, hipStream_t st) {
+                      void* ws, size_t ws_bytes, hipStream_t st, int defer_reduce) {
   GArgs g{};
+  g.defer_reduce = defer_reduce;
   g.stats = stats;
   g.A = (const uint16_t*)x; g.B = (const uint16_t*)wdn; g.C = y;
   int Ho = Hi / 2, Wo = Wi / 2;
@@ -1330,8 +1333,9 @@ int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, in
 
 int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, const void* mask,
                     float mslope, float* stats, void* ws, size_t ws_bytes, hipStream_t st, const float* scale,
-                    const float* shift, float slope, int mask_packed) {
+                    const float* shift, float slope, int mask_packed, int defer_reduce) {
   GArgs g{};
+  g.defer_reduce = defer_reduce;
   RG_REQUIRE(!mask_packed || (mask && rg_mfma_conv_up_maskbits_supported(N, Ho, Wo, O, I)), RG_EUNSUPPORTED,
              "conv_up: packed mask bits need the patch-resident kernel's shape (128 -> 64 channels, width 16..64)");
   g.mask_packed = mask_packed;
@@ -1392,6 +1396,17 @@ int rg_mfma_gemm_fp8(const void* a8, const void* b8, void* y, int M, int K, int 
   g.A = (const uint16_t*)a8; g.B = (const uint16_t*)b8; g.C = y;
   g.M = M; g.Ncols = Ncols; g.Cin = K; g.taps = 1; g.lgW = 0; g.lgH = 0; g.Hs = 1; g.Ws = 1; g.ldc = Ncols; g.b_col = K; g.b_tap = 0;
   return launch_conv8_fp8("gemm_fp8", MODE_PLAIN, g, 1, (size_t)M * K, (size_t)Ncols * K, st);
+}
+
+// split factor of the plain (unmasked, bf16-output) conv launch of this shape: > 1 means the launch leaves fp32 slabs
+// [nsplit][rows_out][Ncols] that a reduction pass (or a fused consumer, rg_splitbn.hip) sums
+int rg_mfma_conv_nsplit(int up, int N, int Hlow, int Wlow, int O, int I) {
+  const int M = N * Hlow * Wlow, Ncols = up ? I : O, Cin = up ? O : I, taps = up ? 4 : 16, nclass = up ? 4 : 1;
+  const size_t a_bytes = up ? (size_t)M * O * 2 : (size_t)M * 4 * I * 2, b_bytes = (size_t)O * 16 * I * 2;
+  if (use_v1() || a_bytes >= 0x7fffff00ull || b_bytes >= 0x7fffff00ull) return 1;
+  const GPlan pl = gather_plan(up ? MODE_UP : MODE_DOWN, true, M, Ncols, Cin, taps, nclass, false, up ? Hlow : 2 * Hlow,
+                               up ? Wlow : 2 * Wlow);
+  return pl.nsplit;
 }
 
 size_t rg_mfma_conv_ws_bytes(int up, int N, int Hlow, int Wlow, int O, int I) {

@@ -172,7 +172,8 @@ def disc_forward(ops, D: DiscNet, x_nchw, update_running=True):
     ctx.a = [a]
     ctx.z, ctx.mean, ctx.invstd = [None], [None], [None]
     for cw, bn in D.blocks:
-        z, st = ops.conv_down(a, cw, want_stats=True)
+        # defer=1: a split-K launch leaves its slabs to the BatchNorm op that follows (one fused reduce + statistics + apply)
+        z, st = ops.conv_down(a, cw, want_stats=True, defer=1)
         a, mean, invstd = _bn_forward(ops, z, bn, D.slope, update_running, st)
         ctx.z.append(z); ctx.mean.append(mean); ctx.invstd.append(invstd); ctx.a.append(a)
     ctx.h, out = ops.head_fwd(a, D.head, D.last_slope)
@@ -205,14 +206,15 @@ def disc_backward(ops, D: DiscNet, ctx, coef: float, wgrad: bool, accumulate: bo
         cw, bn = D.blocks[l - 1]
         gz, s_gy, s_gyxh = ops.bn_act_bwd(ctx.z[l], ga, ctx.mean[l], ctx.invstd[l], bn.gamma, bn.beta,
                                           D.slope, bn.dgamma if wgrad else None,
-                                          bn.dbeta if wgrad else None, accumulate)
+                                          bn.dbeta if wgrad else None, accumulate, keep_ga=keep_for_gp)
         if keep_for_gp:
             ctx.ga1[l], ctx.gz1[l], ctx.s_gy[l], ctx.s_gyxh[l] = ga, gz, s_gy, s_gyxh
         if wgrad:
             with ops.side(gz):
                 ops.conv_wgrad(gz, ctx.a[l - 1], cw, accumulate)
         # the data gradient of layer 1 feeds layer 0's LeakyReLU: its backward is fused into the epilogue
-        ga = ops.conv_up(gz, cw) if l > 1 else ops.conv_up(gz, cw, ctx.a[0], D.slope)
+        # (defer=1: the next op on ga is the BatchNorm backward of the layer below, which reduces split-K slabs itself)
+        ga = ops.conv_up(gz, cw, defer=1) if l > 1 else ops.conv_up(gz, cw, ctx.a[0], D.slope)
     gz0 = ga if R > 0 else ops.lrelu_bwd(ga, ctx.a[0], D.slope)
     if keep_for_gp:
         ctx.gz1[0] = gz0
@@ -241,12 +243,14 @@ def disc_backward_pair(ops, D: DiscNet, ctx_a, coef_a: float, ctx_b, coef_b: flo
     for l in range(R, 0, -1):
         cw, bn = D.blocks[l - 1]
         gz_a, _, _ = ops.bn_act_bwd(ctx_a.z[l], ga_a, ctx_a.mean[l], ctx_a.invstd[l], bn.gamma, bn.beta, D.slope,
-                                    bn.dgamma, bn.dbeta, False)
+                                    bn.dgamma, bn.dbeta, False, keep_ga=False)
         gz_b, _, _ = ops.bn_act_bwd(ctx_b.z[l], ga_b, ctx_b.mean[l], ctx_b.invstd[l], bn.gamma, bn.beta, D.slope,
-                                    bn.dgamma, bn.dbeta, True)
+                                    bn.dgamma, bn.dbeta, True, keep_ga=False)
         with ops.side(gz_a, gz_b):
             ops.conv_wgrad2(gz_a, ctx_a.a[l - 1], gz_b, ctx_b.a[l - 1], cw, False)
         if l > 1:
+            # (no deferred slabs here: the two chains share one workspace and chain a's BatchNorm backward runs -- and uses it --
+            # before chain b's would consume what chain b's conv left there)
             ga_a, ga_b = ops.conv_up(gz_a, cw), ops.conv_up(gz_b, cw)
         else:
             ga_a = ops.conv_up(gz_a, cw, ctx_a.a[0], D.slope)
@@ -344,7 +348,8 @@ def gen_forward(ops, G: GenNet, noise, update_running=True, keep=True):
     a, mean, invstd = _bn_forward(ops, z, G.bn0, G.slope, update_running)
     ctx.z, ctx.mean, ctx.invstd, ctx.a = [z], [mean], [invstd], [a]
     for l, (cw, bn) in enumerate(G.blocks):
-        z, st = ops.conv_up(a, cw, want_stats=True)
+        fused_last = not keep and l == len(G.blocks) - 1        # (that path takes the epilogue statistics, not slabs)
+        z, st = ops.conv_up(a, cw, want_stats=True, defer=0 if fused_last else 1)
         if not keep and l == len(G.blocks) - 1:
             # nothing is kept for a backward pass: the last BatchNorm + LeakyReLU is applied inside the image layer
             img = ops.last_up_bn(z, st, bn, G.slope, G.last, G.last.bias, True, update_running)
@@ -383,7 +388,7 @@ def gen_forward_pair(ops, G: GenNet, noise2, update_running=True):
     z = ops.g0_fwd(noise2, G.g0)
     a, _, _ = ops.bn_forward2(z, G.bn0.gamma, G.bn0.beta, G.slope, G.bn0.eps, G.bn0.momentum, *run(G.bn0))
     for l, (cw, bn) in enumerate(G.blocks):
-        z, st = ops.conv_up(a, cw, want_stats=True)
+        z, st = ops.conv_up(a, cw, want_stats=True, defer=0 if l == len(G.blocks) - 1 else 2)
         st = _class_partials(st, a.numel() // a.shape[-1] // 2)
         if l == len(G.blocks) - 1:
             img = ops.last_up_bn2(z, st, bn, G.slope, G.last, G.last.bias, True, update_running)
@@ -452,12 +457,12 @@ def gen_backward(ops, G: GenNet, ctx, gimg, accumulate: bool, need_input_grad: b
     for l in range(R, 0, -1):
         cw, bn = G.blocks[l - 1]
         gz, _, _ = ops.bn_act_bwd(ctx.z[l], ga, ctx.mean[l], ctx.invstd[l], bn.gamma, bn.beta,
-                                  G.slope, bn.dgamma, bn.dbeta, accumulate)
+                                  G.slope, bn.dgamma, bn.dbeta, accumulate, keep_ga=False)
         with ops.side(gz):
             ops.conv_wgrad(ctx.a[l - 1], gz, cw, accumulate)
-        ga = ops.conv_down(gz, cw)
+        ga = ops.conv_down(gz, cw, defer=1)        # consumed by the BatchNorm backward of the layer below (next op)
     gz0, _, _ = ops.bn_act_bwd(ctx.z[0], ga, ctx.mean[0], ctx.invstd[0], G.bn0.gamma, G.bn0.beta,
-                               G.slope, G.bn0.dgamma, G.bn0.dbeta, accumulate)
+                               G.slope, G.bn0.dgamma, G.bn0.dbeta, accumulate, keep_ga=False)
     ops.g0_wgrad(ctx.noise, gz0, G.g0.dw, accumulate)
     gin = ops.g0_bwd_data(gz0, G.g0) if need_input_grad else None
     ops.join()
@@ -550,7 +555,7 @@ def disc_loss_grads_batched(ops, G, D: DiscNet, real, noise, grad_scale: float =
         a._rg_sign_bits = bits
     acts, zs, means, invstds = [a], [None], [None], [None]
     for cw, bn in D.blocks:
-        z, st = ops.conv_down(a, cw, want_stats=True)
+        z, st = ops.conv_down(a, cw, want_stats=True, defer=2)
         m_half = z.numel() // z.shape[-1] // 2
         if _half_partials(st, m_half, 2 * m_half, 0) is None:
             st = None                                       # a partial row straddles the halves: BatchNorm reduces itself
@@ -569,7 +574,7 @@ def disc_loss_grads_batched(ops, G, D: DiscNet, real, noise, grad_scale: float =
         gz = ops.bn_act_bwd2(zs[l], ga, means[l], invstds[l], bn.gamma, bn.beta, D.slope, bn.dgamma, bn.dbeta, False)
         with ops.side(gz):
             ops.conv_wgrad(gz, acts[l - 1], cw, False)
-        ga = ops.conv_up(gz, cw) if l > 1 else ops.conv_up(gz, cw, acts[0], D.slope)
+        ga = ops.conv_up(gz, cw, defer=2) if l > 1 else ops.conv_up(gz, cw, acts[0], D.slope)
     gz0 = ga if R > 0 else ops.lrelu_bwd(ga, acts[0], D.slope)
     with ops.side(gz0):
         ops.skinny_wgrad(gz0[:n], xs[0], D.conv0.dw, False)

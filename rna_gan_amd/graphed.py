@@ -9,6 +9,7 @@ the Adam step counter / bias corrections and the penalty's eps are device scalar
 """
 from __future__ import annotations
 
+import math
 import os
 
 import torch
@@ -20,8 +21,14 @@ _POOL = None
 
 
 def _pool():
-    """One memory pool for all step graphs: they never run concurrently, so they share activations."""
+    """One memory pool for all step graphs: they never run concurrently, so they share activations.
+    Consequence (torch's rule for shared pools): a graph's replay may overwrite what an EARLIER-REPLAYED graph left in the
+    pool -- its intermediates were free blocks when the other graph was captured.  Tensors handed from one graph to the next
+    are read before anything else replays; small outputs the CALLER reads later (the loss scalars) are therefore copied,
+    inside the captured graph, into buffers that live outside the pool (StepGraph._stable)."""
     global _POOL
+    if os.environ.get("RNAGAN_GRAPH_POOL", "1") == "0":
+        return None                              # diagnostic: a private pool per graph
     if _POOL is None:
         _POOL = torch.cuda.graph_pool_handle()
     return _POOL
@@ -55,6 +62,30 @@ class StepGraph:
         self.static_out = None
         self.calls = 0
         self.failed = False
+        self._out_spec = None          # (shape, dtype, device) of every tensor the last eager run returned
+
+    STABLE_NUMEL = 4096                # outputs up to this size get a home outside the graph pool
+
+    @staticmethod
+    def _flat(out):
+        return list(out) if isinstance(out, (tuple, list)) else [out]
+
+    def _note_outputs(self, out):
+        self._out_spec = [(tuple(t.shape), t.dtype, t.device) if torch.is_tensor(t) else None for t in self._flat(out)]
+        return out
+
+    def _stable(self, out, bufs):
+        """Inside the capture: copy every small output into its persistent buffer (allocated before the capture, i.e. NOT
+        in the shared graph pool) and return the buffers in its place: a loss scalar stays readable after other graphs of
+        the pool have replayed (bench.py reads an iteration's three losses after all three train_ops)."""
+        res = []
+        for t, b in zip(self._flat(out), bufs):
+            if b is not None:
+                b.copy_(t)
+                res.append(b)
+            else:
+                res.append(t)
+        return type(out)(res) if isinstance(out, (tuple, list)) else res[0]
 
     def _run(self):
         return self.fn(*self.static_in)
@@ -72,15 +103,19 @@ class StepGraph:
                     s.copy_(t, non_blocking=True)
         self.calls += 1
         if self.failed or self.calls <= WARMUP_CALLS or (self.graph is None and not allow_capture):
-            return self._run()
+            return self._note_outputs(self._run())
         if self.graph is None:
             try:
                 torch.cuda.synchronize()
+                bufs = [torch.empty(sp[0], dtype=sp[1], device=sp[2])
+                        if sp is not None and math.prod(sp[0]) <= self.STABLE_NUMEL else None
+                        for sp in (self._out_spec or [])]
                 g = torch.cuda.CUDAGraph()
                 # thread_local: other threads (RCCL's watchdog polls events) may touch the HIP runtime while
                 # this thread captures; the default global mode turns that into a capture error / hang
                 with torch.cuda.graph(g, pool=_pool(), capture_error_mode="thread_local"):
-                    self.static_out = self._run()
+                    out = self._run()
+                    self.static_out = self._stable(out, bufs) if len(bufs) == len(self._flat(out)) else out
                 self.graph = g
                 if os.environ.get("RNAGAN_GRAPH_DEBUG"):
                     print("rna_gan_amd: captured graph #%d for %s" % (len(_captured), getattr(self.fn, "__name__", "?")),

@@ -270,10 +270,15 @@ class _DiscForwardFn(torch.autograd.Function):
         ops, net = module.runtime()
         out, dctx = E.disc_forward(ops, net, x, update_running=True)
         ctx.module, ctx.dctx, ctx.need_x = module, dctx, x.requires_grad
+        # a consumer that returns no gradient for this output (losses._GradientPenaltyFn: the penalty's parameter gradients
+        # come from its own second-order pass) must not trigger a whole discriminator backward on a zero cotangent
+        ctx.set_materialize_grads(False)
         return out
 
     @staticmethod
     def backward(ctx, gout):
+        if gout is None:
+            return (None, None) + (None,) * len(ctx.module._rt_flat.params)
         ops, net = ctx.module.runtime()
         wgrad = any(p.requires_grad for p in ctx.module._rt_flat.params)
         gx = E.disc_backward(ops, net, ctx.dctx, gout.contiguous(), wgrad=wgrad, accumulate=True,

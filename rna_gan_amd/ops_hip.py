@@ -18,6 +18,17 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+class SlabRef:
+    """The fp32 split-K slabs a deferred conv launch left in the workspace (conv_down / conv_up with defer=groups): attached
+    to the (not yet written) output tensor as ``t._rg_slabs`` and consumed by the BatchNorm op that follows, which sums the
+    slabs itself and writes the tensor (rg_bn_forward_slabs / rg_bn_act_bwd_slabs).  Holds the workspace tensor alive."""
+
+    __slots__ = ("ws", "nsplit", "stride", "groups")
+
+    def __init__(self, ws, nsplit, stride, groups):
+        self.ws, self.nsplit, self.stride, self.groups = ws, nsplit, stride, groups
+
+
 class HipOps:
     name = "hip"
 
@@ -50,6 +61,13 @@ class HipOps:
         # for small fp32 tensors and the number of ranks; None = rank-local statistics (plain DDP semantics)
         self.stat_reduce = None
         self.stat_world = 1
+        # split-K conv -> BatchNorm without the intermediate passes (rg_splitbn.hip): the conv leaves its slabs, the BatchNorm
+        # kernel reduces them (RNAGAN_SPLIT_BN=0: conv + slab reduction + statistics + finisher + apply as separate launches)
+        self.split_bn = os.environ.get("RNAGAN_SPLIT_BN", "1") != "0"
+        self._slabs_pending = None    # the tensor whose deferred split-K slabs currently occupy the workspace
+        self._sb_sync = None          # hand-off words of the fused kernels: zeroed once, left zero by every launch
+        self._sb_scratch = None
+        self._sb_retired = []
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -60,6 +78,10 @@ class HipOps:
         """Caller-owned workspace of the C ABI calls.  A buffer that is outgrown is RETIRED, not freed: captured HIP
         graphs replay launches that hold its address (growth is geometric, so the retired list stays short)."""
         nbytes = max(int(nbytes), 256)
+        if self._slabs_pending is not None and not self._in_side:
+            # a deferred conv's split-K slabs live in this buffer until the BatchNorm op that was promised consumes them
+            raise RuntimeError("rna_gan_amd: a conv launched with defer= left its split-K slabs in the workspace and another "
+                               "op asked for the workspace before the BatchNorm op consumed them")
         if self._in_side:
             if self._wsbuf_side is None or self._wsbuf_side.numel() < nbytes:
                 if self._wsbuf_side is not None:
@@ -71,6 +93,26 @@ class HipOps:
                 self._ws_retired.append(self._wsbuf)
             self._wsbuf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=self.device)
         return self._wsbuf
+
+    def _sb_bufs(self, M, C, groups):
+        """(scratch, sync) of the fused split-K BatchNorm kernels; an outgrown scratch buffer is retired, not freed (graphs)."""
+        if self._sb_sync is None:
+            self._sb_sync = torch.zeros(int(self.lib.rg_slab_bn_sync_words()), dtype=torch.int32, device=self.device)
+        need = int(self.lib.rg_slab_bn_scratch_bytes(int(M), int(C), int(groups)))
+        if self._sb_scratch is None or self._sb_scratch.numel() < need:
+            if self._sb_scratch is not None:
+                self._sb_retired.append(self._sb_scratch)
+            self._sb_scratch = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
+        return self._sb_scratch, self._sb_sync
+
+    def _defer_split(self, up, N, Hl, Wl, O, I, rows_out, C, groups):
+        """Split factor if this conv launch can hand its slabs to the fused BatchNorm kernel (groups batch groups), else 0."""
+        if not groups or not self.split_bn or self.dt != RG_BF16 or self.stat_reduce is not None or rows_out % groups:
+            return 0
+        ns = int(self.lib.rg_conv_split(up, N, Hl, Wl, O, I, self.dt, self.algo))
+        if ns <= 1 or not self.lib.rg_slab_bn_supported(rows_out // groups, C, groups, ns):
+            return 0
+        return ns
 
     @contextmanager
     def side(self, *tensors):
@@ -151,15 +193,28 @@ class HipOps:
         rows = self.lib.rg_conv_stats_rows(up, N, Hl, Wl, O, I, self.dt, self.algo)
         return self._f32(rows, 2, C) if rows > 0 else None
 
-    def conv_down(self, x, cw: ConvW, want_stats=False):
+    def conv_down(self, x, cw: ConvW, want_stats=False, defer=0):
         """Stride-2 conv.  want_stats: also return the per-tile column sums of y and y^2 written by the MFMA epilogue
-        (None when this shape cannot produce them) for bn_forward(..., partials=...)."""
+        (None when this shape cannot produce them) for bn_forward(..., partials=...).
+        defer = g > 0: the caller promises that the NEXT op on the result is the train-mode BatchNorm op (forward: bn_forward /
+        bn_forward2, backward: bn_act_bwd / bn_act_bwd2) over g batch groups.  If this launch runs split-K, only the slab
+        launch is issued; the result tensor is returned UNWRITTEN with ``_rg_slabs`` attached and the BatchNorm op reduces
+        the slabs (and writes the tensor) itself."""
         N, Hi, Wi, I = x.shape
         O = cw.O
         self._tap_major(cw)
         assert cw.I == I and x.is_contiguous()
         wdn, _ = self._packs(cw)
         y = self._act(N, Hi // 2, Wi // 2, O)
+        ns = self._defer_split(0, N, Hi // 2, Wi // 2, O, I, N * (Hi // 2) * (Wi // 2), O, defer)
+        if ns:
+            ws = self._ws(self.lib.rg_conv_workspace_bytes(0, N, Hi // 2, Wi // 2, O, I, self.dt, self.algo))
+            self._timed("conv_fwd_dgrad", 2.0 * N * (Hi // 2) * (Wi // 2) * O * I * 16, lambda: check(
+                self.lib.rg_conv_down_partial(_ptr(x), _ptr(wdn), N, Hi, Wi, I, O, self.dt, self.algo, _ptr(ws), ws.numel(),
+                                              self.stream), "rg_conv_down_partial"))
+            y._rg_slabs = SlabRef(ws, ns, y.numel(), defer)
+            self._slabs_pending = y
+            return (y, None) if want_stats else y
         st = self._stats_buf(0, N, Hi // 2, Wi // 2, O, I, O) if want_stats else None
         ws = self._ws(self.lib.rg_conv_workspace_bytes(0, N, Hi // 2, Wi // 2, O, I, self.dt, self.algo))
         self._timed("conv_fwd_dgrad", 2.0 * N * (Hi // 2) * (Wi // 2) * O * I * 16, lambda: check(
@@ -167,15 +222,24 @@ class HipOps:
                                   self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_down"))
         return (y, st) if want_stats else y
 
-    def conv_up(self, x, cw: ConvW, mask_act=None, slope=1.0, want_stats=False):
+    def conv_up(self, x, cw: ConvW, mask_act=None, slope=1.0, want_stats=False, defer=0):
         """Transposed conv; with mask_act (same shape as the result) the LeakyReLU backward
-        ``y *= (mask_act > 0 ? 1 : slope)`` is applied in the kernel's epilogue.  want_stats: as conv_down."""
+        ``y *= (mask_act > 0 ? 1 : slope)`` is applied in the kernel's epilogue.  want_stats, defer: as conv_down."""
         N, Ho, Wo, O = x.shape
         I = cw.I
         self._tap_major(cw)
         assert cw.O == O and x.is_contiguous()
         _, wup = self._packs(cw)
         y = self._act(N, 2 * Ho, 2 * Wo, I)
+        ns = self._defer_split(1, N, Ho, Wo, O, I, N * 4 * Ho * Wo, I, defer) if mask_act is None else 0
+        if ns:
+            ws = self._ws(self.lib.rg_conv_workspace_bytes(1, N, Ho, Wo, O, I, self.dt, self.algo))
+            self._timed("conv_fwd_dgrad", 2.0 * N * Ho * Wo * O * I * 16, lambda: check(
+                self.lib.rg_conv_up_partial(_ptr(x), _ptr(wup), N, Ho, Wo, O, I, self.dt, self.algo, _ptr(ws), ws.numel(),
+                                            self.stream), "rg_conv_up_partial"))
+            y._rg_slabs = SlabRef(ws, ns, y.numel(), defer)
+            self._slabs_pending = y
+            return (y, None) if want_stats else y
         assert mask_act is None or (mask_act.shape == y.shape and mask_act.dtype == y.dtype and mask_act.is_contiguous())
         st = self._stats_buf(1, N, Ho, Wo, O, I, I) if (want_stats and mask_act is None) else None
         ws = self._ws(self.lib.rg_conv_workspace_bytes(1, N, Ho, Wo, O, I, self.dt, self.algo))
@@ -612,6 +676,9 @@ class HipOps:
         """Train-mode BatchNorm + LeakyReLU: (a, mean, invstd).  partials: the column sums the producing conv's
         epilogue wrote (conv_down/conv_up want_stats) -- then no statistics pass over z is needed."""
         M, C = self._mc(z)
+        sl = getattr(z, "_rg_slabs", None)
+        if sl is not None:                        # z is still split-K slabs: reduce + statistics + apply in one launch
+            return self._bn_forward_slabs(z, sl, 1, gamma, beta, slope, eps, momentum, running_mean, running_var, nbt, out)
         if self.stat_reduce is not None:          # global statistics: local sums -> all-reduce -> finalize -> apply
             s, ss = self.bn_stats(z)
             self.stat_reduce(s); self.stat_reduce(ss)
@@ -638,6 +705,23 @@ class HipOps:
                                      _ptr(a), self.dt, _ptr(ws), ws.numel(), self.stream), "rg_bn_forward")
         return a, mean, invstd
 
+    def _bn_forward_slabs(self, z, sl: SlabRef, groups, gamma, beta, slope, eps, momentum, running_mean, running_var, nbt,
+                          out=None):
+        M2, C = self._mc(z)
+        assert sl.groups == groups and M2 % groups == 0
+        M = M2 // groups
+        mean, invstd = (self._f32(C), self._f32(C)) if groups == 1 else (self._f32(groups, C), self._f32(groups, C))
+        a = out if out is not None else torch.empty_like(z)
+        assert a.shape == z.shape and a.is_contiguous()
+        scratch, sync = self._sb_bufs(M, C, groups)
+        check(self.lib.rg_bn_forward_slabs(_ptr(sl.ws), sl.nsplit, sl.stride, _ptr(z), _ptr(a), M, C, groups, float(eps),
+                                           float(momentum), _ptr(gamma), _ptr(beta), float(slope), _ptr(mean), _ptr(invstd),
+                                           _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(scratch), scratch.numel(),
+                                           _ptr(sync), self.stream), "rg_bn_forward_slabs")
+        del z._rg_slabs                       # z is an ordinary tensor from here on
+        self._slabs_pending = None
+        return a, mean, invstd
+
     def bn_forward2(self, z, gamma, beta, slope: float, eps: float, momentum: float, running_mean=None,
                     running_var=None, nbt=None, partials=None, nblk=1):
         """bn_forward on the two batch halves of z ([2n, ...]) in one set of launches: (a, mean[2][C], invstd[2][C]), running
@@ -646,6 +730,9 @@ class HipOps:
         M2, C = self._mc(z)
         M = M2 // 2
         assert M2 % 2 == 0 and self.stat_reduce is None
+        sl = getattr(z, "_rg_slabs", None)
+        if sl is not None:
+            return self._bn_forward_slabs(z, sl, 2, gamma, beta, slope, eps, momentum, running_mean, running_var, nbt)
         mean, invstd = self._f32(2, C), self._f32(2, C)
         a = torch.empty_like(z)
         ws = self._ws(2 * self.lib.rg_colreduce_workspace_bytes(M, C, 2) + 2 * 32 * 2 * C * 4)
@@ -662,6 +749,9 @@ class HipOps:
         M2, C = self._mc(z)
         M = M2 // 2
         assert M2 % 2 == 0 and self.stat_reduce is None and mean.shape == (2, C)
+        sl = getattr(ga, "_rg_slabs", None)
+        if sl is not None:
+            return self._bn_act_bwd_slabs(z, ga, sl, 2, mean, invstd, gamma, beta, slope, dgamma, dbeta, accumulate, False)[0]
         gz = torch.empty_like(z)
         s_gy, s_gyxh = self._f32(2, C), self._f32(2, C)
         ws = self._ws(2 * self.lib.rg_colreduce_workspace_bytes(M, C, 2))
@@ -677,9 +767,31 @@ class HipOps:
                                  float(slope), self.dt, self.stream), "rg_bn_act")
         return a
 
+    def _bn_act_bwd_slabs(self, z, ga, sl: SlabRef, groups, mean, invstd, gamma, beta, slope, dgamma, dbeta, accumulate,
+                          keep_ga, out=None):
+        M2, C = self._mc(z)
+        assert sl.groups == groups and ga.shape == z.shape and M2 % groups == 0
+        M = M2 // groups
+        gz = out if out is not None else torch.empty_like(z)
+        s_gy, s_gyxh = (self._f32(C), self._f32(C)) if groups == 1 else (self._f32(groups, C), self._f32(groups, C))
+        scratch, sync = self._sb_bufs(M, C, groups)
+        check(self.lib.rg_bn_act_bwd_slabs(_ptr(sl.ws), sl.nsplit, sl.stride, _ptr(z), _ptr(ga) if keep_ga else 0, _ptr(gz), M,
+                                           C, groups, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), float(slope),
+                                           _ptr(s_gy), _ptr(s_gyxh), _ptr(dgamma), _ptr(dbeta), int(accumulate), _ptr(scratch),
+                                           scratch.numel(), _ptr(sync), self.stream), "rg_bn_act_bwd_slabs")
+        del ga._rg_slabs                     # (ga itself is written only with keep_ga)
+        self._slabs_pending = None
+        return gz, s_gy, s_gyxh
+
     def bn_act_bwd(self, z, ga, mean, invstd, gamma, beta, slope: float, dgamma=None, dbeta=None,
-                   accumulate: bool = False, out=None):
+                   accumulate: bool = False, out=None, keep_ga=True):
+        """keep_ga: only meaningful when ga is still split-K slabs (conv_* with defer): also write the reduced ga tensor
+        (the penalty's first backward keeps it for the double-backward pass)."""
         M, C = self._mc(z)
+        sl = getattr(ga, "_rg_slabs", None)
+        if sl is not None:
+            return self._bn_act_bwd_slabs(z, ga, sl, 1, mean, invstd, gamma, beta, slope, dgamma, dbeta, accumulate, keep_ga,
+                                          out)
         gz = out if out is not None else torch.empty_like(z)
         assert gz.shape == z.shape and gz.is_contiguous()
         s_gy, s_gyxh = self._f32(C), self._f32(C)

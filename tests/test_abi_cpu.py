@@ -23,7 +23,7 @@ def test_library_loads_and_exports_all():
         from rna_gan_amd.build import build_library
         build_library()
     lib = _abi.load()
-    assert lib.rg_version() >= 100
+    assert lib.rg_version() == _abi.ABI_VERSION
     for name in header_symbols():
         assert hasattr(lib, name), name
 

@@ -253,3 +253,92 @@ def test_batched_d_step_matches_two_chains(in_size, n, step):
         assert cos >= 0.97 and 0.85 <= ratio <= 1.15, (k, cos, ratio)
     for k in ba:
         np.testing.assert_allclose(bb[k].numpy(), ba[k].numpy(), rtol=2e-3, atol=1e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("I,O,hs,n,groups", [(256, 512, 32, 64, 1), (512, 1024, 16, 64, 1), (1024, 2048, 8, 64, 1),
+                                              (512, 1024, 16, 128, 2), (1024, 2048, 8, 128, 2)])
+def test_split_k_conv_fused_into_batchnorm(I, O, hs, n, groups):
+    """The deep layers run split-K at the benchmark's batch; with defer= the conv leaves its fp32 slabs and ONE kernel
+    (rg_bn_forward_slabs / rg_bn_act_bwd_slabs: slab reduction + statistics + cross-workgroup hand-off + apply) replaces
+    reduce_slabs + statistics pass + finisher + apply.  Against the separate-launch path of the same library (pinned by
+    test_conv_layers_full_size / test_batchnorm_full_size): z and ga bit-identical (same summation order of the slabs),
+    statistics to fp32 round-off, outputs to one bf16 rounding; and against plain tensor arithmetic.  Both directions
+    (stride-2 conv forward + its BatchNorm; transposed conv as the data gradient + BatchNorm backward), one and two batch
+    groups (a double batch = two forward calls: own statistics, running statistics updated in order).  Run twice: the
+    hand-off words must be left clean for the next launch."""
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(500 + I + n)
+    fu, se = HipOps(torch.bfloat16, dev), HipOps(torch.bfloat16, dev)
+    se.split_bn = False
+    w = (torch.randn(O, 4, 4, I, generator=gen) * (2.0 / (I * 16)) ** 0.5).bfloat16().float().to(dev)
+    cw_f, cw_s = ConvW(w.clone(), None, torch.zeros_like(w), None, "OHWI"), ConvW(w.clone(), None, torch.zeros_like(w), None, "OHWI")
+    x = torch.randn(n, hs, hs, I, generator=gen).bfloat16().to(dev)
+    gam_o, bet_o = (1 + 0.1 * torch.randn(O, generator=gen)).to(dev), (0.1 * torch.randn(O, generator=gen)).to(dev)
+    ho = hs // 2
+
+    def bn_fwd(ops, z, run):
+        rm, rv, nbt = run
+        if groups == 1:
+            return ops.bn_forward(z, gam_o, bet_o, 0.2, 1e-5, 0.1, rm, rv, nbt)
+        return ops.bn_forward2(z, gam_o, bet_o, 0.2, 1e-5, 0.1, rm, rv, nbt)
+
+    for rep in range(2):
+        runs = [(torch.zeros(O, device=dev), torch.ones(O, device=dev), torch.zeros((), dtype=torch.int64, device=dev)) for _ in range(2)]
+        zf, _ = fu.conv_down(x, cw_f, want_stats=True, defer=groups)
+        assert getattr(zf, "_rg_slabs", None) is not None, "this shape is expected to take the split-K slab path"
+        af, mean_f, inv_f = bn_fwd(fu, zf, runs[0])
+        assert getattr(zf, "_rg_slabs", None) is None
+        zs, st = se.conv_down(x, cw_s, want_stats=True, defer=groups)
+        assert getattr(zs, "_rg_slabs", None) is None
+        as_, mean_s, inv_s = bn_fwd(se, zs, runs[1])
+        torch.cuda.synchronize()
+        assert torch.equal(zf.view(torch.int16), zs.view(torch.int16)), "z = bf16(sum of the slabs in split order)"
+        assert relmax(mean_f, mean_s) < 2e-6 and relmax(inv_f, inv_s) < 2e-6
+        assert relmax(af, as_) < 8e-3 and float((af.float() - as_.float()).abs().mean()) < 1e-5
+        assert relmax(runs[0][0], runs[1][0]) < 1e-5 and relmax(runs[0][1], runs[1][1]) < 1e-5
+        assert int(runs[0][2]) == int(runs[1][2]) == groups
+        # independent arithmetic on the stored z
+        for h in range(groups):
+            zh = zf.float().view(groups, -1, O)[h]
+            mu, var = zh.mean(0), zh.var(0, unbiased=False)
+            assert relmax(mean_f.view(groups, O)[h], mu) < 1e-4 and relmax(inv_f.view(groups, O)[h], torch.rsqrt(var + 1e-5)) < 1e-4
+            pre = (zh - mu) * torch.rsqrt(var + 1e-5) * gam_o + bet_o
+            assert relmax(af.view(groups, -1, O)[h], torch.where(pre > 0, pre, 0.2 * pre)) < 8e-3
+
+        # backward: ga = conv_up(g) (data gradient of the Conv2d) arrives as slabs, BatchNorm backward of the layer below
+        g = torch.randn(n, ho, ho, O, generator=gen).bfloat16().to(dev)
+        zb = (torch.randn(n, hs, hs, I, generator=gen) * 1.3 + 0.2).bfloat16().to(dev)          # the lower layer's z
+        gam_i, bet_i = (1 + 0.1 * torch.randn(I, generator=gen)).to(dev), (0.1 * torch.randn(I, generator=gen)).to(dev)
+        res = []
+        for ops, cw in ((fu, cw_f), (se, cw_s)):
+            if groups == 1:
+                _, mean, inv = ops.bn_forward(zb.clone(), gam_i, bet_i, 0.2, 1e-5, 0.1)
+            else:
+                _, mean, inv = ops.bn_forward2(zb.clone(), gam_i, bet_i, 0.2, 1e-5, 0.1)
+            ga = ops.conv_up(g, cw, defer=groups)
+            if ops is fu:
+                assert getattr(ga, "_rg_slabs", None) is not None
+            dg, db = torch.full((I,), 2.0, device=dev), torch.full((I,), -1.0, device=dev)
+            if groups == 1:
+                gz, s1, s2 = ops.bn_act_bwd(zb, ga, mean, inv, gam_i, bet_i, 0.2, dg, db, True, keep_ga=True)
+            else:
+                gz = ops.bn_act_bwd2(zb, ga, mean, inv, gam_i, bet_i, 0.2, dg, db, True)
+                s1 = s2 = None
+            torch.cuda.synchronize()
+            res.append((ga, gz, s1, s2, dg, db, mean, inv))
+        (ga_f, gz_f, s1_f, s2_f, dg_f, db_f, mean_b, inv_b), (ga_s, gz_s, s1_s, s2_s, dg_s, db_s, _, _) = res
+        if groups == 1:
+            assert torch.equal(ga_f.view(torch.int16), ga_s.view(torch.int16)), "ga = bf16(sum of the slabs)"
+            assert relmax(s1_f, s1_s) < 1e-4 and relmax(s2_f, s2_s) < 1e-4
+        assert relmax(gz_f, gz_s) < 8e-3 and float((gz_f.float() - gz_s.float()).abs().mean()) < 1e-5 * float(gz_s.float().abs().mean() + 1)
+        assert relmax(dg_f - 2.0, dg_s - 2.0) < 1e-4 and relmax(db_f + 1.0, db_s + 1.0) < 1e-4      # accumulated onto 2 / -1
+        for h in range(groups):
+            zh = zb.float().view(groups, -1, I)[h]
+            gah = ga_s.float().view(groups, -1, I)[h]
+            mu, rstd = mean_b.view(groups, I)[h], inv_b.view(groups, I)[h]
+            xh = (zh - mu) * rstd
+            gy = gah * torch.where(xh * gam_i + bet_i > 0, 1.0, 0.2)
+            ref = gam_i * rstd * (gy - gy.mean(0) - xh * (gy * xh).mean(0))
+            assert relmax(gz_f.view(groups, -1, I)[h], ref) < 8e-3
+    assert int(fu._sb_sync.abs().sum()) == int(fu._sb_sync[17::16].abs().sum()), "arrival counters / error word left at zero"
+    assert int(fu._sb_sync[0]) == 0, "no hand-off timed out"
