@@ -258,7 +258,7 @@ int rg_bn_finalize_partials(const float* partial, int G, int M, int C, float eps
  * buffer of rg_slab_bn_sync_words() 32-bit words, ZEROED ONCE when allocated and private to one stream (every launch
  * leaves it zero); `scratch`: rg_slab_bn_scratch_bytes(M, C, groups) bytes, contents irrelevant.  M = rows per batch group
  * (groups = 1 or 2, z is [groups * M][C]).  rg_slab_bn_supported: C % 128 == 0, nsplit in {2, 4, 8}, row count divisible
- * into 32..256-row blocks with at most 768 workgroups (all co-resident on the 256 CUs -- required by the hand-off). */
+ * into 64 / 128 / 256-row blocks with at most 256 workgroups (one per CU: all co-resident -- required by the hand-off). */
 int rg_conv_split(int up, int N, int Hlow, int Wlow, int O, int I, int dtype, int algo);
 int rg_conv_down_partial(const void* x, const void* wdn, int N, int Hi, int Wi, int I, int O, int dtype, int algo,
                          void* ws, size_t ws_bytes, void* stream);
@@ -271,6 +271,11 @@ int rg_bn_forward_slabs(const void* slab, int nsplit, size_t slab_stride, void* 
                         float eps, float momentum, const float* gamma, const float* beta, float slope, float* mean,
                         float* invstd, float* running_mean, float* running_var, long long* num_batches_tracked,
                         void* scratch, size_t scratch_bytes, void* sync, void* stream);
+/* the forward-mode tangent of the same block (rg_bn_tangent) with zt arriving as slabs (the penalty's tangent forward):
+ * zt_out = bf16(sum_s slab_s) (always written), at, s_zt, s_xhzt as rg_bn_tangent */
+int rg_bn_tangent_slabs(const void* slab, int nsplit, size_t slab_stride, const void* z, void* zt_out, void* at, long long M,
+                        int C, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                        float* s_zt, float* s_xhzt, void* scratch, size_t scratch_bytes, void* sync, void* stream);
 int rg_bn_act_bwd_slabs(const void* slab, int nsplit, size_t slab_stride, const void* z, void* ga_out, void* gz, long long M,
                         int C, int groups, const float* mean, const float* invstd, const float* gamma, const float* beta,
                         float slope, float* s_gy, float* s_gyxh, float* dgamma, float* dbeta, int accumulate, void* scratch,

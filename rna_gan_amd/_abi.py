@@ -128,6 +128,7 @@ PROTOTYPES = {
     "rg_slab_bn_scratch_bytes": (_z, [C.c_longlong, _i, _i]),
     "rg_slab_bn_sync_words": (_z, []),
     "rg_bn_forward_slabs": (_i, [_p, _i, _z, _p, _p, C.c_longlong, _i, _i, _f, _f, _p, _p, _f, _p, _p, _p, _p, _p, _p, _z, _p, _p]),
+    "rg_bn_tangent_slabs": (_i, [_p, _i, _z, _p, _p, _p, C.c_longlong, _i, _p, _p, _p, _p, _f, _p, _p, _p, _z, _p, _p]),
     "rg_bn_act_bwd_slabs": (_i, [_p, _i, _z, _p, _p, _p, C.c_longlong, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _p, _z,
                                  _p, _p]),
     "rg_conv_up_affine": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _f, _p, _z, _p]),

@@ -21,17 +21,19 @@
 // the two backward sums, hand-off, gz = gamma * invstd * (gy - mean(gy) - xhat * mean(gy * xhat)); dgamma / dbeta.
 // HBM traffic = slabs once + each output once + z once (backward): the minimum.
 //
-// Requirements: the whole grid is co-resident (<= 768 workgroups of 256 threads, one wave per SIMD each: guaranteed on
-// 256 CUs), C % 128 == 0, rows per block in {32, 64, 128, 256}.  Every spin is bounded; a timeout sets sync[SB_ERR].
+// Requirements: the whole grid is co-resident (<= 256 workgroups of 1024 threads, <= 128 VGPRs: one per CU always fits),
+// C % 128 == 0, rows per block in {64, 128, 256}, at most 64 row blocks per batch group.  Every spin is bounded; a timeout
+// sets sync[SB_ERR].
 #include "rg_internal.h"
 
 namespace {
 
 constexpr int SB_COLS = 128;          // columns per slice (16 threads x 8)
-constexpr int SB_TY = 16;             // row lanes per block
+constexpr int SB_TY = 64;             // row lanes per block (1024 threads / 16 column threads)
 constexpr int SB_ERR = 0;             // sync[0]: error word (timeouts); slice s uses sync[16 + 16*s + {0: arrivals, 1: generation}]
 
 typedef unsigned __attribute__((address_space(1))) gu32;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct SbnArgs {
   const float* slab; size_t slab_stride; int nsplit;
@@ -129,31 +131,68 @@ __device__ __forceinline__ void slab_sum(const SlabPiece<NS>& q, float* acc) {
   }
 }
 
-// block partial of two per-thread column sums -> part row (sc1), deterministic: LDS, 16 row lanes summed in order
-__device__ __forceinline__ void block_partial(float (*sm)[2][SB_COLS], const float* s1, const float* s2, float* prow) {
-  const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+// ---- block geometry: 1024 threads = 16 waves (4 per SIMD: enough loads in flight to stream the slabs at HBM speed with one
+// workgroup per CU); thread -> 8 columns (tx = t % 16) of row lane ty = t / 16 (64 row lanes, 4 of them per wave)
+constexpr int SB_THREADS = 1024;
+constexpr int SB_WAVES = SB_THREADS / 64;
+
+// block partial of two per-thread column sums -> part row (sc1).  Deterministic: the 4 row lanes of a wave by shuffles,
+// the 16 waves through LDS in order.
+__device__ __forceinline__ void block_partial(float (*sm)[2][SB_COLS], float* s1, float* s2, float* prow) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tx = lane & 15;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { sm[ty][0][tx * 8 + i] = s1[i]; sm[ty][1][tx * 8 + i] = s2[i]; }
+  for (int i = 0; i < 8; ++i) {
+    s1[i] += __shfl_xor(s1[i], 16, 64); s1[i] += __shfl_xor(s1[i], 32, 64);
+    s2[i] += __shfl_xor(s2[i], 16, 64); s2[i] += __shfl_xor(s2[i], 32, 64);
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sm[wave][0][tx * 8 + i] = s1[i]; sm[wave][1][tx * 8 + i] = s2[i]; }
+  }
   __syncthreads();
-  const int q = threadIdx.x / SB_COLS, col = threadIdx.x % SB_COLS;
-  float t = 0.f;
+  if (threadIdx.x < 2 * SB_COLS) {
+    const int q = threadIdx.x / SB_COLS, col = threadIdx.x % SB_COLS;
+    float t = 0.f;
 #pragma unroll
-  for (int k = 0; k < SB_TY; ++k) t += sm[k][q][col];
-  st_sc1(prow + q * SB_COLS + col, t);
+    for (int k = 0; k < SB_WAVES; ++k) t += sm[k][q][col];
+    st_sc1(prow + q * SB_COLS + col, t);
+  }
 }
 
-// totals of one batch group of this slice: thread (q, col) sums the rbpg partial rows in order -> tot[q][col] (LDS)
-__device__ __forceinline__ void slice_totals(const float* pgrp, int rbpg, float (*tot)[SB_COLS]) {
-  const int q = threadIdx.x / SB_COLS, col = threadIdx.x % SB_COLS;
-  float t = 0.f;
-  for (int r = 0; r < rbpg; ++r) t += ld_sc1(pgrp + (size_t)r * 2 * SB_COLS + q * SB_COLS + col);
-  tot[q][col] = t;
+// totals of one batch group of this slice -> tot[q * 128 + col] (LDS).  The group's rbpg partial rows (256 floats each) are
+// read by ALL threads at once with 16-byte sc1 loads (row lane = t / 64 takes rows rl, rl + 16, ...), then the 16 row
+// lanes are summed in order: fixed order -> every workgroup of the group gets the same bits.
+__device__ __forceinline__ void slice_totals(const float* pgrp, int rbpg, float (*lanes)[2 * SB_COLS], float* tot) {
+  const int q4 = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)pgrp, 0, rbpg * 2 * SB_COLS * 4, 0x00020000);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  u32x4 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {        // rbpg <= 64: at most 4 rows per lane; rows past the end read 0 (buffer range check)
+    const int r = rl + 16 * k;
+    v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, r < rbpg ? (r * 2 * SB_COLS + q4 * 4) * 4 : 0x7ffffff0, 0, 16);   // sc1
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    acc.x += __uint_as_float(v[k].x); acc.y += __uint_as_float(v[k].y);
+    acc.z += __uint_as_float(v[k].z); acc.w += __uint_as_float(v[k].w);
+  }
+  *reinterpret_cast<float4*>(&lanes[rl][q4 * 4]) = acc;
+  __syncthreads();
+  if (threadIdx.x < 2 * SB_COLS) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < SB_WAVES; ++k) t += lanes[k][threadIdx.x];
+    tot[threadIdx.x] = t;
+  }
+  __syncthreads();
 }
 
 template <int RPT, int NS>
-__global__ __launch_bounds__(256) void slab_bn_fwd_kernel(SbnArgs a) {
-  __shared__ float sm[SB_TY][2][SB_COLS];
-  __shared__ float tot[2][SB_COLS];
+__global__ __launch_bounds__(SB_THREADS) void slab_bn_fwd_kernel(SbnArgs a) {
+  __shared__ __attribute__((aligned(16))) float sm[SB_WAVES][2][SB_COLS];     // 16 KB: block partials, then the row lanes of phase 2
+  __shared__ float tot[2 * SB_COLS];
+  float (*lanes)[2 * SB_COLS] = reinterpret_cast<float (*)[2 * SB_COLS]>(&sm[0][0][0]);
   const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
   const int slice = blockIdx.x, grp = blockIdx.y / a.rbpg, rb = blockIdx.y - grp * a.rbpg;
   const int c = slice * SB_COLS + tx * 8;
@@ -194,13 +233,11 @@ __global__ __launch_bounds__(256) void slab_bn_fwd_kernel(SbnArgs a) {
     float rm = 0.f, rv = 0.f;
     if (a.rmean && threadIdx.x < SB_COLS) { rm = a.rmean[slice * SB_COLS + col]; rv = a.rvar[slice * SB_COLS + col]; }
     for (int g = 0; g < a.groups; ++g) {
-      __syncthreads();
-      slice_totals(pslice + (size_t)g * a.rbpg * 2 * SB_COLS, a.rbpg, tot);
-      __syncthreads();
+      slice_totals(pslice + (size_t)g * a.rbpg * 2 * SB_COLS, a.rbpg, lanes, tot);
       if (threadIdx.x < SB_COLS) {
-        const double mud = (double)tot[0][col] / (double)m;
+        const double mud = (double)tot[col] / (double)m;
         const float mu = (float)mud;
-        const float var = (float)fmax((double)tot[1][col] / (double)m - mud * mud, 0.0);
+        const float var = (float)fmax((double)tot[SB_COLS + col] / (double)m - mud * mud, 0.0);
         a.mean[(size_t)g * a.C + slice * SB_COLS + col] = mu;
         a.invstd[(size_t)g * a.C + slice * SB_COLS + col] = rsqrtf(var + a.eps);
         if (a.rmean) {
@@ -209,28 +246,26 @@ __global__ __launch_bounds__(256) void slab_bn_fwd_kernel(SbnArgs a) {
           rv = (1.f - a.momentum) * rv + a.momentum * unb;
         }
       }
+      __syncthreads();
     }
     if (a.rmean && threadIdx.x < SB_COLS) { a.rmean[slice * SB_COLS + col] = rm; a.rvar[slice * SB_COLS + col] = rv; }
     if (a.nbt && slice == 0 && threadIdx.x == 0) *a.nbt += a.groups;
-    __syncthreads();
   }
-  slice_totals(pslice + (size_t)grp * a.rbpg * 2 * SB_COLS, a.rbpg, tot);
-  __syncthreads();
+  if (!(rb == 0 && grp == 0 && a.groups == 1))
+    slice_totals(pslice + (size_t)grp * a.rbpg * 2 * SB_COLS, a.rbpg, lanes, tot);
 
   // ---- phase 3: apply from the registers
-  float sc[8], sh[8];
+  float sc[8], sh[8], bet[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const double mud = (double)tot[0][tx * 8 + i] / (double)m;
+    const double mud = (double)tot[tx * 8 + i] / (double)m;
     const float mu = (float)mud;
-    const float var = (float)fmax((double)tot[1][tx * 8 + i] / (double)m - mud * mud, 0.0);
+    const float var = (float)fmax((double)tot[SB_COLS + tx * 8 + i] / (double)m - mud * mud, 0.0);
     const float rstd = rsqrtf(var + a.eps);
     sc[i] = rstd * a.gamma[c + i];
     sh[i] = mu;
+    bet[i] = a.beta[c + i];
   }
-  float bet[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) bet[i] = a.beta[c + i];
 #pragma unroll
   for (int k = 0; k < RPT; ++k) {
     float v[8], o[8];
@@ -241,10 +276,15 @@ __global__ __launch_bounds__(256) void slab_bn_fwd_kernel(SbnArgs a) {
   }
 }
 
-template <int RPT, int NS>
-__global__ __launch_bounds__(256) void slab_bn_bwd_kernel(SbnArgs a) {
-  __shared__ float sm[SB_TY][2][SB_COLS];
-  __shared__ float tot[2][SB_COLS];
+// MODE 0: BatchNorm + LeakyReLU backward (the slabs are ga, the data gradient arriving at the block).
+// MODE 1: forward-mode tangent of the same block (the slabs are zt = conv(tangent of the layer below)): sums of zt and
+//         xhat * zt, at = lrelu'(y) * gamma * invstd * (zt - mean(zt) - xhat * mean(xhat * zt))  (rg_bn_tangent's arithmetic);
+//         out0 = zt is always written (the penalty's joint reverse pass reads it).
+template <int RPT, int NS, int MODE>
+__global__ __launch_bounds__(SB_THREADS) void slab_bn_bwd_kernel(SbnArgs a) {
+  __shared__ __attribute__((aligned(16))) float sm[SB_WAVES][2][SB_COLS];
+  __shared__ float tot[2 * SB_COLS];
+  float (*lanes)[2 * SB_COLS] = reinterpret_cast<float (*)[2 * SB_COLS]>(&sm[0][0][0]);
   const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
   const int slice = blockIdx.x, grp = blockIdx.y / a.rbpg, rb = blockIdx.y - grp * a.rbpg;
   const int c = slice * SB_COLS + tx * 8;
@@ -279,10 +319,14 @@ __global__ __launch_bounds__(256) void slab_bn_bwd_kernel(SbnArgs a) {
       float g[8], v[8];
       unpack8(gp[k], g); unpack8(zp[k], v);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {                        // BwdRedF's arithmetic
+      for (int i = 0; i < 8; ++i) {
         const float xh = (v[i] - mu[i]) * rstd[i];
-        const float gy = g[i] * lrelu_mask(xh * gam[i] + bet[i], a.slope);
-        s1[i] += gy; s2[i] += gy * xh;
+        if (MODE == 0) {                                    // BwdRedF's arithmetic
+          const float gy = g[i] * lrelu_mask(xh * gam[i] + bet[i], a.slope);
+          s1[i] += gy; s2[i] += gy * xh;
+        } else {                                            // TanRedF's
+          s1[i] += g[i]; s2[i] += xh * g[i];
+        }
       }
     }
   }
@@ -295,37 +339,40 @@ __global__ __launch_bounds__(256) void slab_bn_bwd_kernel(SbnArgs a) {
     const int col = threadIdx.x % SB_COLS;
     float dg = 0.f, db = 0.f;
     for (int g = 0; g < a.groups; ++g) {
-      __syncthreads();
-      slice_totals(pslice + (size_t)g * a.rbpg * 2 * SB_COLS, a.rbpg, tot);
-      __syncthreads();
+      slice_totals(pslice + (size_t)g * a.rbpg * 2 * SB_COLS, a.rbpg, lanes, tot);
       if (threadIdx.x < SB_COLS) {
         const size_t o = (size_t)g * a.C + slice * SB_COLS + col;
-        a.s_gy[o] = tot[0][col]; a.s_gyxh[o] = tot[1][col];
-        if (g == 0) { dg = tot[1][col]; db = tot[0][col]; } else { dg += tot[1][col]; db += tot[0][col]; }
+        a.s_gy[o] = tot[col]; a.s_gyxh[o] = tot[SB_COLS + col];
+        if (g == 0) { dg = tot[SB_COLS + col]; db = tot[col]; } else { dg += tot[SB_COLS + col]; db += tot[col]; }
       }
+      __syncthreads();
     }
-    if (a.dgamma && threadIdx.x < SB_COLS) {
+    if (MODE == 0 && a.dgamma && threadIdx.x < SB_COLS) {
       const int o = slice * SB_COLS + col;
       if (a.accumulate) { a.dgamma[o] += dg; a.dbeta[o] += db; } else { a.dgamma[o] = dg; a.dbeta[o] = db; }
     }
-    __syncthreads();
   }
-  slice_totals(pslice + (size_t)grp * a.rbpg * 2 * SB_COLS, a.rbpg, tot);
-  __syncthreads();
+  if (!(rb == 0 && grp == 0 && a.groups == 1))
+    slice_totals(pslice + (size_t)grp * a.rbpg * 2 * SB_COLS, a.rbpg, lanes, tot);
 
   const float inv_m = 1.f / (float)a.M;
   float m1[8], m2[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { m1[i] = tot[0][tx * 8 + i] * inv_m; m2[i] = tot[1][tx * 8 + i] * inv_m; }
+  for (int i = 0; i < 8; ++i) { m1[i] = tot[tx * 8 + i] * inv_m; m2[i] = tot[SB_COLS + tx * 8 + i] * inv_m; }
 #pragma unroll
   for (int k = 0; k < RPT; ++k) {
     float g[8], v[8], o[8];
     unpack8(gp[k], g); unpack8(zp[k], v);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {                          // BwdApplyF's arithmetic
+    for (int i = 0; i < 8; ++i) {
       const float xh = (v[i] - mu[i]) * rstd[i];
-      const float gy = g[i] * lrelu_mask(xh * gam[i] + bet[i], a.slope);
-      o[i] = (gam[i] * rstd[i]) * (gy - m1[i] - xh * m2[i]);
+      const float mk = lrelu_mask(xh * gam[i] + bet[i], a.slope);
+      if (MODE == 0) {                                      // BwdApplyF's arithmetic
+        const float gy = g[i] * mk;
+        o[i] = (gam[i] * rstd[i]) * (gy - m1[i] - xh * m2[i]);
+      } else {                                              // TanApplyF's
+        o[i] = (gam[i] * rstd[i]) * (g[i] - m1[i] - xh * m2[i]) * mk;
+      }
     }
     *reinterpret_cast<uint4*>(a.out1 + (row0 + (size_t)k * SB_TY) * a.C + c) = pack8(o);
   }
@@ -333,47 +380,46 @@ __global__ __launch_bounds__(256) void slab_bn_bwd_kernel(SbnArgs a) {
 
 struct SbnPlan { int rpt, rbpg, slices; };
 
-// rows per block so that the grid is about one block per CU; false: this shape has no fused form
+// rows per block (64 row lanes x RPT) so that the grid is about one block per CU; false: this shape has no fused form
 static bool sbn_plan(int M, int C, int groups, int nsplit, SbnPlan* p) {
   if (C % SB_COLS || M <= 0 || groups < 1 || groups > 2) return false;
   if (nsplit != 2 && nsplit != 4 && nsplit != 8) return false;
   const int slices = C / SB_COLS;
   const long long rows = (long long)M * groups;
   int best = 0;
-  for (int pass = 0; pass < 2 && !best; ++pass)        // about one block per CU if possible, else up to three per CU
-    for (int rpt = 2; rpt <= 16 && !best; rpt *= 2) {
-      const int rpb = rpt * SB_TY;
-      if (M % rpb) continue;
-      const long long blocks = rows / rpb * slices;
-      if (blocks <= (pass == 0 ? 320 : 768)) best = rpt;      // co-residency bound: 768 blocks of 4 waves on 256 CUs
-    }
+  for (int rpt = 1; rpt <= 4 && !best; rpt *= 2) {
+    const int rpb = rpt * SB_TY;
+    if (M % rpb || M / rpb > 64) continue;             // (a group's partial rows are summed 16 lanes x 4 rows)
+    if (rpt * nsplit > 8) continue;                    // register budget of a 1024-thread block (128 VGPRs, no spills)
+    // co-residency bound of the hand-off: one 1024-thread block per CU (<= 128 VGPRs) always fits; two would too
+    if (rows / rpb * slices <= 256) best = rpt;
+  }
   if (!best) return false;
   p->rpt = best; p->rbpg = M / (best * SB_TY); p->slices = slices;
   return true;
 }
 
-template <bool FWD, int RPT>
+template <int KIND, int RPT>       // KIND 0 forward, 1 backward, 2 tangent
 static void sbn_launch_ns(const SbnArgs& a, dim3 grid, hipStream_t st) {
-  if (FWD) {
-    if (a.nsplit == 2) hipLaunchKernelGGL((slab_bn_fwd_kernel<RPT, 2>), grid, dim3(256), 0, st, a);
-    else if (a.nsplit == 4) hipLaunchKernelGGL((slab_bn_fwd_kernel<RPT, 4>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((slab_bn_fwd_kernel<RPT, 8>), grid, dim3(256), 0, st, a);
-  } else {
-    if (a.nsplit == 2) hipLaunchKernelGGL((slab_bn_bwd_kernel<RPT, 2>), grid, dim3(256), 0, st, a);
-    else if (a.nsplit == 4) hipLaunchKernelGGL((slab_bn_bwd_kernel<RPT, 4>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((slab_bn_bwd_kernel<RPT, 8>), grid, dim3(256), 0, st, a);
-  }
+#define SBN_GO(NS)                                                                                          \
+  do {                                                                                                      \
+    if (KIND == 0) hipLaunchKernelGGL((slab_bn_fwd_kernel<RPT, NS>), grid, dim3(SB_THREADS), 0, st, a);     \
+    else hipLaunchKernelGGL((slab_bn_bwd_kernel<RPT, NS, KIND == 2 ? 1 : 0>), grid, dim3(SB_THREADS), 0, st, a); \
+  } while (0)
+  if constexpr (RPT == 1) { if (a.nsplit == 2) SBN_GO(2); else if (a.nsplit == 4) SBN_GO(4); else SBN_GO(8); }
+  else if constexpr (RPT == 2) { if (a.nsplit == 2) SBN_GO(2); else SBN_GO(4); }
+  else SBN_GO(2);
+#undef SBN_GO
 }
 
-template <bool FWD>
+template <int KIND>
 static int sbn_launch(const char* name, SbnArgs& a, const SbnPlan& p, hipStream_t st) {
   a.rbpg = p.rbpg;
   dim3 grid((unsigned)p.slices, (unsigned)(a.groups * p.rbpg));
   switch (p.rpt) {
-    case 2: sbn_launch_ns<FWD, 2>(a, grid, st); break;
-    case 4: sbn_launch_ns<FWD, 4>(a, grid, st); break;
-    case 8: sbn_launch_ns<FWD, 8>(a, grid, st); break;
-    default: sbn_launch_ns<FWD, 16>(a, grid, st); break;
+    case 1: sbn_launch_ns<KIND, 1>(a, grid, st); break;
+    case 2: sbn_launch_ns<KIND, 2>(a, grid, st); break;
+    default: sbn_launch_ns<KIND, 4>(a, grid, st); break;
   }
   RG_LAUNCH_CHECK(name);
   return RG_OK;
@@ -387,8 +433,8 @@ extern "C" int rg_slab_bn_supported(long long M, int C, int groups, int nsplit) 
   return M < (1ll << 30) && sbn_plan((int)M, C, groups, nsplit, &p) ? 1 : 0;
 }
 extern "C" size_t rg_slab_bn_scratch_bytes(long long M, int C, int groups) {
-  // partial rows: at most (rows / 32) x C x 2 floats; sized for the smallest block
-  return (size_t)((M * groups + 31) / 32) * (size_t)C * 2 * sizeof(float);
+  // partial rows: at most (rows / 64) x C x 2 floats; sized for the smallest block
+  return (size_t)((M * groups + 63) / 64) * (size_t)C * 2 * sizeof(float);
 }
 extern "C" size_t rg_slab_bn_sync_words(void) { return 16 + 16 * 64; }
 
@@ -410,7 +456,7 @@ extern "C" int rg_bn_forward_slabs(const void* slab, int nsplit, size_t slab_str
   a.gamma = gamma; a.beta = beta; a.slope = slope; a.eps = eps; a.momentum = momentum;
   a.mean = mean; a.invstd = invstd; a.rmean = running_mean; a.rvar = running_var; a.nbt = num_batches_tracked;
   a.part = (float*)scratch; a.sync = (unsigned*)sync;
-  return sbn_launch<true>("bn_forward_slabs", a, p, rg_stream(stream));
+  return sbn_launch<0>("bn_forward_slabs", a, p, rg_stream(stream));
 }
 
 extern "C" int rg_bn_act_bwd_slabs(const void* slab, int nsplit, size_t slab_stride, const void* z, void* ga_out, void* gz,
@@ -433,5 +479,27 @@ extern "C" int rg_bn_act_bwd_slabs(const void* slab, int nsplit, size_t slab_str
   a.mean = const_cast<float*>(mean); a.invstd = const_cast<float*>(invstd);
   a.s_gy = s_gy; a.s_gyxh = s_gyxh; a.dgamma = dgamma; a.dbeta = dbeta; a.accumulate = accumulate;
   a.part = (float*)scratch; a.sync = (unsigned*)sync;
-  return sbn_launch<false>("bn_act_bwd_slabs", a, p, rg_stream(stream));
+  return sbn_launch<1>("bn_act_bwd_slabs", a, p, rg_stream(stream));
+}
+
+extern "C" int rg_bn_tangent_slabs(const void* slab, int nsplit, size_t slab_stride, const void* z, void* zt_out, void* at,
+                                   long long M, int C, const float* mean, const float* invstd, const float* gamma,
+                                   const float* beta, float slope, float* s_zt, float* s_xhzt, void* scratch,
+                                   size_t scratch_bytes, void* sync, void* stream) {
+  RG_REQUIRE(slab && z && zt_out && at && mean && invstd && gamma && beta && s_zt && s_xhzt && scratch && sync, RG_EINVAL,
+             "bn_tangent_slabs: null");
+  SbnPlan p;
+  RG_REQUIRE(M < (1ll << 30) && sbn_plan((int)M, C, 1, nsplit, &p), RG_EUNSUPPORTED,
+             "bn_tangent_slabs: M=%lld C=%d nsplit=%d has no fused form (rg_slab_bn_supported)", M, C, nsplit);
+  RG_REQUIRE(p.slices <= 64, RG_EUNSUPPORTED, "bn_tangent_slabs: C > 8192");
+  RG_REQUIRE(scratch_bytes >= (size_t)p.slices * p.rbpg * 2 * SB_COLS * sizeof(float), RG_EWORKSPACE,
+             "bn_tangent_slabs: scratch too small");
+  SbnArgs a{};
+  a.slab = (const float*)slab; a.slab_stride = slab_stride; a.nsplit = nsplit;
+  a.zin = (const uint16_t*)z; a.out0 = (uint16_t*)zt_out; a.out1 = (uint16_t*)at; a.M = (int)M; a.C = C; a.groups = 1;
+  a.gamma = gamma; a.beta = beta; a.slope = slope;
+  a.mean = const_cast<float*>(mean); a.invstd = const_cast<float*>(invstd);
+  a.s_gy = s_zt; a.s_gyxh = s_xhzt;
+  a.part = (float*)scratch; a.sync = (unsigned*)sync;
+  return sbn_launch<2>("bn_tangent_slabs", a, p, rg_stream(stream));
 }

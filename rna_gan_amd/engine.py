@@ -299,7 +299,7 @@ def disc_gp_second(ops, D: DiscNet, ctx, st, accumulate: bool, need_input_grad: 
     ats, zts, s_zt, s_xhzt = [at], [None], [None], [None]
     for l in range(1, R + 1):
         cw, bn = D.blocks[l - 1]
-        zt = ops.conv_down(at, cw)
+        zt = ops.conv_down(at, cw, defer=1)         # split-K slabs are reduced by the tangent BatchNorm op (next)
         at, szt, sxz = ops.bn_tangent(ctx.z[l], zt, ctx.mean[l], ctx.invstd[l], bn.gamma, bn.beta, D.slope)
         zts.append(zt); ats.append(at); s_zt.append(szt); s_xhzt.append(sxz)
     # (4) joint reverse.  Head: t = sum_n lrelu'(h_n) * hdot_n  ->  dW_head = sum_n gh_n * at_R[n]

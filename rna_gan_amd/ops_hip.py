@@ -819,6 +819,16 @@ class HipOps:
         M, C = self._mc(z)
         at = torch.empty_like(z)
         s_zt, s_xhzt = self._f32(C), self._f32(C)
+        sl = getattr(zt, "_rg_slabs", None)
+        if sl is not None:                    # zt is still split-K slabs: reduce + tangent sums + apply in one launch
+            assert sl.groups == 1 and zt.shape == z.shape
+            scratch, sync = self._sb_bufs(M, C, 1)
+            check(self.lib.rg_bn_tangent_slabs(_ptr(sl.ws), sl.nsplit, sl.stride, _ptr(z), _ptr(zt), _ptr(at), M, C, _ptr(mean),
+                                               _ptr(invstd), _ptr(gamma), _ptr(beta), float(slope), _ptr(s_zt), _ptr(s_xhzt),
+                                               _ptr(scratch), scratch.numel(), _ptr(sync), self.stream), "rg_bn_tangent_slabs")
+            del zt._rg_slabs
+            self._slabs_pending = None
+            return at, s_zt, s_xhzt
         ws = self._ws(self.lib.rg_colreduce_workspace_bytes(M, C, 2))
         if self.stat_reduce is not None:
             check(self.lib.rg_bn_tangent_sums(_ptr(z), _ptr(zt), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),

@@ -305,6 +305,21 @@ def test_split_k_conv_fused_into_batchnorm(I, O, hs, n, groups):
             pre = (zh - mu) * torch.rsqrt(var + 1e-5) * gam_o + bet_o
             assert relmax(af.view(groups, -1, O)[h], torch.where(pre > 0, pre, 0.2 * pre)) < 8e-3
 
+        # forward-mode tangent of the same block (the penalty's tangent forward): zt = conv(tangent) arrives as slabs
+        if groups == 1:
+            xt = torch.randn(n, hs, hs, I, generator=gen).bfloat16().to(dev)
+            zt_f = fu.conv_down(xt, cw_f, defer=1)
+            assert getattr(zt_f, "_rg_slabs", None) is not None
+            at_f, t1_f, t2_f = fu.bn_tangent(zf, zt_f, mean_f, inv_f, gam_o, bet_o, 0.2)
+            zt_s = se.conv_down(xt, cw_s, defer=1)
+            at_s, t1_s, t2_s = se.bn_tangent(zs, zt_s, mean_s, inv_s, gam_o, bet_o, 0.2)
+            torch.cuda.synchronize()
+            assert torch.equal(zt_f.view(torch.int16), zt_s.view(torch.int16))
+            # (column sums of signed values: compared on the scale of the summands, sqrt(rows) * |zt|)
+            scale = float(zt_s.float().abs().mean()) * (zt_s.numel() / O) ** 0.5
+            assert float((t1_f - t1_s).abs().max()) < 1e-4 * scale and float((t2_f - t2_s).abs().max()) < 1e-4 * scale
+            assert relmax(at_f, at_s) < 8e-3 and float((at_f.float() - at_s.float()).abs().mean()) < 1e-5 * float(at_s.float().abs().mean() + 1)
+
         # backward: ga = conv_up(g) (data gradient of the Conv2d) arrives as slabs, BatchNorm backward of the layer below
         g = torch.randn(n, ho, ho, O, generator=gen).bfloat16().to(dev)
         zb = (torch.randn(n, hs, hs, I, generator=gen) * 1.3 + 0.2).bfloat16().to(dev)          # the lower layer's z
@@ -316,8 +331,9 @@ def test_split_k_conv_fused_into_batchnorm(I, O, hs, n, groups):
             else:
                 _, mean, inv = ops.bn_forward2(zb.clone(), gam_i, bet_i, 0.2, 1e-5, 0.1)
             ga = ops.conv_up(g, cw, defer=groups)
-            if ops is fu:
-                assert getattr(ga, "_rg_slabs", None) is not None
+            if ops is fu:          # (the 512 -> 256 transposed conv fills the chip without split-K at batch 64: plain path)
+                split = fu.lib.rg_conv_split(1, n, ho, ho, O, I, fu.dt, fu.algo) > 1
+                assert (getattr(ga, "_rg_slabs", None) is not None) == split
             dg, db = torch.full((I,), 2.0, device=dev), torch.full((I,), -1.0, device=dev)
             if groups == 1:
                 gz, s1, s2 = ops.bn_act_bwd(zb, ga, mean, inv, gam_i, bet_i, 0.2, dg, db, True, keep_ga=True)
