@@ -371,6 +371,8 @@ def main(argv=None):
     barrier()
     log("warm-up done; timing %d steps" % args.steps)
     evs = []
+    from rna_gan_amd import losses as _PL
+    enc0 = _PL._LATENT.misses
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ls = one_step()
@@ -405,6 +407,10 @@ def main(argv=None):
                    "losses_last_step": last_losses, "hip_graphs": out_graphs and not D_.sync_stats(),
                    "dp_statistics": "global (sync-stats)" if D_.sync_stats() else "rank-local (DDP)"},
     }
+    if not args.step_plugin:
+        # frozen-betaVAE encodes per timed iteration: 1 (the three plugins share one encode per batch, losses._LatentCache;
+        # the reference encodes three times, src/wgan_loss.py:96-97, :223-224, :353-354)
+        out["config"]["betavae_encodes_per_iteration"] = round((_PL._LATENT.misses - enc0) / max(args.steps, 1), 3)
     if info.get("api_path"):
         out["config"]["api_path"] = info["api_path"]
     if args.step_plugin:

@@ -76,7 +76,12 @@ class betaVAE(nn.Module):
         return self
 
     def _apply(self, fn, *a, **k):
+        # .to() / .cuda() / .float(): the same weights in another place or type (buffers become NEW tensor objects, so the
+        # version snapshot is retaken); device and dtype are part of the signature
+        valid = self._token is not None and self._token_versions == self._versions()
         r = super()._apply(fn, *a, **k)
+        if valid:
+            self._token_versions = self._versions()
         self._plan = None
         self._ops = None
         self._flat = None
@@ -185,8 +190,9 @@ class betaVAE(nn.Module):
         (precision, weights token) while the weights are untouched since the token was adopted; otherwise private to this
         module and its current tensor versions -- never equal to another module's."""
         versions = self._versions()
+        w = self.z_mu.weight
         if self._token is not None and self._token_versions == versions:
-            return (self.precision, self._token)
+            return (self.precision, self._token, str(w.dtype), str(w.device))
         return (self.precision, ("private", id(self)), versions)
 
     def encode(self, x, mean_only=False):

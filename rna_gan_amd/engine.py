@@ -502,6 +502,28 @@ def disc_loss_prefix(ops, D: DiscNet, real):
     return disc_forward(ops, D, real)
 
 
+def disc_loss_prefix_bwd(ops, D: DiscNet, real, grad_scale: float = 1.0):
+    """Data-parallel prefix of the D-loss step: D(real) forward AND its whole backward (the loss is a difference of two
+    means and BatchNorm statistics are per call, so the real half's parameter gradients -mean'(D(real)) do not depend on
+    the generator at all): everything here reads the discriminator only, so the generator's gradient all-reduce of the
+    previous train_op (the largest collective of an iteration) stays in flight under a forward AND a backward pass.
+    Parameter gradients are WRITTEN; disc_loss_rest_acc adds the fake half's."""
+    out_r, ctx_r = disc_forward(ops, D, real)
+    n = out_r.shape[0]
+    disc_backward(ops, D, ctx_r, -grad_scale / n, wgrad=True, accumulate=False, need_input_grad=False)
+    return out_r
+
+
+def disc_loss_rest_acc(ops, G, D: DiscNet, out_r, noise, grad_scale: float = 1.0):
+    """The rest of that step: G(z), D(fake), the loss, and the fake half's backward ACCUMULATED onto the real half's."""
+    n = out_r.shape[0]
+    img, _ = _gen_fwd(ops, G, noise, keep=False)
+    out_f, ctx_f = disc_forward(ops, D, img)
+    loss = ops.mean_diff(out_f, out_r, 1.0)
+    disc_backward(ops, D, ctx_f, grad_scale / n, wgrad=True, accumulate=True, need_input_grad=False)
+    return loss
+
+
 def disc_loss_rest(ops, G, D: DiscNet, pre, noise, grad_scale: float = 1.0):
     out_r, ctx_r = pre
     n = out_r.shape[0]

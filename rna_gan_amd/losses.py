@@ -177,11 +177,20 @@ def _g_rest(generator, discriminator, pre):
     return E.gen_loss_rest(ops, gn, dn, pre, grad_scale=D_.grad_scale())
 
 
+# data-parallel D-loss step: D(real)'s backward belongs to the prefix too (it reads the discriminator only), so the generator's
+# gradient all-reduce -- started by the G-loss step just before -- is covered by a forward and a backward pass
+# (RNAGAN_DP_PREFIX_BWD=0: forward only, as in round 2)
+DP_PREFIX_BWD = os.environ.get("RNAGAN_DP_PREFIX_BWD", "1") != "0"
+
+
 def _d_prefix(generator, discriminator, real, noise, clip):
     ops, _, dn = _nets(generator, discriminator)
     if clip is not None:
         ops.clamp_(discriminator.flat.data, clip[0], clip[1])      # every D parameter (wgan_loss.py:213-215)
         discriminator.weights_changed()
+    if DP_PREFIX_BWD and D_.active():
+        return ("bwd", E.disc_loss_prefix_bwd(ops, dn, real.contiguous().float(), grad_scale=D_.grad_scale())), \
+            noise.contiguous().float()
     return E.disc_loss_prefix(ops, dn, real.contiguous().float()), noise.contiguous().float()
 
 
@@ -253,6 +262,8 @@ def _gp_fake_body(generator, discriminator, lambd):
 def _d_rest(generator, discriminator, pre):
     ops, gn, dn = _nets(generator, discriminator)
     fwd_real, noise = pre
+    if isinstance(fwd_real, tuple) and fwd_real[0] == "bwd":       # the real half's backward ran in the prefix
+        return E.disc_loss_rest_acc(ops, gn, dn, fwd_real[1], noise, grad_scale=D_.grad_scale())
     return E.disc_loss_rest(ops, gn, dn, fwd_real, noise, grad_scale=D_.grad_scale())
 
 

@@ -72,6 +72,16 @@ def test_three_steps_match_autograd(in_size, step, enc, n, tap_major):
     np.testing.assert_allclose(float(loss_e), float(loss_o), rtol=1e-9)
     assert_close_dict(grads_of(D2), grads_of(D), 1e-7, 1e-10)
     assert_close_dict(bufs_of(D2), bufs_of(D), 1e-9, 1e-12)
+    # the data-parallel split of the same step (prefix = D(real) forward + backward, rest = the fake half accumulated):
+    # same gradients; the BatchNorm buffers see the two extra forward calls, which is all that may differ
+    want = {k: v.clone() for k, v in grads_of(D2).items()}
+    for p in D2.parameters():
+        p.grad.zero_()
+    out_r = E.disc_loss_prefix_bwd(ops, Dn, real)
+    loss_s = E.disc_loss_rest_acc(ops, Gn, Dn, out_r, noise)
+    np.testing.assert_allclose(float(loss_s), float(loss_e), rtol=1e-12)
+    assert_close_dict(grads_of(D2), want, 1e-9, 1e-12)
+    D2.load_state_dict(D.state_dict()); G2.load_state_dict(G.state_dict())      # undo the extra running-statistics updates
 
     # ---- GP step gradients (second order)
     for p in D.parameters():

@@ -16,6 +16,13 @@ def test_signature_is_provenance_not_values(tmp_path):
     sd = a.state_dict()
     b.load_state_dict(sd); c.load_state_dict(sd)
     assert a.signature() == b.signature() == c.signature()      # one state_dict loaded into all: shared
+    for m in (a, b, c):
+        m.to(torch.float64)                                     # moved / converted alike (buffers become new tensors): still shared
+    assert a.signature() == b.signature() == c.signature()
+    c.to(torch.float32)                                         # ... not alike: different values, different signature
+    assert c.signature() != a.signature()
+    c.to(torch.float64)
+    assert c.signature() == a.signature()
     with torch.no_grad():
         c.z_mu.bias.add_(1.0)                                   # written since: private again
     assert c.signature() != a.signature()
