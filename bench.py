@@ -216,27 +216,32 @@ def hip_workload(args, rank, world, device):
             self.evs = [None] * depth
             self.i = 0
 
-        def draw(self, fill):
+        def draw(self, fill, dst):
+            """fill a pinned buffer on the host, copy it (asynchronously, stream-ordered) into the PERSISTENT device tensor
+            `dst`: the step graphs read that tensor in place (graphed.mark_static), so a draw costs one H2D copy and no
+            device-to-device copy into a graph's own input buffer"""
             k = self.i % len(self.bufs)
             self.i += 1
             if self.evs[k] is not None:
                 self.evs[k].synchronize()
             fill(self.bufs[k])
-            d = self.bufs[k].to(device, non_blocking=True)
+            dst.copy_(self.bufs[k], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             self.evs[k] = ev
-            return d
+            return dst
 
     u_ring, e_ring = PinnedRing((N, 2048)), PinnedRing((1,))
+    u_dev = [graphed.mark_static(torch.empty(N, 2048, device=device)) for _ in range(3)]      # one per train_op of an iteration
+    eps_dev = graphed.mark_static(torch.empty(1, device=device))
 
-    def draw_u():
+    def draw_u(j):
         # U(-0.3, 0.3) on the CPU generator (src/wgan_loss.py:100), written in place into a pinned
         # buffer so that the H2D copy is asynchronous and the host can run ahead of the GPU
-        return u_ring.draw(lambda b: b.uniform_(-0.3, 0.3, generator=gen))
+        return u_ring.draw(lambda b: b.uniform_(-0.3, 0.3, generator=gen), u_dev[j])
 
     def draw_eps():
-        return e_ring.draw(lambda b: b.uniform_(0.0, 1.0, generator=gen))
+        return e_ring.draw(lambda b: b.uniform_(0.0, 1.0, generator=gen), eps_dev)
 
     if args.api_path:
         one_step, api_info = api_path_step(args, G, Dm, og, od, (lg, ld, lp), device, rank)
@@ -252,7 +257,7 @@ def hip_workload(args, rank, world, device):
             # iteration's RNA rows ONCE (first train_op) and the other two reuse the latent (new_batch() drops it, so
             # every iteration encodes although this benchmark reuses one resident RNA tensor)
             PL.new_batch()
-            u_g, u_d, u_p = draw_u(), draw_u(), draw_u()       # same order of draws as three separate train_ops
+            u_g, u_d, u_p = draw_u(0), draw_u(1), draw_u(2)    # same order of draws as three separate train_ops
             # the D-loss step is told the penalty step's draw: both fake batches (same generator weights) come out of one
             # generator pass over the double batch; the penalty step picks its fake up (losses._FAKE)
             return [lg.step(G, Dm, og, rna, u_g),

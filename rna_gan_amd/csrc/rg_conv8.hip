@@ -272,9 +272,15 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
       asm volatile("s_waitcnt lgkmcnt(0)"                                                                      \
                    : "+v"(bS[SET][0]), "+v"(bS[SET][1]), "+v"(bS[SET][2]), "+v"(bS[SET][3])::"memory");        \
   } while (0)
+// C8_PRIO_MODE (build-time experiment knob): 0 = s_setprio(1) around every MFMA section (CDNA guide T5); 1 = static priority
+// for the second-dispatched half (waves 4-7) set once before the loop, no per-section flips (MI355X_MICROARCH "two waves per
+// SIMD", item 4); 2 = no priority changes
+#ifndef C8_PRIO_MODE
+#define C8_PRIO_MODE 0
+#endif
 #define C8_MFMAS(I, J, SET)                                                                                    \
   do {                                                                                                         \
-    __builtin_amdgcn_s_setprio(1);                                                                             \
+    if (C8_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(1);                                                      \
     _Pragma("unroll") for (int kk_ = 0; kk_ < NKK; ++kk_) _Pragma("unroll") for (int t_ = 0; t_ < NAT; ++t_)   \
     _Pragma("unroll") for (int c_ = 0; c_ < NBT; ++c_) {                                                       \
       if constexpr (EB == 1)                                                                                   \
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
             __builtin_bit_cast(bf16x8_t, aR[(t_ * NKK + kk_) & 7]), __builtin_bit_cast(bf16x8_t, bS[SET][(c_ * NKK + kk_) & 3]), \
             acc[I][J][t_ * NBT + c_], 0, 0, 0);                                                                \
     }                                                                                                          \
-    __builtin_amdgcn_s_setprio(0);                                                                             \
+    if (C8_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(0);                                                      \
   } while (0)
 #define C8_SYNC() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
   // counted waits (see the table in the header): half-tiles allowed to stay in flight behind the one needed next phase
@@ -346,6 +352,7 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
   C8_READ_B(0, 0, 0);                                          // "P4 of k-tile -1"
   C8_WAIT_B(0);
   if (wave >= 4) __builtin_amdgcn_s_barrier();                 // waves 4-7 run one barrier behind waves 0-3
+  if (C8_PRIO_MODE == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
   __builtin_amdgcn_sched_barrier(0);
   for (int u = 0; u < nkt; u += 2) {
     C8_TILE(0, 0, 2, u);
