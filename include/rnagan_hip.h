@@ -244,6 +244,22 @@ int rg_bn_act_bwd(const void* z, const void* ga, const float* mean, const float*
 int rg_bn_finalize_partials(const float* partial, int G, int M, int C, float eps, float momentum, float* mean,
                             float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, void* ws,
                             size_t ws_bytes, void* stream);
+/* ---- Inception-v3 feature extractor of the FID metric (src/fid.py:33-94: torchvision inception_v3 up to Mixed_7c) --------
+ * NHWC fp32.  A BasicConv2d (Conv2d(bias=False) + BatchNorm2d(eval, eps 1e-3) + ReLU) = rg_im2col_nhwc (not needed for 1x1
+ * stride 1) + rg_linear_affine_act with the folded BatchNorm affine and slope 0; ldx / ldy are row strides in elements, so a
+ * branch reads / writes a channel slice of a wider activation (torch.cat of the block outputs is free).
+ *   rg_im2col_nhwc        cols[(n,ho,wo)][(i,j,c)] = x[n][ho*sh-ph+i][wo*sw-pw+j][c] or 0 outside the image
+ *   rg_pool2d_nhwc        mode 0: F.max_pool2d(k, stride) ; mode 1: F.avg_pool2d(k, stride, pad) (padding counted)
+ *   rg_nchw_to_nhwc_affine y[n][p][c] = x[n][c][p] * scale[c] + shift[c]  (x * 2 - 1 and torchvision's transform_input)
+ *   rg_spatial_mean_nhwc  adaptive_avg_pool2d(., (1, 1)) */
+int rg_im2col_nhwc(const float* x, int ldx, float* cols, int N, int H, int W, int C, int kh, int kw, int sh, int sw, int ph,
+                   int pw, void* stream);
+int rg_pool2d_nhwc(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int k, int stride, int pad, int mode,
+                   void* stream);
+int rg_nchw_to_nhwc_affine(const float* x_nchw, float* y_nhwc, int N, int C, int H, int W, const float* scale, const float* shift,
+                           void* stream);
+int rg_spatial_mean_nhwc(const float* x, float* y, int N, int HW, int C, void* stream);
+
 /* ---- split-K conv + train-mode BatchNorm without the intermediate passes (bf16 path) -------------------------------
  * The deep Conv2d / ConvTranspose2d layers at small batch run split-K (rg_conv_split(...) > 1): every launch leaves
  * nsplit fp32 slabs [nsplit][rows][C] in the workspace.  rg_conv_down_partial / rg_conv_up_partial run ONLY that launch

@@ -121,6 +121,10 @@ PROTOTYPES = {
     "rg_fp8_supported": (_i, [_i, _i, _i, _i]),
     "rg_cast_fp8": (_i, [_p, _p, _z, _f, _p]),
     "rg_selftest_fp8": (_i, [_p, _p]),
+    "rg_im2col_nhwc": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "rg_pool2d_nhwc": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "rg_nchw_to_nhwc_affine": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p]),
+    "rg_spatial_mean_nhwc": (_i, [_p, _p, _i, _i, _i, _p]),
     "rg_conv_split": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "rg_conv_down_partial": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_conv_up_partial": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
@@ -136,7 +140,7 @@ PROTOTYPES = {
 }
 
 # must equal rg_version() of the library (rna_gan_amd/csrc/rg_api.hip): bumped together with PROTOTYPES
-ABI_VERSION = 301
+ABI_VERSION = 302
 
 _lib = None
 

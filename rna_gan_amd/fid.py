@@ -107,6 +107,23 @@ def calculate_fid(images1, images2, feature_extractor, batch_size=2, use_multipr
     return frechet_distance(m1, s1, m2, s2)
 
 
+def inception_feature_extractor(weights, device="cuda:0"):
+    """The reference's feature extractor (src/fid.py:33-94: torchvision inception_v3 up to Mixed_7c, spatially averaged) on
+    the HIP kernels, as the ``feature_extractor`` argument of calculate_fid / fid_protocol.  ``weights``: a torchvision
+    ``inception_v3`` state_dict (or the path of a file holding one) -- pretrained weights are not obtainable offline, they
+    are an input here.  Returns a callable (N, 3, 299, 299) float tensor in [0, 1] -> (N, 2048) float32 array."""
+    from .inception import InceptionV3
+    net = InceptionV3()
+    if isinstance(weights, (str, bytes)):
+        weights = torch.load(weights, map_location="cpu")
+    net.load_state_dict(weights)
+    net = net.to(device).eval()
+
+    def extract(x01):
+        return net.features(x01.to(device)).cpu().numpy()
+    return extract
+
+
 def fid_protocol(generate_fake, real_images, feature_extractor, iterations=5, batch_size=2):
     """The reference's reporting protocol (src/fid.py:312-330): `iterations` (= 5) independent generations of the fake
     set against the same real set, FID of each, reported as mean +- std.  generate_fake() -> (N, H, W, 3) images."""
