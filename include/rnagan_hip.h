@@ -76,6 +76,9 @@ int rg_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I, int 
 /* The same wup / G.0 operand images built from the bf16 copy of the masters that rg_adam_step_dev(shadow_bf16) keeps
  * (2-byte instead of 4-byte reads; w_bf16 is [O][16][I] resp. [E][C][16], the master's order). */
 int rg_pack_conv_wup_from_bf16(const void* w_bf16, void* wup, int O, int I, void* stream);
+/* the same for n <= 8 layers in ONE launch (arrays of n pointers / sizes on the host): every layer needs O % 64 == 0,
+ * 16 * I % 128 == 0 and 16-byte aligned buffers, else RG_EUNSUPPORTED (use the single-layer call) */
+int rg_pack_conv_wup_from_bf16_multi(int n, const void* const* w_bf16, void* const* wup, const int* O, const int* I, void* stream);
 int rg_pack_g0_weight_from_bf16(const void* w_bf16, void* wp, int E, int C, void* stream);
 
 /* y[N][Hi/2][Wi/2][O] = conv2d(x[N][Hi][Wi][I], w[O][4][4][I], stride 2, pad 1).

@@ -44,6 +44,7 @@ PROTOTYPES = {
     "rg_skinny_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_pack_g0_weight": (_i, [_p, _p, _i, _i, _i, _p]),
     "rg_pack_conv_wup_from_bf16": (_i, [_p, _p, _i, _i, _p]),
+    "rg_pack_conv_wup_from_bf16_multi": (_i, [_i, _p, _p, _p, _p, _p]),
     "rg_pack_g0_weight_from_bf16": (_i, [_p, _p, _i, _i, _p]),
     "rg_g0_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_g0_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
@@ -140,7 +141,7 @@ PROTOTYPES = {
 }
 
 # must equal rg_version() of the library (rna_gan_amd/csrc/rg_api.hip): bumped together with PROTOTYPES
-ABI_VERSION = 302
+ABI_VERSION = 303
 
 _lib = None
 

@@ -18,7 +18,7 @@ void rg_set_error(const char* fmt, ...) {
 }
 
 // bumped whenever an entry point is added or a signature changes; rna_gan_amd/_abi.py (ABI_VERSION) refuses any other value
-extern "C" int rg_version(void) { return 302; }   // 3.02: round 3 (fused split-K BatchNorm, Inception-v3 data-movement kernels)
+extern "C" int rg_version(void) { return 303; }   // 3.02: round 3 (fused split-K BatchNorm, Inception-v3 data-movement kernels)
 extern "C" const char* rg_last_error(void) { return g_err; }
 
 // ---- kernel-selection knobs: override table in front of the RNAGAN_* environment variables
@@ -259,6 +259,14 @@ extern "C" int rg_skinny_wgrad(const void* low, const float* high_nchw, float* d
 extern "C" int rg_pack_conv_wup_from_bf16(const void* w_bf16, void* wup, int O, int I, void* stream) {
   RG_REQUIRE(w_bf16 && wup && O > 0 && I > 0, RG_EINVAL, "pack_conv_wup_from_bf16: bad args");
   return rg_mfma_transpose_bf16(w_bf16, wup, O, 16 * I, 0, rg_stream(stream));
+}
+// the transposed-conv weight images of up to 8 layers in one launch (each as rg_pack_conv_wup_from_bf16)
+extern "C" int rg_pack_conv_wup_from_bf16_multi(int n, const void* const* w_bf16, void* const* wup, const int* O, const int* I,
+                                                void* stream) {
+  RG_REQUIRE(n >= 1 && n <= 8 && w_bf16 && wup && O && I, RG_EINVAL, "pack_conv_wup_from_bf16_multi: bad args");
+  int Cc[8];
+  for (int i = 0; i < n; ++i) Cc[i] = 16 * I[i];
+  return rg_mfma_transpose_bf16_multi(n, w_bf16, wup, O, Cc, rg_stream(stream));
 }
 extern "C" int rg_pack_g0_weight_from_bf16(const void* w_bf16, void* wp, int E, int C, void* stream) {
   RG_REQUIRE(w_bf16 && wp && E > 0 && C > 0, RG_EINVAL, "pack_g0_weight_from_bf16: bad args");

@@ -72,6 +72,7 @@ int rg_generic_upconv3_bwd_data(const void* gy, int gy_nchw, const float* w, voi
 int rg_generic_upconv3_wgrad(const void* gy, int gy_nchw, const void* x, float* dw, int N, int H, int W, int Cin,
                              int Cout, int dtype, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 int rg_mfma_transpose_bf16(const void* src, void* dst, int R, int Cc, int permute, hipStream_t st);
+int rg_mfma_transpose_bf16_multi(int n, const void* const* src, void* const* dst, const int* R, const int* Cc, hipStream_t st);
 size_t rg_mfma_g0_wgrad_ws_bytes(int N, int E, int C);
 bool rg_mfma_g0_wgrad_supported(int N, int E, int C);
 int rg_mfma_g0_wgrad(const float* z, const void* gy, float* dw, int N, int E, int C, void* ws, size_t ws_bytes,

@@ -1045,6 +1045,43 @@ __global__ __launch_bounds__(256) void transpose_bf16_wide_kernel(const uint16_t
     *reinterpret_cast<uint4*>(dst + (size_t)orow * R + r0 + 8 * rg) = make_uint4(o[0], o[1], o[2], o[3]);
   }
 }
+// The same transpose for up to 8 tensors in ONE launch (the transposed-conv weight images of a whole network after an optimizer
+// step: 5 launches of 10-40 us became one; blocks are dealt to the tensors by a prefix table of tile counts).
+struct TransMulti {
+  const uint16_t* src[8];
+  uint16_t* dst[8];
+  int R[8], Cc[8];
+  int tile_end[8];          // exclusive prefix of 64 x 128 tiles
+  int n;
+};
+__global__ __launch_bounds__(256) void transpose_bf16_multi_kernel(TransMulti tab) {
+  __shared__ __attribute__((aligned(16))) uint16_t tile[64][128];
+  int i = 0;
+  while (i + 1 < tab.n && (int)blockIdx.x >= tab.tile_end[i]) ++i;
+  const int local = (int)blockIdx.x - (i ? tab.tile_end[i - 1] : 0);
+  const int R = tab.R[i], Cc = tab.Cc[i];
+  const uint16_t* __restrict__ src = tab.src[i];
+  uint16_t* __restrict__ dst = tab.dst[i];
+  const int tx = Cc / 128;
+  const int r0 = (local / tx) * 64, c0 = (local % tx) * 128;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = t + 256 * k, row = e >> 4, chunk = e & 15;
+    const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)(r0 + row) * Cc + c0 + chunk * 8);
+    *reinterpret_cast<uint4*>(&tile[row][(chunk ^ ((row >> 3) & 7)) * 8]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = t + 256 * k, c = e >> 3, rg = e & 7;
+    const int pc = (((c >> 3) ^ rg) << 3) | (c & 7);
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (uint32_t)tile[8 * rg + 2 * j][pc] | ((uint32_t)tile[8 * rg + 2 * j + 1][pc] << 16);
+    *reinterpret_cast<uint4*>(dst + (size_t)(c0 + c) * R + r0 + 8 * rg) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
 __global__ void pack_linear_kernel(const float* w, uint16_t* wp, int Nout, int K, int Np, int Kp) {
   size_t n = (size_t)Np * Kp;
   for (size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += (size_t)gridDim.x * blockDim.x) {
@@ -1577,6 +1614,23 @@ int rg_mfma_transpose_bf16(const void* src, void* dst, int R, int Cc, int permut
   hipLaunchKernelGGL(transpose_bf16_kernel, dim3((Cc + 63) / 64, (R + 63) / 64), dim3(256), 0, st, (const uint16_t*)src,
                      (uint16_t*)dst, R, Cc, permute);
   RG_LAUNCH_CHECK("transpose_bf16");
+  return RG_OK;
+}
+// dst_i[Cc_i][R_i] = transpose(src_i[R_i][Cc_i]) for n <= 8 bf16 matrices, one launch (R % 64 == 0, Cc % 128 == 0, 16-byte aligned)
+int rg_mfma_transpose_bf16_multi(int n, const void* const* src, void* const* dst, const int* R, const int* Cc, hipStream_t st) {
+  RG_REQUIRE(n >= 1 && n <= 8, RG_EINVAL, "transpose_bf16_multi: 1..8 tensors");
+  TransMulti tab{};
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    RG_REQUIRE(src[i] && dst[i] && R[i] > 0 && Cc[i] > 0 && R[i] % 64 == 0 && Cc[i] % 128 == 0 && ((uintptr_t)src[i] & 15) == 0 &&
+                   ((uintptr_t)dst[i] & 15) == 0, RG_EUNSUPPORTED, "transpose_bf16_multi: tensor %d is not 64 x 128 tileable", i);
+    tab.src[i] = (const uint16_t*)src[i]; tab.dst[i] = (uint16_t*)dst[i]; tab.R[i] = R[i]; tab.Cc[i] = Cc[i];
+    tiles += (R[i] / 64) * (Cc[i] / 128);
+    tab.tile_end[i] = tiles;
+  }
+  tab.n = n;
+  hipLaunchKernelGGL(transpose_bf16_multi_kernel, dim3((unsigned)tiles), dim3(256), 0, st, tab);
+  RG_LAUNCH_CHECK("transpose_bf16_multi");
   return RG_OK;
 }
 int rg_mfma_pack_g0_weight(const float* w, void* wp, int E, int C, hipStream_t st) {

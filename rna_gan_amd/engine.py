@@ -152,6 +152,13 @@ class _Ctx:
     pass
 
 
+def _refresh(ops, blocks):
+    """Before a network's first conv of a pass: stale bf16 weight images of all its layers rebuilt in one launch (HIP backend)."""
+    fn = getattr(ops, "refresh_packs", None)
+    if fn is not None:
+        fn([b[0] for b in blocks])
+
+
 def _bn_forward(ops, z, bn: BNP, slope, update_running=True, partials=None):
     """partials: BatchNorm column sums written by the epilogue of the conv that produced z (or None)."""
     if update_running:
@@ -168,6 +175,7 @@ def disc_forward(ops, D: DiscNet, x_nchw, update_running=True):
     Returns (out, ctx); ctx keeps what the backward passes need."""
     ctx = _Ctx()
     ctx.x = x_nchw
+    _refresh(ops, D.blocks)
     a = ops.first_down(x_nchw, D.conv0, D.conv0.bias, D.slope)
     ctx.a = [a]
     ctx.z, ctx.mean, ctx.invstd = [None], [None], [None]
@@ -344,6 +352,7 @@ def gen_forward(ops, G: GenNet, noise, update_running=True, keep=True):
     """G(z): ConvT(E->C0,k4,s1,p0)+BN+LReLU, R x [ConvT(k4,s2,p1)+BN+LReLU], ConvT+bias+Tanh."""
     ctx = _Ctx()
     ctx.noise = noise
+    _refresh(ops, G.blocks)
     z = ops.g0_fwd(noise, G.g0)
     a, mean, invstd = _bn_forward(ops, z, G.bn0, G.slope, update_running)
     ctx.z, ctx.mean, ctx.invstd, ctx.a = [z], [mean], [invstd], [a]
@@ -385,6 +394,7 @@ def gen_forward_pair(ops, G: GenNet, noise2, update_running=True):
     generator weights (src/wgan_loss.py:247 and :371): their two forwards become one.  Returns images [2n, 3, H, W]."""
     def run(bn):
         return (bn.running_mean, bn.running_var, bn.nbt) if update_running else (None, None, None)
+    _refresh(ops, G.blocks)
     z = ops.g0_fwd(noise2, G.g0)
     a, _, _ = ops.bn_forward2(z, G.bn0.gamma, G.bn0.beta, G.slope, G.bn0.eps, G.bn0.momentum, *run(G.bn0))
     for l, (cw, bn) in enumerate(G.blocks):
@@ -565,6 +575,7 @@ def disc_loss_grads_batched(ops, G, D: DiscNet, real, noise, grad_scale: float =
         if next_noise is not None:
             fake_next, _ = _gen_fwd(ops, G, next_noise, keep=False)
     xs = (real, img)
+    _refresh(ops, D.blocks)
     H, W = real.shape[2], real.shape[3]
     C0 = D.conv0.w.shape[0]
     a = torch.empty((2 * n, H // 2, W // 2, C0), dtype=ops.act_dtype, device=real.device)

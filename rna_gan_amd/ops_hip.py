@@ -178,6 +178,34 @@ class HipOps:
                 cw.shadow_version = cw.version
         return cw.packs
 
+    def refresh_packs(self, cws):
+        """Rebuild the stale transposed-conv weight images (wup) of several layers in ONE launch when the fused Adam left
+        their bf16 shadows current (the common case after an optimizer step: 5 transposes of 10-40 us per network became
+        one).  Layers that do not qualify are left to the lazy per-layer path (_packs)."""
+        if self.dt != RG_BF16 or not self.pack_from_shadow or os.environ.get("RNAGAN_PACK_MULTI", "1") == "0":
+            return
+        todo = []
+        for cw in cws:
+            if (cw.layout == "OHWI" and cw.shadow is not None and cw.shadow_version == cw.version and
+                    (cw.packs is None or cw.packs_version != cw.version) and cw.O % 64 == 0 and (16 * cw.I) % 128 == 0):
+                if cw.packs is None:
+                    cw.packs = (cw.shadow, torch.empty((16, cw.I, cw.O), dtype=torch.bfloat16, device=self.device))
+                if cw.packs[0] is cw.shadow:
+                    todo.append(cw)
+        if len(todo) < 2:
+            return
+        import ctypes as C
+        for i in range(0, len(todo), 8):
+            part = todo[i:i + 8]
+            n = len(part)
+            src = (C.c_void_p * n)(*[cw.shadow.data_ptr() for cw in part])
+            dst = (C.c_void_p * n)(*[cw.packs[1].data_ptr() for cw in part])
+            Os = (C.c_int * n)(*[cw.O for cw in part])
+            Is = (C.c_int * n)(*[cw.I for cw in part])
+            check(self.lib.rg_pack_conv_wup_from_bf16_multi(n, src, dst, Os, Is, self.stream), "rg_pack_conv_wup_from_bf16_multi")
+            for cw in part:
+                cw.packs_version = cw.version
+
     # ------------------------------------------------------------------ conv family
     @staticmethod
     def _tap_major(cw: ConvW):

@@ -631,3 +631,33 @@ def test_cast_pad_matches_torch(M, K, ldd):
     want = torch.zeros(M, ldd, dtype=torch.bfloat16, device="cuda")
     want[:, :K] = x.to(torch.bfloat16)
     assert torch.equal(out.view(torch.int16), want.view(torch.int16))
+
+
+def test_multi_tensor_weight_image_transpose():
+    """rg_pack_conv_wup_from_bf16_multi: the transposed-conv weight images wup[16*I][O] of several layers from their bf16
+    tap-major images wdn[O][16*I] in one launch == the per-layer call == a plain transpose (exact: data movement)."""
+    import ctypes as C
+    from rna_gan_amd import _abi
+    lib = _abi.load()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(3)
+    shapes = [(128, 64), (256, 128), (512, 256), (64, 8), (1024, 512)]          # (O, I)
+    src = [torch.randn(O, 16 * I, generator=gen).bfloat16().to(dev) for O, I in shapes]
+    dst = [torch.empty(16 * I, O, dtype=torch.bfloat16, device=dev) for O, I in shapes]
+    n = len(shapes)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _abi.check(lib.rg_pack_conv_wup_from_bf16_multi(
+        n, (C.c_void_p * n)(*[t.data_ptr() for t in src]), (C.c_void_p * n)(*[t.data_ptr() for t in dst]),
+        (C.c_int * n)(*[s[0] for s in shapes]), (C.c_int * n)(*[s[1] for s in shapes]), stream), "multi")
+    torch.cuda.synchronize()
+    for (O, I), s, d in zip(shapes, src, dst):
+        assert torch.equal(d, s.t().contiguous()), (O, I)
+        one = torch.empty_like(d)
+        _abi.check(lib.rg_pack_conv_wup_from_bf16(s.data_ptr(), one.data_ptr(), O, I, stream), "single")
+        torch.cuda.synchronize()
+        assert torch.equal(one, d)
+    # a layer that is not 64 x 128 tileable is refused (the caller uses the per-layer kernel)
+    bad = torch.zeros(32, 16 * 8, dtype=torch.bfloat16, device=dev)
+    rc = lib.rg_pack_conv_wup_from_bf16_multi(1, (C.c_void_p * 1)(bad.data_ptr()), (C.c_void_p * 1)(bad.data_ptr()),
+                                              (C.c_int * 1)(32), (C.c_int * 1)(8), stream)
+    assert rc != 0
