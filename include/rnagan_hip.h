@@ -263,6 +263,27 @@ int rg_nchw_to_nhwc_affine(const float* x_nchw, float* y_nhwc, int N, int C, int
                            void* stream);
 int rg_spatial_mean_nhwc(const float* x, float* y, int N, int HW, int C, void* stream);
 
+/* ---- data-gradient conv + the BatchNorm backward it feeds, without the reduction pass (bf16 path) ------------------------
+ * In .backward() through a [Conv -> BatchNorm2d(train) -> LeakyReLU] stack the data gradient ga produced by one layer's
+ * conv (rg_conv_up for nn.Conv2d, rg_conv_down for nn.ConvTranspose2d) is consumed by the BatchNorm backward of the layer
+ * below, whose first pass reduces gy = ga * lrelu'(y) and gy * xhat over all rows.  rg_conv_*_bnbwd compute these column
+ * sums in the conv's epilogue (the tile is in registers; the consumer's z tile is read there) and write one partial row
+ * [2][C] per block tile into sums_partial (rg_conv_bnbwd_rows(...) rows; 0: this shape splits K or runs another kernel --
+ * use rg_conv_* + rg_bn_act_bwd).  rg_bn_act_bwd_partials = rg_bn_act_bwd[_g2] from those partial rows: finisher + pointwise
+ * pass.  groups = 2: two batch halves with their own statistics (mean / invstd [2][C]); G = partial rows per group,
+ * nblk = 1 (rg_conv_down_bnbwd) or 4 (rg_conv_up_bnbwd: rows are parity-class-major). */
+int rg_conv_bnbwd_rows(int up, int N, int Hlow, int Wlow, int O, int I, int groups, int dtype, int algo);
+int rg_conv_down_bnbwd(const void* x, const void* wdn, void* y, int N, int Hi, int Wi, int I, int O, const void* z_next,
+                       const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, int groups,
+                       float* sums_partial, int dtype, int algo, void* ws, size_t ws_bytes, void* stream);
+int rg_conv_up_bnbwd(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, const void* z_next,
+                     const float* mean, const float* invstd, const float* gamma, const float* beta, float slope, int groups,
+                     float* sums_partial, int dtype, int algo, void* ws, size_t ws_bytes, void* stream);
+int rg_bn_act_bwd_partials(const float* partial, int G, int nblk, const void* z, const void* ga, const float* mean,
+                           const float* invstd, const float* gamma, const float* beta, void* gz, float* s_gy, float* s_gyxh,
+                           float* dgamma, float* dbeta, int accumulate, int M, int C, int groups, float slope, int dtype,
+                           void* ws, size_t ws_bytes, void* stream);
+
 /* ---- split-K conv + train-mode BatchNorm without the intermediate passes (bf16 path) -------------------------------
  * The deep Conv2d / ConvTranspose2d layers at small batch run split-K (rg_conv_split(...) > 1): every launch leaves
  * nsplit fp32 slabs [nsplit][rows][C] in the workspace.  rg_conv_down_partial / rg_conv_up_partial run ONLY that launch

@@ -70,11 +70,11 @@ class RefOps:
 
     # ------------------------------------------------------------------ conv family
     # (the handle's master may be stored tap-major; cw.oihw() / cw.store_grad_oihw() give the PyTorch view)
-    def conv_down(self, x, cw: ConvW, want_stats=False, defer=0):      # defer: a launch-fusion hint of the HIP backend
+    def conv_down(self, x, cw: ConvW, want_stats=False, defer=0, bn_bwd=None):      # defer: a launch-fusion hint of the HIP backend
         y = _nhwc(F.conv2d(self._nchw(x), self._wq(cw.oihw()), None, stride=2, padding=1), self.act_dtype)
         return (y, None) if want_stats else y          # the twin has no fused statistics: bn_forward computes them
 
-    def conv_up(self, x, cw: ConvW, mask_act=None, slope=1.0, want_stats=False, defer=0):
+    def conv_up(self, x, cw: ConvW, mask_act=None, slope=1.0, want_stats=False, defer=0, bn_bwd=None):
         y = F.conv_transpose2d(self._nchw(x), self._wq(cw.oihw()), None, stride=2, padding=1)
         if mask_act is not None:       # fused LeakyReLU backward: applied to the fp32 result, rounded once
             y = y * _lrelu_mask(self._nchw(mask_act), slope)

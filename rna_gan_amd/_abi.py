@@ -126,6 +126,11 @@ PROTOTYPES = {
     "rg_pool2d_nhwc": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "rg_nchw_to_nhwc_affine": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "rg_spatial_mean_nhwc": (_i, [_p, _p, _i, _i, _i, _p]),
+    "rg_conv_bnbwd_rows": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "rg_conv_down_bnbwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _i, _p, _i, _i, _p, _z, _p]),
+    "rg_conv_up_bnbwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _f, _i, _p, _i, _i, _p, _z, _p]),
+    "rg_bn_act_bwd_partials": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _z,
+                                    _p]),
     "rg_conv_split": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "rg_conv_down_partial": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_conv_up_partial": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
@@ -141,7 +146,7 @@ PROTOTYPES = {
 }
 
 # must equal rg_version() of the library (rna_gan_amd/csrc/rg_api.hip): bumped together with PROTOTYPES
-ABI_VERSION = 303
+ABI_VERSION = 304
 
 _lib = None
 

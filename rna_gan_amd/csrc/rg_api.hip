@@ -18,7 +18,7 @@ void rg_set_error(const char* fmt, ...) {
 }
 
 // bumped whenever an entry point is added or a signature changes; rna_gan_amd/_abi.py (ABI_VERSION) refuses any other value
-extern "C" int rg_version(void) { return 303; }   // 3.02: round 3 (fused split-K BatchNorm, Inception-v3 data-movement kernels)
+extern "C" int rg_version(void) { return 304; }   // 3.02: round 3 (fused split-K BatchNorm, Inception-v3 data-movement kernels)
 extern "C" const char* rg_last_error(void) { return g_err; }
 
 // ---- kernel-selection knobs: override table in front of the RNAGAN_* environment variables
@@ -98,6 +98,36 @@ extern "C" int rg_conv_up_partial(const void* x, const void* wup, int N, int Ho,
              "conv_up_partial: this shape does not run split-K (rg_conv_split)");
   return rg_mfma_conv_up(x, wup, nullptr, N, Ho, Wo, O, I, nullptr, 1.f, nullptr, ws, ws_bytes, rg_stream(stream), nullptr,
                          nullptr, 1.f, 0, 1);
+}
+
+// ---- data-gradient convs that also produce the BatchNorm-backward sums of the block they feed (rg_bn_act_bwd_partials)
+extern "C" int rg_conv_bnbwd_rows(int up, int N, int Hlow, int Wlow, int O, int I, int groups, int dtype, int algo) {
+  if (N <= 0 || Hlow <= 0 || Wlow <= 0 || O <= 0 || I <= 0 || !want_mfma(algo, dtype)) return 0;
+  if (!rg_mfma_conv_supported(N, Hlow, Wlow, up ? O : I, up ? I : O)) return 0;
+  return rg_mfma_conv_bnbwd_rows(up, N, Hlow, Wlow, O, I, groups);
+}
+
+extern "C" int rg_conv_down_bnbwd(const void* x, const void* wdn, void* y, int N, int Hi, int Wi, int I, int O, const void* z_next,
+                                  const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                                  int groups, float* sums_partial, int dtype, int algo, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(x && wdn && y && z_next && mean && invstd && gamma && beta && sums_partial && N > 0 && Hi > 0 && Wi > 0 && I > 0 &&
+                 O > 0 && Hi % 2 == 0 && Wi % 2 == 0, RG_EINVAL, "conv_down_bnbwd: bad args");
+  RG_REQUIRE(rg_conv_bnbwd_rows(0, N, Hi / 2, Wi / 2, O, I, groups, dtype, algo) > 0, RG_EUNSUPPORTED,
+             "conv_down_bnbwd: this shape has no fused form (rg_conv_bnbwd_rows)");
+  RgBnBwdFuse bf{z_next, mean, invstd, gamma, beta, slope, groups, sums_partial};
+  return rg_mfma_conv_down(x, wdn, y, N, Hi, Wi, I, O, nullptr, ws, ws_bytes, rg_stream(stream), 0, &bf);
+}
+
+extern "C" int rg_conv_up_bnbwd(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, const void* z_next,
+                                const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                                int groups, float* sums_partial, int dtype, int algo, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(x && wup && y && z_next && mean && invstd && gamma && beta && sums_partial && N > 0 && Ho > 0 && Wo > 0 && I > 0 &&
+                 O > 0, RG_EINVAL, "conv_up_bnbwd: bad args");
+  RG_REQUIRE(rg_conv_bnbwd_rows(1, N, Ho, Wo, O, I, groups, dtype, algo) > 0, RG_EUNSUPPORTED,
+             "conv_up_bnbwd: this shape has no fused form (rg_conv_bnbwd_rows)");
+  RgBnBwdFuse bf{z_next, mean, invstd, gamma, beta, slope, groups, sums_partial};
+  return rg_mfma_conv_up(x, wup, y, N, Ho, Wo, O, I, nullptr, 1.f, nullptr, ws, ws_bytes, rg_stream(stream), nullptr, nullptr,
+                         1.f, 0, 0, &bf);
 }
 
 extern "C" int rg_conv_down(const void* x, const float* w, const void* wdn, void* y, int N, int Hi, int Wi, int I,

@@ -875,6 +875,38 @@ extern "C" int rg_bn_act_bwd(const void* z, const void* ga, const float* mean, c
   })
 }
 
+// rg_bn_act_bwd[_g2] with the two sums taken from the partial rows a data-gradient conv's epilogue wrote (rg_conv_*_bnbwd):
+// G rows per batch group [.][2][C], laid out [nblk][groups][G / nblk] (nblk = 1: rg_conv_down_bnbwd's row-tile order; 4:
+// rg_conv_up_bnbwd's class-major order) -> finisher (s_gy, s_gyxh, dgamma, dbeta) + the pointwise pass; the reduction pass
+// over (z, ga) is gone.
+extern "C" int rg_bn_act_bwd_partials(const float* partial, int G, int nblk, const void* z, const void* ga, const float* mean,
+                                      const float* invstd, const float* gamma, const float* beta, void* gz, float* s_gy,
+                                      float* s_gyxh, float* dgamma, float* dbeta, int accumulate, int M, int C, int groups,
+                                      float slope, int dtype, void* ws, size_t ws_bytes, void* stream) {
+  RG_REQUIRE(partial && G > 0 && z && ga && gz && s_gy && s_gyxh && M > 0 && C > 0 && (groups == 1 || groups == 2) && nblk >= 1 &&
+                 G % nblk == 0, RG_EINVAL, "bn_act_bwd_partials: bad args");
+  RG_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), RG_EINVAL, "bn_act_bwd_partials: dgamma/dbeta must come together");
+  BNC p{mean, invstd, gamma, beta, slope};
+  hipStream_t st = rg_stream(stream);
+  BwdFin fin{s_gy, s_gyxh, dgamma, dbeta, accumulate, C};
+  constexpr int SLICES = 32;
+  if (G > 512 && C % 8 == 0 && ws && ws_bytes >= (size_t)groups * SLICES * 2 * C * sizeof(float)) {
+    float* stage = (float*)ws;
+    hipLaunchKernelGGL((colfinish_wide_kernel<2, SliceFin>), dim3(C / 8, SLICES, groups), dim3(256), 0, st,
+                       SliceFin{stage, C, SLICES}, partial, C, G, nblk);
+    RG_LAUNCH_CHECK("bn_act_bwd_partials");
+    hipLaunchKernelGGL((colfinish_kernel<2, BwdFin>), dim3((C + 7) / 8), dim3(256), 0, st, fin, stage, C, SLICES, groups, 1);
+  } else {
+    hipLaunchKernelGGL((colfinish_kernel<2, BwdFin>), dim3((C + 7) / 8), dim3(256), 0, st, fin, partial, C, G, groups, nblk);
+  }
+  RG_LAUNCH_CHECK("bn_act_bwd_partials");
+  const size_t gs = (size_t)M * C;
+  RG_DISPATCH_DTYPE(dtype, T, {
+    return (row_apply_g<T, BwdApplyF>("bn_act_bwd_partials", groups, M, C, st, (const T*)z, (const T*)ga, (T*)gz, p,
+                                      (const float*)s_gy, (const float*)s_gyxh, 1.f / (float)M, C, gs));
+  })
+}
+
 extern "C" int rg_bn_tangent(const void* z, const void* zt, const float* mean, const float* invstd, const float* gamma,
                              const float* beta, void* at, float* s_zt, float* s_xhzt, int M, int C, float slope,
                              int dtype, void* ws, size_t ws_bytes, void* stream) {

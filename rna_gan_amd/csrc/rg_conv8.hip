@@ -452,6 +452,18 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
           }
     __syncthreads();
     const int col = bn + ep * EP_COLS + cg * 8;
+    // consumer's BatchNorm-backward sums (see GArgs::bwd_z): this thread's 8 columns over its BM / RPP rows
+    float bs1[8], bs2[8], bmu[8], brs[8], bga[8], bbe[8];
+    const bool bwd = EB == 2 && g.bwd_z != nullptr && col < g.Ncols;
+    if (EB == 2 && g.bwd_z != nullptr) {
+      const int grp_off = (g.bwd_half_m > 0 && bm >= g.bwd_half_m) ? g.Ncols : 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        bs1[i] = 0.f; bs2[i] = 0.f;
+        const int c = col + i < g.Ncols ? col + i : 0;
+        bmu[i] = g.bwd_mean[grp_off + c]; brs[i] = g.bwd_invstd[grp_off + c]; bga[i] = g.bwd_gamma[c]; bbe[i] = g.bwd_beta[c];
+      }
+    }
 #pragma unroll 4
     for (int p = 0; p < BM / RPP; ++p) {
       const int row = rr + RPP * p;
@@ -494,6 +506,45 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
         o.z = (uint32_t)f32_to_bf16(v1.x) | ((uint32_t)f32_to_bf16(v1.y) << 16);
         o.w = (uint32_t)f32_to_bf16(v1.z) | ((uint32_t)f32_to_bf16(v1.w) << 16);
         *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(g.C) + orow * g.ldc + col) = o;
+        if (bwd) {
+          // BwdRedF's arithmetic on the STORED (bf16-rounded) gradient and the consumer's stored z
+          const uint4 zz = *reinterpret_cast<const uint4*>(g.bwd_z + orow * g.ldc + col);
+          const uint32_t od[4] = {o.x, o.y, o.z, o.w}, zd[4] = {zz.x, zz.y, zz.z, zz.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const int i = 2 * e + hh;
+              const float gaf = __uint_as_float(hh ? (od[e] & 0xffff0000u) : (od[e] << 16));
+              const float zf = __uint_as_float(hh ? (zd[e] & 0xffff0000u) : (zd[e] << 16));
+              const float xh = (zf - bmu[i]) * brs[i];
+              const float gy = gaf * lrelu_mask(xh * bga[i] + bbe[i], g.bwd_slope);
+              bs1[i] += gy; bs2[i] += gy * xh;
+            }
+          }
+        }
+      }
+    }
+    if (EB == 2 && g.bwd_z != nullptr) {
+      // block-tile column sums: the RPP row lanes of a column group through LDS in fixed order -> one partial row per tile
+      __syncthreads();                                    // every thread is done reading its rows of cs
+      float* red = cs;                                    // [RPP][EP_COLS][2]
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        red[(rr * EP_COLS + cg * 8 + i) * 2 + 0] = bs1[i];
+        red[(rr * EP_COLS + cg * 8 + i) * 2 + 1] = bs2[i];
+      }
+      __syncthreads();
+      if (t < 2 * EP_COLS) {
+        const int q = t / EP_COLS, c = t - q * EP_COLS;
+        float sum = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < RPP; ++k) sum += red[(k * EP_COLS + c) * 2 + q];
+        const int gcol = bn + ep * EP_COLS + c;
+        if (gcol < g.Ncols) {
+          const size_t prow = (size_t)par * a2.tiles_m + tile_m;
+          g.bwd_sums[(prow * 2 + q) * g.Ncols + gcol] = sum;
+        }
       }
     }
   }

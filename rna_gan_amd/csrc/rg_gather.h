@@ -38,6 +38,15 @@ struct GArgs {
   float mslope;           // (LeakyReLU backward of the consumer fused into the data-gradient conv)
   int in_fp8, out_fp8;    // conv8_kernel<.., EB = 1>: fp8 e4m3 operands (A, B) / fp8 output (row stride ldc in elements)
   int mask_packed;        // mask holds packed sign bits (one 64-bit word per output pixel: convp_kernel only)
+  // BatchNorm-backward sums of the CONSUMER in this launch's epilogue (conv8_kernel, bf16 output without split-K): the output
+  // is the data gradient ga arriving at a [BatchNorm + LeakyReLU] block whose stored pre-activation is bwd_z (the output's
+  // shape); per block tile the column sums of gy = ga * lrelu'(y) and gy * xhat go to bwd_sums [rows][2][Ncols] (rows =
+  // parity classes x row tiles), which rg_bn_act_bwd_partials finishes -- the separate reduction pass over (z, ga) disappears.
+  const uint16_t* bwd_z;
+  const float* bwd_mean; const float* bwd_invstd; const float* bwd_gamma; const float* bwd_beta;
+  float bwd_slope;
+  float* bwd_sums;
+  int bwd_half_m;         // > 0: two batch groups -- rows m >= bwd_half_m take mean / invstd + Ncols (second group)
   int defer_reduce;       // split-K launches: leave the fp32 slabs in the workspace, do not launch the slab reduction (the consumer
                           // reduces them itself: rg_splitbn.hip fuses the reduction into the BatchNorm pass that follows)
   int affine;             // EPI_BF16, bf16 output without split-K: out = lrelu(acc * scale[col] + shift[col], slope) (eval-mode

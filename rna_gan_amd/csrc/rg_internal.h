@@ -27,6 +27,12 @@ int rg_generic_g0_wgrad(const float* z, const void* gy, float* dw, int N, int E,
 int rg_generic_linear(const float* x, int ldx, const float* w, const float* scale, const float* shift, float* y,
                       int ldy, int M, int K, int Nout, float slope, hipStream_t st);
 
+// BatchNorm-backward sums of the consuming block computed in a conv launch's epilogue (GArgs::bwd_z, rg_conv8.hip)
+struct RgBnBwdFuse {
+  const void* z; const float* mean; const float* invstd; const float* gamma; const float* beta; float slope;
+  int groups; float* sums;
+};
+
 // rg_mfma.hip (bf16 MFMA implicit-GEMM kernels)
 bool rg_mfma_conv_supported(int N, int Hq, int Wq, int Kc, int Ncols);
 bool rg_mfma_plain_supported(int M, int K, int Ncols);
@@ -36,12 +42,14 @@ int rg_mfma_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I,
 int rg_mfma_pack_g0_weight(const float* w, void* wp, int E, int C, hipStream_t st);
 int rg_mfma_pack_linear_weight(const float* w, void* wp, int Nout, int K, int Nout_pad, int K_pad, hipStream_t st);
 int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, int Wi, int I, int O, float* stats,
-                      void* ws, size_t ws_bytes, hipStream_t st, int defer_reduce = 0);
+                      void* ws, size_t ws_bytes, hipStream_t st, int defer_reduce = 0, const RgBnBwdFuse* bf = nullptr);
+int rg_mfma_conv_bnbwd_rows(int up, int N, int Hlow, int Wlow, int O, int I, int groups);
 int rg_mfma_conv_nsplit(int up, int N, int Hlow, int Wlow, int O, int I);
 int rg_mfma_conv_stats_rows(int up, int N, int Hlow, int Wlow, int O, int I);
 int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, const void* mask,
                     float mslope, float* stats, void* ws, size_t ws_bytes, hipStream_t st, const float* scale = nullptr,
-                    const float* shift = nullptr, float slope = 1.f, int mask_packed = 0, int defer_reduce = 0);
+                    const float* shift = nullptr, float slope = 1.f, int mask_packed = 0, int defer_reduce = 0,
+                    const RgBnBwdFuse* bf = nullptr);
 // packed-mask form of the transposed conv's fused LeakyReLU backward (rg_convp.hip): shapes that take it
 bool rg_mfma_conv_up_maskbits_supported(int N, int Ho, int Wo, int O, int I);
 size_t rg_mfma_conv_ws_bytes(int up, int N, int Hlow, int Wlow, int O, int I);

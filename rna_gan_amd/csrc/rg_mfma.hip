@@ -1308,6 +1308,9 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   a2.xcd_swizzle = (xcd && grid.x % 8 == 0 && grid.x >= 16 && (xcd == 2 || a_bytes > b_bytes)) ? 1 : 0;
   // (measured and rejected for the 64-column tile: 2 waves with 128 x 64 wave tiles, 147-154 us vs 109-112 us)
   RG_REQUIRE(!g.mask_packed || pl.pp, RG_EUNSUPPORTED, "%s: packed mask bits without the patch-resident kernel", name);
+  RG_REQUIRE(!g.bwd_z || (c8 && nsplit == 1 && !g.mask && !g.affine && !pl.pp && !pl.n8 &&
+                          (g.bwd_half_m == 0 || g.bwd_half_m % bmm == 0)), RG_EUNSUPPORTED,
+             "%s: BatchNorm-backward sums in the epilogue need the unsplit 8-wave kernel (rg_conv_bnbwd_rows)", name);
   if (pl.pp) {
     if constexpr (EPI == EPI_BF16 && MODE == MODE_UP) {
       RG_REQUIRE(g.ldc == 64 && g.b_col == g.Cin, RG_EUNSUPPORTED, "%s: convp layout", name);
@@ -1355,10 +1358,30 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   return RG_OK;
 }
 
+static void set_bwd_fuse(GArgs& g, const RgBnBwdFuse* bf, int M) {
+  if (!bf) return;
+  g.bwd_z = (const uint16_t*)bf->z; g.bwd_mean = bf->mean; g.bwd_invstd = bf->invstd; g.bwd_gamma = bf->gamma;
+  g.bwd_beta = bf->beta; g.bwd_slope = bf->slope; g.bwd_sums = bf->sums;
+  g.bwd_half_m = bf->groups == 2 ? M / 2 : 0;
+}
+
+// partial rows the epilogue writes for the consumer's BatchNorm backward (0: this launch has no such form)
+int rg_mfma_conv_bnbwd_rows(int up, int N, int Hlow, int Wlow, int O, int I, int groups) {
+  const int M = N * Hlow * Wlow, Ncols = up ? I : O, Cin = up ? O : I, taps = up ? 4 : 16, nclass = up ? 4 : 1;
+  const size_t a_bytes = up ? (size_t)M * O * 2 : (size_t)M * 4 * I * 2, b_bytes = (size_t)O * 16 * I * 2;
+  if (use_v1() || a_bytes >= 0x7fffff00ull || b_bytes >= 0x7fffff00ull || groups < 1 || groups > 2 || Ncols % 8) return 0;
+  const GPlan pl = gather_plan(up ? MODE_UP : MODE_DOWN, true, M, Ncols, Cin, taps, nclass, false, up ? Hlow : 2 * Hlow,
+                               up ? Wlow : 2 * Wlow);
+  if (!pl.c8 || pl.nsplit != 1 || pl.pp || pl.n8) return 0;
+  if (groups == 2 && (M % 2 || (M / 2) % pl.bm)) return 0;
+  return nclass * ((M + pl.bm - 1) / pl.bm);
+}
+
 int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, int Wi, int I, int O, float* stats,
-                      void* ws, size_t ws_bytes, hipStream_t st, int defer_reduce) {
+                      void* ws, size_t ws_bytes, hipStream_t st, int defer_reduce, const RgBnBwdFuse* bf) {
   GArgs g{};
   g.defer_reduce = defer_reduce;
+  set_bwd_fuse(g, bf, N * (Hi / 2) * (Wi / 2));
   g.stats = stats;
   g.A = (const uint16_t*)x; g.B = (const uint16_t*)wdn; g.C = y;
   int Ho = Hi / 2, Wo = Wi / 2;
@@ -1370,9 +1393,10 @@ int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, in
 
 int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, const void* mask,
                     float mslope, float* stats, void* ws, size_t ws_bytes, hipStream_t st, const float* scale,
-                    const float* shift, float slope, int mask_packed, int defer_reduce) {
+                    const float* shift, float slope, int mask_packed, int defer_reduce, const RgBnBwdFuse* bf) {
   GArgs g{};
   g.defer_reduce = defer_reduce;
+  set_bwd_fuse(g, bf, N * Ho * Wo);
   RG_REQUIRE(!mask_packed || (mask && rg_mfma_conv_up_maskbits_supported(N, Ho, Wo, O, I)), RG_EUNSUPPORTED,
              "conv_up: packed mask bits need the patch-resident kernel's shape (128 -> 64 channels, width 16..64)");
   g.mask_packed = mask_packed;

@@ -152,6 +152,13 @@ class _Ctx:
     pass
 
 
+def _bnb(zs, means, invstds, blocks, l, slope, groups):
+    """(z, mean, invstd, gamma, beta, slope, groups) of discriminator block l: what a data-gradient conv needs to produce that
+    block's BatchNorm-backward sums in its own epilogue (HIP backend; the twin ignores it)."""
+    bn = blocks[l - 1][1]
+    return (zs[l], means[l], invstds[l], bn.gamma, bn.beta, slope, groups)
+
+
 def _refresh(ops, blocks):
     """Before a network's first conv of a pass: stale bf16 weight images of all its layers rebuilt in one launch (HIP backend)."""
     fn = getattr(ops, "refresh_packs", None)
@@ -222,7 +229,8 @@ def disc_backward(ops, D: DiscNet, ctx, coef: float, wgrad: bool, accumulate: bo
                 ops.conv_wgrad(gz, ctx.a[l - 1], cw, accumulate)
         # the data gradient of layer 1 feeds layer 0's LeakyReLU: its backward is fused into the epilogue
         # (defer=1: the next op on ga is the BatchNorm backward of the layer below, which reduces split-K slabs itself)
-        ga = ops.conv_up(gz, cw, defer=1) if l > 1 else ops.conv_up(gz, cw, ctx.a[0], D.slope)
+        ga = ops.conv_up(gz, cw, defer=1, bn_bwd=_bnb(ctx.z, ctx.mean, ctx.invstd, D.blocks, l - 1, D.slope, 1)) if l > 1 \
+            else ops.conv_up(gz, cw, ctx.a[0], D.slope)
     gz0 = ga if R > 0 else ops.lrelu_bwd(ga, ctx.a[0], D.slope)
     if keep_for_gp:
         ctx.gz1[0] = gz0
@@ -470,7 +478,10 @@ def gen_backward(ops, G: GenNet, ctx, gimg, accumulate: bool, need_input_grad: b
                                   G.slope, bn.dgamma, bn.dbeta, accumulate, keep_ga=False)
         with ops.side(gz):
             ops.conv_wgrad(ctx.a[l - 1], gz, cw, accumulate)
-        ga = ops.conv_down(gz, cw, defer=1)        # consumed by the BatchNorm backward of the layer below (next op)
+        # consumed by the BatchNorm backward of the layer below (next op): generator block l - 1, or G.0's BatchNorm
+        nxt = (ctx.z[l - 1], ctx.mean[l - 1], ctx.invstd[l - 1]) + \
+            ((G.blocks[l - 2][1].gamma, G.blocks[l - 2][1].beta) if l > 1 else (G.bn0.gamma, G.bn0.beta)) + (G.slope, 1)
+        ga = ops.conv_down(gz, cw, defer=1, bn_bwd=nxt)
     gz0, _, _ = ops.bn_act_bwd(ctx.z[0], ga, ctx.mean[0], ctx.invstd[0], G.bn0.gamma, G.bn0.beta,
                                G.slope, G.bn0.dgamma, G.bn0.dbeta, accumulate, keep_ga=False)
     ops.g0_wgrad(ctx.noise, gz0, G.g0.dw, accumulate)
@@ -607,7 +618,8 @@ def disc_loss_grads_batched(ops, G, D: DiscNet, real, noise, grad_scale: float =
         gz = ops.bn_act_bwd2(zs[l], ga, means[l], invstds[l], bn.gamma, bn.beta, D.slope, bn.dgamma, bn.dbeta, False)
         with ops.side(gz):
             ops.conv_wgrad(gz, acts[l - 1], cw, False)
-        ga = ops.conv_up(gz, cw, defer=2) if l > 1 else ops.conv_up(gz, cw, acts[0], D.slope)
+        ga = ops.conv_up(gz, cw, defer=2, bn_bwd=_bnb(zs, means, invstds, D.blocks, l - 1, D.slope, 2)) if l > 1 \
+            else ops.conv_up(gz, cw, acts[0], D.slope)
     gz0 = ga if R > 0 else ops.lrelu_bwd(ga, acts[0], D.slope)
     with ops.side(gz0):
         ops.skinny_wgrad(gz0[:n], xs[0], D.conv0.dw, False)

@@ -64,6 +64,9 @@ class HipOps:
         # split-K conv -> BatchNorm without the intermediate passes (rg_splitbn.hip): the conv leaves its slabs, the BatchNorm
         # kernel reduces them (RNAGAN_SPLIT_BN=0: conv + slab reduction + statistics + finisher + apply as separate launches)
         self.split_bn = os.environ.get("RNAGAN_SPLIT_BN", "1") != "0"
+        # data-gradient convs also produce the BatchNorm-backward sums of the block they feed (conv8 epilogue; RNAGAN_BWD_EPILOGUE=0:
+        # separate reduction pass over (z, ga))
+        self.bwd_epilogue = os.environ.get("RNAGAN_BWD_EPILOGUE", "1") != "0"
         self._slabs_pending = None    # the tensor whose deferred split-K slabs currently occupy the workspace
         self._sb_sync = None          # hand-off words of the fused kernels: zeroed once, left zero by every launch
         self._sb_scratch = None
@@ -221,7 +224,30 @@ class HipOps:
         rows = self.lib.rg_conv_stats_rows(up, N, Hl, Wl, O, I, self.dt, self.algo)
         return self._f32(rows, 2, C) if rows > 0 else None
 
-    def conv_down(self, x, cw: ConvW, want_stats=False, defer=0):
+    def _bn_bwd_fused(self, up, y, cw_ptr, x, dims, bn_bwd, flops):
+        """Launch the conv with the consumer's BatchNorm-backward sums in its epilogue when this shape has that form; the
+        partial rows ride on the result as ``_rg_bwd_partials`` for bn_act_bwd / bn_act_bwd2.  True when launched."""
+        z, mean, invstd, gamma, beta, slope, groups = bn_bwd
+        N, Hl, Wl, O, I = dims
+        if (self.dt != RG_BF16 or self.stat_reduce is not None or not self.bwd_epilogue or z.shape != y.shape or
+                z.dtype != y.dtype or not z.is_contiguous()):
+            return False
+        rows = int(self.lib.rg_conv_bnbwd_rows(up, N, Hl, Wl, O, I, groups, self.dt, self.algo))
+        if rows <= 0:
+            return False
+        C = y.shape[-1]
+        part = self._f32(rows, 2, C)
+        ws = self._ws(self.lib.rg_conv_workspace_bytes(up, N, Hl, Wl, O, I, self.dt, self.algo))
+        fn = self.lib.rg_conv_up_bnbwd if up else self.lib.rg_conv_down_bnbwd
+        a = (N, Hl, Wl, O, I) if up else (N, 2 * Hl, 2 * Wl, I, O)
+        self._timed("conv_fwd_dgrad", flops, lambda: check(
+            fn(_ptr(x), _ptr(cw_ptr), _ptr(y), *a, _ptr(z), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), float(slope),
+               int(groups), _ptr(part), self.dt, self.algo, _ptr(ws), ws.numel(), self.stream),
+            "rg_conv_up_bnbwd" if up else "rg_conv_down_bnbwd"))
+        y._rg_bwd_partials = (part, 4 if up else 1, groups)
+        return True
+
+    def conv_down(self, x, cw: ConvW, want_stats=False, defer=0, bn_bwd=None):
         """Stride-2 conv.  want_stats: also return the per-tile column sums of y and y^2 written by the MFMA epilogue
         (None when this shape cannot produce them) for bn_forward(..., partials=...).
         defer = g > 0: the caller promises that the NEXT op on the result is the train-mode BatchNorm op (forward: bn_forward /
@@ -243,6 +269,9 @@ class HipOps:
             y._rg_slabs = SlabRef(ws, ns, y.numel(), defer)
             self._slabs_pending = y
             return (y, None) if want_stats else y
+        if bn_bwd is not None and not want_stats and self._bn_bwd_fused(
+                0, y, wdn, x, (N, Hi // 2, Wi // 2, O, I), bn_bwd, 2.0 * N * (Hi // 2) * (Wi // 2) * O * I * 16):
+            return y
         st = self._stats_buf(0, N, Hi // 2, Wi // 2, O, I, O) if want_stats else None
         ws = self._ws(self.lib.rg_conv_workspace_bytes(0, N, Hi // 2, Wi // 2, O, I, self.dt, self.algo))
         self._timed("conv_fwd_dgrad", 2.0 * N * (Hi // 2) * (Wi // 2) * O * I * 16, lambda: check(
@@ -250,7 +279,7 @@ class HipOps:
                                   self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_down"))
         return (y, st) if want_stats else y
 
-    def conv_up(self, x, cw: ConvW, mask_act=None, slope=1.0, want_stats=False, defer=0):
+    def conv_up(self, x, cw: ConvW, mask_act=None, slope=1.0, want_stats=False, defer=0, bn_bwd=None):
         """Transposed conv; with mask_act (same shape as the result) the LeakyReLU backward
         ``y *= (mask_act > 0 ? 1 : slope)`` is applied in the kernel's epilogue.  want_stats, defer: as conv_down."""
         N, Ho, Wo, O = x.shape
@@ -268,6 +297,9 @@ class HipOps:
             y._rg_slabs = SlabRef(ws, ns, y.numel(), defer)
             self._slabs_pending = y
             return (y, None) if want_stats else y
+        if bn_bwd is not None and mask_act is None and not want_stats and self._bn_bwd_fused(
+                1, y, wup, x, (N, Ho, Wo, O, I), bn_bwd, 2.0 * N * Ho * Wo * O * I * 16):
+            return y
         assert mask_act is None or (mask_act.shape == y.shape and mask_act.dtype == y.dtype and mask_act.is_contiguous())
         st = self._stats_buf(1, N, Ho, Wo, O, I, I) if (want_stats and mask_act is None) else None
         ws = self._ws(self.lib.rg_conv_workspace_bytes(1, N, Ho, Wo, O, I, self.dt, self.algo))
@@ -780,6 +812,9 @@ class HipOps:
         sl = getattr(ga, "_rg_slabs", None)
         if sl is not None:
             return self._bn_act_bwd_slabs(z, ga, sl, 2, mean, invstd, gamma, beta, slope, dgamma, dbeta, accumulate, False)[0]
+        bp = getattr(ga, "_rg_bwd_partials", None)
+        if bp is not None and bp[2] == 2:
+            return self._bn_act_bwd_partials(z, ga, bp, 2, mean, invstd, gamma, beta, slope, dgamma, dbeta, accumulate)[0]
         gz = torch.empty_like(z)
         s_gy, s_gyxh = self._f32(2, C), self._f32(2, C)
         ws = self._ws(2 * self.lib.rg_colreduce_workspace_bytes(M, C, 2))
@@ -811,6 +846,20 @@ class HipOps:
         self._slabs_pending = None
         return gz, s_gy, s_gyxh
 
+    def _bn_act_bwd_partials(self, z, ga, bp, groups, mean, invstd, gamma, beta, slope, dgamma, dbeta, accumulate, out=None):
+        part, nblk, _ = bp
+        M2, C = self._mc(z)
+        M = M2 // groups
+        gz = out if out is not None else torch.empty_like(z)
+        s_gy, s_gyxh = (self._f32(C), self._f32(C)) if groups == 1 else (self._f32(groups, C), self._f32(groups, C))
+        ws = self._ws(groups * 32 * 2 * C * 4)
+        check(self.lib.rg_bn_act_bwd_partials(_ptr(part), part.shape[0] // groups, nblk, _ptr(z), _ptr(ga), _ptr(mean),
+                                              _ptr(invstd), _ptr(gamma), _ptr(beta), _ptr(gz), _ptr(s_gy), _ptr(s_gyxh),
+                                              _ptr(dgamma), _ptr(dbeta), int(accumulate), M, C, groups, float(slope), self.dt,
+                                              _ptr(ws), ws.numel(), self.stream), "rg_bn_act_bwd_partials")
+        del ga._rg_bwd_partials
+        return gz, s_gy, s_gyxh
+
     def bn_act_bwd(self, z, ga, mean, invstd, gamma, beta, slope: float, dgamma=None, dbeta=None,
                    accumulate: bool = False, out=None, keep_ga=True):
         """keep_ga: only meaningful when ga is still split-K slabs (conv_* with defer): also write the reduced ga tensor
@@ -820,6 +869,9 @@ class HipOps:
         if sl is not None:
             return self._bn_act_bwd_slabs(z, ga, sl, 1, mean, invstd, gamma, beta, slope, dgamma, dbeta, accumulate, keep_ga,
                                           out)
+        bp = getattr(ga, "_rg_bwd_partials", None)
+        if bp is not None and bp[2] == 1 and self.stat_reduce is None:
+            return self._bn_act_bwd_partials(z, ga, bp, 1, mean, invstd, gamma, beta, slope, dgamma, dbeta, accumulate, out)
         gz = out if out is not None else torch.empty_like(z)
         assert gz.shape == z.shape and gz.is_contiguous()
         s_gy, s_gyxh = self._f32(C), self._f32(C)

@@ -358,3 +358,66 @@ def test_split_k_conv_fused_into_batchnorm(I, O, hs, n, groups):
             assert relmax(gz_f.view(groups, -1, I)[h], ref) < 8e-3
     assert int(fu._sb_sync.abs().sum()) == int(fu._sb_sync[17::16].abs().sum()), "arrival counters / error word left at zero"
     assert int(fu._sb_sync[0]) == 0, "no hand-off timed out"
+
+
+@pytest.mark.parametrize("I,O,hs,n,groups", [(128, 256, 64, 64, 1), (256, 512, 32, 64, 1), (128, 256, 64, 128, 2),
+                                              (512, 1024, 16, 128, 2), (64, 128, 128, 64, 1)])
+def test_bn_backward_sums_in_conv_epilogue(I, O, hs, n, groups):
+    """Data-gradient convs that do not split K produce the BatchNorm-backward sums of the block they feed in their own
+    epilogue (rg_conv_up_bnbwd / rg_conv_down_bnbwd + rg_bn_act_bwd_partials) instead of a reduction pass over (z, ga).
+    Both conv directions against the separate-pass path of the same library: ga bit-identical, sums to fp32 round-off on the
+    scale of the summands, gz to one bf16 rounding, dgamma / dbeta accumulated alike; and gz against plain tensor arithmetic."""
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(900 + I + n)
+    fu, se = HipOps(torch.bfloat16, dev), HipOps(torch.bfloat16, dev)
+    se.bwd_epilogue = False
+    w = (torch.randn(O, 4, 4, I, generator=gen) * (2.0 / (I * 16)) ** 0.5).bfloat16().float().to(dev)
+    cws = [ConvW(w.clone(), None, torch.zeros_like(w), None, "OHWI") for _ in range(2)]
+    ho = hs // 2
+    for direction in ("up", "down"):
+        if direction == "up":       # nn.Conv2d's data gradient: g [n, ho, ho, O] -> ga [n, hs, hs, I], consumer block has I channels
+            src = torch.randn(n, ho, ho, O, generator=gen).bfloat16().to(dev)
+            C, shape = I, (n, hs, hs, I)
+        else:                        # nn.ConvTranspose2d's: x [n, hs, hs, I] -> ga [n, ho, ho, O]
+            src = torch.randn(n, hs, hs, I, generator=gen).bfloat16().to(dev)
+            C, shape = O, (n, ho, ho, O)
+        zb = (torch.randn(*shape, generator=gen) * 1.3 + 0.2).bfloat16().to(dev)
+        gam, bet = (1 + 0.1 * torch.randn(C, generator=gen)).to(dev), (0.1 * torch.randn(C, generator=gen)).to(dev)
+        res = []
+        for ops, cw in ((fu, cws[0]), (se, cws[1])):
+            if groups == 1:
+                _, mean, inv = ops.bn_forward(zb.clone(), gam, bet, 0.2, 1e-5, 0.1)
+            else:
+                _, mean, inv = ops.bn_forward2(zb.clone(), gam, bet, 0.2, 1e-5, 0.1)
+            bnb = (zb, mean, inv, gam, bet, 0.2, groups)
+            ga = ops.conv_up(src, cw, defer=groups, bn_bwd=bnb) if direction == "up" else ops.conv_down(src, cw, defer=groups, bn_bwd=bnb)
+            fused = getattr(ga, "_rg_bwd_partials", None) is not None
+            if ops is fu:
+                rows = fu.lib.rg_conv_bnbwd_rows(1 if direction == "up" else 0, n, ho, ho, O, I, groups, fu.dt, fu.algo)
+                split = fu.lib.rg_conv_split(1 if direction == "up" else 0, n, ho, ho, O, I, fu.dt, fu.algo) > 1
+                assert fused == (rows > 0 and not split), (direction, rows, split)
+            else:
+                assert not fused
+            dg, db = torch.full((C,), 2.0, device=dev), torch.full((C,), -1.0, device=dev)
+            if groups == 1:
+                gz, s1, s2 = ops.bn_act_bwd(zb, ga, mean, inv, gam, bet, 0.2, dg, db, True)
+            else:
+                gz, s1, s2 = ops.bn_act_bwd2(zb, ga, mean, inv, gam, bet, 0.2, dg, db, True), None, None
+            torch.cuda.synchronize()
+            assert getattr(ga, "_rg_bwd_partials", None) is None and getattr(ga, "_rg_slabs", None) is None
+            res.append((ga, gz, s1, s2, dg, db, mean, inv))
+        (ga_f, gz_f, s1_f, s2_f, dg_f, db_f, mean, inv), (ga_s, gz_s, s1_s, s2_s, dg_s, db_s, _, _) = res
+        assert torch.equal(ga_f.view(torch.int16), ga_s.view(torch.int16)), direction
+        rows_per_group = ga_s.numel() // C // groups
+        scale = float(ga_s.float().abs().mean()) * rows_per_group ** 0.5 + 1e-12        # |sum| of signed summands ~ sqrt(rows) |ga|
+        if groups == 1:
+            assert float((s1_f - s1_s).abs().max()) < 2e-4 * scale and float((s2_f - s2_s).abs().max()) < 4e-4 * scale, direction
+        assert float(((dg_f - 2.0) - (dg_s - 2.0)).abs().max()) < 8e-4 * scale and float(((db_f + 1.0) - (db_s + 1.0)).abs().max()) < 4e-4 * scale
+        assert relmax(gz_f, gz_s) < 8e-3 and float((gz_f.float() - gz_s.float()).abs().mean()) < 2e-5 * float(gz_s.float().abs().mean() + 1)
+        for h in range(groups):
+            zh, gah = zb.float().view(groups, -1, C)[h], ga_s.float().view(groups, -1, C)[h]
+            mu, rstd = mean.view(groups, C)[h], inv.view(groups, C)[h]
+            xh = (zh - mu) * rstd
+            gy = gah * torch.where(xh * gam + bet > 0, 1.0, 0.2)
+            ref = gam * rstd * (gy - gy.mean(0) - xh * (gy * xh).mean(0))
+            assert relmax(gz_f.view(groups, -1, C)[h], ref) < 8e-3, (direction, h)
