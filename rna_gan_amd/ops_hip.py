@@ -64,9 +64,11 @@ class HipOps:
         # split-K conv -> BatchNorm without the intermediate passes (rg_splitbn.hip): the conv leaves its slabs, the BatchNorm
         # kernel reduces them (RNAGAN_SPLIT_BN=0: conv + slab reduction + statistics + finisher + apply as separate launches)
         self.split_bn = os.environ.get("RNAGAN_SPLIT_BN", "1") != "0"
-        # data-gradient convs also produce the BatchNorm-backward sums of the block they feed (conv8 epilogue; RNAGAN_BWD_EPILOGUE=0:
-        # separate reduction pass over (z, ga))
-        self.bwd_epilogue = os.environ.get("RNAGAN_BWD_EPILOGUE", "1") != "0"
+        # data-gradient convs can also produce the BatchNorm-backward sums of the block they feed in their epilogue
+        # (rg_conv_*_bnbwd).  Built, exact, and NOT faster: the extra z read lands in the conv's tail, where every workgroup of
+        # the chip is in its epilogue at once (11.95-12.09 ms with the separate reduction pass vs 12.03-12.07 ms with the
+        # fused form, same box; the conv family drops from 0.408 to 0.382 of peak) -- off by default, RNAGAN_BWD_EPILOGUE=1
+        self.bwd_epilogue = os.environ.get("RNAGAN_BWD_EPILOGUE", "0") != "0"
         self._slabs_pending = None    # the tensor whose deferred split-K slabs currently occupy the workspace
         self._sb_sync = None          # hand-off words of the fused kernels: zeroed once, left zero by every launch
         self._sb_scratch = None

@@ -370,7 +370,8 @@ def test_bn_backward_sums_in_conv_epilogue(I, O, hs, n, groups):
     dev = torch.device("cuda:0")
     gen = torch.Generator(device="cpu").manual_seed(900 + I + n)
     fu, se = HipOps(torch.bfloat16, dev), HipOps(torch.bfloat16, dev)
-    se.bwd_epilogue = False
+    fu.bwd_epilogue, se.bwd_epilogue = True, False          # (opt-in: measured no faster than the separate pass, see ops_hip)
+    se.split_bn = False                                     # reference side: conv, slab reduction, reduce, finish, apply
     w = (torch.randn(O, 4, 4, I, generator=gen) * (2.0 / (I * 16)) ** 0.5).bfloat16().float().to(dev)
     cws = [ConvW(w.clone(), None, torch.zeros_like(w), None, "OHWI") for _ in range(2)]
     ho = hs // 2
@@ -407,7 +408,10 @@ def test_bn_backward_sums_in_conv_epilogue(I, O, hs, n, groups):
             assert getattr(ga, "_rg_bwd_partials", None) is None and getattr(ga, "_rg_slabs", None) is None
             res.append((ga, gz, s1, s2, dg, db, mean, inv))
         (ga_f, gz_f, s1_f, s2_f, dg_f, db_f, mean, inv), (ga_s, gz_s, s1_s, s2_s, dg_s, db_s, _, _) = res
-        assert torch.equal(ga_f.view(torch.int16), ga_s.view(torch.int16)), direction
+        if getattr(fu, "_last_ga_written", True) and not (groups == 2 and fu.lib.rg_conv_split(
+                1 if direction == "up" else 0, n, ho, ho, O, I, fu.dt, fu.algo) > 1):
+            # (a double-batch split-K launch hands its slabs to the fused BatchNorm kernel, which does not write ga)
+            assert torch.equal(ga_f.view(torch.int16), ga_s.view(torch.int16)), direction
         rows_per_group = ga_s.numel() // C // groups
         scale = float(ga_s.float().abs().mean()) * rows_per_group ** 0.5 + 1e-12        # |sum| of signed summands ~ sqrt(rows) |ga|
         if groups == 1:
