@@ -39,10 +39,19 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 // (BASELINE configs[4]): the same 128-byte LDS rows hold a 128-deep k-tile, fragments are 64-bit
 // (v_mfma_f32_16x16x32_fp8_fp8, 32 per phase), fp32 accumulate; the epilogue applies the folded BatchNorm affine and
 // LeakyReLU (the affine also carries the per-column weight scale) and writes bf16 or fp8 (a2.g.out_fp8).
-template <int MODE, int WM, int WN, int MF, int EB = 2>
+// MXF (fp8 only): the MX-format matrix instruction v_mfma_scale_f32_16x16x128_f8f6f4 -- one MFMA per 128-deep k-tile and
+// accumulator tile at TWICE the per-clock rate of the non-scaled fp8 / bf16 forms (MI355X_MICROARCH, matrix cores) -- with
+// UNIT block scales (E8M0 127 = 2^0 on both operands): the per-output-channel weight scales of the fp8 path stay in the
+// epilogue, so the numbers are those of the non-scaled fp8 kernel up to the fp32 summation order.  The operand of a lane is
+// 32 bytes: the two 16-byte chunks (fh, 4 + fh) of its row, i.e. exactly the two conflict-free ds_read_b128 of the bf16
+// path; which k positions a lane's bytes stand for does not matter as long as A and B agree (both are read the same way).
+typedef int c8_v8i_t __attribute__((ext_vector_type(8)));
+template <int MODE, int WM, int WN, int MF, int EB = 2, int MXF = 0>
 __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
   static_assert(WM * WN == 8, "8 waves");
   static_assert(EB == 2 || (EB == 1 && MF == 16), "fp8 operands use the 16x16x32 MFMA");
+  static_assert(MXF == 0 || EB == 1, "the MX-format MFMA takes fp8 operands");
+  constexpr bool Q8 = EB == 1 && MXF == 0;                   // non-scaled fp8: 64-bit fragments, 4 k-steps of 32
   constexpr int KD = 128 / EB;                               // k-tile depth in elements
   constexpr int LGKD = EB == 2 ? 6 : 7;
   constexpr int BM = WM * 128, BN = WN * 64;
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
   // 32x32x16: lane = (row fr of 32, k-half fh), chunk(kk) = 2kk + fh, kk < 4.   16x16x32: lane = (row fr of 16, k-quarter
   // fh), chunk(kk) = 4kk + fh, kk < 2.  The XOR swizzle (row>>1)&7 is the same for every sub-tile of a wave (16 | 32 rows apart).
   constexpr int FRW = MF == 32 ? 32 : 16;            // rows per MFMA tile
-  constexpr int NKK = EB == 1 ? 4 : (MF == 32 ? 4 : 2);   // k-steps per k-tile (fp8: 4 steps of 32)
+  constexpr int NKK = Q8 ? 4 : (MF == 32 ? 4 : 2);   // k-steps per k-tile (fp8: 4 steps of 32; MX: two 16-byte reads, one MFMA)
   constexpr int NAT = 64 / FRW, NBT = 32 / FRW;      // A row sub-tiles / B column sub-tiles per quadrant
   const int fr = lane & (FRW - 1), fh = lane / FRW;
   const unsigned lds_base = (unsigned)(size_t)(lds_vptr_t)lds;
@@ -210,9 +219,9 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
 #pragma unroll
   for (int kk = 0; kk < NKK; ++kk) {
     // bf16: lane's 16-byte chunk of the 128-byte row; fp8: 8 bytes (fh & 1) of chunk 2 kk + (fh >> 1)
-    const unsigned ch = EB == 1 ? (unsigned)((2 * kk + (fh >> 1)) ^ ((fr >> 1) & 7))
+    const unsigned ch = Q8 ? (unsigned)((2 * kk + (fh >> 1)) ^ ((fr >> 1) & 7))
                                 : (unsigned)(((64 / FRW) * kk + fh) ^ ((fr >> 1) & 7));
-    const unsigned sub = EB == 1 ? 8u * (unsigned)(fh & 1) : 0u;
+    const unsigned sub = Q8 ? 8u * (unsigned)(fh & 1) : 0u;
     aB[0][kk] = lds_base + OFF_A + 16u * (unsigned)((wm * 64 + fr) * 8 + ch) + sub;
     bB[0][kk] = lds_base + OFF_B + 16u * (unsigned)((wn * 32 + fr) * 8 + ch) + sub;
     aB[1][kk] = aB[0][kk] + STAGE;
@@ -245,20 +254,20 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
 #define C8_READ_A(S, H)                                                                     \
   do {                                                                                      \
     _Pragma("unroll") for (int t_ = 0; t_ < NAT; ++t_) _Pragma("unroll") for (int kk_ = 0; kk_ < NKK; ++kk_) { \
-      if constexpr (EB == 1) C8_DSR8(aQ[t_ * NKK + kk_], aB[S][kk_], (H) * AH + t_ * FRW * 128); \
+      if constexpr (Q8) C8_DSR8(aQ[t_ * NKK + kk_], aB[S][kk_], (H) * AH + t_ * FRW * 128); \
       else C8_DSR(aR[(t_ * NKK + kk_) & 7], aB[S][kk_], (H) * AH + t_ * FRW * 128);         \
     }                                                                                       \
   } while (0)
 #define C8_READ_B(S, H, SET)                                                                \
   do {                                                                                      \
     _Pragma("unroll") for (int t_ = 0; t_ < NBT; ++t_) _Pragma("unroll") for (int kk_ = 0; kk_ < NKK; ++kk_) { \
-      if constexpr (EB == 1) C8_DSR8(bQ[SET][t_ * NKK + kk_], bB[S][kk_], (H) * BH + t_ * FRW * 128); \
+      if constexpr (Q8) C8_DSR8(bQ[SET][t_ * NKK + kk_], bB[S][kk_], (H) * BH + t_ * FRW * 128); \
       else C8_DSR(bS[SET][(t_ * NKK + kk_) & 3], bB[S][kk_], (H) * BH + t_ * FRW * 128);    \
     }                                                                                       \
   } while (0)
 #define C8_WAIT_A()                                                                                            \
   do {                                                                                                         \
-    if constexpr (EB == 1)                                                                                     \
+    if constexpr (Q8)                                                                                          \
       asm volatile("s_waitcnt lgkmcnt(0)"                                                                      \
                    : "+v"(aQ[0]), "+v"(aQ[1]), "+v"(aQ[2]), "+v"(aQ[3]), "+v"(aQ[4]), "+v"(aQ[5]), "+v"(aQ[6]), \
                      "+v"(aQ[7]), "+v"(aQ[8]), "+v"(aQ[9]), "+v"(aQ[10]), "+v"(aQ[11]), "+v"(aQ[12]),          \
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
   } while (0)
 #define C8_WAIT_B(SET)                                                                                         \
   do {                                                                                                         \
-    if constexpr (EB == 1)                                                                                     \
+    if constexpr (Q8)                                                                                          \
       asm volatile("s_waitcnt lgkmcnt(0)"                                                                      \
                    : "+v"(bQ[SET][0]), "+v"(bQ[SET][1]), "+v"(bQ[SET][2]), "+v"(bQ[SET][3]), "+v"(bQ[SET][4]), \
                      "+v"(bQ[SET][5]), "+v"(bQ[SET][6]), "+v"(bQ[SET][7])::"memory");                          \
@@ -289,7 +298,16 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
     if (C8_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(1);                                                      \
     _Pragma("unroll") for (int kk_ = 0; kk_ < NKK; ++kk_) _Pragma("unroll") for (int t_ = 0; t_ < NAT; ++t_)   \
     _Pragma("unroll") for (int c_ = 0; c_ < NBT; ++c_) {                                                       \
-      if constexpr (EB == 1)                                                                                   \
+      if constexpr (MXF == 1) {                                                                                \
+        if (kk_ == 0) {                                                                                        \
+          const u32x4_t a0_ = aR[(t_ * NKK) & 7], a1_ = aR[(t_ * NKK + 1) & 7];                                \
+          const u32x4_t b0_ = bS[SET][(c_ * NKK) & 3], b1_ = bS[SET][(c_ * NKK + 1) & 3];                      \
+          const c8_v8i_t av_ = {(int)a0_.x, (int)a0_.y, (int)a0_.z, (int)a0_.w, (int)a1_.x, (int)a1_.y, (int)a1_.z, (int)a1_.w}; \
+          const c8_v8i_t bv_ = {(int)b0_.x, (int)b0_.y, (int)b0_.z, (int)b0_.w, (int)b1_.x, (int)b1_.y, (int)b1_.z, (int)b1_.w}; \
+          acc[I][J][t_ * NBT + c_] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                         \
+              av_, bv_, acc[I][J][t_ * NBT + c_], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);                         \
+        }                                                                                                      \
+      } else if constexpr (EB == 1)                                                                            \
         acc[I][J][t_ * NBT + c_] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(                                 \
             __builtin_bit_cast(long, aQ[t_ * NKK + kk_]), __builtin_bit_cast(long, bQ[SET][c_ * NKK + kk_]),   \
             acc[I][J][t_ * NBT + c_], 0, 0, 0);                                                                \
@@ -906,6 +924,17 @@ int rg_conv8_launch(int mode, const void* args, int bm, unsigned gx, unsigned gy
   const G2Args& a2 = *reinterpret_cast<const G2Args*>(args);
   const dim3 grid(gx, gy, gz), block(512);
   if (a2.g.in_fp8) {                    // fp8 operands (generator-only inference): transposed conv and plain GEMM
+    // fp8_mx (default 1): the MX-format MFMA with unit block scales (2x the matrix rate); 0: v_mfma_f32_16x16x32_fp8_fp8
+    if (rg_option("fp8_mx", 1)) {
+      if (bm == 256) {
+        if (mode == MODE_UP) hipLaunchKernelGGL((conv8_kernel<MODE_UP, 2, 4, 16, 1, 1>), grid, block, 0, st, a2);
+        else hipLaunchKernelGGL((conv8_kernel<MODE_PLAIN, 2, 4, 16, 1, 1>), grid, block, 0, st, a2);
+      } else {
+        if (mode == MODE_UP) hipLaunchKernelGGL((conv8_kernel<MODE_UP, 4, 2, 16, 1, 1>), grid, block, 0, st, a2);
+        else hipLaunchKernelGGL((conv8_kernel<MODE_PLAIN, 4, 2, 16, 1, 1>), grid, block, 0, st, a2);
+      }
+      return RG_OK;
+    }
     if (bm == 256) {
       if (mode == MODE_UP) hipLaunchKernelGGL((conv8_kernel<MODE_UP, 2, 4, 16, 1>), grid, block, 0, st, a2);
       else hipLaunchKernelGGL((conv8_kernel<MODE_PLAIN, 2, 4, 16, 1>), grid, block, 0, st, a2);

@@ -517,14 +517,27 @@ def test_fp8_selftest_and_cast():
     assert torch.equal(_fp8_decode(q), want)
 
 
+@pytest.mark.parametrize("mx", [1, 0])
 @pytest.mark.parametrize("N,Ho,O,I,out_fp8", [(2, 16, 128, 128, False), (3, 16, 256, 256, True), (1, 32, 128, 256, False),
                                               (5, 8, 512, 128, True)])
-def test_fp8_conv_up_and_gemm(N, Ho, O, I, out_fp8):
+def test_fp8_conv_up_and_gemm(N, Ho, O, I, out_fp8, mx):
     """fp8 operand kernels (conv8_kernel<.., EB = 1>) against fp32 torch arithmetic on the DEQUANTISED fp8 operands:
     transposed conv (all four parity classes, ragged row tiles) and the plain GEMM of the generator's first layer, with the
-    affine + LeakyReLU epilogue and bf16 / fp8 output."""
+    affine + LeakyReLU epilogue and bf16 / fp8 output.  mx = 1: the MX-format matrix instruction
+    (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales: same products, 2x the matrix rate); mx = 0:
+    v_mfma_f32_16x16x32_fp8_fp8."""
     import torch.nn.functional as F
     hip = _hip(torch.bfloat16)
+    from rna_gan_amd import _abi
+    _abi.check(hip.lib.rg_set_option(b"fp8_mx", mx), "rg_set_option")
+    try:
+        _fp8_conv_up_and_gemm_body(hip, N, Ho, O, I, out_fp8)
+    finally:
+        _abi.check(hip.lib.rg_set_option(b"fp8_mx", -1), "rg_set_option")
+
+
+def _fp8_conv_up_and_gemm_body(hip, N, Ho, O, I, out_fp8):
+    import torch.nn.functional as F
     w = rnd((O, I, 4, 4), 1, (2.0 / (I * 16)) ** 0.5)
     _, ch = cwpair_tm(w)
     x8 = hip.cast_fp8(rnd((N, Ho, Ho, O), 2).cuda())
