@@ -776,10 +776,11 @@ class HipOps:
         a = out if out is not None else torch.empty_like(z)
         assert a.shape == z.shape and a.is_contiguous()
         scratch, sync = self._sb_bufs(M, C, groups)
-        check(self.lib.rg_bn_forward_slabs(_ptr(sl.ws), sl.nsplit, sl.stride, _ptr(z), _ptr(a), M, C, groups, float(eps),
-                                           float(momentum), _ptr(gamma), _ptr(beta), float(slope), _ptr(mean), _ptr(invstd),
-                                           _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(scratch), scratch.numel(),
-                                           _ptr(sync), self.stream), "rg_bn_forward_slabs")
+        self._timed("bn_split_fused", 0.0, lambda: check(
+            self.lib.rg_bn_forward_slabs(_ptr(sl.ws), sl.nsplit, sl.stride, _ptr(z), _ptr(a), M, C, groups, float(eps),
+                                         float(momentum), _ptr(gamma), _ptr(beta), float(slope), _ptr(mean), _ptr(invstd),
+                                         _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(scratch), scratch.numel(),
+                                         _ptr(sync), self.stream), "rg_bn_forward_slabs"))
         del z._rg_slabs                       # z is an ordinary tensor from here on
         self._slabs_pending = None
         return a, mean, invstd
@@ -840,10 +841,11 @@ class HipOps:
         gz = out if out is not None else torch.empty_like(z)
         s_gy, s_gyxh = (self._f32(C), self._f32(C)) if groups == 1 else (self._f32(groups, C), self._f32(groups, C))
         scratch, sync = self._sb_bufs(M, C, groups)
-        check(self.lib.rg_bn_act_bwd_slabs(_ptr(sl.ws), sl.nsplit, sl.stride, _ptr(z), _ptr(ga) if keep_ga else 0, _ptr(gz), M,
-                                           C, groups, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), float(slope),
-                                           _ptr(s_gy), _ptr(s_gyxh), _ptr(dgamma), _ptr(dbeta), int(accumulate), _ptr(scratch),
-                                           scratch.numel(), _ptr(sync), self.stream), "rg_bn_act_bwd_slabs")
+        self._timed("bn_split_fused", 0.0, lambda: check(
+            self.lib.rg_bn_act_bwd_slabs(_ptr(sl.ws), sl.nsplit, sl.stride, _ptr(z), _ptr(ga) if keep_ga else 0, _ptr(gz), M,
+                                         C, groups, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), float(slope),
+                                         _ptr(s_gy), _ptr(s_gyxh), _ptr(dgamma), _ptr(dbeta), int(accumulate), _ptr(scratch),
+                                         scratch.numel(), _ptr(sync), self.stream), "rg_bn_act_bwd_slabs"))
         del ga._rg_slabs                     # (ga itself is written only with keep_ga)
         self._slabs_pending = None
         return gz, s_gy, s_gyxh
@@ -905,9 +907,10 @@ class HipOps:
         if sl is not None:                    # zt is still split-K slabs: reduce + tangent sums + apply in one launch
             assert sl.groups == 1 and zt.shape == z.shape
             scratch, sync = self._sb_bufs(M, C, 1)
-            check(self.lib.rg_bn_tangent_slabs(_ptr(sl.ws), sl.nsplit, sl.stride, _ptr(z), _ptr(zt), _ptr(at), M, C, _ptr(mean),
-                                               _ptr(invstd), _ptr(gamma), _ptr(beta), float(slope), _ptr(s_zt), _ptr(s_xhzt),
-                                               _ptr(scratch), scratch.numel(), _ptr(sync), self.stream), "rg_bn_tangent_slabs")
+            self._timed("bn_split_fused", 0.0, lambda: check(
+                self.lib.rg_bn_tangent_slabs(_ptr(sl.ws), sl.nsplit, sl.stride, _ptr(z), _ptr(zt), _ptr(at), M, C, _ptr(mean),
+                                             _ptr(invstd), _ptr(gamma), _ptr(beta), float(slope), _ptr(s_zt), _ptr(s_xhzt),
+                                             _ptr(scratch), scratch.numel(), _ptr(sync), self.stream), "rg_bn_tangent_slabs"))
             del zt._rg_slabs
             self._slabs_pending = None
             return at, s_zt, s_xhzt

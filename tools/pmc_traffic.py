@@ -18,6 +18,7 @@ def load(d, counter):
                "wgrad_dma" if ("wgrad_dma" in n or "wgrad8_kernel" in n) else
                "first_down" if "first_down" in n else "last_up" if "last_up" in n else
                "skinny_wgrad" if "skinny_wgrad" in n else "adam" if ("AdamDev" in n or "adam_dev_kernel" in n) else
+               "bn_split_fused" if "slab_bn_" in n else
                "bn_apply" if "rowapply_kernel" in n else "bn_reduce" if "rowreduce_kernel" in n else None)
         if fam is None:
             continue
