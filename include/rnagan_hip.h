@@ -247,6 +247,17 @@ int rg_bn_act_bwd(const void* z, const void* ga, const float* mean, const float*
 int rg_bn_finalize_partials(const float* partial, int G, int M, int C, float eps, float momentum, float* mean,
                             float* invstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, void* ws,
                             size_t ws_bytes, void* stream);
+/* ---- generator layer 0: weight gradient + optimizer step in one pass --------------------------------------------------
+ * rg_g0_wgrad (.backward() into nn.ConvTranspose2d(E, C, 4, 1, 0).weight, src/wgan_loss.py:126) followed by the Adam step
+ * on that tensor (optimizer_generator.step(), :127) as ONE streaming kernel: the gradient dw[e][c][tap] = sum_n z[n][e] *
+ * gz0[n][tap][c] (K = the batch) is formed in registers and torch.optim.Adam's update applied in place to p / m / v
+ * ([E][C][4][4] fp32, 16-byte aligned), `hyper` = the 8 floats of rg_adam_hyper_dev, shadow_bf16 (may be NULL) = the bf16
+ * image of p that rg_adam_step_dev keeps.  26 B per parameter instead of 4 (gradient written) + 30.  Single-process runs
+ * only: a data-parallel step needs the gradient in memory for its all-reduce.  dtype = element type of gz0. */
+int rg_g0_wgrad_adam_supported(int N, int E, int C, int dtype);
+int rg_g0_wgrad_adam(const float* z, const void* gz0, float* p, float* m, float* v, const float* hyper, void* shadow_bf16,
+                     int N, int E, int C, int dtype, void* stream);
+
 /* ---- Inception-v3 feature extractor of the FID metric (src/fid.py:33-94: torchvision inception_v3 up to Mixed_7c) --------
  * NHWC fp32.  A BasicConv2d (Conv2d(bias=False) + BatchNorm2d(eval, eps 1e-3) + ReLU) = rg_im2col_nhwc (not needed for 1x1
  * stride 1) + rg_linear_affine_act with the folded BatchNorm affine and slope 0; ldx / ldy are row strides in elements, so a

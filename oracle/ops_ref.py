@@ -160,6 +160,9 @@ class RefOps:
         y = torch.einsum("ne,ecij->nijc", z.to(self.f), self._wq(cw.w))
         return y.contiguous().to(self.act_dtype)
 
+    def g0_wgrad_deferred(self, z, gy, cw, accumulate: bool):
+        return False          # (HIP backend: the weight gradient of G.0 can be formed inside the fused optimizer step)
+
     def g0_wgrad(self, z, gy, dw, accumulate: bool):
         g = torch.einsum("ne,nijc->ecij", z.to(self.f), gy.to(self.f))
         if accumulate:

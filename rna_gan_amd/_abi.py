@@ -122,6 +122,8 @@ PROTOTYPES = {
     "rg_fp8_supported": (_i, [_i, _i, _i, _i]),
     "rg_cast_fp8": (_i, [_p, _p, _z, _f, _p]),
     "rg_selftest_fp8": (_i, [_p, _p]),
+    "rg_g0_wgrad_adam_supported": (_i, [_i, _i, _i, _i]),
+    "rg_g0_wgrad_adam": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "rg_im2col_nhwc": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "rg_pool2d_nhwc": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "rg_nchw_to_nhwc_affine": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p]),
@@ -146,7 +148,7 @@ PROTOTYPES = {
 }
 
 # must equal rg_version() of the library (rna_gan_amd/csrc/rg_api.hip): bumped together with PROTOTYPES
-ABI_VERSION = 304
+ABI_VERSION = 305
 
 _lib = None
 

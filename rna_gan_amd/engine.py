@@ -44,7 +44,7 @@ class ConvW:
     """
 
     __slots__ = ("w", "bias", "dw", "dbias", "packs", "packs_version", "version", "layout", "shadow",
-                 "shadow_version", "_fp8")
+                 "shadow_version", "_fp8", "fuse_step", "pending_wgrad")
 
     def __init__(self, w, bias=None, dw=None, dbias=None, layout="OIHW"):
         self.w = w
@@ -58,6 +58,11 @@ class ConvW:
         self.shadow = None            # bf16 [O][16][I] image of a tap-major master maintained by the fused Adam
         self.shadow_version = -1      # master version the shadow reflects
         self._fp8 = None              # backend-private fp8 inference image (key, bytes, column scales)
+        # generator layer 0 only (HIP backend): fuse_step -- set by the train_op runner for the duration of one gradient pass
+        # whose optimizer step follows immediately -- lets g0_wgrad leave its operands in pending_wgrad instead of writing dw;
+        # the fused Adam then forms the gradient and applies the step in one kernel (rg_g0_wgrad_adam)
+        self.fuse_step = False
+        self.pending_wgrad = None
 
     @classmethod
     def from_param(cls, weight, grad=None):
@@ -484,7 +489,8 @@ def gen_backward(ops, G: GenNet, ctx, gimg, accumulate: bool, need_input_grad: b
         ga = ops.conv_down(gz, cw, defer=1, bn_bwd=nxt)
     gz0, _, _ = ops.bn_act_bwd(ctx.z[0], ga, ctx.mean[0], ctx.invstd[0], G.bn0.gamma, G.bn0.beta,
                                G.slope, G.bn0.dgamma, G.bn0.dbeta, accumulate, keep_ga=False)
-    ops.g0_wgrad(ctx.noise, gz0, G.g0.dw, accumulate)
+    if not ops.g0_wgrad_deferred(ctx.noise, gz0, G.g0, accumulate):
+        ops.g0_wgrad(ctx.noise, gz0, G.g0.dw, accumulate)
     gin = ops.g0_bwd_data(gz0, G.g0) if need_input_grad else None
     ops.join()
     return gin

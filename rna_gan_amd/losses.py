@@ -341,10 +341,32 @@ def _dispatch(runner, key, body, inputs, generator, discriminator, stepped, opti
         return runner.run_dp(key, body, inputs, mods, stepped, optimizer)
 
     def full(*a):
-        loss = body.grads(*a)
+        g0 = _fusable_g0(stepped, optimizer)
+        if g0 is not None:
+            g0.fuse_step = True          # this gradient pass is followed at once by optimizer.step(): see ConvW.fuse_step
+        try:
+            loss = body.grads(*a)
+        finally:
+            if g0 is not None:
+                g0.fuse_step = False
         _finish(stepped, optimizer)
         return loss
     return runner.run(key, full, inputs, mods, [optimizer])
+
+
+G0_ADAM = os.environ.get("RNAGAN_G0_ADAM", "1") != "0"
+
+
+def _fusable_g0(stepped, optimizer):
+    """The stepped module's layer-0 weight handle if its gradient may be formed inside the fused optimizer step: the
+    generator (DCGAN recipe), stepped by rna_gan_amd.optim.Adam bound to it, bf16 kernels, single process."""
+    if not G0_ADAM or D_.active() or not hasattr(optimizer, "note_replayed") or getattr(optimizer, "_module", None) is not stepped:
+        return None
+    ops, net = stepped.runtime()
+    g0 = getattr(net, "g0", None)
+    if g0 is None or not isinstance(net, E.GenNet) or ops.act_dtype != torch.bfloat16:
+        return None
+    return g0
 
 
 # D-loss step of a single process: D(real) and D(fake) as one double batch (RNAGAN_D_BATCHED=0: two forward / backward chains)

@@ -649,6 +649,19 @@ class HipOps:
                                  ws.numel(), self.stream), "rg_g0_fwd")
         return y
 
+    def g0_wgrad_deferred(self, z, gy, cw: ConvW, accumulate: bool):
+        """Generator layer 0's weight gradient when the optimizer step follows immediately (cw.fuse_step, set by the train_op
+        runner): nothing is computed here -- the operands are left on the handle and rna_gan_amd.optim.Adam forms the
+        gradient inside its fused step for this tensor (rg_g0_wgrad_adam).  False: compute dw now (g0_wgrad)."""
+        if not cw.fuse_step or accumulate or self.stat_reduce is not None:
+            return False
+        N, E = z.shape
+        C = gy.shape[3]
+        if not self.lib.rg_g0_wgrad_adam_supported(N, E, C, self.dt) or not z.is_contiguous() or not gy.is_contiguous():
+            return False
+        cw.pending_wgrad = (z, gy, self.dt)
+        return True
+
     def g0_wgrad(self, z, gy, dw, accumulate: bool):
         N, E = z.shape
         C = gy.shape[3]

@@ -132,10 +132,29 @@ class Adam(torch.optim.Adam):
                                     self._hyper.data_ptr(), stream),
               "rg_adam_hyper_dev")
         shadow = flat.shadow           # bf16 image of the parameters (bf16 precision only), written by the same launch
-        check(lib.rg_adam_step_dev(flat.data.data_ptr(), flat.grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(),
-                                   flat.data.numel(), self._hyper.data_ptr(),
-                                   0 if shadow is None else shadow.data_ptr(),
-                                   0 if self.grad_wire is None else self.grad_wire.data_ptr(), stream),
+        lo = 0
+        g0 = getattr(getattr(self._module, "_rt_net", None), "g0", None)
+        pend = None if g0 is None else g0.pending_wgrad
+        if pend is not None:
+            # generator layer 0 (60 % of the generator's parameters): its weight gradient was NOT written -- form it and apply
+            # the step in one streaming kernel (26 B per parameter instead of 4 + 30), then step the rest of the buffer
+            g0.pending_wgrad = None
+            z, gy, dt = pend
+            off = (g0.w.data_ptr() - flat.data.data_ptr()) // 4
+            n0 = g0.w.numel()
+            if off != 0 or self.grad_wire is not None:
+                raise RuntimeError("rna_gan_amd.optim.Adam: the deferred G.0 weight gradient expects that tensor at the head "
+                                   "of the flat buffer and a single-process step")
+            E, C = g0.w.shape[0], g0.w.shape[1]
+            check(lib.rg_g0_wgrad_adam(z.data_ptr(), gy.data_ptr(), flat.data.data_ptr(), self._m.data_ptr(),
+                                       self._v.data_ptr(), self._hyper.data_ptr(), 0 if shadow is None else shadow.data_ptr(),
+                                       z.shape[0], E, C, dt, stream), "rg_g0_wgrad_adam")
+            lo = n0
+        nrest = flat.data.numel() - lo
+        check(lib.rg_adam_step_dev(flat.data.data_ptr() + 4 * lo, flat.grad.data_ptr() + 4 * lo, self._m.data_ptr() + 4 * lo,
+                                   self._v.data_ptr() + 4 * lo, nrest, self._hyper.data_ptr(),
+                                   0 if shadow is None else shadow.data_ptr() + 2 * lo,
+                                   0 if self.grad_wire is None else self.grad_wire.data_ptr() + 2 * lo, stream),
               "rg_adam_step_dev")
         if not torch.cuda.is_current_stream_capturing():
             self._host_steps += 1

@@ -522,3 +522,46 @@ def test_generator_forward_pair_on_gpu(in_size, n):
                                                                                           float((a - b).abs().max()))
     for k in res[0][1]:
         assert torch.allclose(res[0][1][k], res[1][1][k], rtol=2e-3, atol=1e-4), k
+
+
+@pytest.mark.parametrize("in_size,enc,n", [(32, 128, 16), (64, 512, 64), (32, 128, 80)])
+def test_generator_layer0_gradient_inside_the_adam_step(in_size, enc, n):
+    """G.0's weight gradient formed inside the fused optimizer step (rg_g0_wgrad_adam: gradient in registers + Adam in one
+    streaming pass, no dw round trip) against the two-kernel form (rg_g0_wgrad, rg_adam_step_dev) for three consecutive
+    generator-loss train_ops: same losses, same parameters / Adam moments to fp32 round-off of a differently ordered 64-term
+    sum, bf16 shadow consistent with the master.  n = 80: a ragged second 64-sample chunk."""
+    step = 64
+    G0 = R.seeded_fill_(R.OracleDCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                               last_nonlinearity=nn.Tanh()), 7)
+    D0 = R.seeded_fill_(R.OracleDCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                                   last_nonlinearity=nn.LeakyReLU(0.2)), 8)
+    res = []
+    keep = PL.G0_ADAM
+    try:
+        for fused in (True, False):
+            PL.G0_ADAM = fused
+            G, D, og, od = product_pair(in_size, step, enc, "bf16", G0, D0)
+            lg = PL.WassersteinGeneratorLoss()
+            losses = []
+            for it in range(3):
+                losses.append(lg.step(G, D, og, R.synthetic_normal(n, enc, seed=50 + it).cuda()).item())
+            torch.cuda.synchronize()
+            _, net = G.runtime()
+            assert net.g0.pending_wgrad is None and not net.g0.fuse_step
+            st = og.state_dict()["state"][0]
+            res.append((losses, G.model[0][0].weight.detach().float().cpu().clone(), st["exp_avg"].float().cpu().clone(),
+                        st["exp_avg_sq"].float().cpu().clone(), G.flat.shadow[:G.model[0][0].weight.numel()].float().cpu().clone(),
+                        {k: v.detach().float().cpu().clone() for k, v in G.state_dict().items()}))
+    finally:
+        PL.G0_ADAM = keep
+    (la, wa, ma, va, sa, sda), (lb, wb, mb, vb, sb, sdb) = res
+    w0 = G0.model[0][0].weight.detach()
+    assert max(abs(x - y) / (abs(y) + 0.1) for x, y in zip(la, lb)) < 2e-3, (la, lb)
+    du_a, du_b = wa - w0, wb - w0
+    cos = float((du_a * du_b).sum() / (du_a.norm() * du_b.norm()))
+    assert cos > 0.999, cos                                   # three sign-like Adam steps: the updates coincide
+    assert float((ma - mb).norm() / mb.norm()) < 2e-3 and float((va - vb).norm() / vb.norm()) < 4e-3
+    assert torch.equal(sa, wa.bfloat16().float())             # the bf16 shadow IS the rounded master
+    for k in sda:                                             # everything else of the generator went through the usual kernels
+        if k != "model.0.0.weight" and sda[k].dtype.is_floating_point:
+            assert float((sda[k] - sdb[k]).abs().max()) <= 5e-3 * float(sdb[k].abs().max() + 1e-6) + 2e-4, k
