@@ -90,6 +90,7 @@ def lz4f_decompress(data: bytes) -> bytes:
             continue
         if magic != LZ4F_MAGIC:
             raise ValueError("lz4f: bad magic 0x%08x" % magic)
+        desc_start = pos
         flg, bd = data[pos], data[pos + 1]; pos += 2
         if (flg >> 6) != 1:
             raise ValueError("lz4f: unsupported version")
@@ -103,7 +104,9 @@ def lz4f_decompress(data: bytes) -> bytes:
             content_size, = struct.unpack_from("<Q", data, pos); pos += 8
         if has_dict:
             pos += 4
-        pos += 1                                                  # header checksum byte (not verified)
+        if pos >= n or data[pos] != (_xxh32(data[desc_start:pos]) >> 8) & 0xFF:   # liblz4 rejects the frame as well
+            raise ValueError("lz4f: frame header checksum mismatch")
+        pos += 1
         frame_start = len(out)
         while True:
             bsz, = struct.unpack_from("<I", data, pos); pos += 4
@@ -116,6 +119,8 @@ def lz4f_decompress(data: bytes) -> bytes:
                 raise ValueError("lz4f: truncated block")
             pos += bsz
             if block_csum:
+                if n - pos < 4 or struct.unpack_from("<I", data, pos)[0] != _xxh32(blk):
+                    raise ValueError("lz4f: block checksum mismatch")
                 pos += 4
             if stored:
                 out += blk
@@ -123,6 +128,8 @@ def lz4f_decompress(data: bytes) -> bytes:
                 prefix = b"" if independent else bytes(out[max(frame_start, len(out) - 65536):])
                 out += lz4_block_decompress(blk, prefix, max_block)
         if content_csum:
+            if n - pos < 4 or struct.unpack_from("<I", data, pos)[0] != _xxh32(bytes(out[frame_start:])):
+                raise ValueError("lz4f: content checksum mismatch")
             pos += 4
         if content_size is not None and len(out) - frame_start != content_size:
             raise ValueError("lz4f: content size mismatch")
@@ -205,10 +212,14 @@ def lz4_block_compress(src: bytes) -> bytes:
 
 
 def lz4f_compress(data: bytes, block_size: int = 1 << 16) -> bytes:
-    """bytes -> LZ4 frame (independent 64 KB blocks, no checksums besides the mandatory header byte, content size
-    recorded): readable by any LZ4 frame decoder, lz4framed.decompress included."""
+    """bytes -> LZ4 frame (independent blocks of one of the format's four sizes, 64 KB by default, no checksums besides
+    the mandatory header byte, content size recorded): readable by any LZ4 frame decoder -- checked against liblz4's
+    LZ4F_decompress, the call lz4framed.decompress makes (tests/test_lz4_system_cpu.py)."""
+    code = {1 << 16: 4, 1 << 18: 5, 1 << 20: 6, 1 << 22: 7}.get(block_size)
+    if code is None:
+        raise ValueError("lz4f: block size must be 64 KB, 256 KB, 1 MB or 4 MB")
     flg = (1 << 6) | 0x20 | 0x08                                   # version 01, independent blocks, content size present
-    bd = 4 << 4                                                    # 64 KB blocks
+    bd = code << 4
     desc = bytes([flg, bd]) + struct.pack("<Q", len(data))
     out = bytearray(struct.pack("<I", LZ4F_MAGIC) + desc + bytes([(_xxh32(desc) >> 8) & 0xFF]))
     for off in range(0, len(data), block_size):

@@ -21,3 +21,4 @@ python3 tools/pmc_traffic.py gpurun_out/${OUT}_fetch gpurun_out/${OUT}_write > g
 grep -E "kernel,|conv8|convp|gather_gemm|wgrad" gpurun_out/${OUT}_layers.csv
 python3 tools/pmc_family.py gpurun_out/${OUT}_layers.csv > gpurun_out/${OUT}_mfma_util.json
 cat gpurun_out/${OUT}_traffic.json
+for d in sq lds fetch write l2; do rm -rf gpurun_out/${OUT}_$d; done   # raw traces stay on the box (64 MiB copy-back limit)

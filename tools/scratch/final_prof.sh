@@ -8,3 +8,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r3_final_prof
 python3 tools/prof_summary.py gpurun_out/r3_final_prof 60 > gpurun_out/r3_final_prof.txt
 head -12 gpurun_out/r3_final_prof.txt
 cp $(ls gpurun_out/r3_final_prof/*/*kernel_stats.csv | head -1) gpurun_out/r3_final_kernel_stats.csv
+rm -rf gpurun_out/r3_final_prof   # raw traces stay on the box (64 MiB copy-back limit)
