@@ -6,7 +6,7 @@ set -u
 OUT=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export RNAGAN_GRAPHS=0
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-roofline"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras"
 run() {  # name, counters...
   local name=$1; shift
   timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/${OUT}_$name -o p -- python3 bench.py $ARGS > gpurun_out/${OUT}_$name.log 2>&1
