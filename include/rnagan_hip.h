@@ -154,6 +154,22 @@ int rg_conv_up_maskbits_supported(int N, int Ho, int Wo, int O, int I, int dtype
 int rg_conv_up_maskbits(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I,
                         const void* mask_bits, float mask_slope, int dtype, int algo, void* ws, size_t ws_bytes,
                         void* stream);
+/* rg_last_up (no bias, no activation) with the FIRST CONSUMER's pass over its fp32 NCHW output fused into the store phase:
+ *   tanh_img (optional, shape of y): y *= 1 - tanh_img^2 -- in the generator-loss step the data gradient of the
+ *     discriminator's layer 0 is the cotangent of the generator's Tanh output (.backward() at src/wgan_loss.py:126 through
+ *     nn.Tanh, src/dcgan.py:82): rg_tanh_bwd's arithmetic without materialising the unmultiplied gradient;
+ *   part (optional): float[rg_last_up_post_blocks(...)][4], one row per workgroup = sums over the rows it wrote of channel
+ *     0, 1, 2 of y and of y^2.  rg_last_up_part_chan_sum adds the rows up into the bias gradient of the generator's last
+ *     ConvTranspose2d (out3[c] (+)= sum); rg_gp_coef_parts into the penalty's squared norm ||d D(xhat) / d xhat||^2 over the
+ *     WHOLE batch (src/wgan_loss.py:34-43: gradients.norm(2) of the flattened (N, -1) tensor), from which it writes loss =
+ *     (norm - 1)^2 and coef = lambd * 2 (norm - 1) / norm as rg_gp_coef does (sq, optional, receives the squared norm).
+ *   Fixed summation order: deterministic.  rg_last_up_post_blocks == 0: no such kernel for the shape (use rg_last_up +
+ *   rg_tanh_bwd / rg_nchw_chan_sum / rg_sqnorm). */
+int rg_last_up_post_blocks(int N, int Ho, int Wo, int O, int I, int dtype);
+int rg_last_up_post(const void* x, const float* w, float* y_nchw, int N, int Ho, int Wo, int O, int I, int dtype,
+                    const float* tanh_img, float* part, void* stream);
+int rg_last_up_part_chan_sum(const float* part, int nblocks, float* out3, int accumulate, void* stream);
+int rg_gp_coef_parts(const float* part, int nblocks, float* sq, float* loss, float* coef, float lambd, void* stream);
 /* rg_last_up with the generator's last train-mode BatchNorm + LeakyReLU applied to its input on the fly (z = the pre-BatchNorm
  * conv output; mean / invstd from rg_bn_finalize_partials or rg_bn_stats_finalize): the no-grad generator forwards of the
  * D-loss and penalty steps (src/wgan_loss.py:247,371) skip the normalisation pass over their largest activation.  Same bf16

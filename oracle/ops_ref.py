@@ -147,6 +147,24 @@ class RefOps:
         y = F.conv_transpose2d(self._nchw(x), self._wq(cw.w), bias, stride=2, padding=1)
         return torch.tanh(y) if tanh else y.contiguous()
 
+    def last_up_post(self, x, cw: ConvW, tanh_img=None):
+        """Twin of HipOps.last_up_post: one "workgroup" row of partial sums (channel sums, sum of squares)."""
+        y = self.last_up(x, cw, None, False)
+        if tanh_img is not None:
+            y = y * (1 - tanh_img * tanh_img)
+        parts = torch.cat([y.sum(dim=(0, 2, 3)), (y * y).sum().reshape(1)]).reshape(1, 4).to(self.f)
+        return y.contiguous(), parts
+
+    def parts_chan_sum(self, parts, out, accumulate: bool):
+        s = parts[:, :3].sum(0)
+        if accumulate:
+            out.add_(s)
+        else:
+            out.copy_(s)
+
+    def gp_coef_parts(self, parts, lambd: float):
+        return self.gp_coef(parts[:, 3].sum().reshape(1), lambd)
+
     def skinny_wgrad(self, low, high_nchw, dw, accumulate: bool):
         g = torch.nn.grad.conv2d_weight(high_nchw.to(self.f), dw.shape, self._nchw(low), stride=2, padding=1)
         if accumulate:

@@ -66,6 +66,10 @@ PROTOTYPES = {
     "rg_bn_act_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _z, _p]),
     "rg_bn_act_bwd_g2": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _z, _p]),
     "rg_bn_finalize_partials": (_i, [_p, _i, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "rg_last_up_post_blocks": (_i, [_i, _i, _i, _i, _i, _i]),
+    "rg_last_up_post": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "rg_last_up_part_chan_sum": (_i, [_p, _i, _p, _i, _p]),
+    "rg_gp_coef_parts": (_i, [_p, _i, _p, _p, _p, _f, _p]),
     "rg_last_up_pre_supported": (_i, [_i, _i, _i, _i]),
     "rg_last_up_pre": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _f, _i, _i, _i, _i, _i, _i, _i, _p]),
     "rg_bn_forward_g2": (_i, [_p, _i, _i, _p, _i, _i, _f, _f, _p, _p, _f, _p, _p, _p, _p, _p, _p, _i, _p, _z, _p]),
@@ -148,7 +152,7 @@ PROTOTYPES = {
 }
 
 # must equal rg_version() of the library (rna_gan_amd/csrc/rg_api.hip): bumped together with PROTOTYPES
-ABI_VERSION = 305
+ABI_VERSION = 306
 
 _lib = None
 

@@ -18,7 +18,7 @@ void rg_set_error(const char* fmt, ...) {
 }
 
 // bumped whenever an entry point is added or a signature changes; rna_gan_amd/_abi.py (ABI_VERSION) refuses any other value
-extern "C" int rg_version(void) { return 305; }   // 3.02: round 3 (fused split-K BatchNorm, Inception-v3 data-movement kernels)
+extern "C" int rg_version(void) { return 306; }   // 3.02: round 3 (fused split-K BatchNorm, Inception-v3 data-movement kernels)
 extern "C" const char* rg_last_error(void) { return g_err; }
 
 // ---- kernel-selection knobs: override table in front of the RNAGAN_* environment variables
@@ -267,6 +267,28 @@ extern "C" int rg_last_up(const void* x, const float* w, const float* bias, floa
   if (rg_skinny_supported(I, O))
     return rg_skinny_last_up(x, w, bias, y_nchw, N, Ho, Wo, O, I, apply_tanh, dtype, rg_stream(stream));
   return rg_generic_last_up(x, w, bias, y_nchw, N, Ho, Wo, O, I, apply_tanh, dtype, rg_stream(stream));
+}
+
+// rg_last_up (no activation) with the first consumer's pass over the output fused into the store phase (rg_skinny.hip LuPost)
+extern "C" int rg_last_up_post_blocks(int N, int Ho, int Wo, int O, int I, int dtype) {
+  return rg_skinny_supported(I, O) ? rg_skinny_last_up_post_blocks(N, Ho, Wo, O, dtype) : 0;
+}
+extern "C" int rg_last_up_post(const void* x, const float* w, float* y_nchw, int N, int Ho, int Wo, int O, int I, int dtype,
+                               const float* tanh_img, float* part, void* stream) {
+  RG_REQUIRE(x && w && y_nchw && N > 0 && Ho > 0 && Wo > 0 && (tanh_img || part), RG_EINVAL, "last_up_post: bad args");
+  RG_REQUIRE(rg_last_up_post_blocks(N, Ho, Wo, O, I, dtype) > 0, RG_EUNSUPPORTED, "last_up_post: shape");
+  RG_REQUIRE((((uintptr_t)tanh_img | (uintptr_t)part) & 15) == 0, RG_EINVAL, "last_up_post: 16-byte aligned buffers required");
+  return rg_skinny_last_up(x, w, nullptr, y_nchw, N, Ho, Wo, O, I, 0, dtype, rg_stream(stream), nullptr, nullptr, nullptr,
+                           nullptr, 1.f, tanh_img, part);
+}
+extern "C" int rg_last_up_part_chan_sum(const float* part, int nblocks, float* out3, int accumulate, void* stream) {
+  RG_REQUIRE(part && out3 && nblocks > 0, RG_EINVAL, "last_up_part_chan_sum: bad args");
+  return rg_skinny_lu_part_final(part, nblocks, out3, accumulate, 0, nullptr, nullptr, 0.f, rg_stream(stream));
+}
+extern "C" int rg_gp_coef_parts(const float* part, int nblocks, float* sq, float* loss, float* coef, float lambd,
+                                void* stream) {
+  RG_REQUIRE(part && loss && coef && nblocks > 0, RG_EINVAL, "gp_coef_parts: bad args");
+  return rg_skinny_lu_part_final(part, nblocks, sq, 0, 1, loss, coef, lambd, rg_stream(stream));
 }
 
 extern "C" size_t rg_skinny_wgrad_workspace_bytes(int N, int Ho, int Wo, int O, int I) {

@@ -128,8 +128,11 @@ int rg_skinny_first_down_masked(const float* x, const float* w, void* y, const v
 int rg_skinny_last_up(const void* x, const float* w, const float* bias, float* y, int N, int Ho, int Wo, int O, int I,
                       int apply_tanh, int dtype, hipStream_t st, const float* pre_mean = nullptr,
                       const float* pre_invstd = nullptr, const float* pre_gamma = nullptr, const float* pre_beta = nullptr,
-                      float pre_slope = 1.f);
+                      float pre_slope = 1.f, const float* post_tb_img = nullptr, float* post_part = nullptr);
 bool rg_skinny_last_up_pre_supported(int Wo, int O, int dtype);
+int rg_skinny_last_up_post_blocks(int N, int Ho, int Wo, int O, int dtype);
+int rg_skinny_lu_part_final(const float* part, int nb, float* out, int accumulate, int mode, float* loss, float* coef,
+                            float lambd, hipStream_t st);
 size_t rg_skinny_wgrad_ws_bytes(int N, int Ho, int Wo, int O, int I);
 int rg_skinny_wgrad_impl(const void* low, const float* high_nchw, float* dw, int N, int Ho, int Wo, int O, int I,
                          int dtype, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);

@@ -382,6 +382,13 @@ __global__ __launch_bounds__(256, 3) void skinny_wgrad_rows_kernel(const uint16_
 // per strip, with the next row's loads in flight during the current row's MFMAs.  The 16x16 results get bias +
 // tanh and go through an LDS tile so that the NCHW rows are written with 16-byte coalesced stores.
 typedef __attribute__((ext_vector_type(4))) float sk_f32x4;
+// tanh(x) = 1 - 2 / (exp(2x) + 1) on the hardware exp2 / rcp units (5 instructions instead of libm's ~40; 12.6 M evaluations per
+// 64-image batch): absolute error <= 2e-7 over the whole range (saturates to +-1 through exp2 -> inf / 0), which is what an
+// image in [-1, 1] needs; the relative error for |x| < 1e-3 is that of the cancellation, ~1e-4.
+__device__ __forceinline__ float sk_fast_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);       // exp(2x)
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+}
 constexpr int LU_PXS = 72;                 // bf16 elements per staged pixel (144 bytes)
 constexpr int LU_MAXC = 128;               // pixels per unit row
 constexpr int LU_OS = 2 * LU_MAXC + 4;     // floats per staged output row
@@ -391,10 +398,16 @@ constexpr int LU_OS = 2 * LU_MAXC + 4;     // floats per staged output row
 // generator forward that keeps nothing for a backward pass (the fakes of the D-loss and penalty steps) skips the BatchNorm
 // apply pass over its largest activation (134 MB read + 134 MB written).
 struct LuPre { const float* mean; const float* invstd; const float* gamma; const float* beta; float slope; };
+// post (optional), applied to the output rows on their way from the LDS tile to memory -- the first consumer's pass fused away:
+//   tb_img: out *= 1 - tb_img^2, tb_img = the generator's image (tanh backward: the data gradient of D's layer 0 in the
+//           generator-loss step IS the cotangent of G's tanh output; rg_tanh_bwd's arithmetic, 100 MB less traffic);
+//   part:   float[gridDim.x][4] per-workgroup sums of the rows this workgroup wrote: channel 0, 1, 2 and the sum of squares
+//           (the bias gradient of G's last layer = the channel sums; the penalty's ||d D / d xhat||^2 = the sum of squares).
+struct LuPost { const float* tb_img; float* part; };
 __global__ __launch_bounds__(256, 2) void last_up_rows_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ y, int N,
                                                               int Ho, int Wo, int apply_tanh, int chunk, int strip,
-                                                              int nstrips, LuPre pre) {
+                                                              int nstrips, LuPre pre, LuPost post) {
   __shared__ __attribute__((aligned(16))) uint16_t ring[3 * (LU_MAXC + 2) * LU_PXS];    // 54.8 KB
   __shared__ __attribute__((aligned(16))) float outt[6 * LU_OS];                          // 6.1 KB
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -444,6 +457,7 @@ __global__ __launch_bounds__(256, 2) void last_up_rows_kernel(const uint16_t* __
     v = make_uint4(d[0], d[1], d[2], d[3]);
   };
   bool row_ok = false, edge_ok = false;            // validity of the row / halo pixel held in lv*, le (padding stays zero)
+  float pc0 = 0.f, pc1 = 0.f, pc2 = 0.f, pq = 0.f; // post.part: this thread's share
 
   for (int sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
     const int cx = sidx % cpr, rest = sidx / cpr;
@@ -518,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void last_up_rows_kernel(const uint16_t* __
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float v = acc[r] + bv;
-              if (apply_tanh) v = tanhf(v);
+              if (apply_tanh) v = sk_fast_tanh(v);
               orow[2 * r] = v;
             }
           }
@@ -528,13 +542,71 @@ __global__ __launch_bounds__(256, 2) void last_up_rows_kernel(const uint16_t* __
         for (int f = t; f < (6 << lgh); f += 256) {
           const int rid = f >> lgh, m = f & ((1 << lgh) - 1);
           const int i = rid >> 1, ph = rid & 1;
-          *reinterpret_cast<float4*>(y + (((size_t)n * SK_I + i) * H + 2 * hq + ph) * W + 2 * wo0 + 4 * m) =
-              *reinterpret_cast<const float4*>(outt + rid * LU_OS + 4 * m);
+          const size_t oi = (((size_t)n * SK_I + i) * H + 2 * hq + ph) * W + 2 * wo0 + 4 * m;
+          float4 v = *reinterpret_cast<const float4*>(outt + rid * LU_OS + 4 * m);
+          if (post.tb_img) {
+            const float4 im = *reinterpret_cast<const float4*>(post.tb_img + oi);
+            v = make_float4(v.x * (1.f - im.x * im.x), v.y * (1.f - im.y * im.y), v.z * (1.f - im.z * im.z),
+                            v.w * (1.f - im.w * im.w));
+          }
+          *reinterpret_cast<float4*>(y + oi) = v;
+          if (post.part) {
+            const float sv = (v.x + v.y) + (v.z + v.w);
+            pc0 += i == 0 ? sv : 0.f; pc1 += i == 1 ? sv : 0.f; pc2 += i == 2 ? sv : 0.f;
+            pq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+          }
         }
       }
       __syncthreads();
     }
 #undef LU_LOAD_ROW
+  }
+  if (post.part) {          // fixed-order block sums (wave butterfly, then the four waves through LDS): deterministic
+    float vals[4] = {pc0, pc1, pc2, pq};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) vals[k] += __shfl_xor(vals[k], o, 64);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) outt[wave * 4 + k] = vals[k];
+    }
+    __syncthreads();
+    if (t < 4) post.part[(size_t)blockIdx.x * 4 + t] = (outt[t] + outt[4 + t]) + (outt[8 + t] + outt[12 + t]);
+  }
+}
+
+// sums of the per-workgroup rows written by last_up_rows_kernel (post.part): out[c] (+)= sum_b part[b][c] for c < 3 (mode 0),
+// or the penalty's coefficient from sq = sum_b part[b][3] (mode 1: gp_coef_kernel's arithmetic)
+__global__ __launch_bounds__(256) void lu_part_final_kernel(const float* __restrict__ part, int nb, float* out, int accumulate,
+                                                            int mode, float* loss, float* coef, float lambd) {
+  __shared__ float sm[4][4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b = t; b < nb; b += 256) {
+    const float4 p = *reinterpret_cast<const float4*>(part + (size_t)b * 4);
+    v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sm[wave][k] = v[k];
+  }
+  __syncthreads();
+  if (t < 4) {
+    const float tot = (sm[0][t] + sm[1][t]) + (sm[2][t] + sm[3][t]);
+    if (mode == 0) {
+      if (t < 3) out[t] = accumulate ? out[t] + tot : tot;
+    } else if (t == 3) {
+      const float nrm = sqrtf(tot);
+      if (out) out[0] = tot;
+      loss[0] = (nrm - 1.f) * (nrm - 1.f);
+      coef[0] = lambd * 2.f * (nrm - 1.f) / nrm;
+    }
   }
 }
 
@@ -808,10 +880,29 @@ bool rg_skinny_last_up_pre_supported(int Wo, int O, int dtype) {
   int chunk;
   return dtype == RG_BF16 && O == 64 && sk_rows_chunk(Wo, &chunk);
 }
+// number of per-workgroup partial rows rg_skinny_last_up writes with post_part (0: this shape has no rows kernel)
+int rg_skinny_last_up_post_blocks(int N, int Ho, int Wo, int O, int dtype) {
+  int chunk;
+  if (!(dtype == RG_BF16 && O == 64 && sk_rows_chunk(Wo, &chunk))) return 0;
+  int strip = Ho < 16 ? Ho : 16;
+  while (Ho % strip) --strip;
+  long long nstrips = (long long)N * (Ho / strip) * (Wo / chunk);
+  return nstrips < 512 ? (int)nstrips : 512;
+}
+int rg_skinny_lu_part_final(const float* part, int nb, float* out, int accumulate, int mode, float* loss, float* coef,
+                            float lambd, hipStream_t st) {
+  hipLaunchKernelGGL(lu_part_final_kernel, dim3(1), dim3(256), 0, st, part, nb, out, accumulate, mode, loss, coef, lambd);
+  RG_LAUNCH_CHECK("last_up_post_final");
+  return RG_OK;
+}
 int rg_skinny_last_up(const void* x, const float* w, const float* bias, float* y, int N, int Ho, int Wo, int O, int I,
                       int apply_tanh, int dtype, hipStream_t st, const float* pre_mean, const float* pre_invstd,
-                      const float* pre_gamma, const float* pre_beta, float pre_slope) {
+                      const float* pre_gamma, const float* pre_beta, float pre_slope, const float* post_tb_img,
+                      float* post_part) {
   const LuPre pre{pre_mean, pre_invstd, pre_gamma, pre_beta, pre_slope};
+  const LuPost post{post_tb_img, post_part};
+  RG_REQUIRE(!(post_tb_img || post_part) || rg_skinny_last_up_post_blocks(N, Ho, Wo, O, dtype) > 0, RG_EUNSUPPORTED,
+             "last_up: fused output epilogue");
   RG_REQUIRE(!pre_mean || rg_skinny_last_up_pre_supported(Wo, O, dtype), RG_EUNSUPPORTED, "last_up: fused BatchNorm input");
   (void)I;
   static int lu_valu = -1;
@@ -823,7 +914,7 @@ int rg_skinny_last_up(const void* x, const float* w, const float* bias, float* y
     long long nstrips = (long long)N * (Ho / strip) * (Wo / chunk);
     int blocks = nstrips < 512 ? (int)nstrips : 512;
     hipLaunchKernelGGL(last_up_rows_kernel, dim3(blocks), dim3(256), 0, st, (const uint16_t*)x, w, bias, y, N, Ho, Wo,
-                       apply_tanh, chunk, strip, (int)nstrips, pre);
+                       apply_tanh, chunk, strip, (int)nstrips, pre, post);
     RG_LAUNCH_CHECK("last_up(mfma)");
     return RG_OK;
   }

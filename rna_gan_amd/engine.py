@@ -201,12 +201,16 @@ def disc_forward(ops, D: DiscNet, x_nchw, update_running=True):
 
 
 def disc_backward(ops, D: DiscNet, ctx, coef: float, wgrad: bool, accumulate: bool,
-                  need_input_grad: bool, keep_for_gp: bool = False):
+                  need_input_grad: bool, keep_for_gp: bool = False, input_post=None):
     """Backward of sum_n coef * D(x)_n (coef: a float, or an (N,) tensor of per-sample cotangents as torch autograd
     hands them over).  wgrad: also produce parameter gradients (written with ``accumulate`` semantics into the
     .dw/.dbias/.dgamma/.dbeta buffers).  Returns d/dx (NCHW fp32) if requested.  keep_for_gp stores the per-layer
-    first-backward gradients on ctx."""
+    first-backward gradients on ctx.  input_post (with need_input_grad): {"tanh_img": img or None} -- the first consumer's
+    pass over d/dx fused into the kernel that writes it (ops.last_up_post): d/dx multiplied by 1 - img^2 (the cotangent of
+    the generator's Tanh) and / or per-workgroup partial sums (channel sums, sum of squares) left in ctx.gx_parts; when the
+    backend has no such kernel for the shape, ctx.gx_parts stays None and d/dx is returned unmodified."""
     R = len(D.blocks)
+    ctx.gx_parts = None
     if torch.is_tensor(coef):       # N-length vector: host-side plumbing
         gh = (coef.reshape(-1).float() * torch.where(ctx.h > 0, torch.ones_like(ctx.h),
                                                      torch.full_like(ctx.h, D.last_slope))).contiguous()
@@ -243,7 +247,13 @@ def disc_backward(ops, D: DiscNet, ctx, coef: float, wgrad: bool, accumulate: bo
         with ops.side(gz0):
             ops.skinny_wgrad(gz0, ctx.x, D.conv0.dw, accumulate)
         ops.col_sum(gz0, D.conv0.dbias, accumulate)
-    gx = ops.last_up(gz0, D.conv0, None, False) if need_input_grad else None
+    gx = None
+    if need_input_grad and input_post is not None:
+        fused = ops.last_up_post(gz0, D.conv0, input_post.get("tanh_img"))
+        if fused is not None:
+            gx, ctx.gx_parts = fused
+    if need_input_grad and gx is None:
+        gx = ops.last_up(gz0, D.conv0, None, False)
     if wgrad:
         ops.join()
     return gx
@@ -302,9 +312,16 @@ def disc_gp_first(ops, D: DiscNet, ctx, lambd):
     g = d sum D(xhat) / d xhat, the UNWEIGHTED penalty (||g|| - 1)^2 (1-element device tensor) and the tangent
     direction v = lambd * 2 (||g|| - 1) / ||g|| * g.  lambd: float, or a 1-element device tensor is NOT supported (the
     coefficient kernel takes a host scalar)."""
-    g = disc_backward(ops, D, ctx, 1.0, wgrad=False, accumulate=False, need_input_grad=True, keep_for_gp=True)
-    sq = ops.stat_allreduce(ops.sqnorm(g))      # whole-batch norm: summed over the ranks when statistics are synchronised
-    loss, coef = ops.gp_coef(sq, lambd)
+    # the squared norm comes out of the kernel that writes g as per-workgroup partial sums (no pass over g) unless the
+    # statistics are synchronised over the ranks (then the scalar itself is all-reduced)
+    fuse = None if ops.stat_reduce is not None else {"tanh_img": None}
+    g = disc_backward(ops, D, ctx, 1.0, wgrad=False, accumulate=False, need_input_grad=True, keep_for_gp=True,
+                      input_post=fuse)
+    if ctx.gx_parts is not None:
+        loss, coef = ops.gp_coef_parts(ctx.gx_parts, lambd)
+    else:
+        sq = ops.stat_allreduce(ops.sqnorm(g))      # whole-batch norm: summed over the ranks when statistics are synchronised
+        loss, coef = ops.gp_coef(sq, lambd)
     return loss, (g, ops.scale_by(g, coef))
 
 
@@ -468,14 +485,20 @@ def _gen_bwd(ops, G, ctx, gimg, accumulate, need_input_grad=False):
     return gen_backward(ops, G, ctx, gimg, accumulate, need_input_grad)
 
 
-def gen_backward(ops, G: GenNet, ctx, gimg, accumulate: bool, need_input_grad: bool = False):
+def gen_backward(ops, G: GenNet, ctx, gimg, accumulate: bool, need_input_grad: bool = False, gzl=None, gzl_parts=None):
     """Parameter gradients of G for d(loss)/d(img) = gimg (NCHW fp32); with need_input_grad also d(loss)/d(noise)
-    (N, E) -- off the reference's path (its noise never requires grad), one extra GEMM."""
+    (N, E) -- off the reference's path (its noise never requires grad), one extra GEMM.  gzl / gzl_parts: the cotangent
+    of the Tanh's input and its per-workgroup channel sums when the caller's kernel produced them (disc_backward
+    input_post); gimg is not read then."""
     R = len(G.blocks)
-    gzl = ops.tanh_bwd(gimg, ctx.img)
+    if gzl is None:
+        gzl = ops.tanh_bwd(gimg, ctx.img)
     with ops.side(gzl):
         ops.skinny_wgrad(ctx.a[R], gzl, G.last.dw, accumulate)
-    ops.nchw_chan_sum(gzl, G.last.dbias, accumulate)
+    if gzl_parts is not None:
+        ops.parts_chan_sum(gzl_parts, G.last.dbias, accumulate)
+    else:
+        ops.nchw_chan_sum(gzl, G.last.dbias, accumulate)
     ga = ops.first_down(gzl, G.last, None, 1.0)
     for l in range(R, 0, -1):
         cw, bn = G.blocks[l - 1]
@@ -513,8 +536,14 @@ def gen_loss_rest(ops, G, D: DiscNet, pre, grad_scale: float = 1.0):
     n = img.shape[0]
     out, dctx = disc_forward(ops, D, img)
     loss = ops.mean_diff(out, None, -1.0)
-    gimg = disc_backward(ops, D, dctx, -grad_scale / n, wgrad=False, accumulate=False, need_input_grad=True)
-    _gen_bwd(ops, G, gctx, gimg, accumulate=False)
+    # DCGAN generator: the cotangent of its Tanh (gimg * (1 - img^2)) and the channel sums of that (the last layer's bias
+    # gradient) come out of the kernel that writes D's input gradient
+    fuse = {"tanh_img": gctx.img} if isinstance(G, GenNet) else None
+    gimg = disc_backward(ops, D, dctx, -grad_scale / n, wgrad=False, accumulate=False, need_input_grad=True, input_post=fuse)
+    if dctx.gx_parts is not None:
+        gen_backward(ops, G, gctx, None, accumulate=False, gzl=gimg, gzl_parts=dctx.gx_parts)
+    else:
+        _gen_bwd(ops, G, gctx, gimg, accumulate=False)
     return loss
 
 

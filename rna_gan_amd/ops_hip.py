@@ -55,6 +55,8 @@ class HipOps:
         self._in_side = False
         self._keep = []
         self.use_side = os.environ.get("RNAGAN_SIDE_STREAM", "0") != "0"
+        # tanh backward / channel sums / squared norm of D's input gradient inside the kernel that writes it
+        self.fuse_input_post = os.environ.get("RNAGAN_INPUT_POST", "1") != "0"
         self.pack_from_shadow = os.environ.get("RNAGAN_PACK_FROM_SHADOW", "1") != "0"
         self.epilogue_stats = os.environ.get("RNAGAN_EPILOGUE_STATS", "1") != "0"
         # synchronised (global-batch) statistics in a data-parallel run (dist.attach_sync): an in-place SUM all-reduce
@@ -607,6 +609,36 @@ class HipOps:
         check(self.lib.rg_last_up(_ptr(x), _ptr(cw.w), _ptr(bias), _ptr(y), N, Ho, Wo, O, I, int(tanh), self.dt,
                                   self.stream), "rg_last_up")
         return y
+
+    def last_up_post(self, x, cw: ConvW, tanh_img=None):
+        """last_up (no bias, no activation) with the first consumer's pass fused into the store phase (rg_last_up_post):
+        y *= 1 - tanh_img^2 when tanh_img is given, and per-workgroup partial sums [blocks][4] (channel 0..2 sums, sum of
+        squares) for parts_chan_sum / gp_coef_parts.  Returns (y, parts), or None when the shape has no such kernel."""
+        N, Ho, Wo, O = x.shape
+        I = cw.w.shape[1]
+        if not self.fuse_input_post:
+            return None
+        nb = self.lib.rg_last_up_post_blocks(N, Ho, Wo, O, I, self.dt)
+        if nb <= 0:
+            return None
+        assert cw.w.shape[0] == O and x.is_contiguous()
+        assert tanh_img is None or (tanh_img.shape == (N, I, 2 * Ho, 2 * Wo) and tanh_img.is_contiguous()
+                                    and tanh_img.dtype == torch.float32)
+        y = self._f32(N, I, 2 * Ho, 2 * Wo)
+        parts = self._f32(nb, 4)
+        check(self.lib.rg_last_up_post(_ptr(x), _ptr(cw.w), _ptr(y), N, Ho, Wo, O, I, self.dt, _ptr(tanh_img), _ptr(parts),
+                                       self.stream), "rg_last_up_post")
+        return y, parts
+
+    def parts_chan_sum(self, parts, out, accumulate: bool):
+        check(self.lib.rg_last_up_part_chan_sum(_ptr(parts), parts.shape[0], _ptr(out), int(accumulate), self.stream),
+              "rg_last_up_part_chan_sum")
+
+    def gp_coef_parts(self, parts, lambd: float):
+        loss, coef = self._f32(1), self._f32(1)
+        check(self.lib.rg_gp_coef_parts(_ptr(parts), parts.shape[0], None, _ptr(loss), _ptr(coef), float(lambd), self.stream),
+              "rg_gp_coef_parts")
+        return loss, coef
 
     def skinny_wgrad(self, low, high_nchw, dw, accumulate: bool):
         N, Ho, Wo, O = low.shape

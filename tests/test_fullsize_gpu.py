@@ -148,6 +148,45 @@ def test_image_side_layers_full_size():
             assert float((y[n, ho, wo].double() - ref).abs().max()) < 8e-3 * float(ref.abs().max() + 1.0)
 
 
+@pytest.mark.parametrize("n,hw", [(64, 128), (3, 32)])
+def test_input_gradient_kernel_with_fused_consumer_pass(n, hw):
+    """rg_last_up_post at the benchmark's shape (and a ragged small one): the transposed conv's output multiplied by
+    1 - img^2 in the store phase equals rg_last_up followed by rg_tanh_bwd BIT FOR BIT (same fp32 products), the
+    per-workgroup partial rows add up to the channel sums (rg_nchw_chan_sum) and to the squared norm (rg_sqnorm) of what
+    was written, and rg_gp_coef_parts gives rg_gp_coef's loss / coefficient from them."""
+    dev = torch.device("cuda:0")
+    ops = HipOps(torch.bfloat16, dev)
+    gen = torch.Generator(device="cpu").manual_seed(23)
+    w = (torch.randn(64, 3, 4, 4, generator=gen) * 0.2).to(dev)
+    cw = ConvW(w, None)
+    g = torch.randn(n, hw, hw, 64, generator=gen).bfloat16().to(dev)
+    img = torch.tanh(torch.randn(n, 3, 2 * hw, 2 * hw, generator=gen)).to(dev)
+    plain = ops.last_up(g, cw, None, False)
+    for tanh_img in (img, None):
+        fused = ops.last_up_post(g, cw, tanh_img)
+        assert fused is not None, "no fused kernel for the benchmark shape"
+        y, parts = fused
+        want = ops.tanh_bwd(plain, img) if tanh_img is not None else plain
+        assert torch.equal(y, want)
+        assert parts.shape[1] == 4 and parts.shape[0] == ops.lib.rg_last_up_post_blocks(n, hw, hw, 64, 3, ops.dt)
+        wd = want.double()
+        cs, sq = wd.sum(dim=(0, 2, 3)), float((wd * wd).sum())
+        scale = float(wd.abs().sum(dim=(0, 2, 3)).max())
+        assert float((parts[:, :3].double().sum(0) - cs).abs().max()) < 1e-5 * scale
+        assert abs(float(parts[:, 3].double().sum()) - sq) < 1e-5 * sq
+        db = torch.full((3,), 0.5, device=dev)
+        ops.parts_chan_sum(parts, db, True)
+        assert float((db.double() - 0.5 - cs).abs().max()) < 1e-5 * scale
+        ops.parts_chan_sum(parts, db, False)
+        ref = torch.zeros(3, device=dev)
+        ops.nchw_chan_sum(want, ref, False)
+        assert float((db - ref).abs().max()) < 1e-5 * scale
+        loss, coef = ops.gp_coef_parts(parts, 10.0)
+        loss0, coef0 = ops.gp_coef(ops.sqnorm(want), 10.0)
+        assert abs(float(loss) - float(loss0)) <= 1e-5 * abs(float(loss0)) + 1e-7
+        assert abs(float(coef) - float(coef0)) <= 1e-5 * abs(float(coef0)) + 1e-7
+
+
 def test_g0_and_head_full_size():
     """G.0 (ConvTranspose2d(2048, 2048, 4) on a 1x1 input = a [64 x 2048] . [2048 x 32768] GEMM), its rank-64 weight
     gradient (268 MB fp32 output) and the discriminator head at the benchmark's sizes: element-wise against the generic
