@@ -310,6 +310,43 @@ __global__ void head_wgrad_kernel(const float* gh, const T* a, float* dw, int N,
   *d = accumulate ? *d + s : s;
 }
 
+// bf16 form: the batch is split over 8 thread groups (a thread: 8 consecutive j = one 16-byte load per sample, N / 8 independent
+// loads in flight instead of a serial walk over the batch: 24 -> 5 us at N = 64, C = 2048), combined through LDS in a fixed order
+__global__ __launch_bounds__(256) void head_wgrad_bf16_kernel(const float* __restrict__ gh, const uint16_t* __restrict__ a,
+                                                              float* __restrict__ dw, int N, int C, int accumulate) {
+  __shared__ float sm[8][256 + 8];
+  const int t = threadIdx.x, jg = t & 31, ng = t >> 5;
+  const int J = 16 * C, j0 = blockIdx.x * 256 + jg * 8;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  if (j0 < J) {
+#pragma unroll 4
+    for (int n = ng; n < N; n += 8) {
+      const uint4 v = *reinterpret_cast<const uint4*>(a + (size_t)n * J + j0);
+      const float g = gh[n];
+      const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc[2 * k] += g * __uint_as_float(d[k] << 16);
+        acc[2 * k + 1] += g * __uint_as_float(d[k] & 0xffff0000u);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sm[ng][jg * 8 + k] = acc[k];
+  __syncthreads();
+  const int j = blockIdx.x * 256 + t;
+  if (j < J) {
+    float s = 0.f;
+#pragma unroll
+    for (int g8 = 0; g8 < 8; ++g8) s += sm[g8][t];
+    const int tap = j / C, c = j - tap * C;
+    float* d = dw + c * 16 + tap;
+    *d = accumulate ? *d + s : s;
+  }
+}
+
 __global__ void widen_bf16_kernel(const uint16_t* src, float* dst, size_t n) {
   size_t n4 = n / 4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -535,6 +572,12 @@ extern "C" int rg_head_bwd_data(const float* gh, const float* w, void* ga, int N
 extern "C" int rg_head_wgrad(const float* gh, const void* a, float* dw, int N, int C, int dtype, int accumulate,
                              void* stream) {
   RG_REQUIRE(gh && a && dw && N > 0 && C > 0, RG_EINVAL, "head_wgrad: bad args");
+  if (dtype == RG_BF16 && (((uintptr_t)a) & 15) == 0 && C % 8 == 0) {
+    hipLaunchKernelGGL(head_wgrad_bf16_kernel, dim3((16 * C + 255) / 256), dim3(256), 0, rg_stream(stream), gh,
+                       (const uint16_t*)a, dw, N, C, accumulate);
+    RG_LAUNCH_CHECK("head_wgrad");
+    return RG_OK;
+  }
   RG_DISPATCH_DTYPE(dtype, T, {
     hipLaunchKernelGGL((head_wgrad_kernel<T>), dim3((16 * C + 255) / 256), dim3(256), 0, rg_stream(stream), gh,
                        (const T*)a, dw, N, C, accumulate);

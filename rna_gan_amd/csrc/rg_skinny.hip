@@ -156,6 +156,7 @@ constexpr int FD_OTS = 72;      // out-tile row stride (bf16): 144 bytes
 // LeakyReLU-backward mask of the data-gradient conv of layer 1 (rg_convp.hip reads 8 B per pixel instead of 128 B).
 // mask_bits (optional): such bits of ANOTHER activation of the output's shape; then y *= (bit ? 1 : mslope) -- the tangent
 // pass of the gradient penalty is lrelu'(a0) * conv(v), one kernel instead of the conv plus a pass over three 134 MB tensors.
+template <bool BITS, bool MASK>      // compile-time presence of bits / mask_bits: the sign-bit packing is 40 % of the epilogue's VALU work
 __global__ __launch_bounds__(256, 3) void first_down_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                  const float* __restrict__ bias, uint16_t* __restrict__ y,
                                                                  unsigned long long* __restrict__ bits,
@@ -216,14 +217,14 @@ __global__ __launch_bounds__(256, 3) void first_down_rows_kernel(const float* __
       // acc[i][4*g + e] = D[ch = 32*i + 8*g + 4*h + e][pixel r]
       unsigned nib = 0;                                    // nibble 4*i + g: sign bits of channels 32*i + 8*g + 4*h + 0..3
       unsigned long long mword = ~0ull;
-      if (mask_bits) mword = mask_bits[((size_t)q.n * Ho + q.ho) * Wo + q.wo0 + wave * 32 + r];
+      if (MASK) mword = mask_bits[((size_t)q.n * Ho + q.ho) * Wo + q.wo0 + wave * 32 + r];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           float v0 = lrelu_f(acc[i][4 * g4 + 0] + bs[i][g4][0], slope), v1 = lrelu_f(acc[i][4 * g4 + 1] + bs[i][g4][1], slope);
           float v2 = lrelu_f(acc[i][4 * g4 + 2] + bs[i][g4][2], slope), v3 = lrelu_f(acc[i][4 * g4 + 3] + bs[i][g4][3], slope);
-          if (mask_bits) {
+          if (MASK) {
             const unsigned mb = (unsigned)(mword >> (32 * i + 8 * g4 + 4 * h)) & 15u;
             v0 *= (mb & 1u) ? 1.f : mslope; v1 *= (mb & 2u) ? 1.f : mslope;
             v2 *= (mb & 4u) ? 1.f : mslope; v3 *= (mb & 8u) ? 1.f : mslope;
@@ -231,11 +232,13 @@ __global__ __launch_bounds__(256, 3) void first_down_rows_kernel(const float* __
           const uint32_t p01 = sk_pack2(v0, v1), p23 = sk_pack2(v2, v3);
           *reinterpret_cast<uint2*>(otw + r * FD_OTS + 32 * i + 8 * g4 + 4 * h) = make_uint2(p01, p23);
           // bit = the STORED bf16 value is > 0 (sign clear, magnitude non-zero): what rg_lmask tests on the bf16 activation
-          const unsigned b = (sk_pos16(p01) ? 1u : 0u) | (sk_pos16(p01 >> 16) ? 2u : 0u) | (sk_pos16(p23) ? 4u : 0u) |
-                             (sk_pos16(p23 >> 16) ? 8u : 0u);
-          nib |= b << (4 * (4 * i + g4));
+          if (BITS) {
+            const unsigned b = (sk_pos16(p01) ? 1u : 0u) | (sk_pos16(p01 >> 16) ? 2u : 0u) | (sk_pos16(p23) ? 4u : 0u) |
+                               (sk_pos16(p23 >> 16) ? 8u : 0u);
+            nib |= b << (4 * (4 * i + g4));
+          }
         }
-      if (bits) {
+      if (BITS) {
         // lanes r and r + 32 hold the low (h = 0) / high (h = 1) nibble of every byte of pixel r's word
         const unsigned other = (unsigned)__shfl_xor((int)nib, 32, 64);
         const unsigned lo = h ? other : nib, hi = h ? nib : other;
@@ -843,8 +846,9 @@ int rg_skinny_first_down_masked(const float* x, const float* w, void* y, const v
   RG_REQUIRE(npix / chunk < 0x7fffffff, RG_EUNSUPPORTED, "first_down_masked: too large");
   int nunits = (int)(npix / chunk);
   int blocks = nunits < SK_ROWS_BLOCKS ? nunits : SK_ROWS_BLOCKS;
-  hipLaunchKernelGGL(first_down_rows_kernel, dim3(blocks), dim3(256), 0, st, x, w, (const float*)nullptr, (uint16_t*)y,
-                     (unsigned long long*)nullptr, (const unsigned long long*)mask_bits, mslope, N, H, W, 1.f, chunk, nunits);
+  hipLaunchKernelGGL((first_down_rows_kernel<false, true>), dim3(blocks), dim3(256), 0, st, x, w, (const float*)nullptr,
+                     (uint16_t*)y, (unsigned long long*)nullptr, (const unsigned long long*)mask_bits, mslope, N, H, W, 1.f,
+                     chunk, nunits);
   RG_LAUNCH_CHECK("first_down_masked");
   return RG_OK;
 }
@@ -859,8 +863,12 @@ int rg_skinny_first_down(const float* x, const float* w, const float* bias, void
   if (dtype == RG_BF16 && O == 64 && sk_rows_chunk(W / 2, &chunk) && npix / chunk < 0x7fffffff && !no_mfma) {
     int nunits = (int)(npix / chunk);
     int blocks = nunits < SK_ROWS_BLOCKS ? nunits : SK_ROWS_BLOCKS;
-    hipLaunchKernelGGL(first_down_rows_kernel, dim3(blocks), dim3(256), 0, st, x, w, bias, (uint16_t*)y,
-                       (unsigned long long*)bits, (const unsigned long long*)nullptr, 1.f, N, H, W, slope, chunk, nunits);
+    if (bits)
+      hipLaunchKernelGGL((first_down_rows_kernel<true, false>), dim3(blocks), dim3(256), 0, st, x, w, bias, (uint16_t*)y,
+                         (unsigned long long*)bits, (const unsigned long long*)nullptr, 1.f, N, H, W, slope, chunk, nunits);
+    else
+      hipLaunchKernelGGL((first_down_rows_kernel<false, false>), dim3(blocks), dim3(256), 0, st, x, w, bias, (uint16_t*)y,
+                         (unsigned long long*)nullptr, (const unsigned long long*)nullptr, 1.f, N, H, W, slope, chunk, nunits);
     RG_LAUNCH_CHECK("first_down(mfma)");
     return RG_OK;
   }
