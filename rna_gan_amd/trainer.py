@@ -28,13 +28,15 @@ import torch
 from . import dist as D_
 from . import losses as L
 from . import optim
+from .prefetch import DevicePrefetcher
 
 
 class Trainer:
     def __init__(self, models, losses_list, metrics_list=None, device=torch.device("cuda:0"), ncritic=1, epochs=5,
                  sample_size=8, checkpoints="./model/gan", retain_checkpoints=5, recon="./images", log_dir=None,
-                 test_noise=None, nrow=8, precision="bf16", **kwargs):
+                 test_noise=None, nrow=8, precision="bf16", prefetch=True, **kwargs):
         self.device = torch.device(device)
+        self.prefetch = bool(prefetch)          # extra knob: host batches are copied to the device one iteration ahead
         self.model_names = []
         self.optimizer_names = []
         self.schedulers = []
@@ -193,7 +195,9 @@ class Trainer:
         for epoch in range(self.start_epoch, self.epochs):
             for name in self.model_names:
                 getattr(self, name).train()
-            for data in data_loader:
+            # batches arrive on the device one iteration ahead (rna_gan_amd/prefetch.py); the .to() calls below and the
+            # plugins' own then find the tensors in place
+            for data in (DevicePrefetcher(data_loader, self.device) if self.prefetch else data_loader):
                 if isinstance(data, (tuple, list)):
                     self.real_inputs = data[0].to(self.device)
                     self.labels = data[1].to(self.device)
