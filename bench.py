@@ -637,7 +637,8 @@ def parity_object(gpu, cpu, precision):
 def measure_extras(args, device, info):
     """Secondary figures, measured after the headline timed region on the same box in the same process."""
     ex = {}
-    for name, fn in (("generate", extra_generate), ("api_path", extra_api_path), ("fp32_step", extra_fp32_step)):
+    for name, fn in (("generate", extra_generate), ("api_path", extra_api_path), ("fp32_step", extra_fp32_step),
+                     ("vae_train", extra_vae_train)):
         try:
             ex[name] = fn(args, device, info)
             log("extra %s: %s" % (name, json.dumps(ex[name])))
@@ -684,6 +685,46 @@ def extra_api_path(args, device, info, steps=20, warm=12):
     torch.cuda.synchronize(device)
     dt = (time.perf_counter() - t0) / steps
     return dict(api_info, ms_per_step=round(dt * 1e3, 3), imgs_per_sec=round(args.batch / dt, 1), steps=steps)
+
+
+def extra_vae_train(args, device, info, steps=10, warm=3):
+    """one betaVAE TRAINING iteration at the reference's full size (src/betaVAE_training.py defaults:
+    19198 genes, [6000, 4000, 2048] / [4000, 6000], batch 64): forward, loss, backward, fused Adam on the HIP GEMM kernels."""
+    import rna_gan_amd as P
+    from rna_gan_amd import synth as R
+    from rna_gan_amd import vae_train as VT
+    N = args.batch
+    dims = (19198, 2048, [6000, 4000, 2048], [4000, 6000])
+    m = P.betaVAE(*dims, beta=2.0)
+    R.seeded_fill_(m, 51)
+    m = m.set_precision("bf16").to(device).train()
+    opt = P.Adam(m.parameters(), lr=3e-3, weight_decay=1e-4).bind(m)
+    gen = torch.Generator(device="cpu").manual_seed(args.seed + 13)
+    x = torch.tanh(torch.randn(N, dims[0], generator=gen)).to(device)
+    nparam = sum(p.numel() for p in m.parameters())
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out, mu, lv = m(x)
+        losses = VT.betaVAEloss(x, out, mu, lv, m.beta, training=True)
+        losses["total_loss"].backward()
+        opt.step()
+        return losses
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses = step()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    floor_bytes = nparam * (28 + 4 + 3 * 2)      # Adam 28 B + fp32 weight gradient written once + weights read 3x as bf16
+    res = {"ms_per_step": round(dt * 1e3, 3), "samples_per_sec": round(N / dt, 1), "parameters_M": round(nparam / 1e6, 1),
+           "precision": "bf16", "hbm_floor_TBps_achieved": round(floor_bytes / dt / 1e12, 2), "steps": steps,
+           "loss": round(float(losses["total_loss"].detach()), 5)}
+    del m, opt
+    torch.cuda.empty_cache()
+    return res
 
 
 def extra_fp32_step(args, device, info, steps=2):
