@@ -499,10 +499,14 @@ class WassersteinGeneratorLoss(GeneratorLoss):
         return _dispatch(self._runner, ("g",), _g_body(generator, discriminator), [noise],
                          generator, discriminator, generator, optimizer_generator)
 
-    def train_ops(self, generator, discriminator, optimizer_generator, device, batch_size, labels=None):
+    def train_ops_async(self, generator, discriminator, optimizer_generator, device, batch_size, labels=None):
         _check_labels(generator, discriminator, labels)
         noise = torch.randn(batch_size, generator.encoding_dims, device=device)
-        return self.step(generator, discriminator, optimizer_generator, noise).item()
+        return self.step(generator, discriminator, optimizer_generator, noise)
+
+    def train_ops(self, generator, discriminator, optimizer_generator, device, batch_size, labels=None):
+        return self.train_ops_async(generator, discriminator, optimizer_generator, device, batch_size, labels).item()
+    train_ops._rg_async = "train_ops_async"
 
 
 class WassersteinDiscriminatorLoss(DiscriminatorLoss):
@@ -524,14 +528,18 @@ class WassersteinDiscriminatorLoss(DiscriminatorLoss):
         return _dispatch(self._runner, ("d", clip), _d_body(generator, discriminator, clip),
                          [real, noise], generator, discriminator, discriminator, optimizer_discriminator)
 
-    def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
+    def train_ops_async(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
         _check_labels(generator, discriminator, labels)
         batch_size = real_inputs.size(0)
         noise = torch.randn(batch_size, generator.encoding_dims, device=device)
         nxt = None
         if TRAINER_LOOKAHEAD[0] and _lookahead_ok():       # the penalty plugin's randn, drawn now (same generator order)
             nxt = _NEXT_NOISE[0] = torch.randn(batch_size, generator.encoding_dims, device=device)
-        return self.step(generator, discriminator, optimizer_discriminator, real_inputs.to(device), noise, nxt).item()
+        return self.step(generator, discriminator, optimizer_discriminator, real_inputs.to(device), noise, nxt)
+
+    def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
+        return self.train_ops_async(generator, discriminator, optimizer_discriminator, real_inputs, device, labels).item()
+    train_ops._rg_async = "train_ops_async"
 
 
 class WassersteinGradientPenalty(DiscriminatorLoss):
@@ -554,15 +562,18 @@ class WassersteinGradientPenalty(DiscriminatorLoss):
         return _dispatch(self._runner, ("gp", lambd), _gp_body(generator, discriminator, lambd),
                          [real, noise, eps], generator, discriminator, discriminator, optimizer_discriminator)
 
-    def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
+    def train_ops_async(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
         _check_labels(generator, discriminator, labels)
         batch_size = real_inputs.size(0)
         noise, _NEXT_NOISE[0] = _NEXT_NOISE[0], None       # drawn ahead by the D-loss plugin (Trainer flow), else now
         if noise is None or noise.shape != (batch_size, generator.encoding_dims):
             noise = torch.randn(batch_size, generator.encoding_dims, device=device)
         eps = _pinned(1).uniform_(0.0, 1.0).to(device, non_blocking=True)   # CPU generator, as the reference
-        return self.step(generator, discriminator, optimizer_discriminator, real_inputs.to(device), noise,
-                         eps).item()
+        return self.step(generator, discriminator, optimizer_discriminator, real_inputs.to(device), noise, eps)
+
+    def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
+        return self.train_ops_async(generator, discriminator, optimizer_discriminator, real_inputs, device, labels).item()
+    train_ops._rg_async = "train_ops_async"
 
 
 # ------------------------------------------------------------------------------------------------
@@ -663,11 +674,17 @@ class WassersteinGeneratorLossVAE(GeneratorLoss, _VAEMixin):
                          _g_body(generator, discriminator, lambda z, uu: self._noise(generator, z, uu)),
                          [self._latent(rna), u], generator, discriminator, generator, optimizer_generator)
 
-    def train_ops(self, generator, discriminator, optimizer_generator, device, batch_size, real_inputs,
-                  labels=None):
+    def train_ops_async(self, generator, discriminator, optimizer_generator, device, batch_size, real_inputs,
+                        labels=None):
         _check_labels(generator, discriminator, labels)
         rna, u = self._inputs(generator, real_inputs, device)
-        return self.step(generator, discriminator, optimizer_generator, rna, u).item()
+        return self.step(generator, discriminator, optimizer_generator, rna, u)
+
+    def train_ops(self, generator, discriminator, optimizer_generator, device, batch_size, real_inputs,
+                  labels=None):
+        return self.train_ops_async(generator, discriminator, optimizer_generator, device, batch_size, real_inputs,
+                                    labels).item()
+    train_ops._rg_async = "train_ops_async"
 
 
 class WassersteinDiscriminatorLossVAE(DiscriminatorLoss, _VAEMixin):
@@ -690,14 +707,18 @@ class WassersteinDiscriminatorLossVAE(DiscriminatorLoss, _VAEMixin):
         return _dispatch(self._runner, ("d", clip), _d_body(generator, discriminator, clip, nf),
                          [real, self._latent(rna), u], generator, discriminator, discriminator, optimizer_discriminator)
 
-    def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
+    def train_ops_async(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
         _check_labels(generator, discriminator, labels)
         rna, u = self._inputs(generator, real_inputs, device)
         nxt = None
         if TRAINER_LOOKAHEAD[0] and _lookahead_ok():       # the penalty plugin's draw, made now (same generator order)
             nxt = _NEXT_NOISE[0] = self._inputs(generator, real_inputs, device)[1]
         real = real_inputs["image"].to(device)
-        return self.step(generator, discriminator, optimizer_discriminator, real, rna, u, nxt).item()
+        return self.step(generator, discriminator, optimizer_discriminator, real, rna, u, nxt)
+
+    def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
+        return self.train_ops_async(generator, discriminator, optimizer_discriminator, real_inputs, device, labels).item()
+    train_ops._rg_async = "train_ops_async"
 
 
 class WassersteinGradientPenaltyVAE(DiscriminatorLoss, _VAEMixin):
@@ -722,7 +743,7 @@ class WassersteinGradientPenaltyVAE(DiscriminatorLoss, _VAEMixin):
                          _gp_body(generator, discriminator, lambd, lambda z, uu: self._noise(generator, z, uu)),
                          [real, self._latent(rna), u, eps], generator, discriminator, discriminator, optimizer_discriminator)
 
-    def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
+    def train_ops_async(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
         _check_labels(generator, discriminator, labels)
         ahead, _NEXT_NOISE[0] = _NEXT_NOISE[0], None       # u drawn ahead by the D-loss plugin (Trainer flow), else now
         if ahead is not None and ahead.shape == (real_inputs["image"].size(0), generator.encoding_dims):
@@ -731,4 +752,8 @@ class WassersteinGradientPenaltyVAE(DiscriminatorLoss, _VAEMixin):
             rna, u = self._inputs(generator, real_inputs, device)
         real = real_inputs["image"].to(device)
         eps = _pinned(1).uniform_(0.0, 1.0).to(device, non_blocking=True)   # torch.rand(1) in the reference (:376)
-        return self.step(generator, discriminator, optimizer_discriminator, real, rna, u, eps).item()
+        return self.step(generator, discriminator, optimizer_discriminator, real, rna, u, eps)
+
+    def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
+        return self.train_ops_async(generator, discriminator, optimizer_discriminator, real_inputs, device, labels).item()
+    train_ops._rg_async = "train_ops_async"

@@ -37,6 +37,7 @@ class Trainer:
                  test_noise=None, nrow=8, precision="bf16", prefetch=True, **kwargs):
         self.device = torch.device(device)
         self.prefetch = bool(prefetch)          # extra knob: host batches are copied to the device one iteration ahead
+        self.pipeline = bool(kwargs.pop("pipeline", True))   # extra knob: see train_iter
         self.model_names = []
         self.optimizer_names = []
         self.schedulers = []
@@ -156,24 +157,88 @@ class Trainer:
             isinstance(a, L._VAEMixin) == isinstance(b, L._VAEMixin)
             for a, b in zip(names, names[1:]))
 
-    def train_iter(self):
-        lgen, ldis, gen_iter, dis_iter = 0.0, 0.0, 0, 0
+    def train_iter(self, carry=False):
+        """One batch through every loss plugin, in list order.  The library's own plugins split their
+        ``train_ops`` into an asynchronous launch (``train_ops_async``: all host-side work -- argument checks, random
+        draws, graph launch -- returning the loss as a device scalar) and the ``.item()`` that ``train_ops`` ends with.
+        With ``pipeline`` (default) the value of train_op k (copied to a pinned host slot right behind it, ``_post``) is read AFTER train_op k + 1 has been launched: same
+        launches, same draws, same values in the same order in ``loss_logs``, but the device queue never runs dry while the
+        host prepares the next launch (three idle gaps of 0.2-0.3 ms per iteration otherwise).  A plugin whose
+        ``train_ops`` is not the library's (a subclass override, a user plugin) is called as is.
+        carry (used by train()): the LAST train_op's .item() is left pending and taken by the next call after its first
+        launch (``flush_pending()`` takes it at the end of an epoch); its value is then part of the next call's sums -- the
+        epoch totals and ``loss_logs`` are unchanged."""
+        acc = {"g": 0.0, "d": 0.0}
+        gen_iter, dis_iter = 0, 0
+        pending = self.__dict__.setdefault("_pending", [])
+
+        def finish():
+            while pending:
+                name, kind, val = pending.pop(0)
+                cur = self._take(val)
+                self.loss_logs[name].append(cur)
+                acc[kind] += cur
+
         L.new_batch()          # the conditioning latent is encoded once per batch and shared by the loss plugins
         for name, loss in self.losses.items():
             if isinstance(loss, L.GeneratorLoss) and isinstance(loss, L.DiscriminatorLoss):
                 raise NotImplementedError("joint generator/discriminator losses are not on the RNA-GAN path")
             if isinstance(loss, L.GeneratorLoss):
-                if self.loss_information["discriminator_iters"] % self.ncritic == 0:
-                    cur = loss.train_ops(**self._get_arguments(self._arg_maps[name]))
-                    self.loss_logs[name].append(cur)
-                    lgen += cur
-                    gen_iter += 1
+                if self.loss_information["discriminator_iters"] % self.ncritic != 0:
+                    continue
+                kind = "g"
+                gen_iter += 1
             elif isinstance(loss, L.DiscriminatorLoss):
-                cur = loss.train_ops(**self._get_arguments(self._arg_maps[name]))
-                self.loss_logs[name].append(cur)
-                ldis += cur
+                kind = "d"
                 dis_iter += 1
-        return lgen, ldis, gen_iter, dis_iter
+            else:
+                continue
+            twin = getattr(type(loss).train_ops, "_rg_async", None) if getattr(self, "pipeline", True) else None
+            fn = getattr(loss, twin) if twin else loss.train_ops
+            val = fn(**self._get_arguments(self._arg_maps[name]))
+            if twin:
+                val = self._post(val)
+            finish()           # the PREVIOUS train_op's value: its copy to the host was enqueued before the launch just made
+            pending.append((name, kind, val))
+        if not carry:
+            finish()
+        return acc["g"], acc["d"], gen_iter, dis_iter
+
+    def _post(self, val):
+        """Enqueue the copy of a train_op's device scalar into a pinned host slot right behind that train_op (a later
+        ``tensor.item()`` would be ordered behind whatever has been launched since -- i.e. behind the NEXT train_op); returns
+        (slot, event)."""
+        if not (torch.is_tensor(val) and val.is_cuda):
+            return val
+        ring = self.__dict__.setdefault("_host_ring", [])
+        if not ring:
+            for _ in range(4):
+                ring.append((torch.empty(1, dtype=torch.float32, pin_memory=True), torch.cuda.Event()))
+            self._host_ring_pos = 0
+        slot, ev = ring[self._host_ring_pos % len(ring)]
+        self._host_ring_pos += 1
+        slot.copy_(val.detach().reshape(1).float(), non_blocking=True)
+        ev.record(torch.cuda.current_stream(val.device))
+        return slot, ev
+
+    @staticmethod
+    def _take(val):
+        if isinstance(val, tuple):
+            slot, ev = val
+            ev.synchronize()
+            return slot.item()
+        return val.item() if torch.is_tensor(val) else val
+
+    def flush_pending(self):
+        """Take the value a train_iter(carry=True) left pending; returns its (generator, discriminator) loss sums."""
+        acc = {"g": 0.0, "d": 0.0}
+        pending = self.__dict__.setdefault("_pending", [])
+        while pending:
+            name, kind, val = pending.pop(0)
+            cur = self._take(val)
+            self.loss_logs[name].append(cur)
+            acc[kind] += cur
+        return acc["g"], acc["d"]
 
     def sample_images(self, epoch):
         if D_.rank() != 0 or not self.recon:
@@ -205,11 +270,14 @@ class Trainer:
                     self.real_inputs = data.to(self.device)
                 else:
                     self.real_inputs = data
-                lgen, ldis, gen_iter, dis_iter = self.train_iter()
+                lgen, ldis, gen_iter, dis_iter = self.train_iter(carry=getattr(self, "pipeline", True))
                 self.loss_information["generator_losses"] += lgen
                 self.loss_information["discriminator_losses"] += ldis
                 self.loss_information["generator_iters"] += gen_iter
                 self.loss_information["discriminator_iters"] += dis_iter
+            lgen, ldis = self.flush_pending()
+            self.loss_information["generator_losses"] += lgen
+            self.loss_information["discriminator_losses"] += ldis
             self.save_model(epoch)
             if D_.rank() == 0:
                 gi = max(self.loss_information["generator_iters"], 1)

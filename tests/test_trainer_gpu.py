@@ -420,3 +420,46 @@ def test_cli_trains_on_mixed_tissue_tables(tmp_path):
     assert files, "no checkpoint written"
     ck = torch.load(files[0], map_location="cpu", weights_only=False)
     assert {"epoch", "generator", "discriminator", "optimizer_generator", "optimizer_discriminator"} <= set(ck)
+
+
+def test_pipelined_train_iter_matches_the_synchronous_loop(tmp_path):
+    """Trainer(pipeline=True) takes train_op k's .item() after launching train_op k + 1; the launches, the random draws and
+    therefore every logged loss value are those of the synchronous loop (pipeline=False), bit for bit, through the eager
+    iterations and the graph replays; a plugin whose train_ops is overridden is called synchronously as written."""
+    import random
+    logs = {}
+    for pipeline in (False, True):
+        torch.manual_seed(3); random.seed(3)
+        imgs = R.synthetic_images(48, 32, seed=9)
+        loader = DataLoader(TensorDataset(imgs, torch.zeros(48)), batch_size=8)
+        losses = [P.WassersteinGeneratorLoss(), P.WassersteinDiscriminatorLoss(), P.WassersteinGradientPenalty()]
+        tr = P.Trainer(network(), losses, checkpoints=str(tmp_path / ("p%d" % pipeline)), sample_size=4, epochs=1,
+                       recon=None, pipeline=pipeline)
+        assert tr.pipeline is pipeline
+        tr(loader)
+        assert tr.loss_information["generator_iters"] == 6 and tr.loss_information["discriminator_iters"] == 12
+        logs[pipeline] = ({k: list(v) for k, v in tr.loss_logs.items()}, dict(tr.loss_information),
+                          {k: v.detach().cpu().clone() for k, v in tr.generator.state_dict().items()})
+    a, b = logs[False], logs[True]
+    assert a[0] == b[0] and all(isinstance(x, float) for v in b[0].values() for x in v)
+    # epoch totals: the same numbers summed in a different grouping (the last train_op of an iteration is added with the next)
+    for k in a[1]:
+        assert a[1][k] == pytest.approx(b[1][k], rel=1e-12, abs=1e-12), k
+    assert all(torch.equal(a[2][k], b[2][k]) for k in a[2])
+
+    calls = []
+
+    class Custom(P.WassersteinDiscriminatorLoss):
+        def train_ops(self, generator, discriminator, optimizer_discriminator, real_inputs, device, labels=None):
+            calls.append("custom")
+            return 1.25
+    assert getattr(Custom.train_ops, "_rg_async", None) is None
+    tr = P.Trainer.__new__(P.Trainer)
+    tr.losses = {"Custom": Custom()}
+    tr.loss_logs = {"Custom": []}
+    tr.loss_information = {"generator_losses": 0.0, "discriminator_losses": 0.0, "generator_iters": 0, "discriminator_iters": 0}
+    tr.ncritic, tr.pipeline = 1, True
+    for k in ("generator", "discriminator", "optimizer_discriminator", "real_inputs", "device", "labels"):
+        setattr(tr, k, None)
+    tr._store_loss_maps()
+    assert tr.train_iter() == (0.0, 1.25, 0, 1) and calls == ["custom"] and tr.loss_logs["Custom"] == [1.25]
