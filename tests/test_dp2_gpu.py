@@ -1,0 +1,202 @@
+"""The data-parallel path at WORLD SIZE 2 on real kernels.  The GPU box has one device, and RCCL refuses two
+ranks on one device, so the two rank processes share cuda:0 and all-reduce over gloo (which stages device tensors through
+the host): everything else is the product's DP route exactly as an 8-GPU run takes it -- the loss plugins' step() ->
+losses._Runner.run_dp: graph(prefix) / flush of the pending optimizer step / graph(rest) / gradient all-reduce started
+eagerly, the optimizer step applied by the NEXT train_op after its prefix, 1/world folded into the backward seed, rank-local
+BatchNorm statistics, the D-loss prefix = D(real) forward + backward.
+
+Checked against a CPU emulation of DistributedDataParallel semantics on the oracle (two replicas with shared parameters and
+their own BatchNorm buffers; per train_op: autograd on each replica's shard, gradients averaged, the same Adam step on both):
+rank-local loss values, the parameter UPDATES (direction), the rank-local BatchNorm buffers; and both ranks must end with
+bit-identical parameters.  fp32 kernels / fp32 wire for the tight comparison, then the bf16 kernels with the bf16 wire (when
+this gloo build reduces bfloat16; fp32 wire otherwise) against the fp32 run."""
+import copy
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_cpu as R
+
+IN_SIZE, STEP, ENC, N, ITERS = 32, 64, 128, 8, 3
+
+WORKER = r'''
+import os, sys, torch, torch.nn as nn
+sys.path.insert(0, os.environ["REPO"])
+import torch.distributed as dist
+from rna_gan_amd import dist as D_, losses as PL
+import rna_gan_amd as P
+from oracle import ref_cpu as R
+rank = int(os.environ["RANK"])
+torch.cuda.set_device(0)
+D_.init_from_env(backend="gloo")
+assert D_.world_size() == 2 and D_.active()
+precision = os.environ["PRECISION"]
+if precision == "bf16":                       # does this gloo build all-reduce bfloat16 device tensors?
+    try:
+        t = torch.ones(8, dtype=torch.bfloat16, device="cuda")
+        dist.all_reduce(t)
+        wire = "bf16" if float(t[0]) == 2.0 else "fp32"
+    except Exception:
+        wire = "fp32"
+    if wire == "fp32":
+        D_.COMPRESS = False
+else:
+    wire = "fp32"
+in_size, step, enc, n, iters = [int(v) for v in os.environ["SHAPE"].split(",")]
+G0 = R.seeded_fill_(R.OracleDCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh()), 7)
+D0 = R.seeded_fill_(R.OracleDCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.LeakyReLU(0.2)), 8)
+G = P.DCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+D = P.DCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.LeakyReLU(0.2))
+G.load_state_dict(G0.state_dict()); D.load_state_dict(D0.state_dict())
+G.set_precision(precision); D.set_precision(precision)
+G, D = G.cuda().train(), D.cuda().train()
+og = P.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.999)).bind(G)
+od = P.Adam(D.parameters(), lr=4e-4, betas=(0.5, 0.999)).bind(D)
+lg, ld, lp = PL.WassersteinGeneratorLoss(), PL.WassersteinDiscriminatorLoss(), PL.WassersteinGradientPenalty()
+losses = []
+for it in range(iters):
+    real = R.synthetic_images(n, in_size, seed=100 + 10 * it + rank).cuda()
+    nz = [R.synthetic_normal(n, enc, seed=200 + 30 * it + 3 * rank + j).cuda() for j in range(3)]
+    eps = torch.tensor([0.15 + 0.2 * it + 0.3 * rank], device="cuda")
+    losses += [lg.step(G, D, og, nz[0]).item(), ld.step(G, D, od, real, nz[1]).item(), lp.step(G, D, od, real, nz[2], eps).item()]
+PL.flush()
+torch.cuda.synchronize()
+torch.save({"losses": losses, "wire": wire, "G": {k: v.cpu() for k, v in G.state_dict().items()},
+            "D": {k: v.cpu() for k, v in D.state_dict().items()}}, os.environ["OUT"] + str(rank))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _run_world2(tmp_path, precision):
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / ("dp2_%s_rank" % precision))
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, REPO=repo, OUT=out, PRECISION=precision, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", RNAGAN_FORCE_DP="0",
+                   SHAPE="%d,%d,%d,%d,%d" % (IN_SIZE, STEP, ENC, N, ITERS))
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                      text=True))
+    for p in procs:
+        try:
+            _, err = p.communicate(timeout=400)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, err[-3000:]
+    return [torch.load(out + str(r)) for r in range(2)]
+
+
+def _ddp_oracle():
+    """DistributedDataParallel semantics on the CPU oracle: replicas share parameters, keep their own BatchNorm buffers."""
+    mk_g = lambda: R.seeded_fill_(R.OracleDCGANGenerator(ENC, IN_SIZE, 3, STEP, nonlinearity=nn.LeakyReLU(0.2),
+                                                          last_nonlinearity=nn.Tanh()), 7).double().train()
+    mk_d = lambda: R.seeded_fill_(R.OracleDCGANDiscriminator(IN_SIZE, 3, STEP, nonlinearity=nn.LeakyReLU(0.2),
+                                                              last_nonlinearity=nn.LeakyReLU(0.2)), 8).double().train()
+    Gs, Ds = [mk_g(), mk_g()], [mk_d(), mk_d()]
+    ogs = [R.make_adam(g.parameters(), 1e-4) for g in Gs]
+    ods = [R.make_adam(d.parameters(), 4e-4) for d in Ds]
+
+    def average_and_step(mods, opts):
+        for ps in zip(*[list(m.parameters()) for m in mods]):
+            g = sum(p.grad for p in ps) / len(ps)
+            for p in ps:
+                p.grad = g.clone()
+        for o in opts:
+            o.step()
+
+    def zero(mods):
+        for m in mods:
+            for p in m.parameters():
+                p.grad = None
+    losses = [[], []]
+    for it in range(ITERS):
+        data = []
+        for r in range(2):
+            real = R.synthetic_images(N, IN_SIZE, seed=100 + 10 * it + r).double()
+            nz = [R.synthetic_normal(N, ENC, seed=200 + 30 * it + 3 * r + j).double() for j in range(3)]
+            data.append((real, nz, 0.15 + 0.2 * it + 0.3 * r))
+        zero(Gs + Ds)
+        for r in range(2):
+            l = R.generator_loss(Ds[r](Gs[r](data[r][1][0]))); l.backward(); losses[r].append(float(l.detach()))
+        average_and_step(Gs, ogs)
+        zero(Gs + Ds)
+        for r in range(2):
+            real, nz, _ = data[r]
+            l = R.discriminator_loss(Ds[r](real), Ds[r](Gs[r](nz[1]).detach())); l.backward(); losses[r].append(float(l.detach()))
+        average_and_step(Ds, ods)
+        zero(Gs + Ds)
+        for r in range(2):
+            real, nz, eps = data[r]
+            xhat = eps * real + (1 - eps) * Gs[r](nz[2])
+            gp = R.gradient_penalty(xhat, Ds[r](xhat)); (10.0 * gp).backward(); losses[r].append(float(gp.detach()))
+        average_and_step(Ds, ods)
+    return Gs, Ds, losses
+
+
+def test_world2_plugins_match_ddp_semantics(tmp_path):
+    res = _run_world2(tmp_path, "fp32")
+    Gs, Ds, want_losses = _ddp_oracle()
+    init_g = R.seeded_fill_(R.OracleDCGANGenerator(ENC, IN_SIZE, 3, STEP, nonlinearity=nn.LeakyReLU(0.2),
+                                                   last_nonlinearity=nn.Tanh()), 7).state_dict()
+    init_d = R.seeded_fill_(R.OracleDCGANDiscriminator(IN_SIZE, 3, STEP, nonlinearity=nn.LeakyReLU(0.2),
+                                                       last_nonlinearity=nn.LeakyReLU(0.2)), 8).state_dict()
+    for r in range(2):
+        got = res[r]["losses"]
+        for i, (a, b) in enumerate(zip(got, want_losses[r])):
+            assert np.isfinite(a) and abs(a - b) <= 2e-3 * (abs(b) + 0.5), (r, i, got, want_losses[r])
+        for name, sd, mod, init in (("G", res[r]["G"], Gs[r], init_g), ("D", res[r]["D"], Ds[r], init_d)):
+            params = dict(mod.named_parameters())
+            for k, v in sd.items():
+                if k in params:
+                    du = v.double() - init[k].double()
+                    dr = params[k].detach().double() - init[k].double()
+                    cos = float((du * dr).sum() / (du.norm() * dr.norm() + 1e-30))
+                    # nine Adam steps of ~lr * sign(g): the cosine counts sign agreements, element by element
+                    assert cos >= (0.98 if dr.numel() >= 4096 else 0.9), (r, name, k, cos)
+                elif k.endswith("num_batches_tracked"):
+                    assert int(v) == int(dict(mod.named_buffers())[k]), (r, k)
+                else:       # BatchNorm running statistics are RANK-LOCAL: replica r's buffers, not an average
+                    b = dict(mod.named_buffers())[k].double()
+                    assert float((v.double() - b).norm() / (b.norm() + 1e-30)) <= 2e-3, (r, name, k)
+    # one all-reduced gradient, one optimizer: the two ranks hold the same parameters bit for bit; their statistics differ
+    for name in ("G", "D"):
+        a, b = res[0][name], res[1][name]
+        for k in a:
+            if "running_" in k:
+                continue
+            assert torch.equal(a[k], b[k]), (name, k)
+    assert any(not torch.equal(res[0]["D"][k], res[1]["D"][k]) for k in res[0]["D"] if "running_mean" in k)
+
+
+def test_world2_bf16_kernels_and_wire(tmp_path):
+    f32 = _run_world2(tmp_path, "fp32")
+    b16 = _run_world2(tmp_path, "bf16")
+    print("all-reduce wire of the bf16 run:", b16[0]["wire"])
+    for name in ("G", "D"):
+        for k in b16[0][name]:
+            if "running_" not in k:
+                assert torch.equal(b16[0][name][k], b16[1][name][k]), (name, k)
+    for r in range(2):
+        for i, (a, b) in enumerate(zip(b16[r]["losses"], f32[r]["losses"])):
+            assert np.isfinite(a) and abs(a - b) <= (0.35 if i % 3 == 2 else 6e-2) * (abs(b) + 0.5), (r, i, a, b)
+    for name in ("G", "D"):
+        for k, v in b16[0][name].items():
+            if v.dtype.is_floating_point and "running_" not in k:
+                rel = float((v.double() - f32[0][name][k].double()).norm() / (f32[0][name][k].double().norm() + 1e-30))
+                assert rel <= 1e-2, (name, k, rel)
