@@ -96,26 +96,56 @@ def gp_grad_scale() -> float:
 
 
 _wire = {}
+# Generator layer 0's weight gradient is a rank-(batch) product dW = z^T gz0 (K = the batch): the ranks all-gather its
+# FACTORS (per rank 64 x 2048 fp32 + 64 x 32768 bf16 = 4.7 MB) instead of all-reducing the 67 M-element product (134 MB on the
+# bf16 wire, 60 % of the generator's collective), and every rank forms sum_r z_r^T gz0_r inside its fused Adam step
+# (rg_g0_wgrad_adam with K = world x batch, fp32 accumulation over ALL ranks' samples -- more accurate than a bf16 ring sum).
+G0_FACTORS = os.environ.get("RNAGAN_DP_G0_FACTORS", "1") != "0"
+_factors = {}
 
 
-def allreduce_start(flat: torch.Tensor, compress: bool = False):
+def factor_buffers(key, n, E, C, gy_dtype, device):
+    """Persistent gathered-factor buffers of one module: (z_all [W n, E] fp32, gy_all [W n, 4, 4, C]) and this rank's slices."""
+    W, r = world_size(), rank()
+    k = (key, n, E, C, gy_dtype, device, W)
+    buf = _factors.get(k)
+    if buf is None:
+        z_all = torch.zeros(W * n, E, dtype=torch.float32, device=device)
+        gy_all = torch.zeros(W * n, 4, 4, C, dtype=gy_dtype, device=device)
+        buf = _factors[k] = (z_all, gy_all, z_all[r * n:(r + 1) * n], gy_all[r * n:(r + 1) * n])
+    return buf
+
+
+def allgather_start(full: torch.Tensor, mine: torch.Tensor):
+    """Start the all-gather of per-rank row blocks into ``full`` (``mine`` = this rank's block, a slice of ``full``)."""
+    if world_size() == 1:
+        return None
+    try:
+        return dist.all_gather_into_tensor(full, mine, async_op=True)
+    except (RuntimeError, NotImplementedError):          # a backend without the flat form: per-rank views
+        return dist.all_gather(list(full.chunk(world_size(), dim=0)), mine.clone(), async_op=True)
+
+
+def allreduce_start(flat: torch.Tensor, compress: bool = False, head: int = 0):
     """Start the in-place SUM all-reduce of a flat fp32 gradient buffer (fixed-size buckets, asynchronous: RCCL runs
     on its own stream behind everything enqueued so far on the current one).  Returns a handle for
-    allreduce_finish(); None when there is nothing to reduce.  `flat` must not be written before the finish."""
+    allreduce_finish(); None when there is nothing to reduce.  `flat` must not be written before the finish.
+    head: the first `head` elements are NOT reduced (their gradient travels as gathered factors, see G0_FACTORS)."""
     if not active():
         return None
+    n = flat.numel()
     if compress and COMPRESS and flat.is_cuda and flat.dtype == torch.float32:
         from . import _abi
         lib = _abi.load()
-        n = flat.numel()
         key = (flat.device, n)
         wire = _wire.get(key)
         if wire is None:
             wire = _wire[key] = torch.empty(n, dtype=torch.bfloat16, device=flat.device)
         stream = torch.cuda.current_stream(flat.device).cuda_stream
-        _abi.check(lib.rg_cast_pad(flat.data_ptr(), wire.data_ptr(), 1, n, n, _abi.RG_BF16, stream), "rg_cast_pad")
-        return (wire, flat, _launch_buckets(wire, BUCKET_BYTES // 2))
-    return (None, flat, _launch_buckets(flat, BUCKET_BYTES // flat.element_size()))
+        _abi.check(lib.rg_cast_pad(flat.data_ptr() + 4 * head, wire.data_ptr() + 2 * head, 1, n - head, n - head,
+                                   _abi.RG_BF16, stream), "rg_cast_pad")
+        return (wire, flat, _launch_buckets(wire[head:], BUCKET_BYTES // 2))
+    return (None, flat, _launch_buckets(flat[head:], BUCKET_BYTES // flat.element_size()))
 
 
 def allreduce_finish(handle, widen=True):

@@ -44,7 +44,7 @@ class ConvW:
     """
 
     __slots__ = ("w", "bias", "dw", "dbias", "packs", "packs_version", "version", "layout", "shadow",
-                 "shadow_version", "_fp8", "fuse_step", "pending_wgrad")
+                 "shadow_version", "_fp8", "fuse_step", "pending_wgrad", "factor_stage")
 
     def __init__(self, w, bias=None, dw=None, dbias=None, layout="OIHW"):
         self.w = w
@@ -63,6 +63,9 @@ class ConvW:
         # the fused Adam then forms the gradient and applies the step in one kernel (rg_g0_wgrad_adam)
         self.fuse_step = False
         self.pending_wgrad = None
+        # data parallel: (z slot, gz0 slot) = this rank's slices of the gathered factor buffers; g0_wgrad then copies its
+        # operands there (the ranks all-gather the FACTORS of the rank-64 gradient instead of all-reducing the gradient)
+        self.factor_stage = None
 
     @classmethod
     def from_param(cls, weight, grad=None):

@@ -379,8 +379,28 @@ FUSED_WIDEN = os.environ.get("RNAGAN_DP_FUSED_WIDEN", "1") != "0"
 
 
 class _Pending:
-    def __init__(self, module, optimizer, handle):
-        self.module, self.optimizer, self.handle = module, optimizer, handle
+    def __init__(self, module, optimizer, handle, factors=None):
+        self.module, self.optimizer, self.handle, self.factors = module, optimizer, handle, factors
+
+
+def _dp_factor_g0(stepped, optimizer, batch):
+    """Data parallel: (g0 handle, gathered-factor buffers) when the stepped module's layer-0 weight gradient can travel as
+    FACTORS (dist.G0_FACTORS): DCGAN generator stepped by rna_gan_amd.optim.Adam bound to it, bf16 kernels, rank-local
+    statistics, and the fused kernel takes K = world x batch."""
+    if not (D_.G0_FACTORS and G0_ADAM and D_.active()) or D_.sync_stats():
+        return None
+    if not hasattr(optimizer, "note_replayed") or getattr(optimizer, "_module", None) is not stepped:
+        return None
+    ops, net = stepped.runtime()
+    g0 = getattr(net, "g0", None)
+    if g0 is None or not isinstance(net, E.GenNet) or ops.act_dtype != torch.bfloat16:
+        return None
+    En, C = g0.w.shape[0], g0.w.shape[1]
+    if (g0.w.data_ptr() - stepped.flat.data.data_ptr()) != 0:
+        return None
+    if not ops.lib.rg_g0_wgrad_adam_supported(D_.world_size() * batch, En, C, ops.dt):
+        return None
+    return g0, D_.factor_buffers(id(stepped), batch, En, C, torch.bfloat16, stepped.flat.data.device), ops.dt
 
 
 def flush():
@@ -392,11 +412,22 @@ def flush():
     # rna_gan_amd.optim.Adam steps straight from the all-reduced bf16 wire buffer (no widening pass; .grad then keeps
     # the rank-local gradient); other optimizers get the averaged gradient back in .grad first
     wire = D_.wire_of(pend.handle) if FUSED_WIDEN and hasattr(pend.optimizer, "grad_wire") else None
-    D_.allreduce_finish(pend.handle, widen=wire is None)
+    D_.allreduce_finish(pend.handle, widen=wire is None and pend.factors is None)
+    fac = pend.factors
+    if fac is not None:
+        g0, (z_all, gy_all, _, _), dt, works = fac
+        for w in works:
+            if w is not None:
+                w.wait()
+        g0.pending_wgrad = (z_all, gy_all, dt)     # every rank's samples: the fused step forms sum_r z_r^T gz0_r itself
     if hasattr(pend.optimizer, "grad_wire"):
         pend.optimizer.grad_wire = wire
-    _APPLY_RUNNER.run(("apply", id(pend.module), wire is not None), lambda: _apply(pend.module, pend.optimizer), [], [],
-                      [pend.optimizer], [pend.module])
+    try:
+        _APPLY_RUNNER.run(("apply", id(pend.module), wire is not None, fac is not None),
+                          lambda: _apply(pend.module, pend.optimizer), [], [], [pend.optimizer], [pend.module])
+    finally:
+        if fac is not None:
+            fac[0].pending_wgrad = None
     if hasattr(pend.optimizer, "grad_wire"):
         pend.optimizer.grad_wire = None
 
@@ -433,14 +464,34 @@ class _Runner:
         # captured, so the rest graph is tied to that prefix graph and may only be captured after it
         holder = self._pre.setdefault((key, id(sg_pre)), {})
         holder["pre"] = pre
-        sg_rest = self._step_graph(key + ("rest", id(sg_pre)), lambda: body.rest(holder["pre"]), [], modules, [], [])
+        # generator-loss step: layer 0's weight gradient travels as gathered factors (dist.G0_FACTORS): the backward copies
+        # z / gz0 into this rank's slices of the gathered buffers instead of forming the 67 M-element product
+        fac = _dp_factor_g0(stepped, optimizer, inputs[0].shape[0]) if stepped is body.prefix_reads and inputs else None
+
+        def rest():
+            if fac is None:
+                return body.rest(holder["pre"])
+            g0, bufs = fac[0], fac[1]
+            g0.fuse_step, g0.factor_stage = True, (bufs[2], bufs[3])
+            try:
+                out = body.rest(holder["pre"])
+                if g0.pending_wgrad != "staged":
+                    raise RuntimeError("data-parallel G step: layer 0's weight gradient was not left as factors")
+                return out
+            finally:
+                g0.fuse_step, g0.factor_stage, g0.pending_wgrad = False, None, None
+        sg_rest = self._step_graph(key + ("rest", id(sg_pre), fac is not None), rest, [], modules, [], [])
         if sg_rest is not None:
             loss = sg_rest(allow_capture=sg_pre is not None and sg_pre.graph is not None)
         else:
-            loss = body.rest(pre)
+            loss = rest()
         ops, _ = stepped.runtime()
-        handle = D_.allreduce_start(stepped.flat.grad, compress=(ops.act_dtype == torch.bfloat16))
-        _PENDING[0] = _Pending(stepped, optimizer, handle)
+        head = fac[0].w.numel() if fac is not None else 0
+        handle = D_.allreduce_start(stepped.flat.grad, compress=(ops.act_dtype == torch.bfloat16), head=head)
+        if fac is not None:
+            z_all, gy_all, z_mine, gy_mine = fac[1]
+            fac = fac + ([D_.allgather_start(z_all, z_mine), D_.allgather_start(gy_all, gy_mine)],)
+        _PENDING[0] = _Pending(stepped, optimizer, handle, fac)
         if not OVERLAP:
             flush()
         return loss

@@ -690,7 +690,19 @@ class HipOps:
         N, E = z.shape
         C = gy.shape[3]
         if not self.lib.rg_g0_wgrad_adam_supported(N, E, C, self.dt) or not z.is_contiguous() or not gy.is_contiguous():
+            if cw.factor_stage is not None:
+                raise RuntimeError("g0_wgrad_deferred: the data-parallel runner announced gathered factors for a shape the "
+                                   "fused kernel does not take")
             return False
+        if cw.factor_stage is not None:
+            # data parallel: the operands go into this rank's slices of the gathered buffers (persistent memory: the
+            # collective reads them after this graph's pool may have been handed to the next graph); losses.flush hands the
+            # GATHERED factors to the optimizer
+            zs, gs = cw.factor_stage
+            zs.copy_(z)
+            gs.copy_(gy.reshape(gs.shape))
+            cw.pending_wgrad = "staged"
+            return True
         cw.pending_wgrad = (z, gy, self.dt)
         return True
 

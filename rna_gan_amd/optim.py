@@ -142,9 +142,11 @@ class Adam(torch.optim.Adam):
             z, gy, dt = pend
             off = (g0.w.data_ptr() - flat.data.data_ptr()) // 4
             n0 = g0.w.numel()
-            if off != 0 or self.grad_wire is not None:
+            if off != 0:
                 raise RuntimeError("rna_gan_amd.optim.Adam: the deferred G.0 weight gradient expects that tensor at the head "
-                                   "of the flat buffer and a single-process step")
+                                   "of the flat buffer")
+            # (data parallel: z / gy are the factors gathered from all ranks, K = world x batch; the rest of the buffer steps
+            # from the all-reduced wire below)
             E, C = g0.w.shape[0], g0.w.shape[1]
             check(lib.rg_g0_wgrad_adam(z.data_ptr(), gy.data_ptr(), flat.data.data_ptr(), self._m.data_ptr(),
                                        self._v.data_ptr(), self._hyper.data_ptr(), 0 if shadow is None else shadow.data_ptr(),

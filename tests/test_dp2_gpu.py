@@ -9,7 +9,8 @@ Checked against a CPU emulation of DistributedDataParallel semantics on the orac
 their own BatchNorm buffers; per train_op: autograd on each replica's shard, gradients averaged, the same Adam step on both):
 rank-local loss values, the parameter UPDATES (direction), the rank-local BatchNorm buffers; and both ranks must end with
 bit-identical parameters.  fp32 kernels / fp32 wire for the tight comparison, then the bf16 kernels with the bf16 wire (when
-this gloo build reduces bfloat16; fp32 wire otherwise) against the fp32 run."""
+this gloo build reduces bfloat16; fp32 wire otherwise) against the fp32 run -- that run also takes the gathered-factor route for
+generator layer 0 (dist.G0_FACTORS: all-gather of z / gz0, the product formed over both ranks' samples inside the Adam step)."""
 import copy
 import os
 import socket
@@ -69,7 +70,7 @@ for it in range(iters):
     losses += [lg.step(G, D, og, nz[0]).item(), ld.step(G, D, od, real, nz[1]).item(), lp.step(G, D, od, real, nz[2], eps).item()]
 PL.flush()
 torch.cuda.synchronize()
-torch.save({"losses": losses, "wire": wire, "G": {k: v.cpu() for k, v in G.state_dict().items()},
+torch.save({"losses": losses, "wire": wire, "factors": len(D_._factors) > 0, "G": {k: v.cpu() for k, v in G.state_dict().items()},
             "D": {k: v.cpu() for k, v in D.state_dict().items()}}, os.environ["OUT"] + str(rank))
 dist.barrier()
 dist.destroy_process_group()
@@ -188,6 +189,9 @@ def test_world2_bf16_kernels_and_wire(tmp_path):
     f32 = _run_world2(tmp_path, "fp32")
     b16 = _run_world2(tmp_path, "bf16")
     print("all-reduce wire of the bf16 run:", b16[0]["wire"])
+    # generator layer 0's weight gradient travelled as all-gathered factors (dist.G0_FACTORS) in the bf16 run: both ranks formed
+    # sum_r z_r^T gz0_r inside the fused Adam step; the fp32 run all-reduced the product
+    assert b16[0]["factors"] and b16[1]["factors"] and not f32[0]["factors"]
     for name in ("G", "D"):
         for k in b16[0][name]:
             if "running_" not in k:
