@@ -114,6 +114,10 @@ int rg_convp_launch(const void* args, hipStream_t st);
 // rg_wgrad8.hip (8-wave ping-pong weight gradient)
 bool rg_wgrad8_supported(int K, int O, int I);
 int rg_wgrad8_split(int K, int O, int I, int* kt_per_split);
+bool rg_wgrad8n_supported(int K, int O, int I);
+int rg_wgrad8n_split(int K, int O, int I, int* kt_per_split);
+int rg_wgrad8n_launch(const void* low0, const void* high0, const void* low1, const void* high1, float* out, int Kseg,
+                      int two, int O, int I, int Ho, int Wo, int nsplit, int kt_per_split, int accumulate, hipStream_t st);
 int rg_wgrad8_launch(const void* low0, const void* high0, const void* low1, const void* high1, float* out, int Kseg,
                      int two, int O, int I, int Ho, int Wo, int nsplit, int kt_per_split, int accumulate, hipStream_t st);
 

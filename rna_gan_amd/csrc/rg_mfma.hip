@@ -1576,6 +1576,17 @@ int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, c
       return rg_reduce_slabs((const float*)ws, dw, elems, ns, accumulate, 0, 0, st);
     }
   }
+  // the 128 x 512 form of that kernel (O = 128 layers); option value 2: only for K >= 2^19 pixels (two segments / batch 128)
+  if (rg_option("wgrad8n", 1) && rg_wgrad8n_supported(K, O, I) && (rg_option("wgrad8n", 1) != 2 || K >= (1 << 19))) {
+    int per = 0;
+    const int ns = rg_wgrad8n_split(K, O, I, &per);
+    if (ns == 1 || (ws && ws_bytes >= (size_t)ns * elems * sizeof(float))) {
+      int rc = rg_wgrad8n_launch(low0, high0, low1, high1, ns == 1 ? dw : (float*)ws, Kseg, two ? 1 : 0, O, I, Ho, Wo, ns,
+                                 per, accumulate, st);
+      if (rc || ns == 1) return rc;
+      return rg_reduce_slabs((const float*)ws, dw, elems, ns, accumulate, 0, 0, st);
+    }
+  }
   int nsplit = mfma_wgrad_split_k(K, O, I);
   RG_REQUIRE(ws && ws_bytes >= (size_t)nsplit * elems * sizeof(float), RG_EWORKSPACE,
              "conv_wgrad(mfma): workspace too small");
@@ -1607,6 +1618,10 @@ size_t rg_mfma_wgrad2_ws_bytes(int N, int Ho, int Wo, int O, int I) {
     if (rg_wgrad8_supported(k * N * Ho * Wo, O, I)) {
       int per = 0;
       const size_t c = (size_t)rg_wgrad8_split(k * N * Ho * Wo, O, I, &per) * O * I * 16 * sizeof(float);
+      if (c > m) m = c;
+    } else if (rg_wgrad8n_supported(k * N * Ho * Wo, O, I)) {
+      int per = 0;
+      const size_t c = (size_t)rg_wgrad8n_split(k * N * Ho * Wo, O, I, &per) * O * I * 16 * sizeof(float);
       if (c > m) m = c;
     }
   return m;

@@ -307,6 +307,284 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(W8Args g) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same pipeline for the layers with 128 low-side channels (O = 128: D.1 and the generator's 128 -> 64 block), which the
+// 256 x 256 tile cannot cover: block tile 128 (o) x 512 (tap, i) -- 8 waves of 64 (o) x 4 x 32 columns, FIVE 16 KB half-tiles
+// per 64-pixel k-tile (A0 = the 128 channels of `low`, B0..B3 = four 128-column slices of the gathered `high`), two stages =
+// all 160 KB of LDS.  105 FLOP per operand byte against 64 of the 128 x 128 tile these layers ran on (wgrad_dma_kernel).
+// Phases of k-tile u (stage S), one MFMA group of 8 per phase and wave; every DMA is issued TWO phases after the last read of
+// the slot it overwrites (as in wgrad8_kernel: the other wave group is one barrier behind and may still have that read in
+// flight one phase later), six phases ahead of its first read:
+//   P0: read A0(u)            issue B2(u+1)            MFMA A0 x B0(u)        (B0(u) was read in P3 of k-tile u - 1)
+//   P1: read B1(u)            issue B3(u+1), B0(u+2)   MFMA A0 x B1
+//   P2: read B2(u)            issue A0(u+2)            MFMA A0 x B2
+//   P3: read B3(u), B0(u+1)   issue B1(u+2)            MFMA A0 x B3
+// Issue order per k-tile is B0 A0 B1 B2 B3; behind the half-tile the NEXT phase reads there are six younger ones (P1: seven),
+// so vmcnt(12) is the wait of every phase (checked by simulation of the issue / read sequence).
+__global__ __launch_bounds__(512, 2) void wgrad8n_kernel(W8Args g) {
+  constexpr int HT = 64 * 256;                     // bytes per half-tile: 64 pixels x 128 channels bf16
+  constexpr int STAGE = 5 * HT;                    // [B0][B1][B2][B3][A0]
+  constexpr int OFF_B = 0, OFF_A = 4 * HT;
+  constexpr int LDS_BYTES = 2 * STAGE;             // 160 KB
+  __shared__ __attribute__((aligned(16))) uint4 lds[LDS_BYTES / 16];
+
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int lane = t & 63;
+  const int ntiles = g.tiles_o * g.tiles_c;
+  const int total = ntiles * g.nsplit;
+  int wid = blockIdx.x;
+  {
+    const int q = total >> 3, r = total & 7, xcd = wid & 7, j = wid >> 3;
+    wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int zs = wid / ntiles;
+  const int tid = wid - zs * ntiles;
+  const int tile_o = tid / g.tiles_c, tile_c = tid - tile_o * g.tiles_c;
+  const int o0 = tile_o * 128, c0 = tile_c * 512;
+  const int Ktot = g.Kseg[0] + g.Kseg[1];
+  const int nkt_all = (Ktot + 63) >> 6;
+  const int kt_begin = zs * g.kt_per_split;
+  const int nkt = min(nkt_all, kt_begin + g.kt_per_split) - kt_begin;     // host: > 0 and even
+  constexpr unsigned OOB = 0x80000000u;
+
+  const __amdgpu_buffer_rsrc_t rsL0 = __builtin_amdgcn_make_buffer_rsrc((void*)g.low[0], 0, g.low_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsH0 = __builtin_amdgcn_make_buffer_rsrc((void*)g.high[0], 0, g.high_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsL1 = __builtin_amdgcn_make_buffer_rsrc((void*)g.low[1], 0, g.low_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsH1 = __builtin_amdgcn_make_buffer_rsrc((void*)g.high[1], 0, g.high_bytes, 0x00020000);
+
+  // DMA lane assignment of a half-tile: as in wgrad8_kernel
+  const int lrow = wave * 4 + (lane >> 4);
+  const int lc = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (wave & 3));
+  const int Wo = 1 << g.lgWo, Ho = 1 << g.lgHo;
+  const int a_off = (lrow * g.O + o0 + lc * 8) * 2;
+  int b_ci[4], b_kh[4], b_kw[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const int col = c0 + h * 128 + lc * 8;
+    const int tap = col / g.I;
+    b_ci[h] = (col - tap * g.I) * 2;
+    b_kh[h] = tap >> 2;
+    b_kw[h] = tap & 3;
+  }
+  char* const ldsb = reinterpret_cast<char*>(lds);
+
+  int px_base[2], px_h[2], px_w[2];
+  bool px_ok[2];
+  auto decode_pixels = [&](int ktr) {
+    const int p0 = (kt_begin + ktr) * 64;
+    const bool seg1 = p0 >= g.Kseg[0];
+    const int pb = seg1 ? p0 - g.Kseg[0] : p0;
+    const int kend = (ktr < nkt) ? (seg1 ? g.Kseg[1] : g.Kseg[0]) : 0;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int p = pb + jj * 32 + lrow;
+      px_ok[jj] = p < kend;
+      const int wo = p & (Wo - 1), ho = (p >> g.lgWo) & (Ho - 1), n = p >> (g.lgWo + g.lgHo);
+      px_h[jj] = 2 * ho - 1;
+      px_w[jj] = 2 * wo - 1;
+      px_base[jj] = n * g.Hh;
+    }
+  };
+  auto issue_a = [&](auto S, int ktr) {
+    constexpr int s = decltype(S)::value;
+    const int p0 = (kt_begin + ktr) * 64;
+    const bool seg1 = p0 >= g.Kseg[0];
+    const int pb = seg1 ? p0 - g.Kseg[0] : p0;
+    const int kend = (ktr < nkt) ? (seg1 ? g.Kseg[1] : g.Kseg[0]) : 0;
+    const __amdgpu_buffer_rsrc_t rs = seg1 ? rsL1 : rsL0;
+    const int so = pb * g.O * 2;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const bool ok = pb + jj * 32 + lrow < kend;
+      const unsigned vo = ok ? (unsigned)(a_off + jj * 64 * g.O + so) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr_t)(ldsb + s * STAGE + OFF_A + jj * 8192 + wave * 1024), 16, vo, 0, 0, 0);
+    }
+  };
+  // B slice h of k-tile ktr; h == 0 decodes the pixel geometry of that k-tile, slices 1..3 of the SAME k-tile reuse it
+  // (B3(u+1) is issued before B0(u+2) in P1)
+  auto issue_b = [&](auto S, auto H, int ktr) {
+    constexpr int s = decltype(S)::value, h = decltype(H)::value;
+    if (h == 0) decode_pixels(ktr);
+    const bool seg1 = (kt_begin + ktr) * 64 >= g.Kseg[0];
+    const __amdgpu_buffer_rsrc_t rs = seg1 ? rsH1 : rsH0;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int hi = px_h[jj] + b_kh[h], wi = px_w[jj] + b_kw[h];
+      const bool v = px_ok[jj] && (unsigned)hi < (unsigned)g.Hh && (unsigned)wi < (unsigned)g.Wh;
+      const unsigned vo = v ? (unsigned)(((px_base[jj] + hi) * g.Wh + wi) * g.I * 2 + b_ci[h]) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr_t)(ldsb + s * STAGE + OFF_B + h * HT + jj * 8192 + wave * 1024),
+                                               16, vo, 0, 0, 0);
+    }
+  };
+
+  const int wm = wave >> 2, wn = wave & 3;          // 64-row half of the 128 o rows; 32-column slice of every 128-column B slice
+  const int grp = lane >> 4, idx = lane & 15;
+  const int q = idx >> 2, p4 = idx & 3, fh = grp >> 1, cb = grp & 1;
+  const int f1 = (q << 2) | (2 * fh), f2 = (q << 2) | (2 * fh + 1);
+  const unsigned lds_base = (unsigned)(size_t)(lds_vptr_t)lds;
+  auto frag_addr = [&](int cb32, int hi) -> unsigned {
+    const int prow = 8 * fh + q + 4 * hi;
+    const int ca = cb32 * 4 + 2 * cb + (p4 >> 1);
+    return (unsigned)(prow * 256 + ((ca ^ (hi ? f2 : f1)) << 4) + (p4 & 1) * 8);
+  };
+  unsigned aA[2][2][2], bA[2][2];                   // [stage][sub-tile][lo/hi], [stage][lo/hi]
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int hl = 0; hl < 2; ++hl) {
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) aA[s][ti][hl] = lds_base + s * STAGE + OFF_A + frag_addr(wm * 2 + ti, hl);
+      bA[s][hl] = lds_base + s * STAGE + OFF_B + frag_addr(wn, hl);
+    }
+  f32x16_t acc[4][2];                               // [B slice j][32-channel sub-tile]
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][s][r] = 0.f;
+  u32x2_t aR[2][4][2];                              // [sub-tile][k-step][lo/hi]
+  u32x2_t bS[3][4][2];                              // set 0: B0, sets 1 / 2 alternate over B1, B2, B3
+
+#define WN_DSR(dst, addr, off) \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define WN_READ_A(S)                                                                                      \
+  do {                                                                                                    \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) _Pragma("unroll") for (int ti_ = 0; ti_ < 2; ++ti_) { \
+      WN_DSR(aR[ti_][ks_][0], aA[S][ti_][0], ks_ * 4096);                                                 \
+      WN_DSR(aR[ti_][ks_][1], aA[S][ti_][1], ks_ * 4096);                                                 \
+    }                                                                                                     \
+  } while (0)
+#define WN_READ_B(S, H, SET)                                                                              \
+  do {                                                                                                    \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                                 \
+      WN_DSR(bS[SET][ks_][0], bA[S][0], (H) * HT + ks_ * 4096);                                           \
+      WN_DSR(bS[SET][ks_][1], bA[S][1], (H) * HT + ks_ * 4096);                                           \
+    }                                                                                                     \
+  } while (0)
+#define WN_WAIT_A()                                                                                        \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                      \
+               : "+v"(aR[0][0][0]), "+v"(aR[0][0][1]), "+v"(aR[0][1][0]), "+v"(aR[0][1][1]), "+v"(aR[0][2][0]), \
+                 "+v"(aR[0][2][1]), "+v"(aR[0][3][0]), "+v"(aR[0][3][1]), "+v"(aR[1][0][0]), "+v"(aR[1][0][1]), \
+                 "+v"(aR[1][1][0]), "+v"(aR[1][1][1]), "+v"(aR[1][2][0]), "+v"(aR[1][2][1]), "+v"(aR[1][3][0]), \
+                 "+v"(aR[1][3][1])::"memory")
+#define WN_WAIT_B(SET)                                                                                     \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                      \
+               : "+v"(bS[SET][0][0]), "+v"(bS[SET][0][1]), "+v"(bS[SET][1][0]), "+v"(bS[SET][1][1]),       \
+                 "+v"(bS[SET][2][0]), "+v"(bS[SET][2][1]), "+v"(bS[SET][3][0]), "+v"(bS[SET][3][1])::"memory")
+#define WN_FRAG(lo, hi) __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3))
+#define WN_MFMAS(J, SET)                                                                                   \
+  do {                                                                                                     \
+    __builtin_amdgcn_s_setprio(1);                                                                         \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) _Pragma("unroll") for (int ti_ = 0; ti_ < 2; ++ti_) \
+        acc[J][ti_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WN_FRAG(aR[ti_][ks_][0], aR[ti_][ks_][1]),   \
+                                                              WN_FRAG(bS[SET][ks_][0], bS[SET][ks_][1]),   \
+                                                              acc[J][ti_], 0, 0, 0);                       \
+    __builtin_amdgcn_s_setprio(0);                                                                         \
+  } while (0)
+#define WN_SYNC() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+  constexpr int WN_ALL = vmcnt_imm(12);
+#define WN_TILE(S, U)                                                                       \
+  do {                                                                                      \
+    WN_READ_A(S);                                                                           \
+    issue_b(ic<1 - (S)>{}, ic<2>{}, (U) + 1);                                               \
+    __builtin_amdgcn_s_waitcnt(WN_ALL);                                                     \
+    WN_SYNC();                                                                              \
+    WN_WAIT_A();                                                                            \
+    WN_MFMAS(0, 0);                                                                         \
+    WN_SYNC();                                                                              \
+    WN_READ_B(S, 1, 1);                                                                     \
+    issue_b(ic<1 - (S)>{}, ic<3>{}, (U) + 1);                                               \
+    issue_b(ic<(S)>{}, ic<0>{}, (U) + 2);                                                   \
+    __builtin_amdgcn_s_waitcnt(WN_ALL);                                                     \
+    WN_SYNC();                                                                              \
+    WN_WAIT_B(1);                                                                           \
+    WN_MFMAS(1, 1);                                                                         \
+    WN_SYNC();                                                                              \
+    WN_READ_B(S, 2, 2);                                                                     \
+    issue_a(ic<(S)>{}, (U) + 2);                                                            \
+    __builtin_amdgcn_s_waitcnt(WN_ALL);                                                     \
+    WN_SYNC();                                                                              \
+    WN_WAIT_B(2);                                                                           \
+    WN_MFMAS(2, 2);                                                                         \
+    WN_SYNC();                                                                              \
+    WN_READ_B(S, 3, 1);                                                                     \
+    WN_READ_B(1 - (S), 0, 0);                                                               \
+    issue_b(ic<(S)>{}, ic<1>{}, (U) + 2);                                                   \
+    __builtin_amdgcn_s_waitcnt(WN_ALL);                                                     \
+    WN_SYNC();                                                                              \
+    WN_WAIT_B(1);                                                                           \
+    WN_WAIT_B(0);                                                                           \
+    WN_MFMAS(3, 1);                                                                         \
+    WN_SYNC();                                                                              \
+  } while (0)
+
+  // prologue: k-tile 0 completely, k-tile 1 up to B1 (B2(1) and B3(1) are issued by P0 / P1 of k-tile 0)
+  issue_b(ic<0>{}, ic<0>{}, 0);
+  issue_a(ic<0>{}, 0);
+  issue_b(ic<0>{}, ic<1>{}, 0);
+  issue_b(ic<0>{}, ic<2>{}, 0);
+  issue_b(ic<0>{}, ic<3>{}, 0);
+  issue_b(ic<1>{}, ic<0>{}, 1);
+  issue_a(ic<1>{}, 1);
+  issue_b(ic<1>{}, ic<1>{}, 1);
+  __builtin_amdgcn_s_waitcnt(WN_ALL);               // B0(0), A0(0) have landed
+  WN_SYNC();
+  WN_READ_B(0, 0, 0);
+  WN_WAIT_B(0);
+  if (wave >= 4) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  for (int u = 0; u < nkt; u += 2) {
+    WN_TILE(0, u);
+    WN_TILE(1, u + 1);
+  }
+  if (wave < 4) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+#undef WN_TILE
+#undef WN_SYNC
+#undef WN_MFMAS
+#undef WN_FRAG
+#undef WN_WAIT_A
+#undef WN_WAIT_B
+#undef WN_READ_A
+#undef WN_READ_B
+#undef WN_DSR
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- epilogue: fp32 [128 o][128 cols] per B slice through LDS, 16-byte stores (512 contiguous bytes per row)
+  float* cs = reinterpret_cast<float*>(lds);
+  const int fr = lane & 31, fh2 = lane >> 5;
+  const long long ldw = (long long)16 * g.I;
+  float* outp = g.out + (g.nsplit > 1 ? (long long)zs * g.O * ldw : 0);
+  const int c4 = (t & 31) * 4, rr = t >> 5;         // 32 threads per row (128 floats), 16 rows per pass
+#pragma unroll
+  for (int ep = 0; ep < 4; ++ep) {
+    if (ep) __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh2;
+        cs[row * 128 + wn * 32 + fr] = acc[ep][s][r];
+      }
+    __syncthreads();
+#pragma unroll 4
+    for (int p = 0; p < 8; ++p) {
+      const int row = rr + 16 * p;
+      float4* d = reinterpret_cast<float4*>(outp + (long long)(o0 + row) * ldw + c0 + ep * 128 + c4);
+      float4 v = *reinterpret_cast<const float4*>(cs + row * 128 + c4);
+      if (g.accumulate) {
+        const float4 a = *d;
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
+      *d = v;
+    }
+  }
+}
+
 }  // namespace
 
 // Shapes of the ping-pong weight-gradient kernel: O and 16*I multiples of 256, I a multiple of 8 that divides the
@@ -328,6 +606,39 @@ int rg_wgrad8_split(int K, int O, int I, int* kt_per_split) {
   ns = (nkt + per - 1) / per;
   *kt_per_split = per;
   return ns;
+}
+
+// The 128 x 512 form: O a multiple of 128 that the 256-row tile does not divide, 16 * I a multiple of 512.
+bool rg_wgrad8n_supported(int K, int O, int I) {
+  return O % 128 == 0 && O % 256 != 0 && (16 * I) % 512 == 0 && I % 8 == 0 && K >= 256;
+}
+int rg_wgrad8n_split(int K, int O, int I, int* kt_per_split) {
+  const int tiles = (O / 128) * (16 * I / 512);
+  const int nkt = (K + 63) / 64;
+  const int target = rg_option("wgrad8_blocks", 256);
+  int ns = (target + tiles - 1) / tiles;
+  if (ns < 1) ns = 1;
+  int per = (nkt + ns - 1) / ns;
+  if (per < 4) per = 4;
+  per = (per + 1) & ~1;
+  ns = (nkt + per - 1) / per;
+  *kt_per_split = per;
+  return ns;
+}
+int rg_wgrad8n_launch(const void* low0, const void* high0, const void* low1, const void* high1, float* out, int Kseg,
+                      int two, int O, int I, int Ho, int Wo, int nsplit, int kt_per_split, int accumulate, hipStream_t st) {
+  W8Args g{};
+  g.low[0] = (const uint16_t*)low0; g.high[0] = (const uint16_t*)high0;
+  g.low[1] = (const uint16_t*)(two ? low1 : low0); g.high[1] = (const uint16_t*)(two ? high1 : high0);
+  g.low_bytes = (unsigned)((size_t)Kseg * O * 2); g.high_bytes = (unsigned)((size_t)Kseg * 4 * I * 2);
+  g.Kseg[0] = Kseg; g.Kseg[1] = two ? Kseg : 0;
+  g.out = out; g.O = O; g.I = I;
+  g.lgWo = rg_ilog2(Wo); g.lgHo = rg_ilog2(Ho); g.Hh = 2 * Ho; g.Wh = 2 * Wo;
+  g.tiles_o = O / 128; g.tiles_c = 16 * I / 512; g.nsplit = nsplit; g.kt_per_split = kt_per_split;
+  g.accumulate = nsplit == 1 ? accumulate : 0;
+  hipLaunchKernelGGL(wgrad8n_kernel, dim3((unsigned)(g.tiles_o * g.tiles_c * nsplit)), dim3(512), 0, st, g);
+  RG_LAUNCH_CHECK("conv_wgrad(mfma, ping-pong, 128 x 512)");
+  return RG_OK;
 }
 
 int rg_wgrad8_launch(const void* low0, const void* high0, const void* low1, const void* high1, float* out, int Kseg,
