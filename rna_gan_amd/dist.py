@@ -7,8 +7,11 @@ the gradient of the MEAN over ranks of the rank-local losses.
   a pure SUM over the flat gradient buffer: no extra pass over the gradients.
 * xGMI is point-to-point (7 links x ~153 GB/s per GPU): the all-reduce is bandwidth-bound per link, so
   the volume is what matters.  In bf16 precision mode the flat fp32 gradient is compressed to bf16 for
-  the wire (805 MB -> 403 MB per iteration and rank) and widened again (two streaming HIP kernels);
+  the wire (805 MB -> 403 MB per iteration and rank; rna_gan_amd.optim.Adam steps straight from the wire buffer);
   the MFMA operands that produced it were bf16 already (DESIGN "Numerics").  fp32 mode sends fp32.
+* The generator's layer-0 weight gradient (60 % of its parameters) is a rank-(batch) product: its FACTORS are all-gathered
+  (4.7 MB per rank) and the product is formed over all ranks' samples inside the fused Adam step (G0_FACTORS below):
+  403 -> 269 MB on the wire per iteration and rank.
 * Collectives are never captured into HIP graphs: for world > 1 each train_op is graph(prefix) / graph(rest) /
   eager all-reduce start, and the wait + optimizer-step graph are issued by the NEXT train_op after its prefix
   (which reads the other network), so the transfer overlaps with compute (losses._Runner.run_dp).
