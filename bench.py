@@ -335,6 +335,8 @@ def main(argv=None):
                          "--nproc-per-node %d, or run `python bench.py --gpus %d` (it starts the ranks itself)"
                          % (args.gpus, world, args.gpus, args.gpus))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if use_cuda and os.environ.get("RNAGAN_DIST_BACKEND") == "gloo":
+        local %= torch.cuda.device_count()        # functional multi-rank runs on fewer devices than ranks (see dist.init_from_env)
     device = torch.device("cuda", local) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)

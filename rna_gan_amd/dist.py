@@ -58,7 +58,9 @@ def init_from_env(backend=None):
     if "RANK" not in os.environ:
         return
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # RNAGAN_DIST_BACKEND=gloo: functional runs of the multi-rank path where RCCL cannot be used -- several ranks SHARING
+        # one device (RCCL refuses duplicate devices; gloo stages device tensors through the host: correct, not fast)
+        backend = os.environ.get("RNAGAN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dist.init_process_group(backend=backend, init_method="env://")
