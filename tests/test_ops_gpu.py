@@ -674,3 +674,45 @@ def test_multi_tensor_weight_image_transpose():
     rc = lib.rg_pack_conv_wup_from_bf16_multi(1, (C.c_void_p * 1)(bad.data_ptr()), (C.c_void_p * 1)(bad.data_ptr()),
                                               (C.c_int * 1)(32), (C.c_int * 1)(8), stream)
     assert rc != 0
+
+
+@pytest.mark.parametrize("N,E,C", [(512, 128, 64), (200, 64, 32), (512, 2048, 2048)])
+def test_fused_layer0_gradient_adam_over_gathered_factors(N, E, C):
+    """rg_g0_wgrad_adam with K = the samples of ALL ranks (data parallel: the all-gathered factors z [W n, E] and gz0
+    [W n, 4, 4, C], dist.G0_FACTORS) -- 8 x 64 samples, a ragged count, and the reference generator's full 2048 x 2048 x 4 x 4
+    tensor: the gradient sum_n z[n][e] * gz0[n][tap][c] formed on MFMA from bf16-rounded operands with fp32 accumulation,
+    then torch.optim.Adam's update (weight decay included), against the same arithmetic in plain tensor operations."""
+    from rna_gan_amd import _abi
+    dev = torch.device("cuda:0")
+    lib = _abi.load()
+    g = torch.Generator().manual_seed(N + E)
+    z = torch.randn(N, E, generator=g).to(dev)
+    gz0 = (torch.randn(N, 4, 4, C, generator=g) * 0.05).bfloat16().to(dev)
+    p = (torch.randn(E, C, 4, 4, generator=g) * 0.02).to(dev)
+    m = (torch.randn(E, C, 4, 4, generator=g) * 1e-3).to(dev)
+    v = (torch.rand(E, C, 4, 4, generator=g) * 1e-4).to(dev)
+    p0, m0, v0 = p.clone(), m.clone(), v.clone()
+    shadow = torch.zeros(E, C, 4, 4, dtype=torch.bfloat16, device=dev)
+    step = torch.full((1,), 4, dtype=torch.int32, device=dev)
+    hyper = torch.zeros(8, device=dev)
+    lr, b1, b2, eps, wd = 1e-3, 0.5, 0.999, 1e-8, 1e-2
+    stream = torch.cuda.current_stream().cuda_stream
+    _abi.check(lib.rg_adam_hyper_dev(step.data_ptr(), lr, b1, b2, eps, wd, hyper.data_ptr(), stream), "rg_adam_hyper_dev")
+    assert lib.rg_g0_wgrad_adam_supported(N, E, C, _abi.RG_BF16) == 1
+    _abi.check(lib.rg_g0_wgrad_adam(z.data_ptr(), gz0.data_ptr(), p.data_ptr(), m.data_ptr(), v.data_ptr(), hyper.data_ptr(),
+                                    shadow.data_ptr(), N, E, C, _abi.RG_BF16, stream), "rg_g0_wgrad_adam")
+    torch.cuda.synchronize()
+    # dw[e][c][kh][kw] = sum_n bf16(z[n][e]) * gz0[n][kh][kw][c], fp32 accumulation
+    dw = torch.einsum("ne,nhwc->echw", z.bfloat16().float(), gz0.float())
+    t = 5                                              # the step the hyper kernel advanced to
+    gg = dw + wd * p0
+    m1 = m0 + (1 - b1) * (gg - m0)
+    v1 = b2 * v0 + (1 - b2) * gg * gg
+    denom = v1.sqrt() / (1 - b2 ** t) ** 0.5 + eps
+    p1 = p0 - (lr / (1 - b1 ** t)) * (m1 / denom)
+    scale = float(dw.abs().mean())
+    assert float((m - m1).abs().max()) <= 2e-4 * (1 - b1) * scale * N ** 0.5 + 1e-6     # order of an N-term fp32 sum
+    assert float(((v - v1) / (v1 + 1e-12)).abs().max()) <= 2e-3
+    upd, upd_ref = p - p0, p1 - p0
+    assert float((upd - upd_ref).abs().max()) <= 2e-3 * float(upd_ref.abs().max())
+    assert torch.equal(shadow, p.bfloat16())
