@@ -12,6 +12,7 @@
 //
 // Tile: 64 e-rows x 256 columns j = (c, tap) (16 channels x 16 taps of the master's [E][C*16] row), 256 threads = 4 waves.
 #include "rg_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -41,7 +42,7 @@ template <typename TG>      // TG: element type of gz0 (bf16_t or float)
 __global__ __launch_bounds__(256) void g0_wgrad_adam_kernel(const float* __restrict__ z, const TG* __restrict__ gz0,
                                                             float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                             const float* __restrict__ hyper, uint16_t* __restrict__ shadow,
-                                                            int N, int E, int C) {
+                                                            int N, int E, int C, int e_fastest) {
   constexpr int OPS = (GA_E + GA_J) * GA_P * 2;                       // 46080 B of operand images
   static_assert(32 * GA_CP * 4 <= OPS, "accumulator tile must fit into the operand area");
   __shared__ __attribute__((aligned(16))) unsigned char smem[OPS];
@@ -50,7 +51,10 @@ __global__ __launch_bounds__(256) void g0_wgrad_adam_kernel(const float* __restr
   float* ct = reinterpret_cast<float*>(smem);                         // [32 e][GA_CP] fp32 = 33 KB, after the k loop
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int fr = lane & 31, fh = lane >> 5;
-  const int e0 = blockIdx.y * GA_E, c0 = blockIdx.x * 16;             // 16 channels = 256 columns
+  // tile order: e_fastest (default) -- the row tiles of one 256-column strip run back to back and share that strip's gz0 slab
+  // (K x 512 B, the large operand) in L2 instead of re-reading it from memory; the other order (column tiles fastest) streams
+  // adjacent 1 KB pieces of the same 64 rows and is slower at every K
+  const int e0 = (e_fastest ? blockIdx.x : blockIdx.y) * GA_E, c0 = (e_fastest ? blockIdx.y : blockIdx.x) * 16;
   ga_f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -59,39 +63,71 @@ __global__ __launch_bounds__(256) void g0_wgrad_adam_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  for (int n0 = 0; n0 < N; n0 += GA_N) {
-    if (n0) __syncthreads();
-    // ---- stage z[n0 .. n0+63][e0 .. e0+63] (fp32 -> bf16) transposed: zsT[e][n]
+  // ---- operand staging, software-pipelined over the 64-sample chunks: the global loads of chunk k + 1 are issued before
+  // the MFMAs of chunk k (K = world x batch in a data-parallel run: up to 8 chunks); two consecutive samples go into one
+  // 4-byte LDS word (half the LDS write instructions of a per-sample scatter).
+  //   z:   thread = (e = t & 63, sample pairs q = (t >> 6) + 4 i, i < 8): 2 x 8 scalar loads, 8 word writes
+  //   gz0: thread = (sample pair np = t & 31, taps 2 (t >> 5), + 1): per tap 2 samples x 32 B, 16 word writes
+  const int ze = t & 63, zq = t >> 6;
+  const int gnp = t & 31, gtap = (t >> 5) * 2;
+  float zr[8][2];
+  uint4 gr[2][2][2];                               // [tap][sample of the pair][8-channel half]
+  auto load_chunk = [&](int n0) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int idx = t + 256 * k;                 // float4 index: n = idx / 16, e4 = idx % 16
-      const int n = idx >> 4, e4 = (idx & 15) * 4;
-      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n0 + n < N) x = *reinterpret_cast<const float4*>(z + (size_t)(n0 + n) * E + e0 + e4);
-      zsT[(e4 + 0) * GA_P + n] = f32_to_bf16(x.x);
-      zsT[(e4 + 1) * GA_P + n] = f32_to_bf16(x.y);
-      zsT[(e4 + 2) * GA_P + n] = f32_to_bf16(x.z);
-      zsT[(e4 + 3) * GA_P + n] = f32_to_bf16(x.w);
+    for (int i = 0; i < 8; ++i) {
+      const int n = n0 + 2 * (zq + 4 * i);
+      zr[i][0] = n < N ? z[(size_t)n * E + e0 + ze] : 0.f;
+      zr[i][1] = n + 1 < N ? z[(size_t)(n + 1) * E + e0 + ze] : 0.f;
     }
-    // ---- stage gz0[n][tap][c0 .. c0+15] -> gsT[cl * 16 + tap][n]; thread = (n, 4 taps)
-    {
-      const int n = t >> 2, tq = (t & 3) * 4;
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const int tap = tq + a;
-        float x[16];
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int cl = 0; cl < 16; ++cl) x[cl] = 0.f;
-        if (n0 + n < N) {
-          const TG* src = gz0 + ((size_t)(n0 + n) * 16 + tap) * C + c0;
-          Vec<TG, 8>::ld(src, x);
-          Vec<TG, 8>::ld(src + 8, x + 8);
+      for (int k = 0; k < 2; ++k) {
+        const int n = n0 + 2 * gnp + k;
+        gr[a][k][0] = gr[a][k][1] = make_uint4(0, 0, 0, 0);
+        if (n < N) {
+          const TG* src = gz0 + ((size_t)n * 16 + gtap + a) * C + c0;
+          if constexpr (sizeof(TG) == 2) {
+            gr[a][k][0] = *reinterpret_cast<const uint4*>(src);
+            gr[a][k][1] = *reinterpret_cast<const uint4*>(src + 8);
+          } else {                                 // fp32 source (fp32 activations): convert on the way in
+            float x[16];
+            Vec<TG, 8>::ld(src, x);
+            Vec<TG, 8>::ld(src + 8, x + 8);
+            uint32_t w[8];
+#pragma unroll
+            for (int c2 = 0; c2 < 8; ++c2) w[c2] = (uint32_t)f32_to_bf16(x[2 * c2]) | ((uint32_t)f32_to_bf16(x[2 * c2 + 1]) << 16);
+            gr[a][k][0] = make_uint4(w[0], w[1], w[2], w[3]);
+            gr[a][k][1] = make_uint4(w[4], w[5], w[6], w[7]);
+          }
         }
-#pragma unroll
-        for (int cl = 0; cl < 16; ++cl) gsT[(cl * 16 + tap) * GA_P + n] = f32_to_bf16(x[cl]);
       }
-    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      *reinterpret_cast<uint32_t*>(zsT + ze * GA_P + 2 * (zq + 4 * i)) =
+          (uint32_t)f32_to_bf16(zr[i][0]) | ((uint32_t)f32_to_bf16(zr[i][1]) << 16);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t lo[4] = {gr[a][0][h].x, gr[a][0][h].y, gr[a][0][h].z, gr[a][0][h].w};   // sample 2 np: channels 8 h .. + 7
+        const uint32_t hi[4] = {gr[a][1][h].x, gr[a][1][h].y, gr[a][1][h].z, gr[a][1][h].w};   // sample 2 np + 1
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2) {
+          const int cl = 8 * h + 2 * c2;
+          *reinterpret_cast<uint32_t*>(gsT + (cl * 16 + gtap + a) * GA_P + 2 * gnp) = (lo[c2] & 0xffffu) | (hi[c2] << 16);
+          *reinterpret_cast<uint32_t*>(gsT + ((cl + 1) * 16 + gtap + a) * GA_P + 2 * gnp) = (lo[c2] >> 16) | (hi[c2] & 0xffff0000u);
+        }
+      }
+  };
+  load_chunk(0);
+  for (int n0 = 0; n0 < N; n0 += GA_N) {
+    if (n0) __syncthreads();                       // the previous chunk's fragment reads are done
+    store_chunk();
     __syncthreads();
+    if (n0 + GA_N < N) load_chunk(n0 + GA_N);      // in flight under this chunk's MFMAs
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       ga_bf16x8 fa[2], fb[2];
@@ -164,14 +200,19 @@ extern "C" int rg_g0_wgrad_adam(const float* z, const void* gz0, float* p, float
   RG_REQUIRE(rg_g0_wgrad_adam_supported(N, E, C, dtype), RG_EUNSUPPORTED, "g0_wgrad_adam: E %% 64 == 0 and C %% 16 == 0 required");
   RG_REQUIRE((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)z | (uintptr_t)gz0) & 15) == 0 &&
                  (((uintptr_t)shadow_bf16) & 7) == 0, RG_EINVAL, "g0_wgrad_adam: 16-byte aligned buffers required");
-  const dim3 grid((unsigned)(C / 16), (unsigned)(E / GA_E));
+  static int order = -1;
+  // measured at E = C = 2048 (tools/scratch/bench_g0adam.py), column tiles fastest / row tiles fastest: K = 64: 345 / 325 us,
+  // 128: 375 / 347, 256: 490 / 397, 512: 779 / 514 -- row tiles fastest at every K (RNAGAN_G0ADAM_ORDER=0: the other order)
+  if (order < 0) { const char* e = getenv("RNAGAN_G0ADAM_ORDER"); order = e ? atoi(e) : 1; }
+  const int e_fastest = order != 0;
+  const dim3 grid(e_fastest ? (unsigned)(E / GA_E) : (unsigned)(C / 16), e_fastest ? (unsigned)(C / 16) : (unsigned)(E / GA_E));
   hipStream_t st = rg_stream(stream);
   if (dtype == RG_BF16)
     hipLaunchKernelGGL(g0_wgrad_adam_kernel<bf16_t>, grid, dim3(256), 0, st, z, (const bf16_t*)gz0, p, m, v, hyper,
-                       (uint16_t*)shadow_bf16, N, E, C);
+                       (uint16_t*)shadow_bf16, N, E, C, e_fastest);
   else
     hipLaunchKernelGGL(g0_wgrad_adam_kernel<float>, grid, dim3(256), 0, st, z, (const float*)gz0, p, m, v, hyper,
-                       (uint16_t*)shadow_bf16, N, E, C);
+                       (uint16_t*)shadow_bf16, N, E, C, e_fastest);
   RG_LAUNCH_CHECK("g0_wgrad_adam");
   return RG_OK;
 }
