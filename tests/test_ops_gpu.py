@@ -716,3 +716,60 @@ def test_fused_layer0_gradient_adam_over_gathered_factors(N, E, C):
     upd, upd_ref = p - p0, p1 - p0
     assert float((upd - upd_ref).abs().max()) <= 2e-3 * float(upd_ref.abs().max())
     assert torch.equal(shadow, p.bfloat16())
+
+
+@pytest.mark.parametrize("I,O,hs,n,groups", [(64, 128, 16, 8, 1), (128, 256, 8, 8, 1), (64, 128, 16, 16, 2), (128, 256, 8, 16, 2),
+                                              (256, 512, 4, 8, 1), (128, 256, 16, 8, 1), (128, 256, 16, 16, 2)])
+def test_split_k_batchnorm_fusion_small_shapes(I, O, hs, n, groups):
+    """The fused split-K reduction + BatchNorm kernels (rg_bn_forward_slabs / rg_bn_act_bwd_slabs) at SMALL shapes (32 x 32 and
+    64 x 64 models, batch 8 / 16) and in all four conv -> BatchNorm pairings the engine uses -- stride-2 conv -> forward
+    (discriminator), transposed conv -> forward (generator), transposed conv -> backward (discriminator's data gradient),
+    stride-2 conv -> backward (generator's) -- against the separate-launch path of the same library: equal to one bf16
+    rounding whether or not a pairing takes the slab path at that shape (tests/test_fullsize_gpu.py covers the benchmark's)."""
+    from rna_gan_amd.engine import ConvW
+    from rna_gan_amd.ops_hip import HipOps
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(7 * I + hs + n)
+    fu, se = HipOps(torch.bfloat16, dev), HipOps(torch.bfloat16, dev)
+    se.split_bn = False
+    w = (torch.randn(O, 4, 4, I, generator=gen) * (2.0 / (I * 16)) ** 0.5).bfloat16().float().to(dev)
+    cf, cs = ConvW(w.clone(), None, torch.zeros_like(w), None, "OHWI"), ConvW(w.clone(), None, torch.zeros_like(w), None, "OHWI")
+    ho = hs // 2
+    x = torch.randn(n, hs, hs, I, generator=gen).bfloat16().to(dev)
+    y = torch.randn(n, ho, ho, O, generator=gen).bfloat16().to(dev)
+    gO, bO = (1 + 0.1 * torch.randn(O, generator=gen)).to(dev), (0.1 * torch.randn(O, generator=gen)).to(dev)
+    gI, bI = (1 + 0.1 * torch.randn(I, generator=gen)).to(dev), (0.1 * torch.randn(I, generator=gen)).to(dev)
+    rel = lambda a, b: float((a.float() - b.float()).abs().max() / (b.float().abs().max() + 1e-30))
+
+    def fwd(ops, z, gam, bet):
+        return (ops.bn_forward if groups == 1 else ops.bn_forward2)(z, gam, bet, 0.2, 1e-5, 0.1)
+    used = 0
+    for conv, src, gam, bet in (("conv_down", x, gO, bO), ("conv_up", y, gI, bI)):
+        res = []
+        for ops, cw in ((fu, cf), (se, cs)):
+            out = getattr(ops, conv)(src, cw, want_stats=True, defer=groups)
+            z = out[0] if isinstance(out, tuple) else out
+            used += getattr(z, "_rg_slabs", None) is not None
+            a, mean, inv = fwd(ops, z, gam, bet)
+            res.append((z, a, mean, inv))
+        torch.cuda.synchronize()
+        assert torch.equal(res[0][0].view(torch.int16), res[1][0].view(torch.int16)), conv
+        assert rel(res[0][1], res[1][1]) < 8e-3 and rel(res[0][2], res[1][2]) < 1e-5 and rel(res[0][3], res[1][3]) < 1e-5, conv
+    for conv, src, C, gam, bet, zshape in (("conv_up", y, I, gI, bI, (n, hs, hs, I)), ("conv_down", x, O, gO, bO, (n, ho, ho, O))):
+        zb = (torch.randn(*zshape, generator=gen) * 1.3 + 0.2).bfloat16().to(dev)
+        res = []
+        for ops, cw in ((fu, cf), (se, cs)):
+            _, mean, inv = fwd(ops, zb.clone(), gam, bet)
+            ga = getattr(ops, conv)(src, cw, defer=groups)
+            ga = ga[0] if isinstance(ga, tuple) else ga
+            used += getattr(ga, "_rg_slabs", None) is not None
+            dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+            if groups == 1:
+                gz, _, _ = ops.bn_act_bwd(zb, ga, mean, inv, gam, bet, 0.2, dg, db, False, keep_ga=False)
+            else:
+                gz = ops.bn_act_bwd2(zb, ga, mean, inv, gam, bet, 0.2, dg, db, False)
+            res.append((gz, dg, db))
+        torch.cuda.synchronize()
+        assert rel(res[0][0], res[1][0]) < 8e-3 and rel(res[0][1], res[1][1]) < 1e-4 and rel(res[0][2], res[1][2]) < 1e-4, conv
+    assert used >= 1, "none of the four pairings took the slab path at this shape: the case checks nothing"
+    assert int(fu._sb_sync[0]) == 0, "no hand-off timed out"
