@@ -1082,11 +1082,36 @@ __global__ __launch_bounds__(256) void transpose_bf16_multi_kernel(TransMulti ta
     *reinterpret_cast<uint4*>(dst + (size_t)(c0 + c) * R + r0 + 8 * rg) = make_uint4(o[0], o[1], o[2], o[3]);
   }
 }
-__global__ void pack_linear_kernel(const float* w, uint16_t* wp, int Nout, int K, int Np, int Kp) {
-  size_t n = (size_t)Np * Kp;
-  for (size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += (size_t)gridDim.x * blockDim.x) {
-    size_t k = d % Kp, j = d / Kp;
-    wp[d] = (j < (size_t)Nout && k < (size_t)K) ? f32_to_bf16(w[j * K + k]) : (uint16_t)0;
+// fp32 [Nout][K] -> bf16 [Np][Kp] (zero padded), 8 outputs = one 16-byte store per thread; the source row pitch K is even on
+// every layer of the models here (8-byte aligned rows): four float2 loads, scalar loads at a ragged row end / odd K
+__global__ void pack_linear_kernel(const float* __restrict__ w, uint16_t* __restrict__ wp, int Nout, int K, int Np, int Kp) {
+  const int kp8 = Kp >> 3;                                   // Kp % 8 == 0 (host)
+  const size_t n8 = (size_t)Np * kp8;
+  const bool even = (K & 1) == 0 && (reinterpret_cast<uintptr_t>(w) & 7) == 0;
+  for (size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x; d < n8; d += (size_t)gridDim.x * blockDim.x) {
+    const size_t j = d / kp8;
+    const int k = (int)(d - j * kp8) * 8;
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = 0.f;
+    if (j < (size_t)Nout && k < K) {
+      const float* src = w + j * (size_t)K + k;
+      if (even && k + 8 <= K) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float2 v = *reinterpret_cast<const float2*>(src + 2 * i);
+          x[2 * i] = v.x; x[2 * i + 1] = v.y;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (k + i < K) x[i] = src[i];
+      }
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (uint32_t)f32_to_bf16(x[2 * i]) | ((uint32_t)f32_to_bf16(x[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(wp + d * 8) = make_uint4(o[0], o[1], o[2], o[3]);
   }
 }
 
@@ -2033,7 +2058,8 @@ int rg_mfma_upconv3_image_wgrad(const float* gy, const void* x, float* dw, int N
 }
 
 int rg_mfma_pack_linear_weight(const float* w, void* wp, int Nout, int K, int Np, int Kp, hipStream_t st) {
-  hipLaunchKernelGGL(pack_linear_kernel, dim3(grid_cap((size_t)Np * Kp)), dim3(256), 0, st, w, (uint16_t*)wp, Nout, K,
+  RG_REQUIRE(Kp % 8 == 0 && (((uintptr_t)wp) & 15) == 0, RG_EINVAL, "pack_linear: Kp %% 8 == 0 and a 16-byte aligned image required");
+  hipLaunchKernelGGL(pack_linear_kernel, dim3(grid_cap((size_t)Np * Kp / 8)), dim3(256), 0, st, w, (uint16_t*)wp, Nout, K,
                      Np, Kp);
   RG_LAUNCH_CHECK("pack_linear");
   return RG_OK;
