@@ -700,7 +700,7 @@ def extra_vae_train(args, device, info, steps=10, warm=3):
     m = P.betaVAE(*dims, beta=2.0)
     R.seeded_fill_(m, 51)
     m = m.set_precision("bf16").to(device).train()
-    opt = P.Adam(m.parameters(), lr=3e-3, weight_decay=1e-4).bind(m)
+    opt = P.Adam(m.parameters(), lr=3e-3, weight_decay=1e-4).bind(m, fuse_linear_wgrad=os.environ.get("VAE_FUSE", "1") != "0")
     gen = torch.Generator(device="cpu").manual_seed(args.seed + 13)
     x = torch.tanh(torch.randn(N, dims[0], generator=gen)).to(device)
     nparam = sum(p.numel() for p in m.parameters())

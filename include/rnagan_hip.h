@@ -274,6 +274,15 @@ int rg_g0_wgrad_adam_supported(int N, int E, int C, int dtype);
 int rg_g0_wgrad_adam(const float* z, const void* gz0, float* p, float* m, float* v, const float* hyper, void* shadow_bf16,
                      int N, int E, int C, int dtype, void* stream);
 
+/* The same fusion for an nn.Linear weight W[O][I] (fp32, row pitch I): dW[o][i] = sum_n g[n][o] * x[n][i], the batch being the
+ * only contraction, formed on MFMA and consumed by torch.optim.Adam's update (weight decay included) in one pass over p / m / v
+ * -- the betaVAE's layers in src/betaVAE_training.py (optimizer.step() at src/betaVAE.py:226 after loss.backward() :225).
+ * gT [>= O][ldn] and xT [>= I][ldn]: bf16, samples contiguous, zero padded to ldn (a multiple of 64) -- the images
+ * rg_transpose_pack_bf16 writes.  p / m / v: the weight's segment of the flat parameter / moment buffers; hyper: rg_adam_hyper_dev.
+ * The gradient itself is not written anywhere. */
+int rg_linear_wgrad_adam(const void* gT, const void* xT, int ldn, int N, float* p, float* m, float* v, const float* hyper, int O,
+                         int I, void* stream);
+
 /* ---- Inception-v3 feature extractor of the FID metric (src/fid.py:33-94: torchvision inception_v3 up to Mixed_7c) --------
  * NHWC fp32.  A BasicConv2d (Conv2d(bias=False) + BatchNorm2d(eval, eps 1e-3) + ReLU) = rg_im2col_nhwc (not needed for 1x1
  * stride 1) + rg_linear_affine_act with the folded BatchNorm affine and slope 0; ldx / ldy are row strides in elements, so a

@@ -188,6 +188,124 @@ __global__ __launch_bounds__(256) void g0_wgrad_adam_kernel(const float* __restr
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same fusion for an nn.Linear weight W[O][I] (row pitch I, any O, I): dW[o][i] = sum_n g[n][o] * x[n][i] with the batch as
+// the only contraction -- the betaVAE's layers (19198 x 6000 ... 2048 x 2048, batch 64: src/betaVAE_training.py) -- formed on
+// MFMA and consumed by torch.optim.Adam's update in the same pass (24 B per parameter instead of 4 + 28 and a GEMM launch).
+// Operands arrive TRANSPOSED and bf16: gT[O' >= O][ldn], xT[I' >= I][ldn] with the samples contiguous and zero padded to a
+// multiple of 64 (rg_transpose_pack_bf16, which the unfused weight-gradient GEMM needs as well), i.e. exactly the k-contiguous
+// LDS images of g0_wgrad_adam_kernel: staging is a straight 16-byte copy.  VEC: floats per access of the Adam stream (4: I % 4
+// == 0 and 16-byte aligned segment; 2: even I, 8-byte aligned; 1 otherwise); ragged tile edges are guarded.
+template <int VEC>
+__global__ __launch_bounds__(256) void lin_wgrad_adam_kernel(const uint16_t* __restrict__ gT, const uint16_t* __restrict__ xT,
+                                                             int ldn, int N, float* __restrict__ p, float* __restrict__ m,
+                                                             float* __restrict__ v, const float* __restrict__ hyper, int O,
+                                                             int I) {
+  constexpr int OPS = (GA_E + GA_J) * GA_P * 2;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[OPS];
+  uint16_t* zsT = reinterpret_cast<uint16_t*>(smem);                  // [64 o][GA_P]
+  uint16_t* gsT = zsT + GA_E * GA_P;                                  // [256 i][GA_P]
+  float* ct = reinterpret_cast<float*>(smem);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int o0 = blockIdx.x * GA_E, i0 = blockIdx.y * GA_J;           // row tiles fastest (see rg_g0_wgrad_adam)
+  ga_f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  for (int n0 = 0; n0 < N; n0 += GA_N) {
+    if (n0) __syncthreads();
+    // 64 samples = 128 B = eight 16-byte pieces per operand row: 512 pieces of gT, 2048 of xT
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int idx = t + 256 * k, row = idx >> 3, pc = idx & 7;
+      uint4 w = make_uint4(0, 0, 0, 0);
+      if (o0 + row < O) w = *reinterpret_cast<const uint4*>(gT + (size_t)(o0 + row) * ldn + n0 + 8 * pc);
+      *reinterpret_cast<uint4*>(zsT + row * GA_P + 8 * pc) = w;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int idx = t + 256 * k, row = idx >> 3, pc = idx & 7;
+      uint4 w = make_uint4(0, 0, 0, 0);
+      if (i0 + row < I) w = *reinterpret_cast<const uint4*>(xT + (size_t)(i0 + row) * ldn + n0 + 8 * pc);
+      *reinterpret_cast<uint4*>(gsT + row * GA_P + 8 * pc) = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      ga_bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+        fa[a] = __builtin_bit_cast(ga_bf16x8, *reinterpret_cast<const uint4*>(zsT + (32 * a + fr) * GA_P + 16 * ks + 8 * fh));
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        fb[b] = __builtin_bit_cast(ga_bf16x8,
+                                   *reinterpret_cast<const uint4*>(gsT + (64 * wave + 32 * b + fr) * GA_P + 16 * ks + 8 * fh));
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  const AdamC hy{hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6], hyper[7]};
+  const int tj = t & 63, te = t >> 6;
+  const int col = i0 + 4 * tj;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        ct[(8 * (r >> 2) + 4 * fh + (r & 3)) * GA_CP + 64 * wave + 32 * b + fr] = acc[a][b][r];
+    __syncthreads();
+#pragma unroll 2
+    for (int k = 0; k < 8; ++k) {
+      const int row = o0 + 32 * a + 8 * te + k;
+      if (row >= O || col >= I) continue;
+      const size_t base = (size_t)row * I + col;
+      const float* gsrc = ct + (8 * te + k) * GA_CP + 4 * tj;
+#pragma unroll
+      for (int q = 0; q < 4; q += VEC) {
+        if (col + q >= I) break;
+        float P[VEC], M[VEC], V[VEC];
+        if (VEC == 4) {
+          const float4 a4 = *reinterpret_cast<const float4*>(p + base), b4 = *reinterpret_cast<const float4*>(m + base),
+                       c4 = *reinterpret_cast<const float4*>(v + base);
+          P[0] = a4.x; P[VEC > 1 ? 1 : 0] = a4.y; P[VEC > 2 ? 2 : 0] = a4.z; P[VEC > 3 ? 3 : 0] = a4.w;
+          M[0] = b4.x; M[VEC > 1 ? 1 : 0] = b4.y; M[VEC > 2 ? 2 : 0] = b4.z; M[VEC > 3 ? 3 : 0] = b4.w;
+          V[0] = c4.x; V[VEC > 1 ? 1 : 0] = c4.y; V[VEC > 2 ? 2 : 0] = c4.z; V[VEC > 3 ? 3 : 0] = c4.w;
+        } else if (VEC == 2) {
+          const float2 a2 = *reinterpret_cast<const float2*>(p + base + q), b2 = *reinterpret_cast<const float2*>(m + base + q),
+                       c2 = *reinterpret_cast<const float2*>(v + base + q);
+          P[0] = a2.x; P[VEC > 1 ? 1 : 0] = a2.y; M[0] = b2.x; M[VEC > 1 ? 1 : 0] = b2.y; V[0] = c2.x; V[VEC > 1 ? 1 : 0] = c2.y;
+        } else {
+          P[0] = p[base + q]; M[0] = m[base + q]; V[0] = v[base + q];
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) adam_upd(hy, P[e], gsrc[q + e], M[e], V[e]);
+        if (VEC == 4) {
+          *reinterpret_cast<float4*>(p + base) = make_float4(P[0], P[VEC > 1 ? 1 : 0], P[VEC > 2 ? 2 : 0], P[VEC > 3 ? 3 : 0]);
+          *reinterpret_cast<float4*>(m + base) = make_float4(M[0], M[VEC > 1 ? 1 : 0], M[VEC > 2 ? 2 : 0], M[VEC > 3 ? 3 : 0]);
+          *reinterpret_cast<float4*>(v + base) = make_float4(V[0], V[VEC > 1 ? 1 : 0], V[VEC > 2 ? 2 : 0], V[VEC > 3 ? 3 : 0]);
+        } else if (VEC == 2) {
+          *reinterpret_cast<float2*>(p + base + q) = make_float2(P[0], P[VEC > 1 ? 1 : 0]);
+          *reinterpret_cast<float2*>(m + base + q) = make_float2(M[0], M[VEC > 1 ? 1 : 0]);
+          *reinterpret_cast<float2*>(v + base + q) = make_float2(V[0], V[VEC > 1 ? 1 : 0]);
+        } else {
+          p[base + q] = P[0]; m[base + q] = M[0]; v[base + q] = V[0];
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int rg_g0_wgrad_adam_supported(int N, int E, int C, int dtype) {
@@ -214,5 +332,25 @@ extern "C" int rg_g0_wgrad_adam(const float* z, const void* gz0, float* p, float
     hipLaunchKernelGGL(g0_wgrad_adam_kernel<float>, grid, dim3(256), 0, st, z, (const float*)gz0, p, m, v, hyper,
                        (uint16_t*)shadow_bf16, N, E, C, e_fastest);
   RG_LAUNCH_CHECK("g0_wgrad_adam");
+  return RG_OK;
+}
+
+extern "C" int rg_linear_wgrad_adam(const void* gT, const void* xT, int ldn, int N, float* p, float* m, float* v,
+                                    const float* hyper, int O, int I, void* stream) {
+  RG_REQUIRE(gT && xT && p && m && v && hyper && N > 0 && O > 0 && I > 0, RG_EINVAL, "linear_wgrad_adam: bad args");
+  RG_REQUIRE(ldn % 64 == 0 && ldn >= N && (((uintptr_t)gT | (uintptr_t)xT) & 15) == 0, RG_EINVAL,
+             "linear_wgrad_adam: operands must be sample-contiguous, zero padded to a multiple of 64 samples, 16-byte aligned");
+  const dim3 grid((unsigned)((O + GA_E - 1) / GA_E), (unsigned)((I + GA_J - 1) / GA_J));
+  hipStream_t st = rg_stream(stream);
+  const uintptr_t al = (uintptr_t)p | (uintptr_t)m | (uintptr_t)v;
+  const uint16_t* a = (const uint16_t*)gT;
+  const uint16_t* b = (const uint16_t*)xT;
+  if (I % 4 == 0 && (al & 15) == 0)
+    hipLaunchKernelGGL(lin_wgrad_adam_kernel<4>, grid, dim3(256), 0, st, a, b, ldn, N, p, m, v, hyper, O, I);
+  else if (I % 2 == 0 && (al & 7) == 0)
+    hipLaunchKernelGGL(lin_wgrad_adam_kernel<2>, grid, dim3(256), 0, st, a, b, ldn, N, p, m, v, hyper, O, I);
+  else
+    hipLaunchKernelGGL(lin_wgrad_adam_kernel<1>, grid, dim3(256), 0, st, a, b, ldn, N, p, m, v, hyper, O, I);
+  RG_LAUNCH_CHECK("linear_wgrad_adam");
   return RG_OK;
 }

@@ -133,6 +133,16 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
   }
 }
 
+// element-per-thread form for ranges that do not start on a 16-byte boundary (the small bias / BatchNorm ranges between the
+// nn.Linear weights that rg_linear_wgrad_adam steps itself): fp32 gradient, no shadow
+__global__ __launch_bounds__(256) void adam_dev_scalar_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                              float* __restrict__ m, float* __restrict__ v,
+                                                              const float* __restrict__ hyper, size_t n) {
+  const Adam a{p, g, m, v, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6], hyper[7]};
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    a.upd(p[i], g[i], m[i], v[i]);
+}
+
 __global__ void adam_hyper_kernel(int* step_dev, double lr, double b1, double b2, double eps, double wd, float* hyper) {
   hyper[7] = (float)wd;
   int step = *step_dev + 1;
@@ -428,10 +438,16 @@ extern "C" int rg_adam_step(float* p, const float* g, float* m, float* v, size_t
 extern "C" int rg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* hyper,
                                 void* shadow_bf16, const void* grad_bf16, void* stream) {
   RG_REQUIRE(p && (g || grad_bf16) && m && v && hyper, RG_EINVAL, "adam_step_dev: bad args");
+  if (n == 0) return RG_OK;
+  if (!(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v)) && !shadow_bf16 && !grad_bf16 && g &&
+      ((((uintptr_t)p ^ (uintptr_t)g) | ((uintptr_t)p ^ (uintptr_t)m) | ((uintptr_t)p ^ (uintptr_t)v)) & 3) == 0) {
+    hipLaunchKernelGGL(adam_dev_scalar_kernel, dim3(grid_for(n, 1)), dim3(256), 0, rg_stream(stream), p, g, m, v, hyper, n);
+    RG_LAUNCH_CHECK("adam_step_dev(scalar)");
+    return RG_OK;
+  }
   RG_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && ((uintptr_t)shadow_bf16 & 7) == 0 &&
                  ((uintptr_t)grad_bf16 & 7) == 0,
              RG_EINVAL, "adam_step_dev: alignment");
-  if (n == 0) return RG_OK;
   uint16_t* sh = (uint16_t*)shadow_bf16;
   const uint16_t* gw = (const uint16_t*)grad_bf16;
   const dim3 grid(grid_for(n, 4)), block(256);

@@ -35,10 +35,14 @@ class Adam(torch.optim.Adam):
         self.buf_gen = 0           # bumped whenever the moment / step buffers are re-allocated (part of the graph keys)
         self.grad_wire = None      # data parallel, bf16 wire: the all-reduced bf16 gradient buffer to step from
 
-    def bind(self, module):
+    def bind(self, module, fuse_linear_wgrad=False):
         """Tell the optimizer which HIP module owns its parameters (done by the Trainer).  The fused step updates the
         module's WHOLE flat buffer with param_groups[0]'s hyper-parameters, so the optimizer must hold exactly one
-        group with every (trainable) parameter of the module."""
+        group with every (trainable) parameter of the module.
+        fuse_linear_wgrad (betaVAE training, bf16 kernels): the module's backward leaves the operands of every nn.Linear
+        weight gradient (batch-only contraction) behind instead of forming it, and step() forms it inside the Adam pass of
+        that weight (rg_linear_wgrad_adam).  Those weights' .grad is then NOT written: for loops of the reference's shape
+        loss.backward(); optimizer.step() (src/betaVAE.py:225-226) with nothing reading .grad in between."""
         mine = {id(p) for g in self.param_groups for p in g["params"]}
         theirs = list(module.parameters())
         if len(self.param_groups) != 1 or mine != {id(p) for p in theirs}:
@@ -47,6 +51,10 @@ class Adam(torch.optim.Adam):
         if not all(p.requires_grad for p in theirs):
             raise ValueError("rna_gan_amd.optim.Adam: frozen parameters (requires_grad=False) are not supported")
         self._module = module
+        if fuse_linear_wgrad:
+            module._fuse_linear_wgrad = True
+            if hasattr(module, "_trt"):
+                module._trt = None                 # the training runtime reads the flag when it is built
         return self
 
     def _ensure(self):
@@ -152,12 +160,33 @@ class Adam(torch.optim.Adam):
                                        self._v.data_ptr(), self._hyper.data_ptr(), 0 if shadow is None else shadow.data_ptr(),
                                        z.shape[0], E, C, dt, stream), "rg_g0_wgrad_adam")
             lo = n0
-        nrest = flat.data.numel() - lo
-        check(lib.rg_adam_step_dev(flat.data.data_ptr() + 4 * lo, flat.grad.data_ptr() + 4 * lo, self._m.data_ptr() + 4 * lo,
-                                   self._v.data_ptr() + 4 * lo, nrest, self._hyper.data_ptr(),
-                                   0 if shadow is None else shadow.data_ptr() + 2 * lo,
-                                   0 if self.grad_wire is None else self.grad_wire.data_ptr() + 2 * lo, stream),
-              "rg_adam_step_dev")
+        # nn.Linear weights whose gradient operands the backward left behind (bind(fuse_linear_wgrad=True)): gradient + Adam
+        # in one pass per weight; everything between those segments (biases, BatchNorm parameters) steps from .grad as usual
+        segs = []
+        pend_lin = getattr(self._module, "_rg_pending_linear", None)
+        if pend_lin:
+            self._module._rg_pending_linear = []
+            if shadow is not None or self.grad_wire is not None:
+                raise RuntimeError("rna_gan_amd.optim.Adam: fused linear weight gradients expect an fp32-only, single-process step")
+            for w, gT, xT, nsamp in pend_lin:
+                off = (w.data_ptr() - flat.data.data_ptr()) // 4
+                O_, I_ = w.shape
+                if not w.is_contiguous() or off < 0 or off + O_ * I_ > flat.data.numel():
+                    raise RuntimeError("rna_gan_amd.optim.Adam: a pending linear weight is not a dense view of the flat buffer")
+                check(lib.rg_linear_wgrad_adam(gT.data_ptr(), xT.data_ptr(), gT.shape[1], nsamp, flat.data.data_ptr() + 4 * off,
+                                               self._m.data_ptr() + 4 * off, self._v.data_ptr() + 4 * off,
+                                               self._hyper.data_ptr(), O_, I_, stream), "rg_linear_wgrad_adam")
+                segs.append((off, off + O_ * I_))
+            segs.sort()
+        pos = lo
+        for a, b in segs + [(flat.data.numel(), flat.data.numel())]:
+            if a > pos:
+                check(lib.rg_adam_step_dev(flat.data.data_ptr() + 4 * pos, flat.grad.data_ptr() + 4 * pos,
+                                           self._m.data_ptr() + 4 * pos, self._v.data_ptr() + 4 * pos, a - pos,
+                                           self._hyper.data_ptr(), 0 if shadow is None else shadow.data_ptr() + 2 * pos,
+                                           0 if self.grad_wire is None else self.grad_wire.data_ptr() + 2 * pos, stream),
+                      "rg_adam_step_dev")
+            pos = max(pos, b)
         if not torch.cuda.is_current_stream_capturing():
             self._host_steps += 1
         self._module.weights_changed(by_optimizer=True)

@@ -47,6 +47,9 @@ class VaeRuntime:
         self.ops = HipOps(torch.float32, dev)          # fp32 rows between the GEMMs
         self.lib, self.dev = self.ops.lib, dev
         self.bf16 = model.precision == "bf16"
+        # rna_gan_amd.optim.Adam.bind(model, fuse_linear_wgrad=True): the Linear weight gradients are formed inside the
+        # optimizer step from the operands linear_bwd leaves behind (bf16 kernels only)
+        self.fuse_wgrad = self.bf16 and bool(getattr(model, "_fuse_linear_wgrad", False))
         self.enc = [(b[0], b[1], float(b[2].negative_slope)) for b in list(model.encoder.encoder.children())[1:]]
         dec = list(model.decoder.children())
         self.dec = [(b[0], b[1], float(b[2].negative_slope)) for b in dec[:-1]]
@@ -111,7 +114,12 @@ class VaeRuntime:
         """hin [N][K>=in] (the layer's input rows), gy [N][C>=out]: writes lin.weight.grad / lin.bias.grad, returns dx"""
         out_f, in_f = lin.weight.shape
         N = gy.shape[0]
-        self.mm(self.opT(gy), self.opT(hin), out_f, in_f, lin.weight.grad, in_f)          # dW = gy^T . hin
+        if self.fuse_wgrad:
+            # dW = gy^T . hin is formed inside the Adam pass of this weight (rg_linear_wgrad_adam): its transposed bf16
+            # operands -- the ones the GEMM below would take -- are left on the model for optimizer.step()
+            self.model._rg_pending_linear.append((lin.weight, self.opT(gy), self.opT(hin), N))
+        else:
+            self.mm(self.opT(gy), self.opT(hin), out_f, in_f, lin.weight.grad, in_f)      # dW = gy^T . hin
         if gy.shape[1] == out_f:
             self.ops.col_sum(gy, lin.bias.grad, False)
         else:
@@ -183,6 +191,7 @@ class VaeRuntime:
     def backward(self, sv, g_out, g_mu, g_lv):
         """g_out [N][ld] dense (d loss / d out, pad columns ignored), g_mu / g_lv [N][Z] or None."""
         m, ops = self.model, self.ops
+        m._rg_pending_linear = []                 # (weight, gT, xT, N) per Linear layer when fuse_wgrad
         gz = torch.empty_like(sv.out)
         check(self.lib.rg_tanh_bwd(_ptr(g_out), _ptr(sv.out), _ptr(gz), gz.numel(), ops.stream), "rg_tanh_bwd")
         gh = self.linear_bwd(self.out_lin, sv.hd, gz, True)
@@ -356,6 +365,10 @@ def train_betaVAE(model, optimizer, dataloader, save_dir="checkpoints/models/", 
     ``model_dict_best.pt``, the last one as ``model_last.pt`` and reloads the best before returning (model, results).
     ``optimizer``: rna_gan_amd.Adam(...).bind(model) runs the fused HIP step; any torch optimizer works on the views."""
     os.makedirs(save_dir, exist_ok=True)
+    if hasattr(optimizer, "note_replayed") and getattr(optimizer, "_module", None) is model and model.precision == "bf16":
+        # this loop steps right after backward and reads no .grad in between: the Linear weight gradients are formed inside
+        # the optimizer step (rg_linear_wgrad_adam)
+        optimizer.bind(model, fuse_linear_wgrad=True)
     best = {"total_loss": float("inf")}
     best_epoch = 0
     history = {ph: {k: [] for k in _KEYS} for ph in ("train", "val")}

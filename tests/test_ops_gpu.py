@@ -773,3 +773,48 @@ def test_split_k_batchnorm_fusion_small_shapes(I, O, hs, n, groups):
         assert rel(res[0][0], res[1][0]) < 8e-3 and rel(res[0][1], res[1][1]) < 1e-4 and rel(res[0][2], res[1][2]) < 1e-4, conv
     assert used >= 1, "none of the four pairings took the slab path at this shape: the case checks nothing"
     assert int(fu._sb_sync[0]) == 0, "no hand-off timed out"
+
+
+@pytest.mark.parametrize("N,O,I", [(64, 200, 774), (100, 64, 515), (40, 130, 1024), (64, 6000, 2048)])
+def test_linear_weight_gradient_inside_adam(N, O, I):
+    """rg_linear_wgrad_adam on a weight segment W[O][I] inside a larger buffer (so that its start is only 4- / 8- / 16-byte
+    aligned as the case may be): dW = g^T x from the transposed, zero-padded bf16 operand images, torch.optim.Adam's update
+    with weight decay; ragged tiles in both directions, odd row pitch, a ragged second 64-sample chunk; the floats around the
+    segment stay untouched."""
+    from rna_gan_amd import _abi
+    dev = torch.device("cuda:0")
+    lib = _abi.load()
+    gen = torch.Generator().manual_seed(N + O + I)
+    lead = {774: 2, 515: 1, 1024: 4, 2048: 0}[I]                 # elements in front of the segment: alignment 8 / 4 / 16 / 16
+    buf = [torch.zeros(lead + O * I + 8, device=dev) for _ in range(3)]
+    p, m, v = [b[lead:lead + O * I].view(O, I) for b in buf]
+    p.copy_((torch.randn(O, I, generator=gen) * 0.05).to(dev)); m.copy_((torch.randn(O, I, generator=gen) * 1e-3).to(dev))
+    v.copy_((torch.rand(O, I, generator=gen) * 1e-4).to(dev))
+    for b in buf:
+        b[:lead] = 7.0; b[lead + O * I:] = 7.0
+    p0, m0, v0 = p.clone(), m.clone(), v.clone()
+    g = (torch.randn(N, O, generator=gen) * 0.1).to(dev)
+    x = torch.randn(N, I, generator=gen).to(dev)
+    ldn = (N + 63) // 64 * 64
+    gT = torch.zeros(O + 3, ldn, dtype=torch.bfloat16, device=dev); gT[:O, :N] = g.t().bfloat16()
+    xT = torch.zeros(I + 5, ldn, dtype=torch.bfloat16, device=dev); xT[:I, :N] = x.t().bfloat16()
+    step = torch.full((1,), 2, dtype=torch.int32, device=dev)
+    hyper = torch.zeros(8, device=dev)
+    lr, b1, b2, eps, wd = 3e-3, 0.9, 0.999, 1e-8, 1e-4
+    stream = torch.cuda.current_stream().cuda_stream
+    _abi.check(lib.rg_adam_hyper_dev(step.data_ptr(), lr, b1, b2, eps, wd, hyper.data_ptr(), stream), "rg_adam_hyper_dev")
+    _abi.check(lib.rg_linear_wgrad_adam(gT.data_ptr(), xT.data_ptr(), ldn, N, p.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                        hyper.data_ptr(), O, I, stream), "rg_linear_wgrad_adam")
+    torch.cuda.synchronize()
+    dw = g.bfloat16().float().t() @ x.bfloat16().float()
+    t = 3
+    gg = dw + wd * p0
+    m1 = m0 + (1 - b1) * (gg - m0)
+    v1 = b2 * v0 + (1 - b2) * gg * gg
+    p1 = p0 - (lr / (1 - b1 ** t)) * (m1 / (v1.sqrt() / (1 - b2 ** t) ** 0.5 + eps))
+    scale = float(dw.abs().mean())
+    assert float((m - m1).abs().max()) <= 2e-4 * (1 - b1) * scale * N ** 0.5 + 1e-6
+    assert float(((v - v1) / (v1 + 1e-12)).abs().max()) <= 2e-3
+    assert float(((p - p0) - (p1 - p0)).abs().max()) <= 2e-3 * float((p1 - p0).abs().max())
+    for b in buf:
+        assert bool((b[:lead] == 7.0).all()) and bool((b[lead + O * I:] == 7.0).all())

@@ -208,3 +208,48 @@ def test_vae_full_size_iteration():
         opt.step()
     assert all(torch.isfinite(v).all() for v in losses.values())
     assert torch.isfinite(m.z_mu.weight).all() and not torch.equal(before, m.z_mu.weight)
+
+
+@pytest.mark.parametrize("dims,N", [((1030, 136, [520, 264, 136], [264, 520]), 40), ((774, 136, [130, 200, 136], [72, 330]), 100)])
+def test_linear_weight_gradients_inside_the_adam_step(dims, N):
+    """P.Adam(...).bind(model, fuse_linear_wgrad=True): the backward leaves the transposed bf16 operands of every nn.Linear
+    weight gradient behind and the optimizer forms dW = g^T x inside that weight's Adam pass (rg_linear_wgrad_adam: MFMA over
+    the batch, weight decay, no gradient round trip).  Three training iterations against the same model stepped through the
+    separate weight-gradient GEMM + flat Adam: same losses, same weights / moments to the round-off of a differently ordered
+    batch sum.  Widths that are no multiple of the 64 x 256 tile, row pitches with I % 4 == 2 (8-byte accesses), a batch of 100
+    (two 64-sample chunks, the second ragged); tests/test_ops_gpu.py drives the kernel directly, odd row pitch included."""
+    om = R.seeded_fill_(R.OracleBetaVAE(*dims, beta=2.0), 41)
+    x = R.synthetic_rna(N, dims[0], seed=42, distinct=N).cuda()
+    res = []
+    for fuse in (True, False):
+        m = product_vae(om, "bf16", dims)
+        opt = P.Adam(m.parameters(), lr=1e-3, weight_decay=1e-4).bind(m, fuse_linear_wgrad=fuse)
+        m.train()
+        gen = torch.Generator().manual_seed(43)
+        losses = []
+        for it in range(3):
+            m.fixed_mask = torch.empty(N, dims[0]).bernoulli_(0.5, generator=gen).to(torch.uint8).cuda()
+            m.fixed_eps = torch.randn(N, dims[1], generator=gen).cuda()
+            opt.zero_grad(set_to_none=True)
+            out, mu, lv = m(x)
+            ls = VT.betaVAEloss(x, out, mu, lv, m.beta, training=True)
+            ls["total_loss"].backward()
+            assert bool(getattr(m, "_rg_pending_linear", None)) == fuse
+            opt.step()
+            assert not getattr(m, "_rg_pending_linear", None)
+            losses.append(float(ls["total_loss"].detach()))
+        torch.cuda.synchronize()
+        st = opt.state_dict()["state"]
+        names = [n for n, _ in m.named_parameters()]
+        res.append((losses, {n: p.detach().float().cpu().clone() for n, p in m.named_parameters()},
+                    {names[i]: (s["exp_avg"].float().cpu().clone(), s["exp_avg_sq"].float().cpu().clone()) for i, s in st.items()}))
+    (la, wa, sa), (lb, wb, sb) = res
+    assert max(abs(a - b) / (abs(b) + 1e-6) for a, b in zip(la, lb)) < 2e-3, (la, lb)
+    init = dict(om.named_parameters())
+    for n in wa:
+        if n in VAE_DEAD_BIASES:
+            continue
+        ua, ub = wa[n] - init[n].detach().float(), wb[n] - init[n].detach().float()
+        cos = float((ua * ub).sum() / (ua.norm() * ub.norm() + 1e-30))
+        assert cos > (0.995 if ub.numel() >= 4096 else 0.97), (n, cos)        # three sign-like Adam steps coincide
+        assert l2rel(sa[n][0], sb[n][0]) < 2e-2 and l2rel(sa[n][1], sb[n][1]) < 4e-2, n

@@ -1,6 +1,6 @@
 """Time one betaVAE training iteration (forward, loss, backward, fused Adam) at the reference's full size
 (19198 genes, [6000, 4000, 2048] / [4000, 6000], batch 64 = src/betaVAE_training.py defaults) on the HIP path."""
-import sys, time
+import os, sys, time
 import torch
 sys.path.insert(0, ".")
 import rna_gan_amd as P
@@ -15,7 +15,7 @@ def main():
     m = P.betaVAE(*dims, beta=2.0)
     R.seeded_fill_(m, 51)
     m = m.set_precision(prec).cuda().train()
-    opt = P.Adam(m.parameters(), lr=3e-3, weight_decay=1e-4).bind(m)
+    opt = P.Adam(m.parameters(), lr=3e-3, weight_decay=1e-4).bind(m, fuse_linear_wgrad=os.environ.get("VAE_FUSE", "1") != "0")
     x = torch.tanh(torch.randn(N, dims[0], device="cuda"))
     nparam = sum(p.numel() for p in m.parameters())
 
