@@ -265,41 +265,58 @@ __global__ __launch_bounds__(256) void lin_wgrad_adam_kernel(const uint16_t* __r
       for (int r = 0; r < 16; ++r)
         ct[(8 * (r >> 2) + 4 * fh + (r & 3)) * GA_CP + 64 * wave + 32 * b + fr] = acc[a][b][r];
     __syncthreads();
-#pragma unroll 2
-    for (int k = 0; k < 8; ++k) {
-      const int row = o0 + 32 * a + 8 * te + k;
-      if (row >= O || col >= I) continue;
-      const size_t base = (size_t)row * I + col;
-      const float* gsrc = ct + (8 * te + k) * GA_CP + 4 * tj;
+    // four rows at a time: their p / m / v are requested before the first update is computed (4 x 3 x 16 B in flight per
+    // thread, as in g0_wgrad_adam_kernel), VPR = vectors of VEC floats per row
+    constexpr int VPR = 4 / VEC;
 #pragma unroll
-      for (int q = 0; q < 4; q += VEC) {
-        if (col + q >= I) break;
-        float P[VEC], M[VEC], V[VEC];
-        if (VEC == 4) {
-          const float4 a4 = *reinterpret_cast<const float4*>(p + base), b4 = *reinterpret_cast<const float4*>(m + base),
-                       c4 = *reinterpret_cast<const float4*>(v + base);
-          P[0] = a4.x; P[VEC > 1 ? 1 : 0] = a4.y; P[VEC > 2 ? 2 : 0] = a4.z; P[VEC > 3 ? 3 : 0] = a4.w;
-          M[0] = b4.x; M[VEC > 1 ? 1 : 0] = b4.y; M[VEC > 2 ? 2 : 0] = b4.z; M[VEC > 3 ? 3 : 0] = b4.w;
-          V[0] = c4.x; V[VEC > 1 ? 1 : 0] = c4.y; V[VEC > 2 ? 2 : 0] = c4.z; V[VEC > 3 ? 3 : 0] = c4.w;
-        } else if (VEC == 2) {
-          const float2 a2 = *reinterpret_cast<const float2*>(p + base + q), b2 = *reinterpret_cast<const float2*>(m + base + q),
-                       c2 = *reinterpret_cast<const float2*>(v + base + q);
-          P[0] = a2.x; P[VEC > 1 ? 1 : 0] = a2.y; M[0] = b2.x; M[VEC > 1 ? 1 : 0] = b2.y; V[0] = c2.x; V[VEC > 1 ? 1 : 0] = c2.y;
-        } else {
-          P[0] = p[base + q]; M[0] = m[base + q]; V[0] = v[base + q];
+    for (int k0 = 0; k0 < 8; k0 += 4) {
+      float P[4][4], M[4][4], V[4][4];
+      bool ok[4][VPR];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = o0 + 32 * a + 8 * te + k0 + k;
+        const size_t base = (size_t)row * I + col;
+#pragma unroll
+        for (int q = 0; q < VPR; ++q) {
+          ok[k][q] = row < O && col + q * VEC < I;
+          if (!ok[k][q]) continue;
+          if constexpr (VEC == 4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(p + base), b4 = *reinterpret_cast<const float4*>(m + base),
+                         c4 = *reinterpret_cast<const float4*>(v + base);
+            P[k][0] = a4.x; P[k][1] = a4.y; P[k][2] = a4.z; P[k][3] = a4.w;
+            M[k][0] = b4.x; M[k][1] = b4.y; M[k][2] = b4.z; M[k][3] = b4.w;
+            V[k][0] = c4.x; V[k][1] = c4.y; V[k][2] = c4.z; V[k][3] = c4.w;
+          } else if constexpr (VEC == 2) {
+            const float2 a2 = *reinterpret_cast<const float2*>(p + base + 2 * q), b2 = *reinterpret_cast<const float2*>(m + base + 2 * q),
+                         c2 = *reinterpret_cast<const float2*>(v + base + 2 * q);
+            P[k][2 * q] = a2.x; P[k][2 * q + 1] = a2.y; M[k][2 * q] = b2.x; M[k][2 * q + 1] = b2.y;
+            V[k][2 * q] = c2.x; V[k][2 * q + 1] = c2.y;
+          } else {
+            P[k][q] = p[base + q]; M[k][q] = m[base + q]; V[k][q] = v[base + q];
+          }
         }
+      }
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) adam_upd(hy, P[e], gsrc[q + e], M[e], V[e]);
-        if (VEC == 4) {
-          *reinterpret_cast<float4*>(p + base) = make_float4(P[0], P[VEC > 1 ? 1 : 0], P[VEC > 2 ? 2 : 0], P[VEC > 3 ? 3 : 0]);
-          *reinterpret_cast<float4*>(m + base) = make_float4(M[0], M[VEC > 1 ? 1 : 0], M[VEC > 2 ? 2 : 0], M[VEC > 3 ? 3 : 0]);
-          *reinterpret_cast<float4*>(v + base) = make_float4(V[0], V[VEC > 1 ? 1 : 0], V[VEC > 2 ? 2 : 0], V[VEC > 3 ? 3 : 0]);
-        } else if (VEC == 2) {
-          *reinterpret_cast<float2*>(p + base + q) = make_float2(P[0], P[VEC > 1 ? 1 : 0]);
-          *reinterpret_cast<float2*>(m + base + q) = make_float2(M[0], M[VEC > 1 ? 1 : 0]);
-          *reinterpret_cast<float2*>(v + base + q) = make_float2(V[0], V[VEC > 1 ? 1 : 0]);
-        } else {
-          p[base + q] = P[0]; m[base + q] = M[0]; v[base + q] = V[0];
+      for (int k = 0; k < 4; ++k) {
+        const int row = o0 + 32 * a + 8 * te + k0 + k;
+        const size_t base = (size_t)row * I + col;
+        const float* gsrc = ct + (8 * te + k0 + k) * GA_CP + 4 * tj;
+#pragma unroll
+        for (int q = 0; q < VPR; ++q) {
+          if (!ok[k][q]) continue;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) adam_upd(hy, P[k][q * VEC + e], gsrc[q * VEC + e], M[k][q * VEC + e], V[k][q * VEC + e]);
+          if constexpr (VEC == 4) {
+            *reinterpret_cast<float4*>(p + base) = make_float4(P[k][0], P[k][1], P[k][2], P[k][3]);
+            *reinterpret_cast<float4*>(m + base) = make_float4(M[k][0], M[k][1], M[k][2], M[k][3]);
+            *reinterpret_cast<float4*>(v + base) = make_float4(V[k][0], V[k][1], V[k][2], V[k][3]);
+          } else if constexpr (VEC == 2) {
+            *reinterpret_cast<float2*>(p + base + 2 * q) = make_float2(P[k][2 * q], P[k][2 * q + 1]);
+            *reinterpret_cast<float2*>(m + base + 2 * q) = make_float2(M[k][2 * q], M[k][2 * q + 1]);
+            *reinterpret_cast<float2*>(v + base + 2 * q) = make_float2(V[k][2 * q], V[k][2 * q + 1]);
+          } else {
+            p[base + q] = P[k][q]; m[base + q] = M[k][q]; v[base + q] = V[k][q];
+          }
         }
       }
     }
