@@ -279,9 +279,11 @@ int rg_g0_wgrad_adam(const float* z, const void* gz0, float* p, float* m, float*
  * -- the betaVAE's layers in src/betaVAE_training.py (optimizer.step() at src/betaVAE.py:226 after loss.backward() :225).
  * gT [>= O][ldn] and xT [>= I][ldn]: bf16, samples contiguous, zero padded to ldn (a multiple of 64) -- the images
  * rg_transpose_pack_bf16 writes.  p / m / v: the weight's segment of the flat parameter / moment buffers; hyper: rg_adam_hyper_dev.
- * The gradient itself is not written anywhere. */
+ * The gradient itself is not written anywhere.  wpack_bf16 (optional): the bf16 operand image [>= O][Kp] of the UPDATED weight in
+ * rg_pack_linear_weight's layout (its zero padding is the caller's: only the O x I entries are written), so that the next
+ * forward needs no packing pass. */
 int rg_linear_wgrad_adam(const void* gT, const void* xT, int ldn, int N, float* p, float* m, float* v, const float* hyper, int O,
-                         int I, void* stream);
+                         int I, void* wpack_bf16, int Kp, void* stream);
 
 /* ---- Inception-v3 feature extractor of the FID metric (src/fid.py:33-94: torchvision inception_v3 up to Mixed_7c) --------
  * NHWC fp32.  A BasicConv2d (Conv2d(bias=False) + BatchNorm2d(eval, eps 1e-3) + ReLU) = rg_im2col_nhwc (not needed for 1x1

@@ -201,7 +201,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void lin_wgrad_adam_kernel(const uint16_t* __restrict__ gT, const uint16_t* __restrict__ xT,
                                                              int ldn, int N, float* __restrict__ p, float* __restrict__ m,
                                                              float* __restrict__ v, const float* __restrict__ hyper, int O,
-                                                             int I) {
+                                                             int I, uint16_t* __restrict__ wpack, int Kp) {
   constexpr int OPS = (GA_E + GA_J) * GA_P * 2;
   __shared__ __attribute__((aligned(16))) unsigned char smem[OPS];
   uint16_t* zsT = reinterpret_cast<uint16_t*>(smem);                  // [64 o][GA_P]
@@ -310,12 +310,20 @@ __global__ __launch_bounds__(256) void lin_wgrad_adam_kernel(const uint16_t* __r
             *reinterpret_cast<float4*>(p + base) = make_float4(P[k][0], P[k][1], P[k][2], P[k][3]);
             *reinterpret_cast<float4*>(m + base) = make_float4(M[k][0], M[k][1], M[k][2], M[k][3]);
             *reinterpret_cast<float4*>(v + base) = make_float4(V[k][0], V[k][1], V[k][2], V[k][3]);
+            if (wpack)      // the next forward's bf16 operand image [.][Kp] of the UPDATED weight (rg_pack_linear_weight's layout)
+              *reinterpret_cast<uint2*>(wpack + (size_t)row * Kp + col) =
+                  make_uint2((uint32_t)f32_to_bf16(P[k][0]) | ((uint32_t)f32_to_bf16(P[k][1]) << 16),
+                             (uint32_t)f32_to_bf16(P[k][2]) | ((uint32_t)f32_to_bf16(P[k][3]) << 16));
           } else if constexpr (VEC == 2) {
             *reinterpret_cast<float2*>(p + base + 2 * q) = make_float2(P[k][2 * q], P[k][2 * q + 1]);
             *reinterpret_cast<float2*>(m + base + 2 * q) = make_float2(M[k][2 * q], M[k][2 * q + 1]);
             *reinterpret_cast<float2*>(v + base + 2 * q) = make_float2(V[k][2 * q], V[k][2 * q + 1]);
+            if (wpack)
+              *reinterpret_cast<uint32_t*>(wpack + (size_t)row * Kp + col + 2 * q) =
+                  (uint32_t)f32_to_bf16(P[k][2 * q]) | ((uint32_t)f32_to_bf16(P[k][2 * q + 1]) << 16);
           } else {
             p[base + q] = P[k][q]; m[base + q] = M[k][q]; v[base + q] = V[k][q];
+            if (wpack) wpack[(size_t)row * Kp + col + q] = f32_to_bf16(P[k][q]);
           }
         }
       }
@@ -353,21 +361,24 @@ extern "C" int rg_g0_wgrad_adam(const float* z, const void* gz0, float* p, float
 }
 
 extern "C" int rg_linear_wgrad_adam(const void* gT, const void* xT, int ldn, int N, float* p, float* m, float* v,
-                                    const float* hyper, int O, int I, void* stream) {
+                                    const float* hyper, int O, int I, void* wpack_bf16, int Kp, void* stream) {
   RG_REQUIRE(gT && xT && p && m && v && hyper && N > 0 && O > 0 && I > 0, RG_EINVAL, "linear_wgrad_adam: bad args");
   RG_REQUIRE(ldn % 64 == 0 && ldn >= N && (((uintptr_t)gT | (uintptr_t)xT) & 15) == 0, RG_EINVAL,
              "linear_wgrad_adam: operands must be sample-contiguous, zero padded to a multiple of 64 samples, 16-byte aligned");
+  RG_REQUIRE(!wpack_bf16 || (Kp >= I && Kp % 8 == 0 && ((uintptr_t)wpack_bf16 & 15) == 0), RG_EINVAL,
+             "linear_wgrad_adam: packed image needs Kp >= I, Kp %% 8 == 0, 16-byte alignment");
+  uint16_t* wpk = (uint16_t*)wpack_bf16;
   const dim3 grid((unsigned)((O + GA_E - 1) / GA_E), (unsigned)((I + GA_J - 1) / GA_J));
   hipStream_t st = rg_stream(stream);
   const uintptr_t al = (uintptr_t)p | (uintptr_t)m | (uintptr_t)v;
   const uint16_t* a = (const uint16_t*)gT;
   const uint16_t* b = (const uint16_t*)xT;
   if (I % 4 == 0 && (al & 15) == 0)
-    hipLaunchKernelGGL(lin_wgrad_adam_kernel<4>, grid, dim3(256), 0, st, a, b, ldn, N, p, m, v, hyper, O, I);
+    hipLaunchKernelGGL(lin_wgrad_adam_kernel<4>, grid, dim3(256), 0, st, a, b, ldn, N, p, m, v, hyper, O, I, wpk, Kp);
   else if (I % 2 == 0 && (al & 7) == 0)
-    hipLaunchKernelGGL(lin_wgrad_adam_kernel<2>, grid, dim3(256), 0, st, a, b, ldn, N, p, m, v, hyper, O, I);
+    hipLaunchKernelGGL(lin_wgrad_adam_kernel<2>, grid, dim3(256), 0, st, a, b, ldn, N, p, m, v, hyper, O, I, wpk, Kp);
   else
-    hipLaunchKernelGGL(lin_wgrad_adam_kernel<1>, grid, dim3(256), 0, st, a, b, ldn, N, p, m, v, hyper, O, I);
+    hipLaunchKernelGGL(lin_wgrad_adam_kernel<1>, grid, dim3(256), 0, st, a, b, ldn, N, p, m, v, hyper, O, I, wpk, Kp);
   RG_LAUNCH_CHECK("linear_wgrad_adam");
   return RG_OK;
 }

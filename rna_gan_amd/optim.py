@@ -168,14 +168,20 @@ class Adam(torch.optim.Adam):
             self._module._rg_pending_linear = []
             if shadow is not None or self.grad_wire is not None:
                 raise RuntimeError("rna_gan_amd.optim.Adam: fused linear weight gradients expect an fp32-only, single-process step")
-            for w, gT, xT, nsamp in pend_lin:
+            for w, gT, xT, nsamp, pack in pend_lin:
                 off = (w.data_ptr() - flat.data.data_ptr()) // 4
                 O_, I_ = w.shape
                 if not w.is_contiguous() or off < 0 or off + O_ * I_ > flat.data.numel():
                     raise RuntimeError("rna_gan_amd.optim.Adam: a pending linear weight is not a dense view of the flat buffer")
+                # pack: {"image": bf16 [Np][Kp] zero-initialised, "version": ...} -- the runtime's operand image of this weight; the
+                # kernel refreshes it from the updated values, and it is marked current for the tensor version seen here
+                img = None if pack is None else pack["image"]
                 check(lib.rg_linear_wgrad_adam(gT.data_ptr(), xT.data_ptr(), gT.shape[1], nsamp, flat.data.data_ptr() + 4 * off,
                                                self._m.data_ptr() + 4 * off, self._v.data_ptr() + 4 * off,
-                                               self._hyper.data_ptr(), O_, I_, stream), "rg_linear_wgrad_adam")
+                                               self._hyper.data_ptr(), O_, I_, 0 if img is None else img.data_ptr(),
+                                               0 if img is None else img.shape[1], stream), "rg_linear_wgrad_adam")
+                if pack is not None:
+                    pack["version"] = w._version
                 segs.append((off, off + O_ * I_))
             segs.sort()
         pos = lo

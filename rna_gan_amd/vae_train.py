@@ -50,6 +50,7 @@ class VaeRuntime:
         # rna_gan_amd.optim.Adam.bind(model, fuse_linear_wgrad=True): the Linear weight gradients are formed inside the
         # optimizer step from the operands linear_bwd leaves behind (bf16 kernels only)
         self.fuse_wgrad = self.bf16 and bool(getattr(model, "_fuse_linear_wgrad", False))
+        self._packs = {}
         self.enc = [(b[0], b[1], float(b[2].negative_slope)) for b in list(model.encoder.encoder.children())[1:]]
         dec = list(model.decoder.children())
         self.dec = [(b[0], b[1], float(b[2].negative_slope)) for b in dec[:-1]]
@@ -71,8 +72,23 @@ class VaeRuntime:
         return a
 
     def opB(self, W):
-        """fp32 [Nout][K] (dense, Linear.weight layout) -> B operand"""
-        return self.ops.pack_linear(W) if self.bf16 else W
+        """fp32 [Nout][K] (dense, Linear.weight layout) -> B operand.  With fuse_wgrad the fused Adam pass keeps a bf16
+        operand image per weight current (rg_linear_wgrad_adam's wpack); it is trusted while the tensor's version counter is
+        the one the optimizer saw (any torch-side write -- load_state_dict, another optimizer -- bumps it: repacked then)."""
+        if not self.bf16:
+            return W
+        pk = self._packs.get(id(W)) if self.fuse_wgrad else None
+        if pk is not None and pk["version"] == W._version:
+            return pk["image"]
+        img = self.ops.pack_linear(W)
+        if self.fuse_wgrad:
+            if pk is None:
+                self._packs[id(W)] = {"image": img, "version": None}       # padding already zero; adopted by the next step
+            else:
+                pk["image"].copy_(img)
+                pk["version"] = None
+                img = pk["image"]
+        return img
 
     def opT(self, S):
         """fp32 [R][C] (dense) -> S^T as an operand: [C][R] (bf16: R zero padded to a multiple of 64)"""
@@ -117,7 +133,7 @@ class VaeRuntime:
         if self.fuse_wgrad:
             # dW = gy^T . hin is formed inside the Adam pass of this weight (rg_linear_wgrad_adam): its transposed bf16
             # operands -- the ones the GEMM below would take -- are left on the model for optimizer.step()
-            self.model._rg_pending_linear.append((lin.weight, self.opT(gy), self.opT(hin), N))
+            self.model._rg_pending_linear.append((lin.weight, self.opT(gy), self.opT(hin), N, self._packs.get(id(lin.weight))))
         else:
             self.mm(self.opT(gy), self.opT(hin), out_f, in_f, lin.weight.grad, in_f)      # dW = gy^T . hin
         if gy.shape[1] == out_f:

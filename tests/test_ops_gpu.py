@@ -803,9 +803,12 @@ def test_linear_weight_gradient_inside_adam(N, O, I):
     lr, b1, b2, eps, wd = 3e-3, 0.9, 0.999, 1e-8, 1e-4
     stream = torch.cuda.current_stream().cuda_stream
     _abi.check(lib.rg_adam_hyper_dev(step.data_ptr(), lr, b1, b2, eps, wd, hyper.data_ptr(), stream), "rg_adam_hyper_dev")
+    Kp = (I + 63) // 64 * 64
+    wpack = torch.full((O + 2, Kp), 3.0, dtype=torch.bfloat16, device=dev)
     _abi.check(lib.rg_linear_wgrad_adam(gT.data_ptr(), xT.data_ptr(), ldn, N, p.data_ptr(), m.data_ptr(), v.data_ptr(),
-                                        hyper.data_ptr(), O, I, stream), "rg_linear_wgrad_adam")
+                                        hyper.data_ptr(), O, I, wpack.data_ptr(), Kp, stream), "rg_linear_wgrad_adam")
     torch.cuda.synchronize()
+    assert torch.equal(wpack[:O, :I], p.bfloat16()) and bool((wpack[:O, I:] == 3.0).all()) and bool((wpack[O:] == 3.0).all())
     dw = g.bfloat16().float().t() @ x.bfloat16().float()
     t = 3
     gg = dw + wd * p0
