@@ -66,6 +66,7 @@ class HipOps:
         # split-K conv -> BatchNorm without the intermediate passes (rg_splitbn.hip): the conv leaves its slabs, the BatchNorm
         # kernel reduces them (RNAGAN_SPLIT_BN=0: conv + slab reduction + statistics + finisher + apply as separate launches)
         self.split_bn = os.environ.get("RNAGAN_SPLIT_BN", "1") != "0"
+        self._split_bn_dp = None       # decided at the first use: fused split-K BatchNorm kernels only outside data-parallel runs
         # data-gradient convs can also produce the BatchNorm-backward sums of the block they feed in their epilogue
         # (rg_conv_*_bnbwd).  Built, exact, and NOT faster: the extra z read lands in the conv's tail, where every workgroup of
         # the chip is in its epilogue at once (11.95-12.09 ms with the separate reduction pass vs 12.03-12.07 ms with the
@@ -115,6 +116,15 @@ class HipOps:
     def _defer_split(self, up, N, Hl, Wl, O, I, rows_out, C, groups):
         """Split factor if this conv launch can hand its slabs to the fused BatchNorm kernel (groups batch groups), else 0."""
         if not groups or not self.split_bn or self.dt != RG_BF16 or self.stat_reduce is not None or rows_out % groups:
+            return 0
+        # The fused kernels rendezvous across ALL their workgroups (<= 256 blocks of 1024 threads: one whole CU each at the
+        # benchmark's shapes).  In a data-parallel run RCCL's kernels hold some CUs for the length of a collective; the blocks
+        # that cannot be placed would keep the resident ones spinning until the collective ends -- the compute stream would
+        # stall exactly where it is meant to overlap the all-reduce.  Separate launches there (RNAGAN_SPLIT_BN_DP=1 overrides).
+        if self._split_bn_dp is None:
+            from . import dist as D_
+            self._split_bn_dp = (not D_.active()) or os.environ.get("RNAGAN_SPLIT_BN_DP", "0") == "1"
+        if not self._split_bn_dp:
             return 0
         ns = int(self.lib.rg_conv_split(up, N, Hl, Wl, O, I, self.dt, self.algo))
         if ns <= 1 or not self.lib.rg_slab_bn_supported(rows_out // groups, C, groups, ns):
