@@ -131,6 +131,37 @@ def allgather_start(full: torch.Tensor, mine: torch.Tensor):
         return dist.all_gather(list(full.chunk(world_size(), dim=0)), mine.clone(), async_op=True)
 
 
+# RNAGAN_DEBUG_HOG="blocks,microseconds": measurement aid for a single-GPU box -- where an all-reduce would run, a kernel that
+# holds `blocks` CUs for `microseconds` is launched on its own stream (behind the gradients, waited for by allreduce_finish as
+# the collective's work object would be): the CU footprint and duration of a collective without a second GPU.  DESIGN 12.7.
+_HOG = [None]
+
+
+def _hog_start(device):
+    spec = os.environ.get("RNAGAN_DEBUG_HOG")
+    if not spec:
+        return None
+    from . import _abi
+    blocks, usec = [int(v) for v in spec.split(",")]
+    if _HOG[0] is None:
+        _HOG[0] = (torch.cuda.Stream(device), torch.zeros(4, device=device))
+    stream, sink = _HOG[0]
+    stream.wait_stream(torch.cuda.current_stream(device))
+    _abi.check(_abi.load().rg_debug_hold_cus(blocks, usec, sink.data_ptr(), stream.cuda_stream), "rg_debug_hold_cus")
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    return ev
+
+
+class _HogWork:
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        if self.ev is not None:
+            torch.cuda.current_stream().wait_event(self.ev)
+
+
 def allreduce_start(flat: torch.Tensor, compress: bool = False, head: int = 0):
     """Start the in-place SUM all-reduce of a flat fp32 gradient buffer (fixed-size buckets, asynchronous: RCCL runs
     on its own stream behind everything enqueued so far on the current one).  Returns a handle for
@@ -149,8 +180,12 @@ def allreduce_start(flat: torch.Tensor, compress: bool = False, head: int = 0):
         stream = torch.cuda.current_stream(flat.device).cuda_stream
         _abi.check(lib.rg_cast_pad(flat.data_ptr() + 4 * head, wire.data_ptr() + 2 * head, 1, n - head, n - head,
                                    _abi.RG_BF16, stream), "rg_cast_pad")
-        return (wire, flat, _launch_buckets(wire[head:], BUCKET_BYTES // 2))
-    return (None, flat, _launch_buckets(flat[head:], BUCKET_BYTES // flat.element_size()))
+        works = _launch_buckets(wire[head:], BUCKET_BYTES // 2)
+        hog = _hog_start(flat.device) if flat.is_cuda else None
+        return (wire, flat, works + ([_HogWork(hog)] if hog is not None else []))
+    works = _launch_buckets(flat[head:], BUCKET_BYTES // flat.element_size())
+    hog = _hog_start(flat.device) if flat.is_cuda else None
+    return (None, flat, works + ([_HogWork(hog)] if hog is not None else []))
 
 
 def allreduce_finish(handle, widen=True):
