@@ -117,13 +117,14 @@ class HipOps:
         """Split factor if this conv launch can hand its slabs to the fused BatchNorm kernel (groups batch groups), else 0."""
         if not groups or not self.split_bn or self.dt != RG_BF16 or self.stat_reduce is not None or rows_out % groups:
             return 0
-        # The fused kernels rendezvous across ALL their workgroups (<= 256 blocks of 1024 threads: one whole CU each at the
-        # benchmark's shapes).  In a data-parallel run RCCL's kernels hold some CUs for the length of a collective; the blocks
-        # that cannot be placed would keep the resident ones spinning until the collective ends -- the compute stream would
-        # stall exactly where it is meant to overlap the all-reduce.  Separate launches there (RNAGAN_SPLIT_BN_DP=1 overrides).
+        # The fused kernels rendezvous across ALL their workgroups (<= 256 blocks of 1024 threads).  In a data-parallel run
+        # RCCL's kernels hold some CUs for the length of a collective, and blocks that cannot be placed keep the resident
+        # ones spinning.  Measured with a stand-in kernel holding 32 CUs for 500 us per collective (DESIGN 12.7): the fused
+        # form stays ahead with a light stand-in (12.6 vs 12.8 ms) and level with a register-heavy one (12.8 vs 12.8), so it
+        # stays on; RNAGAN_SPLIT_BN_DP=0 takes the separate launches under DP.
         if self._split_bn_dp is None:
             from . import dist as D_
-            self._split_bn_dp = (not D_.active()) or os.environ.get("RNAGAN_SPLIT_BN_DP", "0") == "1"
+            self._split_bn_dp = (not D_.active()) or os.environ.get("RNAGAN_SPLIT_BN_DP", "1") != "0"
         if not self._split_bn_dp:
             return 0
         ns = int(self.lib.rg_conv_split(up, N, Hl, Wl, O, I, self.dt, self.algo))
