@@ -165,7 +165,10 @@ def main():
     else:
         raise SystemExit(f"Loss type {args.loss_type} not implemented on this path. Choose wgan or wganvae.")
 
-    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("RNAGAN_DIST_BACKEND") == "gloo":
+        local %= max(torch.cuda.device_count(), 1)       # functional multi-rank runs on fewer devices than ranks (dist.init_from_env)
+    device = torch.device("cuda", local)
     epochs = args.num_epochs if args.num_epochs is not None else 5
     print("Device: {}".format(device)); print("Epochs: {}".format(epochs))
     trainer = P.Trainer(gan_network, losses, checkpoints=args.model_dir, sample_size=64, epochs=epochs, devices=[0],

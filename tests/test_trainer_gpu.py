@@ -375,23 +375,18 @@ def test_penalty_fake_from_the_d_step_generator_pass():
     assert float((ga - gb).norm() / ga.norm()) <= 2e-2 and float((da - db).norm() / da.norm()) <= 2e-2
 
 
-def test_cli_trains_on_mixed_tissue_tables(tmp_path):
-    """The reference CLI's real-data path end to end (src/histopathology_gan.py:111-168, BASELINE configs[3]'s data side): two
-    tissue tables with their own tile stores -> concatenated table -> log / standardised RNA -> per-slide tile sampling ->
-    DataLoader -> Trainer with the three betaVAE-conditioned plugins, on the HIP kernels.  One short epoch at 32 x 32; checks
-    the run completes, the checkpoint has the reference's keys and the logged losses are finite."""
+def _mixed_tissue_config(tmp_path, n_per_tissue=3):
+    """Two tissue tables with their own tile stores (32 x 32 tiles, 48 genes) and the CLI config that names them."""
     import json
-    import subprocess
-    import sys
     import numpy as np
     import pandas as pd
     from rna_gan_amd import data as PD
     rng = np.random.default_rng(11)
     genes = ["rna_G%d" % i for i in range(48)]
     csvs, roots = [], []
-    for t, (tissue, n) in enumerate((("lung", 3), ("brain", 3))):
-        names = ["%s_%d.svs" % (tissue, i) for i in range(n)]
-        df = pd.DataFrame(rng.gamma(2.0, 3.0 + 4.0 * t, size=(n, len(genes))), columns=genes)
+    for t, tissue in enumerate(("lung", "brain")):
+        names = ["%s_%d.svs" % (tissue, i) for i in range(n_per_tissue)]
+        df = pd.DataFrame(rng.gamma(2.0, 3.0 + 4.0 * t, size=(n_per_tissue, len(genes))), columns=genes)
         df.insert(0, "wsi_file_name", names)
         csv = str(tmp_path / (tissue + ".csv"))
         df.to_csv(csv, index=False)
@@ -405,21 +400,77 @@ def test_cli_trains_on_mixed_tissue_tables(tmp_path):
     cfg_path = str(tmp_path / "cfg.json")
     with open(cfg_path, "w") as f:
         json.dump(cfg, f)
+    return cfg_path
+
+
+def _cli_cmd(tmp_path, cfg_path):
+    import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(repo, "histopathology_gan.py"), "--config", cfg_path, "--loss_type", "wganvae",
-           "--num_epochs", "1", "--num_patches", "8", "--batch_size", "8", "--model_dir", str(tmp_path / "model"),
-           "--image_dir", str(tmp_path / "img"), "--betavae_checkpoint", str(tmp_path / "none.pt")]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    return [sys.executable, os.path.join(repo, "histopathology_gan.py"), "--config", cfg_path, "--loss_type", "wganvae",
+            "--num_epochs", "1", "--num_patches", "8", "--batch_size", "8", "--model_dir", str(tmp_path / "model"),
+            "--image_dir", str(tmp_path / "img"), "--betavae_checkpoint", str(tmp_path / "none.pt")]
+
+
+def _checkpoint_files(tmp_path):
+    cks = [f for f in os.listdir(str(tmp_path)) if f.startswith("model")] + \
+          ([os.path.join("model", f) for f in os.listdir(str(tmp_path / "model"))] if os.path.isdir(str(tmp_path / "model")) else [])
+    return [os.path.join(str(tmp_path), c) for c in cks if os.path.isfile(os.path.join(str(tmp_path), c))]
+
+
+def test_cli_trains_on_mixed_tissue_tables(tmp_path):
+    """The reference CLI's real-data path end to end (src/histopathology_gan.py:111-168, BASELINE configs[3]'s data side): two
+    tissue tables with their own tile stores -> concatenated table -> log / standardised RNA -> per-slide tile sampling ->
+    DataLoader -> Trainer with the three betaVAE-conditioned plugins, on the HIP kernels.  One short epoch at 32 x 32; checks
+    the run completes, the checkpoint has the reference's keys and the logged losses are finite."""
+    import subprocess
+    import numpy as np
+    cfg_path = _mixed_tissue_config(tmp_path)
+    r = subprocess.run(_cli_cmd(tmp_path, cfg_path), capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "Training of the Model is Complete" in r.stdout
     vals = [float(l.split(":")[1]) for l in r.stdout.splitlines() if "Mean Loss" in l]
     assert len(vals) >= 2 and all(np.isfinite(v) for v in vals)
-    cks = [f for f in os.listdir(str(tmp_path)) if f.startswith("model")] + \
-          ([os.path.join("model", f) for f in os.listdir(str(tmp_path / "model"))] if os.path.isdir(str(tmp_path / "model")) else [])
-    files = [os.path.join(str(tmp_path), c) for c in cks if os.path.isfile(os.path.join(str(tmp_path), c))]
+    files = _checkpoint_files(tmp_path)
     assert files, "no checkpoint written"
     ck = torch.load(files[0], map_location="cpu", weights_only=False)
     assert {"epoch", "generator", "discriminator", "optimizer_generator", "optimizer_discriminator"} <= set(ck)
+
+
+def test_cli_two_ranks_on_the_shared_gpu(tmp_path):
+    """The same CLI run as TWO data-parallel ranks (the box has one GPU: both ranks use it and all-reduce over gloo,
+    RNAGAN_DIST_BACKEND): equal-length rank shards of the slide table, rank 0's parameters broadcast, the betaVAE broadcast,
+    the plugins' data-parallel route inside Trainer.train (prefetcher + pipelined train_ops on top), checkpoint and console
+    summary from rank 0 only; both ranks finish."""
+    import socket
+    import subprocess
+    import numpy as np
+    cfg_path = _mixed_tissue_config(tmp_path, n_per_tissue=4)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   RNAGAN_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen(_cli_cmd(tmp_path, cfg_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                      cwd=str(tmp_path)))
+    outs = []
+    for p in procs:
+        try:
+            out, err = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, out[-1500:] + err[-2500:]
+        outs.append(out)
+    assert "Training of the Model is Complete" in outs[0] and "Training of the Model is Complete" not in outs[1]
+    vals = [float(l.split(":")[1]) for l in outs[0].splitlines() if "Mean Loss" in l]
+    assert len(vals) >= 2 and all(np.isfinite(v) for v in vals)
+    files = _checkpoint_files(tmp_path)
+    assert files, "no checkpoint written by rank 0"
+    ck = torch.load(files[0], map_location="cpu", weights_only=False)
+    assert {"epoch", "generator", "discriminator", "optimizer_generator", "optimizer_discriminator"} <= set(ck)
+    for k, v in ck["generator"].items():
+        assert not v.dtype.is_floating_point or bool(torch.isfinite(v).all()), k
 
 
 def test_pipelined_train_iter_matches_the_synchronous_loop(tmp_path):
