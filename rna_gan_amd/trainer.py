@@ -118,12 +118,18 @@ class Trainer:
             load_path = self.checkpoints + str(self.last_retained_checkpoint) + ".model"
         print("Loading Model From '{}'".format(load_path))
         try:
-            checkpoint = torch.load(load_path, map_location="cpu", weights_only=False)
+            # A checkpoint written by the reference pickles its live plugin objects (torchgan.losses.*, wgan_loss.*LossVAE
+            # holding a betaVAE.betaVAE each) under loss_objects / metric_objects: a plain torch.load raises
+            # ModuleNotFoundError on the first such class, before the dictionary exists.  The tolerant unpickler resolves
+            # every unimportable global to an inert placeholder; the live plugin objects of THIS trainer are kept
+            # (SURVEY 5 / 8b "Checkpoint": tolerate missing / unknown loss_objects, metric_*).
+            from . import _tolerant_pickle
+            checkpoint = torch.load(load_path, map_location="cpu", weights_only=False, pickle_module=_tolerant_pickle)
             self.start_epoch = checkpoint["epoch"]
             self.loss_information = checkpoint.get("loss_information", self.loss_information)
-            # loss_objects / metric_objects of a reference checkpoint are pickled torchgan objects; they are
-            # tolerated-if-unloadable: the live loss objects are kept.
             self.loss_logs = checkpoint.get("loss_logs", self.loss_logs)
+            for name in self.losses:                       # a log keyed by plugin names this trainer does not know stays
+                self.loss_logs.setdefault(name, [])        # (torchgan keeps it too); every live plugin needs its list
             self.metric_logs = checkpoint.get("metric_logs", self.metric_logs)
             for load_item in self.model_names + self.optimizer_names:
                 getattr(self, load_item).load_state_dict(checkpoint[load_item])
