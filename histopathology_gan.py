@@ -127,11 +127,20 @@ def main():
         else:
             ds = PD.PatchDataset(patch_data_path, train_df, img_size, max_patches_total=args.num_patches, transforms=tf)
 
+        world = D_.world_size()
+
         def collate_fn(batch):                       # src/histopathology_gan.py:24-34: drop unreadable records
             img = (lambda b: b["image"]) if with_rna else (lambda b: b[0])
+            want = len(batch)
             batch = [b for b in batch if img(b) is not None]
+            if world > 1 and len(batch) < want:
+                # data parallel: every rank must see the SAME batch size (the gathered G.0 gradient factors and the captured
+                # step graphs are sized by it, and each train_op issues a collective) -- the dropped records are replaced by
+                # repeating this batch's readable ones instead of shrinking the batch
+                if not batch:
+                    raise RuntimeError("data parallel: a batch with no readable tile record cannot be equalised across ranks")
+                batch = (batch * ((want + len(batch) - 1) // len(batch)))[:want]
             return torch.utils.data.dataloader.default_collate(batch)
-        world = D_.world_size()
         if world > 1:
             # one shard of the (identical) tile list per rank, the SAME number of full batches on every rank: each train_op
             # issues a gradient all-reduce, so a rank with one batch more would pair its collectives with nobody

@@ -578,10 +578,6 @@ int rg_selftest_fp8(int* detail, void* stream);
  * loader hand over uint8 tiles (a quarter of the PCIe bytes) and normalise on the device. */
 int rg_u8_to_norm(const void* src_u8, float* dst, size_t n, float mean, float stdv, void* stream);
 
-/* Diagnostic only (no product path calls it): hold `nblocks` CUs for `microseconds` with register-heavy idle workgroups -- the CU
- * footprint of a collective, for measuring on one GPU what sharing CUs with RCCL does to the overlapped compute
- * (RNAGAN_DEBUG_HOG in rna_gan_amd/dist.py; the reference has no distributed path, src/histopathology_gan.py:298-302). */
-int rg_debug_hold_cus(int nblocks, int microseconds, float* sink, void* stream);
 
 #ifdef __cplusplus
 }

@@ -66,7 +66,6 @@ PROTOTYPES = {
     "rg_bn_act_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _z, _p]),
     "rg_bn_act_bwd_g2": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _p, _z, _p]),
     "rg_bn_finalize_partials": (_i, [_p, _i, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p, _z, _p]),
-    "rg_debug_hold_cus": (_i, [_i, _i, _p, _p]),
     "rg_linear_wgrad_adam": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _i, _i, _p, _i, _p]),
     "rg_last_up_post_blocks": (_i, [_i, _i, _i, _i, _i, _i]),
     "rg_last_up_post": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
@@ -154,7 +153,7 @@ PROTOTYPES = {
 }
 
 # must equal rg_version() of the library (rna_gan_amd/csrc/rg_api.hip): bumped together with PROTOTYPES
-ABI_VERSION = 309
+ABI_VERSION = 400
 
 _lib = None
 

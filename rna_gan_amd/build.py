@@ -59,5 +59,20 @@ def build_library(force=False, verbose=True):
     return OUT
 
 
+def build_debug_library(force=False):
+    """tools/debug/librnagan_debug.so: diagnostic kernels that are NOT part of the product ABI (the CU-holding stand-in for a
+    collective, RNAGAN_DEBUG_HOG).  Built on demand; never loaded by a product path."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    d = os.path.join(os.path.dirname(HERE), "tools", "debug")
+    src, out = os.path.join(d, "rg_debug_hold.hip"), os.path.join(d, "librnagan_debug.so")
+    if force or _stale(out, [src]):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-o", out, src], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
+    return out
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv))

@@ -18,7 +18,7 @@ void rg_set_error(const char* fmt, ...) {
 }
 
 // bumped whenever an entry point is added or a signature changes; rna_gan_amd/_abi.py (ABI_VERSION) refuses any other value
-extern "C" int rg_version(void) { return 309; }   // 3.02: round 3 (fused split-K BatchNorm, Inception-v3 data-movement kernels)
+extern "C" int rg_version(void) { return 400; }   // 4.00: round 4 (the diagnostic rg_debug_hold_cus left the ABI: tools/debug/)
 extern "C" const char* rg_last_error(void) { return g_err; }
 
 // ---- kernel-selection knobs: override table in front of the RNAGAN_* environment variables

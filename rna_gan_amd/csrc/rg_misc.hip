@@ -748,35 +748,3 @@ extern "C" int rg_cast_pad(const float* src, void* dst, int M, int K, int ldd, i
   })
 }
 
-// ---- diagnostic: hold `nblocks` CUs for `microseconds` (register-heavy workgroups that just wait).  Stands in for the CU
-// footprint of an RCCL collective on a single-GPU box: rna_gan_amd.dist launches it where an all-reduce would run
-// (RNAGAN_DEBUG_HOG="blocks,microseconds") so that the effect of sharing CUs between a collective and the overlapped compute
-// can be measured without a second GPU.  Not used by any product path.
-template <int NR>      // NR live floats per thread: the register weight of the stand-in (RCCL's kernels are register-heavy)
-__global__ __launch_bounds__(256) void hold_cus_kernel(long long ticks, float* sink) {
-  float r[NR];
-#pragma unroll
-  for (int i = 0; i < NR; ++i) r[i] = (float)(threadIdx.x + i);
-  const long long t0 = wall_clock64();
-  while (wall_clock64() - t0 < ticks) {
-#pragma unroll
-    for (int i = 0; i < NR; ++i) r[i] = r[i] * 1.0001f + 1.f;
-    __builtin_amdgcn_s_sleep(16);
-  }
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < NR; ++i) s += r[i];
-  if (s == 12345.678f) sink[0] = s;
-}
-extern "C" int rg_debug_hold_cus(int nblocks, int microseconds, float* sink, void* stream) {
-  RG_REQUIRE(nblocks != 0 && nblocks <= 1024 && nblocks >= -1024 && microseconds >= 0 && sink, RG_EINVAL, "debug_hold_cus: bad args");
-  // nblocks < 0: the register-heavy form (~200 VGPRs per wave) with |nblocks| workgroups
-  if (nblocks < 0)
-    hipLaunchKernelGGL(hold_cus_kernel<192>, dim3((unsigned)(-nblocks)), dim3(256), 0, rg_stream(stream),
-                       (long long)microseconds * 100, sink);
-  else
-    hipLaunchKernelGGL(hold_cus_kernel<48>, dim3((unsigned)nblocks), dim3(256), 0, rg_stream(stream), (long long)microseconds * 100,
-                       sink);
-  RG_LAUNCH_CHECK("debug_hold_cus");
-  return RG_OK;
-}

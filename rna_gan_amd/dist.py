@@ -141,13 +141,20 @@ def _hog_start(device):
     spec = os.environ.get("RNAGAN_DEBUG_HOG")
     if not spec:
         return None
-    from . import _abi
+    import ctypes
     blocks, usec = [int(v) for v in spec.split(",")]
     if _HOG[0] is None:
-        _HOG[0] = (torch.cuda.Stream(device), torch.zeros(4, device=device))
-    stream, sink = _HOG[0]
+        # the stand-in kernel lives in a diagnostic library of its own (tools/debug/), not in the product ABI
+        from .build import build_debug_library
+        dbg = ctypes.CDLL(build_debug_library())
+        dbg.rgdbg_hold_cus.restype = ctypes.c_int
+        dbg.rgdbg_hold_cus.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        _HOG[0] = (torch.cuda.Stream(device), torch.zeros(4, device=device), dbg)
+    stream, sink, dbg = _HOG[0]
     stream.wait_stream(torch.cuda.current_stream(device))
-    _abi.check(_abi.load().rg_debug_hold_cus(blocks, usec, sink.data_ptr(), stream.cuda_stream), "rg_debug_hold_cus")
+    rc = dbg.rgdbg_hold_cus(blocks, usec, sink.data_ptr(), stream.cuda_stream)
+    if rc != 0:
+        raise RuntimeError("rgdbg_hold_cus failed: %d" % rc)
     ev = torch.cuda.Event()
     ev.record(stream)
     return ev
@@ -182,24 +189,26 @@ def allreduce_start(flat: torch.Tensor, compress: bool = False, head: int = 0):
                                    _abi.RG_BF16, stream), "rg_cast_pad")
         works = _launch_buckets(wire[head:], BUCKET_BYTES // 2)
         hog = _hog_start(flat.device) if flat.is_cuda else None
-        return (wire, flat, works + ([_HogWork(hog)] if hog is not None else []))
+        return (wire, flat, works + ([_HogWork(hog)] if hog is not None else []), head)
     works = _launch_buckets(flat[head:], BUCKET_BYTES // flat.element_size())
     hog = _hog_start(flat.device) if flat.is_cuda else None
-    return (None, flat, works + ([_HogWork(hog)] if hog is not None else []))
+    return (None, flat, works + ([_HogWork(hog)] if hog is not None else []), head)
 
 
 def allreduce_finish(handle, widen=True):
     """Make the current stream wait for the all-reduce and widen the bf16 wire buffer back into the fp32 gradients
-    (widen=False: the caller's optimizer reads the wire buffer itself, see wire_of)."""
+    (widen=False: the caller's optimizer reads the wire buffer itself, see wire_of).  Only the reduced part
+    ``[head:]`` is widened: the first ``head`` elements never travelled on the wire (allreduce_start's ``head``)."""
     if handle is None:
         return
-    wire, flat, works = handle
+    wire, flat, works, head = handle
     for w in works:
         w.wait()
-    if wire is not None and widen:
+    if wire is not None and widen and flat.numel() > head:
         from . import _abi
         stream = torch.cuda.current_stream(flat.device).cuda_stream
-        _abi.check(_abi.load().rg_widen_bf16(wire.data_ptr(), flat.data_ptr(), flat.numel(), stream), "rg_widen_bf16")
+        _abi.check(_abi.load().rg_widen_bf16(wire.data_ptr() + 2 * head, flat.data_ptr() + 4 * head, flat.numel() - head, stream),
+                   "rg_widen_bf16")
 
 
 def wire_of(handle):

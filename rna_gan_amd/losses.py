@@ -412,7 +412,9 @@ def flush():
     # rna_gan_amd.optim.Adam steps straight from the all-reduced bf16 wire buffer (no widening pass; .grad then keeps
     # the rank-local gradient); other optimizers get the averaged gradient back in .grad first
     wire = D_.wire_of(pend.handle) if FUSED_WIDEN and hasattr(pend.optimizer, "grad_wire") else None
-    D_.allreduce_finish(pend.handle, widen=wire is None and pend.factors is None)
+    # (with gathered G.0 factors the handle's head is excluded from the wire; the tail is widened like any other gradient
+    # when the optimizer does not step from the wire -- RNAGAN_DP_FUSED_WIDEN=0 or a foreign optimizer)
+    D_.allreduce_finish(pend.handle, widen=wire is None)
     fac = pend.factors
     if fac is not None:
         g0, (z_all, gy_all, _, _), dt, works = fac

@@ -5,6 +5,7 @@ only; every arithmetic op below is one or two hand-written HIP kernels.  No fall
 from __future__ import annotations
 
 import os
+import weakref
 from contextlib import contextmanager
 
 import torch
@@ -27,6 +28,27 @@ class SlabRef:
 
     def __init__(self, ws, nsplit, stride, groups):
         self.ws, self.nsplit, self.stride, self.groups = ws, nsplit, stride, groups
+
+
+_LIVE_OPS = weakref.WeakSet()
+
+
+def check_handoffs():
+    """Host-side check of the fused split-K BatchNorm kernels' error word (rg_splitbn.hip: a workgroup whose bounded spin
+    on the in-launch rendezvous timed out sets sync[SB_ERR] and goes on with incomplete sums -- the launch's statistics and
+    activations are then garbage).  Reads one int32 per live backend: a HOST SYNC, so it is called where the host waits
+    anyway (Trainer: end of an epoch / save_model; bench.py: behind the timed region; the tests).  Raises and re-arms."""
+    bad = []
+    for ops in list(_LIVE_OPS):
+        sync = ops._sb_sync
+        if sync is not None and int(sync[0].item()) != 0:
+            sync[0].zero_()
+            bad.append(str(ops.device))
+    if bad:
+        raise RuntimeError("rna_gan_amd: a fused split-K BatchNorm launch timed out waiting for its workgroups (%s): the "
+                           "results of that launch are invalid.  The kernels need all their <= 256 workgroups co-resident; "
+                           "another kernel (a collective?) held CUs.  Set RNAGAN_SPLIT_BN_DP=0 / RNAGAN_SPLIT_BN=0 to use "
+                           "the separate launches." % ", ".join(bad))
 
 
 class HipOps:
@@ -76,6 +98,7 @@ class HipOps:
         self._sb_sync = None          # hand-off words of the fused kernels: zeroed once, left zero by every launch
         self._sb_scratch = None
         self._sb_retired = []
+        _LIVE_OPS.add(self)
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -119,12 +142,16 @@ class HipOps:
             return 0
         # The fused kernels rendezvous across ALL their workgroups (<= 256 blocks of 1024 threads).  In a data-parallel run
         # RCCL's kernels hold some CUs for the length of a collective, and blocks that cannot be placed keep the resident
-        # ones spinning.  Measured with a stand-in kernel holding 32 CUs for 500 us per collective: the fused
-        # form stays ahead with a light stand-in (12.6 vs 12.8 ms) and level with a register-heavy one (12.8 vs 12.8), so it
-        # stays on; RNAGAN_SPLIT_BN_DP=0 takes the separate launches under DP.
+        # ones spinning.  Measured with a STAND-IN kernel holding 32 CUs for 500 us per collective: the fused
+        # form stays ahead with a light stand-in (12.6 vs 12.8 ms) and level with a register-heavy one (12.8 vs 12.8) -- but
+        # that is not RCCL, and a timed-out rendezvous yields garbage, so with more than one rank the separate launches are
+        # the default until a real multi-GPU run has A/B'd it (tools/dp_first_run.sh does): RNAGAN_SPLIT_BN_DP=1 turns the
+        # fused kernels on there; check_handoffs() reports a timeout either way.  One rank (RNAGAN_FORCE_DP) has no collective
+        # kernel beside it and keeps them.
         if self._split_bn_dp is None:
             from . import dist as D_
-            self._split_bn_dp = (not D_.active()) or os.environ.get("RNAGAN_SPLIT_BN_DP", "1") != "0"
+            dflt = "1" if D_.world_size() <= 1 else "0"
+            self._split_bn_dp = (not D_.active()) or os.environ.get("RNAGAN_SPLIT_BN_DP", dflt) != "0"
         if not self._split_bn_dp:
             return 0
         ns = int(self.lib.rg_conv_split(up, N, Hl, Wl, O, I, self.dt, self.algo))

@@ -97,6 +97,8 @@ class Trainer:
 
     # ------------------------------------------------------------------ checkpoints
     def save_model(self, epoch, save_items=None):
+        from .ops_hip import check_handoffs
+        check_handoffs()            # never checkpoint weights behind a fused-kernel hand-off that timed out (every rank)
         if D_.rank() != 0:
             return
         if self.last_retained_checkpoint == self.retain_checkpoints:

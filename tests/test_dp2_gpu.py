@@ -81,15 +81,16 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _run_world2(tmp_path, precision):
+def _run_world2(tmp_path, precision, extra_env=None, tag=""):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = str(tmp_path / ("dp2_%s_rank" % precision))
+    out = str(tmp_path / ("dp2_%s%s_rank" % (precision, tag)))
     port = _free_port()
     procs = []
     for rank in range(2):
         env = dict(os.environ, REPO=repo, OUT=out, PRECISION=precision, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", RNAGAN_FORCE_DP="0",
                    SHAPE="%d,%d,%d,%d,%d" % (IN_SIZE, STEP, ENC, N, ITERS))
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                       text=True))
     for p in procs:
@@ -204,3 +205,23 @@ def test_world2_bf16_kernels_and_wire(tmp_path):
             if v.dtype.is_floating_point and "running_" not in k:
                 rel = float((v.double() - f32[0][name][k].double()).norm() / (f32[0][name][k].double().norm() + 1e-30))
                 assert rel <= 1e-2, (name, k, rel)
+
+
+def test_world2_factors_with_an_optimizer_that_does_not_step_from_the_wire(tmp_path):
+    """with generator layer 0's gradient travelling as gathered factors AND the optimizer not stepping from
+    the bf16 wire (RNAGAN_DP_FUSED_WIDEN=0), the all-reduced TAIL of the generator's gradient must still be widened back into
+    .grad -- otherwise every layer behind layer 0 steps from the rank-local gradient and the ranks drift apart silently.
+    Both ranks must end bit-identical, and equal to the default route (Adam reading the wire) up to nothing at all: the two
+    routes feed Adam the same bf16-rounded averaged gradient."""
+    ref = _run_world2(tmp_path, "bf16")
+    got = _run_world2(tmp_path, "bf16", extra_env={"RNAGAN_DP_FUSED_WIDEN": "0"}, tag="_nowire")
+    assert got[0]["factors"] and got[1]["factors"]
+    for name in ("G", "D"):
+        for k in got[0][name]:
+            if "running_" not in k:
+                assert torch.equal(got[0][name][k], got[1][name][k]), ("ranks differ", name, k)
+    if ref[0]["wire"] == "bf16":
+        for k, v in got[0]["G"].items():
+            if v.dtype.is_floating_point and "running_" not in k:
+                rel = float((v.double() - ref[0]["G"][k].double()).norm() / (ref[0]["G"][k].double().norm() + 1e-30))
+                assert rel <= 2e-3, (k, rel)

@@ -436,6 +436,43 @@ def test_cli_trains_on_mixed_tissue_tables(tmp_path):
     assert {"epoch", "generator", "discriminator", "optimizer_generator", "optimizer_discriminator"} <= set(ck)
 
 
+def test_cli_stock_wgan_literal_command(tmp_path):
+    """BASELINE configs[0]'s literal command (src/histopathology_gan.py:94,267-272): ``--gan_type dcgan --loss_type wgan`` -- the
+    STOCK torchgan losses (randn noise on the device, tensor batches, weight clamp (-0.01, 0.01) before the D step) at the
+    reference's hard-coded batch 8 on 256 x 256 synthetic tiles, reference model size, through the CLI.  Three iterations;
+    checks completion, the checkpoint dictionary's keys, three logged values per plugin, finite weights, and that the
+    discriminator's parameters sit inside the clamp interval up to the one Adam step (lr 4e-4) the penalty train_op takes
+    after the clamp."""
+    import subprocess
+    import sys
+    import numpy as np
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(repo, "histopathology_gan.py"), "--config", os.path.join(repo, "configs", "gan_run_synthetic.json"),
+           "--gan_type", "dcgan", "--loss_type", "wgan", "--synthetic", "--num_epochs", "1", "--steps_per_epoch", "3",
+           "--model_dir", str(tmp_path / "model"), "--image_dir", str(tmp_path / "img")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Training of the Model is Complete" in r.stdout
+    vals = [float(l.split(":")[1]) for l in r.stdout.splitlines() if "Mean Loss" in l]
+    assert len(vals) == 2 and all(np.isfinite(v) for v in vals)
+    files = _checkpoint_files(tmp_path)
+    assert files, "no checkpoint written"
+    ck = torch.load(files[0], map_location="cpu", weights_only=False)
+    assert set(ck) == {"epoch", "loss_information", "loss_objects", "metric_objects", "loss_logs", "metric_logs", "generator",
+                       "discriminator", "optimizer_generator", "optimizer_discriminator"}
+    assert ck["epoch"] == 1
+    assert list(ck["loss_logs"]) == ["WassersteinGeneratorLoss", "WassersteinDiscriminatorLoss", "WassersteinGradientPenalty"]
+    assert all(len(v) == 3 and all(np.isfinite(x) for x in v) for v in ck["loss_logs"].values())
+    assert ck["loss_information"]["generator_iters"] == 3 and ck["loss_information"]["discriminator_iters"] == 6
+    assert ck["generator"]["model.0.0.weight"].shape == (2048, 2048, 4, 4) and ck["discriminator"]["disc.0.weight"].shape == (1, 2048, 4, 4)
+    for k, v in ck["discriminator"].items():
+        if v.dtype.is_floating_point and "running" not in k:
+            assert float(v.abs().max()) <= 0.01 + 2 * 4e-4 + 1e-6, (k, float(v.abs().max()))
+    for k, v in ck["generator"].items():
+        assert not v.dtype.is_floating_point or bool(torch.isfinite(v).all()), k
+    assert os.path.exists(str(tmp_path / "img" / "epoch1_generator.png"))
+
+
 def test_cli_two_ranks_on_the_shared_gpu(tmp_path):
     """The same CLI run as TWO data-parallel ranks (the box has one GPU: both ranks use it and all-reduce over gloo,
     RNAGAN_DIST_BACKEND): equal-length rank shards of the slide table, rank 0's parameters broadcast, the betaVAE broadcast,
