@@ -81,10 +81,11 @@ def build(device, precision, batch, rna_features, seed, gan_type="dcgan", enc=20
     ld = P.WassersteinDiscriminatorLossVAE(checkpoint=None, rna_features=rna_features)
     lp = P.WassersteinGradientPenaltyVAE(checkpoint=None, rna_features=rna_features)
     if enc != 2048:
-        # the plugins build betaVAE(rna_features, 2048, ...) as src/wgan_loss.py:67 hard-codes it; a generator with another
-        # latent width needs the matching z_dim (same encoder trunk, z_mu: 2048 -> enc)
+        # the plugins build betaVAE(rna_features, 2048, [6000, 4000, 2048], ...) as src/wgan_loss.py:67 hard-codes it; a
+        # generator with another latent width needs the matching z_dim, which is also the encoder's last width
+        # (src/betaVAE.py: z_mu = Linear(z_dim, z_dim))
         for l in (lg, ld, lp):
-            l.betavae = P.betaVAE(rna_features, enc, [6000, 4000, 2048], [4000, 6000], beta=0.005)
+            l.betavae = P.betaVAE(rna_features, enc, [6000, 4000, enc], [4000, 6000], beta=0.005)
     R.seeded_fill_(lg.betavae, seed + 2)
     sd = lg.betavae.state_dict()
     for l in (lg, ld, lp):
@@ -743,7 +744,7 @@ def extra_enc200(args, device, info, steps=10, warm=12, enc=200):
     """BASELINE.json's north_star speaks of "random 200-d conditioning latents"; the reference's code uses 2048
     (src/histopathology_gan.py:179, src/wgan_loss.py:67), which SURVEY 0.4 makes the benchmark.  This is the 200-d data point:
     the same iteration (wganvae plugins, batch 64, bf16, step graphs) with encoding_dims = z_dim = 200 -- only G.0
-    (200 x 2048 x 4 x 4 instead of 2048 x ...) and the betaVAE's z_mu layer change."""
+    (200 x 2048 x 4 x 4 instead of 2048 x ...) and the betaVAE's last encoder layer / z_mu (4000 -> 200 -> 200) change."""
     from rna_gan_amd import losses as PL
     N = args.batch
     G, Dm, og, od, (lg, ld, lp) = build(device, "bf16", N, 19198, args.seed, enc=enc)
@@ -774,11 +775,17 @@ def extra_enc200(args, device, info, steps=10, warm=12, enc=200):
     return res
 
 
-def extra_fp32_step(args, device, info, steps=2):
-    """The fp32 parity mode (--precision fp32: VALU functor kernels, the anchor of the tight-tolerance parity tests) on the
-    same workload: throughput of the mode the bf16 numbers are validated against."""
+F32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X fp32 matrix (= vector) peak, MI355X_MICROARCH.md
+
+
+def extra_fp32_step(args, device, info, steps=3, warm=6):
+    """The fp32 parity mode (--precision fp32: the reference's own arithmetic, src/betaVAE.py:184,223,230-236; the anchor of
+    the tight-tolerance parity tests) on the same workload.  Convolutions / dense layers run on the f32 matrix cores
+    (gemm_mfma32_kernel: v_mfma_f32_32x32x2_f32 behind the generic operand functors, rg_generic.hip); everything else is the
+    fp32 form of the bandwidth-bound kernels.  `roofline_fp32`: algorithmic conv FLOPs of the conv + weight-gradient launches
+    of one instrumented eager iteration / their summed HIP-event durations, against the 157.3 TFLOP/s fp32 matrix peak."""
+    from rna_gan_amd import graphed
     from rna_gan_amd import losses as PL
-    from rna_gan_amd import synth as R
     N = args.batch
     G, Dm, og, od, (lg, ld, lp) = build(device, "fp32", N, 19198, args.seed)
     h = info["handles"]
@@ -790,16 +797,55 @@ def extra_fp32_step(args, device, info, steps=2):
         eps = torch.empty(1).uniform_(0.0, 1.0, generator=gen).to(device)
         return [lg.step(G, Dm, og, h["rna"], us[0]), ld.step(G, Dm, od, h["real"], h["rna"], us[1], next_u=us[2]),
                 lp.step(G, Dm, od, h["real"], h["rna"], us[2], eps)]
-    it()
+    for _ in range(warm):           # graph capture: two eager runs per launch-sequence variant, replay from the third on
+        it()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for _ in range(steps):
         ls = it()
     torch.cuda.synchronize(device)
     dt = (time.perf_counter() - t0) / steps
+    res = {"ms_per_step": round(dt * 1e3, 2), "imgs_per_sec": round(N / dt, 1), "steps": steps, "hip_graphs": bool(graphed.ENABLED),
+           "losses": [round(float(l.item()), 5) for l in ls],
+           "kernels": "f32 matrix cores (v_mfma_f32_32x32x2_f32) for the convolutions / dense layers, fp32 activations"}
+    # per-launch events over one eager iteration (same method as the bf16 roofline)
+    ops, _ = G.runtime()
+    was = graphed.ENABLED
+    graphed.ENABLED = False
+    try:
+        it(); torch.cuda.synchronize(device)            # eager warm-up (workspace growth)
+        stream = torch.cuda.current_stream(device)
+        cal = []
+        for _ in range(16):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream); b.record(stream)
+            cal.append((a, b))
+        ops.timing = []
+        it()
+        torch.cuda.synchronize(device)
+        overhead = sorted(a.elapsed_time(b) for a, b in cal)[len(cal) // 2]
+        fam = {}
+        for key, flops, e0, e1 in ops.timing:
+            f = fam.setdefault(key, [0, 0.0, 0.0])
+            f[0] += 1; f[1] += flops; f[2] += max(e0.elapsed_time(e1) - overhead, 0.0)
+    finally:
+        ops.timing = None
+        graphed.ENABLED = was
+    mm = [v for k, v in fam.items() if k in ("conv_fwd_dgrad", "conv_wgrad")]
+    if mm:
+        fl, ms = sum(v[1] for v in mm), sum(v[2] for v in mm)
+        res["roofline_fp32"] = {"bound": "mfma", "kernel": "gemm_mfma32_kernel (conv fwd / dgrad / tangent + weight gradients, fp32)",
+                                "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(fl / (ms * 1e-3) / 1e12 / F32_MATRIX_PEAK_TFLOPS, 4),
+                                "launches": sum(v[0] for v in mm), "ms_total": round(ms, 2),
+                                "share_of_step": round(ms / (dt * 1e3), 3),
+                                "families": {k: {"launches": v[0], "ms": round(v[2], 2),
+                                                 "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 1) if v[2] > 0 else None}
+                                             for k, v in fam.items()}}
     PL.new_batch()
-    return {"ms_per_step": round(dt * 1e3, 2), "imgs_per_sec": round(N / dt, 1), "steps": steps, "hip_graphs": False,
-            "losses": [round(float(l.item()), 5) for l in ls], "kernels": "fp32 functor kernels (no MFMA), fp32 activations"}
+    del G, Dm, og, od, lg, ld, lp
+    torch.cuda.empty_cache()
+    return res
 
 
 if __name__ == "__main__":

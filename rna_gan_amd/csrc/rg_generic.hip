@@ -6,6 +6,8 @@
 // and IS the fp32 parity path (RG_F32 activations): same operation order on every launch,
 // deterministic split-K (slabs summed in fixed order).
 #include "rg_common.h"
+#include "rg_internal.h"
+#include <type_traits>
 
 namespace {
 
@@ -71,11 +73,107 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(FA fa, FB fb, SC sc, 
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// The same GEMM on the f32 MATRIX cores: v_mfma_f32_32x32x2_f32 (f32 operands, f32 accumulate -- exact f32 arithmetic, a
+// fused-multiply-add chain per accumulator like the loop above; 64 FLOP/clk/SIMD = the vector FMA rate, but the operand
+// reads and the issue slots of the vector pipe are left to the functors' address arithmetic).  This is the fp32 mode's
+// conv / dense kernel wherever the output tile is worth it (the reference's own arithmetic is fp32: src/betaVAE.py:184,
+// 223, 230-236; SURVEY 8d "~157 TFLOP/s fp32 matrix").
+//   block = 256 threads = 2 x 2 waves, tile 128 x 128, each wave 64 x 64 = 2 x 2 accumulator tiles of 32 x 32;
+//   k-tile 16: operands fetched through the SAME functors into registers one k-tile ahead (the global loads fly under
+//   the MFMAs of the current tile), staged in LDS k-major ([k][m]: a fragment read is 32 consecutive floats per k row,
+//   conflict-free ds_read_b32); MFMA step s consumes k = 2s (lanes 0-31) and 2s + 1 (lanes 32-63).
+// Same split-K contract and the same store functors as gemm_generic_kernel.
+// ----------------------------------------------------------------------------------------------
+constexpr int MB_M = 128, MB_N = 128, MB_K = 16;
+typedef float mb_f32x16 __attribute__((ext_vector_type(16)));
+
+template <bool A_KFAST, bool B_KFAST, class FA, class FB, class SC>
+__global__ __launch_bounds__(256) void gemm_mfma32_kernel(FA fa, FB fb, SC sc, int M, int N, int K, int nsplit, int klen) {
+  __shared__ float As[MB_K][MB_M + 4];
+  __shared__ float Bs[MB_K][MB_N + 4];
+  const int bm = blockIdx.x * MB_M, bn = blockIdx.y * MB_N;
+  const int zs = blockIdx.z % nsplit, zb = blockIdx.z / nsplit;
+  const int k_begin = zs * klen;
+  const int k_end = min(K, k_begin + klen);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  mb_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float ra[8], rb[8];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = threadIdx.x + i * 256;
+      int kk, mm;
+      if (A_KFAST) { kk = idx & 15; mm = idx >> 4; } else { mm = idx & 127; kk = idx >> 7; }
+      ra[i] = (bm + mm < M && k0 + kk < k_end) ? fa(zb, bm + mm, k0 + kk) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = threadIdx.x + i * 256;
+      int kk, nn;
+      if (B_KFAST) { kk = idx & 15; nn = idx >> 4; } else { nn = idx & 127; kk = idx >> 7; }
+      rb[i] = (bn + nn < N && k0 + kk < k_end) ? fb(zb, k0 + kk, bn + nn) : 0.f;
+    }
+  };
+  if (k_begin < k_end) fetch(k_begin);
+  for (int k0 = k_begin; k0 < k_end; k0 += MB_K) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = threadIdx.x + i * 256;
+      if (A_KFAST) As[idx & 15][idx >> 4] = ra[i]; else As[idx >> 7][idx & 127] = ra[i];
+      if (B_KFAST) Bs[idx & 15][idx >> 4] = rb[i]; else Bs[idx >> 7][idx & 127] = rb[i];
+    }
+    __syncthreads();
+    if (k0 + MB_K < k_end) fetch(k0 + MB_K);
+#pragma unroll
+    for (int st = 0; st < MB_K / 2; ++st) {
+      const float a0 = As[2 * st + lh][wm * 64 + lr], a1 = As[2 * st + lh][wm * 64 + 32 + lr];
+      const float b0 = Bs[2 * st + lh][wn * 64 + lr], b1 = Bs[2 * st + lh][wn * 64 + 32 + lr];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // accumulator register r of a 32 x 32 tile: row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, n = bn + wn * 64 + j * 32 + lr;
+        if (m < M && n < N) sc(zb, zs, m, n, acc[i][j][r]);
+      }
+}
+
+// f32mma (option, default 1): fp32-storage launches whose output covers at least one 128 x 128 tile in each dimension's
+// better half (M >= 96, N >= 96) run on the matrix cores; everything else -- and every bf16-storage launch, whose results
+// the bf16 tests pin to the vector kernel bit for bit -- keeps gemm_generic_kernel.
+static bool use_mfma32(bool f32, int M, int N) { return f32 && M >= 96 && N >= 96 && rg_option("f32mma", 1) != 0; }
+
 template <bool AK, bool BK, class FA, class FB, class SC>
 int launch_generic(const char* name, FA fa, FB fb, SC sc, int M, int N, int K, int nbatch, int nsplit,
-                   hipStream_t st) {
+                   hipStream_t st, bool f32 = false) {
   if (M <= 0 || N <= 0 || K <= 0) return RG_OK;
   int klen = (K + nsplit - 1) / nsplit;
+  if (use_mfma32(f32, M, N)) {
+    klen = (klen + MB_K - 1) / MB_K * MB_K;
+    dim3 grid((M + MB_M - 1) / MB_M, (N + MB_N - 1) / MB_N, nbatch * nsplit);
+    RG_REQUIRE(grid.y <= 65535 && grid.z <= 65535, RG_EINVAL, "%s: grid too large", name);
+    hipLaunchKernelGGL((gemm_mfma32_kernel<AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, nsplit, klen);
+    RG_LAUNCH_CHECK(name);
+    return RG_OK;
+  }
   klen = (klen + GB_K - 1) / GB_K * GB_K;
   dim3 grid((M + GB_M - 1) / GB_M, (N + GB_N - 1) / GB_N, nbatch * nsplit);
   RG_REQUIRE(grid.y <= 65535 && grid.z <= 65535, RG_EINVAL, "%s: grid too large", name);
@@ -158,14 +256,22 @@ namespace {
 // ----------------------------------------------------------------------------------------------
 struct Geo {
   int N, Hl, Wl, Hh, Wh, O, I;  // low-res dims (Hl,Wl), high-res dims (Hh=2Hl, Wh=2Wl)
+  int sWl, sHl, sI;             // log2 + 1 of Wl / Hl / I when they are powers of two (0: general division), see geo_pow2
 };
+static int lg1(int v) { return v > 0 && (v & (v - 1)) == 0 ? rg_ilog2(v) + 1 : 0; }
+static Geo geo_pow2(Geo g) { g.sWl = lg1(g.Wl); g.sHl = lg1(g.Hl); g.sI = lg1(g.I); return g; }
+// q = x / d, r = x % d for x >= 0; s = log2(d) + 1 when d is a power of two (shift / mask instead of a ~40-instruction
+// integer division: the functors below run once per fetched operand element)
+__device__ __forceinline__ void rg_divmod(int x, int d, int s, int& q, int& r) {
+  if (s) { q = x >> (s - 1); r = x & (d - 1); } else { q = x / d; r = x - q * d; }
+}
 
 // ---- conv_down: M = N*Hl*Wl, K = 16*I (k = tap*I + ci: tap-major masters w[O][16][I]), Ncols = O
 template <typename T> struct DownA {
   const T* x; Geo g;
   __device__ float operator()(int, int m, int k) const {
-    int wo = m % g.Wl, t = m / g.Wl, ho = t % g.Hl, n = t / g.Hl;
-    int tap = k / g.I, ci = k - tap * g.I;
+    int wo, t, ho, n, tap, ci;
+    rg_divmod(m, g.Wl, g.sWl, t, wo); rg_divmod(t, g.Hl, g.sHl, n, ho); rg_divmod(k, g.I, g.sI, tap, ci);
     int hi = 2 * ho - 1 + (tap >> 2), wi = 2 * wo - 1 + (tap & 3);
     if (hi < 0 || hi >= g.Hh || wi < 0 || wi >= g.Wh) return 0.f;
     return Elem<T>::ld(x + (((size_t)n * g.Hh + hi) * g.Wh + wi) * g.I + ci);
@@ -189,7 +295,8 @@ __device__ __forceinline__ void up_tap(int par, int a, int q, int& kidx, int& sr
 template <typename T> struct UpA {
   const T* x; Geo g;
   __device__ float operator()(int zb, int m, int k) const {
-    int wq = m % g.Wl, t = m / g.Wl, hq = t % g.Hl, n = t / g.Hl;
+    int wq, t, hq, n;
+    rg_divmod(m, g.Wl, g.sWl, t, wq); rg_divmod(t, g.Hl, g.sHl, n, hq);
     int o = k >> 2, t4 = k & 3, kh, kw, ho, wo;
     up_tap(zb >> 1, t4 >> 1, hq, kh, ho);
     up_tap(zb & 1, t4 & 1, wq, kw, wo);
@@ -219,7 +326,8 @@ struct UpBOihw {
 template <typename T> struct UpC {
   T* y; Geo g; const T* mask; float mslope;       // optional fused LeakyReLU backward: v *= lrelu'(mask)
   __device__ void operator()(int zb, int, int m, int i, float v) const {
-    int wq = m % g.Wl, t = m / g.Wl, hq = t % g.Hl, n = t / g.Hl;
+    int wq, t, hq, n;
+    rg_divmod(m, g.Wl, g.sWl, t, wq); rg_divmod(t, g.Hl, g.sHl, n, hq);
     int hi = 2 * hq + (zb >> 1), wi = 2 * wq + (zb & 1);
     size_t idx = (((size_t)n * g.Hh + hi) * g.Wh + wi) * g.I + i;
     if (mask) v *= lrelu_mask(Elem<T>::ld(mask + idx), mslope);
@@ -230,7 +338,8 @@ template <typename T> struct UpC {
 struct UpCNchw {
   float* y; const float* bias; int tanh_; Geo g;
   __device__ void operator()(int zb, int, int m, int i, float v) const {
-    int wq = m % g.Wl, t = m / g.Wl, hq = t % g.Hl, n = t / g.Hl;
+    int wq, t, hq, n;
+    rg_divmod(m, g.Wl, g.sWl, t, wq); rg_divmod(t, g.Hl, g.sHl, n, hq);
     int hi = 2 * hq + (zb >> 1), wi = 2 * wq + (zb & 1);
     if (bias) v += bias[i];
     if (tanh_) v = tanhf(v);
@@ -242,7 +351,8 @@ struct UpCNchw {
 struct FirstDownA {
   const float* x; Geo g;
   __device__ float operator()(int, int m, int k) const {
-    int wo = m % g.Wl, t = m / g.Wl, ho = t % g.Hl, n = t / g.Hl;
+    int wo, t, ho, n;
+    rg_divmod(m, g.Wl, g.sWl, t, wo); rg_divmod(t, g.Hl, g.sHl, n, ho);
     int ci = k >> 4, tap = k & 15;
     int hi = 2 * ho - 1 + (tap >> 2), wi = 2 * wo - 1 + (tap & 3);
     if (hi < 0 || hi >= g.Hh || wi < 0 || wi >= g.Wh) return 0.f;
@@ -266,8 +376,8 @@ template <typename T> struct WgradA {
 template <typename T> struct WgradB {
   const T* high; Geo g;
   __device__ float operator()(int, int pix, int col) const {
-    int wo = pix % g.Wl, t = pix / g.Wl, ho = t % g.Hl, n = t / g.Hl;
-    int tap = col / g.I, i = col - tap * g.I;
+    int wo, t, ho, n, tap, i;
+    rg_divmod(pix, g.Wl, g.sWl, t, wo); rg_divmod(t, g.Hl, g.sHl, n, ho); rg_divmod(col, g.I, g.sI, tap, i);
     int hi = 2 * ho - 1 + (tap >> 2), wi = 2 * wo - 1 + (tap & 3);
     if (hi < 0 || hi >= g.Hh || wi < 0 || wi >= g.Wh) return 0.f;
     return Elem<T>::ld(high + (((size_t)n * g.Hh + hi) * g.Wh + wi) * g.I + i);
@@ -276,7 +386,8 @@ template <typename T> struct WgradB {
 struct WgradBNchw {
   const float* high; Geo g;
   __device__ float operator()(int, int pix, int col) const {
-    int wo = pix % g.Wl, t = pix / g.Wl, ho = t % g.Hl, n = t / g.Hl;
+    int wo, t, ho, n;
+    rg_divmod(pix, g.Wl, g.sWl, t, wo); rg_divmod(t, g.Hl, g.sHl, n, ho);
     int i = col >> 4, tap = col & 15;
     int hi = 2 * ho - 1 + (tap >> 2), wi = 2 * wo - 1 + (tap & 3);
     if (hi < 0 || hi >= g.Hh || wi < 0 || wi >= g.Wh) return 0.f;
@@ -296,9 +407,10 @@ template <typename T> struct G0A {
   __device__ float operator()(int, int n, int e) const { return Elem<T>::round(z[(size_t)n * E + e]); }
 };
 template <typename T> struct G0B {
-  const float* w; int C;
+  const float* w; int C; int sC;
   __device__ float operator()(int, int e, int col) const {
-    int tap = col / C, c = col % C;
+    int tap, c;
+    rg_divmod(col, C, sC, tap, c);
     return Elem<T>::round(w[((size_t)e * C + c) * 16 + tap]);
   }
 };
@@ -356,26 +468,26 @@ int pick_split(int tiles, int K) {
 // ==============================================================================================
 int rg_generic_conv_down(const void* x, const float* w, void* y, int N, int Hi, int Wi, int I, int O, int dtype,
                          hipStream_t st) {
-  Geo g{N, Hi / 2, Wi / 2, Hi, Wi, O, I};
+  Geo g = geo_pow2(Geo{N, Hi / 2, Wi / 2, Hi, Wi, O, I});
   RG_DISPATCH_DTYPE(dtype, T, {
     return launch_generic<true, true>("conv_down(generic)", DownA<T>{(const T*)x, g}, DownB<T>{w, g},
-                                      RowMajorC<T>{(T*)y, O}, N * g.Hl * g.Wl, O, I * 16, 1, 1, st);
+                                      RowMajorC<T>{(T*)y, O}, N * g.Hl * g.Wl, O, I * 16, 1, 1, st, std::is_same<T, float>::value);
   })
 }
 
 int rg_generic_conv_up(const void* x, const float* w, void* y, int N, int Ho, int Wo, int O, int I, const void* mask,
                        float mslope, int dtype, hipStream_t st) {
-  Geo g{N, Ho, Wo, 2 * Ho, 2 * Wo, O, I};
+  Geo g = geo_pow2(Geo{N, Ho, Wo, 2 * Ho, 2 * Wo, O, I});
   RG_DISPATCH_DTYPE(dtype, T, {
     return launch_generic<true, false>("conv_up(generic)", UpA<T>{(const T*)x, g}, UpB<T>{w, g},
                                        UpC<T>{(T*)y, g, (const T*)mask, mslope},
-                                       N * Ho * Wo, I, O * 4, 4, 1, st);
+                                       N * Ho * Wo, I, O * 4, 4, 1, st, std::is_same<T, float>::value);
   })
 }
 
 int rg_generic_first_down(const float* x, const float* w, const float* bias, void* y, int N, int H, int W, int I,
                           int O, float slope, int dtype, hipStream_t st) {
-  Geo g{N, H / 2, W / 2, H, W, O, I};
+  Geo g = geo_pow2(Geo{N, H / 2, W / 2, H, W, O, I});
   RG_DISPATCH_DTYPE(dtype, T, {
     return launch_generic<true, true>("first_down(generic)", FirstDownA{x, g}, DownB<float>{w, g},
                                       BiasActC<T>{(T*)y, bias, slope, O}, N * g.Hl * g.Wl, O, I * 16, 1, 1, st);
@@ -384,7 +496,7 @@ int rg_generic_first_down(const float* x, const float* w, const float* bias, voi
 
 int rg_generic_last_up(const void* x, const float* w, const float* bias, float* y, int N, int Ho, int Wo, int O,
                        int I, int apply_tanh, int dtype, hipStream_t st) {
-  Geo g{N, Ho, Wo, 2 * Ho, 2 * Wo, O, I};
+  Geo g = geo_pow2(Geo{N, Ho, Wo, 2 * Ho, 2 * Wo, O, I});
   RG_DISPATCH_DTYPE(dtype, T, {
     return launch_generic<true, false>("last_up(generic)", UpA<T>{(const T*)x, g}, UpBOihw{w, g},
                                        UpCNchw{y, bias, apply_tanh, g}, N * Ho * Wo, I, O * 4, 4, 1, st);
@@ -392,6 +504,8 @@ int rg_generic_last_up(const void* x, const float* w, const float* bias, float* 
 }
 
 static int generic_wgrad_split(int N, int Ho, int Wo, int O, int I) {
+  // (tile counts of the vector kernel's 64 x 64 tiles also where the 128 x 128 matrix-core kernel runs: four times the
+  // splits per tile there, i.e. the same number of workgroups' worth of work items and >= 64 k-steps per split)
   int tiles = ((O + GB_M - 1) / GB_M) * ((I * 16 + GB_N - 1) / GB_N);
   return pick_split(tiles, N * Ho * Wo);
 }
@@ -411,20 +525,20 @@ static int generic_wgrad_impl(const char* name, const void* low, FB fb, float* d
     RG_REQUIRE(ws && ws_bytes >= (size_t)s * elems * sizeof(float), RG_EWORKSPACE, "%s: workspace too small", name);
     RG_DISPATCH_DTYPE(dtype, T, {
       int rc = launch_generic<false, false>(name, WgradA<T>{(const T*)low, g}, fb, SlabC{(float*)ws, elems, g.I * 16},
-                                            g.O, g.I * 16, K, 1, s, st);
+                                            g.O, g.I * 16, K, 1, s, st, std::is_same<T, float>::value);
       if (rc) return rc;
     })
     return rg_reduce_slabs((const float*)ws, dw, elems, s, accumulate, 0, 0, st);
   }
   RG_DISPATCH_DTYPE(dtype, T, {
     return launch_generic<false, false>(name, WgradA<T>{(const T*)low, g}, fb, AccumC{dw, g.I * 16, accumulate}, g.O,
-                                        g.I * 16, K, 1, 1, st);
+                                        g.I * 16, K, 1, 1, st, std::is_same<T, float>::value);
   })
 }
 
 int rg_generic_conv_wgrad(const void* low, const void* high, float* dw, int N, int Ho, int Wo, int O, int I,
                           int dtype, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
-  Geo g{N, Ho, Wo, 2 * Ho, 2 * Wo, O, I};
+  Geo g = geo_pow2(Geo{N, Ho, Wo, 2 * Ho, 2 * Wo, O, I});
   if (dtype == RG_F32)
     return generic_wgrad_impl("conv_wgrad(generic)", low, WgradB<float>{(const float*)high, g}, dw, g, dtype,
                               accumulate, ws, ws_bytes, st);
@@ -434,15 +548,15 @@ int rg_generic_conv_wgrad(const void* low, const void* high, float* dw, int N, i
 
 int rg_generic_skinny_wgrad(const void* low, const float* high_nchw, float* dw, int N, int Ho, int Wo, int O, int I,
                             int dtype, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
-  Geo g{N, Ho, Wo, 2 * Ho, 2 * Wo, O, I};
+  Geo g = geo_pow2(Geo{N, Ho, Wo, 2 * Ho, 2 * Wo, O, I});
   return generic_wgrad_impl("skinny_wgrad(generic)", low, WgradBNchw{high_nchw, g}, dw, g, dtype, accumulate, ws,
                             ws_bytes, st);
 }
 
 int rg_generic_g0_fwd(const float* z, const float* w, void* y, int N, int E, int C, int dtype, hipStream_t st) {
   RG_DISPATCH_DTYPE(dtype, T, {
-    return launch_generic<true, false>("g0_fwd(generic)", G0A<T>{z, E}, G0B<T>{w, C}, RowMajorC<T>{(T*)y, 16 * C}, N,
-                                       16 * C, E, 1, 1, st);
+    return launch_generic<true, false>("g0_fwd(generic)", G0A<T>{z, E}, G0B<T>{w, C, lg1(C)}, RowMajorC<T>{(T*)y, 16 * C}, N,
+                                       16 * C, E, 1, 1, st, std::is_same<T, float>::value);
   })
 }
 
@@ -450,14 +564,14 @@ int rg_generic_g0_wgrad(const float* z, const void* gy, float* dw, int N, int E,
                         hipStream_t st) {
   RG_DISPATCH_DTYPE(dtype, T, {
     return launch_generic<false, false>("g0_wgrad(generic)", G0WA<T>{z, E}, G0WB<T>{(const T*)gy, C},
-                                        AccumC{dw, 16 * C, accumulate}, E, 16 * C, N, 1, 1, st);
+                                        AccumC{dw, 16 * C, accumulate}, E, 16 * C, N, 1, 1, st, std::is_same<T, float>::value);
   })
 }
 
 int rg_generic_linear(const float* x, int ldx, const float* w, const float* scale, const float* shift, float* y,
                       int ldy, int M, int K, int Nout, float slope, hipStream_t st) {
   return launch_generic<true, true>("linear(generic)", LinA{x, ldx}, LinB{w, K}, LinC{y, ldy, scale, shift, slope}, M,
-                                    Nout, K, 1, 1, st);
+                                    Nout, K, 1, 1, st, true);
 }
 
 // ================================================================================================

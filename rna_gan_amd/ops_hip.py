@@ -1139,6 +1139,9 @@ class HipOps:
         M, K = x.shape
         Nout = w.shape[0]
         assert x.dtype == torch.float32 and x.is_contiguous()
+        if w.dim() != 2 or w.shape[1] != K:       # the kernels index w[j * K + k]: a mismatch reads out of bounds
+            raise RuntimeError("linear_affine_act: x is (%d, %d) but the weight is %s (nn.Linear layout [out][in] expected)"
+                               % (M, K, tuple(w.shape)))
         y = self._f32(M, Nout)
         algo = self.algo if wp is not None else _abi.ALGO_GENERIC
         ws = self._ws(self.lib.rg_linear_workspace_bytes(M, K, Nout, algo))

@@ -67,6 +67,10 @@ CONV_CASES = [
     (3, 8, 8, 128, 256, torch.bfloat16),       # MFMA, M tail (48 rows), 2 column tiles
     (1, 8, 8, 256, 128, torch.bfloat16),       # MFMA, 16 rows only
     (4, 32, 32, 64, 128, torch.bfloat16),      # MFMA, several row tiles
+    # fp32 storage on the f32 matrix cores (gemm_mfma32_kernel: 128 x 128 tiles, v_mfma_f32_32x32x2_f32)
+    (3, 16, 16, 24, 100, torch.float32),       # down: 192 x 100 (ragged tile), K = 384, non-power-of-two I (division path)
+    (2, 32, 32, 136, 40, torch.float32),       # up: 512 x 136 per class (two column tiles, ragged); down stays on the vector kernel
+    (2, 16, 16, 128, 136, torch.float32),      # both directions + weight gradient (136 x 2048 outputs, split-K slabs)
 ]
 
 
@@ -114,6 +118,36 @@ def test_conv_down_up_wgrad(N, Hi, Wi, I, O, dtype):
     check(ch.dw, cr.dw, TOL[dtype] * 2, "conv_wgrad2")
     hip.conv_wgrad2(dev(g), dev(x), dev(g2), dev(x2), ch, True)
     check(ch.dw, 2 * cr.dw, TOL[dtype] * 2, "conv_wgrad2(accumulate)")
+
+
+@pytest.mark.parametrize("N,Hi,Wi,I,O", [(2, 16, 16, 128, 136), (3, 16, 16, 24, 100), (1, 32, 32, 64, 256)])
+def test_f32_matrix_core_gemm_matches_vector_kernel(N, Hi, Wi, I, O):
+    """fp32 mode: the f32-MFMA GEMM skeleton (option f32mma = 1, default) against the vector-ALU skeleton (f32mma = 0) through
+    the same operand functors -- conv forward, transposed conv, weight gradient, generator layer 0 and a dense layer.  Both
+    are fused-multiply-add chains in fp32; only the association of the k-loop differs (two interleaved k per MFMA step)."""
+    from rna_gan_amd import _abi
+    hip = _hip(torch.float32)
+    lib = hip.lib
+    w = rnd((O, I, 4, 4), 1, (2.0 / (I * 16)) ** 0.5)
+    x, g = dev(rnd((N, Hi, Wi, I), 2)), dev(rnd((N, Hi // 2, Wi // 2, O), 3))
+    z, gy0 = dev(rnd((96, 128), 4)), dev(rnd((96, 4, 4, 96), 5))
+    w0 = rnd((128, 96, 4, 4), 6, 0.05)
+    lx, lw = dev(rnd((200, 300), 7)), dev(rnd((150, 300), 8, 0.05))
+    outs = {}
+    try:
+        for on in (0, 1):
+            _abi.check(lib.rg_set_option(b"f32mma", on), "rg_set_option")
+            _, ch = cwpair_tm(w)
+            _, c0 = cwpair(w0)
+            c0.dw = torch.zeros_like(c0.w)
+            hip.conv_wgrad(g, x, ch, False)
+            hip.g0_wgrad(z, gy0, c0.dw, False)
+            outs[on] = [hip.conv_down(x, ch), hip.conv_up(g, ch), ch.dw.clone(), hip.g0_fwd(z, c0), c0.dw.clone(),
+                        hip.linear_affine_act(lx, lw, None, None, 1.0)]
+    finally:
+        lib.rg_set_option(b"f32mma", -1)
+    for name, a, b in zip(("conv_down", "conv_up", "conv_wgrad", "g0_fwd", "g0_wgrad", "linear"), outs[1], outs[0]):
+        check(a, b, 2e-6, name)
 
 
 CONV8_CASES = [

@@ -441,8 +441,9 @@ def test_cli_stock_wgan_literal_command(tmp_path):
     STOCK torchgan losses (randn noise on the device, tensor batches, weight clamp (-0.01, 0.01) before the D step) at the
     reference's hard-coded batch 8 on 256 x 256 synthetic tiles, reference model size, through the CLI.  Three iterations;
     checks completion, the checkpoint dictionary's keys, three logged values per plugin, finite weights, and that the
-    discriminator's parameters sit inside the clamp interval up to the one Adam step (lr 4e-4) the penalty train_op takes
-    after the clamp."""
+    discriminator's parameters sit inside the clamp interval up to the TWO Adam steps (lr 4e-4; D-loss and penalty train_ops)
+    taken after the last clamp -- early Adam steps are up to ~3 lr per element (bias-corrected m / sqrt(v) with betas (0.5, 0.999)
+    exceeds 1 when a gradient shrinks), an unclamped weight of this layer would be ~0.2."""
     import subprocess
     import sys
     import numpy as np
@@ -467,7 +468,7 @@ def test_cli_stock_wgan_literal_command(tmp_path):
     assert ck["generator"]["model.0.0.weight"].shape == (2048, 2048, 4, 4) and ck["discriminator"]["disc.0.weight"].shape == (1, 2048, 4, 4)
     for k, v in ck["discriminator"].items():
         if v.dtype.is_floating_point and "running" not in k:
-            assert float(v.abs().max()) <= 0.01 + 2 * 4e-4 + 1e-6, (k, float(v.abs().max()))
+            assert float(v.abs().max()) <= 0.01 + 2 * 3 * 4e-4, (k, float(v.abs().max()))
     for k, v in ck["generator"].items():
         assert not v.dtype.is_floating_point or bool(torch.isfinite(v).all()), k
     assert os.path.exists(str(tmp_path / "img" / "epoch1_generator.png"))
