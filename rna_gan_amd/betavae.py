@@ -188,7 +188,14 @@ class betaVAE(nn.Module):
         """Identity of the eval-mode encoder's weights as the loss plugins see it (losses._LatentCache: the reference builds
         three copies from one checkpoint; copies with equal signatures hold the same weights and produce equal latents).
         (precision, weights token) while the weights are untouched since the token was adopted; otherwise private to this
-        module and its current tensor versions -- never equal to another module's."""
+        module and its current tensor versions -- never equal to another module's.
+
+        LIMIT: the token is validated by the tensors' VERSION counters.  A write that bypasses them --
+        ``p.data.copy_(...)``, ``p.data = ...``, a collective on ``p.data``, a custom optimizer stepping ``.data`` -- leaves
+        the token looking valid.  Whoever writes weights that way must call ``weights_changed()`` afterwards (the CLI's
+        broadcast does, then ``adopt_weights_token``); ``load_state_dict``, ``.to()`` and in-place ops on the parameters
+        themselves are tracked.  A value fingerprint would need a device read per batch here, which is what the token
+        replaced."""
         versions = self._versions()
         w = self.z_mu.weight
         if self._token is not None and self._token_versions == versions:

@@ -79,98 +79,236 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(FA fa, FB fb, SC sc, 
 // reads and the issue slots of the vector pipe are left to the functors' address arithmetic).  This is the fp32 mode's
 // conv / dense kernel wherever the output tile is worth it (the reference's own arithmetic is fp32: src/betaVAE.py:184,
 // 223, 230-236; SURVEY 8d "~157 TFLOP/s fp32 matrix").
-//   block = 256 threads = 2 x 2 waves, tile 128 x 128, each wave 64 x 64 = 2 x 2 accumulator tiles of 32 x 32;
+//   block = 256 threads = 2 x 2 waves, tile 128 x 128, each wave 64 x 64 = 2 x 2 accumulator tiles of 32 x 32 (or 64 x 64 with
+//   one accumulator tile per wave where the output has too few large tiles to fill the chip);
 //   k-tile 16: operands fetched through the SAME functors into registers one k-tile ahead (the global loads fly under
 //   the MFMAs of the current tile), staged in LDS k-major ([k][m]: a fragment read is 32 consecutive floats per k row,
 //   conflict-free ds_read_b32); MFMA step s consumes k = 2s (lanes 0-31) and 2s + 1 (lanes 32-63).
 // Same split-K contract and the same store functors as gemm_generic_kernel.
 // ----------------------------------------------------------------------------------------------
-constexpr int MB_M = 128, MB_N = 128, MB_K = 16;
+#ifndef RG_MBK
+#define RG_MBK 16
+#endif
+constexpr int MB_M = 128, MB_N = 128, MB_K = RG_MBK;      // k-tile depth (build-time knob: 16 or 32)
 typedef float mb_f32x16 __attribute__((ext_vector_type(16)));
 
-template <bool A_KFAST, bool B_KFAST, class FA, class FB, class SC>
+// Two-phase operand access.  A thread of gemm_mfma32_kernel fetches the same 1 or 8 tile rows (m for A, n for B) in every
+// k-tile and 8 or 1 k positions per k-tile, so whatever an operand functor derives from the row index alone (pixel
+// coordinates, base offsets) is computed once per thread, and what it derives from k alone once per k position -- not once per
+// fetched element as operator() does (~25 integer operations per element for the gathered operands, which made the vector
+// pipe, not the matrix pipe, the bound of the first version of this kernel: 55 of 157 TFLOP/s).
+//   Op<F, A_SIDE>::row(f, zb, r) / ::col(f, zb, k) / ::at(f, zb, row, col, ok)
+// The primary template wraps operator() (no saving); the gathered operands of the conv layers specialise it below.
+// P2 (compile-time): every divisor the functor uses is a power of two (pow2(f), decided once per launch: the kernel branches
+// once per k-tile between the two instantiations of its fetch code instead of once per index computation).
+template <class F, bool A_SIDE> struct Op {
+  struct R { int r; };
+  struct C { int k; };
+  static __device__ __forceinline__ bool pow2(const F&) { return true; }
+  static bool fits32(const F&) { return true; }          // host: element offsets of the two-phase form fit an int
+  template <bool P2> static __device__ __forceinline__ R row(const F&, int, int r) { return {r}; }
+  template <bool P2> static __device__ __forceinline__ C col(const F&, int, int k) { return {k}; }
+  // ok: false where the element is implicit padding (the caller zeroes the value WHEN IT STORES IT: the load's first use then
+  // sits behind the MFMAs of the current k-tile)
+  static __device__ __forceinline__ float at(const F& f, int zb, const R& r, const C& c, bool& ok) {
+    ok = true;
+    return A_SIDE ? f(zb, r.r, c.k) : f(zb, c.k, r.r);
+  }
+};
+
+// TM x TN: the wave tile (64 x 64 = 2 x 2 accumulator tiles, or 32 x 32 = one); block tile = 2 TM x 2 TN.  The small form
+// has 4 x the workgroups: for the deep layers whose output is only 1-2 hundred 128 x 128 tiles (three workgroups fit a CU).
+template <int TM, int TN, bool A_KFAST, bool B_KFAST, class FA, class FB, class SC>
 __global__ __launch_bounds__(256) void gemm_mfma32_kernel(FA fa, FB fb, SC sc, int M, int N, int K, int nsplit, int klen) {
-  __shared__ float As[MB_K][MB_M + 4];
-  __shared__ float Bs[MB_K][MB_N + 4];
-  const int bm = blockIdx.x * MB_M, bn = blockIdx.y * MB_N;
+  constexpr int BM = 2 * TM, BN = 2 * TN, IA = TM / 32, IB = TN / 32;
+  constexpr int NSA = BM * MB_K / 256, NSB = BN * MB_K / 256;          // fetch slots per thread and k-tile (8 or 4)
+  constexpr int KSA = 256 / BM, KSB = 256 / BN;                        // !KFAST: k rows covered by one pass of the block (2 or 4)
+  __shared__ float As[2][MB_K][BM + 4];
+  __shared__ float Bs[2][MB_K][BN + 4];
+  using OA = Op<FA, true>;
+  using OB = Op<FB, false>;
+  const int bm = blockIdx.x * BM, bn = blockIdx.y * BN;
   const int zs = blockIdx.z % nsplit, zb = blockIdx.z / nsplit;
   const int k_begin = zs * klen;
   const int k_end = min(K, k_begin + klen);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 31, lh = lane >> 5;
-  mb_f32x16 acc[2][2];
+  mb_f32x16 acc[IA][IB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < IA; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < IB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float ra[8], rb[8];
-  auto fetch = [&](int k0) {
+  // fetch slots of this thread: slot i = element (tid + 256 i) of the BM x MB_K tile.  KFAST: k = tid % MB_K (one k, rows
+  // tid / MB_K + RP i, RP = 256 / MB_K); otherwise row = tid % BM (one row, k = tid / BM + KSA i).
+  constexpr int RP = 256 / MB_K;
+  constexpr int NRA = A_KFAST ? NSA : 1, NRB = B_KFAST ? NSB : 1;
+  typename OA::R rowa[NRA];
+  typename OB::R rowb[NRB];
+  bool oka[NRA], okb[NRB];
+  const bool p2 = (int)OA::pow2(fa) & (int)OB::pow2(fb);           // uniform: one branch per k-tile selects the shift / division code
+  auto init_rows = [&](auto P2) __attribute__((always_inline)) {
+    constexpr bool p = decltype(P2)::value;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = threadIdx.x + i * 256;
-      int kk, mm;
-      if (A_KFAST) { kk = idx & 15; mm = idx >> 4; } else { mm = idx & 127; kk = idx >> 7; }
-      ra[i] = (bm + mm < M && k0 + kk < k_end) ? fa(zb, bm + mm, k0 + kk) : 0.f;
+    for (int i = 0; i < NRA; ++i) {
+      const int mm = A_KFAST ? tid / MB_K + RP * i : (tid & (BM - 1));
+      oka[i] = bm + mm < M;
+      rowa[i] = OA::template row<p>(fa, zb, oka[i] ? bm + mm : 0);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = threadIdx.x + i * 256;
-      int kk, nn;
-      if (B_KFAST) { kk = idx & 15; nn = idx >> 4; } else { nn = idx & 127; kk = idx >> 7; }
-      rb[i] = (bn + nn < N && k0 + kk < k_end) ? fb(zb, k0 + kk, bn + nn) : 0.f;
+    for (int i = 0; i < NRB; ++i) {
+      const int nn = B_KFAST ? tid / MB_K + RP * i : (tid & (BN - 1));
+      okb[i] = bn + nn < N;
+      rowb[i] = OB::template row<p>(fb, zb, okb[i] ? bn + nn : 0);
     }
   };
-  if (k_begin < k_end) fetch(k_begin);
-  for (int k0 = k_begin; k0 < k_end; k0 += MB_K) {
+  if (p2) init_rows(std::true_type{}); else init_rows(std::false_type{});
+  float ra[NSA], rb[NSB];
+  unsigned pa = 0, pb = 0;            // validity bits of the fetched slots: applied when the values are stashed, i.e. AFTER the
+                                      // MFMAs of the current k-tile, so that nothing waits for the loads before them
+  // (always_inline: an out-of-line lambda body would reach everything it captures -- the functors, the register arrays --
+  // through memory, i.e. scratch loads in the k-loop)
+  auto fetch_t = [&](int k0, auto P2) __attribute__((always_inline)) {
+    constexpr bool p = decltype(P2)::value;
+    pa = 0; pb = 0;
+    if (A_KFAST) {
+      const int k = k0 + (tid & (MB_K - 1));
+      const bool kv = k < k_end;
+      const typename OA::C c = OA::template col<p>(fa, zb, kv ? k : k_begin);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = threadIdx.x + i * 256;
-      if (A_KFAST) As[idx & 15][idx >> 4] = ra[i]; else As[idx >> 7][idx & 127] = ra[i];
-      if (B_KFAST) Bs[idx & 15][idx >> 4] = rb[i]; else Bs[idx >> 7][idx & 127] = rb[i];
+      for (int i = 0; i < NSA; ++i) {               // (row and k are clamped: the access itself is always in bounds)
+        bool ok;
+        ra[i] = OA::at(fa, zb, rowa[i], c, ok);
+        pa |= ((unsigned)kv & (unsigned)oka[i] & (unsigned)ok) << i;    // (bitwise &: a short-circuit && is control flow, and the load sinks into it)
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NSA; ++i) {
+        const int k = k0 + tid / BM + KSA * i;
+        const bool kv = k < k_end;
+        bool ok;
+        ra[i] = OA::at(fa, zb, rowa[0], OA::template col<p>(fa, zb, kv ? k : k_begin), ok);
+        pa |= ((unsigned)kv & (unsigned)oka[0] & (unsigned)ok) << i;
+      }
     }
-    __syncthreads();
-    if (k0 + MB_K < k_end) fetch(k0 + MB_K);
+    if (B_KFAST) {
+      const int k = k0 + (tid & (MB_K - 1));
+      const bool kv = k < k_end;
+      const typename OB::C c = OB::template col<p>(fb, zb, kv ? k : k_begin);
+#pragma unroll
+      for (int i = 0; i < NSB; ++i) {
+        bool ok;
+        rb[i] = OB::at(fb, zb, rowb[i], c, ok);
+        pb |= ((unsigned)kv & (unsigned)okb[i] & (unsigned)ok) << i;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NSB; ++i) {
+        const int k = k0 + tid / BN + KSB * i;
+        const bool kv = k < k_end;
+        bool ok;
+        rb[i] = OB::at(fb, zb, rowb[0], OB::template col<p>(fb, zb, kv ? k : k_begin), ok);
+        pb |= ((unsigned)kv & (unsigned)okb[0] & (unsigned)ok) << i;
+      }
+    }
+  };
+  auto fetch = [&](int k0) __attribute__((always_inline)) { if (p2) fetch_t(k0, std::true_type{}); else fetch_t(k0, std::false_type{}); };
+  auto stash = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NSA; ++i) {
+      const float v = (pa >> i) & 1u ? ra[i] : 0.f;
+      if (A_KFAST) As[st][tid & (MB_K - 1)][tid / MB_K + RP * i] = v; else As[st][tid / BM + KSA * i][tid & (BM - 1)] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NSB; ++i) {
+      const float v = (pb >> i) & 1u ? rb[i] : 0.f;
+      if (B_KFAST) Bs[st][tid & (MB_K - 1)][tid / MB_K + RP * i] = v; else Bs[st][tid / BN + KSB * i][tid & (BN - 1)] = v;
+    }
+  };
+  if (k_begin < k_end) { fetch(k_begin); stash(0); }
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = k_begin; k0 < k_end; k0 += MB_K) {
+    const bool more = k0 + MB_K < k_end;
+    if (more) fetch(k0 + MB_K);                    // global loads of the next k-tile fly under this tile's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef RG_F32_NOPIPE
 #pragma unroll
     for (int st = 0; st < MB_K / 2; ++st) {
-      const float a0 = As[2 * st + lh][wm * 64 + lr], a1 = As[2 * st + lh][wm * 64 + 32 + lr];
-      const float b0 = Bs[2 * st + lh][wn * 64 + lr], b1 = Bs[2 * st + lh][wn * 64 + 32 + lr];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      float a[IA], b[IB];
+#pragma unroll
+      for (int i = 0; i < IA; ++i) a[i] = As[cur][2 * st + lh][wm * TM + 32 * i + lr];
+#pragma unroll
+      for (int j = 0; j < IB; ++j) b[j] = Bs[cur][2 * st + lh][wn * TN + 32 * j + lr];
+#pragma unroll
+      for (int i = 0; i < IA; ++i)
+#pragma unroll
+        for (int j = 0; j < IB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+#else
+    // the fragments of step st + 1 are read while the MFMAs of step st run (two register sets)
+    float a[2][IA], b[2][IB];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) a[0][i] = As[cur][lh][wm * TM + 32 * i + lr];
+#pragma unroll
+    for (int j = 0; j < IB; ++j) b[0][j] = Bs[cur][lh][wn * TN + 32 * j + lr];
+#pragma unroll
+    for (int st = 0; st < MB_K / 2; ++st) {
+      if (st + 1 < MB_K / 2) {
+#pragma unroll
+        for (int i = 0; i < IA; ++i) a[(st + 1) & 1][i] = As[cur][2 * st + 2 + lh][wm * TM + 32 * i + lr];
+#pragma unroll
+        for (int j = 0; j < IB; ++j) b[(st + 1) & 1][j] = Bs[cur][2 * st + 2 + lh][wn * TN + 32 * j + lr];
+      }
+#pragma unroll
+      for (int i = 0; i < IA; ++i)
+#pragma unroll
+        for (int j = 0; j < IB; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][i], b[st & 1][j], acc[i][j], 0, 0, 0);
+    }
+#endif
+    __builtin_amdgcn_sched_barrier(0);             // the loads stay above the MFMAs, their first use (the stash) below
+    if (more) stash(cur ^ 1);                      // the other stage: its last readers passed the barrier of the previous tile
     __syncthreads();
+    cur ^= 1;
   }
   // accumulator register r of a 32 x 32 tile: row (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column lane & 31
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < IA; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < IB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = bm + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, n = bn + wn * 64 + j * 32 + lr;
+        const int m = bm + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, n = bn + wn * TN + j * 32 + lr;
         if (m < M && n < N) sc(zb, zs, m, n, acc[i][j][r]);
       }
 }
 
-// f32mma (option, default 1): fp32-storage launches whose output covers at least one 128 x 128 tile in each dimension's
-// better half (M >= 96, N >= 96) run on the matrix cores; everything else -- and every bf16-storage launch, whose results
-// the bf16 tests pin to the vector kernel bit for bit -- keeps gemm_generic_kernel.
-static bool use_mfma32(bool f32, int M, int N) { return f32 && M >= 96 && N >= 96 && rg_option("f32mma", 1) != 0; }
+// f32mma (option, default 1): fp32-storage launches with at least 64 rows and more than 32 columns run on the matrix cores;
+// everything else (the 3-column image layers) -- and every bf16-storage launch, whose results the bf16 tests pin to the vector
+// kernel bit for bit -- keeps gemm_generic_kernel.
+static bool use_mfma32(bool f32, int M, int N) { return f32 && M >= 64 && N >= 33 && rg_option("f32mma", 1) != 0; }
 
 template <bool AK, bool BK, class FA, class FB, class SC>
 int launch_generic(const char* name, FA fa, FB fb, SC sc, int M, int N, int K, int nbatch, int nsplit,
                    hipStream_t st, bool f32 = false) {
   if (M <= 0 || N <= 0 || K <= 0) return RG_OK;
   int klen = (K + nsplit - 1) / nsplit;
-  if (use_mfma32(f32, M, N)) {
+  if (use_mfma32(f32, M, N) && Op<FA, true>::fits32(fa) && Op<FB, false>::fits32(fb)) {
     klen = (klen + MB_K - 1) / MB_K * MB_K;
     dim3 grid((M + MB_M - 1) / MB_M, (N + MB_N - 1) / MB_N, nbatch * nsplit);
     RG_REQUIRE(grid.y <= 65535 && grid.z <= 65535, RG_EINVAL, "%s: grid too large", name);
-    hipLaunchKernelGGL((gemm_mfma32_kernel<AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, nsplit, klen);
+    if ((long long)grid.x * grid.y * grid.z < 512 || N <= 64 || M <= 64) {   // fewer than two 128 x 128 tiles per CU, or an
+      // output no wider / taller than 64 (the 64-channel layers, batch-64 dense layers): 64 x 64 tiles, 4 x the blocks
+      grid = dim3((M + 63) / 64, (N + 63) / 64, nbatch * nsplit);
+      RG_REQUIRE(grid.y <= 65535, RG_EINVAL, "%s: grid too large", name);
+      hipLaunchKernelGGL((gemm_mfma32_kernel<32, 32, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, nsplit, klen);
+    } else {
+      hipLaunchKernelGGL((gemm_mfma32_kernel<64, 64, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, nsplit, klen);
+    }
     RG_LAUNCH_CHECK(name);
     return RG_OK;
   }
@@ -229,6 +367,40 @@ __global__ __launch_bounds__(256) void reduce_slabs_wide_kernel(const float* __r
   }
 }
 
+// identity layout, many slabs (>= 16) of a mid-sized tensor (the weight gradients of the shallow conv layers: 32-128 slabs
+// of 0.5-2 MB): 16 bytes per thread, 4 slab lanes per column group -- 64 threads read 1 KB contiguous per slab, 8 loads in
+// flight per thread; fixed summation order (lane-strided partials, then lanes 0..3).  The 16-element form above moved 64-byte
+// pieces (3.8 TB/s on 67 MB of slabs); this one streams at the rate of the vec4 kernel.
+__global__ __launch_bounds__(256) void reduce_slabs_mid_kernel(const float* __restrict__ slab, float* __restrict__ dst,
+                                                               size_t n4, size_t n, int nsplit, int accumulate) {
+  __shared__ float4 sm[4][64];
+  const int c = threadIdx.x & 63, l = threadIdx.x >> 6;
+  const size_t idx = (size_t)blockIdx.x * 64 + c;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (idx < n4) {
+    int z = l;
+    for (; z + 28 < nsplit; z += 32) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const float4*>(slab + (size_t)(z + 4 * u) * n)[idx];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; z < nsplit; z += 4) {
+      const float4 v = reinterpret_cast<const float4*>(slab + (size_t)z * n)[idx];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  sm[l][c] = s;
+  __syncthreads();
+  if (l == 0 && idx < n4) {
+    float4 t = accumulate ? reinterpret_cast<const float4*>(dst)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { t.x += sm[k][c].x; t.y += sm[k][c].y; t.z += sm[k][c].z; t.w += sm[k][c].w; }
+    reinterpret_cast<float4*>(dst)[idx] = t;
+  }
+}
+
 }  // namespace
 
 int rg_reduce_slabs(const float* slab, float* dst, size_t n, int nsplit, int accumulate, int perm_mode, int Q,
@@ -236,7 +408,10 @@ int rg_reduce_slabs(const float* slab, float* dst, size_t n, int nsplit, int acc
   (void)Q;
   if (n == 0) return RG_OK;
   RG_REQUIRE(perm_mode == 0, RG_EINVAL, "reduce_slabs: slabs must have the destination's layout");
-  if (nsplit >= 64 && n <= (1u << 20)) {
+  if (nsplit >= 16 && n % 4 == 0 && n >= 65536 && n <= (1u << 22) && (((uintptr_t)slab | (uintptr_t)dst) & 15) == 0) {
+    hipLaunchKernelGGL(reduce_slabs_mid_kernel, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, st, slab, dst, n / 4, n,
+                       nsplit, accumulate);
+  } else if (nsplit >= 64 && n <= (1u << 20)) {
     hipLaunchKernelGGL(reduce_slabs_wide_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, slab, dst, n, nsplit,
                        accumulate);
   } else if (n % 4 == 0 && n >= 4096) {
@@ -256,12 +431,15 @@ namespace {
 // ----------------------------------------------------------------------------------------------
 struct Geo {
   int N, Hl, Wl, Hh, Wh, O, I;  // low-res dims (Hl,Wl), high-res dims (Hh=2Hl, Wh=2Wl)
-  int sWl, sHl, sI;             // log2 + 1 of Wl / Hl / I when they are powers of two (0: general division), see geo_pow2
+  int sWl, sHl, sI, sO;         // log2 + 1 of Wl / Hl / I / O when they are powers of two (0: general division), see geo_pow2
 };
 static int lg1(int v) { return v > 0 && (v & (v - 1)) == 0 ? rg_ilog2(v) + 1 : 0; }
-static Geo geo_pow2(Geo g) { g.sWl = lg1(g.Wl); g.sHl = lg1(g.Hl); g.sI = lg1(g.I); return g; }
+static Geo geo_pow2(Geo g) { g.sWl = lg1(g.Wl); g.sHl = lg1(g.Hl); g.sI = lg1(g.I); g.sO = lg1(g.O); return g; }
 // q = x / d, r = x % d for x >= 0; s = log2(d) + 1 when d is a power of two (shift / mask instead of a ~40-instruction
 // integer division: the functors below run once per fetched operand element)
+template <bool P2> __device__ __forceinline__ void rg_divmod_t(int x, int d, int s, int& q, int& r) {
+  if (P2) { q = x >> (s - 1); r = x & (d - 1); } else { q = x / d; r = x - q * d; }
+}
 __device__ __forceinline__ void rg_divmod(int x, int d, int s, int& q, int& r) {
   if (s) { q = x >> (s - 1); r = x & (d - 1); } else { q = x / d; r = x - q * d; }
 }
@@ -292,12 +470,23 @@ __device__ __forceinline__ void up_tap(int par, int a, int q, int& kidx, int& sr
   if (par == 0) { kidx = a == 0 ? 1 : 3; src = a == 0 ? q : q - 1; }
   else          { kidx = a == 0 ? 0 : 2; src = a == 0 ? q + 1 : q; }
 }
+// k index of the transposed conv's GEMM (K = 4 taps x O channels): tap-major, k = t4 * O + o, so that consecutive k are
+// consecutive channels of one source pixel (64 contiguous bytes per 16 k in fp32; the channel-major order k = o * 4 + t4 of
+// the first version made every group of 16 k touch four pixels).  RG_UP_KORDER_OLD restores the old order (A/B builds).
+__device__ __forceinline__ void up_k(int k, const Geo& g, int& o, int& t4) {
+#ifdef RG_UP_KORDER_OLD
+  o = k >> 2; t4 = k & 3;
+#else
+  rg_divmod(k, g.O, g.sO, t4, o);
+#endif
+}
 template <typename T> struct UpA {
   const T* x; Geo g;
   __device__ float operator()(int zb, int m, int k) const {
     int wq, t, hq, n;
     rg_divmod(m, g.Wl, g.sWl, t, wq); rg_divmod(t, g.Hl, g.sHl, n, hq);
-    int o = k >> 2, t4 = k & 3, kh, kw, ho, wo;
+    int o, t4, kh, kw, ho, wo;
+    up_k(k, g, o, t4);
     up_tap(zb >> 1, t4 >> 1, hq, kh, ho);
     up_tap(zb & 1, t4 & 1, wq, kw, wo);
     if (ho < 0 || ho >= g.Hl || wo < 0 || wo >= g.Wl) return 0.f;
@@ -307,7 +496,8 @@ template <typename T> struct UpA {
 template <typename T> struct UpB {
   const float* w; Geo g;
   __device__ float operator()(int zb, int k, int i) const {
-    int o = k >> 2, t4 = k & 3, kh, kw, d;
+    int o, t4, kh, kw, d;
+    up_k(k, g, o, t4);
     up_tap(zb >> 1, t4 >> 1, 0, kh, d);
     up_tap(zb & 1, t4 & 1, 0, kw, d);
     return Elem<T>::round(w[((size_t)o * 16 + kh * 4 + kw) * g.I + i]);      // tap-major master
@@ -317,7 +507,8 @@ template <typename T> struct UpB {
 struct UpBOihw {
   const float* w; Geo g;
   __device__ float operator()(int zb, int k, int i) const {
-    int o = k >> 2, t4 = k & 3, kh, kw, d;
+    int o, t4, kh, kw, d;
+    up_k(k, g, o, t4);
     up_tap(zb >> 1, t4 >> 1, 0, kh, d);
     up_tap(zb & 1, t4 & 1, 0, kw, d);
     return w[((size_t)o * g.I + i) * 16 + kh * 4 + kw];
@@ -448,6 +639,140 @@ struct LinC {
     if (scale) v *= scale[j];
     if (shift) v += shift[j];
     y[(size_t)m * ldy + j] = lrelu_f(v, slope);
+  }
+};
+
+// ---- two-phase forms (Op<>, see gemm_mfma32_kernel) of the gathered conv operands.  Element offsets are 32-bit (fits32: the
+// launcher keeps the vector kernel for a tensor of 2^31 elements or more) and, in the P2 instantiation, built with shifts:
+// Hh = 2 Hl and Wh = 2 Wl are powers of two with log2 = sHl, sWl (the "+ 1" of the encoding), log2(I) = sI - 1.
+template <typename T> struct Op<DownA<T>, true> {
+  struct R { int base, h0, w0; };
+  struct C { int off, dh, dw; };
+  static __device__ __forceinline__ bool pow2(const DownA<T>& f) { return f.g.sWl && f.g.sHl && f.g.sI; }
+  static bool fits32(const DownA<T>& f) { return (long long)f.g.N * f.g.Hh * f.g.Wh * f.g.I < (1ll << 31); }
+  template <bool P2> static __device__ __forceinline__ R row(const DownA<T>& f, int, int m) {
+    int wo, t, ho, n;
+    rg_divmod_t<P2>(m, f.g.Wl, f.g.sWl, t, wo); rg_divmod_t<P2>(t, f.g.Hl, f.g.sHl, n, ho);
+    const int h0 = 2 * ho - 1, w0 = 2 * wo - 1;
+    const int base = P2 ? ((((n << f.g.sHl) + h0) << f.g.sWl) + w0) << (f.g.sI - 1) : ((n * f.g.Hh + h0) * f.g.Wh + w0) * f.g.I;
+    return {base, h0, w0};
+  }
+  template <bool P2> static __device__ __forceinline__ C col(const DownA<T>& f, int, int k) {
+    int tap, ci;
+    rg_divmod_t<P2>(k, f.g.I, f.g.sI, tap, ci);
+    const int dh = tap >> 2, dw = tap & 3;
+    const int off = P2 ? ((((dh << f.g.sWl) + dw) << (f.g.sI - 1)) + ci) : (dh * f.g.Wh + dw) * f.g.I + ci;
+    return {off, dh, dw};
+  }
+  static __device__ __forceinline__ float at(const DownA<T>& f, int, const R& r, const C& c, bool& ok) {
+    const int hi = r.h0 + c.dh, wi = r.w0 + c.dw;
+    ok = (int)((unsigned)hi < (unsigned)f.g.Hh) & (int)((unsigned)wi < (unsigned)f.g.Wh);
+    return Elem<T>::ld(f.x + (ok ? r.base + c.off : 0));        // branch-free: a padding tap reads element 0
+  }
+};
+template <typename T> struct Op<UpA<T>, true> {
+  struct R { int base, hq, wq; };
+  struct C { int off, dh, dw; };
+  static __device__ __forceinline__ bool pow2(const UpA<T>& f) { return f.g.sWl && f.g.sHl && f.g.sO; }
+  static bool fits32(const UpA<T>& f) { return (long long)f.g.N * f.g.Hl * f.g.Wl * f.g.O < (1ll << 31); }
+  template <bool P2> static __device__ __forceinline__ R row(const UpA<T>& f, int, int m) {
+    int wq, t, hq, n;
+    rg_divmod_t<P2>(m, f.g.Wl, f.g.sWl, t, wq); rg_divmod_t<P2>(t, f.g.Hl, f.g.sHl, n, hq);
+    const int base = P2 ? ((((n << (f.g.sHl - 1)) + hq) << (f.g.sWl - 1)) + wq) << (f.g.sO - 1) : ((n * f.g.Hl + hq) * f.g.Wl + wq) * f.g.O;
+    return {base, hq, wq};
+  }
+  template <bool P2> static __device__ __forceinline__ C col(const UpA<T>& f, int zb, int k) {
+    int o, t4;
+#ifdef RG_UP_KORDER_OLD
+    o = k >> 2; t4 = k & 3;
+#else
+    rg_divmod_t<P2>(k, f.g.O, f.g.sO, t4, o);
+#endif
+    int kh, kw, sh, sw;
+    up_tap(zb >> 1, t4 >> 1, 0, kh, sh);          // source offset of the tap along each axis (q = 0: src = the offset)
+    up_tap(zb & 1, t4 & 1, 0, kw, sw);
+    const int off = P2 ? (((sh << (f.g.sWl - 1)) + sw) << (f.g.sO - 1)) + o : (sh * f.g.Wl + sw) * f.g.O + o;
+    return {off, sh, sw};
+  }
+  static __device__ __forceinline__ float at(const UpA<T>& f, int, const R& r, const C& c, bool& ok) {
+    const int ho = r.hq + c.dh, wo = r.wq + c.dw;
+    ok = (int)((unsigned)ho < (unsigned)f.g.Hl) & (int)((unsigned)wo < (unsigned)f.g.Wl);
+    return Elem<T>::ld(f.x + (ok ? r.base + c.off : 0));
+  }
+};
+template <typename T> struct Op<WgradB<T>, false> {       // B side: operator()(zb, pix = k, col = n)
+  struct R { int off, kh, kw; };                          // of the output column (tap, i)
+  struct C { int base, h0, w0; };                         // of the pixel
+  static __device__ __forceinline__ bool pow2(const WgradB<T>& f) { return f.g.sWl && f.g.sHl && f.g.sI; }
+  static bool fits32(const WgradB<T>& f) { return (long long)f.g.N * f.g.Hh * f.g.Wh * f.g.I < (1ll << 31); }
+  template <bool P2> static __device__ __forceinline__ R row(const WgradB<T>& f, int, int col) {
+    int tap, i;
+    rg_divmod_t<P2>(col, f.g.I, f.g.sI, tap, i);
+    const int kh = tap >> 2, kw = tap & 3;
+    const int off = P2 ? ((((kh << f.g.sWl) + kw) << (f.g.sI - 1)) + i) : (kh * f.g.Wh + kw) * f.g.I + i;
+    return {off, kh, kw};
+  }
+  template <bool P2> static __device__ __forceinline__ C col(const WgradB<T>& f, int, int pix) {
+    int wo, t, ho, n;
+    rg_divmod_t<P2>(pix, f.g.Wl, f.g.sWl, t, wo); rg_divmod_t<P2>(t, f.g.Hl, f.g.sHl, n, ho);
+    const int h0 = 2 * ho - 1, w0 = 2 * wo - 1;
+    const int base = P2 ? ((((n << f.g.sHl) + h0) << f.g.sWl) + w0) << (f.g.sI - 1) : ((n * f.g.Hh + h0) * f.g.Wh + w0) * f.g.I;
+    return {base, h0, w0};
+  }
+  static __device__ __forceinline__ float at(const WgradB<T>& f, int, const R& r, const C& c, bool& ok) {
+    const int hi = c.h0 + r.kh, wi = c.w0 + r.kw;
+    ok = (int)((unsigned)hi < (unsigned)f.g.Hh) & (int)((unsigned)wi < (unsigned)f.g.Wh);
+    return Elem<T>::ld(f.high + (ok ? c.base + r.off : 0));
+  }
+};
+// the weight operands: a row base per output column, a k offset per k position
+template <typename T> struct Op<DownB<T>, false> {        // operator()(zb, k, o) = w[o * 16 I + k]
+  struct R { int base; };
+  struct C { int k; };
+  static __device__ __forceinline__ bool pow2(const DownB<T>&) { return true; }
+  static bool fits32(const DownB<T>& f) { return (long long)f.g.O * f.g.I * 16 < (1ll << 31); }
+  template <bool P2> static __device__ __forceinline__ R row(const DownB<T>& f, int, int o) { return {o * f.g.I * 16}; }
+  template <bool P2> static __device__ __forceinline__ C col(const DownB<T>&, int, int k) { return {k}; }
+  static __device__ __forceinline__ float at(const DownB<T>& f, int, const R& r, const C& c, bool& ok) {
+    ok = true;
+    return Elem<T>::round(f.w[r.base + c.k]);
+  }
+};
+template <typename T> struct Op<UpB<T>, false> {          // operator()(zb, k, i) = w[(o * 16 + kh * 4 + kw) * I + i]
+  struct R { int i; };
+  struct C { int off; };
+  static __device__ __forceinline__ bool pow2(const UpB<T>& f) { return f.g.sO != 0; }
+  static bool fits32(const UpB<T>& f) { return (long long)f.g.O * f.g.I * 16 < (1ll << 31); }
+  template <bool P2> static __device__ __forceinline__ R row(const UpB<T>&, int, int i) { return {i}; }
+  template <bool P2> static __device__ __forceinline__ C col(const UpB<T>& f, int zb, int k) {
+    int o, t4, kh, kw, d;
+#ifdef RG_UP_KORDER_OLD
+    o = k >> 2; t4 = k & 3;
+#else
+    rg_divmod_t<P2>(k, f.g.O, f.g.sO, t4, o);
+#endif
+    up_tap(zb >> 1, t4 >> 1, 0, kh, d);
+    up_tap(zb & 1, t4 & 1, 0, kw, d);
+    return {(o * 16 + kh * 4 + kw) * f.g.I};
+  }
+  static __device__ __forceinline__ float at(const UpB<T>& f, int, const R& r, const C& c, bool& ok) {
+    ok = true;
+    return Elem<T>::round(f.w[c.off + r.i]);
+  }
+};
+// (low[pix][o]: one multiply per element; in the P2 form a shift)
+template <typename T> struct Op<WgradA<T>, true> {
+  struct R { int o; };
+  struct C { int poff; };
+  static __device__ __forceinline__ bool pow2(const WgradA<T>& f) { return f.g.sO != 0; }
+  static bool fits32(const WgradA<T>& f) { return (long long)f.g.N * f.g.Hl * f.g.Wl * f.g.O < (1ll << 31); }
+  template <bool P2> static __device__ __forceinline__ R row(const WgradA<T>&, int, int o) { return {o}; }
+  template <bool P2> static __device__ __forceinline__ C col(const WgradA<T>& f, int, int pix) {
+    return {P2 ? pix << (f.g.sO - 1) : pix * f.g.O};
+  }
+  static __device__ __forceinline__ float at(const WgradA<T>& f, int, const R& r, const C& c, bool& ok) {
+    ok = true;
+    return Elem<T>::ld(f.low + (c.poff + r.o));
   }
 };
 

@@ -203,16 +203,23 @@ def disc_forward(ops, D: DiscNet, x_nchw, update_running=True):
     return out, ctx
 
 
-def disc_backward(ops, D: DiscNet, ctx, coef: float, wgrad: bool, accumulate: bool,
-                  need_input_grad: bool, keep_for_gp: bool = False, input_post=None):
+def disc_backward(ops, D: DiscNet, ctx, coef: float, wgrad, accumulate: bool,
+                  need_input_grad: bool, keep_for_gp: bool = False, input_post=None, partner=None):
     """Backward of sum_n coef * D(x)_n (coef: a float, or an (N,) tensor of per-sample cotangents as torch autograd
     hands them over).  wgrad: also produce parameter gradients (written with ``accumulate`` semantics into the
     .dw/.dbias/.dgamma/.dbeta buffers).  Returns d/dx (NCHW fp32) if requested.  keep_for_gp stores the per-layer
     first-backward gradients on ctx.  input_post (with need_input_grad): {"tanh_img": img or None} -- the first consumer's
     pass over d/dx fused into the kernel that writes it (ops.last_up_post): d/dx multiplied by 1 - img^2 (the cotangent of
     the generator's Tanh) and / or per-workgroup partial sums (channel sums, sum of squares) left in ctx.gx_parts; when the
-    backend has no such kernel for the shape, ctx.gx_parts stays None and d/dx is returned unmodified."""
+    backend has no such kernel for the shape, ctx.gx_parts stays None and d/dx is returned unmodified.
+    wgrad == "defer": the small parameter gradients (head, BatchNorm, layer-0 bias) are produced now, the conv weight
+    gradients are NOT -- their operands gz stay on ctx.gz_keep for a later call with partner=ctx, whose per-layer weight
+    gradient is then ONE two-segment launch over both chains (written, whatever ``accumulate`` says for the rest): the
+    data-parallel D-loss step's prefix / rest pair (disc_loss_prefix_dgrad / disc_loss_rest_pairw)."""
     R = len(D.blocks)
+    defer_w = isinstance(wgrad, str) and wgrad == "defer"
+    if defer_w:
+        ctx.gz_keep = [None] * (R + 1)
     ctx.gx_parts = None
     if torch.is_tensor(coef):       # N-length vector: host-side plumbing
         gh = (coef.reshape(-1).float() * torch.where(ctx.h > 0, torch.ones_like(ctx.h),
@@ -236,7 +243,12 @@ def disc_backward(ops, D: DiscNet, ctx, coef: float, wgrad: bool, accumulate: bo
                                           bn.dbeta if wgrad else None, accumulate, keep_ga=keep_for_gp)
         if keep_for_gp:
             ctx.ga1[l], ctx.gz1[l], ctx.s_gy[l], ctx.s_gyxh[l] = ga, gz, s_gy, s_gyxh
-        if wgrad:
+        if defer_w:
+            ctx.gz_keep[l] = gz
+        elif wgrad and partner is not None:
+            with ops.side(gz, partner.gz_keep[l]):
+                ops.conv_wgrad2(gz, ctx.a[l - 1], partner.gz_keep[l], partner.a[l - 1], cw, False)
+        elif wgrad:
             with ops.side(gz):
                 ops.conv_wgrad(gz, ctx.a[l - 1], cw, accumulate)
         # the data gradient of layer 1 feeds layer 0's LeakyReLU: its backward is fused into the epilogue
@@ -246,7 +258,15 @@ def disc_backward(ops, D: DiscNet, ctx, coef: float, wgrad: bool, accumulate: bo
     gz0 = ga if R > 0 else ops.lrelu_bwd(ga, ctx.a[0], D.slope)
     if keep_for_gp:
         ctx.gz1[0] = gz0
-    if wgrad:
+    if defer_w:
+        ctx.gz_keep[0] = gz0
+        ops.col_sum(gz0, D.conv0.dbias, accumulate)
+    elif wgrad and partner is not None:
+        with ops.side(gz0, partner.gz_keep[0]):
+            ops.skinny_wgrad(gz0, ctx.x, D.conv0.dw, False)
+            ops.skinny_wgrad(partner.gz_keep[0], partner.x, D.conv0.dw, True)
+        ops.col_sum(gz0, D.conv0.dbias, accumulate)
+    elif wgrad:
         with ops.side(gz0):
             ops.skinny_wgrad(gz0, ctx.x, D.conv0.dw, accumulate)
         ops.col_sum(gz0, D.conv0.dbias, accumulate)
@@ -580,6 +600,27 @@ def disc_loss_rest_acc(ops, G, D: DiscNet, out_r, noise, grad_scale: float = 1.0
     out_f, ctx_f = disc_forward(ops, D, img)
     loss = ops.mean_diff(out_f, out_r, 1.0)
     disc_backward(ops, D, ctx_f, grad_scale / n, wgrad=True, accumulate=True, need_input_grad=False)
+    return loss
+
+
+def disc_loss_prefix_dgrad(ops, D: DiscNet, real, grad_scale: float = 1.0):
+    """Data-parallel prefix, third form (RNAGAN_DP_PREFIX_BWD=2): D(real) forward and its DATA-gradient chain (BatchNorm
+    backward, transposed convs, the small parameter gradients); the conv weight gradients wait for the fake half so that each
+    layer's is one two-segment launch with one split-K reduction (disc_loss_rest_pairw) -- the prefix is shorter by those
+    launches (less cover for the generator's all-reduce), the train_op loses five weight-gradient launches and reductions."""
+    out_r, ctx_r = disc_forward(ops, D, real)
+    n = out_r.shape[0]
+    disc_backward(ops, D, ctx_r, -grad_scale / n, wgrad="defer", accumulate=False, need_input_grad=False)
+    return out_r, ctx_r
+
+
+def disc_loss_rest_pairw(ops, G, D: DiscNet, pre, noise, grad_scale: float = 1.0):
+    out_r, ctx_r = pre
+    n = out_r.shape[0]
+    img, _ = _gen_fwd(ops, G, noise, keep=False)
+    out_f, ctx_f = disc_forward(ops, D, img)
+    loss = ops.mean_diff(out_f, out_r, 1.0)
+    disc_backward(ops, D, ctx_f, grad_scale / n, wgrad=True, accumulate=True, need_input_grad=False, partner=ctx_r)
     return loss
 
 

@@ -180,7 +180,12 @@ def _g_rest(generator, discriminator, pre):
 # data-parallel D-loss step: D(real)'s backward belongs to the prefix too (it reads the discriminator only), so the generator's
 # gradient all-reduce -- started by the G-loss step just before -- is covered by a forward and a backward pass
 # (RNAGAN_DP_PREFIX_BWD=0: forward only, as in round 2)
-DP_PREFIX_BWD = os.environ.get("RNAGAN_DP_PREFIX_BWD", "1") != "0"
+# RNAGAN_DP_PREFIX_BWD=2 (default since round 4): forward + data-gradient chain in the prefix, the conv weight gradients of
+# both halves as two-segment launches in the rest -- engine.disc_loss_prefix_dgrad.  One rank, same box, interleaved: 12.07 ms
+# against 12.21 ms for mode 1 (single-process path 11.24-11.39); the prefix shrinks from ~1.3 to ~0.9 ms, still longer than the
+# generator's 90 MB collective at any plausible bus bandwidth.  1: the whole backward of the real half in the prefix (round 3).
+DP_PREFIX_MODE = int(os.environ.get("RNAGAN_DP_PREFIX_BWD", "2"))
+DP_PREFIX_BWD = DP_PREFIX_MODE != 0
 
 
 def _d_prefix(generator, discriminator, real, noise, clip):
@@ -188,6 +193,9 @@ def _d_prefix(generator, discriminator, real, noise, clip):
     if clip is not None:
         ops.clamp_(discriminator.flat.data, clip[0], clip[1])      # every D parameter (wgan_loss.py:213-215)
         discriminator.weights_changed()
+    if DP_PREFIX_MODE == 2 and D_.active():
+        return ("dgrad", E.disc_loss_prefix_dgrad(ops, dn, real.contiguous().float(), grad_scale=D_.grad_scale())), \
+            noise.contiguous().float()
     if DP_PREFIX_BWD and D_.active():
         return ("bwd", E.disc_loss_prefix_bwd(ops, dn, real.contiguous().float(), grad_scale=D_.grad_scale())), \
             noise.contiguous().float()
@@ -264,6 +272,8 @@ def _d_rest(generator, discriminator, pre):
     fwd_real, noise = pre
     if isinstance(fwd_real, tuple) and fwd_real[0] == "bwd":       # the real half's backward ran in the prefix
         return E.disc_loss_rest_acc(ops, gn, dn, fwd_real[1], noise, grad_scale=D_.grad_scale())
+    if isinstance(fwd_real, tuple) and fwd_real[0] == "dgrad":     # ... its data-gradient chain did; weight gradients pair up here
+        return E.disc_loss_rest_pairw(ops, gn, dn, fwd_real[1], noise, grad_scale=D_.grad_scale())
     return E.disc_loss_rest(ops, gn, dn, fwd_real, noise, grad_scale=D_.grad_scale())
 
 

@@ -225,3 +225,24 @@ def test_world2_factors_with_an_optimizer_that_does_not_step_from_the_wire(tmp_p
             if v.dtype.is_floating_point and "running_" not in k:
                 rel = float((v.double() - ref[0]["G"][k].double()).norm() / (ref[0]["G"][k].double().norm() + 1e-30))
                 assert rel <= 2e-3, (k, rel)
+
+
+def test_world2_prefix_with_paired_weight_gradients(tmp_path):
+    """RNAGAN_DP_PREFIX_BWD=2 (the default): the D-loss prefix runs D(real)'s forward and data-gradient chain only; each layer's
+    conv weight gradient is one two-segment launch over the real and the fake half in the rest (engine.disc_loss_prefix_dgrad /
+    disc_loss_rest_pairw).  Same mathematics as mode 1 (real half's weight gradients written in the prefix, fake half's
+    accumulated): fp32 kernels, fp32 wire -- rank-identical parameters, losses equal to the other route's to rounding."""
+    ref = _run_world2(tmp_path, "fp32", extra_env={"RNAGAN_DP_PREFIX_BWD": "1"}, tag="_mode1")
+    got = _run_world2(tmp_path, "fp32", extra_env={"RNAGAN_DP_PREFIX_BWD": "2"}, tag="_pairw")
+    for name in ("G", "D"):
+        for k in got[0][name]:
+            if "running_" not in k:
+                assert torch.equal(got[0][name][k], got[1][name][k]), ("ranks differ", name, k)
+    for r in range(2):
+        for i, (a, b) in enumerate(zip(got[r]["losses"], ref[r]["losses"])):
+            assert np.isfinite(a) and abs(a - b) <= 2e-3 * (abs(b) + 0.5), (r, i, a, b)
+    for name in ("G", "D"):
+        for k, v in got[0][name].items():
+            if v.dtype.is_floating_point and "running_" not in k:
+                rel = float((v.double() - ref[0][name][k].double()).norm() / (ref[0][name][k].double().norm() + 1e-30))
+                assert rel <= 2e-3, (name, k, rel)

@@ -565,3 +565,52 @@ def test_generator_layer0_gradient_inside_the_adam_step(in_size, enc, n):
     for k in sda:                                             # everything else of the generator went through the usual kernels
         if k != "model.0.0.weight" and sda[k].dtype.is_floating_point:
             assert float((sda[k] - sdb[k]).abs().max()) <= 5e-3 * float(sdb[k].abs().max() + 1e-6) + 2e-4, k
+
+
+def test_unselected_inputs_loss_agreement_statistics():
+    """smoke() and two tests in tests/test_engine_gpu.py CHOOSE their inputs (on the CPU oracle) for a
+    clear LeakyReLU margin at the critic head, so the suite never said how often arbitrary inputs fall outside the stated
+    tolerance.  This test takes 24 CONSECUTIVE seeds with no selection -- weights, tiles and draws all change with the seed --
+    runs one iteration (G-loss, D-loss, penalty train_ops) on the HIP path in both precisions and on the CPU oracle, and
+    reports the distribution of |hip - oracle| / (|oracle| + 0.1) per loss.  Asserted: fp32 kernels within 2e-3 on every seed
+    (the reference's arithmetic: no tolerance for a flipped slope is needed at these sizes); bf16 kernels: median <= 2e-2 and at
+    least 75 % of the 72 loss values within the stated 6e-2 -- the rest are the ill-conditioned inputs DESIGN 12.9 describes
+    (a head pre-activation within bf16 noise of the kink), printed so that their frequency is on record."""
+    in_size, step, enc, n = 32, 64, 128, 8
+    seeds = list(range(101, 125))
+    errs = {"fp32": [], "bf16": []}
+    for seed in seeds:
+        G0 = R.seeded_fill_(R.OracleDCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                                   last_nonlinearity=nn.Tanh()), seed)
+        D0 = R.seeded_fill_(R.OracleDCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                                       last_nonlinearity=nn.LeakyReLU(0.2)), seed + 1000)
+        Go, Do = copy.deepcopy(G0).train(), copy.deepcopy(D0).train()
+        ogo, odo = R.make_adam(Go.parameters(), 1e-4), R.make_adam(Do.parameters(), 4e-4)
+        real = R.synthetic_images(n, in_size, seed=seed)
+        noises = [R.synthetic_normal(n, enc, seed=100 * seed + 2 + j) for j in range(3)]
+        ref = R.train_iteration(Go, Do, ogo, odo, real, noises, 0.4)
+        for precision in ("fp32", "bf16"):
+            G = P.DCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+            D = P.DCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.LeakyReLU(0.2))
+            G.load_state_dict(G0.state_dict()); D.load_state_dict(D0.state_dict())
+            G.set_precision(precision); D.set_precision(precision)
+            G, D = G.cuda().train(), D.cuda().train()
+            og = P.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.999)).bind(G)
+            od = P.Adam(D.parameters(), lr=4e-4, betas=(0.5, 0.999)).bind(D)
+            rd = real.cuda()
+            got = {"g": PL._g_step(G, D, og, noises[0].cuda()).item(),
+                   "d": PL._d_step(G, D, od, rd, noises[1].cuda(), None).item(),
+                   "gp": PL._gp_step(G, D, od, rd, noises[2].cuda(), 0.4, 10.0).item()}
+            errs[precision].append([abs(got[k] - ref[k]) / (abs(ref[k]) + 0.1) for k in ("g", "d", "gp")])
+    for precision in ("fp32", "bf16"):
+        e = np.asarray(errs[precision])
+        flat = np.sort(e.reshape(-1))
+        print("%s: %d seeds x 3 losses: median %.2e, 90th percentile %.2e, max %.2e; per loss max (g, d, gp) %s; "
+              "values beyond 6e-2: %d of %d (seeds %s)" % (
+                  precision, len(seeds), np.median(flat), flat[int(0.9 * len(flat))], flat[-1], np.round(e.max(0), 4).tolist(),
+                  int((flat > 6e-2).sum()), flat.size, [seeds[i] for i in np.where((e > 6e-2).any(1))[0]]))
+    f32, b16 = np.asarray(errs["fp32"]), np.asarray(errs["bf16"])
+    assert np.isfinite(f32).all() and np.isfinite(b16).all()
+    assert float(f32.max()) <= 2e-3, f32.max()
+    assert float(np.median(b16)) <= 2e-2, np.median(b16)
+    assert float((b16 <= 6e-2).mean()) >= 0.75, (b16 <= 6e-2).mean()
