@@ -8,6 +8,7 @@
 #include "rg_common.h"
 #include "rg_internal.h"
 #include <type_traits>
+#include <algorithm>
 
 namespace {
 
@@ -828,15 +829,26 @@ int rg_generic_last_up(const void* x, const float* w, const float* bias, float* 
   })
 }
 
-static int generic_wgrad_split(int N, int Ho, int Wo, int O, int I) {
-  // (tile counts of the vector kernel's 64 x 64 tiles also where the 128 x 128 matrix-core kernel runs: four times the
-  // splits per tile there, i.e. the same number of workgroups' worth of work items and >= 64 k-steps per split)
+// f32 = the launch will take the matrix-core kernel (fp32 storage, f32mma on, >= 64 x 33 outputs): enough splits for three
+// 128 x 128 tiles per CU (three workgroups fit a CU) with at least 32 k-tiles each -- the 64 x 64 tile that a short grid would
+// fall back to has half the FLOP per LDS byte and per barrier (PMC: MFMA-busy 0.41 against 0.52-0.57 on the weight gradients).
+static int generic_wgrad_split(int N, int Ho, int Wo, int O, int I, bool f32) {
+  const int K = N * Ho * Wo;
+  if (f32 && use_mfma32(true, O, I * 16)) {
+    const int tiles = ((O + MB_M - 1) / MB_M) * ((I * 16 + MB_N - 1) / MB_N);
+    int want = (768 + tiles - 1) / tiles, maxs = K / (MB_K * 32);
+    if (maxs < 1) maxs = 1;
+    int s = want < maxs ? want : maxs;
+    if (s > 256) s = 256;
+    return s < 1 ? 1 : s;
+  }
   int tiles = ((O + GB_M - 1) / GB_M) * ((I * 16 + GB_N - 1) / GB_N);
-  return pick_split(tiles, N * Ho * Wo);
+  return pick_split(tiles, K);
 }
 
 size_t rg_generic_wgrad_ws_bytes(int N, int Ho, int Wo, int O, int I) {
-  int s = generic_wgrad_split(N, Ho, Wo, O, I);
+  // (the dtype is not known here: room for the larger of the two split plans)
+  int s = std::max(generic_wgrad_split(N, Ho, Wo, O, I, false), generic_wgrad_split(N, Ho, Wo, O, I, true));
   return s > 1 ? (size_t)s * O * I * 16 * sizeof(float) : 0;
 }
 
@@ -844,7 +856,7 @@ template <class FB>
 static int generic_wgrad_impl(const char* name, const void* low, FB fb, float* dw, Geo g, int dtype, int accumulate,
                               void* ws, size_t ws_bytes, hipStream_t st) {
   int K = g.N * g.Hl * g.Wl;
-  int s = generic_wgrad_split(g.N, g.Hl, g.Wl, g.O, g.I);
+  int s = generic_wgrad_split(g.N, g.Hl, g.Wl, g.O, g.I, dtype == RG_F32);
   size_t elems = (size_t)g.O * g.I * 16;
   if (s > 1) {
     RG_REQUIRE(ws && ws_bytes >= (size_t)s * elems * sizeof(float), RG_EWORKSPACE, "%s: workspace too small", name);
