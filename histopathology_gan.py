@@ -71,6 +71,23 @@ EXTRA_FLAGS = [
 ]
 
 
+def make_collate_fn(with_rna: bool, world: int):
+    """The reference's collate_fn (src/histopathology_gan.py:24-34): drop records whose tile could not be read.  Data
+    parallel (world > 1): every rank must see the SAME batch size -- the gathered G.0 gradient factors and the captured step
+    graphs are sized by it, and each train_op issues a collective -- so the dropped records are replaced by repeating this
+    batch's readable ones instead of shrinking the batch."""
+    def collate_fn(batch):
+        img = (lambda b: b["image"]) if with_rna else (lambda b: b[0])
+        want = len(batch)
+        batch = [b for b in batch if img(b) is not None]
+        if world > 1 and len(batch) < want:
+            if not batch:
+                raise RuntimeError("data parallel: a batch with no readable tile record cannot be equalised across ranks")
+            batch = (batch * ((want + len(batch) - 1) // len(batch)))[:want]
+        return torch.utils.data.dataloader.default_collate(batch)
+    return collate_fn
+
+
 def shard_indices(n_items: int, rank: int, world: int, batch_size: int):
     """Indices of rank ``rank``'s shard of a list of n_items: strided (rank, rank + world, ...), truncated so that EVERY rank
     gets the same number of items and that number is a multiple of the batch size (equal batch counts on all ranks)."""
@@ -128,19 +145,7 @@ def main():
             ds = PD.PatchDataset(patch_data_path, train_df, img_size, max_patches_total=args.num_patches, transforms=tf)
 
         world = D_.world_size()
-
-        def collate_fn(batch):                       # src/histopathology_gan.py:24-34: drop unreadable records
-            img = (lambda b: b["image"]) if with_rna else (lambda b: b[0])
-            want = len(batch)
-            batch = [b for b in batch if img(b) is not None]
-            if world > 1 and len(batch) < want:
-                # data parallel: every rank must see the SAME batch size (the gathered G.0 gradient factors and the captured
-                # step graphs are sized by it, and each train_op issues a collective) -- the dropped records are replaced by
-                # repeating this batch's readable ones instead of shrinking the batch
-                if not batch:
-                    raise RuntimeError("data parallel: a batch with no readable tile record cannot be equalised across ranks")
-                batch = (batch * ((want + len(batch) - 1) // len(batch)))[:want]
-            return torch.utils.data.dataloader.default_collate(batch)
+        collate_fn = make_collate_fn(with_rna, world)
         if world > 1:
             # one shard of the (identical) tile list per rank, the SAME number of full batches on every rank: each train_op
             # issues a gradient all-reduce, so a rank with one batch more would pair its collectives with nobody

@@ -183,3 +183,32 @@ def test_rank_shards_have_equal_batch_counts():
                 flat = [i for s in shards for i in s]
                 assert len(set(flat)) == len(flat) and all(0 <= i < n_items for i in flat)
                 assert len(flat) >= n_items - world * bs - world + 1 or n_items < world * bs
+
+
+def test_collate_keeps_the_batch_size_under_data_parallel():
+    """the reference's collate_fn drops unreadable records (src/histopathology_gan.py:24-34).  One process: the
+    batch shrinks, as in the reference.  Data parallel: every rank must see the same batch size (gathered G.0 factors, captured
+    step graphs and the per-train_op collectives are sized by it), so the dropped records are replaced by repeating the
+    readable ones; a batch with nothing readable is an error there."""
+    import importlib.util
+    import pytest
+    import torch
+    spec = importlib.util.spec_from_file_location("cli_hgan2", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "histopathology_gan.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    good = lambda v: {"image": torch.full((3, 4, 4), float(v)), "rna_data": torch.full((5,), float(v)), "labels": torch.tensor(0.0)}
+    bad = {"image": None, "rna_data": torch.zeros(5), "labels": torch.tensor(0.0)}
+    batch = [good(1), bad, good(2), bad, bad, good(3), good(4), bad]
+    one = cli.make_collate_fn(True, 1)(list(batch))
+    assert one["image"].shape[0] == 4 and one["rna_data"].shape == (4, 5)
+    dp = cli.make_collate_fn(True, 8)(list(batch))
+    assert dp["image"].shape[0] == 8 and dp["rna_data"].shape == (8, 5)
+    assert sorted(dp["image"][:, 0, 0, 0].tolist()) == [1.0, 1.0, 2.0, 2.0, 3.0, 3.0, 4.0, 4.0]     # readable records, repeated
+    assert torch.equal(dp["image"][:, 0, 0, 0], dp["rna_data"][:, 0])                               # rows stay paired
+    with pytest.raises(RuntimeError, match="no readable"):
+        cli.make_collate_fn(True, 2)([bad, bad])
+    # tuple batches (the stock-loss datasets): (image, label)
+    tup = [(torch.ones(3, 2, 2), torch.tensor(0.0)), (None, torch.tensor(0.0))]
+    assert cli.make_collate_fn(False, 1)(list(tup))[0].shape[0] == 1
+    assert cli.make_collate_fn(False, 2)(list(tup))[0].shape[0] == 2
