@@ -130,6 +130,11 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
         mask = 1u;
       }
       a_off[h * NA + j] = (int)((base + lc * (16 / EB)) * EB);
+#ifdef C8_FOLD_PROBE
+      // measurement probe (build-time, never shipped; results are wrong): every A row inside one 2 MB window = the gather is
+      // served from L2 whatever the tile's input footprint -- what the launch would cost without the re-fetches
+      a_off[h * NA + j] &= 0x1FFFFF;
+#endif
       a_mask[j] |= (ok ? mask : 0u) << (16 * h);
     }
 #pragma unroll
@@ -496,6 +501,10 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
       } else {
         orow = m;
       }
+#ifdef C8_NOEPI_PROBE
+      if (a2.korder == 12345) continue;      // (never true: keeps the loads / conversions; the probe variant below skips the stores)
+      if (a2.nsplit >= 1) continue;          // measurement probe (build-time, never shipped): no global stores in the epilogue
+#endif
       if (a2.nsplit > 1) {
         float* so = a2.slab + (long long)zs * a2.slab_stride + orow * g.ldc + col;
         *reinterpret_cast<float4*>(so) = v0;
