@@ -162,6 +162,53 @@ def test_full_size_one_iteration_bf16():
     assert img.shape == (n, 3, 256, 256) and torch.isfinite(img).all() and float(img.abs().max()) <= 1.0
 
 
+def test_full_size_one_iteration_fp32():
+    """The reference's own configuration -- model size of src/histopathology_gan.py:178-192, its hard-coded batch 8 (:94), fp32
+    arithmetic (src/betaVAE.py:184,223,230-236) -- on the fp32 mode, whose convolutions run on the f32 matrix cores
+    (gemm_mfma32_kernel: 128 x 128 and 64 x 64 tiles, split-K weight gradients, every layer shape of the model): one iteration
+    against the fp32 CPU oracle.  Losses within 3e-3 (|want| + 0.1) (measured 2e-5 / 7e-4 / 8e-4); direction of the Adam update of
+    every parameter tensor (cosine >= 0.95 for tensors of >= 4096 elements, measured >= 0.974: the first Adam steps are lr *
+    sign(g), so the cosine counts sign agreements -- two fp32 evaluations with different summation orders disagree on the
+    elements whose gradient is within rounding noise of zero, and the discriminator takes two such steps)."""
+    in_size, step, enc, n = 256, 64, 2048, 8
+    G0 = R.seeded_fill_(R.OracleDCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                               last_nonlinearity=nn.Tanh()), 17)
+    D0 = R.seeded_fill_(R.OracleDCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                                   last_nonlinearity=nn.LeakyReLU(0.2)), 18)
+    Go, Do = copy.deepcopy(G0).train(), copy.deepcopy(D0).train()
+    ogo, odo = R.make_adam(Go.parameters(), 1e-4), R.make_adam(Do.parameters(), 4e-4)
+    G, D, og, od = product_pair(in_size, step, enc, "fp32", G0, D0)
+    real = R.synthetic_images(n, in_size, seed=300)
+    noises = [R.synthetic_normal(n, enc, seed=400 + j) for j in range(3)]
+    ref = R.train_iteration(Go, Do, ogo, odo, real, noises, 0.4)
+    rd = real.cuda()
+    lg = PL._g_step(G, D, og, noises[0].cuda()).item()
+    ld = PL._d_step(G, D, od, rd, noises[1].cuda(), None).item()
+    lp = PL._gp_step(G, D, od, rd, noises[2].cuda(), 0.4, 10.0).item()
+    print("full-size fp32 losses hip/ref:", lg, ref["g"], ld, ref["d"], lp, ref["gp"])
+    for got, want in ((lg, ref["g"]), (ld, ref["d"]), (lp, ref["gp"])):
+        assert np.isfinite(got) and abs(got - want) <= 3e-3 * (abs(want) + 0.1), (got, want)
+    worst = (1.0, None)
+    for tag, mod, mod0, modo in (("G", G, G0, Go), ("D", D, D0, Do)):
+        sd, sdo, sd0 = mod.state_dict(), modo.state_dict(), mod0.state_dict()
+        for name, _ in mod0.named_parameters():
+            w0 = sd0[name].double()
+            du_hip, du_ref = sd[name].cpu().double() - w0, sdo[name].double() - w0
+            cos = float((du_hip * du_ref).sum() / (du_hip.norm() * du_ref.norm() + 1e-30))
+            worst = min(worst, (cos, tag + "." + name))
+            assert cos >= (0.95 if w0.numel() >= 4096 else 0.85), (tag, name, cos)
+    print("worst update cosine (fp32 mode):", worst)
+    for mod, ref_mod in ((G, Go), (D, Do)):
+        for (k, b), (_, q) in zip(mod.named_buffers(), ref_mod.named_buffers()):
+            if not k.endswith("num_batches_tracked"):
+                # (the penalty step's forward runs behind the discriminator's first Adam step, whose sign-like update differs
+                # in the elements counted above: 7e-4 measured on the first block's running mean, 2.6e-3 on the fourth's, whose
+                # means are near zero)
+                assert l2rel(b.cpu().numpy(), q.numpy()) <= 1e-2, k
+            else:
+                assert int(b) == int(q), k
+
+
 def test_full_size_batch64_bf16():
     """BASELINE configs[1] shape exactly (batch 64 at the reference model size): this is where the MFMA launchers pick
     their large-batch variants (256x256 tiles, class-fastest block order, 512-block wgrad grids, row-staged image-side
