@@ -234,7 +234,9 @@ __global__ __launch_bounds__(256) void gemm_mfma32_kernel(FA fa, FB fb, SC sc, i
   int cur = 0;
   for (int k0 = k_begin; k0 < k_end; k0 += MB_K) {
     const bool more = k0 + MB_K < k_end;
+#ifndef RG_F32_NOLOAD     // (measurement probe, never shipped: -DRG_F32_NOLOAD keeps the first k-tile's operands for the whole loop)
     if (more) fetch(k0 + MB_K);                    // global loads of the next k-tile fly under this tile's MFMAs
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #ifdef RG_F32_NOPIPE
 #pragma unroll
@@ -268,7 +270,11 @@ __global__ __launch_bounds__(256) void gemm_mfma32_kernel(FA fa, FB fb, SC sc, i
       for (int i = 0; i < IA; ++i)
 #pragma unroll
         for (int j = 0; j < IB; ++j)
+#ifdef RG_F32_NOMFMA       // measurement probe (never shipped): operands are read, no matrix instruction is issued
+          asm volatile("" ::"v"(a[st & 1][i]), "v"(b[st & 1][j]));
+#else
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][i], b[st & 1][j], acc[i][j], 0, 0, 0);
+#endif
     }
 #endif
     __builtin_amdgcn_sched_barrier(0);             // the loads stay above the MFMAs, their first use (the stash) below
