@@ -53,7 +53,8 @@ int rg_version(void);
 const char* rg_last_error(void);
 /* Kernel-selection knobs for A/B measurements inside one process (tools/, tests/): name = the part of the matching
  * environment variable after "RNAGAN_", lower case ("conv8", "conv8_blocks", "conv_tile", "xcd", "class_fast",
- * "wgrad_blocks", "wgrad8", ...).  An option set here overrides the environment; value < 0 clears the override.  Returns RG_EINVAL for an
+ * "wgrad_blocks", "wgrad8", ..., "f32mma": 0 sends the RG_F32 conv / dense launches back to the vector-ALU GEMM instead of the
+ * f32 matrix-core one).  An option set here overrides the environment; value < 0 clears the override.  Returns RG_EINVAL for an
  * unknown name.  Not thread-safe against concurrent launches. */
 int rg_set_option(const char* name, int value);
 
