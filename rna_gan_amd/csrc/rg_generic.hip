@@ -365,6 +365,11 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma32_kernel(FA fa, FB fb, SC sc
 // kernel bit for bit -- keeps gemm_generic_kernel.
 static bool use_mfma32(bool f32, int M, int N) { return f32 && M >= 64 && N >= 33 && rg_option("f32mma", 1) != 0; }
 
+// (defined with gemm_mfma32s_kernel below: launches it and returns true when both operands have a structured form)
+template <bool AK, bool BK, class FA, class FB, class SC>
+static bool launch_structured(const char* name, FA fa, FB fb, SC sc, int M, int N, int K, int nsplit, int klen, dim3 grid,
+                              bool small, hipStream_t st);
+
 template <bool AK, bool BK, class FA, class FB, class SC>
 int launch_generic(const char* name, FA fa, FB fb, SC sc, int M, int N, int K, int nbatch, int nsplit,
                    hipStream_t st, bool f32 = false) {
@@ -378,11 +383,13 @@ int launch_generic(const char* name, FA fa, FB fb, SC sc, int M, int N, int K, i
       // output no wider / taller than 64 (the 64-channel layers, batch-64 dense layers): 64 x 64 tiles, 4 x the blocks
       grid = dim3((M + 63) / 64, (N + 63) / 64, nbatch * nsplit);
       RG_REQUIRE(grid.y <= 65535, RG_EINVAL, "%s: grid too large", name);
-      hipLaunchKernelGGL((gemm_mfma32_kernel<32, 32, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, nsplit, klen);
+      if (!launch_structured<AK, BK>(name, fa, fb, sc, M, N, K, nsplit, klen, grid, true, st))
+        hipLaunchKernelGGL((gemm_mfma32_kernel<32, 32, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, nsplit, klen);
     } else {
       // (measured and rejected: a 128 x 256 block tile -- wave tile 64 x 128, 8 accumulator tiles, one or two workgroups per CU by
       // registers -- 97.9 against 95.6 ms per iteration, two interleaved rounds)
-      hipLaunchKernelGGL((gemm_mfma32_kernel<64, 64, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, nsplit, klen);
+      if (!launch_structured<AK, BK>(name, fa, fb, sc, M, N, K, nsplit, klen, grid, false, st))
+        hipLaunchKernelGGL((gemm_mfma32_kernel<64, 64, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, nsplit, klen);
     }
     RG_LAUNCH_CHECK(name);
     return RG_OK;
@@ -919,6 +926,287 @@ template <typename T> struct Op<WgradA<T>, true> {
     return Elem<T>::ld(f.low + (c.poff + r.o));
   }
 };
+
+// ----------------------------------------------------------------------------------------------
+// gemm_mfma32s_kernel: the matrix-core GEMM above for launches whose BOTH operands are STRUCTURED (power-of-two geometry):
+// the operand's K axis is a sequence of segments (a tap's channels, a weight row, a row of output pixels) inside which the
+// 16 k of a k-tile are consecutive elements at a uniform distance.  A thread keeps, per fetch slot,
+//     base (bytes, everything that depends on the slot's row and k position) and m (its "invalid" bits),
+// the k-loop derives per k-tile -- on the SCALAR unit --
+//     id (segment), so (byte offset inside the segment: the load's scalar offset), add (bytes), f (which invalid bits count),
+// and a slot's load offset is  (base + add) | (min(m & f, 1) << 31):  bit 31 = beyond the buffer's 2 GB range, the load
+// returns 0 -- that is the zero padding of the convolution, the rows beyond M / N and the k tail, with no predicate, no
+// select and no branch around any load; the offsets are rebuilt only when id changes (4 vector instructions per slot).
+// The two-phase kernel above spent ~570 non-matrix instructions per k-tile of 32 MFMAs on the same launches (per-slot
+// exec-mask branches the compiler built from its selects); this one ~130.  It remains the kernel for every other launch.
+// ----------------------------------------------------------------------------------------------
+struct SSlot { int base; unsigned m; };
+struct SSeg { int id; unsigned so; int add; unsigned f; };
+template <class F> struct SOp { static constexpr bool OK = false; };
+
+template <> struct SOp<DownA<float>> {                    // A(m = (n, ho, wo), k = tap * I + c) = x[n][2ho-1+kh][2wo-1+kw][c]
+  using F = DownA<float>;
+  static constexpr bool OK = true;
+  static bool ok(const F& f, int) { return f.g.sWl && f.g.sHl && f.g.sI && f.g.I >= MB_K && (long long)f.g.N * f.g.Hh * f.g.Wh * f.g.I < (1ll << 29); }
+  static __device__ __forceinline__ const void* ptr(const F& f) { return f.x; }
+  static __device__ __forceinline__ SSlot slot(const F& f, int, int m, bool ok, int ks) {
+    const int wo = m & (f.g.Wl - 1), t = m >> (f.g.sWl - 1), ho = t & (f.g.Hl - 1), n = t >> (f.g.sHl - 1);
+    const int base = (((n * f.g.Hh + 2 * ho - 1) * f.g.Wh + 2 * wo - 1) * f.g.I + ks) * 4;
+    // invalid bits: kh in bits 0-3 (row 2ho-1+kh outside the image), kw in bits 4-7
+    const unsigned im = (ho == 0 ? 1u : 0u) | (ho == f.g.Hl - 1 ? 8u : 0u) | (wo == 0 ? 0x10u : 0u) | (wo == f.g.Wl - 1 ? 0x80u : 0u);
+    return {base, ok ? im : 0xffu};
+  }
+  static __device__ __forceinline__ void seg(const F& f, int, int k0, SSeg& u) {
+    const int tap = k0 >> (f.g.sI - 1), dh = tap >> 2, dw = tap & 3;
+    u.id = tap;
+    u.so = (unsigned)(k0 & (f.g.I - 1)) * 4u;
+    u.add = ((dh * f.g.Wh + dw) * f.g.I) * 4;
+    u.f = (1u << dh) | (0x10u << dw);
+  }
+};
+template <> struct SOp<DownB<float>> {                    // B(k, o) = w[o * 16 I + k]
+  using F = DownB<float>;
+  static constexpr bool OK = true;
+  static bool ok(const F& f, int) { return (long long)f.g.O * f.g.I * 16 < (1ll << 29); }
+  static __device__ __forceinline__ const void* ptr(const F& f) { return f.w; }
+  static __device__ __forceinline__ SSlot slot(const F& f, int, int o, bool ok, int ks) { return {(o * f.g.I * 16 + ks) * 4, ok ? 0u : 1u}; }
+  static __device__ __forceinline__ void seg(const F&, int, int k0, SSeg& u) { u.id = 0; u.so = (unsigned)k0 * 4u; u.add = 0; u.f = 1u; }
+};
+template <> struct SOp<UpA<float>> {                      // A(m = (n, hq, wq), k = t4 * O + o) = x[n][hq + sh][wq + sw][o], class zb
+  using F = UpA<float>;
+#ifndef RG_UP_KORDER_OLD
+  static constexpr bool OK = true;
+#else
+  static constexpr bool OK = false;
+#endif
+  static bool ok(const F& f, int) { return f.g.sWl && f.g.sHl && f.g.sO && f.g.O >= MB_K && (long long)f.g.N * f.g.Hl * f.g.Wl * f.g.O < (1ll << 29); }
+  static __device__ __forceinline__ const void* ptr(const F& f) { return f.x; }
+  static __device__ __forceinline__ SSlot slot(const F& f, int zb, int m, bool ok, int ks) {
+    const int wq = m & (f.g.Wl - 1), t = m >> (f.g.sWl - 1), hq = t & (f.g.Hl - 1), n = t >> (f.g.sHl - 1);
+    const int base = (((n * f.g.Hl + hq) * f.g.Wl + wq) * f.g.O + ks) * 4;
+    // parity 0: tap a = 1 reads q - 1; parity 1: tap a = 0 reads q + 1 (up_tap).  Invalid bits: a in bits 0-1, c in bits 4-5
+    const int ph = zb >> 1, pw = zb & 1;
+    const unsigned im = (ph == 0 ? (hq == 0 ? 2u : 0u) : (hq == f.g.Hl - 1 ? 1u : 0u)) |
+                        (pw == 0 ? (wq == 0 ? 0x20u : 0u) : (wq == f.g.Wl - 1 ? 0x10u : 0u));
+    return {base, ok ? im : 0xffu};
+  }
+  static __device__ __forceinline__ void seg(const F& f, int zb, int k0, SSeg& u) {
+    const int t4 = k0 >> (f.g.sO - 1);
+    int kh, kw, sh, sw;
+    up_tap(zb >> 1, t4 >> 1, 0, kh, sh);
+    up_tap(zb & 1, t4 & 1, 0, kw, sw);
+    u.id = t4;
+    u.so = (unsigned)(k0 & (f.g.O - 1)) * 4u;
+    u.add = ((sh * f.g.Wl + sw) * f.g.O) * 4;
+    u.f = (1u << (t4 >> 1)) | (0x10u << (t4 & 1));
+  }
+};
+template <> struct SOp<UpB<float>> {                      // B(k = t4 * O + o, i) = w[(o * 16 + kh * 4 + kw) * I + i]
+  using F = UpB<float>;
+#ifndef RG_UP_KORDER_OLD
+  static constexpr bool OK = true;
+#else
+  static constexpr bool OK = false;
+#endif
+  static bool ok(const F& f, int) { return f.g.sO != 0 && f.g.O >= MB_K && (long long)f.g.O * f.g.I * 16 < (1ll << 29); }
+  static __device__ __forceinline__ const void* ptr(const F& f) { return f.w; }
+  static __device__ __forceinline__ SSlot slot(const F& f, int, int i, bool ok, int ks) { return {(ks * 16 * f.g.I + i) * 4, ok ? 0u : 1u}; }
+  static __device__ __forceinline__ void seg(const F& f, int zb, int k0, SSeg& u) {
+    const int t4 = k0 >> (f.g.sO - 1);
+    int kh, kw, d;
+    up_tap(zb >> 1, t4 >> 1, 0, kh, d);
+    up_tap(zb & 1, t4 & 1, 0, kw, d);
+    u.id = 0;
+    u.so = (unsigned)(((k0 & (f.g.O - 1)) * 16 + kh * 4 + kw) * f.g.I) * 4u;
+    u.add = 0;
+    u.f = 1u;
+  }
+};
+template <> struct SOp<WgradA<float>> {                   // A(o, k = pixel) = low[pixel * O + o]
+  using F = WgradA<float>;
+  static constexpr bool OK = true;
+  static bool ok(const F& f, int) { return (long long)f.g.N * f.g.Hl * f.g.Wl * f.g.O < (1ll << 29); }
+  static __device__ __forceinline__ const void* ptr(const F& f) { return f.low; }
+  static __device__ __forceinline__ SSlot slot(const F& f, int, int o, bool ok, int ks) { return {(ks * f.g.O + o) * 4, ok ? 0u : 1u}; }
+  static __device__ __forceinline__ void seg(const F& f, int, int k0, SSeg& u) { u.id = 0; u.so = (unsigned)(k0 * f.g.O) * 4u; u.add = 0; u.f = 1u; }
+};
+template <> struct SOp<WgradB<float>> {                   // B(k = pixel (n, ho, wo), col = tap * I + i) = high[n][2ho-1+kh][2wo-1+kw][i]
+  using F = WgradB<float>;                                // segment = the k-tile: 16 consecutive wo of one output row (Wl >= 16)
+  static constexpr bool OK = true;
+  static bool ok(const F& f, int) { return f.g.sWl && f.g.sHl && f.g.sI && f.g.Wl >= MB_K && (long long)f.g.N * f.g.Hh * f.g.Wh * f.g.I < (1ll << 29); }
+  static __device__ __forceinline__ const void* ptr(const F& f) { return f.high; }
+  static __device__ __forceinline__ SSlot slot(const F& f, int, int col, bool ok, int ks) {
+    const int tap = col >> (f.g.sI - 1), i = col & (f.g.I - 1), kh = tap >> 2, kw = tap & 3;
+    const int base = ((kh * f.g.Wh + kw - 1 + 2 * ks) * f.g.I + i) * 4;
+    // invalid bits: 0 = needs ho > 0, 1 = needs ho < Hl - 1, 2 = needs wo0 > 0 (first pixel of the tile), 3 = needs wo0 < Wl - 16 (last)
+    const unsigned im = (kh == 0 ? 1u : 0u) | (kh == 3 ? 2u : 0u) | ((kw == 0) & (ks == 0) ? 4u : 0u) | ((kw == 3) & (ks == MB_K - 1) ? 8u : 0u);
+    return {base, ok ? im : 0x10u};
+  }
+  static __device__ __forceinline__ void seg(const F& f, int, int k0, SSeg& u) {
+    const int wo0 = k0 & (f.g.Wl - 1), t = k0 >> (f.g.sWl - 1), ho = t & (f.g.Hl - 1), n = t >> (f.g.sHl - 1);
+    // (the buffer's range check sees base + add only, not so: a valid slot's base + add must not be negative.  The one that
+    // would be -- image 0, input row 0, kw = 0, the tile's first pixel, valid when wo0 > 0 -- is kept at >= 0 by moving one
+    // pixel of the scalar offset into add.)
+    const int mv = wo0 ? f.g.I : 0;
+    u.id = k0 >> 4;
+    u.so = (unsigned)(2 * wo0 * f.g.I - mv) * 4u;
+    u.add = ((n * f.g.Hh + 2 * ho - 1) * f.g.Wh * f.g.I + mv) * 4;
+    u.f = (ho == 0 ? 1u : 0u) | (ho == f.g.Hl - 1 ? 2u : 0u) | (wo0 == 0 ? 4u : 0u) | (wo0 == f.g.Wl - MB_K ? 8u : 0u) | 0x10u;
+  }
+};
+template <> struct SOp<LinA> {                            // A(m, k) = x[m * ldx + k]
+  using F = LinA;
+  static constexpr bool OK = true;
+  static bool ok(const F& f, int rows) { return (long long)rows * f.ldx < (1ll << 29); }
+  static __device__ __forceinline__ const void* ptr(const F& f) { return f.x; }
+  static __device__ __forceinline__ SSlot slot(const F& f, int, int m, bool ok, int ks) { return {(m * f.ldx + ks) * 4, ok ? 0u : 1u}; }
+  static __device__ __forceinline__ void seg(const F&, int, int k0, SSeg& u) { u.id = 0; u.so = (unsigned)k0 * 4u; u.add = 0; u.f = 1u; }
+};
+template <> struct SOp<LinB> {                            // B(k, j) = w[j * K + k]
+  using F = LinB;
+  static constexpr bool OK = true;
+  static bool ok(const F& f, int rows) { return (long long)rows * f.K < (1ll << 29); }
+  static __device__ __forceinline__ const void* ptr(const F& f) { return f.w; }
+  static __device__ __forceinline__ SSlot slot(const F& f, int, int j, bool ok, int ks) { return {(j * f.K + ks) * 4, ok ? 0u : 1u}; }
+  static __device__ __forceinline__ void seg(const F&, int, int k0, SSeg& u) { u.id = 0; u.so = (unsigned)k0 * 4u; u.add = 0; u.f = 1u; }
+};
+
+template <int TM, int TN, bool A_KFAST, bool B_KFAST, class FA, class FB, class SC>
+__global__ __launch_bounds__(256, 3) void gemm_mfma32s_kernel(FA fa, FB fb, SC sc, int M, int N, int K, int nsplit, int klen) {
+  constexpr int BM = 2 * TM, BN = 2 * TN, IA = TM / 32, IB = TN / 32;
+  constexpr int NSA = BM * MB_K / 256, NSB = BN * MB_K / 256;
+  constexpr int KSA = 256 / BM, KSB = 256 / BN;
+  constexpr int RP = 256 / MB_K;
+  constexpr unsigned TAIL = 0x100u;                       // invalid bit of the slots beyond K in the last k-tile
+  static_assert(MB_K == 16, "the structured operands assume 16-deep k-tiles");
+  __shared__ float As[2][MB_K][BM + 4];
+  __shared__ float Bs[2][MB_K][BN + 4];
+  using SA = SOp<FA>;
+  using SB = SOp<FB>;
+  const int bm = blockIdx.x * BM, bn = blockIdx.y * BN;
+  const int zs = blockIdx.z % nsplit, zb = blockIdx.z / nsplit;
+  const int k_begin = zs * klen;
+  const int k_end = min(K, k_begin + klen);
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  mb_f32x16 acc[IA][IB];
+#pragma unroll
+  for (int i = 0; i < IA; ++i)
+#pragma unroll
+    for (int j = 0; j < IB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int ktail = K & (MB_K - 1);                       // 0: no partial k-tile
+  SSlot sla[NSA], slb[NSB];
+#pragma unroll
+  for (int i = 0; i < NSA; ++i) {
+    const int mm = A_KFAST ? tid / MB_K + RP * i : (tid & (BM - 1));
+    const int ks = A_KFAST ? (tid & (MB_K - 1)) : tid / BM + KSA * i;
+    const bool ok = bm + mm < M;
+    sla[i] = SA::slot(fa, zb, ok ? bm + mm : 0, ok, ks);
+    sla[i].m |= (ktail != 0) & (ks >= ktail) ? TAIL : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < NSB; ++i) {
+    const int nn = B_KFAST ? tid / MB_K + RP * i : (tid & (BN - 1));
+    const int ks = B_KFAST ? (tid & (MB_K - 1)) : tid / BN + KSB * i;
+    const bool ok = bn + nn < N;
+    slb[i] = SB::slot(fb, zb, ok ? bn + nn : 0, ok, ks);
+    slb[i].m |= (ktail != 0) & (ks >= ktail) ? TAIL : 0u;
+  }
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)SA::ptr(fa), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)SB::ptr(fb), 0, 0x7ffffff0, 0x00020000);
+  unsigned voa[NSA], vob[NSB];
+  float ra[NSA], rb[NSB];
+  int ida = -1, idb = -1;
+  auto issue = [&](int k0) __attribute__((always_inline)) {
+    const bool tail = k0 + MB_K > K;                      // uniform
+    SSeg ua, ub;
+    SA::seg(fa, zb, k0, ua);
+    SB::seg(fb, zb, k0, ub);
+    if (tail) { ua.id |= 0x40000000; ua.f |= TAIL; ub.id |= 0x40000000; ub.f |= TAIL; }
+    if (ua.id != ida) {
+      ida = ua.id;
+#pragma unroll
+      for (int i = 0; i < NSA; ++i) voa[i] = (unsigned)(sla[i].base + ua.add) | (min(sla[i].m & ua.f, 1u) << 31);
+    }
+    if (ub.id != idb) {
+      idb = ub.id;
+#pragma unroll
+      for (int i = 0; i < NSB; ++i) vob[i] = (unsigned)(slb[i].base + ub.add) | (min(slb[i].m & ub.f, 1u) << 31);
+    }
+#pragma unroll
+    for (int i = 0; i < NSA; ++i) ra[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsa, (int)voa[i], (int)ua.so, 0));
+#pragma unroll
+    for (int i = 0; i < NSB; ++i) rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsb, (int)vob[i], (int)ub.so, 0));
+  };
+  auto stash = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NSA; ++i) {
+      if (A_KFAST) As[st][tid & (MB_K - 1)][tid / MB_K + RP * i] = ra[i]; else As[st][tid / BM + KSA * i][tid & (BM - 1)] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NSB; ++i) {
+      if (B_KFAST) Bs[st][tid & (MB_K - 1)][tid / MB_K + RP * i] = rb[i]; else Bs[st][tid / BN + KSB * i][tid & (BN - 1)] = rb[i];
+    }
+  };
+  if (k_begin < k_end) { issue(k_begin); stash(0); }
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = k_begin; k0 < k_end; k0 += MB_K) {
+    const bool more = k0 + MB_K < k_end;
+    if (more) issue(k0 + MB_K);                    // global loads of the next k-tile fly under this tile's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    float a[2][IA], b[2][IB];                      // the fragments of step st + 1 are read while the MFMAs of step st run
+#pragma unroll
+    for (int i = 0; i < IA; ++i) a[0][i] = As[cur][lh][wm * TM + 32 * i + lr];
+#pragma unroll
+    for (int j = 0; j < IB; ++j) b[0][j] = Bs[cur][lh][wn * TN + 32 * j + lr];
+#pragma unroll
+    for (int st = 0; st < MB_K / 2; ++st) {
+      if (st + 1 < MB_K / 2) {
+#pragma unroll
+        for (int i = 0; i < IA; ++i) a[(st + 1) & 1][i] = As[cur][2 * st + 2 + lh][wm * TM + 32 * i + lr];
+#pragma unroll
+        for (int j = 0; j < IB; ++j) b[(st + 1) & 1][j] = Bs[cur][2 * st + 2 + lh][wn * TN + 32 * j + lr];
+      }
+#pragma unroll
+      for (int i = 0; i < IA; ++i)
+#pragma unroll
+        for (int j = 0; j < IB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][i], b[st & 1][j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);             // the loads stay above the MFMAs, their first use (the stash) below
+    if (more) stash(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < IA; ++i)
+#pragma unroll
+    for (int j = 0; j < IB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = bm + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, n = bn + wn * TN + j * 32 + lr;
+        if (m < M && n < N) sc(zb, zs, m, n, acc[i][j][r]);
+      }
+}
+
+template <bool AK, bool BK, class FA, class FB, class SC>
+static bool launch_structured(const char* name, FA fa, FB fb, SC sc, int M, int N, int K, int nsplit, int klen, dim3 grid,
+                              bool small, hipStream_t st) {
+  if constexpr (SOp<FA>::OK && SOp<FB>::OK) {
+#ifndef RG_F32_NOSTRUCT
+    if (SOp<FA>::ok(fa, M) && SOp<FB>::ok(fb, N)) {
+      if (small) hipLaunchKernelGGL((gemm_mfma32s_kernel<32, 32, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, nsplit, klen);
+      else hipLaunchKernelGGL((gemm_mfma32s_kernel<64, 64, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, nsplit, klen);
+      return true;
+    }
+#endif
+  }
+  return false;
+}
 
 int pick_split(int tiles, int K) {
   // enough blocks to fill 256 CUs a few times, at least 64 k-steps per split

@@ -71,6 +71,10 @@ CONV_CASES = [
     (3, 16, 16, 24, 100, torch.float32),       # down: 192 x 100 (ragged tile), K = 384, non-power-of-two I (division path)
     (2, 32, 32, 136, 40, torch.float32),       # up: 512 x 136 per class (two column tiles, ragged); down stays on the vector kernel
     (2, 16, 16, 128, 136, torch.float32),      # both directions + weight gradient (136 x 2048 outputs, split-K slabs)
+    # structured operands (gemm_mfma32s_kernel: power-of-two geometry, padding / tails as out-of-range buffer offsets)
+    (2, 64, 64, 32, 72, torch.float32),        # down (ragged 72 columns) + weight gradient with 32-pixel output rows: two k-tiles
+                                               # per row (first / last pixel flags), 72 x 512 outputs, split-K; up: general (O = 72)
+    (2, 32, 32, 40, 64, torch.float32),        # up structured (O = 64) with 40 ragged columns per class; down general (I = 40)
 ]
 
 
@@ -120,7 +124,10 @@ def test_conv_down_up_wgrad(N, Hi, Wi, I, O, dtype):
     check(ch.dw, 2 * cr.dw, TOL[dtype] * 2, "conv_wgrad2(accumulate)")
 
 
-@pytest.mark.parametrize("N,Hi,Wi,I,O", [(2, 16, 16, 128, 136), (3, 16, 16, 24, 100), (1, 32, 32, 64, 256)])
+@pytest.mark.parametrize("N,Hi,Wi,I,O", [(2, 16, 16, 128, 136), (3, 16, 16, 24, 100), (1, 32, 32, 64, 256),
+                                         (3, 64, 64, 32, 72),        # structured, ragged, 3 images
+                                         (4, 128, 128, 64, 512),     # 128 x 128 tiles: down (512 tiles) and weight gradient (768)
+                                         (4, 128, 128, 128, 32)])    # 128 x 128 tiles: up (512 tiles over the four classes)
 def test_f32_matrix_core_gemm_matches_vector_kernel(N, Hi, Wi, I, O):
     """fp32 mode: the f32-MFMA GEMM skeleton (option f32mma = 1, default) against the vector-ALU skeleton (f32mma = 0) through
     the same operand functors -- conv forward, transposed conv, weight gradient, generator layer 0 and a dense layer.  Both
