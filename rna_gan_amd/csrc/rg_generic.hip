@@ -367,7 +367,7 @@ static bool use_mfma32(bool f32, int M, int N) { return f32 && M >= 64 && N >= 3
 
 // (defined with gemm_mfma32s_kernel below: launches it and returns true when both operands have a structured form)
 template <bool AK, bool BK, class FA, class FB, class SC>
-static bool launch_structured(const char* name, FA fa, FB fb, SC sc, int M, int N, int K, int nsplit, int klen, dim3 grid,
+static bool launch_structured(const char* name, FA fa, FB fb, SC sc, int M, int N, int K, int nbatch, int klen, dim3 grid,
                               bool small, hipStream_t st);
 
 template <bool AK, bool BK, class FA, class FB, class SC>
@@ -383,12 +383,12 @@ int launch_generic(const char* name, FA fa, FB fb, SC sc, int M, int N, int K, i
       // output no wider / taller than 64 (the 64-channel layers, batch-64 dense layers): 64 x 64 tiles, 4 x the blocks
       grid = dim3((M + 63) / 64, (N + 63) / 64, nbatch * nsplit);
       RG_REQUIRE(grid.y <= 65535, RG_EINVAL, "%s: grid too large", name);
-      if (!launch_structured<AK, BK>(name, fa, fb, sc, M, N, K, nsplit, klen, grid, true, st))
+      if (!launch_structured<AK, BK>(name, fa, fb, sc, M, N, K, nbatch, klen, grid, true, st))
         hipLaunchKernelGGL((gemm_mfma32_kernel<32, 32, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, nsplit, klen);
     } else {
       // (measured and rejected: a 128 x 256 block tile -- wave tile 64 x 128, 8 accumulator tiles, one or two workgroups per CU by
       // registers -- 97.9 against 95.6 ms per iteration, two interleaved rounds)
-      if (!launch_structured<AK, BK>(name, fa, fb, sc, M, N, K, nsplit, klen, grid, false, st))
+      if (!launch_structured<AK, BK>(name, fa, fb, sc, M, N, K, nbatch, klen, grid, false, st))
         hipLaunchKernelGGL((gemm_mfma32_kernel<64, 64, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, nsplit, klen);
     }
     RG_LAUNCH_CHECK(name);
@@ -1031,27 +1031,51 @@ template <> struct SOp<WgradA<float>> {                   // A(o, k = pixel) = l
   static __device__ __forceinline__ void seg(const F& f, int, int k0, SSeg& u) { u.id = 0; u.so = (unsigned)(k0 * f.g.O) * 4u; u.add = 0; u.f = 1u; }
 };
 template <> struct SOp<WgradB<float>> {                   // B(k = pixel (n, ho, wo), col = tap * I + i) = high[n][2ho-1+kh][2wo-1+kw][i]
-  using F = WgradB<float>;                                // segment = the k-tile: 16 consecutive wo of one output row (Wl >= 16)
+  using F = WgradB<float>;
+  // A k-tile = 16 consecutive output pixels: a piece of one output row (Wl >= 16; the piece's first wo goes into the scalar
+  // offset) or 16 / Wl whole rows of one image (Wl < 16, Hl * Wl >= 16).  The segment is the k-tile itself.
   static constexpr bool OK = true;
-  static bool ok(const F& f, int) { return f.g.sWl && f.g.sHl && f.g.sI && f.g.Wl >= MB_K && (long long)f.g.N * f.g.Hh * f.g.Wh * f.g.I < (1ll << 29); }
+  static bool ok(const F& f, int) {
+#ifdef RG_WGRADB_NARROW_OFF
+    if (f.g.Wl < MB_K) return false;
+#endif
+    return f.g.sWl && f.g.sHl && f.g.sI && f.g.Hl * f.g.Wl >= MB_K && (long long)f.g.N * f.g.Hh * f.g.Wh * f.g.I < (1ll << 29);
+  }
   static __device__ __forceinline__ const void* ptr(const F& f) { return f.high; }
   static __device__ __forceinline__ SSlot slot(const F& f, int, int col, bool ok, int ks) {
     const int tap = col >> (f.g.sI - 1), i = col & (f.g.I - 1), kh = tap >> 2, kw = tap & 3;
-    const int base = ((kh * f.g.Wh + kw - 1 + 2 * ks) * f.g.I + i) * 4;
-    // invalid bits: 0 = needs ho > 0, 1 = needs ho < Hl - 1, 2 = needs wo0 > 0 (first pixel of the tile), 3 = needs wo0 < Wl - 16 (last)
-    const unsigned im = (kh == 0 ? 1u : 0u) | (kh == 3 ? 2u : 0u) | ((kw == 0) & (ks == 0) ? 4u : 0u) | ((kw == 3) & (ks == MB_K - 1) ? 8u : 0u);
+    if (f.g.Wl >= MB_K) {
+      const int base = ((kh * f.g.Wh + kw - 1 + 2 * ks) * f.g.I + i) * 4;
+      // invalid bits: 0 = needs ho > 0, 1 = needs ho < Hl - 1, 2 = needs wo0 > 0 (first pixel of the tile), 3 = needs wo0 < Wl - 16 (last)
+      const unsigned im = (kh == 0 ? 1u : 0u) | (kh == 3 ? 2u : 0u) | ((int)(kw == 0) & (int)(ks == 0) ? 4u : 0u) |
+                          ((int)(kw == 3) & (int)(ks == MB_K - 1) ? 8u : 0u);
+      return {base, ok ? im : 0x10u};
+    }
+    // rows r = ks / Wl of the tile, pixel wo = ks % Wl: the column padding is known per slot (bit 4 = always), the row padding
+    // needs the tile's first row ho0: bit 0 = needs ho0 > 0 (first row of the tile), bit 1 = needs ho0 < Hl - rows (last)
+    const int wo = ks & (f.g.Wl - 1), r = ks >> (f.g.sWl - 1), rows = MB_K >> (f.g.sWl - 1);
+    const int base = (((2 * r + kh) * f.g.Wh + 2 * wo - 1 + kw) * f.g.I + i) * 4;
+    const bool wbad = ((int)(kw == 0) & (int)(wo == 0)) | ((int)(kw == 3) & (int)(wo == f.g.Wl - 1));
+    const unsigned im = ((int)(kh == 0) & (int)(r == 0) ? 1u : 0u) | ((int)(kh == 3) & (int)(r == rows - 1) ? 2u : 0u) | (wbad ? 0x10u : 0u);
     return {base, ok ? im : 0x10u};
   }
   static __device__ __forceinline__ void seg(const F& f, int, int k0, SSeg& u) {
-    const int wo0 = k0 & (f.g.Wl - 1), t = k0 >> (f.g.sWl - 1), ho = t & (f.g.Hl - 1), n = t >> (f.g.sHl - 1);
-    // (the buffer's range check sees base + add only, not so: a valid slot's base + add must not be negative.  The one that
-    // would be -- image 0, input row 0, kw = 0, the tile's first pixel, valid when wo0 > 0 -- is kept at >= 0 by moving one
-    // pixel of the scalar offset into add.)
-    const int mv = wo0 ? f.g.I : 0;
     u.id = k0 >> 4;
-    u.so = (unsigned)(2 * wo0 * f.g.I - mv) * 4u;
-    u.add = ((n * f.g.Hh + 2 * ho - 1) * f.g.Wh * f.g.I + mv) * 4;
-    u.f = (ho == 0 ? 1u : 0u) | (ho == f.g.Hl - 1 ? 2u : 0u) | (wo0 == 0 ? 4u : 0u) | (wo0 == f.g.Wl - MB_K ? 8u : 0u) | 0x10u;
+    if (f.g.Wl >= MB_K) {
+      const int wo0 = k0 & (f.g.Wl - 1), t = k0 >> (f.g.sWl - 1), ho = t & (f.g.Hl - 1), n = t >> (f.g.sHl - 1);
+      // (the buffer's range check sees base + add only, not so: a valid slot's base + add must not be negative.  The one that
+      // would be -- image 0, input row 0, kw = 0, the tile's first pixel, valid when wo0 > 0 -- is kept at >= 0 by moving one
+      // pixel of the scalar offset into add.)
+      const int mv = wo0 ? f.g.I : 0;
+      u.so = (unsigned)(2 * wo0 * f.g.I - mv) * 4u;
+      u.add = ((n * f.g.Hh + 2 * ho - 1) * f.g.Wh * f.g.I + mv) * 4;
+      u.f = (ho == 0 ? 1u : 0u) | (ho == f.g.Hl - 1 ? 2u : 0u) | (wo0 == 0 ? 4u : 0u) | (wo0 == f.g.Wl - MB_K ? 8u : 0u) | 0x10u;
+    } else {
+      const int t = k0 >> (f.g.sWl - 1), ho0 = t & (f.g.Hl - 1), n = t >> (f.g.sHl - 1), rows = MB_K >> (f.g.sWl - 1);
+      u.so = 0u;
+      u.add = ((n * f.g.Hh + 2 * ho0 - 1) * f.g.Wh * f.g.I) * 4;
+      u.f = (ho0 == 0 ? 1u : 0u) | (ho0 == f.g.Hl - rows ? 2u : 0u) | 0x10u;
+    }
   }
 };
 template <> struct SOp<LinA> {                            // A(m, k) = x[m * ldx + k]
@@ -1072,7 +1096,7 @@ template <> struct SOp<LinB> {                            // B(k, j) = w[j * K +
 };
 
 template <int TM, int TN, bool A_KFAST, bool B_KFAST, class FA, class FB, class SC>
-__global__ __launch_bounds__(256, 3) void gemm_mfma32s_kernel(FA fa, FB fb, SC sc, int M, int N, int K, int nsplit, int klen) {
+__global__ __launch_bounds__(256, 3) void gemm_mfma32s_kernel(FA fa, FB fb, SC sc, int M, int N, int K, int lgb, int klen) {
   constexpr int BM = 2 * TM, BN = 2 * TN, IA = TM / 32, IB = TN / 32;
   constexpr int NSA = BM * MB_K / 256, NSB = BN * MB_K / 256;
   constexpr int KSA = 256 / BM, KSB = 256 / BN;
@@ -1084,7 +1108,12 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma32s_kernel(FA fa, FB fb, SC s
   using SA = SOp<FA>;
   using SB = SOp<FB>;
   const int bm = blockIdx.x * BM, bn = blockIdx.y * BN;
-  const int zs = blockIdx.z % nsplit, zb = blockIdx.z / nsplit;
+  // blockIdx.z = zs << lgb | zb (batch count = 2^lgb: 1, or the 4 output classes of the transposed conv).  Shift / mask, not
+  // the / nsplit of the kernels above: an integer division is a vector-unit sequence, and in the transposed-conv and weight-
+  // gradient instantiations the compiler then kept everything derived from it (k0, every load's scalar offset) in vector
+  // registers, where instruction legalisation wraps each buffer load in a waterfall loop (readfirstlane / compare / masked
+  // load / branch per load: the transposed convs ran at 97 TFLOP/s against the forward convs' 120).
+  const int zb = blockIdx.z & ((1 << lgb) - 1), zs = blockIdx.z >> lgb;
   const int k_begin = zs * klen;
   const int k_end = min(K, k_begin + klen);
   const int tid = threadIdx.x;
@@ -1106,7 +1135,7 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma32s_kernel(FA fa, FB fb, SC s
     const int ks = A_KFAST ? (tid & (MB_K - 1)) : tid / BM + KSA * i;
     const bool ok = bm + mm < M;
     sla[i] = SA::slot(fa, zb, ok ? bm + mm : 0, ok, ks);
-    sla[i].m |= (ktail != 0) & (ks >= ktail) ? TAIL : 0u;
+    sla[i].m |= ((int)(ktail != 0) & (int)(ks >= ktail)) ? TAIL : 0u;
   }
 #pragma unroll
   for (int i = 0; i < NSB; ++i) {
@@ -1114,7 +1143,7 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma32s_kernel(FA fa, FB fb, SC s
     const int ks = B_KFAST ? (tid & (MB_K - 1)) : tid / BN + KSB * i;
     const bool ok = bn + nn < N;
     slb[i] = SB::slot(fb, zb, ok ? bn + nn : 0, ok, ks);
-    slb[i].m |= (ktail != 0) & (ks >= ktail) ? TAIL : 0u;
+    slb[i].m |= ((int)(ktail != 0) & (int)(ks >= ktail)) ? TAIL : 0u;
   }
   const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)SA::ptr(fa), 0, 0x7ffffff0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)SB::ptr(fb), 0, 0x7ffffff0, 0x00020000);
@@ -1194,13 +1223,14 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma32s_kernel(FA fa, FB fb, SC s
 }
 
 template <bool AK, bool BK, class FA, class FB, class SC>
-static bool launch_structured(const char* name, FA fa, FB fb, SC sc, int M, int N, int K, int nsplit, int klen, dim3 grid,
+static bool launch_structured(const char* name, FA fa, FB fb, SC sc, int M, int N, int K, int nbatch, int klen, dim3 grid,
                               bool small, hipStream_t st) {
   if constexpr (SOp<FA>::OK && SOp<FB>::OK) {
 #ifndef RG_F32_NOSTRUCT
-    if (SOp<FA>::ok(fa, M) && SOp<FB>::ok(fb, N)) {
-      if (small) hipLaunchKernelGGL((gemm_mfma32s_kernel<32, 32, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, nsplit, klen);
-      else hipLaunchKernelGGL((gemm_mfma32s_kernel<64, 64, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, nsplit, klen);
+    if (SOp<FA>::ok(fa, M) && SOp<FB>::ok(fb, N) && lg1(nbatch)) {
+      const int lgb = lg1(nbatch) - 1;
+      if (small) hipLaunchKernelGGL((gemm_mfma32s_kernel<32, 32, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, lgb, klen);
+      else hipLaunchKernelGGL((gemm_mfma32s_kernel<64, 64, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, lgb, klen);
       return true;
     }
 #endif

@@ -75,6 +75,7 @@ CONV_CASES = [
     (2, 64, 64, 32, 72, torch.float32),        # down (ragged 72 columns) + weight gradient with 32-pixel output rows: two k-tiles
                                                # per row (first / last pixel flags), 72 x 512 outputs, split-K; up: general (O = 72)
     (2, 32, 32, 40, 64, torch.float32),        # up structured (O = 64) with 40 ragged columns per class; down general (I = 40)
+    (3, 8, 8, 64, 64, torch.float32),          # weight gradient over 4 x 4 outputs: a k-tile = one whole image (rows of 4 pixels)
 ]
 
 
@@ -126,6 +127,7 @@ def test_conv_down_up_wgrad(N, Hi, Wi, I, O, dtype):
 
 @pytest.mark.parametrize("N,Hi,Wi,I,O", [(2, 16, 16, 128, 136), (3, 16, 16, 24, 100), (1, 32, 32, 64, 256),
                                          (3, 64, 64, 32, 72),        # structured, ragged, 3 images
+                                         (5, 8, 8, 64, 96),          # weight gradient, 4-pixel rows (k-tile = one image)
                                          (4, 128, 128, 64, 512),     # 128 x 128 tiles: down (512 tiles) and weight gradient (768)
                                          (4, 128, 128, 128, 32)])    # 128 x 128 tiles: up (512 tiles over the four classes)
 def test_f32_matrix_core_gemm_matches_vector_kernel(N, Hi, Wi, I, O):
