@@ -781,7 +781,7 @@ F32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X fp32 matrix (= vector) peak, MI355X
 def extra_fp32_step(args, device, info, steps=3, warm=6):
     """The fp32 parity mode (--precision fp32: the reference's own arithmetic, src/betaVAE.py:184,223,230-236; the anchor of
     the tight-tolerance parity tests) on the same workload.  Convolutions / dense layers run on the f32 matrix cores
-    (gemm_mfma32_kernel: v_mfma_f32_32x32x2_f32 behind the generic operand functors, rg_generic.hip); everything else is the
+    (gemm_mfma32s_kernel / gemm_mfma32_kernel: v_mfma_f32_32x32x2_f32 with structured operands / behind the generic operand functors, rg_generic.hip); everything else is the
     fp32 form of the bandwidth-bound kernels.  `roofline_fp32`: algorithmic conv FLOPs of the conv + weight-gradient launches
     of one instrumented eager iteration / their summed HIP-event durations, against the 157.3 TFLOP/s fp32 matrix peak."""
     from rna_gan_amd import graphed
@@ -834,7 +834,7 @@ def extra_fp32_step(args, device, info, steps=3, warm=6):
     mm = [v for k, v in fam.items() if k in ("conv_fwd_dgrad", "conv_wgrad")]
     if mm:
         fl, ms = sum(v[1] for v in mm), sum(v[2] for v in mm)
-        res["roofline_fp32"] = {"bound": "mfma", "kernel": "gemm_mfma32_kernel (conv fwd / dgrad / tangent + weight gradients, fp32)",
+        res["roofline_fp32"] = {"bound": "mfma", "kernel": "gemm_mfma32s_kernel (conv fwd / dgrad / tangent + weight gradients, fp32)",
                                 "achieved": round(fl / (ms * 1e-3) / 1e12, 1), "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(fl / (ms * 1e-3) / 1e12 / F32_MATRIX_PEAK_TFLOPS, 4),
                                 "launches": sum(v[0] for v in mm), "ms_total": round(ms, 2),
