@@ -196,7 +196,7 @@ extern "C" int rg_first_down(const float* x_nchw, const float* w, const float* b
                              int I, int O, float slope, int dtype, void* stream) {
   RG_REQUIRE(x_nchw && w && y && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && I > 0 && O > 0, RG_EINVAL,
              "first_down: bad args");
-  if (rg_skinny_supported(I, O))
+  if (rg_skinny_supported(I, O) && !(dtype == RG_F32 && rg_generic_f32_image_side(N, H, W, I, O)))
     return rg_skinny_first_down(x_nchw, w, bias, y, nullptr, N, H, W, I, O, slope, dtype, rg_stream(stream));
   return rg_generic_first_down(x_nchw, w, bias, y, N, H, W, I, O, slope, dtype, rg_stream(stream));
 }
@@ -301,7 +301,7 @@ extern "C" int rg_skinny_wgrad(const void* low, const float* high_nchw, float* d
                                int dtype, int accumulate, void* ws, size_t ws_bytes, void* stream) {
   RG_REQUIRE(low && high_nchw && dw && N > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0, RG_EINVAL,
              "skinny_wgrad: bad args");
-  if (rg_skinny_supported(I, O))
+  if (rg_skinny_supported(I, O) && !(dtype == RG_F32 && rg_generic_f32_image_side(N, 2 * Ho, 2 * Wo, I, O)))
     return rg_skinny_wgrad_impl(low, high_nchw, dw, N, Ho, Wo, O, I, dtype, accumulate, ws, ws_bytes,
                                 rg_stream(stream));
   return rg_generic_skinny_wgrad(low, high_nchw, dw, N, Ho, Wo, O, I, dtype, accumulate, ws, ws_bytes,

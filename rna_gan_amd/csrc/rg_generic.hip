@@ -1078,6 +1078,42 @@ template <> struct SOp<WgradB<float>> {                   // B(k = pixel (n, ho,
     }
   }
 };
+template <> struct SOp<FirstDownA> {                      // A(m = (n, ho, wo), k = ci * 16 + tap) = x[n][ci][2ho-1+kh][2wo-1+kw] (NCHW fp32 image)
+  using F = FirstDownA;                                   // a k-tile = the 16 taps of one input channel: a slot's tap is fixed,
+  static constexpr bool OK = true;                        // its padding a constant of the slot; the channel is the scalar offset
+  static bool ok(const F& f, int) { return f.g.sWl && f.g.sHl && (long long)f.g.N * f.g.I * f.g.Hh * f.g.Wh < (1ll << 29); }
+  static __device__ __forceinline__ const void* ptr(const F& f) { return f.x; }
+  static __device__ __forceinline__ SSlot slot(const F& f, int, int m, bool ok, int ks) {
+    const int wo = m & (f.g.Wl - 1), t = m >> (f.g.sWl - 1), ho = t & (f.g.Hl - 1), n = t >> (f.g.sHl - 1);
+    const int hi = 2 * ho - 1 + (ks >> 2), wi = 2 * wo - 1 + (ks & 3);
+    const bool v = (int)ok & (int)((unsigned)hi < (unsigned)f.g.Hh) & (int)((unsigned)wi < (unsigned)f.g.Wh);
+    return {((n * f.g.I * f.g.Hh + hi) * f.g.Wh + wi) * 4, v ? 0u : 1u};
+  }
+  static __device__ __forceinline__ void seg(const F& f, int, int k0, SSeg& u) {
+    u.id = 0; u.so = (unsigned)((k0 >> 4) * f.g.Hh * f.g.Wh) * 4u; u.add = 0; u.f = 1u;
+  }
+};
+template <> struct SOp<WgradBNchw> {                      // B(k = pixel (n, ho, wo), col = i * 16 + tap) = x[n][i][2ho-1+kh][2wo-1+kw]
+  using F = WgradBNchw;                                   // (the image-side layer's weight gradient; output rows of >= 16 pixels)
+  static constexpr bool OK = true;
+  static bool ok(const F& f, int) { return f.g.sWl && f.g.sHl && f.g.Wl >= MB_K && (long long)f.g.N * f.g.I * f.g.Hh * f.g.Wh < (1ll << 29); }
+  static __device__ __forceinline__ const void* ptr(const F& f) { return f.high; }
+  static __device__ __forceinline__ SSlot slot(const F& f, int, int col, bool ok, int ks) {
+    const int i = col >> 4, kh = (col >> 2) & 3, kw = col & 3;
+    const int base = ((i * f.g.Hh + kh) * f.g.Wh + kw - 1 + 2 * ks) * 4;
+    const unsigned im = (kh == 0 ? 1u : 0u) | (kh == 3 ? 2u : 0u) | ((int)(kw == 0) & (int)(ks == 0) ? 4u : 0u) |
+                        ((int)(kw == 3) & (int)(ks == MB_K - 1) ? 8u : 0u);
+    return {base, ok ? im : 0x10u};
+  }
+  static __device__ __forceinline__ void seg(const F& f, int, int k0, SSeg& u) {
+    const int wo0 = k0 & (f.g.Wl - 1), t = k0 >> (f.g.sWl - 1), ho = t & (f.g.Hl - 1), n = t >> (f.g.sHl - 1);
+    const int mv = wo0 ? 1 : 0;                           // (as SOp<WgradB>: keeps a valid slot's base + add >= 0)
+    u.id = k0 >> 4;
+    u.so = (unsigned)(2 * wo0 - mv) * 4u;
+    u.add = ((n * f.g.I * f.g.Hh + 2 * ho - 1) * f.g.Wh + mv) * 4;
+    u.f = (ho == 0 ? 1u : 0u) | (ho == f.g.Hl - 1 ? 2u : 0u) | (wo0 == 0 ? 4u : 0u) | (wo0 == f.g.Wl - MB_K ? 8u : 0u) | 0x10u;
+  }
+};
 template <> struct SOp<LinA> {                            // A(m, k) = x[m * ldx + k]
   using F = LinA;
   static constexpr bool OK = true;
@@ -1272,12 +1308,25 @@ int rg_generic_conv_up(const void* x, const float* w, void* y, int N, int Ho, in
   })
 }
 
+// fp32 image-side layers (3 input channels): true when the matrix-core kernel with structured operands takes the launch
+// (f32mma on, power-of-two image, output rows of >= 16 pixels) -- rg_first_down / rg_skinny_wgrad then come here instead of the
+// vector-ALU kernels of rg_skinny.hip (first_down 285 -> see DESIGN 13.2; the 3-column transposed conv stays there: an MFMA
+// tile would be 29 / 32 padding).  H, W: the layer's INPUT (high-resolution) size.
+bool rg_generic_f32_image_side(int N, int H, int W, int I, int O) {
+#ifdef RG_F32_IMAGE_VALU       // (A/B builds)
+  return false;
+#endif
+  return rg_option("f32mma", 1) != 0 && lg1(H / 2) && lg1(W / 2) && W / 2 >= MB_K && O >= 33 && (long long)N * (H / 2) * (W / 2) >= 64 &&
+         (long long)N * I * H * W < (1ll << 29);
+}
+
 int rg_generic_first_down(const float* x, const float* w, const float* bias, void* y, int N, int H, int W, int I,
                           int O, float slope, int dtype, hipStream_t st) {
   Geo g = geo_pow2(Geo{N, H / 2, W / 2, H, W, O, I});
   RG_DISPATCH_DTYPE(dtype, T, {
     return launch_generic<true, true>("first_down(generic)", FirstDownA{x, g}, DownB<float>{w, g},
-                                      BiasActC<T>{(T*)y, bias, slope, O}, N * g.Hl * g.Wl, O, I * 16, 1, 1, st);
+                                      BiasActC<T>{(T*)y, bias, slope, O}, N * g.Hl * g.Wl, O, I * 16, 1, 1, st,
+                                      std::is_same<T, float>::value);
   })
 }
 
@@ -1300,7 +1349,10 @@ static int generic_wgrad_split(int N, int Ho, int Wo, int O, int I, bool f32) {
     int want = (768 + tiles - 1) / tiles, maxs = K / (MB_K * 32);
     if (maxs < 1) maxs = 1;
     int s = want < maxs ? want : maxs;
-    if (s > 256) s = 256;
+    // (one or two output tiles -- the image-side layer's 64 x 48 gradient over a million pixels: the slabs are tiny, and 256
+    // workgroups would be one wave per SIMD)
+    const int cap = tiles <= 2 ? 1024 : 256;
+    if (s > cap) s = cap;
     return s < 1 ? 1 : s;
   }
   int tiles = ((O + GB_M - 1) / GB_M) * ((I * 16 + GB_N - 1) / GB_N);

@@ -12,6 +12,7 @@ int rg_generic_conv_down(const void* x, const float* w, void* y, int N, int Hi, 
                          hipStream_t st);
 int rg_generic_conv_up(const void* x, const float* w, void* y, int N, int Ho, int Wo, int O, int I, const void* mask,
                        float mslope, int dtype, hipStream_t st);
+bool rg_generic_f32_image_side(int N, int H, int W, int I, int O);
 int rg_generic_first_down(const float* x, const float* w, const float* bias, void* y, int N, int H, int W, int I,
                           int O, float slope, int dtype, hipStream_t st);
 int rg_generic_last_up(const void* x, const float* w, const float* bias, float* y, int N, int Ho, int Wo, int O,

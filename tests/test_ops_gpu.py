@@ -345,7 +345,9 @@ def test_u8_to_norm_bit_exact():
 
 @pytest.mark.parametrize("O,dtype,W", [(4, torch.float32, 32), (4, torch.bfloat16, 32), (64, torch.float32, 32),
                                        (64, torch.bfloat16, 32), (128, torch.bfloat16, 32),
-                                       (64, torch.bfloat16, 128), (64, torch.bfloat16, 64)])   # last two: MFMA path
+                                       (64, torch.bfloat16, 128), (64, torch.bfloat16, 64),    # these two: bf16 MFMA path
+                                       # fp32 on the f32 matrix cores with structured operands (as (64, float32, 32) above)
+                                       (64, torch.float32, 128), (128, torch.float32, 64)])
 def test_image_side_layers(O, dtype, W):
     ref, hip = RefOps(dtype), _hip(dtype)
     N, H, I = 3, 16, 3
