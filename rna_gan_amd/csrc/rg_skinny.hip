@@ -619,12 +619,15 @@ __global__ __launch_bounds__(256) void lu_part_final_kernel(const float* __restr
 // lane per pixel); each thread produces its 2x2 output quad x 3 channels and stores float2 pairs that
 // are contiguous across the wave (NCHW rows).
 constexpr int LU_TW = 32;
-template <typename T, int LU_TH>
+// CCH > 0: the channels are staged CCH at a time (fp32 storage: the whole 64-channel halo tile is 36 KB per 64 threads, i.e.
+// one wave per SIMD and a latency-bound kernel -- 541 us for 6.4 GFLOP; 16 channels at a time are 15 KB per 128 threads)
+template <typename T, int LU_TH, int CCH = 0>
 __global__ __launch_bounds__(LU_TH * 32) void last_up_kernel(const T* __restrict__ x, const float* __restrict__ wq,
                                                       const float* __restrict__ bias, float* __restrict__ y, int N,
                                                       int Ho, int Wo, int O, int apply_tanh) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int rowb = O * (int)sizeof(T) + 8;                 // bytes per staged pixel (padded)
+  const int CH = CCH ? CCH : O;                            // channels per staging pass
+  const int rowb = CH * (int)sizeof(T) + 8;                // bytes per staged pixel (padded)
   const int t = threadIdx.x;
   const int tiles_w = (Wo + LU_TW - 1) / LU_TW, tiles_h = (Ho + LU_TH - 1) / LU_TH;
   int b = blockIdx.x;
@@ -633,21 +636,8 @@ __global__ __launch_bounds__(LU_TH * 32) void last_up_kernel(const T* __restrict
   const int n = b / tiles_h;
   const int h0 = th * LU_TH - 1, w0 = tw * LU_TW - 1;      // halo origin
   const T* xb = x + (long long)n * Ho * Wo * O;
-  // stage: (LU_TH+2)*(LU_TW+2) pixels x O channels, 16 bytes per lane
-  const int chunks = O * (int)sizeof(T) / 16;
+  const int chunks = CH * (int)sizeof(T) / 16;
   const int npx = (LU_TH + 2) * (LU_TW + 2);
-  for (int i = t; i < npx * chunks; i += LU_TH * 32) {
-    int px = i / chunks, ch = i - px * chunks;
-    int hh = h0 + px / (LU_TW + 2), ww = w0 + px % (LU_TW + 2);
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if ((unsigned)hh < (unsigned)Ho && (unsigned)ww < (unsigned)Wo)
-      v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(xb + ((long long)hh * Wo + ww) * O) + ch * 16);
-    // 8-byte stores keep the padded rows 8-byte aligned
-    uint2* d = reinterpret_cast<uint2*>(smem + px * rowb + ch * 16);
-    d[0] = make_uint2(v.x, v.y);
-    d[1] = make_uint2(v.z, v.w);
-  }
-  __syncthreads();
   const int lh = t / LU_TW, lw = t % LU_TW;
   const int hq = th * LU_TH + lh, wq_ = tw * LU_TW + lw;
   float acc[2][2][SK_I];
@@ -657,7 +647,22 @@ __global__ __launch_bounds__(LU_TH * 32) void last_up_kernel(const T* __restrict
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int i = 0; i < SK_I; ++i) acc[a][c][i] = bias ? bias[i] : 0.f;
-  for (int o0 = 0; o0 < O; o0 += 4) {
+  for (int c0 = 0; c0 < O; c0 += CH) {
+  if (c0) __syncthreads();                                 // the previous pass's readers are done
+  // stage: (LU_TH+2)*(LU_TW+2) pixels x CH channels, 16 bytes per lane
+  for (int i = t; i < npx * chunks; i += LU_TH * 32) {
+    int px = i / chunks, ch = i - px * chunks;
+    int hh = h0 + px / (LU_TW + 2), ww = w0 + px % (LU_TW + 2);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if ((unsigned)hh < (unsigned)Ho && (unsigned)ww < (unsigned)Wo)
+      v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(xb + ((long long)hh * Wo + ww) * O + c0) + ch * 16);
+    // 8-byte stores keep the padded rows 8-byte aligned
+    uint2* d = reinterpret_cast<uint2*>(smem + px * rowb + ch * 16);
+    d[0] = make_uint2(v.x, v.y);
+    d[1] = make_uint2(v.z, v.w);
+  }
+  __syncthreads();
+  for (int o0 = 0; o0 < CH; o0 += 4) {
     float xv[3][3][4];
 #pragma unroll
     for (int dh = 0; dh < 3; ++dh)
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(LU_TH * 32) void last_up_kernel(const T* __restrict
       }
 #pragma unroll
     for (int oo = 0; oo < 4; ++oo) {
-      const float* wr = wq + (size_t)(o0 + oo) * SK_K;      // uniform -> scalar loads
+      const float* wr = wq + (size_t)(c0 + o0 + oo) * SK_K;      // uniform -> scalar loads
 #pragma unroll
       for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
@@ -687,6 +692,7 @@ __global__ __launch_bounds__(LU_TH * 32) void last_up_kernel(const T* __restrict
                 acc[ph][pw][i] = fmaf(xval, Elem<T>::round(wr[i * 16 + kh * 4 + kw]), acc[ph][pw][i]);
             }
     }
+  }
   }
   if (hq >= Ho || wq_ >= Wo) return;
   const int H = 2 * Ho, W = 2 * Wo;
@@ -933,11 +939,19 @@ int rg_skinny_last_up(const void* x, const float* w, const float* bias, float* y
     hipLaunchKernelGGL((last_up_kernel<bf16_t, TH>), dim3((unsigned)((long long)N * tiles)), dim3(TH * 32), sh, st,
                        (const bf16_t*)x, w, bias, y, N, Ho, Wo, O, apply_tanh);
   } else if (dtype == RG_F32) {
-    constexpr int TH = 2;
-    int tiles = ((Wo + LU_TW - 1) / LU_TW) * ((Ho + TH - 1) / TH);
-    size_t sh = (size_t)(TH + 2) * (LU_TW + 2) * (O * 4 + 8);
-    hipLaunchKernelGGL((last_up_kernel<float, TH>), dim3((unsigned)((long long)N * tiles)), dim3(TH * 32), sh, st,
-                       (const float*)x, w, bias, y, N, Ho, Wo, O, apply_tanh);
+    if (O % 16 == 0 && !getenv("RNAGAN_LASTUP_WHOLE")) {    // 16 channels per staging pass: 15 KB per 128 threads
+      constexpr int TH = 4, CCH = 16;
+      int tiles = ((Wo + LU_TW - 1) / LU_TW) * ((Ho + TH - 1) / TH);
+      size_t sh = (size_t)(TH + 2) * (LU_TW + 2) * (CCH * 4 + 8);
+      hipLaunchKernelGGL((last_up_kernel<float, TH, CCH>), dim3((unsigned)((long long)N * tiles)), dim3(TH * 32), sh, st,
+                         (const float*)x, w, bias, y, N, Ho, Wo, O, apply_tanh);
+    } else {
+      constexpr int TH = 2;
+      int tiles = ((Wo + LU_TW - 1) / LU_TW) * ((Ho + TH - 1) / TH);
+      size_t sh = (size_t)(TH + 2) * (LU_TW + 2) * (O * 4 + 8);
+      hipLaunchKernelGGL((last_up_kernel<float, TH>), dim3((unsigned)((long long)N * tiles)), dim3(TH * 32), sh, st,
+                         (const float*)x, w, bias, y, N, Ho, Wo, O, apply_tanh);
+    }
   } else {
     rg_set_error("bad dtype %d", dtype);
     return RG_EINVAL;
