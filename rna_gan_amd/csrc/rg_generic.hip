@@ -687,6 +687,19 @@ template <typename T> struct G0B {
     return Elem<T>::round(w[((size_t)e * C + c) * 16 + tap]);
   }
 };
+// The same GEMM with its columns in MEMORY order of w[E][C][16] (col' = c * 16 + tap: consecutive threads read consecutive
+// floats; with col = tap * C + c a 64-lane load touched 64 different 64-byte segments, 16 x the weight bytes through L2:
+// 3.25 GB fetched for a 134 MB tensor, 500 us) and the permutation in the store (the output is 16 x smaller than w).
+template <typename T> struct G0Bm {
+  const float* w; int C;
+  __device__ float operator()(int, int e, int colm) const { return Elem<T>::round(w[(size_t)e * C * 16 + colm]); }
+};
+template <typename T> struct G0Cm {
+  T* y; int C;
+  __device__ void operator()(int, int, int m, int colm, float v) const {
+    Elem<T>::st(y + (size_t)m * 16 * C + (size_t)(colm & 15) * C + (colm >> 4), v);
+  }
+};
 template <typename T> struct G0WA {
   const float* z; int E;
   __device__ float operator()(int, int e, int n) const { return Elem<T>::round(z[(size_t)n * E + e]); }
@@ -947,7 +960,7 @@ template <class F> struct SOp { static constexpr bool OK = false; };
 template <> struct SOp<DownA<float>> {                    // A(m = (n, ho, wo), k = tap * I + c) = x[n][2ho-1+kh][2wo-1+kw][c]
   using F = DownA<float>;
   static constexpr bool OK = true;
-  static bool ok(const F& f, int) { return f.g.sWl && f.g.sHl && f.g.sI && f.g.I >= MB_K && (long long)f.g.N * f.g.Hh * f.g.Wh * f.g.I < (1ll << 29); }
+  static bool ok(const F& f, int, int) { return f.g.sWl && f.g.sHl && f.g.sI && f.g.I >= MB_K && (long long)f.g.N * f.g.Hh * f.g.Wh * f.g.I < (1ll << 29); }
   static __device__ __forceinline__ const void* ptr(const F& f) { return f.x; }
   static __device__ __forceinline__ SSlot slot(const F& f, int, int m, bool ok, int ks) {
     const int wo = m & (f.g.Wl - 1), t = m >> (f.g.sWl - 1), ho = t & (f.g.Hl - 1), n = t >> (f.g.sHl - 1);
@@ -967,7 +980,7 @@ template <> struct SOp<DownA<float>> {                    // A(m = (n, ho, wo), 
 template <> struct SOp<DownB<float>> {                    // B(k, o) = w[o * 16 I + k]
   using F = DownB<float>;
   static constexpr bool OK = true;
-  static bool ok(const F& f, int) { return (long long)f.g.O * f.g.I * 16 < (1ll << 29); }
+  static bool ok(const F& f, int, int) { return (long long)f.g.O * f.g.I * 16 < (1ll << 29); }
   static __device__ __forceinline__ const void* ptr(const F& f) { return f.w; }
   static __device__ __forceinline__ SSlot slot(const F& f, int, int o, bool ok, int ks) { return {(o * f.g.I * 16 + ks) * 4, ok ? 0u : 1u}; }
   static __device__ __forceinline__ void seg(const F&, int, int k0, SSeg& u) { u.id = 0; u.so = (unsigned)k0 * 4u; u.add = 0; u.f = 1u; }
@@ -979,7 +992,7 @@ template <> struct SOp<UpA<float>> {                      // A(m = (n, hq, wq), 
 #else
   static constexpr bool OK = false;
 #endif
-  static bool ok(const F& f, int) { return f.g.sWl && f.g.sHl && f.g.sO && f.g.O >= MB_K && (long long)f.g.N * f.g.Hl * f.g.Wl * f.g.O < (1ll << 29); }
+  static bool ok(const F& f, int, int) { return f.g.sWl && f.g.sHl && f.g.sO && f.g.O >= MB_K && (long long)f.g.N * f.g.Hl * f.g.Wl * f.g.O < (1ll << 29); }
   static __device__ __forceinline__ const void* ptr(const F& f) { return f.x; }
   static __device__ __forceinline__ SSlot slot(const F& f, int zb, int m, bool ok, int ks) {
     const int wq = m & (f.g.Wl - 1), t = m >> (f.g.sWl - 1), hq = t & (f.g.Hl - 1), n = t >> (f.g.sHl - 1);
@@ -1008,7 +1021,7 @@ template <> struct SOp<UpB<float>> {                      // B(k = t4 * O + o, i
 #else
   static constexpr bool OK = false;
 #endif
-  static bool ok(const F& f, int) { return f.g.sO != 0 && f.g.O >= MB_K && (long long)f.g.O * f.g.I * 16 < (1ll << 29); }
+  static bool ok(const F& f, int, int) { return f.g.sO != 0 && f.g.O >= MB_K && (long long)f.g.O * f.g.I * 16 < (1ll << 29); }
   static __device__ __forceinline__ const void* ptr(const F& f) { return f.w; }
   static __device__ __forceinline__ SSlot slot(const F& f, int, int i, bool ok, int ks) { return {(ks * 16 * f.g.I + i) * 4, ok ? 0u : 1u}; }
   static __device__ __forceinline__ void seg(const F& f, int zb, int k0, SSeg& u) {
@@ -1025,7 +1038,7 @@ template <> struct SOp<UpB<float>> {                      // B(k = t4 * O + o, i
 template <> struct SOp<WgradA<float>> {                   // A(o, k = pixel) = low[pixel * O + o]
   using F = WgradA<float>;
   static constexpr bool OK = true;
-  static bool ok(const F& f, int) { return (long long)f.g.N * f.g.Hl * f.g.Wl * f.g.O < (1ll << 29); }
+  static bool ok(const F& f, int, int) { return (long long)f.g.N * f.g.Hl * f.g.Wl * f.g.O < (1ll << 29); }
   static __device__ __forceinline__ const void* ptr(const F& f) { return f.low; }
   static __device__ __forceinline__ SSlot slot(const F& f, int, int o, bool ok, int ks) { return {(ks * f.g.O + o) * 4, ok ? 0u : 1u}; }
   static __device__ __forceinline__ void seg(const F& f, int, int k0, SSeg& u) { u.id = 0; u.so = (unsigned)(k0 * f.g.O) * 4u; u.add = 0; u.f = 1u; }
@@ -1035,7 +1048,7 @@ template <> struct SOp<WgradB<float>> {                   // B(k = pixel (n, ho,
   // A k-tile = 16 consecutive output pixels: a piece of one output row (Wl >= 16; the piece's first wo goes into the scalar
   // offset) or 16 / Wl whole rows of one image (Wl < 16, Hl * Wl >= 16).  The segment is the k-tile itself.
   static constexpr bool OK = true;
-  static bool ok(const F& f, int) {
+  static bool ok(const F& f, int, int) {
 #ifdef RG_WGRADB_NARROW_OFF
     if (f.g.Wl < MB_K) return false;
 #endif
@@ -1081,7 +1094,7 @@ template <> struct SOp<WgradB<float>> {                   // B(k = pixel (n, ho,
 template <> struct SOp<FirstDownA> {                      // A(m = (n, ho, wo), k = ci * 16 + tap) = x[n][ci][2ho-1+kh][2wo-1+kw] (NCHW fp32 image)
   using F = FirstDownA;                                   // a k-tile = the 16 taps of one input channel: a slot's tap is fixed,
   static constexpr bool OK = true;                        // its padding a constant of the slot; the channel is the scalar offset
-  static bool ok(const F& f, int) { return f.g.sWl && f.g.sHl && (long long)f.g.N * f.g.I * f.g.Hh * f.g.Wh < (1ll << 29); }
+  static bool ok(const F& f, int, int) { return f.g.sWl && f.g.sHl && (long long)f.g.N * f.g.I * f.g.Hh * f.g.Wh < (1ll << 29); }
   static __device__ __forceinline__ const void* ptr(const F& f) { return f.x; }
   static __device__ __forceinline__ SSlot slot(const F& f, int, int m, bool ok, int ks) {
     const int wo = m & (f.g.Wl - 1), t = m >> (f.g.sWl - 1), ho = t & (f.g.Hl - 1), n = t >> (f.g.sHl - 1);
@@ -1096,7 +1109,7 @@ template <> struct SOp<FirstDownA> {                      // A(m = (n, ho, wo), 
 template <> struct SOp<WgradBNchw> {                      // B(k = pixel (n, ho, wo), col = i * 16 + tap) = x[n][i][2ho-1+kh][2wo-1+kw]
   using F = WgradBNchw;                                   // (the image-side layer's weight gradient; output rows of >= 16 pixels)
   static constexpr bool OK = true;
-  static bool ok(const F& f, int) { return f.g.sWl && f.g.sHl && f.g.Wl >= MB_K && (long long)f.g.N * f.g.I * f.g.Hh * f.g.Wh < (1ll << 29); }
+  static bool ok(const F& f, int, int) { return f.g.sWl && f.g.sHl && f.g.Wl >= MB_K && (long long)f.g.N * f.g.I * f.g.Hh * f.g.Wh < (1ll << 29); }
   static __device__ __forceinline__ const void* ptr(const F& f) { return f.high; }
   static __device__ __forceinline__ SSlot slot(const F& f, int, int col, bool ok, int ks) {
     const int i = col >> 4, kh = (col >> 2) & 3, kw = col & 3;
@@ -1114,10 +1127,26 @@ template <> struct SOp<WgradBNchw> {                      // B(k = pixel (n, ho,
     u.f = (ho == 0 ? 1u : 0u) | (ho == f.g.Hl - 1 ? 2u : 0u) | (wo0 == 0 ? 4u : 0u) | (wo0 == f.g.Wl - MB_K ? 8u : 0u) | 0x10u;
   }
 };
+template <> struct SOp<G0A<float>> {                      // A(n, e) = z[n * E + e]
+  using F = G0A<float>;
+  static constexpr bool OK = true;
+  static bool ok(const F& f, int rows, int) { return (long long)rows * f.E < (1ll << 29); }
+  static __device__ __forceinline__ const void* ptr(const F& f) { return f.z; }
+  static __device__ __forceinline__ SSlot slot(const F& f, int, int m, bool ok, int ks) { return {(m * f.E + ks) * 4, ok ? 0u : 1u}; }
+  static __device__ __forceinline__ void seg(const F&, int, int k0, SSeg& u) { u.id = 0; u.so = (unsigned)k0 * 4u; u.add = 0; u.f = 1u; }
+};
+template <> struct SOp<G0Bm<float>> {                     // B(e, col') = w[e * 16 C + col']
+  using F = G0Bm<float>;
+  static constexpr bool OK = true;
+  static bool ok(const F&, int cols, int K) { return (long long)cols * K < (1ll << 29); }
+  static __device__ __forceinline__ const void* ptr(const F& f) { return f.w; }
+  static __device__ __forceinline__ SSlot slot(const F& f, int, int colm, bool ok, int ks) { return {(ks * f.C * 16 + colm) * 4, ok ? 0u : 1u}; }
+  static __device__ __forceinline__ void seg(const F& f, int, int k0, SSeg& u) { u.id = 0; u.so = (unsigned)(k0 * f.C * 16) * 4u; u.add = 0; u.f = 1u; }
+};
 template <> struct SOp<LinA> {                            // A(m, k) = x[m * ldx + k]
   using F = LinA;
   static constexpr bool OK = true;
-  static bool ok(const F& f, int rows) { return (long long)rows * f.ldx < (1ll << 29); }
+  static bool ok(const F& f, int rows, int) { return (long long)rows * f.ldx < (1ll << 29); }
   static __device__ __forceinline__ const void* ptr(const F& f) { return f.x; }
   static __device__ __forceinline__ SSlot slot(const F& f, int, int m, bool ok, int ks) { return {(m * f.ldx + ks) * 4, ok ? 0u : 1u}; }
   static __device__ __forceinline__ void seg(const F&, int, int k0, SSeg& u) { u.id = 0; u.so = (unsigned)k0 * 4u; u.add = 0; u.f = 1u; }
@@ -1125,7 +1154,7 @@ template <> struct SOp<LinA> {                            // A(m, k) = x[m * ldx
 template <> struct SOp<LinB> {                            // B(k, j) = w[j * K + k]
   using F = LinB;
   static constexpr bool OK = true;
-  static bool ok(const F& f, int rows) { return (long long)rows * f.K < (1ll << 29); }
+  static bool ok(const F& f, int rows, int) { return (long long)rows * f.K < (1ll << 29); }
   static __device__ __forceinline__ const void* ptr(const F& f) { return f.w; }
   static __device__ __forceinline__ SSlot slot(const F& f, int, int j, bool ok, int ks) { return {(j * f.K + ks) * 4, ok ? 0u : 1u}; }
   static __device__ __forceinline__ void seg(const F&, int, int k0, SSeg& u) { u.id = 0; u.so = (unsigned)k0 * 4u; u.add = 0; u.f = 1u; }
@@ -1263,7 +1292,7 @@ static bool launch_structured(const char* name, FA fa, FB fb, SC sc, int M, int 
                               bool small, hipStream_t st) {
   if constexpr (SOp<FA>::OK && SOp<FB>::OK) {
 #ifndef RG_F32_NOSTRUCT
-    if (SOp<FA>::ok(fa, M) && SOp<FB>::ok(fb, N) && lg1(nbatch)) {
+    if (SOp<FA>::ok(fa, M, K) && SOp<FB>::ok(fb, N, K) && lg1(nbatch)) {
       const int lgb = lg1(nbatch) - 1;
       if (small) hipLaunchKernelGGL((gemm_mfma32s_kernel<32, 32, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, lgb, klen);
       else hipLaunchKernelGGL((gemm_mfma32s_kernel<64, 64, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, lgb, klen);
@@ -1405,7 +1434,7 @@ int rg_generic_skinny_wgrad(const void* low, const float* high_nchw, float* dw, 
 
 int rg_generic_g0_fwd(const float* z, const float* w, void* y, int N, int E, int C, int dtype, hipStream_t st) {
   RG_DISPATCH_DTYPE(dtype, T, {
-    return launch_generic<true, false>("g0_fwd(generic)", G0A<T>{z, E}, G0B<T>{w, C, lg1(C)}, RowMajorC<T>{(T*)y, 16 * C}, N,
+    return launch_generic<true, false>("g0_fwd(generic)", G0A<T>{z, E}, G0Bm<T>{w, C}, G0Cm<T>{(T*)y, C}, N,
                                        16 * C, E, 1, 1, st, std::is_same<T, float>::value);
   })
 }
