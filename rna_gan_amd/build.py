@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "librnagan_hip.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
-SOURCES = ["rg_api.hip", "rg_generic.hip", "rg_bn.hip", "rg_misc.hip", "rg_mfma.hip", "rg_conv8.hip", "rg_convp.hip", "rg_wgrad8.hip", "rg_skinny.hip", "rg_vae.hip", "rg_splitbn.hip", "rg_incep.hip", "rg_g0adam.hip"]
+SOURCES = ["rg_api.hip", "rg_generic.hip", "rg_bn.hip", "rg_misc.hip", "rg_mfma.hip", "rg_conv8.hip", "rg_convp.hip", "rg_convd.hip", "rg_wgrad8.hip", "rg_skinny.hip", "rg_vae.hip", "rg_splitbn.hip", "rg_incep.hip", "rg_g0adam.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
 

@@ -1192,7 +1192,7 @@ static bool use_v1() { return rg_option("conv_v1", 0) == 1; }
 
 // split-K policy of the DMA kernel: only when the grid cannot fill the chip (< 1 block per CU) and K is long
 // tile variant / split-K decision of the DMA kernel, shared by the launcher and by rg_mfma_conv_stats_rows
-struct GPlan { bool narrow, wide; int nsplit; bool c8; int bm, bn; bool n8, pp; };
+struct GPlan { bool narrow, wide; int nsplit; bool c8; int bm, bn; bool n8, pp, pd; };
 
 static int gather_split(int M, int Ncols, int nclass, int nkt, bool allow, int cap = 4, int min_kt = 16) {
   if (!allow) return 1;
@@ -1237,6 +1237,14 @@ static GPlan gather_plan(int mode, bool bf16_out, int M, int Ncols, int Cin, int
   if (rg_option("convp", 1) && !has_mask && bf16_out && mode == MODE_UP && nclass == 4 && taps == 4 && Ws > 0 &&
       rg_convp_supported(M, Ncols, Cin, Hs, Ws)) {
     pl.pp = true; pl.nsplit = 1; pl.bm = 256; pl.bn = 64;
+    return pl;
+  }
+  // pd: the 64 -> 128 channel stride-2 conv on a 128-pixel-wide input with its parity planes resident in LDS (rg_convd.hip;
+  // RNAGAN_CONVD=0: off).  Only where the implicit-GEMM kernel would not split K either (>= 256 of its 512-row tiles): the
+  // split / no-split answer of the plan queries then does not depend on which of the two kernels runs.
+  if (rg_option("convd", 1) && !masked && bf16_out && mode == MODE_DOWN && nclass == 1 && taps == 16 && Ws > 0 &&
+      rg_convd_supported(M, Ncols, Cin, Hs, Ws) && M / 512 >= conv8_blocks_target()) {
+    pl.pd = true; pl.nsplit = 1; pl.bm = 256; pl.bn = 128;
     return pl;
   }
   if (rg_option("narrow8", 0) && bf16_out && mode == MODE_UP && nclass == 4 && Ncols == 64 && rg_is_pow2(cpt) && M >= 512) {
@@ -1292,6 +1300,7 @@ int rg_mfma_conv_stats_rows(int up, int N, int Hlow, int Wlow, int O, int I) {
                          up ? Wlow : 2 * Wlow);
   if (pl.nsplit > 1) return 0;
   if (pl.pp) return 4 * rg_convp_tiles(M) * 2;
+  if (pl.pd) return rg_convd_stats_rows(M);
   if (pl.n8) return 4 * ((M + 511) / 512) * 8;
   if (pl.c8) return nclass * ((M + pl.bm - 1) / pl.bm) * (pl.bm / 128);
   const int bmm = (pl.narrow || pl.wide) ? 256 : 128, parts = pl.narrow ? 4 : 2;      // BM / wave-tile rows
@@ -1333,10 +1342,17 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   a2.xcd_swizzle = (xcd && grid.x % 8 == 0 && grid.x >= 16 && (xcd == 2 || a_bytes > b_bytes)) ? 1 : 0;
   // (measured and rejected for the 64-column tile: 2 waves with 128 x 64 wave tiles, 147-154 us vs 109-112 us)
   RG_REQUIRE(!g.mask_packed || pl.pp, RG_EUNSUPPORTED, "%s: packed mask bits without the patch-resident kernel", name);
-  RG_REQUIRE(!g.bwd_z || (c8 && nsplit == 1 && !g.mask && !g.affine && !pl.pp && !pl.n8 &&
+  RG_REQUIRE(!g.bwd_z || (c8 && nsplit == 1 && !g.mask && !g.affine && !pl.pp && !pl.n8 && !pl.pd &&
                           (g.bwd_half_m == 0 || g.bwd_half_m % bmm == 0)), RG_EUNSUPPORTED,
              "%s: BatchNorm-backward sums in the epilogue need the unsplit 8-wave kernel (rg_conv_bnbwd_rows)", name);
-  if (pl.pp) {
+  if (pl.pd) {
+    if constexpr (EPI == EPI_BF16 && MODE == MODE_DOWN) {
+      RG_REQUIRE(g.ldc == 128 && g.lgW == 6 && !g.mask && !g.affine && nsplit == 1, RG_EUNSUPPORTED, "%s: convd layout", name);
+      a2.g.tiles_n = 1;
+      a2.tiles_m = g.M / 256;
+      rg_convd_launch(&a2, st);
+    }
+  } else if (pl.pp) {
     if constexpr (EPI == EPI_BF16 && MODE == MODE_UP) {
       RG_REQUIRE(g.ldc == 64 && g.b_col == g.Cin, RG_EUNSUPPORTED, "%s: convp layout", name);
       a2.g.tiles_n = 1;

@@ -262,6 +262,44 @@ def test_convp_patch_resident_kernel(N, Ws, blocks):
             lib.rg_set_option(k, -1)
 
 
+@pytest.mark.parametrize("blocks", [256, 3])
+@pytest.mark.parametrize("N,Hs", [(1, 128), (3, 128), (2, 32), (5, 8)])
+def test_convd_plane_resident_kernel(N, Hs, blocks):
+    """The 64 -> 128 channel stride-2 conv on a 128-pixel-wide input with the input's parity planes resident in LDS
+    (rg_convd.hip): one and several tiles per workgroup (blocks = 3: persistent loop with the cross-tile prefetch), image
+    heights down to one tile per image (every row of the tile touches the padding), plain and with BatchNorm partial sums --
+    against the torch twin and against the implicit-GEMM kernel it replaces (same products, another summation order)."""
+    from rna_gan_amd import _abi
+    lib = _abi.load()
+    dtype = torch.bfloat16
+    ref, hip = RefOps(dtype), _hip(dtype)
+    O, I, Ws = 128, 64, 128
+    w = rnd((O, I, 4, 4), 1, (2.0 / (I * 16)) ** 0.5)
+    cr, ch = cwpair_tm(w)
+    x = rnd((N, Hs, Ws, I), 2).to(dtype)
+    M = N * (Hs // 2) * (Ws // 2)
+    try:
+        _abi.check(lib.rg_set_option(b"conv8_blocks", 1), "rg_set_option")      # (the kernel is selected from 256 tiles up)
+        _abi.check(lib.rg_set_option(b"convd_blocks", blocks), "rg_set_option")
+        outs = {}
+        for on in (1, 0):
+            _abi.check(lib.rg_set_option(b"convd", on), "rg_set_option")
+            y, st = hip.conv_down(dev(x), ch, want_stats=True)
+            outs[on] = (y, st, hip.conv_down(dev(x), ch))
+        y, st, yp = outs[1]
+        y_ref = ref.conv_down(x, cr)
+        check(y, y_ref, TOL[dtype], "conv_down")
+        assert torch.equal(y, yp)
+        check(y, outs[0][0], 4e-3, "conv_down against the implicit-GEMM kernel")
+        assert st is not None and st.shape[0] == M // 64, (None if st is None else st.shape, M // 64)
+        yf = y.float().reshape(-1, O)
+        check(st[:, 0, :].sum(0), yf.sum(0), 1e-4, "epilogue sum")
+        check(st[:, 1, :].sum(0), (yf * yf).sum(0), 1e-4, "epilogue sumsq")
+    finally:
+        for k in (b"convd", b"convd_blocks", b"conv8_blocks"):
+            lib.rg_set_option(k, -1)
+
+
 def test_first_down_sign_bits():
     """first_down writes the packed sign bits of its output itself (discriminator layer 0); they equal rg_sign_pack of the
     stored activation, and the data-gradient conv of layer 1 picks them up from the tensor."""
