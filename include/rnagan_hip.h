@@ -54,7 +54,8 @@ const char* rg_last_error(void);
 /* Kernel-selection knobs for A/B measurements inside one process (tools/, tests/): name = the part of the matching
  * environment variable after "RNAGAN_", lower case ("conv8", "conv8_blocks", "conv_tile", "xcd", "class_fast",
  * "wgrad_blocks", "wgrad8", ..., "f32mma": 0 sends the RG_F32 conv / dense launches back to the vector-ALU GEMM instead of the
- * f32 matrix-core one).  An option set here overrides the environment; value < 0 clears the override.  Returns RG_EINVAL for an
+ * f32 matrix-core one; "convd": 0 sends the 64 -> 128 channel stride-2 conv back from the parity-plane-resident kernel to the
+ * implicit-GEMM one, "convd_blocks": its persistent grid).  An option set here overrides the environment; value < 0 clears the override.  Returns RG_EINVAL for an
  * unknown name.  Not thread-safe against concurrent launches. */
 int rg_set_option(const char* name, int value);
 
