@@ -112,7 +112,11 @@ __global__ __launch_bounds__(512, 2) void convd_kernel(G2Args a2) {
     for (int j = 0; j < 4; ++j) acc[i][j] = cd_f32x4{0.f, 0.f, 0.f, 0.f};
   u32x4_t aF[2][4], bF[2][4];
 
+#ifdef CD_PROBE_NOREAD     // (measurement probe: fragments are never read)
+#define CD_DSR(dst, addr, off) asm volatile("" : "=v"(dst) : "v"(addr))
+#else
 #define CD_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#endif
 #define CD_WAIT8(N, A, B)                                                                                      \
   asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                     \
                : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3])::"memory")
@@ -190,7 +194,11 @@ __global__ __launch_bounds__(512, 2) void convd_kernel(G2Args a2) {
     }
   };
 
+#ifdef CD_PROBE_NOBAR      // (measurement probe: no workgroup barrier in the loop)
+#define CD_SYNC() do { __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
 #define CD_SYNC() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
   int wslot = 3, rslot = 0;                                // ring slot the next issue_b writes / the current step reads
   // ---- prologue: plane 0 of the first tile, weight slices of steps 0 .. 2; the first k-half's fragments
 #pragma unroll
