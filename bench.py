@@ -500,7 +500,7 @@ def measure_roofline(ops, device, one_step, step_ms):
                    "tflops": round(f["flops"] / (f["ms"] * 1e-3) / 1e12, 1) if f["ms"] > 0 else None,
                    "share_of_step": round(f["ms"] / step_ms, 3)}
     dom = max((k for k in rows if k != "bn_split_fused"), key=lambda k: rows[k]["ms_total"])
-    names = {"conv_fwd_dgrad": "conv8_kernel + convp_kernel + gather_gemm_dma_kernel (bf16 MFMA implicit-GEMM conv: fwd / dgrad / tangent)",
+    names = {"conv_fwd_dgrad": "conv8_kernel + convp_kernel + convd_kernel + gather_gemm_dma_kernel (bf16 MFMA implicit-GEMM / patch-resident conv: fwd / dgrad / tangent)",
              "conv_wgrad": "wgrad8_kernel / wgrad_dma_kernel (bf16 MFMA weight gradient) + reduce_slabs_kernel"}
     pmc_fam = {"conv_fwd_dgrad": "gather_gemm", "conv_wgrad": "wgrad_dma"}.get(dom)
     traffic, traffic_src = pmc_traffic(pmc_fam)

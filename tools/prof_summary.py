@@ -9,7 +9,7 @@ print("total ms", round(tot / 1e6, 3), "file", f)
 fam = {}
 for r in rows:
     n = r["Name"]
-    key = ("gather" if ("gather_gemm" in n or "conv8_kernel" in n) else "wgrad" if "wgrad" in n else "bn" if ("rowreduce" in n or "rowapply" in n or "colfinish" in n or "bn_" in n or "slab_bn" in n)
+    key = ("gather" if ("gather_gemm" in n or "conv8_kernel" in n or "convp_kernel" in n or "convd_kernel" in n) else "wgrad" if "wgrad" in n else "bn" if ("rowreduce" in n or "rowapply" in n or "colfinish" in n or "bn_" in n or "slab_bn" in n)
            else "reduce" if "reduce_" in n else "pack" if ("pack" in n or "widen" in n) else "adam" if "adam" in n.lower()
            else "image-side" if ("first_down" in n or "last_up" in n or "skinny" in n) else "other")
     fam[key] = fam.get(key, 0.0) + float(r["TotalDurationNs"])
