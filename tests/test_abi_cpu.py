@@ -34,3 +34,15 @@ def test_product_does_not_import_oracle():
         if fn.endswith(".py"):
             txt = open(os.path.join(pkg, fn)).read()
             assert "import oracle" not in txt and "from oracle" not in txt, fn
+
+
+def test_kernel_selection_options_are_known():
+    """rg_set_option is host-only: every knob the header, the tools and the tests name is accepted (and cleared again),
+    an unknown name is RG_EINVAL with a message."""
+    lib = _abi.load()
+    for name in (b"conv8", b"conv8_blocks", b"conv_tile", b"xcd", b"class_fast", b"wgrad_blocks", b"wgrad8", b"korder",
+                 b"convp", b"convp_blocks", b"convd", b"convd_blocks", b"fp8_mx", b"wgrad8n", b"f32mma"):
+        assert lib.rg_set_option(name, 1) == 0, name
+        assert lib.rg_set_option(name, -1) == 0, name
+    assert lib.rg_set_option(b"no_such_knob", 1) != 0
+    assert b"no_such_knob" in lib.rg_last_error()
