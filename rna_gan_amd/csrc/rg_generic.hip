@@ -102,26 +102,10 @@ typedef float mb_f32x16 __attribute__((ext_vector_type(16)));
 // The primary template wraps operator() (no saving); the gathered operands of the conv layers specialise it below.
 // P2 (compile-time): every divisor the functor uses is a power of two (pow2(f), decided once per launch: the kernel branches
 // once per k-tile between the two instantiations of its fetch code instead of once per index computation).
-// STRUCT (compile-time, with pow2(f) at run time): the operand's K axis is a sequence of SEGMENTS (a tap's channels, a
-// weight row) inside which consecutive k are consecutive elements, and a 16-deep k-tile never straddles two segments.  The
-// kernel then keeps one byte offset per fetch slot (recomputed only when the k-loop enters a new segment -- padding
-// predicates included: an out-of-image tap is the out-of-range sentinel, the buffer load returns 0) and adds the uniform
-// position inside the segment as the load's scalar offset: NO per-element vector arithmetic in the k-loop.
-//   rsrc(f) / seg(f, zb, k0, seg, soff_bytes) [uniform] / voff(f, zb, row, seg, kslot) [byte offset or OOB]
-constexpr unsigned RG_OOB = 0x80000000u;
-// members of an Op<> specialisation that has no structured form
-#define RG_OP_NO_STRUCT(FT)                                                                                          \
-  static constexpr bool STRUCT = false;                                                                               \
-  static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const FT&) { return __builtin_amdgcn_make_buffer_rsrc(nullptr, 0, 0, 0); } \
-  static __device__ __forceinline__ void seg(const FT&, int, int, int& sg, unsigned& so) { sg = 0; so = 0; }          \
-  static __device__ __forceinline__ unsigned voff(const FT&, int, const R&, int, int) { return RG_OOB; }
+// (Launches whose both operands are structured -- power-of-two conv geometry, dense layers -- take gemm_mfma32s_kernel below.)
 template <class F, bool A_SIDE> struct Op {
   struct R { int r; };
   struct C { int k; };
-  static constexpr bool STRUCT = false;
-  static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const F&) { return __builtin_amdgcn_make_buffer_rsrc(nullptr, 0, 0, 0); }
-  static __device__ __forceinline__ void seg(const F&, int, int, int& sg, unsigned& so) { sg = 0; so = 0; }
-  static __device__ __forceinline__ unsigned voff(const F&, int, const R&, int, int) { return RG_OOB; }
   static __device__ __forceinline__ bool pow2(const F&) { return true; }
   static bool fits32(const F&) { return true; }          // host: element offsets of the two-phase form fit an int
   template <bool P2> static __device__ __forceinline__ R row(const F&, int, int r) { return {r}; }
@@ -187,59 +171,12 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma32_kernel(FA fa, FB fb, SC sc
   float ra[NSA], rb[NSB];
   unsigned pa = 0, pb = 0;            // validity bits of the fetched slots: applied when the values are stashed, i.e. AFTER the
                                       // MFMAs of the current k-tile, so that nothing waits for the loads before them
-  // structured operands (Op<>::STRUCT, all-power-of-two geometry): one byte offset per slot, refreshed per segment
-  constexpr bool SA = OA::STRUCT, SB = OB::STRUCT;
-  unsigned voa[SA ? NSA : 1], vob[SB ? NSB : 1];
-  int sega = -1, segb = -1;
-  const __amdgpu_buffer_rsrc_t rsa = OA::rsrc(fa), rsb = OB::rsrc(fb);
-  auto fetch_sa = [&](int k0) __attribute__((always_inline)) {
-    int sg; unsigned so;
-    OA::seg(fa, zb, k0, sg, so);
-    if (sg != sega) {
-      sega = sg;
-#pragma unroll
-      for (int i = 0; i < NSA; ++i) {
-        const bool okr = A_KFAST ? oka[i] : oka[0];
-        const unsigned v = OA::voff(fa, zb, A_KFAST ? rowa[i] : rowa[0], sg, A_KFAST ? (tid & (MB_K - 1)) : tid / BM + KSA * i);
-        voa[i] = okr ? v : RG_OOB;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NSA; ++i) {
-      const int kslot = A_KFAST ? (tid & (MB_K - 1)) : tid / BM + KSA * i;
-      const unsigned v = k0 + kslot < k_end ? voa[i] : RG_OOB;
-      ra[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsa, (int)v, (int)so, 0));
-    }
-    pa = (1u << NSA) - 1u;
-  };
-  auto fetch_sb = [&](int k0) __attribute__((always_inline)) {
-    int sg; unsigned so;
-    OB::seg(fb, zb, k0, sg, so);
-    if (sg != segb) {
-      segb = sg;
-#pragma unroll
-      for (int i = 0; i < NSB; ++i) {
-        const bool okr = B_KFAST ? okb[i] : okb[0];
-        const unsigned v = OB::voff(fb, zb, B_KFAST ? rowb[i] : rowb[0], sg, B_KFAST ? (tid & (MB_K - 1)) : tid / BN + KSB * i);
-        vob[i] = okr ? v : RG_OOB;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NSB; ++i) {
-      const int kslot = B_KFAST ? (tid & (MB_K - 1)) : tid / BN + KSB * i;
-      const unsigned v = k0 + kslot < k_end ? vob[i] : RG_OOB;
-      rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsb, (int)v, (int)so, 0));
-    }
-    pb = (1u << NSB) - 1u;
-  };
   // (always_inline: an out-of-line lambda body would reach everything it captures -- the functors, the register arrays --
   // through memory, i.e. scratch loads in the k-loop)
   auto fetch_t = [&](int k0, auto P2) __attribute__((always_inline)) {
     constexpr bool p = decltype(P2)::value;
     pa = 0; pb = 0;
-    if (p && SA) {
-      fetch_sa(k0);
-    } else if (A_KFAST) {
+    if (A_KFAST) {
       const int k = k0 + (tid & (MB_K - 1));
       const bool kv = k < k_end;
       const typename OA::C c = OA::template col<p>(fa, zb, kv ? k : k_begin);
@@ -259,9 +196,7 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma32_kernel(FA fa, FB fb, SC sc
         pa |= ((unsigned)kv & (unsigned)oka[0] & (unsigned)ok) << i;
       }
     }
-    if (p && SB) {
-      fetch_sb(k0);
-    } else if (B_KFAST) {
+    if (B_KFAST) {
       const int k = k0 + (tid & (MB_K - 1));
       const bool kv = k < k_end;
       const typename OB::C c = OB::template col<p>(fb, zb, kv ? k : k_begin);
@@ -743,21 +678,8 @@ struct LinC {
 template <typename T> struct Op<DownA<T>, true> {
   struct R { int base, h0, w0; };
   struct C { int off, dh, dw; };
-  static constexpr bool STRUCT = std::is_same<T, float>::value;
   static __device__ __forceinline__ bool pow2(const DownA<T>& f) { return f.g.sWl && f.g.sHl && f.g.sI && f.g.I >= MB_K; }
   static bool fits32(const DownA<T>& f) { return (long long)f.g.N * f.g.Hh * f.g.Wh * f.g.I < (1ll << 29); }
-  static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const DownA<T>& f) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)f.x, 0, 0x7ffffff0, 0x00020000);
-  }
-  static __device__ __forceinline__ void seg(const DownA<T>& f, int, int k0, int& sg, unsigned& so) {
-    sg = k0 >> (f.g.sI - 1);                                   // the tap; its I channels are the segment
-    so = (unsigned)(k0 & (f.g.I - 1)) * 4u;
-  }
-  static __device__ __forceinline__ unsigned voff(const DownA<T>& f, int, const R& r, int sg, int ks) {
-    const int dh = sg >> 2, dw = sg & 3, hi = r.h0 + dh, wi = r.w0 + dw;
-    const bool ok = (int)((unsigned)hi < (unsigned)f.g.Hh) & (int)((unsigned)wi < (unsigned)f.g.Wh);
-    return ok ? (unsigned)(r.base + ((((dh << f.g.sWl) + dw) << (f.g.sI - 1)) + ks)) * 4u : RG_OOB;
-  }
   template <bool P2> static __device__ __forceinline__ R row(const DownA<T>& f, int, int m) {
     int wo, t, ho, n;
     rg_divmod_t<P2>(m, f.g.Wl, f.g.sWl, t, wo); rg_divmod_t<P2>(t, f.g.Hl, f.g.sHl, n, ho);
@@ -783,26 +705,6 @@ template <typename T> struct Op<UpA<T>, true> {
   struct C { int off, dh, dw; };
   static __device__ __forceinline__ bool pow2(const UpA<T>& f) { return f.g.sWl && f.g.sHl && f.g.sO && f.g.O >= MB_K; }
   static bool fits32(const UpA<T>& f) { return (long long)f.g.N * f.g.Hl * f.g.Wl * f.g.O < (1ll << 29); }
-#ifndef RG_UP_KORDER_OLD
-  static constexpr bool STRUCT = std::is_same<T, float>::value;
-  static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const UpA<T>& f) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)f.x, 0, 0x7ffffff0, 0x00020000);
-  }
-  static __device__ __forceinline__ void seg(const UpA<T>& f, int, int k0, int& sg, unsigned& so) {
-    sg = k0 >> (f.g.sO - 1);                                   // t4 (tap-major k order); its O channels are the segment
-    so = (unsigned)(k0 & (f.g.O - 1)) * 4u;
-  }
-  static __device__ __forceinline__ unsigned voff(const UpA<T>& f, int zb, const R& r, int sg, int ks) {
-    int kh, kw, sh, sw;
-    up_tap(zb >> 1, sg >> 1, 0, kh, sh);
-    up_tap(zb & 1, sg & 1, 0, kw, sw);
-    const int ho = r.hq + sh, wo = r.wq + sw;
-    const bool ok = (int)((unsigned)ho < (unsigned)f.g.Hl) & (int)((unsigned)wo < (unsigned)f.g.Wl);
-    return ok ? (unsigned)(r.base + ((((sh << (f.g.sWl - 1)) + sw) << (f.g.sO - 1)) + ks)) * 4u : RG_OOB;
-  }
-#else
-  RG_OP_NO_STRUCT(UpA<T>)
-#endif
   template <bool P2> static __device__ __forceinline__ R row(const UpA<T>& f, int, int m) {
     int wq, t, hq, n;
     rg_divmod_t<P2>(m, f.g.Wl, f.g.sWl, t, wq); rg_divmod_t<P2>(t, f.g.Hl, f.g.sHl, n, hq);
@@ -831,7 +733,6 @@ template <typename T> struct Op<UpA<T>, true> {
 template <typename T> struct Op<WgradB<T>, false> {       // B side: operator()(zb, pix = k, col = n)
   struct R { int off, kh, kw; };                          // of the output column (tap, i)
   struct C { int base, h0, w0; };                         // of the pixel
-  RG_OP_NO_STRUCT(WgradB<T>)
   static __device__ __forceinline__ bool pow2(const WgradB<T>& f) { return f.g.sWl && f.g.sHl && f.g.sI; }
   static bool fits32(const WgradB<T>& f) { return (long long)f.g.N * f.g.Hh * f.g.Wh * f.g.I < (1ll << 31); }
   template <bool P2> static __device__ __forceinline__ R row(const WgradB<T>& f, int, int col) {
@@ -858,14 +759,8 @@ template <typename T> struct Op<WgradB<T>, false> {       // B side: operator()(
 template <typename T> struct Op<DownB<T>, false> {        // operator()(zb, k, o) = w[o * 16 I + k]
   struct R { int base; };
   struct C { int k; };
-  static constexpr bool STRUCT = std::is_same<T, float>::value;
   static __device__ __forceinline__ bool pow2(const DownB<T>&) { return true; }
   static bool fits32(const DownB<T>& f) { return (long long)f.g.O * f.g.I * 16 < (1ll << 29); }
-  static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const DownB<T>& f) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)f.w, 0, 0x7ffffff0, 0x00020000);
-  }
-  static __device__ __forceinline__ void seg(const DownB<T>&, int, int k0, int& sg, unsigned& so) { sg = 0; so = (unsigned)k0 * 4u; }
-  static __device__ __forceinline__ unsigned voff(const DownB<T>&, int, const R& r, int, int ks) { return (unsigned)(r.base + ks) * 4u; }
   template <bool P2> static __device__ __forceinline__ R row(const DownB<T>& f, int, int o) { return {o * f.g.I * 16}; }
   template <bool P2> static __device__ __forceinline__ C col(const DownB<T>&, int, int k) { return {k}; }
   static __device__ __forceinline__ float at(const DownB<T>& f, int, const R& r, const C& c, bool& ok) {
@@ -878,24 +773,6 @@ template <typename T> struct Op<UpB<T>, false> {          // operator()(zb, k, i
   struct C { int off; };
   static __device__ __forceinline__ bool pow2(const UpB<T>& f) { return f.g.sO != 0 && f.g.O >= MB_K; }
   static bool fits32(const UpB<T>& f) { return (long long)f.g.O * f.g.I * 16 < (1ll << 29); }
-#ifndef RG_UP_KORDER_OLD
-  static constexpr bool STRUCT = std::is_same<T, float>::value;
-  static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const UpB<T>& f) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)f.w, 0, 0x7ffffff0, 0x00020000);
-  }
-  static __device__ __forceinline__ void seg(const UpB<T>& f, int zb, int k0, int& sg, unsigned& so) {
-    sg = k0 >> (f.g.sO - 1);                                   // t4; w[(o * 16 + tap) * I + i] with o = o0 + the slot's k offset
-    int kh, kw, d;
-    up_tap(zb >> 1, sg >> 1, 0, kh, d);
-    up_tap(zb & 1, sg & 1, 0, kw, d);
-    so = (unsigned)(((k0 & (f.g.O - 1)) * 16 + kh * 4 + kw) * f.g.I) * 4u;
-  }
-  static __device__ __forceinline__ unsigned voff(const UpB<T>& f, int, const R& r, int, int ks) {
-    return (unsigned)(ks * 16 * f.g.I + r.i) * 4u;
-  }
-#else
-  RG_OP_NO_STRUCT(UpB<T>)
-#endif
   template <bool P2> static __device__ __forceinline__ R row(const UpB<T>&, int, int i) { return {i}; }
   template <bool P2> static __device__ __forceinline__ C col(const UpB<T>& f, int zb, int k) {
     int o, t4, kh, kw, d;
@@ -917,19 +794,8 @@ template <typename T> struct Op<UpB<T>, false> {          // operator()(zb, k, i
 template <typename T> struct Op<WgradA<T>, true> {
   struct R { int o; };
   struct C { int poff; };
-  static constexpr bool STRUCT = std::is_same<T, float>::value;
   static __device__ __forceinline__ bool pow2(const WgradA<T>& f) { return f.g.sO != 0; }
   static bool fits32(const WgradA<T>& f) { return (long long)f.g.N * f.g.Hl * f.g.Wl * f.g.O < (1ll << 29); }
-  static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const WgradA<T>& f) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)f.low, 0, 0x7ffffff0, 0x00020000);
-  }
-  static __device__ __forceinline__ void seg(const WgradA<T>& f, int, int k0, int& sg, unsigned& so) {
-    sg = 0;                                                    // low[pix][o]: one segment, the k-tile's first pixel row as offset
-    so = ((unsigned)k0 << (f.g.sO - 1)) * 4u;
-  }
-  static __device__ __forceinline__ unsigned voff(const WgradA<T>& f, int, const R& r, int, int ks) {
-    return (unsigned)((ks << (f.g.sO - 1)) + r.o) * 4u;
-  }
   template <bool P2> static __device__ __forceinline__ R row(const WgradA<T>&, int, int o) { return {o}; }
   template <bool P2> static __device__ __forceinline__ C col(const WgradA<T>& f, int, int pix) {
     return {P2 ? pix << (f.g.sO - 1) : pix * f.g.O};
