@@ -33,6 +33,10 @@ import subprocess
 import sys
 import time
 
+# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise); the launchers
+# export it, this is the default for a bare `torchrun bench.py` (read by the HSA runtime when HIP initialises: before torch)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
