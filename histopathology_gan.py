@@ -17,6 +17,8 @@ import datetime
 import json
 import os
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL on this driver stack (before torch initialises HIP)
+
 import numpy as np
 import torch
 import torch.nn as nn
