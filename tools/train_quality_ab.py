@@ -70,16 +70,25 @@ def make_slides(n_slides, tiles_per_slide, size, rna_features, seed, mix_seed=77
                 img += (0.04 + 0.05 * attr[4]) * np.sin(2 * np.pi * (fx * xx + fy * yy) + ph)[None] * np.array([1.0, 0.6, 0.8], dtype=np.float32)[:, None, None]
             n_nuc = rng.poisson(2 + 22 * attr[0] * (size / 64.0) ** 2)
             nuc = np.array([0.35 - 0.2 * attr[3], 0.20 - 0.1 * attr[3], 0.55 - 0.15 * attr[3]], dtype=np.float32)
+            if n_nuc > 0:
+                img = img.astype(np.float64)          # (what the whole-image blend with the float64 mask made of it: same values)
             for _n in range(n_nuc):
                 cx, cy = rng.uniform(0, size, size=2)
                 r = (1.5 + 3.5 * attr[1]) * (size / 64.0) * rng.uniform(0.7, 1.3)
                 el = 1.0 + 1.5 * attr[5] * rng.uniform(0, 1)
                 th = rng.uniform(0, np.pi)
-                dx, dy = xx - cx, yy - cy
+                # (the blend is the identity where m = 0, i.e. outside the ellipse u^2 + v^2 < 1.5: only its bounding box is touched --
+                # bit-identical to the whole-image form, 4-60 x faster at 256 x 256)
+                hb = int(np.ceil(1.25 * r * el)) + 2
+                y0, y1 = max(0, int(cy) - hb), min(size, int(cy) + hb + 1)
+                x0, x1 = max(0, int(cx) - hb), min(size, int(cx) + hb + 1)
+                if y0 >= y1 or x0 >= x1:
+                    continue
+                dx, dy = xx[y0:y1, x0:x1] - cx, yy[y0:y1, x0:x1] - cy
                 u = (dx * np.cos(th) + dy * np.sin(th)) / (r * el)
                 v = (-dx * np.sin(th) + dy * np.cos(th)) / r
                 m = np.clip(1.5 - (u * u + v * v), 0, 1)[None]
-                img = img * (1 - m) + nuc[:, None, None] * m
+                img[:, y0:y1, x0:x1] = img[:, y0:y1, x0:x1] * (1 - m) + nuc[:, None, None] * m
             imgs[k] = np.clip(img, 0, 1)
             rna[k] = row
             sid[k] = s
@@ -288,11 +297,15 @@ def main():
     ap.add_argument("--n-eval", type=int, default=2048)
     ap.add_argument("--step", type=int, default=64)
     ap.add_argument("--enc", type=int, default=2048)
+    ap.add_argument("--n-slides", type=int, default=64)
+    ap.add_argument("--tiles-per-slide", type=int, default=48)
+    ap.add_argument("--rna-features", type=int, default=512)
     ap.add_argument("--no-inception", action="store_true")
     ap.add_argument("--out", default="gpurun_out/train_quality_ab.json")
     args = ap.parse_args()
     log = lambda *a: print(*a, file=sys.stderr, flush=True)
     recs = [run_ab(lt, size=args.size, step=args.step, enc=args.enc, iters=args.iters, batch=args.batch, n_eval=args.n_eval,
+                   rna_features=args.rna_features, n_slides=args.n_slides, tiles_per_slide=args.tiles_per_slide,
                    inception=not args.no_inception, log=log) for lt in args.loss_types.split(",")]
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     with open(args.out, "w") as f:
