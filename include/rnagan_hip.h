@@ -55,7 +55,8 @@ const char* rg_last_error(void);
  * environment variable after "RNAGAN_", lower case ("conv8", "conv8_blocks", "conv_tile", "xcd", "class_fast",
  * "wgrad_blocks", "wgrad8", ..., "f32mma": 0 sends the RG_F32 conv / dense launches back to the vector-ALU GEMM instead of the
  * f32 matrix-core one; "convd": 0 sends the 64 -> 128 channel stride-2 conv back from the parity-plane-resident kernel to the
- * implicit-GEMM one, "convd_blocks": its persistent grid).  An option set here overrides the environment; value < 0 clears the override.  Returns RG_EINVAL for an
+ * implicit-GEMM one, "convd_blocks": its persistent grid; "skinny128": 0 sends the image-side layers of 256 x 256 images back
+ * from the control-flow-free row kernels to the general row-staged ones).  An option set here overrides the environment; value < 0 clears the override.  Returns RG_EINVAL for an
  * unknown name.  Not thread-safe against concurrent launches. */
 int rg_set_option(const char* name, int value);
 

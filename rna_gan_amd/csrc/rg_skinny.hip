@@ -785,8 +785,463 @@ __global__ __launch_bounds__(256) void skinny_wgrad_kernel(const T* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The three row-staged kernels again for the benchmark's geometry: 256 x 256 images, so an output / low-resolution row is
+// Wo = 128 pixels = ONE unit, no column chunks, the halo columns are always padding.  Same arithmetic, same LDS images and the
+// same summation order as the kernels above (bit-identical results; tests/test_fullsize_gpu.py compares the two forms), but a
+// loop body WITHOUT control flow around vector-memory instructions.  In the general kernels every load sits in an exec-masked
+// branch (chunk width, image border, edge lanes); hipcc's waitcnt insertion merges the counter state over those branches
+// conservatively and the ISA shows `s_waitcnt vmcnt(0)` in front of each unit's loads and between them: every unit drained
+// its own output STORES (and loaded its rows one after the other) before the next unit's loads were issued -- 3.3-3.5 TB/s.
+// Here rows outside the image are read from a clamped address and zeroed by a select when they are staged, loads are issued
+// unconditionally PF units ahead, and the waits in front of a unit's staging are counted (`vmcnt(N)` with the younger loads
+// and stores left in flight).
+constexpr int R128_H = 256, R128_W = 256, R128_HO = 128, R128_WO = 128;
+
+struct Fd128Rows { float4 v[3]; };
+// thread (wave kh, lane m): input row 2*ho - 1 + kh of the three channels, columns 4m .. 4m + 3
+__device__ __forceinline__ void fd128_load(Fd128Rows& r, const float* __restrict__ x, int u, int wave, int lane) {
+  const int n = u >> 7, ho = u & 127;
+  int hi = 2 * ho - 1 + wave;
+  hi = hi < 0 ? 0 : (hi > R128_H - 1 ? R128_H - 1 : hi);
+  const float* p = x + ((size_t)n * SK_I * R128_H + hi) * R128_W + 4 * lane;
+  r.v[0] = *reinterpret_cast<const float4*>(p);
+  r.v[1] = *reinterpret_cast<const float4*>(p + R128_H * R128_W);
+  r.v[2] = *reinterpret_cast<const float4*>(p + 2 * R128_H * R128_W);
+}
+__device__ __forceinline__ bool fd128_row_ok(int u, int wave) { return (unsigned)(2 * (u & 127) - 1 + wave) < (unsigned)R128_H; }
+template <int PTS>
+__device__ __forceinline__ void fd128_scatter(uint16_t* pt, const Fd128Rows& r, bool ok, int wave, int lane) {
+#pragma unroll
+  for (int ci = 0; ci < SK_I; ++ci) {
+    float4 v = r.v[ci];
+    v.x = ok ? v.x : 0.f; v.y = ok ? v.y : 0.f; v.z = ok ? v.z : 0.f; v.w = ok ? v.w : 0.f;
+    uint16_t* k0 = pt + (4 * (4 * ci + wave)) * PTS + 2 * lane;         // k = 4*row + kw, row = ci*4 + kh
+    *reinterpret_cast<uint32_t*>(k0 + 1 * PTS) = sk_pack2(v.x, v.z);
+    *reinterpret_cast<uint32_t*>(k0 + 2 * PTS) = sk_pack2(v.y, v.w);
+    k0[3 * PTS] = f32_to_bf16(v.z);
+    if (lane > 0) k0[3 * PTS - 1] = f32_to_bf16(v.x);
+    k0[1] = f32_to_bf16(v.y);
+    if (lane < 63) k0[2] = f32_to_bf16(v.w);
+  }
+}
+// the two patch columns outside the image (kw = 0 at pixel 0, kw = 3 at pixel 127) are never written by fd128_scatter
+template <int PTS>
+__device__ __forceinline__ void fd128_zero_edges(uint16_t* pt, int t) {
+  if (t < 24) {
+    const int row = t >> 1;
+    if (t & 1) pt[(4 * row + 3) * PTS + R128_WO - 1] = 0;
+    else       pt[(4 * row) * PTS] = 0;
+  }
+}
+
+template <bool BITS, bool MASK>
+__global__ __launch_bounds__(256, 3) void first_down_rows128_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                    const float* __restrict__ bias, uint16_t* __restrict__ y,
+                                                                    unsigned long long* __restrict__ bits,
+                                                                    const unsigned long long* __restrict__ mask_bits,
+                                                                    float mslope, float slope, int nunits) {
+  __shared__ __attribute__((aligned(16))) uint16_t pt[2][SK_K * FD_PTS];     // 2 x 15 KB: one barrier per unit
+  __shared__ __attribute__((aligned(16))) uint16_t ot[4 * 32 * FD_OTS];      // 18 KB
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  sk_bf16x8 wa[2][SK_I];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int ci = 0; ci < SK_I; ++ci) {
+      const float4* wp = reinterpret_cast<const float4*>(w + ((size_t)(32 * i + r) * SK_I + ci) * 16 + 8 * h);
+      float4 a = wp[0], b = wp[1];
+      uint4 v = make_uint4(sk_pack2(a.x, a.y), sk_pack2(a.z, a.w), sk_pack2(b.x, b.y), sk_pack2(b.z, b.w));
+      wa[i][ci] = __builtin_bit_cast(sk_bf16x8, v);
+    }
+  float bs[2][4][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bs[i][g4][e] = bias ? bias[32 * i + 8 * g4 + 4 * h + e] : 0.f;
+  const int grp16 = lane >> 4, idx = lane & 15, q4 = idx >> 2, p4 = idx & 3, fh = grp16 >> 1, cb = grp16 & 1;
+  uint16_t* otw = ot + wave * 32 * FD_OTS;
+  const int per = (nunits + gridDim.x - 1) / gridDim.x;
+  const int u0 = blockIdx.x * per, u1 = min(nunits, u0 + per);
+  if (u0 >= u1) return;
+  fd128_zero_edges<FD_PTS>(pt[0], t);
+  fd128_zero_edges<FD_PTS>(pt[1], t);
+  Fd128Rows ra, rb;                       // units u and u + 1 in flight (no register copies: a unit's registers are re-loaded
+                                          // for unit u + 2 right behind the barrier that follows their staging)
+  fd128_load(ra, x, u0, wave, lane);
+  fd128_load(rb, x, min(u0 + 1, u1 - 1), wave, lane);
+  auto step = [&](int u, Fd128Rows& cur, uint16_t* ptu) __attribute__((always_inline)) {
+    fd128_scatter<FD_PTS>(ptu, cur, fd128_row_ok(u, wave), wave, lane);
+    __syncthreads();
+    unsigned long long mword = ~0ull;
+    if (MASK) mword = mask_bits[(size_t)u * R128_WO + wave * 32 + r];   // in front of the row loads: waited for with them in flight
+    fd128_load(cur, x, min(u + 2, u1 - 1), wave, lane);
+    sk_f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < SK_I; ++ci) {
+      const uint16_t* bp = ptu + (16 * ci + 8 * fh + q4) * FD_PTS + wave * 32 + 16 * cb + 4 * p4;
+      sk_s16x4 lo = sk_tr_read(bp), hi = sk_tr_read(bp + 4 * FD_PTS);
+      sk_bf16x8 pb = __builtin_bit_cast(sk_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i][ci], pb, acc[i], 0, 0, 0);
+    }
+    unsigned nib = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float v0 = lrelu_f(acc[i][4 * g4 + 0] + bs[i][g4][0], slope), v1 = lrelu_f(acc[i][4 * g4 + 1] + bs[i][g4][1], slope);
+        float v2 = lrelu_f(acc[i][4 * g4 + 2] + bs[i][g4][2], slope), v3 = lrelu_f(acc[i][4 * g4 + 3] + bs[i][g4][3], slope);
+        if (MASK) {
+          const unsigned mb = (unsigned)(mword >> (32 * i + 8 * g4 + 4 * h)) & 15u;
+          v0 *= (mb & 1u) ? 1.f : mslope; v1 *= (mb & 2u) ? 1.f : mslope;
+          v2 *= (mb & 4u) ? 1.f : mslope; v3 *= (mb & 8u) ? 1.f : mslope;
+        }
+        const uint32_t p01 = sk_pack2(v0, v1), p23 = sk_pack2(v2, v3);
+        *reinterpret_cast<uint2*>(otw + r * FD_OTS + 32 * i + 8 * g4 + 4 * h) = make_uint2(p01, p23);
+        if (BITS) {
+          const unsigned b = (sk_pos16(p01) ? 1u : 0u) | (sk_pos16(p01 >> 16) ? 2u : 0u) | (sk_pos16(p23) ? 4u : 0u) |
+                             (sk_pos16(p23 >> 16) ? 8u : 0u);
+          nib |= b << (4 * (4 * i + g4));
+        }
+      }
+    if (BITS) {
+      const unsigned other = (unsigned)__shfl_xor((int)nib, 32, 64);
+      const unsigned lo = h ? other : nib, hi = h ? nib : other;
+      unsigned long long word = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        word |= ((unsigned long long)(((lo >> (4 * k)) & 15u) | (((hi >> (4 * k)) & 15u) << 4))) << (8 * k);
+      // every lane stores (lanes r and r + 32 the same word to the same address): no exec-masked branch around the store
+      bits[(size_t)u * R128_WO + wave * 32 + r] = word;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // wave-private tile: in-order DS pipe, no barrier needed
+    uint16_t* yo = y + ((size_t)u * R128_WO + wave * 32) * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int sidx = j * 64 + lane, px = sidx >> 3, c = sidx & 7;
+      *reinterpret_cast<uint4*>(yo + px * 64 + c * 8) = *reinterpret_cast<const uint4*>(otw + px * FD_OTS + c * 8);
+    }
+  };
+  // The first pair is peeled so that the loop is ENTERED with the same vector-memory operations pending as at its back edge
+  // (loads, stores, loads, stores): hipcc merges the two states, and with only the prologue's loads pending at the entry it
+  // would wait for the younger unit's loads before staging the older one (vmcnt(5) instead of vmcnt(15) in the ISA).
+  int u = u0;
+  if (u + 1 < u1) {
+    step(u, ra, pt[0]);
+    step(u + 1, rb, pt[1]);
+    u += 2;
+#pragma unroll 1
+    for (; u + 1 < u1; u += 2) {
+      step(u, ra, pt[0]);
+      step(u + 1, rb, pt[1]);
+    }
+  }
+  if (u < u1) step(u, ra, pt[0]);          // odd tail outside the loop: the loop body stays free of control flow
+}
+
+// last_up at Ho = Wo = 128: a strip = 16 whole low-resolution rows (+ a halo row above and below); the halo PIXELS left and
+// right of a row are padding (zeroed once per ring slot).  Two input rows in flight in registers behind the one being staged.
+struct Lu128Row { uint4 v[4]; };
+__device__ __forceinline__ void lu128_load(Lu128Row& r, const uint16_t* __restrict__ xn, int row, int t) {
+  row = row < 0 ? 0 : (row > R128_HO - 1 ? R128_HO - 1 : row);
+  const uint16_t* src = xn + (size_t)row * R128_WO * 64 + (size_t)t * 8;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r.v[j] = *reinterpret_cast<const uint4*>(src + 2048 * j);
+}
+
+template <bool PRE, bool TB, bool PART>
+__global__ __launch_bounds__(256, 2) void last_up_rows128_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, float* __restrict__ y,
+                                                                 int apply_tanh, int nstrips, LuPre pre, LuPost post) {
+  constexpr int Ho = R128_HO, Wo = R128_WO, H = R128_H, W = R128_W, STRIP = 16, SLOT = (LU_MAXC + 2) * LU_PXS;
+  __shared__ __attribute__((aligned(16))) uint16_t ring[3 * SLOT];                       // 54.8 KB
+  __shared__ __attribute__((aligned(16))) float outt[6 * LU_OS];                          // 6.1 KB
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lp = lane & 15, lq = lane >> 4;
+  const int ni = lp >> 2, nph = (lp >> 1) & 1, npw = lp & 1;
+  sk_bf16x8 wf[3][3][2];
+#pragma unroll
+  for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+    for (int dw = 0; dw < 3; ++dw) {
+      const int kh = nph + 3 - 2 * dh, kw = npw + 3 - 2 * dw;
+      const bool ok = ni < SK_I && (unsigned)kh < 4u && (unsigned)kw < 4u;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        if (ok) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = w[(size_t)(32 * c + 8 * lq + j) * SK_K + ni * 16 + kh * 4 + kw];
+        }
+        uint4 pk = make_uint4(sk_pack2(v[0], v[1]), sk_pack2(v[2], v[3]), sk_pack2(v[4], v[5]), sk_pack2(v[6], v[7]));
+        wf[dh][dw][c] = __builtin_bit_cast(sk_bf16x8, pk);
+      }
+    }
+  const float bv = (bias && ni < SK_I) ? bias[ni] : 0.f;
+  float pm[8], pr[8], pb[8];
+  if (PRE) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = (t & 7) * 8 + j;
+      pm[j] = pre.mean[c]; pr[j] = pre.invstd[c] * pre.gamma[c]; pb[j] = pre.beta[c];
+    }
+  }
+  auto bn8 = [&](uint4& v) {
+    uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float lo = lrelu_f((bf16_to_f32((uint16_t)d[j]) - pm[2 * j]) * pr[2 * j] + pb[2 * j], pre.slope);
+      const float hi = lrelu_f((bf16_to_f32((uint16_t)(d[j] >> 16)) - pm[2 * j + 1]) * pr[2 * j + 1] + pb[2 * j + 1], pre.slope);
+      d[j] = sk_pack2(lo, hi);
+    }
+    v = make_uint4(d[0], d[1], d[2], d[3]);
+  };
+  float pc0 = 0.f, pc1 = 0.f, pc2 = 0.f, pq = 0.f;
+  // the halo pixels (LDS pixel 0 and Wo + 1) of the three ring slots: padding, never written again
+  if (t < 48) *reinterpret_cast<uint4*>(ring + (t >> 4) * SLOT + (((t >> 3) & 1) ? Wo + 1 : 0) * LU_PXS + (t & 7) * 8) =
+      make_uint4(0, 0, 0, 0);
+  // write-out map of one output row group (3 channels x 2 row parities x 256 floats = 384 float4): every thread one float4
+  // of rows 0..3 and one float2 of rows 4, 5 -- no partial trip through a loop
+  const int rid4 = t >> 6, m4 = t & 63;                  // float4 m4 of staged row rid4
+  const int rid2 = 4 + (t >> 7), m2 = t & 127;           // float2 m2 of staged row rid2
+
+  for (int sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+    const int hq0 = (sidx & 7) * STRIP, n = sidx >> 3;
+    const uint16_t* xn = x + (size_t)n * Ho * Wo * 64;
+    Lu128Row ra, rb;
+    lu128_load(ra, xn, hq0 - 1, t);
+    lu128_load(rb, xn, hq0, t);
+    // step k: stage row hq0 - 1 + k (held in `cur`) into ring slot k % 3, re-load `cur` with row hq0 + 1 + k (two steps ahead),
+    // and for k >= 2 produce output row group hq0 + k - 2 from the three slots
+    auto step = [&](int k, Lu128Row& cur, bool compute) __attribute__((always_inline)) {
+      uint16_t* slot = ring + (k % 3) * SLOT;
+      {
+        const bool row_ok = (unsigned)(hq0 - 1 + k) < (unsigned)Ho;
+        uint16_t* d = slot + (1 + (t >> 3)) * LU_PXS + (t & 7) * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          uint4 v = cur.v[j];
+          if (PRE) bn8(v);
+          v.x = row_ok ? v.x : 0u; v.y = row_ok ? v.y : 0u; v.z = row_ok ? v.z : 0u; v.w = row_ok ? v.w : 0u;
+          *reinterpret_cast<uint4*>(d + 32 * j * LU_PXS) = v;
+        }
+      }
+      __syncthreads();
+      lu128_load(cur, xn, hq0 + 1 + k, t);         // beyond the strip's halo: a harmless clamped re-read
+      if (compute) {
+        const int hq = hq0 + k - 2;
+        // the tanh-backward factor's image values: issued before the MFMAs, used behind the barrier
+        float4 im4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2 im2 = make_float2(0.f, 0.f);
+        const size_t oi4 = (((size_t)n * SK_I + (rid4 >> 1)) * H + 2 * hq + (rid4 & 1)) * W + 4 * m4;
+        const size_t oi2 = (((size_t)n * SK_I + (rid2 >> 1)) * H + 2 * hq + (rid2 & 1)) * W + 2 * m2;
+        if (TB) {
+          im4 = *reinterpret_cast<const float4*>(post.tb_img + oi4);
+          im2 = *reinterpret_cast<const float2*>(post.tb_img + oi2);
+        }
+        const uint16_t* s0 = ring + ((k - 2) % 3) * SLOT;
+        const uint16_t* s1 = ring + ((k - 1) % 3) * SLOT;
+        const uint16_t* s2 = slot;
+#pragma unroll
+        for (int sj = 0; sj < 2; ++sj) {
+          const int st = wave + 4 * sj;
+          sk_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          const int aoff = (16 * st + lp) * LU_PXS + 8 * lq;
+#pragma unroll
+          for (int dw = 0; dw < 3; ++dw)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              const int o = aoff + dw * LU_PXS + 32 * c;
+              sk_bf16x8 a0 = __builtin_bit_cast(sk_bf16x8, *reinterpret_cast<const uint4*>(s0 + o));
+              sk_bf16x8 a1 = __builtin_bit_cast(sk_bf16x8, *reinterpret_cast<const uint4*>(s1 + o));
+              sk_bf16x8 a2 = __builtin_bit_cast(sk_bf16x8, *reinterpret_cast<const uint4*>(s2 + o));
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wf[0][dw][c], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wf[1][dw][c], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, wf[2][dw][c], acc, 0, 0, 0);
+            }
+          if (ni < SK_I) {
+            float* orow = outt + (ni * 2 + nph) * LU_OS + 2 * (16 * st + 4 * lq) + npw;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float v = acc[r] + bv;
+              if (apply_tanh) v = sk_fast_tanh(v);
+              orow[2 * r] = v;
+            }
+          }
+        }
+        __syncthreads();
+        float4 v4 = *reinterpret_cast<const float4*>(outt + rid4 * LU_OS + 4 * m4);
+        float2 v2 = *reinterpret_cast<const float2*>(outt + rid2 * LU_OS + 2 * m2);
+        if (TB) {
+          v4 = make_float4(v4.x * (1.f - im4.x * im4.x), v4.y * (1.f - im4.y * im4.y), v4.z * (1.f - im4.z * im4.z),
+                           v4.w * (1.f - im4.w * im4.w));
+          v2 = make_float2(v2.x * (1.f - im2.x * im2.x), v2.y * (1.f - im2.y * im2.y));
+        }
+        *reinterpret_cast<float4*>(y + oi4) = v4;
+        *reinterpret_cast<float2*>(y + oi2) = v2;
+        if (PART) {
+          const float s4 = (v4.x + v4.y) + (v4.z + v4.w), s2 = v2.x + v2.y;
+          const int i4 = rid4 >> 1;                      // 0 or 1; the float2 rows are channel 2
+          pc0 += i4 == 0 ? s4 : 0.f; pc1 += i4 == 1 ? s4 : 0.f; pc2 += s2;
+          pq += ((v4.x * v4.x + v4.y * v4.y) + (v4.z * v4.z + v4.w * v4.w)) + (v2.x * v2.x + v2.y * v2.y);
+        }
+      }
+    };
+    step(0, ra, false);
+    step(1, rb, false);
+    step(2, ra, true);          // peeled: the loop is entered with the pending loads / stores of its back edge (see first_down)
+    step(3, rb, true);
+#pragma unroll 1
+    for (int k = 4; k < STRIP + 2; k += 2) {
+      step(k, ra, true);
+      step(k + 1, rb, true);
+    }
+    // no barrier between strips: the next strip's first ring store (slot 0) comes behind the barrier that follows step 17's
+    // MFMAs, the last readers of the ring
+  }
+  if (PART) {
+    float vals[4] = {pc0, pc1, pc2, pq};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) vals[k] += __shfl_xor(vals[k], o, 64);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) outt[wave * 4 + k] = vals[k];
+    }
+    __syncthreads();
+    if (t < 4) post.part[(size_t)blockIdx.x * 4 + t] = (outt[t] + outt[4 + t]) + (outt[8 + t] + outt[12 + t]);
+  }
+}
+
+// skinny weight gradient at Wo = 128: unit = one whole row of `low` (128 pixels x 64 channels) and its 12 image rows
+// (a native vector type: HIP's uint4 is a class, and a uint4 that is only copied -- global -> register -> LDS -- stays a
+// memcpy through a private-memory object that hipcc then places in scratch / LDS)
+typedef __attribute__((ext_vector_type(4))) unsigned sk_u32x4;
+struct Sw128Low { sk_u32x4 v0, v1, v2, v3; };
+__device__ __forceinline__ void sw128_load_low(Sw128Low& r, const uint16_t* __restrict__ low, int u, int t) {
+  const uint16_t* src = low + (size_t)u * R128_WO * 64 + (size_t)t * 8;
+  r.v0 = *reinterpret_cast<const sk_u32x4*>(src);
+  r.v1 = *reinterpret_cast<const sk_u32x4*>(src + 2048);
+  r.v2 = *reinterpret_cast<const sk_u32x4*>(src + 4096);
+  r.v3 = *reinterpret_cast<const sk_u32x4*>(src + 6144);
+}
+
+__global__ __launch_bounds__(256, 2) void skinny_wgrad_rows128_kernel(const uint16_t* __restrict__ low,
+                                                                      const float* __restrict__ x, float* __restrict__ slab,
+                                                                      int nunits) {
+  // both LDS images double-buffered (one barrier per unit), two units of loads in flight in registers (7 x 16 B per thread and
+  // unit): 59 KB and ~200 registers, two workgroups per CU
+  __shared__ __attribute__((aligned(16))) uint16_t pt2[2][SK_K * SW_PTS];    // 2 x 12.75 KB
+  __shared__ __attribute__((aligned(16))) uint16_t lt2[2][128 * 64];         // 2 x 16 KB (lt2[0] reused for the final reduction)
+  uint16_t* const lt = lt2[0];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  sk_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int grp16 = lane >> 4, idx = lane & 15, q4 = idx >> 2, p4 = idx & 3, fh = grp16 >> 1, cb = grp16 & 1;
+  const int per = (nunits + gridDim.x - 1) / gridDim.x;
+  const int u0 = blockIdx.x * per, u1 = min(nunits, u0 + per);
+  if (u0 < u1) {
+    fd128_zero_edges<SW_PTS>(pt2[0], t);
+    fd128_zero_edges<SW_PTS>(pt2[1], t);
+    Fd128Rows ra, rb;
+    Sw128Low la, lb;
+    fd128_load(ra, x, u0, wave, lane);
+    sw128_load_low(la, low, u0, t);
+    fd128_load(rb, x, min(u0 + 1, u1 - 1), wave, lane);
+    sw128_load_low(lb, low, min(u0 + 1, u1 - 1), t);
+    auto step = [&](int u, Fd128Rows& cur, Sw128Low& lcur, uint16_t* ptu, uint16_t* ltu) __attribute__((always_inline)) {
+      fd128_scatter<SW_PTS>(ptu, cur, fd128_row_ok(u, wave), wave, lane);
+      {
+        const int px = t >> 3, c = t & 7;
+        uint16_t* d = ltu + px * 64 + ((c ^ (((px >> 1) & 1) << 2)) << 3);
+        *reinterpret_cast<sk_u32x4*>(d) = lcur.v0;
+        *reinterpret_cast<sk_u32x4*>(d + 32 * 64) = lcur.v1;
+        *reinterpret_cast<sk_u32x4*>(d + 64 * 64) = lcur.v2;
+        *reinterpret_cast<sk_u32x4*>(d + 96 * 64) = lcur.v3;
+      }
+      __syncthreads();
+      fd128_load(cur, x, min(u + 2, u1 - 1), wave, lane);
+      sw128_load_low(lcur, low, min(u + 2, u1 - 1), t);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int prow = wave * 32 + ks * 16 + 8 * fh + q4;
+        const int sw = ((prow >> 1) & 1) << 2;                 // same for prow + 4
+        sk_bf16x8 fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int c = 4 * i + 2 * cb + (p4 >> 1);
+          const uint16_t* ap = ltu + prow * 64 + ((c ^ sw) << 3) + (p4 & 1) * 4;
+          sk_s16x4 lo = sk_tr_read(ap), hi = sk_tr_read(ap + 4 * 64);
+          fa[i] = __builtin_bit_cast(sk_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          const int k = 32 * i + r;
+          fb[i] = __builtin_bit_cast(sk_bf16x8, *reinterpret_cast<const uint4*>(ptu + (k < SK_K ? k : 0) * SW_PTS +
+                                                                                wave * 32 + ks * 16 + 8 * h));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    };
+    int u = u0;
+    if (u + 1 < u1) {
+      step(u, ra, la, pt2[0], lt2[0]);
+      step(u + 1, rb, lb, pt2[1], lt2[1]);
+      u += 2;
+#pragma unroll 1
+      for (; u + 1 < u1; u += 2) {
+        step(u, ra, la, pt2[0], lt2[0]);
+        step(u + 1, rb, lb, pt2[1], lt2[1]);
+      }
+    }
+    if (u < u1) step(u, ra, la, pt2[0], lt2[0]);
+  }
+  __syncthreads();
+  // block reduction of the 4 waves: acc[i][j][reg] = D[o = 32i + (reg&3)+8(reg>>2)+4h][k = 32j + r]
+  float* red = reinterpret_cast<float*>(lt);
+  for (int i = t; i < 64 * SK_K; i += 256) red[i] = 0.f;
+  __syncthreads();
+  for (int wv = 0; wv < 4; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int k = 32 * j + r;
+          if (k < SK_K) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[(32 * i + (e & 3) + 8 * (e >> 2) + 4 * h) * SK_K + k] += acc[i][j][e];
+          }
+        }
+    }
+    __syncthreads();
+  }
+  float* sl = slab + (size_t)blockIdx.x * 64 * SK_K;
+  for (int i = t; i < 64 * SK_K; i += 256) sl[i] = red[i];
+}
+
 // row-staged bf16 kernels: unit width (output pixels) for an output row of Wo pixels; 3 resident blocks per CU (VGPR-limited)
 constexpr int SK_ROWS_BLOCKS = 768;
+// the benchmark's geometry takes the control-flow-free kernels (`skinny128` = 0 / RNAGAN_SKINNY128=0: the general ones)
+bool sk_rows128(int H, int W) { return H == R128_H && W == R128_W && rg_option("skinny128", 1) != 0; }
 bool sk_rows_chunk(int Wo, int* chunk) {
   if (Wo >= 128 && Wo % 128 == 0) { *chunk = 128; return true; }
   if (Wo == 32 || Wo == 64) { *chunk = Wo; return true; }
@@ -852,6 +1307,12 @@ int rg_skinny_first_down_masked(const float* x, const float* w, void* y, const v
   RG_REQUIRE(npix / chunk < 0x7fffffff, RG_EUNSUPPORTED, "first_down_masked: too large");
   int nunits = (int)(npix / chunk);
   int blocks = nunits < SK_ROWS_BLOCKS ? nunits : SK_ROWS_BLOCKS;
+  if (sk_rows128(H, W)) {
+    hipLaunchKernelGGL((first_down_rows128_kernel<false, true>), dim3(blocks), dim3(256), 0, st, x, w, (const float*)nullptr,
+                       (uint16_t*)y, (unsigned long long*)nullptr, (const unsigned long long*)mask_bits, mslope, 1.f, nunits);
+    RG_LAUNCH_CHECK("first_down_masked(128)");
+    return RG_OK;
+  }
   hipLaunchKernelGGL((first_down_rows_kernel<false, true>), dim3(blocks), dim3(256), 0, st, x, w, (const float*)nullptr,
                      (uint16_t*)y, (unsigned long long*)nullptr, (const unsigned long long*)mask_bits, mslope, N, H, W, 1.f,
                      chunk, nunits);
@@ -869,6 +1330,16 @@ int rg_skinny_first_down(const float* x, const float* w, const float* bias, void
   if (dtype == RG_BF16 && O == 64 && sk_rows_chunk(W / 2, &chunk) && npix / chunk < 0x7fffffff && !no_mfma) {
     int nunits = (int)(npix / chunk);
     int blocks = nunits < SK_ROWS_BLOCKS ? nunits : SK_ROWS_BLOCKS;
+    if (sk_rows128(H, W)) {
+      if (bits)
+        hipLaunchKernelGGL((first_down_rows128_kernel<true, false>), dim3(blocks), dim3(256), 0, st, x, w, bias, (uint16_t*)y,
+                           (unsigned long long*)bits, (const unsigned long long*)nullptr, 1.f, slope, nunits);
+      else
+        hipLaunchKernelGGL((first_down_rows128_kernel<false, false>), dim3(blocks), dim3(256), 0, st, x, w, bias, (uint16_t*)y,
+                           (unsigned long long*)nullptr, (const unsigned long long*)nullptr, 1.f, slope, nunits);
+      RG_LAUNCH_CHECK("first_down(128)");
+      return RG_OK;
+    }
     if (bits)
       hipLaunchKernelGGL((first_down_rows_kernel<true, false>), dim3(blocks), dim3(256), 0, st, x, w, bias, (uint16_t*)y,
                          (unsigned long long*)bits, (const unsigned long long*)nullptr, 1.f, N, H, W, slope, chunk, nunits);
@@ -927,6 +1398,22 @@ int rg_skinny_last_up(const void* x, const float* w, const float* bias, float* y
     while (Ho % strip) --strip;
     long long nstrips = (long long)N * (Ho / strip) * (Wo / chunk);
     int blocks = nstrips < 512 ? (int)nstrips : 512;
+    if (sk_rows128(2 * Ho, 2 * Wo)) {
+#define LU128(PRE_, TB_, PART_)                                                                                          \
+  hipLaunchKernelGGL((last_up_rows128_kernel<PRE_, TB_, PART_>), dim3(blocks), dim3(256), 0, st, (const uint16_t*)x, w, bias, \
+                     y, apply_tanh, (int)nstrips, pre, post)
+      if (pre_mean) {
+        RG_REQUIRE(!post_tb_img && !post_part, RG_EUNSUPPORTED, "last_up: fused input and output passes together");
+        LU128(true, false, false);
+      } else if (post_tb_img) {
+        if (post_part) LU128(false, true, true); else LU128(false, true, false);
+      } else {
+        if (post_part) LU128(false, false, true); else LU128(false, false, false);
+      }
+#undef LU128
+      RG_LAUNCH_CHECK("last_up(128)");
+      return RG_OK;
+    }
     hipLaunchKernelGGL(last_up_rows_kernel, dim3(blocks), dim3(256), 0, st, (const uint16_t*)x, w, bias, y, N, Ho, Wo,
                        apply_tanh, chunk, strip, (int)nstrips, pre, post);
     RG_LAUNCH_CHECK("last_up(mfma)");
@@ -982,6 +1469,13 @@ int rg_skinny_wgrad_impl(const void* low, const float* high_nchw, float* dw, int
     int nunits = (int)(npix / chunk);
     int nbm = nunits < SK_ROWS_BLOCKS ? nunits : SK_ROWS_BLOCKS;
     RG_REQUIRE(ws && ws_bytes >= (size_t)nbm * elems * sizeof(float), RG_EWORKSPACE, "skinny_wgrad: workspace too small");
+    if (sk_rows128(2 * Ho, 2 * Wo)) {
+      if (nbm > 512) nbm = 512;                     // two workgroups per CU (59 KB of LDS each)
+      hipLaunchKernelGGL(skinny_wgrad_rows128_kernel, dim3(nbm), dim3(256), 0, st, (const uint16_t*)low, high_nchw, (float*)ws,
+                         nunits);
+      RG_LAUNCH_CHECK("skinny_wgrad(128)");
+      return rg_reduce_slabs((const float*)ws, dw, elems, nbm, accumulate, 0, 0, st);
+    }
     hipLaunchKernelGGL(skinny_wgrad_rows_kernel, dim3(nbm), dim3(256), 0, st, (const uint16_t*)low, high_nchw, (float*)ws,
                        N, 2 * Ho, 2 * Wo, chunk, nunits);
     RG_LAUNCH_CHECK("skinny_wgrad(mfma)");

@@ -148,6 +148,68 @@ def test_image_side_layers_full_size():
             assert float((y[n, ho, wo].double() - ref).abs().max()) < 8e-3 * float(ref.abs().max() + 1.0)
 
 
+@pytest.mark.parametrize("n", [64, 5])
+def test_image_side_rows128_kernels_equal_the_general_row_kernels(n):
+    """The control-flow-free forms of the three image-side kernels for 256 x 256 images (rg_skinny.hip, `skinny128`) against
+    the general row-staged kernels they replace there: same LDS images, same MFMA order, so the outputs are BIT-IDENTICAL
+    (first_down with / without sign bits and in the masked tangent form; last_up plain, with tanh, with the fused BatchNorm
+    input and with the fused consumer pass); the weight gradient differs by the fp32 summation order over workgroups only.
+    n = 5: an odd unit count per workgroup (the peeled tail) and fewer strips than workgroups."""
+    dev = torch.device("cuda:0")
+    ops = HipOps(torch.bfloat16, dev)
+    lib = _abi.load()
+    gen = torch.Generator(device="cpu").manual_seed(29)
+    O, I, S = 64, 3, 256
+    w = (torch.randn(O, I, 4, 4, generator=gen) * 0.2).to(dev)
+    b64, b3 = (0.1 * torch.randn(O, generator=gen)).to(dev), (0.1 * torch.randn(I, generator=gen)).to(dev)
+    cw = ConvW(w, None)
+    x = torch.randn(n, I, S, S, generator=gen).to(dev)
+    v = torch.randn(n, I, S, S, generator=gen).to(dev)
+    g = torch.randn(n, S // 2, S // 2, O, generator=gen).bfloat16().to(dev)
+    img = torch.tanh(torch.randn(n, I, S, S, generator=gen)).to(dev)
+    mean, invstd = (0.2 * torch.randn(O, generator=gen)).to(dev), (1 + 0.3 * torch.rand(O, generator=gen)).to(dev)
+    gam, bet = (1 + 0.1 * torch.randn(O, generator=gen)).to(dev), (0.1 * torch.randn(O, generator=gen)).to(dev)
+
+    def run():
+        out = {}
+        a = ops.first_down(x, cw, b64, 0.2)
+        out["fd_bits"] = a.clone()
+        bits = getattr(a, "_rg_sign_bits", None)
+        assert bits is not None, "layer 0 of the discriminator writes its sign bits at this shape"
+        out["bits"] = bits.clone()
+        out["fd_raw"] = ops.first_down(x, cw, None, 1.0).clone()
+        out["fd_tan"] = ops.first_down_tangent(v, cw, a, 0.2).clone()
+        out["lu"] = ops.last_up(g, cw, None, False).clone()
+        out["lu_tanh"] = ops.last_up(g, cw, b3, True).clone()
+        y = torch.empty(n, I, S, S, device=dev)
+        _abi.check(lib.rg_last_up_pre(g.data_ptr(), w.data_ptr(), b3.data_ptr(), y.data_ptr(), mean.data_ptr(),
+                                      invstd.data_ptr(), gam.data_ptr(), bet.data_ptr(), 0.2, n, S // 2, S // 2, O, I, 1,
+                                      ops.dt, ops.stream), "rg_last_up_pre")
+        out["lu_pre"] = y
+        for tag, ti in (("post_tb", img), ("post", None)):
+            yy, parts = ops.last_up_post(g, cw, ti)
+            out["lu_" + tag], out["parts_" + tag] = yy.clone(), parts.clone()
+        dw = torch.zeros(O, I, 4, 4, device=dev)
+        ops.skinny_wgrad(g, x, dw, False)
+        out["dw"] = dw
+        torch.cuda.synchronize()
+        return out
+    try:
+        _abi.check(lib.rg_set_option(b"skinny128", 0), "rg_set_option")
+        old = run()
+        _abi.check(lib.rg_set_option(b"skinny128", 1), "rg_set_option")
+        new = run()
+    finally:
+        lib.rg_set_option(b"skinny128", -1)
+    for k in ("fd_bits", "bits", "fd_raw", "fd_tan", "lu", "lu_tanh", "lu_pre", "lu_post_tb", "lu_post"):
+        assert torch.equal(old[k], new[k]), (k, float((old[k].float() - new[k].float()).abs().max()))
+    for k in ("parts_post_tb", "parts_post"):
+        so, sn = old[k].double().sum(0), new[k].double().sum(0)
+        assert float(((so - sn).abs() / (so.abs() + 1e-3)).max()) < 1e-5, k
+    scale = float(old["dw"].abs().max())
+    assert float((old["dw"] - new["dw"]).abs().max()) < 2e-5 * scale
+
+
 @pytest.mark.parametrize("n,hw", [(64, 128), (3, 32)])
 def test_input_gradient_kernel_with_fused_consumer_pass(n, hw):
     """rg_last_up_post at the benchmark's shape (and a ragged small one): the transposed conv's output multiplied by
