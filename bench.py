@@ -490,12 +490,20 @@ def measure_roofline(ops, device, one_step, step_ms):
     torch.cuda.synchronize(device)
     graphed.ENABLED = was
     overhead_ms = sorted(a.elapsed_time(b) for a, b in cal)[len(cal) // 2]
-    fam = {}
-    for key, flops, e0, e1 in ops.timing:
+    fam, stacks = {}, {}
+    for key, flops, e0, e1, owner in ops.timing:
+        ms = max(e0.elapsed_time(e1) - overhead_ms, 0.0)
         f = fam.setdefault(key, {"launches": 0, "flops": 0.0, "ms": 0.0})
         f["launches"] += 1
         f["flops"] += flops
-        f["ms"] += max(e0.elapsed_time(e1) - overhead_ms, 0.0)
+        f["ms"] += ms
+        if key == "conv_fwd_dgrad" and owner in ("G", "D"):
+            # the same launches split by the network whose layer they run: the discriminator's conv stack (forward, data
+            # gradient, the penalty's tangent and joint reverse passes: the stack BASELINE.json's north_star names) / the generator's
+            g = stacks.setdefault(owner, {"launches": 0, "flops": 0.0, "ms": 0.0})
+            g["launches"] += 1
+            g["flops"] += flops
+            g["ms"] += ms
     ops.timing = None
     rows = {}
     for k, f in fam.items():
@@ -528,7 +536,19 @@ def measure_roofline(ops, device, one_step, step_ms):
             "event_pair_overhead_us": round(overhead_ms * 1e3, 2),
             "launches": rows[dom]["launches"], "avg_us_per_launch": rows[dom]["avg_us_per_launch"],
             "share_of_step": rows[dom]["share_of_step"],
+            "d_stack": stack_row(stacks.get("D")), "g_stack": stack_row(stacks.get("G")),
             "others": {k: v for k, v in rows.items() if k != dom}}
+
+
+def stack_row(g):
+    """One network's share of the conv family (measure_roofline): algorithmic FLOPs of its MFMA conv launches / their summed
+    HIP-event durations, as a fraction of the bf16 peak."""
+    if not g or g["ms"] <= 0:
+        return None
+    tf = g["flops"] / (g["ms"] * 1e-3) / 1e12
+    return {"what": "bf16 MFMA conv launches of this network's layers (forward, data gradient, tangent): algorithmic FLOPs / "
+                    "summed HIP-event time", "launches": g["launches"], "ms_total": round(g["ms"], 3),
+            "achieved": round(tf, 1), "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4)}
 
 
 def pmc_traffic(family):
@@ -655,7 +675,9 @@ def measure_extras(args, device, info):
     """Secondary figures, measured after the headline timed region on the same box in the same process."""
     ex = {}
     for name, fn in (("generate", extra_generate), ("api_path", extra_api_path), ("fp32_step", extra_fp32_step),
-                     ("vae_train", extra_vae_train), ("enc200", extra_enc200)):
+                     ("vae_train", extra_vae_train), ("enc200", extra_enc200),
+                     ("batch128", lambda a, d, i: extra_batch(a, d, i, 128)),
+                     ("batch256", lambda a, d, i: extra_batch(a, d, i, 256))):
         try:
             ex[name] = fn(args, device, info)
             log("extra %s: %s" % (name, json.dumps(ex[name])))
@@ -779,6 +801,39 @@ def extra_enc200(args, device, info, steps=10, warm=12, enc=200):
     return res
 
 
+def extra_batch(args, device, info, batch, steps=6, warm=14):
+    """The SAME iteration at a larger per-GPU batch, with the same roofline object: separates kernel quality from launch
+    granularity.  At batch 64 a conv launch is 68.7 GFLOP = 27 us at peak on 256 CUs -- fill, drain, the split-K slabs of
+    the deep layers and the epilogue are a fixed cost per launch; at batch 128 / 256 the same kernels run 2 x / 4 x the work
+    per launch (fewer or no split-K launches).  Own models / plug-ins / step graphs; never part of `value`."""
+    import copy
+    from rna_gan_amd import losses as PL
+    a2 = copy.copy(args)
+    a2.batch = batch
+    one_step, flush, n, inf = hip_workload(a2, 0, 1, device)
+    for _ in range(warm):               # graph capture (two eager runs per launch-sequence variant) + settling
+        one_step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ls = one_step()
+    flush()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    roof = measure_roofline(inf["ops"], device, one_step, dt * 1e3)
+    flush()
+    torch.cuda.synchronize(device)
+    res = {"batch": batch, "ms_per_step": round(dt * 1e3, 3), "imgs_per_sec": round(batch / dt, 1), "steps": steps,
+           "losses": [round(float(l.item()), 5) for l in ls],
+           "roofline": {k: roof[k] for k in ("achieved", "achieved_incl_split_bn", "peak", "unit", "frac", "launches",
+                                             "avg_us_per_launch", "share_of_step", "d_stack", "g_stack")},
+           "conv_wgrad": roof["others"].get("conv_wgrad"), "bn_split_fused": roof["others"].get("bn_split_fused")}
+    PL.new_batch()
+    del one_step, flush, inf
+    torch.cuda.empty_cache()
+    return res
+
+
 F32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X fp32 matrix (= vector) peak, MI355X_MICROARCH.md
 
 
@@ -829,7 +884,7 @@ def extra_fp32_step(args, device, info, steps=3, warm=6):
         torch.cuda.synchronize(device)
         overhead = sorted(a.elapsed_time(b) for a, b in cal)[len(cal) // 2]
         fam = {}
-        for key, flops, e0, e1 in ops.timing:
+        for key, flops, e0, e1, _owner in ops.timing:
             f = fam.setdefault(key, [0, 0.0, 0.0])
             f[0] += 1; f[1] += flops; f[2] += max(e0.elapsed_time(e1) - overhead, 0.0)
     finally:

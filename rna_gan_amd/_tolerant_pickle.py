@@ -64,6 +64,11 @@ def missing_globals():
     return sorted(_PLACEHOLDERS)
 
 
+def is_placeholder(obj):
+    """True for an instance (or class) that stands in for an unimportable global."""
+    return isinstance(obj, MissingGlobal) or (isinstance(obj, type) and issubclass(obj, MissingGlobal))
+
+
 class Unpickler(_pickle.Unpickler):
     def find_class(self, module, name):
         try:
@@ -71,8 +76,10 @@ class Unpickler(_pickle.Unpickler):
         except (ImportError, AttributeError):
             # ModuleNotFoundError: torchgan / wgan_loss / betaVAE / dcgan absent; AttributeError: the module exists under
             # that name but is a different one (e.g. another project's ``dcgan``)
-            if module.split(".", 1)[0] in ("torch", "builtins", "collections", "numpy", "copyreg", "_codecs"):
-                raise                      # a genuinely broken stream must not be papered over
+            if module.split(".", 1)[0] in ("torch", "builtins", "collections", "numpy", "copyreg", "_codecs", "rna_gan_amd"):
+                # a genuinely broken stream must not be papered over -- and neither must THIS package's own classes: a
+                # renamed / removed rna_gan_amd global means the checkpoint predates a refactor, which the caller has to see
+                raise
             return _placeholder(module, name)
 
 

@@ -68,9 +68,16 @@ def build_debug_library(force=False):
     d = os.path.join(os.path.dirname(HERE), "tools", "debug")
     src, out = os.path.join(d, "rg_debug_hold.hip"), os.path.join(d, "librnagan_debug.so")
     if force or _stale(out, [src]):
-        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-o", out, src], capture_output=True, text=True)
+        # several ranks may get here at once (RNAGAN_DEBUG_HOG under torchrun): each compiles to a file of its own and renames
+        # it into place -- a rank never dlopens a half-written library; a read-only tree falls back to a per-user cache
+        d_out = d if os.access(d, os.W_OK) else os.path.join(os.path.expanduser("~"), ".cache", "rna_gan_amd")
+        os.makedirs(d_out, exist_ok=True)
+        out = os.path.join(d_out, "librnagan_debug.so")
+        tmp = "%s.%d.tmp" % (out, os.getpid())
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-o", tmp, src], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
+        os.replace(tmp, out)
     return out
 
 

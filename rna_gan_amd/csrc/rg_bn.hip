@@ -337,9 +337,11 @@ template <typename T, int VEC> struct StatsF {
   __device__ void shift(int g) { z += g * gs; }
   __device__ void init(int) {}
   static constexpr int U = 4;
-  struct In { float v[VEC]; };
-  __device__ __forceinline__ void load(int r, int c, In& in) const { Vec<T, VEC>::ld(z + (size_t)r * C + c, in.v); }
-  __device__ __forceinline__ void accum(const In& in, float (*acc)[VEC]) const {
+  struct In { RawVec<T, VEC> v; };
+  __device__ __forceinline__ void load(int r, int c, In& in) const { in.v.ld(z + (size_t)r * C + c); }
+  __device__ __forceinline__ void accum(const In& raw, float (*acc)[VEC]) const {
+    struct { float v[VEC]; } in;
+    raw.v.cvt(in.v);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) { acc[0][i] += in.v[i]; acc[1][i] += in.v[i] * in.v[i]; }
   }
@@ -378,10 +380,12 @@ template <typename T, int VEC> struct BnActF {
   BNR<VEC> q;
   __device__ void shift(int g) { z += g * gs; a += g * gs; p.mean += g * C; p.invstd += g * C; }
   static constexpr int U = 4;
-  struct In { float v[VEC]; };
+  struct In { RawVec<T, VEC> v; };
   __device__ void init(int c) { q.load(p, c); }
-  __device__ __forceinline__ void load(int r, int c, In& in) const { Vec<T, VEC>::ld(z + (size_t)r * C + c, in.v); }
-  __device__ __forceinline__ void finish(int r, int c, const In& in) const {
+  __device__ __forceinline__ void load(int r, int c, In& in) const { in.v.ld(z + (size_t)r * C + c); }
+  __device__ __forceinline__ void finish(int r, int c, const In& raw) const {
+    struct { float v[VEC]; } in;
+    raw.v.cvt(in.v);
     float o[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) o[i] = lrelu_f((in.v[i] - q.mean[i]) * (q.rstd[i] * q.gam[i]) + q.bet[i], p.slope);
@@ -397,12 +401,15 @@ template <typename T, int VEC> struct BwdRedF {
   __device__ void shift(int g) { z += g * gs; ga += g * gs; p.mean += g * C; p.invstd += g * C; }
   __device__ void init(int c) { q.load(p, c); }
   static constexpr int U = 4;
-  struct In { float v[VEC], g[VEC]; };
+  struct In { RawVec<T, VEC> v, g; };
   __device__ __forceinline__ void load(int r, int c, In& in) const {
-    Vec<T, VEC>::ld(z + (size_t)r * C + c, in.v);
-    Vec<T, VEC>::ld(ga + (size_t)r * C + c, in.g);
+    in.v.ld(z + (size_t)r * C + c);
+    in.g.ld(ga + (size_t)r * C + c);
   }
-  __device__ __forceinline__ void accum(const In& in, float (*acc)[VEC]) const {
+  __device__ __forceinline__ void accum(const In& raw, float (*acc)[VEC]) const {
+    struct { float v[VEC], g[VEC]; } in;
+    raw.v.cvt(in.v);
+    raw.g.cvt(in.g);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       float xh = (in.v[i] - q.mean[i]) * q.rstd[i];
@@ -435,12 +442,15 @@ template <typename T, int VEC> struct BwdApplyF {
     for (int i = 0; i < VEC; ++i) { m1[i] = s_gy[c + i] * inv_m; m2[i] = s_gyxh[c + i] * inv_m; }
   }
   static constexpr int U = 4;
-  struct In { float v[VEC], g[VEC]; };
+  struct In { RawVec<T, VEC> v, g; };
   __device__ __forceinline__ void load(int r, int c, In& in) const {
-    Vec<T, VEC>::ld(z + (size_t)r * C + c, in.v);
-    Vec<T, VEC>::ld(ga + (size_t)r * C + c, in.g);
+    in.v.ld(z + (size_t)r * C + c);
+    in.g.ld(ga + (size_t)r * C + c);
   }
-  __device__ __forceinline__ void finish(int r, int c, const In& in) const {
+  __device__ __forceinline__ void finish(int r, int c, const In& raw) const {
+    struct { float v[VEC], g[VEC]; } in;
+    raw.v.cvt(in.v);
+    raw.g.cvt(in.g);
     float o[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -459,12 +469,15 @@ template <typename T, int VEC> struct TanRedF {
   BNR<VEC> q;
   __device__ void init(int c) { q.load(p, c); }
   static constexpr int U = 4;
-  struct In { float v[VEC], t[VEC]; };
+  struct In { RawVec<T, VEC> v, t; };
   __device__ __forceinline__ void load(int r, int c, In& in) const {
-    Vec<T, VEC>::ld(z + (size_t)r * C + c, in.v);
-    Vec<T, VEC>::ld(zt + (size_t)r * C + c, in.t);
+    in.v.ld(z + (size_t)r * C + c);
+    in.t.ld(zt + (size_t)r * C + c);
   }
-  __device__ __forceinline__ void accum(const In& in, float (*acc)[VEC]) const {
+  __device__ __forceinline__ void accum(const In& raw, float (*acc)[VEC]) const {
+    struct { float v[VEC], t[VEC]; } in;
+    raw.v.cvt(in.v);
+    raw.t.cvt(in.t);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       float xh = (in.v[i] - q.mean[i]) * q.rstd[i];
@@ -482,12 +495,15 @@ template <typename T, int VEC> struct TanApplyF {
     for (int i = 0; i < VEC; ++i) { m1[i] = s_zt[c + i] * inv_m; m2[i] = s_xhzt[c + i] * inv_m; }
   }
   static constexpr int U = 4;
-  struct In { float v[VEC], t[VEC]; };
+  struct In { RawVec<T, VEC> v, t; };
   __device__ __forceinline__ void load(int r, int c, In& in) const {
-    Vec<T, VEC>::ld(z + (size_t)r * C + c, in.v);
-    Vec<T, VEC>::ld(zt + (size_t)r * C + c, in.t);
+    in.v.ld(z + (size_t)r * C + c);
+    in.t.ld(zt + (size_t)r * C + c);
   }
-  __device__ __forceinline__ void finish(int r, int c, const In& in) const {
+  __device__ __forceinline__ void finish(int r, int c, const In& raw) const {
+    struct { float v[VEC], t[VEC]; } in;
+    raw.v.cvt(in.v);
+    raw.t.cvt(in.t);
     float o[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -506,14 +522,19 @@ template <typename T, int VEC> struct DblRedF {
   BNR<VEC> q;
   __device__ void init(int c) { q.load(p, c); }
   static constexpr int U = 2;
-  struct In { float v[VEC], t[VEC], g[VEC], qq[VEC]; };
+  struct In { RawVec<T, VEC> v, t, g, qq; };
   __device__ __forceinline__ void load(int r, int c, In& in) const {
-    Vec<T, VEC>::ld(z + (size_t)r * C + c, in.v);
-    Vec<T, VEC>::ld(zt + (size_t)r * C + c, in.t);
-    Vec<T, VEC>::ld(ga1 + (size_t)r * C + c, in.g);
-    if (qa) Vec<T, VEC>::ld(qa + (size_t)r * C + c, in.qq);
+    in.v.ld(z + (size_t)r * C + c);
+    in.t.ld(zt + (size_t)r * C + c);
+    in.g.ld(ga1 + (size_t)r * C + c);
+    if (qa) in.qq.ld(qa + (size_t)r * C + c);
   }
-  __device__ __forceinline__ void accum(const In& in, float (*acc)[VEC]) const {
+  __device__ __forceinline__ void accum(const In& raw, float (*acc)[VEC]) const {
+    struct { float v[VEC], t[VEC], g[VEC], qq[VEC]; } in;
+    raw.v.cvt(in.v);
+    raw.t.cvt(in.t);
+    raw.g.cvt(in.g);
+    if (qa) raw.qq.cvt(in.qq);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
       float xh = (in.v[i] - q.mean[i]) * q.rstd[i];
@@ -557,14 +578,19 @@ template <typename T, int VEC> struct DblApplyF {
     }
   }
   static constexpr int U = 2;
-  struct In { float v[VEC], t[VEC], g[VEC], qq[VEC]; };
+  struct In { RawVec<T, VEC> v, t, g, qq; };
   __device__ __forceinline__ void load(int r, int c, In& in) const {
-    Vec<T, VEC>::ld(z + (size_t)r * C + c, in.v);
-    Vec<T, VEC>::ld(zt + (size_t)r * C + c, in.t);
-    Vec<T, VEC>::ld(ga1 + (size_t)r * C + c, in.g);
-    if (qa) Vec<T, VEC>::ld(qa + (size_t)r * C + c, in.qq);
+    in.v.ld(z + (size_t)r * C + c);
+    in.t.ld(zt + (size_t)r * C + c);
+    in.g.ld(ga1 + (size_t)r * C + c);
+    if (qa) in.qq.ld(qa + (size_t)r * C + c);
   }
-  __device__ __forceinline__ void finish(int r, int c, const In& in) const {
+  __device__ __forceinline__ void finish(int r, int c, const In& raw) const {
+    struct { float v[VEC], t[VEC], g[VEC], qq[VEC]; } in;
+    raw.v.cvt(in.v);
+    raw.t.cvt(in.t);
+    raw.g.cvt(in.g);
+    if (qa) raw.qq.cvt(in.qq);
     float o[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -614,9 +640,11 @@ template <typename T, int VEC> struct ColSumF {
   const T* g; int C;
   __device__ void init(int) {}
   static constexpr int U = 4;
-  struct In { float v[VEC]; };
-  __device__ __forceinline__ void load(int r, int c, In& in) const { Vec<T, VEC>::ld(g + (size_t)r * C + c, in.v); }
-  __device__ __forceinline__ void accum(const In& in, float (*acc)[VEC]) const {
+  struct In { RawVec<T, VEC> v; };
+  __device__ __forceinline__ void load(int r, int c, In& in) const { in.v.ld(g + (size_t)r * C + c); }
+  __device__ __forceinline__ void accum(const In& raw, float (*acc)[VEC]) const {
+    struct { float v[VEC]; } in;
+    raw.v.cvt(in.v);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) acc[0][i] += in.v[i];
   }

@@ -117,6 +117,57 @@ template <> struct Vec<bf16_t, 8> {
   }
 };
 
+// VEC consecutive elements AS LOADED (a native vector: one load instruction, no arithmetic behind it); cvt() widens to floats.
+// The row kernels of rg_bn.hip issue the loads of several rows / operands first and convert when they compute: with the
+// conversion inside the load helper (Vec<>::ld above) hipcc serialised the loads of the multi-operand passes -- load, load,
+// s_waitcnt vmcnt(0), convert, load, ... in the ISA of the BatchNorm-backward apply.
+typedef __attribute__((ext_vector_type(4))) unsigned rg_u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned rg_u32x2;
+typedef __attribute__((ext_vector_type(4))) float rg_f32x4;
+template <typename T, int VEC> struct RawVec;
+template <> struct RawVec<float, 1> {
+  float r;
+  __device__ __forceinline__ void ld(const float* p) { r = p[0]; }
+  __device__ __forceinline__ void cvt(float* o) const { o[0] = r; }
+};
+template <> struct RawVec<float, 4> {
+  rg_f32x4 r;
+  __device__ __forceinline__ void ld(const float* p) { r = *reinterpret_cast<const rg_f32x4*>(p); }
+  __device__ __forceinline__ void cvt(float* o) const { o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w; }
+};
+template <> struct RawVec<float, 8> {
+  rg_f32x4 r0, r1;
+  __device__ __forceinline__ void ld(const float* p) {
+    r0 = *reinterpret_cast<const rg_f32x4*>(p); r1 = *reinterpret_cast<const rg_f32x4*>(p + 4);
+  }
+  __device__ __forceinline__ void cvt(float* o) const {
+    o[0] = r0.x; o[1] = r0.y; o[2] = r0.z; o[3] = r0.w; o[4] = r1.x; o[5] = r1.y; o[6] = r1.z; o[7] = r1.w;
+  }
+};
+template <> struct RawVec<bf16_t, 1> {
+  uint16_t r;
+  __device__ __forceinline__ void ld(const bf16_t* p) { r = p->bits; }
+  __device__ __forceinline__ void cvt(float* o) const { o[0] = bf16_to_f32(r); }
+};
+template <> struct RawVec<bf16_t, 4> {
+  rg_u32x2 r;
+  __device__ __forceinline__ void ld(const bf16_t* p) { r = *reinterpret_cast<const rg_u32x2*>(p); }
+  __device__ __forceinline__ void cvt(float* o) const {
+    o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
+    o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
+  }
+};
+template <> struct RawVec<bf16_t, 8> {
+  rg_u32x4 r;
+  __device__ __forceinline__ void ld(const bf16_t* p) { r = *reinterpret_cast<const rg_u32x4*>(p); }
+  __device__ __forceinline__ void cvt(float* o) const {
+    o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
+    o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
+    o[4] = __uint_as_float(r.z << 16); o[5] = __uint_as_float(r.z & 0xffff0000u);
+    o[6] = __uint_as_float(r.w << 16); o[7] = __uint_as_float(r.w & 0xffff0000u);
+  }
+};
+
 __device__ __forceinline__ float lrelu_f(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float lrelu_mask(float v, float slope) { return v > 0.f ? 1.f : slope; }
 

@@ -130,11 +130,6 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
         mask = 1u;
       }
       a_off[h * NA + j] = (int)((base + lc * (16 / EB)) * EB);
-#ifdef C8_FOLD_PROBE
-      // measurement probe (build-time, never shipped; results are wrong): every A row inside one 2 MB window = the gather is
-      // served from L2 whatever the tile's input footprint -- what the launch would cost without the re-fetches
-      a_off[h * NA + j] &= 0x1FFFFF;
-#endif
       a_mask[j] |= (ok ? mask : 0u) << (16 * h);
     }
 #pragma unroll
@@ -243,12 +238,6 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
       for (int s = 0; s < NACC; ++s)
 #pragma unroll
         for (int r = 0; r < ACC_R; ++r) acc[i][j][s][r] = 0.f;
-#ifdef C8_BNFUSE_PROBE
-  // identity-like parameters read at run time (so that nothing folds): scale 1, shift 0, slope 1 -> results unchanged up to
-  // one bf16 rounding of an exactly representable value (i.e. unchanged)
-  const float probe_sc = a2.g.mslope == 12345.f ? 2.f : 1.f, probe_sh = a2.g.mslope == 12345.f ? 1.f : 0.f;
-  const float probe_sl = a2.g.mslope == 54321.f ? 0.2f : 1.f;
-#endif
   u32x4_t aR[8];                     // A fragments of the current quadrant row: [A sub-tile][k-step]
   u32x4_t bS[3][4];                  // three rotating B fragment sets: [set][B sub-tile][k-step]
   u32x2_t aQ[16];                    // fp8: 64-bit fragments, [A sub-tile (4)][k-step (4)]
@@ -327,29 +316,6 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
     }                                                                                                          \
     if (C8_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(0);                                                      \
   } while (0)
-// C8_BNFUSE_PROBE (build-time measurement probe, never shipped): the VALU work a consumer-side BatchNorm + LeakyReLU on the
-// A fragments would add to every phase ("normalise + activate in the consumer's tile load") -- per
-// 16-byte fragment 8 x (unpack, fma with a per-channel scale / shift, LeakyReLU as max(y, slope*y)) and 4 packs; the
-// padding mask and the per-k-tile parameter loads a real version also needs are NOT included (lower bound of its cost).
-#ifdef C8_BNFUSE_PROBE
-#define C8_BNFUSE_APPLY()                                                                                      \
-  do {                                                                                                         \
-    if constexpr (EB == 2) {                                                                                   \
-      _Pragma("unroll") for (int f_ = 0; f_ < 8; ++f_) {                                                       \
-        uint32_t d_[4] = {aR[f_].x, aR[f_].y, aR[f_].z, aR[f_].w};                                             \
-        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                     \
-          float lo_ = __uint_as_float(d_[e_] << 16), hi_ = __uint_as_float(d_[e_] & 0xffff0000u);            \
-          lo_ = lo_ * probe_sc + probe_sh; hi_ = hi_ * probe_sc + probe_sh;                                    \
-          lo_ = fmaxf(lo_, lo_ * probe_sl); hi_ = fmaxf(hi_, hi_ * probe_sl);                                  \
-          d_[e_] = (uint32_t)f32_to_bf16(lo_) | ((uint32_t)f32_to_bf16(hi_) << 16);                            \
-        }                                                                                                      \
-        aR[f_].x = d_[0]; aR[f_].y = d_[1]; aR[f_].z = d_[2]; aR[f_].w = d_[3];                                \
-      }                                                                                                        \
-    }                                                                                                          \
-  } while (0)
-#else
-#define C8_BNFUSE_APPLY() do { } while (0)
-#endif
 #define C8_SYNC() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
   // counted waits (see the table in the header): half-tiles allowed to stay in flight behind the one needed next phase
   constexpr int W_ODD = vmcnt_imm(3 * NA + 2 * NB);     // P1, P3
@@ -363,7 +329,6 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
     __builtin_amdgcn_s_waitcnt(W_ODD);                                                      \
     C8_SYNC();                                                                              \
     C8_WAIT_A();                                                                            \
-    C8_BNFUSE_APPLY();                                                                      \
     C8_MFMAS(0, 0, SB0);                                                                    \
     C8_SYNC();                                                                              \
     /* P2 */                                                                                \
@@ -380,7 +345,6 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
     __builtin_amdgcn_s_waitcnt(W_ODD);                                                      \
     C8_SYNC();                                                                              \
     C8_WAIT_A();                                                                            \
-    C8_BNFUSE_APPLY();                                                                      \
     C8_MFMAS(1, 1, 1);                                                                      \
     C8_SYNC();                                                                              \
     /* P4 */                                                                                \
@@ -501,10 +465,6 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
       } else {
         orow = m;
       }
-#ifdef C8_NOEPI_PROBE
-      if (a2.korder == 12345) continue;      // (never true: keeps the loads / conversions; the probe variant below skips the stores)
-      if (a2.nsplit >= 1) continue;          // measurement probe (build-time, never shipped): no global stores in the epilogue
-#endif
       if (a2.nsplit > 1) {
         float* so = a2.slab + (long long)zs * a2.slab_stride + orow * g.ldc + col;
         *reinterpret_cast<float4*>(so) = v0;

@@ -112,11 +112,7 @@ __global__ __launch_bounds__(512, 2) void convd_kernel(G2Args a2) {
     for (int j = 0; j < 4; ++j) acc[i][j] = cd_f32x4{0.f, 0.f, 0.f, 0.f};
   u32x4_t aF[2][4], bF[2][4];
 
-#ifdef CD_PROBE_NOREAD     // (measurement probe: fragments are never read)
-#define CD_DSR(dst, addr, off) asm volatile("" : "=v"(dst) : "v"(addr))
-#else
 #define CD_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
-#endif
 #define CD_WAIT8(N, A, B)                                                                                      \
   asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                     \
                : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(B[0]), "+v"(B[1]), "+v"(B[2]), "+v"(B[3])::"memory")
@@ -133,10 +129,6 @@ __global__ __launch_bounds__(512, 2) void convd_kernel(G2Args a2) {
   };
   // 4 MFMAs: column tile j of fragment set `set` against the four pixel tiles
   auto mfma4 = [&](int set, int j) __attribute__((always_inline)) {
-#ifdef CD_PROBE_NOMFMA
-    asm volatile("" ::"v"(bF[set][j]), "v"(aF[set][0]), "v"(aF[set][1]), "v"(aF[set][2]), "v"(aF[set][3]));
-    return;
-#endif
 #pragma unroll
     for (int it = 0; it < 4; ++it)
       acc[it][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bF[set][j]),
@@ -194,11 +186,7 @@ __global__ __launch_bounds__(512, 2) void convd_kernel(G2Args a2) {
     }
   };
 
-#ifdef CD_PROBE_NOBAR      // (measurement probe: no workgroup barrier in the loop)
-#define CD_SYNC() do { __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
 #define CD_SYNC() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#endif
   int wslot = 3, rslot = 0;                                // ring slot the next issue_b writes / the current step reads
   // ---- prologue: plane 0 of the first tile, weight slices of steps 0 .. 2; the first k-half's fragments
 #pragma unroll
@@ -234,18 +222,14 @@ __global__ __launch_bounds__(512, 2) void convd_kernel(G2Args a2) {
     read_b(1, rbase, 1);
     __builtin_amdgcn_sched_barrier(0);
     mfma4(0, 2);
-#ifndef CD_PROBE_NODMA      // (measurement probes, never shipped: results wrong by construction)
     if constexpr (tp < 2) {                                // the next plane (of the next tile behind plane 3) into the other buffer
       issue_plane(p == 3 ? T + 1 : T, (p + 1) & 3, 3 * tp);
       issue_plane(p == 3 ? T + 1 : T, (p + 1) & 3, 3 * tp + 1);
       issue_plane(p == 3 ? T + 1 : T, (p + 1) & 3, 3 * tp + 2);
     }
-#endif
     __builtin_amdgcn_sched_barrier(0);
     mfma4(0, 3);
-#ifndef CD_PROBE_NODMA
     issue_b(s2 >> 2, s2 & 3, wslot);                       // (its slot was read last in step s - 1: behind that step's barrier)
-#endif
     wslot = wslot == CD_NSLOT - 1 ? 0 : wslot + 1;
     __builtin_amdgcn_sched_barrier(0);
     CD_WAIT8(0, aF[1], bF[1]);

@@ -235,24 +235,8 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma32_kernel(FA fa, FB fb, SC sc
   int cur = 0;
   for (int k0 = k_begin; k0 < k_end; k0 += MB_K) {
     const bool more = k0 + MB_K < k_end;
-#ifndef RG_F32_NOLOAD     // (measurement probe, never shipped: -DRG_F32_NOLOAD keeps the first k-tile's operands for the whole loop)
     if (more) fetch(k0 + MB_K);                    // global loads of the next k-tile fly under this tile's MFMAs
-#endif
     __builtin_amdgcn_sched_barrier(0);
-#ifdef RG_F32_NOPIPE
-#pragma unroll
-    for (int st = 0; st < MB_K / 2; ++st) {
-      float a[IA], b[IB];
-#pragma unroll
-      for (int i = 0; i < IA; ++i) a[i] = As[cur][2 * st + lh][wm * TM + 32 * i + lr];
-#pragma unroll
-      for (int j = 0; j < IB; ++j) b[j] = Bs[cur][2 * st + lh][wn * TN + 32 * j + lr];
-#pragma unroll
-      for (int i = 0; i < IA; ++i)
-#pragma unroll
-        for (int j = 0; j < IB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-#else
     // the fragments of step st + 1 are read while the MFMAs of step st run (two register sets)
     float a[2][IA], b[2][IB];
 #pragma unroll
@@ -271,13 +255,8 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma32_kernel(FA fa, FB fb, SC sc
       for (int i = 0; i < IA; ++i)
 #pragma unroll
         for (int j = 0; j < IB; ++j)
-#ifdef RG_F32_NOMFMA       // measurement probe (never shipped): operands are read, no matrix instruction is issued
-          asm volatile("" ::"v"(a[st & 1][i]), "v"(b[st & 1][j]));
-#else
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st & 1][i], b[st & 1][j], acc[i][j], 0, 0, 0);
-#endif
     }
-#endif
     __builtin_amdgcn_sched_barrier(0);             // the loads stay above the MFMAs, their first use (the stash) below
     if (more) stash(cur ^ 1);                      // the other stage: its last readers passed the barrier of the previous tile
     __syncthreads();
@@ -296,8 +275,9 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma32_kernel(FA fa, FB fb, SC sc
 }
 
 // f32mma (option, default 1): fp32-storage launches with at least 64 rows and more than 32 columns run on the matrix cores;
-// everything else (the 3-column image layers) -- and every bf16-storage launch, whose results the bf16 tests pin to the vector
-// kernel bit for bit -- keeps gemm_generic_kernel.
+// everything else (the 3-column image layers) -- and every bf16-storage launch -- keeps gemm_generic_kernel.  (Its bf16 results
+// are deterministic but NOT pinned bit for bit across rounds: round 4 made the transposed conv's K order tap-major, permuted the
+// G.0 columns and re-associated the split-K slab sums; the bf16 tests compare with tolerances.)
 static bool use_mfma32(bool f32, int M, int N) { return f32 && M >= 64 && N >= 33 && rg_option("f32mma", 1) != 0; }
 
 // (defined with gemm_mfma32s_kernel below: launches it and returns true when both operands have a structured form)
@@ -684,7 +664,8 @@ template <typename T> struct Op<DownA<T>, true> {
     int wo, t, ho, n;
     rg_divmod_t<P2>(m, f.g.Wl, f.g.sWl, t, wo); rg_divmod_t<P2>(t, f.g.Hl, f.g.sHl, n, ho);
     const int h0 = 2 * ho - 1, w0 = 2 * wo - 1;
-    const int base = P2 ? ((((n << f.g.sHl) + h0) << f.g.sWl) + w0) << (f.g.sI - 1) : ((n * f.g.Hh + h0) * f.g.Wh + w0) * f.g.I;
+    // (multiplications by powers of two, not shifts: h0 / w0 are -1 on the border, and a left shift of a negative int is undefined)
+    const int base = P2 ? (((n << f.g.sHl) + h0) * (1 << f.g.sWl) + w0) * (1 << (f.g.sI - 1)) : ((n * f.g.Hh + h0) * f.g.Wh + w0) * f.g.I;
     return {base, h0, w0};
   }
   template <bool P2> static __device__ __forceinline__ C col(const DownA<T>& f, int, int k) {
@@ -746,7 +727,8 @@ template <typename T> struct Op<WgradB<T>, false> {       // B side: operator()(
     int wo, t, ho, n;
     rg_divmod_t<P2>(pix, f.g.Wl, f.g.sWl, t, wo); rg_divmod_t<P2>(t, f.g.Hl, f.g.sHl, n, ho);
     const int h0 = 2 * ho - 1, w0 = 2 * wo - 1;
-    const int base = P2 ? ((((n << f.g.sHl) + h0) << f.g.sWl) + w0) << (f.g.sI - 1) : ((n * f.g.Hh + h0) * f.g.Wh + w0) * f.g.I;
+    // (multiplications by powers of two, not shifts: h0 / w0 are -1 on the border, and a left shift of a negative int is undefined)
+    const int base = P2 ? (((n << f.g.sHl) + h0) * (1 << f.g.sWl) + w0) * (1 << (f.g.sI - 1)) : ((n * f.g.Hh + h0) * f.g.Wh + w0) * f.g.I;
     return {base, h0, w0};
   }
   static __device__ __forceinline__ float at(const WgradB<T>& f, int, const R& r, const C& c, bool& ok) {
@@ -1157,14 +1139,12 @@ template <bool AK, bool BK, class FA, class FB, class SC>
 static bool launch_structured(const char* name, FA fa, FB fb, SC sc, int M, int N, int K, int nbatch, int klen, dim3 grid,
                               bool small, hipStream_t st) {
   if constexpr (SOp<FA>::OK && SOp<FB>::OK) {
-#ifndef RG_F32_NOSTRUCT
     if (SOp<FA>::ok(fa, M, K) && SOp<FB>::ok(fb, N, K) && lg1(nbatch)) {
       const int lgb = lg1(nbatch) - 1;
       if (small) hipLaunchKernelGGL((gemm_mfma32s_kernel<32, 32, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, lgb, klen);
       else hipLaunchKernelGGL((gemm_mfma32s_kernel<64, 64, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, lgb, klen);
       return true;
     }
-#endif
   }
   return false;
 }

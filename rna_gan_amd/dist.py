@@ -62,6 +62,14 @@ def init_from_env(backend=None):
         # one device (RCCL refuses duplicate devices; gloo stages device tensors through the host: correct, not fast)
         backend = os.environ.get("RNAGAN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
+        if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+            # RCCL shares buffers between the rank processes through dmabuf IPC on this driver stack; the HSA runtime reads the
+            # variable when HIP initialises, i.e. it has to be in the environment BEFORE the first torch.cuda call of the
+            # process (bench.py and the CLI export it themselves; a user script under torchrun must do the same)
+            import warnings
+            warnings.warn("rna_gan_amd.dist: HSA_ENABLE_IPC_MODE_LEGACY=0 is not exported; RCCL's inter-process buffer "
+                          "sharing fails with 'hipIpcGetMemHandle: invalid argument' on hosts that only support dmabuf IPC "
+                          "(export it before python starts)")
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dist.init_process_group(backend=backend, init_method="env://")
 

@@ -44,7 +44,7 @@ class ConvW:
     """
 
     __slots__ = ("w", "bias", "dw", "dbias", "packs", "packs_version", "version", "layout", "shadow",
-                 "shadow_version", "_fp8", "fuse_step", "pending_wgrad", "factor_stage")
+                 "shadow_version", "_fp8", "fuse_step", "pending_wgrad", "factor_stage", "owner")
 
     def __init__(self, w, bias=None, dw=None, dbias=None, layout="OIHW"):
         self.w = w
@@ -58,6 +58,7 @@ class ConvW:
         self.shadow = None            # bf16 [O][16][I] image of a tap-major master maintained by the fused Adam
         self.shadow_version = -1      # master version the shadow reflects
         self._fp8 = None              # backend-private fp8 inference image (key, bytes, column scales)
+        self.owner = None             # "G" / "D": which network the layer belongs to (bench.py's per-network roofline rows)
         # generator layer 0 only (HIP backend): fuse_step -- set by the train_op runner for the duration of one gradient pass
         # whose optimizer step follows immediately -- lets g0_wgrad leave its operands in pending_wgrad instead of writing dw;
         # the fused Adam then forms the gradient and applies the step in one kernel (rg_g0_wgrad_adam)

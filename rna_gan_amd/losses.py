@@ -184,7 +184,17 @@ def _g_rest(generator, discriminator, pre):
 # both halves as two-segment launches in the rest -- engine.disc_loss_prefix_dgrad.  One rank, same box, interleaved: 12.07 ms
 # against 12.21 ms for mode 1 (single-process path 11.24-11.39); the prefix shrinks from ~1.3 to ~0.9 ms, still longer than the
 # generator's 90 MB collective at any plausible bus bandwidth.  1: the whole backward of the real half in the prefix (round 3).
-DP_PREFIX_MODE = int(os.environ.get("RNAGAN_DP_PREFIX_BWD", "2"))
+# PROVISIONAL default: the only evidence is a one-rank timing and a world-2 run over gloo on a shared GPU; mode 2's shorter
+# prefix gives the generator's collective less cover, and tools/dp_first_run.sh A/Bs mode 1 on the first real multi-GPU node.
+def _env_int(name, dflt, allowed):
+    try:
+        v = int(os.environ.get(name, "") or dflt)
+    except ValueError:
+        v = dflt
+    return v if v in allowed else dflt
+
+
+DP_PREFIX_MODE = _env_int("RNAGAN_DP_PREFIX_BWD", 2, (0, 1, 2))
 DP_PREFIX_BWD = DP_PREFIX_MODE != 0
 
 

@@ -128,6 +128,8 @@ class _HipModule(nn.Module):
             dt = torch.bfloat16 if self.precision == "bf16" else torch.float32
             self._rt_ops = D_.attach_sync(HipOps(dt, p0.device))
             self._rt_net = self._build_net()
+            for cw in self._rt_net.convs():
+                cw.owner = "D" if hasattr(self, "disc") else "G"
             if self.precision == "bf16" and p0.dtype == torch.float32:
                 self._attach_shadows()
         return self._rt_ops, self._rt_net

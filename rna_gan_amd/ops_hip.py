@@ -33,22 +33,82 @@ class SlabRef:
 _LIVE_OPS = weakref.WeakSet()
 
 
+def _handoff_flag(device=None):
+    """int32[1] device tensor = the largest error word of the live backends (optionally of one device), or None when no
+    backend has launched a fused split-K BatchNorm kernel yet.  No host sync."""
+    words = [ops._sb_sync[0:1] for ops in list(_LIVE_OPS)
+             if ops._sb_sync is not None and (device is None or ops.device == device)]
+    if not words:
+        return None
+    flag = words[0].clone()
+    for w in words[1:]:
+        flag = torch.maximum(flag, w.to(flag.device))
+    return flag
+
+
+def _rearm():
+    for ops in list(_LIVE_OPS):
+        if ops._sb_sync is not None:
+            ops._sb_sync[0].zero_()
+
+
+_HANDOFF_MSG = ("rna_gan_amd: a fused split-K BatchNorm launch timed out waiting for its workgroups%s: the results of that "
+                "launch are invalid.  The kernels need all their <= 256 workgroups co-resident; another kernel (a "
+                "collective?) held CUs.  Set RNAGAN_SPLIT_BN_DP=0 / RNAGAN_SPLIT_BN=0 to use the separate launches.")
+
+
 def check_handoffs():
     """Host-side check of the fused split-K BatchNorm kernels' error word (rg_splitbn.hip: a workgroup whose bounded spin
     on the in-launch rendezvous timed out sets sync[SB_ERR] and goes on with incomplete sums -- the launch's statistics and
-    activations are then garbage).  Reads one int32 per live backend: a HOST SYNC, so it is called where the host waits
-    anyway (Trainer: end of an epoch / save_model; bench.py: behind the timed region; the tests).  Raises and re-arms."""
-    bad = []
-    for ops in list(_LIVE_OPS):
-        sync = ops._sb_sync
-        if sync is not None and int(sync[0].item()) != 0:
-            sync[0].zero_()
-            bad.append(str(ops.device))
-    if bad:
-        raise RuntimeError("rna_gan_amd: a fused split-K BatchNorm launch timed out waiting for its workgroups (%s): the "
-                           "results of that launch are invalid.  The kernels need all their <= 256 workgroups co-resident; "
-                           "another kernel (a collective?) held CUs.  Set RNAGAN_SPLIT_BN_DP=0 / RNAGAN_SPLIT_BN=0 to use "
-                           "the separate launches." % ", ".join(bad))
+    activations are then garbage).  A HOST SYNC, so it is called where the host waits anyway (Trainer.save_model at the end
+    of an epoch; bench.py behind the timed region; the tests); inside an epoch the Trainer polls the same word every
+    ``handoff_check_every`` iterations without a sync (handoffs_poll_start / handoffs_poll_finish).
+    RANK-COLLECTIVE under data parallelism: the word is MAX-all-reduced, so EVERY rank raises when ANY rank's launch timed
+    out -- the gradient all-reduce has already spread that rank's garbage, rank 0 must not checkpoint it, and a rank that
+    raised alone would leave the others hanging in their next collective.  Every rank must therefore call it at the same
+    point (save_model, bench.py and the poll do).  Raises and re-arms."""
+    from . import dist as D_
+    flag = _handoff_flag()
+    if D_.active():
+        if flag is None:                     # no fused launch on this rank yet: still take part in the collective
+            dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+            flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+    if flag is not None and int(flag.item()) != 0:
+        _rearm()
+        raise RuntimeError(_HANDOFF_MSG % (" on at least one rank" if D_.active() else ""))
+
+
+def handoffs_poll_start():
+    """The check above without the host sync: enqueue (rank-collective under data parallelism) the MAX of the error words
+    and its copy into a pinned host slot; returns the handle handoffs_poll_finish takes an iteration or more later."""
+    from . import dist as D_
+    flag = _handoff_flag()
+    if flag is None:
+        if not D_.active() or not torch.cuda.is_available():
+            return None
+        flag = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+    if D_.active():
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+    slot = torch.empty(1, dtype=torch.int32, pin_memory=flag.is_cuda)
+    slot.copy_(flag, non_blocking=True)
+    ev = None
+    if flag.is_cuda:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(flag.device))
+    return slot, ev, flag
+
+
+def handoffs_poll_finish(handle):
+    if handle is None:
+        return
+    from . import dist as D_
+    slot, ev, _flag = handle
+    if ev is not None:
+        ev.synchronize()
+    if int(slot.item()) != 0:
+        _rearm()
+        raise RuntimeError(_HANDOFF_MSG % (" on at least one rank" if D_.active() else ""))
 
 
 class HipOps:
@@ -184,14 +244,15 @@ class HipOps:
             torch.cuda.current_stream(self.device).wait_stream(self.side_stream)
         self._keep.clear()
 
-    def _timed(self, key, flops, thunk):
+    def _timed(self, key, flops, thunk, cw=None):
         if self.timing is None:
             return thunk()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream(self.device))
         r = thunk()
         e1.record(torch.cuda.current_stream(self.device))
-        self.timing.append((key, float(flops), e0, e1))
+        # (family, algorithmic FLOPs, start, end, network the layer belongs to: "G" / "D" / None)
+        self.timing.append((key, float(flops), e0, e1, getattr(cw, "owner", None)))
         return r
 
     def _act(self, *shape):
@@ -307,7 +368,7 @@ class HipOps:
             ws = self._ws(self.lib.rg_conv_workspace_bytes(0, N, Hi // 2, Wi // 2, O, I, self.dt, self.algo))
             self._timed("conv_fwd_dgrad", 2.0 * N * (Hi // 2) * (Wi // 2) * O * I * 16, lambda: check(
                 self.lib.rg_conv_down_partial(_ptr(x), _ptr(wdn), N, Hi, Wi, I, O, self.dt, self.algo, _ptr(ws), ws.numel(),
-                                              self.stream), "rg_conv_down_partial"))
+                                              self.stream), "rg_conv_down_partial"), cw=cw)
             y._rg_slabs = SlabRef(ws, ns, y.numel(), defer)
             self._slabs_pending = y
             return (y, None) if want_stats else y
@@ -318,7 +379,7 @@ class HipOps:
         ws = self._ws(self.lib.rg_conv_workspace_bytes(0, N, Hi // 2, Wi // 2, O, I, self.dt, self.algo))
         self._timed("conv_fwd_dgrad", 2.0 * N * (Hi // 2) * (Wi // 2) * O * I * 16, lambda: check(
             self.lib.rg_conv_down(_ptr(x), _ptr(cw.w), _ptr(wdn), _ptr(y), N, Hi, Wi, I, O, _ptr(st), self.dt,
-                                  self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_down"))
+                                  self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_down"), cw=cw)
         return (y, st) if want_stats else y
 
     def conv_up(self, x, cw: ConvW, mask_act=None, slope=1.0, want_stats=False, defer=0, bn_bwd=None):
@@ -335,7 +396,7 @@ class HipOps:
             ws = self._ws(self.lib.rg_conv_workspace_bytes(1, N, Ho, Wo, O, I, self.dt, self.algo))
             self._timed("conv_fwd_dgrad", 2.0 * N * Ho * Wo * O * I * 16, lambda: check(
                 self.lib.rg_conv_up_partial(_ptr(x), _ptr(wup), N, Ho, Wo, O, I, self.dt, self.algo, _ptr(ws), ws.numel(),
-                                            self.stream), "rg_conv_up_partial"))
+                                            self.stream), "rg_conv_up_partial"), cw=cw)
             y._rg_slabs = SlabRef(ws, ns, y.numel(), defer)
             self._slabs_pending = y
             return (y, None) if want_stats else y
@@ -349,11 +410,11 @@ class HipOps:
         if bits is not None and self.lib.rg_conv_up_maskbits_supported(N, Ho, Wo, O, I, self.dt, self.algo):
             self._timed("conv_fwd_dgrad", 2.0 * N * Ho * Wo * O * I * 16, lambda: check(
                 self.lib.rg_conv_up_maskbits(_ptr(x), _ptr(wup), _ptr(y), N, Ho, Wo, O, I, _ptr(bits), float(slope), self.dt,
-                                             self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_up_maskbits"))
+                                             self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_up_maskbits"), cw=cw)
             return (y, None) if want_stats else y
         self._timed("conv_fwd_dgrad", 2.0 * N * Ho * Wo * O * I * 16, lambda: check(
             self.lib.rg_conv_up(_ptr(x), _ptr(cw.w), _ptr(wup), _ptr(y), N, Ho, Wo, O, I, _ptr(mask_act), float(slope),
-                                _ptr(st), self.dt, self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_up"))
+                                _ptr(st), self.dt, self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_up"), cw=cw)
         return (y, st) if want_stats else y
 
     def conv_up_affine(self, x, cw: ConvW, scale, shift, slope: float):
@@ -372,7 +433,7 @@ class HipOps:
         sc, sh = scale.float().contiguous(), shift.float().contiguous()
         self._timed("conv_fwd_dgrad", 2.0 * N * Ho * Wo * O * I * 16, lambda: check(
             self.lib.rg_conv_up_affine(_ptr(x), _ptr(wup), _ptr(y), N, Ho, Wo, O, I, _ptr(sc), _ptr(sh), float(slope),
-                                       _ptr(ws), ws.numel(), self.stream), "rg_conv_up_affine"))
+                                       _ptr(ws), ws.numel(), self.stream), "rg_conv_up_affine"), cw=cw)
         return y
 
     def g0_fwd_affine(self, z, cw: ConvW, scale, shift, slope: float):
@@ -436,7 +497,7 @@ class HipOps:
         sc, sh = (scale.float() * s).contiguous(), shift.float().contiguous()
         self._timed("conv_fwd_dgrad", 2.0 * N * Ho * Wo * O * I * 16, lambda: check(
             self.lib.rg_conv_up_fp8(_ptr(x8), _ptr(q), _ptr(y), N, Ho, Wo, O, I, _ptr(sc), _ptr(sh), float(slope),
-                                    int(out_fp8), self.stream), "rg_conv_up_fp8"))
+                                    int(out_fp8), self.stream), "rg_conv_up_fp8"), cw=cw)
         return y
 
     def g0_fwd_fp8(self, z8, cw: ConvW, scale, shift, slope: float, out_fp8: bool):
@@ -464,7 +525,7 @@ class HipOps:
         ws = self._ws(nb)
         self._timed("conv_wgrad", 2.0 * N * Ho * Wo * O * I * 16, lambda: check(
             self.lib.rg_conv_wgrad(_ptr(low), _ptr(high), _ptr(dw), N, Ho, Wo, O, I, self.dt, int(accumulate),
-                                   self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_wgrad"))
+                                   self.algo, _ptr(ws), ws.numel(), self.stream), "rg_conv_wgrad"), cw=cw)
 
     def conv_wgrad2(self, low0, high0, low1, high1, cw: ConvW, accumulate: bool):
         """dw (+)= wgrad(low0, high0) + wgrad(low1, high1) in one launch (one split-K reduction)."""
@@ -479,7 +540,7 @@ class HipOps:
         self._timed("conv_wgrad", 4.0 * N * Ho * Wo * O * I * 16, lambda: check(
             self.lib.rg_conv_wgrad2(_ptr(low0), _ptr(high0), _ptr(low1), _ptr(high1), _ptr(dw), N, Ho, Wo, O, I,
                                     self.dt, int(accumulate), self.algo, _ptr(ws), ws.numel(), self.stream),
-            "rg_conv_wgrad2"))
+            "rg_conv_wgrad2"), cw=cw)
 
     def u8_to_norm(self, u8, mean=0.5, std=0.5):
         """uint8 tiles (any shape, CHW order kept) -> fp32 (x / 255 - mean) / std on the device: the input transform of

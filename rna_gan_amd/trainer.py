@@ -126,7 +126,13 @@ class Trainer:
             # every unimportable global to an inert placeholder; the live plugin objects of THIS trainer are kept
             # (SURVEY 5 / 8b "Checkpoint": tolerate missing / unknown loss_objects, metric_*).
             from . import _tolerant_pickle
+            before = set(_tolerant_pickle.missing_globals())
             checkpoint = torch.load(load_path, map_location="cpu", weights_only=False, pickle_module=_tolerant_pickle)
+            absent = [k for k in _tolerant_pickle.missing_globals() if k not in before]
+            if absent:      # say what was replaced: the reference's plugin classes are expected, anything else is worth a look
+                print("load_model: {} global(s) of the checkpoint are not importable here and were read as inert "
+                      "placeholders: {}".format(len(absent), ", ".join("%s.%s" % k for k in absent[:12]) +
+                                                (" ..." if len(absent) > 12 else "")))
             self.start_epoch = checkpoint["epoch"]
             self.loss_information = checkpoint.get("loss_information", self.loss_information)
             self.loss_logs = checkpoint.get("loss_logs", self.loss_logs)
@@ -137,7 +143,14 @@ class Trainer:
                 getattr(self, load_item).load_state_dict(checkpoint[load_item])
             if load_items is not None:
                 for it in ([load_items] if isinstance(load_items, str) else load_items):
-                    setattr(self, it, checkpoint[it])
+                    obj = checkpoint[it]
+                    inner = list(obj.values()) if isinstance(obj, dict) else list(obj) if isinstance(obj, (list, tuple)) else []
+                    for o in [obj] + inner:               # the item itself or a member of a plain container
+                        if _tolerant_pickle.is_placeholder(o):
+                            cls = o if isinstance(o, type) else type(o)
+                            raise RuntimeError("load_items: '%s' holds an object pickled as %s.%s, which is not importable "
+                                               "here" % ((it,) + tuple(cls._rg_missing)))
+                    setattr(self, it, obj)
         except Exception as e:  # torchgan prints and continues; a silent restart would hide corruption
             raise RuntimeError("Model could not be loaded from {}: {}".format(load_path, e))
 
@@ -248,6 +261,21 @@ class Trainer:
             acc[kind] += cur
         return acc["g"], acc["d"]
 
+    def _poll_handoffs(self, final=False):
+        """Every ``handoff_check_every`` iterations (default 64; 0 = only at save_model): start a sync-free read of the fused
+        split-K BatchNorm kernels' error word (ops_hip.handoffs_poll_start: MAX over the ranks under data parallelism, copied
+        to a pinned slot behind this iteration's launches) and look at the one started earlier -- a timed-out in-kernel
+        rendezvous stops the run within that many iterations, on every rank together, instead of poisoning an epoch."""
+        from . import ops_hip as H
+        every = int(getattr(self, "handoff_check_every", 64))
+        st = self.__dict__.setdefault("_handoff_state", {"it": 0, "pending": None})
+        st["it"] += 1
+        if st["pending"] is not None and (final or st["it"] % max(every, 1) == 1 or every == 1):
+            h, st["pending"] = st["pending"], None
+            H.handoffs_poll_finish(h)
+        if not final and every > 0 and st["it"] % every == 0:
+            st["pending"] = H.handoffs_poll_start()
+
     def sample_images(self, epoch):
         if D_.rank() != 0 or not self.recon:
             return
@@ -279,11 +307,13 @@ class Trainer:
                 else:
                     self.real_inputs = data
                 lgen, ldis, gen_iter, dis_iter = self.train_iter(carry=getattr(self, "pipeline", True))
+                self._poll_handoffs()
                 self.loss_information["generator_losses"] += lgen
                 self.loss_information["discriminator_losses"] += ldis
                 self.loss_information["generator_iters"] += gen_iter
                 self.loss_information["discriminator_iters"] += dis_iter
             lgen, ldis = self.flush_pending()
+            self._poll_handoffs(final=True)
             self.loss_information["generator_losses"] += lgen
             self.loss_information["discriminator_losses"] += ldis
             self.save_model(epoch)

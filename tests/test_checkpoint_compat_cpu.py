@@ -214,3 +214,37 @@ def test_a_corrupt_stream_is_not_papered_over(tmp_path):
     tr = Trainer(_network(), _plugins(), device=torch.device("cpu"), checkpoints=str(tmp_path / "g"), recon=None)
     with pytest.raises(RuntimeError, match="could not be loaded"):
         tr.load_model(load_path=str(bad))
+
+
+def test_own_package_globals_and_placeholder_load_items_are_refused(reference_checkpoint, tmp_path, capsys):
+    """(1) a checkpoint that refers to a global of THIS package that no longer exists is an error, not a
+    placeholder (a refactor must not be papered over); (2) load_items must not attach a placeholder to the trainer;
+    (3) load_model says which globals it replaced."""
+    import pickle
+
+    class Gone:                                           # pickled as rna_gan_amd.losses.NoSuchPlugin
+        pass
+    Gone.__module__, Gone.__qualname__, Gone.__name__ = "rna_gan_amd.losses", "NoSuchPlugin", "NoSuchPlugin"
+    L.NoSuchPlugin = Gone
+    try:
+        blob = pickle.dumps({"epoch": 1, "x": Gone()})
+    finally:
+        del L.NoSuchPlugin
+    with pytest.raises(AttributeError):
+        _tolerant_pickle.loads(blob)
+    path, _, _ = reference_checkpoint
+    net = _network()
+    for cfg in net.values():
+        cfg["optimizer"]["name"] = Adam
+    tr = Trainer(net, _plugins(), device=torch.device("cpu"), checkpoints=str(tmp_path / "dst"), recon=None)
+    capsys.readouterr()
+    _tolerant_pickle._PLACEHOLDERS.clear()                # as a fresh process: the report lists what THIS load replaced
+    tr.load_model(load_path=path)
+    out = capsys.readouterr().out
+    assert "inert placeholders" in out and "wgan_loss.WassersteinGeneratorLossVAE" in out
+    with pytest.raises(RuntimeError, match="not importable"):      # a dict of the reference's metric objects: placeholders
+        tr.load_model(load_path=path, load_items="metric_objects")
+    assert not hasattr(tr, "metric_objects") or not any(
+        _tolerant_pickle.is_placeholder(v) for v in getattr(tr, "metric_objects", {}).values())
+    tr.load_model(load_path=path, load_items="metric_logs")        # plain data passes
+    assert tr.metric_logs == {"ClassifierScore": [1.0]}

@@ -135,3 +135,62 @@ def test_dp2_sync_stats_matches_single_process_global_batch():
             n = want[k].numel()
             np.testing.assert_allclose(res[r][k][:n], want[k].numpy(), rtol=1e-6, atol=1e-9, err_msg=f"rank{r} {k}")
         np.testing.assert_allclose(res[r]["rm"], want_rm.numpy(), rtol=1e-9, atol=1e-12, err_msg="BN buffers")
+
+
+def _handoff_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from rna_gan_amd import dist as D_, ops_hip as H
+    torch.set_num_threads(1)
+    D_.init_from_env(backend="gloo")
+
+    class FakeOps:                       # what check_handoffs reads of a backend: its device and the error word
+        device = torch.device("cpu")
+
+        def __init__(self):
+            self._sb_sync = torch.zeros(4, dtype=torch.int32)
+    ops = FakeOps()
+    H._LIVE_OPS.add(ops)
+    res = {}
+    H.check_handoffs()                   # clean on every rank: no error
+    if rank == world - 1:
+        ops._sb_sync[0] = 1              # ONE rank's in-kernel rendezvous timed out
+    try:
+        H.check_handoffs()
+        res["raised"] = False
+    except RuntimeError as e:
+        res["raised"] = "timed out" in str(e)
+    res["rearmed"] = int(ops._sb_sync[0]) == 0
+    H.check_handoffs()                   # re-armed: clean again (and still collective: no rank hangs)
+    # the sync-free poll of the Trainer: same semantics
+    h = H.handoffs_poll_start()
+    H.handoffs_poll_finish(h)
+    if rank == 0:
+        ops._sb_sync[0] = 7
+    h = H.handoffs_poll_start()
+    try:
+        H.handoffs_poll_finish(h)
+        res["poll_raised"] = False
+    except RuntimeError:
+        res["poll_raised"] = True
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_check_handoffs_is_rank_collective():
+    """the error word of the fused split-K BatchNorm kernels is MAX-all-reduced, so EVERY rank raises when
+    one rank's launch timed out (rank 0 must not checkpoint weights that absorbed that rank's gradients, and no rank may be
+    left waiting in the next collective); three ranks over gloo, the word set on the last / the first rank only."""
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_handoff_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert got[r] == {"raised": True, "rearmed": True, "poll_raised": True}, (r, got[r])
