@@ -837,7 +837,7 @@ def extra_batch(args, device, info, batch, steps=6, warm=14):
 F32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X fp32 matrix (= vector) peak, MI355X_MICROARCH.md
 
 
-def extra_fp32_step(args, device, info, steps=3, warm=6):
+def extra_fp32_step(args, device, info, steps=4, warm=10):
     """The fp32 parity mode (--precision fp32: the reference's own arithmetic, src/betaVAE.py:184,223,230-236; the anchor of
     the tight-tolerance parity tests) on the same workload.  Convolutions / dense layers run on the f32 matrix cores
     (gemm_mfma32s_kernel / gemm_mfma32_kernel: v_mfma_f32_32x32x2_f32 with structured operands / behind the generic operand functors, rg_generic.hip); everything else is the
@@ -857,7 +857,7 @@ def extra_fp32_step(args, device, info, steps=3, warm=6):
         return [lg.step(G, Dm, og, h["rna"], us[0]), ld.step(G, Dm, od, h["real"], h["rna"], us[1], next_u=us[2]),
                 lp.step(G, Dm, od, h["real"], h["rna"], us[2], eps)]
     for _ in range(warm):           # graph capture: two eager runs per launch-sequence variant, replay from the third on
-        it()
+        it()                        # (6 were not always enough: a capture inside the timed steps read 83 instead of 65 ms)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for _ in range(steps):

@@ -122,6 +122,13 @@ int rg_conv_wgrad(const void* low, const void* high, float* dw, int N, int Ho, i
 int rg_conv_wgrad2(const void* low0, const void* high0, const void* low1, const void* high1, float* dw, int N,
                    int Ho, int Wo, int O, int I, int dtype, int accumulate, int algo, void* ws, size_t ws_bytes,
                    void* stream);
+/* rg_conv_wgrad (low1 = high1 = NULL) / rg_conv_wgrad2 with the split-K reduction LEFT TO THE CALLER'S OPTIMIZER STEP
+ * (.backward() directly followed by optimizer.step(), src/wgan_loss.py:126-127, :260-261, :387-388): a plan with
+ * *nsplit_out > 1 leaves its fp32 partial slabs [nsplit][O][16][I] in `slab` (>= rg_conv_wgrad_workspace_bytes, caller-owned,
+ * must stay untouched until rg_adam_step_slabs has consumed it) and does not write dw; *nsplit_out == 1: dw was written
+ * (not accumulated) and nothing is pending.  RG_EUNSUPPORTED where the bf16 matrix-core weight gradient does not apply. */
+int rg_conv_wgrad_slabs(const void* low0, const void* high0, const void* low1, const void* high1, float* dw, int N, int Ho,
+                        int Wo, int O, int I, int dtype, int algo, void* slab, size_t slab_bytes, int* nsplit_out, void* stream);
 
 /* Image-side layers (I = 3 channels, NCHW fp32 on the high-resolution side; HBM-bound).  Their weights keep
  * the PyTorch layout w[O][I][4][4] (48 values per O).
@@ -440,6 +447,14 @@ int rg_clamp(float* p, size_t n, float lo, float hi, void* stream);
  * run, which then needs no widening pass back to fp32. */
 int rg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, void* shadow_bf16,
                      const void* grad_bf16, void* stream);
+/* rg_adam_step_dev over [p, p + n) cut into nseg <= 24 consecutive segments (seg_off / seg_n in elements, tiling the range in
+ * order, every offset a multiple of 4): a segment with seg_slab[i] != NULL takes its gradient as the sum, in slab order, of
+ * seg_nsplit[i] fp32 slabs of seg_n[i] elements (what rg_conv_wgrad_slabs left in the caller's buffer) instead of reading g --
+ * the split-K reduction launches of the backward pass and the write + re-read of the reduced gradient disappear (one launch
+ * for the whole buffer; deterministic summation order).  Segment tables are HOST arrays. */
+int rg_adam_step_slabs(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, void* shadow_bf16, int nseg,
+                       const unsigned long long* seg_off, const unsigned long long* seg_n, const void* const* seg_slab,
+                       const int* seg_nsplit, void* stream);
 /* ++(*step_dev) and recompute hyper[0..6] from it on the device (double arithmetic, one thread): with
  * this launch in front of rg_adam_step_dev the whole optimizer step replays from a graph untouched.
  * hyper[7] = weight_decay (torch.optim.Adam's L2 term g += wd * p; 0 on the GAN path, betaVAE training sets it,

@@ -18,7 +18,7 @@ void rg_set_error(const char* fmt, ...) {
 }
 
 // bumped whenever an entry point is added or a signature changes; rna_gan_amd/_abi.py (ABI_VERSION) refuses any other value
-extern "C" int rg_version(void) { return 400; }   // 4.00: round 4 (the diagnostic rg_debug_hold_cus left the ABI: tools/debug/)
+extern "C" int rg_version(void) { return 500; }   // 5.00: round 5 (rg_conv_wgrad_slabs, rg_adam_step_slabs)
 extern "C" const char* rg_last_error(void) { return g_err; }
 
 // ---- kernel-selection knobs: override table in front of the RNAGAN_* environment variables
@@ -180,6 +180,19 @@ extern "C" int rg_conv_wgrad2(const void* low0, const void* high0, const void* l
   int rc = rg_generic_conv_wgrad(low0, high0, dw, N, Ho, Wo, O, I, dtype, accumulate, ws, ws_bytes, rg_stream(stream));
   if (rc) return rc;
   return rg_generic_conv_wgrad(low1, high1, dw, N, Ho, Wo, O, I, dtype, 1, ws, ws_bytes, rg_stream(stream));
+}
+
+// rg_conv_wgrad / rg_conv_wgrad2 (low1 / high1 may be NULL: one segment) with the split-K reduction LEFT TO THE CALLER: a plan
+// with nsplit > 1 leaves its fp32 slabs [nsplit][O][16][I] in `slab` (at least rg_conv_wgrad_workspace_bytes) and does not
+// touch dw; *nsplit_out says how many (1: dw was written, nothing is pending).  The consumer is rg_adam_step_slabs.
+extern "C" int rg_conv_wgrad_slabs(const void* low0, const void* high0, const void* low1, const void* high1, float* dw, int N,
+                                   int Ho, int Wo, int O, int I, int dtype, int algo, void* slab, size_t slab_bytes,
+                                   int* nsplit_out, void* stream) {
+  RG_REQUIRE(low0 && high0 && dw && nsplit_out && (low1 == nullptr) == (high1 == nullptr) && N > 0 && Ho > 0 && Wo > 0 && I > 0 &&
+                 O > 0, RG_EINVAL, "conv_wgrad_slabs: bad args");
+  RG_REQUIRE(want_mfma(algo, dtype) && rg_mfma_wgrad_supported(N, Ho, Wo, O, I), RG_EUNSUPPORTED,
+             "conv_wgrad_slabs: only the bf16 matrix-core weight gradient leaves slabs");
+  return rg_mfma_conv_wgrad2(low0, high0, low1, high1, dw, N, Ho, Wo, O, I, 0, slab, slab_bytes, rg_stream(stream), nsplit_out);
 }
 
 extern "C" int rg_conv_wgrad(const void* low, const void* high, float* dw, int N, int Ho, int Wo, int O, int I,

@@ -144,10 +144,16 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
   // with U wave-uniform (fr < 16 <= Ws never carries into the image row).  Row tiles of one image row are 16 patch rows =
   // 2048 B apart with the same swizzle (rho & 6 ignores multiples of 16): one address + immediates per image row.
   const int fr = lane & 15, fh = lane >> 4;
-  // B (= MFMA A operand, see the epilogue): row i of column tile j is output channel 16 (i >> 2) + 4 j + (i & 3), so that the
-  // four tiles give a lane 16 CONSECUTIVE channels of its pixel (two 16-byte stores per pixel and lane)
+  // B (= MFMA A operand, see the epilogue): row i of column tile j is output channel 32 (j >> 1) + 8 (i >> 2) + 4 (j & 1) + (i & 3),
+  // so that tiles 0, 1 give a lane (px, fq = i >> 2) the 8 consecutive channels 8 fq .. 8 fq + 7 and tiles 2, 3 the channels
+  // 32 + 8 fq .. + 7: each of the lane's two 16-byte stores, taken over the four lanes of a pixel, covers one CONTIGUOUS
+  // 64-byte half of the pixel's 128-byte line.  (Until round 5 a lane held 16 consecutive channels and each store instruction
+  // wrote 16-byte pieces with 16-byte holes: half-written 32-byte sectors that the L2 evicted and wrote again -- the PMC
+  // counted 168-209 MB written for 134 MB of output.)  The ring's swizzle is a function of the COLUMN, (col >> 4) & 1, as
+  // before: with col = 8 (fr >> 2) + (fr & 3) (+ 0, 4, 32, 36 per tile) that is bit 3 of fr, and the four segment values of
+  // every ds_read_b128 lane group stay distinct.
   const unsigned b_rd = lds_base + CP_OFF_RING + cls * 4096 +
-                        (unsigned)((16 * (fr >> 2) + (fr & 3)) * 64 + ((fh ^ (((fr >> 2) & 1) << 1)) << 4));
+                        (unsigned)((8 * (fr >> 2) + (fr & 3)) * 64 + ((fh ^ (((fr >> 3) & 1) << 1)) << 4));
   f32x4_t acc[8][4];
   u32x4_t aS0[4], aS1[4], bS[2][4];                       // B(s) lives in set s & 1
 
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
     asm volatile("" : "+v"(ba_));                                                                 \
     ba_ += (SLOTOFF);                                                                             \
     CP_DSR(bS[SET][0], ba_, 0); CP_DSR(bS[SET][1], ba_, 256);                                     \
-    CP_DSR(bS[SET][2], ba_, 512); CP_DSR(bS[SET][3], ba_, 768);                                   \
+    CP_DSR(bS[SET][2], ba_, 2048); CP_DSR(bS[SET][3], ba_, 2304);                                 \
   } while (0)
 #define CP_WAIT4(X) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3])::"memory")
 // MFMAs as inline asm with the accumulator tied in place ("+v"): with the builtin hipcc lets D and C differ and walks the
@@ -214,9 +220,9 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
 #define CP_SYNC() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 
   // ---- epilogue.  The MFMAs compute the TRANSPOSED tile (weights as the A operand, pixels as the B operand): accumulator
-  // lane (px = lane & 15, fq = lane >> 4) of tile (rt, j) holds channels 16 j + 4 fq .. + 3 of pixel rt*16 + px -- four
-  // consecutive channels = 8 contiguous output bytes, stored straight from registers (no LDS transposition; the four
-  // j-stores of a pixel fill its 128-byte line in L2).
+  // lane (px = lane & 15, fq = lane >> 4) of tile (rt, j) holds channels CH(fq, j) .. + 3 = 32 (j >> 1) + 8 fq + 4 (j & 1) .. + 3
+  // of pixel rt*16 + px -- tiles 0, 1 are 8 consecutive channels = one 16-byte store, tiles 2, 3 the second, stored straight
+  // from registers (no LDS transposition); per store instruction the four lanes of a pixel write 64 contiguous bytes.
   constexpr int Wq2 = 2 * Ws;
   // byte offset of output pixel (class (ph, pw)) of low-resolution pixel m (wave-uniform m), 128 B per output pixel
   auto out_base = [&](int mu) {
@@ -250,18 +256,24 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
 
   auto epilogue = [&](int T) {
     CP_ACC_FENCE();                                       // MFMA write -> VALU read
+    // ... and the operands of the tile's LAST MFMA group (CP_LAST: sub-block 1 with aS1 / bS[1]) stay allocated across that
+    // fence: the group has no wait behind it, and hipcc hoists the epilogue's lane arithmetic above the fence into registers it
+    // considers dead -- a VALU write into a fragment register while its MFMA still re-reads it corrupts rows 2, 3 of the later
+    // passes (round 5: after a change that moved the allocation, channels 32 + 8 fq + 2, 3 of the last row tiles were garbage
+    // in the mask variant; the tests caught it)
+    CP_KEEP_ALL(aS1, 1);
     const int m_w = (T << 8) + half * 128;                // first pixel of this wave
     const int ln = opq();
-    const int px = ln & 15, fq = ln >> 4;                 // the lane's pixel of a row tile; its channels are 16 fq + 4 j + r
-    const unsigned e_off = (unsigned)(px * 256 + fq * 32);
+    const int px = ln & 15, fq = ln >> 4;                 // the lane's pixel of a row tile; its channels are 32 (j >> 1) + 8 fq + 4 (j & 1) + r
+    const unsigned e_off = (unsigned)(px * 256 + fq * 16);
     const unsigned bits_r = lds_base + CP_OFF_BITS + wave * 1024 + (unsigned)(px * 8);
-    u32x4_t asc[4], ash[4];                               // scale / shift of channels 16 fq + 4 j .. + 3 (LDS table, asm reads)
+    u32x4_t asc[4], ash[4];                               // scale / shift of channels CH(fq, j) .. + 3 (LDS table, asm reads)
     if constexpr (HAS_AFFINE) {
-      const unsigned aff_r = lds_base + CP_OFF_AFF + (unsigned)(fq * 64);
+      const unsigned aff_r = lds_base + CP_OFF_AFF + (unsigned)(fq * 32);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(asc[j]) : "v"(aff_r), "n"(j * 16) : "memory");
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ash[j]) : "v"(aff_r), "n"(256 + j * 16) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(asc[j]) : "v"(aff_r), "n"((j >> 1) * 128 + (j & 1) * 16) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ash[j]) : "v"(aff_r), "n"(256 + (j >> 1) * 128 + (j & 1) * 16) : "memory");
       }
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(asc[0]), "+v"(asc[1]), "+v"(asc[2]), "+v"(asc[3]), "+v"(ash[0]), "+v"(ash[1]),
                    "+v"(ash[2]), "+v"(ash[3])::"memory");
@@ -273,12 +285,19 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
       for (int h = 0; h < 2; ++h) { s1[j][h] = f32x2_t{0.f, 0.f}; s2[j][h] = f32x2_t{0.f, 0.f}; }
 #pragma unroll
     for (int rt = 0; rt < 8; ++rt) {
-      unsigned b16 = 0;
+      unsigned b8lo = 0, b8hi = 0;                        // sign bits of channels 8 fq .. + 7 and 32 + 8 fq .. + 7
       if constexpr (HAS_MASK) {
         u32x2_t w;
         asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(w) : "v"(bits_r), "n"(rt * 128) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w)::"memory");
-        b16 = ((fq & 2) ? w.y : w.x) >> ((fq & 1) * 16);
+        b8lo = w.x >> (fq * 8);
+        b8hi = w.y >> (fq * 8);
+        // both words are formed HERE, right behind the wait (an opaque use pins the two shifts to this point).  Left to the
+        // compiler, the second shift was sunk 60 instructions down to its first use and lanes 12..15 of every row tile read
+        // garbage for channels 32 + 8 fq + 2, 3 (found by the bit-exact test against the implicit-GEMM kernel; a build with
+        // more wait states in front of the shift failed on MORE elements, one with the shifts pinned passed -- the register of
+        // the read's second dword does not survive the masked stores' address arithmetic; cause not isolated further)
+        asm volatile("" : "+v"(b8lo), "+v"(b8hi));
       }
       u32x4_t o[2];
 #pragma unroll
@@ -286,7 +305,7 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
         f32x4_t v = acc[rt][j];
         if constexpr (HAS_MASK) {
           const float sl = g.mslope;
-          const unsigned b4 = b16 >> (4 * j);
+          const unsigned b4 = ((j >> 1) ? b8hi : b8lo) >> (4 * (j & 1));
           v[0] *= (b4 & 1u) ? 1.f : sl; v[1] *= (b4 & 2u) ? 1.f : sl;
           v[2] *= (b4 & 4u) ? 1.f : sl; v[3] *= (b4 & 8u) ? 1.f : sl;
         }
@@ -308,19 +327,19 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
       }
       char* cb = reinterpret_cast<char*>(g.C) + out_base(m_w + rt * 16);
       asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(e_off), "v"(o[0]), "s"(cb) : "memory");
-      asm volatile("global_store_dwordx4 %0, %1, %2 offset:16" ::"v"(e_off), "v"(o[1]), "s"(cb) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, %2 offset:64" ::"v"(e_off), "v"(o[1]), "s"(cb) : "memory");
     }
     if constexpr (HAS_STATS) {
       const size_t grow = ((size_t)cls * tiles + T) * 2 + half;
       const char* sb = reinterpret_cast<const char*>(g.stats + grow * 128);       // wave-uniform row [2][64]
-      const unsigned so = (unsigned)(fq * 64);
+      const unsigned so = (unsigned)(fq * 32);             // floats CH(fq, j) .. + 3 of the [2][64] row
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const f32x4_t q1 = {dpp_sum16(s1[j][0][0]), dpp_sum16(s1[j][0][1]), dpp_sum16(s1[j][1][0]), dpp_sum16(s1[j][1][1])};
         const f32x4_t q2 = {dpp_sum16(s2[j][0][0]), dpp_sum16(s2[j][0][1]), dpp_sum16(s2[j][1][0]), dpp_sum16(s2[j][1][1])};
         if (px == 0) {
-          asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" ::"v"(so), "v"(q1), "s"(sb), "n"(j * 16) : "memory");
-          asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" ::"v"(so), "v"(q2), "s"(sb), "n"(256 + j * 16) : "memory");
+          asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" ::"v"(so), "v"(q1), "s"(sb), "n"((j >> 1) * 128 + (j & 1) * 16) : "memory");
+          asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" ::"v"(so), "v"(q2), "s"(sb), "n"(256 + (j >> 1) * 128 + (j & 1) * 16) : "memory");
         }
       }
     }

@@ -95,7 +95,8 @@ int rg_mfma_conv_wgrad(const void* low, const void* high, float* dw, int N, int 
                        int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
 
 int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, const void* high1, float* dw, int N,
-                        int Ho, int Wo, int O, int I, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+                        int Ho, int Wo, int O, int I, int accumulate, void* ws, size_t ws_bytes, hipStream_t st,
+                        int* nsplit_out = nullptr);
 size_t rg_mfma_wgrad2_ws_bytes(int N, int Ho, int Wo, int O, int I);
 
 bool rg_mfma_fp8_supported(int M, int K, int Ncols, int taps);

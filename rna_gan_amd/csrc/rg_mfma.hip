@@ -1591,8 +1591,13 @@ static int mfma_wgrad_split_k(int K, int O, int I) {
   return s < 1 ? 1 : s;
 }
 
+// nsplit_out (optional): the split-K launch leaves its fp32 slabs [nsplit][O][16][I] in `ws` and the REDUCTION IS SKIPPED
+// (*nsplit_out = nsplit > 1; dw untouched) -- the caller's optimizer step sums the slabs itself (rg_adam_step_slabs); a plan
+// without a split writes dw as usual and reports 1.
 int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, const void* high1, float* dw, int N,
-                        int Ho, int Wo, int O, int I, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+                        int Ho, int Wo, int O, int I, int accumulate, void* ws, size_t ws_bytes, hipStream_t st,
+                        int* nsplit_out) {
+  if (nsplit_out) *nsplit_out = 1;
   const int Kseg = N * Ho * Wo;
   const bool two = low1 != nullptr;
   size_t lowb = (size_t)Kseg * O * 2, highb = (size_t)Kseg * 4 * I * 2;
@@ -1614,6 +1619,7 @@ int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, c
       int rc = rg_wgrad8_launch(low0, high0, low1, high1, ns == 1 ? dw : (float*)ws, Kseg, two ? 1 : 0, O, I, Ho, Wo, ns,
                                 per, accumulate, st);
       if (rc || ns == 1) return rc;
+      if (nsplit_out) { *nsplit_out = ns; return RG_OK; }
       return rg_reduce_slabs((const float*)ws, dw, elems, ns, accumulate, 0, 0, st);
     }
   }
@@ -1625,6 +1631,7 @@ int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, c
       int rc = rg_wgrad8n_launch(low0, high0, low1, high1, ns == 1 ? dw : (float*)ws, Kseg, two ? 1 : 0, O, I, Ho, Wo, ns,
                                  per, accumulate, st);
       if (rc || ns == 1) return rc;
+      if (nsplit_out) { *nsplit_out = ns; return RG_OK; }
       return rg_reduce_slabs((const float*)ws, dw, elems, ns, accumulate, 0, 0, st);
     }
   }
@@ -1648,6 +1655,7 @@ int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, c
   hipLaunchKernelGGL(wgrad_dma_kernel<false>, dim3((unsigned)(g.tiles_o * g.tiles_c * nsplit)), dim3(256), 0, st, g);
   RG_LAUNCH_CHECK("conv_wgrad(mfma)");
   if (nsplit == 1) return RG_OK;
+  if (nsplit_out) { *nsplit_out = nsplit; return RG_OK; }
   return rg_reduce_slabs((const float*)ws, dw, elems, nsplit, accumulate, 0, 0, st);
 }
 

@@ -133,6 +133,100 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
   }
 }
 
+// ---- Adam over a flat buffer cut into SEGMENTS, some of whose gradients are still split-K partial slabs of their weight-
+// gradient launch ([nsplit][n] fp32, rg_conv_wgrad_slabs): the step sums them itself, in slab order, instead of reading a
+// reduced gradient -- the reduction launches of a backward pass (5-6 per pass at ~12 us: bandwidth-bound, 67 MB of slabs each)
+// and the write + re-read of the reduced gradient disappear.  One launch for the whole buffer: every workgroup walks the
+// segments in order.  A slab segment is processed by groups of SL threads per 16-byte column (SL = 1 / 4 / 16 chosen from
+// nsplit: lane l sums slabs l, l + SL, ... with 8 loads in flight, the SL partial sums are combined through LDS in lane order:
+// a fixed summation order, deterministic); the group's first thread applies Adam.
+constexpr int ADAM_MAX_SEGS = 24;
+struct AdamSeg { unsigned long long off, n; const float* slab; int nsplit; int pad; };
+struct AdamSegs { int nseg; int pad; AdamSeg s[ADAM_MAX_SEGS]; };
+
+template <bool SHADOW, int SL>
+__device__ __forceinline__ void adam_slab_segment(const Adam& a, float* __restrict__ p, float* __restrict__ m,
+                                                  float* __restrict__ v, uint16_t* __restrict__ shadow,
+                                                  const float* __restrict__ slab, int nsplit, size_t n, float4 (*sm)[64]) {
+  // n is a multiple of 4 (conv weights: O * 16 * I); a block takes 256 / SL columns per trip
+  constexpr int COLS = 256 / SL;
+  const int col = threadIdx.x % COLS, l = threadIdx.x / COLS;
+  const size_t n4 = n / 4;
+  const size_t trips = (n4 + COLS - 1) / COLS;
+  for (size_t tb = blockIdx.x; tb < trips; tb += gridDim.x) {
+    const size_t q = tb * COLS + col;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < n4) {
+      int z = l;
+      for (; z + 7 * SL < nsplit; z += 8 * SL) {           // 8 independent loads, added in slab order
+        float4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = nt_ld4(slab + (size_t)(z + k * SL) * n + q * 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s.x += t[k].x; s.y += t[k].y; s.z += t[k].z; s.w += t[k].w; }
+      }
+      for (; z < nsplit; z += SL) {
+        const float4 t = nt_ld4(slab + (size_t)z * n + q * 4);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+    }
+    if (SL > 1) {
+      __syncthreads();                                     // the previous trip's readers are done
+      sm[l][col] = s;
+      __syncthreads();
+      if (l == 0) {
+#pragma unroll
+        for (int k = 1; k < SL; ++k) { const float4 t = sm[k][col]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+      }
+    }
+    if (l == 0 && q < n4) {
+      const size_t i = q * 4;
+      float4 P = *(float4*)(p + i), M = nt_ld4(m + i), V = nt_ld4(v + i);
+      a.upd(P.x, s.x, M.x, V.x); a.upd(P.y, s.y, M.y, V.y); a.upd(P.z, s.z, M.z, V.z); a.upd(P.w, s.w, M.w, V.w);
+      *(float4*)(p + i) = P; nt_st4(m + i, M); nt_st4(v + i, V);
+      if (SHADOW)
+        *(uint2*)(shadow + i) = make_uint2((uint32_t)f32_to_bf16(P.x) | ((uint32_t)f32_to_bf16(P.y) << 16),
+                                           (uint32_t)f32_to_bf16(P.z) | ((uint32_t)f32_to_bf16(P.w) << 16));
+    }
+  }
+}
+
+template <bool SHADOW>
+__global__ __launch_bounds__(256) void adam_segs_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        const float* __restrict__ hyper, uint16_t* __restrict__ shadow,
+                                                        AdamSegs t) {
+  __shared__ float4 sm[16][64];                            // [slab lane][column]: SL = 4 uses [4][64], SL = 16 [16][16]
+  const Adam a{p, g, m, v, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6], hyper[7]};
+  for (int si = 0; si < t.nseg; ++si) {
+    const AdamSeg sg = t.s[si];
+    float* ps = p + sg.off; float* ms = m + sg.off; float* vs = v + sg.off;
+    uint16_t* sh = SHADOW ? shadow + sg.off : nullptr;
+    if (sg.slab) {
+      if (sg.nsplit <= 4) adam_slab_segment<SHADOW, 1>(a, ps, ms, vs, sh, sg.slab, sg.nsplit, sg.n, sm);
+      else if (sg.nsplit <= 32) adam_slab_segment<SHADOW, 4>(a, ps, ms, vs, sh, sg.slab, sg.nsplit, sg.n, sm);
+      else adam_slab_segment<SHADOW, 16>(a, ps, ms, vs, sh, sg.slab, sg.nsplit, sg.n, reinterpret_cast<float4(*)[64]>(sm));
+      continue;
+    }
+    const float* gs = g + sg.off;
+    const size_t n4 = sg.n / 4, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
+      const size_t i = q * 4;
+      float4 P = *(float4*)(ps + i), M = nt_ld4(ms + i), V = nt_ld4(vs + i), G = nt_ld4(gs + i);
+      a.upd(P.x, G.x, M.x, V.x); a.upd(P.y, G.y, M.y, V.y); a.upd(P.z, G.z, M.z, V.z); a.upd(P.w, G.w, M.w, V.w);
+      *(float4*)(ps + i) = P; nt_st4(ms + i, M); nt_st4(vs + i, V);
+      if (SHADOW)
+        *(uint2*)(sh + i) = make_uint2((uint32_t)f32_to_bf16(P.x) | ((uint32_t)f32_to_bf16(P.y) << 16),
+                                       (uint32_t)f32_to_bf16(P.z) | ((uint32_t)f32_to_bf16(P.w) << 16));
+    }
+    const size_t tl = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // tail (a segment that is not a multiple of 4)
+    if (tl < sg.n) {
+      a.upd(ps[tl], gs[tl], ms[tl], vs[tl]);
+      if (SHADOW) sh[tl] = f32_to_bf16(ps[tl]);
+    }
+  }
+}
+
 // element-per-thread form for ranges that do not start on a 16-byte boundary (the small bias / BatchNorm ranges between the
 // nn.Linear weights that rg_linear_wgrad_adam steps itself): fp32 gradient, no shadow
 __global__ __launch_bounds__(256) void adam_dev_scalar_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -457,6 +551,36 @@ extern "C" int rg_adam_step_dev(float* p, const float* g, float* m, float* v, si
   else if (sh) hipLaunchKernelGGL((adam_dev_kernel<false, true>), grid, block, 0, st, p, g, m, v, hyper, sh, gw, n);
   else hipLaunchKernelGGL((adam_dev_kernel<false, false>), grid, block, 0, st, p, g, m, v, hyper, sh, gw, n);
   RG_LAUNCH_CHECK("adam_step_dev");
+  return RG_OK;
+}
+// Adam over [p, p + n) cut into nseg consecutive segments (seg_off / seg_n in elements, covering the range in order; every
+// seg_off a multiple of 4); segment i with seg_slab[i] != NULL takes its gradient as the sum of seg_nsplit[i] fp32 slabs of
+// seg_n[i] elements each (what rg_conv_wgrad_slabs left), the others read g.  See adam_segs_kernel.
+extern "C" int rg_adam_step_slabs(float* p, const float* g, float* m, float* v, size_t n, const float* hyper,
+                                  void* shadow_bf16, int nseg, const unsigned long long* seg_off,
+                                  const unsigned long long* seg_n, const void* const* seg_slab, const int* seg_nsplit,
+                                  void* stream) {
+  RG_REQUIRE(p && g && m && v && hyper && seg_off && seg_n && seg_slab && seg_nsplit, RG_EINVAL, "adam_step_slabs: bad args");
+  RG_REQUIRE(nseg >= 1 && nseg <= ADAM_MAX_SEGS, RG_EINVAL, "adam_step_slabs: 1 .. %d segments", ADAM_MAX_SEGS);
+  RG_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && ((uintptr_t)shadow_bf16 & 7) == 0, RG_EINVAL,
+             "adam_step_slabs: alignment");
+  AdamSegs t{};
+  t.nseg = nseg;
+  unsigned long long pos = 0;
+  for (int i = 0; i < nseg; ++i) {
+    RG_REQUIRE(seg_off[i] == pos && seg_off[i] % 4 == 0, RG_EINVAL, "adam_step_slabs: segments must tile the range in order, "
+               "each starting on a multiple of 4 elements (segment %d)", i);
+    RG_REQUIRE(!seg_slab[i] || (seg_nsplit[i] >= 1 && seg_n[i] % 4 == 0 && aligned16(seg_slab[i])), RG_EINVAL,
+               "adam_step_slabs: slab segment %d", i);
+    t.s[i] = AdamSeg{seg_off[i], seg_n[i], (const float*)seg_slab[i], seg_slab[i] ? seg_nsplit[i] : 0, 0};
+    pos += seg_n[i];
+  }
+  RG_REQUIRE(pos == n, RG_EINVAL, "adam_step_slabs: the segments cover %llu of %zu elements", pos, n);
+  const dim3 grid(grid_for(n, 4)), block(256);
+  hipStream_t st = rg_stream(stream);
+  if (shadow_bf16) hipLaunchKernelGGL((adam_segs_kernel<true>), grid, block, 0, st, p, g, m, v, hyper, (uint16_t*)shadow_bf16, t);
+  else hipLaunchKernelGGL((adam_segs_kernel<false>), grid, block, 0, st, p, g, m, v, hyper, (uint16_t*)nullptr, t);
+  RG_LAUNCH_CHECK("adam_step_slabs");
   return RG_OK;
 }
 extern "C" int rg_adam_hyper_dev(int* step_dev, double lr, double beta1, double beta2, double eps, double weight_decay,

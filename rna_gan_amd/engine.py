@@ -44,7 +44,8 @@ class ConvW:
     """
 
     __slots__ = ("w", "bias", "dw", "dbias", "packs", "packs_version", "version", "layout", "shadow",
-                 "shadow_version", "_fp8", "fuse_step", "pending_wgrad", "factor_stage", "owner")
+                 "shadow_version", "_fp8", "fuse_step", "pending_wgrad", "factor_stage", "owner", "defer_slabs",
+                 "pending_slabs", "_slab_ws")
 
     def __init__(self, w, bias=None, dw=None, dbias=None, layout="OIHW"):
         self.w = w
@@ -59,6 +60,12 @@ class ConvW:
         self.shadow_version = -1      # master version the shadow reflects
         self._fp8 = None              # backend-private fp8 inference image (key, bytes, column scales)
         self.owner = None             # "G" / "D": which network the layer belongs to (bench.py's per-network roofline rows)
+        # 4 x 4 conv layers (HIP backend, bf16, single process): defer_slabs -- set by the train_op runner for a gradient pass whose
+        # optimizer step follows immediately -- lets a split-K weight-gradient launch leave its fp32 slabs in _slab_ws
+        # (pending_slabs = (buffer, nsplit)) instead of reducing them into dw: rna_gan_amd.optim.Adam sums them inside its step
+        self.defer_slabs = False
+        self.pending_slabs = None
+        self._slab_ws = None
         # generator layer 0 only (HIP backend): fuse_step -- set by the train_op runner for the duration of one gradient pass
         # whose optimizer step follows immediately -- lets g0_wgrad leave its operands in pending_wgrad instead of writing dw;
         # the fused Adam then forms the gradient and applies the step in one kernel (rg_g0_wgrad_adam)

@@ -364,14 +364,34 @@ def _dispatch(runner, key, body, inputs, generator, discriminator, stepped, opti
         g0 = _fusable_g0(stepped, optimizer)
         if g0 is not None:
             g0.fuse_step = True          # this gradient pass is followed at once by optimizer.step(): see ConvW.fuse_step
+        deferred = _slab_layers(stepped, optimizer)
+        for cw in deferred:
+            cw.defer_slabs = True        # ... and the split-K weight gradients of its 4 x 4 layers may stay unreduced slabs
         try:
             loss = body.grads(*a)
         finally:
             if g0 is not None:
                 g0.fuse_step = False
+            for cw in deferred:
+                cw.defer_slabs = False
         _finish(stepped, optimizer)
         return loss
     return runner.run(key, full, inputs, mods, [optimizer])
+
+
+# split-K weight-gradient slabs summed inside the optimizer step instead of by a reduction launch per layer (single process,
+# bf16 kernels, rna_gan_amd.optim.Adam bound to the stepped module): ConvW.defer_slabs / ops_hip._wgrad_slabs / rg_adam_step_slabs
+SLAB_ADAM = os.environ.get("RNAGAN_SLAB_ADAM", "1") != "0"
+
+
+def _slab_layers(stepped, optimizer):
+    if (not SLAB_ADAM or D_.active() or not hasattr(optimizer, "note_replayed") or
+            getattr(optimizer, "_module", None) is not stepped):
+        return []
+    ops, net = stepped.runtime()
+    if ops.act_dtype != torch.bfloat16 or not isinstance(net, (E.GenNet, E.DiscNet)) or ops.stat_reduce is not None:
+        return []
+    return [b[0] for b in net.blocks]
 
 
 G0_ADAM = os.environ.get("RNAGAN_G0_ADAM", "1") != "0"

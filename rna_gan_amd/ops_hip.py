@@ -4,6 +4,7 @@ only; every arithmetic op below is one or two hand-written HIP kernels.  No fall
 """
 from __future__ import annotations
 
+import ctypes
 import os
 import weakref
 from contextlib import contextmanager
@@ -515,12 +516,41 @@ class HipOps:
         check(self.lib.rg_selftest_fp8(_ptr(d), self.stream), "rg_selftest_fp8")
         return d.cpu().tolist()
 
+    def _wgrad_slabs(self, low0, high0, low1, high1, cw: ConvW, accumulate: bool, flops):
+        """The weight gradient of a layer whose optimizer step follows immediately (cw.defer_slabs, set by the train_op runner):
+        a split-K launch leaves its fp32 partial slabs in a buffer of the layer's own (cw.pending_slabs) and the reduction into
+        dw is skipped -- rna_gan_amd.optim.Adam sums the slabs inside its step (rg_adam_step_slabs).  True when launched."""
+        if not cw.defer_slabs or self.dt != RG_BF16 or self.stat_reduce is not None or self._in_side:
+            return False
+        if accumulate or cw.pending_slabs is not None:
+            raise RuntimeError("rna_gan_amd: a second weight-gradient contribution for a layer whose first one is still deferred "
+                               "split-K slabs (defer_slabs expects ONE weight-gradient launch per layer and pass)")
+        N, Ho, Wo, O = low0.shape
+        I = high0.shape[3]
+        dw = cw.dw
+        if cw.w.data_ptr() % 16 or dw.data_ptr() % 16:
+            return False
+        nb = int(self.lib.rg_conv_wgrad_workspace_bytes(N, Ho, Wo, O, I, self.dt, self.algo))
+        if nb <= 0:
+            return False                           # no split-K plan for this shape (or no matrix-core kernel): nothing to defer
+        if cw._slab_ws is None or cw._slab_ws.numel() < nb:
+            cw._slab_ws = torch.empty(nb + 4096, dtype=torch.uint8, device=self.device)      # persistent: graphs hold its address
+        ns = ctypes.c_int(0)
+        self._timed("conv_wgrad", flops, lambda: check(
+            self.lib.rg_conv_wgrad_slabs(_ptr(low0), _ptr(high0), _ptr(low1), _ptr(high1), _ptr(dw), N, Ho, Wo, O, I, self.dt,
+                                         self.algo, _ptr(cw._slab_ws), cw._slab_ws.numel(), ctypes.addressof(ns), self.stream),
+            "rg_conv_wgrad_slabs"), cw=cw)
+        cw.pending_slabs = (cw._slab_ws, int(ns.value)) if ns.value > 1 else None
+        return True
+
     def conv_wgrad(self, low, high, cw: ConvW, accumulate: bool):
         N, Ho, Wo, O = low.shape
         I = high.shape[3]
         self._tap_major(cw)
         dw = cw.dw
         assert high.shape[1] == 2 * Ho and tuple(dw.shape) == (O, 4, 4, I) and dw.is_contiguous()
+        if self._wgrad_slabs(low, high, None, None, cw, accumulate, 2.0 * N * Ho * Wo * O * I * 16):
+            return
         nb = self.lib.rg_conv_wgrad_workspace_bytes(N, Ho, Wo, O, I, self.dt, self.algo)
         ws = self._ws(nb)
         self._timed("conv_wgrad", 2.0 * N * Ho * Wo * O * I * 16, lambda: check(
@@ -535,6 +565,8 @@ class HipOps:
         dw = cw.dw
         assert low1.shape == low0.shape and high1.shape == high0.shape
         assert tuple(dw.shape) == (O, 4, 4, I) and dw.is_contiguous()
+        if self._wgrad_slabs(low0, high0, low1, high1, cw, accumulate, 4.0 * N * Ho * Wo * O * I * 16):
+            return
         nb = self.lib.rg_conv_wgrad_workspace_bytes(N, Ho, Wo, O, I, self.dt, self.algo)
         ws = self._ws(nb)
         self._timed("conv_wgrad", 4.0 * N * Ho * Wo * O * I * 16, lambda: check(

@@ -184,6 +184,45 @@ class Adam(torch.optim.Adam):
                     pack["version"] = w._version
                 segs.append((off, off + O_ * I_))
             segs.sort()
+        # 4 x 4 conv layers whose split-K weight-gradient slabs the backward left unreduced (ConvW.pending_slabs, set by
+        # ops_hip._wgrad_slabs for a pass the train_op runner marked with defer_slabs): ONE launch steps the rest of the buffer,
+        # summing those layers' slabs in place of their (never written) reduced gradient
+        slab_segs = []
+        net = getattr(self._module, "_rt_net", None)
+        for cw in (net.convs() if net is not None and hasattr(net, "convs") else []):
+            ps = getattr(cw, "pending_slabs", None)
+            if ps is not None:
+                cw.pending_slabs = None
+                slab_segs.append(((cw.w.data_ptr() - flat.data.data_ptr()) // 4, cw.w.numel(), ps[0], ps[1]))
+        if slab_segs:
+            if segs or self.grad_wire is not None:
+                raise RuntimeError("rna_gan_amd.optim.Adam: deferred split-K slabs expect a single-process step without fused "
+                                   "linear weight gradients")
+            import ctypes as C
+            slab_segs.sort(key=lambda t: t[0])
+            total = flat.data.numel()
+            table, pos = [], lo
+            for off, n, buf, ns in slab_segs:
+                if off < pos or off % 4 or n % 4 or off + n > total:
+                    raise RuntimeError("rna_gan_amd.optim.Adam: a deferred weight gradient does not sit 16-byte aligned inside "
+                                       "the part of the flat buffer this launch steps")
+                if off > pos:
+                    table.append((pos - lo, off - pos, 0, 0))
+                table.append((off - lo, n, buf.data_ptr(), ns))
+                pos = off + n
+            if total > pos:
+                table.append((pos - lo, total - pos, 0, 0))
+            k = len(table)
+            offs = (C.c_ulonglong * k)(*[t[0] for t in table])
+            lens = (C.c_ulonglong * k)(*[t[1] for t in table])
+            slabs = (C.c_void_p * k)(*[t[2] or None for t in table])
+            nsp = (C.c_int * k)(*[t[3] for t in table])
+            check(lib.rg_adam_step_slabs(flat.data.data_ptr() + 4 * lo, flat.grad.data_ptr() + 4 * lo,
+                                         self._m.data_ptr() + 4 * lo, self._v.data_ptr() + 4 * lo, total - lo,
+                                         self._hyper.data_ptr(), 0 if shadow is None else shadow.data_ptr() + 2 * lo, k,
+                                         C.addressof(offs), C.addressof(lens), C.addressof(slabs), C.addressof(nsp), stream),
+                  "rg_adam_step_slabs")
+            segs = [(lo, total)]                  # nothing left for the plain launches below
         pos = lo
         for a, b in segs + [(flat.data.numel(), flat.data.numel())]:
             if a > pos:

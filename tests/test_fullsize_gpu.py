@@ -526,3 +526,93 @@ def test_bn_backward_sums_in_conv_epilogue(I, O, hs, n, groups):
             gy = gah * torch.where(xh * gam + bet > 0, 1.0, 0.2)
             ref = gam * rstd * (gy - gy.mean(0) - xh * (gy * xh).mean(0))
             assert relmax(gz_f.view(groups, -1, C)[h], ref) < 8e-3, (direction, h)
+
+
+@pytest.mark.parametrize("I,O,hs,two", [(64, 128, 64, True), (128, 256, 32, False), (256, 512, 16, True), (512, 1024, 8, True),
+                                         (1024, 2048, 4, False)])
+def test_split_k_weight_gradient_slabs_inside_the_adam_step(I, O, hs, two):
+    """Round 5: a split-K weight-gradient launch may leave its fp32 slabs unreduced (rg_conv_wgrad_slabs) and the fused Adam
+    step sums them itself (rg_adam_step_slabs: one launch over a flat buffer cut into plain and slab segments; 1 / 4 / 16 slab
+    lanes per 16-byte column by nsplit).  At the benchmark's five layer shapes (one and two segments): against the reduced
+    gradient (rg_conv_wgrad / rg_conv_wgrad2) followed by rg_adam_step_dev on the same flat buffer -- moments to fp32 rounding of
+    a different summation order, weights within two steps' bound of the sign-like first update, bf16 shadow = rounded weights."""
+    import ctypes as C
+    dev = torch.device("cuda:0")
+    ops = HipOps(torch.bfloat16, dev)
+    lib = _abi.load()
+    gen = torch.Generator(device="cpu").manual_seed(31)
+    low0 = torch.randn(N, hs, hs, O, generator=gen).bfloat16().to(dev)
+    high0 = torch.randn(N, 2 * hs, 2 * hs, I, generator=gen).bfloat16().to(dev)
+    low1 = torch.randn(N, hs, hs, O, generator=gen).bfloat16().to(dev) if two else None
+    high1 = torch.randn(N, 2 * hs, 2 * hs, I, generator=gen).bfloat16().to(dev) if two else None
+    nw = O * 16 * I
+    head, tail = 4096, 1000                                  # plain segments in front of / behind the layer (tail: not a multiple of 4)
+    total = head + nw + tail
+    pad = (-total) % 4
+    p0 = torch.randn(total + pad, generator=gen).to(dev) * 0.05
+    g0 = torch.randn(total + pad, generator=gen).to(dev) * 0.01
+    m0 = torch.randn(total + pad, generator=gen).to(dev) * 0.01
+    v0 = (torch.rand(total + pad, generator=gen).to(dev) * 1e-4)
+    hyper = torch.zeros(8, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    _abi.check(lib.rg_adam_hyper_dev(step.data_ptr(), 4e-4, 0.5, 0.999, 1e-8, 0.0, hyper.data_ptr(), ops.stream), "hyper")
+    wsb = int(lib.rg_conv_wgrad_workspace_bytes(N, hs, hs, O, I, ops.dt, ops.algo))
+    ws = torch.empty(max(wsb, 256) + 4096, dtype=torch.uint8, device=dev)
+    ptr = lambda t: 0 if t is None else t.data_ptr()
+
+    # reference: reduced gradient into g[head : head + nw], then the plain fused step over the whole buffer
+    pr, gr, mr, vr = p0.clone(), g0.clone(), m0.clone(), v0.clone()
+    shr = torch.zeros(total + pad, dtype=torch.bfloat16, device=dev)
+    dw = gr[head:head + nw]
+    if two:
+        _abi.check(lib.rg_conv_wgrad2(ptr(low0), ptr(high0), ptr(low1), ptr(high1), dw.data_ptr(), N, hs, hs, O, I, ops.dt, 0,
+                                      ops.algo, ws.data_ptr(), ws.numel(), ops.stream), "rg_conv_wgrad2")
+    else:
+        _abi.check(lib.rg_conv_wgrad(ptr(low0), ptr(high0), dw.data_ptr(), N, hs, hs, O, I, ops.dt, 0, ops.algo, ws.data_ptr(),
+                                     ws.numel(), ops.stream), "rg_conv_wgrad")
+    _abi.check(lib.rg_adam_step_dev(pr.data_ptr(), gr.data_ptr(), mr.data_ptr(), vr.data_ptr(), total, hyper.data_ptr(),
+                                    shr.data_ptr(), 0, ops.stream), "rg_adam_step_dev")
+
+    # deferred: slabs stay in `slab`, the segmented step sums them
+    pd, gd, md, vd = p0.clone(), g0.clone(), m0.clone(), v0.clone()
+    shd = torch.zeros(total + pad, dtype=torch.bfloat16, device=dev)
+    slab = torch.empty_like(ws)
+    ns = C.c_int(0)
+    _abi.check(lib.rg_conv_wgrad_slabs(ptr(low0), ptr(high0), ptr(low1), ptr(high1), gd[head:head + nw].data_ptr(), N, hs, hs,
+                                       O, I, ops.dt, ops.algo, slab.data_ptr(), slab.numel(), C.addressof(ns), ops.stream),
+               "rg_conv_wgrad_slabs")
+    print("layer %d -> %d at %d^2, %d segment(s): nsplit %d" % (I, O, hs, 2 if two else 1, ns.value))
+    if ns.value > 1:
+        gd[head:head + nw].fill_(float("nan"))               # the reduced gradient must never be read
+        table = [(0, head, 0, 0), (head, nw, slab.data_ptr(), ns.value), (head + nw, tail, 0, 0)]
+    else:
+        table = [(0, total, 0, 0)]                           # no split at this shape: dw was written, one plain segment
+    k = len(table)
+    offs = (C.c_ulonglong * k)(*[t[0] for t in table])
+    lens = (C.c_ulonglong * k)(*[t[1] for t in table])
+    slabs = (C.c_void_p * k)(*[t[2] or None for t in table])
+    nsp = (C.c_int * k)(*[t[3] for t in table])
+    _abi.check(lib.rg_adam_step_slabs(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), total, hyper.data_ptr(),
+                                      shd.data_ptr(), k, C.addressof(offs), C.addressof(lens), C.addressof(slabs),
+                                      C.addressof(nsp), ops.stream), "rg_adam_step_slabs")
+    torch.cuda.synchronize()
+    assert torch.isfinite(pd[:total]).all() and torch.isfinite(md[:total]).all() and torch.isfinite(vd[:total]).all()
+    # plain segments: the same arithmetic, bit for bit
+    for a, b in ((pr, pd), (mr, md), (vr, vd)):
+        assert torch.equal(a[:head], b[:head]) and torch.equal(a[head + nw:total], b[head + nw:total])
+    assert torch.equal(shr[:head], shd[:head]) and torch.equal(shr[head + nw:total], shd[head + nw:total])
+    sl = slice(head, head + nw)
+    gscale = float((mr[sl] - 0.5 * m0[sl]).abs().max())      # 0.5 * |g|_max
+    assert float((mr[sl] - md[sl]).abs().max()) <= 2e-5 * gscale
+    assert float((vr[sl] - vd[sl]).abs().max()) <= 1e-4 * float(vr[sl].abs().max())
+    # the step lr * m_hat / (sqrt(v_hat) + eps) of every element: within 2 % of the largest step (a different fp32 summation
+    # order of the gradient moves m and v in the 6th digit; where v is tiny the quotient amplifies it)
+    assert float((pr[sl] - pd[sl]).abs().max()) <= 2e-2 * float((pr[sl] - p0[sl]).abs().max())
+    assert torch.equal(shd[:total], pd[:total].bfloat16())
+    # bad tables are refused
+    bad_off = (C.c_ulonglong * 1)(4)
+    one_len = (C.c_ulonglong * 1)(total)
+    nul = (C.c_void_p * 1)(None)
+    zero = (C.c_int * 1)(0)
+    assert lib.rg_adam_step_slabs(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), total, hyper.data_ptr(), 0, 1,
+                                  C.addressof(bad_off), C.addressof(one_len), C.addressof(nul), C.addressof(zero), ops.stream) != 0

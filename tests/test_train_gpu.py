@@ -514,6 +514,36 @@ def test_generator_inference_fp8():
                 d_mean, d_max = max(d_mean, float(d.mean())), max(d_max, float(d.max()))
     print("fp8 vs bf16 at the reference size: mean |diff| %.4f, max %.4f" % (d_mean, d_max))
     assert d_mean <= 3e-2
+    # configs[4] at FULL size against the ORACLE: 32 samples through the oracle generator in eval
+    # mode on the CPU (fp32, the reference's arithmetic, src/gan_utils.py:217-221,236-242 with running statistics) -- not
+    # against this product's own bf16 path.  Non-trivial running statistics, so the folded affine is exercised.
+    G0f = R.seeded_fill_(R.OracleDCGANGenerator(2048, 256, 3, 64, nonlinearity=nn.LeakyReLU(0.2),
+                                                last_nonlinearity=nn.Tanh()), 3)
+    gen = torch.Generator().manual_seed(17)
+    with torch.no_grad():
+        for m in G0f.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.copy_(0.05 * torch.randn(m.num_features, generator=gen))
+                m.running_var.copy_(0.5 + torch.rand(m.num_features, generator=gen))
+    G0f = G0f.eval()
+    Gq = P.DCGANGenerator(2048, 256, 3, 64, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+    Gq.load_state_dict(G0f.state_dict())
+    Gq = Gq.set_precision("bf16").cuda().eval()
+    z256 = R.synthetic_normal(256, 2048, seed=9)              # the fp8 kernels take whole 256-row tiles: a chunk of 256 samples,
+    z32 = z256[:32]                                            # of which the first 32 go through the oracle (eval mode: per sample)
+    with torch.no_grad():
+        want = G0f(z32)
+        ops, net = Gq.runtime()
+        img8, nfp8 = E.gen_forward_eval_fp8(ops, net, z256.cuda())
+        img16 = E.gen_forward_eval(ops, net, z256.cuda())
+    assert nfp8 == 5
+    e8, e16 = (img8[:32].cpu() - want).abs(), (img16[:32].cpu() - want).abs()
+    print("reference size, 32 samples vs the ORACLE (fp32 CPU, eval mode): fp8 mean |diff| %.4f max %.4f ; bf16 mean %.4f max %.4f"
+          % (e8.mean(), e8.max(), e16.mean(), e16.max()))
+    # stated tolerance for images in [-1, 1]: fp8 e4m3 operands (3 mantissa bits, per-output-channel weight scales) through
+    # 5 of the 7 layers: mean |diff| <= 3e-2, max <= 0.5; the bf16 path on the same inputs: mean <= 6e-3
+    assert float(e8.mean()) <= 3e-2 and float(e8.max()) <= 0.5, (float(e8.mean()), float(e8.max()))
+    assert float(e16.mean()) <= 6e-3, float(e16.mean())
 
 
 def test_generator_forward_without_kept_context_fuses_last_batchnorm():
@@ -661,3 +691,79 @@ def test_unselected_inputs_loss_agreement_statistics():
     assert float(f32.max()) <= 2e-3, f32.max()
     assert float(np.median(b16)) <= 2e-2, np.median(b16)
     assert float((b16 <= 6e-2).mean()) >= 0.75, (b16 <= 6e-2).mean()
+
+
+def _loss_and_update_statistics(in_size, seeds, n=8, step=64, enc=128):
+    """One iteration (G-loss, D-loss, penalty train_ops) per seed -- weights, tiles and draws all change with the seed, nothing
+    is selected -- on the HIP path in both precisions and on the CPU oracle.  Returns per precision: errs [seed][3] =
+    |hip - oracle| / (|oracle| + 0.1) of the three losses, cos [seed][2] = cosine between the product's and the oracle's
+    parameter UPDATES (all parameters of G / of D concatenated: the gate smoke() and tests/test_bench_step_gpu.py use)."""
+    errs = {"fp32": [], "bf16": []}
+    coss = {"fp32": [], "bf16": []}
+    for seed in seeds:
+        G0 = R.seeded_fill_(R.OracleDCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                                   last_nonlinearity=nn.Tanh()), seed)
+        D0 = R.seeded_fill_(R.OracleDCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
+                                                       last_nonlinearity=nn.LeakyReLU(0.2)), seed + 1000)
+        Go, Do = copy.deepcopy(G0).train(), copy.deepcopy(D0).train()
+        ogo, odo = R.make_adam(Go.parameters(), 1e-4), R.make_adam(Do.parameters(), 4e-4)
+        real = R.synthetic_images(n, in_size, seed=seed)
+        noises = [R.synthetic_normal(n, enc, seed=100 * seed + 2 + j) for j in range(3)]
+        ref = R.train_iteration(Go, Do, ogo, odo, real, noises, 0.4)
+        upd_ref = [torch.cat([(a.detach() - b.detach()).reshape(-1).double() for a, b in zip(m1.parameters(), m0.parameters())])
+                   for m1, m0 in ((Go, G0), (Do, D0))]
+        for precision in ("fp32", "bf16"):
+            G = P.DCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
+            D = P.DCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.LeakyReLU(0.2))
+            G.load_state_dict(G0.state_dict()); D.load_state_dict(D0.state_dict())
+            G.set_precision(precision); D.set_precision(precision)
+            G, D = G.cuda().train(), D.cuda().train()
+            og = P.Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.999)).bind(G)
+            od = P.Adam(D.parameters(), lr=4e-4, betas=(0.5, 0.999)).bind(D)
+            rd = real.cuda()
+            got = {"g": PL._g_step(G, D, og, noises[0].cuda()).item(),
+                   "d": PL._d_step(G, D, od, rd, noises[1].cuda(), None).item(),
+                   "gp": PL._gp_step(G, D, od, rd, noises[2].cuda(), 0.4, 10.0).item()}
+            errs[precision].append([abs(got[k] - ref[k]) / (abs(ref[k]) + 0.1) for k in ("g", "d", "gp")])
+            cs = []
+            for mod, m0, ur in ((G, G0, upd_ref[0]), (D, D0, upd_ref[1])):
+                sd0 = dict(m0.named_parameters())
+                u = torch.cat([(p.detach().cpu().double() - sd0[k].detach().double()).reshape(-1)
+                               for k, p in mod.named_parameters()])
+                cs.append(float((u * ur).sum() / (u.norm() * ur.norm() + 1e-300)))
+            coss[precision].append(cs)
+    return {k: np.asarray(v) for k, v in errs.items()}, {k: np.asarray(v) for k, v in coss.items()}
+
+
+def _describe(tag, e, c, seeds):
+    flat = np.sort(e.reshape(-1))
+    q = lambda f: flat[min(int(f * len(flat)), len(flat) - 1)]
+    line = ("%s: %d seeds x 3 losses: median %.2e, 90th %.2e, 99th %.2e, max %.2e; per loss max (g, d, gp) %s; beyond 6e-2: %d of %d "
+            "(seeds %s); update cosine G: min %.3f 1st-pct %.3f median %.3f, D: min %.3f 1st-pct %.3f median %.3f"
+            % (tag, len(seeds), np.median(flat), q(0.9), q(0.99), flat[-1], np.round(e.max(0), 4).tolist(),
+               int((flat > 6e-2).sum()), flat.size, [seeds[i] for i in np.where((e > 6e-2).any(1))[0]],
+               c[:, 0].min(), np.sort(c[:, 0])[max(int(0.01 * len(c)), 0)], np.median(c[:, 0]),
+               c[:, 1].min(), np.sort(c[:, 1])[max(int(0.01 * len(c)), 0)], np.median(c[:, 1])))
+    print(line)
+    return line
+
+
+def test_unselected_inputs_statistics_at_64():
+    """the bf16 tolerances as DISTRIBUTIONS on unselected inputs at a second size -- 64 x 64, 40
+    consecutive seeds in the suite (tools/tolerance_stats.py runs 200 and writes profiles/round5_tolerance_statistics.txt) --
+    for the loss values AND for the update-cosine gate.  What is asserted is what the 200-seed run supports with headroom
+    (DESIGN 14.6): fp32 kernels every loss <= 2e-3 and every update cosine >= 0.99; bf16 kernels loss error median <= 1.5e-2,
+    95 % of the values <= 6e-2 (the stated tolerance is a 95th-percentile bound on ARBITRARY inputs, an every-seed bound only on
+    inputs with a LeakyReLU margin at the critic head, which is how smoke() / the engine tests choose theirs), and the update
+    cosine >= 0.80 on every seed with a median >= 0.90."""
+    seeds = list(range(301, 341))
+    errs, coss = _loss_and_update_statistics(64, seeds)
+    for precision in ("fp32", "bf16"):
+        _describe(precision + " 64x64", errs[precision], coss[precision], seeds)
+    f32, b16 = errs["fp32"], errs["bf16"]
+    assert np.isfinite(f32).all() and np.isfinite(b16).all()
+    assert float(f32.max()) <= 2e-3, f32.max()
+    assert float(coss["fp32"].min()) >= 0.99, coss["fp32"].min()
+    assert float(np.median(b16)) <= 1.5e-2, np.median(b16)
+    assert float((b16 <= 6e-2).mean()) >= 0.95, (b16 <= 6e-2).mean()
+    assert float(coss["bf16"].min()) >= 0.80 and float(np.median(coss["bf16"])) >= 0.90, (coss["bf16"].min(), np.median(coss["bf16"]))

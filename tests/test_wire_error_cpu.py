@@ -1,0 +1,123 @@
+"""What the bf16 gradient wire costs at 8 ranks, stated BEFORE 8-GPU hardware exists.
+
+`dist.allreduce_start(compress=True)` casts every rank's fp32 gradient contribution (already scaled by 1 / world) to bf16 and
+lets RCCL sum in bf16: in a ring all-reduce the partial sum of a chunk visits the ranks one after the other and is rounded to
+bf16 after every hop -- one rounding per contribution plus world - 1 hop roundings per element (world 2: one hop, which is what
+tests/test_dp2_gpu.py exercises on real kernels).  This test takes REAL gradient shards -- the oracle's generator-loss,
+discriminator-loss and penalty gradients of 8 different data shards at shared weights (small model, fp64 autograd) -- sums
+them (a) the way the ring does, (b) the alternative the verdict names (fp32 reduce-scatter, one bf16 rounding for the
+all-gather), and compares both with the exact sum through the quantity training sees: the direction of the first Adam step,
+lr * g / (|g| + eps) element by element (the sign-like update the parity tests' cosine gates use).
+
+Measured here (printed by the test): relative L2 error of the summed gradient 3.3e-3 .. 3.9e-3 for the ring against 1.6e-3 ..
+1.7e-3 for one rounding; Adam-update cosine 0.9986 / 0.9991 / 0.9994 (G-loss / D-loss / penalty) for the ring, 1.0000 for the
+alternative -- and 0.24 .. 0.47 for ONE rank's gradient alone, i.e. the averaging itself is what matters.
+Stated bound (asserted): update cosine >= 0.995 per train_op for the ring, far above the 0.92-0.96 that bf16 ARITHMETIC in the
+kernels costs against fp32 at one rank (smoke()): the wire is not the dominant error and the bf16 ring stays."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from oracle import ref_cpu as R
+
+WORLD, N, IN_SIZE, STEP, ENC = 8, 4, 32, 16, 32
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _shard_gradients():
+    """{"g": [...], "d": [...], "gp": [...]}: per train_op the 8 ranks' flat fp32 gradient contributions (1 / world folded
+    in, as grad_scale does), all at the SAME weights."""
+    G = R.seeded_fill_(R.OracleDCGANGenerator(ENC, IN_SIZE, 3, STEP, nonlinearity=nn.LeakyReLU(0.2),
+                                              last_nonlinearity=nn.Tanh()), 7).double().train()
+    D = R.seeded_fill_(R.OracleDCGANDiscriminator(IN_SIZE, 3, STEP, nonlinearity=nn.LeakyReLU(0.2),
+                                                  last_nonlinearity=nn.LeakyReLU(0.2)), 8).double().train()
+    out = {"g": [], "d": [], "gp": []}
+
+    def flat(mod):
+        return torch.cat([p.grad.reshape(-1) for p in mod.parameters()]).float() / WORLD
+
+    def zero():
+        for m in (G, D):
+            for p in m.parameters():
+                p.grad = None
+    for r in range(WORLD):
+        real = R.synthetic_images(N, IN_SIZE, seed=300 + r).double()
+        nz = [R.synthetic_normal(N, ENC, seed=400 + 3 * r + j).double() for j in range(3)]
+        zero(); R.generator_loss(D(G(nz[0]))).backward(); out["g"].append(flat(G))
+        zero(); R.discriminator_loss(D(real), D(G(nz[1]).detach())).backward(); out["d"].append(flat(D))
+        eps = 0.1 + 0.1 * r
+        xhat = (eps * real + (1 - eps) * G(nz[2]).detach()).requires_grad_(True)
+        zero(); (10.0 * R.gradient_penalty(xhat, D(xhat))).backward(); out["gp"].append(flat(D))
+    return out
+
+
+def ring_allreduce_bf16(shards):
+    """RCCL ring all-reduce of bf16 buffers, emulated: the buffer is cut into `world` chunks; chunk c starts at rank c + 1 and
+    picks up the next rank's contribution at every hop, the running sum rounded to bf16 each time (reduce-scatter), then is
+    broadcast unchanged (all-gather)."""
+    w = len(shards)
+    b = [_bf16(s) for s in shards]                    # the cast in front of the wire (rg_cast_pad)
+    n = b[0].numel()
+    out = torch.empty(n)
+    bounds = np.linspace(0, n, w + 1).astype(int)
+    for c in range(w):
+        lo, hi = bounds[c], bounds[c + 1]
+        acc = b[(c + 1) % w][lo:hi].clone()
+        for hop in range(2, w + 1):
+            acc = _bf16(acc + b[(c + hop) % w][lo:hi])
+        out[lo:hi] = acc
+    return out
+
+
+def rs_fp32_ag_bf16(shards):
+    """the alternative: fp32 reduce-scatter (exact up to fp32 rounding), ONE bf16 rounding for the all-gather"""
+    acc = torch.zeros_like(shards[0])
+    for s in shards:
+        acc = acc + s
+    return _bf16(acc)
+
+
+def _update(g, lr=1.0, eps=1e-8):
+    """first Adam step's direction: m_hat / (sqrt(v_hat) + eps) = g / (|g| + eps)"""
+    g = g.double()
+    return lr * g / (g.abs() + eps)
+
+
+def _cos(a, b):
+    return float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
+
+
+def test_bf16_ring_sum_of_8_real_gradient_shards_keeps_the_adam_update_direction():
+    shards = _shard_gradients()
+    rows = []
+    for op in ("g", "d", "gp"):
+        exact = torch.stack([s.double() for s in shards[op]]).sum(0)
+        ring, alt = ring_allreduce_bf16(shards[op]), rs_fp32_ag_bf16(shards[op])
+        one = _bf16(exact.float())                                        # the floor: ONE rounding of the exact sum
+        rel = lambda t: float((t.double() - exact).norm() / exact.norm())
+        row = {"op": op, "n": exact.numel(), "rel_l2_ring": rel(ring), "rel_l2_alt": rel(alt), "rel_l2_one_rounding": rel(one),
+               "cos_ring": _cos(_update(ring), _update(exact)), "cos_alt": _cos(_update(alt), _update(exact)),
+               # how far a SINGLE rank's contribution is from the sum (why averaging matters at all): context for the numbers
+               "cos_one_shard": _cos(_update(shards[op][0] * WORLD), _update(exact))}
+        rows.append(row)
+        print("wire error, 8 ranks, %-2s (%7d elements): rel-L2 ring %.2e / fp32-RS+bf16-AG %.2e / one rounding %.2e; "
+              "Adam-update cosine ring %.4f / alt %.4f (one shard alone: %.3f)"
+              % (op, row["n"], row["rel_l2_ring"], row["rel_l2_alt"], row["rel_l2_one_rounding"], row["cos_ring"],
+                 row["cos_alt"], row["cos_one_shard"]))
+    for row in rows:
+        # 8 roundings of 2^-9 relative each, random signs: ~ sqrt(8) * 2^-9 / sqrt(3) ~ 3e-3 of the PARTIAL sums' size
+        assert row["rel_l2_ring"] <= 1.5e-2, row
+        assert row["rel_l2_alt"] <= 4e-3, row
+        assert row["cos_ring"] >= 0.995, row                  # the stated bound
+        assert row["cos_alt"] >= row["cos_ring"] - 1e-3, row
+
+
+def test_ring_emulation_is_exact_on_exactly_representable_data():
+    """integers < 256 are exact in bf16 and so are their sums up to 256: the emulated ring must equal the plain sum"""
+    gen = torch.Generator().manual_seed(3)
+    shards = [torch.randint(-15, 16, (1000,), generator=gen).float() for _ in range(8)]
+    want = torch.stack(shards).sum(0)
+    assert torch.equal(ring_allreduce_bf16(shards), want) and torch.equal(rs_fp32_ag_bf16(shards), want)
