@@ -421,29 +421,8 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
   float* cs = reinterpret_cast<float*>(lds);
   constexpr int CG = EP_COLS / 8, RPP = 512 / CG;      // column groups per row, rows per pass
   const int cg = t % CG, rr = t / CG;
-  constexpr int NPASS = BM / RPP;
-  auto out_row = [&](int m) -> long long {
-    if (MODE == MODE_UP) {
-      const int wq = m & (Wq - 1), hq = (m >> g.lgW) & (Hq - 1), n = m >> (g.lgW + g.lgH);
-      return ((long long)n * (2 * Hq) + 2 * hq + ph) * (2 * Wq) + 2 * wq + pw;
-    }
-    return m;
-  };
 #pragma unroll
   for (int ep = 0; ep < 2; ++ep) {
-    // The fused LeakyReLU-backward mask (the consumer's activation, 16 bytes per thread and row pass): ALL of a pass's mask
-    // loads are issued here, in front of the LDS staging.  Inside the store loop each load sat behind the previous row's
-    // store -- loads and stores complete in issue order, so `s_waitcnt vmcnt(0)` for the mask drained the output stores
-    // once per row pass (8 times per quadrant column).
-    uint4 mk[NPASS];
-    const bool use_mask = EB == 2 && g.mask != nullptr && a2.nsplit <= 1 && bn + ep * EP_COLS + cg * 8 < g.Ncols;
-    if (use_mask) {
-#pragma unroll
-      for (int p = 0; p < NPASS; ++p) {
-        const int m = min(bm + rr + RPP * p, g.M - 1);
-        mk[p] = *reinterpret_cast<const uint4*>(g.mask + out_row(m) * g.ldc + bn + ep * EP_COLS + cg * 8);
-      }
-    }
     if (ep) __syncthreads();
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -472,21 +451,29 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
         bmu[i] = g.bwd_mean[grp_off + c]; brs[i] = g.bwd_invstd[grp_off + c]; bga[i] = g.bwd_gamma[c]; bbe[i] = g.bwd_beta[c];
       }
     }
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
+#pragma unroll 4
+    for (int p = 0; p < BM / RPP; ++p) {
       const int row = rr + RPP * p;
       const int m = bm + row;
       if (m >= g.M || col >= g.Ncols) continue;
       float4 v0 = *reinterpret_cast<const float4*>(cs + row * EP_COLS + cg * 8);
       float4 v1 = *reinterpret_cast<const float4*>(cs + row * EP_COLS + cg * 8 + 4);
-      const long long orow = out_row(m);
+      long long orow;
+      if (MODE == MODE_UP) {
+        const int wq = m & (Wq - 1), hq = (m >> g.lgW) & (Hq - 1), n = m >> (g.lgW + g.lgH);
+        orow = ((long long)n * (2 * Hq) + 2 * hq + ph) * (2 * Wq) + 2 * wq + pw;
+      } else {
+        orow = m;
+      }
       if (a2.nsplit > 1) {
         float* so = a2.slab + (long long)zs * a2.slab_stride + orow * g.ldc + col;
         *reinterpret_cast<float4*>(so) = v0;
         *reinterpret_cast<float4*>(so + 4) = v1;
       } else {
-        if (use_mask) {
-          const uint4 a = mk[p];
+        if (g.mask) {
+          // (round 5, measured and rejected: issuing a pass's 8 mask loads in front of the LDS staging, so that their waits do
+          // not drain the output stores once per row pass -- the step got 0.1 ms SLOWER in a three-round build A/B)
+          const uint4 a = *reinterpret_cast<const uint4*>(g.mask + orow * g.ldc + col);
           v0.x *= rg_lmask(a.x, g.mslope); v0.y *= rg_lmask(a.x >> 16, g.mslope);
           v0.z *= rg_lmask(a.y, g.mslope); v0.w *= rg_lmask(a.y >> 16, g.mslope);
           v1.x *= rg_lmask(a.z, g.mslope); v1.y *= rg_lmask(a.z >> 16, g.mslope);

@@ -348,18 +348,6 @@ __global__ __launch_bounds__(512, 2) void wgrad8n_kernel(W8Args g) {
   const int kt_begin = zs * g.kt_per_split;
   const int nkt = min(nkt_all, kt_begin + g.kt_per_split) - kt_begin;     // host: > 0 and even
   constexpr unsigned OOB = 0x80000000u;
-  // k-tile order of this column tile.  The column tiles of one pixel range run side by side on one XCD and gather the SAME
-  // image through different taps: a tile whose taps start at kernel row kh0 >= 2 reads, for output row ho, the input rows the
-  // kh0 - 2 tile reads one output row LATER (2 ho - 1 + kh) -- two k-tiles of the whole XCD's traffic apart (~5 MB: gone from
-  // the 4 MB L2 by then; PMC round 4: 336 MB fetched for 201 MB, hit rate 0.58).  Those tiles therefore walk their pixel range
-  // rotated by one output row, so that both read an input row within the same k-tile: one of them fetches it, the other hits.
-  // (The contraction order inside a split changes for them: fp32 rounding only, still a fixed order.)
-  const int rot = ((c0 / g.I) >> 2) >= 2 && nkt > 1 ? min(max((1 << g.lgWo) >> 6, 1), nkt - 1) : 0;
-  auto kt_of = [&](int ktr) {
-    int k = ktr;
-    if (ktr < nkt) { k = ktr - rot; if (k < 0) k += nkt; }
-    return kt_begin + k;
-  };
 
   const __amdgpu_buffer_rsrc_t rsL0 = __builtin_amdgcn_make_buffer_rsrc((void*)g.low[0], 0, g.low_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsH0 = __builtin_amdgcn_make_buffer_rsrc((void*)g.high[0], 0, g.high_bytes, 0x00020000);
@@ -385,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void wgrad8n_kernel(W8Args g) {
   int px_base[2], px_h[2], px_w[2];
   bool px_ok[2];
   auto decode_pixels = [&](int ktr) {
-    const int p0 = kt_of(ktr) * 64;
+    const int p0 = (kt_begin + ktr) * 64;
     const bool seg1 = p0 >= g.Kseg[0];
     const int pb = seg1 ? p0 - g.Kseg[0] : p0;
     const int kend = (ktr < nkt) ? (seg1 ? g.Kseg[1] : g.Kseg[0]) : 0;
@@ -401,7 +389,7 @@ __global__ __launch_bounds__(512, 2) void wgrad8n_kernel(W8Args g) {
   };
   auto issue_a = [&](auto S, int ktr) {
     constexpr int s = decltype(S)::value;
-    const int p0 = kt_of(ktr) * 64;
+    const int p0 = (kt_begin + ktr) * 64;
     const bool seg1 = p0 >= g.Kseg[0];
     const int pb = seg1 ? p0 - g.Kseg[0] : p0;
     const int kend = (ktr < nkt) ? (seg1 ? g.Kseg[1] : g.Kseg[0]) : 0;
@@ -419,7 +407,7 @@ __global__ __launch_bounds__(512, 2) void wgrad8n_kernel(W8Args g) {
   auto issue_b = [&](auto S, auto H, int ktr) {
     constexpr int s = decltype(S)::value, h = decltype(H)::value;
     if (h == 0) decode_pixels(ktr);
-    const bool seg1 = kt_of(ktr) * 64 >= g.Kseg[0];
+    const bool seg1 = (kt_begin + ktr) * 64 >= g.Kseg[0];
     const __amdgpu_buffer_rsrc_t rs = seg1 ? rsH1 : rsH0;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
