@@ -417,7 +417,7 @@ extern "C" int rg_pack_linear_weight(const float* w, void* wp, int Nout, int K, 
 }
 
 extern "C" size_t rg_linear_workspace_bytes(int M, int K, int Nout, int algo) {
-  if (algo == RG_ALGO_GENERIC) return 0;
+  if (algo == RG_ALGO_GENERIC) return rg_generic_linear_ws_bytes(M, K, Nout);     // split-K slabs of the fp32 kernel (0: no split)
   size_t kp = rg_align_up((size_t)K, 64);
   return rg_align_up((size_t)M * kp * 2, 256) + rg_mfma_linear_ws_bytes(M, (int)kp, Nout);
 }
@@ -440,7 +440,7 @@ extern "C" int rg_linear_affine_act(const float* x, int ldx, const float* w, con
   }
   RG_REQUIRE(algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "linear: MFMA path needs the packed weight");
   RG_REQUIRE(w, RG_EINVAL, "linear: generic kernel needs the fp32 weight");
-  return rg_generic_linear(x, ldx, w, scale, shift, y, ldy, M, K, Nout, slope, rg_stream(stream));
+  return rg_generic_linear(x, ldx, w, scale, shift, y, ldy, M, K, Nout, slope, rg_stream(stream), ws, ws_bytes);
 }
 
 /* ---- resize-convolution block of DCGANUpGenerator (src/dcgan.py:45-56,76-84) ---- */

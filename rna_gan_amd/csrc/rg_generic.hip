@@ -1293,8 +1293,49 @@ int rg_generic_g0_wgrad(const float* z, const void* gy, float* dw, int N, int E,
   })
 }
 
+// split-K plan of the fp32 linear layers: a batch-64 layer is ONE row tile (the frozen betaVAE encoder, 19198 -> 6000 -> 4000 ->
+// 2048 -> 2048: 94 / 63 / 32 / 32 workgroups of 64 x 64 on 256 CUs, 350 us per layer in round 4) -- K is cut so that about two
+// workgroups per CU run, every split at least 1024 deep; the partial tiles go to fp32 slabs, one pass sums them in slab order
+// and applies the affine + activation epilogue.
+int rg_generic_linear_nsplit(int M, int K, int Nout) {
+  if (M > 128 || K < 4096) return 1;
+  const long long tiles = (long long)((M + 63) / 64) * ((Nout + 63) / 64);
+  long long ns = (512 + tiles - 1) / tiles;
+  if (ns > K / 1024) ns = K / 1024;
+  if (ns > 16) ns = 16;
+  return ns < 2 ? 1 : (int)ns;
+}
+size_t rg_generic_linear_ws_bytes(int M, int K, int Nout) {
+  const int ns = rg_generic_linear_nsplit(M, K, Nout);
+  return ns > 1 ? (size_t)ns * M * Nout * sizeof(float) : 0;
+}
+namespace {
+__global__ __launch_bounds__(256) void reduce_linear_f32_kernel(const float* __restrict__ slab, float* __restrict__ y, int M,
+                                                                int Nout, int ldy, int nsplit, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, float slope) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n = (size_t)M * Nout;
+  if (i >= n) return;
+  const int m = (int)(i / Nout), j = (int)(i - (size_t)m * Nout);
+  float v = 0.f;
+  for (int z = 0; z < nsplit; ++z) v += slab[(size_t)z * n + i];
+  if (scale) v *= scale[j];
+  if (shift) v += shift[j];
+  y[(size_t)m * ldy + j] = lrelu_f(v, slope);
+}
+}  // namespace
 int rg_generic_linear(const float* x, int ldx, const float* w, const float* scale, const float* shift, float* y,
-                      int ldy, int M, int K, int Nout, float slope, hipStream_t st) {
+                      int ldy, int M, int K, int Nout, float slope, hipStream_t st, void* ws, size_t ws_bytes) {
+  const int ns = rg_generic_linear_nsplit(M, K, Nout);
+  if (ns > 1 && ws && ws_bytes >= (size_t)ns * M * Nout * sizeof(float)) {
+    int rc = launch_generic<true, true>("linear(generic, split-K)", LinA{x, ldx}, LinB{w, K},
+                                        SlabC{(float*)ws, (size_t)M * Nout, Nout}, M, Nout, K, 1, ns, st, true);
+    if (rc) return rc;
+    const size_t n = (size_t)M * Nout;
+    hipLaunchKernelGGL(reduce_linear_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, y, M,
+                       Nout, ldy, ns, scale, shift, slope);
+    RG_LAUNCH_CHECK("linear(generic, split-K reduce)");
+    return RG_OK;
+  }
   return launch_generic<true, true>("linear(generic)", LinA{x, ldx}, LinB{w, K}, LinC{y, ldy, scale, shift, slope}, M,
                                     Nout, K, 1, 1, st, true);
 }

@@ -26,7 +26,8 @@ int rg_generic_g0_fwd(const float* z, const float* w, void* y, int N, int E, int
 int rg_generic_g0_wgrad(const float* z, const void* gy, float* dw, int N, int E, int C, int dtype, int accumulate,
                         hipStream_t st);
 int rg_generic_linear(const float* x, int ldx, const float* w, const float* scale, const float* shift, float* y,
-                      int ldy, int M, int K, int Nout, float slope, hipStream_t st);
+                      int ldy, int M, int K, int Nout, float slope, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0);
+size_t rg_generic_linear_ws_bytes(int M, int K, int Nout);
 
 // BatchNorm-backward sums of the consuming block computed in a conv launch's epilogue (GArgs::bwd_z, rg_conv8.hip)
 struct RgBnBwdFuse {
