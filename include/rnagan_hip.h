@@ -55,7 +55,8 @@ const char* rg_last_error(void);
  * environment variable after "RNAGAN_", lower case ("conv8", "conv8_blocks", "conv_tile", "xcd", "class_fast",
  * "wgrad_blocks", "wgrad8", ..., "f32mma": 0 sends the RG_F32 conv / dense launches back to the vector-ALU GEMM instead of the
  * f32 matrix-core one; "convd": 0 sends the 64 -> 128 channel stride-2 conv back from the parity-plane-resident kernel to the
- * implicit-GEMM one, "convd_blocks": its persistent grid; "skinny128": 0 sends the image-side layers of 256 x 256 images back
+ * implicit-GEMM one, "convd_blocks": its persistent grid; "slab16": 0 keeps the split-K partial tiles of the conv launches fp32;
+ * "skinny128": 0 sends the image-side layers of 256 x 256 images back
  * from the control-flow-free row kernels to the general row-staged ones).  An option set here overrides the environment; value < 0 clears the override.  Returns RG_EINVAL for an
  * unknown name.  Not thread-safe against concurrent launches. */
 int rg_set_option(const char* name, int value);
@@ -348,6 +349,10 @@ int rg_bn_act_bwd_partials(const float* partial, int G, int nblk, const void* z,
  * (groups = 1 or 2, z is [groups * M][C]).  rg_slab_bn_supported: C % 128 == 0, nsplit in {2, 4, 8}, row count divisible
  * into 64 / 128 / 256-row blocks with at most 256 workgroups (one per CU: all co-resident -- required by the hand-off). */
 int rg_conv_split(int up, int N, int Hlow, int Wlow, int O, int I, int dtype, int algo);
+/* element type of the slabs that launch leaves: RG_F32, or RG_BF16 where the 8-wave kernel stores its partial tiles as bf16
+ * (option "slab16", default on: half the slab bytes written and re-read; each partial sum is rounded to bf16 before the
+ * consumer adds them in fp32).  Pass it to the consumer as slab_dtype; the slab stride stays in ELEMENTS. */
+int rg_conv_slab_dtype(int up, int N, int Hlow, int Wlow, int O, int I, int dtype, int algo);
 int rg_conv_down_partial(const void* x, const void* wdn, int N, int Hi, int Wi, int I, int O, int dtype, int algo,
                          void* ws, size_t ws_bytes, void* stream);
 int rg_conv_up_partial(const void* x, const void* wup, int N, int Ho, int Wo, int O, int I, int dtype, int algo,
@@ -355,16 +360,16 @@ int rg_conv_up_partial(const void* x, const void* wup, int N, int Ho, int Wo, in
 int rg_slab_bn_supported(long long M, int C, int groups, int nsplit);
 size_t rg_slab_bn_scratch_bytes(long long M, int C, int groups);
 size_t rg_slab_bn_sync_words(void);
-int rg_bn_forward_slabs(const void* slab, int nsplit, size_t slab_stride, void* z, void* a, long long M, int C, int groups,
+int rg_bn_forward_slabs(const void* slab, int nsplit, size_t slab_stride, int slab_dtype, void* z, void* a, long long M, int C, int groups,
                         float eps, float momentum, const float* gamma, const float* beta, float slope, float* mean,
                         float* invstd, float* running_mean, float* running_var, long long* num_batches_tracked,
                         void* scratch, size_t scratch_bytes, void* sync, void* stream);
 /* the forward-mode tangent of the same block (rg_bn_tangent) with zt arriving as slabs (the penalty's tangent forward):
  * zt_out = bf16(sum_s slab_s) (always written), at, s_zt, s_xhzt as rg_bn_tangent */
-int rg_bn_tangent_slabs(const void* slab, int nsplit, size_t slab_stride, const void* z, void* zt_out, void* at, long long M,
+int rg_bn_tangent_slabs(const void* slab, int nsplit, size_t slab_stride, int slab_dtype, const void* z, void* zt_out, void* at, long long M,
                         int C, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
                         float* s_zt, float* s_xhzt, void* scratch, size_t scratch_bytes, void* sync, void* stream);
-int rg_bn_act_bwd_slabs(const void* slab, int nsplit, size_t slab_stride, const void* z, void* ga_out, void* gz, long long M,
+int rg_bn_act_bwd_slabs(const void* slab, int nsplit, size_t slab_stride, int slab_dtype, const void* z, void* ga_out, void* gz, long long M,
                         int C, int groups, const float* mean, const float* invstd, const float* gamma, const float* beta,
                         float slope, float* s_gy, float* s_gyxh, float* dgamma, float* dbeta, int accumulate, void* scratch,
                         size_t scratch_bytes, void* sync, void* stream);

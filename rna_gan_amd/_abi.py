@@ -141,14 +141,15 @@ PROTOTYPES = {
     "rg_bn_act_bwd_partials": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _p, _z,
                                     _p]),
     "rg_conv_split": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "rg_conv_slab_dtype": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "rg_conv_down_partial": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_conv_up_partial": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_slab_bn_supported": (_i, [C.c_longlong, _i, _i, _i]),
     "rg_slab_bn_scratch_bytes": (_z, [C.c_longlong, _i, _i]),
     "rg_slab_bn_sync_words": (_z, []),
-    "rg_bn_forward_slabs": (_i, [_p, _i, _z, _p, _p, C.c_longlong, _i, _i, _f, _f, _p, _p, _f, _p, _p, _p, _p, _p, _p, _z, _p, _p]),
-    "rg_bn_tangent_slabs": (_i, [_p, _i, _z, _p, _p, _p, C.c_longlong, _i, _p, _p, _p, _p, _f, _p, _p, _p, _z, _p, _p]),
-    "rg_bn_act_bwd_slabs": (_i, [_p, _i, _z, _p, _p, _p, C.c_longlong, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _p, _z,
+    "rg_bn_forward_slabs": (_i, [_p, _i, _z, _i, _p, _p, C.c_longlong, _i, _i, _f, _f, _p, _p, _f, _p, _p, _p, _p, _p, _p, _z, _p, _p]),
+    "rg_bn_tangent_slabs": (_i, [_p, _i, _z, _i, _p, _p, _p, C.c_longlong, _i, _p, _p, _p, _p, _f, _p, _p, _p, _z, _p, _p]),
+    "rg_bn_act_bwd_slabs": (_i, [_p, _i, _z, _i, _p, _p, _p, C.c_longlong, _i, _i, _p, _p, _p, _p, _f, _p, _p, _p, _p, _i, _p, _z,
                                  _p, _p]),
     "rg_conv_up_affine": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _f, _p, _z, _p]),
     "rg_g0_fwd_affine": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _f, _p, _z, _p]),

@@ -24,7 +24,7 @@ extern "C" const char* rg_last_error(void) { return g_err; }
 // ---- kernel-selection knobs: override table in front of the RNAGAN_* environment variables
 static const char* const g_opt_names[] = {"conv8", "conv8_blocks", "conv_tile", "xcd", "class_fast", "wgrad_blocks",
                                           "wgrad8", "conv_v1", "stream_tile", "narrow8", "conv8_mfma", "conv8_epi", "wgrad8_blocks", "korder", "convp", "convp_blocks",
-                                          "fp8_mx", "wgrad8n", "f32mma", "convd", "convd_blocks", "skinny128"};
+                                          "fp8_mx", "wgrad8n", "f32mma", "convd", "convd_blocks", "skinny128", "slab16"};
 constexpr int G_NOPT = sizeof(g_opt_names) / sizeof(g_opt_names[0]);
 static int g_opt_override[G_NOPT];      // value + 1; 0 = not set
 static int g_opt_env[G_NOPT];           // cached environment value + 1; 0 = not read yet; -1 = variable absent
@@ -81,6 +81,11 @@ extern "C" int rg_conv_split(int up, int N, int Hlow, int Wlow, int O, int I, in
   if (N <= 0 || Hlow <= 0 || Wlow <= 0 || O <= 0 || I <= 0 || !want_mfma(algo, dtype)) return 1;
   if (!rg_mfma_conv_supported(N, Hlow, Wlow, up ? O : I, up ? I : O)) return 1;
   return rg_mfma_conv_nsplit(up, N, Hlow, Wlow, O, I);
+}
+
+extern "C" int rg_conv_slab_dtype(int up, int N, int Hlow, int Wlow, int O, int I, int dtype, int algo) {
+  if (rg_conv_split(up, N, Hlow, Wlow, O, I, dtype, algo) <= 1) return RG_F32;
+  return rg_mfma_conv_slab16(up, N, Hlow, Wlow, O, I) ? RG_BF16 : RG_F32;
 }
 
 extern "C" int rg_conv_down_partial(const void* x, const void* wdn, int N, int Hi, int Wi, int I, int O, int dtype, int algo,

@@ -466,6 +466,15 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
         orow = m;
       }
       if (a2.nsplit > 1) {
+        if (a2.slab16) {                 // bf16 partial tile: 16 instead of 32 bytes per thread and row (rounded partial sums)
+          uint4 o;
+          o.x = (uint32_t)f32_to_bf16(v0.x) | ((uint32_t)f32_to_bf16(v0.y) << 16);
+          o.y = (uint32_t)f32_to_bf16(v0.z) | ((uint32_t)f32_to_bf16(v0.w) << 16);
+          o.z = (uint32_t)f32_to_bf16(v1.x) | ((uint32_t)f32_to_bf16(v1.y) << 16);
+          o.w = (uint32_t)f32_to_bf16(v1.z) | ((uint32_t)f32_to_bf16(v1.w) << 16);
+          *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a2.slab) + (long long)zs * a2.slab_stride + orow * g.ldc + col) = o;
+          continue;
+        }
         float* so = a2.slab + (long long)zs * a2.slab_stride + orow * g.ldc + col;
         *reinterpret_cast<float4*>(so) = v0;
         *reinterpret_cast<float4*>(so + 4) = v1;

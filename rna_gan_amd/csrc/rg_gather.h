@@ -88,8 +88,9 @@ struct G2Args {
   int tiles_m;                 // number of row tiles (per parity class)
   int class_fast;              // MODE_UP: the 4 output-parity classes are the fastest-varying part of blockIdx.x (they
                                // read the same input rows: back to back on one XCD the rows are fetched from HBM once)
-  float* slab;                 // [nsplit][rows_out][Ncols] fp32 when nsplit > 1
+  float* slab;                 // [nsplit][rows_out][Ncols] fp32 when nsplit > 1 (bf16 with slab16, same element stride)
   long long slab_stride;       // elements per split
+  int slab16;                  // conv8_kernel, EPI bf16: the split-K partial tiles are stored as bf16 (option slab16)
   int lgcpt, cmask;            // conv8_kernel: k-tile kt -> tap = kt >> lgcpt, channel block = kt & cmask
   int korder;                  // 1: channel-block-major k order (tap = kt & (taps-1), block = kt / taps; MODE_DOWN taps in
                                // parity-class order): the taps that revisit the same input lines are adjacent k-tiles

@@ -47,6 +47,10 @@ int rg_mfma_conv_down(const void* x, const void* wdn, void* y, int N, int Hi, in
                       void* ws, size_t ws_bytes, hipStream_t st, int defer_reduce = 0, const RgBnBwdFuse* bf = nullptr);
 int rg_mfma_conv_bnbwd_rows(int up, int N, int Hlow, int Wlow, int O, int I, int groups);
 int rg_mfma_conv_nsplit(int up, int N, int Hlow, int Wlow, int O, int I);
+// split-K partial tiles of the 8-wave conv kernel as bf16 instead of fp32 (option `slab16`): half the slab bytes written by the
+// conv launch and read by the fused reduction + BatchNorm kernel; the partial sums are rounded to bf16 before they are added
+constexpr int RG_SLAB16_DEFAULT = 1;
+int rg_mfma_conv_slab16(int up, int N, int Hlow, int Wlow, int O, int I);
 int rg_mfma_conv_stats_rows(int up, int N, int Hlow, int Wlow, int O, int I);
 int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, const void* mask,
                     float mslope, float* stats, void* ws, size_t ws_bytes, hipStream_t st, const float* scale = nullptr,

@@ -627,14 +627,25 @@ __global__ void reduce_linear_kernel(const float* __restrict__ slab, float* __re
 }
 
 // out_bf16[i] = sum_z slab[z][i]   (split-K partials of gather_gemm_dma_kernel; 8 elements per thread)
+// S16: the slabs themselves are bf16 (conv8_kernel with G2Args::slab16)
+template <bool S16>
 __global__ void reduce_slabs_bf16_kernel(const float* __restrict__ slab, uint16_t* __restrict__ out, size_t n8,
                                          size_t stride, int nsplit) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n8) return;
   float4 a = make_float4(0, 0, 0, 0), b = a;
   for (int z = 0; z < nsplit; ++z) {
-    const float4* p = reinterpret_cast<const float4*>(slab + (size_t)z * stride + i * 8);
-    float4 x = p[0], y = p[1];
+    float4 x, y;
+    if (S16) {
+      const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(slab) + (size_t)z * stride + i * 8);
+      x = make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16),
+                      __uint_as_float(t.y & 0xffff0000u));
+      y = make_float4(__uint_as_float(t.z << 16), __uint_as_float(t.z & 0xffff0000u), __uint_as_float(t.w << 16),
+                      __uint_as_float(t.w & 0xffff0000u));
+    } else {
+      const float4* p = reinterpret_cast<const float4*>(slab + (size_t)z * stride + i * 8);
+      x = p[0]; y = p[1];
+    }
     a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
     b.x += y.x; b.y += y.y; b.z += y.z; b.w += y.w;
   }
@@ -1329,6 +1340,8 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
   const int stream_tile = rg_option("stream_tile", 1);
   const bool stream = stream_tile && EPI == EPI_LINEAR && MODE == MODE_PLAIN && g.M <= 64 && !narrow;
   const bool c8 = pl.c8 && nsplit == pl.nsplit;      // (a missing split-K workspace falls back to the 2-stage kernel)
+  // bf16 partial tiles (option slab16): only the 8-wave kernel writes them; rg_mfma_conv_slab16 answers the same for the consumer
+  a2.slab16 = (EPI == EPI_BF16 && nsplit > 1 && c8 && !pl.pp && !pl.pd && !pl.n8 && rg_option("slab16", RG_SLAB16_DEFAULT)) ? 1 : 0;
   const int bn = c8 ? pl.bn : narrow ? 64 : wide ? 256 : 128, bmm = c8 ? pl.bm : stream ? 64 : (narrow || wide) ? 256 : 128;
   g.tiles_n = (g.Ncols + bn - 1) / bn;
   a2.g = g;
@@ -1392,8 +1405,12 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
     RG_LAUNCH_CHECK(name);
   } else if (nsplit > 1 && !g.defer_reduce) {
     size_t n8 = (size_t)rows_out * g.Ncols / 8;
-    hipLaunchKernelGGL(reduce_slabs_bf16_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, (const float*)ws,
-                       (uint16_t*)g.C, n8, (size_t)rows_out * g.Ncols, nsplit);
+    if (a2.slab16)
+      hipLaunchKernelGGL(reduce_slabs_bf16_kernel<true>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, (const float*)ws,
+                         (uint16_t*)g.C, n8, (size_t)rows_out * g.Ncols, nsplit);
+    else
+      hipLaunchKernelGGL(reduce_slabs_bf16_kernel<false>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, (const float*)ws,
+                         (uint16_t*)g.C, n8, (size_t)rows_out * g.Ncols, nsplit);
     RG_LAUNCH_CHECK(name);
   }
   return RG_OK;
@@ -1509,6 +1526,16 @@ int rg_mfma_conv_nsplit(int up, int N, int Hlow, int Wlow, int O, int I) {
   const GPlan pl = gather_plan(up ? MODE_UP : MODE_DOWN, true, M, Ncols, Cin, taps, nclass, false, up ? Hlow : 2 * Hlow,
                                up ? Wlow : 2 * Wlow);
   return pl.nsplit;
+}
+
+// 1: the split-K launch of this layer (rg_conv_*_partial, no mask / affine) leaves bf16 partial tiles (launch_gather2: slab16)
+int rg_mfma_conv_slab16(int up, int N, int Hlow, int Wlow, int O, int I) {
+  const int M = N * Hlow * Wlow, Ncols = up ? I : O, Cin = up ? O : I, taps = up ? 4 : 16, nclass = up ? 4 : 1;
+  const size_t a_bytes = up ? (size_t)M * O * 2 : (size_t)M * 4 * I * 2, b_bytes = (size_t)O * 16 * I * 2;
+  if (use_v1() || a_bytes >= 0x7fffff00ull || b_bytes >= 0x7fffff00ull) return 0;
+  const GPlan pl = gather_plan(up ? MODE_UP : MODE_DOWN, true, M, Ncols, Cin, taps, nclass, false, up ? Hlow : 2 * Hlow,
+                               up ? Wlow : 2 * Wlow);
+  return (pl.nsplit > 1 && pl.c8 && !pl.pp && !pl.pd && !pl.n8 && rg_option("slab16", RG_SLAB16_DEFAULT)) ? 1 : 0;
 }
 
 size_t rg_mfma_conv_ws_bytes(int up, int N, int Hlow, int Wlow, int O, int I) {

@@ -37,6 +37,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct SbnArgs {
   const float* slab; size_t slab_stride; int nsplit;
+  int slab16;               // the slabs are bf16 (RG_BF16 slab_dtype: conv8_kernel's slab16 form), else fp32
   const uint16_t* zin;      // backward: the layer's stored pre-activation z
   uint16_t* out0;           // forward: z ; backward: ga (may be null)
   uint16_t* out1;           // forward: a ; backward: gz
@@ -110,24 +111,45 @@ __device__ __forceinline__ uint4 pack8(const float* v) {
 
 // the NS slab pieces of (row, c .. c+7): loads issued together (a thread keeps 16 x 16 B in flight: rows are processed in
 // chunks of U = 8 / NS so that the next rows' loads are not held back by the previous rows' stores)
-template <int NS> struct SlabPiece { float4 v[NS][2]; };
+// S16: the slabs are bf16 (conv8_kernel with G2Args::slab16): ONE 16-byte load per piece, widened when summed.
+template <int NS, bool S16> struct SlabPiece;
+template <int NS> struct SlabPiece<NS, false> { float4 v[NS][2]; };
+template <int NS> struct SlabPiece<NS, true> { uint4 v[NS]; };
 template <int NS>
-__device__ __forceinline__ void slab_load(const float* __restrict__ p, size_t stride, SlabPiece<NS>& q) {
+__device__ __forceinline__ void slab_load(const float* __restrict__ p, size_t off, size_t stride, SlabPiece<NS, false>& q) {
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    q.v[s][0] = *reinterpret_cast<const float4*>(p + s * stride);
-    q.v[s][1] = *reinterpret_cast<const float4*>(p + s * stride + 4);
+    q.v[s][0] = *reinterpret_cast<const float4*>(p + off + s * stride);
+    q.v[s][1] = *reinterpret_cast<const float4*>(p + off + s * stride + 4);
   }
+}
+template <int NS>
+__device__ __forceinline__ void slab_load(const float* __restrict__ p, size_t off, size_t stride, SlabPiece<NS, true>& q) {
+  const uint16_t* h = reinterpret_cast<const uint16_t*>(p);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) q.v[s] = *reinterpret_cast<const uint4*>(h + off + s * stride);
 }
 // their sum in fixed order s = 0 .. NS-1 (the order reduce_slabs_bf16_kernel uses)
 template <int NS>
-__device__ __forceinline__ void slab_sum(const SlabPiece<NS>& q, float* acc) {
+__device__ __forceinline__ void slab_sum(const SlabPiece<NS, false>& q, float* acc) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     acc[0] += q.v[s][0].x; acc[1] += q.v[s][0].y; acc[2] += q.v[s][0].z; acc[3] += q.v[s][0].w;
     acc[4] += q.v[s][1].x; acc[5] += q.v[s][1].y; acc[6] += q.v[s][1].z; acc[7] += q.v[s][1].w;
+  }
+}
+template <int NS>
+__device__ __forceinline__ void slab_sum(const SlabPiece<NS, true>& q, float* acc) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    float v[8];
+    unpack8(q.v[s], v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += v[i];
   }
 }
 
@@ -188,7 +210,7 @@ __device__ __forceinline__ void slice_totals(const float* pgrp, int rbpg, float 
   __syncthreads();
 }
 
-template <int RPT, int NS>
+template <int RPT, int NS, bool S16>
 __global__ __launch_bounds__(SB_THREADS) void slab_bn_fwd_kernel(SbnArgs a) {
   __shared__ __attribute__((aligned(16))) float sm[SB_WAVES][2][SB_COLS];     // 16 KB: block partials, then the row lanes of phase 2
   __shared__ float tot[2 * SB_COLS];
@@ -204,9 +226,9 @@ __global__ __launch_bounds__(SB_THREADS) void slab_bn_fwd_kernel(SbnArgs a) {
   constexpr int U = (8 / NS) < RPT ? (8 / NS) : RPT;
 #pragma unroll
   for (int k0 = 0; k0 < RPT; k0 += U) {
-    SlabPiece<NS> q[U];
+    SlabPiece<NS, S16> q[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) slab_load<NS>(a.slab + (row0 + (size_t)(k0 + u) * SB_TY) * a.C + c, a.slab_stride, q[u]);
+    for (int u = 0; u < U; ++u) slab_load<NS>(a.slab, (row0 + (size_t)(k0 + u) * SB_TY) * a.C + c, a.slab_stride, q[u]);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int k = k0 + u;
@@ -280,7 +302,7 @@ __global__ __launch_bounds__(SB_THREADS) void slab_bn_fwd_kernel(SbnArgs a) {
 // MODE 1: forward-mode tangent of the same block (the slabs are zt = conv(tangent of the layer below)): sums of zt and
 //         xhat * zt, at = lrelu'(y) * gamma * invstd * (zt - mean(zt) - xhat * mean(xhat * zt))  (rg_bn_tangent's arithmetic);
 //         out0 = zt is always written (the penalty's joint reverse pass reads it).
-template <int RPT, int NS, int MODE>
+template <int RPT, int NS, int MODE, bool S16>
 __global__ __launch_bounds__(SB_THREADS) void slab_bn_bwd_kernel(SbnArgs a) {
   __shared__ __attribute__((aligned(16))) float sm[SB_WAVES][2][SB_COLS];
   __shared__ float tot[2 * SB_COLS];
@@ -302,12 +324,12 @@ __global__ __launch_bounds__(SB_THREADS) void slab_bn_bwd_kernel(SbnArgs a) {
   constexpr int U = (8 / NS) < RPT ? (8 / NS) : RPT;
 #pragma unroll
   for (int k0 = 0; k0 < RPT; k0 += U) {
-    SlabPiece<NS> q[U];
+    SlabPiece<NS, S16> q[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const size_t off = (row0 + (size_t)(k0 + u) * SB_TY) * a.C + c;
       zp[k0 + u] = *reinterpret_cast<const uint4*>(a.zin + off);
-      slab_load<NS>(a.slab + off, a.slab_stride, q[u]);
+      slab_load<NS>(a.slab, off, a.slab_stride, q[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -403,8 +425,14 @@ template <int KIND, int RPT>       // KIND 0 forward, 1 backward, 2 tangent
 static void sbn_launch_ns(const SbnArgs& a, dim3 grid, hipStream_t st) {
 #define SBN_GO(NS)                                                                                          \
   do {                                                                                                      \
-    if (KIND == 0) hipLaunchKernelGGL((slab_bn_fwd_kernel<RPT, NS>), grid, dim3(SB_THREADS), 0, st, a);     \
-    else hipLaunchKernelGGL((slab_bn_bwd_kernel<RPT, NS, KIND == 2 ? 1 : 0>), grid, dim3(SB_THREADS), 0, st, a); \
+    if (KIND == 0) {                                                                                         \
+      if (a.slab16) hipLaunchKernelGGL((slab_bn_fwd_kernel<RPT, NS, true>), grid, dim3(SB_THREADS), 0, st, a);  \
+      else hipLaunchKernelGGL((slab_bn_fwd_kernel<RPT, NS, false>), grid, dim3(SB_THREADS), 0, st, a);          \
+    } else if (a.slab16) {                                                                                   \
+      hipLaunchKernelGGL((slab_bn_bwd_kernel<RPT, NS, KIND == 2 ? 1 : 0, true>), grid, dim3(SB_THREADS), 0, st, a);  \
+    } else {                                                                                                 \
+      hipLaunchKernelGGL((slab_bn_bwd_kernel<RPT, NS, KIND == 2 ? 1 : 0, false>), grid, dim3(SB_THREADS), 0, st, a); \
+    }                                                                                                        \
   } while (0)
   if constexpr (RPT == 1) { if (a.nsplit == 2) SBN_GO(2); else if (a.nsplit == 4) SBN_GO(4); else SBN_GO(8); }
   else if constexpr (RPT == 2) { if (a.nsplit == 2) SBN_GO(2); else SBN_GO(4); }
@@ -438,7 +466,7 @@ extern "C" size_t rg_slab_bn_scratch_bytes(long long M, int C, int groups) {
 }
 extern "C" size_t rg_slab_bn_sync_words(void) { return 16 + 16 * 64; }
 
-extern "C" int rg_bn_forward_slabs(const void* slab, int nsplit, size_t slab_stride, void* z, void* a_out, long long M, int C,
+extern "C" int rg_bn_forward_slabs(const void* slab, int nsplit, size_t slab_stride, int slab_dtype, void* z, void* a_out, long long M, int C,
                                    int groups, float eps, float momentum, const float* gamma, const float* beta, float slope,
                                    float* mean, float* invstd, float* running_mean, float* running_var,
                                    long long* num_batches_tracked, void* scratch, size_t scratch_bytes, void* sync,
@@ -451,7 +479,7 @@ extern "C" int rg_bn_forward_slabs(const void* slab, int nsplit, size_t slab_str
   RG_REQUIRE(scratch_bytes >= (size_t)p.slices * groups * p.rbpg * 2 * SB_COLS * sizeof(float), RG_EWORKSPACE,
              "bn_forward_slabs: scratch too small");
   SbnArgs a{};
-  a.slab = (const float*)slab; a.slab_stride = slab_stride; a.nsplit = nsplit;
+  a.slab = (const float*)slab; a.slab_stride = slab_stride; a.nsplit = nsplit; a.slab16 = slab_dtype == RG_BF16 ? 1 : 0;
   a.out0 = (uint16_t*)z; a.out1 = (uint16_t*)a_out; a.M = (int)M; a.C = C; a.groups = groups;
   a.gamma = gamma; a.beta = beta; a.slope = slope; a.eps = eps; a.momentum = momentum;
   a.mean = mean; a.invstd = invstd; a.rmean = running_mean; a.rvar = running_var; a.nbt = num_batches_tracked;
@@ -459,7 +487,7 @@ extern "C" int rg_bn_forward_slabs(const void* slab, int nsplit, size_t slab_str
   return sbn_launch<0>("bn_forward_slabs", a, p, rg_stream(stream));
 }
 
-extern "C" int rg_bn_act_bwd_slabs(const void* slab, int nsplit, size_t slab_stride, const void* z, void* ga_out, void* gz,
+extern "C" int rg_bn_act_bwd_slabs(const void* slab, int nsplit, size_t slab_stride, int slab_dtype, const void* z, void* ga_out, void* gz,
                                    long long M, int C, int groups, const float* mean, const float* invstd, const float* gamma,
                                    const float* beta, float slope, float* s_gy, float* s_gyxh, float* dgamma, float* dbeta,
                                    int accumulate, void* scratch, size_t scratch_bytes, void* sync, void* stream) {
@@ -473,7 +501,7 @@ extern "C" int rg_bn_act_bwd_slabs(const void* slab, int nsplit, size_t slab_str
   RG_REQUIRE(scratch_bytes >= (size_t)p.slices * groups * p.rbpg * 2 * SB_COLS * sizeof(float), RG_EWORKSPACE,
              "bn_act_bwd_slabs: scratch too small");
   SbnArgs a{};
-  a.slab = (const float*)slab; a.slab_stride = slab_stride; a.nsplit = nsplit;
+  a.slab = (const float*)slab; a.slab_stride = slab_stride; a.nsplit = nsplit; a.slab16 = slab_dtype == RG_BF16 ? 1 : 0;
   a.zin = (const uint16_t*)z; a.out0 = (uint16_t*)ga_out; a.out1 = (uint16_t*)gz; a.M = (int)M; a.C = C; a.groups = groups;
   a.gamma = gamma; a.beta = beta; a.slope = slope;
   a.mean = const_cast<float*>(mean); a.invstd = const_cast<float*>(invstd);
@@ -482,7 +510,7 @@ extern "C" int rg_bn_act_bwd_slabs(const void* slab, int nsplit, size_t slab_str
   return sbn_launch<1>("bn_act_bwd_slabs", a, p, rg_stream(stream));
 }
 
-extern "C" int rg_bn_tangent_slabs(const void* slab, int nsplit, size_t slab_stride, const void* z, void* zt_out, void* at,
+extern "C" int rg_bn_tangent_slabs(const void* slab, int nsplit, size_t slab_stride, int slab_dtype, const void* z, void* zt_out, void* at,
                                    long long M, int C, const float* mean, const float* invstd, const float* gamma,
                                    const float* beta, float slope, float* s_zt, float* s_xhzt, void* scratch,
                                    size_t scratch_bytes, void* sync, void* stream) {
@@ -495,7 +523,7 @@ extern "C" int rg_bn_tangent_slabs(const void* slab, int nsplit, size_t slab_str
   RG_REQUIRE(scratch_bytes >= (size_t)p.slices * p.rbpg * 2 * SB_COLS * sizeof(float), RG_EWORKSPACE,
              "bn_tangent_slabs: scratch too small");
   SbnArgs a{};
-  a.slab = (const float*)slab; a.slab_stride = slab_stride; a.nsplit = nsplit;
+  a.slab = (const float*)slab; a.slab_stride = slab_stride; a.nsplit = nsplit; a.slab16 = slab_dtype == RG_BF16 ? 1 : 0;
   a.zin = (const uint16_t*)z; a.out0 = (uint16_t*)zt_out; a.out1 = (uint16_t*)at; a.M = (int)M; a.C = C; a.groups = 1;
   a.gamma = gamma; a.beta = beta; a.slope = slope;
   a.mean = const_cast<float*>(mean); a.invstd = const_cast<float*>(invstd);

@@ -25,10 +25,10 @@ class SlabRef:
     to the (not yet written) output tensor as ``t._rg_slabs`` and consumed by the BatchNorm op that follows, which sums the
     slabs itself and writes the tensor (rg_bn_forward_slabs / rg_bn_act_bwd_slabs).  Holds the workspace tensor alive."""
 
-    __slots__ = ("ws", "nsplit", "stride", "groups")
+    __slots__ = ("ws", "nsplit", "stride", "groups", "dtype")
 
-    def __init__(self, ws, nsplit, stride, groups):
-        self.ws, self.nsplit, self.stride, self.groups = ws, nsplit, stride, groups
+    def __init__(self, ws, nsplit, stride, groups, dtype=RG_F32):
+        self.ws, self.nsplit, self.stride, self.groups, self.dtype = ws, nsplit, stride, groups, dtype
 
 
 _LIVE_OPS = weakref.WeakSet()
@@ -370,7 +370,8 @@ class HipOps:
             self._timed("conv_fwd_dgrad", 2.0 * N * (Hi // 2) * (Wi // 2) * O * I * 16, lambda: check(
                 self.lib.rg_conv_down_partial(_ptr(x), _ptr(wdn), N, Hi, Wi, I, O, self.dt, self.algo, _ptr(ws), ws.numel(),
                                               self.stream), "rg_conv_down_partial"), cw=cw)
-            y._rg_slabs = SlabRef(ws, ns, y.numel(), defer)
+            y._rg_slabs = SlabRef(ws, ns, y.numel(), defer,
+                                  self.lib.rg_conv_slab_dtype(0, N, Hi // 2, Wi // 2, O, I, self.dt, self.algo))
             self._slabs_pending = y
             return (y, None) if want_stats else y
         if bn_bwd is not None and not want_stats and self._bn_bwd_fused(
@@ -398,7 +399,8 @@ class HipOps:
             self._timed("conv_fwd_dgrad", 2.0 * N * Ho * Wo * O * I * 16, lambda: check(
                 self.lib.rg_conv_up_partial(_ptr(x), _ptr(wup), N, Ho, Wo, O, I, self.dt, self.algo, _ptr(ws), ws.numel(),
                                             self.stream), "rg_conv_up_partial"), cw=cw)
-            y._rg_slabs = SlabRef(ws, ns, y.numel(), defer)
+            y._rg_slabs = SlabRef(ws, ns, y.numel(), defer,
+                                  self.lib.rg_conv_slab_dtype(1, N, Ho, Wo, O, I, self.dt, self.algo))
             self._slabs_pending = y
             return (y, None) if want_stats else y
         if bn_bwd is not None and mask_act is None and not want_stats and self._bn_bwd_fused(
@@ -965,7 +967,7 @@ class HipOps:
         assert a.shape == z.shape and a.is_contiguous()
         scratch, sync = self._sb_bufs(M, C, groups)
         self._timed("bn_split_fused", 0.0, lambda: check(
-            self.lib.rg_bn_forward_slabs(_ptr(sl.ws), sl.nsplit, sl.stride, _ptr(z), _ptr(a), M, C, groups, float(eps),
+            self.lib.rg_bn_forward_slabs(_ptr(sl.ws), sl.nsplit, sl.stride, sl.dtype, _ptr(z), _ptr(a), M, C, groups, float(eps),
                                          float(momentum), _ptr(gamma), _ptr(beta), float(slope), _ptr(mean), _ptr(invstd),
                                          _ptr(running_mean), _ptr(running_var), _ptr(nbt), _ptr(scratch), scratch.numel(),
                                          _ptr(sync), self.stream), "rg_bn_forward_slabs"))
@@ -1030,7 +1032,7 @@ class HipOps:
         s_gy, s_gyxh = (self._f32(C), self._f32(C)) if groups == 1 else (self._f32(groups, C), self._f32(groups, C))
         scratch, sync = self._sb_bufs(M, C, groups)
         self._timed("bn_split_fused", 0.0, lambda: check(
-            self.lib.rg_bn_act_bwd_slabs(_ptr(sl.ws), sl.nsplit, sl.stride, _ptr(z), _ptr(ga) if keep_ga else 0, _ptr(gz), M,
+            self.lib.rg_bn_act_bwd_slabs(_ptr(sl.ws), sl.nsplit, sl.stride, sl.dtype, _ptr(z), _ptr(ga) if keep_ga else 0, _ptr(gz), M,
                                          C, groups, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), float(slope),
                                          _ptr(s_gy), _ptr(s_gyxh), _ptr(dgamma), _ptr(dbeta), int(accumulate), _ptr(scratch),
                                          scratch.numel(), _ptr(sync), self.stream), "rg_bn_act_bwd_slabs"))
@@ -1096,7 +1098,7 @@ class HipOps:
             assert sl.groups == 1 and zt.shape == z.shape
             scratch, sync = self._sb_bufs(M, C, 1)
             self._timed("bn_split_fused", 0.0, lambda: check(
-                self.lib.rg_bn_tangent_slabs(_ptr(sl.ws), sl.nsplit, sl.stride, _ptr(z), _ptr(zt), _ptr(at), M, C, _ptr(mean),
+                self.lib.rg_bn_tangent_slabs(_ptr(sl.ws), sl.nsplit, sl.stride, sl.dtype, _ptr(z), _ptr(zt), _ptr(at), M, C, _ptr(mean),
                                              _ptr(invstd), _ptr(gamma), _ptr(beta), float(slope), _ptr(s_zt), _ptr(s_xhzt),
                                              _ptr(scratch), scratch.numel(), _ptr(sync), self.stream), "rg_bn_tangent_slabs"))
             del zt._rg_slabs
