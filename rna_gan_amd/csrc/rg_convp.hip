@@ -295,8 +295,8 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
         // both words are formed HERE, right behind the wait (an opaque use pins the two shifts to this point).  Left to the
         // compiler, the second shift was sunk 60 instructions down to its first use and lanes 12..15 of every row tile read
         // garbage for channels 32 + 8 fq + 2, 3 (found by the bit-exact test against the implicit-GEMM kernel; a build with
-        // more wait states in front of the shift failed on MORE elements, one with the shifts pinned passed -- the register of
-        // the read's second dword does not survive the masked stores' address arithmetic; cause not isolated further)
+        // more wait states in front of the shift failed on MORE elements, one with the shifts pinned passed.  The cause was NOT
+        // isolated: the pin is what the measurements support, nothing more)
         asm volatile("" : "+v"(b8lo), "+v"(b8hi));
       }
       u32x4_t o[2];

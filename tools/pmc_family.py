@@ -4,7 +4,7 @@ weighted by n x us).  Usage: pmc_family.py <layers.csv>  -> JSON"""
 import csv, json, sys
 
 fam_of = lambda n: ("gather_gemm" if ("gather_gemm_dma_kernel<0" in n or "gather_gemm_dma_kernel<1" in n or "conv8" in n or "convp_kernel" in n or "convd_kernel" in n)
-                    else "wgrad_dma" if ("wgrad8_kernel" in n or "wgrad_dma_kernel" in n) else None)   # the MFMA conv weight gradients
+                    else "wgrad_dma" if ("wgrad8_kernel" in n or "wgrad8n_kernel" in n or "wgrad_dma_kernel" in n) else None)   # the MFMA conv weight gradients
 # (g0_wgrad_adam_kernel is an HBM-streaming Adam pass with 16 MFMAs per tile, head_wgrad a VALU reduction: neither belongs here)
 acc = {}
 for r in csv.DictReader(open(sys.argv[1])):

@@ -15,7 +15,7 @@ def load(d, counter):
         n = r["Kernel_Name"]
         fam = ("gather_gemm_linear" if "gather_gemm_dma_kernel<2" in n else
                "gather_gemm" if ("gather_gemm_dma" in n or "conv8_kernel" in n or "conv8n_kernel" in n or "convp_kernel" in n or "convd_kernel" in n) else
-               "wgrad_dma" if ("wgrad_dma" in n or "wgrad8_kernel" in n) else
+               "wgrad_dma" if ("wgrad_dma" in n or "wgrad8_kernel" in n or "wgrad8n_kernel" in n) else
                "first_down" if "first_down" in n else "last_up" if "last_up" in n else
                "skinny_wgrad" if "skinny_wgrad" in n else "adam" if ("AdamDev" in n or "adam_dev_kernel" in n) else
                "bn_split_fused" if "slab_bn_" in n else
