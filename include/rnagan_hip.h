@@ -127,9 +127,20 @@ int rg_conv_wgrad2(const void* low0, const void* high0, const void* low1, const 
  * (.backward() directly followed by optimizer.step(), src/wgan_loss.py:126-127, :260-261, :387-388): a plan with
  * *nsplit_out > 1 leaves its fp32 partial slabs [nsplit][O][16][I] in `slab` (>= rg_conv_wgrad_workspace_bytes, caller-owned,
  * must stay untouched until rg_adam_step_slabs has consumed it) and does not write dw; *nsplit_out == 1: dw was written
- * (not accumulated) and nothing is pending.  RG_EUNSUPPORTED where the bf16 matrix-core weight gradient does not apply. */
+ * (not accumulated) and nothing is pending -- also the outcome for every shape / dtype the matrix-core kernel does not take
+ * (the generic kernel runs with `slab` as its workspace). */
 int rg_conv_wgrad_slabs(const void* low0, const void* high0, const void* low1, const void* high1, float* dw, int N, int Ho,
                         int Wo, int O, int I, int dtype, int algo, void* slab, size_t slab_bytes, int* nsplit_out, void* stream);
+/* The same pair of calls (weight gradient, then optimizer.step()) as ONE launch for a layer whose plan has no split-K: the
+ * gradient tile is never written -- the kernel's epilogue applies the Adam update (the arithmetic of rg_adam_step_dev, bit for
+ * bit) to the tensor's fp32 master p, moments m, v and optional bf16 operand image, all tap-major [O][16][I] like dw.
+ * hyper = the 8 constants rg_adam_hyper_dev wrote for THIS step.  26 bytes per parameter instead of 4 + 30.
+ * rg_conv_wgrad_adam_supported: 1 when the shape / dtype has such a plan (bf16, 256 | O, 16 | I, no split-K at this pixel
+ * count); the caller's streaming step then leaves the tensor out (rg_adam_step_slabs, seg_nsplit = -1). */
+int rg_conv_wgrad_adam_supported(int N, int Ho, int Wo, int O, int I, int two, int dtype, int algo);
+int rg_conv_wgrad_adam(const void* low0, const void* high0, const void* low1, const void* high1, float* p, float* m, float* v,
+                       const float* hyper, void* shadow_bf16, int N, int Ho, int Wo, int O, int I, int dtype, int algo,
+                       void* stream);
 
 /* Image-side layers (I = 3 channels, NCHW fp32 on the high-resolution side; HBM-bound).  Their weights keep
  * the PyTorch layout w[O][I][4][4] (48 values per O).
@@ -456,7 +467,8 @@ int rg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, con
  * order, every offset a multiple of 4): a segment with seg_slab[i] != NULL takes its gradient as the sum, in slab order, of
  * seg_nsplit[i] fp32 slabs of seg_n[i] elements (what rg_conv_wgrad_slabs left in the caller's buffer) instead of reading g --
  * the split-K reduction launches of the backward pass and the write + re-read of the reduced gradient disappear (one launch
- * for the whole buffer; deterministic summation order).  Segment tables are HOST arrays. */
+ * for the whole buffer; deterministic summation order).  A segment with seg_slab[i] == NULL and seg_nsplit[i] == -1 is SKIPPED
+ * (its tensor is stepped by rg_conv_wgrad_adam).  Segment tables are HOST arrays. */
 int rg_adam_step_slabs(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, void* shadow_bf16, int nseg,
                        const unsigned long long* seg_off, const unsigned long long* seg_n, const void* const* seg_slab,
                        const int* seg_nsplit, void* stream);

@@ -18,7 +18,7 @@ void rg_set_error(const char* fmt, ...) {
 }
 
 // bumped whenever an entry point is added or a signature changes; rna_gan_amd/_abi.py (ABI_VERSION) refuses any other value
-extern "C" int rg_version(void) { return 500; }   // 5.00: round 5 (rg_conv_wgrad_slabs, rg_adam_step_slabs)
+extern "C" int rg_version(void) { return 501; }   // 5.01: round 5 (rg_conv_wgrad_slabs, rg_adam_step_slabs, rg_conv_wgrad_adam)
 extern "C" const char* rg_last_error(void) { return g_err; }
 
 // ---- kernel-selection knobs: override table in front of the RNAGAN_* environment variables
@@ -195,9 +195,38 @@ extern "C" int rg_conv_wgrad_slabs(const void* low0, const void* high0, const vo
                                    int* nsplit_out, void* stream) {
   RG_REQUIRE(low0 && high0 && dw && nsplit_out && (low1 == nullptr) == (high1 == nullptr) && N > 0 && Ho > 0 && Wo > 0 && I > 0 &&
                  O > 0, RG_EINVAL, "conv_wgrad_slabs: bad args");
-  RG_REQUIRE(want_mfma(algo, dtype) && rg_mfma_wgrad_supported(N, Ho, Wo, O, I), RG_EUNSUPPORTED,
-             "conv_wgrad_slabs: only the bf16 matrix-core weight gradient leaves slabs");
+  if (!(want_mfma(algo, dtype) && rg_mfma_wgrad_supported(N, Ho, Wo, O, I))) {
+    // a shape the matrix-core kernel does not take (small models): the generic kernel reduces its own split-K through `slab`
+    // as a workspace and WRITES dw -- nothing pending, *nsplit_out = 1
+    *nsplit_out = 1;
+    RG_REQUIRE(algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "conv_wgrad_slabs: shape/dtype not supported by the MFMA kernel");
+    int rc = rg_generic_conv_wgrad(low0, high0, dw, N, Ho, Wo, O, I, dtype, 0, slab, slab_bytes, rg_stream(stream));
+    if (rc || !low1) return rc;
+    return rg_generic_conv_wgrad(low1, high1, dw, N, Ho, Wo, O, I, dtype, 1, slab, slab_bytes, rg_stream(stream));
+  }
   return rg_mfma_conv_wgrad2(low0, high0, low1, high1, dw, N, Ho, Wo, O, I, 0, slab, slab_bytes, rg_stream(stream), nsplit_out);
+}
+
+// Weight gradient of a 4 x 4 stride-2 layer AND the Adam step of that tensor in one launch (low1 / high1 may be NULL): p, m, v
+// (fp32) and the optional bf16 operand image `shadow_bf16` are the tensor's tap-major [O][16][I] buffers, hyper the 8 constants
+// of rg_adam_hyper_dev.  The gradient is never written.  rg_conv_wgrad_adam_supported says whether the shape has such a plan
+// (bf16 operands, the matrix-core kernel without split-K); the caller's streaming step must leave the tensor out
+// (rg_adam_step_slabs: a segment with nsplit = -1).
+extern "C" int rg_conv_wgrad_adam_supported(int N, int Ho, int Wo, int O, int I, int two, int dtype, int algo) {
+  return N > 0 && Ho > 0 && Wo > 0 && O > 0 && I > 0 && want_mfma(algo, dtype) && rg_mfma_wgrad_supported(N, Ho, Wo, O, I) &&
+         rg_mfma_conv_wgrad_adam_supported(N, Ho, Wo, O, I, two != 0) ? 1 : 0;
+}
+extern "C" int rg_conv_wgrad_adam(const void* low0, const void* high0, const void* low1, const void* high1, float* p, float* m,
+                                  float* v, const float* hyper, void* shadow_bf16, int N, int Ho, int Wo, int O, int I, int dtype,
+                                  int algo, void* stream) {
+  RG_REQUIRE(low0 && high0 && p && m && v && hyper && (low1 == nullptr) == (high1 == nullptr) && N > 0 && Ho > 0 && Wo > 0 &&
+                 I > 0 && O > 0, RG_EINVAL, "conv_wgrad_adam: bad args");
+  RG_REQUIRE((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && ((uintptr_t)shadow_bf16 & 7) == 0, RG_EINVAL,
+             "conv_wgrad_adam: p, m, v must be 16-byte aligned (the bf16 image 8-byte)");
+  RG_REQUIRE(rg_conv_wgrad_adam_supported(N, Ho, Wo, O, I, low1 != nullptr, dtype, algo), RG_EUNSUPPORTED,
+             "conv_wgrad_adam: shape / dtype without a single-split matrix-core plan");
+  return rg_mfma_conv_wgrad_adam(low0, high0, low1, high1, N, Ho, Wo, O, I, p, m, v, (uint16_t*)shadow_bf16, hyper,
+                                 rg_stream(stream));
 }
 
 extern "C" int rg_conv_wgrad(const void* low, const void* high, float* dw, int N, int Ho, int Wo, int O, int I,

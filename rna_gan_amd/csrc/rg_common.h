@@ -201,6 +201,30 @@ __device__ __forceinline__ void up_taps(int u, int L, int& i0, int& i1, float& l
   else       { i0 = max(q - 1, 0); i1 = q; l1 = 0.75f; }
 }
 
+// ---- the Adam update of one element (torch.optim.Adam, single-tensor path), shared by every kernel that applies it (rg_misc.hip's
+// streaming kernels, the generator layer-0 and conv weight-gradient kernels that step their tensor in the epilogue): ONE
+// expression, so that a tensor stepped by any of them comes out bit-identical.  hyper[0..7] = b1, b2, 1 - b1, 1 - b2, eps,
+// lr / bc1, 1 / sqrt(bc2), weight decay (rg_adam_hyper_dev).
+__device__ __forceinline__ void rg_adam_upd(float& pp, float gg, float& mm, float& vv, float b2, float omb1, float omb2, float eps,
+                                            float step_size, float inv_sqrt_bc2, float wd) {
+  if (wd != 0.f) gg += wd * pp;               // torch.optim.Adam weight_decay (L2 on the gradient); betaVAE training
+  // m = b1*m + (1-b1)g ; v = b2*v + (1-b2)g^2 ; denom = sqrt(v)/sqrt(bc2) + eps ; p -= (lr/bc1) * m/denom
+  // (1-beta) is rounded from double like torch's python-side `1 - beta2`; lerp form for m as torch
+  mm = mm + omb1 * (gg - mm);
+  vv = b2 * vv + omb2 * gg * gg;
+  float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+  pp -= step_size * (mm / denom);
+}
+struct RgAdamHyper {
+  float b1, b2, omb1, omb2, eps, step_size, inv_sqrt_bc2, wd;
+  __device__ __forceinline__ void load(const float* __restrict__ h) {
+    b1 = h[0]; b2 = h[1]; omb1 = h[2]; omb2 = h[3]; eps = h[4]; step_size = h[5]; inv_sqrt_bc2 = h[6]; wd = h[7];
+  }
+  __device__ __forceinline__ void upd(float& pp, float gg, float& mm, float& vv) const {
+    rg_adam_upd(pp, gg, mm, vv, b2, omb1, omb2, eps, step_size, inv_sqrt_bc2, wd);
+  }
+};
+
 // dtype dispatch helper for host code
 #define RG_DISPATCH_DTYPE(dtype, T, ...)                                  \
   if ((dtype) == RG_F32) { using T = float; __VA_ARGS__ }                 \

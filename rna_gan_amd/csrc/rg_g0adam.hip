@@ -20,12 +20,7 @@ constexpr int GA_E = 64, GA_J = 256, GA_N = 64;
 
 struct AdamC { float b1, b2, omb1, omb2, eps, step_size, inv_sqrt_bc2, wd; };
 __device__ __forceinline__ void adam_upd(const AdamC& a, float& pp, float gg, float& mm, float& vv) {
-  // rg_misc.hip Adam::upd (torch.optim.Adam single-tensor arithmetic)
-  if (a.wd != 0.f) gg += a.wd * pp;
-  mm = mm + a.omb1 * (gg - mm);
-  vv = a.b2 * vv + a.omb2 * gg * gg;
-  const float denom = sqrtf(vv) * a.inv_sqrt_bc2 + a.eps;
-  pp -= a.step_size * (mm / denom);
+  rg_adam_upd(pp, gg, mm, vv, a.b2, a.omb1, a.omb2, a.eps, a.step_size, a.inv_sqrt_bc2, a.wd);     // rg_common.h
 }
 
 typedef __attribute__((ext_vector_type(8))) __bf16 ga_bf16x8;

@@ -131,6 +131,13 @@ int rg_wgrad8n_launch(const void* low0, const void* high0, const void* low1, con
                       int two, int O, int I, int Ho, int Wo, int nsplit, int kt_per_split, int accumulate, hipStream_t st);
 int rg_wgrad8_launch(const void* low0, const void* high0, const void* low1, const void* high1, float* out, int Kseg,
                      int two, int O, int I, int Ho, int Wo, int nsplit, int kt_per_split, int accumulate, hipStream_t st);
+int rg_wgrad8_adam_launch(const void* low0, const void* high0, const void* low1, const void* high1, int Kseg, int two, int O,
+                          int I, int Ho, int Wo, int kt_per_split, float* p, float* m, float* v, uint16_t* shadow,
+                          const float* hyper, hipStream_t st);
+// weight gradient + Adam step of the tensor in one launch (plans of the 256 x 256 ping-pong kernel without split-K)
+bool rg_mfma_conv_wgrad_adam_supported(int N, int Ho, int Wo, int O, int I, bool two);
+int rg_mfma_conv_wgrad_adam(const void* low0, const void* high0, const void* low1, const void* high1, int N, int Ho, int Wo,
+                            int O, int I, float* p, float* m, float* v, uint16_t* shadow, const float* hyper, hipStream_t st);
 
 // rg_skinny.hip (image-side 3-channel layers)
 bool rg_skinny_supported(int I, int O);

@@ -1686,6 +1686,28 @@ int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, c
   return rg_reduce_slabs((const float*)ws, dw, elems, nsplit, accumulate, 0, 0, st);
 }
 
+// ---- weight gradient + optimizer step in one launch: the plans of rg_mfma_conv_wgrad2 that run wgrad8_kernel WITHOUT split-K
+// (the two 33.5 M-parameter layers at batch 64: D.5 and G.1, 512 tiles) can apply Adam to their tile where it sits in LDS
+// instead of writing 4 bytes per parameter that the streaming Adam reads back.
+bool rg_mfma_conv_wgrad_adam_supported(int N, int Ho, int Wo, int O, int I, bool two) {
+  const int Kseg = N * Ho * Wo;
+  const size_t lowb = (size_t)Kseg * O * 2, highb = (size_t)Kseg * 4 * I * 2;
+  if (use_v1() || lowb >= 0x7fffff00ull || highb >= 0x7fffff00ull || (two && Kseg % 64 != 0)) return false;
+  const int K = two ? 2 * Kseg : Kseg;
+  if (!rg_option("wgrad8", 1) || !rg_wgrad8_supported(K, O, I)) return false;
+  int per = 0;
+  return rg_wgrad8_split(K, O, I, &per) == 1;
+}
+int rg_mfma_conv_wgrad_adam(const void* low0, const void* high0, const void* low1, const void* high1, int N, int Ho, int Wo,
+                            int O, int I, float* p, float* m, float* v, uint16_t* shadow, const float* hyper, hipStream_t st) {
+  const bool two = low1 != nullptr;
+  RG_REQUIRE(rg_mfma_conv_wgrad_adam_supported(N, Ho, Wo, O, I, two), RG_EUNSUPPORTED,
+             "conv_wgrad_adam: no single-split plan of the 256 x 256 kernel for this shape");
+  int per = 0;
+  rg_wgrad8_split((two ? 2 : 1) * N * Ho * Wo, O, I, &per);
+  return rg_wgrad8_adam_launch(low0, high0, low1, high1, N * Ho * Wo, two ? 1 : 0, O, I, Ho, Wo, per, p, m, v, shadow, hyper, st);
+}
+
 size_t rg_mfma_wgrad2_ws_bytes(int N, int Ho, int Wo, int O, int I) {
   size_t a = (size_t)mfma_wgrad_split_k(N * Ho * Wo, O, I) * O * I * 16 * sizeof(float);
   size_t b = (size_t)mfma_wgrad_split_k(2 * N * Ho * Wo, O, I) * O * I * 16 * sizeof(float);

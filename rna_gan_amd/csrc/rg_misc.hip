@@ -72,14 +72,7 @@ struct Clamp {
 struct Adam {
   float* p; const float* g; float* m; float* v; float b1, b2, omb1, omb2, eps, step_size, inv_sqrt_bc2, wd;
   __device__ __forceinline__ void upd(float& pp, float gg, float& mm, float& vv) const {
-    if (wd != 0.f) gg += wd * pp;               // torch.optim.Adam weight_decay (L2 on the gradient); betaVAE training
-    // torch.optim.Adam (single-tensor path): m = b1*m + (1-b1)g ; v = b2*v + (1-b2)g^2 ;
-    // denom = sqrt(v)/sqrt(bc2) + eps ; p -= (lr/bc1) * m/denom
-    // (1-beta) is rounded from double like torch's python-side `1 - beta2`; lerp form for m as torch
-    mm = mm + omb1 * (gg - mm);
-    vv = b2 * vv + omb2 * gg * gg;
-    float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
-    pp -= step_size * (mm / denom);
+    rg_adam_upd(pp, gg, mm, vv, b2, omb1, omb2, eps, step_size, inv_sqrt_bc2, wd);      // rg_common.h: the one expression
   }
   __device__ void vec(size_t i) const {
     float4 P = *(float4*)(p + i), G = *(const float4*)(g + i), M = *(float4*)(m + i), V = *(float4*)(v + i);
@@ -200,6 +193,7 @@ __global__ __launch_bounds__(256) void adam_segs_kernel(float* __restrict__ p, c
   const Adam a{p, g, m, v, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6], hyper[7]};
   for (int si = 0; si < t.nseg; ++si) {
     const AdamSeg sg = t.s[si];
+    if (sg.nsplit < 0) continue;                           // stepped elsewhere
     float* ps = p + sg.off; float* ms = m + sg.off; float* vs = v + sg.off;
     uint16_t* sh = SHADOW ? shadow + sg.off : nullptr;
     if (sg.slab) {
@@ -572,7 +566,8 @@ extern "C" int rg_adam_step_slabs(float* p, const float* g, float* m, float* v, 
                "each starting on a multiple of 4 elements (segment %d)", i);
     RG_REQUIRE(!seg_slab[i] || (seg_nsplit[i] >= 1 && seg_n[i] % 4 == 0 && aligned16(seg_slab[i])), RG_EINVAL,
                "adam_step_slabs: slab segment %d", i);
-    t.s[i] = AdamSeg{seg_off[i], seg_n[i], (const float*)seg_slab[i], seg_slab[i] ? seg_nsplit[i] : 0, 0};
+    // nsplit = -1 without a slab: the segment is SKIPPED (its tensor is stepped by another launch: rg_conv_wgrad_adam)
+    t.s[i] = AdamSeg{seg_off[i], seg_n[i], (const float*)seg_slab[i], seg_slab[i] ? seg_nsplit[i] : (seg_nsplit[i] < 0 ? -1 : 0), 0};
     pos += seg_n[i];
   }
   RG_REQUIRE(pos == n, RG_EINVAL, "adam_step_slabs: the segments cover %llu of %zu elements", pos, n);

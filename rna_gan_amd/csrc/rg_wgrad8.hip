@@ -32,10 +32,14 @@ struct W8Args {
   int tiles_c, tiles_o, nsplit;
   int kt_per_split;      // k-tiles (64 pixels) per split, even
   int accumulate;        // nsplit == 1 only: add to dW
+  // ADAM form (nsplit == 1 only): the tile is not written -- the epilogue applies the optimizer step to the tensor's master,
+  // moments and bf16 operand image, which share dW's tap-major layout [O][16][I] (rg_conv_wgrad_adam)
+  float* ap; float* am; float* av; uint16_t* ash; const float* hyper;
 };
 
 __device__ __forceinline__ int w8_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
+template <bool ADAM>
 __global__ __launch_bounds__(512, 2) void wgrad8_kernel(W8Args g) {
   constexpr int HT = 64 * 256;                     // bytes per half-tile: 64 pixels x 128 channels bf16
   constexpr int STAGE = 4 * HT;                    // [B0][B1][A0][A1]
@@ -293,16 +297,54 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(W8Args g) {
           cs[row * 128 + wn * 32 + fr] = acc[i][ep][s][r];
         }
     __syncthreads();
-#pragma unroll 4
-    for (int p = 0; p < 16; ++p) {
-      const int row = rr + 16 * p;
-      float4* d = reinterpret_cast<float4*>(outp + (long long)(o0 + row) * ldw + c0 + ep * 128 + c4);
-      float4 v = *reinterpret_cast<const float4*>(cs + row * 128 + c4);
-      if (g.accumulate) {
-        const float4 a = *d;
-        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    if constexpr (ADAM) {
+      // the optimizer step of this 256 x 128 piece: 26 bytes per element (p, m, v read and written, the bf16 image written)
+      // instead of the 4 written here + 30 of the streaming Adam.  Four rows per trip with all 12 loads issued first.
+      RgAdamHyper hy;
+      hy.load(g.hyper);
+#pragma unroll 1
+      for (int pq = 0; pq < 4; ++pq) {
+        typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+        f32x4_nt P[4], M[4], V[4];
+        long long off[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int row = rr + 16 * (4 * pq + k);
+          off[k] = (long long)(o0 + row) * ldw + c0 + ep * 128 + c4;
+          P[k] = *reinterpret_cast<const f32x4_nt*>(g.ap + off[k]);
+          M[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(g.am + off[k]));
+          V[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(g.av + off[k]));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int row = rr + 16 * (4 * pq + k);
+          const float4 gv = *reinterpret_cast<const float4*>(cs + row * 128 + c4);
+          float pe[4] = {P[k].x, P[k].y, P[k].z, P[k].w}, me[4] = {M[k].x, M[k].y, M[k].z, M[k].w};
+          float ve[4] = {V[k].x, V[k].y, V[k].z, V[k].w};
+          const float ge[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hy.upd(pe[e], ge[e], me[e], ve[e]);
+          *reinterpret_cast<f32x4_nt*>(g.ap + off[k]) = f32x4_nt{pe[0], pe[1], pe[2], pe[3]};
+          __builtin_nontemporal_store(f32x4_nt{me[0], me[1], me[2], me[3]}, reinterpret_cast<f32x4_nt*>(g.am + off[k]));
+          __builtin_nontemporal_store(f32x4_nt{ve[0], ve[1], ve[2], ve[3]}, reinterpret_cast<f32x4_nt*>(g.av + off[k]));
+          if (g.ash)
+            *reinterpret_cast<uint2*>(g.ash + off[k]) =
+                make_uint2((uint32_t)f32_to_bf16(pe[0]) | ((uint32_t)f32_to_bf16(pe[1]) << 16),
+                           (uint32_t)f32_to_bf16(pe[2]) | ((uint32_t)f32_to_bf16(pe[3]) << 16));
+        }
       }
-      *d = v;
+    } else {
+#pragma unroll 4
+      for (int p = 0; p < 16; ++p) {
+        const int row = rr + 16 * p;
+        float4* d = reinterpret_cast<float4*>(outp + (long long)(o0 + row) * ldw + c0 + ep * 128 + c4);
+        float4 v = *reinterpret_cast<const float4*>(cs + row * 128 + c4);
+        if (g.accumulate) {
+          const float4 a = *d;
+          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        *d = v;
+      }
     }
   }
 }
@@ -653,7 +695,25 @@ int rg_wgrad8_launch(const void* low0, const void* high0, const void* low1, cons
   g.lgWo = rg_ilog2(Wo); g.lgHo = rg_ilog2(Ho); g.Hh = 2 * Ho; g.Wh = 2 * Wo;
   g.tiles_o = O / 256; g.tiles_c = 16 * I / 256; g.nsplit = nsplit; g.kt_per_split = kt_per_split;
   g.accumulate = nsplit == 1 ? accumulate : 0;
-  hipLaunchKernelGGL(wgrad8_kernel, dim3((unsigned)(g.tiles_o * g.tiles_c * nsplit)), dim3(512), 0, st, g);
+  hipLaunchKernelGGL(wgrad8_kernel<false>, dim3((unsigned)(g.tiles_o * g.tiles_c * nsplit)), dim3(512), 0, st, g);
   RG_LAUNCH_CHECK("conv_wgrad(mfma, ping-pong)");
+  return RG_OK;
+}
+
+// One launch = weight gradient + optimizer step of the tensor (a plan without split-K only): see W8Args::ap.
+int rg_wgrad8_adam_launch(const void* low0, const void* high0, const void* low1, const void* high1, int Kseg, int two, int O,
+                          int I, int Ho, int Wo, int kt_per_split, float* p, float* m, float* v, uint16_t* shadow,
+                          const float* hyper, hipStream_t st) {
+  W8Args g{};
+  g.low[0] = (const uint16_t*)low0; g.high[0] = (const uint16_t*)high0;
+  g.low[1] = (const uint16_t*)(two ? low1 : low0); g.high[1] = (const uint16_t*)(two ? high1 : high0);
+  g.low_bytes = (unsigned)((size_t)Kseg * O * 2); g.high_bytes = (unsigned)((size_t)Kseg * 4 * I * 2);
+  g.Kseg[0] = Kseg; g.Kseg[1] = two ? Kseg : 0;
+  g.out = nullptr; g.O = O; g.I = I;
+  g.lgWo = rg_ilog2(Wo); g.lgHo = rg_ilog2(Ho); g.Hh = 2 * Ho; g.Wh = 2 * Wo;
+  g.tiles_o = O / 256; g.tiles_c = 16 * I / 256; g.nsplit = 1; g.kt_per_split = kt_per_split;
+  g.ap = p; g.am = m; g.av = v; g.ash = shadow; g.hyper = hyper;
+  hipLaunchKernelGGL(wgrad8_kernel<true>, dim3((unsigned)(g.tiles_o * g.tiles_c)), dim3(512), 0, st, g);
+  RG_LAUNCH_CHECK("conv_wgrad_adam(mfma, ping-pong)");
   return RG_OK;
 }

@@ -141,6 +141,8 @@ class HipOps:
         # tanh backward / channel sums / squared norm of D's input gradient inside the kernel that writes it
         self.fuse_input_post = os.environ.get("RNAGAN_INPUT_POST", "1") != "0"
         self.pack_from_shadow = os.environ.get("RNAGAN_PACK_FROM_SHADOW", "1") != "0"
+        # a deferred weight gradient without split-K is formed AND stepped by one launch of the optimizer (rg_conv_wgrad_adam)
+        self.wgrad_in_step = os.environ.get("RNAGAN_WGRAD_ADAM", "1") != "0"
         self.epilogue_stats = os.environ.get("RNAGAN_EPILOGUE_STATS", "1") != "0"
         # synchronised (global-batch) statistics in a data-parallel run (dist.attach_sync): an in-place SUM all-reduce
         # for small fp32 tensors and the number of ranks; None = rank-local statistics (plain DDP semantics)
@@ -524,7 +526,7 @@ class HipOps:
         dw is skipped -- rna_gan_amd.optim.Adam sums the slabs inside its step (rg_adam_step_slabs).  True when launched."""
         if not cw.defer_slabs or self.dt != RG_BF16 or self.stat_reduce is not None or self._in_side:
             return False
-        if accumulate or cw.pending_slabs is not None:
+        if accumulate or cw.pending_slabs is not None or cw.pending_wgrad is not None:
             raise RuntimeError("rna_gan_amd: a second weight-gradient contribution for a layer whose first one is still deferred "
                                "split-K slabs (defer_slabs expects ONE weight-gradient launch per layer and pass)")
         N, Ho, Wo, O = low0.shape
@@ -532,6 +534,13 @@ class HipOps:
         dw = cw.dw
         if cw.w.data_ptr() % 16 or dw.data_ptr() % 16:
             return False
+        if (self.wgrad_in_step and cw.shadow is not None and
+                self.lib.rg_conv_wgrad_adam_supported(N, Ho, Wo, O, I, int(low1 is not None), self.dt, self.algo)):
+            # a plan WITHOUT split-K (the two 33.5 M-parameter layers at batch 64): nothing is launched here -- the operands
+            # stay on the handle and the optimizer forms the gradient tile and applies its step to it in one launch
+            # (rg_conv_wgrad_adam: the 4 bytes per parameter written here and read back by the streaming Adam disappear)
+            cw.pending_wgrad = ("conv", low0, high0, low1, high1, (N, Ho, Wo, O, I), self.dt, self.algo, flops)
+            return True
         nb = int(self.lib.rg_conv_wgrad_workspace_bytes(N, Ho, Wo, O, I, self.dt, self.algo))
         if nb <= 0:
             return False                           # no split-K plan for this shape (or no matrix-core kernel): nothing to defer

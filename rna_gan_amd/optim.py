@@ -194,6 +194,27 @@ class Adam(torch.optim.Adam):
             if ps is not None:
                 cw.pending_slabs = None
                 slab_segs.append(((cw.w.data_ptr() - flat.data.data_ptr()) // 4, cw.w.numel(), ps[0], ps[1]))
+            pw = getattr(cw, "pending_wgrad", None)
+            if isinstance(pw, tuple) and isinstance(pw[0], str) and pw[0] == "conv":
+                # a layer whose weight-gradient plan has no split-K (ops_hip._wgrad_slabs left the operands): gradient tile and
+                # Adam step in ONE launch; the streaming launch below skips the tensor (segment with nsplit = -1)
+                cw.pending_wgrad = None
+                _, low0, high0, low1, high1, (N_, Ho_, Wo_, O_, I_), dt, algo, flops = pw
+                off = (cw.w.data_ptr() - flat.data.data_ptr()) // 4
+                if shadow is None or off % 4 or off < lo:
+                    raise RuntimeError("rna_gan_amd.optim.Adam: a deferred single-launch weight gradient expects a bf16 step and "
+                                       "a 16-byte aligned tensor inside the flat buffer")
+                ops = getattr(self._module, "_rt_ops", None)
+                call = lambda: check(lib.rg_conv_wgrad_adam(
+                    low0.data_ptr(), high0.data_ptr(), 0 if low1 is None else low1.data_ptr(),
+                    0 if high1 is None else high1.data_ptr(), flat.data.data_ptr() + 4 * off, self._m.data_ptr() + 4 * off,
+                    self._v.data_ptr() + 4 * off, self._hyper.data_ptr(), shadow.data_ptr() + 2 * off, N_, Ho_, Wo_, O_, I_, dt,
+                    algo, stream), "rg_conv_wgrad_adam")
+                if ops is not None and hasattr(ops, "_timed"):
+                    ops._timed("conv_wgrad", flops, call, cw=cw)       # bench.py's per-family timing sees the launch
+                else:
+                    call()
+                slab_segs.append((off, cw.w.numel(), None, -1))
         if slab_segs:
             if segs or self.grad_wire is not None:
                 raise RuntimeError("rna_gan_amd.optim.Adam: deferred split-K slabs expect a single-process step without fused "
@@ -208,7 +229,7 @@ class Adam(torch.optim.Adam):
                                        "the part of the flat buffer this launch steps")
                 if off > pos:
                     table.append((pos - lo, off - pos, 0, 0))
-                table.append((off - lo, n, buf.data_ptr(), ns))
+                table.append((off - lo, n, 0 if buf is None else buf.data_ptr(), ns))
                 pos = off + n
             if total > pos:
                 table.append((pos - lo, total - pos, 0, 0))

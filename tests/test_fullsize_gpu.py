@@ -616,3 +616,76 @@ def test_split_k_weight_gradient_slabs_inside_the_adam_step(I, O, hs, two):
     zero = (C.c_int * 1)(0)
     assert lib.rg_adam_step_slabs(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), total, hyper.data_ptr(), 0, 1,
                                   C.addressof(bad_off), C.addressof(one_len), C.addressof(nul), C.addressof(zero), ops.stream) != 0
+
+
+@pytest.mark.parametrize("two", [False, True])
+def test_weight_gradient_and_adam_step_in_one_launch(two):
+    """Round 5 (b2): the two 33.5 M-parameter layers (D.5, G.1: 1024 <-> 2048 channels at 4 x 4 / 8 x 8) have a weight-gradient
+    plan without split-K; rg_conv_wgrad_adam applies the optimizer step to the gradient tile where it sits instead of writing
+    it.  Against rg_conv_wgrad[2] + rg_adam_step_dev on the same buffers: the same products in the same order and the one Adam
+    expression (rg_common.h) -- bit for bit on p, m, v and the bf16 image; the plain segments around the tensor are stepped by
+    rg_adam_step_slabs with the tensor's segment skipped (nsplit = -1)."""
+    import ctypes as C
+    I, O, hs = 1024, 2048, 4
+    dev = torch.device("cuda:0")
+    ops = HipOps(torch.bfloat16, dev)
+    lib = _abi.load()
+    assert lib.rg_conv_wgrad_adam_supported(N, hs, hs, O, I, int(two), ops.dt, ops.algo) == 1
+    assert lib.rg_conv_wgrad_adam_supported(N, 64, 64, 128, 64, 1, ops.dt, ops.algo) == 0          # a split-K plan
+    gen = torch.Generator(device="cpu").manual_seed(47)
+    low0 = torch.randn(N, hs, hs, O, generator=gen).bfloat16().to(dev)
+    high0 = torch.randn(N, 2 * hs, 2 * hs, I, generator=gen).bfloat16().to(dev)
+    low1 = torch.randn(N, hs, hs, O, generator=gen).bfloat16().to(dev) if two else None
+    high1 = torch.randn(N, 2 * hs, 2 * hs, I, generator=gen).bfloat16().to(dev) if two else None
+    nw = O * 16 * I
+    head, tail = 4096, 1000
+    total = head + nw + tail
+    pad = (-total) % 4
+    p0 = torch.randn(total + pad, generator=gen).to(dev) * 0.05
+    g0 = torch.randn(total + pad, generator=gen).to(dev) * 0.01
+    m0 = torch.randn(total + pad, generator=gen).to(dev) * 0.01
+    v0 = (torch.rand(total + pad, generator=gen).to(dev) * 1e-4)
+    hyper = torch.zeros(8, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    _abi.check(lib.rg_adam_hyper_dev(step.data_ptr(), 4e-4, 0.5, 0.999, 1e-8, 0.0, hyper.data_ptr(), ops.stream), "hyper")
+    wsb = int(lib.rg_conv_wgrad_workspace_bytes(N, hs, hs, O, I, ops.dt, ops.algo))
+    ws = torch.empty(max(wsb, 256) + 4096, dtype=torch.uint8, device=dev)
+    ptr = lambda t: 0 if t is None else t.data_ptr()
+
+    pr, gr, mr, vr = p0.clone(), g0.clone(), m0.clone(), v0.clone()
+    shr = torch.zeros(total + pad, dtype=torch.bfloat16, device=dev)
+    dw = gr[head:head + nw]
+    if two:
+        _abi.check(lib.rg_conv_wgrad2(ptr(low0), ptr(high0), ptr(low1), ptr(high1), dw.data_ptr(), N, hs, hs, O, I, ops.dt, 0,
+                                      ops.algo, ws.data_ptr(), ws.numel(), ops.stream), "rg_conv_wgrad2")
+    else:
+        _abi.check(lib.rg_conv_wgrad(ptr(low0), ptr(high0), dw.data_ptr(), N, hs, hs, O, I, ops.dt, 0, ops.algo, ws.data_ptr(),
+                                     ws.numel(), ops.stream), "rg_conv_wgrad")
+    _abi.check(lib.rg_adam_step_dev(pr.data_ptr(), gr.data_ptr(), mr.data_ptr(), vr.data_ptr(), total, hyper.data_ptr(),
+                                    shr.data_ptr(), 0, ops.stream), "rg_adam_step_dev")
+
+    pd, gd, md, vd = p0.clone(), g0.clone(), m0.clone(), v0.clone()
+    gd[head:head + nw].fill_(float("nan"))                   # never written, never read
+    shd = torch.zeros(total + pad, dtype=torch.bfloat16, device=dev)
+    _abi.check(lib.rg_conv_wgrad_adam(ptr(low0), ptr(high0), ptr(low1), ptr(high1), pd[head:].data_ptr(), md[head:].data_ptr(),
+                                      vd[head:].data_ptr(), hyper.data_ptr(), shd[head:].data_ptr(), N, hs, hs, O, I, ops.dt,
+                                      ops.algo, ops.stream), "rg_conv_wgrad_adam")
+    table = [(0, head, 0, 0), (head, nw, 0, -1), (head + nw, tail, 0, 0)]
+    k = len(table)
+    offs = (C.c_ulonglong * k)(*[t[0] for t in table])
+    lens = (C.c_ulonglong * k)(*[t[1] for t in table])
+    slabs = (C.c_void_p * k)(*[None for t in table])
+    nsp = (C.c_int * k)(*[t[3] for t in table])
+    _abi.check(lib.rg_adam_step_slabs(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), total, hyper.data_ptr(),
+                                      shd.data_ptr(), k, C.addressof(offs), C.addressof(lens), C.addressof(slabs),
+                                      C.addressof(nsp), ops.stream), "rg_adam_step_slabs")
+    torch.cuda.synchronize()
+    assert not torch.equal(pr[head:head + nw], p0[head:head + nw])
+    for name, a, b in (("p", pr, pd), ("m", mr, md), ("v", vr, vd)):
+        assert torch.equal(a[:total], b[:total]), (name, float((a[:total] - b[:total]).abs().max()))
+    assert torch.equal(shr[:total], shd[:total])
+    # refused: a shape whose plan splits K, unaligned moments
+    assert lib.rg_conv_wgrad_adam(ptr(low0), ptr(high0), 0, 0, pd[head:].data_ptr(), md[head:].data_ptr(), vd[head:].data_ptr(),
+                                  hyper.data_ptr(), 0, N, hs, hs, O, 64, ops.dt, ops.algo, ops.stream) != 0
+    assert lib.rg_conv_wgrad_adam(ptr(low0), ptr(high0), ptr(low1), ptr(high1), pd[head:].data_ptr(), md[head + 1:].data_ptr(),
+                                  vd[head:].data_ptr(), hyper.data_ptr(), 0, N, hs, hs, O, I, ops.dt, ops.algo, ops.stream) != 0
