@@ -126,11 +126,13 @@ int rg_conv_wgrad2(const void* low0, const void* high0, const void* low1, const 
 /* rg_conv_wgrad (low1 = high1 = NULL) / rg_conv_wgrad2 with the split-K reduction LEFT TO THE CALLER'S OPTIMIZER STEP
  * (.backward() directly followed by optimizer.step(), src/wgan_loss.py:126-127, :260-261, :387-388): a plan with
  * *nsplit_out > 1 leaves its fp32 partial slabs [nsplit][O][16][I] in `slab` (>= rg_conv_wgrad_workspace_bytes, caller-owned,
- * must stay untouched until rg_adam_step_slabs has consumed it) and does not write dw; *nsplit_out == 1: dw was written
+ * must stay untouched until rg_adam_step_slabs has consumed it; *slab_dtype_out says whether the partial tiles are fp32 or
+ * bf16 -- option wslab16, default bf16: each partial sum rounded once, added in fp32) and does not write dw; *nsplit_out == 1: dw was written
  * (not accumulated) and nothing is pending -- also the outcome for every shape / dtype the matrix-core kernel does not take
  * (the generic kernel runs with `slab` as its workspace). */
 int rg_conv_wgrad_slabs(const void* low0, const void* high0, const void* low1, const void* high1, float* dw, int N, int Ho,
-                        int Wo, int O, int I, int dtype, int algo, void* slab, size_t slab_bytes, int* nsplit_out, void* stream);
+                        int Wo, int O, int I, int dtype, int algo, void* slab, size_t slab_bytes, int* nsplit_out,
+                        int* slab_dtype_out, void* stream);
 /* The same pair of calls (weight gradient, then optimizer.step()) as ONE launch for a layer whose plan has no split-K: the
  * gradient tile is never written -- the kernel's epilogue applies the Adam update (the arithmetic of rg_adam_step_dev, bit for
  * bit) to the tensor's fp32 master p, moments m, v and optional bf16 operand image, all tap-major [O][16][I] like dw.
@@ -465,13 +467,14 @@ int rg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, con
                      const void* grad_bf16, void* stream);
 /* rg_adam_step_dev over [p, p + n) cut into nseg <= 24 consecutive segments (seg_off / seg_n in elements, tiling the range in
  * order, every offset a multiple of 4): a segment with seg_slab[i] != NULL takes its gradient as the sum, in slab order, of
- * seg_nsplit[i] fp32 slabs of seg_n[i] elements (what rg_conv_wgrad_slabs left in the caller's buffer) instead of reading g --
+ * seg_nsplit[i] slabs of seg_n[i] elements, fp32 or bf16 by seg_dtype[i] (what rg_conv_wgrad_slabs left in the caller's buffer
+ * and reported) instead of reading g --
  * the split-K reduction launches of the backward pass and the write + re-read of the reduced gradient disappear (one launch
  * for the whole buffer; deterministic summation order).  A segment with seg_slab[i] == NULL and seg_nsplit[i] == -1 is SKIPPED
  * (its tensor is stepped by rg_conv_wgrad_adam).  Segment tables are HOST arrays. */
 int rg_adam_step_slabs(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, void* shadow_bf16, int nseg,
                        const unsigned long long* seg_off, const unsigned long long* seg_n, const void* const* seg_slab,
-                       const int* seg_nsplit, void* stream);
+                       const int* seg_nsplit, const int* seg_dtype, void* stream);
 /* ++(*step_dev) and recompute hyper[0..6] from it on the device (double arithmetic, one thread): with
  * this launch in front of rg_adam_step_dev the whole optimizer step replays from a graph untouched.
  * hyper[7] = weight_decay (torch.optim.Adam's L2 term g += wd * p; 0 on the GAN path, betaVAE training sets it,

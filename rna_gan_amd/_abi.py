@@ -32,7 +32,7 @@ PROTOTYPES = {
     "rg_conv_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),
     "rg_conv_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_conv_wgrad2": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
-    "rg_conv_wgrad_slabs": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p, _p]),
+    "rg_conv_wgrad_slabs": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p, _p, _p]),
     "rg_conv_wgrad_adam_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "rg_conv_wgrad_adam": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "rg_first_down": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
@@ -108,7 +108,7 @@ PROTOTYPES = {
     "rg_latent_stats": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "rg_latent_apply": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "rg_adam_step_dev": (_i, [_p, _p, _p, _p, _z, _p, _p, _p, _p]),
-    "rg_adam_step_slabs": (_i, [_p, _p, _p, _p, _z, _p, _p, _i, _p, _p, _p, _p, _p]),
+    "rg_adam_step_slabs": (_i, [_p, _p, _p, _p, _z, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
     "rg_interp_dev": (_i, [_p, _p, _p, _z, _p, _p]),
     "rg_adam_hyper_dev": (_i, [_p, _d, _d, _d, _d, _d, _p, _p]),
     "rg_transpose_f32": (_i, [_p, _p, _i, _i, _p]),
@@ -158,7 +158,7 @@ PROTOTYPES = {
 }
 
 # must equal rg_version() of the library (rna_gan_amd/csrc/rg_api.hip): bumped together with PROTOTYPES
-ABI_VERSION = 501
+ABI_VERSION = 502
 
 _lib = None
 

@@ -18,13 +18,13 @@ void rg_set_error(const char* fmt, ...) {
 }
 
 // bumped whenever an entry point is added or a signature changes; rna_gan_amd/_abi.py (ABI_VERSION) refuses any other value
-extern "C" int rg_version(void) { return 501; }   // 5.01: round 5 (rg_conv_wgrad_slabs, rg_adam_step_slabs, rg_conv_wgrad_adam)
+extern "C" int rg_version(void) { return 502; }   // 5.02: round 5 (rg_conv_wgrad_slabs, rg_adam_step_slabs, rg_conv_wgrad_adam; slab dtypes)
 extern "C" const char* rg_last_error(void) { return g_err; }
 
 // ---- kernel-selection knobs: override table in front of the RNAGAN_* environment variables
 static const char* const g_opt_names[] = {"conv8", "conv8_blocks", "conv_tile", "xcd", "class_fast", "wgrad_blocks",
                                           "wgrad8", "conv_v1", "stream_tile", "narrow8", "conv8_mfma", "conv8_epi", "wgrad8_blocks", "korder", "convp", "convp_blocks",
-                                          "fp8_mx", "wgrad8n", "f32mma", "convd", "convd_blocks", "skinny128", "slab16"};
+                                          "fp8_mx", "wgrad8n", "f32mma", "convd", "convd_blocks", "skinny128", "slab16", "wslab16"};
 constexpr int G_NOPT = sizeof(g_opt_names) / sizeof(g_opt_names[0]);
 static int g_opt_override[G_NOPT];      // value + 1; 0 = not set
 static int g_opt_env[G_NOPT];           // cached environment value + 1; 0 = not read yet; -1 = variable absent
@@ -192,9 +192,10 @@ extern "C" int rg_conv_wgrad2(const void* low0, const void* high0, const void* l
 // touch dw; *nsplit_out says how many (1: dw was written, nothing is pending).  The consumer is rg_adam_step_slabs.
 extern "C" int rg_conv_wgrad_slabs(const void* low0, const void* high0, const void* low1, const void* high1, float* dw, int N,
                                    int Ho, int Wo, int O, int I, int dtype, int algo, void* slab, size_t slab_bytes,
-                                   int* nsplit_out, void* stream) {
-  RG_REQUIRE(low0 && high0 && dw && nsplit_out && (low1 == nullptr) == (high1 == nullptr) && N > 0 && Ho > 0 && Wo > 0 && I > 0 &&
-                 O > 0, RG_EINVAL, "conv_wgrad_slabs: bad args");
+                                   int* nsplit_out, int* slab_dtype_out, void* stream) {
+  RG_REQUIRE(low0 && high0 && dw && nsplit_out && slab_dtype_out && (low1 == nullptr) == (high1 == nullptr) && N > 0 && Ho > 0 &&
+                 Wo > 0 && I > 0 && O > 0, RG_EINVAL, "conv_wgrad_slabs: bad args");
+  *slab_dtype_out = RG_F32;
   if (!(want_mfma(algo, dtype) && rg_mfma_wgrad_supported(N, Ho, Wo, O, I))) {
     // a shape the matrix-core kernel does not take (small models): the generic kernel reduces its own split-K through `slab`
     // as a workspace and WRITES dw -- nothing pending, *nsplit_out = 1
@@ -204,7 +205,8 @@ extern "C" int rg_conv_wgrad_slabs(const void* low0, const void* high0, const vo
     if (rc || !low1) return rc;
     return rg_generic_conv_wgrad(low1, high1, dw, N, Ho, Wo, O, I, dtype, 1, slab, slab_bytes, rg_stream(stream));
   }
-  return rg_mfma_conv_wgrad2(low0, high0, low1, high1, dw, N, Ho, Wo, O, I, 0, slab, slab_bytes, rg_stream(stream), nsplit_out);
+  return rg_mfma_conv_wgrad2(low0, high0, low1, high1, dw, N, Ho, Wo, O, I, 0, slab, slab_bytes, rg_stream(stream), nsplit_out,
+                             slab_dtype_out);
 }
 
 // Weight gradient of a 4 x 4 stride-2 layer AND the Adam step of that tensor in one launch (low1 / high1 may be NULL): p, m, v

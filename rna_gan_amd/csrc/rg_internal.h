@@ -50,6 +50,7 @@ int rg_mfma_conv_nsplit(int up, int N, int Hlow, int Wlow, int O, int I);
 // split-K partial tiles of the 8-wave conv kernel as bf16 instead of fp32 (option `slab16`): half the slab bytes written by the
 // conv launch and read by the fused reduction + BatchNorm kernel; the partial sums are rounded to bf16 before they are added
 constexpr int RG_SLAB16_DEFAULT = 1;
+constexpr int RG_WSLAB16_DEFAULT = 1;    // deferred split-K weight-gradient slabs (rg_conv_wgrad_slabs) as bf16: option wslab16
 int rg_mfma_conv_slab16(int up, int N, int Hlow, int Wlow, int O, int I);
 int rg_mfma_conv_stats_rows(int up, int N, int Hlow, int Wlow, int O, int I);
 int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int Wo, int O, int I, const void* mask,
@@ -101,7 +102,7 @@ int rg_mfma_conv_wgrad(const void* low, const void* high, float* dw, int N, int 
 
 int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, const void* high1, float* dw, int N,
                         int Ho, int Wo, int O, int I, int accumulate, void* ws, size_t ws_bytes, hipStream_t st,
-                        int* nsplit_out = nullptr);
+                        int* nsplit_out = nullptr, int* slab_dtype_out = nullptr);
 size_t rg_mfma_wgrad2_ws_bytes(int N, int Ho, int Wo, int O, int I);
 
 bool rg_mfma_fp8_supported(int M, int K, int Ncols, int taps);
@@ -128,9 +129,11 @@ int rg_wgrad8_split(int K, int O, int I, int* kt_per_split);
 bool rg_wgrad8n_supported(int K, int O, int I);
 int rg_wgrad8n_split(int K, int O, int I, int* kt_per_split);
 int rg_wgrad8n_launch(const void* low0, const void* high0, const void* low1, const void* high1, float* out, int Kseg,
-                      int two, int O, int I, int Ho, int Wo, int nsplit, int kt_per_split, int accumulate, hipStream_t st);
+                      int two, int O, int I, int Ho, int Wo, int nsplit, int kt_per_split, int accumulate, hipStream_t st,
+                      int slab16 = 0);
 int rg_wgrad8_launch(const void* low0, const void* high0, const void* low1, const void* high1, float* out, int Kseg,
-                     int two, int O, int I, int Ho, int Wo, int nsplit, int kt_per_split, int accumulate, hipStream_t st);
+                     int two, int O, int I, int Ho, int Wo, int nsplit, int kt_per_split, int accumulate, hipStream_t st,
+                     int slab16 = 0);
 int rg_wgrad8_adam_launch(const void* low0, const void* high0, const void* low1, const void* high1, int Kseg, int two, int O,
                           int I, int Ho, int Wo, int kt_per_split, float* p, float* m, float* v, uint16_t* shadow,
                           const float* hyper, hipStream_t st);

@@ -1623,8 +1623,12 @@ static int mfma_wgrad_split_k(int K, int O, int I) {
 // without a split writes dw as usual and reports 1.
 int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, const void* high1, float* dw, int N,
                         int Ho, int Wo, int O, int I, int accumulate, void* ws, size_t ws_bytes, hipStream_t st,
-                        int* nsplit_out) {
+                        int* nsplit_out, int* slab_dtype_out) {
   if (nsplit_out) *nsplit_out = 1;
+  if (slab_dtype_out) *slab_dtype_out = RG_F32;
+  // slabs LEFT to the caller may be bf16 (the two ping-pong kernels; option wslab16): each partial sum rounded once, added in
+  // fp32 by rg_adam_step_slabs -- half the bytes written here and read there
+  const int s16 = (nsplit_out && slab_dtype_out && rg_option("wslab16", RG_WSLAB16_DEFAULT)) ? 1 : 0;
   const int Kseg = N * Ho * Wo;
   const bool two = low1 != nullptr;
   size_t lowb = (size_t)Kseg * O * 2, highb = (size_t)Kseg * 4 * I * 2;
@@ -1644,9 +1648,9 @@ int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, c
     const bool old_direct = mfma_wgrad_split_k(K, O, I) == 1 && ns > 1 && !two && K < 8192 && rg_option("wgrad8", 1) == 1;
     if (!old_direct && (ns == 1 || (ws && ws_bytes >= (size_t)ns * elems * sizeof(float)))) {
       int rc = rg_wgrad8_launch(low0, high0, low1, high1, ns == 1 ? dw : (float*)ws, Kseg, two ? 1 : 0, O, I, Ho, Wo, ns,
-                                per, accumulate, st);
+                                per, accumulate, st, s16);
       if (rc || ns == 1) return rc;
-      if (nsplit_out) { *nsplit_out = ns; return RG_OK; }
+      if (nsplit_out) { *nsplit_out = ns; if (s16) *slab_dtype_out = RG_BF16; return RG_OK; }
       return rg_reduce_slabs((const float*)ws, dw, elems, ns, accumulate, 0, 0, st);
     }
   }
@@ -1656,9 +1660,9 @@ int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, c
     const int ns = rg_wgrad8n_split(K, O, I, &per);
     if (ns == 1 || (ws && ws_bytes >= (size_t)ns * elems * sizeof(float))) {
       int rc = rg_wgrad8n_launch(low0, high0, low1, high1, ns == 1 ? dw : (float*)ws, Kseg, two ? 1 : 0, O, I, Ho, Wo, ns,
-                                 per, accumulate, st);
+                                 per, accumulate, st, s16);
       if (rc || ns == 1) return rc;
-      if (nsplit_out) { *nsplit_out = ns; return RG_OK; }
+      if (nsplit_out) { *nsplit_out = ns; if (s16) *slab_dtype_out = RG_BF16; return RG_OK; }
       return rg_reduce_slabs((const float*)ws, dw, elems, ns, accumulate, 0, 0, st);
     }
   }

@@ -134,10 +134,22 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
 // nsplit: lane l sums slabs l, l + SL, ... with 8 loads in flight, the SL partial sums are combined through LDS in lane order:
 // a fixed summation order, deterministic); the group's first thread applies Adam.
 constexpr int ADAM_MAX_SEGS = 24;
-struct AdamSeg { unsigned long long off, n; const float* slab; int nsplit; int pad; };
+struct AdamSeg { unsigned long long off, n; const float* slab; int nsplit; int s16; };      // s16: the slabs are bf16
 struct AdamSegs { int nseg; int pad; AdamSeg s[ADAM_MAX_SEGS]; };
 
-template <bool SHADOW, int SL>
+// one 4-element column piece of slab z: fp32 (16 bytes) or bf16 (8 bytes, widened)
+template <bool S16>
+__device__ __forceinline__ float4 adam_slab_ld(const float* __restrict__ slab, size_t z, size_t n, size_t q) {
+  if (S16) {
+    typedef unsigned nt_u2 __attribute__((ext_vector_type(2)));
+    const nt_u2 w = __builtin_nontemporal_load(reinterpret_cast<const nt_u2*>(reinterpret_cast<const uint16_t*>(slab) + z * n + q * 4));
+    return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                       __uint_as_float(w.y & 0xffff0000u));
+  }
+  return nt_ld4(slab + z * n + q * 4);
+}
+
+template <bool SHADOW, int SL, bool S16>
 __device__ __forceinline__ void adam_slab_segment(const Adam& a, float* __restrict__ p, float* __restrict__ m,
                                                   float* __restrict__ v, uint16_t* __restrict__ shadow,
                                                   const float* __restrict__ slab, int nsplit, size_t n, float4 (*sm)[64]) {
@@ -154,12 +166,12 @@ __device__ __forceinline__ void adam_slab_segment(const Adam& a, float* __restri
       for (; z + 7 * SL < nsplit; z += 8 * SL) {           // 8 independent loads, added in slab order
         float4 t[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = nt_ld4(slab + (size_t)(z + k * SL) * n + q * 4);
+        for (int k = 0; k < 8; ++k) t[k] = adam_slab_ld<S16>(slab, (size_t)(z + k * SL), n, q);
 #pragma unroll
         for (int k = 0; k < 8; ++k) { s.x += t[k].x; s.y += t[k].y; s.z += t[k].z; s.w += t[k].w; }
       }
       for (; z < nsplit; z += SL) {
-        const float4 t = nt_ld4(slab + (size_t)z * n + q * 4);
+        const float4 t = adam_slab_ld<S16>(slab, (size_t)z, n, q);
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
       }
     }
@@ -197,9 +209,15 @@ __global__ __launch_bounds__(256) void adam_segs_kernel(float* __restrict__ p, c
     float* ps = p + sg.off; float* ms = m + sg.off; float* vs = v + sg.off;
     uint16_t* sh = SHADOW ? shadow + sg.off : nullptr;
     if (sg.slab) {
-      if (sg.nsplit <= 4) adam_slab_segment<SHADOW, 1>(a, ps, ms, vs, sh, sg.slab, sg.nsplit, sg.n, sm);
-      else if (sg.nsplit <= 32) adam_slab_segment<SHADOW, 4>(a, ps, ms, vs, sh, sg.slab, sg.nsplit, sg.n, sm);
-      else adam_slab_segment<SHADOW, 16>(a, ps, ms, vs, sh, sg.slab, sg.nsplit, sg.n, reinterpret_cast<float4(*)[64]>(sm));
+      if (sg.s16) {
+        if (sg.nsplit <= 4) adam_slab_segment<SHADOW, 1, true>(a, ps, ms, vs, sh, sg.slab, sg.nsplit, sg.n, sm);
+        else if (sg.nsplit <= 32) adam_slab_segment<SHADOW, 4, true>(a, ps, ms, vs, sh, sg.slab, sg.nsplit, sg.n, sm);
+        else adam_slab_segment<SHADOW, 16, true>(a, ps, ms, vs, sh, sg.slab, sg.nsplit, sg.n, reinterpret_cast<float4(*)[64]>(sm));
+      } else {
+        if (sg.nsplit <= 4) adam_slab_segment<SHADOW, 1, false>(a, ps, ms, vs, sh, sg.slab, sg.nsplit, sg.n, sm);
+        else if (sg.nsplit <= 32) adam_slab_segment<SHADOW, 4, false>(a, ps, ms, vs, sh, sg.slab, sg.nsplit, sg.n, sm);
+        else adam_slab_segment<SHADOW, 16, false>(a, ps, ms, vs, sh, sg.slab, sg.nsplit, sg.n, reinterpret_cast<float4(*)[64]>(sm));
+      }
       continue;
     }
     const float* gs = g + sg.off;
@@ -553,8 +571,9 @@ extern "C" int rg_adam_step_dev(float* p, const float* g, float* m, float* v, si
 extern "C" int rg_adam_step_slabs(float* p, const float* g, float* m, float* v, size_t n, const float* hyper,
                                   void* shadow_bf16, int nseg, const unsigned long long* seg_off,
                                   const unsigned long long* seg_n, const void* const* seg_slab, const int* seg_nsplit,
-                                  void* stream) {
-  RG_REQUIRE(p && g && m && v && hyper && seg_off && seg_n && seg_slab && seg_nsplit, RG_EINVAL, "adam_step_slabs: bad args");
+                                  const int* seg_dtype, void* stream) {
+  RG_REQUIRE(p && g && m && v && hyper && seg_off && seg_n && seg_slab && seg_nsplit && seg_dtype, RG_EINVAL,
+             "adam_step_slabs: bad args");
   RG_REQUIRE(nseg >= 1 && nseg <= ADAM_MAX_SEGS, RG_EINVAL, "adam_step_slabs: 1 .. %d segments", ADAM_MAX_SEGS);
   RG_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && ((uintptr_t)shadow_bf16 & 7) == 0, RG_EINVAL,
              "adam_step_slabs: alignment");
@@ -564,10 +583,12 @@ extern "C" int rg_adam_step_slabs(float* p, const float* g, float* m, float* v, 
   for (int i = 0; i < nseg; ++i) {
     RG_REQUIRE(seg_off[i] == pos && seg_off[i] % 4 == 0, RG_EINVAL, "adam_step_slabs: segments must tile the range in order, "
                "each starting on a multiple of 4 elements (segment %d)", i);
-    RG_REQUIRE(!seg_slab[i] || (seg_nsplit[i] >= 1 && seg_n[i] % 4 == 0 && aligned16(seg_slab[i])), RG_EINVAL,
+    RG_REQUIRE(!seg_slab[i] || (seg_nsplit[i] >= 1 && seg_n[i] % 4 == 0 && aligned16(seg_slab[i]) &&
+                                (seg_dtype[i] == RG_F32 || seg_dtype[i] == RG_BF16)), RG_EINVAL,
                "adam_step_slabs: slab segment %d", i);
     // nsplit = -1 without a slab: the segment is SKIPPED (its tensor is stepped by another launch: rg_conv_wgrad_adam)
-    t.s[i] = AdamSeg{seg_off[i], seg_n[i], (const float*)seg_slab[i], seg_slab[i] ? seg_nsplit[i] : (seg_nsplit[i] < 0 ? -1 : 0), 0};
+    t.s[i] = AdamSeg{seg_off[i], seg_n[i], (const float*)seg_slab[i], seg_slab[i] ? seg_nsplit[i] : (seg_nsplit[i] < 0 ? -1 : 0),
+                     seg_slab[i] && seg_dtype[i] == RG_BF16 ? 1 : 0};
     pos += seg_n[i];
   }
   RG_REQUIRE(pos == n, RG_EINVAL, "adam_step_slabs: the segments cover %llu of %zu elements", pos, n);

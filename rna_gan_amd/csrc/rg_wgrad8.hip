@@ -35,7 +35,27 @@ struct W8Args {
   // ADAM form (nsplit == 1 only): the tile is not written -- the epilogue applies the optimizer step to the tensor's master,
   // moments and bf16 operand image, which share dW's tap-major layout [O][16][I] (rg_conv_wgrad_adam)
   float* ap; float* am; float* av; uint16_t* ash; const float* hyper;
+  int slab16;            // nsplit > 1 only: the partial tiles are stored as bf16 [nsplit][O][16*I] (each partial sum rounded once;
+                         // the consumer -- rg_adam_step_slabs -- adds them in fp32): half the slab bytes written and re-read
 };
+
+// the epilogue's store loop for bf16 slabs: `rows` rows of the 128-column fp32 LDS image go to `tile` (this slab's element
+// [o0][first column of the piece]), 16 threads x 8 columns per row and 32 rows per pass: 16-byte stores, 256 contiguous bytes per row
+__device__ __forceinline__ void w8_store_slab16(const float* cs, uint16_t* tile, long long ldw, int rows, int t) {
+  const int c8 = (t & 15) * 8, r32 = t >> 4;
+#pragma unroll 4
+  for (int p = 0; p < rows / 32; ++p) {
+    const int row = r32 + 32 * p;
+    const float4 a = *reinterpret_cast<const float4*>(cs + row * 128 + c8);
+    const float4 b = *reinterpret_cast<const float4*>(cs + row * 128 + c8 + 4);
+    uint4 o;
+    o.x = (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16);
+    o.y = (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16);
+    o.z = (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16);
+    o.w = (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16);
+    *reinterpret_cast<uint4*>(tile + (long long)row * ldw + c8) = o;
+  }
+}
 
 __device__ __forceinline__ int w8_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
@@ -333,6 +353,8 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(W8Args g) {
                            (uint32_t)f32_to_bf16(pe[2]) | ((uint32_t)f32_to_bf16(pe[3]) << 16));
         }
       }
+    } else if (g.slab16) {
+      w8_store_slab16(cs, reinterpret_cast<uint16_t*>(g.out) + ((long long)zs * g.O + o0) * ldw + c0 + ep * 128, ldw, 256, t);
     } else {
 #pragma unroll 4
       for (int p = 0; p < 16; ++p) {
@@ -613,6 +635,10 @@ __global__ __launch_bounds__(512, 2) void wgrad8n_kernel(W8Args g) {
         cs[row * 128 + wn * 32 + fr] = acc[ep][s][r];
       }
     __syncthreads();
+    if (g.slab16) {
+      w8_store_slab16(cs, reinterpret_cast<uint16_t*>(g.out) + ((long long)zs * g.O + o0) * ldw + c0 + ep * 128, ldw, 128, t);
+      continue;
+    }
 #pragma unroll 4
     for (int p = 0; p < 8; ++p) {
       const int row = rr + 16 * p;
@@ -668,7 +694,8 @@ int rg_wgrad8n_split(int K, int O, int I, int* kt_per_split) {
   return ns;
 }
 int rg_wgrad8n_launch(const void* low0, const void* high0, const void* low1, const void* high1, float* out, int Kseg,
-                      int two, int O, int I, int Ho, int Wo, int nsplit, int kt_per_split, int accumulate, hipStream_t st) {
+                      int two, int O, int I, int Ho, int Wo, int nsplit, int kt_per_split, int accumulate, hipStream_t st,
+                      int slab16) {
   W8Args g{};
   g.low[0] = (const uint16_t*)low0; g.high[0] = (const uint16_t*)high0;
   g.low[1] = (const uint16_t*)(two ? low1 : low0); g.high[1] = (const uint16_t*)(two ? high1 : high0);
@@ -678,6 +705,7 @@ int rg_wgrad8n_launch(const void* low0, const void* high0, const void* low1, con
   g.lgWo = rg_ilog2(Wo); g.lgHo = rg_ilog2(Ho); g.Hh = 2 * Ho; g.Wh = 2 * Wo;
   g.tiles_o = O / 128; g.tiles_c = 16 * I / 512; g.nsplit = nsplit; g.kt_per_split = kt_per_split;
   g.accumulate = nsplit == 1 ? accumulate : 0;
+  g.slab16 = nsplit > 1 ? slab16 : 0;
   hipLaunchKernelGGL(wgrad8n_kernel, dim3((unsigned)(g.tiles_o * g.tiles_c * nsplit)), dim3(512), 0, st, g);
   RG_LAUNCH_CHECK("conv_wgrad(mfma, ping-pong, 128 x 512)");
   return RG_OK;
@@ -685,7 +713,7 @@ int rg_wgrad8n_launch(const void* low0, const void* high0, const void* low1, con
 
 int rg_wgrad8_launch(const void* low0, const void* high0, const void* low1, const void* high1, float* out, int Kseg,
                      int two, int O, int I, int Ho, int Wo, int nsplit, int kt_per_split, int accumulate,
-                     hipStream_t st) {
+                     hipStream_t st, int slab16) {
   W8Args g{};
   g.low[0] = (const uint16_t*)low0; g.high[0] = (const uint16_t*)high0;
   g.low[1] = (const uint16_t*)(two ? low1 : low0); g.high[1] = (const uint16_t*)(two ? high1 : high0);
@@ -695,6 +723,7 @@ int rg_wgrad8_launch(const void* low0, const void* high0, const void* low1, cons
   g.lgWo = rg_ilog2(Wo); g.lgHo = rg_ilog2(Ho); g.Hh = 2 * Ho; g.Wh = 2 * Wo;
   g.tiles_o = O / 256; g.tiles_c = 16 * I / 256; g.nsplit = nsplit; g.kt_per_split = kt_per_split;
   g.accumulate = nsplit == 1 ? accumulate : 0;
+  g.slab16 = nsplit > 1 ? slab16 : 0;
   hipLaunchKernelGGL(wgrad8_kernel<false>, dim3((unsigned)(g.tiles_o * g.tiles_c * nsplit)), dim3(512), 0, st, g);
   RG_LAUNCH_CHECK("conv_wgrad(mfma, ping-pong)");
   return RG_OK;

@@ -546,12 +546,14 @@ class HipOps:
             return False                           # no split-K plan for this shape (or no matrix-core kernel): nothing to defer
         if cw._slab_ws is None or cw._slab_ws.numel() < nb:
             cw._slab_ws = torch.empty(nb + 4096, dtype=torch.uint8, device=self.device)      # persistent: graphs hold its address
-        ns = ctypes.c_int(0)
+        ns, sdt = ctypes.c_int(0), ctypes.c_int(0)
         self._timed("conv_wgrad", flops, lambda: check(
             self.lib.rg_conv_wgrad_slabs(_ptr(low0), _ptr(high0), _ptr(low1), _ptr(high1), _ptr(dw), N, Ho, Wo, O, I, self.dt,
-                                         self.algo, _ptr(cw._slab_ws), cw._slab_ws.numel(), ctypes.addressof(ns), self.stream),
+                                         self.algo, _ptr(cw._slab_ws), cw._slab_ws.numel(), ctypes.addressof(ns),
+                                         ctypes.addressof(sdt), self.stream),
             "rg_conv_wgrad_slabs"), cw=cw)
-        cw.pending_slabs = (cw._slab_ws, int(ns.value)) if ns.value > 1 else None
+        # (buffer, number of partial slabs, their element type: RG_F32 / RG_BF16)
+        cw.pending_slabs = (cw._slab_ws, int(ns.value), int(sdt.value)) if ns.value > 1 else None
         return True
 
     def conv_wgrad(self, low, high, cw: ConvW, accumulate: bool):

@@ -193,7 +193,7 @@ class Adam(torch.optim.Adam):
             ps = getattr(cw, "pending_slabs", None)
             if ps is not None:
                 cw.pending_slabs = None
-                slab_segs.append(((cw.w.data_ptr() - flat.data.data_ptr()) // 4, cw.w.numel(), ps[0], ps[1]))
+                slab_segs.append(((cw.w.data_ptr() - flat.data.data_ptr()) // 4, cw.w.numel(), ps[0], ps[1], ps[2]))
             pw = getattr(cw, "pending_wgrad", None)
             if isinstance(pw, tuple) and isinstance(pw[0], str) and pw[0] == "conv":
                 # a layer whose weight-gradient plan has no split-K (ops_hip._wgrad_slabs left the operands): gradient tile and
@@ -214,7 +214,7 @@ class Adam(torch.optim.Adam):
                     ops._timed("conv_wgrad", flops, call, cw=cw)       # bench.py's per-family timing sees the launch
                 else:
                     call()
-                slab_segs.append((off, cw.w.numel(), None, -1))
+                slab_segs.append((off, cw.w.numel(), None, -1, 0))
         if slab_segs:
             if segs or self.grad_wire is not None:
                 raise RuntimeError("rna_gan_amd.optim.Adam: deferred split-K slabs expect a single-process step without fused "
@@ -223,25 +223,27 @@ class Adam(torch.optim.Adam):
             slab_segs.sort(key=lambda t: t[0])
             total = flat.data.numel()
             table, pos = [], lo
-            for off, n, buf, ns in slab_segs:
+            for off, n, buf, ns, sdt in slab_segs:
                 if off < pos or off % 4 or n % 4 or off + n > total:
                     raise RuntimeError("rna_gan_amd.optim.Adam: a deferred weight gradient does not sit 16-byte aligned inside "
                                        "the part of the flat buffer this launch steps")
                 if off > pos:
-                    table.append((pos - lo, off - pos, 0, 0))
-                table.append((off - lo, n, 0 if buf is None else buf.data_ptr(), ns))
+                    table.append((pos - lo, off - pos, 0, 0, 0))
+                table.append((off - lo, n, 0 if buf is None else buf.data_ptr(), ns, sdt))
                 pos = off + n
             if total > pos:
-                table.append((pos - lo, total - pos, 0, 0))
+                table.append((pos - lo, total - pos, 0, 0, 0))
             k = len(table)
             offs = (C.c_ulonglong * k)(*[t[0] for t in table])
             lens = (C.c_ulonglong * k)(*[t[1] for t in table])
             slabs = (C.c_void_p * k)(*[t[2] or None for t in table])
             nsp = (C.c_int * k)(*[t[3] for t in table])
+            sdts = (C.c_int * k)(*[t[4] for t in table])
             check(lib.rg_adam_step_slabs(flat.data.data_ptr() + 4 * lo, flat.grad.data_ptr() + 4 * lo,
                                          self._m.data_ptr() + 4 * lo, self._v.data_ptr() + 4 * lo, total - lo,
                                          self._hyper.data_ptr(), 0 if shadow is None else shadow.data_ptr() + 2 * lo, k,
-                                         C.addressof(offs), C.addressof(lens), C.addressof(slabs), C.addressof(nsp), stream),
+                                         C.addressof(offs), C.addressof(lens), C.addressof(slabs), C.addressof(nsp),
+                                         C.addressof(sdts), stream),
                   "rg_adam_step_slabs")
             segs = [(lo, total)]                  # nothing left for the plain launches below
         pos = lo

@@ -528,18 +528,29 @@ def test_bn_backward_sums_in_conv_epilogue(I, O, hs, n, groups):
             assert relmax(gz_f.view(groups, -1, C)[h], ref) < 8e-3, (direction, h)
 
 
+@pytest.mark.parametrize("wslab16", [0, 1])
 @pytest.mark.parametrize("I,O,hs,two", [(64, 128, 64, True), (128, 256, 32, False), (256, 512, 16, True), (512, 1024, 8, True),
                                          (1024, 2048, 4, False)])
-def test_split_k_weight_gradient_slabs_inside_the_adam_step(I, O, hs, two):
+def test_split_k_weight_gradient_slabs_inside_the_adam_step(I, O, hs, two, wslab16):
     """Round 5: a split-K weight-gradient launch may leave its fp32 slabs unreduced (rg_conv_wgrad_slabs) and the fused Adam
     step sums them itself (rg_adam_step_slabs: one launch over a flat buffer cut into plain and slab segments; 1 / 4 / 16 slab
     lanes per 16-byte column by nsplit).  At the benchmark's five layer shapes (one and two segments): against the reduced
     gradient (rg_conv_wgrad / rg_conv_wgrad2) followed by rg_adam_step_dev on the same flat buffer -- moments to fp32 rounding of
-    a different summation order, weights within two steps' bound of the sign-like first update, bf16 shadow = rounded weights."""
+    a different summation order, weights within two steps' bound of the sign-like first update, bf16 shadow = rounded weights.
+    wslab16 = 1 (the default): the partial tiles are bf16 -- each partial sum rounded once (2^-9 relative), added in fp32."""
     import ctypes as C
     dev = torch.device("cuda:0")
     ops = HipOps(torch.bfloat16, dev)
     lib = _abi.load()
+    _abi.check(lib.rg_set_option(b"wslab16", wslab16), "set_option")
+    try:
+        _slabs_inside_adam(lib, ops, dev, I, O, hs, two, wslab16)
+    finally:
+        lib.rg_set_option(b"wslab16", -1)
+
+
+def _slabs_inside_adam(lib, ops, dev, I, O, hs, two, wslab16):
+    import ctypes as C
     gen = torch.Generator(device="cpu").manual_seed(31)
     low0 = torch.randn(N, hs, hs, O, generator=gen).bfloat16().to(dev)
     high0 = torch.randn(N, 2 * hs, 2 * hs, I, generator=gen).bfloat16().to(dev)
@@ -577,24 +588,28 @@ def test_split_k_weight_gradient_slabs_inside_the_adam_step(I, O, hs, two):
     pd, gd, md, vd = p0.clone(), g0.clone(), m0.clone(), v0.clone()
     shd = torch.zeros(total + pad, dtype=torch.bfloat16, device=dev)
     slab = torch.empty_like(ws)
-    ns = C.c_int(0)
+    ns, sdt = C.c_int(0), C.c_int(-1)
     _abi.check(lib.rg_conv_wgrad_slabs(ptr(low0), ptr(high0), ptr(low1), ptr(high1), gd[head:head + nw].data_ptr(), N, hs, hs,
-                                       O, I, ops.dt, ops.algo, slab.data_ptr(), slab.numel(), C.addressof(ns), ops.stream),
-               "rg_conv_wgrad_slabs")
-    print("layer %d -> %d at %d^2, %d segment(s): nsplit %d" % (I, O, hs, 2 if two else 1, ns.value))
+                                       O, I, ops.dt, ops.algo, slab.data_ptr(), slab.numel(), C.addressof(ns), C.addressof(sdt),
+                                       ops.stream), "rg_conv_wgrad_slabs")
+    print("layer %d -> %d at %d^2, %d segment(s): nsplit %d, slab dtype %d" % (I, O, hs, 2 if two else 1, ns.value, sdt.value))
+    s16 = sdt.value == _abi.RG_BF16
     if ns.value > 1:
+        assert s16 == bool(wslab16) or not s16               # (the 128 x 128 kernel's slabs stay fp32 under either setting)
         gd[head:head + nw].fill_(float("nan"))               # the reduced gradient must never be read
-        table = [(0, head, 0, 0), (head, nw, slab.data_ptr(), ns.value), (head + nw, tail, 0, 0)]
+        table = [(0, head, 0, 0, 0), (head, nw, slab.data_ptr(), ns.value, sdt.value), (head + nw, tail, 0, 0, 0)]
     else:
-        table = [(0, total, 0, 0)]                           # no split at this shape: dw was written, one plain segment
+        assert sdt.value == _abi.RG_F32
+        table = [(0, total, 0, 0, 0)]                        # no split at this shape: dw was written, one plain segment
     k = len(table)
     offs = (C.c_ulonglong * k)(*[t[0] for t in table])
     lens = (C.c_ulonglong * k)(*[t[1] for t in table])
     slabs = (C.c_void_p * k)(*[t[2] or None for t in table])
     nsp = (C.c_int * k)(*[t[3] for t in table])
+    sdts = (C.c_int * k)(*[t[4] for t in table])
     _abi.check(lib.rg_adam_step_slabs(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), total, hyper.data_ptr(),
                                       shd.data_ptr(), k, C.addressof(offs), C.addressof(lens), C.addressof(slabs),
-                                      C.addressof(nsp), ops.stream), "rg_adam_step_slabs")
+                                      C.addressof(nsp), C.addressof(sdts), ops.stream), "rg_adam_step_slabs")
     torch.cuda.synchronize()
     assert torch.isfinite(pd[:total]).all() and torch.isfinite(md[:total]).all() and torch.isfinite(vd[:total]).all()
     # plain segments: the same arithmetic, bit for bit
@@ -603,11 +618,26 @@ def test_split_k_weight_gradient_slabs_inside_the_adam_step(I, O, hs, two):
     assert torch.equal(shr[:head], shd[:head]) and torch.equal(shr[head + nw:total], shd[head + nw:total])
     sl = slice(head, head + nw)
     gscale = float((mr[sl] - 0.5 * m0[sl]).abs().max())      # 0.5 * |g|_max
-    assert float((mr[sl] - md[sl]).abs().max()) <= 2e-5 * gscale
-    assert float((vr[sl] - vd[sl]).abs().max()) <= 1e-4 * float(vr[sl].abs().max())
+    # bf16 partial tiles: every partial sum carries a relative 2^-9 rounding, the sum of nsplit of them ~ 2^-9 of the gradient's
+    # typical size (independent signs); m moves by half of that, v by 2 g dg / 1000
+    assert float((mr[sl] - md[sl]).abs().max()) <= (1e-2 if s16 else 2e-5) * gscale
+    assert float((vr[sl] - vd[sl]).abs().max()) <= (2e-2 if s16 else 1e-4) * float(vr[sl].abs().max())
+    if s16:
+        rel = float((mr[sl] - md[sl]).norm() / (mr[sl] - 0.5 * m0[sl]).norm())
+        print("  bf16 partial tiles: relative L2 error of the summed gradient %.2e" % rel)
+        assert rel <= 4e-3
     # the step lr * m_hat / (sqrt(v_hat) + eps) of every element: within 2 % of the largest step (a different fp32 summation
     # order of the gradient moves m and v in the 6th digit; where v is tiny the quotient amplifies it)
-    assert float((pr[sl] - pd[sl]).abs().max()) <= 2e-2 * float((pr[sl] - p0[sl]).abs().max())
+    if s16:
+        # an element whose gradient nearly cancels its old moment may flip the sign of its (sign-like) first step under a 2^-9
+        # perturbation of the gradient: no per-element bound -- the update as a whole, and how many elements moved visibly
+        du_r, du_d = (pr[sl] - p0[sl]).double(), (pd[sl] - p0[sl]).double()
+        cos = float((du_r * du_d).sum() / (du_r.norm() * du_d.norm()))
+        moved = float(((du_r - du_d).abs() > 5e-2 * float(du_r.abs().max())).float().mean())
+        print("  update cosine %.6f, elements whose step moved by more than 5 %% of the largest step: %.2e" % (cos, moved))
+        assert cos >= 0.998 and moved <= 4e-3          # measured: 0.99925 / 1.05e-3 (random gradients against random old moments)
+    else:
+        assert float((pr[sl] - pd[sl]).abs().max()) <= 2e-2 * float((pr[sl] - p0[sl]).abs().max())
     assert torch.equal(shd[:total], pd[:total].bfloat16())
     # bad tables are refused
     bad_off = (C.c_ulonglong * 1)(4)
@@ -615,7 +645,8 @@ def test_split_k_weight_gradient_slabs_inside_the_adam_step(I, O, hs, two):
     nul = (C.c_void_p * 1)(None)
     zero = (C.c_int * 1)(0)
     assert lib.rg_adam_step_slabs(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), total, hyper.data_ptr(), 0, 1,
-                                  C.addressof(bad_off), C.addressof(one_len), C.addressof(nul), C.addressof(zero), ops.stream) != 0
+                                  C.addressof(bad_off), C.addressof(one_len), C.addressof(nul), C.addressof(zero),
+                                  C.addressof(zero), ops.stream) != 0
 
 
 @pytest.mark.parametrize("two", [False, True])
@@ -676,9 +707,10 @@ def test_weight_gradient_and_adam_step_in_one_launch(two):
     lens = (C.c_ulonglong * k)(*[t[1] for t in table])
     slabs = (C.c_void_p * k)(*[None for t in table])
     nsp = (C.c_int * k)(*[t[3] for t in table])
+    sdts = (C.c_int * k)(*[0 for t in table])
     _abi.check(lib.rg_adam_step_slabs(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), total, hyper.data_ptr(),
                                       shd.data_ptr(), k, C.addressof(offs), C.addressof(lens), C.addressof(slabs),
-                                      C.addressof(nsp), ops.stream), "rg_adam_step_slabs")
+                                      C.addressof(nsp), C.addressof(sdts), ops.stream), "rg_adam_step_slabs")
     torch.cuda.synchronize()
     assert not torch.equal(pr[head:head + nw], p0[head:head + nw])
     for name, a, b in (("p", pr, pd), ("m", mr, md), ("v", vr, vd)):
