@@ -6,7 +6,9 @@
 // Per-channel sums use a deterministic two-stage reduction (block partials in the caller's workspace,
 // then a small finishing kernel).
 #include "rg_common.h"
+#include "rg_internal.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -43,9 +45,19 @@ static int max_gy(int M, int C) {
 template <class F> __device__ __forceinline__ auto shift_group(F& f, int g, int) -> decltype(f.shift(g), void()) { f.shift(g); }
 template <class F> __device__ __forceinline__ void shift_group(F&, int, long) {}
 
+// ---- the order in which a pass walks its row blocks (blockIdx.y is dispatched in ascending order): rev = from the END of the
+// tensor.  What a pass reads first should be what the kernel in front of it touched last -- the memory-side cache holds a fraction
+// of a 67-134 MB activation tensor, not all of it.  Measured on the benchmarked iteration (option bn_rev): the
+// REDUCTIONS from the end (their operand was just written, its tail last) and the apply passes behind them from the front (the
+// reduction read the head last): -0.07 ms; every other combination, an eight-range interleave matching the conv launches' XCD
+// order and the conv launches themselves from the end: 0 ... +0.16 ms.
+__device__ __forceinline__ int row_block_order(int rev) {
+  return rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+}
+
 // ---- reduction skeleton: F has  init(c)  and  row(r, c, acc[NQ][VEC])
 template <int NQ, int VEC, int TX, class F>
-__global__ __launch_bounds__(256) void rowreduce_kernel(F f, int M, int C, int rows_per_block, float* partial) {
+__global__ __launch_bounds__(256) void rowreduce_kernel(F f, int M, int C, int rows_per_block, float* partial, int rev) {
   constexpr int TY = 256 / TX;
   shift_group(f, (int)blockIdx.z, 0);
   partial += (size_t)blockIdx.z * gridDim.y * NQ * C;
@@ -57,7 +69,10 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(F f, int M, int C, int r
   for (int q = 0; q < NQ; ++q)
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[q][v] = 0.f;
-  const int r0 = blockIdx.y * rows_per_block;
+  // rev (option bn_rev bit 2): the row blocks are walked from the end of the tensor (the producer wrote its last rows last);
+  // partial row `by` holds the same rows' sums either way, so the finisher's result does not change by a bit
+  const int by = row_block_order(rev);
+  const int r0 = by * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
   if (c < C) {
     f.init(c);
@@ -85,7 +100,7 @@ __global__ __launch_bounds__(256) void rowreduce_kernel(F f, int M, int C, int r
         float s = 0.f;
 #pragma unroll
         for (int t = 0; t < TY; ++t) s += sm[t][q][tx * VEC + v];
-        partial[((size_t)blockIdx.y * NQ + q) * C + c + v] = s;
+        partial[((size_t)by * NQ + q) * C + c + v] = s;
       }
   }
 }
@@ -195,12 +210,15 @@ struct SliceFin {
 // U x (inputs) x 16 bytes outstanding -- with one row at a time the kernels sat at ~3.7 TB/s, latency-bound (the
 // compiler cannot hoist the next row's loads over the previous row's store: the pointers may alias).
 template <int VEC, int TX, class F>
-__global__ __launch_bounds__(256) void rowapply_kernel(F f, int M, int C, int rows_per_block) {
+__global__ __launch_bounds__(256) void rowapply_kernel(F f, int M, int C, int rows_per_block, int rev) {
   constexpr int TY = 256 / TX, U = F::U;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int c = (blockIdx.x * TX + tx) * VEC;
   if (c >= C) return;
-  const int r0 = blockIdx.y * rows_per_block;
+  // rev: the row blocks are walked from the END of the tensor -- the pass in front of this one (a reduction over the same
+  // operands, or the kernel that wrote them) touched the last rows last, so they are what the memory-side cache still holds
+  const int by = row_block_order(rev);
+  const int r0 = by * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
   shift_group(f, (int)blockIdx.z, 0);
   f.init(c);
@@ -222,10 +240,11 @@ int row_reduce_g(const char* name, int groups, int M, int C, void* ws, size_t ws
   RG_REQUIRE(ws && ws_bytes >= need, RG_EWORKSPACE, "%s: workspace %zu < %zu", name, ws_bytes, need);
   float* partial = (float*)ws;
   dim3 grid(p.gx, p.gy, groups);
+  const int rev = (rg_option("bn_rev", RG_BN_REV_DEFAULT) >> 2) & 1;
 #define RG_RR(V, X)                                                                                          \
   do {                                                                                                       \
     F<T, V> f{args...};                                                                                      \
-    hipLaunchKernelGGL((rowreduce_kernel<NQ, V, X, F<T, V>>), grid, dim3(256), 0, st, f, M, C, p.rows_per_block, partial); \
+    hipLaunchKernelGGL((rowreduce_kernel<NQ, V, X, F<T, V>>), grid, dim3(256), 0, st, f, M, C, p.rows_per_block, partial, rev); \
   } while (0)
   if (p.vec == 8) { if (p.tx == 32) RG_RR(8, 32); else if (p.tx == 16) RG_RR(8, 16); else RG_RR(8, 8); }
   else if (p.vec == 4) { if (p.tx == 32) RG_RR(4, 32); else if (p.tx == 16) RG_RR(4, 16); else RG_RR(4, 8); }
@@ -245,10 +264,14 @@ template <typename T, template <typename, int> class F, class... Args>
 int row_apply_g(const char* name, int groups, int M, int C, hipStream_t st, Args... args) {
   Plan p = make_plan<T>(M, C, 4096 / groups, 8192);      // no partial rows behind an apply pass: as many blocks as the target asks
   dim3 grid(p.gx, p.gy, groups);
+  // option bn_rev (bit 0: the passes behind a reduction over the same operands -- backward / tangent / double-backward applies;
+  // bit 1: the forward apply behind the kernel that wrote its input): walk the rows from the end (see rowapply_kernel)
+  const bool fwd = strncmp(name, "bn_forward", 10) == 0 || strcmp(name, "bn_act") == 0;
+  const int rev = (rg_option("bn_rev", RG_BN_REV_DEFAULT) >> (fwd ? 1 : 0)) & 1;
 #define RG_RA(V, X)                                                                                   \
   do {                                                                                                \
     F<T, V> f{args...};                                                                               \
-    hipLaunchKernelGGL((rowapply_kernel<V, X, F<T, V>>), grid, dim3(256), 0, st, f, M, C, p.rows_per_block); \
+    hipLaunchKernelGGL((rowapply_kernel<V, X, F<T, V>>), grid, dim3(256), 0, st, f, M, C, p.rows_per_block, rev); \
   } while (0)
   if (p.vec == 8) { if (p.tx == 32) RG_RA(8, 32); else if (p.tx == 16) RG_RA(8, 16); else RG_RA(8, 8); }
   else if (p.vec == 4) { if (p.tx == 32) RG_RA(4, 32); else if (p.tx == 16) RG_RA(4, 16); else RG_RA(4, 8); }

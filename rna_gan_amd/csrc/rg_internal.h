@@ -50,6 +50,8 @@ int rg_mfma_conv_nsplit(int up, int N, int Hlow, int Wlow, int O, int I);
 // split-K partial tiles of the 8-wave conv kernel as bf16 instead of fp32 (option `slab16`): half the slab bytes written by the
 // conv launch and read by the fused reduction + BatchNorm kernel; the partial sums are rounded to bf16 before they are added
 constexpr int RG_SLAB16_DEFAULT = 1;
+constexpr int RG_BN_REV_DEFAULT = 4;     // option bn_rev: BatchNorm row passes that walk their rows from the END (bit 0: backward-kind applies, bit 1: forward
+                                         // applies, bit 2: reductions).  Measured: reductions only
 constexpr int RG_WSLAB16_DEFAULT = 1;    // deferred split-K weight-gradient slabs (rg_conv_wgrad_slabs) as bf16: option wslab16
 int rg_mfma_conv_slab16(int up, int N, int Hlow, int Wlow, int O, int I);
 int rg_mfma_conv_stats_rows(int up, int N, int Hlow, int Wlow, int O, int I);
