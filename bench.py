@@ -470,6 +470,8 @@ def measure_roofline(ops, device, one_step, step_ms):
       conv_fwd_dgrad = gather_gemm_kernel (bf16 MFMA implicit GEMM; every stride-2 conv / transposed
                        conv, forward, data-gradient and GP tangent pass of both networks)
       conv_wgrad     = wgrad_kernel + its slab reduction
+      conv_wgrad_adam = the weight-gradient launches that also apply the Adam step of their tensor (rg_conv_wgrad_adam: the two
+                       33.5 M-parameter layers; their interval is dominated by the optimizer's 26 bytes per parameter)
     `achieved` = algorithmic FLOPs of the family's launches / their summed duration (SURVEY 8d:
     2*N*Ho*Wo*Cout*Cin*16 per launch); a launch's duration is its event interval minus the interval an empty event
     pair reads (calibrated just before; reported as event_pair_overhead_us) and includes the split-K slab reduction

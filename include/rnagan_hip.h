@@ -475,6 +475,17 @@ int rg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, con
 int rg_adam_step_slabs(float* p, const float* g, float* m, float* v, size_t n, const float* hyper, void* shadow_bf16, int nseg,
                        const unsigned long long* seg_off, const unsigned long long* seg_n, const void* const* seg_slab,
                        const int* seg_nsplit, const int* seg_dtype, void* stream);
+/* Data parallel (one process per GPU, bf16 gradient wire; the reference has no distributed path -- SURVEY 8 e): the flat fp32
+ * gradient g[n] goes onto the bf16 wire buffer of the all-reduce with the segment table of rg_adam_step_slabs: a plain segment is
+ * rounded, a slab segment is summed (slab order, fp32) and rounded once, a segment with seg_nsplit = -1 is left alone (its
+ * weight-gradient launch wrote it: rg_conv_wgrad_wire).  Replaces the per-layer reduction launches + one cast pass. */
+int rg_grad_to_wire(const float* g, void* wire_bf16, size_t n, int nseg, const unsigned long long* seg_off,
+                    const unsigned long long* seg_n, const void* const* seg_slab, const int* seg_nsplit, const int* seg_dtype,
+                    void* stream);
+/* rg_conv_wgrad / rg_conv_wgrad2 (low1 = high1 = NULL: one segment) of a layer whose plan has no split-K
+ * (rg_conv_wgrad_adam_supported) written as bf16 into the tensor's 16-byte aligned slice of that wire buffer. */
+int rg_conv_wgrad_wire(const void* low0, const void* high0, const void* low1, const void* high1, void* wire_bf16, int N, int Ho,
+                       int Wo, int O, int I, int dtype, int algo, void* stream);
 /* ++(*step_dev) and recompute hyper[0..6] from it on the device (double arithmetic, one thread): with
  * this launch in front of rg_adam_step_dev the whole optimizer step replays from a graph untouched.
  * hyper[7] = weight_decay (torch.optim.Adam's L2 term g += wd * p; 0 on the GAN path, betaVAE training sets it,

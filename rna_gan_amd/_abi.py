@@ -33,6 +33,8 @@ PROTOTYPES = {
     "rg_conv_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_conv_wgrad2": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_conv_wgrad_slabs": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p, _p, _p]),
+    "rg_grad_to_wire": (_i, [_p, _p, _z, _i, _p, _p, _p, _p, _p, _p]),
+    "rg_conv_wgrad_wire": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "rg_conv_wgrad_adam_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "rg_conv_wgrad_adam": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "rg_first_down": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
@@ -158,7 +160,7 @@ PROTOTYPES = {
 }
 
 # must equal rg_version() of the library (rna_gan_amd/csrc/rg_api.hip): bumped together with PROTOTYPES
-ABI_VERSION = 502
+ABI_VERSION = 503
 
 _lib = None
 

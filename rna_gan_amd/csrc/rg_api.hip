@@ -18,7 +18,7 @@ void rg_set_error(const char* fmt, ...) {
 }
 
 // bumped whenever an entry point is added or a signature changes; rna_gan_amd/_abi.py (ABI_VERSION) refuses any other value
-extern "C" int rg_version(void) { return 502; }   // 5.02: round 5 (rg_conv_wgrad_slabs, rg_adam_step_slabs, rg_conv_wgrad_adam; slab dtypes)
+extern "C" int rg_version(void) { return 503; }   // 5.03: round 5 (rg_conv_wgrad_slabs, rg_adam_step_slabs, rg_conv_wgrad_adam; slab dtypes; rg_grad_to_wire, rg_conv_wgrad_wire)
 extern "C" const char* rg_last_error(void) { return g_err; }
 
 // ---- kernel-selection knobs: override table in front of the RNAGAN_* environment variables
@@ -229,6 +229,19 @@ extern "C" int rg_conv_wgrad_adam(const void* low0, const void* high0, const voi
              "conv_wgrad_adam: shape / dtype without a single-split matrix-core plan");
   return rg_mfma_conv_wgrad_adam(low0, high0, low1, high1, N, Ho, Wo, O, I, p, m, v, (uint16_t*)shadow_bf16, hyper,
                                  rg_stream(stream));
+}
+
+// Data parallel: the weight gradient of a layer whose plan has no split-K (rg_conv_wgrad_adam_supported) written ONCE, as bf16,
+// straight into the tensor's slice of the all-reduce wire buffer (tap-major [O][16][I] like dw) -- no fp32 gradient, no cast pass
+// over it; the segment table of rg_grad_to_wire skips the tensor (nsplit = -1).
+extern "C" int rg_conv_wgrad_wire(const void* low0, const void* high0, const void* low1, const void* high1, void* wire_bf16, int N,
+                                  int Ho, int Wo, int O, int I, int dtype, int algo, void* stream) {
+  RG_REQUIRE(low0 && high0 && wire_bf16 && (low1 == nullptr) == (high1 == nullptr) && N > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0,
+             RG_EINVAL, "conv_wgrad_wire: bad args");
+  RG_REQUIRE(((uintptr_t)wire_bf16 & 15) == 0, RG_EINVAL, "conv_wgrad_wire: the wire slice must be 16-byte aligned");
+  RG_REQUIRE(rg_conv_wgrad_adam_supported(N, Ho, Wo, O, I, low1 != nullptr, dtype, algo), RG_EUNSUPPORTED,
+             "conv_wgrad_wire: shape / dtype without a single-split matrix-core plan");
+  return rg_mfma_conv_wgrad_wire(low0, high0, low1, high1, N, Ho, Wo, O, I, (uint16_t*)wire_bf16, rg_stream(stream));
 }
 
 extern "C" int rg_conv_wgrad(const void* low, const void* high, float* dw, int N, int Ho, int Wo, int O, int I,

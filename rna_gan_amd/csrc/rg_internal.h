@@ -136,6 +136,10 @@ int rg_wgrad8n_launch(const void* low0, const void* high0, const void* low1, con
 int rg_wgrad8_launch(const void* low0, const void* high0, const void* low1, const void* high1, float* out, int Kseg,
                      int two, int O, int I, int Ho, int Wo, int nsplit, int kt_per_split, int accumulate, hipStream_t st,
                      int slab16 = 0);
+int rg_wgrad8_wire_launch(const void* low0, const void* high0, const void* low1, const void* high1, uint16_t* out16, int Kseg,
+                          int two, int O, int I, int Ho, int Wo, int kt_per_split, hipStream_t st);
+int rg_mfma_conv_wgrad_wire(const void* low0, const void* high0, const void* low1, const void* high1, int N, int Ho, int Wo,
+                            int O, int I, uint16_t* out16, hipStream_t st);
 int rg_wgrad8_adam_launch(const void* low0, const void* high0, const void* low1, const void* high1, int Kseg, int two, int O,
                           int I, int Ho, int Wo, int kt_per_split, float* p, float* m, float* v, uint16_t* shadow,
                           const float* hyper, hipStream_t st);

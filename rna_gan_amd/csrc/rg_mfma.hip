@@ -1712,6 +1712,16 @@ int rg_mfma_conv_wgrad_adam(const void* low0, const void* high0, const void* low
   return rg_wgrad8_adam_launch(low0, high0, low1, high1, N * Ho * Wo, two ? 1 : 0, O, I, Ho, Wo, per, p, m, v, shadow, hyper, st);
 }
 
+int rg_mfma_conv_wgrad_wire(const void* low0, const void* high0, const void* low1, const void* high1, int N, int Ho, int Wo,
+                            int O, int I, uint16_t* out16, hipStream_t st) {
+  const bool two = low1 != nullptr;
+  RG_REQUIRE(rg_mfma_conv_wgrad_adam_supported(N, Ho, Wo, O, I, two), RG_EUNSUPPORTED,
+             "conv_wgrad_wire: no single-split plan of the 256 x 256 kernel for this shape");
+  int per = 0;
+  rg_wgrad8_split((two ? 2 : 1) * N * Ho * Wo, O, I, &per);
+  return rg_wgrad8_wire_launch(low0, high0, low1, high1, out16, N * Ho * Wo, two ? 1 : 0, O, I, Ho, Wo, per, st);
+}
+
 size_t rg_mfma_wgrad2_ws_bytes(int N, int Ho, int Wo, int O, int I) {
   size_t a = (size_t)mfma_wgrad_split_k(N * Ho * Wo, O, I) * O * I * 16 * sizeof(float);
   size_t b = (size_t)mfma_wgrad_split_k(2 * N * Ho * Wo, O, I) * O * I * 16 * sizeof(float);

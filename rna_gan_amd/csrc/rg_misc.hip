@@ -239,6 +239,79 @@ __global__ __launch_bounds__(256) void adam_segs_kernel(float* __restrict__ p, c
   }
 }
 
+// ---- the data-parallel counterpart of adam_segs_kernel: the flat fp32 gradient goes onto the bf16 WIRE buffer of the all-reduce
+// (rg_cast_pad's job) with the same segment table -- a slab segment is summed here (slab order, fp32) and rounded once onto the
+// wire, so the reduction launch of every split layer and the fp32 gradient it wrote for this pass to read back disappear; a
+// skipped segment (nsplit = -1) was put on the wire by its weight-gradient launch (rg_conv_wgrad_wire).
+template <int SL, bool S16>
+__device__ __forceinline__ void wire_slab_segment(uint16_t* __restrict__ wire, const float* __restrict__ slab, int nsplit,
+                                                  size_t n, float4 (*sm)[64]) {
+  constexpr int COLS = 256 / SL;
+  const int col = threadIdx.x % COLS, l = threadIdx.x / COLS;
+  const size_t n4 = n / 4;
+  const size_t trips = (n4 + COLS - 1) / COLS;
+  for (size_t tb = blockIdx.x; tb < trips; tb += gridDim.x) {
+    const size_t q = tb * COLS + col;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < n4) {
+      int z = l;
+      for (; z + 7 * SL < nsplit; z += 8 * SL) {
+        float4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = adam_slab_ld<S16>(slab, (size_t)(z + k * SL), n, q);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s.x += t[k].x; s.y += t[k].y; s.z += t[k].z; s.w += t[k].w; }
+      }
+      for (; z < nsplit; z += SL) {
+        const float4 t = adam_slab_ld<S16>(slab, (size_t)z, n, q);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+    }
+    if (SL > 1) {
+      __syncthreads();
+      sm[l][col] = s;
+      __syncthreads();
+      if (l == 0) {
+#pragma unroll
+        for (int k = 1; k < SL; ++k) { const float4 t = sm[k][col]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+      }
+    }
+    if (l == 0 && q < n4)
+      *(uint2*)(wire + q * 4) = make_uint2((uint32_t)f32_to_bf16(s.x) | ((uint32_t)f32_to_bf16(s.y) << 16),
+                                           (uint32_t)f32_to_bf16(s.z) | ((uint32_t)f32_to_bf16(s.w) << 16));
+  }
+}
+
+__global__ __launch_bounds__(256) void wire_segs_kernel(const float* __restrict__ g, uint16_t* __restrict__ wire, AdamSegs t) {
+  __shared__ float4 sm[16][64];
+  for (int si = 0; si < t.nseg; ++si) {
+    const AdamSeg sg = t.s[si];
+    if (sg.nsplit < 0) continue;                           // already on the wire
+    uint16_t* ws = wire + sg.off;
+    if (sg.slab) {
+      if (sg.s16) {
+        if (sg.nsplit <= 4) wire_slab_segment<1, true>(ws, sg.slab, sg.nsplit, sg.n, sm);
+        else if (sg.nsplit <= 32) wire_slab_segment<4, true>(ws, sg.slab, sg.nsplit, sg.n, sm);
+        else wire_slab_segment<16, true>(ws, sg.slab, sg.nsplit, sg.n, reinterpret_cast<float4(*)[64]>(sm));
+      } else {
+        if (sg.nsplit <= 4) wire_slab_segment<1, false>(ws, sg.slab, sg.nsplit, sg.n, sm);
+        else if (sg.nsplit <= 32) wire_slab_segment<4, false>(ws, sg.slab, sg.nsplit, sg.n, sm);
+        else wire_slab_segment<16, false>(ws, sg.slab, sg.nsplit, sg.n, reinterpret_cast<float4(*)[64]>(sm));
+      }
+      continue;
+    }
+    const float* gs = g + sg.off;
+    const size_t n4 = sg.n / 4, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
+      const float4 G = nt_ld4(gs + q * 4);
+      *(uint2*)(ws + q * 4) = make_uint2((uint32_t)f32_to_bf16(G.x) | ((uint32_t)f32_to_bf16(G.y) << 16),
+                                         (uint32_t)f32_to_bf16(G.z) | ((uint32_t)f32_to_bf16(G.w) << 16));
+    }
+    const size_t tl = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tl < sg.n) ws[tl] = f32_to_bf16(gs[tl]);
+  }
+}
+
 // element-per-thread form for ranges that do not start on a 16-byte boundary (the small bias / BatchNorm ranges between the
 // nn.Linear weights that rg_linear_wgrad_adam steps itself): fp32 gradient, no shadow
 __global__ __launch_bounds__(256) void adam_dev_scalar_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -597,6 +670,32 @@ extern "C" int rg_adam_step_slabs(float* p, const float* g, float* m, float* v, 
   if (shadow_bf16) hipLaunchKernelGGL((adam_segs_kernel<true>), grid, block, 0, st, p, g, m, v, hyper, (uint16_t*)shadow_bf16, t);
   else hipLaunchKernelGGL((adam_segs_kernel<false>), grid, block, 0, st, p, g, m, v, hyper, (uint16_t*)nullptr, t);
   RG_LAUNCH_CHECK("adam_step_slabs");
+  return RG_OK;
+}
+// The gradient's way onto the bf16 wire of a data-parallel all-reduce with the segment table of rg_adam_step_slabs (see
+// wire_segs_kernel): g fp32 [n], wire bf16 [n]; plain segments are rounded, slab segments summed and rounded once, segments with
+// nsplit = -1 left as they are.
+extern "C" int rg_grad_to_wire(const float* g, void* wire_bf16, size_t n, int nseg, const unsigned long long* seg_off,
+                               const unsigned long long* seg_n, const void* const* seg_slab, const int* seg_nsplit,
+                               const int* seg_dtype, void* stream) {
+  RG_REQUIRE(g && wire_bf16 && seg_off && seg_n && seg_slab && seg_nsplit && seg_dtype, RG_EINVAL, "grad_to_wire: bad args");
+  RG_REQUIRE(nseg >= 1 && nseg <= ADAM_MAX_SEGS, RG_EINVAL, "grad_to_wire: 1 .. %d segments", ADAM_MAX_SEGS);
+  RG_REQUIRE(aligned16(g) && ((uintptr_t)wire_bf16 & 7) == 0, RG_EINVAL, "grad_to_wire: alignment");
+  AdamSegs t{};
+  t.nseg = nseg;
+  unsigned long long pos = 0;
+  for (int i = 0; i < nseg; ++i) {
+    RG_REQUIRE(seg_off[i] == pos && seg_off[i] % 4 == 0, RG_EINVAL, "grad_to_wire: segments must tile the range in order, each "
+               "starting on a multiple of 4 elements (segment %d)", i);
+    RG_REQUIRE(!seg_slab[i] || (seg_nsplit[i] >= 1 && seg_n[i] % 4 == 0 && aligned16(seg_slab[i]) &&
+                                (seg_dtype[i] == RG_F32 || seg_dtype[i] == RG_BF16)), RG_EINVAL, "grad_to_wire: slab segment %d", i);
+    t.s[i] = AdamSeg{seg_off[i], seg_n[i], (const float*)seg_slab[i], seg_slab[i] ? seg_nsplit[i] : (seg_nsplit[i] < 0 ? -1 : 0),
+                     seg_slab[i] && seg_dtype[i] == RG_BF16 ? 1 : 0};
+    pos += seg_n[i];
+  }
+  RG_REQUIRE(pos == n, RG_EINVAL, "grad_to_wire: the segments cover %llu of %zu elements", pos, n);
+  hipLaunchKernelGGL(wire_segs_kernel, dim3(grid_for(n, 4)), dim3(256), 0, rg_stream(stream), g, (uint16_t*)wire_bf16, t);
+  RG_LAUNCH_CHECK("grad_to_wire");
   return RG_OK;
 }
 extern "C" int rg_adam_hyper_dev(int* step_dev, double lr, double beta1, double beta2, double eps, double weight_decay,

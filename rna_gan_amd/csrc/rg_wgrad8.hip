@@ -729,6 +729,23 @@ int rg_wgrad8_launch(const void* low0, const void* high0, const void* low1, cons
   return RG_OK;
 }
 
+// A plan without split-K writing its tile as bf16 [O][16*I] (the data-parallel wire buffer's slice for this tensor) instead of fp32
+int rg_wgrad8_wire_launch(const void* low0, const void* high0, const void* low1, const void* high1, uint16_t* out16, int Kseg,
+                          int two, int O, int I, int Ho, int Wo, int kt_per_split, hipStream_t st) {
+  W8Args g{};
+  g.low[0] = (const uint16_t*)low0; g.high[0] = (const uint16_t*)high0;
+  g.low[1] = (const uint16_t*)(two ? low1 : low0); g.high[1] = (const uint16_t*)(two ? high1 : high0);
+  g.low_bytes = (unsigned)((size_t)Kseg * O * 2); g.high_bytes = (unsigned)((size_t)Kseg * 4 * I * 2);
+  g.Kseg[0] = Kseg; g.Kseg[1] = two ? Kseg : 0;
+  g.out = reinterpret_cast<float*>(out16); g.O = O; g.I = I;
+  g.lgWo = rg_ilog2(Wo); g.lgHo = rg_ilog2(Ho); g.Hh = 2 * Ho; g.Wh = 2 * Wo;
+  g.tiles_o = O / 256; g.tiles_c = 16 * I / 256; g.nsplit = 1; g.kt_per_split = kt_per_split;
+  g.slab16 = 1;                                    // zs = 0: the "slab" is the tensor itself
+  hipLaunchKernelGGL(wgrad8_kernel<false>, dim3((unsigned)(g.tiles_o * g.tiles_c)), dim3(512), 0, st, g);
+  RG_LAUNCH_CHECK("conv_wgrad_wire(mfma, ping-pong)");
+  return RG_OK;
+}
+
 // One launch = weight gradient + optimizer step of the tensor (a plan without split-K only): see W8Args::ap.
 int rg_wgrad8_adam_launch(const void* low0, const void* high0, const void* low1, const void* high1, int Kseg, int two, int O,
                           int I, int Ho, int Wo, int kt_per_split, float* p, float* m, float* v, uint16_t* shadow,

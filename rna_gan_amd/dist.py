@@ -177,24 +177,48 @@ class _HogWork:
             torch.cuda.current_stream().wait_event(self.ev)
 
 
-def allreduce_start(flat: torch.Tensor, compress: bool = False, head: int = 0):
+def wire_for(flat: torch.Tensor):
+    """The persistent bf16 wire buffer of a flat fp32 gradient buffer (one per device and length), or None when the gradients
+    travel as fp32."""
+    if not (COMPRESS and flat.is_cuda and flat.dtype == torch.float32):
+        return None
+    key = (flat.device, flat.numel(), flat.data_ptr())
+    wire = _wire.get(key)
+    if wire is None:
+        wire = _wire[key] = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
+    return wire
+
+
+def allreduce_start(flat: torch.Tensor, compress: bool = False, head: int = 0, table=None):
     """Start the in-place SUM all-reduce of a flat fp32 gradient buffer (fixed-size buckets, asynchronous: RCCL runs
     on its own stream behind everything enqueued so far on the current one).  Returns a handle for
     allreduce_finish(); None when there is nothing to reduce.  `flat` must not be written before the finish.
-    head: the first `head` elements are NOT reduced (their gradient travels as gathered factors, see G0_FACTORS)."""
+    head: the first `head` elements are NOT reduced (their gradient travels as gathered factors, see G0_FACTORS).
+    table (bf16 wire only): segment table over ``[head:]`` -- rows (offset, length, slab address or 0, nsplit, slab dtype) as for
+    rg_adam_step_slabs -- of layers whose weight gradient was NOT reduced into ``flat`` in this pass: split-K slabs are summed
+    straight onto the wire, nsplit = -1 marks a slice its weight-gradient launch already wrote there (rg_grad_to_wire)."""
     if not active():
         return None
     n = flat.numel()
     if compress and COMPRESS and flat.is_cuda and flat.dtype == torch.float32:
         from . import _abi
         lib = _abi.load()
-        key = (flat.device, n)
-        wire = _wire.get(key)
-        if wire is None:
-            wire = _wire[key] = torch.empty(n, dtype=torch.bfloat16, device=flat.device)
+        wire = wire_for(flat)
         stream = torch.cuda.current_stream(flat.device).cuda_stream
-        _abi.check(lib.rg_cast_pad(flat.data_ptr() + 4 * head, wire.data_ptr() + 2 * head, 1, n - head, n - head,
-                                   _abi.RG_BF16, stream), "rg_cast_pad")
+        if table:
+            import ctypes as C
+            k = len(table)
+            offs = (C.c_ulonglong * k)(*[t[0] for t in table])
+            lens = (C.c_ulonglong * k)(*[t[1] for t in table])
+            slabs = (C.c_void_p * k)(*[t[2] or None for t in table])
+            nsp = (C.c_int * k)(*[t[3] for t in table])
+            sdts = (C.c_int * k)(*[t[4] for t in table])
+            _abi.check(lib.rg_grad_to_wire(flat.data_ptr() + 4 * head, wire.data_ptr() + 2 * head, n - head, k, C.addressof(offs),
+                                           C.addressof(lens), C.addressof(slabs), C.addressof(nsp), C.addressof(sdts), stream),
+                       "rg_grad_to_wire")
+        else:
+            _abi.check(lib.rg_cast_pad(flat.data_ptr() + 4 * head, wire.data_ptr() + 2 * head, 1, n - head, n - head,
+                                       _abi.RG_BF16, stream), "rg_cast_pad")
         works = _launch_buckets(wire[head:], BUCKET_BYTES // 2)
         hog = _hog_start(flat.device) if flat.is_cuda else None
         return (wire, flat, works + ([_HogWork(hog)] if hog is not None else []), head)

@@ -45,7 +45,7 @@ class ConvW:
 
     __slots__ = ("w", "bias", "dw", "dbias", "packs", "packs_version", "version", "layout", "shadow",
                  "shadow_version", "_fp8", "fuse_step", "pending_wgrad", "factor_stage", "owner", "defer_slabs",
-                 "pending_slabs", "_slab_ws")
+                 "pending_slabs", "_slab_ws", "wire_slot")
 
     def __init__(self, w, bias=None, dw=None, dbias=None, layout="OIHW"):
         self.w = w
@@ -66,6 +66,10 @@ class ConvW:
         self.defer_slabs = False
         self.pending_slabs = None
         self._slab_ws = None
+        # data parallel (bf16 wire): the layer's slice of the all-reduce wire buffer, set by the train_op runner together with
+        # defer_slabs -- a weight-gradient launch without split-K writes its bf16 tile there (pending_slabs = (None, -1, 0)), a
+        # split one leaves its slabs for rg_grad_to_wire; no fp32 gradient of the layer is formed in that pass
+        self.wire_slot = None
         # generator layer 0 only (HIP backend): fuse_step -- set by the train_op runner for the duration of one gradient pass
         # whose optimizer step follows immediately -- lets g0_wgrad leave its operands in pending_wgrad instead of writing dw;
         # the fused Adam then forms the gradient and applies the step in one kernel (rg_g0_wgrad_adam)

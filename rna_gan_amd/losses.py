@@ -423,6 +423,60 @@ class _Pending:
         self.module, self.optimizer, self.handle, self.factors = module, optimizer, handle, factors
 
 
+# data parallel, bf16 wire: the 4 x 4 layers' weight gradients go onto the wire without an fp32 gradient in between -- a split-K
+# launch leaves its (bf16) slabs for rg_grad_to_wire, a launch without split-K writes its bf16 tile into the wire slice
+# (ConvW.wire_slot / ops_hip._wgrad_slabs); needs ONE weight-gradient launch per layer and pass (the paired prefix form)
+DP_WIRE_DIRECT = os.environ.get("RNAGAN_DP_WIRE_DIRECT", "1") != "0"
+
+
+def _dp_wire_layers(stepped, optimizer):
+    """[(ConvW, wire slice)] of the stepped module's layers whose weight gradients may bypass the fp32 gradient buffer."""
+    if not (DP_WIRE_DIRECT and SLAB_ADAM and D_.active() and FUSED_WIDEN and DP_PREFIX_MODE == 2) or D_.sync_stats():
+        return []
+    if not hasattr(optimizer, "grad_wire") or getattr(optimizer, "_module", None) is not stepped:
+        return []
+    ops, net = stepped.runtime()
+    if ops.act_dtype != torch.bfloat16 or not isinstance(net, (E.GenNet, E.DiscNet)) or ops.stat_reduce is not None:
+        return []
+    flat = stepped.flat
+    wire = D_.wire_for(flat.grad)
+    if wire is None:
+        return []
+    out = []
+    for cw, _ in net.blocks:
+        off = (cw.w.data_ptr() - flat.data.data_ptr()) // 4
+        n = cw.w.numel()
+        if cw.layout == "OHWI" and off % 8 == 0 and n % 4 == 0 and off >= 0 and off + n <= flat.data.numel():
+            out.append((cw, wire[off:off + n]))
+    return out
+
+
+def _dp_wire_table(stepped, layers, head):
+    """Segment table over flat[head:] from what the pass left on the layers (pending_slabs), or None when nothing was deferred."""
+    flat = stepped.flat
+    rows = []
+    for cw, _ in layers:
+        ps, cw.pending_slabs = cw.pending_slabs, None
+        if ps is not None:
+            rows.append(((cw.w.data_ptr() - flat.data.data_ptr()) // 4, cw.w.numel(), 0 if ps[0] is None else ps[0].data_ptr(),
+                         ps[1], ps[2]))
+    if not rows:
+        return None
+    rows.sort(key=lambda t: t[0])
+    total, pos, table = flat.data.numel(), head, []
+    for off, n, ptr, ns, sdt in rows:
+        if off < pos:
+            raise RuntimeError("rna_gan_amd: a deferred weight gradient overlaps the part of the flat buffer that does not travel "
+                               "on the wire")
+        if off > pos:
+            table.append((pos - head, off - pos, 0, 0, 0))
+        table.append((off - head, n, ptr, ns, sdt))
+        pos = off + n
+    if total > pos:
+        table.append((pos - head, total - pos, 0, 0, 0))
+    return table
+
+
 def _dp_factor_g0(stepped, optimizer, batch):
     """Data parallel: (g0 handle, gathered-factor buffers) when the stepped module's layer-0 weight gradient can travel as
     FACTORS (dist.G0_FACTORS): DCGAN generator stepped by rna_gan_amd.optim.Adam bound to it, bf16 kernels, rank-local
@@ -510,26 +564,42 @@ class _Runner:
         # z / gz0 into this rank's slices of the gathered buffers instead of forming the 67 M-element product
         fac = _dp_factor_g0(stepped, optimizer, inputs[0].shape[0]) if stepped is body.prefix_reads and inputs else None
 
+        wired = _dp_wire_layers(stepped, optimizer)
+        head = fac[0].w.numel() if fac is not None else 0
+
+        def rest_body():
+            for cw, slot in wired:
+                cw.defer_slabs, cw.wire_slot, cw.pending_slabs = True, slot, None
+            try:
+                out = body.rest(holder["pre"])
+                # what the weight-gradient launches of this pass left: kept with the graph this call captures (a replay runs
+                # no host code, its launches are these)
+                holder["wire_table", fac is not None] = _dp_wire_table(stepped, wired, head)
+                return out
+            finally:
+                for cw, _ in wired:
+                    cw.defer_slabs, cw.wire_slot, cw.pending_slabs = False, None, None
+
         def rest():
             if fac is None:
-                return body.rest(holder["pre"])
+                return rest_body()
             g0, bufs = fac[0], fac[1]
             g0.fuse_step, g0.factor_stage = True, (bufs[2], bufs[3])
             try:
-                out = body.rest(holder["pre"])
+                out = rest_body()
                 if g0.pending_wgrad != "staged":
                     raise RuntimeError("data-parallel G step: layer 0's weight gradient was not left as factors")
                 return out
             finally:
                 g0.fuse_step, g0.factor_stage, g0.pending_wgrad = False, None, None
-        sg_rest = self._step_graph(key + ("rest", id(sg_pre), fac is not None), rest, [], modules, [], [])
+        sg_rest = self._step_graph(key + ("rest", id(sg_pre), fac is not None, len(wired)), rest, [], modules, [], [])
         if sg_rest is not None:
             loss = sg_rest(allow_capture=sg_pre is not None and sg_pre.graph is not None)
         else:
             loss = rest()
         ops, _ = stepped.runtime()
-        head = fac[0].w.numel() if fac is not None else 0
-        handle = D_.allreduce_start(stepped.flat.grad, compress=(ops.act_dtype == torch.bfloat16), head=head)
+        handle = D_.allreduce_start(stepped.flat.grad, compress=(ops.act_dtype == torch.bfloat16), head=head,
+                                    table=holder.get(("wire_table", fac is not None)) if wired else None)
         if fac is not None:
             z_all, gy_all, z_mine, gy_mine = fac[1]
             fac = fac + ([D_.allgather_start(z_all, z_mine), D_.allgather_start(gy_all, gy_mine)],)

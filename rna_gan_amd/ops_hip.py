@@ -534,7 +534,15 @@ class HipOps:
         dw = cw.dw
         if cw.w.data_ptr() % 16 or dw.data_ptr() % 16:
             return False
-        if (self.wgrad_in_step and cw.shadow is not None and
+        if cw.wire_slot is not None:
+            if self.lib.rg_conv_wgrad_adam_supported(N, Ho, Wo, O, I, int(low1 is not None), self.dt, self.algo):
+                # data parallel, a plan without split-K: the tile goes onto the wire as bf16, once (rg_conv_wgrad_wire)
+                self._timed("conv_wgrad", flops, lambda: check(
+                    self.lib.rg_conv_wgrad_wire(_ptr(low0), _ptr(high0), _ptr(low1), _ptr(high1), _ptr(cw.wire_slot), N, Ho, Wo,
+                                                O, I, self.dt, self.algo, self.stream), "rg_conv_wgrad_wire"), cw=cw)
+                cw.pending_slabs = (None, -1, 0)
+                return True
+        elif (self.wgrad_in_step and cw.shadow is not None and
                 self.lib.rg_conv_wgrad_adam_supported(N, Ho, Wo, O, I, int(low1 is not None), self.dt, self.algo)):
             # a plan WITHOUT split-K (the two 33.5 M-parameter layers at batch 64): nothing is launched here -- the operands
             # stay on the handle and the optimizer forms the gradient tile and applies its step to it in one launch

@@ -211,7 +211,8 @@ class Adam(torch.optim.Adam):
                     self._v.data_ptr() + 4 * off, self._hyper.data_ptr(), shadow.data_ptr() + 2 * off, N_, Ho_, Wo_, O_, I_, dt,
                     algo, stream), "rg_conv_wgrad_adam")
                 if ops is not None and hasattr(ops, "_timed"):
-                    ops._timed("conv_wgrad", flops, call, cw=cw)       # bench.py's per-family timing sees the launch
+                    # bench.py's per-family timing: a family of its own -- the launch's interval includes the Adam epilogue
+                    ops._timed("conv_wgrad_adam", flops, call, cw=cw)
                 else:
                     call()
                 slab_segs.append((off, cw.w.numel(), None, -1, 0))

@@ -721,3 +721,88 @@ def test_weight_gradient_and_adam_step_in_one_launch(two):
                                   hyper.data_ptr(), 0, N, hs, hs, O, 64, ops.dt, ops.algo, ops.stream) != 0
     assert lib.rg_conv_wgrad_adam(ptr(low0), ptr(high0), ptr(low1), ptr(high1), pd[head:].data_ptr(), md[head + 1:].data_ptr(),
                                   vd[head:].data_ptr(), hyper.data_ptr(), 0, N, hs, hs, O, I, ops.dt, ops.algo, ops.stream) != 0
+
+
+def test_weight_gradients_straight_onto_the_data_parallel_wire():
+    """Round 5: in a data-parallel bf16 run the 4 x 4 layers' weight gradients reach the all-reduce wire without an fp32 gradient
+    in between.  rg_conv_wgrad_wire (a plan without split-K) must equal rg_conv_wgrad + one bf16 rounding bit for bit;
+    rg_grad_to_wire must round plain segments like rg_cast_pad, sum slab segments (fp32 and bf16 slabs) to within one bf16 ulp
+    of the reduced gradient's rounding, and leave skipped segments alone."""
+    import ctypes as C
+    dev = torch.device("cuda:0")
+    ops = HipOps(torch.bfloat16, dev)
+    lib = _abi.load()
+    gen = torch.Generator(device="cpu").manual_seed(53)
+    ptr = lambda t: 0 if t is None else t.data_ptr()
+    # (a) the no-split layer, one and two segments
+    I, O, hs = 1024, 2048, 4
+    nw = O * 16 * I
+    for two in (False, True):
+        low0 = torch.randn(N, hs, hs, O, generator=gen).bfloat16().to(dev)
+        high0 = torch.randn(N, 2 * hs, 2 * hs, I, generator=gen).bfloat16().to(dev)
+        low1 = torch.randn(N, hs, hs, O, generator=gen).bfloat16().to(dev) if two else None
+        high1 = torch.randn(N, 2 * hs, 2 * hs, I, generator=gen).bfloat16().to(dev) if two else None
+        wsb = int(lib.rg_conv_wgrad_workspace_bytes(N, hs, hs, O, I, ops.dt, ops.algo))
+        ws = torch.empty(max(wsb, 256) + 4096, dtype=torch.uint8, device=dev)
+        dw = torch.empty(nw, device=dev)
+        if two:
+            _abi.check(lib.rg_conv_wgrad2(ptr(low0), ptr(high0), ptr(low1), ptr(high1), dw.data_ptr(), N, hs, hs, O, I, ops.dt, 0,
+                                          ops.algo, ws.data_ptr(), ws.numel(), ops.stream), "rg_conv_wgrad2")
+        else:
+            _abi.check(lib.rg_conv_wgrad(ptr(low0), ptr(high0), dw.data_ptr(), N, hs, hs, O, I, ops.dt, 0, ops.algo,
+                                         ws.data_ptr(), ws.numel(), ops.stream), "rg_conv_wgrad")
+        wire = torch.zeros(nw + 8, dtype=torch.bfloat16, device=dev)
+        _abi.check(lib.rg_conv_wgrad_wire(ptr(low0), ptr(high0), ptr(low1), ptr(high1), wire[8:].data_ptr(), N, hs, hs, O, I,
+                                          ops.dt, ops.algo, ops.stream), "rg_conv_wgrad_wire")
+        torch.cuda.synchronize()
+        assert torch.equal(wire[8:], dw.bfloat16()) and float(wire[:8].abs().max()) == 0.0
+        assert lib.rg_conv_wgrad_wire(ptr(low0), ptr(high0), ptr(low1), ptr(high1), wire[1:].data_ptr(), N, hs, hs, O, I, ops.dt,
+                                      ops.algo, ops.stream) != 0          # unaligned slice
+    # (b) the segmented cast: plain / fp32 slabs / bf16 slabs / skipped / plain tail
+    I, O, hs = 256, 512, 16
+    nw = O * 16 * I
+    low0 = torch.randn(N, hs, hs, O, generator=gen).bfloat16().to(dev)
+    high0 = torch.randn(N, 2 * hs, 2 * hs, I, generator=gen).bfloat16().to(dev)
+    wsb = int(lib.rg_conv_wgrad_workspace_bytes(N, hs, hs, O, I, ops.dt, ops.algo))
+    ws = torch.empty(max(wsb, 256) + 4096, dtype=torch.uint8, device=dev)
+    head, skip, tail = 4096, 2048, 1002
+    total = head + nw + nw + skip + tail
+    g = torch.randn(total + 2, generator=gen).to(dev)
+    dw = torch.empty(nw, device=dev)
+    _abi.check(lib.rg_conv_wgrad(ptr(low0), ptr(high0), dw.data_ptr(), N, hs, hs, O, I, ops.dt, 0, ops.algo, ws.data_ptr(),
+                                 ws.numel(), ops.stream), "rg_conv_wgrad")
+    slabs = {}
+    for w16 in (0, 1):
+        _abi.check(lib.rg_set_option(b"wslab16", w16), "set_option")
+        try:
+            buf = torch.empty_like(ws)
+            ns, sdt = C.c_int(0), C.c_int(-1)
+            _abi.check(lib.rg_conv_wgrad_slabs(ptr(low0), ptr(high0), 0, 0, g[head:].data_ptr(), N, hs, hs, O, I, ops.dt, ops.algo,
+                                               buf.data_ptr(), buf.numel(), C.addressof(ns), C.addressof(sdt), ops.stream), "slabs")
+            assert ns.value > 1 and sdt.value == (_abi.RG_BF16 if w16 else _abi.RG_F32)
+            slabs[w16] = (buf, ns.value, sdt.value)
+        finally:
+            lib.rg_set_option(b"wslab16", -1)
+    table = [(0, head, 0, 0, 0), (head, nw, slabs[0][0].data_ptr(), slabs[0][1], slabs[0][2]),
+             (head + nw, nw, slabs[1][0].data_ptr(), slabs[1][1], slabs[1][2]), (head + 2 * nw, skip, 0, -1, 0),
+             (head + 2 * nw + skip, tail, 0, 0, 0)]
+    k = len(table)
+    offs = (C.c_ulonglong * k)(*[t[0] for t in table])
+    lens = (C.c_ulonglong * k)(*[t[1] for t in table])
+    sl = (C.c_void_p * k)(*[t[2] or None for t in table])
+    nsp = (C.c_int * k)(*[t[3] for t in table])
+    sdts = (C.c_int * k)(*[t[4] for t in table])
+    wire = torch.full((total + 2,), 7.0, dtype=torch.bfloat16, device=dev)
+    _abi.check(lib.rg_grad_to_wire(g.data_ptr(), wire.data_ptr(), total, k, C.addressof(offs), C.addressof(lens), C.addressof(sl),
+                                   C.addressof(nsp), C.addressof(sdts), ops.stream), "rg_grad_to_wire")
+    torch.cuda.synchronize()
+    assert torch.equal(wire[:head], g[:head].bfloat16())
+    assert torch.equal(wire[head + 2 * nw + skip:total], g[head + 2 * nw + skip:total].bfloat16())
+    assert float((wire[head + 2 * nw:head + 2 * nw + skip].float() - 7.0).abs().max()) == 0.0        # skipped: untouched
+    assert float((wire[total:].float() - 7.0).abs().max()) == 0.0
+    scale = float(dw.abs().max())
+    e32 = (wire[head:head + nw].float() - dw).abs()
+    e16 = (wire[head + nw:head + 2 * nw].float() - dw).abs()
+    # fp32 slabs: the reduced gradient up to its summation order, rounded once; bf16 slabs: one more rounding per partial sum
+    assert float(e32.max()) <= 2.0 ** -8 * scale and float((e32 / (dw.abs() + 1e-3 * scale)).max()) <= 2.0 ** -7
+    assert float(e16.norm() / dw.norm()) <= 4e-3
