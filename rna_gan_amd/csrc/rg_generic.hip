@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma32_kernel(FA fa, FB fb, SC sc
 // everything else (the 3-column image layers) -- and every bf16-storage launch -- keeps gemm_generic_kernel.  (Its bf16 results
 // are deterministic but NOT pinned bit for bit across rounds: round 4 made the transposed conv's K order tap-major, permuted the
 // G.0 columns and re-associated the split-K slab sums; the bf16 tests compare with tolerances.)
-static bool use_mfma32(bool f32, int M, int N) { return f32 && M >= 64 && N >= 33 && rg_option("f32mma", 1) != 0; }
+static bool use_mfma32(bool f32, int M, int N) { return f32 && M >= 64 && N >= 33 && rg_option("f32mma", RG_F32MMA_DEFAULT) != 0; }
 
 // (defined with gemm_mfma32s_kernel below: launches it and returns true when both operands have a structured form)
 template <bool AK, bool BK, class FA, class FB, class SC>
@@ -1135,12 +1135,167 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma32s_kernel(FA fa, FB fb, SC s
       }
 }
 
+// ----------------------------------------------------------------------------------------------
+// gemm_bf16x3s_kernel: the structured fp32 GEMM above on the BF16 matrix cores (option f32mma = 2).  An fp32 value is the exact
+// sum of three bf16 numbers,  v = h + m + l  (h = bf16(v), m = bf16(v - h), l = bf16(v - h - m): 8 + 8 + 8 significant bits,
+// round-to-nearest each, the residuals are exact in fp32), a product of two bf16 numbers is exact in fp32, and
+//     a b = ah bh + (ah bm + am bh) + (ah bl + al bh + am bm) + [am bl + al bm + al bl: < 2^-23 |a b|, dropped]
+// so SIX v_mfma_f32_32x32x16_bf16 (fp32 accumulate) per 16-deep k-tile and accumulator tile give the fp32 product to fp32
+// rounding accuracy -- 6 x 32 = 192 matrix-pipe cycles where the 8 v_mfma_f32_32x32x2_f32 of the kernel above take 512.
+// Same loads, same slot / segment machinery and store functors; the split happens once per element when a thread stashes
+// its slots (v_cvt_pk_bf16_f32), into three bf16 planes per operand laid out [row][16 k] (32-byte rows: a fragment is one
+// ds_read_b128 per plane, contiguous over the wave).  An m-fast operand's thread holds NS CONSECUTIVE k of one row (one 8- or
+// 16-byte LDS store per plane), a k-fast operand's thread one k of NS rows (2-byte stores, contiguous over the wave).
+// Not bit-identical to the f32 MFMA chain (neither is that to the vector-ALU kernel: summation order); tested to the same
+// tolerances.  MEASURED: the wave's issue port, not the matrix pipe, then paces the loop -- per k-tile and wave ~150
+// vector instructions (the split is 7 of them per element) + 60 LDS instructions + 24 MFMAs x 8 issue cycles, summed over the two
+// waves of a SIMD -- so the 128 x 128 tile gains 10-25 % (586 -> 442 us on the 64 -> 128 channel layer) instead of the 2.6 x of
+// the matrix pipe, and the 64 x 64 tile (6 MFMAs per k-tile) LOSES 30-40 %: the option routes only the large tile here.  Variants
+// measured and dropped: a truncating split with all nine plane products (exact product; 504 us: more MFMA issue slots), the same
+// with eight products, two register sets and the split interleaved between the MFMAs by sched_group_barrier (475 us).
+// ----------------------------------------------------------------------------------------------
+typedef __bf16 bx_bf16x8 __attribute__((ext_vector_type(8)));
+struct BxSplit { unsigned short h, m, l; };
+__device__ __forceinline__ BxSplit bx_split(float v) {
+  const __bf16 h = (__bf16)v;                   // v_cvt_pk_bf16_f32: round to nearest even
+  const float r1 = v - (float)h;
+  const __bf16 m = (__bf16)r1;
+  const float r2 = r1 - (float)m;
+  const __bf16 l = (__bf16)r2;
+  return {__builtin_bit_cast(unsigned short, h), __builtin_bit_cast(unsigned short, m), __builtin_bit_cast(unsigned short, l)};
+}
+
+template <int TM, int TN, bool A_KFAST, bool B_KFAST, class FA, class FB, class SC>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3s_kernel(FA fa, FB fb, SC sc, int M, int N, int K, int lgb, int klen) {
+  constexpr int BM = 2 * TM, BN = 2 * TN, IA = TM / 32, IB = TN / 32;
+  constexpr int NSA = BM * MB_K / 256, NSB = BN * MB_K / 256;
+  constexpr int RP = 256 / MB_K;
+  constexpr unsigned TAIL = 0x100u;
+  static_assert(MB_K == 16, "one v_mfma_f32_32x32x16_bf16 per k-tile and plane pair");
+  __shared__ __attribute__((aligned(16))) unsigned short Ap[2][3][BM][MB_K];
+  __shared__ __attribute__((aligned(16))) unsigned short Bp[2][3][BN][MB_K];
+  using SA = SOp<FA>;
+  using SB = SOp<FB>;
+  const int bm = blockIdx.x * BM, bn = blockIdx.y * BN;
+  const int zb = blockIdx.z & ((1 << lgb) - 1), zs = blockIdx.z >> lgb;
+  const int k_begin = zs * klen;
+  const int k_end = min(K, k_begin + klen);
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  mb_f32x16 acc[IA][IB];
+#pragma unroll
+  for (int i = 0; i < IA; ++i)
+#pragma unroll
+    for (int j = 0; j < IB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int ktail = K & (MB_K - 1);
+  SSlot sla[NSA], slb[NSB];
+#pragma unroll
+  for (int i = 0; i < NSA; ++i) {
+    const int mm = A_KFAST ? tid / MB_K + RP * i : (tid & (BM - 1));
+    const int ks = A_KFAST ? (tid & (MB_K - 1)) : (tid / BM) * NSA + i;       // m-fast: NSA consecutive k of one row
+    const bool ok = bm + mm < M;
+    sla[i] = SA::slot(fa, zb, ok ? bm + mm : 0, ok, ks);
+    sla[i].m |= ((int)(ktail != 0) & (int)(ks >= ktail)) ? TAIL : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < NSB; ++i) {
+    const int nn = B_KFAST ? tid / MB_K + RP * i : (tid & (BN - 1));
+    const int ks = B_KFAST ? (tid & (MB_K - 1)) : (tid / BN) * NSB + i;
+    const bool ok = bn + nn < N;
+    slb[i] = SB::slot(fb, zb, ok ? bn + nn : 0, ok, ks);
+    slb[i].m |= ((int)(ktail != 0) & (int)(ks >= ktail)) ? TAIL : 0u;
+  }
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)SA::ptr(fa), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)SB::ptr(fb), 0, 0x7ffffff0, 0x00020000);
+  unsigned voa[NSA], vob[NSB];
+  float ra[NSA], rb[NSB];
+  int ida = -1, idb = -1;
+  auto issue = [&](int k0) __attribute__((always_inline)) {
+    const bool tail = k0 + MB_K > K;                      // uniform
+    SSeg ua, ub;
+    SA::seg(fa, zb, k0, ua);
+    SB::seg(fb, zb, k0, ub);
+    if (tail) { ua.id |= 0x40000000; ua.f |= TAIL; ub.id |= 0x40000000; ub.f |= TAIL; }
+    if (ua.id != ida) {
+      ida = ua.id;
+#pragma unroll
+      for (int i = 0; i < NSA; ++i) voa[i] = (unsigned)(sla[i].base + ua.add) | (min(sla[i].m & ua.f, 1u) << 31);
+    }
+    if (ub.id != idb) {
+      idb = ub.id;
+#pragma unroll
+      for (int i = 0; i < NSB; ++i) vob[i] = (unsigned)(slb[i].base + ub.add) | (min(slb[i].m & ub.f, 1u) << 31);
+    }
+#pragma unroll
+    for (int i = 0; i < NSA; ++i) ra[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsa, (int)voa[i], (int)ua.so, 0));
+#pragma unroll
+    for (int i = 0; i < NSB; ++i) rb[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsb, (int)vob[i], (int)ub.so, 0));
+  };
+  auto stash = [&](int st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NSA; ++i) {
+      const BxSplit q = bx_split(ra[i]);
+      const int row = A_KFAST ? tid / MB_K + RP * i : (tid & (BM - 1)), k = A_KFAST ? (tid & (MB_K - 1)) : (tid / BM) * NSA + i;
+      Ap[st][0][row][k] = q.h; Ap[st][1][row][k] = q.m; Ap[st][2][row][k] = q.l;
+    }
+#pragma unroll
+    for (int i = 0; i < NSB; ++i) {
+      const BxSplit q = bx_split(rb[i]);
+      const int row = B_KFAST ? tid / MB_K + RP * i : (tid & (BN - 1)), k = B_KFAST ? (tid & (MB_K - 1)) : (tid / BN) * NSB + i;
+      Bp[st][0][row][k] = q.h; Bp[st][1][row][k] = q.m; Bp[st][2][row][k] = q.l;
+    }
+  };
+  if (k_begin < k_end) { issue(k_begin); stash(0); }
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = k_begin; k0 < k_end; k0 += MB_K) {
+    const bool more = k0 + MB_K < k_end;
+    if (more) issue(k0 + MB_K);                    // global loads of the next k-tile fly under this tile's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    bx_bf16x8 a[3][IA], b[3][IB];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < IA; ++i) a[p][i] = *reinterpret_cast<const bx_bf16x8*>(&Ap[cur][p][wm * TM + 32 * i + lr][lh * 8]);
+#pragma unroll
+      for (int j = 0; j < IB; ++j) b[p][j] = *reinterpret_cast<const bx_bf16x8*>(&Bp[cur][p][wn * TN + 32 * j + lr][lh * 8]);
+    }
+    // smallest terms first; the IA x IB accumulators between two uses of the same one keep the matrix pipe fed
+#define BX_PAIR(PA, PB)                                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < IA; ++i) _Pragma("unroll") for (int j = 0; j < IB; ++j)                          \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][i], b[PB][j], acc[i][j], 0, 0, 0)
+    BX_PAIR(1, 1); BX_PAIR(2, 0); BX_PAIR(0, 2); BX_PAIR(1, 0); BX_PAIR(0, 1); BX_PAIR(0, 0);
+#undef BX_PAIR
+    __builtin_amdgcn_sched_barrier(0);             // the loads stay above the MFMAs, their first use (the stash) below
+    if (more) stash(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < IA; ++i)
+#pragma unroll
+    for (int j = 0; j < IB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = bm + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, n = bn + wn * TN + j * 32 + lr;
+        if (m < M && n < N) sc(zb, zs, m, n, acc[i][j][r]);
+      }
+}
+
 template <bool AK, bool BK, class FA, class FB, class SC>
 static bool launch_structured(const char* name, FA fa, FB fb, SC sc, int M, int N, int K, int nbatch, int klen, dim3 grid,
                               bool small, hipStream_t st) {
   if constexpr (SOp<FA>::OK && SOp<FB>::OK) {
     if (SOp<FA>::ok(fa, M, K) && SOp<FB>::ok(fb, N, K) && lg1(nbatch)) {
       const int lgb = lg1(nbatch) - 1;
+      if (!small && rg_option("f32mma", RG_F32MMA_DEFAULT) == 2) {      // each product as six bf16 matrix-core products
+        hipLaunchKernelGGL((gemm_bf16x3s_kernel<64, 64, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, lgb, klen);
+        return true;
+      }
       if (small) hipLaunchKernelGGL((gemm_mfma32s_kernel<32, 32, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, lgb, klen);
       else hipLaunchKernelGGL((gemm_mfma32s_kernel<64, 64, AK, BK, FA, FB, SC>), grid, dim3(256), 0, st, fa, fb, sc, M, N, K, lgb, klen);
       return true;
@@ -1191,7 +1346,7 @@ bool rg_generic_f32_image_side(int N, int H, int W, int I, int O) {
 #ifdef RG_F32_IMAGE_VALU       // (A/B builds)
   return false;
 #endif
-  return rg_option("f32mma", 1) != 0 && lg1(H / 2) && lg1(W / 2) && W / 2 >= MB_K && O >= 33 && (long long)N * (H / 2) * (W / 2) >= 64 &&
+  return rg_option("f32mma", RG_F32MMA_DEFAULT) != 0 && lg1(H / 2) && lg1(W / 2) && W / 2 >= MB_K && O >= 33 && (long long)N * (H / 2) * (W / 2) >= 64 &&
          (long long)N * I * H * W < (1ll << 29);
 }
 

@@ -133,7 +133,9 @@ def test_conv_down_up_wgrad(N, Hi, Wi, I, O, dtype):
 def test_f32_matrix_core_gemm_matches_vector_kernel(N, Hi, Wi, I, O):
     """fp32 mode: the f32-MFMA GEMM skeleton (option f32mma = 1, default) against the vector-ALU skeleton (f32mma = 0) through
     the same operand functors -- conv forward, transposed conv, weight gradient, generator layer 0 and a dense layer.  Both
-    are fused-multiply-add chains in fp32; only the association of the k-loop differs (two interleaved k per MFMA step)."""
+    are fused-multiply-add chains in fp32; only the association of the k-loop differs (two interleaved k per MFMA step).
+    f32mma = 2 (opt-in): the 128 x 128-tile launches form every fp32 product as six bf16 matrix-core products of the operands'
+    exact three-way bf16 splits (gemm_bf16x3s_kernel; < 2^-25 relative per product, fp32 accumulation) -- same bound."""
     from rna_gan_amd import _abi
     hip = _hip(torch.float32)
     lib = hip.lib
@@ -144,7 +146,7 @@ def test_f32_matrix_core_gemm_matches_vector_kernel(N, Hi, Wi, I, O):
     lx, lw = dev(rnd((200, 300), 7)), dev(rnd((150, 300), 8, 0.05))
     outs = {}
     try:
-        for on in (0, 1):
+        for on in (0, 1, 2):
             _abi.check(lib.rg_set_option(b"f32mma", on), "rg_set_option")
             _, ch = cwpair_tm(w)
             _, c0 = cwpair(w0)
@@ -157,6 +159,10 @@ def test_f32_matrix_core_gemm_matches_vector_kernel(N, Hi, Wi, I, O):
         lib.rg_set_option(b"f32mma", -1)
     for name, a, b in zip(("conv_down", "conv_up", "conv_wgrad", "g0_fwd", "g0_wgrad", "linear"), outs[1], outs[0]):
         check(a, b, 2e-6, name)
+    for name, a, b in zip(("conv_down", "conv_up", "conv_wgrad", "g0_fwd", "g0_wgrad", "linear"), outs[2], outs[0]):
+        # (one MFMA adds 16 k positions x 6 plane products into the accumulator: a coarser association than the f32 chain's
+        # two k per step -- measured 2.1e-6 at K = 1024, the 128 x 128-tile case)
+        check(a, b, 4e-6, name + " (six bf16 products)")
 
 
 CONV8_CASES = [
