@@ -194,3 +194,33 @@ def test_check_handoffs_is_rank_collective():
         assert p.exitcode == 0
     for r in range(world):
         assert got[r] == {"raised": True, "rearmed": True, "poll_raised": True}, (r, got[r])
+
+
+def test_dp_wire_table_tiles_the_travelling_part_of_the_flat_buffer():
+    """Host logic of the data-parallel wire-direct route (losses._dp_wire_table): what the weight-gradient launches of a pass left
+    on the layer handles -- split-K slabs (buffer, nsplit, dtype) or a slice already written to the wire (None, -1, 0) -- becomes
+    a segment table that tiles flat[head:] in order, plain ranges in between; layers that left nothing stay plain; the handles
+    are cleared."""
+    from rna_gan_amd import losses as PL
+
+    flat = torch.zeros(10000)
+
+    class CW:
+        def __init__(self, off, n, pending):
+            self.w = flat[off:off + n]
+            self.pending_slabs = pending
+
+    class Stepped:
+        pass
+    st = Stepped()
+    st.flat = type("F", (), {"data": flat})()
+    slab = torch.zeros(64)
+    a, b, c = CW(1000, 2000, (slab, 8, 1)), CW(4000, 1000, None), CW(6000, 3000, (None, -1, 0))
+    table = PL._dp_wire_table(st, [(a, None), (b, None), (c, None)], head=400)
+    assert table == [(0, 600, 0, 0, 0), (600, 2000, slab.data_ptr(), 8, 1), (2600, 3000, 0, 0, 0), (5600, 3000, 0, -1, 0),
+                     (8600, 1000, 0, 0, 0)]
+    assert sum(r[1] for r in table) == flat.numel() - 400 and all(x.pending_slabs is None for x in (a, b, c))
+    assert PL._dp_wire_table(st, [(a, None), (b, None)], head=0) is None            # nothing pending: the plain cast pass
+    a.pending_slabs = (slab, 4, 0)
+    with pytest.raises(RuntimeError):
+        PL._dp_wire_table(st, [(a, None)], head=2000)                                # a deferred layer inside the factor head
