@@ -904,8 +904,42 @@ def extra_fp32_step(args, device, info, steps=4, warm=10):
                                                  "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 1) if v[2] > 0 else None}
                                              for k, v in fam.items()}}
     PL.new_batch()
-    del G, Dm, og, od, lg, ld, lp
+    del G, Dm, og, od, lg, ld, lp, it
     torch.cuda.empty_cache()
+    # the opt-in form of the same mode (option f32mma = 2: each fp32 product of the 128 x 128-tile launches as six bf16
+    # matrix-core products of exact three-way bf16 splits, gemm_bf16x3s_kernel): a fresh workload, so that its graphs capture it
+    try:
+        from rna_gan_amd import _abi
+        lib = _abi.load()
+        _abi.check(lib.rg_set_option(b"f32mma", 2), "rg_set_option")
+        try:
+            G, Dm, og, od, (lg, ld, lp) = build(device, "fp32", N, 19198, args.seed)
+
+            def it2():
+                PL.new_batch()
+                us = [torch.empty(N, 2048).uniform_(-0.3, 0.3, generator=gen).to(device) for _ in range(3)]
+                eps = torch.empty(1).uniform_(0.0, 1.0, generator=gen).to(device)
+                return [lg.step(G, Dm, og, h["rna"], us[0]), ld.step(G, Dm, od, h["real"], h["rna"], us[1], next_u=us[2]),
+                        lp.step(G, Dm, od, h["real"], h["rna"], us[2], eps)]
+            for _ in range(warm):
+                it2()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                ls = it2()
+            torch.cuda.synchronize(device)
+            dt2 = (time.perf_counter() - t0) / steps
+            res["f32mma2"] = {"ms_per_step": round(dt2 * 1e3, 2), "imgs_per_sec": round(N / dt2, 1),
+                              "losses": [round(float(l.item()), 5) for l in ls],
+                              "kernels": "RNAGAN_F32MMA=2 (opt-in): 128 x 128-tile fp32 GEMMs as six v_mfma_f32_32x32x16_bf16 per "
+                                         "k-tile on exact three-way bf16 splits of both operands"}
+            PL.new_batch()
+            del G, Dm, og, od, lg, ld, lp, it2
+        finally:
+            lib.rg_set_option(b"f32mma", -1)
+            torch.cuda.empty_cache()
+    except Exception as e:                                   # an extra never takes the headline down
+        res["f32mma2"] = {"error": repr(e)[:200]}
     return res
 
 

@@ -207,6 +207,13 @@ int rg_last_up_pre(const void* z, const float* w, const float* bias, float* y_nc
 size_t rg_skinny_wgrad_workspace_bytes(int N, int Ho, int Wo, int O, int I);
 int rg_skinny_wgrad(const void* low, const float* high_nchw, float* dw, int N, int Ho, int Wo, int O, int I,
                     int dtype, int accumulate, void* ws, size_t ws_bytes, void* stream);
+/* rg_skinny_wgrad with the reduction of its per-workgroup partial gradients LEFT to the optimizer step that follows at once
+ * (src/wgan_loss.py:126-127, :260-261, :387-388): `slab` receives *nslab_out fp32 slabs of O * 48 elements in dw's layout
+ * (at most rg_skinny_wgrad_workspace_bytes), to be handed to rg_adam_step_slabs as that tensor's segment; a second contribution
+ * to the same tensor (D(real) + D(fake), primal + tangent) is a second call with `slab` advanced by the first call's slabs.
+ * *nslab_out = 0: this shape / dtype has no such form and nothing was launched. */
+int rg_skinny_wgrad_slabs(const void* low, const float* high_nchw, int N, int Ho, int Wo, int O, int I, int dtype, void* slab,
+                          size_t slab_bytes, int* nslab_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense layers: generator layer 0 (K4), discriminator head (K5), betaVAE encoder (K8)

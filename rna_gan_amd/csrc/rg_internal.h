@@ -166,5 +166,7 @@ int rg_skinny_last_up_post_blocks(int N, int Ho, int Wo, int O, int dtype);
 int rg_skinny_lu_part_final(const float* part, int nb, float* out, int accumulate, int mode, float* loss, float* coef,
                             float lambd, hipStream_t st);
 size_t rg_skinny_wgrad_ws_bytes(int N, int Ho, int Wo, int O, int I);
+int rg_skinny_wgrad_slabs_impl(const void* low, const float* high_nchw, int N, int Ho, int Wo, int O, int I, int dtype,
+                               void* slab, size_t slab_bytes, int* nslab_out, hipStream_t st);
 int rg_skinny_wgrad_impl(const void* low, const float* high_nchw, float* dw, int N, int Ho, int Wo, int O, int I,
                          int dtype, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);

@@ -1457,6 +1457,34 @@ size_t rg_skinny_wgrad_ws_bytes(int N, int Ho, int Wo, int O, int I) {
   return (size_t)nb * O * SK_K * sizeof(float);
 }
 
+// The row-kernel form with the per-workgroup partial gradients LEFT in `slab` ([*nslab_out][O * 48] fp32, the layout of dw): the
+// caller's optimizer step sums them (rg_adam_step_slabs).  *nslab_out = 0: this shape / dtype has no such form, nothing was
+// launched.
+int rg_skinny_wgrad_slabs_impl(const void* low, const float* high_nchw, int N, int Ho, int Wo, int O, int I, int dtype,
+                               void* slab, size_t slab_bytes, int* nslab_out, hipStream_t st) {
+  (void)I;
+  *nslab_out = 0;
+  const size_t elems = (size_t)O * SK_K;
+  const long long npix = (long long)N * Ho * Wo;
+  int chunk;
+  if (!(dtype == RG_BF16 && O == 64 && sk_rows_chunk(Wo, &chunk) && npix / chunk < 0x7fffffff)) return RG_OK;
+  const int nunits = (int)(npix / chunk);
+  int nbm = nunits < SK_ROWS_BLOCKS ? nunits : SK_ROWS_BLOCKS;
+  if (sk_rows128(2 * Ho, 2 * Wo)) {
+    if (nbm > 512) nbm = 512;
+    RG_REQUIRE(slab && slab_bytes >= (size_t)nbm * elems * sizeof(float), RG_EWORKSPACE, "skinny_wgrad_slabs: buffer too small");
+    hipLaunchKernelGGL(skinny_wgrad_rows128_kernel, dim3(nbm), dim3(256), 0, st, (const uint16_t*)low, high_nchw, (float*)slab,
+                       nunits);
+  } else {
+    RG_REQUIRE(slab && slab_bytes >= (size_t)nbm * elems * sizeof(float), RG_EWORKSPACE, "skinny_wgrad_slabs: buffer too small");
+    hipLaunchKernelGGL(skinny_wgrad_rows_kernel, dim3(nbm), dim3(256), 0, st, (const uint16_t*)low, high_nchw, (float*)slab, N,
+                       2 * Ho, 2 * Wo, chunk, nunits);
+  }
+  RG_LAUNCH_CHECK("skinny_wgrad_slabs");
+  *nslab_out = nbm;
+  return RG_OK;
+}
+
 int rg_skinny_wgrad_impl(const void* low, const float* high_nchw, float* dw, int N, int Ho, int Wo, int O, int I,
                          int dtype, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
   (void)I;

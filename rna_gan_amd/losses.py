@@ -367,6 +367,11 @@ def _dispatch(runner, key, body, inputs, generator, discriminator, stepped, opti
         deferred = _slab_layers(stepped, optimizer)
         for cw in deferred:
             cw.defer_slabs = True        # ... and the split-K weight gradients of its 4 x 4 layers may stay unreduced slabs
+        sk = _skinny_slab_layer(stepped, optimizer)
+        ops_s = stepped.runtime()[0] if sk is not None else None
+        if sk is not None:
+            sk.pending_slabs = None
+            ops_s._skinny_defer = {sk.dw.data_ptr(): sk}      # ... and the image-side layer's per-workgroup partials too
         try:
             loss = body.grads(*a)
         finally:
@@ -374,6 +379,8 @@ def _dispatch(runner, key, body, inputs, generator, discriminator, stepped, opti
                 g0.fuse_step = False
             for cw in deferred:
                 cw.defer_slabs = False
+            if sk is not None:
+                ops_s._skinny_defer = None
         _finish(stepped, optimizer)
         return loss
     return runner.run(key, full, inputs, mods, [optimizer])
@@ -392,6 +399,24 @@ def _slab_layers(stepped, optimizer):
     if ops.act_dtype != torch.bfloat16 or not isinstance(net, (E.GenNet, E.DiscNet)) or ops.stat_reduce is not None:
         return []
     return [b[0] for b in net.blocks]
+
+
+SKINNY_SLAB_ADAM = os.environ.get("RNAGAN_SKINNY_SLAB_ADAM", "1") != "0"
+
+
+def _skinny_slab_layer(stepped, optimizer):
+    """The stepped network's image-side 4 x 4 layer (D's first conv / G's last transposed conv: 64 <-> 3 channels, PyTorch-layout
+    weight) when its weight gradient's per-workgroup partials may stay unreduced for the optimizer step (conditions of
+    _slab_layers; the tensor must sit 16-byte aligned in the flat buffer)."""
+    if not SKINNY_SLAB_ADAM or not _slab_layers(stepped, optimizer):
+        return None
+    _, net = stepped.runtime()
+    cw = net.conv0 if isinstance(net, E.DiscNet) else net.last
+    flat = stepped.flat
+    off = (cw.w.data_ptr() - flat.data.data_ptr()) // 4
+    if cw.dw is None or not cw.w.is_contiguous() or off % 4 or cw.w.numel() % 4 or cw.w.shape[0] != 64:
+        return None
+    return cw
 
 
 G0_ADAM = os.environ.get("RNAGAN_G0_ADAM", "1") != "0"

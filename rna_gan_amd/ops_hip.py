@@ -143,6 +143,9 @@ class HipOps:
         self.pack_from_shadow = os.environ.get("RNAGAN_PACK_FROM_SHADOW", "1") != "0"
         # a deferred weight gradient without split-K is formed AND stepped by one launch of the optimizer (rg_conv_wgrad_adam)
         self.wgrad_in_step = os.environ.get("RNAGAN_WGRAD_ADAM", "1") != "0"
+        # {dw address: ConvW} of the image-side layers whose weight-gradient partials the optimizer sums (set by the train_op runner
+        # for the duration of one gradient pass, with ConvW.defer_slabs)
+        self._skinny_defer = None
         self.epilogue_stats = os.environ.get("RNAGAN_EPILOGUE_STATS", "1") != "0"
         # synchronised (global-batch) statistics in a data-parallel run (dist.attach_sync): an in-place SUM all-reduce
         # for small fp32 tensors and the number of ranks; None = rank-local statistics (plain DDP semantics)
@@ -797,6 +800,27 @@ class HipOps:
         I = high_nchw.shape[1]
         assert high_nchw.dtype == torch.float32 and high_nchw.is_contiguous() and low.is_contiguous()
         nb = self.lib.rg_skinny_wgrad_workspace_bytes(N, Ho, Wo, O, I)
+        cw = self._skinny_defer.get(dw.data_ptr()) if self._skinny_defer else None
+        if cw is not None and self.dt == RG_BF16 and self.stat_reduce is None and not self._in_side:
+            # the optimizer step follows at once (the train_op runner registered the layer): the per-workgroup partial gradients
+            # stay in a buffer of the layer's own -- a second contribution (accumulate) behind the first one's -- and Adam sums them
+            prev = cw.pending_slabs
+            if (prev is None) == bool(accumulate):
+                raise RuntimeError("rna_gan_amd: deferred image-side weight gradient: contributions out of order")
+            have = 0 if prev is None else prev[1]
+            if cw._slab_ws is None or cw._slab_ws.numel() < 2 * nb + 4096:
+                if prev is not None:
+                    raise RuntimeError("rna_gan_amd: deferred image-side weight gradient: the slab buffer grew between two contributions")
+                cw._slab_ws = torch.empty(2 * nb + 4096, dtype=torch.uint8, device=self.device)     # persistent: graphs hold its address
+            off = have * O * 48 * 4
+            ns = ctypes.c_int(0)
+            check(self.lib.rg_skinny_wgrad_slabs(_ptr(low), _ptr(high_nchw), N, Ho, Wo, O, I, self.dt, cw._slab_ws.data_ptr() + off,
+                                                 cw._slab_ws.numel() - off, ctypes.addressof(ns), self.stream), "rg_skinny_wgrad_slabs")
+            if ns.value > 0:
+                cw.pending_slabs = (cw._slab_ws, have + int(ns.value), RG_F32)
+                return
+            if prev is not None:
+                raise RuntimeError("rna_gan_amd: deferred image-side weight gradient: the second contribution has no slab form")
         ws = self._ws(nb)
         check(self.lib.rg_skinny_wgrad(_ptr(low), _ptr(high_nchw), _ptr(dw), N, Ho, Wo, O, I, self.dt,
                                        int(accumulate), _ptr(ws), ws.numel(), self.stream), "rg_skinny_wgrad")

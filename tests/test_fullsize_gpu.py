@@ -806,3 +806,75 @@ def test_weight_gradients_straight_onto_the_data_parallel_wire():
     # fp32 slabs: the reduced gradient up to its summation order, rounded once; bf16 slabs: one more rounding per partial sum
     assert float(e32.max()) <= 2.0 ** -8 * scale and float((e32 / (dw.abs() + 1e-3 * scale)).max()) <= 2.0 ** -7
     assert float(e16.norm() / dw.norm()) <= 4e-3
+
+
+def test_image_side_weight_gradient_partials_inside_the_adam_step():
+    """Round 5: the image-side layers' weight gradient (rg_skinny_wgrad: 512 per-workgroup partial gradients + a reduction launch)
+    with the partials LEFT for the optimizer step (rg_skinny_wgrad_slabs -> rg_adam_step_slabs), two contributions to one tensor
+    (D(real) + D(fake); primal + tangent) as one run of 1024 slabs: against rg_skinny_wgrad twice (accumulate) + rg_adam_step_dev."""
+    import ctypes as C
+    dev = torch.device("cuda:0")
+    ops = HipOps(torch.bfloat16, dev)
+    lib = _abi.load()
+    gen = torch.Generator(device="cpu").manual_seed(61)
+    O, I, S = 64, 3, 256
+    xs = [torch.randn(N, I, S, S, generator=gen).to(dev) for _ in range(2)]
+    gs = [torch.randn(N, S // 2, S // 2, O, generator=gen).bfloat16().to(dev) for _ in range(2)]
+    nw = O * I * 16
+    wsb = int(lib.rg_skinny_wgrad_workspace_bytes(N, S // 2, S // 2, O, I))
+    ws = torch.empty(wsb + 4096, dtype=torch.uint8, device=dev)
+    head, tail = 1024, 500
+    total = head + nw + tail
+    p0 = torch.randn(total, generator=gen).to(dev) * 0.05
+    g0 = torch.randn(total, generator=gen).to(dev) * 0.01
+    m0 = torch.randn(total, generator=gen).to(dev) * 0.01
+    v0 = torch.rand(total, generator=gen).to(dev) * 1e-4
+    hyper = torch.zeros(8, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    _abi.check(lib.rg_adam_hyper_dev(step.data_ptr(), 4e-4, 0.5, 0.999, 1e-8, 0.0, hyper.data_ptr(), ops.stream), "hyper")
+    # reference: reduced gradient (two contributions), plain step
+    pr, gr, mr, vr = p0.clone(), g0.clone(), m0.clone(), v0.clone()
+    shr = torch.zeros(total, dtype=torch.bfloat16, device=dev)
+    for k in range(2):
+        _abi.check(lib.rg_skinny_wgrad(gs[k].data_ptr(), xs[k].data_ptr(), gr[head:].data_ptr(), N, S // 2, S // 2, O, I, ops.dt, k,
+                                       ws.data_ptr(), ws.numel(), ops.stream), "rg_skinny_wgrad")
+    _abi.check(lib.rg_adam_step_dev(pr.data_ptr(), gr.data_ptr(), mr.data_ptr(), vr.data_ptr(), total, hyper.data_ptr(),
+                                    shr.data_ptr(), 0, ops.stream), "rg_adam_step_dev")
+    # deferred
+    pd, gd, md, vd = p0.clone(), g0.clone(), m0.clone(), v0.clone()
+    gd[head:head + nw].fill_(float("nan"))
+    shd = torch.zeros(total, dtype=torch.bfloat16, device=dev)
+    slab = torch.empty(2 * wsb + 4096, dtype=torch.uint8, device=dev)
+    have = 0
+    for k in range(2):
+        ns = C.c_int(0)
+        off = have * nw * 4
+        _abi.check(lib.rg_skinny_wgrad_slabs(gs[k].data_ptr(), xs[k].data_ptr(), N, S // 2, S // 2, O, I, ops.dt,
+                                             slab.data_ptr() + off, slab.numel() - off, C.addressof(ns), ops.stream), "slabs")
+        assert ns.value > 0
+        have += ns.value
+    print("image-side weight gradient: %d partial slabs of %d elements" % (have, nw))
+    table = [(0, head, 0, 0, 0), (head, nw, slab.data_ptr(), have, _abi.RG_F32), (head + nw, tail, 0, 0, 0)]
+    k = len(table)
+    offs = (C.c_ulonglong * k)(*[t[0] for t in table])
+    lens = (C.c_ulonglong * k)(*[t[1] for t in table])
+    sl = (C.c_void_p * k)(*[t[2] or None for t in table])
+    nsp = (C.c_int * k)(*[t[3] for t in table])
+    sdts = (C.c_int * k)(*[t[4] for t in table])
+    _abi.check(lib.rg_adam_step_slabs(pd.data_ptr(), gd.data_ptr(), md.data_ptr(), vd.data_ptr(), total, hyper.data_ptr(),
+                                      shd.data_ptr(), k, C.addressof(offs), C.addressof(lens), C.addressof(sl), C.addressof(nsp),
+                                      C.addressof(sdts), ops.stream), "rg_adam_step_slabs")
+    torch.cuda.synchronize()
+    for a, b in ((pr, pd), (mr, md), (vr, vd)):
+        assert torch.equal(a[:head], b[:head]) and torch.equal(a[head + nw:], b[head + nw:])
+    sl_ = slice(head, head + nw)
+    gscale = float((mr[sl_] - 0.5 * m0[sl_]).abs().max())
+    assert float((mr[sl_] - md[sl_]).abs().max()) <= 2e-5 * gscale
+    assert float((vr[sl_] - vd[sl_]).abs().max()) <= 1e-4 * float(vr[sl_].abs().max())
+    assert float((pr[sl_] - pd[sl_]).abs().max()) <= 2e-2 * float((pr[sl_] - p0[sl_]).abs().max())
+    assert torch.equal(shd, pd.bfloat16())
+    # the 64 x 64 generic shape has no slab form: nothing launched, 0 reported
+    ns = C.c_int(7)
+    _abi.check(lib.rg_skinny_wgrad_slabs(gs[0].data_ptr(), xs[0].data_ptr(), N, S // 2, S // 2, O, I, _abi.RG_F32, slab.data_ptr(),
+                                         slab.numel(), C.addressof(ns), ops.stream), "slabs(f32)")
+    assert ns.value == 0
