@@ -213,7 +213,15 @@ int rg_skinny_wgrad(const void* low, const float* high_nchw, float* dw, int N, i
  * to the same tensor (D(real) + D(fake), primal + tangent) is a second call with `slab` advanced by the first call's slabs.
  * *nslab_out = 0: this shape / dtype has no such form and nothing was launched. */
 int rg_skinny_wgrad_slabs(const void* low, const float* high_nchw, int N, int Ho, int Wo, int O, int I, int dtype, void* slab,
-                          size_t slab_bytes, int* nslab_out, void* stream);
+                          size_t slab_bytes, int* nslab_out, float* bias_slab, int* bias_done_out, void* stream);
+/* rg_skinny_wgrad that also forms the layer's bias gradient dbias[O] = sum over the pixels of `low` (what autograd adds to
+ * Conv2d(3, 64).bias.grad, histopathology_gan.py:186-192) as a by-product of its pass over `low` where the kernel can (a column of
+ * ones in the patch operand of the 256 x 256 bf16 row kernel): *bias_done_out = 1; otherwise 0 and dbias is untouched (rg_col_sum
+ * then).  bias_accumulate: add to dbias.  rg_skinny_wgrad_slabs' bias_slab / bias_done_out: the same by-product as partials
+ * [*nslab_out][O] for the optimizer step (a segment of rg_adam_step_slabs). */
+int rg_skinny_wgrad_bias(const void* low, const float* high_nchw, float* dw, float* dbias, int N, int Ho, int Wo, int O, int I,
+                         int dtype, int accumulate, int bias_accumulate, void* ws, size_t ws_bytes, int* bias_done_out,
+                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense layers: generator layer 0 (K4), discriminator head (K5), betaVAE encoder (K8)

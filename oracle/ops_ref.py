@@ -165,12 +165,13 @@ class RefOps:
     def gp_coef_parts(self, parts, lambd: float):
         return self.gp_coef(parts[:, 3].sum().reshape(1), lambd)
 
-    def skinny_wgrad(self, low, high_nchw, dw, accumulate: bool):
+    def skinny_wgrad(self, low, high_nchw, dw, accumulate: bool, dbias=None, dbias_accumulate=False):
         g = torch.nn.grad.conv2d_weight(high_nchw.to(self.f), dw.shape, self._nchw(low), stride=2, padding=1)
         if accumulate:
             dw.add_(g)
         else:
             dw.copy_(g)
+        return False          # the bias gradient is not formed here: the engine calls col_sum
 
     # ------------------------------------------------------------------ G.0 / head
     def g0_fwd(self, z, cw: ConvW):

@@ -47,7 +47,8 @@ PROTOTYPES = {
     "rg_last_up": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "rg_skinny_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "rg_skinny_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
-    "rg_skinny_wgrad_slabs": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p, _p]),
+    "rg_skinny_wgrad_slabs": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p, _p, _p, _p]),
+    "rg_skinny_wgrad_bias": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p, _p]),
     "rg_pack_g0_weight": (_i, [_p, _p, _i, _i, _i, _p]),
     "rg_pack_conv_wup_from_bf16": (_i, [_p, _p, _i, _i, _p]),
     "rg_pack_conv_wup_from_bf16_multi": (_i, [_i, _p, _p, _p, _p, _p]),
@@ -161,7 +162,7 @@ PROTOTYPES = {
 }
 
 # must equal rg_version() of the library (rna_gan_amd/csrc/rg_api.hip): bumped together with PROTOTYPES
-ABI_VERSION = 504
+ABI_VERSION = 505
 
 _lib = None
 

@@ -18,7 +18,7 @@ void rg_set_error(const char* fmt, ...) {
 }
 
 // bumped whenever an entry point is added or a signature changes; rna_gan_amd/_abi.py (ABI_VERSION) refuses any other value
-extern "C" int rg_version(void) { return 504; }   // 5.04: round 5 (rg_conv_wgrad_slabs, rg_adam_step_slabs, rg_conv_wgrad_adam; slab dtypes; rg_grad_to_wire, rg_conv_wgrad_wire; rg_skinny_wgrad_slabs)
+extern "C" int rg_version(void) { return 505; }   // 5.05: round 5 (rg_conv_wgrad_slabs, rg_adam_step_slabs, rg_conv_wgrad_adam; slab dtypes; rg_grad_to_wire, rg_conv_wgrad_wire; rg_skinny_wgrad_slabs, rg_skinny_wgrad_bias)
 extern "C" const char* rg_last_error(void) { return g_err; }
 
 // ---- kernel-selection knobs: override table in front of the RNAGAN_* environment variables
@@ -370,17 +370,37 @@ extern "C" int rg_skinny_wgrad(const void* low, const float* high_nchw, float* d
                                  rg_stream(stream));
 }
 
+// rg_skinny_wgrad that ALSO produces the layer's bias gradient dbias[O] = sum over the pixels of `low` (the Conv2d(3, 64) /
+// ConvTranspose2d(64, 3) pair keeps a bias, src/histopathology_gan.py:186-192) where the kernel can form it as a by-product of its
+// pass over `low` (a column of ones in the patch operand: the 256 x 256 bf16 row kernel) -- *bias_done_out = 1; otherwise 0 and
+// dbias is untouched (call rg_col_sum).  dbias may be NULL (= rg_skinny_wgrad).
+extern "C" int rg_skinny_wgrad_bias(const void* low, const float* high_nchw, float* dw, float* dbias, int N, int Ho, int Wo, int O,
+                                    int I, int dtype, int accumulate, int bias_accumulate, void* ws, size_t ws_bytes,
+                                    int* bias_done_out, void* stream) {
+  RG_REQUIRE(low && high_nchw && dw && bias_done_out && N > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0, RG_EINVAL,
+             "skinny_wgrad_bias: bad args");
+  *bias_done_out = 0;
+  if (rg_skinny_supported(I, O) && !(dtype == RG_F32 && rg_generic_f32_image_side(N, 2 * Ho, 2 * Wo, I, O)))
+    return rg_skinny_wgrad_impl(low, high_nchw, dw, N, Ho, Wo, O, I, dtype, accumulate, ws, ws_bytes, rg_stream(stream),
+                                O == 64 ? dbias : nullptr, bias_accumulate, bias_done_out);
+  return rg_generic_skinny_wgrad(low, high_nchw, dw, N, Ho, Wo, O, I, dtype, accumulate, ws, ws_bytes, rg_stream(stream));
+}
+
 // rg_skinny_wgrad with the per-workgroup partial gradients LEFT to the caller's optimizer step (rg_adam_step_slabs): `slab`
 // receives *nslab_out fp32 slabs of O * 48 elements in dw's layout (at most rg_skinny_wgrad_workspace_bytes); a second
 // contribution to the same tensor is a second call with `slab` advanced by the first one's slabs.  *nslab_out = 0: no such form
-// for this shape / dtype, nothing launched (call rg_skinny_wgrad).
+// for this shape / dtype, nothing launched (call rg_skinny_wgrad).  bias_slab (optional): receives the bias-gradient partials
+// [*nslab_out][O] of the same pass when *bias_done_out comes back 1 (see rg_skinny_wgrad_bias).
 extern "C" int rg_skinny_wgrad_slabs(const void* low, const float* high_nchw, int N, int Ho, int Wo, int O, int I, int dtype,
-                                     void* slab, size_t slab_bytes, int* nslab_out, void* stream) {
-  RG_REQUIRE(low && high_nchw && slab && nslab_out && N > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0, RG_EINVAL,
-             "skinny_wgrad_slabs: bad args");
+                                     void* slab, size_t slab_bytes, int* nslab_out, float* bias_slab, int* bias_done_out,
+                                     void* stream) {
+  RG_REQUIRE(low && high_nchw && slab && nslab_out && N > 0 && Ho > 0 && Wo > 0 && I > 0 && O > 0 &&
+                 (bias_slab == nullptr || bias_done_out != nullptr), RG_EINVAL, "skinny_wgrad_slabs: bad args");
   *nslab_out = 0;
+  if (bias_done_out) *bias_done_out = 0;
   if (!rg_skinny_supported(I, O)) return RG_OK;
-  return rg_skinny_wgrad_slabs_impl(low, high_nchw, N, Ho, Wo, O, I, dtype, slab, slab_bytes, nslab_out, rg_stream(stream));
+  return rg_skinny_wgrad_slabs_impl(low, high_nchw, N, Ho, Wo, O, I, dtype, slab, slab_bytes, nslab_out, bias_slab, bias_done_out,
+                                    rg_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -167,6 +167,8 @@ int rg_skinny_lu_part_final(const float* part, int nb, float* out, int accumulat
                             float lambd, hipStream_t st);
 size_t rg_skinny_wgrad_ws_bytes(int N, int Ho, int Wo, int O, int I);
 int rg_skinny_wgrad_slabs_impl(const void* low, const float* high_nchw, int N, int Ho, int Wo, int O, int I, int dtype,
-                               void* slab, size_t slab_bytes, int* nslab_out, hipStream_t st);
+                               void* slab, size_t slab_bytes, int* nslab_out, float* bias_slab, int* bias_done_out,
+                               hipStream_t st);
 int rg_skinny_wgrad_impl(const void* low, const float* high_nchw, float* dw, int N, int Ho, int Wo, int O, int I,
-                         int dtype, int accumulate, void* ws, size_t ws_bytes, hipStream_t st);
+                         int dtype, int accumulate, void* ws, size_t ws_bytes, hipStream_t st, float* dbias = nullptr,
+                         int bias_accumulate = 0, int* bias_done_out = nullptr);

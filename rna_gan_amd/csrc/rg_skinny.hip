@@ -1140,10 +1140,13 @@ __device__ __forceinline__ void sw128_load_low(Sw128Low& r, const uint16_t* __re
 
 __global__ __launch_bounds__(256, 2) void skinny_wgrad_rows128_kernel(const uint16_t* __restrict__ low,
                                                                       const float* __restrict__ x, float* __restrict__ slab,
-                                                                      int nunits) {
+                                                                      int nunits, float* __restrict__ bias_slab) {
   // both LDS images double-buffered (one barrier per unit), two units of loads in flight in registers (7 x 16 B per thread and
-  // unit): 59 KB and ~200 registers, two workgroups per CU
-  __shared__ __attribute__((aligned(16))) uint16_t pt2[2][SK_K * SW_PTS];    // 2 x 12.75 KB
+  // unit): 59 KB and ~200 registers, two workgroups per CU.
+  // The MFMA tile has 64 columns for the 48 patch taps: column 48 is a row of ONES in the patch image, so that
+  // D[o][48] = sum_pixels low[pixel][o] -- the layer's BIAS gradient partial (bias_slab[block][64], optional), a by-product of the
+  // pass over `low` that rg_col_sum otherwise makes on its own (134-268 MB per call)
+  __shared__ __attribute__((aligned(16))) uint16_t pt2[2][(SK_K + 1) * SW_PTS];    // 2 x 13 KB
   __shared__ __attribute__((aligned(16))) uint16_t lt2[2][128 * 64];         // 2 x 16 KB (lt2[0] reused for the final reduction)
   uint16_t* const lt = lt2[0];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1161,6 +1164,7 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_rows128_kernel(const uint
   if (u0 < u1) {
     fd128_zero_edges<SW_PTS>(pt2[0], t);
     fd128_zero_edges<SW_PTS>(pt2[1], t);
+    if (t < SW_PTS) { pt2[0][SK_K * SW_PTS + t] = 0x3f80; pt2[1][SK_K * SW_PTS + t] = 0x3f80; }     // bf16 1.0
     Fd128Rows ra, rb;
     Sw128Low la, lb;
     fd128_load(ra, x, u0, wave, lane);
@@ -1192,7 +1196,7 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_rows128_kernel(const uint
           sk_s16x4 lo = sk_tr_read(ap), hi = sk_tr_read(ap + 4 * 64);
           fa[i] = __builtin_bit_cast(sk_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
           const int k = 32 * i + r;
-          fb[i] = __builtin_bit_cast(sk_bf16x8, *reinterpret_cast<const uint4*>(ptu + (k < SK_K ? k : 0) * SW_PTS +
+          fb[i] = __builtin_bit_cast(sk_bf16x8, *reinterpret_cast<const uint4*>(ptu + (k <= SK_K ? k : 0) * SW_PTS +
                                                                                 wave * 32 + ks * 16 + 8 * h));
         }
 #pragma unroll
@@ -1217,7 +1221,7 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_rows128_kernel(const uint
   __syncthreads();
   // block reduction of the 4 waves: acc[i][j][reg] = D[o = 32i + (reg&3)+8(reg>>2)+4h][k = 32j + r]
   float* red = reinterpret_cast<float*>(lt);
-  for (int i = t; i < 64 * SK_K; i += 256) red[i] = 0.f;
+  for (int i = t; i < 64 * SK_K + 64; i += 256) red[i] = 0.f;         // [64][48] + the bias column [64] behind it
   __syncthreads();
   for (int wv = 0; wv < 4; ++wv) {
     if (wave == wv) {
@@ -1229,6 +1233,9 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_rows128_kernel(const uint
           if (k < SK_K) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) red[(32 * i + (e & 3) + 8 * (e >> 2) + 4 * h) * SK_K + k] += acc[i][j][e];
+          } else if (k == SK_K) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[64 * SK_K + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h] += acc[i][j][e];
           }
         }
     }
@@ -1236,6 +1243,7 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_rows128_kernel(const uint
   }
   float* sl = slab + (size_t)blockIdx.x * 64 * SK_K;
   for (int i = t; i < 64 * SK_K; i += 256) sl[i] = red[i];
+  if (bias_slab && t < 64) bias_slab[(size_t)blockIdx.x * 64 + t] = red[64 * SK_K + t];
 }
 
 // row-staged bf16 kernels: unit width (output pixels) for an output row of Wo pixels; 3 resident blocks per CU (VGPR-limited)
@@ -1454,16 +1462,18 @@ size_t rg_skinny_wgrad_ws_bytes(int N, int Ho, int Wo, int O, int I) {
   int ppb;
   int nb = skinny_wgrad_blocks((long long)N * Ho * Wo, &ppb);
   if (nb < SKW_BLOCKS) nb = SKW_BLOCKS;
-  return (size_t)nb * O * SK_K * sizeof(float);
+  return (size_t)nb * (O * SK_K + 64) * sizeof(float);          // + the bias-gradient partials of the row kernel
 }
 
 // The row-kernel form with the per-workgroup partial gradients LEFT in `slab` ([*nslab_out][O * 48] fp32, the layout of dw): the
 // caller's optimizer step sums them (rg_adam_step_slabs).  *nslab_out = 0: this shape / dtype has no such form, nothing was
 // launched.
 int rg_skinny_wgrad_slabs_impl(const void* low, const float* high_nchw, int N, int Ho, int Wo, int O, int I, int dtype,
-                               void* slab, size_t slab_bytes, int* nslab_out, hipStream_t st) {
+                               void* slab, size_t slab_bytes, int* nslab_out, float* bias_slab, int* bias_done_out,
+                               hipStream_t st) {
   (void)I;
   *nslab_out = 0;
+  if (bias_done_out) *bias_done_out = 0;
   const size_t elems = (size_t)O * SK_K;
   const long long npix = (long long)N * Ho * Wo;
   int chunk;
@@ -1474,7 +1484,8 @@ int rg_skinny_wgrad_slabs_impl(const void* low, const float* high_nchw, int N, i
     if (nbm > 512) nbm = 512;
     RG_REQUIRE(slab && slab_bytes >= (size_t)nbm * elems * sizeof(float), RG_EWORKSPACE, "skinny_wgrad_slabs: buffer too small");
     hipLaunchKernelGGL(skinny_wgrad_rows128_kernel, dim3(nbm), dim3(256), 0, st, (const uint16_t*)low, high_nchw, (float*)slab,
-                       nunits);
+                       nunits, bias_slab);
+    if (bias_done_out) *bias_done_out = bias_slab ? 1 : 0;
   } else {
     RG_REQUIRE(slab && slab_bytes >= (size_t)nbm * elems * sizeof(float), RG_EWORKSPACE, "skinny_wgrad_slabs: buffer too small");
     hipLaunchKernelGGL(skinny_wgrad_rows_kernel, dim3(nbm), dim3(256), 0, st, (const uint16_t*)low, high_nchw, (float*)slab, N,
@@ -1486,8 +1497,12 @@ int rg_skinny_wgrad_slabs_impl(const void* low, const float* high_nchw, int N, i
 }
 
 int rg_skinny_wgrad_impl(const void* low, const float* high_nchw, float* dw, int N, int Ho, int Wo, int O, int I,
-                         int dtype, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+                         int dtype, int accumulate, void* ws, size_t ws_bytes, hipStream_t st, float* dbias, int bias_accumulate,
+                         int* bias_done_out) {
   (void)I;
+  int bias_done_local = 0;
+  if (!bias_done_out) bias_done_out = &bias_done_local;
+  *bias_done_out = 0;
   size_t elems = (size_t)O * SK_K;
   long long npix = (long long)N * Ho * Wo;
   static int no_mfma = -1;
@@ -1499,10 +1514,15 @@ int rg_skinny_wgrad_impl(const void* low, const float* high_nchw, float* dw, int
     RG_REQUIRE(ws && ws_bytes >= (size_t)nbm * elems * sizeof(float), RG_EWORKSPACE, "skinny_wgrad: workspace too small");
     if (sk_rows128(2 * Ho, 2 * Wo)) {
       if (nbm > 512) nbm = 512;                     // two workgroups per CU (59 KB of LDS each)
+      // dbias (optional): the kernel's bias column, partials behind the weight partials in the workspace
+      float* bpart = (dbias && ws_bytes >= (size_t)nbm * (elems + 64) * sizeof(float)) ? (float*)ws + (size_t)nbm * elems : nullptr;
       hipLaunchKernelGGL(skinny_wgrad_rows128_kernel, dim3(nbm), dim3(256), 0, st, (const uint16_t*)low, high_nchw, (float*)ws,
-                         nunits);
+                         nunits, bpart);
       RG_LAUNCH_CHECK("skinny_wgrad(128)");
-      return rg_reduce_slabs((const float*)ws, dw, elems, nbm, accumulate, 0, 0, st);
+      int rc = rg_reduce_slabs((const float*)ws, dw, elems, nbm, accumulate, 0, 0, st);
+      if (rc || !bpart) return rc;
+      *bias_done_out = 1;
+      return rg_reduce_slabs(bpart, dbias, 64, nbm, bias_accumulate, 0, 0, st);
     }
     hipLaunchKernelGGL(skinny_wgrad_rows_kernel, dim3(nbm), dim3(256), 0, st, (const uint16_t*)low, high_nchw, (float*)ws,
                        N, 2 * Ho, 2 * Wo, chunk, nunits);

@@ -45,7 +45,7 @@ class ConvW:
 
     __slots__ = ("w", "bias", "dw", "dbias", "packs", "packs_version", "version", "layout", "shadow",
                  "shadow_version", "_fp8", "fuse_step", "pending_wgrad", "factor_stage", "owner", "defer_slabs",
-                 "pending_slabs", "_slab_ws", "wire_slot")
+                 "pending_slabs", "_slab_ws", "wire_slot", "pending_bias", "_bias_ws")
 
     def __init__(self, w, bias=None, dw=None, dbias=None, layout="OIHW"):
         self.w = w
@@ -66,6 +66,8 @@ class ConvW:
         self.defer_slabs = False
         self.pending_slabs = None
         self._slab_ws = None
+        self.pending_bias = None      # image-side layers: (buffer, count) of deferred BIAS-gradient partials [count][64] (same pass)
+        self._bias_ws = None
         # data parallel (bf16 wire): the layer's slice of the all-reduce wire buffer, set by the train_op runner together with
         # defer_slabs -- a weight-gradient launch without split-K writes its bf16 tile there (pending_slabs = (None, -1, 0)), a
         # split one leaves its slabs for rg_grad_to_wire; no fp32 gradient of the layer is formed in that pass
@@ -275,13 +277,16 @@ def disc_backward(ops, D: DiscNet, ctx, coef: float, wgrad, accumulate: bool,
         ops.col_sum(gz0, D.conv0.dbias, accumulate)
     elif wgrad and partner is not None:
         with ops.side(gz0, partner.gz_keep[0]):
-            ops.skinny_wgrad(gz0, ctx.x, D.conv0.dw, False)
+            # (dbias: the kernel forms the bias gradient -- the column sums of gz0 -- in the same pass where it can)
+            done = ops.skinny_wgrad(gz0, ctx.x, D.conv0.dw, False, dbias=D.conv0.dbias, dbias_accumulate=accumulate)
             ops.skinny_wgrad(partner.gz_keep[0], partner.x, D.conv0.dw, True)
-        ops.col_sum(gz0, D.conv0.dbias, accumulate)
+        if not done:
+            ops.col_sum(gz0, D.conv0.dbias, accumulate)
     elif wgrad:
         with ops.side(gz0):
-            ops.skinny_wgrad(gz0, ctx.x, D.conv0.dw, accumulate)
-        ops.col_sum(gz0, D.conv0.dbias, accumulate)
+            done = ops.skinny_wgrad(gz0, ctx.x, D.conv0.dw, accumulate, dbias=D.conv0.dbias, dbias_accumulate=accumulate)
+        if not done:
+            ops.col_sum(gz0, D.conv0.dbias, accumulate)
     gx = None
     if need_input_grad and input_post is not None:
         fused = ops.last_up_post(gz0, D.conv0, input_post.get("tanh_img"))
@@ -393,9 +398,10 @@ def disc_gp_second(ops, D: DiscNet, ctx, st, accumulate: bool, need_input_grad: 
         raise NotImplementedError("gradient penalty needs at least one Conv+BN block (in_size >= 32)")
     p0 = qa
     with ops.side(p0, v):
-        ops.skinny_wgrad(p0, xhat, D.conv0.dw, accumulate)
+        done = ops.skinny_wgrad(p0, xhat, D.conv0.dw, accumulate, dbias=D.conv0.dbias, dbias_accumulate=accumulate)
         ops.skinny_wgrad(ctx.gz1[0], v, D.conv0.dw, True)
-    ops.col_sum(p0, D.conv0.dbias, accumulate)
+    if not done:
+        ops.col_sum(p0, D.conv0.dbias, accumulate)
     gx = ops.last_up(p0, D.conv0, None, False) if need_input_grad else None
     ops.join()
     return gx
@@ -713,9 +719,12 @@ def disc_loss_grads_batched(ops, G, D: DiscNet, real, noise, grad_scale: float =
             else ops.conv_up(gz, cw, acts[0], D.slope)
     gz0 = ga if R > 0 else ops.lrelu_bwd(ga, acts[0], D.slope)
     with ops.side(gz0):
-        ops.skinny_wgrad(gz0[:n], xs[0], D.conv0.dw, False)
-        ops.skinny_wgrad(gz0[n:], xs[1], D.conv0.dw, True)
-    ops.col_sum(gz0, D.conv0.dbias, False)
+        d0 = ops.skinny_wgrad(gz0[:n], xs[0], D.conv0.dw, False, dbias=D.conv0.dbias, dbias_accumulate=False)
+        d1 = ops.skinny_wgrad(gz0[n:], xs[1], D.conv0.dw, True, dbias=D.conv0.dbias if d0 else None, dbias_accumulate=True)
+    if not d0:
+        ops.col_sum(gz0, D.conv0.dbias, False)
+    elif not d1:
+        ops.col_sum(gz0[n:], D.conv0.dbias, True)
     ops.join()
     return loss if next_noise is None else (loss, fake_next)
 

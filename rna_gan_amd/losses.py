@@ -370,7 +370,7 @@ def _dispatch(runner, key, body, inputs, generator, discriminator, stepped, opti
         sk = _skinny_slab_layer(stepped, optimizer)
         ops_s = stepped.runtime()[0] if sk is not None else None
         if sk is not None:
-            sk.pending_slabs = None
+            sk.pending_slabs, sk.pending_bias = None, None
             ops_s._skinny_defer = {sk.dw.data_ptr(): sk}      # ... and the image-side layer's per-workgroup partials too
         try:
             loss = body.grads(*a)
@@ -416,6 +416,8 @@ def _skinny_slab_layer(stepped, optimizer):
     off = (cw.w.data_ptr() - flat.data.data_ptr()) // 4
     if cw.dw is None or not cw.w.is_contiguous() or off % 4 or cw.w.numel() % 4 or cw.w.shape[0] != 64:
         return None
+    if cw.bias is not None and ((cw.bias.data_ptr() - flat.data.data_ptr()) // 4) % 4:
+        return None                     # (its bias-gradient partials become a segment of the same step: 16-byte aligned too)
     return cw
 
 

@@ -146,6 +146,8 @@ class HipOps:
         # {dw address: ConvW} of the image-side layers whose weight-gradient partials the optimizer sums (set by the train_op runner
         # for the duration of one gradient pass, with ConvW.defer_slabs)
         self._skinny_defer = None
+        # the image-side weight-gradient kernel also forms the layer's bias gradient (a column of ones in its patch operand)
+        self.skinny_bias = os.environ.get("RNAGAN_SKINNY_BIAS", "1") != "0"
         self.epilogue_stats = os.environ.get("RNAGAN_EPILOGUE_STATS", "1") != "0"
         # synchronised (global-batch) statistics in a data-parallel run (dist.attach_sync): an in-place SUM all-reduce
         # for small fp32 tensors and the number of ranks; None = rank-local statistics (plain DDP semantics)
@@ -795,10 +797,15 @@ class HipOps:
               "rg_gp_coef_parts")
         return loss, coef
 
-    def skinny_wgrad(self, low, high_nchw, dw, accumulate: bool):
+    def skinny_wgrad(self, low, high_nchw, dw, accumulate: bool, dbias=None, dbias_accumulate=False):
+        """Weight gradient of an image-side layer.  dbias (optional): the layer's bias gradient = the column sums of `low`, formed
+        by the same kernel where it can (rg_skinny_wgrad_bias); returns True when dbias was written (or left as deferred
+        partials), False when the caller still has to call col_sum."""
         N, Ho, Wo, O = low.shape
         I = high_nchw.shape[1]
         assert high_nchw.dtype == torch.float32 and high_nchw.is_contiguous() and low.is_contiguous()
+        if not self.skinny_bias:
+            dbias = None
         nb = self.lib.rg_skinny_wgrad_workspace_bytes(N, Ho, Wo, O, I)
         cw = self._skinny_defer.get(dw.data_ptr()) if self._skinny_defer else None
         if cw is not None and self.dt == RG_BF16 and self.stat_reduce is None and not self._in_side:
@@ -812,18 +819,35 @@ class HipOps:
                 if prev is not None:
                     raise RuntimeError("rna_gan_amd: deferred image-side weight gradient: the slab buffer grew between two contributions")
                 cw._slab_ws = torch.empty(2 * nb + 4096, dtype=torch.uint8, device=self.device)     # persistent: graphs hold its address
+                cw._bias_ws = torch.empty(2 * 1024 * O, dtype=torch.float32, device=self.device)
+            want_bias = (dbias is not None and cw.bias is not None and cw.dbias is not None and
+                         dbias.data_ptr() == cw.dbias.data_ptr() and O == 64)
+            bprev = cw.pending_bias
+            if want_bias and (bprev is None) == bool(dbias_accumulate):
+                want_bias = False                        # (a bias contribution out of order: the caller's col_sum handles it)
+            bhave = 0 if bprev is None else bprev[1]
             off = have * O * 48 * 4
-            ns = ctypes.c_int(0)
+            ns, bdone = ctypes.c_int(0), ctypes.c_int(0)
             check(self.lib.rg_skinny_wgrad_slabs(_ptr(low), _ptr(high_nchw), N, Ho, Wo, O, I, self.dt, cw._slab_ws.data_ptr() + off,
-                                                 cw._slab_ws.numel() - off, ctypes.addressof(ns), self.stream), "rg_skinny_wgrad_slabs")
+                                                 cw._slab_ws.numel() - off, ctypes.addressof(ns),
+                                                 cw._bias_ws.data_ptr() + bhave * O * 4 if want_bias else 0,
+                                                 ctypes.addressof(bdone), self.stream), "rg_skinny_wgrad_slabs")
             if ns.value > 0:
                 cw.pending_slabs = (cw._slab_ws, have + int(ns.value), RG_F32)
-                return
+                if want_bias and bdone.value:
+                    if bhave + ns.value > 2 * 1024:
+                        raise RuntimeError("rna_gan_amd: deferred bias-gradient partials exceed their buffer")
+                    cw.pending_bias = (cw._bias_ws, bhave + int(ns.value))
+                    return True
+                return False
             if prev is not None:
                 raise RuntimeError("rna_gan_amd: deferred image-side weight gradient: the second contribution has no slab form")
         ws = self._ws(nb)
-        check(self.lib.rg_skinny_wgrad(_ptr(low), _ptr(high_nchw), _ptr(dw), N, Ho, Wo, O, I, self.dt,
-                                       int(accumulate), _ptr(ws), ws.numel(), self.stream), "rg_skinny_wgrad")
+        bdone = ctypes.c_int(0)
+        check(self.lib.rg_skinny_wgrad_bias(_ptr(low), _ptr(high_nchw), _ptr(dw), _ptr(dbias), N, Ho, Wo, O, I, self.dt,
+                                            int(accumulate), int(dbias_accumulate), _ptr(ws), ws.numel(), ctypes.addressof(bdone),
+                                            self.stream), "rg_skinny_wgrad_bias")
+        return bool(bdone.value)
 
     # ------------------------------------------------------------------ G.0 / head
     def g0_pack(self, cw: ConvW):

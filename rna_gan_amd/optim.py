@@ -194,6 +194,11 @@ class Adam(torch.optim.Adam):
             if ps is not None:
                 cw.pending_slabs = None
                 slab_segs.append(((cw.w.data_ptr() - flat.data.data_ptr()) // 4, cw.w.numel(), ps[0], ps[1], ps[2]))
+            pb = getattr(cw, "pending_bias", None)
+            if pb is not None:
+                # the image-side layer's bias-gradient partials of the same pass ([count][64] fp32): one more slab segment
+                cw.pending_bias = None
+                slab_segs.append(((cw.bias.data_ptr() - flat.data.data_ptr()) // 4, cw.bias.numel(), pb[0], pb[1], 0))
             pw = getattr(cw, "pending_wgrad", None)
             if isinstance(pw, tuple) and isinstance(pw[0], str) and pw[0] == "conv":
                 # a layer whose weight-gradient plan has no split-K (ops_hip._wgrad_slabs left the operands): gradient tile and

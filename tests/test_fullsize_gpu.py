@@ -845,13 +845,16 @@ def test_image_side_weight_gradient_partials_inside_the_adam_step():
     gd[head:head + nw].fill_(float("nan"))
     shd = torch.zeros(total, dtype=torch.bfloat16, device=dev)
     slab = torch.empty(2 * wsb + 4096, dtype=torch.uint8, device=dev)
+    bias_part = torch.full((2048, O), float("nan"), device=dev)
     have = 0
     for k in range(2):
         ns = C.c_int(0)
         off = have * nw * 4
+        bd = C.c_int(0)
         _abi.check(lib.rg_skinny_wgrad_slabs(gs[k].data_ptr(), xs[k].data_ptr(), N, S // 2, S // 2, O, I, ops.dt,
-                                             slab.data_ptr() + off, slab.numel() - off, C.addressof(ns), ops.stream), "slabs")
-        assert ns.value > 0
+                                             slab.data_ptr() + off, slab.numel() - off, C.addressof(ns),
+                                             bias_part[have:].data_ptr(), C.addressof(bd), ops.stream), "slabs")
+        assert ns.value > 0 and bd.value == 1
         have += ns.value
     print("image-side weight gradient: %d partial slabs of %d elements" % (have, nw))
     table = [(0, head, 0, 0, 0), (head, nw, slab.data_ptr(), have, _abi.RG_F32), (head + nw, tail, 0, 0, 0)]
@@ -873,8 +876,29 @@ def test_image_side_weight_gradient_partials_inside_the_adam_step():
     assert float((vr[sl_] - vd[sl_]).abs().max()) <= 1e-4 * float(vr[sl_].abs().max())
     assert float((pr[sl_] - pd[sl_]).abs().max()) <= 2e-2 * float((pr[sl_] - p0[sl_]).abs().max())
     assert torch.equal(shd, pd.bfloat16())
-    # the 64 x 64 generic shape has no slab form: nothing launched, 0 reported
-    ns = C.c_int(7)
+    # the bias gradient as a by-product of the same pass (a column of ones in the patch operand): the partials' sum, and the
+    # reducing entry point, against the column sums of `low` (rg_col_sum and fp64)
+    torch.cuda.synchronize()
+    want = sum(g.double().sum(dim=(0, 1, 2)) for g in gs)
+    got = bias_part[:have].double().sum(0)
+    assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-3
+    db = torch.zeros(O, device=dev)
+    dw = torch.empty(nw, device=dev)
+    for k in range(2):
+        bd = C.c_int(0)
+        _abi.check(lib.rg_skinny_wgrad_bias(gs[k].data_ptr(), xs[k].data_ptr(), dw.data_ptr(), db.data_ptr(), N, S // 2, S // 2, O,
+                                            I, ops.dt, k, k, ws.data_ptr(), ws.numel(), C.addressof(bd), ops.stream), "wgrad_bias")
+        assert bd.value == 1
+    torch.cuda.synchronize()
+    assert torch.equal(dw, gr[head:head + nw])                   # the weight gradient itself is what rg_skinny_wgrad writes
+    assert float((db.double() - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-3
+    ref = torch.zeros(O, device=dev)
+    for k in range(2):
+        ops.col_sum(gs[k], ref, bool(k))
+    torch.cuda.synchronize()
+    assert float((db - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-4
+    # the fp32 generic shape has no slab form: nothing launched, 0 reported
+    ns, bd = C.c_int(7), C.c_int(7)
     _abi.check(lib.rg_skinny_wgrad_slabs(gs[0].data_ptr(), xs[0].data_ptr(), N, S // 2, S // 2, O, I, _abi.RG_F32, slab.data_ptr(),
-                                         slab.numel(), C.addressof(ns), ops.stream), "slabs(f32)")
-    assert ns.value == 0
+                                         slab.numel(), C.addressof(ns), 0, C.addressof(bd), ops.stream), "slabs(f32)")
+    assert ns.value == 0 and bd.value == 0
