@@ -8,6 +8,9 @@ round's ms per iteration, the mean, and the paired difference to the first varia
 
     python tools/ab_step.py --variants "base:skinny128=0;new:" --rounds 5 --steps 20
 
+The first variant is built twice (`name#control`): two identically configured workloads differ by 0.006 ... 0.12 ms in one
+process (each owns its buffers), and that difference -- `noise_floor_ms` in the result -- is what a delta has to exceed.
+
 A variant is  name:key=value,key=value ...  with keys of three kinds
   * kernel-selection options of the C ABI (rg_set_option: conv8, convp, convd, skinny128, ...), re-applied at every switch
     (they only act when a launch is issued eagerly or captured; a captured graph replays what it captured);
@@ -93,6 +96,10 @@ def main():
     ap.add_argument("--prime", type=int, default=40)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--json", default=None, help="write the result object here as well")
+    ap.add_argument("--no-control", action="store_true",
+                    help="by default the FIRST variant is built a second time (name + '#control', same settings, own buffers) "
+                         "and measured last: its difference to the first is the noise floor of the comparison -- two identically "
+                         "configured workloads in one process differ by 0.006 ... 0.12 ms (buffer placement), DESIGN 14.1")
     a = ap.parse_args()
     import bench
     from rna_gan_amd import _abi, losses
@@ -102,7 +109,10 @@ def main():
     torch.set_num_threads(min(8, torch.get_num_threads()))
     bargs = bench.parse_args(["--batch", str(a.batch), "--no-cpu-baseline", "--no-roofline", "--no-extras"])
     bargs.prime = a.prime
-    vs = [Variant(n, kv, lib) for n, kv in parse_variants(a.variants)]
+    pv = parse_variants(a.variants)
+    if not a.no_control and pv:
+        pv.append((pv[0][0] + "#control", dict(pv[0][1])))
+    vs = [Variant(n, kv, lib) for n, kv in pv]
     assert len(vs) >= 2, "need at least two variants"
     all_copts = sorted({k for v in vs for k in v.copts})
     base_mod = {k: getattr(losses, k) for v in vs for k in v.mod}
@@ -139,6 +149,8 @@ def main():
                                 "delta_vs_first": {"mean": round(sum(d) / len(d), 3), "min": round(min(d), 3),
                                                    "max": round(max(d), 3)},
                                 "losses_last_step": [round(x, 5) for x in v.last]})
+    if not a.no_control:
+        res["noise_floor_ms"] = abs(res["variants"][-1]["delta_vs_first"]["mean"])
     line = json.dumps(res)
     print(line)
     if a.json:
