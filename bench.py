@@ -437,7 +437,9 @@ def main(argv=None):
         out["config"]["step_plugin"] = args.step_plugin
 
     # the instrumented extra iteration contains collectives in a data-parallel run: every rank runs it
-    roof = None if args.no_roofline or args.api_path else measure_roofline(info["ops"], device, one_step, ms_per_step)
+    roof = None if args.no_roofline or args.api_path else measure_roofline(info["ops"], device, one_step, ms_per_step,
+                                                                              extra_ops=[m.runtime()[0] for m in (info["handles"]["G"], info["handles"]["D"])
+                                                                                         if m.runtime()[0] is not info["ops"]])
     flush()
     extras = parity_gpu = None
     if rank == 0 and world == 1 and not args.no_extras:
@@ -463,7 +465,7 @@ def main(argv=None):
         torch.distributed.destroy_process_group()
 
 
-def measure_roofline(ops, device, one_step, step_ms):
+def measure_roofline(ops, device, one_step, step_ms, extra_ops=()):
     """Per-launch HIP events (recorded on the stream the kernels are enqueued on) around every conv
     launch of ONE extra, instrumented iteration of the same workload, run right after the timed
     region.  Kernel families:
@@ -488,6 +490,8 @@ def measure_roofline(ops, device, one_step, step_ms):
         a.record(stream); b.record(stream)
         cal.append((a, b))
     ops.timing = []
+    for o in extra_ops:                # (the discriminator's optimizer launches its fused weight-gradient + Adam kernel through the
+        o.timing = ops.timing          # discriminator module's own HipOps: same list)
     one_step()
     torch.cuda.synchronize(device)
     graphed.ENABLED = was
@@ -507,6 +511,8 @@ def measure_roofline(ops, device, one_step, step_ms):
             g["flops"] += flops
             g["ms"] += ms
     ops.timing = None
+    for o in extra_ops:
+        o.timing = None
     rows = {}
     for k, f in fam.items():
         rows[k] = {"launches": f["launches"], "ms_total": round(f["ms"], 3),
@@ -822,7 +828,9 @@ def extra_batch(args, device, info, batch, steps=6, warm=14):
     flush()
     torch.cuda.synchronize(device)
     dt = (time.perf_counter() - t0) / steps
-    roof = measure_roofline(inf["ops"], device, one_step, dt * 1e3)
+    roof = measure_roofline(inf["ops"], device, one_step, dt * 1e3,
+                            extra_ops=[m.runtime()[0] for m in (inf["handles"]["G"], inf["handles"]["D"])
+                                       if m.runtime()[0] is not inf["ops"]])
     flush()
     torch.cuda.synchronize(device)
     res = {"batch": batch, "ms_per_step": round(dt * 1e3, 3), "imgs_per_sec": round(batch / dt, 1), "steps": steps,

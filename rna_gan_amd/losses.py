@@ -368,7 +368,7 @@ def _dispatch(runner, key, body, inputs, generator, discriminator, stepped, opti
         for cw in deferred:
             cw.defer_slabs = True        # ... and the split-K weight gradients of its 4 x 4 layers may stay unreduced slabs
         sk = _skinny_slab_layer(stepped, optimizer)
-        ops_s = stepped.runtime()[0] if sk is not None else None
+        ops_s = generator.runtime()[0] if sk is not None else None      # the HipOps the engine runs BOTH networks on (_nets)
         if sk is not None:
             sk.pending_slabs, sk.pending_bias = None, None
             ops_s._skinny_defer = {sk.dw.data_ptr(): sk}      # ... and the image-side layer's per-workgroup partials too

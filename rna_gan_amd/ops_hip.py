@@ -808,6 +808,8 @@ class HipOps:
             dbias = None
         nb = self.lib.rg_skinny_wgrad_workspace_bytes(N, Ho, Wo, O, I)
         cw = self._skinny_defer.get(dw.data_ptr()) if self._skinny_defer else None
+        if cw is not None and cw.pending_slabs is None and accumulate:
+            cw = None          # the first contribution had no slab form (a small image) and wrote dw: this one adds to it
         if cw is not None and self.dt == RG_BF16 and self.stat_reduce is None and not self._in_side:
             # the optimizer step follows at once (the train_op runner registered the layer): the per-workgroup partial gradients
             # stay in a buffer of the layer's own -- a second contribution (accumulate) behind the first one's -- and Adam sums them
