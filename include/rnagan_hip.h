@@ -54,8 +54,9 @@ const char* rg_last_error(void);
 /* Kernel-selection knobs for A/B measurements inside one process (tools/, tests/): name = the part of the matching
  * environment variable after "RNAGAN_", lower case ("conv8", "conv8_blocks", "conv_tile", "xcd", "class_fast",
  * "wgrad_blocks", "wgrad8", ..., "f32mma": 0 sends the RG_F32 conv / dense launches back to the vector-ALU GEMM instead of the
- * f32 matrix-core one, 2 lets their 128 x 128-tile launches form every fp32 product as six bf16 matrix-core products of the
- * operands' exact three-way bf16 splits (fp32-grade accuracy, ~11 % faster fp32 iteration; opt-in); "wslab16": 0 keeps the deferred
+ * f32 matrix-core one, 1 keeps every such launch on the f32 matrix instruction, 2 (the default) lets their 128 x 128-tile launches
+ * form every fp32 product as six bf16 matrix-core products of the operands' exact three-way bf16 splits (fp32-grade accuracy,
+ * ~11 % faster fp32 iteration); "wslab16": 0 keeps the deferred
  * weight-gradient slabs fp32; "bn_rev": which BatchNorm row passes walk their rows from the end (bit 2, the default: reductions); "convd": 0 sends the 64 -> 128 channel stride-2 conv back from the parity-plane-resident kernel to the
  * implicit-GEMM one, "convd_blocks": its persistent grid; "slab16": 0 keeps the split-K partial tiles of the conv launches fp32;
  * "skinny128": 0 sends the image-side layers of 256 x 256 images back

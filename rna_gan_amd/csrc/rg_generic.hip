@@ -274,7 +274,8 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma32_kernel(FA fa, FB fb, SC sc
       }
 }
 
-// f32mma (option, default 1): fp32-storage launches with at least 64 rows and more than 32 columns run on the matrix cores;
+// f32mma (option; 0 off, 1 the f32 instruction everywhere, 2 = default: see gemm_bf16x3s_kernel): fp32-storage launches with at least
+// 64 rows and more than 32 columns run on the matrix cores;
 // everything else (the 3-column image layers) -- and every bf16-storage launch -- keeps gemm_generic_kernel.  (Its bf16 results
 // are deterministic but NOT pinned bit for bit across rounds: round 4 made the transposed conv's K order tap-major, permuted the
 // G.0 columns and re-associated the split-K slab sums; the bf16 tests compare with tolerances.)
@@ -1136,7 +1137,7 @@ __global__ __launch_bounds__(256, 3) void gemm_mfma32s_kernel(FA fa, FB fb, SC s
 }
 
 // ----------------------------------------------------------------------------------------------
-// gemm_bf16x3s_kernel: the structured fp32 GEMM above on the BF16 matrix cores (option f32mma = 2).  An fp32 value is the exact
+// gemm_bf16x3s_kernel: the structured fp32 GEMM above on the BF16 matrix cores (option f32mma = 2, the default).  An fp32 value is the exact
 // sum of three bf16 numbers,  v = h + m + l  (h = bf16(v), m = bf16(v - h), l = bf16(v - h - m): 8 + 8 + 8 significant bits,
 // round-to-nearest each, the residuals are exact in fp32), a product of two bf16 numbers is exact in fp32, and
 //     a b = ah bh + (ah bm + am bh) + (ah bl + al bh + am bm) + [am bl + al bm + al bl: < 2^-23 |a b|, dropped]

@@ -131,10 +131,10 @@ def test_conv_down_up_wgrad(N, Hi, Wi, I, O, dtype):
                                          (4, 128, 128, 64, 512),     # 128 x 128 tiles: down (512 tiles) and weight gradient (768)
                                          (4, 128, 128, 128, 32)])    # 128 x 128 tiles: up (512 tiles over the four classes)
 def test_f32_matrix_core_gemm_matches_vector_kernel(N, Hi, Wi, I, O):
-    """fp32 mode: the f32-MFMA GEMM skeleton (option f32mma = 1, default) against the vector-ALU skeleton (f32mma = 0) through
+    """fp32 mode: the f32-MFMA GEMM skeleton (option f32mma = 1) against the vector-ALU skeleton (f32mma = 0) through
     the same operand functors -- conv forward, transposed conv, weight gradient, generator layer 0 and a dense layer.  Both
     are fused-multiply-add chains in fp32; only the association of the k-loop differs (two interleaved k per MFMA step).
-    f32mma = 2 (opt-in): the 128 x 128-tile launches form every fp32 product as six bf16 matrix-core products of the operands'
+    f32mma = 2 (the default): the 128 x 128-tile launches form every fp32 product as six bf16 matrix-core products of the operands'
     exact three-way bf16 splits (gemm_bf16x3s_kernel; < 2^-25 relative per product, fp32 accumulation) -- same bound."""
     from rna_gan_amd import _abi
     hip = _hip(torch.float32)
