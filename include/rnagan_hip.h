@@ -645,6 +645,21 @@ int rg_selftest_fp8(int* detail, void* stream);
  * loader hand over uint8 tiles (a quarter of the PCIe bytes) and normalise on the device. */
 int rg_u8_to_norm(const void* src_u8, float* dst, size_t n, float mean, float stdv, void* stream);
 
+/* On-box ceilings for the roofline object of bench.py ("re-measure both on the box (MFMA-loop and stream-copy
+ * microbenchmarks) and report against both nominal and measured peak").  Measurement kernels only -- no product path calls
+ * them; the caller times back-to-back launches with events on `stream`.  (rna_gan_amd/csrc/rg_probe.hip)
+ * rg_probe_mfma_bare: `blocks` workgroups of 4 * waves_per_simd waves, each wave `iters` times the MFMAs of one 128 x 64 x 64
+ *   wave k-tile (v_mfma_f32_16x16x32_bf16: mfma_shape 16, v_mfma_f32_32x32x16_bf16: 32) on random register operands.
+ * rg_probe_lds_mfma: the product's 8-wave conv k-loop (conv8_kernel, 256 x 256 x 64 tile) over LDS-resident stages with its
+ *   LDS-DMA issue compiled out; a[blocks * 256][128], b[256][128] bf16 operands, c[blocks * 256][256] bf16 result; iters even.
+ * rg_probe_copy: float4 stream copy of nbytes (multiple of 16).  rg_probe_fill_bf16: n bf16 values uniform in [-1, 1).
+ * *flops_out = algorithmic FLOPs of the launch. */
+int rg_probe_mfma_bare(int mfma_shape, int waves_per_simd, int blocks, int iters, float* scratch, double* flops_out, void* stream);
+int rg_probe_lds_mfma(int mfma_shape, int blocks, int iters, const void* a, const void* b, void* c, double* flops_out,
+                      void* stream);
+int rg_probe_copy(const void* src, void* dst, size_t nbytes, void* stream);
+int rg_probe_fill_bf16(void* p, size_t n, unsigned seed, void* stream);
+
 
 #ifdef __cplusplus
 }

@@ -159,10 +159,14 @@ PROTOTYPES = {
                                  _p, _p]),
     "rg_conv_up_affine": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _f, _p, _z, _p]),
     "rg_g0_fwd_affine": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _f, _p, _z, _p]),
+    "rg_probe_mfma_bare": (_i, [_i, _i, _i, _i, _p, _p, _p]),
+    "rg_probe_lds_mfma": (_i, [_i, _i, _i, _p, _p, _p, _p, _p]),
+    "rg_probe_copy": (_i, [_p, _p, _z, _p]),
+    "rg_probe_fill_bf16": (_i, [_p, _z, C.c_uint, _p]),
 }
 
 # must equal rg_version() of the library (rna_gan_amd/csrc/rg_api.hip): bumped together with PROTOTYPES
-ABI_VERSION = 505
+ABI_VERSION = 600
 
 _lib = None
 

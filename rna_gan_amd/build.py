@@ -12,7 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "librnagan_hip.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
-SOURCES = ["rg_api.hip", "rg_generic.hip", "rg_bn.hip", "rg_misc.hip", "rg_mfma.hip", "rg_conv8.hip", "rg_convp.hip", "rg_convd.hip", "rg_wgrad8.hip", "rg_skinny.hip", "rg_vae.hip", "rg_splitbn.hip", "rg_incep.hip", "rg_g0adam.hip"]
+SOURCES = ["rg_api.hip", "rg_generic.hip", "rg_bn.hip", "rg_misc.hip", "rg_mfma.hip", "rg_conv8.hip", "rg_convp.hip", "rg_convd.hip", "rg_wgrad8.hip", "rg_skinny.hip", "rg_vae.hip", "rg_splitbn.hip", "rg_incep.hip", "rg_g0adam.hip", "rg_probe.hip"]
+# sources a translation unit #includes besides the headers (rg_probe.hip instantiates the product's conv8_kernel template with
+# its measurement flag from the same source text)
+EXTRA_DEPS = {"rg_probe.hip": ["rg_conv8.hip"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
 
@@ -35,7 +38,7 @@ def build_library(force=False, verbose=True):
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ, s.replace(".hip", ".o"))
-        if force or _stale(obj, [src] + headers):
+        if force or _stale(obj, [src] + headers + [os.path.join(CSRC, d) for d in EXTRA_DEPS.get(s, [])]):
             jobs.append((src, obj))
 
     def cc(job):
@@ -66,13 +69,14 @@ def build_debug_library(force=False):
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     d = os.path.join(os.path.dirname(HERE), "tools", "debug")
-    src, out = os.path.join(d, "rg_debug_hold.hip"), os.path.join(d, "librnagan_debug.so")
+    src = os.path.join(d, "rg_debug_hold.hip")
+    # several ranks may get here at once (RNAGAN_DEBUG_HOG under torchrun): each compiles to a file of its own and renames
+    # it into place -- a rank never dlopens a half-written library; a read-only tree uses a per-user cache (the output path is
+    # chosen FIRST, so that the staleness check looks at the copy that will be loaded and a cached build is reused)
+    d_out = d if os.access(d, os.W_OK) else os.path.join(os.path.expanduser("~"), ".cache", "rna_gan_amd")
+    os.makedirs(d_out, exist_ok=True)
+    out = os.path.join(d_out, "librnagan_debug.so")
     if force or _stale(out, [src]):
-        # several ranks may get here at once (RNAGAN_DEBUG_HOG under torchrun): each compiles to a file of its own and renames
-        # it into place -- a rank never dlopens a half-written library; a read-only tree falls back to a per-user cache
-        d_out = d if os.access(d, os.W_OK) else os.path.join(os.path.expanduser("~"), ".cache", "rna_gan_amd")
-        os.makedirs(d_out, exist_ok=True)
-        out = os.path.join(d_out, "librnagan_debug.so")
         tmp = "%s.%d.tmp" % (out, os.getpid())
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-o", tmp, src], capture_output=True, text=True)
         if r.returncode != 0:

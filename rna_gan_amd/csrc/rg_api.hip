@@ -18,7 +18,7 @@ void rg_set_error(const char* fmt, ...) {
 }
 
 // bumped whenever an entry point is added or a signature changes; rna_gan_amd/_abi.py (ABI_VERSION) refuses any other value
-extern "C" int rg_version(void) { return 505; }   // 5.05: round 5 (rg_conv_wgrad_slabs, rg_adam_step_slabs, rg_conv_wgrad_adam; slab dtypes; rg_grad_to_wire, rg_conv_wgrad_wire; rg_skinny_wgrad_slabs, rg_skinny_wgrad_bias)
+extern "C" int rg_version(void) { return 600; }   // 6.00: round 6 (rg_probe_*: on-box ceilings)
 extern "C" const char* rg_last_error(void) { return g_err; }
 
 // ---- kernel-selection knobs: override table in front of the RNAGAN_* environment variables

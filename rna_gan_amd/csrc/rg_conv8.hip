@@ -46,7 +46,10 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 // 32 bytes: the two 16-byte chunks (fh, 4 + fh) of its row, i.e. exactly the two conflict-free ds_read_b128 of the bf16
 // path; which k positions a lane's bytes stand for does not matter as long as A and B agree (both are read the same way).
 typedef int c8_v8i_t __attribute__((ext_vector_type(8)));
-template <int MODE, int WM, int WN, int MF, int EB = 2, int MXF = 0>
+// PROBE (rg_probe.hip only): the k-loop WITHOUT its LDS-DMA issue -- the prologue stages two k-tiles, the loop then runs
+// a2.probe_iters k-tiles over those resident stages (fragment reads, counted waits, barriers and MFMAs unchanged): the rate the
+// 8-wave schedule reaches when nothing has to arrive from L2 -- the measured ceiling bench.py quotes beside the nominal peak.
+template <int MODE, int WM, int WN, int MF, int EB = 2, int MXF = 0, int PROBE = 0>
 __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
   static_assert(WM * WN == 8, "8 waves");
   static_assert(EB == 2 || (EB == 1 && MF == 16), "fp8 operands use the 16x16x32 MFMA");
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
   do {                                                                                      \
     /* P1 */                                                                                \
     C8_READ_A(S, 0);                                                                        \
-    issue_a(ic<1 - (S)>{}, ic<1>{}, (U) + 1);                                               \
+    if constexpr (!PROBE) issue_a(ic<1 - (S)>{}, ic<1>{}, (U) + 1);                        \
     __builtin_amdgcn_s_waitcnt(W_ODD);                                                      \
     C8_SYNC();                                                                              \
     C8_WAIT_A();                                                                            \
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
     C8_SYNC();                                                                              \
     /* P2 */                                                                                \
     C8_READ_B(S, 1, 1);                                                                     \
-    issue_b(ic<(S)>{}, ic<0>{}, (U) + 2);                                                   \
+    if constexpr (!PROBE) issue_b(ic<(S)>{}, ic<0>{}, (U) + 2);                            \
     __builtin_amdgcn_s_waitcnt(W_EVEN);                                                     \
     C8_SYNC();                                                                              \
     C8_WAIT_B(1);                                                                           \
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
     C8_SYNC();                                                                              \
     /* P3 */                                                                                \
     C8_READ_A(S, 1);                                                                        \
-    issue_a(ic<(S)>{}, ic<0>{}, (U) + 2);                                                   \
+    if constexpr (!PROBE) issue_a(ic<(S)>{}, ic<0>{}, (U) + 2);                            \
     __builtin_amdgcn_s_waitcnt(W_ODD);                                                      \
     C8_SYNC();                                                                              \
     C8_WAIT_A();                                                                            \
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
     C8_SYNC();                                                                              \
     /* P4 */                                                                                \
     C8_READ_B(1 - (S), 0, SNX);                                                             \
-    issue_b(ic<(S)>{}, ic<1>{}, (U) + 2);                                                   \
+    if constexpr (!PROBE) issue_b(ic<(S)>{}, ic<1>{}, (U) + 2);                            \
     __builtin_amdgcn_s_waitcnt(W_EVEN);                                                     \
     C8_SYNC();                                                                              \
     C8_WAIT_B(SNX);                                                                         \
@@ -365,6 +368,10 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
   issue_b(ic<1>{}, ic<0>{}, 1);
   issue_a(ic<1>{}, ic<0>{}, 1);
   issue_b(ic<1>{}, ic<1>{}, 1);
+  if constexpr (PROBE) {                                       // the loop issues nothing: both stages complete before it starts
+    issue_a(ic<1>{}, ic<1>{}, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * NA + 3 * NB));      // B0[0] and A0[0] landed (this wave's part)
   C8_SYNC();
   C8_READ_B(0, 0, 0);                                          // "P4 of k-tile -1"
@@ -372,7 +379,8 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
   if (wave >= 4) __builtin_amdgcn_s_barrier();                 // waves 4-7 run one barrier behind waves 0-3
   if (C8_PRIO_MODE == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
   __builtin_amdgcn_sched_barrier(0);
-  for (int u = 0; u < nkt; u += 2) {
+  const int nloop = PROBE ? a2.probe_iters : nkt;
+  for (int u = 0; u < nloop; u += 2) {
     C8_TILE(0, 0, 2, u);
     C8_TILE(1, 2, 0, u + 1);
   }
@@ -549,6 +557,7 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
 }
 
 
+#ifndef RG_CONV8_PROBE_TU
 // ================================================================================================================
 // conv8n_kernel: the transposed conv with 64 output channels (the generator's last MFMA layer 128 -> 64 at 128 x 128 and
 // the discriminator's data gradient of layer 1).  K per parity class is only 4 taps x Cin (8 k-tiles at Cin = 128), so
@@ -890,9 +899,11 @@ __global__ __launch_bounds__(512, 2) void conv8n_kernel(G2Args a2) {
 #undef N8_DSR
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
+#endif  // RG_CONV8_PROBE_TU
 
 }  // namespace
 
+#ifndef RG_CONV8_PROBE_TU
 // transposed conv with 64 output channels, all four parity classes per block (conv8n_kernel): grid = row tiles of 512
 int rg_conv8n_launch(const void* args, unsigned tiles_m, hipStream_t st) {
   const G2Args& a2 = *reinterpret_cast<const G2Args*>(args);
@@ -942,3 +953,4 @@ int rg_conv8_launch(int mode, const void* args, int bm, unsigned gx, unsigned gy
 #undef C8_GO
   return RG_OK;
 }
+#endif  // RG_CONV8_PROBE_TU

@@ -94,6 +94,7 @@ struct G2Args {
   int lgcpt, cmask;            // conv8_kernel: k-tile kt -> tap = kt >> lgcpt, channel block = kt & cmask
   int korder;                  // 1: channel-block-major k order (tap = kt & (taps-1), block = kt / taps; MODE_DOWN taps in
                                // parity-class order): the taps that revisit the same input lines are adjacent k-tiles
+  int probe_iters;             // conv8_kernel<..., PROBE = 1> (rg_probe.hip): k-tiles the loop runs over the two resident stages
 };
 
 typedef __attribute__((address_space(3))) void* lds_vptr_t;

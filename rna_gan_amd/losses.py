@@ -369,11 +369,16 @@ def _dispatch(runner, key, body, inputs, generator, discriminator, stepped, opti
             cw.defer_slabs = True        # ... and the split-K weight gradients of its 4 x 4 layers may stay unreduced slabs
         sk = _skinny_slab_layer(stepped, optimizer)
         ops_s = generator.runtime()[0] if sk is not None else None      # the HipOps the engine runs BOTH networks on (_nets)
+        # nothing deferred may be left over from an earlier pass that raised before its optimizer step consumed it (a stale
+        # pending_wgrad would also keep that pass's operand activations alive)
+        _drop_deferred(deferred, sk, g0)
         if sk is not None:
-            sk.pending_slabs, sk.pending_bias = None, None
             ops_s._skinny_defer = {sk.dw.data_ptr(): sk}      # ... and the image-side layer's per-workgroup partials too
         try:
             loss = body.grads(*a)
+        except BaseException:
+            _drop_deferred(deferred, sk, g0)     # the step below does not run: the next train_op starts clean
+            raise
         finally:
             if g0 is not None:
                 g0.fuse_step = False
@@ -384,6 +389,14 @@ def _dispatch(runner, key, body, inputs, generator, discriminator, stepped, opti
         _finish(stepped, optimizer)
         return loss
     return runner.run(key, full, inputs, mods, [optimizer])
+
+
+def _drop_deferred(deferred, sk, g0):
+    """Forget what a gradient pass left for an optimizer step that will not consume it (see _dispatch.full)."""
+    for cw in list(deferred) + [c for c in (sk, g0) if c is not None]:
+        cw.pending_slabs = None
+        cw.pending_bias = None
+        cw.pending_wgrad = None
 
 
 # split-K weight-gradient slabs summed inside the optimizer step instead of by a reduction launch per layer (single process,
@@ -593,6 +606,9 @@ class _Runner:
 
         wired = _dp_wire_layers(stepped, optimizer)
         head = fac[0].w.numel() if fac is not None else 0
+        # the wire segment table describes the launches of ONE rest graph: it lives with the StepGraph whose function wrote it
+        # (sg_rest.wire_cell below), not in a holder that every variant under this prefix (packs_stale, lr, buf_gen) overwrites
+        cell = {}
 
         def rest_body():
             for cw, slot in wired:
@@ -601,7 +617,7 @@ class _Runner:
                 out = body.rest(holder["pre"])
                 # what the weight-gradient launches of this pass left: kept with the graph this call captures (a replay runs
                 # no host code, its launches are these)
-                holder["wire_table", fac is not None] = _dp_wire_table(stepped, wired, head)
+                cell["wire_table"] = _dp_wire_table(stepped, wired, head)
                 return out
             finally:
                 for cw, _ in wired:
@@ -621,12 +637,15 @@ class _Runner:
                 g0.fuse_step, g0.factor_stage, g0.pending_wgrad = False, None, None
         sg_rest = self._step_graph(key + ("rest", id(sg_pre), fac is not None, len(wired)), rest, [], modules, [], [])
         if sg_rest is not None:
+            if getattr(sg_rest, "wire_cell", None) is None:
+                sg_rest.wire_cell = cell              # created by this call: its function is the closure over this cell
+            cell = sg_rest.wire_cell                  # (an existing graph runs / replays the closure of the call that created it)
             loss = sg_rest(allow_capture=sg_pre is not None and sg_pre.graph is not None)
         else:
             loss = rest()
         ops, _ = stepped.runtime()
         handle = D_.allreduce_start(stepped.flat.grad, compress=(ops.act_dtype == torch.bfloat16), head=head,
-                                    table=holder.get(("wire_table", fac is not None)) if wired else None)
+                                    table=cell.get("wire_table") if wired else None)
         if fac is not None:
             z_all, gy_all, z_mine, gy_mine = fac[1]
             fac = fac + ([D_.allgather_start(z_all, z_mine), D_.allgather_start(gy_all, gy_mine)],)

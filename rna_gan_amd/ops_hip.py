@@ -558,7 +558,11 @@ class HipOps:
         if nb <= 0:
             return False                           # no split-K plan for this shape (or no matrix-core kernel): nothing to defer
         if cw._slab_ws is None or cw._slab_ws.numel() < nb:
-            cw._slab_ws = torch.empty(nb + 4096, dtype=torch.uint8, device=self.device)      # persistent: graphs hold its address
+            # persistent: captured graphs (keyed per batch shape) and the data-parallel wire table hold its address, so a buffer
+            # that a larger batch outgrows is RETIRED, never freed -- a replay of the smaller batch's graph still writes / reads it
+            if cw._slab_ws is not None:
+                self._ws_retired.append(cw._slab_ws)
+            cw._slab_ws = torch.empty(nb + 4096, dtype=torch.uint8, device=self.device)
         ns, sdt = ctypes.c_int(0), ctypes.c_int(0)
         self._timed("conv_wgrad", flops, lambda: check(
             self.lib.rg_conv_wgrad_slabs(_ptr(low0), _ptr(high0), _ptr(low1), _ptr(high1), _ptr(dw), N, Ho, Wo, O, I, self.dt,
@@ -820,7 +824,9 @@ class HipOps:
             if cw._slab_ws is None or cw._slab_ws.numel() < 2 * nb + 4096:
                 if prev is not None:
                     raise RuntimeError("rna_gan_amd: deferred image-side weight gradient: the slab buffer grew between two contributions")
-                cw._slab_ws = torch.empty(2 * nb + 4096, dtype=torch.uint8, device=self.device)     # persistent: graphs hold its address
+                # persistent: graphs hold the addresses -- outgrown buffers are retired, not freed (see _wgrad_slabs)
+                self._ws_retired.extend(b for b in (cw._slab_ws, cw._bias_ws) if b is not None)
+                cw._slab_ws = torch.empty(2 * nb + 4096, dtype=torch.uint8, device=self.device)
                 cw._bias_ws = torch.empty(2 * 1024 * O, dtype=torch.float32, device=self.device)
             want_bias = (dbias is not None and cw.bias is not None and cw.dbias is not None and
                          dbias.data_ptr() == cw.dbias.data_ptr() and O == 64)

@@ -17,6 +17,9 @@ ap.add_argument("--trees", required=True)
 ap.add_argument("--rounds", type=int, default=5)
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--json", default=None)
+ap.add_argument("--cleanup", action="store_true",
+                help="afterwards remove every tree that lives under tools/scratch/ (extracted copies of other commits: they are not "
+                     "source of this tree and inflate line counts / the gpurun snapshot)")
 a = ap.parse_args()
 trees = [t.split("=", 1) for t in a.trees.split(",")]
 res = {n: [] for n, _ in trees}
@@ -41,3 +44,12 @@ line = json.dumps(summary)
 print(line)
 if a.json:
     open(a.json, "w").write(line + "\n")
+
+if a.cleanup:
+    import shutil
+    scratch = os.path.join(os.path.dirname(os.path.abspath(__file__)), "scratch") + os.sep
+    for _, p in trees:
+        p = os.path.abspath(p) + os.sep
+        if p.startswith(scratch) and p != scratch:
+            shutil.rmtree(p, ignore_errors=True)
+            print("[ab_trees] removed %s" % p, file=sys.stderr)
