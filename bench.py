@@ -118,7 +118,7 @@ def parse_args(argv=None):
                     help="N > 1: global-batch BatchNorm / latent / penalty statistics (exact single-process semantics, no "
                          "HIP graphs); default: rank-local statistics (plain DDP), which every reported number uses")
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE configs[1])")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-ceilings", action="store_true", help="skip the on-box ceiling probes (~15 s) of roofline.peak_measured")
@@ -689,7 +689,7 @@ def cpu_baseline(seed):
 
 
 PARITY_EPS = 0.5          # the interpolation coefficient of the parity iteration (both legs)
-PARITY_TOL = {"bf16": 6e-2, "fp32": 2e-3}       # |gpu - cpu| <= tol * (|cpu| + 0.1), as tests/test_train_gpu.py states it
+PARITY_TOL = {"bf16": 6e-2, "fp32": 2e-3, "fp16": 2e-2}       # |gpu - cpu| <= tol * (|cpu| + 0.1), as tests/test_train_gpu.py states it
 
 
 def parity_gpu_leg(args, device):
@@ -727,6 +727,7 @@ def measure_extras(args, device, info):
     """Secondary figures, measured after the headline timed region on the same box in the same process."""
     ex = {}
     for name, fn in (("generate", extra_generate), ("api_path", extra_api_path), ("fp32_step", extra_fp32_step),
+                     ("fp16_step", extra_fp16_step),
                      ("vae_train", extra_vae_train), ("enc200", extra_enc200),
                      ("batch128", lambda a, d, i: extra_batch(a, d, i, 128)),
                      ("batch256", lambda a, d, i: extra_batch(a, d, i, 256))):
@@ -889,6 +890,45 @@ def extra_batch(args, device, info, batch, steps=6, warm=14):
 
 
 F32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X fp32 matrix (= vector) peak, MI355X_MICROARCH.md
+
+
+def extra_fp16_step(args, device, info, steps=10, warm=14):
+    """BASELINE.json configs[3] names fp16 storage: the SAME iteration (same workload, batch, graphs) on the fp16 build of the
+    library (librnagan_hip_f16.so: IEEE fp16 activations / operand images / slabs, v_mfma_f32_*_f16, fp32 accumulation and
+    masters) with the static loss scale on the backward seeds (default 4096 = 64 x 64: seed scale x tangent scale in the
+    penalty step) that rna_gan_amd.optim.Adam removes inside its kernels."""
+    from rna_gan_amd import graphed
+    from rna_gan_amd import losses as PL
+    N = args.batch
+    G, Dm, og, od, (lg, ld, lp) = build(device, "fp16", N, 19198, args.seed)
+    h = info["handles"]
+    gen = torch.Generator(device="cpu").manual_seed(args.seed + 13)
+
+    def it():
+        PL.new_batch()
+        us = [torch.empty(N, 2048).uniform_(-0.3, 0.3, generator=gen).to(device) for _ in range(3)]
+        eps = torch.empty(1).uniform_(0.0, 1.0, generator=gen).to(device)
+        return [lg.step(G, Dm, og, h["rna"], us[0]), ld.step(G, Dm, od, h["real"], h["rna"], us[1], next_u=us[2]),
+                lp.step(G, Dm, od, h["real"], h["rna"], us[2], eps)]
+    for _ in range(warm):
+        it()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ls = it()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    ops, _ = G.runtime()
+    res = {"ms_per_step": round(dt * 1e3, 3), "imgs_per_sec": round(N / dt, 1), "steps": steps, "hip_graphs": bool(graphed.ENABLED),
+           "losses": [round(float(l.item()), 5) for l in ls], "loss_scale": ops.loss_scale,
+           "penalty_seed_scale": ops.gp_seed_scale, "penalty_tangent_scale": ops.gp_tangent_scale,
+           "finite": bool(all(torch.isfinite(p).all() for p in list(G.parameters()) + list(Dm.parameters()))),
+           "kernels": "librnagan_hip_f16.so: the bf16 step's kernels compiled for IEEE fp16 storage (v_mfma_f32_16x16x32_f16 / "
+                      "32x32x16_f16), fp32 accumulation, statistics and masters"}
+    PL.new_batch()
+    del G, Dm, og, od, lg, ld, lp, it
+    torch.cuda.empty_cache()
+    return res
 
 
 def extra_fp32_step(args, device, info, steps=4, warm=10):

@@ -67,7 +67,7 @@ EXTRA_FLAGS = [
     ("--sync_stats", int, 0, "data parallel: 1 = BatchNorm / latent / penalty statistics over the GLOBAL batch (exact "
                               "single-process semantics, no HIP graphs), 0 = rank-local statistics (plain DDP)"),
     ("--batch_size", int, 8, "per-process batch (the reference hard-codes 8, :94)"),
-    ("--precision", str, "bf16", "bf16 (MFMA kernels) or fp32 (parity mode)"),
+    ("--precision", str, "bf16", "bf16 (MFMA kernels), fp16 (the same kernels built for IEEE fp16 storage, loss-scaled backward) or fp32 (parity mode)"),
     ("--betavae_checkpoint", str, "checkpoints/betavae_training_tissues/model_dict_best.pt", "frozen betaVAE weights"),
     ("--steps_per_epoch", int, 100, "synthetic dataset length / batch"),
 ]
@@ -107,8 +107,8 @@ def parse_args():
 
 def main():
     args = parse_args()
-    if args.precision not in ("bf16", "fp32"):
-        raise SystemExit("--precision must be bf16 or fp32")
+    if args.precision not in ("bf16", "fp32", "fp16"):
+        raise SystemExit("--precision must be bf16, fp16 or fp32")
 
     D_.set_sync_stats(bool(args.sync_stats))
     D_.init_from_env()

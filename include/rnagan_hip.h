@@ -44,6 +44,7 @@ extern "C" {
 
 #define RG_F32 0
 #define RG_BF16 1
+#define RG_F16 2   /* IEEE fp16 storage: librnagan_hip_f16.so only (the same sources built with -DRG_HALF_F16; see "fp16 build" below) */
 
 #define RG_ALGO_AUTO 0
 #define RG_ALGO_GENERIC 1
@@ -197,6 +198,11 @@ int rg_last_up_post(const void* x, const float* w, float* y_nchw, int N, int Ho,
                     const float* tanh_img, float* part, void* stream);
 int rg_last_up_part_chan_sum(const float* part, int nblocks, float* out3, int accumulate, void* stream);
 int rg_gp_coef_parts(const float* part, int nblocks, float* sq, float* loss, float* coef, float lambd, void* stream);
+/* the same when the gradient whose squared norm the partials hold carries a loss scale (fp16 build): norm = sqrt(sum) / in_scale,
+ * loss from that norm, coef = lambd * 2 (norm - 1) / norm * out_scale / in_scale -- the tangent direction coef * g' then carries
+ * out_scale.  Scales are powers of two (exact); with in_scale = out_scale = 1 this is rg_gp_coef_parts bit for bit. */
+int rg_gp_coef_parts_scaled(const float* part, int nblocks, float* sq, float* loss, float* coef, float lambd, float in_scale,
+                            float out_scale, void* stream);
 /* rg_last_up with the generator's last train-mode BatchNorm + LeakyReLU applied to its input on the fly (z = the pre-BatchNorm
  * conv output; mean / invstd from rg_bn_finalize_partials or rg_bn_stats_finalize): the no-grad generator forwards of the
  * D-loss and penalty steps (src/wgan_loss.py:247,371) skip the normalisation pass over their largest activation.  Same bf16
@@ -457,6 +463,7 @@ size_t rg_reduce_workspace_bytes(size_t n);
 int rg_sqnorm(const float* x, float* out, size_t n, void* ws, size_t ws_bytes, void* stream);
 /* from sq = ||g||^2: loss = (sqrt(sq)-1)^2 ; coef = lambd*2*(sqrt(sq)-1)/sqrt(sq) (wgan_loss.py:43) */
 int rg_gp_coef(const float* sq, float* loss, float* coef, float lambd, void* stream);
+int rg_gp_coef_scaled(const float* sq, float* loss, float* coef, float lambd, float in_scale, float out_scale, void* stream);
 /* out = x * coef[0] (coef on device: no host sync inside the step) */
 int rg_scale_by(const float* x, const float* coef, float* out, size_t n, void* stream);
 /* out[0] = sign * mean(a - b) (b may be NULL) (wgan_loss.py:24-29) */
@@ -510,6 +517,17 @@ int rg_conv_wgrad_wire(const void* low0, const void* high0, const void* low1, co
  * src/betaVAE_training.py:163). */
 int rg_adam_hyper_dev(int* step_dev, double lr, double beta1, double beta2, double eps, double weight_decay, float* hyper,
                       void* stream);
+/* ... and hyper[8] = grad_scale_inv: every Adam kernel multiplies the gradient it reads (fp32 gradient, slab sums, wire, the tile
+ * of the fused weight-gradient launches) by it before the update -- the unscale of a loss-scaled backward pass (fp16 build:
+ * the backward seeds carry a static power-of-two scale, the mechanism sketched at src/betaVAE.py:184,230-236).  `hyper` is
+ * therefore >= 9 floats for BOTH entry points; rg_adam_hyper_dev writes hyper[8] = 1 (exact: results unchanged). */
+int rg_adam_hyper_dev2(int* step_dev, double lr, double beta1, double beta2, double eps, double weight_decay,
+                       double grad_scale_inv, float* hyper, void* stream);
+/* The 16-bit storage type of this build of the library: RG_BF16 (librnagan_hip.so) or RG_F16 (librnagan_hip_f16.so: the same
+ * sources compiled with -DRG_HALF_F16 -- activations, operand images, split-K slabs and the data-parallel wire are IEEE fp16,
+ * the MFMAs the _f16 forms; every entry point takes RG_F16 where this header says RG_BF16; no rg_probe_* entry points).
+ * BASELINE.json configs[3] names fp16 storage. */
+int rg_storage_dtype(void);
 
 /* ---------------------------------------------------------------------------------------------
  * betaVAE TRAINING (src/betaVAE.py:63-107 model, :145-163 loss, :166-284 train loop).
@@ -652,12 +670,13 @@ int rg_u8_to_norm(const void* src_u8, float* dst, size_t n, float mean, float st
  *   wave k-tile (v_mfma_f32_16x16x32_bf16: mfma_shape 16, v_mfma_f32_32x32x16_bf16: 32) on random register operands.
  * rg_probe_lds_mfma: the product's 8-wave conv k-loop (conv8_kernel, 256 x 256 x 64 tile) over LDS-resident stages with its
  *   LDS-DMA issue compiled out; a[blocks * 256][128], b[256][128] bf16 operands, c[blocks * 256][256] bf16 result; iters even.
- * rg_probe_copy: float4 stream copy of nbytes (multiple of 16).  rg_probe_fill_bf16: n bf16 values uniform in [-1, 1).
+ * rg_probe_copy: float4 stream copy of nbytes (multiple of 16); variant 0 plain / 1 non-temporal loads and stores, `blocks`
+ *   workgroups (0: 2048).  rg_probe_fill_bf16: n bf16 values uniform in [-1, 1).
  * *flops_out = algorithmic FLOPs of the launch. */
 int rg_probe_mfma_bare(int mfma_shape, int waves_per_simd, int blocks, int iters, float* scratch, double* flops_out, void* stream);
 int rg_probe_lds_mfma(int mfma_shape, int blocks, int iters, const void* a, const void* b, void* c, double* flops_out,
                       void* stream);
-int rg_probe_copy(const void* src, void* dst, size_t nbytes, void* stream);
+int rg_probe_copy(const void* src, void* dst, size_t nbytes, int variant, int blocks, void* stream);
 int rg_probe_fill_bf16(void* p, size_t n, unsigned seed, void* stream);
 
 

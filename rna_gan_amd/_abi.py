@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librnagan_hip.so")
 
-RG_F32, RG_BF16 = 0, 1
+RG_F32, RG_BF16, RG_F16 = 0, 1, 2
 ALGO_AUTO, ALGO_GENERIC, ALGO_MFMA = 0, 1, 2
 
 _p = C.c_void_p
@@ -115,6 +115,10 @@ PROTOTYPES = {
     "rg_adam_step_slabs": (_i, [_p, _p, _p, _p, _z, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
     "rg_interp_dev": (_i, [_p, _p, _p, _z, _p, _p]),
     "rg_adam_hyper_dev": (_i, [_p, _d, _d, _d, _d, _d, _p, _p]),
+    "rg_adam_hyper_dev2": (_i, [_p, _d, _d, _d, _d, _d, _d, _p, _p]),
+    "rg_storage_dtype": (_i, []),
+    "rg_gp_coef_scaled": (_i, [_p, _p, _p, _f, _f, _f, _p]),
+    "rg_gp_coef_parts_scaled": (_i, [_p, _i, _p, _p, _p, _f, _f, _f, _p]),
     "rg_transpose_f32": (_i, [_p, _p, _i, _i, _p]),
     "rg_transpose_pack_bf16": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "rg_gemm_nt_bf16_workspace_bytes": (_z, [_i, _i, _i]),
@@ -161,45 +165,65 @@ PROTOTYPES = {
     "rg_g0_fwd_affine": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _f, _p, _z, _p]),
     "rg_probe_mfma_bare": (_i, [_i, _i, _i, _i, _p, _p, _p]),
     "rg_probe_lds_mfma": (_i, [_i, _i, _i, _p, _p, _p, _p, _p]),
-    "rg_probe_copy": (_i, [_p, _p, _z, _p]),
+    "rg_probe_copy": (_i, [_p, _p, _z, _i, _i, _p]),
     "rg_probe_fill_bf16": (_i, [_p, _z, C.c_uint, _p]),
 }
 
 # must equal rg_version() of the library (rna_gan_amd/csrc/rg_api.hip): bumped together with PROTOTYPES
 ABI_VERSION = 600
 
-_lib = None
+_libs = {}
+LIB_PATH_F16 = os.path.join(_HERE, "librnagan_hip_f16.so")
+# entry points that exist only in the bf16 build (measurement kernels written for bf16 operands)
+BF16_ONLY_PREFIXES = ("rg_probe_",)
 
 
-def load():
-    """Load the HIP library (once).  Raises RuntimeError if it cannot be loaded."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(half: str = "bf16"):
+    """Load the HIP library (once per build).  half = "bf16": librnagan_hip.so; "f16": librnagan_hip_f16.so (the same sources,
+    IEEE fp16 as the 16-bit storage type).  Raises RuntimeError if it cannot be loaded."""
+    if half in _libs:
+        return _libs[half]
+    if half not in ("bf16", "f16"):
+        raise ValueError("half must be 'bf16' or 'f16'")
+    path = LIB_PATH if half == "bf16" else LIB_PATH_F16
+    if not os.path.exists(path):
         raise RuntimeError(
             "rna_gan_amd: %s not found. Build it with `python -m rna_gan_amd.build` "
-            "(hipcc --offload-arch=gfx950). There is no CPU / eager fallback." % LIB_PATH)
+            "(hipcc --offload-arch=gfx950). There is no CPU / eager fallback." % path)
     try:
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(path)
     except OSError as e:  # pragma: no cover
-        raise RuntimeError("rna_gan_amd: cannot load %s: %s" % (LIB_PATH, e))
+        raise RuntimeError("rna_gan_amd: cannot load %s: %s" % (path, e))
     for name, (res, args) in PROTOTYPES.items():
+        if half == "f16" and name.startswith(BF16_ONLY_PREFIXES):
+            continue
         fn = getattr(lib, name, None)
         if fn is None:
             raise RuntimeError("rna_gan_amd: symbol %s missing from %s: the library is older than this package -- rebuild "
-                               "it with `python -m rna_gan_amd.build`" % (name, LIB_PATH))
+                               "it with `python -m rna_gan_amd.build`" % (name, path))
         fn.restype = res
         fn.argtypes = args
     got = lib.rg_version()
     if got != ABI_VERSION:
         raise RuntimeError("rna_gan_amd: %s reports ABI version %d, this package binds version %d (a stale or swapped "
-                           "build): rebuild it with `python -m rna_gan_amd.build`" % (LIB_PATH, got, ABI_VERSION))
-    _lib = lib
+                           "build): rebuild it with `python -m rna_gan_amd.build`" % (path, got, ABI_VERSION))
+    want = RG_BF16 if half == "bf16" else RG_F16
+    if lib.rg_storage_dtype() != want:
+        raise RuntimeError("rna_gan_amd: %s stores dtype code %d, expected %d (a swapped build)" % (path, lib.rg_storage_dtype(), want))
+    _libs[half] = lib
     return lib
+
+
+_LAST_ERR_LIBS = ("bf16", "f16")
 
 
 def check(rc: int, what: str):
     if rc != 0:
-        msg = load().rg_last_error()
-        raise RuntimeError("rna_gan_amd: %s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+        # (the error string is thread-local per library: take it from whichever loaded build has one)
+        msgs = []
+        for h in _LAST_ERR_LIBS:
+            if h in _libs:
+                m = _libs[h].rg_last_error()
+                if m:
+                    msgs.append(m.decode() if len(_libs) == 1 else "[%s build] %s" % (h, m.decode()))
+        raise RuntimeError("rna_gan_amd: %s failed (%d): %s" % (what, rc, " | ".join(msgs) if msgs else "?"))

@@ -169,8 +169,9 @@ class betaVAE(nn.Module):
         dev = self.z_mu.weight.device
         if dev.type != "cuda":
             raise RuntimeError("betaVAE.encode runs on the HIP kernels only (move the module to a ROCm GPU)")
-        self._ops = HipOps(torch.bfloat16, dev)
-        packed = self.precision == "bf16"
+        # precision "fp16": the fp16 build of the library (fp16 operand images, v_mfma_*_f16); "fp32": unpacked fp32 weights
+        self._ops = HipOps(torch.float16 if self.precision == "fp16" else torch.bfloat16, dev)
+        packed = self.precision in ("bf16", "fp16")
         plan = []
         with torch.no_grad():
             for blk in list(self.encoder.encoder.children())[1:]:

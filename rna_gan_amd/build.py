@@ -11,11 +11,13 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "librnagan_hip.so")
+OUT_F16 = os.path.join(HERE, "librnagan_hip_f16.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 SOURCES = ["rg_api.hip", "rg_generic.hip", "rg_bn.hip", "rg_misc.hip", "rg_mfma.hip", "rg_conv8.hip", "rg_convp.hip", "rg_convd.hip", "rg_wgrad8.hip", "rg_skinny.hip", "rg_vae.hip", "rg_splitbn.hip", "rg_incep.hip", "rg_g0adam.hip", "rg_probe.hip"]
 # sources a translation unit #includes besides the headers (rg_probe.hip instantiates the product's conv8_kernel template with
 # its measurement flag from the same source text)
 EXTRA_DEPS = {"rg_probe.hip": ["rg_conv8.hip"]}
+BF16_ONLY = ("rg_probe.hip",)      # measurement kernels written for bf16 operands: not part of the fp16 build
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
 
@@ -27,23 +29,32 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=True):
+def build_library(force=False, verbose=True, half="bf16"):
+    """half = "bf16": rna_gan_amd/librnagan_hip.so.  half = "f16": the SAME sources with -DRG_HALF_F16 (the library's 16-bit
+    storage type is IEEE fp16, rg_common.h) -> rna_gan_amd/librnagan_hip_f16.so, without the measurement probes."""
+    if half not in ("bf16", "f16"):
+        raise ValueError("half must be 'bf16' or 'f16'")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    os.makedirs(OBJ, exist_ok=True)
+    f16 = half == "f16"
+    objdir = OBJ + ("_f16" if f16 else "")
+    out = OUT_F16 if f16 else OUT
+    sources = [s for s in SOURCES if not (f16 and s in BF16_ONLY)]
+    flags = FLAGS + (["-DRG_HALF_F16=1"] if f16 else [])
+    os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "rnagan_hip.h"))
     jobs = []
-    for s in SOURCES:
+    for s in sources:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ, s.replace(".hip", ".o"))
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
         if force or _stale(obj, [src] + headers + [os.path.join(CSRC, d) for d in EXTRA_DEPS.get(s, [])]):
             jobs.append((src, obj))
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))
@@ -53,13 +64,18 @@ def build_library(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(cc, jobs))
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(OUT, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in sources]
+    if force or jobs or _stale(out, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s" % r.stderr[-4000:])
-    return OUT
+    return out
+
+
+def build_all(force=False, verbose=True):
+    """Both builds of the library (what __graft_entry__.build() runs)."""
+    return [build_library(force, verbose, "bf16"), build_library(force, verbose, "f16")]
 
 
 def build_debug_library(force=False):
@@ -86,4 +102,4 @@ def build_debug_library(force=False):
 
 
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv))
+    print("\n".join(build_all(force="--force" in sys.argv)))

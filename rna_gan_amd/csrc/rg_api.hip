@@ -55,12 +55,12 @@ extern "C" int rg_set_option(const char* name, int value) {
   return RG_EINVAL;
 }
 
-static bool want_mfma(int algo, int dtype) { return algo != RG_ALGO_GENERIC && dtype == RG_BF16; }
+static bool want_mfma(int algo, int dtype) { return algo != RG_ALGO_GENERIC && dtype == RG_H16; }
 
 // ------------------------------------------------------------------------------------------------
 extern "C" int rg_pack_conv_weight(const float* w, void* wdn, void* wup, int O, int I, int dtype, void* stream) {
   RG_REQUIRE(w && O > 0 && I > 0, RG_EINVAL, "pack_conv_weight: bad args");
-  RG_REQUIRE(dtype == RG_BF16, RG_EUNSUPPORTED, "pack_conv_weight: only bf16 packs exist (fp32 kernels read w)");
+  RG_REQUIRE(dtype == RG_H16, RG_EUNSUPPORTED, "pack_conv_weight: only bf16 packs exist (fp32 kernels read w)");
   return rg_mfma_pack_conv_weight(w, wdn, wup, O, I, rg_stream(stream));
 }
 
@@ -85,7 +85,7 @@ extern "C" int rg_conv_split(int up, int N, int Hlow, int Wlow, int O, int I, in
 
 extern "C" int rg_conv_slab_dtype(int up, int N, int Hlow, int Wlow, int O, int I, int dtype, int algo) {
   if (rg_conv_split(up, N, Hlow, Wlow, O, I, dtype, algo) <= 1) return RG_F32;
-  return rg_mfma_conv_slab16(up, N, Hlow, Wlow, O, I) ? RG_BF16 : RG_F32;
+  return rg_mfma_conv_slab16(up, N, Hlow, Wlow, O, I) ? RG_H16 : RG_F32;
 }
 
 extern "C" int rg_conv_down_partial(const void* x, const void* wdn, int N, int Hi, int Wi, int I, int O, int dtype, int algo,
@@ -267,7 +267,7 @@ extern "C" int rg_first_down(const float* x_nchw, const float* w, const float* b
 extern "C" int rg_first_down_bits(const float* x_nchw, const float* w, const float* bias, void* y, void* bits, int N, int H,
                                   int W, int I, int O, float slope, int dtype, void* stream) {
   RG_REQUIRE(x_nchw && w && y && bits && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && I > 0 && O == 64 &&
-                 dtype == RG_BF16, RG_EINVAL, "first_down_bits: bad args (64 bf16 output channels)");
+                 dtype == RG_H16, RG_EINVAL, "first_down_bits: bad args (64 bf16 output channels)");
   if (rg_skinny_supported(I, O))
     return rg_skinny_first_down(x_nchw, w, bias, y, bits, N, H, W, I, O, slope, dtype, rg_stream(stream));
   int rc = rg_generic_first_down(x_nchw, w, bias, y, N, H, W, I, O, slope, dtype, rg_stream(stream));
@@ -347,6 +347,13 @@ extern "C" int rg_last_up_part_chan_sum(const float* part, int nblocks, float* o
   RG_REQUIRE(part && out3 && nblocks > 0, RG_EINVAL, "last_up_part_chan_sum: bad args");
   return rg_skinny_lu_part_final(part, nblocks, out3, accumulate, 0, nullptr, nullptr, 0.f, rg_stream(stream));
 }
+extern "C" int rg_gp_coef_parts_scaled(const float* part, int nblocks, float* sq, float* loss, float* coef, float lambd,
+                                       float in_scale, float out_scale, void* stream) {
+  RG_REQUIRE(part && loss && coef && nblocks > 0 && in_scale > 0.f && out_scale > 0.f, RG_EINVAL, "gp_coef_parts: bad args");
+  return rg_skinny_lu_part_final(part, nblocks, sq, 0, 1, loss, coef, lambd, rg_stream(stream), in_scale, out_scale);
+}
+// the 16-bit storage type of this build of the library: RG_BF16 (librnagan_hip.so) or RG_F16 (librnagan_hip_f16.so)
+extern "C" int rg_storage_dtype(void) { return RG_H16; }
 extern "C" int rg_gp_coef_parts(const float* part, int nblocks, float* sq, float* loss, float* coef, float lambd,
                                 void* stream) {
   RG_REQUIRE(part && loss && coef && nblocks > 0, RG_EINVAL, "gp_coef_parts: bad args");
@@ -422,7 +429,7 @@ extern "C" int rg_pack_g0_weight_from_bf16(const void* w_bf16, void* wp, int E, 
 }
 extern "C" int rg_pack_g0_weight(const float* w, void* wp, int E, int C, int dtype, void* stream) {
   RG_REQUIRE(w && wp && E > 0 && C > 0, RG_EINVAL, "pack_g0_weight: bad args");
-  RG_REQUIRE(dtype == RG_BF16, RG_EUNSUPPORTED, "pack_g0_weight: only bf16 packs exist");
+  RG_REQUIRE(dtype == RG_H16, RG_EUNSUPPORTED, "pack_g0_weight: only bf16 packs exist");
   return rg_mfma_pack_g0_weight(w, wp, E, C, rg_stream(stream));
 }
 
@@ -438,7 +445,7 @@ extern "C" int rg_g0_fwd(const float* z, const float* w, const void* wp, void* y
   RG_REQUIRE(z && y && N > 0 && E > 0 && C > 0, RG_EINVAL, "g0_fwd: bad args");
   if (want_mfma(algo, dtype) && wp && rg_mfma_plain_supported(N, E, 16 * C)) {
     RG_REQUIRE(ws && ws_bytes >= (size_t)N * E * 2, RG_EWORKSPACE, "g0_fwd: workspace too small");
-    int rc = rg_cast_pad(z, ws, N, E, E, RG_BF16, stream);
+    int rc = rg_cast_pad(z, ws, N, E, E, RG_H16, stream);
     if (rc) return rc;
     return rg_mfma_gemm_plain(ws, wp, y, N, E, 16 * C, 16 * C, rg_stream(stream));
   }
@@ -452,7 +459,7 @@ extern "C" int rg_g0_fwd_affine(const float* z, const void* wp, void* y, int N, 
   RG_REQUIRE(z && wp && y && scale && shift && N > 0 && E > 0 && C > 0, RG_EINVAL, "g0_fwd_affine: bad args");
   RG_REQUIRE(rg_mfma_plain_supported(N, E, 16 * C), RG_EUNSUPPORTED, "g0_fwd_affine: shape not supported by the MFMA kernel");
   RG_REQUIRE(ws && ws_bytes >= (size_t)N * E * 2, RG_EWORKSPACE, "g0_fwd_affine: workspace too small");
-  int rc = rg_cast_pad(z, ws, N, E, E, RG_BF16, stream);
+  int rc = rg_cast_pad(z, ws, N, E, E, RG_H16, stream);
   if (rc) return rc;
   return rg_mfma_gemm_plain(ws, wp, y, N, E, 16 * C, 16 * C, rg_stream(stream), scale, shift, slope);
 }
@@ -514,7 +521,7 @@ extern "C" int rg_linear_affine_act(const float* x, int ldx, const float* w, con
     size_t xb = rg_align_up((size_t)M * kp * 2, 256);
     RG_REQUIRE(ws && ws_bytes >= (size_t)M * kp * 2, RG_EWORKSPACE, "linear: workspace too small");
     RG_REQUIRE(ldx == K, RG_EINVAL, "linear(MFMA): x must be dense");
-    int rc = rg_cast_pad(x, ws, M, K, kp, RG_BF16, stream);
+    int rc = rg_cast_pad(x, ws, M, K, kp, RG_H16, stream);
     if (rc) return rc;
     void* slab = ws_bytes > xb ? (char*)ws + xb : nullptr;
     return rg_mfma_linear(ws, wp, scale, shift, y, ldy, M, kp, Nout, slope, slab, ws_bytes > xb ? ws_bytes - xb : 0,
@@ -541,7 +548,7 @@ extern "C" int rg_upconv3_fwd(const void* x, const float* w, const float* bias, 
                               int Cout, int out_nchw_f32, int dtype, int algo, void* ws, size_t ws_bytes, void* stream) {
   RG_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, RG_EINVAL, "upconv3_fwd: bad args");
   // bf16 NHWC output with Cin % 64 == 0: matrix cores (pad image + 9-tap implicit GEMM); otherwise the functor kernel
-  const bool mfma_ok = dtype == RG_BF16 && (out_nchw_f32 ? rg_mfma_upconv3_image_supported(N, H, W, Cin, Cout)
+  const bool mfma_ok = dtype == RG_H16 && (out_nchw_f32 ? rg_mfma_upconv3_image_supported(N, H, W, Cin, Cout)
                                                          : rg_mfma_upconv3_supported(N, H, W, Cin, Cout));
   RG_REQUIRE(mfma_ok || algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "upconv3_fwd: shape/dtype not supported by the MFMA kernel");
   if (mfma_ok && algo != RG_ALGO_GENERIC && out_nchw_f32)
@@ -553,7 +560,7 @@ extern "C" int rg_upconv3_fwd(const void* x, const float* w, const float* bias, 
 extern "C" int rg_upconv3_bwd_data(const void* gy, int gy_nchw_f32, const float* w, void* gx, int N, int H, int W,
                                    int Cin, int Cout, int dtype, int algo, void* ws, size_t ws_bytes, void* stream) {
   RG_REQUIRE(gy && w && gx && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, RG_EINVAL, "upconv3_bwd_data: bad args");
-  const bool mfma_ok = dtype == RG_BF16 && !gy_nchw_f32 && rg_mfma_upconv3_bwd_supported(N, H, W, Cin, Cout);
+  const bool mfma_ok = dtype == RG_H16 && !gy_nchw_f32 && rg_mfma_upconv3_bwd_supported(N, H, W, Cin, Cout);
   RG_REQUIRE(mfma_ok || algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "upconv3_bwd_data: shape/dtype not supported by the MFMA kernel");
   if (mfma_ok && algo != RG_ALGO_GENERIC)
     return rg_mfma_upconv3_bwd_data(gy, w, gx, N, H, W, Cin, Cout, ws, ws_bytes, rg_stream(stream));
@@ -562,7 +569,7 @@ extern "C" int rg_upconv3_bwd_data(const void* gy, int gy_nchw_f32, const float*
 extern "C" int rg_upconv3_wgrad(const void* gy, int gy_nchw_f32, const void* x, float* dw, int N, int H, int W, int Cin,
                                 int Cout, int dtype, int algo, int accumulate, void* ws, size_t ws_bytes, void* stream) {
   RG_REQUIRE(gy && x && dw && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, RG_EINVAL, "upconv3_wgrad: bad args");
-  const bool mfma_ok = dtype == RG_BF16 && (gy_nchw_f32 ? rg_mfma_upconv3_image_supported(N, H, W, Cin, Cout)
+  const bool mfma_ok = dtype == RG_H16 && (gy_nchw_f32 ? rg_mfma_upconv3_image_supported(N, H, W, Cin, Cout)
                                                         : rg_mfma_upconv3_wgrad_supported(N, H, W, Cin, Cout));
   RG_REQUIRE(mfma_ok || algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "upconv3_wgrad: shape/dtype not supported by the MFMA kernel");
   if (mfma_ok && algo != RG_ALGO_GENERIC && gy_nchw_f32)

@@ -35,7 +35,7 @@ static Plan make_plan(int M, int C, int target_blocks, int gy_cap = 512) {
 
 // upper bound of gy over both element types (workspace sizing)
 static int max_gy(int M, int C) {
-  Plan a = make_plan<float>(M, C, 1536), b = make_plan<bf16_t>(M, C, 1536);
+  Plan a = make_plan<float>(M, C, 1536), b = make_plan<h16_t>(M, C, 1536);
   return a.gy > b.gy ? a.gy : b.gy;
 }
 

@@ -28,25 +28,75 @@ void rg_set_error(const char* fmt, ...);
     }                                                                      \
   } while (0)
 
+#ifdef RG_HALF_F16
+#define RG_H16 RG_F16      /* the dtype code of this build's 16-bit storage type (see below) */
+#else
+#define RG_H16 RG_BF16
+#endif
 static inline hipStream_t rg_stream(void* s) { return (hipStream_t)s; }
-static inline size_t rg_dtype_size(int dtype) { return dtype == RG_BF16 ? 2 : 4; }
+static inline size_t rg_dtype_size(int dtype) { return dtype == RG_H16 ? 2 : 4; }
 static inline bool rg_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int rg_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline size_t rg_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---------------------------------------------------------------------------------------------
-// bf16 storage type (raw 16 bits) and conversions.  Round-to-nearest-even via the compiler's
-// native conversion (v_cvt_pk_bf16_f32 on gfx950, NaN-preserving).
+// The 16-bit storage type of this BUILD of the library (raw 16 bits in memory; arithmetic, statistics and accumulation are
+// fp32 everywhere).  Default: bf16 (librnagan_hip.so; callers pass RG_BF16).  With -DRG_HALF_F16 the same sources build
+// librnagan_hip_f16.so, whose 16-bit type is IEEE fp16 (callers pass RG_F16; BASELINE.json configs[3]: the same kernels on
+// v_mfma_f32_*_f16, which take the same cycles as the bf16 forms -- MI355X_MICROARCH, matrix cores).  Everything that touches
+// the stored bits goes through these helpers and the RG_MFMA_* macros of rg_gather.h.  Round-to-nearest-even by the
+// compiler's native conversions (v_cvt_pk_bf16_f32 / v_cvt_f16_f32: NaN-preserving; fp16 overflow gives infinity).
 // ---------------------------------------------------------------------------------------------
-struct bf16_t { uint16_t bits; };
+struct h16_t { uint16_t bits; };
 
-__device__ __forceinline__ float bf16_to_f32(uint16_t b) {
+#ifdef RG_HALF_F16
+#define RG_H16_NAME "f16"
+#define RG_H16_ONE 0x3c00      /* 1.0 */
+__device__ __forceinline__ float h16_to_f32(uint16_t b) { return (float)__builtin_bit_cast(_Float16, b); }
+__device__ __forceinline__ uint16_t f32_to_h16(float f) {
+  _Float16 h = (_Float16)f;
+  return __builtin_bit_cast(uint16_t, h);
+}
+// the low / high element of a packed pair
+__device__ __forceinline__ float h16lo_to_f32(uint32_t pair) { return h16_to_f32((uint16_t)pair); }
+__device__ __forceinline__ float h16hi_to_f32(uint32_t pair) { return h16_to_f32((uint16_t)(pair >> 16)); }
+#else
+#define RG_H16_NAME "bf16"
+#define RG_H16_ONE 0x3f80      /* 1.0 */
+__device__ __forceinline__ float h16_to_f32(uint16_t b) {
   return __uint_as_float(((uint32_t)b) << 16);
 }
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+__device__ __forceinline__ uint16_t f32_to_h16(float f) {
   __bf16 h = (__bf16)f;
   return __builtin_bit_cast(uint16_t, h);
 }
+__device__ __forceinline__ float h16lo_to_f32(uint32_t pair) { return __uint_as_float(pair << 16); }
+__device__ __forceinline__ float h16hi_to_f32(uint32_t pair) { return __uint_as_float(pair & 0xffff0000u); }
+#endif
+
+// matrix instructions on the library's 16-bit type (8 elements per lane and operand; the trailing cbsz / abid / blgp arguments of
+// the builtins are always 0 here and are accepted for call-site compatibility)
+typedef __attribute__((ext_vector_type(16))) float rg_f32x16;
+typedef __attribute__((ext_vector_type(4))) float rg_f32x4;
+#ifdef RG_HALF_F16
+typedef __attribute__((ext_vector_type(8))) _Float16 rg_h16x8;
+#define RG_MFMA_H16_ASM_16x16x32 "v_mfma_f32_16x16x32_f16"
+__device__ __forceinline__ rg_f32x16 rg_mfma_h16_32x32x16(rg_h16x8 a, rg_h16x8 b, rg_f32x16 c, int, int, int) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ rg_f32x4 rg_mfma_h16_16x16x32(rg_h16x8 a, rg_h16x8 b, rg_f32x4 c, int, int, int) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+#else
+typedef __attribute__((ext_vector_type(8))) __bf16 rg_h16x8;
+#define RG_MFMA_H16_ASM_16x16x32 "v_mfma_f32_16x16x32_bf16"
+__device__ __forceinline__ rg_f32x16 rg_mfma_h16_32x32x16(rg_h16x8 a, rg_h16x8 b, rg_f32x16 c, int, int, int) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ rg_f32x4 rg_mfma_h16_16x16x32(rg_h16x8 a, rg_h16x8 b, rg_f32x4 c, int, int, int) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+#endif
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -55,11 +105,11 @@ template <> struct Elem<float> {
   __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
   __device__ static __forceinline__ float round(float v) { return v; }
 };
-template <> struct Elem<bf16_t> {
-  static constexpr int dtype = RG_BF16;
-  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(p->bits); }
-  __device__ static __forceinline__ void st(bf16_t* p, float v) { p->bits = f32_to_bf16(v); }
-  __device__ static __forceinline__ float round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+template <> struct Elem<h16_t> {
+  static constexpr int dtype = RG_H16;
+  __device__ static __forceinline__ float ld(const h16_t* p) { return h16_to_f32(p->bits); }
+  __device__ static __forceinline__ void st(h16_t* p, float v) { p->bits = f32_to_h16(v); }
+  __device__ static __forceinline__ float round(float v) { return h16_to_f32(f32_to_h16(v)); }
 };
 
 // vector load/store of VEC (1 or 4) consecutive elements as floats
@@ -77,20 +127,20 @@ template <> struct Vec<float, 4> {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
   }
 };
-template <> struct Vec<bf16_t, 1> {
-  __device__ static __forceinline__ void ld(const bf16_t* p, float* o) { o[0] = bf16_to_f32(p->bits); }
-  __device__ static __forceinline__ void st(bf16_t* p, const float* v) { p->bits = f32_to_bf16(v[0]); }
+template <> struct Vec<h16_t, 1> {
+  __device__ static __forceinline__ void ld(const h16_t* p, float* o) { o[0] = h16_to_f32(p->bits); }
+  __device__ static __forceinline__ void st(h16_t* p, const float* v) { p->bits = f32_to_h16(v[0]); }
 };
-template <> struct Vec<bf16_t, 4> {
-  __device__ static __forceinline__ void ld(const bf16_t* p, float* o) {
+template <> struct Vec<h16_t, 4> {
+  __device__ static __forceinline__ void ld(const h16_t* p, float* o) {
     uint2 t = *reinterpret_cast<const uint2*>(p);
-    o[0] = __uint_as_float(t.x << 16); o[1] = __uint_as_float(t.x & 0xffff0000u);
-    o[2] = __uint_as_float(t.y << 16); o[3] = __uint_as_float(t.y & 0xffff0000u);
+    o[0] = h16lo_to_f32(t.x); o[1] = h16hi_to_f32(t.x);
+    o[2] = h16lo_to_f32(t.y); o[3] = h16hi_to_f32(t.y);
   }
-  __device__ static __forceinline__ void st(bf16_t* p, const float* v) {
+  __device__ static __forceinline__ void st(h16_t* p, const float* v) {
     uint2 t;
-    t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    t.x = (uint32_t)f32_to_h16(v[0]) | ((uint32_t)f32_to_h16(v[1]) << 16);
+    t.y = (uint32_t)f32_to_h16(v[2]) | ((uint32_t)f32_to_h16(v[3]) << 16);
     *reinterpret_cast<uint2*>(p) = t;
   }
 };
@@ -99,20 +149,20 @@ template <> struct Vec<float, 8> {
   __device__ static __forceinline__ void ld(const float* p, float* o) { Vec<float, 4>::ld(p, o); Vec<float, 4>::ld(p + 4, o + 4); }
   __device__ static __forceinline__ void st(float* p, const float* v) { Vec<float, 4>::st(p, v); Vec<float, 4>::st(p + 4, v + 4); }
 };
-template <> struct Vec<bf16_t, 8> {
-  __device__ static __forceinline__ void ld(const bf16_t* p, float* o) {
+template <> struct Vec<h16_t, 8> {
+  __device__ static __forceinline__ void ld(const h16_t* p, float* o) {
     uint4 t = *reinterpret_cast<const uint4*>(p);
-    o[0] = __uint_as_float(t.x << 16); o[1] = __uint_as_float(t.x & 0xffff0000u);
-    o[2] = __uint_as_float(t.y << 16); o[3] = __uint_as_float(t.y & 0xffff0000u);
-    o[4] = __uint_as_float(t.z << 16); o[5] = __uint_as_float(t.z & 0xffff0000u);
-    o[6] = __uint_as_float(t.w << 16); o[7] = __uint_as_float(t.w & 0xffff0000u);
+    o[0] = h16lo_to_f32(t.x); o[1] = h16hi_to_f32(t.x);
+    o[2] = h16lo_to_f32(t.y); o[3] = h16hi_to_f32(t.y);
+    o[4] = h16lo_to_f32(t.z); o[5] = h16hi_to_f32(t.z);
+    o[6] = h16lo_to_f32(t.w); o[7] = h16hi_to_f32(t.w);
   }
-  __device__ static __forceinline__ void st(bf16_t* p, const float* v) {
+  __device__ static __forceinline__ void st(h16_t* p, const float* v) {
     uint4 t;
-    t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-    t.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-    t.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+    t.x = (uint32_t)f32_to_h16(v[0]) | ((uint32_t)f32_to_h16(v[1]) << 16);
+    t.y = (uint32_t)f32_to_h16(v[2]) | ((uint32_t)f32_to_h16(v[3]) << 16);
+    t.z = (uint32_t)f32_to_h16(v[4]) | ((uint32_t)f32_to_h16(v[5]) << 16);
+    t.w = (uint32_t)f32_to_h16(v[6]) | ((uint32_t)f32_to_h16(v[7]) << 16);
     *reinterpret_cast<uint4*>(p) = t;
   }
 };
@@ -123,7 +173,6 @@ template <> struct Vec<bf16_t, 8> {
 // s_waitcnt vmcnt(0), convert, load, ... in the ISA of the BatchNorm-backward apply.
 typedef __attribute__((ext_vector_type(4))) unsigned rg_u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned rg_u32x2;
-typedef __attribute__((ext_vector_type(4))) float rg_f32x4;
 template <typename T, int VEC> struct RawVec;
 template <> struct RawVec<float, 1> {
   float r;
@@ -144,27 +193,27 @@ template <> struct RawVec<float, 8> {
     o[0] = r0.x; o[1] = r0.y; o[2] = r0.z; o[3] = r0.w; o[4] = r1.x; o[5] = r1.y; o[6] = r1.z; o[7] = r1.w;
   }
 };
-template <> struct RawVec<bf16_t, 1> {
+template <> struct RawVec<h16_t, 1> {
   uint16_t r;
-  __device__ __forceinline__ void ld(const bf16_t* p) { r = p->bits; }
-  __device__ __forceinline__ void cvt(float* o) const { o[0] = bf16_to_f32(r); }
+  __device__ __forceinline__ void ld(const h16_t* p) { r = p->bits; }
+  __device__ __forceinline__ void cvt(float* o) const { o[0] = h16_to_f32(r); }
 };
-template <> struct RawVec<bf16_t, 4> {
+template <> struct RawVec<h16_t, 4> {
   rg_u32x2 r;
-  __device__ __forceinline__ void ld(const bf16_t* p) { r = *reinterpret_cast<const rg_u32x2*>(p); }
+  __device__ __forceinline__ void ld(const h16_t* p) { r = *reinterpret_cast<const rg_u32x2*>(p); }
   __device__ __forceinline__ void cvt(float* o) const {
-    o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
-    o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
+    o[0] = h16lo_to_f32(r.x); o[1] = h16hi_to_f32(r.x);
+    o[2] = h16lo_to_f32(r.y); o[3] = h16hi_to_f32(r.y);
   }
 };
-template <> struct RawVec<bf16_t, 8> {
+template <> struct RawVec<h16_t, 8> {
   rg_u32x4 r;
-  __device__ __forceinline__ void ld(const bf16_t* p) { r = *reinterpret_cast<const rg_u32x4*>(p); }
+  __device__ __forceinline__ void ld(const h16_t* p) { r = *reinterpret_cast<const rg_u32x4*>(p); }
   __device__ __forceinline__ void cvt(float* o) const {
-    o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
-    o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
-    o[4] = __uint_as_float(r.z << 16); o[5] = __uint_as_float(r.z & 0xffff0000u);
-    o[6] = __uint_as_float(r.w << 16); o[7] = __uint_as_float(r.w & 0xffff0000u);
+    o[0] = h16lo_to_f32(r.x); o[1] = h16hi_to_f32(r.x);
+    o[2] = h16lo_to_f32(r.y); o[3] = h16hi_to_f32(r.y);
+    o[4] = h16lo_to_f32(r.z); o[5] = h16hi_to_f32(r.z);
+    o[6] = h16lo_to_f32(r.w); o[7] = h16hi_to_f32(r.w);
   }
 };
 
@@ -204,7 +253,9 @@ __device__ __forceinline__ void up_taps(int u, int L, int& i0, int& i1, float& l
 // ---- the Adam update of one element (torch.optim.Adam, single-tensor path), shared by every kernel that applies it (rg_misc.hip's
 // streaming kernels, the generator layer-0 and conv weight-gradient kernels that step their tensor in the epilogue): ONE
 // expression, so that a tensor stepped by any of them comes out bit-identical.  hyper[0..7] = b1, b2, 1 - b1, 1 - b2, eps,
-// lr / bc1, 1 / sqrt(bc2), weight decay (rg_adam_hyper_dev).
+// lr / bc1, 1 / sqrt(bc2), weight decay (rg_adam_hyper_dev); hyper[8] = 1 / loss scale: the factor every kernel applies to the
+// gradient it reads before the update (1 except in the fp16 build's loss-scaled backward; a multiplication by 1.0f is exact, so the
+// unscaled paths are bit for bit what they were).
 __device__ __forceinline__ void rg_adam_upd(float& pp, float gg, float& mm, float& vv, float b2, float omb1, float omb2, float eps,
                                             float step_size, float inv_sqrt_bc2, float wd) {
   if (wd != 0.f) gg += wd * pp;               // torch.optim.Adam weight_decay (L2 on the gradient); betaVAE training
@@ -216,17 +267,17 @@ __device__ __forceinline__ void rg_adam_upd(float& pp, float gg, float& mm, floa
   pp -= step_size * (mm / denom);
 }
 struct RgAdamHyper {
-  float b1, b2, omb1, omb2, eps, step_size, inv_sqrt_bc2, wd;
+  float b1, b2, omb1, omb2, eps, step_size, inv_sqrt_bc2, wd, ginv;
   __device__ __forceinline__ void load(const float* __restrict__ h) {
-    b1 = h[0]; b2 = h[1]; omb1 = h[2]; omb2 = h[3]; eps = h[4]; step_size = h[5]; inv_sqrt_bc2 = h[6]; wd = h[7];
+    b1 = h[0]; b2 = h[1]; omb1 = h[2]; omb2 = h[3]; eps = h[4]; step_size = h[5]; inv_sqrt_bc2 = h[6]; wd = h[7]; ginv = h[8];
   }
   __device__ __forceinline__ void upd(float& pp, float gg, float& mm, float& vv) const {
-    rg_adam_upd(pp, gg, mm, vv, b2, omb1, omb2, eps, step_size, inv_sqrt_bc2, wd);
+    rg_adam_upd(pp, gg * ginv, mm, vv, b2, omb1, omb2, eps, step_size, inv_sqrt_bc2, wd);
   }
 };
 
 // dtype dispatch helper for host code
 #define RG_DISPATCH_DTYPE(dtype, T, ...)                                  \
   if ((dtype) == RG_F32) { using T = float; __VA_ARGS__ }                 \
-  else if ((dtype) == RG_BF16) { using T = bf16_t; __VA_ARGS__ }          \
+  else if ((dtype) == RG_H16) { using T = h16_t; __VA_ARGS__ }          \
   else { rg_set_error("bad dtype %d", (int)(dtype)); return RG_EINVAL; }

@@ -309,12 +309,12 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
             __builtin_bit_cast(long, aQ[t_ * NKK + kk_]), __builtin_bit_cast(long, bQ[SET][c_ * NKK + kk_]),   \
             acc[I][J][t_ * NBT + c_], 0, 0, 0);                                                                \
       else if constexpr (MF == 32)                                                                             \
-        acc[I][J][t_ * NBT + c_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                    \
-            __builtin_bit_cast(bf16x8_t, aR[(t_ * NKK + kk_) & 7]), __builtin_bit_cast(bf16x8_t, bS[SET][(c_ * NKK + kk_) & 3]), \
+        acc[I][J][t_ * NBT + c_] = rg_mfma_h16_32x32x16(                                    \
+            __builtin_bit_cast(h16x8_t, aR[(t_ * NKK + kk_) & 7]), __builtin_bit_cast(h16x8_t, bS[SET][(c_ * NKK + kk_) & 3]), \
             acc[I][J][t_ * NBT + c_], 0, 0, 0);                                                                \
       else                                                                                                     \
-        acc[I][J][t_ * NBT + c_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                    \
-            __builtin_bit_cast(bf16x8_t, aR[(t_ * NKK + kk_) & 7]), __builtin_bit_cast(bf16x8_t, bS[SET][(c_ * NKK + kk_) & 3]), \
+        acc[I][J][t_ * NBT + c_] = rg_mfma_h16_16x16x32(                                    \
+            __builtin_bit_cast(h16x8_t, aR[(t_ * NKK + kk_) & 7]), __builtin_bit_cast(h16x8_t, bS[SET][(c_ * NKK + kk_) & 3]), \
             acc[I][J][t_ * NBT + c_], 0, 0, 0);                                                                \
     }                                                                                                          \
     if (C8_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(0);                                                      \
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
           for (int s = 0; s < NAT; ++s)
 #pragma unroll
             for (int r = 0; r < ACC_R; ++r) {
-              const float v = bf16_to_f32(f32_to_bf16(acc[i][j][s * NBT + c][r]));
+              const float v = h16_to_f32(f32_to_h16(acc[i][j][s * NBT + c][r]));
               s1 += v; s2 += v * v;
             }
 #pragma unroll
@@ -476,10 +476,10 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
       if (a2.nsplit > 1) {
         if (a2.slab16) {                 // bf16 partial tile: 16 instead of 32 bytes per thread and row (rounded partial sums)
           uint4 o;
-          o.x = (uint32_t)f32_to_bf16(v0.x) | ((uint32_t)f32_to_bf16(v0.y) << 16);
-          o.y = (uint32_t)f32_to_bf16(v0.z) | ((uint32_t)f32_to_bf16(v0.w) << 16);
-          o.z = (uint32_t)f32_to_bf16(v1.x) | ((uint32_t)f32_to_bf16(v1.y) << 16);
-          o.w = (uint32_t)f32_to_bf16(v1.z) | ((uint32_t)f32_to_bf16(v1.w) << 16);
+          o.x = (uint32_t)f32_to_h16(v0.x) | ((uint32_t)f32_to_h16(v0.y) << 16);
+          o.y = (uint32_t)f32_to_h16(v0.z) | ((uint32_t)f32_to_h16(v0.w) << 16);
+          o.z = (uint32_t)f32_to_h16(v1.x) | ((uint32_t)f32_to_h16(v1.y) << 16);
+          o.w = (uint32_t)f32_to_h16(v1.z) | ((uint32_t)f32_to_h16(v1.w) << 16);
           *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a2.slab) + (long long)zs * a2.slab_stride + orow * g.ldc + col) = o;
           continue;
         }
@@ -507,10 +507,10 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
           continue;
         }
         uint4 o;
-        o.x = (uint32_t)f32_to_bf16(v0.x) | ((uint32_t)f32_to_bf16(v0.y) << 16);
-        o.y = (uint32_t)f32_to_bf16(v0.z) | ((uint32_t)f32_to_bf16(v0.w) << 16);
-        o.z = (uint32_t)f32_to_bf16(v1.x) | ((uint32_t)f32_to_bf16(v1.y) << 16);
-        o.w = (uint32_t)f32_to_bf16(v1.z) | ((uint32_t)f32_to_bf16(v1.w) << 16);
+        o.x = (uint32_t)f32_to_h16(v0.x) | ((uint32_t)f32_to_h16(v0.y) << 16);
+        o.y = (uint32_t)f32_to_h16(v0.z) | ((uint32_t)f32_to_h16(v0.w) << 16);
+        o.z = (uint32_t)f32_to_h16(v1.x) | ((uint32_t)f32_to_h16(v1.y) << 16);
+        o.w = (uint32_t)f32_to_h16(v1.z) | ((uint32_t)f32_to_h16(v1.w) << 16);
         *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(g.C) + orow * g.ldc + col) = o;
         if (bwd) {
           // BwdRedF's arithmetic on the STORED (bf16-rounded) gradient and the consumer's stored z
@@ -521,8 +521,8 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
               const int i = 2 * e + hh;
-              const float gaf = __uint_as_float(hh ? (od[e] & 0xffff0000u) : (od[e] << 16));
-              const float zf = __uint_as_float(hh ? (zd[e] & 0xffff0000u) : (zd[e] << 16));
+              const float gaf = hh ? h16hi_to_f32(od[e]) : h16lo_to_f32(od[e]);
+              const float zf = hh ? h16hi_to_f32(zd[e]) : h16lo_to_f32(zd[e]);
               const float xh = (zf - bmu[i]) * brs[i];
               const float gy = gaf * lrelu_mask(xh * bga[i] + bbe[i], g.bwd_slope);
               bs1[i] += gy; bs2[i] += gy * xh;
@@ -694,8 +694,8 @@ __global__ __launch_bounds__(512, 2) void conv8n_kernel(G2Args a2) {
     __builtin_amdgcn_s_setprio(1);                                                                             \
     _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_) _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_)       \
     _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_)                                                           \
-        acc[I][J][t_ * 2 + c_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                      \
-            __builtin_bit_cast(bf16x8_t, aR[t_ * 2 + kk_]), __builtin_bit_cast(bf16x8_t, bS[SET][c_ * 2 + kk_]), \
+        acc[I][J][t_ * 2 + c_] = rg_mfma_h16_16x16x32(                                      \
+            __builtin_bit_cast(h16x8_t, aR[t_ * 2 + kk_]), __builtin_bit_cast(h16x8_t, bS[SET][c_ * 2 + kk_]), \
             acc[I][J][t_ * 2 + c_], 0, 0, 0);                                                                  \
     __builtin_amdgcn_s_setprio(0);                                                                             \
   } while (0)
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(512, 2) void conv8n_kernel(G2Args a2) {
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const float v = bf16_to_f32(f32_to_bf16(acc[i][j][rt * 2 + c][r]));
+                const float v = h16_to_f32(f32_to_h16(acc[i][j][rt * 2 + c][r]));
                 s1 += v; s2 += v * v;
               }
           s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
@@ -836,10 +836,10 @@ __global__ __launch_bounds__(512, 2) void conv8n_kernel(G2Args a2) {
           v1.z *= rg_lmask(a.w, g.mslope); v1.w *= rg_lmask(a.w >> 16, g.mslope);
         }
         uint4 o;
-        o.x = (uint32_t)f32_to_bf16(v0.x) | ((uint32_t)f32_to_bf16(v0.y) << 16);
-        o.y = (uint32_t)f32_to_bf16(v0.z) | ((uint32_t)f32_to_bf16(v0.w) << 16);
-        o.z = (uint32_t)f32_to_bf16(v1.x) | ((uint32_t)f32_to_bf16(v1.y) << 16);
-        o.w = (uint32_t)f32_to_bf16(v1.z) | ((uint32_t)f32_to_bf16(v1.w) << 16);
+        o.x = (uint32_t)f32_to_h16(v0.x) | ((uint32_t)f32_to_h16(v0.y) << 16);
+        o.y = (uint32_t)f32_to_h16(v0.z) | ((uint32_t)f32_to_h16(v0.w) << 16);
+        o.z = (uint32_t)f32_to_h16(v1.x) | ((uint32_t)f32_to_h16(v1.y) << 16);
+        o.w = (uint32_t)f32_to_h16(v1.z) | ((uint32_t)f32_to_h16(v1.w) << 16);
         *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(g.C) + orow * 64 + e_c8) = o;
       }
     }

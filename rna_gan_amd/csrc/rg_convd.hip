@@ -131,8 +131,8 @@ __global__ __launch_bounds__(512, 2) void convd_kernel(G2Args a2) {
   auto mfma4 = [&](int set, int j) __attribute__((always_inline)) {
 #pragma unroll
     for (int it = 0; it < 4; ++it)
-      acc[it][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bF[set][j]),
-                                                           __builtin_bit_cast(bf16x8_t, aF[set][it]), acc[it][j], 0, 0, 0);
+      acc[it][j] = rg_mfma_h16_16x16x32(__builtin_bit_cast(h16x8_t, bF[set][j]),
+                                                           __builtin_bit_cast(h16x8_t, aF[set][it]), acc[it][j], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -157,12 +157,12 @@ __global__ __launch_bounds__(512, 2) void convd_kernel(G2Args a2) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const cd_f32x4 v = acc[it][j];
-        const uint32_t h0 = f32_to_bf16(v[0]), h1 = f32_to_bf16(v[1]), h2 = f32_to_bf16(v[2]), h3 = f32_to_bf16(v[3]);
+        const uint32_t h0 = f32_to_h16(v[0]), h1 = f32_to_h16(v[1]), h2 = f32_to_h16(v[2]), h3 = f32_to_h16(v[3]);
         o[j >> 1][(j & 1) * 2] = h0 | (h1 << 16);
         o[j >> 1][(j & 1) * 2 + 1] = h2 | (h3 << 16);
         if constexpr (HAS_STATS) {
-          const float r0 = __builtin_bit_cast(float, h0 << 16), r1 = __builtin_bit_cast(float, h1 << 16);
-          const float r2 = __builtin_bit_cast(float, h2 << 16), r3 = __builtin_bit_cast(float, h3 << 16);
+          const float r0 = h16lo_to_f32(h0), r1 = h16lo_to_f32(h1);
+          const float r2 = h16lo_to_f32(h2), r3 = h16lo_to_f32(h3);
           s1[4 * j] += r0; s1[4 * j + 1] += r1; s1[4 * j + 2] += r2; s1[4 * j + 3] += r3;
           s2[4 * j] += r0 * r0; s2[4 * j + 1] += r1 * r1; s2[4 * j + 2] += r2 * r2; s2[4 * j + 3] += r3 * r3;
         }

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
   do {                                                                                            \
     __builtin_amdgcn_s_setprio(1);                                                                \
     _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)   \
-        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[(RT0) + i_][j_]) : "v"(bS[SET][j_]), "v"(AS[i_])); \
+        asm volatile(RG_MFMA_H16_ASM_16x16x32 " %0, %1, %2, %0" : "+v"(acc[(RT0) + i_][j_]) : "v"(bS[SET][j_]), "v"(AS[i_])); \
     __builtin_amdgcn_s_setprio(0);                                                                \
   } while (0)
 // wait states tied to every accumulator: hazards between the asm MFMAs and the VALU instructions around them (the clearing
@@ -314,13 +314,13 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
           v[0] = lrelu_f(v[0] * sc.x + sh.x, g.slope); v[1] = lrelu_f(v[1] * sc.y + sh.y, g.slope);
           v[2] = lrelu_f(v[2] * sc.z + sh.z, g.slope); v[3] = lrelu_f(v[3] * sc.w + sh.w, g.slope);
         }
-        const uint32_t h0 = f32_to_bf16(v[0]), h1 = f32_to_bf16(v[1]), h2 = f32_to_bf16(v[2]), h3 = f32_to_bf16(v[3]);
+        const uint32_t h0 = f32_to_h16(v[0]), h1 = f32_to_h16(v[1]), h2 = f32_to_h16(v[2]), h3 = f32_to_h16(v[3]);
         const uint32_t d0 = h0 | (h1 << 16), d1 = h2 | (h3 << 16);
         o[j >> 1][(j & 1) * 2] = d0;
         o[j >> 1][(j & 1) * 2 + 1] = d1;
         if constexpr (HAS_STATS) {
-          const f32x2_t r01 = {__builtin_bit_cast(float, d0 << 16), __builtin_bit_cast(float, d0 & 0xffff0000u)};
-          const f32x2_t r23 = {__builtin_bit_cast(float, d1 << 16), __builtin_bit_cast(float, d1 & 0xffff0000u)};
+          const f32x2_t r01 = {h16lo_to_f32(d0), h16hi_to_f32(d0)};
+          const f32x2_t r23 = {h16lo_to_f32(d1), h16hi_to_f32(d1)};
           s1[j][0] += r01; s2[j][0] += r01 * r01;
           s1[j][1] += r23; s2[j][1] += r23 * r23;
         }

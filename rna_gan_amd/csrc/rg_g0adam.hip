@@ -18,12 +18,12 @@ namespace {
 
 constexpr int GA_E = 64, GA_J = 256, GA_N = 64;
 
-struct AdamC { float b1, b2, omb1, omb2, eps, step_size, inv_sqrt_bc2, wd; };
+struct AdamC { float b1, b2, omb1, omb2, eps, step_size, inv_sqrt_bc2, wd, ginv; };
 __device__ __forceinline__ void adam_upd(const AdamC& a, float& pp, float gg, float& mm, float& vv) {
-  rg_adam_upd(pp, gg, mm, vv, a.b2, a.omb1, a.omb2, a.eps, a.step_size, a.inv_sqrt_bc2, a.wd);     // rg_common.h
+  rg_adam_upd(pp, gg * a.ginv, mm, vv, a.b2, a.omb1, a.omb2, a.eps, a.step_size, a.inv_sqrt_bc2, a.wd);     // rg_common.h
 }
 
-typedef __attribute__((ext_vector_type(8))) __bf16 ga_bf16x8;
+typedef rg_h16x8 ga_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float ga_f32x16;
 constexpr int GA_CP = GA_J + 4;  // fp32 pitch of the accumulator tile: rows 4 apart (the two lane halves) land 16 banks apart
 constexpr int GA_P = 72;       // LDS row pitch (bf16) of the k-contiguous operand images: 144 B, 16-byte fragment reads spread over the banks
@@ -33,7 +33,7 @@ constexpr int GA_P = 72;       // LDS row pitch (bf16) of the k-contiguous opera
 // Wave w owns columns 64 w .. 64 w + 63 of the 64 x 256 tile: 2 x 2 MFMA tiles, 4 k-steps per 64 samples (16 MFMAs where the
 // VALU form issued 4096 FMAs per thread).  The accumulators go through an LDS tile, one 32-row half at a time, into the
 // thread -> (8 rows x 4 consecutive columns) map of the streaming Adam pass (16-byte accesses, 1 KB per wave and row).
-template <typename TG>      // TG: element type of gz0 (bf16_t or float)
+template <typename TG>      // TG: element type of gz0 (h16_t or float)
 __global__ __launch_bounds__(256) void g0_wgrad_adam_kernel(const float* __restrict__ z, const TG* __restrict__ gz0,
                                                             float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                                                             const float* __restrict__ hyper, uint16_t* __restrict__ shadow,
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void g0_wgrad_adam_kernel(const float* __restr
             Vec<TG, 8>::ld(src + 8, x + 8);
             uint32_t w[8];
 #pragma unroll
-            for (int c2 = 0; c2 < 8; ++c2) w[c2] = (uint32_t)f32_to_bf16(x[2 * c2]) | ((uint32_t)f32_to_bf16(x[2 * c2 + 1]) << 16);
+            for (int c2 = 0; c2 < 8; ++c2) w[c2] = (uint32_t)f32_to_h16(x[2 * c2]) | ((uint32_t)f32_to_h16(x[2 * c2 + 1]) << 16);
             gr[a][k][0] = make_uint4(w[0], w[1], w[2], w[3]);
             gr[a][k][1] = make_uint4(w[4], w[5], w[6], w[7]);
           }
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void g0_wgrad_adam_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       *reinterpret_cast<uint32_t*>(zsT + ze * GA_P + 2 * (zq + 4 * i)) =
-          (uint32_t)f32_to_bf16(zr[i][0]) | ((uint32_t)f32_to_bf16(zr[i][1]) << 16);
+          (uint32_t)f32_to_h16(zr[i][0]) | ((uint32_t)f32_to_h16(zr[i][1]) << 16);
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -136,12 +136,12 @@ __global__ __launch_bounds__(256) void g0_wgrad_adam_kernel(const float* __restr
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = rg_mfma_h16_32x32x16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
   }
 
   // ---- Adam on the tile, one 32-row half at a time: acc[i][j][4 g + q] = dW[e = 32 i + 8 g + 4 fh + q][j = 64 wave + 32 j + fr]
-  const AdamC a{hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6], hyper[7]};
+  const AdamC a{hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6], hyper[7], hyper[8]};
   const size_t ld = (size_t)C * 16;
   const int tj = t & 63, te = t >> 6;
   const size_t col = (size_t)c0 * 16 + 4 * tj;
@@ -176,8 +176,8 @@ __global__ __launch_bounds__(256) void g0_wgrad_adam_kernel(const float* __restr
         *reinterpret_cast<float4*>(m + idx) = M[k];
         *reinterpret_cast<float4*>(v + idx) = V[k];
         if (shadow)
-          *reinterpret_cast<uint2*>(shadow + idx) = make_uint2((uint32_t)f32_to_bf16(P[k].x) | ((uint32_t)f32_to_bf16(P[k].y) << 16),
-                                                               (uint32_t)f32_to_bf16(P[k].z) | ((uint32_t)f32_to_bf16(P[k].w) << 16));
+          *reinterpret_cast<uint2*>(shadow + idx) = make_uint2((uint32_t)f32_to_h16(P[k].x) | ((uint32_t)f32_to_h16(P[k].y) << 16),
+                                                               (uint32_t)f32_to_h16(P[k].z) | ((uint32_t)f32_to_h16(P[k].w) << 16));
       }
     }
   }
@@ -244,11 +244,11 @@ __global__ __launch_bounds__(256) void lin_wgrad_adam_kernel(const uint16_t* __r
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 2; ++b) acc[a][b] = rg_mfma_h16_32x32x16(fa[a], fb[b], acc[a][b], 0, 0, 0);
     }
   }
 
-  const AdamC hy{hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6], hyper[7]};
+  const AdamC hy{hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6], hyper[7], hyper[8]};
   const int tj = t & 63, te = t >> 6;
   const int col = i0 + 4 * tj;
 #pragma unroll
@@ -307,18 +307,18 @@ __global__ __launch_bounds__(256) void lin_wgrad_adam_kernel(const uint16_t* __r
             *reinterpret_cast<float4*>(v + base) = make_float4(V[k][0], V[k][1], V[k][2], V[k][3]);
             if (wpack)      // the next forward's bf16 operand image [.][Kp] of the UPDATED weight (rg_pack_linear_weight's layout)
               *reinterpret_cast<uint2*>(wpack + (size_t)row * Kp + col) =
-                  make_uint2((uint32_t)f32_to_bf16(P[k][0]) | ((uint32_t)f32_to_bf16(P[k][1]) << 16),
-                             (uint32_t)f32_to_bf16(P[k][2]) | ((uint32_t)f32_to_bf16(P[k][3]) << 16));
+                  make_uint2((uint32_t)f32_to_h16(P[k][0]) | ((uint32_t)f32_to_h16(P[k][1]) << 16),
+                             (uint32_t)f32_to_h16(P[k][2]) | ((uint32_t)f32_to_h16(P[k][3]) << 16));
           } else if constexpr (VEC == 2) {
             *reinterpret_cast<float2*>(p + base + 2 * q) = make_float2(P[k][2 * q], P[k][2 * q + 1]);
             *reinterpret_cast<float2*>(m + base + 2 * q) = make_float2(M[k][2 * q], M[k][2 * q + 1]);
             *reinterpret_cast<float2*>(v + base + 2 * q) = make_float2(V[k][2 * q], V[k][2 * q + 1]);
             if (wpack)
               *reinterpret_cast<uint32_t*>(wpack + (size_t)row * Kp + col + 2 * q) =
-                  (uint32_t)f32_to_bf16(P[k][2 * q]) | ((uint32_t)f32_to_bf16(P[k][2 * q + 1]) << 16);
+                  (uint32_t)f32_to_h16(P[k][2 * q]) | ((uint32_t)f32_to_h16(P[k][2 * q + 1]) << 16);
           } else {
             p[base + q] = P[k][q]; m[base + q] = M[k][q]; v[base + q] = V[k][q];
-            if (wpack) wpack[(size_t)row * Kp + col + q] = f32_to_bf16(P[k][q]);
+            if (wpack) wpack[(size_t)row * Kp + col + q] = f32_to_h16(P[k][q]);
           }
         }
       }
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void lin_wgrad_adam_kernel(const uint16_t* __r
 }  // namespace
 
 extern "C" int rg_g0_wgrad_adam_supported(int N, int E, int C, int dtype) {
-  return N > 0 && E % GA_E == 0 && C % 16 == 0 && (dtype == RG_BF16 || dtype == RG_F32) ? 1 : 0;
+  return N > 0 && E % GA_E == 0 && C % 16 == 0 && (dtype == RG_H16 || dtype == RG_F32) ? 1 : 0;
 }
 
 extern "C" int rg_g0_wgrad_adam(const float* z, const void* gz0, float* p, float* m, float* v, const float* hyper,
@@ -345,8 +345,8 @@ extern "C" int rg_g0_wgrad_adam(const float* z, const void* gz0, float* p, float
   const int e_fastest = order != 0;
   const dim3 grid(e_fastest ? (unsigned)(E / GA_E) : (unsigned)(C / 16), e_fastest ? (unsigned)(C / 16) : (unsigned)(E / GA_E));
   hipStream_t st = rg_stream(stream);
-  if (dtype == RG_BF16)
-    hipLaunchKernelGGL(g0_wgrad_adam_kernel<bf16_t>, grid, dim3(256), 0, st, z, (const bf16_t*)gz0, p, m, v, hyper,
+  if (dtype == RG_H16)
+    hipLaunchKernelGGL(g0_wgrad_adam_kernel<h16_t>, grid, dim3(256), 0, st, z, (const h16_t*)gz0, p, m, v, hyper,
                        (uint16_t*)shadow_bf16, N, E, C, e_fastest);
   else
     hipLaunchKernelGGL(g0_wgrad_adam_kernel<float>, grid, dim3(256), 0, st, z, (const float*)gz0, p, m, v, hyper,

@@ -1423,7 +1423,7 @@ int rg_generic_conv_wgrad(const void* low, const void* high, float* dw, int N, i
   if (dtype == RG_F32)
     return generic_wgrad_impl("conv_wgrad(generic)", low, WgradB<float>{(const float*)high, g}, dw, g, dtype,
                               accumulate, ws, ws_bytes, st);
-  return generic_wgrad_impl("conv_wgrad(generic)", low, WgradB<bf16_t>{(const bf16_t*)high, g}, dw, g, dtype,
+  return generic_wgrad_impl("conv_wgrad(generic)", low, WgradB<h16_t>{(const h16_t*)high, g}, dw, g, dtype,
                             accumulate, ws, ws_bytes, st);
 }
 

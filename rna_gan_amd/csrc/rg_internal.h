@@ -165,7 +165,7 @@ int rg_skinny_last_up(const void* x, const float* w, const float* bias, float* y
 bool rg_skinny_last_up_pre_supported(int Wo, int O, int dtype);
 int rg_skinny_last_up_post_blocks(int N, int Ho, int Wo, int O, int dtype);
 int rg_skinny_lu_part_final(const float* part, int nb, float* out, int accumulate, int mode, float* loss, float* coef,
-                            float lambd, hipStream_t st);
+                            float lambd, hipStream_t st, float in_scale = 1.f, float out_scale = 1.f);
 size_t rg_skinny_wgrad_ws_bytes(int N, int Ho, int Wo, int O, int I);
 int rg_skinny_wgrad_slabs_impl(const void* low, const float* high_nchw, int N, int Ho, int Wo, int O, int I, int dtype,
                                void* slab, size_t slab_bytes, int* nslab_out, float* bias_slab, int* bias_done_out,

@@ -158,24 +158,24 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(GArgs g) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int ch = 2 * kk + fh;
-      bf16x8_t fa[2], fb[2];
+      h16x8_t fa[2], fb[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         int row = wm * 64 + i * 32 + fr;
         uint4 v = sa[lds_chunk_index(row, ch)];
-        fa[i] = __builtin_bit_cast(bf16x8_t, v);
+        fa[i] = __builtin_bit_cast(h16x8_t, v);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         int row = wn * 64 + j * 32 + fr;
         uint4 v = sb[lds_chunk_index(row, ch)];
-        fb[j] = __builtin_bit_cast(bf16x8_t, v);
+        fb[j] = __builtin_bit_cast(h16x8_t, v);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = rg_mfma_h16_32x32x16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     if (more) RG_STORE_TILE(cur ^ 1);
     __syncthreads();
@@ -223,10 +223,10 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(GArgs g) {
         v1.z *= rg_lmask(a.w, g.mslope); v1.w *= rg_lmask(a.w >> 16, g.mslope);
       }
       uint4 o;
-      o.x = (uint32_t)f32_to_bf16(v0.x) | ((uint32_t)f32_to_bf16(v0.y) << 16);
-      o.y = (uint32_t)f32_to_bf16(v0.z) | ((uint32_t)f32_to_bf16(v0.w) << 16);
-      o.z = (uint32_t)f32_to_bf16(v1.x) | ((uint32_t)f32_to_bf16(v1.y) << 16);
-      o.w = (uint32_t)f32_to_bf16(v1.z) | ((uint32_t)f32_to_bf16(v1.w) << 16);
+      o.x = (uint32_t)f32_to_h16(v0.x) | ((uint32_t)f32_to_h16(v0.y) << 16);
+      o.y = (uint32_t)f32_to_h16(v0.z) | ((uint32_t)f32_to_h16(v0.w) << 16);
+      o.z = (uint32_t)f32_to_h16(v1.x) | ((uint32_t)f32_to_h16(v1.y) << 16);
+      o.w = (uint32_t)f32_to_h16(v1.z) | ((uint32_t)f32_to_h16(v1.w) << 16);
       *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(g.C) + orow * g.ldc + col) = o;
     } else {
       float vals[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -462,8 +462,8 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
   } while (0)
 #define RG_MFMAS(buf)                                                                                              \
   _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] =         \
-      __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, qa[buf][i]),                            \
-                                              __builtin_bit_cast(bf16x8_t, qb[buf][j]), acc[i][j], 0, 0, 0)
+      rg_mfma_h16_32x32x16(__builtin_bit_cast(h16x8_t, qa[buf][i]),                            \
+                                              __builtin_bit_cast(h16x8_t, qb[buf][j]), acc[i][j], 0, 0, 0)
   constexpr int WAIT_A = vmcnt_imm((A_LD + B_LD) * (NSTAGE > 2 ? NSTAGE - 2 : 0));
   constexpr int WAIT_B = vmcnt_imm((A_LD + B_LD) * (NSTAGE > 3 ? NSTAGE - 3 : 0));
   for (int kt = 0; kt < nkt; ++kt) {
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float v = bf16_to_f32(f32_to_bf16(acc[i][j][r]));
+          const float v = h16_to_f32(f32_to_h16(acc[i][j][r]));
           s1 += v; s2 += v * v;
         }
       s1 += __shfl_xor(s1, 32, 64);
@@ -585,10 +585,10 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
         }
         if (g.affine) rg_affine8(v0, v1, g.scale + col, g.shift + col, g.slope);
         uint4 o;
-        o.x = (uint32_t)f32_to_bf16(v0.x) | ((uint32_t)f32_to_bf16(v0.y) << 16);
-        o.y = (uint32_t)f32_to_bf16(v0.z) | ((uint32_t)f32_to_bf16(v0.w) << 16);
-        o.z = (uint32_t)f32_to_bf16(v1.x) | ((uint32_t)f32_to_bf16(v1.y) << 16);
-        o.w = (uint32_t)f32_to_bf16(v1.z) | ((uint32_t)f32_to_bf16(v1.w) << 16);
+        o.x = (uint32_t)f32_to_h16(v0.x) | ((uint32_t)f32_to_h16(v0.y) << 16);
+        o.y = (uint32_t)f32_to_h16(v0.z) | ((uint32_t)f32_to_h16(v0.w) << 16);
+        o.z = (uint32_t)f32_to_h16(v1.x) | ((uint32_t)f32_to_h16(v1.y) << 16);
+        o.w = (uint32_t)f32_to_h16(v1.z) | ((uint32_t)f32_to_h16(v1.w) << 16);
         *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(g.C) + orow * g.ldc + col) = o;
       } else {
         float vals[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -638,10 +638,10 @@ __global__ void reduce_slabs_bf16_kernel(const float* __restrict__ slab, uint16_
     float4 x, y;
     if (S16) {
       const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(slab) + (size_t)z * stride + i * 8);
-      x = make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16),
-                      __uint_as_float(t.y & 0xffff0000u));
-      y = make_float4(__uint_as_float(t.z << 16), __uint_as_float(t.z & 0xffff0000u), __uint_as_float(t.w << 16),
-                      __uint_as_float(t.w & 0xffff0000u));
+      x = make_float4(h16lo_to_f32(t.x), h16hi_to_f32(t.x), h16lo_to_f32(t.y),
+                      h16hi_to_f32(t.y));
+      y = make_float4(h16lo_to_f32(t.z), h16hi_to_f32(t.z), h16lo_to_f32(t.w),
+                      h16hi_to_f32(t.w));
     } else {
       const float4* p = reinterpret_cast<const float4*>(slab + (size_t)z * stride + i * 8);
       x = p[0]; y = p[1];
@@ -650,10 +650,10 @@ __global__ void reduce_slabs_bf16_kernel(const float* __restrict__ slab, uint16_
     b.x += y.x; b.y += y.y; b.z += y.z; b.w += y.w;
   }
   uint4 o;
-  o.x = (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16);
-  o.y = (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16);
-  o.z = (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16);
-  o.w = (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16);
+  o.x = (uint32_t)f32_to_h16(a.x) | ((uint32_t)f32_to_h16(a.y) << 16);
+  o.y = (uint32_t)f32_to_h16(a.z) | ((uint32_t)f32_to_h16(a.w) << 16);
+  o.z = (uint32_t)f32_to_h16(b.x) | ((uint32_t)f32_to_h16(b.y) << 16);
+  o.w = (uint32_t)f32_to_h16(b.z) | ((uint32_t)f32_to_h16(b.w) << 16);
   reinterpret_cast<uint4*>(out)[i] = o;
 }
 
@@ -750,14 +750,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WArgs g) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int prow = ks * 16 + 8 * fh + q;
-      bf16x8_t fa[2], fb[2];
+      h16x8_t fa[2], fb[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const uint16_t* p = sl + prow * WROW + wm * 64 + i * 32 + 16 * cb + 4 * p4;
         s16x4_t lo = lds_tr_read(p);
         s16x4_t hi = lds_tr_read(p + 4 * WROW);
         s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        fa[i] = __builtin_bit_cast(bf16x8_t, v);
+        fa[i] = __builtin_bit_cast(h16x8_t, v);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -765,13 +765,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WArgs g) {
         s16x4_t lo = lds_tr_read(p);
         s16x4_t hi = lds_tr_read(p + 4 * WROW);
         s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        fb[j] = __builtin_bit_cast(bf16x8_t, v);
+        fb[j] = __builtin_bit_cast(h16x8_t, v);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = rg_mfma_h16_32x32x16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     if (more) RG_WSTORE_TILE(cur ^ 1);
     __syncthreads();
@@ -931,8 +931,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(W2Args g) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, qa[ks][i]),
-                                                              __builtin_bit_cast(bf16x8_t, qb[ks][j]), acc[i][j], 0, 0,
+          acc[i][j] = rg_mfma_h16_32x32x16(__builtin_bit_cast(h16x8_t, qa[ks][i]),
+                                                              __builtin_bit_cast(h16x8_t, qb[ks][j]), acc[i][j], 0, 0,
                                                               0);
     __builtin_amdgcn_s_setprio(0);
   }
@@ -974,13 +974,13 @@ __global__ void cast_bf16_kernel(const float* __restrict__ w, uint16_t* __restri
   for (size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x; d < n8; d += (size_t)gridDim.x * blockDim.x) {
     float v[8];
     Vec<float, 8>::ld(w + d * 8, v);
-    Vec<bf16_t, 8>::st(reinterpret_cast<bf16_t*>(out) + d * 8, v);
+    Vec<h16_t, 8>::st(reinterpret_cast<h16_t*>(out) + d * 8, v);
   }
 }
 // generic tiled transpose-pack: src[R][Cc] (fp32 or bf16) -> dst[perm(col)][R] bf16.  permute 0: identity;
 // 1: col = c*16 + tap -> tap*(Cc/16) + c;  2: the inverse, col = tap*(Cc/16) + c -> c*16 + tap.
 __device__ __forceinline__ float tp_load(const float* p) { return *p; }
-__device__ __forceinline__ float tp_load(const uint16_t* p) { return bf16_to_f32(*p); }
+__device__ __forceinline__ float tp_load(const uint16_t* p) { return h16_to_f32(*p); }
 template <typename S>
 __global__ __launch_bounds__(256) void transpose_pack_kernel(const S* src, uint16_t* dst, int R, int Cc, int permute) {
   __shared__ float tile[64][65];
@@ -997,7 +997,7 @@ __global__ __launch_bounds__(256) void transpose_pack_kernel(const S* src, uint1
       int pc = c;
       if (permute == 1) { int tap = c & 15, ch = c >> 4; pc = tap * (Cc >> 4) + ch; }
       else if (permute == 2) { int q = Cc >> 4, tap = c / q, ch = c - tap * q; pc = ch * 16 + tap; }
-      dst[(size_t)pc * R + r] = f32_to_bf16(tile[tx][cc]);
+      dst[(size_t)pc * R + r] = f32_to_h16(tile[tx][cc]);
     }
   }
 }
@@ -1121,7 +1121,7 @@ __global__ void pack_linear_kernel(const float* __restrict__ w, uint16_t* __rest
     }
     uint32_t o[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = (uint32_t)f32_to_bf16(x[2 * i]) | ((uint32_t)f32_to_bf16(x[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) o[i] = (uint32_t)f32_to_h16(x[2 * i]) | ((uint32_t)f32_to_h16(x[2 * i + 1]) << 16);
     *reinterpret_cast<uint4*>(wp + d * 8) = make_uint4(o[0], o[1], o[2], o[3]);
   }
 }
@@ -1137,8 +1137,8 @@ __global__ void selftest_kernel(int* out) {
   int lane = threadIdx.x;
   for (int i = lane; i < 32 * 16; i += 64) {
     int r = i / 16, k = i % 16;
-    A[i] = f32_to_bf16((float)((r * 3 + k * 5) % 7 - 3));
-    Bt[i] = f32_to_bf16((float)((r * 2 + k * 7 + 1) % 5 - 2));   // asymmetric in (col r, k)
+    A[i] = f32_to_h16((float)((r * 3 + k * 5) % 7 - 3));
+    Bt[i] = f32_to_h16((float)((r * 2 + k * 7 + 1) % 5 - 2));   // asymmetric in (col r, k)
   }
   for (int i = lane; i < 16 * 32; i += 64) {
     int p = i / 32, c = i % 32;
@@ -1148,15 +1148,15 @@ __global__ void selftest_kernel(int* out) {
   int fr = lane & 31, fh = lane >> 5;
   int bad_mfma = 0, bad_tr = 0;
   // (1) MFMA operand / accumulator maps
-  bf16x8_t fa = *reinterpret_cast<const bf16x8_t*>(A + fr * 16 + fh * 8);
-  bf16x8_t fb = *reinterpret_cast<const bf16x8_t*>(Bt + fr * 16 + fh * 8);
+  h16x8_t fa = *reinterpret_cast<const h16x8_t*>(A + fr * 16 + fh * 8);
+  h16x8_t fb = *reinterpret_cast<const h16x8_t*>(Bt + fr * 16 + fh * 8);
   f32x16_t acc;
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc, 0, 0, 0);
+  acc = rg_mfma_h16_32x32x16(fa, fb, acc, 0, 0, 0);
   for (int r = 0; r < 16; ++r) {
     int row = (r & 3) + 8 * (r >> 2) + 4 * fh, col = fr;
     float ref = 0.f;
-    for (int k = 0; k < 16; ++k) ref += bf16_to_f32(A[row * 16 + k]) * bf16_to_f32(Bt[col * 16 + k]);
+    for (int k = 0; k < 16; ++k) ref += h16_to_f32(A[row * 16 + k]) * h16_to_f32(Bt[col * 16 + k]);
     if (ref != acc[r]) ++bad_mfma;
   }
   // (2) transposed LDS read: lane must receive P[8*fh + e][16*cb + idx], e = 0..7
@@ -1650,7 +1650,7 @@ int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, c
       int rc = rg_wgrad8_launch(low0, high0, low1, high1, ns == 1 ? dw : (float*)ws, Kseg, two ? 1 : 0, O, I, Ho, Wo, ns,
                                 per, accumulate, st, s16);
       if (rc || ns == 1) return rc;
-      if (nsplit_out) { *nsplit_out = ns; if (s16) *slab_dtype_out = RG_BF16; return RG_OK; }
+      if (nsplit_out) { *nsplit_out = ns; if (s16) *slab_dtype_out = RG_H16; return RG_OK; }
       return rg_reduce_slabs((const float*)ws, dw, elems, ns, accumulate, 0, 0, st);
     }
   }
@@ -1662,7 +1662,7 @@ int rg_mfma_conv_wgrad2(const void* low0, const void* high0, const void* low1, c
       int rc = rg_wgrad8n_launch(low0, high0, low1, high1, ns == 1 ? dw : (float*)ws, Kseg, two ? 1 : 0, O, I, Ho, Wo, ns,
                                  per, accumulate, st, s16);
       if (rc || ns == 1) return rc;
-      if (nsplit_out) { *nsplit_out = ns; if (s16) *slab_dtype_out = RG_BF16; return RG_OK; }
+      if (nsplit_out) { *nsplit_out = ns; if (s16) *slab_dtype_out = RG_H16; return RG_OK; }
       return rg_reduce_slabs((const float*)ws, dw, elems, ns, accumulate, 0, 0, st);
     }
   }
@@ -1831,11 +1831,11 @@ __global__ void uppad_bf16_kernel(const uint16_t* __restrict__ x, uint16_t* __re
       int h0, h1, w0, w1;
       up_taps(up_reflect(i, 2 * H), H, h0, h1, lh[u]);
       up_taps(up_reflect(j, 2 * W), W, w0, w1, lw[u]);
-      const bf16_t* xn = reinterpret_cast<const bf16_t*>(x) + (size_t)n * H * W * C + c8 * 8;
-      Vec<bf16_t, 8>::ld(xn + ((size_t)h0 * W + w0) * C, v[u][0]);
-      Vec<bf16_t, 8>::ld(xn + ((size_t)h0 * W + w1) * C, v[u][1]);
-      Vec<bf16_t, 8>::ld(xn + ((size_t)h1 * W + w0) * C, v[u][2]);
-      Vec<bf16_t, 8>::ld(xn + ((size_t)h1 * W + w1) * C, v[u][3]);
+      const h16_t* xn = reinterpret_cast<const h16_t*>(x) + (size_t)n * H * W * C + c8 * 8;
+      Vec<h16_t, 8>::ld(xn + ((size_t)h0 * W + w0) * C, v[u][0]);
+      Vec<h16_t, 8>::ld(xn + ((size_t)h0 * W + w1) * C, v[u][1]);
+      Vec<h16_t, 8>::ld(xn + ((size_t)h1 * W + w0) * C, v[u][2]);
+      Vec<h16_t, 8>::ld(xn + ((size_t)h1 * W + w1) * C, v[u][3]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -1846,7 +1846,7 @@ __global__ void uppad_bf16_kernel(const uint16_t* __restrict__ x, uint16_t* __re
       for (int k = 0; k < 8; ++k)
         o[k] = (1.f - lh[u]) * ((1.f - lw[u]) * v[u][0][k] + lw[u] * v[u][1][k]) +
                lh[u] * ((1.f - lw[u]) * v[u][2][k] + lw[u] * v[u][3][k]);
-      Vec<bf16_t, 8>::st(reinterpret_cast<bf16_t*>(pad) + idx * 8, o);
+      Vec<h16_t, 8>::st(reinterpret_cast<h16_t*>(pad) + idx * 8, o);
     }
   }
 }
@@ -1856,7 +1856,7 @@ __global__ void pack_w3_kernel(const float* __restrict__ w, uint16_t* __restrict
   for (size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += (size_t)gridDim.x * blockDim.x) {
     const size_t c = d % Cin, ot = d / Cin;
     const size_t tap = ot % 9, o = ot / 9;
-    wp[d] = f32_to_bf16(w[(o * Cin + c) * 9 + tap]);
+    wp[d] = f32_to_h16(w[(o * Cin + c) * 9 + tap]);
   }
 }
 bool rg_mfma_upconv3_supported(int N, int H, int W, int Cin, int Cout) {
@@ -1944,7 +1944,7 @@ __global__ void pack_w3t_kernel(const float* __restrict__ w, uint16_t* __restric
   for (size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x; d < n; d += (size_t)gridDim.x * blockDim.x) {
     const size_t o = d % Cout, ct = d / Cout;
     const size_t tap = ct % 9, c = ct / 9;
-    wt[d] = f32_to_bf16(w[(o * Cin + c) * 9 + tap]);
+    wt[d] = f32_to_h16(w[(o * Cin + c) * 9 + tap]);
   }
 }
 // adjoint of (reflection pad o bilinear x2) on a bf16 padded-grid gradient, 8 channels per thread:
@@ -1960,7 +1960,7 @@ __global__ void uppad_adjoint_bf16_kernel(const uint16_t* __restrict__ gpad, uin
     const int w = (int)(t % W); t /= W;
     const int h = (int)(t % H);
     const int n = (int)(t / H);
-    const bf16_t* gp = reinterpret_cast<const bf16_t*>(gpad) + (size_t)n * (H2 + 2) * Wp * C + c8 * 8;
+    const h16_t* gp = reinterpret_cast<const h16_t*>(gpad) + (size_t)n * (H2 + 2) * Wp * C + c8 * 8;
     float acc[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = 0.f;
@@ -1986,14 +1986,14 @@ __global__ void uppad_adjoint_bf16_kernel(const uint16_t* __restrict__ gpad, uin
             const int j = rj == 0 ? v + 1 : (rj == 1 ? (v == 1 ? 0 : -1) : (v == W2 - 2 ? W2 + 1 : -1));
             if (j < 0) continue;
             float gv[8];
-            Vec<bf16_t, 8>::ld(gp + ((size_t)i * Wp + j) * C, gv);
+            Vec<h16_t, 8>::ld(gp + ((size_t)i * Wp + j) * C, gv);
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[k] += f * gv[k];
           }
         }
       }
     }
-    Vec<bf16_t, 8>::st(reinterpret_cast<bf16_t*>(gx) + idx * 8, acc);
+    Vec<h16_t, 8>::st(reinterpret_cast<h16_t*>(gx) + idx * 8, acc);
   }
 }
 // data gradient: Cout % 64 == 0 (K = 9 * Cout), Cin % 8 == 0
@@ -2098,7 +2098,7 @@ __global__ void nchw_to_rows8_kernel(const float* __restrict__ gy, uint16_t* __r
     const size_t n = m / HW, p = m - n * HW;
     uint32_t h[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) h[c] = c < Cout ? (uint32_t)f32_to_bf16(gy[(n * Cout + c) * HW + p]) : 0u;
+    for (int c = 0; c < 8; ++c) h[c] = c < Cout ? (uint32_t)f32_to_h16(gy[(n * Cout + c) * HW + p]) : 0u;
     uint4 o;
     o.x = h[0] | (h[1] << 16); o.y = h[2] | (h[3] << 16); o.z = h[4] | (h[5] << 16); o.w = h[6] | (h[7] << 16);
     *reinterpret_cast<uint4*>(rows + m * 8) = o;

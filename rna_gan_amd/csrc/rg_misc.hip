@@ -70,9 +70,10 @@ struct Clamp {
   __device__ void one(size_t i) const { p[i] = fminf(fmaxf(p[i], lo), hi); }
 };
 struct Adam {
-  float* p; const float* g; float* m; float* v; float b1, b2, omb1, omb2, eps, step_size, inv_sqrt_bc2, wd;
+  float* p; const float* g; float* m; float* v; float b1, b2, omb1, omb2, eps, step_size, inv_sqrt_bc2, wd = 0.f;
+  float ginv = 1.f;                    // 1 / loss scale (hyper[8]; rg_common.h)
   __device__ __forceinline__ void upd(float& pp, float gg, float& mm, float& vv) const {
-    rg_adam_upd(pp, gg, mm, vv, b2, omb1, omb2, eps, step_size, inv_sqrt_bc2, wd);      // rg_common.h: the one expression
+    rg_adam_upd(pp, gg * ginv, mm, vv, b2, omb1, omb2, eps, step_size, inv_sqrt_bc2, wd);      // rg_common.h: the one expression
   }
   __device__ void vec(size_t i) const {
     float4 P = *(float4*)(p + i), G = *(const float4*)(g + i), M = *(float4*)(m + i), V = *(float4*)(v + i);
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
                                                        float* __restrict__ m, float* __restrict__ v,
                                                        const float* __restrict__ hyper, uint16_t* __restrict__ shadow,
                                                        const uint16_t* __restrict__ gw, size_t n) {
-  const Adam a{p, g, m, v, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6], hyper[7]};
+  const Adam a{p, g, m, v, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6], hyper[7], hyper[8]};
   const size_t n4 = n / 4, stride = (size_t)gridDim.x * blockDim.x;
   for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
     const size_t i = q * 4;
@@ -108,21 +109,21 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
     float4 P = *(float4*)(p + i), M = nt_ld4(m + i), V = nt_ld4(v + i), G;
     if (WIRE) {
       const uint2 w = *(const uint2*)(gw + i);
-      G = make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
-                      __uint_as_float(w.y & 0xffff0000u));
+      G = make_float4(h16lo_to_f32(w.x), h16hi_to_f32(w.x), h16lo_to_f32(w.y),
+                      h16hi_to_f32(w.y));
     } else {
       G = nt_ld4(g + i);
     }
     a.upd(P.x, G.x, M.x, V.x); a.upd(P.y, G.y, M.y, V.y); a.upd(P.z, G.z, M.z, V.z); a.upd(P.w, G.w, M.w, V.w);
     *(float4*)(p + i) = P; nt_st4(m + i, M); nt_st4(v + i, V);
     if (SHADOW)
-      *(uint2*)(shadow + i) = make_uint2((uint32_t)f32_to_bf16(P.x) | ((uint32_t)f32_to_bf16(P.y) << 16),
-                                         (uint32_t)f32_to_bf16(P.z) | ((uint32_t)f32_to_bf16(P.w) << 16));
+      *(uint2*)(shadow + i) = make_uint2((uint32_t)f32_to_h16(P.x) | ((uint32_t)f32_to_h16(P.y) << 16),
+                                         (uint32_t)f32_to_h16(P.z) | ((uint32_t)f32_to_h16(P.w) << 16));
   }
   const size_t t = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // tail
   if (t < n) {
-    a.upd(p[t], WIRE ? bf16_to_f32(gw[t]) : g[t], m[t], v[t]);
-    if (SHADOW) shadow[t] = f32_to_bf16(p[t]);
+    a.upd(p[t], WIRE ? h16_to_f32(gw[t]) : g[t], m[t], v[t]);
+    if (SHADOW) shadow[t] = f32_to_h16(p[t]);
   }
 }
 
@@ -143,8 +144,8 @@ __device__ __forceinline__ float4 adam_slab_ld(const float* __restrict__ slab, s
   if (S16) {
     typedef unsigned nt_u2 __attribute__((ext_vector_type(2)));
     const nt_u2 w = __builtin_nontemporal_load(reinterpret_cast<const nt_u2*>(reinterpret_cast<const uint16_t*>(slab) + z * n + q * 4));
-    return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
-                       __uint_as_float(w.y & 0xffff0000u));
+    return make_float4(h16lo_to_f32(w.x), h16hi_to_f32(w.x), h16lo_to_f32(w.y),
+                       h16hi_to_f32(w.y));
   }
   return nt_ld4(slab + z * n + q * 4);
 }
@@ -190,8 +191,8 @@ __device__ __forceinline__ void adam_slab_segment(const Adam& a, float* __restri
       a.upd(P.x, s.x, M.x, V.x); a.upd(P.y, s.y, M.y, V.y); a.upd(P.z, s.z, M.z, V.z); a.upd(P.w, s.w, M.w, V.w);
       *(float4*)(p + i) = P; nt_st4(m + i, M); nt_st4(v + i, V);
       if (SHADOW)
-        *(uint2*)(shadow + i) = make_uint2((uint32_t)f32_to_bf16(P.x) | ((uint32_t)f32_to_bf16(P.y) << 16),
-                                           (uint32_t)f32_to_bf16(P.z) | ((uint32_t)f32_to_bf16(P.w) << 16));
+        *(uint2*)(shadow + i) = make_uint2((uint32_t)f32_to_h16(P.x) | ((uint32_t)f32_to_h16(P.y) << 16),
+                                           (uint32_t)f32_to_h16(P.z) | ((uint32_t)f32_to_h16(P.w) << 16));
     }
   }
 }
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void adam_segs_kernel(float* __restrict__ p, c
                                                         const float* __restrict__ hyper, uint16_t* __restrict__ shadow,
                                                         AdamSegs t) {
   __shared__ float4 sm[16][64];                            // [slab lane][column]: SL = 4 uses [4][64], SL = 16 [16][16]
-  const Adam a{p, g, m, v, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6], hyper[7]};
+  const Adam a{p, g, m, v, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6], hyper[7], hyper[8]};
   for (int si = 0; si < t.nseg; ++si) {
     const AdamSeg sg = t.s[si];
     if (sg.nsplit < 0) continue;                           // stepped elsewhere
@@ -228,13 +229,13 @@ __global__ __launch_bounds__(256) void adam_segs_kernel(float* __restrict__ p, c
       a.upd(P.x, G.x, M.x, V.x); a.upd(P.y, G.y, M.y, V.y); a.upd(P.z, G.z, M.z, V.z); a.upd(P.w, G.w, M.w, V.w);
       *(float4*)(ps + i) = P; nt_st4(ms + i, M); nt_st4(vs + i, V);
       if (SHADOW)
-        *(uint2*)(sh + i) = make_uint2((uint32_t)f32_to_bf16(P.x) | ((uint32_t)f32_to_bf16(P.y) << 16),
-                                       (uint32_t)f32_to_bf16(P.z) | ((uint32_t)f32_to_bf16(P.w) << 16));
+        *(uint2*)(sh + i) = make_uint2((uint32_t)f32_to_h16(P.x) | ((uint32_t)f32_to_h16(P.y) << 16),
+                                       (uint32_t)f32_to_h16(P.z) | ((uint32_t)f32_to_h16(P.w) << 16));
     }
     const size_t tl = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // tail (a segment that is not a multiple of 4)
     if (tl < sg.n) {
       a.upd(ps[tl], gs[tl], ms[tl], vs[tl]);
-      if (SHADOW) sh[tl] = f32_to_bf16(ps[tl]);
+      if (SHADOW) sh[tl] = f32_to_h16(ps[tl]);
     }
   }
 }
@@ -277,8 +278,8 @@ __device__ __forceinline__ void wire_slab_segment(uint16_t* __restrict__ wire, c
       }
     }
     if (l == 0 && q < n4)
-      *(uint2*)(wire + q * 4) = make_uint2((uint32_t)f32_to_bf16(s.x) | ((uint32_t)f32_to_bf16(s.y) << 16),
-                                           (uint32_t)f32_to_bf16(s.z) | ((uint32_t)f32_to_bf16(s.w) << 16));
+      *(uint2*)(wire + q * 4) = make_uint2((uint32_t)f32_to_h16(s.x) | ((uint32_t)f32_to_h16(s.y) << 16),
+                                           (uint32_t)f32_to_h16(s.z) | ((uint32_t)f32_to_h16(s.w) << 16));
   }
 }
 
@@ -304,11 +305,11 @@ __global__ __launch_bounds__(256) void wire_segs_kernel(const float* __restrict_
     const size_t n4 = sg.n / 4, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
       const float4 G = nt_ld4(gs + q * 4);
-      *(uint2*)(ws + q * 4) = make_uint2((uint32_t)f32_to_bf16(G.x) | ((uint32_t)f32_to_bf16(G.y) << 16),
-                                         (uint32_t)f32_to_bf16(G.z) | ((uint32_t)f32_to_bf16(G.w) << 16));
+      *(uint2*)(ws + q * 4) = make_uint2((uint32_t)f32_to_h16(G.x) | ((uint32_t)f32_to_h16(G.y) << 16),
+                                         (uint32_t)f32_to_h16(G.z) | ((uint32_t)f32_to_h16(G.w) << 16));
     }
     const size_t tl = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tl < sg.n) ws[tl] = f32_to_bf16(gs[tl]);
+    if (tl < sg.n) ws[tl] = f32_to_h16(gs[tl]);
   }
 }
 
@@ -317,13 +318,14 @@ __global__ __launch_bounds__(256) void wire_segs_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void adam_dev_scalar_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                               float* __restrict__ m, float* __restrict__ v,
                                                               const float* __restrict__ hyper, size_t n) {
-  const Adam a{p, g, m, v, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6], hyper[7]};
+  const Adam a{p, g, m, v, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[5], hyper[6], hyper[7], hyper[8]};
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     a.upd(p[i], g[i], m[i], v[i]);
 }
 
-__global__ void adam_hyper_kernel(int* step_dev, double lr, double b1, double b2, double eps, double wd, float* hyper) {
+__global__ void adam_hyper_kernel(int* step_dev, double lr, double b1, double b2, double eps, double wd, double ginv, float* hyper) {
   hyper[7] = (float)wd;
+  hyper[8] = (float)ginv;
   int step = *step_dev + 1;
   *step_dev = step;
   double bc1 = 1.0 - pow(b1, (double)step);
@@ -386,10 +388,12 @@ __global__ void nchw_chan_final_kernel(const float* partial, float* out, int C, 
   out[c] = accumulate ? out[c] + s : s;
 }
 
-__global__ void gp_coef_kernel(const float* sq, float* loss, float* coef, float lambd) {
-  float nrm = sqrtf(sq[0]);
+// in_inv = 1 / (the scale the gradient whose squared norm is sq carries), out_scale = the scale the tangent direction is to
+// carry (both 1 outside the fp16 build's loss-scaled penalty step; powers of two, so exact)
+__global__ void gp_coef_kernel(const float* sq, float* loss, float* coef, float lambd, float in_inv, float out_scale) {
+  float nrm = sqrtf(sq[0]) * in_inv;
   loss[0] = (nrm - 1.f) * (nrm - 1.f);
-  coef[0] = lambd * 2.f * (nrm - 1.f) / nrm;
+  coef[0] = lambd * 2.f * (nrm - 1.f) / nrm * (in_inv * out_scale);
 }
 
 __global__ __launch_bounds__(256) void mean_diff_kernel(const float* a, const float* b, float* out, int n, float sign) {
@@ -517,8 +521,8 @@ __global__ __launch_bounds__(256) void head_wgrad_bf16_kernel(const float* __res
       const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        acc[2 * k] += g * __uint_as_float(d[k] << 16);
-        acc[2 * k + 1] += g * __uint_as_float(d[k] & 0xffff0000u);
+        acc[2 * k] += g * h16lo_to_f32(d[k]);
+        acc[2 * k + 1] += g * h16hi_to_f32(d[k]);
       }
     }
   }
@@ -540,11 +544,11 @@ __global__ void widen_bf16_kernel(const uint16_t* src, float* dst, size_t n) {
   size_t n4 = n / 4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     uint2 v = reinterpret_cast<const uint2*>(src)[i];
-    reinterpret_cast<float4*>(dst)[i] = make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
-                                                    __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+    reinterpret_cast<float4*>(dst)[i] = make_float4(h16lo_to_f32(v.x), h16hi_to_f32(v.x),
+                                                    h16lo_to_f32(v.y), h16hi_to_f32(v.y));
   }
   size_t t = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n) dst[t] = bf16_to_f32(src[t]);
+  if (t < n) dst[t] = h16_to_f32(src[t]);
 }
 
 template <typename T>
@@ -563,10 +567,10 @@ __global__ __launch_bounds__(256) void cast_bf16x8_kernel(const float* __restric
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
     const float4 a = *reinterpret_cast<const float4*>(src + 8 * i), b = *reinterpret_cast<const float4*>(src + 8 * i + 4);
     uint4 o;
-    o.x = (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16);
-    o.y = (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16);
-    o.z = (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16);
-    o.w = (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16);
+    o.x = (uint32_t)f32_to_h16(a.x) | ((uint32_t)f32_to_h16(a.y) << 16);
+    o.y = (uint32_t)f32_to_h16(a.z) | ((uint32_t)f32_to_h16(a.w) << 16);
+    o.z = (uint32_t)f32_to_h16(b.x) | ((uint32_t)f32_to_h16(b.y) << 16);
+    o.w = (uint32_t)f32_to_h16(b.z) | ((uint32_t)f32_to_h16(b.w) << 16);
     *reinterpret_cast<uint4*>(dst + 8 * i) = o;
   }
 }
@@ -657,11 +661,11 @@ extern "C" int rg_adam_step_slabs(float* p, const float* g, float* m, float* v, 
     RG_REQUIRE(seg_off[i] == pos && seg_off[i] % 4 == 0, RG_EINVAL, "adam_step_slabs: segments must tile the range in order, "
                "each starting on a multiple of 4 elements (segment %d)", i);
     RG_REQUIRE(!seg_slab[i] || (seg_nsplit[i] >= 1 && seg_n[i] % 4 == 0 && aligned16(seg_slab[i]) &&
-                                (seg_dtype[i] == RG_F32 || seg_dtype[i] == RG_BF16)), RG_EINVAL,
+                                (seg_dtype[i] == RG_F32 || seg_dtype[i] == RG_H16)), RG_EINVAL,
                "adam_step_slabs: slab segment %d", i);
     // nsplit = -1 without a slab: the segment is SKIPPED (its tensor is stepped by another launch: rg_conv_wgrad_adam)
     t.s[i] = AdamSeg{seg_off[i], seg_n[i], (const float*)seg_slab[i], seg_slab[i] ? seg_nsplit[i] : (seg_nsplit[i] < 0 ? -1 : 0),
-                     seg_slab[i] && seg_dtype[i] == RG_BF16 ? 1 : 0};
+                     seg_slab[i] && seg_dtype[i] == RG_H16 ? 1 : 0};
     pos += seg_n[i];
   }
   RG_REQUIRE(pos == n, RG_EINVAL, "adam_step_slabs: the segments cover %llu of %zu elements", pos, n);
@@ -688,9 +692,9 @@ extern "C" int rg_grad_to_wire(const float* g, void* wire_bf16, size_t n, int ns
     RG_REQUIRE(seg_off[i] == pos && seg_off[i] % 4 == 0, RG_EINVAL, "grad_to_wire: segments must tile the range in order, each "
                "starting on a multiple of 4 elements (segment %d)", i);
     RG_REQUIRE(!seg_slab[i] || (seg_nsplit[i] >= 1 && seg_n[i] % 4 == 0 && aligned16(seg_slab[i]) &&
-                                (seg_dtype[i] == RG_F32 || seg_dtype[i] == RG_BF16)), RG_EINVAL, "grad_to_wire: slab segment %d", i);
+                                (seg_dtype[i] == RG_F32 || seg_dtype[i] == RG_H16)), RG_EINVAL, "grad_to_wire: slab segment %d", i);
     t.s[i] = AdamSeg{seg_off[i], seg_n[i], (const float*)seg_slab[i], seg_slab[i] ? seg_nsplit[i] : (seg_nsplit[i] < 0 ? -1 : 0),
-                     seg_slab[i] && seg_dtype[i] == RG_BF16 ? 1 : 0};
+                     seg_slab[i] && seg_dtype[i] == RG_H16 ? 1 : 0};
     pos += seg_n[i];
   }
   RG_REQUIRE(pos == n, RG_EINVAL, "grad_to_wire: the segments cover %llu of %zu elements", pos, n);
@@ -698,13 +702,17 @@ extern "C" int rg_grad_to_wire(const float* g, void* wire_bf16, size_t n, int ns
   RG_LAUNCH_CHECK("grad_to_wire");
   return RG_OK;
 }
-extern "C" int rg_adam_hyper_dev(int* step_dev, double lr, double beta1, double beta2, double eps, double weight_decay,
-                                 float* hyper, void* stream) {
-  RG_REQUIRE(step_dev && hyper, RG_EINVAL, "adam_hyper_dev: bad args");
+extern "C" int rg_adam_hyper_dev2(int* step_dev, double lr, double beta1, double beta2, double eps, double weight_decay,
+                                  double grad_scale_inv, float* hyper, void* stream) {
+  RG_REQUIRE(step_dev && hyper && grad_scale_inv > 0.0, RG_EINVAL, "adam_hyper_dev: bad args");
   hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(1), 0, rg_stream(stream), step_dev, lr, beta1, beta2, eps, weight_decay,
-                     hyper);
+                     grad_scale_inv, hyper);
   RG_LAUNCH_CHECK("adam_hyper_dev");
   return RG_OK;
+}
+extern "C" int rg_adam_hyper_dev(int* step_dev, double lr, double beta1, double beta2, double eps, double weight_decay,
+                                 float* hyper, void* stream) {
+  return rg_adam_hyper_dev2(step_dev, lr, beta1, beta2, eps, weight_decay, 1.0, hyper, stream);
 }
 extern "C" int rg_interp_dev(const float* real, const float* fake, float* out, size_t n, const float* eps,
                              void* stream) {
@@ -744,9 +752,16 @@ extern "C" int rg_nchw_chan_sum(const float* g, float* out, int N, int C, int HW
   return RG_OK;
 }
 
+extern "C" int rg_gp_coef_scaled(const float* sq, float* loss, float* coef, float lambd, float in_scale, float out_scale,
+                                 void* stream) {
+  RG_REQUIRE(sq && loss && coef && in_scale > 0.f && out_scale > 0.f, RG_EINVAL, "gp_coef: bad args");
+  hipLaunchKernelGGL(gp_coef_kernel, dim3(1), dim3(1), 0, rg_stream(stream), sq, loss, coef, lambd, 1.f / in_scale, out_scale);
+  RG_LAUNCH_CHECK("gp_coef");
+  return RG_OK;
+}
 extern "C" int rg_gp_coef(const float* sq, float* loss, float* coef, float lambd, void* stream) {
   RG_REQUIRE(sq && loss && coef, RG_EINVAL, "gp_coef: bad args");
-  hipLaunchKernelGGL(gp_coef_kernel, dim3(1), dim3(1), 0, rg_stream(stream), sq, loss, coef, lambd);
+  hipLaunchKernelGGL(gp_coef_kernel, dim3(1), dim3(1), 0, rg_stream(stream), sq, loss, coef, lambd, 1.f, 1.f);
   RG_LAUNCH_CHECK("gp_coef");
   return RG_OK;
 }
@@ -827,7 +842,7 @@ extern "C" int rg_head_bwd_data(const float* gh, const float* w, void* ga, int N
 extern "C" int rg_head_wgrad(const float* gh, const void* a, float* dw, int N, int C, int dtype, int accumulate,
                              void* stream) {
   RG_REQUIRE(gh && a && dw && N > 0 && C > 0, RG_EINVAL, "head_wgrad: bad args");
-  if (dtype == RG_BF16 && (((uintptr_t)a) & 15) == 0 && C % 8 == 0) {
+  if (dtype == RG_H16 && (((uintptr_t)a) & 15) == 0 && C % 8 == 0) {
     hipLaunchKernelGGL(head_wgrad_bf16_kernel, dim3((16 * C + 255) / 256), dim3(256), 0, rg_stream(stream), gh,
                        (const uint16_t*)a, dw, N, C, accumulate);
     RG_LAUNCH_CHECK("head_wgrad");
@@ -972,7 +987,7 @@ extern "C" int rg_widen_bf16(const void* src, float* dst, size_t n, void* stream
 extern "C" int rg_cast_pad(const float* src, void* dst, int M, int K, int ldd, int dtype, void* stream) {
   RG_REQUIRE(src && dst && M > 0 && K > 0 && ldd >= K, RG_EINVAL, "cast_pad: bad args");
   const size_t tot = (size_t)M * ldd;
-  if (dtype == RG_BF16 && K == ldd && tot % 8 == 0 && tot >= 4096 && aligned16(src) && aligned16(dst)) {
+  if (dtype == RG_H16 && K == ldd && tot % 8 == 0 && tot >= 4096 && aligned16(src) && aligned16(dst)) {
     const size_t n8 = tot / 8, want = (n8 + 255) / 256;
     hipLaunchKernelGGL(cast_bf16x8_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, rg_stream(stream), src,
                        (uint16_t*)dst, n8);

@@ -14,7 +14,10 @@
 
 namespace {
 
+// (bf16 library only: build.py leaves this file out of librnagan_hip_f16.so)
 typedef __attribute__((ext_vector_type(4))) float pf32x4_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { __bf16 h = (__bf16)f; return __builtin_bit_cast(uint16_t, h); }
 
 __device__ __forceinline__ unsigned probe_hash(unsigned x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -82,14 +85,24 @@ __global__ __launch_bounds__(NT, NT == 512 ? 2 : 1) void probe_mfma_bare_kernel(
   if (s == 123.456f) out[0] = s;                      // keeps the chain alive, writes (practically) never
 }
 
-__global__ __launch_bounds__(256) void probe_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t stride = (size_t)gridDim.x * 256;
-  for (; i + 3 * stride < n4; i += 4 * stride) {      // four loads in flight per thread
-    const float4 v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
-    dst[i] = v0; dst[i + stride] = v1; dst[i + 2 * stride] = v2; dst[i + 3 * stride] = v3;
+// a workgroup copies contiguous 32 KB pieces (8 x 16-byte loads in flight per thread, each instruction 4 KB contiguous over the
+// workgroup), grid-striding over the pieces; NT: non-temporal loads and stores (the data is touched once)
+template <bool NT>
+__global__ __launch_bounds__(256) void probe_copy_kernel(const pf32x4_t* __restrict__ src, pf32x4_t* __restrict__ dst, size_t n4) {
+  constexpr int U = 8;
+  const size_t pieces = n4 / (256 * U);
+  for (size_t pc = blockIdx.x; pc < pieces; pc += gridDim.x) {
+    const size_t base = pc * (256 * U) + threadIdx.x;
+    pf32x4_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(src + base + u * 256) : src[base + u * 256];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (NT) __builtin_nontemporal_store(v[u], dst + base + u * 256);
+      else dst[base + u * 256] = v[u];
+    }
   }
-  for (; i < n4; i += stride) dst[i] = src[i];
+  for (size_t i = pieces * (256 * U) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
 __global__ void probe_fill_bf16_kernel(uint16_t* p, size_t n, unsigned seed) {
@@ -140,10 +153,14 @@ extern "C" int rg_probe_lds_mfma(int mfma_shape, int blocks, int iters, const vo
   return RG_OK;
 }
 
-// (c) n bytes (multiple of 16) src -> dst
-extern "C" int rg_probe_copy(const void* src, void* dst, size_t nbytes, void* stream) {
-  RG_REQUIRE(src && dst && nbytes % 16 == 0 && nbytes > 0, RG_EINVAL, "probe_copy: bad args");
-  hipLaunchKernelGGL(probe_copy_kernel, dim3(2048), dim3(256), 0, rg_stream(stream), (const float4*)src, (float4*)dst, nbytes / 16);
+// (c) n bytes (multiple of 16) src -> dst; variant: 0 plain / 1 non-temporal loads and stores; blocks: grid size (0 = 2048)
+extern "C" int rg_probe_copy(const void* src, void* dst, size_t nbytes, int variant, int blocks, void* stream) {
+  RG_REQUIRE(src && dst && nbytes % 16 == 0 && nbytes > 0 && blocks >= 0, RG_EINVAL, "probe_copy: bad args");
+  const dim3 grid(blocks ? blocks : 2048);
+  if (variant == 1)
+    hipLaunchKernelGGL(probe_copy_kernel<true>, grid, dim3(256), 0, rg_stream(stream), (const pf32x4_t*)src, (pf32x4_t*)dst, nbytes / 16);
+  else
+    hipLaunchKernelGGL(probe_copy_kernel<false>, grid, dim3(256), 0, rg_stream(stream), (const pf32x4_t*)src, (pf32x4_t*)dst, nbytes / 16);
   RG_LAUNCH_CHECK("probe_copy");
   return RG_OK;
 }

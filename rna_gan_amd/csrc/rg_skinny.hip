@@ -71,13 +71,13 @@ __global__ __launch_bounds__(256) void first_down_kernel(const float* __restrict
 // x0 at 2m-1 and x2 at 2m, kw=0 <- x1 at 2m+1 and x3 at 2m+2; the two columns outside the aligned span
 // (2*wo0 - 1 and 2*wo0 + 2*chunk) are loaded by 24 edge lanes.  The NEXT unit's loads are issued into registers
 // before the current unit is computed (4 blocks/CU keep > 100 KB in flight per CU).
-typedef __attribute__((ext_vector_type(8))) __bf16 sk_bf16x8;
+typedef rg_h16x8 sk_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float sk_f32x16;
 typedef __attribute__((ext_vector_type(4))) short sk_s16x4;
 typedef __attribute__((ext_vector_type(8))) short sk_s16x8;
 
 __device__ __forceinline__ uint32_t sk_pack2(float a, float b) {
-  return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+  return (uint32_t)f32_to_h16(a) | ((uint32_t)f32_to_h16(b) << 16);
 }
 __device__ __forceinline__ sk_s16x4 sk_tr_read(const uint16_t* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) sk_s16x4*)(p));
@@ -124,10 +124,10 @@ __device__ __forceinline__ void sk_scatter4(uint16_t* pt, float4 v, int lgc, int
   uint16_t* k0 = pt + (4 * row) * PTS + 2 * m;               // k = 4*row + kw
   *reinterpret_cast<uint32_t*>(k0 + 1 * PTS) = sk_pack2(v.x, v.z);
   *reinterpret_cast<uint32_t*>(k0 + 2 * PTS) = sk_pack2(v.y, v.w);
-  k0[3 * PTS] = f32_to_bf16(v.z);
-  if (m > 0) k0[3 * PTS - 1] = f32_to_bf16(v.x);
-  k0[1] = f32_to_bf16(v.y);
-  if (2 * m + 2 < chunk) k0[2] = f32_to_bf16(v.w);
+  k0[3 * PTS] = f32_to_h16(v.z);
+  if (m > 0) k0[3 * PTS - 1] = f32_to_h16(v.x);
+  k0[1] = f32_to_h16(v.y);
+  if (2 * m + 2 < chunk) k0[2] = f32_to_h16(v.w);
 }
 __device__ __forceinline__ bool sk_pos16(uint32_t h) { return !(h & 0x8000u) && (h & 0x7fffu); }
 template <int PTS>
@@ -138,8 +138,8 @@ __device__ __forceinline__ void sk_scatter_rows(uint16_t* pt, const SkRows& r, i
   sk_scatter4<PTS>(pt, r.v2, lgc, chunk, t + 512, nf);
   if (t < 24) {
     const int row = t >> 1;
-    if (t & 1) pt[(4 * row + 3) * PTS + chunk - 1] = f32_to_bf16(r.edge);
-    else       pt[(4 * row) * PTS] = f32_to_bf16(r.edge);
+    if (t & 1) pt[(4 * row + 3) * PTS + chunk - 1] = f32_to_h16(r.edge);
+    else       pt[(4 * row) * PTS] = f32_to_h16(r.edge);
   }
 }
 
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256, 3) void first_down_rows_kernel(const float* __
         sk_s16x4 lo = sk_tr_read(bp), hi = sk_tr_read(bp + 4 * FD_PTS);
         sk_bf16x8 pb = __builtin_bit_cast(sk_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i][ci], pb, acc[i], 0, 0, 0);
+        for (int i = 0; i < 2; ++i) acc[i] = rg_mfma_h16_32x32x16(wa[i][ci], pb, acc[i], 0, 0, 0);
       }
       // acc[i][4*g + e] = D[ch = 32*i + 8*g + 4*h + e][pixel r]
       unsigned nib = 0;                                    // nibble 4*i + g: sign bits of channels 32*i + 8*g + 4*h + 0..3
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, 3) void skinny_wgrad_rows_kernel(const uint16_
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) acc[i][j] = rg_mfma_h16_32x32x16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
     }
     __syncthreads();
@@ -453,8 +453,8 @@ __global__ __launch_bounds__(256, 2) void last_up_rows_kernel(const uint16_t* __
     uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float lo = lrelu_f((bf16_to_f32((uint16_t)d[j]) - pm[2 * j]) * pr[2 * j] + pb[2 * j], pre.slope);
-      const float hi = lrelu_f((bf16_to_f32((uint16_t)(d[j] >> 16)) - pm[2 * j + 1]) * pr[2 * j + 1] + pb[2 * j + 1], pre.slope);
+      const float lo = lrelu_f((h16_to_f32((uint16_t)d[j]) - pm[2 * j]) * pr[2 * j] + pb[2 * j], pre.slope);
+      const float hi = lrelu_f((h16_to_f32((uint16_t)(d[j] >> 16)) - pm[2 * j + 1]) * pr[2 * j + 1] + pb[2 * j + 1], pre.slope);
       d[j] = sk_pack2(lo, hi);
     }
     v = make_uint4(d[0], d[1], d[2], d[3]);
@@ -525,9 +525,9 @@ __global__ __launch_bounds__(256, 2) void last_up_rows_kernel(const uint16_t* __
               sk_bf16x8 a0 = __builtin_bit_cast(sk_bf16x8, *reinterpret_cast<const uint4*>(s0 + o));
               sk_bf16x8 a1 = __builtin_bit_cast(sk_bf16x8, *reinterpret_cast<const uint4*>(s1 + o));
               sk_bf16x8 a2 = __builtin_bit_cast(sk_bf16x8, *reinterpret_cast<const uint4*>(s2 + o));
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wf[0][dw][c], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wf[1][dw][c], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, wf[2][dw][c], acc, 0, 0, 0);
+              acc = rg_mfma_h16_16x16x32(a0, wf[0][dw][c], acc, 0, 0, 0);
+              acc = rg_mfma_h16_16x16x32(a1, wf[1][dw][c], acc, 0, 0, 0);
+              acc = rg_mfma_h16_16x16x32(a2, wf[2][dw][c], acc, 0, 0, 0);
             }
           // acc[r] = D[pixel 16 st + 4 lq + r][column lp]
           if (ni < SK_I) {
@@ -583,7 +583,8 @@ __global__ __launch_bounds__(256, 2) void last_up_rows_kernel(const uint16_t* __
 // sums of the per-workgroup rows written by last_up_rows_kernel (post.part): out[c] (+)= sum_b part[b][c] for c < 3 (mode 0),
 // or the penalty's coefficient from sq = sum_b part[b][3] (mode 1: gp_coef_kernel's arithmetic)
 __global__ __launch_bounds__(256) void lu_part_final_kernel(const float* __restrict__ part, int nb, float* out, int accumulate,
-                                                            int mode, float* loss, float* coef, float lambd) {
+                                                            int mode, float* loss, float* coef, float lambd, float in_inv,
+                                                            float out_scale) {
   __shared__ float sm[4][4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -605,10 +606,10 @@ __global__ __launch_bounds__(256) void lu_part_final_kernel(const float* __restr
     if (mode == 0) {
       if (t < 3) out[t] = accumulate ? out[t] + tot : tot;
     } else if (t == 3) {
-      const float nrm = sqrtf(tot);
-      if (out) out[0] = tot;
+      const float nrm = sqrtf(tot) * in_inv;                 // (in_inv, out_scale: gp_coef_kernel, rg_misc.hip)
+      if (out) out[0] = tot * in_inv * in_inv;
       loss[0] = (nrm - 1.f) * (nrm - 1.f);
-      coef[0] = lambd * 2.f * (nrm - 1.f) / nrm;
+      coef[0] = lambd * 2.f * (nrm - 1.f) / nrm * (in_inv * out_scale);
     }
   }
 }
@@ -819,10 +820,10 @@ __device__ __forceinline__ void fd128_scatter(uint16_t* pt, const Fd128Rows& r, 
     uint16_t* k0 = pt + (4 * (4 * ci + wave)) * PTS + 2 * lane;         // k = 4*row + kw, row = ci*4 + kh
     *reinterpret_cast<uint32_t*>(k0 + 1 * PTS) = sk_pack2(v.x, v.z);
     *reinterpret_cast<uint32_t*>(k0 + 2 * PTS) = sk_pack2(v.y, v.w);
-    k0[3 * PTS] = f32_to_bf16(v.z);
-    if (lane > 0) k0[3 * PTS - 1] = f32_to_bf16(v.x);
-    k0[1] = f32_to_bf16(v.y);
-    if (lane < 63) k0[2] = f32_to_bf16(v.w);
+    k0[3 * PTS] = f32_to_h16(v.z);
+    if (lane > 0) k0[3 * PTS - 1] = f32_to_h16(v.x);
+    k0[1] = f32_to_h16(v.y);
+    if (lane < 63) k0[2] = f32_to_h16(v.w);
   }
 }
 // the two patch columns outside the image (kw = 0 at pixel 0, kw = 3 at pixel 127) are never written by fd128_scatter
@@ -890,7 +891,7 @@ __global__ __launch_bounds__(256, 3) void first_down_rows128_kernel(const float*
       sk_s16x4 lo = sk_tr_read(bp), hi = sk_tr_read(bp + 4 * FD_PTS);
       sk_bf16x8 pb = __builtin_bit_cast(sk_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[i][ci], pb, acc[i], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[i] = rg_mfma_h16_32x32x16(wa[i][ci], pb, acc[i], 0, 0, 0);
     }
     unsigned nib = 0;
 #pragma unroll
@@ -1000,8 +1001,8 @@ __global__ __launch_bounds__(256, 2) void last_up_rows128_kernel(const uint16_t*
     uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float lo = lrelu_f((bf16_to_f32((uint16_t)d[j]) - pm[2 * j]) * pr[2 * j] + pb[2 * j], pre.slope);
-      const float hi = lrelu_f((bf16_to_f32((uint16_t)(d[j] >> 16)) - pm[2 * j + 1]) * pr[2 * j + 1] + pb[2 * j + 1], pre.slope);
+      const float lo = lrelu_f((h16_to_f32((uint16_t)d[j]) - pm[2 * j]) * pr[2 * j] + pb[2 * j], pre.slope);
+      const float hi = lrelu_f((h16_to_f32((uint16_t)(d[j] >> 16)) - pm[2 * j + 1]) * pr[2 * j + 1] + pb[2 * j + 1], pre.slope);
       d[j] = sk_pack2(lo, hi);
     }
     v = make_uint4(d[0], d[1], d[2], d[3]);
@@ -1065,9 +1066,9 @@ __global__ __launch_bounds__(256, 2) void last_up_rows128_kernel(const uint16_t*
               sk_bf16x8 a0 = __builtin_bit_cast(sk_bf16x8, *reinterpret_cast<const uint4*>(s0 + o));
               sk_bf16x8 a1 = __builtin_bit_cast(sk_bf16x8, *reinterpret_cast<const uint4*>(s1 + o));
               sk_bf16x8 a2 = __builtin_bit_cast(sk_bf16x8, *reinterpret_cast<const uint4*>(s2 + o));
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wf[0][dw][c], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wf[1][dw][c], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, wf[2][dw][c], acc, 0, 0, 0);
+              acc = rg_mfma_h16_16x16x32(a0, wf[0][dw][c], acc, 0, 0, 0);
+              acc = rg_mfma_h16_16x16x32(a1, wf[1][dw][c], acc, 0, 0, 0);
+              acc = rg_mfma_h16_16x16x32(a2, wf[2][dw][c], acc, 0, 0, 0);
             }
           if (ni < SK_I) {
             float* orow = outt + (ni * 2 + nph) * LU_OS + 2 * (16 * st + 4 * lq) + npw;
@@ -1164,7 +1165,7 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_rows128_kernel(const uint
   if (u0 < u1) {
     fd128_zero_edges<SW_PTS>(pt2[0], t);
     fd128_zero_edges<SW_PTS>(pt2[1], t);
-    if (t < SW_PTS) { pt2[0][SK_K * SW_PTS + t] = 0x3f80; pt2[1][SK_K * SW_PTS + t] = 0x3f80; }     // bf16 1.0
+    if (t < SW_PTS) { pt2[0][SK_K * SW_PTS + t] = RG_H16_ONE; pt2[1][SK_K * SW_PTS + t] = RG_H16_ONE; }     // 1.0 in the 16-bit type
     Fd128Rows ra, rb;
     Sw128Low la, lb;
     fd128_load(ra, x, u0, wave, lane);
@@ -1202,7 +1203,7 @@ __global__ __launch_bounds__(256, 2) void skinny_wgrad_rows128_kernel(const uint
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; ++j) acc[i][j] = rg_mfma_h16_32x32x16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
     };
     int u = u0;
@@ -1292,7 +1293,7 @@ __global__ __launch_bounds__(256) void sign_pack64_kernel(const uint16_t* __rest
 }
 
 int rg_skinny_sign_pack(const void* a, void* bits, long long npix, int C, int dtype, hipStream_t st) {
-  RG_REQUIRE(C == 64 && dtype == RG_BF16, RG_EUNSUPPORTED, "sign_pack: 64 bf16 channels only");
+  RG_REQUIRE(C == 64 && dtype == RG_H16, RG_EUNSUPPORTED, "sign_pack: 64 bf16 channels only");
   const unsigned blocks = (unsigned)((npix * 8 + 255) / 256);
   hipLaunchKernelGGL(sign_pack64_kernel, dim3(blocks), dim3(256), 0, st, (const uint16_t*)a, (unsigned long long*)bits,
                      (size_t)npix);
@@ -1304,7 +1305,7 @@ int rg_skinny_sign_pack(const void* a, void* bits, long long npix, int C, int dt
 // false when this shape has no such kernel (the caller then runs first_down + lrelu_bwd)
 bool rg_skinny_first_down_masked_supported(int H, int W, int I, int O, int dtype) {
   int chunk;
-  return dtype == RG_BF16 && I == SK_I && O == 64 && sk_rows_chunk(W / 2, &chunk);
+  return dtype == RG_H16 && I == SK_I && O == 64 && sk_rows_chunk(W / 2, &chunk);
 }
 int rg_skinny_first_down_masked(const float* x, const float* w, void* y, const void* mask_bits, float mslope, int N, int H,
                                 int W, int I, int O, int dtype, hipStream_t st) {
@@ -1335,7 +1336,7 @@ int rg_skinny_first_down(const float* x, const float* w, const float* bias, void
   static int no_mfma = -1;
   if (no_mfma < 0) { const char* e = getenv("RNAGAN_SKINNY_VALU"); no_mfma = (e && e[0] == '1') ? 1 : 0; }
   int chunk;
-  if (dtype == RG_BF16 && O == 64 && sk_rows_chunk(W / 2, &chunk) && npix / chunk < 0x7fffffff && !no_mfma) {
+  if (dtype == RG_H16 && O == 64 && sk_rows_chunk(W / 2, &chunk) && npix / chunk < 0x7fffffff && !no_mfma) {
     int nunits = (int)(npix / chunk);
     int blocks = nunits < SK_ROWS_BLOCKS ? nunits : SK_ROWS_BLOCKS;
     if (sk_rows128(H, W)) {
@@ -1371,20 +1372,21 @@ int rg_skinny_first_down(const float* x, const float* w, const float* bias, void
 
 bool rg_skinny_last_up_pre_supported(int Wo, int O, int dtype) {
   int chunk;
-  return dtype == RG_BF16 && O == 64 && sk_rows_chunk(Wo, &chunk);
+  return dtype == RG_H16 && O == 64 && sk_rows_chunk(Wo, &chunk);
 }
 // number of per-workgroup partial rows rg_skinny_last_up writes with post_part (0: this shape has no rows kernel)
 int rg_skinny_last_up_post_blocks(int N, int Ho, int Wo, int O, int dtype) {
   int chunk;
-  if (!(dtype == RG_BF16 && O == 64 && sk_rows_chunk(Wo, &chunk))) return 0;
+  if (!(dtype == RG_H16 && O == 64 && sk_rows_chunk(Wo, &chunk))) return 0;
   int strip = Ho < 16 ? Ho : 16;
   while (Ho % strip) --strip;
   long long nstrips = (long long)N * (Ho / strip) * (Wo / chunk);
   return nstrips < 512 ? (int)nstrips : 512;
 }
 int rg_skinny_lu_part_final(const float* part, int nb, float* out, int accumulate, int mode, float* loss, float* coef,
-                            float lambd, hipStream_t st) {
-  hipLaunchKernelGGL(lu_part_final_kernel, dim3(1), dim3(256), 0, st, part, nb, out, accumulate, mode, loss, coef, lambd);
+                            float lambd, hipStream_t st, float in_scale, float out_scale) {
+  hipLaunchKernelGGL(lu_part_final_kernel, dim3(1), dim3(256), 0, st, part, nb, out, accumulate, mode, loss, coef, lambd,
+                     1.f / in_scale, out_scale);
   RG_LAUNCH_CHECK("last_up_post_final");
   return RG_OK;
 }
@@ -1401,7 +1403,7 @@ int rg_skinny_last_up(const void* x, const float* w, const float* bias, float* y
   static int lu_valu = -1;
   if (lu_valu < 0) { const char* e = getenv("RNAGAN_SKINNY_VALU"); lu_valu = (e && e[0] == '1') ? 1 : 0; }
   int chunk;
-  if (dtype == RG_BF16 && O == 64 && sk_rows_chunk(Wo, &chunk) && !lu_valu) {
+  if (dtype == RG_H16 && O == 64 && sk_rows_chunk(Wo, &chunk) && !lu_valu) {
     int strip = Ho < 16 ? Ho : 16;
     while (Ho % strip) --strip;
     long long nstrips = (long long)N * (Ho / strip) * (Wo / chunk);
@@ -1427,12 +1429,12 @@ int rg_skinny_last_up(const void* x, const float* w, const float* bias, float* y
     RG_LAUNCH_CHECK("last_up(mfma)");
     return RG_OK;
   }
-  if (dtype == RG_BF16) {
+  if (dtype == RG_H16) {
     constexpr int TH = 8;
     int tiles = ((Wo + LU_TW - 1) / LU_TW) * ((Ho + TH - 1) / TH);
     size_t sh = (size_t)(TH + 2) * (LU_TW + 2) * (O * 2 + 8);
-    hipLaunchKernelGGL((last_up_kernel<bf16_t, TH>), dim3((unsigned)((long long)N * tiles)), dim3(TH * 32), sh, st,
-                       (const bf16_t*)x, w, bias, y, N, Ho, Wo, O, apply_tanh);
+    hipLaunchKernelGGL((last_up_kernel<h16_t, TH>), dim3((unsigned)((long long)N * tiles)), dim3(TH * 32), sh, st,
+                       (const h16_t*)x, w, bias, y, N, Ho, Wo, O, apply_tanh);
   } else if (dtype == RG_F32) {
     if (O % 16 == 0 && !getenv("RNAGAN_LASTUP_WHOLE")) {    // 16 channels per staging pass: 15 KB per 128 threads
       constexpr int TH = 4, CCH = 16;
@@ -1477,7 +1479,7 @@ int rg_skinny_wgrad_slabs_impl(const void* low, const float* high_nchw, int N, i
   const size_t elems = (size_t)O * SK_K;
   const long long npix = (long long)N * Ho * Wo;
   int chunk;
-  if (!(dtype == RG_BF16 && O == 64 && sk_rows_chunk(Wo, &chunk) && npix / chunk < 0x7fffffff)) return RG_OK;
+  if (!(dtype == RG_H16 && O == 64 && sk_rows_chunk(Wo, &chunk) && npix / chunk < 0x7fffffff)) return RG_OK;
   const int nunits = (int)(npix / chunk);
   int nbm = nunits < SK_ROWS_BLOCKS ? nunits : SK_ROWS_BLOCKS;
   if (sk_rows128(2 * Ho, 2 * Wo)) {
@@ -1508,7 +1510,7 @@ int rg_skinny_wgrad_impl(const void* low, const float* high_nchw, float* dw, int
   static int no_mfma = -1;
   if (no_mfma < 0) { const char* e = getenv("RNAGAN_SKINNY_VALU"); no_mfma = (e && e[0] == '1') ? 1 : 0; }
   int chunk;
-  if (dtype == RG_BF16 && O == 64 && sk_rows_chunk(Wo, &chunk) && npix / chunk < 0x7fffffff && !no_mfma) {
+  if (dtype == RG_H16 && O == 64 && sk_rows_chunk(Wo, &chunk) && npix / chunk < 0x7fffffff && !no_mfma) {
     int nunits = (int)(npix / chunk);
     int nbm = nunits < SK_ROWS_BLOCKS ? nunits : SK_ROWS_BLOCKS;
     RG_REQUIRE(ws && ws_bytes >= (size_t)nbm * elems * sizeof(float), RG_EWORKSPACE, "skinny_wgrad: workspace too small");

@@ -37,7 +37,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct SbnArgs {
   const float* slab; size_t slab_stride; int nsplit;
-  int slab16;               // the slabs are bf16 (RG_BF16 slab_dtype: conv8_kernel's slab16 form), else fp32
+  int slab16;               // the slabs are bf16 (RG_H16 slab_dtype: conv8_kernel's slab16 form), else fp32
   const uint16_t* zin;      // backward: the layer's stored pre-activation z
   uint16_t* out0;           // forward: z ; backward: ga (may be null)
   uint16_t* out1;           // forward: a ; backward: gz
@@ -95,17 +95,17 @@ __device__ __forceinline__ void slice_rendezvous(unsigned* sync, int slice, unsi
 }
 
 __device__ __forceinline__ void unpack8(const uint4& t, float* o) {
-  o[0] = __uint_as_float(t.x << 16); o[1] = __uint_as_float(t.x & 0xffff0000u);
-  o[2] = __uint_as_float(t.y << 16); o[3] = __uint_as_float(t.y & 0xffff0000u);
-  o[4] = __uint_as_float(t.z << 16); o[5] = __uint_as_float(t.z & 0xffff0000u);
-  o[6] = __uint_as_float(t.w << 16); o[7] = __uint_as_float(t.w & 0xffff0000u);
+  o[0] = h16lo_to_f32(t.x); o[1] = h16hi_to_f32(t.x);
+  o[2] = h16lo_to_f32(t.y); o[3] = h16hi_to_f32(t.y);
+  o[4] = h16lo_to_f32(t.z); o[5] = h16hi_to_f32(t.z);
+  o[6] = h16lo_to_f32(t.w); o[7] = h16hi_to_f32(t.w);
 }
 __device__ __forceinline__ uint4 pack8(const float* v) {
   uint4 t;
-  t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-  t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-  t.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-  t.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+  t.x = (uint32_t)f32_to_h16(v[0]) | ((uint32_t)f32_to_h16(v[1]) << 16);
+  t.y = (uint32_t)f32_to_h16(v[2]) | ((uint32_t)f32_to_h16(v[3]) << 16);
+  t.z = (uint32_t)f32_to_h16(v[4]) | ((uint32_t)f32_to_h16(v[5]) << 16);
+  t.w = (uint32_t)f32_to_h16(v[6]) | ((uint32_t)f32_to_h16(v[7]) << 16);
   return t;
 }
 
@@ -479,7 +479,7 @@ extern "C" int rg_bn_forward_slabs(const void* slab, int nsplit, size_t slab_str
   RG_REQUIRE(scratch_bytes >= (size_t)p.slices * groups * p.rbpg * 2 * SB_COLS * sizeof(float), RG_EWORKSPACE,
              "bn_forward_slabs: scratch too small");
   SbnArgs a{};
-  a.slab = (const float*)slab; a.slab_stride = slab_stride; a.nsplit = nsplit; a.slab16 = slab_dtype == RG_BF16 ? 1 : 0;
+  a.slab = (const float*)slab; a.slab_stride = slab_stride; a.nsplit = nsplit; a.slab16 = slab_dtype == RG_H16 ? 1 : 0;
   a.out0 = (uint16_t*)z; a.out1 = (uint16_t*)a_out; a.M = (int)M; a.C = C; a.groups = groups;
   a.gamma = gamma; a.beta = beta; a.slope = slope; a.eps = eps; a.momentum = momentum;
   a.mean = mean; a.invstd = invstd; a.rmean = running_mean; a.rvar = running_var; a.nbt = num_batches_tracked;
@@ -501,7 +501,7 @@ extern "C" int rg_bn_act_bwd_slabs(const void* slab, int nsplit, size_t slab_str
   RG_REQUIRE(scratch_bytes >= (size_t)p.slices * groups * p.rbpg * 2 * SB_COLS * sizeof(float), RG_EWORKSPACE,
              "bn_act_bwd_slabs: scratch too small");
   SbnArgs a{};
-  a.slab = (const float*)slab; a.slab_stride = slab_stride; a.nsplit = nsplit; a.slab16 = slab_dtype == RG_BF16 ? 1 : 0;
+  a.slab = (const float*)slab; a.slab_stride = slab_stride; a.nsplit = nsplit; a.slab16 = slab_dtype == RG_H16 ? 1 : 0;
   a.zin = (const uint16_t*)z; a.out0 = (uint16_t*)ga_out; a.out1 = (uint16_t*)gz; a.M = (int)M; a.C = C; a.groups = groups;
   a.gamma = gamma; a.beta = beta; a.slope = slope;
   a.mean = const_cast<float*>(mean); a.invstd = const_cast<float*>(invstd);
@@ -523,7 +523,7 @@ extern "C" int rg_bn_tangent_slabs(const void* slab, int nsplit, size_t slab_str
   RG_REQUIRE(scratch_bytes >= (size_t)p.slices * p.rbpg * 2 * SB_COLS * sizeof(float), RG_EWORKSPACE,
              "bn_tangent_slabs: scratch too small");
   SbnArgs a{};
-  a.slab = (const float*)slab; a.slab_stride = slab_stride; a.nsplit = nsplit; a.slab16 = slab_dtype == RG_BF16 ? 1 : 0;
+  a.slab = (const float*)slab; a.slab_stride = slab_stride; a.nsplit = nsplit; a.slab16 = slab_dtype == RG_H16 ? 1 : 0;
   a.zin = (const uint16_t*)z; a.out0 = (uint16_t*)zt_out; a.out1 = (uint16_t*)at; a.M = (int)M; a.C = C; a.groups = 1;
   a.gamma = gamma; a.beta = beta; a.slope = slope;
   a.mean = const_cast<float*>(mean); a.invstd = const_cast<float*>(invstd);

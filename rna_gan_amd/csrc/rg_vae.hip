@@ -52,8 +52,8 @@ __global__ __launch_bounds__(256) void transpose_pack_bf16_kernel(const float* _
   for (int k = 0; k < 8; ++k) {
     const int c = c0 + py + 8 * k, r = r0 + 2 * px;
     if (c < Cp && r < Rp) {                                     // Rp is even (a multiple of 64)
-      const uint32_t v = (uint32_t)f32_to_bf16(tile[2 * px][py + 8 * k]) |
-                         ((uint32_t)f32_to_bf16(tile[2 * px + 1][py + 8 * k]) << 16);
+      const uint32_t v = (uint32_t)f32_to_h16(tile[2 * px][py + 8 * k]) |
+                         ((uint32_t)f32_to_h16(tile[2 * px + 1][py + 8 * k]) << 16);
       *reinterpret_cast<uint32_t*>(dst + (size_t)c * Rp + r) = v;
     }
   }

@@ -49,10 +49,10 @@ __device__ __forceinline__ void w8_store_slab16(const float* cs, uint16_t* tile,
     const float4 a = *reinterpret_cast<const float4*>(cs + row * 128 + c8);
     const float4 b = *reinterpret_cast<const float4*>(cs + row * 128 + c8 + 4);
     uint4 o;
-    o.x = (uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16);
-    o.y = (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16);
-    o.z = (uint32_t)f32_to_bf16(b.x) | ((uint32_t)f32_to_bf16(b.y) << 16);
-    o.w = (uint32_t)f32_to_bf16(b.z) | ((uint32_t)f32_to_bf16(b.w) << 16);
+    o.x = (uint32_t)f32_to_h16(a.x) | ((uint32_t)f32_to_h16(a.y) << 16);
+    o.y = (uint32_t)f32_to_h16(a.z) | ((uint32_t)f32_to_h16(a.w) << 16);
+    o.z = (uint32_t)f32_to_h16(b.x) | ((uint32_t)f32_to_h16(b.y) << 16);
+    o.w = (uint32_t)f32_to_h16(b.z) | ((uint32_t)f32_to_h16(b.w) << 16);
     *reinterpret_cast<uint4*>(tile + (long long)row * ldw + c8) = o;
   }
 }
@@ -221,12 +221,12 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(W8Args g) {
   asm volatile("s_waitcnt lgkmcnt(0)"                                                                      \
                : "+v"(bS[SET][0][0]), "+v"(bS[SET][0][1]), "+v"(bS[SET][1][0]), "+v"(bS[SET][1][1]),       \
                  "+v"(bS[SET][2][0]), "+v"(bS[SET][2][1]), "+v"(bS[SET][3][0]), "+v"(bS[SET][3][1])::"memory")
-#define W8_FRAG(lo, hi) __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3))
+#define W8_FRAG(lo, hi) __builtin_bit_cast(h16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3))
 #define W8_MFMAS(I, J, SET)                                                                                \
   do {                                                                                                     \
     __builtin_amdgcn_s_setprio(1);                                                                         \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) _Pragma("unroll") for (int ti_ = 0; ti_ < 2; ++ti_) \
-        acc[I][J][ti_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W8_FRAG(aR[ti_][ks_][0], aR[ti_][ks_][1]), \
+        acc[I][J][ti_] = rg_mfma_h16_32x32x16(W8_FRAG(aR[ti_][ks_][0], aR[ti_][ks_][1]), \
                                                                  W8_FRAG(bS[SET][ks_][0], bS[SET][ks_][1]), \
                                                                  acc[I][J][ti_], 0, 0, 0);                  \
     __builtin_amdgcn_s_setprio(0);                                                                         \
@@ -349,8 +349,8 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(W8Args g) {
           __builtin_nontemporal_store(f32x4_nt{ve[0], ve[1], ve[2], ve[3]}, reinterpret_cast<f32x4_nt*>(g.av + off[k]));
           if (g.ash)
             *reinterpret_cast<uint2*>(g.ash + off[k]) =
-                make_uint2((uint32_t)f32_to_bf16(pe[0]) | ((uint32_t)f32_to_bf16(pe[1]) << 16),
-                           (uint32_t)f32_to_bf16(pe[2]) | ((uint32_t)f32_to_bf16(pe[3]) << 16));
+                make_uint2((uint32_t)f32_to_h16(pe[0]) | ((uint32_t)f32_to_h16(pe[1]) << 16),
+                           (uint32_t)f32_to_h16(pe[2]) | ((uint32_t)f32_to_h16(pe[3]) << 16));
         }
       }
     } else if (g.slab16) {
@@ -538,12 +538,12 @@ __global__ __launch_bounds__(512, 2) void wgrad8n_kernel(W8Args g) {
   asm volatile("s_waitcnt lgkmcnt(0)"                                                                      \
                : "+v"(bS[SET][0][0]), "+v"(bS[SET][0][1]), "+v"(bS[SET][1][0]), "+v"(bS[SET][1][1]),       \
                  "+v"(bS[SET][2][0]), "+v"(bS[SET][2][1]), "+v"(bS[SET][3][0]), "+v"(bS[SET][3][1])::"memory")
-#define WN_FRAG(lo, hi) __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3))
+#define WN_FRAG(lo, hi) __builtin_bit_cast(h16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3))
 #define WN_MFMAS(J, SET)                                                                                   \
   do {                                                                                                     \
     __builtin_amdgcn_s_setprio(1);                                                                         \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) _Pragma("unroll") for (int ti_ = 0; ti_ < 2; ++ti_) \
-        acc[J][ti_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WN_FRAG(aR[ti_][ks_][0], aR[ti_][ks_][1]),   \
+        acc[J][ti_] = rg_mfma_h16_32x32x16(WN_FRAG(aR[ti_][ks_][0], aR[ti_][ks_][1]),   \
                                                               WN_FRAG(bS[SET][ks_][0], bS[SET][ks_][1]),   \
                                                               acc[J][ti_], 0, 0, 0);                       \
     __builtin_amdgcn_s_setprio(0);                                                                         \

@@ -177,19 +177,27 @@ class _HogWork:
             torch.cuda.current_stream().wait_event(self.ev)
 
 
-def wire_for(flat: torch.Tensor):
-    """The persistent bf16 wire buffer of a flat fp32 gradient buffer (one per device and length), or None when the gradients
-    travel as fp32."""
+def _half_of(compress):
+    """compress argument -> "bf16" / "f16" (the build of the library whose 16-bit type the wire carries) or None."""
+    if not compress:
+        return None
+    return "f16" if compress == "f16" else "bf16"
+
+
+def wire_for(flat: torch.Tensor, half: str = "bf16"):
+    """The persistent 16-bit wire buffer (bf16, or fp16 for the fp16 build) of a flat fp32 gradient buffer (one per device,
+    length and type), or None when the gradients travel as fp32."""
     if not (COMPRESS and flat.is_cuda and flat.dtype == torch.float32):
         return None
-    key = (flat.device, flat.numel(), flat.data_ptr())
+    key = (flat.device, flat.numel(), flat.data_ptr(), half)
     wire = _wire.get(key)
     if wire is None:
-        wire = _wire[key] = torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
+        wire = _wire[key] = torch.empty(flat.numel(), dtype=torch.float16 if half == "f16" else torch.bfloat16,
+                                        device=flat.device)
     return wire
 
 
-def allreduce_start(flat: torch.Tensor, compress: bool = False, head: int = 0, table=None):
+def allreduce_start(flat: torch.Tensor, compress=False, head: int = 0, table=None):
     """Start the in-place SUM all-reduce of a flat fp32 gradient buffer (fixed-size buckets, asynchronous: RCCL runs
     on its own stream behind everything enqueued so far on the current one).  Returns a handle for
     allreduce_finish(); None when there is nothing to reduce.  `flat` must not be written before the finish.
@@ -202,8 +210,9 @@ def allreduce_start(flat: torch.Tensor, compress: bool = False, head: int = 0, t
     n = flat.numel()
     if compress and COMPRESS and flat.is_cuda and flat.dtype == torch.float32:
         from . import _abi
-        lib = _abi.load()
-        wire = wire_for(flat)
+        half = _half_of(compress)
+        lib = _abi.load(half)
+        wire = wire_for(flat, half)
         stream = torch.cuda.current_stream(flat.device).cuda_stream
         if table:
             import ctypes as C
@@ -218,7 +227,7 @@ def allreduce_start(flat: torch.Tensor, compress: bool = False, head: int = 0, t
                        "rg_grad_to_wire")
         else:
             _abi.check(lib.rg_cast_pad(flat.data_ptr() + 4 * head, wire.data_ptr() + 2 * head, 1, n - head, n - head,
-                                       _abi.RG_BF16, stream), "rg_cast_pad")
+                                       _abi.RG_F16 if half == "f16" else _abi.RG_BF16, stream), "rg_cast_pad")
         works = _launch_buckets(wire[head:], BUCKET_BYTES // 2)
         hog = _hog_start(flat.device) if flat.is_cuda else None
         return (wire, flat, works + ([_HogWork(hog)] if hog is not None else []), head)
@@ -239,7 +248,7 @@ def allreduce_finish(handle, widen=True):
     if wire is not None and widen and flat.numel() > head:
         from . import _abi
         stream = torch.cuda.current_stream(flat.device).cuda_stream
-        _abi.check(_abi.load().rg_widen_bf16(wire.data_ptr() + 2 * head, flat.data_ptr() + 4 * head, flat.numel() - head, stream),
+        _abi.check(_abi.load("f16" if wire.dtype == torch.float16 else "bf16").rg_widen_bf16(wire.data_ptr() + 2 * head, flat.data_ptr() + 4 * head, flat.numel() - head, stream),
                    "rg_widen_bf16")
 
 

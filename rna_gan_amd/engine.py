@@ -355,7 +355,12 @@ def disc_gp_first(ops, D: DiscNet, ctx, lambd):
     # the squared norm comes out of the kernel that writes g as per-workgroup partial sums (no pass over g) unless the
     # statistics are synchronised over the ranks (then the scalar itself is all-reduced)
     fuse = None if ops.stat_reduce is not None else {"tanh_img": None}
-    g = disc_backward(ops, D, ctx, 1.0, wgrad=False, accumulate=False, need_input_grad=True, keep_for_gp=True,
+    # fp16 storage (HIP backend): the seed carries ops.gp_seed_scale so that the data gradients stay in fp16's normal range;
+    # gp_coef / gp_coef_parts divide the norm by it and put ops.gp_tangent_scale on the tangent direction instead -- the joint
+    # reverse sweep is bilinear in (first-backward gradients, tangents), so its parameter gradients arrive scaled by the product
+    # (= the step's loss scale, which the optimizer removes).  1.0 everywhere else.
+    seed = float(getattr(ops, "gp_seed_scale", 1.0))
+    g = disc_backward(ops, D, ctx, seed, wgrad=False, accumulate=False, need_input_grad=True, keep_for_gp=True,
                       input_post=fuse)
     if ctx.gx_parts is not None:
         loss, coef = ops.gp_coef_parts(ctx.gx_parts, lambd)

@@ -143,6 +143,16 @@ def _nets(generator, discriminator):
     return og, gn, dn
 
 
+def _is_half(ops):
+    """The backend runs the 16-bit-storage MFMA kernels (bf16 build, or the fp16 build of the same sources)."""
+    return ops.act_dtype in (torch.bfloat16, torch.float16)
+
+
+def _wire_kind(ops):
+    """compress argument of the data-parallel all-reduce: the gradients travel in the build's 16-bit type, or as fp32."""
+    return ops.half if _is_half(ops) else False
+
+
 def _finish(module, optimizer):
     """all-reduce (data parallel) -> optimizer step -> invalidate packed weights."""
     _reduce(module)
@@ -151,10 +161,15 @@ def _finish(module, optimizer):
 
 def _reduce(module):
     ops, _ = module.runtime()
-    D_.allreduce_sum_(module.flat.grad, compress=(ops.act_dtype == torch.bfloat16))
+    D_.allreduce_sum_(module.flat.grad, compress=_wire_kind(ops))
 
 
 def _apply(module, optimizer):
+    ops, _ = module.runtime()
+    if ops.loss_scale != 1.0 and getattr(optimizer, "_module", None) is not module:
+        # fp16: the gradients in module.flat.grad carry the loss scale; only rna_gan_amd.optim.Adam bound to the module unscales
+        raise RuntimeError("fp16 precision needs rna_gan_amd.optim.Adam(...).bind(module): a foreign optimizer would step on "
+                           "loss-scaled gradients")
     optimizer.step()
     if not hasattr(optimizer, "note_replayed"):      # rna_gan_amd.optim.Adam reports the change itself
         module.weights_changed()
@@ -174,7 +189,7 @@ def _g_prefix(generator, discriminator, noise):
 
 def _g_rest(generator, discriminator, pre):
     ops, gn, dn = _nets(generator, discriminator)
-    return E.gen_loss_rest(ops, gn, dn, pre, grad_scale=D_.grad_scale())
+    return E.gen_loss_rest(ops, gn, dn, pre, grad_scale=D_.grad_scale() * ops.loss_scale)
 
 
 # data-parallel D-loss step: D(real)'s backward belongs to the prefix too (it reads the discriminator only), so the generator's
@@ -204,10 +219,10 @@ def _d_prefix(generator, discriminator, real, noise, clip):
         ops.clamp_(discriminator.flat.data, clip[0], clip[1])      # every D parameter (wgan_loss.py:213-215)
         discriminator.weights_changed()
     if DP_PREFIX_MODE == 2 and D_.active():
-        return ("dgrad", E.disc_loss_prefix_dgrad(ops, dn, real.contiguous().float(), grad_scale=D_.grad_scale())), \
+        return ("dgrad", E.disc_loss_prefix_dgrad(ops, dn, real.contiguous().float(), grad_scale=D_.grad_scale() * ops.loss_scale)), \
             noise.contiguous().float()
     if DP_PREFIX_BWD and D_.active():
-        return ("bwd", E.disc_loss_prefix_bwd(ops, dn, real.contiguous().float(), grad_scale=D_.grad_scale())), \
+        return ("bwd", E.disc_loss_prefix_bwd(ops, dn, real.contiguous().float(), grad_scale=D_.grad_scale() * ops.loss_scale)), \
             noise.contiguous().float()
     return E.disc_loss_prefix(ops, dn, real.contiguous().float()), noise.contiguous().float()
 
@@ -220,7 +235,7 @@ def _d_batched(generator, discriminator, real, noise, clip, next_noise=None):
         ops.clamp_(discriminator.flat.data, clip[0], clip[1])
         discriminator.weights_changed()
     return E.disc_loss_grads_batched(ops, gn, dn, real.contiguous().float(), noise.contiguous().float(),
-                                     grad_scale=D_.grad_scale(),
+                                     grad_scale=D_.grad_scale() * ops.loss_scale,
                                      next_noise=None if next_noise is None else next_noise.contiguous().float())
 
 
@@ -281,10 +296,10 @@ def _d_rest(generator, discriminator, pre):
     ops, gn, dn = _nets(generator, discriminator)
     fwd_real, noise = pre
     if isinstance(fwd_real, tuple) and fwd_real[0] == "bwd":       # the real half's backward ran in the prefix
-        return E.disc_loss_rest_acc(ops, gn, dn, fwd_real[1], noise, grad_scale=D_.grad_scale())
+        return E.disc_loss_rest_acc(ops, gn, dn, fwd_real[1], noise, grad_scale=D_.grad_scale() * ops.loss_scale)
     if isinstance(fwd_real, tuple) and fwd_real[0] == "dgrad":     # ... its data-gradient chain did; weight gradients pair up here
-        return E.disc_loss_rest_pairw(ops, gn, dn, fwd_real[1], noise, grad_scale=D_.grad_scale())
-    return E.disc_loss_rest(ops, gn, dn, fwd_real, noise, grad_scale=D_.grad_scale())
+        return E.disc_loss_rest_pairw(ops, gn, dn, fwd_real[1], noise, grad_scale=D_.grad_scale() * ops.loss_scale)
+    return E.disc_loss_rest(ops, gn, dn, fwd_real, noise, grad_scale=D_.grad_scale() * ops.loss_scale)
 
 
 def _gp_prefix(generator, discriminator, real, noise, eps):
@@ -409,7 +424,7 @@ def _slab_layers(stepped, optimizer):
             getattr(optimizer, "_module", None) is not stepped):
         return []
     ops, net = stepped.runtime()
-    if ops.act_dtype != torch.bfloat16 or not isinstance(net, (E.GenNet, E.DiscNet)) or ops.stat_reduce is not None:
+    if not _is_half(ops) or not isinstance(net, (E.GenNet, E.DiscNet)) or ops.stat_reduce is not None:
         return []
     return [b[0] for b in net.blocks]
 
@@ -444,7 +459,7 @@ def _fusable_g0(stepped, optimizer):
         return None
     ops, net = stepped.runtime()
     g0 = getattr(net, "g0", None)
-    if g0 is None or not isinstance(net, E.GenNet) or ops.act_dtype != torch.bfloat16:
+    if g0 is None or not isinstance(net, E.GenNet) or not _is_half(ops):
         return None
     return g0
 
@@ -476,10 +491,10 @@ def _dp_wire_layers(stepped, optimizer):
     if not hasattr(optimizer, "grad_wire") or getattr(optimizer, "_module", None) is not stepped:
         return []
     ops, net = stepped.runtime()
-    if ops.act_dtype != torch.bfloat16 or not isinstance(net, (E.GenNet, E.DiscNet)) or ops.stat_reduce is not None:
+    if not _is_half(ops) or not isinstance(net, (E.GenNet, E.DiscNet)) or ops.stat_reduce is not None:
         return []
     flat = stepped.flat
-    wire = D_.wire_for(flat.grad)
+    wire = D_.wire_for(flat.grad, ops.half)
     if wire is None:
         return []
     out = []
@@ -527,14 +542,14 @@ def _dp_factor_g0(stepped, optimizer, batch):
         return None
     ops, net = stepped.runtime()
     g0 = getattr(net, "g0", None)
-    if g0 is None or not isinstance(net, E.GenNet) or ops.act_dtype != torch.bfloat16:
+    if g0 is None or not isinstance(net, E.GenNet) or not _is_half(ops):
         return None
     En, C = g0.w.shape[0], g0.w.shape[1]
     if (g0.w.data_ptr() - stepped.flat.data.data_ptr()) != 0:
         return None
     if not ops.lib.rg_g0_wgrad_adam_supported(D_.world_size() * batch, En, C, ops.dt):
         return None
-    return g0, D_.factor_buffers(id(stepped), batch, En, C, torch.bfloat16, stepped.flat.data.device), ops.dt
+    return g0, D_.factor_buffers(id(stepped), batch, En, C, ops.h16, stepped.flat.data.device), ops.dt
 
 
 def flush():
@@ -644,7 +659,7 @@ class _Runner:
         else:
             loss = rest()
         ops, _ = stepped.runtime()
-        handle = D_.allreduce_start(stepped.flat.grad, compress=(ops.act_dtype == torch.bfloat16), head=head,
+        handle = D_.allreduce_start(stepped.flat.grad, compress=_wire_kind(ops), head=head,
                                     table=cell.get("wire_table") if wired else None)
         if fac is not None:
             z_all, gy_all, z_mine, gy_mine = fac[1]

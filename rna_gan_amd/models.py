@@ -69,9 +69,10 @@ class FlatParams:
             off += n
         self.params = params
 
-    def ensure_shadow(self):
-        if self.shadow is None:
-            self.shadow = torch.zeros(self.data.numel(), dtype=torch.bfloat16, device=self.data.device)
+    def ensure_shadow(self, dtype=torch.bfloat16):
+        """dtype: the 16-bit type of the library build that writes it (bf16, or fp16 for precision "fp16")."""
+        if self.shadow is None or self.shadow.dtype != dtype:
+            self.shadow = torch.zeros(self.data.numel(), dtype=dtype, device=self.data.device)
         return self.shadow
 
     def owns(self, module: nn.Module) -> bool:
@@ -99,11 +100,13 @@ class _HipModule(nn.Module):
         self._rt_ops = None
         self._rt_net = None
         self._rt_flat = None
-        self.precision = "bf16"     # "bf16" (MFMA kernels) or "fp32" (generic fp32 kernels, parity mode)
+        # "bf16" (MFMA kernels), "fp32" (fp32 storage, parity mode) or "fp16" (the MFMA kernels built for IEEE fp16 storage,
+        # loss-scaled backward: BASELINE configs[3])
+        self.precision = "bf16"
 
     def set_precision(self, precision: str):
-        if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        if precision not in ("bf16", "fp32", "fp16"):
+            raise ValueError("precision must be 'bf16', 'fp32' or 'fp16'")
         if precision != self.precision:
             self.precision = precision
             self._rt_ops = None
@@ -125,12 +128,12 @@ class _HipModule(nn.Module):
             self._rt_net = None
         if self._rt_ops is None or self._rt_net is None:
             from .ops_hip import HipOps
-            dt = torch.bfloat16 if self.precision == "bf16" else torch.float32
+            dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[self.precision]
             self._rt_ops = D_.attach_sync(HipOps(dt, p0.device))
             self._rt_net = self._build_net()
             for cw in self._rt_net.convs():
                 cw.owner = "D" if hasattr(self, "disc") else "G"
-            if self.precision == "bf16" and p0.dtype == torch.float32:
+            if self.precision in ("bf16", "fp16") and p0.dtype == torch.float32:
                 self._attach_shadows()
         return self._rt_ops, self._rt_net
 
@@ -138,7 +141,7 @@ class _HipModule(nn.Module):
         """bf16 precision: the tap-major conv weights' GEMM operand (wdn) is a slice of the flat bf16 shadow that
         the fused Adam writes together with the fp32 masters."""
         flat = self._rt_flat
-        shadow = flat.ensure_shadow()
+        shadow = flat.ensure_shadow(self._rt_ops.h16)
         base = flat.data.data_ptr()
         g0 = getattr(self._rt_net, "g0", None)
         for cw in self._rt_net.convs():

@@ -12,7 +12,7 @@ from contextlib import contextmanager
 import torch
 
 from . import _abi
-from ._abi import RG_BF16, RG_F32, check
+from ._abi import RG_BF16, RG_F16, RG_F32, check
 from .engine import ConvW
 
 
@@ -118,12 +118,30 @@ class HipOps:
     def __init__(self, act_dtype=torch.bfloat16, device="cuda:0", algo=_abi.ALGO_AUTO):
         if not torch.cuda.is_available():
             raise RuntimeError("rna_gan_amd.HipOps needs a ROCm GPU (no CPU fallback exists)")
-        self.lib = _abi.load()
+        if act_dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError("act_dtype must be torch.float32, torch.bfloat16 or torch.float16")
+        # torch.float16 selects the fp16 BUILD of the library (librnagan_hip_f16.so: the same kernels with IEEE fp16 as the
+        # 16-bit storage type, BASELINE configs[3]); its callers pass RG_F16 where the bf16 build takes RG_BF16
+        self.half = "f16" if act_dtype == torch.float16 else "bf16"
+        self.lib = _abi.load(self.half)
         self.device = torch.device(device)
-        if act_dtype not in (torch.float32, torch.bfloat16):
-            raise ValueError("act_dtype must be torch.float32 or torch.bfloat16")
         self.act_dtype = act_dtype
-        self.dt = RG_F32 if act_dtype == torch.float32 else RG_BF16
+        self.h16 = torch.float16 if self.half == "f16" else torch.bfloat16       # torch dtype of the build's 16-bit type
+        self.H16 = RG_F16 if self.half == "f16" else RG_BF16                      # ... and its dtype code
+        self.dt = RG_F32 if act_dtype == torch.float32 else self.H16
+        # loss scaling (fp16 only; src/betaVAE.py:184,230-236 is the reference authors' commented-out GradScaler): the backward
+        # seeds of the three train_ops carry loss_scale, the penalty's first backward gp_seed_scale and its tangent direction
+        # gp_tangent_scale with gp_seed_scale * gp_tangent_scale == loss_scale, so EVERY parameter gradient of a step arrives
+        # scaled by loss_scale and rna_gan_amd.optim.Adam unscales inside its kernels (hyper[8]).  Powers of two: exact.
+        self.loss_scale = 1.0
+        self.gp_seed_scale = 1.0
+        self.gp_tangent_scale = 1.0
+        if self.half == "f16":
+            ls = float(os.environ.get("RNAGAN_F16_LOSS_SCALE", "4096"))
+            rt = ls ** 0.5
+            if ls < 1.0 or rt != int(rt) or (int(rt) & (int(rt) - 1)) != 0:
+                raise ValueError("RNAGAN_F16_LOSS_SCALE must be the square of a power of two (1, 4, 16, ..., 4096, 16384, ...)")
+            self.loss_scale, self.gp_seed_scale, self.gp_tangent_scale = ls, rt, rt
         self.algo = algo
         self._wsbuf = None
         # optional per-launch timing (bench.py roofline): list of (kernel family, algorithmic FLOPs,
@@ -206,7 +224,7 @@ class HipOps:
 
     def _defer_split(self, up, N, Hl, Wl, O, I, rows_out, C, groups):
         """Split factor if this conv launch can hand its slabs to the fused BatchNorm kernel (groups batch groups), else 0."""
-        if not groups or not self.split_bn or self.dt != RG_BF16 or self.stat_reduce is not None or rows_out % groups:
+        if not groups or not self.split_bn or self.dt == RG_F32 or self.stat_reduce is not None or rows_out % groups:
             return 0
         # The fused kernels rendezvous across ALL their workgroups (<= 256 blocks of 1024 threads).  In a data-parallel run
         # RCCL's kernels hold some CUs for the length of a collective, and blocks that cannot be placed keep the resident
@@ -270,19 +288,19 @@ class HipOps:
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
     def _packs(self, cw: ConvW):
-        if self.dt != RG_BF16:
+        if self.dt == RG_F32:
             return None, None
         if cw.packs is None or cw.packs_version != cw.version:
             O, I = cw.O, cw.I
             if cw.packs is None:
-                wdn = cw.shadow if cw.shadow is not None else torch.empty((O, 16, I), dtype=torch.bfloat16,
+                wdn = cw.shadow if cw.shadow is not None else torch.empty((O, 16, I), dtype=self.h16,
                                                                          device=self.device)
-                cw.packs = (wdn, torch.empty((16, I, O), dtype=torch.bfloat16, device=self.device))
+                cw.packs = (wdn, torch.empty((16, I, O), dtype=self.h16, device=self.device))
             # wdn is a cast of the tap-major master: skipped when the fused Adam already wrote it (shadow), and then
             # wup is transposed from that bf16 copy (half the read traffic of the fp32 master)
             need_wdn = cw.shadow is None or cw.shadow_version != cw.version or not self.pack_from_shadow
             if need_wdn:
-                check(self.lib.rg_pack_conv_weight(_ptr(cw.w), _ptr(cw.packs[0]), _ptr(cw.packs[1]), O, I, RG_BF16,
+                check(self.lib.rg_pack_conv_weight(_ptr(cw.w), _ptr(cw.packs[0]), _ptr(cw.packs[1]), O, I, self.H16,
                                                    self.stream), "rg_pack_conv_weight")
             else:
                 check(self.lib.rg_pack_conv_wup_from_bf16(_ptr(cw.shadow), _ptr(cw.packs[1]), O, I, self.stream),
@@ -296,14 +314,14 @@ class HipOps:
         """Rebuild the stale transposed-conv weight images (wup) of several layers in ONE launch when the fused Adam left
         their bf16 shadows current (the common case after an optimizer step: 5 transposes of 10-40 us per network became
         one).  Layers that do not qualify are left to the lazy per-layer path (_packs)."""
-        if self.dt != RG_BF16 or not self.pack_from_shadow or os.environ.get("RNAGAN_PACK_MULTI", "1") == "0":
+        if self.dt == RG_F32 or not self.pack_from_shadow or os.environ.get("RNAGAN_PACK_MULTI", "1") == "0":
             return
         todo = []
         for cw in cws:
             if (cw.layout == "OHWI" and cw.shadow is not None and cw.shadow_version == cw.version and
                     (cw.packs is None or cw.packs_version != cw.version) and cw.O % 64 == 0 and (16 * cw.I) % 128 == 0):
                 if cw.packs is None:
-                    cw.packs = (cw.shadow, torch.empty((16, cw.I, cw.O), dtype=torch.bfloat16, device=self.device))
+                    cw.packs = (cw.shadow, torch.empty((16, cw.I, cw.O), dtype=self.h16, device=self.device))
                 if cw.packs[0] is cw.shadow:
                     todo.append(cw)
         if len(todo) < 2:
@@ -340,7 +358,7 @@ class HipOps:
         partial rows ride on the result as ``_rg_bwd_partials`` for bn_act_bwd / bn_act_bwd2.  True when launched."""
         z, mean, invstd, gamma, beta, slope, groups = bn_bwd
         N, Hl, Wl, O, I = dims
-        if (self.dt != RG_BF16 or self.stat_reduce is not None or not self.bwd_epilogue or z.shape != y.shape or
+        if (self.dt == RG_F32 or self.stat_reduce is not None or not self.bwd_epilogue or z.shape != y.shape or
                 z.dtype != y.dtype or not z.is_contiguous()):
             return False
         rows = int(self.lib.rg_conv_bnbwd_rows(up, N, Hl, Wl, O, I, groups, self.dt, self.algo))
@@ -430,7 +448,7 @@ class HipOps:
     def conv_up_affine(self, x, cw: ConvW, scale, shift, slope: float):
         """Transposed conv with the eval-mode BatchNorm affine and LeakyReLU fused into its epilogue (bf16 MFMA path):
         lrelu(conv_up(x) * scale[c] + shift[c], slope), rounded once.  None when this shape / precision has no fused form."""
-        if self.dt != RG_BF16:
+        if self.dt == RG_F32:
             return None
         N, Ho, Wo, O = x.shape
         I = cw.I
@@ -451,7 +469,7 @@ class HipOps:
         c, expanded here to the layer's 16*C (tap, c) columns).  None when there is no fused form."""
         N, E = z.shape
         C = cw.w.shape[1]
-        if self.dt != RG_BF16 or E % 64 != 0 or C % 8 != 0:
+        if self.dt == RG_F32 or E % 64 != 0 or C % 8 != 0:
             return None
         self.g0_pack(cw)
         y = self._act(N, 4, 4, C)
@@ -529,7 +547,7 @@ class HipOps:
         """The weight gradient of a layer whose optimizer step follows immediately (cw.defer_slabs, set by the train_op runner):
         a split-K launch leaves its fp32 partial slabs in a buffer of the layer's own (cw.pending_slabs) and the reduction into
         dw is skipped -- rna_gan_amd.optim.Adam sums the slabs inside its step (rg_adam_step_slabs).  True when launched."""
-        if not cw.defer_slabs or self.dt != RG_BF16 or self.stat_reduce is not None or self._in_side:
+        if not cw.defer_slabs or self.dt == RG_F32 or self.stat_reduce is not None or self._in_side:
             return False
         if accumulate or cw.pending_slabs is not None or cw.pending_wgrad is not None:
             raise RuntimeError("rna_gan_amd: a second weight-gradient contribution for a layer whose first one is still deferred "
@@ -679,7 +697,7 @@ class HipOps:
         # picks them up from the tensor: 8 B instead of 128 B per pixel, and the patch-resident kernel).
         # (the caller of layer 1's data gradient decides by rg_conv_up_maskbits_supported with ITS channel counts whether
         # the bits are used; a 64 -> 128 second layer is the only shape that has the kernel)
-        if (self.dt == RG_BF16 and O == 64 and slope != 1.0 and H % 4 == 0 and W % 4 == 0 and
+        if (self.dt != RG_F32 and O == 64 and slope != 1.0 and H % 4 == 0 and W % 4 == 0 and
                 self.lib.rg_conv_up_maskbits_supported(N, H // 4, W // 4, 128, 64, self.dt, self.algo)):
             bits = torch.empty((N, H // 2, W // 2), dtype=torch.int64, device=self.device)
             check(self.lib.rg_first_down_bits(_ptr(x_nchw), _ptr(cw.w), _ptr(bias), _ptr(y), _ptr(bits), N, H, W, I, O,
@@ -705,7 +723,7 @@ class HipOps:
 
     def sign_pack(self, a):
         """Packed sign bits (uint64 per pixel, bit c = a[pixel][c] > 0) of a bf16 activation [..., 64]."""
-        assert a.dtype == torch.bfloat16 and a.shape[-1] == 64 and a.is_contiguous()
+        assert a.dtype == self.h16 and a.shape[-1] == 64 and a.is_contiguous()
         bits = torch.empty(a.shape[:-1], dtype=torch.int64, device=a.device)
         check(self.lib.rg_sign_pack(_ptr(a), _ptr(bits), a.numel() // 64, 64, self.dt, self.stream), "rg_sign_pack")
         return bits
@@ -797,8 +815,9 @@ class HipOps:
 
     def gp_coef_parts(self, parts, lambd: float):
         loss, coef = self._f32(1), self._f32(1)
-        check(self.lib.rg_gp_coef_parts(_ptr(parts), parts.shape[0], None, _ptr(loss), _ptr(coef), float(lambd), self.stream),
-              "rg_gp_coef_parts")
+        check(self.lib.rg_gp_coef_parts_scaled(_ptr(parts), parts.shape[0], None, _ptr(loss), _ptr(coef), float(lambd),
+                                               float(self.gp_seed_scale), float(self.gp_tangent_scale), self.stream),
+              "rg_gp_coef_parts_scaled")
         return loss, coef
 
     def skinny_wgrad(self, low, high_nchw, dw, accumulate: bool, dbias=None, dbias_accumulate=False):
@@ -814,7 +833,7 @@ class HipOps:
         cw = self._skinny_defer.get(dw.data_ptr()) if self._skinny_defer else None
         if cw is not None and cw.pending_slabs is None and accumulate:
             cw = None          # the first contribution had no slab form (a small image) and wrote dw: this one adds to it
-        if cw is not None and self.dt == RG_BF16 and self.stat_reduce is None and not self._in_side:
+        if cw is not None and self.dt != RG_F32 and self.stat_reduce is None and not self._in_side:
             # the optimizer step follows at once (the train_op runner registered the layer): the per-workgroup partial gradients
             # stay in a buffer of the layer's own -- a second contribution (accumulate) behind the first one's -- and Adam sums them
             prev = cw.pending_slabs
@@ -864,12 +883,12 @@ class HipOps:
         if True:
             if cw.packs is None or cw.packs_version != cw.version:
                 if cw.packs is None:
-                    cw.packs = (torch.empty((16 * C, E), dtype=torch.bfloat16, device=self.device),)
+                    cw.packs = (torch.empty((16 * C, E), dtype=self.h16, device=self.device),)
                 if cw.shadow is not None and cw.shadow_version == cw.version and self.pack_from_shadow:
                     check(self.lib.rg_pack_g0_weight_from_bf16(_ptr(cw.shadow), _ptr(cw.packs[0]), E, C, self.stream),
                           "rg_pack_g0_weight_from_bf16")
                 else:
-                    check(self.lib.rg_pack_g0_weight(_ptr(cw.w), _ptr(cw.packs[0]), E, C, RG_BF16, self.stream),
+                    check(self.lib.rg_pack_g0_weight(_ptr(cw.w), _ptr(cw.packs[0]), E, C, self.H16, self.stream),
                           "rg_pack_g0_weight")
                 cw.packs_version = cw.version
                 if cw.shadow is not None:
@@ -880,7 +899,7 @@ class HipOps:
         C = cw.w.shape[1]
         assert z.dtype == torch.float32 and z.is_contiguous() and cw.w.shape[0] == E
         wp = None
-        if self.dt == RG_BF16:
+        if self.dt != RG_F32:
             self.g0_pack(cw)
             wp = cw.packs[0]
         y = self._act(N, 4, 4, C)
@@ -993,7 +1012,7 @@ class HipOps:
         """An (uninitialised) packed sign-bit tensor for a [N, H, W, C0] activation when the data-gradient conv above it
         (C1 -> C0 channels) takes its LeakyReLU mask in that form (see first_down), else None.  rg_first_down_bits packs one
         uint64 per pixel: 64 channels exactly."""
-        if (self.dt == RG_BF16 and C0 == 64 and H % 2 == 0 and W % 2 == 0 and
+        if (self.dt != RG_F32 and C0 == 64 and H % 2 == 0 and W % 2 == 0 and
                 self.lib.rg_conv_up_maskbits_supported(N, H // 2, W // 2, C1, C0, self.dt, self.algo)):
             return torch.empty((N, H, W), dtype=torch.int64, device=self.device)
         return None
@@ -1264,7 +1283,8 @@ class HipOps:
 
     def gp_coef(self, sq, lambd: float):
         loss, coef = self._f32(1), self._f32(1)
-        check(self.lib.rg_gp_coef(_ptr(sq), _ptr(loss), _ptr(coef), float(lambd), self.stream), "rg_gp_coef")
+        check(self.lib.rg_gp_coef_scaled(_ptr(sq), _ptr(loss), _ptr(coef), float(lambd), float(self.gp_seed_scale),
+                                         float(self.gp_tangent_scale), self.stream), "rg_gp_coef_scaled")
         return loss, coef
 
     def scale_by(self, x, coef_dev):
@@ -1324,7 +1344,7 @@ class HipOps:
         Nout, K = w.shape
         Kp = (K + 63) // 64 * 64
         Np = (Nout + 127) // 128 * 128
-        wp = torch.empty((Np, Kp), dtype=torch.bfloat16, device=self.device)
+        wp = torch.empty((Np, Kp), dtype=self.h16, device=self.device)
         check(self.lib.rg_pack_linear_weight(_ptr(w), _ptr(wp), Nout, K, Np, Kp, self.stream),
               "rg_pack_linear_weight")
         return wp

@@ -30,7 +30,7 @@ class Adam(torch.optim.Adam):
         self._v = None
         self._flat_id = None
         self._step_dev = None      # int32[1] on the device
-        self._hyper = None         # float32[8] on the device
+        self._hyper = None         # float32[12] on the device (9 used: rg_adam_hyper_dev2)
         self._host_steps = 0       # number of steps enqueued/replayed so far (mirror of *_step_dev)
         self.buf_gen = 0           # bumped whenever the moment / step buffers are re-allocated (part of the graph keys)
         self.grad_wire = None      # data parallel, bf16 wire: the all-reduced bf16 gradient buffer to step from
@@ -77,7 +77,7 @@ class Adam(torch.optim.Adam):
                 self.state[p] = {"step": torch.tensor(float(step0)), "exp_avg": m, "exp_avg_sq": v}
             self._host_steps = step0
             self._step_dev = torch.tensor([step0], dtype=torch.int32, device=flat.data.device)
-            self._hyper = torch.zeros(8, dtype=torch.float32, device=flat.data.device)
+            self._hyper = torch.zeros(12, dtype=torch.float32, device=flat.data.device)
             self._flat_id = flat
             self.buf_gen += 1
         return flat
@@ -133,12 +133,16 @@ class Adam(torch.optim.Adam):
     def step(self, closure=None):
         flat = self._ensure()
         g = self.param_groups[0]
-        lib = _abi.load()
+        # the module's backend decides the build of the library (bf16 / fp16 storage: the shadow image, the slabs and the wire
+        # are in ITS 16-bit type) and the loss scale its backward passes put on every gradient of this step
+        mops = getattr(self._module, "_rt_ops", None)
+        lib = mops.lib if mops is not None else _abi.load()
+        ginv = 1.0 / float(getattr(mops, "loss_scale", 1.0)) if mops is not None else 1.0
         stream = torch.cuda.current_stream(flat.data.device).cuda_stream
-        check(lib.rg_adam_hyper_dev(self._step_dev.data_ptr(), float(g["lr"]), float(g["betas"][0]),
-                                    float(g["betas"][1]), float(g["eps"]), float(g.get("weight_decay", 0.0)),
-                                    self._hyper.data_ptr(), stream),
-              "rg_adam_hyper_dev")
+        check(lib.rg_adam_hyper_dev2(self._step_dev.data_ptr(), float(g["lr"]), float(g["betas"][0]),
+                                     float(g["betas"][1]), float(g["eps"]), float(g.get("weight_decay", 0.0)), ginv,
+                                     self._hyper.data_ptr(), stream),
+              "rg_adam_hyper_dev2")
         shadow = flat.shadow           # bf16 image of the parameters (bf16 precision only), written by the same launch
         lo = 0
         g0 = getattr(getattr(self._module, "_rt_net", None), "g0", None)

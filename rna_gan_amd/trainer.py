@@ -68,6 +68,9 @@ class Trainer:
         self.losses = {}
         for loss in losses_list:
             self.losses[type(loss).__name__] = loss
+            bv = getattr(loss, "betavae", None)
+            if precision == "fp16" and bv is not None and hasattr(bv, "set_precision"):
+                bv.set_precision("fp16")                  # the frozen encoder's GEMMs in the same 16-bit type as the GAN (configs[3])
         self.metrics = {} if metrics_list is None else {type(m).__name__: m for m in metrics_list}
         self.sample_size = sample_size
         self.nrow = nrow

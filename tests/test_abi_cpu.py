@@ -24,7 +24,23 @@ def test_library_loads_and_exports_all():
         build_library()
     lib = _abi.load()
     assert lib.rg_version() == _abi.ABI_VERSION
+    assert lib.rg_storage_dtype() == _abi.RG_BF16
     for name in header_symbols():
+        assert hasattr(lib, name), name
+
+
+def test_fp16_build_loads_and_exports_all_but_the_probes():
+    """librnagan_hip_f16.so: the same sources with IEEE fp16 as the 16-bit storage type (BASELINE configs[3]); it reports
+    RG_F16 and exports every entry point of the header except the bf16-only measurement probes."""
+    if not os.path.exists(_abi.LIB_PATH_F16):
+        from rna_gan_amd.build import build_library
+        build_library(half="f16")
+    lib = _abi.load("f16")
+    assert lib.rg_version() == _abi.ABI_VERSION
+    assert lib.rg_storage_dtype() == _abi.RG_F16
+    for name in header_symbols():
+        if name.startswith(_abi.BF16_ONLY_PREFIXES):
+            continue
         assert hasattr(lib, name), name
 
 

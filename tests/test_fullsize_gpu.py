@@ -564,7 +564,7 @@ def _slabs_inside_adam(lib, ops, dev, I, O, hs, two, wslab16):
     g0 = torch.randn(total + pad, generator=gen).to(dev) * 0.01
     m0 = torch.randn(total + pad, generator=gen).to(dev) * 0.01
     v0 = (torch.rand(total + pad, generator=gen).to(dev) * 1e-4)
-    hyper = torch.zeros(8, device=dev)
+    hyper = torch.zeros(12, device=dev)
     step = torch.zeros(1, dtype=torch.int32, device=dev)
     _abi.check(lib.rg_adam_hyper_dev(step.data_ptr(), 4e-4, 0.5, 0.999, 1e-8, 0.0, hyper.data_ptr(), ops.stream), "hyper")
     wsb = int(lib.rg_conv_wgrad_workspace_bytes(N, hs, hs, O, I, ops.dt, ops.algo))
@@ -676,7 +676,7 @@ def test_weight_gradient_and_adam_step_in_one_launch(two):
     g0 = torch.randn(total + pad, generator=gen).to(dev) * 0.01
     m0 = torch.randn(total + pad, generator=gen).to(dev) * 0.01
     v0 = (torch.rand(total + pad, generator=gen).to(dev) * 1e-4)
-    hyper = torch.zeros(8, device=dev)
+    hyper = torch.zeros(12, device=dev)
     step = torch.zeros(1, dtype=torch.int32, device=dev)
     _abi.check(lib.rg_adam_hyper_dev(step.data_ptr(), 4e-4, 0.5, 0.999, 1e-8, 0.0, hyper.data_ptr(), ops.stream), "hyper")
     wsb = int(lib.rg_conv_wgrad_workspace_bytes(N, hs, hs, O, I, ops.dt, ops.algo))
@@ -829,7 +829,7 @@ def test_image_side_weight_gradient_partials_inside_the_adam_step():
     g0 = torch.randn(total, generator=gen).to(dev) * 0.01
     m0 = torch.randn(total, generator=gen).to(dev) * 0.01
     v0 = torch.rand(total, generator=gen).to(dev) * 1e-4
-    hyper = torch.zeros(8, device=dev)
+    hyper = torch.zeros(12, device=dev)
     step = torch.zeros(1, dtype=torch.int32, device=dev)
     _abi.check(lib.rg_adam_hyper_dev(step.data_ptr(), 4e-4, 0.5, 0.999, 1e-8, 0.0, hyper.data_ptr(), ops.stream), "hyper")
     # reference: reduced gradient (two contributions), plain step

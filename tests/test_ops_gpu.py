@@ -783,7 +783,7 @@ def test_fused_layer0_gradient_adam_over_gathered_factors(N, E, C):
     p0, m0, v0 = p.clone(), m.clone(), v.clone()
     shadow = torch.zeros(E, C, 4, 4, dtype=torch.bfloat16, device=dev)
     step = torch.full((1,), 4, dtype=torch.int32, device=dev)
-    hyper = torch.zeros(8, device=dev)
+    hyper = torch.zeros(12, device=dev)
     lr, b1, b2, eps, wd = 1e-3, 0.5, 0.999, 1e-8, 1e-2
     stream = torch.cuda.current_stream().cuda_stream
     _abi.check(lib.rg_adam_hyper_dev(step.data_ptr(), lr, b1, b2, eps, wd, hyper.data_ptr(), stream), "rg_adam_hyper_dev")
@@ -888,7 +888,7 @@ def test_linear_weight_gradient_inside_adam(N, O, I):
     gT = torch.zeros(O + 3, ldn, dtype=torch.bfloat16, device=dev); gT[:O, :N] = g.t().bfloat16()
     xT = torch.zeros(I + 5, ldn, dtype=torch.bfloat16, device=dev); xT[:I, :N] = x.t().bfloat16()
     step = torch.full((1,), 2, dtype=torch.int32, device=dev)
-    hyper = torch.zeros(8, device=dev)
+    hyper = torch.zeros(12, device=dev)
     lr, b1, b2, eps, wd = 3e-3, 0.9, 0.999, 1e-8, 1e-4
     stream = torch.cuda.current_stream().cuda_stream
     _abi.check(lib.rg_adam_hyper_dev(step.data_ptr(), lr, b1, b2, eps, wd, hyper.data_ptr(), stream), "rg_adam_hyper_dev")

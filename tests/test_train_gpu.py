@@ -666,7 +666,7 @@ def test_unselected_inputs_loss_agreement_statistics():
         real = R.synthetic_images(n, in_size, seed=seed)
         noises = [R.synthetic_normal(n, enc, seed=100 * seed + 2 + j) for j in range(3)]
         ref = R.train_iteration(Go, Do, ogo, odo, real, noises, 0.4)
-        for precision in ("fp32", "bf16"):
+        for precision in precisions:
             G = P.DCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
             D = P.DCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.LeakyReLU(0.2))
             G.load_state_dict(G0.state_dict()); D.load_state_dict(D0.state_dict())
@@ -693,13 +693,13 @@ def test_unselected_inputs_loss_agreement_statistics():
     assert float((b16 <= 6e-2).mean()) >= 0.75, (b16 <= 6e-2).mean()
 
 
-def _loss_and_update_statistics(in_size, seeds, n=8, step=64, enc=128):
+def _loss_and_update_statistics(in_size, seeds, n=8, step=64, enc=128, precisions=("fp32", "bf16")):
     """One iteration (G-loss, D-loss, penalty train_ops) per seed -- weights, tiles and draws all change with the seed, nothing
     is selected -- on the HIP path in both precisions and on the CPU oracle.  Returns per precision: errs [seed][3] =
     |hip - oracle| / (|oracle| + 0.1) of the three losses, cos [seed][2] = cosine between the product's and the oracle's
     parameter UPDATES (all parameters of G / of D concatenated: the gate smoke() and tests/test_bench_step_gpu.py use)."""
-    errs = {"fp32": [], "bf16": []}
-    coss = {"fp32": [], "bf16": []}
+    errs = {p: [] for p in precisions}
+    coss = {p: [] for p in precisions}
     for seed in seeds:
         G0 = R.seeded_fill_(R.OracleDCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2),
                                                    last_nonlinearity=nn.Tanh()), seed)
@@ -712,7 +712,7 @@ def _loss_and_update_statistics(in_size, seeds, n=8, step=64, enc=128):
         ref = R.train_iteration(Go, Do, ogo, odo, real, noises, 0.4)
         upd_ref = [torch.cat([(a.detach() - b.detach()).reshape(-1).double() for a, b in zip(m1.parameters(), m0.parameters())])
                    for m1, m0 in ((Go, G0), (Do, D0))]
-        for precision in ("fp32", "bf16"):
+        for precision in precisions:
             G = P.DCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
             D = P.DCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.LeakyReLU(0.2))
             G.load_state_dict(G0.state_dict()); D.load_state_dict(D0.state_dict())

@@ -417,7 +417,8 @@ def _checkpoint_files(tmp_path):
     return [os.path.join(str(tmp_path), c) for c in cks if os.path.isfile(os.path.join(str(tmp_path), c))]
 
 
-def test_cli_trains_on_mixed_tissue_tables(tmp_path):
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_cli_trains_on_mixed_tissue_tables(tmp_path, precision):
     """The reference CLI's real-data path end to end (src/histopathology_gan.py:111-168, BASELINE configs[3]'s data side): two
     tissue tables with their own tile stores -> concatenated table -> log / standardised RNA -> per-slide tile sampling ->
     DataLoader -> Trainer with the three betaVAE-conditioned plugins, on the HIP kernels.  One short epoch at 32 x 32; checks
@@ -425,7 +426,9 @@ def test_cli_trains_on_mixed_tissue_tables(tmp_path):
     import subprocess
     import numpy as np
     cfg_path = _mixed_tissue_config(tmp_path)
-    r = subprocess.run(_cli_cmd(tmp_path, cfg_path), capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    # (precision fp16: BASELINE configs[3] in its stated dtype -- fp16 storage, fp16 betaVAE encoder GEMMs, loss-scaled backward)
+    r = subprocess.run(_cli_cmd(tmp_path, cfg_path) + ["--precision", precision], capture_output=True, text=True, timeout=600,
+                       cwd=str(tmp_path))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "Training of the Model is Complete" in r.stdout
     vals = [float(l.split(":")[1]) for l in r.stdout.splitlines() if "Mean Loss" in l]
@@ -434,6 +437,9 @@ def test_cli_trains_on_mixed_tissue_tables(tmp_path):
     assert files, "no checkpoint written"
     ck = torch.load(files[0], map_location="cpu", weights_only=False)
     assert {"epoch", "generator", "discriminator", "optimizer_generator", "optimizer_discriminator"} <= set(ck)
+    for net in ("generator", "discriminator"):
+        for k, v in ck[net].items():
+            assert not v.dtype.is_floating_point or (v.dtype == torch.float32 and bool(torch.isfinite(v).all())), (net, k)
 
 
 def test_cli_stock_wgan_literal_command(tmp_path):
