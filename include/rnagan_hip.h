@@ -663,6 +663,28 @@ int rg_selftest_fp8(int* detail, void* stream);
  * loader hand over uint8 tiles (a quarter of the PCIe bytes) and normalise on the device. */
 int rg_u8_to_norm(const void* src_u8, float* dst, size_t n, float mean, float stdv, void* stream);
 
+/* ---- the fp32 mode on the bf16 matrix cores, operands split ONCE PER TENSOR (rna_gan_amd/csrc/rg_conv8f.hip, rg_wgrad8f.hip) ----
+ * The reference computes in fp32 (src/betaVAE.py:184,223; the GAN CLI never enables AMP).  An fp32 value is the exact sum of three
+ * bf16 numbers v = h + m + l; rg_split_planes writes them as a plane-major buffer planes[3][n] (bf16, n % 8 == 0) in one
+ * bandwidth-bound pass, and the stride-2 conv / transposed conv / weight gradient run the product's 8-wave bf16 kernels over
+ * K-concatenated plane pairs with fp32 accumulation and an fp32 result:
+ *   products = 6: hh hm mh hl lh mm -- every term down to 2^-24 |a b| (the f32 instruction's accuracy class)
+ *   products = 3: hh hm mh          -- 2^-16 |a b| per product
+ * x_planes: planes of the NHWC activation the bf16 entry point would take (rg_conv_down: [N][2Hlow][2Wlow][I]; rg_conv_up:
+ * [N][Hlow][Wlow][O]); w_planes: planes of wdn[O][16][I] (down) / wup[16][I][O] (up); y fp32 NHWC.  stats_partial as rg_conv_down
+ * (rg_f32p_conv_stats_rows rows; 0 = the launch splits K and writes none).  rg_f32p_wgrad: dw[O][16][I] (+)= one or two
+ * (low, high) segments, all four operands as planes.  *_supported: 0 = use the RG_F32 entry points.  bf16 library only. */
+int rg_split_planes(const float* src, void* planes_bf16, size_t n, void* stream);
+int rg_f32p_conv_supported(int up, int N, int Hlow, int Wlow, int O, int I, int products);
+size_t rg_f32p_conv_workspace_bytes(int up, int N, int Hlow, int Wlow, int O, int I, int products);
+int rg_f32p_conv_stats_rows(int up, int N, int Hlow, int Wlow, int O, int I, int products);
+int rg_f32p_conv(int up, const void* x_planes, const void* w_planes, float* y, int N, int Hlow, int Wlow, int O, int I,
+                 int products, float* stats_partial, void* ws, size_t ws_bytes, void* stream);
+int rg_f32p_wgrad_supported(int N, int Ho, int Wo, int O, int I, int products);
+size_t rg_f32p_wgrad_workspace_bytes(int N, int Ho, int Wo, int O, int I, int products, int two);
+int rg_f32p_wgrad(const void* low0, const void* high0, const void* low1, const void* high1, float* dw, int N, int Ho, int Wo,
+                  int O, int I, int products, int accumulate, void* ws, size_t ws_bytes, void* stream);
+
 /* On-box ceilings for the roofline object of bench.py ("re-measure both on the box (MFMA-loop and stream-copy
  * microbenchmarks) and report against both nominal and measured peak").  Measurement kernels only -- no product path calls
  * them; the caller times back-to-back launches with events on `stream`.  (rna_gan_amd/csrc/rg_probe.hip)

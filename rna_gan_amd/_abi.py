@@ -163,6 +163,14 @@ PROTOTYPES = {
                                  _p, _p]),
     "rg_conv_up_affine": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _f, _p, _z, _p]),
     "rg_g0_fwd_affine": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _f, _p, _z, _p]),
+    "rg_split_planes": (_i, [_p, _p, _z, _p]),
+    "rg_f32p_conv_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "rg_f32p_conv_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),
+    "rg_f32p_conv_stats_rows": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "rg_f32p_conv": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _z, _p]),
+    "rg_f32p_wgrad_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "rg_f32p_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),
+    "rg_f32p_wgrad": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "rg_probe_mfma_bare": (_i, [_i, _i, _i, _i, _p, _p, _p]),
     "rg_probe_lds_mfma": (_i, [_i, _i, _i, _p, _p, _p, _p, _p]),
     "rg_probe_copy": (_i, [_p, _p, _z, _i, _i, _p]),
@@ -174,8 +182,8 @@ ABI_VERSION = 600
 
 _libs = {}
 LIB_PATH_F16 = os.path.join(_HERE, "librnagan_hip_f16.so")
-# entry points that exist only in the bf16 build (measurement kernels written for bf16 operands)
-BF16_ONLY_PREFIXES = ("rg_probe_",)
+# entry points that exist only in the bf16 build (measurement probes; the fp32 mode's bf16-plane kernels)
+BF16_ONLY_PREFIXES = ("rg_probe_", "rg_split_planes", "rg_f32p_")
 
 
 def load(half: str = "bf16"):

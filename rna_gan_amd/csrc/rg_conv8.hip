@@ -49,7 +49,13 @@ typedef int c8_v8i_t __attribute__((ext_vector_type(8)));
 // PROBE (rg_probe.hip only): the k-loop WITHOUT its LDS-DMA issue -- the prologue stages two k-tiles, the loop then runs
 // a2.probe_iters k-tiles over those resident stages (fragment reads, counted waits, barriers and MFMAs unchanged): the rate the
 // 8-wave schedule reaches when nothing has to arrive from L2 -- the measured ceiling bench.py quotes beside the nominal peak.
-template <int MODE, int WM, int WN, int MF, int EB = 2, int MXF = 0, int PROBE = 0>
+// NP (rg_conv8f.hip only; 0 = off): fp32 operands as K-concatenated bf16 PLANES.  An fp32 value is the exact sum of three bf16
+// numbers v = h + m + l (rg_split_planes: h = bf16(v), m = bf16(v - h), l = bf16(v - h - m)); A and B are plane-major buffers
+// [3][...] of the layouts this kernel takes anyway, and the k loop runs NP times as many k-tiles: flat k-tile q -> plane pair
+// q % NP, k-tile q / NP.  NP = 6: hh, hm, mh, hl, lh, mm -- every product down to 2^-24 |a b|, fp32-grade; NP = 3: hh, hm, mh --
+// 2^-16 |a b|.  The matrix pipe, the schedule and the operand traffic per k-tile are the bf16 kernel's; accumulation is the same
+// fp32 MFMA chain; the result (and the BatchNorm statistics, and split-K slabs) leave as fp32.
+template <int MODE, int WM, int WN, int MF, int EB = 2, int MXF = 0, int PROBE = 0, int NP = 0>
 __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
   static_assert(WM * WN == 8, "8 waves");
   static_assert(EB == 2 || (EB == 1 && MF == 16), "fp8 operands use the 16x16x32 MFMA");
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
     }
 
   const int cpt = g.Cin >> LGKD;
-  const int nkt_all = g.taps * cpt;
+  const int nkt_all = g.taps * cpt * (NP > 0 ? NP : 1);
   const int per = (nkt_all + a2.nsplit - 1) / a2.nsplit;      // host guarantees an even count per split
   const int kt_begin = zs * per;
   const int kt_end = min(nkt_all, kt_begin + per);
@@ -154,7 +160,14 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
 
   // k-tile index (relative to kt_begin) -> byte offsets added to the A row bases / B column bases, and the tap
   auto decode = [&](int ktr, int& ao, int& bo, int& tap) {
-    const int kt = kt_begin + ktr;
+    int kt = kt_begin + ktr;
+    int pa = 0, pb = 0;                  // planes of A / B this k-tile multiplies (NP > 0)
+    if constexpr (NP > 0) {
+      const int pp = kt % NP;
+      kt = kt / NP;
+      pa = (0x120100 >> (4 * pp)) & 15;  // pairs (A plane, B plane): hh hm mh hl lh mm
+      pb = (0x102010 >> (4 * pp)) & 15;
+    }
     int cb;
     if (a2.korder && MODE != MODE_PLAIN) {
       const int ti = kt & (g.taps - 1);
@@ -181,6 +194,7 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
     }
     ao = (a_delta + c0) * EB;
     bo = (b_tap * g.b_tap + c0) * EB;
+    if constexpr (NP > 0) { ao += pa * (int)a2.a_plane; bo += pb * (int)a2.b_plane; }
   };
   // one half-tile of k-tile ktr into stage S: NA (A) or NB (B) block-wide DMA instructions
   auto issue_a = [&](auto S, auto H, int ktr) {
@@ -411,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
           for (int s = 0; s < NAT; ++s)
 #pragma unroll
             for (int r = 0; r < ACC_R; ++r) {
-              const float v = h16_to_f32(f32_to_h16(acc[i][j][s * NBT + c][r]));
+              const float v = NP > 0 ? acc[i][j][s * NBT + c][r] : h16_to_f32(f32_to_h16(acc[i][j][s * NBT + c][r]));
               s1 += v; s2 += v * v;
             }
 #pragma unroll
@@ -472,6 +486,13 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
         orow = ((long long)n * (2 * Hq) + 2 * hq + ph) * (2 * Wq) + 2 * wq + pw;
       } else {
         orow = m;
+      }
+      if constexpr (NP > 0) {            // fp32 result (or fp32 partial tile): two 16-byte stores per thread and row
+        float* so = a2.nsplit > 1 ? a2.slab + (long long)zs * a2.slab_stride + orow * g.ldc + col
+                                  : reinterpret_cast<float*>(g.C) + orow * g.ldc + col;
+        *reinterpret_cast<float4*>(so) = v0;
+        *reinterpret_cast<float4*>(so + 4) = v1;
+        continue;
       }
       if (a2.nsplit > 1) {
         if (a2.slab16) {                 // bf16 partial tile: 16 instead of 32 bytes per thread and row (rounded partial sums)
@@ -557,7 +578,7 @@ __global__ __launch_bounds__(512, 2) void conv8_kernel(G2Args a2) {
 }
 
 
-#ifndef RG_CONV8_PROBE_TU
+#ifndef RG_CONV8_KERNEL_ONLY
 // ================================================================================================================
 // conv8n_kernel: the transposed conv with 64 output channels (the generator's last MFMA layer 128 -> 64 at 128 x 128 and
 // the discriminator's data gradient of layer 1).  K per parity class is only 4 taps x Cin (8 k-tiles at Cin = 128), so
@@ -899,11 +920,11 @@ __global__ __launch_bounds__(512, 2) void conv8n_kernel(G2Args a2) {
 #undef N8_DSR
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-#endif  // RG_CONV8_PROBE_TU
+#endif  // RG_CONV8_KERNEL_ONLY
 
 }  // namespace
 
-#ifndef RG_CONV8_PROBE_TU
+#ifndef RG_CONV8_KERNEL_ONLY
 // transposed conv with 64 output channels, all four parity classes per block (conv8n_kernel): grid = row tiles of 512
 int rg_conv8n_launch(const void* args, unsigned tiles_m, hipStream_t st) {
   const G2Args& a2 = *reinterpret_cast<const G2Args*>(args);
@@ -953,4 +974,4 @@ int rg_conv8_launch(int mode, const void* args, int bm, unsigned gx, unsigned gy
 #undef C8_GO
   return RG_OK;
 }
-#endif  // RG_CONV8_PROBE_TU
+#endif  // RG_CONV8_KERNEL_ONLY

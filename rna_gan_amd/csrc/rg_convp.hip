@@ -493,6 +493,14 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
 // shapes convp_kernel takes: 128 input channels, 64 output channels, power-of-two maps of 16 .. 64 pixels width, whole
 // 256-pixel tiles inside one image
 bool rg_convp_supported(int M, int Ncols, int Cin, int Hs, int Ws) {
+#ifdef RG_HALF_F16
+  // The fp16 build does not use this kernel: its MFMAs are inline asm whose hazards were closed by measurement for the bf16
+  // instruction stream (DESIGN: "two latent hazards"); with the fp16 conversions in the epilogue the statistics variant wrote
+  // wrong outputs (found by the layer-by-layer comparison against the fp32 kernels, 2.7e-1 on this layer, exact with the
+  // implicit-GEMM kernels).  The 128 -> 64 channel transposed conv runs on the gather kernel instead.
+  (void)M; (void)Ncols; (void)Cin; (void)Hs; (void)Ws;
+  return false;
+#endif
   return Ncols == 64 && Cin == 128 && Ws >= 16 && Ws <= 64 && rg_is_pow2(Ws) && rg_is_pow2(Hs) && (Hs * Ws) % 256 == 0 &&
          M % 256 == 0 && M >= 256;
 }

@@ -95,6 +95,7 @@ struct G2Args {
   int korder;                  // 1: channel-block-major k order (tap = kt & (taps-1), block = kt / taps; MODE_DOWN taps in
                                // parity-class order): the taps that revisit the same input lines are adjacent k-tiles
   int probe_iters;             // conv8_kernel<..., PROBE = 1> (rg_probe.hip): k-tiles the loop runs over the two resident stages
+  unsigned a_plane, b_plane;   // conv8_kernel<..., NP > 0> (rg_conv8f.hip): bytes between consecutive bf16 planes of A / of B
 };
 
 typedef __attribute__((address_space(3))) void* lds_vptr_t;

@@ -37,6 +37,7 @@ struct W8Args {
   float* ap; float* am; float* av; uint16_t* ash; const float* hyper;
   int slab16;            // nsplit > 1 only: the partial tiles are stored as bf16 [nsplit][O][16*I] (each partial sum rounded once;
                          // the consumer -- rg_adam_step_slabs -- adds them in fp32): half the slab bytes written and re-read
+  unsigned low_plane, high_plane;   // wgrad8_kernel<.., NP > 0> (rg_conv8f.hip): bytes between the bf16 planes of low / of high
 };
 
 // the epilogue's store loop for bf16 slabs: `rows` rows of the 128-column fp32 LDS image go to `tile` (this slab's element
@@ -59,7 +60,9 @@ __device__ __forceinline__ void w8_store_slab16(const float* cs, uint16_t* tile,
 
 __device__ __forceinline__ int w8_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
-template <bool ADAM>
+// NP > 0 (rg_conv8f.hip only): fp32 operands as K-concatenated bf16 planes, exactly as conv8_kernel's NP (rg_conv8.hip): low and
+// high are plane-major [3][pixels][channels] buffers, flat k-tile q -> plane pair q % NP (hh hm mh hl lh mm), pixel tile q / NP.
+template <bool ADAM, int NP = 0>
 __global__ __launch_bounds__(512, 2) void wgrad8_kernel(W8Args g) {
   constexpr int HT = 64 * 256;                     // bytes per half-tile: 64 pixels x 128 channels bf16
   constexpr int STAGE = 4 * HT;                    // [B0][B1][A0][A1]
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(W8Args g) {
   const int tile_o = tid / g.tiles_c, tile_c = tid - tile_o * g.tiles_c;
   const int o0 = tile_o * 256, c0 = tile_c * 256;
   const int Ktot = g.Kseg[0] + g.Kseg[1];
-  const int nkt_all = (Ktot + 63) >> 6;
+  const int nkt_all = ((Ktot + 63) >> 6) * (NP > 0 ? NP : 1);
   const int kt_begin = zs * g.kt_per_split;
   const int nkt = min(nkt_all, kt_begin + g.kt_per_split) - kt_begin;     // host: > 0 and even
   constexpr unsigned OOB = 0x80000000u;
@@ -115,8 +118,22 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(W8Args g) {
   // pixel geometry of this lane's two rows of k-tile ktr (decoded when B0 of that k-tile is issued, reused for B1)
   int px_base[2], px_h[2], px_w[2];
   bool px_ok[2];
+  int px_plane = 0;                   // NP > 0: byte offset of the `high` plane of the k-tile decoded last
+  // flat k-tile -> (first pixel, byte offsets of the low / high planes it multiplies)
+  auto flat_tile = [&](int ktr, int& lo_off, int& hi_off) -> int {
+    int q = kt_begin + ktr;
+    lo_off = 0; hi_off = 0;
+    if constexpr (NP > 0) {
+      const int pp = q % NP;
+      q = q / NP;
+      lo_off = ((0x120100 >> (4 * pp)) & 15) * (int)g.low_plane;
+      hi_off = ((0x102010 >> (4 * pp)) & 15) * (int)g.high_plane;
+    }
+    return q * 64;
+  };
   auto decode_pixels = [&](int ktr) {
-    const int p0 = (kt_begin + ktr) * 64;
+    int lo_off;
+    const int p0 = flat_tile(ktr, lo_off, px_plane);
     const bool seg1 = p0 >= g.Kseg[0];
     const int pb = seg1 ? p0 - g.Kseg[0] : p0;
     const int kend = (ktr < nkt) ? (seg1 ? g.Kseg[1] : g.Kseg[0]) : 0;
@@ -132,12 +149,13 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(W8Args g) {
   };
   auto issue_a = [&](auto S, auto H, int ktr) {
     constexpr int s = decltype(S)::value, h = decltype(H)::value;
-    const int p0 = (kt_begin + ktr) * 64;
+    int lo_off, hi_off;
+    const int p0 = flat_tile(ktr, lo_off, hi_off);
     const bool seg1 = p0 >= g.Kseg[0];
     const int pb = seg1 ? p0 - g.Kseg[0] : p0;
     const int kend = (ktr < nkt) ? (seg1 ? g.Kseg[1] : g.Kseg[0]) : 0;
     const __amdgpu_buffer_rsrc_t rs = seg1 ? rsL1 : rsL0;
-    const int so = pb * g.O * 2;
+    const int so = pb * g.O * 2 + lo_off;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const bool ok = pb + jj * 32 + lrow < kend;
@@ -149,13 +167,14 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(W8Args g) {
   auto issue_b = [&](auto S, auto H, int ktr) {
     constexpr int s = decltype(S)::value, h = decltype(H)::value;
     if (h == 0) decode_pixels(ktr);
-    const bool seg1 = (kt_begin + ktr) * 64 >= g.Kseg[0];
+    int lo_off, hi_off;
+    const bool seg1 = flat_tile(ktr, lo_off, hi_off) >= g.Kseg[0];
     const __amdgpu_buffer_rsrc_t rs = seg1 ? rsH1 : rsH0;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int hi = px_h[jj] + b_kh[h], wi = px_w[jj] + b_kw[h];
       const bool v = px_ok[jj] && (unsigned)hi < (unsigned)g.Hh && (unsigned)wi < (unsigned)g.Wh;
-      const unsigned vo = v ? (unsigned)(((px_base[jj] + hi) * g.Wh + wi) * g.I * 2 + b_ci[h]) : OOB;
+      const unsigned vo = v ? (unsigned)(((px_base[jj] + hi) * g.Wh + wi) * g.I * 2 + b_ci[h] + px_plane) : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr_t)(ldsb + s * STAGE + OFF_B + h * HT + jj * 8192 + wave * 1024),
                                                16, vo, 0, 0, 0);
     }
@@ -372,6 +391,7 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(W8Args g) {
 }
 
 
+#ifndef RG_WGRAD8_KERNEL_ONLY
 // ---------------------------------------------------------------------------------------------------------------------------
 // The same pipeline for the layers with 128 low-side channels (O = 128: D.1 and the generator's 128 -> 64 block), which the
 // 256 x 256 tile cannot cover: block tile 128 (o) x 512 (tap, i) -- 8 waves of 64 (o) x 4 x 32 columns, FIVE 16 KB half-tiles
@@ -653,8 +673,11 @@ __global__ __launch_bounds__(512, 2) void wgrad8n_kernel(W8Args g) {
   }
 }
 
+#endif  // RG_WGRAD8_KERNEL_ONLY
+
 }  // namespace
 
+#ifndef RG_WGRAD8_KERNEL_ONLY
 // Shapes of the ping-pong weight-gradient kernel: O and 16*I multiples of 256, I a multiple of 8 that divides the
 // 128-column half-tiles into whole 8-column chunks of one tap (I % 8 == 0), at least 4 k-tiles of 64 pixels per split.
 bool rg_wgrad8_supported(int K, int O, int I) {
@@ -763,3 +786,4 @@ int rg_wgrad8_adam_launch(const void* low0, const void* high0, const void* low1,
   RG_LAUNCH_CHECK("conv_wgrad_adam(mfma, ping-pong)");
   return RG_OK;
 }
+#endif  // RG_WGRAD8_KERNEL_ONLY

@@ -175,6 +175,8 @@ class _HipModule(nn.Module):
             return 2
         st = 0
         for cw in self._rt_net.convs():
+            if cw.packs is None and self.precision == "fp32":
+                continue          # fp32 storage: only the layers that run on bf16 planes (ops_hip._plane_packs) keep operand images
             if cw.packs_version != cw.version:
                 st = max(st, 2 if (cw.shadow is not None and cw.shadow_version != cw.version) else 1)
         return st

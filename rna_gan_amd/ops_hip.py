@@ -180,6 +180,12 @@ class HipOps:
         # the chip is in its epilogue at once (11.95-12.09 ms with the separate reduction pass vs 12.03-12.07 ms with the
         # fused form, same box; the conv family drops from 0.408 to 0.382 of peak) -- off by default, RNAGAN_BWD_EPILOGUE=1
         self.bwd_epilogue = os.environ.get("RNAGAN_BWD_EPILOGUE", "0") != "0"
+        # fp32 storage: the stride-2 convs / transposed convs / weight gradients on the bf16 matrix cores from operands split ONCE
+        # PER TENSOR into bf16 planes (rg_conv8f.hip): products per fp32 product -- 6 (every term down to 2^-24: fp32-grade, the
+        # default), 3 (2^-16 per product), 0: the per-tile kernels of rg_generic.hip (f32mma option)
+        self.f32_planes = int(os.environ.get("RNAGAN_F32_PLANES", "6")) if self.dt == RG_F32 else 0
+        if self.f32_planes not in (0, 3, 6):
+            raise ValueError("RNAGAN_F32_PLANES must be 0, 3 or 6")
         self._slabs_pending = None    # the tensor whose deferred split-K slabs currently occupy the workspace
         self._sb_sync = None          # hand-off words of the fused kernels: zeroed once, left zero by every launch
         self._sb_scratch = None
@@ -287,6 +293,48 @@ class HipOps:
     def _f32(self, *shape):
         return torch.empty(shape, dtype=torch.float32, device=self.device)
 
+    def _planes(self, t):
+        """bf16 planes [3][numel] of an fp32 tensor (v = h + m + l exactly, rg_split_planes), cached on the tensor object: an
+        activation is split once for the conv that consumes it and for the weight gradient that reads it again."""
+        p = getattr(t, "_rg_planes", None)
+        if p is None:
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() % 8 == 0
+            p = torch.empty((3, t.numel()), dtype=torch.bfloat16, device=self.device)
+            check(self.lib.rg_split_planes(_ptr(t), _ptr(p), t.numel(), self.stream), "rg_split_planes")
+            t._rg_planes = p
+        return p
+
+    def _plane_packs(self, cw: ConvW):
+        """(planes of wdn[O][16][I], planes of wup[16][I][O]) of a tap-major fp32 master, rebuilt when its version changes."""
+        if cw.packs is None or cw.packs_version != cw.version:
+            O, I = cw.O, cw.I
+            if cw.packs is None:
+                cw.packs = (torch.empty((3, O, 16, I), dtype=torch.bfloat16, device=self.device),
+                            torch.empty((3, 16, I, O), dtype=torch.bfloat16, device=self.device))
+            check(self.lib.rg_split_planes(_ptr(cw.w), _ptr(cw.packs[0]), cw.w.numel(), self.stream), "rg_split_planes")
+            for p in range(3):          # the transposed conv's operand image, plane by plane
+                check(self.lib.rg_pack_conv_wup_from_bf16(_ptr(cw.packs[0][p]), _ptr(cw.packs[1][p]), O, I, self.stream),
+                      "rg_pack_conv_wup_from_bf16")
+            cw.packs_version = cw.version
+        return cw.packs
+
+    def _conv_planes(self, up, x, cw: ConvW, N, Hl, Wl, O, I, y, want_stats):
+        """The fp32 conv on bf16 planes (rg_f32p_conv) when the shape has that kernel; returns the statistics partials (or None),
+        or False when the caller has to use the RG_F32 entry point."""
+        if not self.f32_planes or not self.lib.rg_f32p_conv_supported(up, N, Hl, Wl, O, I, self.f32_planes):
+            return False
+        wp = self._plane_packs(cw)[1 if up else 0]
+        xp = self._planes(x)
+        st = None
+        if want_stats and self.epilogue_stats and self.stat_reduce is None:
+            rows = self.lib.rg_f32p_conv_stats_rows(up, N, Hl, Wl, O, I, self.f32_planes)
+            st = self._f32(rows, 2, I if up else O) if rows > 0 else None
+        ws = self._ws(self.lib.rg_f32p_conv_workspace_bytes(up, N, Hl, Wl, O, I, self.f32_planes))
+        self._timed("conv_fwd_dgrad", 2.0 * N * Hl * Wl * O * I * 16, lambda: check(
+            self.lib.rg_f32p_conv(up, _ptr(xp), _ptr(wp), _ptr(y), N, Hl, Wl, O, I, self.f32_planes, _ptr(st), _ptr(ws), ws.numel(),
+                                  self.stream), "rg_f32p_conv"), cw=cw)
+        return st
+
     def _packs(self, cw: ConvW):
         if self.dt == RG_F32:
             return None, None
@@ -387,8 +435,12 @@ class HipOps:
         O = cw.O
         self._tap_major(cw)
         assert cw.I == I and x.is_contiguous()
-        wdn, _ = self._packs(cw)
         y = self._act(N, Hi // 2, Wi // 2, O)
+        if self.f32_planes:
+            st = self._conv_planes(0, x, cw, N, Hi // 2, Wi // 2, O, I, y, want_stats)
+            if st is not False:
+                return (y, st) if want_stats else y
+        wdn, _ = self._packs(cw)
         ns = self._defer_split(0, N, Hi // 2, Wi // 2, O, I, N * (Hi // 2) * (Wi // 2), O, defer)
         if ns:
             ws = self._ws(self.lib.rg_conv_workspace_bytes(0, N, Hi // 2, Wi // 2, O, I, self.dt, self.algo))
@@ -416,8 +468,12 @@ class HipOps:
         I = cw.I
         self._tap_major(cw)
         assert cw.O == O and x.is_contiguous()
-        _, wup = self._packs(cw)
         y = self._act(N, 2 * Ho, 2 * Wo, I)
+        if self.f32_planes and mask_act is None:
+            st = self._conv_planes(1, x, cw, N, Ho, Wo, O, I, y, want_stats)
+            if st is not False:
+                return (y, st) if want_stats else y
+        _, wup = self._packs(cw)
         ns = self._defer_split(1, N, Ho, Wo, O, I, N * 4 * Ho * Wo, I, defer) if mask_act is None else 0
         if ns:
             ws = self._ws(self.lib.rg_conv_workspace_bytes(1, N, Ho, Wo, O, I, self.dt, self.algo))
@@ -591,6 +647,23 @@ class HipOps:
         cw.pending_slabs = (cw._slab_ws, int(ns.value), int(sdt.value)) if ns.value > 1 else None
         return True
 
+    def _wgrad_planes(self, low0, high0, low1, high1, cw: ConvW, accumulate: bool, flops):
+        """fp32 storage: the weight gradient on bf16 planes of its operands (rg_f32p_wgrad); True when launched."""
+        if not self.f32_planes:
+            return False
+        N, Ho, Wo, O = low0.shape
+        I = high0.shape[3]
+        if not self.lib.rg_f32p_wgrad_supported(N, Ho, Wo, O, I, self.f32_planes):
+            return False
+        two = low1 is not None
+        pl0, ph0 = self._planes(low0), self._planes(high0)
+        pl1, ph1 = (self._planes(low1), self._planes(high1)) if two else (None, None)
+        ws = self._ws(self.lib.rg_f32p_wgrad_workspace_bytes(N, Ho, Wo, O, I, self.f32_planes, int(two)))
+        self._timed("conv_wgrad", flops, lambda: check(
+            self.lib.rg_f32p_wgrad(_ptr(pl0), _ptr(ph0), _ptr(pl1), _ptr(ph1), _ptr(cw.dw), N, Ho, Wo, O, I, self.f32_planes,
+                                   int(accumulate), _ptr(ws), ws.numel(), self.stream), "rg_f32p_wgrad"), cw=cw)
+        return True
+
     def conv_wgrad(self, low, high, cw: ConvW, accumulate: bool):
         N, Ho, Wo, O = low.shape
         I = high.shape[3]
@@ -598,6 +671,8 @@ class HipOps:
         dw = cw.dw
         assert high.shape[1] == 2 * Ho and tuple(dw.shape) == (O, 4, 4, I) and dw.is_contiguous()
         if self._wgrad_slabs(low, high, None, None, cw, accumulate, 2.0 * N * Ho * Wo * O * I * 16):
+            return
+        if self._wgrad_planes(low, high, None, None, cw, accumulate, 2.0 * N * Ho * Wo * O * I * 16):
             return
         nb = self.lib.rg_conv_wgrad_workspace_bytes(N, Ho, Wo, O, I, self.dt, self.algo)
         ws = self._ws(nb)
@@ -614,6 +689,8 @@ class HipOps:
         assert low1.shape == low0.shape and high1.shape == high0.shape
         assert tuple(dw.shape) == (O, 4, 4, I) and dw.is_contiguous()
         if self._wgrad_slabs(low0, high0, low1, high1, cw, accumulate, 4.0 * N * Ho * Wo * O * I * 16):
+            return
+        if self._wgrad_planes(low0, high0, low1, high1, cw, accumulate, 4.0 * N * Ho * Wo * O * I * 16):
             return
         nb = self.lib.rg_conv_wgrad_workspace_bytes(N, Ho, Wo, O, I, self.dt, self.algo)
         ws = self._ws(nb)
