@@ -211,6 +211,16 @@ def _env_int(name, dflt, allowed):
 
 DP_PREFIX_MODE = _env_int("RNAGAN_DP_PREFIX_BWD", 2, (0, 1, 2))
 DP_PREFIX_BWD = DP_PREFIX_MODE != 0
+# Data-parallel ROUTE of a train_op.  "prefix" (default): graph(prefix) / graph(rest) / all-reduce started and left in flight
+# under the next train_op's prefix, which reads the other network (_Runner.run_dp) -- it HIDES the collectives, and gives up what a
+# single process gains from running a train_op as one body: D(real) + D(fake) as one double batch, the penalty step's fake batch
+# out of the D-loss step's generator pass, graph boundaries (+0.6 ms of 10.4 at one rank, DESIGN).  "whole": the single
+# process's body as ONE graph (gradients onto the wire), then the all-reduce, waited for at once, then the optimizer step --
+# nothing is hidden and none of that is lost.  Which of the two is faster depends on the collectives' real duration: the first
+# run on a multi-GPU node A/Bs them (tools/dp_first_run.sh).
+DP_ROUTE = os.environ.get("RNAGAN_DP_ROUTE", "prefix")
+if DP_ROUTE not in ("prefix", "whole"):
+    DP_ROUTE = "prefix"
 
 
 def _d_prefix(generator, discriminator, real, noise, clip):
@@ -273,7 +283,9 @@ TRAINER_LOOKAHEAD = [False]     # set by Trainer when a gradient-penalty plugin 
 
 
 def _lookahead_ok():
-    return LOOKAHEAD and D_BATCHED and not D_.active()
+    # (data parallel, route "whole": the generator's pending update is applied before the D-loss step starts, so its weights are
+    # the same in the D-loss and the penalty step, as in a single process)
+    return LOOKAHEAD and D_BATCHED and (not D_.active() or DP_ROUTE == "whole")
 
 
 def _d_step_lookahead(runner, key, generator, discriminator, optimizer, clip, inputs, noise_fn, next_tensors):
@@ -341,7 +353,7 @@ class _Body:
         self.prefix, self.rest, self.prefix_reads, self.whole = prefix, rest, prefix_reads, whole
 
     def grads(self, *inputs):
-        if self.whole is not None and not D_.active():
+        if self.whole is not None and (not D_.active() or DP_ROUTE == "whole"):
             return self.whole(*inputs)
         return self.rest(self.prefix(*inputs))
 
@@ -486,7 +498,8 @@ DP_WIRE_DIRECT = os.environ.get("RNAGAN_DP_WIRE_DIRECT", "1") != "0"
 
 def _dp_wire_layers(stepped, optimizer):
     """[(ConvW, wire slice)] of the stepped module's layers whose weight gradients may bypass the fp32 gradient buffer."""
-    if not (DP_WIRE_DIRECT and SLAB_ADAM and D_.active() and FUSED_WIDEN and DP_PREFIX_MODE == 2) or D_.sync_stats():
+    if not (DP_WIRE_DIRECT and SLAB_ADAM and D_.active() and FUSED_WIDEN and (DP_PREFIX_MODE == 2 or DP_ROUTE == "whole")) \
+            or D_.sync_stats():
         return []
     if not hasattr(optimizer, "grad_wire") or getattr(optimizer, "_module", None) is not stepped:
         return []
@@ -605,6 +618,8 @@ class _Runner:
         eager all-reduce START; the all-reduce is only waited for -- and the optimizer step applied (a graph of its
         own) -- by the NEXT train_op after it has enqueued its prefix, which reads the other network: the RCCL
         transfer over xGMI overlaps with that compute.  flush() applies a trailing update."""
+        if DP_ROUTE == "whole":
+            return self._run_dp_whole(key, body, inputs, modules, stepped, optimizer)
         pend = _PENDING[0]
         if pend is not None and (not OVERLAP or pend.module is body.prefix_reads):
             flush()                                   # the prefix needs the updated weights: no overlap possible
@@ -667,6 +682,49 @@ class _Runner:
         _PENDING[0] = _Pending(stepped, optimizer, handle, fac)
         if not OVERLAP:
             flush()
+        return loss
+
+    def _run_dp_whole(self, key, body, inputs, modules, stepped, optimizer):
+        """Route "whole" (DP_ROUTE): graph(the single process's gradient body) -> all-reduce -> wait -> graph(optimizer step)."""
+        flush()
+        _, net = stepped.runtime()
+        fac = _dp_factor_g0(stepped, optimizer, inputs[0].shape[0]) if isinstance(net, E.GenNet) and inputs else None
+        wired = _dp_wire_layers(stepped, optimizer)
+        head = fac[0].w.numel() if fac is not None else 0
+        cell = {}
+
+        def grads(*a):
+            for cw, slot in wired:
+                cw.defer_slabs, cw.wire_slot, cw.pending_slabs = True, slot, None
+            if fac is not None:
+                fac[0].fuse_step, fac[0].factor_stage = True, (fac[1][2], fac[1][3])
+            try:
+                out = body.grads(*a)
+                cell["wire_table"] = _dp_wire_table(stepped, wired, head)
+                if fac is not None and fac[0].pending_wgrad != "staged":
+                    raise RuntimeError("data-parallel G step: layer 0's weight gradient was not left as factors")
+                return out
+            finally:
+                for cw, _ in wired:
+                    cw.defer_slabs, cw.wire_slot, cw.pending_slabs = False, None, None
+                if fac is not None:
+                    fac[0].fuse_step, fac[0].factor_stage, fac[0].pending_wgrad = False, None, None
+        sg = self._step_graph(key + ("whole", fac is not None, len(wired)), grads, inputs, modules, [], [])
+        if sg is not None:
+            if getattr(sg, "wire_cell", None) is None:
+                sg.wire_cell = cell
+            cell = sg.wire_cell
+            loss = sg(*inputs)
+        else:
+            loss = grads(*inputs)
+        ops, _ = stepped.runtime()
+        handle = D_.allreduce_start(stepped.flat.grad, compress=_wire_kind(ops), head=head,
+                                    table=cell.get("wire_table") if wired else None)
+        if fac is not None:
+            z_all, gy_all, z_mine, gy_mine = fac[1]
+            fac = fac + ([D_.allgather_start(z_all, z_mine), D_.allgather_start(gy_all, gy_mine)],)
+        _PENDING[0] = _Pending(stepped, optimizer, handle, fac)
+        flush()                                   # nothing to overlap with: wait and apply now
         return loss
 
     def run(self, key, fn, inputs, modules, optimizers, stepped=None):

@@ -256,6 +256,29 @@ def test_world2_prefix_with_paired_weight_gradients(tmp_path):
 
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_world2_whole_route(tmp_path, precision):
+    """RNAGAN_DP_ROUTE=whole: a train_op is the single process's gradient body as ONE graph (D(real) + D(fake) as one double
+    batch, the penalty's fake batch out of the D-loss step's generator pass), then the all-reduce, waited for at once, then the
+    optimizer step -- no prefix, nothing in flight.  Same DDP semantics as the prefix route: rank-identical parameters; fp32:
+    losses and parameters equal to the prefix route's to rounding; bf16: within the bf16 tolerances."""
+    ref = _run_world2(tmp_path, precision, tag="_prefix_" + precision)
+    got = _run_world2(tmp_path, precision, extra_env={"RNAGAN_DP_ROUTE": "whole"}, tag="_whole_" + precision)
+    for name in ("G", "D"):
+        for k in got[0][name]:
+            if "running_" not in k:
+                assert torch.equal(got[0][name][k], got[1][name][k]), ("ranks differ", name, k)
+    tol_l, tol_p = (2e-3, 2e-3) if precision == "fp32" else (6e-2, 2e-2)
+    for r in range(2):
+        for i, (a, b) in enumerate(zip(got[r]["losses"], ref[r]["losses"])):
+            assert np.isfinite(a) and abs(a - b) <= (0.35 if precision == "bf16" and i % 3 == 2 else tol_l) * (abs(b) + 0.5), (r, i, a, b)
+    for name in ("G", "D"):
+        for k, v in got[0][name].items():
+            if v.dtype.is_floating_point and "running_" not in k:
+                rel = float((v.double() - ref[0][name][k].double()).norm() / (ref[0][name][k].double().norm() + 1e-30))
+                assert rel <= tol_p, (name, k, rel)
+
+
 @pytest.mark.parametrize("world", [4, 8])
 def test_world4_and_world8_plugins_match_ddp_semantics(tmp_path, world):
     """nothing above world size 2 had ever executed.  4 and 8 rank processes share the box's GPU

@@ -86,11 +86,17 @@ if [ "$MAXG" -ge 2 ]; then
   run_bench "$MAXG" "knob_nchannels8"      NCCL_MAX_NCHANNELS=8
   run_bench "$MAXG" "knob_nchannels16"     NCCL_MAX_NCHANNELS=16
   run_bench "$MAXG" "knob_prefix_bwd1"     RNAGAN_DP_PREFIX_BWD=1      # round 3's prefix (whole backward of the real half): longer cover
+  # route "whole": the single process's train_op bodies (double batch, shared generator pass), collectives NOT hidden -- the A/B
+  # that prices the prefixes: hide the all-reduces, or keep the 0.5-0.6 ms per iteration the prefix route gives up
+  run_bench "$MAXG" "knob_route_whole"     RNAGAN_DP_ROUTE=whole
+  run_bench "$MAXG" "knob_route_whole_splitbn" RNAGAN_DP_ROUTE=whole RNAGAN_SPLIT_BN_DP=1
   echo "== one-rank overhead of the DP route (RNAGAN_FORCE_DP=1 on one GPU vs the single-process path) =="
   # (the DP route at one rank needs a process group of one: RANK / WORLD_SIZE / MASTER_* make dist.init_from_env create it)
   PORT=$((PORT + 1))
   run_bench 1 "force_dp_1rank"             RNAGAN_FORCE_DP=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=$PORT
   PORT=$((PORT + 1))
   run_bench 1 "force_dp_1rank_prefix1"     RNAGAN_FORCE_DP=1 RNAGAN_DP_PREFIX_BWD=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=$PORT
+  PORT=$((PORT + 1))
+  run_bench 1 "force_dp_1rank_whole"       RNAGAN_FORCE_DP=1 RNAGAN_DP_ROUTE=whole RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=$PORT
 fi
 echo "records under $OUT/"
