@@ -94,7 +94,8 @@ extern "C" int rg_split_planes(const float* src, void* planes_bf16, size_t n, vo
 
 extern "C" int rg_f32p_conv_supported(int up, int N, int Hlow, int Wlow, int O, int I, int products) {
   FPlan pl;
-  return fplan(up, N, Hlow, Wlow, O, I, products, &pl) ? 1 : 0;
+  if (fplan(up, N, Hlow, Wlow, O, I, products, &pl)) return 1;
+  return up && rg_mfma_conv_up_planes64_supported(N, Hlow, Wlow, O, I, products) ? 1 : 0;     // 64 output channels: rg_mfma.hip
 }
 extern "C" size_t rg_f32p_conv_workspace_bytes(int up, int N, int Hlow, int Wlow, int O, int I, int products) {
   FPlan pl;
@@ -114,6 +115,8 @@ extern "C" int rg_f32p_conv(int up, const void* x_planes, const void* w_planes, 
                             int products, float* stats_partial, void* ws, size_t ws_bytes, void* stream) {
   FPlan pl;
   RG_REQUIRE(x_planes && w_planes && y, RG_EINVAL, "f32p_conv: null");
+  if (!fplan(up, N, Hlow, Wlow, O, I, products, &pl) && up && rg_mfma_conv_up_planes64_supported(N, Hlow, Wlow, O, I, products))
+    return rg_mfma_conv_up_planes64(x_planes, w_planes, y, N, Hlow, Wlow, O, I, products, rg_stream(stream));
   RG_REQUIRE(fplan(up, N, Hlow, Wlow, O, I, products, &pl), RG_EUNSUPPORTED, "f32p_conv: shape has no planes kernel");
   hipStream_t st = rg_stream(stream);
   G2Args a2{};

@@ -253,7 +253,9 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(GArgs g) {
 // swizzled source, swizzled read).  2 stages, tile k+1 in flight during the MFMAs of tile k, one
 // barrier per k-tile.  Tile = BM x BN with 64x64 wave tiles: 128x128 (2x2 waves) or 256x64 (4x1 waves,
 // for 64-channel outputs).  SPLITK: blockIdx.z owns a k-tile range and writes fp32 partials.
-template <int MODE, int EPI, int BM, int BN, int NSTAGE, int NT, int WTM = 64>
+// NP > 0: fp32 operands as K-concatenated bf16 planes (rg_conv8f.hip has the scheme; flat k-tile -> plane pair fastest), used
+// with EPI_LINEAR (fp32 result) for the 64-column transposed conv of the fp32 mode, which the 8-wave kernel's tiles do not cover.
+template <int MODE, int EPI, int BM, int BN, int NSTAGE, int NT, int WTM = 64, int NP = 0>
 __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT == 256) ? 2 : 1) void gather_gemm_dma_kernel(G2Args a2) {
   constexpr int WN = BN / 64;                                // waves along N (WTM x 64 wave tiles)
   constexpr int TI = WTM / 32;                               // 32-row MFMA sub-tiles per wave (2 or 4)
@@ -351,14 +353,14 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
   }
 
   const int cpt = g.Cin >> 6;
-  const int nkt_all = g.taps * cpt;
+  const int nkt_all = g.taps * cpt * (NP > 0 ? NP : 1);
   const int per = (nkt_all + a2.nsplit - 1) / a2.nsplit;
   const int kt_begin = zs * per;
   const int kt_end = min(nkt_all, kt_begin + per);
   const int nkt = kt_end - kt_begin;
 
   const bool korder = a2.korder && (MODE == MODE_DOWN || MODE == MODE_UP);
-  auto issue = [&](int stage, int tap, int c0) {
+  auto issue = [&](int stage, int tap, int c0, int pp) {
     int a_delta, b_tap;
     if (MODE == MODE_DOWN && korder) tap = rg_down_tap(tap);
     if (MODE == MODE_DOWN) {
@@ -382,7 +384,11 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
       a_delta = 0;
       b_tap = 0;
     }
-    const int ao = (a_delta + c0) * 2, bo = (b_tap * g.b_tap + c0) * 2;
+    int ao = (a_delta + c0) * 2, bo = (b_tap * g.b_tap + c0) * 2;
+    if constexpr (NP > 0) {              // plane pair pp: hh hm mh hl lh mm
+      ao += ((0x120100 >> (4 * pp)) & 15) * (int)a2.a_plane;
+      bo += ((0x102010 >> (4 * pp)) & 15) * (int)a2.b_plane;
+    }
     uint4* sbase = lds + stage * STAGE_SLOTS;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
@@ -408,9 +414,15 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  int tap_n = kt_begin / cpt, cc_n = kt_begin - tap_n * cpt;
-  if (korder) { cc_n = kt_begin / g.taps; tap_n = kt_begin - cc_n * g.taps; }
+  int pp_n = 0, q_begin = kt_begin;
+  if constexpr (NP > 0) { pp_n = kt_begin % NP; q_begin = kt_begin / NP; }
+  int tap_n = q_begin / cpt, cc_n = q_begin - tap_n * cpt;
+  if (korder) { cc_n = q_begin / g.taps; tap_n = q_begin - cc_n * g.taps; }
   auto advance = [&]() {
+    if constexpr (NP > 0) {
+      if (++pp_n < NP) return;
+      pp_n = 0;
+    }
     if (korder) { if (++tap_n == g.taps) { tap_n = 0; ++cc_n; } }
     else if (++cc_n == cpt) { cc_n = 0; ++tap_n; }
   };
@@ -418,7 +430,7 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
 #pragma unroll
   for (int p = 0; p < NSTAGE - 1; ++p)
     if (p < nkt) {
-      issue(p, tap_n, cc_n << 6);
+      issue(p, tap_n, cc_n << 6, pp_n);
       advance();
     }
   int st_c = 0, st_i = NSTAGE - 1;     // stage being computed / stage to issue into
@@ -473,7 +485,7 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();      // everyone's part of tile kt landed; everyone finished reading tile kt-1
     if (kt + NSTAGE - 1 < nkt) {       // refill the stage tile kt-1 lived in
-      issue(st_i, tap_n, cc_n << 6);
+      issue(st_i, tap_n, cc_n << 6, pp_n);
       advance();
     }
     const unsigned so = (unsigned)(st_c * STAGE_SLOTS * 16);
@@ -1470,6 +1482,32 @@ int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int 
 
 bool rg_mfma_conv_up_maskbits_supported(int N, int Ho, int Wo, int O, int I) {
   return rg_option("convp", 1) && rg_convp_supported(N * Ho * Wo, I, O, Ho, Wo) && (size_t)N * Ho * Wo * O * 2 < 0x7fffff00ull;
+}
+
+// ---- fp32 mode, 64-column transposed conv on bf16 planes (rg_conv8f.hip): the 256 x 64 tile of the 2-stage kernel with an fp32
+// result; x planes [3][N][Ho][Wo][O], w planes wup[3][16][I][O], y fp32 [N][2Ho][2Wo][I]
+bool rg_mfma_conv_up_planes64_supported(int N, int Ho, int Wo, int O, int I, int products) {
+  return (products == 3 || products == 6) && I == 64 && O % 64 == 0 && rg_is_pow2(Ho) && rg_is_pow2(Wo) && N * Ho * Wo >= 256 &&
+         3ull * N * Ho * Wo * O * 2 < 0x7fffff00ull;
+}
+int rg_mfma_conv_up_planes64(const void* xp, const void* wp, float* y, int N, int Ho, int Wo, int O, int I, int products,
+                             hipStream_t st) {
+  G2Args a2{};
+  GArgs& g = a2.g;
+  g.A = (const uint16_t*)xp; g.B = (const uint16_t*)wp; g.C = y;
+  g.M = N * Ho * Wo; g.Ncols = I; g.Cin = O; g.taps = 4;
+  g.lgW = rg_ilog2(Wo); g.lgH = rg_ilog2(Ho); g.Hs = Ho; g.Ws = Wo; g.ldc = I; g.b_col = O; g.b_tap = I * O;
+  g.slope = 1.f; g.tiles_n = 1;
+  a2.a_plane = (unsigned)((size_t)g.M * O * 2); a2.b_plane = (unsigned)((size_t)I * 16 * O * 2);
+  a2.a_bytes = 3 * a2.a_plane; a2.b_bytes = 3 * a2.b_plane;
+  a2.korder = rg_option("korder", 1); a2.nsplit = 1;
+  a2.tiles_m = (g.M + 255) / 256;
+  dim3 grid((unsigned)a2.tiles_m, 4, 1);
+  a2.xcd_swizzle = (rg_option("xcd", 1) && grid.x % 8 == 0 && grid.x >= 16) ? 1 : 0;
+  if (products == 6) hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE_UP, EPI_LINEAR, 256, 64, 2, 256, 64, 6>), grid, dim3(256), 0, st, a2);
+  else hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE_UP, EPI_LINEAR, 256, 64, 2, 256, 64, 3>), grid, dim3(256), 0, st, a2);
+  RG_LAUNCH_CHECK("conv_up_planes64");
+  return RG_OK;
 }
 
 // ---- fp8 e4m3 operands (generator-only inference, BASELINE configs[4]): conv8_kernel<.., EB = 1> only, no split-K

@@ -391,7 +391,6 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(W8Args g) {
 }
 
 
-#ifndef RG_WGRAD8_KERNEL_ONLY
 // ---------------------------------------------------------------------------------------------------------------------------
 // The same pipeline for the layers with 128 low-side channels (O = 128: D.1 and the generator's 128 -> 64 block), which the
 // 256 x 256 tile cannot cover: block tile 128 (o) x 512 (tap, i) -- 8 waves of 64 (o) x 4 x 32 columns, FIVE 16 KB half-tiles
@@ -406,6 +405,7 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(W8Args g) {
 //   P3: read B3(u), B0(u+1)   issue B1(u+2)            MFMA A0 x B3
 // Issue order per k-tile is B0 A0 B1 B2 B3; behind the half-tile the NEXT phase reads there are six younger ones (P1: seven),
 // so vmcnt(12) is the wait of every phase (checked by simulation of the issue / read sequence).
+template <int NP = 0>      // NP > 0: K-concatenated bf16 planes of fp32 operands, as wgrad8_kernel's NP
 __global__ __launch_bounds__(512, 2) void wgrad8n_kernel(W8Args g) {
   constexpr int HT = 64 * 256;                     // bytes per half-tile: 64 pixels x 128 channels bf16
   constexpr int STAGE = 5 * HT;                    // [B0][B1][B2][B3][A0]
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(512, 2) void wgrad8n_kernel(W8Args g) {
   const int tile_o = tid / g.tiles_c, tile_c = tid - tile_o * g.tiles_c;
   const int o0 = tile_o * 128, c0 = tile_c * 512;
   const int Ktot = g.Kseg[0] + g.Kseg[1];
-  const int nkt_all = (Ktot + 63) >> 6;
+  const int nkt_all = ((Ktot + 63) >> 6) * (NP > 0 ? NP : 1);
   const int kt_begin = zs * g.kt_per_split;
   const int nkt = min(nkt_all, kt_begin + g.kt_per_split) - kt_begin;     // host: > 0 and even
   constexpr unsigned OOB = 0x80000000u;
@@ -456,8 +456,21 @@ __global__ __launch_bounds__(512, 2) void wgrad8n_kernel(W8Args g) {
 
   int px_base[2], px_h[2], px_w[2];
   bool px_ok[2];
+  int px_plane = 0;
+  auto flat_tile = [&](int ktr, int& lo_off, int& hi_off) -> int {
+    int q = kt_begin + ktr;
+    lo_off = 0; hi_off = 0;
+    if constexpr (NP > 0) {
+      const int pp = q % NP;
+      q = q / NP;
+      lo_off = ((0x120100 >> (4 * pp)) & 15) * (int)g.low_plane;
+      hi_off = ((0x102010 >> (4 * pp)) & 15) * (int)g.high_plane;
+    }
+    return q * 64;
+  };
   auto decode_pixels = [&](int ktr) {
-    const int p0 = (kt_begin + ktr) * 64;
+    int lo_off;
+    const int p0 = flat_tile(ktr, lo_off, px_plane);
     const bool seg1 = p0 >= g.Kseg[0];
     const int pb = seg1 ? p0 - g.Kseg[0] : p0;
     const int kend = (ktr < nkt) ? (seg1 ? g.Kseg[1] : g.Kseg[0]) : 0;
@@ -473,12 +486,13 @@ __global__ __launch_bounds__(512, 2) void wgrad8n_kernel(W8Args g) {
   };
   auto issue_a = [&](auto S, int ktr) {
     constexpr int s = decltype(S)::value;
-    const int p0 = (kt_begin + ktr) * 64;
+    int lo_off, hi_off;
+    const int p0 = flat_tile(ktr, lo_off, hi_off);
     const bool seg1 = p0 >= g.Kseg[0];
     const int pb = seg1 ? p0 - g.Kseg[0] : p0;
     const int kend = (ktr < nkt) ? (seg1 ? g.Kseg[1] : g.Kseg[0]) : 0;
     const __amdgpu_buffer_rsrc_t rs = seg1 ? rsL1 : rsL0;
-    const int so = pb * g.O * 2;
+    const int so = pb * g.O * 2 + lo_off;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const bool ok = pb + jj * 32 + lrow < kend;
@@ -491,13 +505,14 @@ __global__ __launch_bounds__(512, 2) void wgrad8n_kernel(W8Args g) {
   auto issue_b = [&](auto S, auto H, int ktr) {
     constexpr int s = decltype(S)::value, h = decltype(H)::value;
     if (h == 0) decode_pixels(ktr);
-    const bool seg1 = (kt_begin + ktr) * 64 >= g.Kseg[0];
+    int lo_off, hi_off;
+    const bool seg1 = flat_tile(ktr, lo_off, hi_off) >= g.Kseg[0];
     const __amdgpu_buffer_rsrc_t rs = seg1 ? rsH1 : rsH0;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int hi = px_h[jj] + b_kh[h], wi = px_w[jj] + b_kw[h];
       const bool v = px_ok[jj] && (unsigned)hi < (unsigned)g.Hh && (unsigned)wi < (unsigned)g.Wh;
-      const unsigned vo = v ? (unsigned)(((px_base[jj] + hi) * g.Wh + wi) * g.I * 2 + b_ci[h]) : OOB;
+      const unsigned vo = v ? (unsigned)(((px_base[jj] + hi) * g.Wh + wi) * g.I * 2 + b_ci[h] + px_plane) : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vptr_t)(ldsb + s * STAGE + OFF_B + h * HT + jj * 8192 + wave * 1024),
                                                16, vo, 0, 0, 0);
     }
@@ -673,8 +688,6 @@ __global__ __launch_bounds__(512, 2) void wgrad8n_kernel(W8Args g) {
   }
 }
 
-#endif  // RG_WGRAD8_KERNEL_ONLY
-
 }  // namespace
 
 #ifndef RG_WGRAD8_KERNEL_ONLY
@@ -729,7 +742,7 @@ int rg_wgrad8n_launch(const void* low0, const void* high0, const void* low1, con
   g.tiles_o = O / 128; g.tiles_c = 16 * I / 512; g.nsplit = nsplit; g.kt_per_split = kt_per_split;
   g.accumulate = nsplit == 1 ? accumulate : 0;
   g.slab16 = nsplit > 1 ? slab16 : 0;
-  hipLaunchKernelGGL(wgrad8n_kernel, dim3((unsigned)(g.tiles_o * g.tiles_c * nsplit)), dim3(512), 0, st, g);
+  hipLaunchKernelGGL(wgrad8n_kernel<0>, dim3((unsigned)(g.tiles_o * g.tiles_c * nsplit)), dim3(512), 0, st, g);
   RG_LAUNCH_CHECK("conv_wgrad(mfma, ping-pong, 128 x 512)");
   return RG_OK;
 }

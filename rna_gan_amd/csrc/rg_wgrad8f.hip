@@ -6,18 +6,21 @@
 
 namespace {
 
-struct WPlan { int nsplit, per; };
+struct WPlan { int nsplit, per; bool narrow; };      // narrow: the 128 x 512 tile (O = 128: wgrad8n_kernel)
 
 bool wplan(int N, int Ho, int Wo, int O, int I, int products, WPlan* pl) {
   const long long K = (long long)N * Ho * Wo;
   if (!(products == 3 || products == 6) || N <= 0 || !rg_is_pow2(Ho) || !rg_is_pow2(Wo)) return false;
-  if (!(O % 256 == 0 && (16 * I) % 256 == 0 && I % 8 == 0 && K >= 256 && K % 64 == 0)) return false;
+  if (!(I % 8 == 0 && K >= 256 && K % 64 == 0)) return false;
+  if (O % 256 == 0 && (16 * I) % 256 == 0) pl->narrow = false;
+  else if (O % 128 == 0 && (16 * I) % 512 == 0) pl->narrow = true;
+  else return false;
   if (3ull * K * O * 2 >= 0x7fffff00ull || 3ull * K * 4 * I * 2 >= 0x7fffff00ull) return false;
   return true;
 }
 // split-K over the flat (plane pair, pixel tile) index: one block per CU where the tiles allow it
 void wsplit(long long Kflat_tiles, int O, int I, WPlan* pl) {
-  const int tiles = (O / 256) * (16 * I / 256);
+  const int tiles = pl->narrow ? (O / 128) * (16 * I / 512) : (O / 256) * (16 * I / 256);
   const int target = rg_option("wgrad8_blocks", 256);
   int ns = (target + tiles - 1) / tiles;
   if (ns < 1) ns = 1;
@@ -62,11 +65,17 @@ extern "C" int rg_f32p_wgrad(const void* low0, const void* high0, const void* lo
   g.Kseg[0] = Kseg; g.Kseg[1] = two ? Kseg : 0;
   g.out = pl.nsplit > 1 ? (float*)ws : dw; g.O = O; g.I = I;
   g.lgWo = rg_ilog2(Wo); g.lgHo = rg_ilog2(Ho); g.Hh = 2 * Ho; g.Wh = 2 * Wo;
-  g.tiles_o = O / 256; g.tiles_c = 16 * I / 256; g.nsplit = pl.nsplit; g.kt_per_split = pl.per;
+  g.tiles_o = pl.narrow ? O / 128 : O / 256; g.tiles_c = pl.narrow ? 16 * I / 512 : 16 * I / 256;
+  g.nsplit = pl.nsplit; g.kt_per_split = pl.per;
   g.accumulate = pl.nsplit == 1 ? accumulate : 0;
   const dim3 grid((unsigned)(g.tiles_o * g.tiles_c * pl.nsplit));
-  if (products == 6) hipLaunchKernelGGL((wgrad8_kernel<false, 6>), grid, dim3(512), 0, st, g);
-  else hipLaunchKernelGGL((wgrad8_kernel<false, 3>), grid, dim3(512), 0, st, g);
+  if (pl.narrow) {
+    if (products == 6) hipLaunchKernelGGL((wgrad8n_kernel<6>), grid, dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((wgrad8n_kernel<3>), grid, dim3(512), 0, st, g);
+  } else {
+    if (products == 6) hipLaunchKernelGGL((wgrad8_kernel<false, 6>), grid, dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((wgrad8_kernel<false, 3>), grid, dim3(512), 0, st, g);
+  }
   RG_LAUNCH_CHECK("f32p_wgrad");
   if (pl.nsplit > 1) return rg_reduce_slabs((const float*)ws, dw, (size_t)O * 16 * I, pl.nsplit, accumulate, 0, 0, st);
   return RG_OK;

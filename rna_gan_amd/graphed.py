@@ -63,6 +63,7 @@ class StepGraph:
         self.calls = 0
         self.failed = False
         self._out_spec = None          # (shape, dtype, device) of every tensor the last eager run returned
+        self._rebuilt = {}             # fp32-storage modules: {id(module): [ConvW whose operand images the captured function rebuilds]}
 
     STABLE_NUMEL = 4096                # outputs up to this size get a home outside the graph pool
 
@@ -110,6 +111,8 @@ class StepGraph:
                 bufs = [torch.empty(sp[0], dtype=sp[1], device=sp[2])
                         if sp is not None and math.prod(sp[0]) <= self.STABLE_NUMEL else None
                         for sp in (self._out_spec or [])]
+                # fp32-storage modules: the operand images (bf16 planes) this function rebuilds, by their version stamps
+                before = {id(m): m.pack_versions() for m in self.modules if getattr(m, "precision", None) == "fp32"}
                 g = torch.cuda.CUDAGraph()
                 # thread_local: other threads (RCCL's watchdog polls events) may touch the HIP runtime while
                 # this thread captures; the default global mode turns that into a capture error / hang
@@ -117,6 +120,7 @@ class StepGraph:
                     out = self._run()
                     self.static_out = self._stable(out, bufs) if len(bufs) == len(self._flat(out)) else out
                 self.graph = g
+                self._rebuilt = {mid: [cw for cw, pv in snap.items() if cw.packs_version != pv] for mid, snap in before.items()}
                 if os.environ.get("RNAGAN_GRAPH_DEBUG"):
                     print("rna_gan_amd: captured graph #%d for %s" % (len(_captured), getattr(self.fn, "__name__", "?")),
                           flush=True)
@@ -133,7 +137,7 @@ class StepGraph:
         for o in self.optimizers:
             o.note_replayed()
         for m in self.modules:
-            m.mark_packs_fresh()
+            m.mark_packs_fresh(only=self._rebuilt.get(id(m)))
         for m in self.stepped:
             m.weights_changed(by_optimizer=True)      # the replayed fused Adam refreshed the bf16 shadows too
         return self.static_out

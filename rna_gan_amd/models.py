@@ -181,13 +181,21 @@ class _HipModule(nn.Module):
                 st = max(st, 2 if (cw.shadow is not None and cw.shadow_version != cw.version) else 1)
         return st
 
-    def mark_packs_fresh(self):
-        """A captured graph that rebuilt the packs was replayed: bring the Python-side counters in line."""
+    def mark_packs_fresh(self, only=None):
+        """A captured graph that rebuilt the packs was replayed: bring the Python-side counters in line.
+        only (fp32 storage): the layers whose operand images THAT graph rebuilds (StepGraph records them at capture).  With
+        16-bit storage every train_op uses -- and rebuilds -- every layer's images; with fp32 storage a layer runs on bf16
+        planes only at the shapes that have that kernel, e.g. the double batch of the D-loss step but not the single batch of the
+        other two train_ops, so a replayed graph says nothing about the layers it did not rebuild."""
         if self._rt_net is not None:
-            for cw in self._rt_net.convs():
+            for cw in (self._rt_net.convs() if only is None else only):
                 cw.packs_version = cw.version
                 if cw.shadow is not None:
                     cw.shadow_version = cw.version
+
+    def pack_versions(self):
+        """{conv handle: packs_version} (StepGraph: which images a captured function rebuilt)."""
+        return {} if self._rt_net is None else {cw: cw.packs_version for cw in self._rt_net.convs()}
 
     def load_state_dict(self, *a, **k):
         D_.flush()

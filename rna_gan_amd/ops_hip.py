@@ -469,9 +469,12 @@ class HipOps:
         self._tap_major(cw)
         assert cw.O == O and x.is_contiguous()
         y = self._act(N, 2 * Ho, 2 * Wo, I)
-        if self.f32_planes and mask_act is None:
-            st = self._conv_planes(1, x, cw, N, Ho, Wo, O, I, y, want_stats)
+        if self.f32_planes:
+            st = self._conv_planes(1, x, cw, N, Ho, Wo, O, I, y, want_stats and mask_act is None)
             if st is not False:
+                if mask_act is not None:          # the consumer's LeakyReLU backward as one elementwise pass behind the conv
+                    assert mask_act.shape == y.shape and mask_act.dtype == y.dtype
+                    y = self.lrelu_bwd(y, mask_act, slope)
                 return (y, st) if want_stats else y
         _, wup = self._packs(cw)
         ns = self._defer_split(1, N, Ho, Wo, O, I, N * 4 * Ho * Wo, I, defer) if mask_act is None else 0

@@ -63,10 +63,11 @@ def test_conv_down_up_on_planes(products, tol, N, H, I, O, monkeypatch):
 
 
 @pytest.mark.parametrize("products,tol", [(6, 2e-6), (3, 6e-5)])
-def test_weight_gradient_on_planes_one_and_two_segments(products, tol, monkeypatch):
+@pytest.mark.parametrize("N,H,I,O", [(8, 32, 128, 256),      # 256 x 256 tiles (wgrad8_kernel)
+                                      (8, 64, 64, 128)])      # 128 x 512 tiles (wgrad8n_kernel: the layers with 128 low-side channels)
+def test_weight_gradient_on_planes_one_and_two_segments(products, tol, N, H, I, O, monkeypatch):
     ops = _ops(products, monkeypatch)
     g = torch.Generator().manual_seed(9)
-    N, H, I, O = 8, 32, 128, 256
     x0, x1 = torch.randn(N, H, H, I, generator=g).cuda(), torch.randn(N, H, H, I, generator=g).cuda()
     g0, g1 = torch.randn(N, H // 2, H // 2, O, generator=g).cuda(), torch.randn(N, H // 2, H // 2, O, generator=g).cuda()
     wt = torch.zeros(O, 4, 4, I).cuda()

@@ -666,7 +666,7 @@ def test_unselected_inputs_loss_agreement_statistics():
         real = R.synthetic_images(n, in_size, seed=seed)
         noises = [R.synthetic_normal(n, enc, seed=100 * seed + 2 + j) for j in range(3)]
         ref = R.train_iteration(Go, Do, ogo, odo, real, noises, 0.4)
-        for precision in precisions:
+        for precision in ("fp32", "bf16"):
             G = P.DCGANGenerator(enc, in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.Tanh())
             D = P.DCGANDiscriminator(in_size, 3, step, nonlinearity=nn.LeakyReLU(0.2), last_nonlinearity=nn.LeakyReLU(0.2))
             G.load_state_dict(G0.state_dict()); D.load_state_dict(D0.state_dict())
