@@ -931,117 +931,109 @@ def extra_fp16_step(args, device, info, steps=10, warm=14):
     return res
 
 
-def extra_fp32_step(args, device, info, steps=4, warm=10):
-    """The fp32 parity mode (--precision fp32: the reference's own arithmetic, src/betaVAE.py:184,223,230-236; the anchor of
-    the tight-tolerance parity tests) on the same workload.  Convolutions / dense layers run on the f32 matrix cores
-    (gemm_mfma32s_kernel / gemm_mfma32_kernel: v_mfma_f32_32x32x2_f32 with structured operands / behind the generic operand functors, rg_generic.hip); everything else is the
-    fp32 form of the bandwidth-bound kernels.  `roofline_fp32`: algorithmic conv FLOPs of the conv + weight-gradient launches
-    of one instrumented eager iteration / their summed HIP-event durations, against the 157.3 TFLOP/s fp32 matrix peak."""
-    from rna_gan_amd import graphed
+def _fp32_variant(args, device, info, planes, f32mma, steps, warm, want_roofline):
+    """One timed fp32 workload: planes = RNAGAN_F32_PLANES (6 / 3 bf16 products per fp32 product on planes split once per tensor;
+    0 = the per-tile kernels of rg_generic.hip under option f32mma)."""
+    from rna_gan_amd import graphed, _abi
     from rna_gan_amd import losses as PL
     N = args.batch
-    G, Dm, og, od, (lg, ld, lp) = build(device, "fp32", N, 19198, args.seed)
-    h = info["handles"]
-    gen = torch.Generator(device="cpu").manual_seed(args.seed + 11)
-
-    def it():
-        PL.new_batch()
-        us = [torch.empty(N, 2048).uniform_(-0.3, 0.3, generator=gen).to(device) for _ in range(3)]
-        eps = torch.empty(1).uniform_(0.0, 1.0, generator=gen).to(device)
-        return [lg.step(G, Dm, og, h["rna"], us[0]), ld.step(G, Dm, od, h["real"], h["rna"], us[1], next_u=us[2]),
-                lp.step(G, Dm, od, h["real"], h["rna"], us[2], eps)]
-    for _ in range(warm):           # graph capture: two eager runs per launch-sequence variant, replay from the third on
-        it()                        # (6 were not always enough: a capture inside the timed steps read 83 instead of 65 ms)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        ls = it()
-    torch.cuda.synchronize(device)
-    dt = (time.perf_counter() - t0) / steps
-    res = {"ms_per_step": round(dt * 1e3, 2), "imgs_per_sec": round(N / dt, 1), "steps": steps, "hip_graphs": bool(graphed.ENABLED),
-           "losses": [round(float(l.item()), 5) for l in ls],
-           "kernels": "fp32 activations; convolutions / dense layers on the matrix cores: the 128 x 128-tile launches as six "
-                      "v_mfma_f32_32x32x16_bf16 per k-tile on exact three-way bf16 splits of both fp32 operands (f32mma = 2), the "
-                      "others on v_mfma_f32_32x32x2_f32"}
-    # per-launch events over one eager iteration (same method as the bf16 roofline)
-    ops, _ = G.runtime()
-    was = graphed.ENABLED
-    graphed.ENABLED = False
+    lib = _abi.load()
+    old_env = os.environ.get("RNAGAN_F32_PLANES")
+    os.environ["RNAGAN_F32_PLANES"] = str(planes)
+    if f32mma is not None:
+        _abi.check(lib.rg_set_option(b"f32mma", f32mma), "rg_set_option")
     try:
-        it(); torch.cuda.synchronize(device)            # eager warm-up (workspace growth)
-        stream = torch.cuda.current_stream(device)
-        cal = []
-        for _ in range(16):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(stream); b.record(stream)
-            cal.append((a, b))
-        ops.timing = []
-        it()
-        torch.cuda.synchronize(device)
-        overhead = sorted(a.elapsed_time(b) for a, b in cal)[len(cal) // 2]
-        fam = {}
-        for key, flops, e0, e1, _owner in ops.timing:
-            f = fam.setdefault(key, [0, 0.0, 0.0])
-            f[0] += 1; f[1] += flops; f[2] += max(e0.elapsed_time(e1) - overhead, 0.0)
-    finally:
-        ops.timing = None
-        graphed.ENABLED = was
-    mm = [v for k, v in fam.items() if k in ("conv_fwd_dgrad", "conv_wgrad")]
-    if mm:
-        fl, ms = sum(v[1] for v in mm), sum(v[2] for v in mm)
-        # ceiling of what executes: with f32mma = 2 (the default) the large-tile launches -- nearly all of these FLOPs -- form each fp32
-        # product from SIX v_mfma_f32_32x32x16_bf16 products, so the matrix pipe allows 2500 / 6 TFLOP/s of fp32-equivalent work; the
-        # f32 instruction's own peak (157.3) is kept beside it
-        ach = fl / (ms * 1e-3) / 1e12
-        res["roofline_fp32"] = {"bound": "mfma", "kernel": "gemm_bf16x3s_kernel (large tiles: six bf16 matrix-core products per fp32 product) / gemm_mfma32s_kernel "
-                                          "(v_mfma_f32_32x32x2_f32) -- conv fwd / dgrad / tangent + weight gradients, fp32 operands and accumulation",
-                                "achieved": round(ach, 1), "peak": round(MFMA_BF16_PEAK_TFLOPS / 6.0, 1), "unit": "TFLOP/s",
-                                "peak_what": "bf16 matrix peak / 6 products per fp32 product (the executing unit's ceiling for the bf16x3 launches)",
-                                "frac": round(ach / (MFMA_BF16_PEAK_TFLOPS / 6.0), 4),
-                                "peak_f32_instruction": F32_MATRIX_PEAK_TFLOPS,
-                                "frac_of_f32_instruction_peak": round(ach / F32_MATRIX_PEAK_TFLOPS, 4),
-                                "launches": sum(v[0] for v in mm), "ms_total": round(ms, 2),
-                                "share_of_step": round(ms / (dt * 1e3), 3),
-                                "families": {k: {"launches": v[0], "ms": round(v[2], 2),
-                                                 "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 1) if v[2] > 0 else None}
-                                             for k, v in fam.items()}}
-    PL.new_batch()
-    del G, Dm, og, od, lg, ld, lp, it
-    torch.cuda.empty_cache()
-    # the same mode with the f32 matrix instruction for EVERY launch (option f32mma = 1, the default until the end of round 5; the
-    # default, 2, forms each fp32 product of the 128 x 128-tile launches as six bf16 matrix-core products of exact three-way bf16
-    # splits, gemm_bf16x3s_kernel): a fresh workload, so that its graphs capture it
-    try:
-        from rna_gan_amd import _abi
-        lib = _abi.load()
-        _abi.check(lib.rg_set_option(b"f32mma", 1), "rg_set_option")
-        try:
-            G, Dm, og, od, (lg, ld, lp) = build(device, "fp32", N, 19198, args.seed)
+        G, Dm, og, od, (lg, ld, lp) = build(device, "fp32", N, 19198, args.seed)
+        h = info["handles"]
+        gen = torch.Generator(device="cpu").manual_seed(args.seed + 11)
 
-            def it2():
-                PL.new_batch()
-                us = [torch.empty(N, 2048).uniform_(-0.3, 0.3, generator=gen).to(device) for _ in range(3)]
-                eps = torch.empty(1).uniform_(0.0, 1.0, generator=gen).to(device)
-                return [lg.step(G, Dm, og, h["rna"], us[0]), ld.step(G, Dm, od, h["real"], h["rna"], us[1], next_u=us[2]),
-                        lp.step(G, Dm, od, h["real"], h["rna"], us[2], eps)]
-            for _ in range(warm):
-                it2()
-            torch.cuda.synchronize(device)
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                ls = it2()
-            torch.cuda.synchronize(device)
-            dt2 = (time.perf_counter() - t0) / steps
-            res["f32mma1"] = {"ms_per_step": round(dt2 * 1e3, 2), "imgs_per_sec": round(N / dt2, 1),
-                              "losses": [round(float(l.item()), 5) for l in ls],
-                              "kernels": "RNAGAN_F32MMA=1: v_mfma_f32_32x32x2_f32 for every conv / dense launch"}
+        def it():
             PL.new_batch()
-            del G, Dm, og, od, lg, ld, lp, it2
-        finally:
+            us = [torch.empty(N, 2048).uniform_(-0.3, 0.3, generator=gen).to(device) for _ in range(3)]
+            eps = torch.empty(1).uniform_(0.0, 1.0, generator=gen).to(device)
+            return [lg.step(G, Dm, og, h["rna"], us[0]), ld.step(G, Dm, od, h["real"], h["rna"], us[1], next_u=us[2]),
+                    lp.step(G, Dm, od, h["real"], h["rna"], us[2], eps)]
+        for _ in range(warm):           # graph capture: two eager runs per launch-sequence variant, replay from the third on
+            it()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ls = it()
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / steps
+        res = {"ms_per_step": round(dt * 1e3, 2), "imgs_per_sec": round(N / dt, 1), "steps": steps,
+               "hip_graphs": bool(graphed.ENABLED), "losses": [round(float(l.item()), 5) for l in ls]}
+        if want_roofline:
+            # per-launch events over one eager iteration (same method as the bf16 roofline)
+            ops, _ = G.runtime()
+            was = graphed.ENABLED
+            graphed.ENABLED = False
+            try:
+                it(); torch.cuda.synchronize(device)            # eager warm-up (workspace growth)
+                stream = torch.cuda.current_stream(device)
+                cal = []
+                for _ in range(16):
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(stream); b.record(stream)
+                    cal.append((a, b))
+                ops.timing = []
+                it()
+                torch.cuda.synchronize(device)
+                overhead = sorted(a.elapsed_time(b) for a, b in cal)[len(cal) // 2]
+                fam = {}
+                for key, flops, e0, e1, _owner in ops.timing:
+                    f = fam.setdefault(key, [0, 0.0, 0.0])
+                    f[0] += 1; f[1] += flops; f[2] += max(e0.elapsed_time(e1) - overhead, 0.0)
+            finally:
+                ops.timing = None
+                graphed.ENABLED = was
+            mm = [v for k, v in fam.items() if k in ("conv_fwd_dgrad", "conv_wgrad")]
+            if mm:
+                fl, ms = sum(v[1] for v in mm), sum(v[2] for v in mm)
+                ach = fl / (ms * 1e-3) / 1e12
+                prod = planes if planes else 6
+                res["roofline_fp32"] = {
+                    "bound": "mfma", "kernel": "conv8_kernel / wgrad8_kernel over K-concatenated bf16 planes (rg_conv8f.hip, rg_wgrad8f.hip): conv fwd / "
+                                               "dgrad / tangent + weight gradients, fp32 operands, accumulation and results",
+                    "achieved": round(ach, 1), "peak": round(MFMA_BF16_PEAK_TFLOPS / prod, 1), "unit": "TFLOP/s",
+                    "peak_what": "nominal bf16 matrix peak / %d bf16 products per fp32 product (the executing unit's ceiling)" % prod,
+                    "frac": round(ach / (MFMA_BF16_PEAK_TFLOPS / prod), 4),
+                    "bf16_equivalent_tflops": round(ach * prod, 1),
+                    "peak_f32_instruction": F32_MATRIX_PEAK_TFLOPS, "frac_of_f32_instruction_peak": round(ach / F32_MATRIX_PEAK_TFLOPS, 4),
+                    "launches": sum(v[0] for v in mm), "ms_total": round(ms, 2), "share_of_step": round(ms / (dt * 1e3), 3),
+                    "families": {k: {"launches": v[0], "ms": round(v[2], 2),
+                                     "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 1) if v[2] > 0 else None} for k, v in fam.items()}}
+        PL.new_batch()
+        del G, Dm, og, od, lg, ld, lp, it
+        return res
+    finally:
+        if f32mma is not None:
             lib.rg_set_option(b"f32mma", -1)
-            torch.cuda.empty_cache()
-    except Exception as e:                                   # an extra never takes the headline down
-        res["f32mma1"] = {"error": repr(e)[:200]}
+        if old_env is None:
+            os.environ.pop("RNAGAN_F32_PLANES", None)
+        else:
+            os.environ["RNAGAN_F32_PLANES"] = old_env
+        torch.cuda.empty_cache()
+
+
+def extra_fp32_step(args, device, info, steps=4, warm=10):
+    """The fp32 parity mode (--precision fp32: the reference's own arithmetic, src/betaVAE.py:184,223,230-236; the anchor of the
+    tight-tolerance parity tests) on the same workload.  Default since round 6: fp32 tensors are split ONCE into three bf16
+    planes (v = h + m + l exactly) and the stride-2 convs / transposed convs / weight gradients run the bf16 step's 8-wave
+    kernels over K-concatenated plane pairs with fp32 accumulation -- 6 bf16 products per fp32 product (fp32-grade: the tolerance
+    statistics of the f32 instruction).  `planes3`: the 3-product tier (2^-16 per product; its own tolerance table in
+    profiles/).  `per_tile_kernels`: round 5's default (operands split per tile inside gemm_bf16x3s_kernel)."""
+    res = _fp32_variant(args, device, info, 6, None, steps, warm, True)
+    res["kernels"] = ("fp32 activations; 4 x 4 convs / weight gradients: conv8_kernel / wgrad8_kernel over bf16 planes split once per tensor, "
+                      "6 bf16 matrix-core products per fp32 product (RNAGAN_F32_PLANES=6, the default); G.0, image-side layers, head: "
+                      "f32-instruction kernels")
+    for name, planes, f32mma in (("planes3", 3, None), ("per_tile_kernels", 0, 2)):
+        try:
+            res[name] = _fp32_variant(args, device, info, planes, f32mma, steps, warm, name == "planes3")
+        except Exception as e:                                   # an extra never takes the headline down
+            res[name] = {"error": repr(e)[:200]}
+    res["planes3"]["kernels"] = "RNAGAN_F32_PLANES=3: three bf16 products per fp32 product (hh + hm + mh)"
+    res["per_tile_kernels"]["kernels"] = "RNAGAN_F32_PLANES=0, f32mma=2: round 5's default (three-way split per tile inside gemm_bf16x3s_kernel)"
     return res
 
 

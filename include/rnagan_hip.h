@@ -679,7 +679,11 @@ int rg_f32p_conv_supported(int up, int N, int Hlow, int Wlow, int O, int I, int 
 size_t rg_f32p_conv_workspace_bytes(int up, int N, int Hlow, int Wlow, int O, int I, int products);
 int rg_f32p_conv_stats_rows(int up, int N, int Hlow, int Wlow, int O, int I, int products);
 int rg_f32p_conv(int up, const void* x_planes, const void* w_planes, float* y, int N, int Hlow, int Wlow, int O, int I,
-                 int products, float* stats_partial, void* ws, size_t ws_bytes, void* stream);
+                 int products, float* stats_partial, const float* mask_f32, float mask_slope, void* ws, size_t ws_bytes,
+                 void* stream);
+/* mask_f32 (optional, y's shape): y *= (mask > 0 ? 1 : mask_slope), the consumer's LeakyReLU backward as in rg_conv_up -- only
+ * where rg_f32p_conv_mask_supported says 1 (the 64-column transposed conv); elsewhere the caller runs rg_lrelu_bwd behind it. */
+int rg_f32p_conv_mask_supported(int up, int N, int Hlow, int Wlow, int O, int I, int products);
 int rg_f32p_wgrad_supported(int N, int Ho, int Wo, int O, int I, int products);
 size_t rg_f32p_wgrad_workspace_bytes(int N, int Ho, int Wo, int O, int I, int products, int two);
 int rg_f32p_wgrad(const void* low0, const void* high0, const void* low1, const void* high1, float* dw, int N, int Ho, int Wo,

@@ -167,7 +167,8 @@ PROTOTYPES = {
     "rg_f32p_conv_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "rg_f32p_conv_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),
     "rg_f32p_conv_stats_rows": (_i, [_i, _i, _i, _i, _i, _i, _i]),
-    "rg_f32p_conv": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _z, _p]),
+    "rg_f32p_conv": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _f, _p, _z, _p]),
+    "rg_f32p_conv_mask_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "rg_f32p_wgrad_supported": (_i, [_i, _i, _i, _i, _i, _i]),
     "rg_f32p_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),
     "rg_f32p_wgrad": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),

@@ -111,12 +111,21 @@ extern "C" int rg_f32p_conv_stats_rows(int up, int N, int Hlow, int Wlow, int O,
   return (up ? 4 : 1) * ((M + pl.bm - 1) / pl.bm) * (pl.bm / 128);
 }
 
+// 1 when rg_f32p_conv applies mask_f32 / mask_slope itself for this shape (the 64-column transposed conv); 0: the caller runs
+// rg_lrelu_bwd behind the conv
+extern "C" int rg_f32p_conv_mask_supported(int up, int N, int Hlow, int Wlow, int O, int I, int products) {
+  FPlan pl;
+  return up && !fplan(up, N, Hlow, Wlow, O, I, products, &pl) && rg_mfma_conv_up_planes64_supported(N, Hlow, Wlow, O, I, products);
+}
+
 extern "C" int rg_f32p_conv(int up, const void* x_planes, const void* w_planes, float* y, int N, int Hlow, int Wlow, int O, int I,
-                            int products, float* stats_partial, void* ws, size_t ws_bytes, void* stream) {
+                            int products, float* stats_partial, const float* mask_f32, float mask_slope, void* ws, size_t ws_bytes,
+                            void* stream) {
   FPlan pl;
   RG_REQUIRE(x_planes && w_planes && y, RG_EINVAL, "f32p_conv: null");
   if (!fplan(up, N, Hlow, Wlow, O, I, products, &pl) && up && rg_mfma_conv_up_planes64_supported(N, Hlow, Wlow, O, I, products))
-    return rg_mfma_conv_up_planes64(x_planes, w_planes, y, N, Hlow, Wlow, O, I, products, rg_stream(stream));
+    return rg_mfma_conv_up_planes64(x_planes, w_planes, y, N, Hlow, Wlow, O, I, products, rg_stream(stream), mask_f32, mask_slope);
+  RG_REQUIRE(!mask_f32, RG_EUNSUPPORTED, "f32p_conv: a fused mask only with the 64-column transposed conv (rg_f32p_conv_mask_supported)");
   RG_REQUIRE(fplan(up, N, Hlow, Wlow, O, I, products, &pl), RG_EUNSUPPORTED, "f32p_conv: shape has no planes kernel");
   hipStream_t st = rg_stream(stream);
   G2Args a2{};

@@ -49,6 +49,8 @@ struct GArgs {
   int bwd_half_m;         // > 0: two batch groups -- rows m >= bwd_half_m take mean / invstd + Ncols (second group)
   int defer_reduce;       // split-K launches: leave the fp32 slabs in the workspace, do not launch the slab reduction (the consumer
                           // reduces them itself: rg_splitbn.hip fuses the reduction into the BatchNorm pass that follows)
+  const float* maskf;     // EPI_LINEAR (fp32 result), optional: fp32 activation with the output's shape; out *= (maskf > 0 ? 1 : mslope)
+                          // (the fp32 mode's 64-column transposed conv on bf16 planes: the consumer's LeakyReLU backward)
   int affine;             // EPI_BF16, bf16 output without split-K: out = lrelu(acc * scale[col] + shift[col], slope) (eval-mode
                           // BatchNorm folded into the conv epilogue: generator-only inference)
 };

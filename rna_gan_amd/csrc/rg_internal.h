@@ -111,7 +111,7 @@ size_t rg_mfma_wgrad2_ws_bytes(int N, int Ho, int Wo, int O, int I);
 
 bool rg_mfma_conv_up_planes64_supported(int N, int Ho, int Wo, int O, int I, int products);
 int rg_mfma_conv_up_planes64(const void* xp, const void* wp, float* y, int N, int Ho, int Wo, int O, int I, int products,
-                             hipStream_t st);
+                             hipStream_t st, const float* maskf = nullptr, float mslope = 1.f);
 bool rg_mfma_fp8_supported(int M, int K, int Ncols, int taps);
 int rg_mfma_conv_up_fp8(const void* x8, const void* wup8, void* y, int N, int Ho, int Wo, int O, int I, const float* scale,
                         const float* shift, float slope, int out_fp8, hipStream_t st);

@@ -605,6 +605,13 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
       } else {
         float vals[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
         float* yo = reinterpret_cast<float*>(g.C) + orow * g.ldc + col;
+        if (g.maskf) {                                         // LeakyReLU backward of the consumer (fp32 activation as the mask)
+          const float4 m0 = *reinterpret_cast<const float4*>(g.maskf + orow * g.ldc + col);
+          const float4 m1 = *reinterpret_cast<const float4*>(g.maskf + orow * g.ldc + col + 4);
+          const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) vals[e] *= mm[e] > 0.f ? 1.f : g.mslope;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float v = vals[e];
@@ -1491,10 +1498,11 @@ bool rg_mfma_conv_up_planes64_supported(int N, int Ho, int Wo, int O, int I, int
          3ull * N * Ho * Wo * O * 2 < 0x7fffff00ull;
 }
 int rg_mfma_conv_up_planes64(const void* xp, const void* wp, float* y, int N, int Ho, int Wo, int O, int I, int products,
-                             hipStream_t st) {
+                             hipStream_t st, const float* maskf, float mslope) {
   G2Args a2{};
   GArgs& g = a2.g;
   g.A = (const uint16_t*)xp; g.B = (const uint16_t*)wp; g.C = y;
+  g.maskf = maskf; g.mslope = mslope;
   g.M = N * Ho * Wo; g.Ncols = I; g.Cin = O; g.taps = 4;
   g.lgW = rg_ilog2(Wo); g.lgH = rg_ilog2(Ho); g.Hs = Ho; g.Ws = Wo; g.ldc = I; g.b_col = O; g.b_tap = I * O;
   g.slope = 1.f; g.tiles_n = 1;

@@ -318,7 +318,7 @@ class HipOps:
             cw.packs_version = cw.version
         return cw.packs
 
-    def _conv_planes(self, up, x, cw: ConvW, N, Hl, Wl, O, I, y, want_stats):
+    def _conv_planes(self, up, x, cw: ConvW, N, Hl, Wl, O, I, y, want_stats, mask=None, mslope=1.0):
         """The fp32 conv on bf16 planes (rg_f32p_conv) when the shape has that kernel; returns the statistics partials (or None),
         or False when the caller has to use the RG_F32 entry point."""
         if not self.f32_planes or not self.lib.rg_f32p_conv_supported(up, N, Hl, Wl, O, I, self.f32_planes):
@@ -331,8 +331,8 @@ class HipOps:
             st = self._f32(rows, 2, I if up else O) if rows > 0 else None
         ws = self._ws(self.lib.rg_f32p_conv_workspace_bytes(up, N, Hl, Wl, O, I, self.f32_planes))
         self._timed("conv_fwd_dgrad", 2.0 * N * Hl * Wl * O * I * 16, lambda: check(
-            self.lib.rg_f32p_conv(up, _ptr(xp), _ptr(wp), _ptr(y), N, Hl, Wl, O, I, self.f32_planes, _ptr(st), _ptr(ws), ws.numel(),
-                                  self.stream), "rg_f32p_conv"), cw=cw)
+            self.lib.rg_f32p_conv(up, _ptr(xp), _ptr(wp), _ptr(y), N, Hl, Wl, O, I, self.f32_planes, _ptr(st), _ptr(mask), float(mslope),
+                                  _ptr(ws), ws.numel(), self.stream), "rg_f32p_conv"), cw=cw)
         return st
 
     def _packs(self, cw: ConvW):
@@ -470,10 +470,12 @@ class HipOps:
         assert cw.O == O and x.is_contiguous()
         y = self._act(N, 2 * Ho, 2 * Wo, I)
         if self.f32_planes:
-            st = self._conv_planes(1, x, cw, N, Ho, Wo, O, I, y, want_stats and mask_act is None)
+            assert mask_act is None or (mask_act.shape == y.shape and mask_act.dtype == y.dtype and mask_act.is_contiguous())
+            fused = mask_act is not None and bool(self.lib.rg_f32p_conv_mask_supported(1, N, Ho, Wo, O, I, self.f32_planes))
+            st = self._conv_planes(1, x, cw, N, Ho, Wo, O, I, y, want_stats and mask_act is None,
+                                   mask=mask_act if fused else None, mslope=slope)
             if st is not False:
-                if mask_act is not None:          # the consumer's LeakyReLU backward as one elementwise pass behind the conv
-                    assert mask_act.shape == y.shape and mask_act.dtype == y.dtype
+                if mask_act is not None and not fused:   # the consumer's LeakyReLU backward as one elementwise pass behind the conv
                     y = self.lrelu_bwd(y, mask_act, slope)
                 return (y, st) if want_stats else y
         _, wup = self._packs(cw)
