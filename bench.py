@@ -608,7 +608,7 @@ def pmc_traffic(family):
     FETCH_SIZE doubled per the gfx950 correction; tools/pmc_traffic.py).  Counters cannot be read from inside
     this process, so the figure is the one measured on this workload (batch 64) when the profile was taken."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = next((p for p in (os.path.join(here, "round%d_pmc_hbm_traffic.json" % r) for r in (5, 4, 3, 2, 1)) if os.path.exists(p)),
+    path = next((p for p in (os.path.join(here, "round%d_pmc_hbm_traffic.json" % r) for r in (6, 5, 4, 3, 2, 1)) if os.path.exists(p)),
                 os.path.join(here, "round3_pmc_hbm_traffic.json"))
     try:
         with open(path) as f:
@@ -622,7 +622,7 @@ def pmc_mfma_util(family):
     """Time-weighted MFMA utilisation (SQ_VALU_MFMA_BUSY_CYCLES / elapsed cycles over the 4 x 256 SIMDs) of a kernel family
     from the committed rocprofv3 --pmc summary of this workload (tools/pmc_bench.sh + tools/pmc_family.py)."""
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    path = next((p for p in (os.path.join(here, "round%d_mfma_util.json" % r) for r in (5, 4, 3, 2)) if os.path.exists(p)),
+    path = next((p for p in (os.path.join(here, "round%d_mfma_util.json" % r) for r in (6, 5, 4, 3, 2)) if os.path.exists(p)),
                 os.path.join(here, "round3_mfma_util.json"))
     try:
         with open(path) as f:

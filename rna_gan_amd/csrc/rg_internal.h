@@ -53,6 +53,7 @@ constexpr int RG_SLAB16_DEFAULT = 1;
 constexpr int RG_BN_REV_DEFAULT = 4;     // option bn_rev: BatchNorm row passes that walk their rows from the END (bit 0: backward-kind applies, bit 1: forward
                                          // applies, bit 2: reductions).  Measured: reductions only
 constexpr int RG_WSLAB16_DEFAULT = 1;
+constexpr int RG_WGRAD8_MFMA_DEFAULT = 32;   // option wgrad8_mfma: 32 = v_mfma_f32_32x32x16, 16 = v_mfma_f32_16x16x32 in wgrad8_kernel
 constexpr int RG_F32MMA_DEFAULT = 2;     // option f32mma: 0 vector ALU, 1 f32 matrix cores, 2 (default since the end of round 5) the same with the
                                          // 128 x 128-tile structured launches as six bf16 matrix-core products per fp32 product    // deferred split-K weight-gradient slabs (rg_conv_wgrad_slabs) as bf16: option wslab16
 int rg_mfma_conv_slab16(int up, int N, int Hlow, int Wlow, int O, int I);

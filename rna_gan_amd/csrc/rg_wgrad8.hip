@@ -62,8 +62,15 @@ __device__ __forceinline__ int w8_swz(int row) { return ((row & 3) << 2) | ((row
 
 // NP > 0 (rg_conv8f.hip only): fp32 operands as K-concatenated bf16 planes, exactly as conv8_kernel's NP (rg_conv8.hip): low and
 // high are plane-major [3][pixels][channels] buffers, flat k-tile q -> plane pair q % NP (hh hm mh hl lh mm), pixel tile q / NP.
-template <bool ADAM, int NP = 0>
+// MF: 32 = v_mfma_f32_32x32x16 (16 pixels per k-step, 32-channel operand tiles), 16 = v_mfma_f32_16x16x32 (32 pixels per k-step,
+// 16-channel tiles: the four 16-lane groups of a transposed read take the four pixel octets of the SAME 16 channels).  Same LDS
+// images, DMA stream, waits and accumulator footprint; chosen by option wgrad8_mfma.
+template <bool ADAM, int NP = 0, int MF = 32>
 __global__ __launch_bounds__(512, 2) void wgrad8_kernel(W8Args g) {
+  constexpr int NAT = MF == 32 ? 2 : 4;      // A (low channel) tiles per quadrant row (64 channels)
+  constexpr int NBT = MF == 32 ? 1 : 2;      // B (column) tiles per quadrant column (32 columns)
+  constexpr int NKS = MF == 32 ? 4 : 2;      // k-steps per 64-pixel k-tile
+  constexpr int KSB = MF == 32 ? 4096 : 8192;   // LDS bytes per k-step (16 / 32 pixel rows of 256 bytes)
   constexpr int HT = 64 * 256;                     // bytes per half-tile: 64 pixels x 128 channels bf16
   constexpr int STAGE = 4 * HT;                    // [B0][B1][A0][A1]
   constexpr int OFF_B = 0, OFF_A = 2 * HT;
@@ -186,68 +193,77 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(W8Args g) {
   const int wm = wave >> 2, wn = wave & 3;
   const int grp = lane >> 4, idx = lane & 15;
   const int q = idx >> 2, p4 = idx & 3, fh = grp >> 1, cb = grp & 1;
-  const int f1 = (q << 2) | (2 * fh), f2 = (q << 2) | (2 * fh + 1);          // w8_swz(8 fh + q), w8_swz(8 fh + q + 4)
   const unsigned lds_base = (unsigned)(size_t)(lds_vptr_t)lds;
-  auto frag_addr = [&](int cb32, int hi) -> unsigned {
-    const int prow = 8 * fh + q + 4 * hi;
-    const int ca = cb32 * 4 + 2 * cb + (p4 >> 1);
-    return (unsigned)(prow * 256 + ((ca ^ (hi ? f2 : f1)) << 4) + (p4 & 1) * 8);
+  // transposed-read address of operand tile `tile` (32 channels: MF 32; 16 channels: MF 16) of a 128-channel half-tile, pixel
+  // rows +0..3 (hi = 0) / +4..7 (hi = 1) of this lane group's pixel octet: 8 fh (two octets per 16-pixel k-step, two channel
+  // blocks cb per tile) or 8 grp (four octets per 32-pixel k-step).  Swizzle f(row) = ((row & 3) << 2) | ((row >> 2) & 3).
+  auto frag_addr = [&](int tile, int hi) -> unsigned {
+    const int oct = MF == 32 ? fh : grp;
+    const int prow = 8 * oct + q + 4 * hi;
+    const int ca = MF == 32 ? tile * 4 + 2 * cb + (p4 >> 1) : tile * 2 + (p4 >> 1);
+    const int swz = (q << 2) | ((2 * oct + hi) & 3);
+    return (unsigned)(prow * 256 + ((ca ^ swz) << 4) + (p4 & 1) * 8);
   };
-  unsigned aA[2][2][2], bA[2][2];                   // [stage][sub-tile][lo/hi], [stage][lo/hi]
+  unsigned aA[2][NAT][2], bA[2][NBT][2];            // [stage][tile][lo/hi]
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int hl = 0; hl < 2; ++hl) {
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti) aA[s][ti][hl] = lds_base + s * STAGE + OFF_A + frag_addr(wm * 2 + ti, hl);
-      bA[s][hl] = lds_base + s * STAGE + OFF_B + frag_addr(wn, hl);
+      for (int ti = 0; ti < NAT; ++ti) aA[s][ti][hl] = lds_base + s * STAGE + OFF_A + frag_addr(wm * NAT + ti, hl);
+#pragma unroll
+      for (int tj = 0; tj < NBT; ++tj) bA[s][tj][hl] = lds_base + s * STAGE + OFF_B + frag_addr(wn * NBT + tj, hl);
     }
-  f32x16_t acc[2][2][2];                            // [quadrant row i][quadrant column j][32-channel sub-tile]
+  using acc_t = std::conditional_t<MF == 32, f32x16_t, rg_f32x4>;
+  constexpr int NACC = NAT * NBT, ACC_R = MF == 32 ? 16 : 4;
+  acc_t acc[2][2][NACC];                            // [quadrant row i][quadrant column j][A tile * NBT + B tile]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+      for (int s = 0; s < NACC; ++s)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][s][r] = 0.f;
-  u32x2_t aR[2][4][2];                              // [sub-tile][k-step][lo/hi]
-  u32x2_t bS[3][4][2];                              // three rotating B sets
+        for (int r = 0; r < ACC_R; ++r) acc[i][j][s][r] = 0.f;
+  u32x2_t aR[16];                                   // [(A tile * NKS + k-step) * 2 + lo/hi]
+  u32x2_t bS[3][8];                                 // three rotating B sets, [(B tile * NKS + k-step) * 2 + lo/hi]
 
 #define W8_DSR(dst, addr, off) \
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
 #define W8_READ_A(S, H)                                                                                   \
   do {                                                                                                    \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) _Pragma("unroll") for (int ti_ = 0; ti_ < 2; ++ti_) { \
-      W8_DSR(aR[ti_][ks_][0], aA[S][ti_][0], (H) * HT + ks_ * 4096);                                      \
-      W8_DSR(aR[ti_][ks_][1], aA[S][ti_][1], (H) * HT + ks_ * 4096);                                      \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < NKS; ++ks_) _Pragma("unroll") for (int ti_ = 0; ti_ < NAT; ++ti_) { \
+      W8_DSR(aR[(ti_ * NKS + ks_) * 2], aA[S][ti_][0], (H) * HT + ks_ * KSB);                             \
+      W8_DSR(aR[(ti_ * NKS + ks_) * 2 + 1], aA[S][ti_][1], (H) * HT + ks_ * KSB);                         \
     }                                                                                                     \
   } while (0)
 #define W8_READ_B(S, H, SET)                                                                              \
   do {                                                                                                    \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) {                                                 \
-      W8_DSR(bS[SET][ks_][0], bA[S][0], (H) * HT + ks_ * 4096);                                           \
-      W8_DSR(bS[SET][ks_][1], bA[S][1], (H) * HT + ks_ * 4096);                                           \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < NKS; ++ks_) _Pragma("unroll") for (int tj_ = 0; tj_ < NBT; ++tj_) { \
+      W8_DSR(bS[SET][(tj_ * NKS + ks_) * 2], bA[S][tj_][0], (H) * HT + ks_ * KSB);                        \
+      W8_DSR(bS[SET][(tj_ * NKS + ks_) * 2 + 1], bA[S][tj_][1], (H) * HT + ks_ * KSB);                    \
     }                                                                                                     \
   } while (0)
 #define W8_WAIT_A()                                                                                        \
   asm volatile("s_waitcnt lgkmcnt(0)"                                                                      \
-               : "+v"(aR[0][0][0]), "+v"(aR[0][0][1]), "+v"(aR[0][1][0]), "+v"(aR[0][1][1]), "+v"(aR[0][2][0]), \
-                 "+v"(aR[0][2][1]), "+v"(aR[0][3][0]), "+v"(aR[0][3][1]), "+v"(aR[1][0][0]), "+v"(aR[1][0][1]), \
-                 "+v"(aR[1][1][0]), "+v"(aR[1][1][1]), "+v"(aR[1][2][0]), "+v"(aR[1][2][1]), "+v"(aR[1][3][0]), \
-                 "+v"(aR[1][3][1])::"memory")
+               : "+v"(aR[0]), "+v"(aR[1]), "+v"(aR[2]), "+v"(aR[3]), "+v"(aR[4]), "+v"(aR[5]), "+v"(aR[6]), "+v"(aR[7]), \
+                 "+v"(aR[8]), "+v"(aR[9]), "+v"(aR[10]), "+v"(aR[11]), "+v"(aR[12]), "+v"(aR[13]), "+v"(aR[14]),        \
+                 "+v"(aR[15])::"memory")
 #define W8_WAIT_B(SET)                                                                                     \
   asm volatile("s_waitcnt lgkmcnt(0)"                                                                      \
-               : "+v"(bS[SET][0][0]), "+v"(bS[SET][0][1]), "+v"(bS[SET][1][0]), "+v"(bS[SET][1][1]),       \
-                 "+v"(bS[SET][2][0]), "+v"(bS[SET][2][1]), "+v"(bS[SET][3][0]), "+v"(bS[SET][3][1])::"memory")
+               : "+v"(bS[SET][0]), "+v"(bS[SET][1]), "+v"(bS[SET][2]), "+v"(bS[SET][3]), "+v"(bS[SET][4]), \
+                 "+v"(bS[SET][5]), "+v"(bS[SET][6]), "+v"(bS[SET][7])::"memory")
 #define W8_FRAG(lo, hi) __builtin_bit_cast(h16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3))
 #define W8_MFMAS(I, J, SET)                                                                                \
   do {                                                                                                     \
     __builtin_amdgcn_s_setprio(1);                                                                         \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) _Pragma("unroll") for (int ti_ = 0; ti_ < 2; ++ti_) \
-        acc[I][J][ti_] = rg_mfma_h16_32x32x16(W8_FRAG(aR[ti_][ks_][0], aR[ti_][ks_][1]), \
-                                                                 W8_FRAG(bS[SET][ks_][0], bS[SET][ks_][1]), \
-                                                                 acc[I][J][ti_], 0, 0, 0);                  \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < NKS; ++ks_) _Pragma("unroll") for (int ti_ = 0; ti_ < NAT; ++ti_) \
+    _Pragma("unroll") for (int tj_ = 0; tj_ < NBT; ++tj_) {                                                \
+      const h16x8_t fa_ = W8_FRAG(aR[(ti_ * NKS + ks_) * 2], aR[(ti_ * NKS + ks_) * 2 + 1]);               \
+      const h16x8_t fb_ = W8_FRAG(bS[SET][(tj_ * NKS + ks_) * 2], bS[SET][(tj_ * NKS + ks_) * 2 + 1]);     \
+      if constexpr (MF == 32) acc[I][J][ti_ * NBT + tj_] = rg_mfma_h16_32x32x16(fa_, fb_, acc[I][J][ti_ * NBT + tj_], 0, 0, 0); \
+      else acc[I][J][ti_ * NBT + tj_] = rg_mfma_h16_16x16x32(fa_, fb_, acc[I][J][ti_ * NBT + tj_], 0, 0, 0); \
+    }                                                                                                      \
     __builtin_amdgcn_s_setprio(0);                                                                         \
   } while (0)
 #define W8_SYNC() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -329,12 +345,17 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(W8Args g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+      for (int ti = 0; ti < NAT; ++ti)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = i * 128 + wm * 64 + s * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh2;
-          cs[row * 128 + wn * 32 + fr] = acc[i][ep][s][r];
-        }
+        for (int tj = 0; tj < NBT; ++tj)
+#pragma unroll
+          for (int r = 0; r < ACC_R; ++r) {
+            // accumulator maps: 32x32 -> row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31; 16x16 -> row 4*(lane>>4) + r, column lane&15
+            const int row = MF == 32 ? i * 128 + wm * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh2
+                                     : i * 128 + wm * 64 + ti * 16 + 4 * (lane >> 4) + r;
+            const int col = MF == 32 ? wn * 32 + fr : wn * 32 + tj * 16 + (lane & 15);
+            cs[row * 128 + col] = acc[i][ep][ti * NBT + tj][r];
+          }
     __syncthreads();
     if constexpr (ADAM) {
       // the optimizer step of this 256 x 128 piece: 26 bytes per element (p, m, v read and written, the bf16 image written)
@@ -760,7 +781,10 @@ int rg_wgrad8_launch(const void* low0, const void* high0, const void* low1, cons
   g.tiles_o = O / 256; g.tiles_c = 16 * I / 256; g.nsplit = nsplit; g.kt_per_split = kt_per_split;
   g.accumulate = nsplit == 1 ? accumulate : 0;
   g.slab16 = nsplit > 1 ? slab16 : 0;
-  hipLaunchKernelGGL(wgrad8_kernel<false>, dim3((unsigned)(g.tiles_o * g.tiles_c * nsplit)), dim3(512), 0, st, g);
+  if (rg_option("wgrad8_mfma", RG_WGRAD8_MFMA_DEFAULT) == 16)
+    hipLaunchKernelGGL((wgrad8_kernel<false, 0, 16>), dim3((unsigned)(g.tiles_o * g.tiles_c * nsplit)), dim3(512), 0, st, g);
+  else
+    hipLaunchKernelGGL((wgrad8_kernel<false, 0, 32>), dim3((unsigned)(g.tiles_o * g.tiles_c * nsplit)), dim3(512), 0, st, g);
   RG_LAUNCH_CHECK("conv_wgrad(mfma, ping-pong)");
   return RG_OK;
 }
@@ -777,7 +801,10 @@ int rg_wgrad8_wire_launch(const void* low0, const void* high0, const void* low1,
   g.lgWo = rg_ilog2(Wo); g.lgHo = rg_ilog2(Ho); g.Hh = 2 * Ho; g.Wh = 2 * Wo;
   g.tiles_o = O / 256; g.tiles_c = 16 * I / 256; g.nsplit = 1; g.kt_per_split = kt_per_split;
   g.slab16 = 1;                                    // zs = 0: the "slab" is the tensor itself
-  hipLaunchKernelGGL(wgrad8_kernel<false>, dim3((unsigned)(g.tiles_o * g.tiles_c)), dim3(512), 0, st, g);
+  if (rg_option("wgrad8_mfma", RG_WGRAD8_MFMA_DEFAULT) == 16)
+    hipLaunchKernelGGL((wgrad8_kernel<false, 0, 16>), dim3((unsigned)(g.tiles_o * g.tiles_c)), dim3(512), 0, st, g);
+  else
+    hipLaunchKernelGGL((wgrad8_kernel<false, 0, 32>), dim3((unsigned)(g.tiles_o * g.tiles_c)), dim3(512), 0, st, g);
   RG_LAUNCH_CHECK("conv_wgrad_wire(mfma, ping-pong)");
   return RG_OK;
 }
@@ -795,7 +822,10 @@ int rg_wgrad8_adam_launch(const void* low0, const void* high0, const void* low1,
   g.lgWo = rg_ilog2(Wo); g.lgHo = rg_ilog2(Ho); g.Hh = 2 * Ho; g.Wh = 2 * Wo;
   g.tiles_o = O / 256; g.tiles_c = 16 * I / 256; g.nsplit = 1; g.kt_per_split = kt_per_split;
   g.ap = p; g.am = m; g.av = v; g.ash = shadow; g.hyper = hyper;
-  hipLaunchKernelGGL(wgrad8_kernel<true>, dim3((unsigned)(g.tiles_o * g.tiles_c)), dim3(512), 0, st, g);
+  if (rg_option("wgrad8_mfma", RG_WGRAD8_MFMA_DEFAULT) == 16)
+    hipLaunchKernelGGL((wgrad8_kernel<true, 0, 16>), dim3((unsigned)(g.tiles_o * g.tiles_c)), dim3(512), 0, st, g);
+  else
+    hipLaunchKernelGGL((wgrad8_kernel<true, 0, 32>), dim3((unsigned)(g.tiles_o * g.tiles_c)), dim3(512), 0, st, g);
   RG_LAUNCH_CHECK("conv_wgrad_adam(mfma, ping-pong)");
   return RG_OK;
 }
