@@ -727,7 +727,7 @@ def measure_extras(args, device, info):
     """Secondary figures, measured after the headline timed region on the same box in the same process."""
     ex = {}
     for name, fn in (("generate", extra_generate), ("api_path", extra_api_path), ("fp32_step", extra_fp32_step),
-                     ("fp16_step", extra_fp16_step),
+                     ("fp16_step", extra_fp16_step), ("dcgan_up", extra_dcgan_up),
                      ("vae_train", extra_vae_train), ("enc200", extra_enc200),
                      ("batch128", lambda a, d, i: extra_batch(a, d, i, 128)),
                      ("batch256", lambda a, d, i: extra_batch(a, d, i, 256))):
@@ -925,6 +925,39 @@ def extra_fp16_step(args, device, info, steps=10, warm=14):
            "finite": bool(all(torch.isfinite(p).all() for p in list(G.parameters()) + list(Dm.parameters()))),
            "kernels": "librnagan_hip_f16.so: the bf16 step's kernels compiled for IEEE fp16 storage (v_mfma_f32_16x16x32_f16 / "
                       "32x32x16_f16), fp32 accumulation, statistics and masters"}
+    PL.new_batch()
+    del G, Dm, og, od, lg, ld, lp, it
+    torch.cuda.empty_cache()
+    return res
+
+
+def extra_dcgan_up(args, device, info, steps=8, warm=12):
+    """The same iteration with the reference's OTHER generator, src/dcgan.py's DCGANUpGenerator (resize-convolution blocks:
+    bilinear x2 + ReflectionPad2d(1) + Conv3x3, src/dcgan.py:45-56,76-84; `--gan_type dcgan_up`; the reference CLI never selects
+    it): bf16, batch 64.  Its upsample + pad image is materialised once per block (uppad_bf16_kernel) and read by a 9-tap MFMA conv."""
+    from rna_gan_amd import graphed
+    from rna_gan_amd import losses as PL
+    N = args.batch
+    G, Dm, og, od, (lg, ld, lp) = build(device, "bf16", N, 19198, args.seed, gan_type="dcgan_up")
+    h = info["handles"]
+    gen = torch.Generator(device="cpu").manual_seed(args.seed + 17)
+
+    def it():
+        PL.new_batch()
+        us = [torch.empty(N, 2048).uniform_(-0.3, 0.3, generator=gen).to(device) for _ in range(3)]
+        eps = torch.empty(1).uniform_(0.0, 1.0, generator=gen).to(device)
+        return [lg.step(G, Dm, og, h["rna"], us[0]), ld.step(G, Dm, od, h["real"], h["rna"], us[1], next_u=us[2]),
+                lp.step(G, Dm, od, h["real"], h["rna"], us[2], eps)]
+    for _ in range(warm):
+        it()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ls = it()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    res = {"ms_per_step": round(dt * 1e3, 3), "imgs_per_sec": round(N / dt, 1), "steps": steps, "hip_graphs": bool(graphed.ENABLED),
+           "losses": [round(float(l.item()), 5) for l in ls], "generator": "DCGANUpGenerator (92.3 M parameters)", "precision": "bf16"}
     PL.new_batch()
     del G, Dm, og, od, lg, ld, lp, it
     torch.cuda.empty_cache()

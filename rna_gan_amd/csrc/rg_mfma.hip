@@ -1859,40 +1859,47 @@ int rg_mfma_g0_wgrad(const float* z, const void* gy, float* dw, int N, int E, in
 // ---- resize-convolution block on the matrix cores (forward): materialise pad = ReflectionPad(1)(bilinear_x2(x)) as
 // bf16 NHWC once (HBM-bound pass, 16 bytes per thread), then a 9-tap stride-1 implicit GEMM over it (MODE_C3) with
 // the Conv2d bias in the epilogue.
-__global__ void uppad_bf16_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ pad, int N, int H, int W, int C) {
+// One workgroup per padded output row (n, i): the two source rows and the vertical weight are block constants, a thread walks
+// (j, 8-channel group) items of the row with U = 4 items -- 16 x 16-byte loads -- in flight and NO control flow around the loads
+// (items beyond the row end read a clamped address and are not stored: with a branch around them hipcc serialises the loads
+// behind s_waitcnt vmcnt(0), rg_skinny.hip's round-5 finding).  The four source pixels of neighbouring outputs overlap: the 4 x
+// read amplification is served by L2.
+__global__ __launch_bounds__(256) void uppad_bf16_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ pad, int N, int H,
+                                                         int W, int C) {
   const int C8 = C >> 3, Hp = 2 * H + 2, Wp = 2 * W + 2;
-  const size_t tot = (size_t)N * Hp * Wp * C8, stride = (size_t)gridDim.x * blockDim.x;
-  constexpr int U = 2;                      // outputs per thread per pass: 8 x 16-byte loads in flight before the stores
-  for (size_t base = (size_t)blockIdx.x * blockDim.x + threadIdx.x; base < tot; base += U * stride) {
-    float v[U][4][8], lh[U], lw[U];
+  const int n = blockIdx.x / Hp, i = blockIdx.x - n * Hp;
+  int h0, h1;
+  float lh;
+  up_taps(up_reflect(i, 2 * H), H, h0, h1, lh);
+  const h16_t* r0 = reinterpret_cast<const h16_t*>(x) + ((size_t)n * H + h0) * W * C;
+  const h16_t* r1 = reinterpret_cast<const h16_t*>(x) + ((size_t)n * H + h1) * W * C;
+  h16_t* orow = reinterpret_cast<h16_t*>(pad) + ((size_t)n * Hp + i) * Wp * C;
+  const int items = Wp * C8;
+  constexpr int U = 4;
+  for (int base = threadIdx.x; base < items; base += U * 256) {
+    RawVec<h16_t, 8> v[U][4];
+    float lw[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const size_t idx = base + u * stride;
-      if (idx >= tot) continue;
-      const int c8 = (int)(idx % C8);
-      size_t t = idx / C8;
-      const int j = (int)(t % Wp); t /= Wp;
-      const int i = (int)(t % Hp);
-      const int n = (int)(t / Hp);
-      int h0, h1, w0, w1;
-      up_taps(up_reflect(i, 2 * H), H, h0, h1, lh[u]);
+      const int it = min(base + u * 256, items - 1);
+      const int j = it / C8, c8 = it - j * C8;
+      int w0, w1;
       up_taps(up_reflect(j, 2 * W), W, w0, w1, lw[u]);
-      const h16_t* xn = reinterpret_cast<const h16_t*>(x) + (size_t)n * H * W * C + c8 * 8;
-      Vec<h16_t, 8>::ld(xn + ((size_t)h0 * W + w0) * C, v[u][0]);
-      Vec<h16_t, 8>::ld(xn + ((size_t)h0 * W + w1) * C, v[u][1]);
-      Vec<h16_t, 8>::ld(xn + ((size_t)h1 * W + w0) * C, v[u][2]);
-      Vec<h16_t, 8>::ld(xn + ((size_t)h1 * W + w1) * C, v[u][3]);
+      v[u][0].ld(r0 + (size_t)w0 * C + c8 * 8);
+      v[u][1].ld(r0 + (size_t)w1 * C + c8 * 8);
+      v[u][2].ld(r1 + (size_t)w0 * C + c8 * 8);
+      v[u][3].ld(r1 + (size_t)w1 * C + c8 * 8);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const size_t idx = base + u * stride;
-      if (idx >= tot) continue;
-      float o[8];
+      float a[4][8], o[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[u][k].cvt(a[k]);
 #pragma unroll
       for (int k = 0; k < 8; ++k)
-        o[k] = (1.f - lh[u]) * ((1.f - lw[u]) * v[u][0][k] + lw[u] * v[u][1][k]) +
-               lh[u] * ((1.f - lw[u]) * v[u][2][k] + lw[u] * v[u][3][k]);
-      Vec<h16_t, 8>::st(reinterpret_cast<h16_t*>(pad) + idx * 8, o);
+        o[k] = (1.f - lh) * ((1.f - lw[u]) * a[0][k] + lw[u] * a[1][k]) + lh * ((1.f - lw[u]) * a[2][k] + lw[u] * a[3][k]);
+      const int it = base + u * 256;
+      if (it < items) Vec<h16_t, 8>::st(orow + (size_t)it * 8, o);
     }
   }
 }
@@ -1922,8 +1929,7 @@ int rg_mfma_upconv3_fwd(const void* x, const float* w, const float* bias, void* 
   const size_t padb = rg_align_up((size_t)N * Hp * Wp * Cin * 2, 256), wpb = rg_align_up((size_t)Cout * 9 * Cin * 2, 256);
   uint16_t* pad = (uint16_t*)ws;
   uint16_t* wp = (uint16_t*)((char*)ws + padb);
-  hipLaunchKernelGGL(uppad_bf16_kernel, dim3(grid_cap((size_t)N * Hp * Wp * (Cin >> 3))), dim3(256), 0, st,
-                     (const uint16_t*)x, pad, N, H, W, Cin);
+  hipLaunchKernelGGL(uppad_bf16_kernel, dim3((unsigned)(N * Hp)), dim3(256), 0, st, (const uint16_t*)x, pad, N, H, W, Cin);
   RG_LAUNCH_CHECK("upconv3_fwd(pad)");
   hipLaunchKernelGGL(pack_w3_kernel, dim3(grid_cap((size_t)Cout * 9 * Cin)), dim3(256), 0, st, w, wp, Cout, Cin);
   RG_LAUNCH_CHECK("upconv3_fwd(pack)");
@@ -1965,8 +1971,7 @@ int rg_mfma_upconv3_image_fwd(const void* x, const float* w, const float* bias, 
   uint16_t* pad = (uint16_t*)ws;
   uint16_t* wp = (uint16_t*)((char*)ws + padb);
   float* tmp = (float*)((char*)ws + padb + wpb);
-  hipLaunchKernelGGL(uppad_bf16_kernel, dim3(grid_cap((size_t)N * Hp * Wp * (Cin >> 3))), dim3(256), 0, st,
-                     (const uint16_t*)x, pad, N, H, W, Cin);
+  hipLaunchKernelGGL(uppad_bf16_kernel, dim3((unsigned)(N * Hp)), dim3(256), 0, st, (const uint16_t*)x, pad, N, H, W, Cin);
   RG_LAUNCH_CHECK("upconv3_fwd(pad)");
   hipLaunchKernelGGL(pack_w3_kernel, dim3(grid_cap((size_t)Cout * 9 * Cin)), dim3(256), 0, st, w, wp, Cout, Cin);
   RG_LAUNCH_CHECK("upconv3_fwd(pack)");
@@ -2114,8 +2119,7 @@ int rg_mfma_upconv3_wgrad(const void* gy, const void* x, float* dw, int N, int H
   const size_t padb = rg_align_up((size_t)N * Hp * Wp * Cin * 2, 256);
   uint16_t* pad = (uint16_t*)ws;
   float* slab = (float*)((char*)ws + padb);
-  hipLaunchKernelGGL(uppad_bf16_kernel, dim3(grid_cap((size_t)N * Hp * Wp * (Cin >> 3))), dim3(256), 0, st,
-                     (const uint16_t*)x, pad, N, H, W, Cin);
+  hipLaunchKernelGGL(uppad_bf16_kernel, dim3((unsigned)(N * Hp)), dim3(256), 0, st, (const uint16_t*)x, pad, N, H, W, Cin);
   RG_LAUNCH_CHECK("upconv3_wgrad(pad)");
   int nsplit = upconv3_wgrad_split(K, Cout, Cin);
   W2Args g{};
@@ -2163,8 +2167,7 @@ int rg_mfma_upconv3_image_wgrad(const float* gy, const void* x, float* dw, int N
   uint16_t* pad = (uint16_t*)ws;
   uint16_t* rows = (uint16_t*)((char*)ws + padb);
   float* slab = (float*)((char*)ws + padb + rowb);
-  hipLaunchKernelGGL(uppad_bf16_kernel, dim3(grid_cap((size_t)N * Hp * Wp * (Cin >> 3))), dim3(256), 0, st,
-                     (const uint16_t*)x, pad, N, H, W, Cin);
+  hipLaunchKernelGGL(uppad_bf16_kernel, dim3((unsigned)(N * Hp)), dim3(256), 0, st, (const uint16_t*)x, pad, N, H, W, Cin);
   RG_LAUNCH_CHECK("upconv3_wgrad(pad)");
   hipLaunchKernelGGL(nchw_to_rows8_kernel, dim3(grid_cap((size_t)K)), dim3(256), 0, st, gy, rows, Cout, (unsigned)(4 * H * W),
                      (size_t)K);
