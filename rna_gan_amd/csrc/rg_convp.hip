@@ -217,6 +217,7 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
                      "+v"(acc[rt_ + 2][1]), "+v"(acc[rt_ + 2][2]), "+v"(acc[rt_ + 2][3]), "+v"(acc[rt_ + 3][0]),              \
                      "+v"(acc[rt_ + 3][1]), "+v"(acc[rt_ + 3][2]), "+v"(acc[rt_ + 3][3]));                                    \
   } while (0)
+#define CP_STORE_TAIL "\n\ts_nop 2"
 #define CP_SYNC() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
 
   // ---- epilogue.  The MFMAs compute the TRANSPOSED tile (weights as the A operand, pixels as the B operand): accumulator
@@ -326,8 +327,11 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
         }
       }
       char* cb = reinterpret_cast<char*>(g.C) + out_base(m_w + rt * 16);
-      asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(e_off), "v"(o[0]), "s"(cb) : "memory");
-      asm volatile("global_store_dwordx4 %0, %1, %2 offset:64" ::"v"(e_off), "v"(o[1]), "s"(cb) : "memory");
+      // (CP_STORE_TAIL: a VALU write into the data registers of a store of more than 8 bytes needs wait states behind the store (two on gfx940 and later; three are given) --
+      // hipcc provides it for its own stores, not for these: the fp16 build's statistics variant reused o[0] in the very next
+      // instruction and stored garbage in the first channel pair of every pixel)
+      asm volatile("global_store_dwordx4 %0, %1, %2" CP_STORE_TAIL ::"v"(e_off), "v"(o[0]), "s"(cb) : "memory");
+      asm volatile("global_store_dwordx4 %0, %1, %2 offset:64" CP_STORE_TAIL ::"v"(e_off), "v"(o[1]), "s"(cb) : "memory");
     }
     if constexpr (HAS_STATS) {
       const size_t grow = ((size_t)cls * tiles + T) * 2 + half;
@@ -338,8 +342,8 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
         const f32x4_t q1 = {dpp_sum16(s1[j][0][0]), dpp_sum16(s1[j][0][1]), dpp_sum16(s1[j][1][0]), dpp_sum16(s1[j][1][1])};
         const f32x4_t q2 = {dpp_sum16(s2[j][0][0]), dpp_sum16(s2[j][0][1]), dpp_sum16(s2[j][1][0]), dpp_sum16(s2[j][1][1])};
         if (px == 0) {
-          asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" ::"v"(so), "v"(q1), "s"(sb), "n"((j >> 1) * 128 + (j & 1) * 16) : "memory");
-          asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" ::"v"(so), "v"(q2), "s"(sb), "n"(256 + (j >> 1) * 128 + (j & 1) * 16) : "memory");
+          asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" CP_STORE_TAIL ::"v"(so), "v"(q1), "s"(sb), "n"((j >> 1) * 128 + (j & 1) * 16) : "memory");
+          asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" CP_STORE_TAIL ::"v"(so), "v"(q2), "s"(sb), "n"(256 + (j >> 1) * 128 + (j & 1) * 16) : "memory");
         }
       }
     }
@@ -493,14 +497,6 @@ __global__ __launch_bounds__(512, 2) void convp_kernel(G2Args a2) {
 // shapes convp_kernel takes: 128 input channels, 64 output channels, power-of-two maps of 16 .. 64 pixels width, whole
 // 256-pixel tiles inside one image
 bool rg_convp_supported(int M, int Ncols, int Cin, int Hs, int Ws) {
-#ifdef RG_HALF_F16
-  // The fp16 build does not use this kernel: its MFMAs are inline asm whose hazards were closed by measurement for the bf16
-  // instruction stream (DESIGN: "two latent hazards"); with the fp16 conversions in the epilogue the statistics variant wrote
-  // wrong outputs (found by the layer-by-layer comparison against the fp32 kernels, 2.7e-1 on this layer, exact with the
-  // implicit-GEMM kernels).  The 128 -> 64 channel transposed conv runs on the gather kernel instead.
-  (void)M; (void)Ncols; (void)Cin; (void)Hs; (void)Ws;
-  return false;
-#endif
   return Ncols == 64 && Cin == 128 && Ws >= 16 && Ws <= 64 && rg_is_pow2(Ws) && rg_is_pow2(Hs) && (Hs * Ws) % 256 == 0 &&
          M % 256 == 0 && M >= 256;
 }

@@ -124,6 +124,7 @@ int rg_conv8_launch(int mode, const void* args, int bm, unsigned gx, unsigned gy
 int rg_conv8n_launch(const void* args, unsigned tiles_m, hipStream_t st);
 // rg_convp.hip: 128 -> 64 channel transposed conv with the input patch resident in LDS
 bool rg_convp_supported(int M, int Ncols, int Cin, int Hs, int Ws);
+constexpr int RG_CONVP_DEFAULT = 1;
 // rg_convd.hip: 64 -> 128 channel stride-2 conv (128-pixel-wide input) with the input's parity planes resident in LDS
 bool rg_convd_supported(int M, int Ncols, int Cin, int Hs, int Ws);
 int rg_convd_stats_rows(int M);

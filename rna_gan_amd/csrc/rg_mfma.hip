@@ -1264,7 +1264,7 @@ static GPlan gather_plan(int mode, bool bf16_out, int M, int Ncols, int Cin, int
   // by default (RNAGAN_NARROW8=1 / rg_set_option("narrow8", 1) selects it); kept as the starting point of a kernel
   // that keeps the input patch resident in LDS instead of re-fetching it per tap.
   // pp: the same layer with the input patch resident in LDS (rg_convp.hip; RNAGAN_CONVP=0: off)
-  if (rg_option("convp", 1) && !has_mask && bf16_out && mode == MODE_UP && nclass == 4 && taps == 4 && Ws > 0 &&
+  if (rg_option("convp", RG_CONVP_DEFAULT) && !has_mask && bf16_out && mode == MODE_UP && nclass == 4 && taps == 4 && Ws > 0 &&
       rg_convp_supported(M, Ncols, Cin, Hs, Ws)) {
     pl.pp = true; pl.nsplit = 1; pl.bm = 256; pl.bn = 64;
     return pl;
@@ -1488,7 +1488,7 @@ int rg_mfma_conv_up(const void* x, const void* wup, void* y, int N, int Ho, int 
 }
 
 bool rg_mfma_conv_up_maskbits_supported(int N, int Ho, int Wo, int O, int I) {
-  return rg_option("convp", 1) && rg_convp_supported(N * Ho * Wo, I, O, Ho, Wo) && (size_t)N * Ho * Wo * O * 2 < 0x7fffff00ull;
+  return rg_option("convp", RG_CONVP_DEFAULT) && rg_convp_supported(N * Ho * Wo, I, O, Ho, Wo) && (size_t)N * Ho * Wo * O * 2 < 0x7fffff00ull;
 }
 
 // ---- fp32 mode, 64-column transposed conv on bf16 planes (rg_conv8f.hip): the 256 x 64 tile of the 2-stage kernel with an fp32

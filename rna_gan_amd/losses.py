@@ -837,7 +837,7 @@ class WassersteinGradientPenalty(DiscriminatorLoss):
     def step(self, generator, discriminator, optimizer_discriminator, real, noise, eps):
         """eps: 1-element float32 device tensor (read inside the graph)."""
         lambd = self.lambd
-        fake = _FAKE.take(generator, (noise,)) if not D_.active() else None
+        fake = _FAKE.take(generator, (noise,)) if (not D_.active() or DP_ROUTE == "whole") else None
         if fake is not None:                  # G(noise) came out of the D-loss step's generator pass
             return _dispatch(self._runner, ("gpf", lambd), _gp_fake_body(generator, discriminator, lambd),
                              [real, fake, eps], generator, discriminator, discriminator, optimizer_discriminator)
@@ -1017,7 +1017,7 @@ class WassersteinGradientPenaltyVAE(DiscriminatorLoss, _VAEMixin):
 
     def step(self, generator, discriminator, optimizer_discriminator, real, rna, u, eps):
         lambd = self.lambd
-        fake = _FAKE.take(generator, (u,)) if not D_.active() else None
+        fake = _FAKE.take(generator, (u,)) if (not D_.active() or DP_ROUTE == "whole") else None
         if fake is not None:                  # G(noise(u)) came out of the D-loss step's generator pass
             return _dispatch(self._runner, ("gpf", lambd), _gp_fake_body(generator, discriminator, lambd),
                              [real, fake, eps], generator, discriminator, discriminator, optimizer_discriminator)

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 from oracle.ops_ref import RefOps
 from rna_gan_amd.engine import ConvW
 
-TOL = {torch.float32: 2e-5, torch.bfloat16: 1.5e-2}
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.5e-2, torch.float16: 2e-3}
 
 
 def _hip(dtype):
@@ -212,19 +212,19 @@ def test_conv8_pingpong_kernel(N, Hi, Wi, I, O, mode, mfma):
             lib.rg_set_option(k, -1)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("blocks", [256, 3])
 @pytest.mark.parametrize("N,Ws", [(1, 16), (3, 16), (2, 32), (1, 64), (5, 64)])
-def test_convp_patch_resident_kernel(N, Ws, blocks):
+def test_convp_patch_resident_kernel(N, Ws, blocks, dtype):
     """The 128 -> 64 channel transposed conv with the input patch resident in LDS (rg_convp.hip), all three image widths,
     one and several tiles per workgroup (blocks = 3: persistent loop with the cross-tile prefetch): plain, BatchNorm partial
     sums, fused LeakyReLU mask from PACKED sign bits (rg_sign_pack), folded affine -- against the torch twin, and
     bit-identical to the implicit-GEMM kernel it replaces."""
     from rna_gan_amd import _abi
-    lib = _abi.load()
-    dtype = torch.bfloat16
     ref, hip = RefOps(dtype), _hip(dtype)
+    lib = hip.lib                                            # (the fp16 build is a library of its own, with its own option table)
     O, I = 128, 64
-    assert lib.rg_conv_up_maskbits_supported(N, Ws, Ws, O, I, _abi.RG_BF16, 0) == 1
+    assert lib.rg_conv_up_maskbits_supported(N, Ws, Ws, O, I, hip.H16, 0) == 1
     w = rnd((O, I, 4, 4), 1, (2.0 / (O * 4)) ** 0.5)
     cr, ch = cwpair_tm(w)
     g = rnd((N, Ws, Ws, O), 3).to(dtype)
