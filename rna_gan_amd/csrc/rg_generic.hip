@@ -1159,7 +1159,9 @@ typedef __bf16 bx_bf16x8 __attribute__((ext_vector_type(8)));
 struct BxSplit { unsigned short h, m, l; };
 __device__ __forceinline__ BxSplit bx_split(float v) {
   const __bf16 h = (__bf16)v;                   // v_cvt_pk_bf16_f32: round to nearest even
-  const float r1 = v - (float)h;
+  const float hf = (float)h;
+  // a non-finite h (v = +-inf / NaN, or |v| above the largest bf16) keeps its class: residuals 0, not inf - inf = NaN
+  const float r1 = __builtin_fabsf(hf) <= 3.38953139e38f ? v - hf : 0.f;
   const __bf16 m = (__bf16)r1;
   const float r2 = r1 - (float)m;
   const __bf16 l = (__bf16)r2;

@@ -212,6 +212,26 @@ def test_conv8_pingpong_kernel(N, Hi, Wi, I, O, mode, mfma):
             lib.rg_set_option(k, -1)
 
 
+def test_f32_mode_infinity_stays_infinity():
+    """fp32 mode forms products from three-way bf16 splits (f32mma = 2, and the plane kernels): an infinite operand keeps its class
+    (h = inf, residuals 0) instead of turning into inf - inf = NaN, so a row with one +inf comes out as +-inf like in IEEE fp32
+    (ADVICE round 5)."""
+    hip = _hip(torch.float32)
+    lx, lw = rnd((256, 512), 7), rnd((256, 512), 8, 0.05)
+    lw[lw == 0] = 0.01
+    lx[3, 7] = float("inf")
+    out = hip.linear_affine_act(dev(lx), dev(lw), None, None, 1.0).cpu()
+    ref = lx @ lw.t()
+    assert torch.isinf(out[3]).all() and torch.equal(torch.sign(out[3]), torch.sign(ref[3]))
+    rest = torch.cat([out[:3], out[4:]])
+    assert torch.isfinite(rest).all()
+    x = rnd((4, 128, 128, 64), 2)
+    x[1, 5, 9, 3] = float("-inf")
+    _, ch = cwpair_tm(rnd((128, 64, 4, 4), 1, 0.05))
+    y = hip.conv_down(dev(x), ch).cpu()
+    assert not torch.isnan(y).any() and torch.isinf(y[1]).any() and torch.isfinite(y[0]).all() and torch.isfinite(y[2:]).all()
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("blocks", [256, 3])
 @pytest.mark.parametrize("N,Ws", [(1, 16), (3, 16), (2, 32), (1, 64), (5, 64)])
