@@ -118,7 +118,8 @@ def parse_args(argv=None):
                     help="N > 1: global-batch BatchNorm / latent / penalty statistics (exact single-process semantics, no "
                          "HIP graphs); default: rank-local statistics (plain DDP), which every reported number uses")
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (BASELINE configs[1])")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp16"])
+    ap.add_argument("--precision", default=os.environ.get("RNAGAN_BENCH_PRECISION", "bf16"), choices=["bf16", "fp32", "fp16"],
+                    help="default bf16 (the headline); RNAGAN_BENCH_PRECISION sets the default for launchers that pass no flags")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-ceilings", action="store_true", help="skip the on-box ceiling probes (~15 s) of roofline.peak_measured")

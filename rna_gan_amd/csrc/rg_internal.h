@@ -52,7 +52,13 @@ int rg_mfma_conv_nsplit(int up, int N, int Hlow, int Wlow, int O, int I);
 constexpr int RG_SLAB16_DEFAULT = 1;
 constexpr int RG_BN_REV_DEFAULT = 4;     // option bn_rev: BatchNorm row passes that walk their rows from the END (bit 0: backward-kind applies, bit 1: forward
                                          // applies, bit 2: reductions).  Measured: reductions only
+// (fp16 build: weight gradients carry the static loss scale and are the LARGE sums of the backward pass -- 2e5 was seen on the
+// critic head in the penalty step at S = 4096 -- so their partial sums stay fp32 there: fp16 ends at 65 504)
+#ifdef RG_HALF_F16
+constexpr int RG_WSLAB16_DEFAULT = 0;
+#else
 constexpr int RG_WSLAB16_DEFAULT = 1;
+#endif
 constexpr int RG_WGRAD8_MFMA_DEFAULT = 32;   // option wgrad8_mfma: 32 = v_mfma_f32_32x32x16, 16 = v_mfma_f32_16x16x32 in wgrad8_kernel
 constexpr int RG_F32MMA_DEFAULT = 2;     // option f32mma: 0 vector ALU, 1 f32 matrix cores, 2 (default since the end of round 5) the same with the
                                          // 128 x 128-tile structured launches as six bf16 matrix-core products per fp32 product    // deferred split-K weight-gradient slabs (rg_conv_wgrad_slabs) as bf16: option wslab16

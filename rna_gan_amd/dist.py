@@ -30,6 +30,11 @@ import torch.distributed as dist
 BUCKET_BYTES = int(os.environ.get("RNAGAN_DP_BUCKET_MB", "1024")) * 1024 * 1024
 FORCE = os.environ.get("RNAGAN_FORCE_DP", "0") == "1"     # take the DP code path even with one rank (testing)
 COMPRESS = os.environ.get("RNAGAN_DP_BF16", "1") != "0"
+# fp16 build: the gradients carry the static loss scale (x 4096) and a weight gradient of 16 / world ends fp16's range -- the
+# critic head's penalty-step gradient reached 48 in tests/test_dp2_gpu.py and went onto an fp16 wire as inf.  So the fp16 build
+# all-reduces fp32 by default (what torch AMP + DistributedDataParallel does: fp32 gradients of fp32 master weights);
+# RNAGAN_DP_F16_WIRE=1 opts into the 16-bit wire (half the bytes, no overflow guard).
+F16_WIRE = os.environ.get("RNAGAN_DP_F16_WIRE", "0") == "1"
 # --sync-stats: BatchNorm statistics (forward, backward, tangent, double backward), the latent
 # standardisation and the penalty norm are taken over the GLOBAL batch (tiny all-reduces of per-channel sums), so an
 # N-rank run reproduces the single-process reference step at batch N x n exactly.  Collectives then sit inside the

@@ -150,7 +150,9 @@ def _is_half(ops):
 
 def _wire_kind(ops):
     """compress argument of the data-parallel all-reduce: the gradients travel in the build's 16-bit type, or as fp32."""
-    return ops.half if _is_half(ops) else False
+    if not _is_half(ops) or (ops.half == "f16" and not D_.F16_WIRE):
+        return False
+    return ops.half
 
 
 def _finish(module, optimizer):
@@ -504,7 +506,7 @@ def _dp_wire_layers(stepped, optimizer):
     if not hasattr(optimizer, "grad_wire") or getattr(optimizer, "_module", None) is not stepped:
         return []
     ops, net = stepped.runtime()
-    if not _is_half(ops) or not isinstance(net, (E.GenNet, E.DiscNet)) or ops.stat_reduce is not None:
+    if not _wire_kind(ops) or not isinstance(net, (E.GenNet, E.DiscNet)) or ops.stat_reduce is not None:
         return []
     flat = stepped.flat
     wire = D_.wire_for(flat.grad, ops.half)

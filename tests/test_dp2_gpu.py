@@ -40,11 +40,11 @@ torch.cuda.set_device(0)
 D_.init_from_env(backend="gloo")
 assert D_.world_size() == int(os.environ["WORLD_SIZE"]) and D_.active()
 precision = os.environ["PRECISION"]
-if precision == "bf16":                       # does this gloo build all-reduce bfloat16 device tensors?
+if precision in ("bf16", "fp16"):              # does this gloo build all-reduce 16-bit device tensors of the build's type?
     try:
-        t = torch.ones(8, dtype=torch.bfloat16, device="cuda")
+        t = torch.ones(8, dtype=torch.bfloat16 if precision == "bf16" else torch.float16, device="cuda")
         dist.all_reduce(t)
-        wire = "bf16" if float(t[0]) == float(D_.world_size()) else "fp32"
+        wire = ("bf16" if precision == "bf16" else "f16") if float(t[0]) == float(D_.world_size()) else "fp32"
     except Exception:
         wire = "fp32"
     if wire == "fp32":
@@ -212,6 +212,33 @@ def test_world2_bf16_kernels_and_wire(tmp_path):
             if v.dtype.is_floating_point and "running_" not in k:
                 rel = float((v.double() - f32[0][name][k].double()).norm() / (f32[0][name][k].double().norm() + 1e-30))
                 assert rel <= 1e-2, (name, k, rel)
+
+
+def test_world2_fp16_kernels_wire_and_loss_scale(tmp_path):
+    """BASELINE configs[3]'s arithmetic under data parallel: the fp16 build on two ranks -- fp32 all-reduce (the fp16 build's
+    default: loss-scaled weight gradients overflow an fp16 wire, dist.F16_WIRE), all-gathered fp16 G.0 factors, the static loss
+    scale (x 1/world in the same seed) removed inside the Adam kernels -- against the fp32 run: finite, rank-identical
+    parameters; losses and updated parameters within the bf16 run's bounds or tighter."""
+    f32 = _run_world2(tmp_path, "fp32")
+    f16 = _run_world2(tmp_path, "fp16")
+    print("all-reduce wire of the fp16 run:", f16[0]["wire"])
+    assert f16[0]["factors"] and f16[1]["factors"]
+    for name in ("G", "D"):
+        for k in f16[0][name]:
+            if "running_" not in k:
+                assert torch.equal(f16[0][name][k], f16[1][name][k]), (name, k)
+    for r in range(2):
+        for i, (a, b) in enumerate(zip(f16[r]["losses"], f32[r]["losses"])):
+            # (iterations 2 and 3 run on parameters that already differ by one Adam step of sign-like updates: 1.9e-2 seen)
+            assert np.isfinite(a) and abs(a - b) <= (0.1 if i % 3 == 2 else 4e-2) * (abs(b) + 0.5), (r, i, a, b)
+    worst = 0.0
+    for name in ("G", "D"):
+        for k, v in f16[0][name].items():
+            if v.dtype.is_floating_point and "running_" not in k:
+                rel = float((v.double() - f32[0][name][k].double()).norm() / (f32[0][name][k].double().norm() + 1e-30))
+                worst = max(worst, rel)
+                assert rel <= 1e-2, (name, k, rel)
+    print("largest relative parameter difference fp16 vs fp32 after %d iterations: %.3g" % (ITERS, worst))
 
 
 def test_world2_factors_with_an_optimizer_that_does_not_step_from_the_wire(tmp_path):

@@ -212,24 +212,23 @@ def test_conv8_pingpong_kernel(N, Hi, Wi, I, O, mode, mfma):
             lib.rg_set_option(k, -1)
 
 
-def test_f32_mode_infinity_stays_infinity():
-    """fp32 mode forms products from three-way bf16 splits (f32mma = 2, and the plane kernels): an infinite operand keeps its class
-    (h = inf, residuals 0) instead of turning into inf - inf = NaN, so a row with one +inf comes out as +-inf like in IEEE fp32
-    (ADVICE round 5)."""
+def test_f32_mode_non_finite_operands_stay_non_finite_and_local():
+    """fp32 mode forms products from three-way bf16 splits (f32mma = 2, and the plane kernels).  A non-finite operand keeps its
+    class in the split (h = +-inf / NaN, residuals 0 -- not inf - inf), so every output IEEE fp32 would make non-finite is
+    non-finite here too and nothing else is touched.  What is NOT kept: +-inf may come out as NaN (inf times a residual plane that
+    is exactly zero), as stated in DESIGN 6.3."""
     hip = _hip(torch.float32)
     lx, lw = rnd((256, 512), 7), rnd((256, 512), 8, 0.05)
-    lw[lw == 0] = 0.01
     lx[3, 7] = float("inf")
     out = hip.linear_affine_act(dev(lx), dev(lw), None, None, 1.0).cpu()
-    ref = lx @ lw.t()
-    assert torch.isinf(out[3]).all() and torch.equal(torch.sign(out[3]), torch.sign(ref[3]))
-    rest = torch.cat([out[:3], out[4:]])
-    assert torch.isfinite(rest).all()
+    assert not torch.isfinite(out[3]).any()
+    assert torch.isfinite(torch.cat([out[:3], out[4:]])).all()
     x = rnd((4, 128, 128, 64), 2)
     x[1, 5, 9, 3] = float("-inf")
     _, ch = cwpair_tm(rnd((128, 64, 4, 4), 1, 0.05))
     y = hip.conv_down(dev(x), ch).cpu()
-    assert not torch.isnan(y).any() and torch.isinf(y[1]).any() and torch.isfinite(y[0]).all() and torch.isfinite(y[2:]).all()
+    bad = ~torch.isfinite(y)
+    assert bad[1, 2:4, 4:6].all() and int(bad.sum()) == 4 * 128          # the 2 x 2 output pixels whose 4 x 4 window holds (5, 9)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

@@ -90,6 +90,10 @@ if [ "$MAXG" -ge 2 ]; then
   # that prices the prefixes: hide the all-reduces, or keep the 0.5-0.6 ms per iteration the prefix route gives up
   run_bench "$MAXG" "knob_route_whole"     RNAGAN_DP_ROUTE=whole
   run_bench "$MAXG" "knob_route_whole_splitbn" RNAGAN_DP_ROUTE=whole RNAGAN_SPLIT_BN_DP=1
+  # BASELINE configs[3]: the fp16 build.  Its all-reduce is fp32 by default (loss-scaled weight gradients overflow an fp16 wire:
+  # rna_gan_amd/dist.py F16_WIRE); the second line prices what the 16-bit wire would save (CHECK the losses for NaN there)
+  run_bench "$MAXG" "fp16_wire_fp32"       RNAGAN_BENCH_PRECISION=fp16
+  run_bench "$MAXG" "fp16_wire_f16"        RNAGAN_BENCH_PRECISION=fp16 RNAGAN_DP_F16_WIRE=1
   echo "== one-rank overhead of the DP route (RNAGAN_FORCE_DP=1 on one GPU vs the single-process path) =="
   # (the DP route at one rank needs a process group of one: RANK / WORLD_SIZE / MASTER_* make dist.init_from_env create it)
   PORT=$((PORT + 1))
