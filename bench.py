@@ -429,6 +429,10 @@ def main(argv=None):
                    "losses_last_step": last_losses, "hip_graphs": out_graphs and not D_.sync_stats(),
                    "dp_statistics": "global (sync-stats)" if D_.sync_stats() else "rank-local (DDP)"},
     }
+    if D_.active():
+        ops_h = "f16" if args.precision == "fp16" else "bf16"
+        out["config"]["dp_route"] = _PL.DP_ROUTE
+        out["config"]["dp_wire"] = "fp32" if (args.precision == "fp32" or not D_.COMPRESS or (ops_h == "f16" and not D_.F16_WIRE)) else ops_h
     if not args.step_plugin:
         # frozen-betaVAE encodes per timed iteration: 1 (the three plugins share one encode per batch, losses._LatentCache;
         # the reference encodes three times, src/wgan_loss.py:96-97, :223-224, :353-354)

@@ -28,16 +28,17 @@ echo "devices visible: $NDEV (asked for up to $MAXG)"
 if [ "$NDEV" -lt 2 ]; then echo "needs >= 2 GPUs: only the N = 1 line will be produced"; fi
 [ "$MAXG" -gt "$NDEV" ] && MAXG=$NDEV
 PORT=29611
+EXTRA=""; [ "${DP_FIRST_RUN_SELFTEST:-0}" = "1" ] && EXTRA="--no-roofline --no-ceilings"     # (the self-test checks that the lines run, not their fractions)
 
 run_bench () {   # run_bench N tag [ENV=VAL ...]
   local n=$1 tag=$2; shift 2
   local f="$OUT/${tag}.json"
   if [ "$n" -eq 1 ]; then
-    env "$@" python3 bench.py --gpus 1 --steps "$STEPS" --warmup "$WARM" --no-cpu-baseline --no-extras > "$f" 2> "$OUT/${tag}.err"
+    env "$@" python3 bench.py --gpus 1 --steps "$STEPS" --warmup "$WARM" --no-cpu-baseline --no-extras $EXTRA > "$f" 2> "$OUT/${tag}.err"
   else
     PORT=$((PORT + 1))
     env "$@" python3 -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 --master-port "$PORT" \
-        bench.py --gpus "$n" --steps "$STEPS" --warmup "$WARM" --no-cpu-baseline --no-extras > "$f" 2> "$OUT/${tag}.err"
+        bench.py --gpus "$n" --steps "$STEPS" --warmup "$WARM" --no-cpu-baseline --no-extras $EXTRA > "$f" 2> "$OUT/${tag}.err"
   fi
   local rc=$?
   if [ $rc -ne 0 ]; then echo "  $tag: bench.py exited $rc (see $OUT/${tag}.err)"; tail -3 "$OUT/${tag}.err"; return $rc; fi
@@ -52,6 +53,20 @@ if n > 1:
 print("  %-28s N=%d  %9.1f imgs/s  %7.3f ms/iteration  roofline.frac=%s" % (
     tag, n, rec["value"], rec["ms_per_step"], (rec.get("roofline") or {}).get("frac")))
 EOF
+}
+
+# DP_FIRST_RUN_SELFTEST=1: the kit checks ITSELF on a one-GPU box -- every knob line below runs through the data-parallel route
+# on a one-rank RCCL group (RNAGAN_FORCE_DP=1), so a knob that no longer exists or a route that no longer runs fails here
+# (tests/test_dp_first_run_gpu.py) and not on the first multi-GPU node.  The numbers of such a run mean nothing.
+SELFTEST=${DP_FIRST_RUN_SELFTEST:-0}
+knob () {   # knob tag [ENV=VAL ...]
+  local tag=$1; shift
+  if [ "$SELFTEST" = "1" ]; then
+    PORT=$((PORT + 1))
+    run_bench 1 "$tag" RNAGAN_FORCE_DP=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=$PORT "$@"
+  else
+    run_bench "$MAXG" "$tag" "$@"
+  fi
 }
 
 echo "== 1. RCCL bus bandwidth for the step's messages =="
@@ -78,22 +93,22 @@ if 1 in vals:
         print("  N=%d: %.1f imgs/s, efficiency vs N=1: %.3f" % (n, v, v / (n * vals[1])))
 EOF
 
-if [ "$MAXG" -ge 2 ]; then
+if [ "$MAXG" -ge 2 ] || [ "$SELFTEST" = "1" ]; then
   echo "== 3. knobs at N=$MAXG (one change each; compare with scale_$MAXG above) =="
-  run_bench "$MAXG" "knob_overlap0"        RNAGAN_DP_OVERLAP=0
-  run_bench "$MAXG" "knob_g0factors0"      RNAGAN_DP_G0_FACTORS=0
-  run_bench "$MAXG" "knob_splitbn_dp1"     RNAGAN_SPLIT_BN_DP=1
-  run_bench "$MAXG" "knob_nchannels8"      NCCL_MAX_NCHANNELS=8
-  run_bench "$MAXG" "knob_nchannels16"     NCCL_MAX_NCHANNELS=16
-  run_bench "$MAXG" "knob_prefix_bwd1"     RNAGAN_DP_PREFIX_BWD=1      # round 3's prefix (whole backward of the real half): longer cover
+  knob "knob_overlap0"        RNAGAN_DP_OVERLAP=0
+  knob "knob_g0factors0"      RNAGAN_DP_G0_FACTORS=0
+  knob "knob_splitbn_dp1"     RNAGAN_SPLIT_BN_DP=1
+  knob "knob_nchannels8"      NCCL_MAX_NCHANNELS=8
+  knob "knob_nchannels16"     NCCL_MAX_NCHANNELS=16
+  knob "knob_prefix_bwd1"     RNAGAN_DP_PREFIX_BWD=1      # round 3's prefix (whole backward of the real half): longer cover
   # route "whole": the single process's train_op bodies (double batch, shared generator pass), collectives NOT hidden -- the A/B
   # that prices the prefixes: hide the all-reduces, or keep the 0.5-0.6 ms per iteration the prefix route gives up
-  run_bench "$MAXG" "knob_route_whole"     RNAGAN_DP_ROUTE=whole
-  run_bench "$MAXG" "knob_route_whole_splitbn" RNAGAN_DP_ROUTE=whole RNAGAN_SPLIT_BN_DP=1
+  knob "knob_route_whole"     RNAGAN_DP_ROUTE=whole
+  knob "knob_route_whole_splitbn" RNAGAN_DP_ROUTE=whole RNAGAN_SPLIT_BN_DP=1
   # BASELINE configs[3]: the fp16 build.  Its all-reduce is fp32 by default (loss-scaled weight gradients overflow an fp16 wire:
   # rna_gan_amd/dist.py F16_WIRE); the second line prices what the 16-bit wire would save (CHECK the losses for NaN there)
-  run_bench "$MAXG" "fp16_wire_fp32"       RNAGAN_BENCH_PRECISION=fp16
-  run_bench "$MAXG" "fp16_wire_f16"        RNAGAN_BENCH_PRECISION=fp16 RNAGAN_DP_F16_WIRE=1
+  knob "fp16_wire_fp32"       RNAGAN_BENCH_PRECISION=fp16
+  knob "fp16_wire_f16"        RNAGAN_BENCH_PRECISION=fp16 RNAGAN_DP_F16_WIRE=1
   echo "== one-rank overhead of the DP route (RNAGAN_FORCE_DP=1 on one GPU vs the single-process path) =="
   # (the DP route at one rank needs a process group of one: RANK / WORLD_SIZE / MASTER_* make dist.init_from_env create it)
   PORT=$((PORT + 1))
