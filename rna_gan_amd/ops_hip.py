@@ -296,13 +296,16 @@ class HipOps:
     def _planes(self, t):
         """bf16 planes [3][numel] of an fp32 tensor (v = h + m + l exactly, rg_split_planes), cached on the tensor object: an
         activation is split once for the conv that consumes it and for the weight gradient that reads it again."""
-        p = getattr(t, "_rg_planes", None)
-        if p is None:
+        # (keyed by the tensor's version counter: a torch in-place op on it invalidates the planes.  The library's own kernels
+        # write through raw pointers without touching that counter -- every op of this class returns a FRESH tensor, and a caller
+        # that overwrites an activation through the C ABI has to `del t._rg_planes`)
+        c = getattr(t, "_rg_planes", None)
+        if c is None or c[0] != t._version:
             assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() % 8 == 0
-            p = torch.empty((3, t.numel()), dtype=torch.bfloat16, device=self.device)
+            p = c[1] if c is not None else torch.empty((3, t.numel()), dtype=torch.bfloat16, device=self.device)
             check(self.lib.rg_split_planes(_ptr(t), _ptr(p), t.numel(), self.stream), "rg_split_planes")
-            t._rg_planes = p
-        return p
+            c = t._rg_planes = (t._version, p)
+        return c[1]
 
     def _plane_packs(self, cw: ConvW):
         """(planes of wdn[O][16][I], planes of wup[16][I][O]) of a tap-major fp32 master, rebuilt when its version changes."""

@@ -67,6 +67,23 @@ def test_conv_down_up_on_planes(products, tol, N, H, I, O, monkeypatch):
         assert float((gm.double() - refm).abs().max()) <= tol * float(refx.abs().max())
 
 
+def test_cached_planes_follow_in_place_changes(monkeypatch):
+    """The planes of an activation are cached on the tensor (split once for the conv and for the weight gradient that reads it
+    again); a torch in-place op on the tensor bumps its version counter and the planes are split again."""
+    ops = _ops(6, monkeypatch)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(8, 32, 32, 128, generator=g).cuda()
+    wt = (torch.randn(256, 4, 4, 128, generator=g) * 0.05).cuda()
+    cw = ConvW(wt, None, torch.zeros_like(wt), None, "OHWI")
+    y1 = ops.conv_down(x, cw)
+    planes = x._rg_planes[1]
+    y1b = ops.conv_down(x, cw)
+    assert x._rg_planes[1] is planes and torch.equal(y1, y1b)
+    x.mul_(2.0)
+    y2 = ops.conv_down(x, cw)
+    assert torch.equal(y2, 2.0 * y1)                         # (a power of two: exact)
+
+
 @pytest.mark.parametrize("products,tol", [(6, 2e-6), (3, 6e-5)])
 @pytest.mark.parametrize("N,H,I,O", [(8, 32, 128, 256),      # 256 x 256 tiles (wgrad8_kernel)
                                       (8, 64, 64, 128)])      # 128 x 512 tiles (wgrad8n_kernel: the layers with 128 low-side channels)
