@@ -242,7 +242,7 @@ def windows(curve, k=5):
 
 # ---------------------------------------------------------------------------------------------- the A/B
 def run_ab(loss_type, size=64, step=64, enc=2048, iters=500, batch=64, n_eval=2048, rna_features=512, n_slides=64,
-           tiles_per_slide=48, seeds=(11, 12), device="cuda:0", inception=True, log=print):
+           tiles_per_slide=48, seeds=(11, 12), device="cuda:0", inception=True, log=print, b_precision="bf16"):
     device = torch.device(device)
     train = make_slides(n_slides, tiles_per_slide, size, rna_features, seed=1)
     held = make_slides(max(8, n_eval // tiles_per_slide + 1), tiles_per_slide, size, rna_features, seed=2)
@@ -250,14 +250,16 @@ def run_ab(loss_type, size=64, step=64, enc=2048, iters=500, batch=64, n_eval=20
     log("%s: %d training tiles of %d slides, %d held-out tiles; %d iterations at batch %d, %d x %d" % (
         loss_type, train[0].shape[0], n_slides, held_imgs.shape[0], iters, batch, size, size))
     runs = {}
-    for tag, prec, seed in (("A_fp32_s1", "fp32", seeds[0]), ("B_bf16_s1", "bf16", seeds[0]), ("C_fp32_s2", "fp32", seeds[1])):
+    # (arm B: the 16-bit mode under test -- bf16, the benchmarked one, or fp16 with its static loss scale, BASELINE configs[3];
+    # the record keeps the key names of the bf16 table and says which mode B was in "b_precision")
+    for tag, prec, seed in (("A_fp32_s1", "fp32", seeds[0]), ("B_bf16_s1", b_precision, seeds[0]), ("C_fp32_s2", "fp32", seeds[1])):
         runs[tag] = train_run(loss_type, prec, seed, train, size, step, enc, iters, batch, device, log)
     D_ref = _fp32_twin(runs["A_fp32_s1"][1], size, step, enc, device)
     sets = {tag: sample(G, pl, loss_type, held_rna, n_eval, size, step, enc, 64, device, seed=99)
             for tag, (G, _, pl, _) in runs.items()}
     sets["real_heldout"] = held_imgs
     rec = {"loss_type": loss_type, "size": size, "iters": iters, "batch": batch, "n_eval": int(held_imgs.shape[0]),
-           "step_channels": step, "encoding_dims": enc, "seeds": list(seeds),
+           "step_channels": step, "encoding_dims": enc, "seeds": list(seeds), "b_precision": b_precision,
            "loss_curves_windowed_means[g,d,gp]": {tag: windows(r[3]) for tag, r in runs.items()}, "frechet": {}}
     extractors = [("d_trunk(A)", lambda x: trunk_features(D_ref, x))]
     if inception:
@@ -278,7 +280,8 @@ def run_ab(loss_type, size=64, step=64, enc=2048, iters=500, batch=64, n_eval=20
 
 
 def markdown(recs):
-    lines = ["| loss type | features | FD(bf16, fp32) same seed | FD(fp32 seed 2, fp32 seed 1) | ratio | FD(fp32 s1, real) | FD(bf16 s1, real) | FD(fp32 s2, real) |",
+    b = recs[0].get("b_precision", "bf16") if recs else "bf16"
+    lines = ["| loss type | features | FD(%s, fp32) same seed | FD(fp32 seed 2, fp32 seed 1) | ratio | FD(fp32 s1, real) | FD(%s s1, real) | FD(fp32 s2, real) |" % (b, b),
              "|---|---|---|---|---|---|---|---|"]
     for r in recs:
         for name, row in r["frechet"].items():
@@ -301,12 +304,13 @@ def main():
     ap.add_argument("--tiles-per-slide", type=int, default=48)
     ap.add_argument("--rna-features", type=int, default=512)
     ap.add_argument("--no-inception", action="store_true")
+    ap.add_argument("--b-precision", default="bf16", choices=["bf16", "fp16"], help="the 16-bit mode of arm B")
     ap.add_argument("--out", default="gpurun_out/train_quality_ab.json")
     args = ap.parse_args()
     log = lambda *a: print(*a, file=sys.stderr, flush=True)
     recs = [run_ab(lt, size=args.size, step=args.step, enc=args.enc, iters=args.iters, batch=args.batch, n_eval=args.n_eval,
                    rna_features=args.rna_features, n_slides=args.n_slides, tiles_per_slide=args.tiles_per_slide,
-                   inception=not args.no_inception, log=log) for lt in args.loss_types.split(",")]
+                   inception=not args.no_inception, log=log, b_precision=args.b_precision) for lt in args.loss_types.split(",")]
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     with open(args.out, "w") as f:
         json.dump(recs, f, indent=1)
