@@ -61,7 +61,9 @@ const char* rg_last_error(void);
  * weight-gradient slabs fp32; "bn_rev": which BatchNorm row passes walk their rows from the end (bit 2, the default: reductions); "convd": 0 sends the 64 -> 128 channel stride-2 conv back from the parity-plane-resident kernel to the
  * implicit-GEMM one, "convd_blocks": its persistent grid; "slab16": 0 keeps the split-K partial tiles of the conv launches fp32;
  * "skinny128": 0 sends the image-side layers of 256 x 256 images back
- * from the control-flow-free row kernels to the general row-staged ones).  An option set here overrides the environment; value < 0 clears the override.  Returns RG_EINVAL for an
+ * from the control-flow-free row kernels to the general row-staged ones; "wgrad8_mfma": 32 (default) / 16 = the matrix instruction
+ * shape of the 256 x 256-tile weight-gradient kernel, bit-identical results; "narrow32": 0 sends 3 x 3 convs of <= 32 output columns
+ * back to the kernel that issues MFMAs for all 64 columns of its tile).  An option set here overrides the environment; value < 0 clears the override.  Returns RG_EINVAL for an
  * unknown name.  Not thread-safe against concurrent launches. */
 int rg_set_option(const char* name, int value);
 

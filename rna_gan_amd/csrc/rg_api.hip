@@ -24,7 +24,7 @@ extern "C" const char* rg_last_error(void) { return g_err; }
 // ---- kernel-selection knobs: override table in front of the RNAGAN_* environment variables
 static const char* const g_opt_names[] = {"conv8", "conv8_blocks", "conv_tile", "xcd", "class_fast", "wgrad_blocks",
                                           "wgrad8", "conv_v1", "stream_tile", "narrow8", "conv8_mfma", "conv8_epi", "wgrad8_blocks", "korder", "convp", "convp_blocks",
-                                          "fp8_mx", "wgrad8n", "f32mma", "convd", "convd_blocks", "skinny128", "slab16", "wslab16", "bn_rev", "wgrad8_mfma"};
+                                          "fp8_mx", "wgrad8n", "f32mma", "convd", "convd_blocks", "skinny128", "slab16", "wslab16", "bn_rev", "wgrad8_mfma", "narrow32"};
 constexpr int G_NOPT = sizeof(g_opt_names) / sizeof(g_opt_names[0]);
 static int g_opt_override[G_NOPT];      // value + 1; 0 = not set
 static int g_opt_env[G_NOPT];           // cached environment value + 1; 0 = not read yet; -1 = variable absent

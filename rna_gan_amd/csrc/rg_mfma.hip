@@ -255,8 +255,11 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(GArgs g) {
 // for 64-channel outputs).  SPLITK: blockIdx.z owns a k-tile range and writes fp32 partials.
 // NP > 0: fp32 operands as K-concatenated bf16 planes (rg_conv8f.hip has the scheme; flat k-tile -> plane pair fastest), used
 // with EPI_LINEAR (fp32 result) for the 64-column transposed conv of the fp32 mode, which the 8-wave kernel's tiles do not cover.
-template <int MODE, int EPI, int BM, int BN, int NSTAGE, int NT, int WTM = 64, int NP = 0>
+// NJ: live 32-column sub-tiles of a wave's 64 columns.  1 = outputs of <= 32 columns (the resize-convolution generator's image layer:
+// 3 channels in an 8-column row): the second sub-tile's B fragments are not read and its MFMAs not issued (they would multiply zeros).
+template <int MODE, int EPI, int BM, int BN, int NSTAGE, int NT, int WTM = 64, int NP = 0, int NJ = 2>
 __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT == 256) ? 2 : 1) void gather_gemm_dma_kernel(G2Args a2) {
+  static_assert(NJ == 2 || (NJ == 1 && BN == 64), "NJ = 1: one wave column, first 32 columns live");
   constexpr int WN = BN / 64;                                // waves along N (WTM x 64 wave tiles)
   constexpr int TI = WTM / 32;                               // 32-row MFMA sub-tiles per wave (2 or 4)
   constexpr int RPI = NT / 8;                                // rows covered by one block-wide load instruction
@@ -456,15 +459,29 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
     RG_DSR(qa[buf][0], fas[kk], 0);                       \
     RG_DSR(qb[buf][0], fbs[kk], 0);                       \
     RG_DSR(qa[buf][1], fas[kk], 4096);                    \
-    RG_DSR(qb[buf][1], fbs[kk], 4096);                    \
+    if constexpr (NJ == 2) RG_DSR(qb[buf][1], fbs[kk], 4096); \
     if constexpr (TI == 4) {                              \
       RG_DSR(qa[buf][2], fas[kk], 8192);                  \
       RG_DSR(qa[buf][3], fas[kk], 12288);                 \
     }                                                     \
   } while (0)
+// (cnt4 / cnt6: reads of the NEXT step that may stay in flight with TI = 2 / TI = 4 and both column sub-tiles; with NJ = 1 a step
+// has one read fewer, so "next step in flight" is 3 / 5; 0 = everything landed)
 #define RG_WAIT(buf, cnt4, cnt6)                                                                                    \
   do {                                                                                                              \
-    if constexpr (TI == 4)                                                                                          \
+    if constexpr (NJ == 1 && TI == 2) {                                                                             \
+      if constexpr (cnt4 == 0)                                                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qa[buf][0]), "+v"(qa[buf][1]), "+v"(qb[buf][0])::"memory");      \
+      else                                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(qa[buf][0]), "+v"(qa[buf][1]), "+v"(qb[buf][0])::"memory");      \
+    } else if constexpr (NJ == 1) {                                                                                 \
+      if constexpr (cnt6 == 0)                                                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)"                                                                         \
+                     : "+v"(qa[buf][0]), "+v"(qa[buf][1]), "+v"(qa[buf][2]), "+v"(qa[buf][3]), "+v"(qb[buf][0])::"memory"); \
+      else                                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(5)"                                                                         \
+                     : "+v"(qa[buf][0]), "+v"(qa[buf][1]), "+v"(qa[buf][2]), "+v"(qa[buf][3]), "+v"(qb[buf][0])::"memory"); \
+    } else if constexpr (TI == 4)                                                                                   \
       asm volatile("s_waitcnt lgkmcnt(" #cnt6 ")"                                                                   \
                    : "+v"(qa[buf][0]), "+v"(qa[buf][1]), "+v"(qa[buf][2]), "+v"(qa[buf][3]), "+v"(qb[buf][0]),      \
                      "+v"(qb[buf][1])::"memory");                                                                   \
@@ -473,7 +490,7 @@ __global__ __launch_bounds__(NT, (NSTAGE * (BM + BN) * 128 <= 80 * 1024 && NT ==
                    : "+v"(qa[buf][0]), "+v"(qa[buf][1]), "+v"(qb[buf][0]), "+v"(qb[buf][1])::"memory");             \
   } while (0)
 #define RG_MFMAS(buf)                                                                                              \
-  _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] =         \
+  _Pragma("unroll") for (int i = 0; i < TI; ++i) _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] =        \
       rg_mfma_h16_32x32x16(__builtin_bit_cast(h16x8_t, qa[buf][i]),                            \
                                               __builtin_bit_cast(h16x8_t, qb[buf][j]), acc[i][j], 0, 0, 0)
   constexpr int WAIT_A = vmcnt_imm((A_LD + B_LD) * (NSTAGE > 2 ? NSTAGE - 2 : 0));
@@ -1410,7 +1427,14 @@ static int launch_gather2(const char* name, GArgs& g, int nclass, long long rows
     if constexpr (EPI == EPI_LINEAR && MODE == MODE_PLAIN)
       hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 64, 128, 3, 128>), grid, dim3(128), 0, st, a2);
   } else if (narrow) {
-    hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 256, 64, 2, 256>), grid, dim3(256), 0, st, a2);
+    bool done = false;
+    if constexpr (MODE == MODE_C3 && EPI == EPI_LINEAR) {
+      if (g.Ncols <= 32 && rg_option("narrow32", 1)) {     // the image layer of the resize-convolution generator (3 of 8 columns)
+        hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 256, 64, 2, 256, 64, 0, 1>), grid, dim3(256), 0, st, a2);
+        done = true;
+      }
+    }
+    if (!done) hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 256, 64, 2, 256>), grid, dim3(256), 0, st, a2);
   } else if (wide) {
     hipLaunchKernelGGL((gather_gemm_dma_kernel<MODE, EPI, 256, 256, 2, 512, 128>), grid, dim3(512), 0, st, a2);
   } else {
