@@ -63,7 +63,9 @@ const char* rg_last_error(void);
  * "skinny128": 0 sends the image-side layers of 256 x 256 images back
  * from the control-flow-free row kernels to the general row-staged ones; "wgrad8_mfma": 32 (default) / 16 = the matrix instruction
  * shape of the 256 x 256-tile weight-gradient kernel, bit-identical results; "narrow32": 0 sends 3 x 3 convs of <= 32 output columns
- * back to the kernel that issues MFMAs for all 64 columns of its tile).  An option set here overrides the environment; value < 0 clears the override.  Returns RG_EINVAL for an
+ * back to the kernel that issues MFMAs for all 64 columns of its tile; "upimg": 0 sends the resize-convolution generator's image
+ * block back to the path that materialises its upsampled + padded input, "upimg_blocks": the fused kernel's grid).  An option set here
+ * overrides the environment; value < 0 clears the override.  Returns RG_EINVAL for an
  * unknown name.  Not thread-safe against concurrent launches. */
 int rg_set_option(const char* name, int value);
 

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "librnagan_hip.so")
 OUT_F16 = os.path.join(HERE, "librnagan_hip_f16.so")
 OBJ = os.path.join(HERE, "csrc", "_obj")
-SOURCES = ["rg_api.hip", "rg_generic.hip", "rg_bn.hip", "rg_misc.hip", "rg_mfma.hip", "rg_conv8.hip", "rg_convp.hip", "rg_convd.hip", "rg_wgrad8.hip", "rg_skinny.hip", "rg_vae.hip", "rg_splitbn.hip", "rg_incep.hip", "rg_g0adam.hip", "rg_probe.hip", "rg_conv8f.hip", "rg_wgrad8f.hip"]
+SOURCES = ["rg_api.hip", "rg_generic.hip", "rg_bn.hip", "rg_misc.hip", "rg_mfma.hip", "rg_conv8.hip", "rg_convp.hip", "rg_convd.hip", "rg_wgrad8.hip", "rg_skinny.hip", "rg_vae.hip", "rg_splitbn.hip", "rg_incep.hip", "rg_g0adam.hip", "rg_upimg.hip", "rg_probe.hip", "rg_conv8f.hip", "rg_wgrad8f.hip"]
 # sources a translation unit #includes besides the headers (rg_probe.hip instantiates the product's conv8_kernel template with
 # its measurement flag from the same source text)
 EXTRA_DEPS = {"rg_probe.hip": ["rg_conv8.hip"], "rg_conv8f.hip": ["rg_conv8.hip"], "rg_wgrad8f.hip": ["rg_wgrad8.hip"]}

@@ -24,7 +24,7 @@ extern "C" const char* rg_last_error(void) { return g_err; }
 // ---- kernel-selection knobs: override table in front of the RNAGAN_* environment variables
 static const char* const g_opt_names[] = {"conv8", "conv8_blocks", "conv_tile", "xcd", "class_fast", "wgrad_blocks",
                                           "wgrad8", "conv_v1", "stream_tile", "narrow8", "conv8_mfma", "conv8_epi", "wgrad8_blocks", "korder", "convp", "convp_blocks",
-                                          "fp8_mx", "wgrad8n", "f32mma", "convd", "convd_blocks", "skinny128", "slab16", "wslab16", "bn_rev", "wgrad8_mfma", "narrow32"};
+                                          "fp8_mx", "wgrad8n", "f32mma", "convd", "convd_blocks", "skinny128", "slab16", "wslab16", "bn_rev", "wgrad8_mfma", "narrow32", "upimg", "upimg_blocks"};
 constexpr int G_NOPT = sizeof(g_opt_names) / sizeof(g_opt_names[0]);
 static int g_opt_override[G_NOPT];      // value + 1; 0 = not set
 static int g_opt_env[G_NOPT];           // cached environment value + 1; 0 = not read yet; -1 = variable absent
@@ -551,6 +551,8 @@ extern "C" int rg_upconv3_fwd(const void* x, const float* w, const float* bias, 
   const bool mfma_ok = dtype == RG_H16 && (out_nchw_f32 ? rg_mfma_upconv3_image_supported(N, H, W, Cin, Cout)
                                                          : rg_mfma_upconv3_supported(N, H, W, Cin, Cout));
   RG_REQUIRE(mfma_ok || algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "upconv3_fwd: shape/dtype not supported by the MFMA kernel");
+  if (mfma_ok && algo != RG_ALGO_GENERIC && out_nchw_f32 && rg_option("upimg", 1) && rg_upimg_fwd_supported(N, H, W, Cin, Cout))
+    return rg_upimg_fwd(x, w, bias, (float*)y, N, H, W, Cin, Cout, rg_stream(stream));     // upsample + pad formed in LDS
   if (mfma_ok && algo != RG_ALGO_GENERIC && out_nchw_f32)
     return rg_mfma_upconv3_image_fwd(x, w, bias, (float*)y, N, H, W, Cin, Cout, ws, ws_bytes, rg_stream(stream));
   if (mfma_ok && algo != RG_ALGO_GENERIC)

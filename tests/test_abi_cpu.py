@@ -57,7 +57,7 @@ def test_kernel_selection_options_are_known():
     an unknown name is RG_EINVAL with a message."""
     lib = _abi.load()
     for name in (b"conv8", b"conv8_blocks", b"conv_tile", b"xcd", b"class_fast", b"wgrad_blocks", b"wgrad8", b"korder",
-                 b"convp", b"convp_blocks", b"convd", b"convd_blocks", b"fp8_mx", b"wgrad8n", b"f32mma", b"skinny128", b"slab16", b"wslab16", b"bn_rev", b"wgrad8_mfma", b"narrow32"):
+                 b"convp", b"convp_blocks", b"convd", b"convd_blocks", b"fp8_mx", b"wgrad8n", b"f32mma", b"skinny128", b"slab16", b"wslab16", b"bn_rev", b"wgrad8_mfma", b"narrow32", b"upimg", b"upimg_blocks"):
         assert lib.rg_set_option(name, 1) == 0, name
         assert lib.rg_set_option(name, -1) == 0, name
     assert lib.rg_set_option(b"no_such_knob", 1) != 0

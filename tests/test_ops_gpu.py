@@ -212,6 +212,34 @@ def test_conv8_pingpong_kernel(N, Hi, Wi, I, O, mode, mfma):
             lib.rg_set_option(k, -1)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,W,Cout", [(2, 4, 16, 3),       # ONE tile row: first and last padded row in the same tile
+                                        (3, 16, 16, 3), (2, 32, 64, 1), (5, 64, 64, 8), (2, 128, 128, 3)])
+def test_image_block_without_the_materialised_upsample(N, H, W, Cout, dtype):
+    """rg_upimg.hip: the resize-convolution generator's image block with upsample + reflection pad formed in LDS --
+    against the path that materialises the padded image (option upimg = 0): the same roundings in the same order, so the
+    two outputs are bit-identical; and against torch's interpolate + pad + conv2d in fp64."""
+    hip = _hip(dtype)
+    lib = hip.lib
+    w = rnd((Cout, 64, 3, 3), 1, (2.0 / (9 * 64)) ** 0.5)
+    b = rnd((Cout,), 2, 0.1)
+    x = rnd((N, H, W, 64), 3).to(dtype)
+    cw = ConvW(dev(w), dev(b), torch.zeros_like(dev(w)))
+    outs = {}
+    try:
+        for on in (1, 0):
+            _abi_check = lib.rg_set_option(b"upimg", on)
+            assert _abi_check == 0
+            outs[on] = hip.upconv3(dev(x), cw, dev(b), out_nchw=True)
+    finally:
+        lib.rg_set_option(b"upimg", -1)
+    assert torch.equal(outs[1], outs[0])
+    up = torch.nn.functional.interpolate(x.double().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False)
+    pad = torch.nn.functional.pad(up, (1, 1, 1, 1), mode="reflect")
+    ref = torch.nn.functional.conv2d(pad, w.to(dtype).double(), b.double())
+    check(outs[1], ref, 1.5e-2 if dtype == torch.bfloat16 else 2e-3, "image block")
+
+
 def test_f32_mode_non_finite_operands_stay_non_finite_and_local():
     """fp32 mode forms products from three-way bf16 splits (f32mma = 2, and the plane kernels).  A non-finite operand keeps its
     class in the split (h = +-inf / NaN, residuals 0 -- not inf - inf), so every output IEEE fp32 would make non-finite is
