@@ -539,6 +539,7 @@ extern "C" size_t rg_upconv3_workspace_bytes(int N, int H, int W, int Cin, int C
   if (rg_mfma_upconv3_supported(N, H, W, Cin, Cout)) b = std::max(b, rg_mfma_upconv3_fwd_ws_bytes(N, H, W, Cin, Cout));
   if (rg_mfma_upconv3_bwd_supported(N, H, W, Cin, Cout)) b = std::max(b, rg_mfma_upconv3_bwd_ws_bytes(N, H, W, Cin, Cout));
   if (rg_mfma_upconv3_wgrad_supported(N, H, W, Cin, Cout)) b = std::max(b, rg_mfma_upconv3_wgrad_ws_bytes(N, H, W, Cin, Cout));
+  b = std::max(b, rg_upimg_wgrad_ws_bytes(N, H, W, Cin, Cout));
   if (rg_mfma_upconv3_image_supported(N, H, W, Cin, Cout))
     b = std::max(b, std::max(rg_mfma_upconv3_image_fwd_ws_bytes(N, H, W, Cin, Cout),
                              rg_mfma_upconv3_image_wgrad_ws_bytes(N, H, W, Cin, Cout)));
@@ -574,6 +575,9 @@ extern "C" int rg_upconv3_wgrad(const void* gy, int gy_nchw_f32, const void* x, 
   const bool mfma_ok = dtype == RG_H16 && (gy_nchw_f32 ? rg_mfma_upconv3_image_supported(N, H, W, Cin, Cout)
                                                         : rg_mfma_upconv3_wgrad_supported(N, H, W, Cin, Cout));
   RG_REQUIRE(mfma_ok || algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "upconv3_wgrad: shape/dtype not supported by the MFMA kernel");
+  if (mfma_ok && algo != RG_ALGO_GENERIC && gy_nchw_f32 && rg_option("upimg", 1) && rg_upimg_wgrad_supported(N, H, W, Cin, Cout) &&
+      ws && ws_bytes >= rg_upimg_wgrad_ws_bytes(N, H, W, Cin, Cout))
+    return rg_upimg_wgrad((const float*)gy, x, dw, N, H, W, Cin, Cout, accumulate, ws, ws_bytes, rg_stream(stream));
   if (mfma_ok && algo != RG_ALGO_GENERIC && gy_nchw_f32)
     return rg_mfma_upconv3_image_wgrad((const float*)gy, x, dw, N, H, W, Cin, Cout, accumulate, ws, ws_bytes, rg_stream(stream));
   if (mfma_ok && algo != RG_ALGO_GENERIC)

@@ -21,6 +21,8 @@ namespace {
 typedef rg_h16x8 h16x8_t;
 typedef rg_f32x4 f32x4_t;
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_vptr_t;
 
 constexpr int UI_TR = 8, UI_TC = 32;                            // output tile
 constexpr int UI_PR = UI_TR + 2, UI_PC = UI_TC + 2;             // padded positions of the tile: 10 x 34
@@ -42,30 +44,45 @@ __device__ __forceinline__ uint32_t ui_pack2(float a, float b) { return (uint32_
 // byte offset of (padded row i, padded column j, 8-channel chunk c) in the P tile
 __device__ __forceinline__ int ui_paddr(int i, int j, int c) { return ((i * UI_PC + j) * 8 + (c ^ ((j >> 1) & 7))) * 16; }
 
-__global__ __launch_bounds__(256, 2) void upimg_fwd_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, float* __restrict__ y, int H, int W,
-                                                           int Cout, int tiles_x, int tiles_y, int total) {
+// MODE 0: forward (w, bias -> y).  MODE 1: weight gradient: `y` is the image gradient gy (fp32 NCHW, READ), `part` receives this
+// workgroup's partial dW[o][64][3][3] over its tiles (summed by upimg_wgrad_reduce_kernel: a fixed order, no atomics).  Phases 0
+// and 1 are the forward's; phase 2 contracts over the PIXELS of an output row: D[o][ci] += gy^T[o][32 pixels] P[32 pixels][ci],
+// A = 8 consecutive pixels of one gy channel per lane (rounded to the 16-bit type as the materialising path rounds gy), B = the
+// P tile read through ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group, delivered pixel-contiguous per channel);
+// wave w owns input channels 16 w .. + 15 and keeps its nine tap accumulators over all its tiles.
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void upimg_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y,
+                                                       float* __restrict__ part, int H, int W, int Cout, int tiles_x, int tiles_y,
+                                                       int total) {
   __shared__ __attribute__((aligned(16))) unsigned char xs[UI_XITEMS * 16];
   __shared__ __attribute__((aligned(16))) unsigned char pt[UI_PITEMS * 16];
+  __shared__ __attribute__((aligned(16))) float gys[MODE == 1 ? 4 * UI_TR * UI_TC : 4];      // [o][row][32] (wgrad)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lp = lane & 15, lq = lane >> 4;
   const int H2 = 2 * H, W2 = 2 * W;
 
-  // A operand: row lp = output channel (zero rows beyond Cout), k = input channels 32 ks + 8 lq .. + 7 of tap (dy, dx)
+  // forward: A operand: row lp = output channel (zero rows beyond Cout), k = input channels 32 ks + 8 lq .. + 7 of tap (dy, dx)
   h16x8_t af[9][2];
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = lp < Cout ? w[((size_t)lp * 64 + ks * 32 + lq * 8 + e) * 9 + tap] : 0.f;
-      const uint4 pk = make_uint4(ui_pack2(v[0], v[1]), ui_pack2(v[2], v[3]), ui_pack2(v[4], v[5]), ui_pack2(v[6], v[7]));
-      af[tap][ks] = __builtin_bit_cast(h16x8_t, pk);
-    }
   float bv[4];
+  f32x4_t wacc[9];                                    // weight gradient: D[o = 4 lq + r][ci = 16 wave + lp] per tap
+  if constexpr (MODE == 0) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) bv[r] = (bias && 4 * lq + r < Cout) ? bias[4 * lq + r] : 0.f;
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = lp < Cout ? w[((size_t)lp * 64 + ks * 32 + lq * 8 + e) * 9 + tap] : 0.f;
+        const uint4 pk = make_uint4(ui_pack2(v[0], v[1]), ui_pack2(v[2], v[3]), ui_pack2(v[4], v[5]), ui_pack2(v[6], v[7]));
+        af[tap][ks] = __builtin_bit_cast(h16x8_t, pk);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = (bias && 4 * lq + r < Cout) ? bias[4 * lq + r] : 0.f;
+  } else {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) wacc[tap] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
 
   // the low-resolution patch of a tile: four 16-byte loads per thread (clamped addresses, no branch around them), issued ONE TILE
   // AHEAD into registers -- a tile's three phases take a few microseconds, an HBM / L2 round trip in front of each would double that
@@ -73,6 +90,7 @@ __global__ __launch_bounds__(256, 2) void upimg_fwd_kernel(const uint16_t* __res
   // AMDGPUPromoteAlloca -- and waited for every load right behind its issue)
   uint4 xv0, xv1, xv2, xv3;
   xv0 = xv1 = xv2 = xv3 = make_uint4(0, 0, 0, 0);
+  float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);        // weight gradient: this thread's float4 of the gy tile [o = t >> 6][row][32]
 #define UI_FETCH1(dst, k, xn_, hb_, wb_)                                                          \
   do {                                                                                            \
     const int it_ = min(t + 256 * (k), UI_XITEMS - 1);                                            \
@@ -88,6 +106,10 @@ __global__ __launch_bounds__(256, 2) void upimg_fwd_kernel(const uint16_t* __res
     const uint16_t* xn_ = x + (size_t)n_ * H * W * 64;                                            \
     UI_FETCH1(xv0, 0, xn_, hb_, wb_); UI_FETCH1(xv1, 1, xn_, hb_, wb_);                           \
     UI_FETCH1(xv2, 2, xn_, hb_, wb_); UI_FETCH1(xv3, 3, xn_, hb_, wb_);                           \
+    if constexpr (MODE == 1) {                                                                    \
+      const int o_ = min(t >> 6, Cout - 1), row_ = (t >> 3) & 7, x4_ = (t & 7) * 4;               \
+      gv = *reinterpret_cast<const float4*>(y + (((size_t)n_ * Cout + o_) * H2 + ty_ * UI_TR + row_) * W2 + tx_ * UI_TC + x4_); \
+    }                                                                                             \
   } while (0)
   if ((int)blockIdx.x < total) UI_FETCH((int)blockIdx.x);
 
@@ -103,6 +125,8 @@ __global__ __launch_bounds__(256, 2) void upimg_fwd_kernel(const uint16_t* __res
     *reinterpret_cast<uint4*>(xs + (t + 512) * 16) = xv2;
     if (t + 768 < UI_XITEMS) *reinterpret_cast<uint4*>(xs + (t + 768) * 16) = xv3;
     UI_BARRIER();          // (also: every wave is done with the MFMAs of the previous tile before P is overwritten below)
+    if constexpr (MODE == 1)       // gy tile: read in phase 2, so it is replaced only behind the barrier above (channels beyond Cout: zero)
+      *reinterpret_cast<float4*>(gys + t * 4) = (t >> 6) < Cout ? gv : make_float4(0.f, 0.f, 0.f, 0.f);
     if (tile + (int)gridDim.x < total) UI_FETCH(tile + (int)gridDim.x);
 
     // ---- phase 1: P for the tile's padded positions.  A thread owns ONE (padded column, 8-channel chunk) pair -- column
@@ -162,33 +186,82 @@ __global__ __launch_bounds__(256, 2) void upimg_fwd_kernel(const uint16_t* __res
     }
     UI_BARRIER();
 
-    // ---- phase 2: wave `wave` owns output rows 2 wave, 2 wave + 1 of the tile: four groups of 16 pixels
-    f32x4_t acc[4];
+    if constexpr (MODE == 0) {
+      // ---- phase 2: wave `wave` owns output rows 2 wave, 2 wave + 1 of the tile: four groups of 16 pixels
+      f32x4_t acc[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < 4; ++g) acc[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
+      for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx)
+        for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+          for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int i = 2 * wave + (g >> 1) + dy, j = 16 * (g & 1) + lp + dx;
-            const h16x8_t b = *reinterpret_cast<const h16x8_t*>(pt + ui_paddr(i, j, ks * 4 + lq));
-            acc[g] = rg_mfma_h16_16x16x32(af[dy * 3 + dx][ks], b, acc[g], 0, 0, 0);
+            for (int g = 0; g < 4; ++g) {
+              const int i = 2 * wave + (g >> 1) + dy, j = 16 * (g & 1) + lp + dx;
+              const h16x8_t b = *reinterpret_cast<const h16x8_t*>(pt + ui_paddr(i, j, ks * 4 + lq));
+              acc[g] = rg_mfma_h16_16x16x32(af[dy * 3 + dx][ks], b, acc[g], 0, 0, 0);
+            }
+      // D[row = channel 4 lq + r][col = pixel lp]
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int oy = oy0 + 2 * wave + (g >> 1), ox = ox0 + 16 * (g & 1) + lp;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 4 * lq + r;
+          if (c < Cout) y[(((size_t)n * Cout + c) * H2 + oy) * W2 + ox] = acc[g][r] + bv[r];
+        }
+      }
+    } else {
+      // ---- phase 2 (weight gradient): per output row of the tile one 32-pixel k-step per tap
+      const int q4 = lp >> 2, p4 = lp & 3;            // transposed read: this lane addresses pixel q4 of its group's four,
+      const int chunk = 2 * wave + (p4 >> 1);         // channels 16 wave + 4 p4 .. + 3 (8 bytes of the pixel's 128)
+#pragma unroll 2
+      for (int row = 0; row < UI_TR; ++row) {
+        // A: gy[o = lp][row][8 lq .. + 7] (rows beyond 3 of the 16: zero)
+        const int o = min(lp, 3);
+        const float4 g0 = *reinterpret_cast<const float4*>(gys + (o * UI_TR + row) * UI_TC + 8 * lq);
+        const float4 g1 = *reinterpret_cast<const float4*>(gys + (o * UI_TR + row) * UI_TC + 8 * lq + 4);
+        const bool live = lp < 4;
+        const uint4 pk = make_uint4(live ? ui_pack2(g0.x, g0.y) : 0u, live ? ui_pack2(g0.z, g0.w) : 0u,
+                                    live ? ui_pack2(g1.x, g1.y) : 0u, live ? ui_pack2(g1.z, g1.w) : 0u);
+        const h16x8_t a = __builtin_bit_cast(h16x8_t, pk);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            u32x2_t b0, b1;
+            const int i = row + dy, j0 = 8 * lq + q4 + dx, j1 = j0 + 4;
+            const unsigned a0 = (unsigned)(size_t)(lds_vptr_t)pt + (unsigned)(ui_paddr(i, j0, chunk) + (p4 & 1) * 8);
+            const unsigned a1 = (unsigned)(size_t)(lds_vptr_t)pt + (unsigned)(ui_paddr(i, j1, chunk) + (p4 & 1) * 8);
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b0) : "v"(a0) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b1) : "v"(a1) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1)::"memory");
+            const uint4 bb = make_uint4(b0.x, b0.y, b1.x, b1.y);
+            wacc[dy * 3 + dx] = rg_mfma_h16_16x16x32(a, __builtin_bit_cast(h16x8_t, bb), wacc[dy * 3 + dx], 0, 0, 0);
           }
-    // D[row = channel 4 lq + r][col = pixel lp]
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int oy = oy0 + 2 * wave + (g >> 1), ox = ox0 + 16 * (g & 1) + lp;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = 4 * lq + r;
-        if (c < Cout) y[(((size_t)n * Cout + c) * H2 + oy) * W2 + ox] = acc[g][r] + bv[r];
       }
     }
   }
+  if constexpr (MODE == 1) {
+    // this workgroup's partial sums: part[block][o][ci][tap], lanes of the first 16-lane group hold o = 0 .. 3
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (lq == 0 && r < Cout)
+          part[(size_t)blockIdx.x * Cout * 576 + ((size_t)r * 64 + 16 * wave + lp) * 9 + tap] = wacc[tap][r];
+  }
+}
+
+// dw[idx] (+)= sum over the workgroups' partials, fixed order
+__global__ void upimg_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int n, int blocks, int accumulate) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  float s = 0.f;
+  for (int b = 0; b < blocks; ++b) s += part[(size_t)b * n + idx];
+  dw[idx] = accumulate ? dw[idx] + s : s;
 }
 
 }  // namespace
@@ -198,16 +271,43 @@ bool rg_upimg_fwd_supported(int N, int H, int W, int Cin, int Cout) {
   return N > 0 && Cin == 64 && Cout >= 1 && Cout <= 8 && H >= 4 && W >= 16 && (2 * H) % UI_TR == 0 && (2 * W) % UI_TC == 0 &&
          (long long)N * (2 * H / UI_TR) * (2 * W / UI_TC) < 0x7fffffffLL;
 }
+static int upimg_blocks(int total) {
+  int blocks = rg_option("upimg_blocks", 512);      // two workgroups per CU, each walks its tiles (measured: 512 < 1024 < 2048)
+  if (blocks > total) blocks = total;
+  return blocks < 1 ? 1 : blocks;
+}
 int rg_upimg_fwd(const void* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin, int Cout,
                  hipStream_t st) {
   RG_REQUIRE(rg_upimg_fwd_supported(N, H, W, Cin, Cout), RG_EUNSUPPORTED, "upimg_fwd: shape");
   const int tiles_x = 2 * W / UI_TC, tiles_y = 2 * H / UI_TR;
   const int total = N * tiles_x * tiles_y;
-  int blocks = rg_option("upimg_blocks", 512);      // two workgroups per CU, each walks its tiles (measured: 512 < 1024 < 2048)
-  if (blocks > total) blocks = total;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(upimg_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint16_t*)x, w, bias, y, H, W, Cout,
-                     tiles_x, tiles_y, total);
+  hipLaunchKernelGGL(upimg_kernel<0>, dim3((unsigned)upimg_blocks(total)), dim3(256), 0, st, (const uint16_t*)x, w, bias, y,
+                     (float*)nullptr, H, W, Cout, tiles_x, tiles_y, total);
   RG_LAUNCH_CHECK("upimg_fwd");
+  return RG_OK;
+}
+
+// weight gradient of the same block from the image gradient gy (fp32 NCHW): at most 4 output channels (one 16-lane group of the
+// accumulator holds them)
+bool rg_upimg_wgrad_supported(int N, int H, int W, int Cin, int Cout) {
+  return Cout <= 4 && rg_upimg_fwd_supported(N, H, W, Cin, Cout);
+}
+size_t rg_upimg_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout) {
+  if (!rg_upimg_wgrad_supported(N, H, W, Cin, Cout)) return 0;
+  const int total = N * (2 * W / UI_TC) * (2 * H / UI_TR);
+  return (size_t)upimg_blocks(total) * Cout * 576 * sizeof(float);
+}
+int rg_upimg_wgrad(const float* gy, const void* x, float* dw, int N, int H, int W, int Cin, int Cout, int accumulate, void* ws,
+                   size_t ws_bytes, hipStream_t st) {
+  RG_REQUIRE(rg_upimg_wgrad_supported(N, H, W, Cin, Cout), RG_EUNSUPPORTED, "upimg_wgrad: shape");
+  RG_REQUIRE(ws && ws_bytes >= rg_upimg_wgrad_ws_bytes(N, H, W, Cin, Cout), RG_EWORKSPACE, "upimg_wgrad: workspace too small");
+  const int tiles_x = 2 * W / UI_TC, tiles_y = 2 * H / UI_TR;
+  const int total = N * tiles_x * tiles_y, blocks = upimg_blocks(total), n = Cout * 576;
+  hipLaunchKernelGGL(upimg_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, (const uint16_t*)x, (const float*)nullptr,
+                     (const float*)nullptr, const_cast<float*>(gy), (float*)ws, H, W, Cout, tiles_x, tiles_y, total);
+  RG_LAUNCH_CHECK("upimg_wgrad");
+  hipLaunchKernelGGL(upimg_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, dw, n, blocks,
+                     accumulate);
+  RG_LAUNCH_CHECK("upimg_wgrad(reduce)");
   return RG_OK;
 }

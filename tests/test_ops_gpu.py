@@ -240,6 +240,36 @@ def test_image_block_without_the_materialised_upsample(N, H, W, Cout, dtype):
     check(outs[1], ref, 1.5e-2 if dtype == torch.bfloat16 else 2e-3, "image block")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,W,Cout", [(2, 4, 16, 3), (3, 16, 16, 3), (2, 32, 64, 1), (5, 64, 64, 4), (8, 128, 128, 3)])
+def test_image_block_weight_gradient_without_the_materialised_upsample(N, H, W, Cout, dtype):
+    """rg_upimg.hip, weight gradient: the padded tile formed in LDS and contracted over its pixels through transposed LDS reads
+    (ds_read_b64_tr_b16), per-workgroup partial sums reduced in a fixed order -- against fp64 (unfold of torch's interpolate + pad,
+    operands rounded as the kernels round them), overwrite and accumulate; and within the same bound as the materialising path."""
+    hip = _hip(dtype)
+    lib = hip.lib
+    w = rnd((Cout, 64, 3, 3), 1, 0.04)
+    x = rnd((N, H, W, 64), 3).to(dtype)
+    gy = rnd((N, Cout, 2 * H, 2 * W), 4)
+    up = torch.nn.functional.interpolate(x.double().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False)
+    pad = torch.nn.functional.pad(up.to(dtype).double(), (1, 1, 1, 1), mode="reflect")
+    ref = torch.einsum("nohw,nchwyx->ocyx", gy.to(dtype).double(), pad.unfold(2, 3, 1).unfold(3, 3, 1))
+    got = {}
+    try:
+        for on in (1, 0):
+            assert lib.rg_set_option(b"upimg", on) == 0
+            cw = ConvW(dev(w), None, torch.full_like(dev(w), 5.0))
+            hip.upconv3_wgrad(dev(gy), dev(x), cw, False, gy_nchw=True)
+            once = cw.dw.clone()
+            hip.upconv3_wgrad(dev(gy), dev(x), cw, True, gy_nchw=True)
+            got[on] = (once, cw.dw.clone())
+    finally:
+        lib.rg_set_option(b"upimg", -1)
+    for on in (1, 0):
+        check(got[on][0], ref, 1e-5, "dw (upimg = %d)" % on)
+        check(got[on][1], 2 * ref, 1e-5, "dw accumulated (upimg = %d)" % on)
+
+
 def test_f32_mode_non_finite_operands_stay_non_finite_and_local():
     """fp32 mode forms products from three-way bf16 splits (f32mma = 2, and the plane kernels).  A non-finite operand keeps its
     class in the split (h = +-inf / NaN, residuals 0 -- not inf - inf), so every output IEEE fp32 would make non-finite is
