@@ -565,6 +565,8 @@ extern "C" int rg_upconv3_bwd_data(const void* gy, int gy_nchw_f32, const float*
   RG_REQUIRE(gy && w && gx && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, RG_EINVAL, "upconv3_bwd_data: bad args");
   const bool mfma_ok = dtype == RG_H16 && !gy_nchw_f32 && rg_mfma_upconv3_bwd_supported(N, H, W, Cin, Cout);
   RG_REQUIRE(mfma_ok || algo != RG_ALGO_MFMA, RG_EUNSUPPORTED, "upconv3_bwd_data: shape/dtype not supported by the MFMA kernel");
+  if (dtype == RG_H16 && gy_nchw_f32 && algo != RG_ALGO_GENERIC && rg_option("upimg", 1) && rg_upimg_bwd_supported(N, H, W, Cin, Cout))
+    return rg_upimg_bwd_data((const float*)gy, w, gx, N, H, W, Cin, Cout, rg_stream(stream));     // the image block, fused
   if (mfma_ok && algo != RG_ALGO_GENERIC)
     return rg_mfma_upconv3_bwd_data(gy, w, gx, N, H, W, Cin, Cout, ws, ws_bytes, rg_stream(stream));
   return rg_generic_upconv3_bwd_data(gy, gy_nchw_f32, w, gx, N, H, W, Cin, Cout, dtype, ws, ws_bytes, rg_stream(stream));

@@ -86,6 +86,8 @@ int rg_mfma_upconv3_wgrad(const void* gy, const void* x, float* dw, int N, int H
 // rg_upimg.hip: the resize-convolution generator's image block without the materialised upsample + pad image
 bool rg_upimg_fwd_supported(int N, int H, int W, int Cin, int Cout);
 int rg_upimg_fwd(const void* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, hipStream_t st);
+bool rg_upimg_bwd_supported(int N, int H, int W, int Cin, int Cout);
+int rg_upimg_bwd_data(const float* gy, const float* w, void* gx, int N, int H, int W, int Cin, int Cout, hipStream_t st);
 bool rg_upimg_wgrad_supported(int N, int H, int W, int Cin, int Cout);
 size_t rg_upimg_wgrad_ws_bytes(int N, int H, int W, int Cin, int Cout);
 int rg_upimg_wgrad(const float* gy, const void* x, float* dw, int N, int H, int W, int Cin, int Cout, int accumulate, void* ws,

@@ -255,6 +255,163 @@ __global__ __launch_bounds__(256, 2) void upimg_kernel(const uint16_t* __restric
   }
 }
 
+// ---- data gradient of the same block: gx[n][h][w][64] (16-bit NHWC) from the image gradient gy (fp32 NCHW), per low-resolution
+// tile of 4 x 16 pixels (= the forward's 8 x 32 output tile):
+//   0. the 12 x 36 window of gy the tile's padded positions depend on (zero outside the image)          global -> LDS, 6.8 KB
+//   1. gP = transposed 3 x 3 conv at the 10 x 34 padded positions: one k-step of v_mfma_f32_16x16x32 per 16 positions and 16
+//      channels (k = (output channel, tap): 27 of 32 live), A = the weights, B = eight gy values per lane gathered from the
+//      window; rounded to the 16-bit type (as the matrix-core path of the other blocks rounds its padded-grid gradient)  -> LDS
+//   2. the adjoint of (reflection pad o bilinear x2): every low-resolution pixel collects its up to 16 upsampled positions
+//      (each with the padded positions that mirror it at the image border) with the weights 0.25 / 0.75 squared      LDS -> global
+constexpr int UB_GR = UI_PR + 2, UB_GC = UI_PC + 2;             // gy window: 12 x 36
+constexpr int UB_GITEMS = 4 * UB_GR * UB_GC;                    // floats, four channel planes: 1728
+constexpr int UB_NONE = 1 << 30;                                // "this k is padding" (valid offsets are small, of either sign)
+
+__global__ __launch_bounds__(256, 2) void upimg_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                           uint16_t* __restrict__ gx, int H, int W, int Cout, int tiles_x,
+                                                           int tiles_y, int total) {
+  __shared__ __attribute__((aligned(16))) float gyw[UB_GITEMS];
+  __shared__ __attribute__((aligned(16))) unsigned char gpt[UI_PITEMS * 16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lp = lane & 15, lq = lane >> 4;
+  const int H2 = 2 * H, W2 = 2 * W;
+
+  // A operand of phase 1: row = input channel 16 ct + lp, k = 8 lq + e = (o, dy, dx) flattened o * 9 + dy * 3 + dx
+  h16x8_t aw[4];
+  int koff[8];                                        // gy-window offset of k relative to (padded row + 2, padded column + 2)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 8 * lq + e, o = k / 9, tt = k - 9 * o, dy = tt / 3, dx = tt - 3 * dy;
+    koff[e] = (k < 27 && o < Cout) ? (o * UB_GR - dy) * UB_GC - dx : UB_NONE;
+  }
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 8 * lq + e, o = k / 9, tt = k - 9 * o;
+      v[e] = (k < 27 && o < Cout) ? w[((size_t)o * 64 + 16 * ct + lp) * 9 + tt] : 0.f;
+    }
+    const uint4 pk = make_uint4(ui_pack2(v[0], v[1]), ui_pack2(v[2], v[3]), ui_pack2(v[4], v[5]), ui_pack2(v[6], v[7]));
+    aw[ct] = __builtin_bit_cast(h16x8_t, pk);
+  }
+
+  // the gy window of a tile, one tile ahead in registers (seven floats per thread; clamped addresses, zero outside the image)
+  float g0, g1, g2, g3, g4, g5, g6;
+  g0 = g1 = g2 = g3 = g4 = g5 = g6 = 0.f;
+#define UB_FETCH1(dst, k, n_, oyb_, oxb_)                                                          \
+  do {                                                                                             \
+    const int e_ = min(t + 256 * (k), UB_GITEMS - 1);                                              \
+    const int o_ = e_ / (UB_GR * UB_GC), rem_ = e_ - o_ * (UB_GR * UB_GC);                         \
+    const int r_ = rem_ / UB_GC, c_ = rem_ - r_ * UB_GC;                                           \
+    const int oy_ = (oyb_) + r_, ox_ = (oxb_) + c_;                                                \
+    const bool ok_ = o_ < Cout && (unsigned)oy_ < (unsigned)H2 && (unsigned)ox_ < (unsigned)W2;    \
+    const float v_ = gy[(((size_t)(n_) * Cout + min(o_, Cout - 1)) * H2 + min(max(oy_, 0), H2 - 1)) * W2 + min(max(ox_, 0), W2 - 1)]; \
+    dst = ok_ ? v_ : 0.f;                                                                          \
+  } while (0)
+#define UB_FETCH(tile_)                                                                            \
+  do {                                                                                             \
+    const int tx_ = (tile_) % tiles_x, ty_ = ((tile_) / tiles_x) % tiles_y, n_ = (tile_) / (tiles_x * tiles_y);   \
+    const int oyb_ = ty_ * UI_TR - 2, oxb_ = tx_ * UI_TC - 2;                                      \
+    UB_FETCH1(g0, 0, n_, oyb_, oxb_); UB_FETCH1(g1, 1, n_, oyb_, oxb_); UB_FETCH1(g2, 2, n_, oyb_, oxb_);          \
+    UB_FETCH1(g3, 3, n_, oyb_, oxb_); UB_FETCH1(g4, 4, n_, oyb_, oxb_); UB_FETCH1(g5, 5, n_, oyb_, oxb_);          \
+    UB_FETCH1(g6, 6, n_, oyb_, oxb_);                                                              \
+  } while (0)
+  if ((int)blockIdx.x < total) UB_FETCH((int)blockIdx.x);
+
+  for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+    const int oy0 = ty * UI_TR, ox0 = tx * UI_TC;      // padded coordinates of the window's first row / column
+    const int hb = ty * (UI_TR / 2), wb = tx * (UI_TC / 2);
+
+    // ---- phase 0 (the previous tile's phase 2 reads gpt only; its phase 1, the reader of gyw, is behind that tile's barrier)
+    gyw[t] = g0; gyw[t + 256] = g1; gyw[t + 512] = g2; gyw[t + 768] = g3; gyw[t + 1024] = g4; gyw[t + 1280] = g5;
+    if (t + 1536 < UB_GITEMS) gyw[t + 1536] = g6;
+    UI_BARRIER();          // (also: every wave is done with phase 2 of the previous tile before gpt is overwritten)
+    if (tile + (int)gridDim.x < total) UB_FETCH(tile + (int)gridDim.x);
+
+    // ---- phase 1: gP for 16 padded positions per MFMA column group; wave w takes groups w, w + 4, ...
+#pragma unroll 1
+    for (int g = wave; g < (UI_PR * UI_PC + 15) / 16; g += 4) {
+      const int p = min(16 * g + lp, UI_PR * UI_PC - 1);        // (the last group's spare lanes repeat position 339)
+      const int il = p / UI_PC, jl = p - il * UI_PC;
+      const int base = (il + 2) * UB_GC + jl + 2;
+      float bv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float v = gyw[koff[e] == UB_NONE ? 0 : base + koff[e]];
+        bv[e] = koff[e] == UB_NONE ? 0.f : v;
+      }
+      const uint4 pk = make_uint4(ui_pack2(bv[0], bv[1]), ui_pack2(bv[2], bv[3]), ui_pack2(bv[4], bv[5]), ui_pack2(bv[6], bv[7]));
+      const h16x8_t b = __builtin_bit_cast(h16x8_t, pk);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const f32x4_t d = rg_mfma_h16_16x16x32(aw[ct], b, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        // D[row = channel 16 ct + 4 lq + r][col = position lp]: four consecutive channels of one position = 8 bytes
+        *reinterpret_cast<uint2*>(gpt + ui_paddr(il, jl, 2 * ct + (lq >> 1)) + (lq & 1) * 8) =
+            make_uint2(ui_pack2(d[0], d[1]), ui_pack2(d[2], d[3]));
+      }
+    }
+    UI_BARRIER();
+
+    // ---- phase 2: adjoint of pad o upsample; a thread owns (low-resolution pixel, 8-channel chunk) pairs
+#pragma unroll 1
+    for (int it = t; it < (UI_TR / 2) * (UI_TC / 2) * 8; it += 256) {
+      const int ch = it & 7, px = it >> 3;
+      const int hl = px / (UI_TC / 2), wl = px - hl * (UI_TC / 2);
+      const int h = hb + hl, wq = wb + wl;
+      // per direction: up to four upsampled positions with their weight, each read at up to two padded positions
+      float cu[4], cv[4];
+      int iu[4][2], jv[4][2];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int u = 2 * h + d - 1, v = 2 * wq + d - 1;
+        int a0, a1, b0, b1;
+        float la, lb;
+        up_taps(min(max(u, 0), H2 - 1), H, a0, a1, la);
+        up_taps(min(max(v, 0), W2 - 1), W, b0, b1, lb);
+        const bool uok = u >= 0 && u < H2, vok = v >= 0 && v < W2;
+        cu[d] = uok ? (a0 == h ? 1.f - la : 0.f) + (a1 == h ? la : 0.f) : 0.f;
+        cv[d] = vok ? (b0 == wq ? 1.f - lb : 0.f) + (b1 == wq ? lb : 0.f) : 0.f;
+        iu[d][0] = u + 1 - oy0;                                         // padded row u + 1 ...
+        iu[d][1] = u == 1 ? 0 - oy0 : (u == H2 - 2 ? H2 + 1 - oy0 : -1);   // ... and the mirrored border row that reads u
+        jv[d][0] = v + 1 - ox0;
+        jv[d][1] = v == 1 ? 0 - ox0 : (v == W2 - 2 ? W2 + 1 - ox0 : -1);
+      }
+      f32x2_t acc[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = f32x2_t{0.f, 0.f};
+#pragma unroll
+      for (int du = 0; du < 4; ++du)
+#pragma unroll
+        for (int dv = 0; dv < 4; ++dv) {
+          const float f = cu[du] * cv[dv];
+          if (f == 0.f) continue;
+          f32x2_t sacc[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sacc[e] = f32x2_t{0.f, 0.f};
+#pragma unroll
+          for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+            for (int rj = 0; rj < 2; ++rj) {
+              const int i = iu[du][ri], j = jv[dv][rj];
+              if (i < 0 || j < 0) continue;
+              const uint4 q = *reinterpret_cast<const uint4*>(gpt + ui_paddr(i, j, ch));
+              const uint32_t dd[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) sacc[e] += f32x2_t{h16lo_to_f32(dd[e]), h16hi_to_f32(dd[e])};
+            }
+          const f32x2_t vf = {f, f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += vf * sacc[e];
+        }
+      *reinterpret_cast<uint4*>(gx + (((size_t)n * H + h) * W + wq) * 64 + ch * 8) =
+          make_uint4(ui_pack2(acc[0][0], acc[0][1]), ui_pack2(acc[1][0], acc[1][1]), ui_pack2(acc[2][0], acc[2][1]),
+                     ui_pack2(acc[3][0], acc[3][1]));
+    }
+  }
+}
+
 // dw[idx] (+)= sum over the workgroups' partials, fixed order
 __global__ void upimg_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int n, int blocks, int accumulate) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -309,5 +466,19 @@ int rg_upimg_wgrad(const float* gy, const void* x, float* dw, int N, int H, int 
   hipLaunchKernelGGL(upimg_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, dw, n, blocks,
                      accumulate);
   RG_LAUNCH_CHECK("upimg_wgrad(reduce)");
+  return RG_OK;
+}
+
+// data gradient of the same block (gy fp32 NCHW -> gx 16-bit NHWC)
+bool rg_upimg_bwd_supported(int N, int H, int W, int Cin, int Cout) {
+  return Cout <= 3 && rg_upimg_fwd_supported(N, H, W, Cin, Cout);       // k = 9 Cout <= 32: one MFMA k-step
+}
+int rg_upimg_bwd_data(const float* gy, const float* w, void* gx, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
+  RG_REQUIRE(rg_upimg_bwd_supported(N, H, W, Cin, Cout), RG_EUNSUPPORTED, "upimg_bwd_data: shape");
+  const int tiles_x = 2 * W / UI_TC, tiles_y = 2 * H / UI_TR;
+  const int total = N * tiles_x * tiles_y;
+  hipLaunchKernelGGL(upimg_bwd_kernel, dim3((unsigned)upimg_blocks(total)), dim3(256), 0, st, gy, w, (uint16_t*)gx, H, W, Cout,
+                     tiles_x, tiles_y, total);
+  RG_LAUNCH_CHECK("upimg_bwd_data");
   return RG_OK;
 }

@@ -270,6 +270,36 @@ def test_image_block_weight_gradient_without_the_materialised_upsample(N, H, W, 
         check(got[on][1], 2 * ref, 1e-5, "dw accumulated (upimg = %d)" % on)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,W,Cout", [(2, 4, 16, 3), (3, 16, 16, 3), (2, 32, 64, 1), (5, 64, 64, 2), (4, 128, 128, 3)])
+def test_image_block_data_gradient_without_the_materialised_upsample(N, H, W, Cout, dtype):
+    """rg_upimg.hip, data gradient: transposed 3 x 3 conv at the tile's padded positions (one MFMA k-step over (channel, tap)) into
+    LDS, then the adjoint of reflection pad o bilinear x2 -- against torch autograd through interpolate + pad + conv2d in fp64
+    (image borders included: the one-tile-row shape puts the first and the last padded row into the same tile), and no further
+    from it than the path that materialises the padded-grid gradient."""
+    hip = _hip(dtype)
+    lib = hip.lib
+    w = rnd((Cout, 64, 3, 3), 1, 0.04)
+    gy = rnd((N, Cout, 2 * H, 2 * W), 4)
+    x = torch.zeros(N, 64, H, W, dtype=torch.float64, requires_grad=True)
+    up = torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    yy = torch.nn.functional.conv2d(torch.nn.functional.pad(up, (1, 1, 1, 1), mode="reflect"), w.to(dtype).double())
+    (ref,) = torch.autograd.grad(yy, x, gy.to(dtype).double())
+    ref = ref.permute(0, 2, 3, 1)
+    cw = ConvW(dev(w), None, torch.zeros_like(dev(w)))
+    errs = {}
+    try:
+        for on in (1, 0):
+            assert lib.rg_set_option(b"upimg", on) == 0
+            gx = hip.upconv3_bwd_data(dev(gy), cw, gy_nchw=True)
+            assert gx.dtype == dtype and tuple(gx.shape) == (N, H, W, 64)
+            errs[on] = relerr(gx, ref)
+    finally:
+        lib.rg_set_option(b"upimg", -1)
+    tol = 6e-3 if dtype == torch.bfloat16 else 8e-4          # the 16-bit rounding of the result (+ of the padded-grid gradient)
+    assert errs[1] <= tol and errs[1] <= 1.5 * errs[0] + 1e-4, errs
+
+
 def test_f32_mode_non_finite_operands_stay_non_finite_and_local():
     """fp32 mode forms products from three-way bf16 splits (f32mma = 2, and the plane kernels).  A non-finite operand keeps its
     class in the split (h = +-inf / NaN, residuals 0 -- not inf - inf), so every output IEEE fp32 would make non-finite is
