@@ -227,20 +227,27 @@ __global__ __launch_bounds__(256, 2) void upimg_kernel(const uint16_t* __restric
         const uint4 pk = make_uint4(live ? ui_pack2(g0.x, g0.y) : 0u, live ? ui_pack2(g0.z, g0.w) : 0u,
                                     live ? ui_pack2(g1.x, g1.y) : 0u, live ? ui_pack2(g1.z, g1.w) : 0u);
         const h16x8_t a = __builtin_bit_cast(h16x8_t, pk);
+        // all nine taps' transposed reads go out before the first wait (18 reads in flight; waited for once per row)
+        u32x2_t b0[9], b1[9];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
           for (int dx = 0; dx < 3; ++dx) {
-            u32x2_t b0, b1;
             const int i = row + dy, j0 = 8 * lq + q4 + dx, j1 = j0 + 4;
             const unsigned a0 = (unsigned)(size_t)(lds_vptr_t)pt + (unsigned)(ui_paddr(i, j0, chunk) + (p4 & 1) * 8);
             const unsigned a1 = (unsigned)(size_t)(lds_vptr_t)pt + (unsigned)(ui_paddr(i, j1, chunk) + (p4 & 1) * 8);
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b0) : "v"(a0) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b1) : "v"(a1) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b0), "+v"(b1)::"memory");
-            const uint4 bb = make_uint4(b0.x, b0.y, b1.x, b1.y);
-            wacc[dy * 3 + dx] = rg_mfma_h16_16x16x32(a, __builtin_bit_cast(h16x8_t, bb), wacc[dy * 3 + dx], 0, 0, 0);
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b0[dy * 3 + dx]) : "v"(a0) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b1[dy * 3 + dx]) : "v"(a1) : "memory");
           }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(b0[0]), "+v"(b1[0]), "+v"(b0[1]), "+v"(b1[1]), "+v"(b0[2]), "+v"(b1[2]), "+v"(b0[3]), "+v"(b1[3]),
+                       "+v"(b0[4]), "+v"(b1[4])::"memory");
+        asm volatile("" : "+v"(b0[5]), "+v"(b1[5]), "+v"(b0[6]), "+v"(b1[6]), "+v"(b0[7]), "+v"(b1[7]), "+v"(b0[8]), "+v"(b1[8]));
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const uint4 bb = make_uint4(b0[tap].x, b0[tap].y, b1[tap].x, b1[tap].y);
+          wacc[tap] = rg_mfma_h16_16x16x32(a, __builtin_bit_cast(h16x8_t, bb), wacc[tap], 0, 0, 0);
+        }
       }
     }
   }
