@@ -1,8 +1,10 @@
 // rg_upimg.hip -- the IMAGE block of DCGANUpGenerator (src/dcgan.py:45-56,76-84: Upsample(x2, bilinear) + ReflectionPad2d(1) +
 // Conv2d(64 -> 3, 3 x 3)) without the materialised upsample + pad image: at 128 -> 256 pixels and batch 64 that
 // image is 545 MB (bf16, 64 channels) written by one kernel and gathered nine times by the next, for an output of 50 MB.
+// Three kernels, all per 8 x 32 output tile (= 4 x 16 low-resolution pixels) of one image, persistent workgroups of 4 waves, the
+// next tile's global loads in flight (registers) during the current tile's phases, LDS-only barriers between phases:
 //
-// Forward, one workgroup (4 waves) per 8 x 32 output tile of one image, three phases, everything between them in LDS:
+// upimg_kernel<0>, forward:
 //   0. the 6 x 18 low-resolution pixels the tile depends on (clamped at the image border)           global -> LDS, 13.5 KB
 //   1. P = pad(upsample(x)) for the tile's 10 x 34 padded positions: bilinear weights 0.25 / 0.75 in fp32 from four staged
 //      pixels, rounded ONCE to the 16-bit type (the arithmetic and the rounding of uppad_bf16_kernel: the results of the two
@@ -11,8 +13,10 @@
 //      fragments stay in registers for the whole launch), B = 16 consecutive pixels of a P row at the tap's offset (one
 //      ds_read_b128 per MFMA; the channel chunk of a pixel is XOR-swizzled with bits 1..3 of its column so that the 16 lanes
 //      of a read hit 16 different bank groups), D = [channel][pixel]: lanes 0..15 hold a pixel's three channels -> fp32 NCHW rows.
-// HBM traffic: x once (+ the tiles' halo, from L2) and y once.  Batch 64 at 128 -> 256: 240 us against 633 us for uppad + 9-tap GEMM +
-// NCHW pass (the remaining time is phase 1's vector arithmetic, ~110 us, the 64-byte output segments and the tile prologues).
+//   HBM traffic: x once (+ the tiles' halo, from L2) and y once.  Batch 64 at 128 -> 256: 228 us against 633 us for uppad + 9-tap
+//   GEMM + NCHW pass (what is left: phase 1's vector arithmetic, ~110 us, the 64-byte output segments, the tile prologues).
+// upimg_kernel<1>, weight gradient (368 us against 1562): phases 0 / 1 as above, phase 2 contracts the tile over its pixels.
+// upimg_bwd_kernel, data gradient (477 us against 1083): transposed conv into LDS, then the adjoint of pad o upsample.
 #include "rg_common.h"
 #include "rg_internal.h"
 
